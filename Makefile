@@ -1,0 +1,46 @@
+# Builds the native pieces in-tree (the .so files travel to the GPU box with gpurun):
+#   csvplus_amd/lib/libcsvplus_hip.so   HIP kernels + C ABI (gfx950 only)
+#   csvplus_amd/lib/libcph_datagen.so   synthetic table generator (CPU, OpenMP)
+#   oracle/_build/liboracle.so          CPU restatement of the reference (test infrastructure)
+#   tests/cpp/test_host                 C++ host facade tests (reference-style tests)
+HIPCC   ?= /opt/rocm/bin/hipcc
+ARCH    ?= gfx950
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function
+CC      ?= gcc
+CXX     ?= g++
+
+LIBDIR  = csvplus_amd/lib
+CSRC    = csvplus_amd/csrc
+HIP_SRCS = $(CSRC)/capi.hip $(CSRC)/keycodec.hip $(CSRC)/radix_sort.hip $(CSRC)/probe.hip
+HIP_OBJS = $(patsubst $(CSRC)/%.hip,$(LIBDIR)/obj/%.o,$(HIP_SRCS))
+HIP_HDRS = $(CSRC)/cph_internal.hpp $(CSRC)/device_utils.hpp $(CSRC)/codec_device.hpp include/csvplus_hip.h
+
+all: hip datagen oracle host
+
+hip: $(LIBDIR)/libcsvplus_hip.so
+datagen: $(LIBDIR)/libcph_datagen.so
+oracle: oracle/_build/liboracle.so
+host: tests/cpp/test_host
+
+$(LIBDIR)/obj/%.o: $(CSRC)/%.hip $(HIP_HDRS)
+	@mkdir -p $(LIBDIR)/obj
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/libcsvplus_hip.so: $(HIP_OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(HIP_OBJS) -o $@
+
+$(LIBDIR)/libcph_datagen.so: $(CSRC)/datagen.c
+	@mkdir -p $(LIBDIR)
+	$(CC) -O3 -fopenmp -fPIC -shared -fvisibility=hidden -Wall $< -o $@
+
+oracle/_build/liboracle.so: oracle/csvplus_oracle.c
+	@mkdir -p oracle/_build
+	$(CC) -O2 -fPIC -shared -fvisibility=hidden -Wall $< -o $@
+
+tests/cpp/test_host: tests/cpp/test_host.cpp csvplus_amd/host/csvplus.hpp include/csvplus_hip.h $(LIBDIR)/libcsvplus_hip.so
+	$(CXX) -O2 -std=c++17 -Wall -Iinclude -Icsvplus_amd/host $< -L$(LIBDIR) -lcsvplus_hip -Wl,-rpath,'$$ORIGIN/../../csvplus_amd/lib' -o $@
+
+clean:
+	rm -rf $(LIBDIR) oracle/_build tests/cpp/test_host
+
+.PHONY: all hip datagen oracle host clean

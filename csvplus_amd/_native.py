@@ -1,0 +1,333 @@
+"""ctypes binding of the C ABI declared in include/csvplus_hip.h.
+
+This is the same boundary a cgo shim would bind.  There is no
+CPU implementation behind it: when libcsvplus_hip.so is missing or no GPU is
+present every call fails loudly (NativeLibraryMissing / CphError).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "lib" / "libcsvplus_hip.so"
+
+# status codes (include/csvplus_hip.h)
+CPH_OK = 0
+CPH_ERR_INVALID = -1
+CPH_ERR_HIP = -2
+CPH_ERR_NO_DEVICE = -3
+CPH_ERR_DUPLICATE = -4
+CPH_ERR_TOO_MANY_ROWS = -5
+CPH_ERR_KEY_TOO_LONG = -6
+CPH_ERR_TOO_MANY_COLS = -7
+CPH_ERR_NOMEM = -8
+CPH_MEM_HOST = 0
+CPH_MEM_DEVICE = 1
+CPH_MAX_KEY_BYTES = 128
+UINT64_MAX = 0xFFFFFFFFFFFFFFFF
+
+_STATUS_NAMES = {
+    CPH_ERR_INVALID: "CPH_ERR_INVALID",
+    CPH_ERR_HIP: "CPH_ERR_HIP",
+    CPH_ERR_NO_DEVICE: "CPH_ERR_NO_DEVICE",
+    CPH_ERR_DUPLICATE: "CPH_ERR_DUPLICATE",
+    CPH_ERR_TOO_MANY_ROWS: "CPH_ERR_TOO_MANY_ROWS",
+    CPH_ERR_KEY_TOO_LONG: "CPH_ERR_KEY_TOO_LONG",
+    CPH_ERR_TOO_MANY_COLS: "CPH_ERR_TOO_MANY_COLS",
+    CPH_ERR_NOMEM: "CPH_ERR_NOMEM",
+}
+
+
+class NativeLibraryMissing(ImportError):
+    pass
+
+
+class CphError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{_STATUS_NAMES.get(code, code)}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+class cph_strcol(C.Structure):
+    _fields_ = [
+        ("data", C.c_void_p),
+        ("offsets", C.c_void_p),
+        ("nrows", C.c_uint64),
+        ("offset_bits", C.c_int32),
+        ("mem", C.c_int32),
+    ]
+
+
+class cph_strval(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("len", C.c_uint64)]
+
+
+class cph_matches(C.Structure):
+    _fields_ = [
+        ("nprobe", C.c_uint64),
+        ("nmatches", C.c_uint64),
+        ("lo", C.c_void_p),
+        ("cnt", C.c_void_p),
+        ("probe_idx", C.c_void_p),
+        ("build_row", C.c_void_p),
+        ("mem", C.c_int32),
+        ("reserved_", C.c_int32),
+    ]
+
+
+class cph_index_info(C.Structure):
+    _fields_ = [
+        ("nrows", C.c_uint64),
+        ("nkeycols", C.c_int32),
+        ("key_positions", C.c_int32),
+        ("code_words", C.c_int32),
+        ("code_bits", C.c_int32),
+        ("key_bytes", C.c_int32),
+        ("sort_passes", C.c_int32),
+        ("direct_table", C.c_int32),
+        ("reserved_", C.c_int32),
+        ("table_entries", C.c_uint64),
+    ]
+
+
+# every symbol include/csvplus_hip.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+PROTOTYPES = [
+    ("cph_version", C.c_char_p, []),
+    ("cph_ctx_create", C.c_int32, [C.c_int32, C.POINTER(_P)]),
+    ("cph_ctx_destroy", None, [_P]),
+    ("cph_last_error", C.c_char_p, [_P]),
+    ("cph_ctx_set_stream", C.c_int32, [_P, _P]),
+    ("cph_ctx_synchronize", C.c_int32, [_P]),
+    ("cph_pinned_alloc", C.c_int32, [_P, C.c_size_t, C.POINTER(_P)]),
+    ("cph_pinned_free", C.c_int32, [_P, _P]),
+    ("cph_index_build", C.c_int32,
+     [_P, C.POINTER(cph_strcol), C.c_int32, C.c_int32, C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    ("cph_index_destroy", None, [_P]),
+    ("cph_index_nrows", C.c_uint64, [_P]),
+    ("cph_index_nkeycols", C.c_int32, [_P]),
+    ("cph_index_perm", C.c_int32, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    ("cph_join_probe", C.c_int32,
+     [_P, _P, C.POINTER(cph_strcol), C.c_int32, _P, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32,
+      C.c_int32, C.POINTER(C.POINTER(cph_matches))]),
+    ("cph_matches_release", None, [C.POINTER(cph_matches)]),
+    ("cph_index_find", C.c_int32,
+     [_P, _P, C.POINTER(cph_strval), C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("cph_index_get_info", C.c_int32, [_P, C.POINTER(cph_index_info)]),
+]
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Loads libcsvplus_hip.so (built by `make hip` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("CSVPLUS_HIP_LIB", LIB_PATH))
+    if not path.exists():
+        raise NativeLibraryMissing(
+            f"{path} not found: build it with `make hip` (or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "csvplus_amd has no CPU fallback.")
+    lib = C.CDLL(str(path))
+    for name, restype, argtypes in PROTOTYPES:
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def _ptr_array(ptr: int, n: int, dtype) -> np.ndarray:
+    """numpy view (no copy) over `n` items at host address `ptr`."""
+    if n == 0 or not ptr:
+        return np.empty(0, dtype=dtype)
+    nbytes = n * np.dtype(dtype).itemsize
+    buf = (C.c_uint8 * nbytes).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n)
+
+
+class Context:
+    """One cph_ctx: single-threaded, bound to one GPU."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = _P()
+        rc = self.lib.cph_ctx_create(device, C.byref(h))
+        if rc != CPH_OK:
+            raise CphError(rc, f"cph_ctx_create(device={device}) failed: no usable GPU "
+                               "(csvplus_amd has no CPU fallback)")
+        self.handle = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.cph_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != CPH_OK:
+            raise CphError(rc, (self.lib.cph_last_error(self.handle) or b"").decode("utf-8", "replace"))
+
+    def set_stream(self, stream_handle: int | None):
+        self._check(self.lib.cph_ctx_set_stream(self.handle, _P(stream_handle or 0)))
+
+    def synchronize(self):
+        self._check(self.lib.cph_ctx_synchronize(self.handle))
+
+    def last_error(self) -> str:
+        return (self.lib.cph_last_error(self.handle) or b"").decode("utf-8", "replace")
+
+
+def _cols_array(cols):
+    arr = (cph_strcol * len(cols))()
+    keep = []
+    for i, c in enumerate(cols):
+        sc, k = c.as_c()
+        arr[i] = sc
+        keep.append(k)
+    return arr, keep
+
+
+class DeviceIndex:
+    """Handle on a GPU-resident index (cph_index)."""
+
+    def __init__(self, ctx: Context, keycols, unique: bool = False):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        arr, keep = _cols_array(keycols)
+        h = _P()
+        dup = C.c_uint64(UINT64_MAX)
+        rc = self.lib.cph_index_build(ctx.handle, arr, len(keycols), 1 if unique else 0, C.byref(h), C.byref(dup))
+        del keep
+        self.handle = h if h.value else None
+        self.first_dup = None if dup.value == UINT64_MAX else int(dup.value)
+        self.status = rc
+        if rc not in (CPH_OK, CPH_ERR_DUPLICATE):
+            ctx._check(rc)
+
+    @property
+    def nrows(self) -> int:
+        return int(self.lib.cph_index_nrows(self.handle))
+
+    def perm(self) -> np.ndarray:
+        """perm[i] = original row id at sorted position i (host copy)."""
+        p = _P()
+        n = C.c_uint64()
+        self.ctx._check(self.lib.cph_index_perm(self.handle, CPH_MEM_HOST, C.byref(p), C.byref(n)))
+        return _ptr_array(p.value, int(n.value), np.uint32).copy()
+
+    def perm_device_ptr(self) -> int:
+        p = _P()
+        n = C.c_uint64()
+        self.ctx._check(self.lib.cph_index_perm(self.handle, CPH_MEM_DEVICE, C.byref(p), C.byref(n)))
+        return int(p.value or 0)
+
+    def info(self) -> dict:
+        inf = cph_index_info()
+        rc = self.lib.cph_index_get_info(self.handle, C.byref(inf))
+        if rc != CPH_OK:
+            raise CphError(rc, "cph_index_get_info")
+        return {k: int(getattr(inf, k)) for k, _ in cph_index_info._fields_ if k != "reserved_"}
+
+    def probe(self, probecols, row_sel=None, probe_base: int = 0, want_pairs: bool = True,
+              out_mem: int = CPH_MEM_HOST) -> "Matches":
+        arr, keep = _cols_array(probecols)
+        sel_ptr, sel_bits, sel_base, nsel = _P(0), 32, 0, 0
+        if row_sel is not None:
+            if isinstance(row_sel, np.ndarray):
+                if row_sel.dtype != np.uint64:
+                    row_sel = np.ascontiguousarray(row_sel, dtype=np.uint32)
+                row_sel = np.ascontiguousarray(row_sel)
+                sel_ptr, sel_bits, nsel = _P(row_sel.ctypes.data), row_sel.dtype.itemsize * 8, len(row_sel)
+            else:  # (device pointer, bits, base, count)
+                sel_ptr, sel_bits, sel_base, nsel = _P(row_sel[0]), int(row_sel[1]), int(row_sel[2]), int(row_sel[3])
+        out = C.POINTER(cph_matches)()
+        rc = self.lib.cph_join_probe(self.ctx.handle, self.handle, arr, len(probecols), sel_ptr, sel_bits, sel_base,
+                                     nsel, probe_base, 1 if want_pairs else 0, out_mem, C.byref(out))
+        del keep
+        self.ctx._check(rc)
+        return Matches(self.lib, out, owner=self)
+
+    def find(self, *values: bytes):
+        vals = (cph_strval * max(1, len(values)))()
+        keep = []
+        for i, v in enumerate(values):
+            b = np.frombuffer(bytes(v), dtype=np.uint8)
+            keep.append(b)
+            vals[i].data = b.ctypes.data if len(b) else None
+            vals[i].len = len(b)
+        lo, hi = C.c_uint64(), C.c_uint64()
+        self.ctx._check(self.lib.cph_index_find(self.ctx.handle, self.handle, vals, len(values), C.byref(lo),
+                                                C.byref(hi)))
+        return int(lo.value), int(hi.value)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.cph_index_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Matches:
+    """Result of one probe (cph_matches).  Host results are exposed as numpy copies."""
+
+    def __init__(self, lib, ptr, owner=None):
+        self.lib = lib
+        self.ptr = ptr
+        self.owner = owner  # keeps the index (and its ctx) alive: the arrays come from the ctx's pool
+        m = ptr.contents
+        self.nprobe = int(m.nprobe)
+        self.nmatches = int(m.nmatches)
+        self.mem = int(m.mem)
+
+    def _host(self, field, n, dtype):
+        assert self.mem == CPH_MEM_HOST
+        return _ptr_array(getattr(self.ptr.contents, field), n, dtype).copy()
+
+    @property
+    def lo(self):
+        return self._host("lo", self.nprobe, np.uint32)
+
+    @property
+    def cnt(self):
+        return self._host("cnt", self.nprobe, np.uint32)
+
+    @property
+    def probe_idx(self):
+        return self._host("probe_idx", self.nmatches, np.uint64)
+
+    @property
+    def build_row(self):
+        return self._host("build_row", self.nmatches, np.uint32)
+
+    def device_ptrs(self) -> dict:
+        m = self.ptr.contents
+        return {k: int(getattr(m, k) or 0) for k in ("lo", "cnt", "probe_idx", "build_row")}
+
+    def release(self):
+        if self.ptr:
+            self.lib.cph_matches_release(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass

@@ -1,0 +1,532 @@
+// capi.hip — the C ABI of libcsvplus_hip (include/csvplus_hip.h): context, memory,
+// IndexOn / UniqueIndexOn (csvplus.go:529-537, 707-756), Join probe (csvplus.go:545-569),
+// Find bounds (csvplus.go:870-891).  No CPU fallback anywhere: without a GPU every entry
+// point fails with CPH_ERR_NO_DEVICE / CPH_ERR_HIP.
+#include <algorithm>
+#include <new>
+
+#include "cph_internal.hpp"
+
+namespace cph {
+
+// ---- DevicePool ------------------------------------------------------------------------------
+Status DevicePool::alloc(size_t bytes, void** out) {
+    const size_t want = (bytes + 255) & ~(size_t)255;
+    int best = -1;
+    for (int i = 0; i < (int)free_.size(); i++) {
+        if (free_[i].cap >= want && free_[i].cap <= want * 2 + (1u << 20)) {
+            if (best < 0 || free_[i].cap < free_[best].cap) best = i;
+        }
+    }
+    Block b;
+    if (best >= 0) {
+        b = free_[best];
+        free_.erase(free_.begin() + best);
+        bytes_cached -= b.cap;
+    } else {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            trim();   // give cached blocks back and retry once
+            e = hipMalloc(&p, want);
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            char buf[128];
+            snprintf(buf, sizeof buf, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+            return {CPH_ERR_NOMEM, buf};
+        }
+        n_hipmalloc++;
+        b = Block{p, want};
+    }
+    live_.push_back(b);
+    bytes_live += b.cap;
+    *out = b.p;
+    return {};
+}
+
+void DevicePool::release(void* p) {
+    for (size_t i = 0; i < live_.size(); i++) {
+        if (live_[i].p == p) {
+            bytes_live -= live_[i].cap;
+            bytes_cached += live_[i].cap;
+            free_.push_back(live_[i]);
+            live_[i] = live_.back();
+            live_.pop_back();
+            return;
+        }
+    }
+}
+
+void DevicePool::trim() {
+    for (auto& b : free_) (void)hipFree(b.p);
+    free_.clear();
+    bytes_cached = 0;
+}
+
+DevicePool::~DevicePool() {
+    trim();
+    for (auto& b : live_) (void)hipFree(b.p);
+    live_.clear();
+}
+
+Status ensure_pinned_scratch(cph_ctx* ctx, size_t bytes) {
+    if (ctx->pinned_scratch_bytes >= bytes) return {};
+    if (ctx->pinned_scratch) {
+        CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        (void)hipHostFree(ctx->pinned_scratch);
+        ctx->pinned_scratch = nullptr;
+        ctx->pinned_scratch_bytes = 0;
+    }
+    size_t cap = std::max<size_t>(bytes, 1 << 16);
+    CPH_HIP_TRY(hipHostMalloc(&ctx->pinned_scratch, cap, hipHostMallocDefault));
+    ctx->pinned_scratch_bytes = cap;
+    return {};
+}
+
+// ---- staging ----------------------------------------------------------------------------------
+static Status validate_cols(const cph_strcol* cols, int32_t ncols) {
+    if (!cols || ncols <= 0) return {CPH_ERR_INVALID, "no key columns"};
+    if (ncols > kMaxKeyCols) return {CPH_ERR_INVALID, "too many key columns"};
+    for (int c = 0; c < ncols; c++) {
+        if (cols[c].offset_bits != 32 && cols[c].offset_bits != 64) return {CPH_ERR_INVALID, "offset_bits must be 32 or 64"};
+        if (cols[c].mem != CPH_MEM_HOST && cols[c].mem != CPH_MEM_DEVICE) return {CPH_ERR_INVALID, "bad mem"};
+        if (cols[c].nrows != cols[0].nrows) return {CPH_ERR_INVALID, "key columns differ in row count"};
+        if (cols[c].nrows && !cols[c].offsets) return {CPH_ERR_INVALID, "offsets is NULL"};
+    }
+    if (cols[0].nrows > 0xFFFFFFFFull) return {CPH_ERR_TOO_MANY_ROWS, "more than 2^32-1 rows"};
+    return {};
+}
+
+// Makes the columns device resident (copies host columns into pool blocks kept in `storage`).
+static Status stage_cols(cph_ctx* ctx, const cph_strcol* cols, int32_t ncols, std::vector<DevBuf>* storage,
+                         DevCol* out) {
+    for (int c = 0; c < ncols; c++) {
+        DevCol d;
+        d.nrows = cols[c].nrows;
+        d.offset_bits = cols[c].offset_bits;
+        if (cols[c].mem == CPH_MEM_DEVICE || cols[c].nrows == 0) {
+            d.data = cols[c].data;
+            d.offsets = cols[c].offsets;
+        } else {
+            const size_t obytes = (size_t)(cols[c].nrows + 1) * (size_t)(cols[c].offset_bits / 8);
+            const uint64_t first = cols[c].offset_bits == 32 ? ((const uint32_t*)cols[c].offsets)[0]
+                                                             : ((const uint64_t*)cols[c].offsets)[0];
+            const uint64_t last = cols[c].offset_bits == 32 ? ((const uint32_t*)cols[c].offsets)[cols[c].nrows]
+                                                            : ((const uint64_t*)cols[c].offsets)[cols[c].nrows];
+            if (last < first) return {CPH_ERR_INVALID, "offsets are not monotonic"};
+            // copy data[0..last): offsets stay valid as they are
+            DevBuf bo, bd;
+            CPH_TRY(bo.alloc(&ctx->pool, obytes));
+            CPH_TRY(bd.alloc(&ctx->pool, (size_t)last + 8));
+            CPH_HIP_TRY(hipMemcpyAsync(bo.get(), cols[c].offsets, obytes, hipMemcpyHostToDevice, ctx->stream));
+            if (last) CPH_HIP_TRY(hipMemcpyAsync(bd.get(), cols[c].data, (size_t)last, hipMemcpyHostToDevice, ctx->stream));
+            d.data = bd.as<uint8_t>();
+            d.offsets = bo.get();
+            storage->push_back(std::move(bo));
+            storage->push_back(std::move(bd));
+        }
+        out[c] = d;
+    }
+    return {};
+}
+
+static int32_t fail(cph_ctx* ctx, const Status& s) {
+    if (ctx) ctx->err = s.msg;
+    return s.code;
+}
+
+static Status enter(cph_ctx* ctx) {
+    if (!ctx) return {CPH_ERR_INVALID, "ctx is NULL"};
+    CPH_HIP_TRY(hipSetDevice(ctx->device));
+    return {};
+}
+
+// ---- IndexOn ------------------------------------------------------------------------------------
+static Status index_build_impl(cph_ctx* ctx, const cph_strcol* keycols, int32_t nkeycols, cph_index* ix) {
+    CPH_TRY(validate_cols(keycols, nkeycols));
+    const uint64_t n = keycols[0].nrows;
+    ix->ctx = ctx;
+    ix->nrows = n;
+    ix->nkeycols = nkeycols;
+
+    std::vector<DevBuf> staged;
+    DevCol dcols[kMaxKeyCols];
+    CPH_TRY(stage_cols(ctx, keycols, nkeycols, &staged, dcols));
+
+    // K0: alphabets -> codec
+    std::vector<ColStats> stats;
+    CPH_TRY(codec_collect_stats(ctx, dcols, nkeycols, &stats));
+    CPH_TRY(codec_build(stats, &ix->codec));
+    CPH_TRY(codec_upload(ctx, ix->codec, &ix->codec_dev));
+    const CodecHost& cd = ix->codec;
+
+    DevBuf va, vb;
+    CPH_TRY(va.alloc(&ctx->pool, n * sizeof(uint32_t)));
+    CPH_TRY(vb.alloc(&ctx->pool, n * sizeof(uint32_t)));
+    ix->sort_passes = 0;
+    int passes = 0;
+
+    if (cd.key32) {
+        DevBuf ka, kb;
+        CPH_TRY(ka.alloc(&ctx->pool, n * sizeof(uint32_t)));
+        CPH_TRY(kb.alloc(&ctx->pool, n * sizeof(uint32_t)));
+        CPH_TRY(codec_encode_build(ctx, cd, ix->codec_dev, dcols, n, ka.get()));
+        uint32_t* kout;
+        uint32_t* vout;
+        CPH_TRY(radix_sort_pairs<uint32_t>(ctx, ka.as<uint32_t>(), kb.as<uint32_t>(), va.as<uint32_t>(),
+                                           vb.as<uint32_t>(), true, n, cd.word_bits[0], &kout, &vout, &passes));
+        ix->sort_passes = passes;
+        ix->sorted_codes = std::move(kout == ka.as<uint32_t>() ? ka : kb);
+        ix->perm = std::move(vout == va.as<uint32_t>() ? va : vb);
+    } else if (cd.nwords == 1) {
+        DevBuf ka, kb;
+        CPH_TRY(ka.alloc(&ctx->pool, n * sizeof(uint64_t)));
+        CPH_TRY(kb.alloc(&ctx->pool, n * sizeof(uint64_t)));
+        CPH_TRY(codec_encode_build(ctx, cd, ix->codec_dev, dcols, n, ka.get()));
+        uint64_t* kout;
+        uint32_t* vout;
+        CPH_TRY(radix_sort_pairs<uint64_t>(ctx, ka.as<uint64_t>(), kb.as<uint64_t>(), va.as<uint32_t>(),
+                                           vb.as<uint32_t>(), true, n, cd.word_bits[0], &kout, &vout, &passes));
+        ix->sort_passes = passes;
+        ix->sorted_codes = std::move(kout == ka.as<uint64_t>() ? ka : kb);
+        ix->perm = std::move(vout == va.as<uint32_t>() ? va : vb);
+    } else {
+        // multi-word codes: LSD over the words, least significant word first
+        const int nw = cd.nwords;
+        DevBuf all, ka, kb;
+        CPH_TRY(all.alloc(&ctx->pool, (size_t)nw * n * sizeof(uint64_t)));
+        CPH_TRY(ka.alloc(&ctx->pool, n * sizeof(uint64_t)));
+        CPH_TRY(kb.alloc(&ctx->pool, n * sizeof(uint64_t)));
+        CPH_TRY(codec_encode_build(ctx, cd, ix->codec_dev, dcols, n, all.get()));
+        uint32_t* vcur = va.as<uint32_t>();
+        uint32_t* vother = vb.as<uint32_t>();
+        bool first = true;
+        for (int w = nw - 1; w >= 0; w--) {
+            const uint64_t* word = all.as<uint64_t>() + (uint64_t)w * n;
+            if (first) {
+                if (n) CPH_HIP_TRY(hipMemcpyAsync(ka.get(), word, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+            } else {
+                CPH_TRY(gather_u64(ctx, word, vcur, ka.as<uint64_t>(), n));
+            }
+            uint64_t* kout;
+            uint32_t* vout;
+            CPH_TRY(radix_sort_pairs<uint64_t>(ctx, ka.as<uint64_t>(), kb.as<uint64_t>(), vcur, vother, first, n,
+                                               cd.word_bits[w], &kout, &vout, &passes));
+            ix->sort_passes += passes;
+            if (vout != vcur) { vother = vcur; vcur = vout; }
+            first = false;
+        }
+        DevBuf sorted;
+        CPH_TRY(sorted.alloc(&ctx->pool, (size_t)nw * n * sizeof(uint64_t)));
+        for (int w = 0; w < nw; w++)
+            CPH_TRY(gather_u64(ctx, all.as<uint64_t>() + (uint64_t)w * n, vcur, sorted.as<uint64_t>() + (uint64_t)w * n, n));
+        ix->sorted_codes = std::move(sorted);
+        ix->perm = std::move(vcur == va.as<uint32_t>() ? va : vb);
+    }
+
+    CPH_TRY(index_first_dup(ctx, ix, &ix->first_dup));
+    CPH_TRY(index_build_table(ctx, ix));
+    // staged input copies are released here (stream-ordered reuse is safe)
+    return {};
+}
+
+}  // namespace cph
+
+using namespace cph;
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+CPH_API const char* cph_version(void) { return "csvplus_hip 0.1 (gfx950)"; }
+
+CPH_API int32_t cph_ctx_create(int32_t device_id, cph_ctx** out) {
+    if (!out) return CPH_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return CPH_ERR_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= count) return CPH_ERR_NO_DEVICE;
+    if (hipSetDevice(device_id) != hipSuccess) return CPH_ERR_NO_DEVICE;
+    cph_ctx* ctx = new (std::nothrow) cph_ctx();
+    if (!ctx) return CPH_ERR_NOMEM;
+    ctx->device = device_id;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return CPH_ERR_HIP;
+    }
+    ctx->own_stream = true;
+    *out = ctx;
+    return CPH_OK;
+}
+
+CPH_API void cph_ctx_destroy(cph_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->pinned_scratch) (void)hipHostFree(ctx->pinned_scratch);
+    for (void* p : ctx->pinned_user) (void)hipHostFree(p);
+    hipStream_t own = ctx->own_stream ? ctx->stream : nullptr;
+    ctx->pool.trim();
+    if (own) (void)hipStreamDestroy(own);
+    delete ctx;
+}
+
+CPH_API const char* cph_last_error(const cph_ctx* ctx) { return ctx ? ctx->err.c_str() : "ctx is NULL"; }
+
+CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream) {
+    Status s = enter(ctx);
+    if (!s.ok()) return fail(ctx, s);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (hip_stream) {
+        if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+        ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+        ctx->own_stream = false;
+    } else if (!ctx->own_stream) {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
+            return fail(ctx, {CPH_ERR_HIP, "hipStreamCreate failed"});
+        ctx->own_stream = true;
+    }
+    return CPH_OK;
+}
+
+CPH_API int32_t cph_ctx_synchronize(cph_ctx* ctx) {
+    Status s = enter(ctx);
+    if (!s.ok()) return fail(ctx, s);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return fail(ctx, {CPH_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e)});
+    return CPH_OK;
+}
+
+CPH_API int32_t cph_pinned_alloc(cph_ctx* ctx, size_t bytes, void** out) {
+    Status s = enter(ctx);
+    if (!s.ok()) return fail(ctx, s);
+    if (!out) return fail(ctx, {CPH_ERR_INVALID, "out is NULL"});
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(ctx, {CPH_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)});
+    ctx->pinned_user.push_back(p);
+    *out = p;
+    return CPH_OK;
+}
+
+CPH_API int32_t cph_pinned_free(cph_ctx* ctx, void* p) {
+    Status s = enter(ctx);
+    if (!s.ok()) return fail(ctx, s);
+    auto it = std::find(ctx->pinned_user.begin(), ctx->pinned_user.end(), p);
+    if (it == ctx->pinned_user.end()) return fail(ctx, {CPH_ERR_INVALID, "not a cph_pinned_alloc block"});
+    ctx->pinned_user.erase(it);
+    (void)hipHostFree(p);
+    return CPH_OK;
+}
+
+CPH_API int32_t cph_index_build(cph_ctx* ctx, const cph_strcol* keycols, int32_t nkeycols, int32_t unique,
+                                cph_index** out, uint64_t* first_dup_pos) {
+    Status s = enter(ctx);
+    if (!s.ok()) return fail(ctx, s);
+    if (!out) return fail(ctx, {CPH_ERR_INVALID, "out is NULL"});
+    *out = nullptr;
+    if (first_dup_pos) *first_dup_pos = UINT64_MAX;
+    cph_index* ix = new (std::nothrow) cph_index();
+    if (!ix) return fail(ctx, {CPH_ERR_NOMEM, "out of host memory"});
+    s = index_build_impl(ctx, keycols, nkeycols, ix);
+    if (!s.ok()) {
+        delete ix;
+        return fail(ctx, s);
+    }
+    if (first_dup_pos) *first_dup_pos = ix->first_dup;
+    *out = ix;
+    if (unique && ix->first_dup != UINT64_MAX) {
+        char b[128];
+        snprintf(b, sizeof b, "duplicate value while creating unique index (sorted position %llu)",
+                 (unsigned long long)ix->first_dup);
+        return fail(ctx, {CPH_ERR_DUPLICATE, b});
+    }
+    return CPH_OK;
+}
+
+CPH_API void cph_index_destroy(cph_index* ix) {
+    if (!ix) return;
+    if (ix->ctx) (void)hipSetDevice(ix->ctx->device);
+    if (ix->perm_host) (void)hipHostFree(ix->perm_host);
+    delete ix;
+}
+
+CPH_API uint64_t cph_index_nrows(const cph_index* ix) { return ix ? ix->nrows : 0; }
+CPH_API int32_t cph_index_nkeycols(const cph_index* ix) { return ix ? ix->nkeycols : 0; }
+
+CPH_API int32_t cph_index_perm(cph_index* ix, int32_t mem, const uint32_t** perm, uint64_t* n) {
+    if (!ix || !perm) return CPH_ERR_INVALID;
+    cph_ctx* ctx = ix->ctx;
+    Status s = enter(ctx);
+    if (!s.ok()) return fail(ctx, s);
+    if (n) *n = ix->nrows;
+    if (mem == CPH_MEM_DEVICE) {
+        *perm = ix->perm.as<uint32_t>();
+        return CPH_OK;
+    }
+    if (!ix->perm_host) {
+        const size_t bytes = (size_t)ix->nrows * sizeof(uint32_t);
+        void* p = nullptr;
+        hipError_t e = hipHostMalloc(&p, bytes ? bytes : 4, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(ctx, {CPH_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)});
+        if (bytes) {
+            e = hipMemcpyAsync(p, ix->perm.get(), bytes, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) {
+                (void)hipHostFree(p);
+                return fail(ctx, {CPH_ERR_HIP, std::string("perm read-back: ") + hipGetErrorString(e)});
+            }
+        }
+        ix->perm_host = static_cast<uint32_t*>(p);
+    }
+    *perm = ix->perm_host;
+    return CPH_OK;
+}
+
+CPH_API int32_t cph_join_probe(cph_ctx* ctx, const cph_index* ix, const cph_strcol* probecols, int32_t nprobecols,
+                               const void* row_sel, int32_t sel_bits, uint64_t sel_base, uint64_t nsel,
+                               uint64_t probe_base, int32_t want_pairs, int32_t out_mem, cph_matches** out) {
+    Status s = enter(ctx);
+    if (!s.ok()) return fail(ctx, s);
+    if (!ix || !out) return fail(ctx, {CPH_ERR_INVALID, "index/out is NULL"});
+    *out = nullptr;
+    if (nprobecols > ix->nkeycols) return fail(ctx, {CPH_ERR_TOO_MANY_COLS, "too many source columns in Join()"});
+    s = validate_cols(probecols, nprobecols);
+    if (!s.ok()) return fail(ctx, s);
+    if (out_mem != CPH_MEM_HOST && out_mem != CPH_MEM_DEVICE) return fail(ctx, {CPH_ERR_INVALID, "bad out_mem"});
+    if (row_sel && sel_bits != 32 && sel_bits != 64) return fail(ctx, {CPH_ERR_INVALID, "sel_bits must be 32 or 64"});
+    if (row_sel && nsel > 0xFFFFFFFFull) return fail(ctx, {CPH_ERR_TOO_MANY_ROWS, "more than 2^32-1 selected rows"});
+
+    cph_matches_impl* m = new (std::nothrow) cph_matches_impl();
+    if (!m) return fail(ctx, {CPH_ERR_NOMEM, "out of host memory"});
+    m->ctx = ctx;
+    auto run = [&]() -> Status {
+        std::vector<DevBuf> staged;
+        DevCol dcols[kMaxKeyCols];
+        CPH_TRY(stage_cols(ctx, probecols, nprobecols, &staged, dcols));
+        RowSel dsel;
+        dsel.ptr = row_sel;
+        dsel.bits = sel_bits;
+        dsel.base = sel_base;
+        DevBuf selbuf;
+        const bool cols_on_host = probecols[0].mem == CPH_MEM_HOST;
+        if (row_sel && cols_on_host && nsel) {
+            const size_t sb = nsel * (size_t)(sel_bits / 8);
+            CPH_TRY(selbuf.alloc(&ctx->pool, sb));
+            CPH_HIP_TRY(hipMemcpyAsync(selbuf.get(), row_sel, sb, hipMemcpyHostToDevice, ctx->stream));
+            dsel.ptr = selbuf.get();
+        }
+        const uint64_t nprobe = row_sel ? nsel : probecols[0].nrows;
+        ProbeOut po;
+        CPH_TRY(probe_run(ctx, ix, dcols, nprobecols, dsel, nprobe, probe_base, want_pairs != 0, &po));
+        m->pub.nprobe = nprobe;
+        m->pub.nmatches = po.nmatches;
+        m->pub.mem = out_mem;
+        const bool pairs = want_pairs && po.nmatches;
+        if (out_mem == CPH_MEM_DEVICE) {
+            m->d_lo = std::move(po.lo);
+            m->d_cnt = std::move(po.cnt);
+            m->d_pidx = std::move(po.pidx);
+            m->d_brow = std::move(po.brow);
+            m->pub.lo = m->d_lo.as<uint32_t>();
+            m->pub.cnt = m->d_cnt.as<uint32_t>();
+            m->pub.probe_idx = pairs ? m->d_pidx.as<uint64_t>() : nullptr;
+            m->pub.build_row = pairs ? m->d_brow.as<uint32_t>() : nullptr;
+            // the caller may read on another stream / the host
+            CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        } else {
+            auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+            const size_t b_lo = a16(nprobe * sizeof(uint32_t));
+            const size_t b_pi = pairs ? a16(po.nmatches * sizeof(uint64_t)) : 0;
+            const size_t b_br = pairs ? a16(po.nmatches * sizeof(uint32_t)) : 0;
+            const size_t total = 2 * b_lo + b_pi + b_br + 16;
+            CPH_HIP_TRY(hipHostMalloc(&m->h_block, total, hipHostMallocDefault));
+            uint8_t* h = static_cast<uint8_t*>(m->h_block);
+            uint8_t* h_pidx = h;                       // u64 first: keeps 8-byte alignment
+            uint8_t* h_lo = h + b_pi;
+            uint8_t* h_cnt = h_lo + b_lo;
+            uint8_t* h_brow = h_cnt + b_lo;
+            if (nprobe) {
+                CPH_HIP_TRY(hipMemcpyAsync(h_lo, po.lo.get(), nprobe * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+                CPH_HIP_TRY(hipMemcpyAsync(h_cnt, po.cnt.get(), nprobe * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            }
+            if (pairs) {
+                CPH_HIP_TRY(hipMemcpyAsync(h_pidx, po.pidx.get(), po.nmatches * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+                CPH_HIP_TRY(hipMemcpyAsync(h_brow, po.brow.get(), po.nmatches * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            }
+            CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+            m->pub.lo = reinterpret_cast<const uint32_t*>(h_lo);
+            m->pub.cnt = reinterpret_cast<const uint32_t*>(h_cnt);
+            m->pub.probe_idx = pairs ? reinterpret_cast<const uint64_t*>(h_pidx) : nullptr;
+            m->pub.build_row = pairs ? reinterpret_cast<const uint32_t*>(h_brow) : nullptr;
+        }
+        return {};
+    };
+    s = run();
+    if (!s.ok()) {
+        if (m->h_block) (void)hipHostFree(m->h_block);
+        delete m;
+        return fail(ctx, s);
+    }
+    *out = &m->pub;
+    return CPH_OK;
+}
+
+CPH_API void cph_matches_release(cph_matches* pub) {
+    if (!pub) return;
+    cph_matches_impl* m = reinterpret_cast<cph_matches_impl*>(pub);
+    if (m->ctx) (void)hipSetDevice(m->ctx->device);
+    if (m->h_block) (void)hipHostFree(m->h_block);
+    delete m;
+}
+
+CPH_API int32_t cph_index_find(cph_ctx* ctx, const cph_index* ix, const cph_strval* values, int32_t nvalues,
+                               uint64_t* lower, uint64_t* upper) {
+    Status s = enter(ctx);
+    if (!s.ok()) return fail(ctx, s);
+    if (!ix || !lower || !upper || nvalues < 0 || (nvalues && !values))
+        return fail(ctx, {CPH_ERR_INVALID, "bad argument"});
+    if (nvalues > ix->nkeycols) return fail(ctx, {CPH_ERR_TOO_MANY_COLS, "too many columns in indexImpl.find()"});
+    if (nvalues == 0) {   // csvplus.go:872-874
+        *lower = 0;
+        *upper = ix->nrows;
+        return CPH_OK;
+    }
+    uint64_t q_exact[kMaxWords];
+    int32_t nq = 0;
+    uint64_t qlo = 0, qhi = 0;
+    if (!codec_encode_values_host(ix->codec, values, nvalues, q_exact, &nq, &qlo, &qhi)) {
+        *lower = 0;
+        *upper = 0;   // empty: the values cannot occur in the index
+        return CPH_OK;
+    }
+    s = index_find_device(ctx, ix, q_exact, nq, qlo, qhi, lower, upper);
+    if (!s.ok()) return fail(ctx, s);
+    return CPH_OK;
+}
+
+CPH_API int32_t cph_index_get_info(const cph_index* ix, cph_index_info* info) {
+    if (!ix || !info) return CPH_ERR_INVALID;
+    memset(info, 0, sizeof *info);
+    info->nrows = ix->nrows;
+    info->nkeycols = ix->nkeycols;
+    info->key_positions = ix->codec.npos;
+    info->code_words = ix->codec.nwords;
+    int bits = 0;
+    for (int w = 0; w < ix->codec.nwords; w++) bits += ix->codec.word_bits[w];
+    info->code_bits = bits;
+    info->key_bytes = ix->codec.key32 ? 4 : 8;
+    info->sort_passes = ix->sort_passes;
+    info->direct_table = ix->table_entries ? 1 : 0;
+    info->table_entries = ix->table_entries;
+    return CPH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+// codec_device.hpp — device side of the order-preserving key codec (see keycodec.hip).
+#pragma once
+
+#include "cph_internal.hpp"
+#include "device_utils.hpp"
+
+namespace cph {
+
+// Kernel-argument bundle: the key columns of one table.
+struct ColsArg {
+    DevCol c[kMaxKeyCols];
+};
+
+// View of the codec block once it sits in LDS.
+struct CodecView {
+    const CodecDevHeader* hdr;
+    const uint64_t* mult;
+    const uint8_t* word_of;
+    const uint16_t* lut;
+};
+
+// Cooperative copy of the codec block (global) into dynamic LDS; returns a view.
+// `lds` must be 16-byte aligned and hold hdr.total_bytes.  Contains __syncthreads.
+__device__ __forceinline__ CodecView codec_load_to_lds(const uint8_t* g_blob, uint8_t* lds) {
+    const CodecDevHeader* gh = reinterpret_cast<const CodecDevHeader*>(g_blob);
+    const int total = gh->total_bytes;
+    const uint4* src = reinterpret_cast<const uint4*>(g_blob);
+    uint4* dst = reinterpret_cast<uint4*>(lds);
+    for (int i = threadIdx.x; i < total / 16; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+    CodecView v;
+    v.hdr = reinterpret_cast<const CodecDevHeader*>(lds);
+    v.mult = reinterpret_cast<const uint64_t*>(lds + v.hdr->mult_off);
+    v.word_of = lds + v.hdr->wordof_off;
+    v.lut = reinterpret_cast<const uint16_t*>(lds + v.hdr->lut_off);
+    return v;
+}
+
+// Encodes the leading `ncols_used` key columns of row `row`.
+//   emit(word, value, last_pos) is called once per (possibly partial, for a prefix of
+//   the columns) code word, most significant word first; last_pos is the last byte
+//   position folded into that word.
+// Returns false when the key cannot be present in the index the codec was built from
+// (a byte outside the position's alphabet, or a value longer than the column's maximum);
+// emit may then have been called for a prefix of the words only.
+template <class Emit>
+__device__ __forceinline__ bool encode_key(const CodecView& cv, const ColsArg& cols, int ncols_used, uint64_t row,
+                                           Emit&& emit) {
+    const int p_end = cv.hdr->col_start[ncols_used];
+    uint64_t acc = 0;
+    bool valid = true;
+    for (int c = 0; c < ncols_used; c++) {
+        const DevCol& col = cols.c[c];
+        const uint64_t begin = load_offset(col.offsets, col.offset_bits, row);
+        const uint64_t len = load_offset(col.offsets, col.offset_bits, row + 1) - begin;
+        const int maxlen = cv.hdr->col_maxlen[c];
+        const int p0 = cv.hdr->col_start[c];
+        if (len > (uint64_t)maxlen) valid = false;
+        uint64_t chunk = 0;
+        for (int q = 0; q < maxlen; q++) {
+            if ((q & 7) == 0 && (uint64_t)q < len) chunk = load_value_chunk(col.data, begin, len, q >> 3);
+            const int sym = (uint64_t)q < len ? (int)((chunk >> (8 * (q & 7))) & 0xFF) + 1 : 0;
+            const int p = p0 + q;
+            const uint32_t r = cv.lut[p * kLutStride + sym];
+            if (r == kLutInvalid) valid = false;
+            acc += (uint64_t)r * cv.mult[p];
+            if (p + 1 == p_end || cv.word_of[p + 1] != cv.word_of[p]) {
+                emit((int)cv.word_of[p], acc, p);
+                acc = 0;
+            }
+        }
+    }
+    return valid;
+}
+
+}  // namespace cph

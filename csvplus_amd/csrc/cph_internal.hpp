@@ -1,0 +1,231 @@
+// cph_internal.hpp — internal structures of libcsvplus_hip (not part of the C ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/csvplus_hip.h"
+
+namespace cph {
+
+// ---- limits / launch geometry ------------------------------------------------
+constexpr int kMaxKeyBytes = CPH_MAX_KEY_BYTES;  // total encoded byte positions
+constexpr int kMaxKeyCols  = CPH_MAX_KEY_COLS;
+constexpr int kLutStride   = 257;                // symbols per position: pad + 256 byte values
+constexpr uint16_t kLutInvalid = 0xFFFF;
+constexpr int kMaxWords    = 16;                 // code words per key (each < 2^63 states)
+
+// ---- error plumbing ------------------------------------------------------------
+struct Status {
+    int32_t code = CPH_OK;
+    std::string msg;
+    bool ok() const { return code == CPH_OK; }
+};
+
+#define CPH_HIP_TRY(expr)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            char buf_[512];                                                                        \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),     \
+                     __FILE__, __LINE__);                                                          \
+            return ::cph::Status{CPH_ERR_HIP, buf_};                                               \
+        }                                                                                          \
+    } while (0)
+
+#define CPH_TRY(expr)                        \
+    do {                                     \
+        ::cph::Status s_ = (expr);           \
+        if (!s_.ok()) return s_;             \
+    } while (0)
+
+// ---- device memory pool -----------------------------------------------------------
+// All work of a ctx runs on one stream, so a block freed (in host program order)
+// after the kernels using it were enqueued can be handed to the next user: reuse is
+// stream-ordered.  Blocks are cached until cph_ctx_destroy / trim().
+class DevicePool {
+public:
+    Status alloc(size_t bytes, void** out);
+    void   release(void* p);   // returns the block to the cache
+    void   trim();             // hipFree everything cached
+    ~DevicePool();
+    size_t bytes_live = 0, bytes_cached = 0, n_hipmalloc = 0;
+
+private:
+    struct Block { void* p; size_t cap; };
+    std::vector<Block> free_;
+    std::vector<Block> live_;
+};
+
+// RAII handle on a pool block.
+class DevBuf {
+public:
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept { *this = std::move(o); }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) { reset(); pool_ = o.pool_; p_ = o.p_; bytes_ = o.bytes_; o.p_ = nullptr; o.pool_ = nullptr; o.bytes_ = 0; }
+        return *this;
+    }
+    ~DevBuf() { reset(); }
+    Status alloc(DevicePool* pool, size_t bytes) {
+        reset();
+        pool_ = pool;
+        bytes_ = bytes;
+        return pool->alloc(bytes ? bytes : 1, &p_);
+    }
+    void reset() {
+        if (p_ && pool_) pool_->release(p_);
+        p_ = nullptr;
+    }
+    template <class T> T* as() const { return static_cast<T*>(p_); }
+    void* get() const { return p_; }
+    size_t bytes() const { return bytes_; }
+    explicit operator bool() const { return p_ != nullptr; }
+
+private:
+    DevicePool* pool_ = nullptr;
+    void* p_ = nullptr;
+    size_t bytes_ = 0;
+};
+
+}  // namespace cph
+
+// ---- key codec description (host + device copies) -------------------------------------
+namespace cph {
+
+// How the key columns map to the mixed-radix code (see keycodec.hip).
+struct CodecHost {
+    int32_t ncols = 0;
+    int32_t npos = 0;                       // total byte positions (sum of maxlen)
+    int32_t nwords = 1;                     // code words per key
+    bool    key32 = false;                  // single word that fits 32 bits
+    int32_t col_start[kMaxKeyCols + 1] = {0};   // first position of each column
+    int32_t col_maxlen[kMaxKeyCols] = {0};
+    int32_t col_minlen[kMaxKeyCols] = {0};
+    int32_t word_bits[kMaxWords] = {0};     // significant bits per word
+    uint64_t word_states[kMaxWords] = {0};  // number of states per word (product of radices)
+    // per position
+    std::vector<uint16_t> radix;            // [npos]
+    std::vector<uint64_t> mult;             // [npos] weight inside its word
+    std::vector<int32_t>  word_of;          // [npos]
+    std::vector<uint16_t> lut;              // [npos][257] rank or kLutInvalid
+};
+
+// Device-side codec block, laid out for one cooperative copy into LDS:
+//   header (CodecDevHeader) | mult[npos] u64 | word_of[npos] u8 (padded) | lut[npos*257] u16
+struct CodecDevHeader {
+    int32_t ncols;
+    int32_t npos;
+    int32_t nwords;
+    int32_t key32;
+    int32_t col_start[kMaxKeyCols + 1];
+    int32_t col_maxlen[kMaxKeyCols];
+    int32_t mult_off;      // byte offsets from the start of the block
+    int32_t wordof_off;
+    int32_t lut_off;
+    int32_t total_bytes;   // multiple of 16
+};
+
+}  // namespace cph
+
+// ---- the opaque C types ------------------------------------------------------------------
+struct cph_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    cph::DevicePool pool;
+    // small pinned scratch for read-backs
+    void* pinned_scratch = nullptr;
+    size_t pinned_scratch_bytes = 0;
+    std::vector<void*> pinned_user;
+};
+
+struct cph_index {
+    cph_ctx* ctx = nullptr;
+    uint64_t nrows = 0;
+    int32_t nkeycols = 0;
+    cph::CodecHost codec;
+    cph::DevBuf codec_dev;         // CodecDevHeader block
+    cph::DevBuf sorted_codes;      // key32: u32[n]; else u64[nwords][n] word-major
+    cph::DevBuf perm;              // u32[n]
+    cph::DevBuf table;             // direct-address table {lo,end} u32x2 [table_entries] (optional)
+    uint64_t table_entries = 0;
+    int32_t sort_passes = 0;
+    uint64_t first_dup = UINT64_MAX;
+    uint32_t* perm_host = nullptr; // pinned copy (lazy)
+};
+
+struct cph_matches_impl {
+    cph_matches pub;               // must stay first: the public view
+    cph_ctx* ctx = nullptr;
+    cph::DevBuf d_lo, d_cnt, d_pidx, d_brow;
+    void* h_block = nullptr;       // one pinned block holding the host copies
+};
+
+// ---- cross-file entry points (host functions launching kernels) -------------------------------
+namespace cph {
+
+// A string column resident on the device.
+struct DevCol {
+    const uint8_t* data = nullptr;
+    const void* offsets = nullptr;
+    uint64_t nrows = 0;
+    int32_t offset_bits = 32;
+};
+
+// keycodec.hip
+struct ColStats {              // per column, produced by one pass over the column
+    uint32_t minlen, maxlen;
+    uint32_t mask[kMaxKeyBytes][8];   // presence bitmap of byte values per position
+};
+Status codec_collect_stats(cph_ctx* ctx, const DevCol* cols, int32_t ncols, std::vector<ColStats>* out);
+Status codec_build(const std::vector<ColStats>& stats, CodecHost* codec);   // host only
+Status codec_upload(cph_ctx* ctx, const CodecHost& codec, DevBuf* dev);
+// Encodes the build-side keys.  key32: out32[n]; else out64[nwords][n].
+Status codec_encode_build(cph_ctx* ctx, const CodecHost& codec, const DevBuf& codec_dev, const DevCol* cols,
+                          uint64_t n, void* out_codes);
+// Host-side encoding of literal values (cph_index_find).  Returns false when a
+// value cannot occur in the index (symbol outside the alphabet / too long).
+bool codec_encode_values_host(const CodecHost& codec, const cph_strval* values, int32_t nvalues,
+                              uint64_t* q_exact, int32_t* nq, uint64_t* qlo, uint64_t* qhi);
+
+// radix_sort.hip
+// Stable LSD radix sort of (key,val) pairs over key bits [0,bits).  keys_in may be
+// clobbered.  vals_in == nullptr means vals = 0..n-1.  On return *keys_out/*vals_out
+// point at whichever of the two buffer pairs holds the result.
+template <class K>
+Status radix_sort_pairs(cph_ctx* ctx, K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b, bool vals_iota,
+                        uint64_t n, int bits, K** keys_out, uint32_t** vals_out, int* passes);
+Status exclusive_scan_u32(cph_ctx* ctx, uint32_t* data, uint64_t n);
+Status gather_u64(cph_ctx* ctx, const uint64_t* src, const uint32_t* idx, uint64_t* dst, uint64_t n);
+Status fill_iota_u32(cph_ctx* ctx, uint32_t* dst, uint64_t n);
+
+// probe.hip
+Status index_first_dup(cph_ctx* ctx, const cph_index* ix, uint64_t* first_dup);
+Status index_build_table(cph_ctx* ctx, cph_index* ix);
+struct ProbeOut {
+    DevBuf lo, cnt, pidx, brow;
+    uint64_t nprobe = 0, nmatches = 0;
+};
+struct RowSel {                // optional selection of probe rows (device memory)
+    const void* ptr = nullptr; // NULL: rows 0..nprobe-1
+    int32_t bits = 32;         // 32 or 64
+    uint64_t base = 0;         // subtracted from every entry
+};
+Status probe_run(cph_ctx* ctx, const cph_index* ix, const DevCol* cols, int32_t ncols, RowSel sel,
+                 uint64_t nprobe, uint64_t probe_base, bool want_pairs, ProbeOut* out);
+Status index_find_device(cph_ctx* ctx, const cph_index* ix, const uint64_t* q_exact, int32_t nq, uint64_t qlo,
+                         uint64_t qhi, uint64_t* lower, uint64_t* upper);
+
+// capi.hip helpers
+Status ensure_pinned_scratch(cph_ctx* ctx, size_t bytes);
+
+}  // namespace cph

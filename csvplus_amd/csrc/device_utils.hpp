@@ -1,0 +1,100 @@
+// device_utils.hpp — wave64 / workgroup primitives shared by the gfx950 kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace cph {
+
+constexpr int kWave = 64;  // gfx950 wavefront width (hard-coded on purpose)
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+
+// lanes strictly below the caller
+__device__ __forceinline__ uint64_t lanemask_lt() {
+    return (lane_id() == 0) ? 0ull : (~0ull >> (64 - lane_id()));
+}
+
+// Inclusive wave scan (sum) with shuffles.
+template <class T>
+__device__ __forceinline__ T wave_inclusive_sum(T v) {
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        T o = __shfl_up(v, d, kWave);
+        if (lane_id() >= d) v += o;
+    }
+    return v;
+}
+
+template <class T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, kWave);
+    return v;
+}
+
+template <class T>
+__device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+        T o = __shfl_xor(v, d, kWave);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+template <class T>
+__device__ __forceinline__ T wave_min(T v) {
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+        T o = __shfl_xor(v, d, kWave);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// Exclusive workgroup scan of one value per thread.  `smem` needs NWAVES+1
+// entries of T.  Returns the exclusive prefix; *total gets the workgroup sum.
+// Contains __syncthreads: every thread of the block must call it.
+template <class T, int NTHREADS>
+__device__ __forceinline__ T block_exclusive_sum(T v, T* smem, T* total) {
+    constexpr int NW = NTHREADS / kWave;
+    T incl = wave_inclusive_sum(v);
+    if (lane_id() == kWave - 1) smem[wave_id()] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T run = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) { T t = smem[w]; smem[w] = run; run += t; }
+        smem[NW] = run;
+    }
+    __syncthreads();
+    T res = smem[wave_id()] + incl - v;
+    *total = smem[NW];
+    __syncthreads();  // smem may be reused by the caller right away
+    return res;
+}
+
+// ---- reading a string value's bytes with aligned 8-byte loads ------------------------------
+// chunk j of a value = its bytes [8j, 8j+8) packed little-endian (byte 8j in bits 0..7); bytes
+// past the end of the value are unspecified.  Only the aligned 8-byte words that contain at
+// least one byte of the value are touched, so no load can cross into an unmapped page.
+__device__ __forceinline__ uint64_t load_value_chunk(const uint8_t* data, uint64_t begin, uint64_t len, int j) {
+    const uint64_t first = begin + 8ull * (uint64_t)j;                       // byte offset of the chunk
+    const uint64_t a = (uint64_t)(uintptr_t)data + first;                    // absolute address
+    const uint64_t last = (uint64_t)(uintptr_t)data + begin + (len < 8ull * (j + 1) ? len : 8ull * (j + 1)) - 1;
+    const uint64_t* wp = reinterpret_cast<const uint64_t*>(a & ~7ull);
+    const int sh = (int)(a & 7ull) * 8;
+    uint64_t w0 = wp[0];
+    uint64_t v = w0 >> sh;
+    if (sh != 0 && (last & ~7ull) != (a & ~7ull)) v |= wp[1] << (64 - sh);
+    return v;
+}
+
+__device__ __forceinline__ uint64_t load_offset(const void* offsets, int offset_bits, uint64_t i) {
+    return offset_bits == 32 ? (uint64_t) reinterpret_cast<const uint32_t*>(offsets)[i]
+                             : reinterpret_cast<const uint64_t*>(offsets)[i];
+}
+
+}  // namespace cph

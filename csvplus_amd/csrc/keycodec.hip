@@ -1,0 +1,290 @@
+// keycodec.hip — order-preserving, alphabet-compacted key codes.
+//
+// The reference orders index rows by the tuple of key columns under strings.Compare
+// (csvplus.go:794-807): unsigned bytewise lexicographic, proper prefix first.  Instead of
+// radix-sorting raw bytes (8 bits per byte position whatever the data), the GPU path
+// re-codes every key as a mixed-radix number:
+//
+//   position p  = (key column c, byte offset q), c-major: leftmost column, first byte first
+//   symbol      = 0 ("value ended before q": pad) or 1 + byte value
+//   alphabet_p  = set of symbols occurring at p anywhere in the build table
+//   rank_p(s)   = number of symbols of alphabet_p smaller than s   (order preserving)
+//   code        = sum_p rank_p(sym_p) * prod_{p' > p} |alphabet_p'|
+//
+// pad < every byte value, so "a" < "a\0" < "ab" exactly as strings.Compare orders them,
+// NUL bytes included; comparing codes == comparing the key tuples.  Keys that need more
+// than 63 bits are split into several words at position boundaries (most significant word
+// first).  For the decimal ids of the reference's fixtures (csvplus_test.go:1241,
+// :1321-1324) a position holds 10 symbols, so 1e7 eight-digit ids become 24-bit codes:
+// 3 radix passes over 4-byte keys instead of 8 passes over 8-byte keys.
+//
+// A probe key containing a symbol outside alphabet_p (or longer than the column's longest
+// value) cannot equal any index key: it is "invalid" and matches nothing.
+#include "codec_device.hpp"
+
+namespace cph {
+
+// ---------------------------------------------------------------------------------------------
+// K0: one pass over a column: min/max value length and, per byte position, the 256-bit
+// presence bitmap of the byte values seen there.
+// ---------------------------------------------------------------------------------------------
+constexpr int kStatsThreads = 256;
+
+__global__ __launch_bounds__(kStatsThreads) void k_col_stats(DevCol col, uint32_t* __restrict__ g_minmax,
+                                                            uint32_t* __restrict__ g_mask) {
+    __shared__ uint32_t s_mask[kMaxKeyBytes * 8];
+    __shared__ uint32_t s_min, s_max;
+    for (int i = threadIdx.x; i < kMaxKeyBytes * 8; i += kStatsThreads) s_mask[i] = 0;
+    if (threadIdx.x == 0) { s_min = 0xFFFFFFFFu; s_max = 0; }
+    __syncthreads();
+
+    uint32_t mn = 0xFFFFFFFFu, mx = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * kStatsThreads;
+    for (uint64_t row = (uint64_t)blockIdx.x * kStatsThreads + threadIdx.x; row < col.nrows; row += stride) {
+        const uint64_t begin = load_offset(col.offsets, col.offset_bits, row);
+        const uint64_t len64 = load_offset(col.offsets, col.offset_bits, row + 1) - begin;
+        const uint32_t len = len64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)len64;
+        mn = len < mn ? len : mn;
+        mx = len > mx ? len : mx;
+        const int lim = len < (uint32_t)kMaxKeyBytes ? (int)len : kMaxKeyBytes;
+        uint64_t chunk = 0;
+        for (int q = 0; q < lim; q++) {
+            if ((q & 7) == 0) chunk = load_value_chunk(col.data, begin, len64, q >> 3);
+            const uint32_t b = (uint32_t)((chunk >> (8 * (q & 7))) & 0xFF);
+            const int idx = q * 8 + (int)(b >> 5);
+            const uint32_t bit = 1u << (b & 31);
+            if (!(s_mask[idx] & bit)) atomicOr(&s_mask[idx], bit);
+        }
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    if (lane_id() == 0) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kMaxKeyBytes * 8; i += kStatsThreads)
+        if (s_mask[i]) atomicOr(&g_mask[i], s_mask[i]);
+    if (threadIdx.x == 0) { atomicMin(&g_minmax[0], s_min); atomicMax(&g_minmax[1], s_max); }
+}
+
+Status codec_collect_stats(cph_ctx* ctx, const DevCol* cols, int32_t ncols, std::vector<ColStats>* out) {
+    out->assign((size_t)ncols, ColStats{});
+    const size_t per = sizeof(ColStats);
+    DevBuf d;
+    CPH_TRY(d.alloc(&ctx->pool, per * (size_t)ncols));
+    CPH_TRY(ensure_pinned_scratch(ctx, per * (size_t)ncols));
+    // init: minlen = 0xFFFFFFFF, everything else 0
+    CPH_HIP_TRY(hipMemsetAsync(d.get(), 0, per * (size_t)ncols, ctx->stream));
+    for (int c = 0; c < ncols; c++)
+        CPH_HIP_TRY(hipMemsetAsync(d.as<uint8_t>() + per * (size_t)c, 0xFF, sizeof(uint32_t), ctx->stream));
+    for (int c = 0; c < ncols; c++) {
+        if (cols[c].nrows == 0) continue;
+        uint64_t nblk = (cols[c].nrows + kStatsThreads - 1) / kStatsThreads;
+        if (nblk > 2048) nblk = 2048;
+        uint32_t* base = reinterpret_cast<uint32_t*>(d.as<uint8_t>() + per * (size_t)c);
+        hipLaunchKernelGGL(k_col_stats, dim3((unsigned)nblk), dim3(kStatsThreads), 0, ctx->stream, cols[c], base,
+                           base + 2);
+        CPH_HIP_TRY(hipGetLastError());
+    }
+    CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, d.get(), per * (size_t)ncols, hipMemcpyDeviceToHost, ctx->stream));
+    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    memcpy(out->data(), ctx->pinned_scratch, per * (size_t)ncols);
+    for (int c = 0; c < ncols; c++)
+        if (cols[c].nrows == 0) { (*out)[c].minlen = 0; (*out)[c].maxlen = 0; }
+    return {};
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host: alphabets -> radices, rank LUT, word split.
+// ---------------------------------------------------------------------------------------------
+static int bits_needed(uint64_t states) {  // bits to represent values 0..states-1
+    if (states <= 1) return 0;
+    int b = 0;
+    uint64_t v = states - 1;
+    while (v) { b++; v >>= 1; }
+    return b;
+}
+
+Status codec_build(const std::vector<ColStats>& stats, CodecHost* codec) {
+    CodecHost& cd = *codec;
+    cd = CodecHost{};
+    cd.ncols = (int32_t)stats.size();
+    if (cd.ncols <= 0 || cd.ncols > kMaxKeyCols) return {CPH_ERR_INVALID, "bad number of key columns"};
+    int npos = 0;
+    for (int c = 0; c < cd.ncols; c++) {
+        cd.col_start[c] = npos;
+        cd.col_maxlen[c] = (int32_t)stats[c].maxlen;
+        cd.col_minlen[c] = (int32_t)stats[c].minlen;
+        if ((uint64_t)npos + stats[c].maxlen > (uint64_t)kMaxKeyBytes) {
+            char b[160];
+            snprintf(b, sizeof b, "key too long: key columns need more than %d byte positions (column %d has a %u-byte value)",
+                     kMaxKeyBytes, c, stats[c].maxlen);
+            return {CPH_ERR_KEY_TOO_LONG, b};
+        }
+        npos += (int)stats[c].maxlen;
+    }
+    cd.col_start[cd.ncols] = npos;
+    cd.npos = npos;
+    cd.radix.assign((size_t)npos, 1);
+    cd.mult.assign((size_t)npos, 1);
+    cd.word_of.assign((size_t)npos, 0);
+    cd.lut.assign((size_t)npos * kLutStride, kLutInvalid);
+
+    for (int c = 0; c < cd.ncols; c++) {
+        for (int q = 0; q < cd.col_maxlen[c]; q++) {
+            const int p = cd.col_start[c] + q;
+            uint16_t* lut = &cd.lut[(size_t)p * kLutStride];
+            uint16_t rank = 0;
+            if (q >= cd.col_minlen[c]) lut[0] = rank++;   // some value ends before q: pad occurs
+            for (int b = 0; b < 256; b++)
+                if (stats[c].mask[q][b >> 5] & (1u << (b & 31))) lut[1 + b] = rank++;
+            cd.radix[(size_t)p] = rank;   // >= 1 because q < maxlen
+        }
+    }
+    // split positions into words of < 2^63 states, most significant first
+    const unsigned __int128 kLimit = (unsigned __int128)1 << 63;
+    int w = 0;
+    unsigned __int128 prod = 1;
+    int word_first = 0;
+    auto close_word = [&](int first, int last_excl, int word, unsigned __int128 states) {
+        uint64_t m = 1;
+        for (int p = last_excl - 1; p >= first; p--) {
+            cd.mult[(size_t)p] = m;
+            cd.word_of[(size_t)p] = word;
+            m *= cd.radix[(size_t)p];
+        }
+        cd.word_states[word] = (uint64_t)states;
+        cd.word_bits[word] = bits_needed((uint64_t)states);
+    };
+    for (int p = 0; p < npos; p++) {
+        if (prod * cd.radix[(size_t)p] > kLimit) {
+            if (w + 1 >= kMaxWords) return {CPH_ERR_KEY_TOO_LONG, "key needs too many code words"};
+            close_word(word_first, p, w, prod);
+            w++;
+            word_first = p;
+            prod = 1;
+        }
+        prod *= cd.radix[(size_t)p];
+    }
+    close_word(word_first, npos, w, prod);
+    cd.nwords = w + 1;
+    cd.key32 = (cd.nwords == 1 && cd.word_states[0] <= (1ull << 32));
+    return {};
+}
+
+Status codec_upload(cph_ctx* ctx, const CodecHost& cd, DevBuf* dev) {
+    CodecDevHeader h{};
+    h.ncols = cd.ncols;
+    h.npos = cd.npos;
+    h.nwords = cd.nwords;
+    h.key32 = cd.key32 ? 1 : 0;
+    for (int c = 0; c <= cd.ncols; c++) h.col_start[c] = cd.col_start[c];
+    for (int c = cd.ncols + 1; c <= kMaxKeyCols; c++) h.col_start[c] = cd.npos;
+    for (int c = 0; c < cd.ncols; c++) h.col_maxlen[c] = cd.col_maxlen[c];
+    auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    size_t off = align16(sizeof(CodecDevHeader));
+    h.mult_off = (int32_t)off;
+    off = align16(off + sizeof(uint64_t) * (size_t)cd.npos);
+    h.wordof_off = (int32_t)off;
+    off = align16(off + (size_t)cd.npos + 1);   // +1: word_of[p+1] is read at p = npos-1 only when guarded
+    h.lut_off = (int32_t)off;
+    off = align16(off + sizeof(uint16_t) * (size_t)cd.npos * kLutStride);
+    h.total_bytes = (int32_t)off;
+
+    std::vector<uint8_t> blob(off, 0);
+    memcpy(blob.data(), &h, sizeof h);
+    if (cd.npos) {
+        memcpy(blob.data() + h.mult_off, cd.mult.data(), sizeof(uint64_t) * (size_t)cd.npos);
+        for (int p = 0; p < cd.npos; p++) blob[(size_t)h.wordof_off + (size_t)p] = (uint8_t)cd.word_of[(size_t)p];
+        blob[(size_t)h.wordof_off + (size_t)cd.npos] = 0xFF;
+        memcpy(blob.data() + h.lut_off, cd.lut.data(), sizeof(uint16_t) * (size_t)cd.npos * kLutStride);
+    }
+    CPH_TRY(dev->alloc(&ctx->pool, off));
+    CPH_TRY(ensure_pinned_scratch(ctx, off));
+    memcpy(ctx->pinned_scratch, blob.data(), off);
+    CPH_HIP_TRY(hipMemcpyAsync(dev->get(), ctx->pinned_scratch, off, hipMemcpyHostToDevice, ctx->stream));
+    // the pinned scratch is reused by later calls: wait for the copy
+    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return {};
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: encode the build-side keys.
+// ---------------------------------------------------------------------------------------------
+constexpr int kEncodeThreads = 256;
+
+template <bool KEY32>
+__global__ __launch_bounds__(kEncodeThreads) void k_encode_build(ColsArg cols, const uint8_t* __restrict__ g_codec,
+                                                                uint64_t n, void* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const CodecView cv = codec_load_to_lds(g_codec, smem);
+    const int ncols = cv.hdr->ncols;
+    const uint64_t stride = (uint64_t)gridDim.x * kEncodeThreads;
+    for (uint64_t row = (uint64_t)blockIdx.x * kEncodeThreads + threadIdx.x; row < n; row += stride) {
+        if constexpr (KEY32) {
+            uint32_t code = 0;
+            encode_key(cv, cols, ncols, row, [&](int, uint64_t v, int) { code = (uint32_t)v; });
+            reinterpret_cast<uint32_t*>(out)[row] = code;
+        } else {
+            uint64_t* o = reinterpret_cast<uint64_t*>(out);
+            if (cv.hdr->npos == 0) o[row] = 0;
+            encode_key(cv, cols, ncols, row, [&](int word, uint64_t v, int) { o[(uint64_t)word * n + row] = v; });
+        }
+    }
+}
+
+Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec_dev, const DevCol* cols, uint64_t n,
+                          void* out_codes) {
+    if (n == 0) return {};
+    ColsArg arg{};
+    for (int c = 0; c < cd.ncols; c++) arg.c[c] = cols[c];
+    uint64_t nblk = (n + kEncodeThreads - 1) / kEncodeThreads;
+    if (nblk > 4096) nblk = 4096;
+    const size_t lds = codec_dev.bytes();
+    if (cd.key32) {
+        CPH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode_build<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_encode_build<true>, dim3((unsigned)nblk), dim3(kEncodeThreads), lds, ctx->stream, arg,
+                           codec_dev.as<uint8_t>(), n, out_codes);
+    } else {
+        CPH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode_build<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_encode_build<false>, dim3((unsigned)nblk), dim3(kEncodeThreads), lds, ctx->stream, arg,
+                           codec_dev.as<uint8_t>(), n, out_codes);
+    }
+    CPH_HIP_TRY(hipGetLastError());
+    return {};
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host-side encoding of literal values (Index.Find / SubIndex bounds, csvplus.go:870-891).
+// ---------------------------------------------------------------------------------------------
+bool codec_encode_values_host(const CodecHost& cd, const cph_strval* values, int32_t nvalues, uint64_t* q_exact,
+                              int32_t* nq, uint64_t* qlo, uint64_t* qhi) {
+    *nq = 0;
+    *qlo = 0;
+    *qhi = 0;
+    const int p_end = cd.col_start[nvalues];
+    uint64_t acc = 0;
+    for (int c = 0; c < nvalues; c++) {
+        if (values[c].len > (uint64_t)cd.col_maxlen[c]) return false;
+        for (int q = 0; q < cd.col_maxlen[c]; q++) {
+            const int sym = (uint64_t)q < values[c].len ? (int)values[c].data[q] + 1 : 0;
+            const int p = cd.col_start[c] + q;
+            const uint16_t r = cd.lut[(size_t)p * kLutStride + (size_t)sym];
+            if (r == kLutInvalid) return false;
+            acc += (uint64_t)r * cd.mult[(size_t)p];
+            if (p + 1 == p_end || cd.word_of[(size_t)p + 1] != cd.word_of[(size_t)p]) {
+                if (p + 1 == p_end) {
+                    *qlo = acc;
+                    *qhi = acc + cd.mult[(size_t)p] - 1;
+                } else {
+                    q_exact[*nq] = acc;
+                }
+                (*nq)++;
+                acc = 0;
+            }
+        }
+    }
+    return true;
+}
+
+}  // namespace cph

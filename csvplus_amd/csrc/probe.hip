@@ -1,0 +1,385 @@
+// probe.hip — index post-processing and the Join probe.
+//
+//   k_first_dup     createUniqueIndex's adjacent-equal scan (csvplus.go:749-753)
+//   k_build_table   direct-address table code -> [lo,end) when the code space is dense
+//   k_probe         per stream row: encode key, first()+forward scan bounds
+//                   (csvplus.go:556-559, :893-920) -> (lo,cnt), per-tile match totals
+//   k_scan_tiles    exclusive scan of the per-tile totals
+//   k_expand        emits (probe_idx, build_row) pairs in the reference's order:
+//                   stream order, then ascending index position (csvplus.go:559-563)
+//   k_find          Find/SubIndex bounds (csvplus.go:870-891)
+//
+// Integer / byte work bound by HBM + cache bandwidth; no MFMA.
+#include "codec_device.hpp"
+
+namespace cph {
+
+constexpr int kProbeThreads = 256;
+constexpr int kProbeItems   = 8;
+constexpr int kProbeTile    = kProbeThreads * kProbeItems;   // 2048 probe rows per workgroup
+
+struct TableEntry { uint32_t lo, end; };
+
+// ---- searches over one sorted code word restricted to [lo,hi) --------------------------------
+// sort.Search shape (Go stdlib): smallest i in [lo,hi) with pred(i), else hi.
+template <class K>
+__device__ __forceinline__ uint64_t lower_bound_dev(const K* __restrict__ a, uint64_t lo, uint64_t hi, K v) {
+    while (lo < hi) {
+        const uint64_t h = (lo + hi) >> 1;
+        if (a[h] < v) lo = h + 1; else hi = h;
+    }
+    return lo;
+}
+template <class K>
+__device__ __forceinline__ uint64_t upper_bound_dev(const K* __restrict__ a, uint64_t lo, uint64_t hi, K v) {
+    while (lo < hi) {
+        const uint64_t h = (lo + hi) >> 1;
+        if (a[h] <= v) lo = h + 1; else hi = h;
+    }
+    return lo;
+}
+
+// ---------------------------------------------------------------------------------------------
+// unique check
+// ---------------------------------------------------------------------------------------------
+template <bool KEY32>
+__global__ void k_first_dup(const void* __restrict__ codes, uint64_t n, int nwords, uint32_t* __restrict__ result) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t best = 0xFFFFFFFFu;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; i < n; i += stride) {
+        bool eq = true;
+        if constexpr (KEY32) {
+            const uint32_t* c = reinterpret_cast<const uint32_t*>(codes);
+            eq = c[i] == c[i - 1];
+        } else {
+            const uint64_t* c = reinterpret_cast<const uint64_t*>(codes);
+            for (int w = 0; w < nwords && eq; w++) eq = c[(uint64_t)w * n + i] == c[(uint64_t)w * n + i - 1];
+        }
+        if (eq && (uint32_t)i < best) best = (uint32_t)i;
+    }
+    best = wave_min(best);
+    if (lane_id() == 0 && best != 0xFFFFFFFFu) atomicMin(result, best);
+}
+
+Status index_first_dup(cph_ctx* ctx, const cph_index* ix, uint64_t* first_dup) {
+    *first_dup = UINT64_MAX;
+    const uint64_t n = ix->nrows;
+    if (n < 2) return {};
+    DevBuf d;
+    CPH_TRY(d.alloc(&ctx->pool, sizeof(uint32_t)));
+    CPH_TRY(ensure_pinned_scratch(ctx, sizeof(uint32_t)));
+    CPH_HIP_TRY(hipMemsetAsync(d.get(), 0xFF, sizeof(uint32_t), ctx->stream));
+    uint64_t nblk = (n + 255) / 256;
+    if (nblk > 4096) nblk = 4096;
+    if (ix->codec.key32)
+        hipLaunchKernelGGL(k_first_dup<true>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, ix->sorted_codes.get(), n,
+                           ix->codec.nwords, d.as<uint32_t>());
+    else
+        hipLaunchKernelGGL(k_first_dup<false>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, ix->sorted_codes.get(),
+                           n, ix->codec.nwords, d.as<uint32_t>());
+    CPH_HIP_TRY(hipGetLastError());
+    CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, d.get(), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const uint32_t r = *reinterpret_cast<const uint32_t*>(ctx->pinned_scratch);
+    if (r != 0xFFFFFFFFu) *first_dup = r;
+    return {};
+}
+
+// ---------------------------------------------------------------------------------------------
+// direct-address table: entry[code] = {lo, end}; absent codes stay {0,0} (cnt 0)
+// ---------------------------------------------------------------------------------------------
+template <class K>
+__global__ void k_build_table(const K* __restrict__ codes, uint64_t n, TableEntry* __restrict__ table) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const K c = codes[i];
+        if (i == 0 || codes[i - 1] != c) table[c].lo = (uint32_t)i;
+        if (i + 1 == n || codes[i + 1] != c) table[c].end = (uint32_t)(i + 1);
+    }
+}
+
+Status index_build_table(cph_ctx* ctx, cph_index* ix) {
+    ix->table_entries = 0;
+    const uint64_t n = ix->nrows;
+    if (n == 0 || ix->codec.nwords != 1) return {};
+    const uint64_t states = ix->codec.word_states[0];
+    uint64_t limit = 8 * n;
+    if (limit < (1ull << 20)) limit = 1ull << 20;
+    if (states > limit || states > (1ull << 30)) return {};
+    CPH_TRY(ix->table.alloc(&ctx->pool, states * sizeof(TableEntry)));
+    CPH_HIP_TRY(hipMemsetAsync(ix->table.get(), 0, states * sizeof(TableEntry), ctx->stream));
+    uint64_t nblk = (n + 255) / 256;
+    if (nblk > 8192) nblk = 8192;
+    if (ix->codec.key32)
+        hipLaunchKernelGGL(k_build_table<uint32_t>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream,
+                           ix->sorted_codes.as<uint32_t>(), n, ix->table.as<TableEntry>());
+    else
+        hipLaunchKernelGGL(k_build_table<uint64_t>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream,
+                           ix->sorted_codes.as<uint64_t>(), n, ix->table.as<TableEntry>());
+    CPH_HIP_TRY(hipGetLastError());
+    ix->table_entries = states;
+    return {};
+}
+
+// ---------------------------------------------------------------------------------------------
+// probe
+// ---------------------------------------------------------------------------------------------
+template <bool KEY32, bool TABLE>
+__global__ __launch_bounds__(kProbeThreads) void k_probe(ColsArg cols, int ncols_used,
+                                                        const uint8_t* __restrict__ g_codec,
+                                                        const void* __restrict__ codes, uint64_t n_index,
+                                                        const TableEntry* __restrict__ table,
+                                                        RowSel sel, uint64_t nprobe,
+                                                        uint32_t* __restrict__ out_lo, uint32_t* __restrict__ out_cnt,
+                                                        uint64_t* __restrict__ tile_sums) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ uint64_t s_wsum[kProbeThreads / kWave];
+    const CodecView cv = codec_load_to_lds(g_codec, smem);
+    const int p_end = cv.hdr->col_start[ncols_used];
+    const uint64_t tile0 = (uint64_t)blockIdx.x * kProbeTile;
+    uint64_t my_sum = 0;
+#pragma unroll 1
+    for (int k = 0; k < kProbeItems; k++) {
+        const uint64_t i = tile0 + (uint64_t)k * kProbeThreads + threadIdx.x;
+        if (i >= nprobe) break;
+        uint64_t row = i;
+        if (sel.ptr)
+            row = (sel.bits == 32 ? (uint64_t) reinterpret_cast<const uint32_t*>(sel.ptr)[i]
+                                  : reinterpret_cast<const uint64_t*>(sel.ptr)[i]) - sel.base;
+        uint64_t lo = 0, hi = n_index;
+        bool valid;
+        if constexpr (TABLE) {
+            uint64_t code = 0;
+            valid = encode_key(cv, cols, ncols_used, row, [&](int, uint64_t v, int) { code = v; });
+            if (valid) {
+                const TableEntry e = table[code];
+                lo = e.lo;
+                hi = e.end;
+            }
+        } else {
+            valid = encode_key(cv, cols, ncols_used, row, [&](int word, uint64_t v, int p) {
+                const uint64_t vhi = (p + 1 == p_end) ? v + cv.mult[p] - 1 : v;
+                if constexpr (KEY32) {
+                    const uint32_t* a = reinterpret_cast<const uint32_t*>(codes);
+                    const uint64_t l2 = lower_bound_dev<uint32_t>(a, lo, hi, (uint32_t)v);
+                    hi = upper_bound_dev<uint32_t>(a, l2, hi, (uint32_t)vhi);
+                    lo = l2;
+                } else {
+                    const uint64_t* a = reinterpret_cast<const uint64_t*>(codes) + (uint64_t)word * n_index;
+                    const uint64_t l2 = lower_bound_dev<uint64_t>(a, lo, hi, v);
+                    hi = upper_bound_dev<uint64_t>(a, l2, hi, vhi);
+                    lo = l2;
+                }
+            });
+        }
+        const uint32_t cnt = valid ? (uint32_t)(hi - lo) : 0u;
+        out_lo[i] = (uint32_t)lo;
+        out_cnt[i] = cnt;
+        my_sum += cnt;
+    }
+    my_sum = wave_sum(my_sum);
+    if (lane_id() == 0) s_wsum[wave_id()] = my_sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0;
+        for (int w = 0; w < kProbeThreads / kWave; w++) t += s_wsum[w];
+        tile_sums[blockIdx.x] = t;
+    }
+}
+
+// single workgroup: tile_sums[0..m) -> exclusive prefix in place, total in tile_sums[m]
+__global__ __launch_bounds__(256) void k_scan_tiles(uint64_t* __restrict__ sums, uint64_t m) {
+    __shared__ uint64_t s_tmp[256 / kWave + 1];
+    uint64_t carry = 0;
+    for (uint64_t base = 0; base < m; base += 256) {
+        const uint64_t i = base + threadIdx.x;
+        const uint64_t v = i < m ? sums[i] : 0ull;
+        uint64_t total;
+        const uint64_t ex = block_exclusive_sum<uint64_t, 256>(v, s_tmp, &total);
+        if (i < m) sums[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) sums[m] = carry;
+}
+
+// ---------------------------------------------------------------------------------------------
+// expand
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kProbeThreads) void k_expand(const uint32_t* __restrict__ lo_arr,
+                                                         const uint32_t* __restrict__ cnt_arr, uint64_t nprobe,
+                                                         const uint64_t* __restrict__ tile_base,
+                                                         const uint32_t* __restrict__ perm, uint64_t probe_base,
+                                                         uint64_t* __restrict__ out_pidx,
+                                                         uint32_t* __restrict__ out_brow) {
+    __shared__ uint64_t s_off[kProbeTile + 1];
+    __shared__ uint32_t s_lo[kProbeTile];
+    __shared__ uint64_t s_tmp[kProbeThreads / kWave + 1];
+    __shared__ uint32_t s_max;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * kProbeTile;
+    const uint64_t rem = nprobe - tile0;
+    const uint32_t tile_n = rem < (uint64_t)kProbeTile ? (uint32_t)rem : (uint32_t)kProbeTile;
+    if (threadIdx.x == 0) s_max = 0;
+    // stage cnt (into s_off) and lo, coalesced
+    uint32_t mx = 0;
+    for (uint32_t r = threadIdx.x; r < (uint32_t)kProbeTile; r += kProbeThreads) {
+        const uint32_t c = r < tile_n ? cnt_arr[tile0 + r] : 0u;
+        s_off[r] = c;
+        s_lo[r] = r < tile_n ? lo_arr[tile0 + r] : 0u;
+        mx = c > mx ? c : mx;
+    }
+    __syncthreads();
+    mx = wave_max(mx);
+    if (lane_id() == 0) atomicMax(&s_max, mx);
+    // thread t scans its kProbeItems consecutive rows
+    uint64_t v[kProbeItems];
+    uint64_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < kProbeItems; k++) {
+        v[k] = s_off[threadIdx.x * kProbeItems + k];
+        sum += v[k];
+    }
+    uint64_t total;
+    uint64_t run = block_exclusive_sum<uint64_t, kProbeThreads>(sum, s_tmp, &total);   // syncs inside
+#pragma unroll
+    for (int k = 0; k < kProbeItems; k++) {
+        s_off[threadIdx.x * kProbeItems + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == kProbeThreads - 1) s_off[kProbeTile] = run;
+    __syncthreads();
+    const uint64_t out0 = tile_base[blockIdx.x];
+    if (s_max <= 1) {
+        // at most one match per stream row (unique build side): direct placement
+        for (uint32_t r = threadIdx.x; r < tile_n; r += kProbeThreads) {
+            if (s_off[r + 1] != s_off[r]) {
+                const uint64_t o = out0 + s_off[r];
+                out_pidx[o] = probe_base + tile0 + r;
+                out_brow[o] = perm[s_lo[r]];
+            }
+        }
+    } else {
+        // one output slot per thread-iteration: balanced whatever the cnt skew
+        for (uint64_t o = threadIdx.x; o < total; o += kProbeThreads) {
+            uint32_t a = 0, b = kProbeTile;   // last r with s_off[r] <= o
+            while (b - a > 1) {
+                const uint32_t h = (a + b) >> 1;
+                if (s_off[h] <= o) a = h; else b = h;
+            }
+            const uint64_t j = o - s_off[a];
+            out_pidx[out0 + o] = probe_base + tile0 + a;
+            out_brow[out0 + o] = perm[(uint64_t)s_lo[a] + j];
+        }
+    }
+}
+
+template <bool KEY32, bool TABLE>
+static Status launch_probe(cph_ctx* ctx, const cph_index* ix, const ColsArg& arg, int ncols, RowSel row_sel,
+                           uint64_t nprobe, uint32_t* lo, uint32_t* cnt, uint64_t* tile_sums, unsigned ntiles) {
+    const size_t lds = ix->codec_dev.bytes();
+    CPH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_probe<KEY32, TABLE>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_probe<KEY32, TABLE>), dim3(ntiles), dim3(kProbeThreads), lds, ctx->stream, arg, ncols,
+                       ix->codec_dev.as<uint8_t>(), ix->sorted_codes.get(), ix->nrows, ix->table.as<TableEntry>(),
+                       row_sel, nprobe, lo, cnt, tile_sums);
+    CPH_HIP_TRY(hipGetLastError());
+    return {};
+}
+
+Status probe_run(cph_ctx* ctx, const cph_index* ix, const DevCol* cols, int32_t ncols, RowSel row_sel,
+                 uint64_t nprobe, uint64_t probe_base, bool want_pairs, ProbeOut* out) {
+    out->nprobe = nprobe;
+    out->nmatches = 0;
+    if (nprobe == 0) return {};
+    const uint64_t ntiles64 = (nprobe + kProbeTile - 1) / kProbeTile;
+    const unsigned ntiles = (unsigned)ntiles64;
+    CPH_TRY(out->lo.alloc(&ctx->pool, nprobe * sizeof(uint32_t)));
+    CPH_TRY(out->cnt.alloc(&ctx->pool, nprobe * sizeof(uint32_t)));
+    DevBuf tiles;
+    CPH_TRY(tiles.alloc(&ctx->pool, (ntiles64 + 1) * sizeof(uint64_t)));
+    ColsArg arg{};
+    for (int c = 0; c < ncols; c++) arg.c[c] = cols[c];
+    const bool full_key = ncols == ix->codec.ncols;
+    const bool use_table = ix->table_entries != 0 && full_key;
+    uint32_t* lo = out->lo.as<uint32_t>();
+    uint32_t* cnt = out->cnt.as<uint32_t>();
+    uint64_t* ts = tiles.as<uint64_t>();
+    if (ix->codec.key32) {
+        if (use_table) CPH_TRY((launch_probe<true, true>(ctx, ix, arg, ncols, row_sel, nprobe, lo, cnt, ts, ntiles)));
+        else CPH_TRY((launch_probe<true, false>(ctx, ix, arg, ncols, row_sel, nprobe, lo, cnt, ts, ntiles)));
+    } else {
+        if (use_table) CPH_TRY((launch_probe<false, true>(ctx, ix, arg, ncols, row_sel, nprobe, lo, cnt, ts, ntiles)));
+        else CPH_TRY((launch_probe<false, false>(ctx, ix, arg, ncols, row_sel, nprobe, lo, cnt, ts, ntiles)));
+    }
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(256), 0, ctx->stream, ts, ntiles64);
+    CPH_HIP_TRY(hipGetLastError());
+    CPH_TRY(ensure_pinned_scratch(ctx, sizeof(uint64_t)));
+    CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, ts + ntiles64, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    out->nmatches = *reinterpret_cast<const uint64_t*>(ctx->pinned_scratch);
+    if (!want_pairs || out->nmatches == 0) return {};
+    CPH_TRY(out->pidx.alloc(&ctx->pool, out->nmatches * sizeof(uint64_t)));
+    CPH_TRY(out->brow.alloc(&ctx->pool, out->nmatches * sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_expand, dim3(ntiles), dim3(kProbeThreads), 0, ctx->stream, lo, cnt, nprobe, ts,
+                       ix->perm.as<uint32_t>(), probe_base, out->pidx.as<uint64_t>(), out->brow.as<uint32_t>());
+    CPH_HIP_TRY(hipGetLastError());
+    return {};
+}
+
+// ---------------------------------------------------------------------------------------------
+// Find / SubIndex bounds
+// ---------------------------------------------------------------------------------------------
+template <bool KEY32>
+__global__ void k_find(const void* __restrict__ codes, uint64_t n, const uint64_t* __restrict__ q, int nq,
+                       uint64_t* __restrict__ result) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint64_t lo = 0, hi = n;
+    for (int w = 0; w < nq; w++) {
+        const uint64_t vlo = (w + 1 == nq) ? q[nq - 1] : q[w];
+        const uint64_t vhi = (w + 1 == nq) ? q[nq] : q[w];
+        if constexpr (KEY32) {
+            const uint32_t* a = reinterpret_cast<const uint32_t*>(codes);
+            const uint64_t l2 = lower_bound_dev<uint32_t>(a, lo, hi, (uint32_t)vlo);
+            hi = upper_bound_dev<uint32_t>(a, l2, hi, (uint32_t)vhi);
+            lo = l2;
+        } else {
+            const uint64_t* a = reinterpret_cast<const uint64_t*>(codes) + (uint64_t)w * n;
+            const uint64_t l2 = lower_bound_dev<uint64_t>(a, lo, hi, vlo);
+            hi = upper_bound_dev<uint64_t>(a, l2, hi, vhi);
+            lo = l2;
+        }
+    }
+    result[0] = lo;
+    result[1] = hi;
+}
+
+// q layout: q_exact[0..nq-2], then qlo at [nq-1], qhi at [nq]
+Status index_find_device(cph_ctx* ctx, const cph_index* ix, const uint64_t* q_exact, int32_t nq, uint64_t qlo,
+                         uint64_t qhi, uint64_t* lower, uint64_t* upper) {
+    const uint64_t n = ix->nrows;
+    if (nq == 0 || n == 0) { *lower = 0; *upper = n; return {}; }
+    DevBuf d;
+    const size_t qbytes = sizeof(uint64_t) * (size_t)(nq + 1);
+    CPH_TRY(d.alloc(&ctx->pool, qbytes + 2 * sizeof(uint64_t)));
+    CPH_TRY(ensure_pinned_scratch(ctx, qbytes + 2 * sizeof(uint64_t)));
+    uint64_t* h = reinterpret_cast<uint64_t*>(ctx->pinned_scratch);
+    for (int i = 0; i + 1 < nq; i++) h[i] = q_exact[i];
+    h[nq - 1] = qlo;
+    h[nq] = qhi;
+    CPH_HIP_TRY(hipMemcpyAsync(d.get(), h, qbytes, hipMemcpyHostToDevice, ctx->stream));
+    uint64_t* dres = d.as<uint64_t>() + (nq + 1);
+    if (ix->codec.key32)
+        hipLaunchKernelGGL(k_find<true>, dim3(1), dim3(64), 0, ctx->stream, ix->sorted_codes.get(), n, d.as<uint64_t>(), nq,
+                           dres);
+    else
+        hipLaunchKernelGGL(k_find<false>, dim3(1), dim3(64), 0, ctx->stream, ix->sorted_codes.get(), n, d.as<uint64_t>(),
+                           nq, dres);
+    CPH_HIP_TRY(hipGetLastError());
+    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));   // h (input) consumed
+    CPH_HIP_TRY(hipMemcpyAsync(h, dres, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *lower = h[0];
+    *upper = h[1];
+    return {};
+}
+
+}  // namespace cph

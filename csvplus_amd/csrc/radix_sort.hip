@@ -1,0 +1,323 @@
+// radix_sort.hip — stable LSD radix sort of (key code, row id) pairs for IndexOn
+// (replaces sort.Sort(&index.impl), csvplus.go:736).
+//
+// 8-bit digits.  Per pass:
+//   k_radix_hist     per-tile 256-bin digit histogram (LDS atomics)      reads  K B/row
+//   exclusive scan   over the [256][ntiles] count matrix (digit-major)
+//   k_radix_scatter  wave-ballot digit matching -> stable ranks, tile reordered in LDS,
+//                    runs written out coalesced                          reads+writes (K+4) B/row
+// K = 4 (32-bit codes) or 8.  HBM-bound integer work: no MFMA.
+//
+// Stability matters twice: LSD needs it between passes, and the index contract is that
+// rows with equal keys keep their input order.  Ranks therefore come from
+// wave-level digit matching (`__ballot` + popcount of the lanes below), never from
+// returning LDS atomics, whose intra-instruction order is unspecified.
+#include "cph_internal.hpp"
+#include "device_utils.hpp"
+
+namespace cph {
+
+constexpr int kSortThreads = 256;                         // 4 waves
+constexpr int kSortWaves   = kSortThreads / kWave;
+constexpr int kSortItems   = 16;                          // keys per thread
+constexpr int kSortTile    = kSortThreads * kSortItems;   // 4096 keys per workgroup
+constexpr int kRadixBits   = 8;
+constexpr int kRadix       = 1 << kRadixBits;
+
+// ---------------------------------------------------------------------------------------------
+// histogram
+// ---------------------------------------------------------------------------------------------
+template <class K>
+__global__ __launch_bounds__(kSortThreads) void k_radix_hist(const K* __restrict__ keys, uint64_t n, int shift,
+                                                            uint32_t digit_mask, uint32_t* __restrict__ counts,
+                                                            uint32_t ntiles) {
+    __shared__ uint32_t s_hist[kSortWaves][kRadix];
+    for (int i = threadIdx.x; i < kSortWaves * kRadix; i += kSortThreads) (&s_hist[0][0])[i] = 0;
+    __syncthreads();
+    const uint64_t tile0 = (uint64_t)blockIdx.x * kSortTile;
+    const int w = wave_id();
+#pragma unroll
+    for (int k = 0; k < kSortItems; k++) {
+        const uint64_t i = tile0 + (uint64_t)k * kSortThreads + threadIdx.x;
+        if (i < n) {
+            const uint32_t d = (uint32_t)(keys[i] >> shift) & digit_mask;
+            atomicAdd(&s_hist[w][d], 1u);
+        }
+    }
+    __syncthreads();
+    const int d = threadIdx.x;  // kSortThreads == kRadix
+    uint32_t c = 0;
+#pragma unroll
+    for (int ww = 0; ww < kSortWaves; ww++) c += s_hist[ww][d];
+    counts[(uint64_t)d * ntiles + blockIdx.x] = c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// scatter
+// ---------------------------------------------------------------------------------------------
+template <class K>
+struct ScatterSmem {
+    K keys[kSortTile];
+    uint32_t vals[kSortTile];
+    uint32_t wave_cnt[kSortWaves][kRadix];   // per-wave digit counts, then exclusive over waves
+    uint32_t digit_start[kRadix];            // first local slot of each digit's run
+    uint32_t gdelta[kRadix];                 // global position = local slot + gdelta[digit] (mod 2^32)
+    uint32_t scan_tmp[kSortWaves + 1];
+};
+
+template <class K>
+__global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const K* __restrict__ keys_in,
+                                                               const uint32_t* __restrict__ vals_in,
+                                                               K* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                               uint64_t n, int shift, uint32_t digit_mask,
+                                                               const uint32_t* __restrict__ bases, uint32_t ntiles) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+    ScatterSmem<K>& s = *reinterpret_cast<ScatterSmem<K>*>(smem_raw);
+
+    const int w = wave_id();
+    const int lane = lane_id();
+    const uint64_t tile0 = (uint64_t)blockIdx.x * kSortTile;
+    const uint64_t remaining = n - tile0;
+    const uint32_t tile_n = remaining < (uint64_t)kSortTile ? (uint32_t)remaining : (uint32_t)kSortTile;
+    const uint64_t lt = lanemask_lt();
+
+    for (int i = threadIdx.x; i < kSortWaves * kRadix; i += kSortThreads) (&s.wave_cnt[0][0])[i] = 0;
+    __syncthreads();
+
+    // wave w owns tile slots [w*64*ITEMS, (w+1)*64*ITEMS); item k of lane l is slot base + k*64 + l,
+    // so (wave, item, lane) order == memory order.
+    K key[kSortItems];
+    uint32_t val[kSortItems];
+    uint32_t rank[kSortItems];
+    const uint32_t wave_base = (uint32_t)w * kWave * kSortItems;
+#pragma unroll
+    for (int k = 0; k < kSortItems; k++) {
+        const uint32_t slot = wave_base + (uint32_t)k * kWave + (uint32_t)lane;
+        const bool valid = slot < tile_n;
+        key[k] = valid ? keys_in[tile0 + slot] : (K)0;
+        val[k] = valid ? (vals_in ? vals_in[tile0 + slot] : (uint32_t)(tile0 + slot)) : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < kSortItems; k++) {
+        const uint32_t slot = wave_base + (uint32_t)k * kWave + (uint32_t)lane;
+        const bool valid = slot < tile_n;
+        const uint32_t d = (uint32_t)(key[k] >> shift) & digit_mask;
+        // lanes of this wave holding the same digit
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < kRadixBits; b++) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        const uint32_t before = s.wave_cnt[w][d];          // same value for all peers
+        rank[k] = before + (uint32_t)__popcll(peers & lt);
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (peers & lt) == 0) s.wave_cnt[w][d] = before + (uint32_t)__popcll(peers);  // leader
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+
+    // digit d = threadIdx.x: exclusive over waves, tile total, exclusive over digits
+    {
+        const int d = threadIdx.x;
+        uint32_t run = 0;
+#pragma unroll
+        for (int ww = 0; ww < kSortWaves; ww++) {
+            const uint32_t c = s.wave_cnt[ww][d];
+            s.wave_cnt[ww][d] = run;
+            run += c;
+        }
+        uint32_t total;
+        const uint32_t start = block_exclusive_sum<uint32_t, kSortThreads>(run, s.scan_tmp, &total);
+        s.digit_start[d] = start;
+        s.gdelta[d] = bases[(uint64_t)d * ntiles + blockIdx.x] - start;
+    }
+    __syncthreads();
+
+    // place the pairs at their tile-local sorted slot
+#pragma unroll
+    for (int k = 0; k < kSortItems; k++) {
+        const uint32_t slot = wave_base + (uint32_t)k * kWave + (uint32_t)lane;
+        if (slot < tile_n) {
+            const uint32_t d = (uint32_t)(key[k] >> shift) & digit_mask;
+            const uint32_t pos = s.digit_start[d] + s.wave_cnt[w][d] + rank[k];
+            s.keys[pos] = key[k];
+            s.vals[pos] = val[k];
+        }
+    }
+    __syncthreads();
+
+    // write out: consecutive threads -> consecutive slots -> coalesced runs per digit
+#pragma unroll
+    for (int k = 0; k < kSortItems; k++) {
+        const uint32_t i = (uint32_t)k * kSortThreads + threadIdx.x;
+        if (i < tile_n) {
+            const K kk = s.keys[i];
+            const uint32_t d = (uint32_t)(kk >> shift) & digit_mask;
+            const uint32_t g = i + s.gdelta[d];
+            keys_out[g] = kk;
+            vals_out[g] = s.vals[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// device-wide exclusive scan of uint32 (in place): reduce / scan block sums / apply
+// ---------------------------------------------------------------------------------------------
+constexpr int kScanThreads = 256;
+constexpr int kScanItems   = 16;
+constexpr int kScanTile    = kScanThreads * kScanItems;
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_reduce(const uint32_t* __restrict__ data, uint64_t n,
+                                                             uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t s_w[kScanThreads / kWave];
+    const uint64_t base = (uint64_t)blockIdx.x * kScanTile;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; k++) {
+        const uint64_t i = base + (uint64_t)k * kScanThreads + threadIdx.x;
+        if (i < n) sum += data[i];
+    }
+    sum = wave_sum(sum);
+    if (lane_id() == 0) s_w[wave_id()] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < kScanThreads / kWave; w++) t += s_w[w];
+        block_sums[blockIdx.x] = t;
+    }
+}
+
+// single workgroup: exclusive scan of `m` block sums in place
+__global__ __launch_bounds__(kScanThreads) void k_scan_block_sums(uint32_t* __restrict__ sums, uint64_t m) {
+    __shared__ uint32_t s_tmp[kScanThreads / kWave + 1];
+    uint32_t carry = 0;
+    for (uint64_t base = 0; base < m; base += kScanThreads) {
+        const uint64_t i = base + threadIdx.x;
+        const uint32_t v = i < m ? sums[i] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_sum<uint32_t, kScanThreads>(v, s_tmp, &total);
+        if (i < m) sums[i] = carry + ex;
+        carry += total;
+    }
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_apply(uint32_t* __restrict__ data, uint64_t n,
+                                                            const uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t s_tmp[kScanThreads / kWave + 1];
+    // thread t owns kScanItems consecutive elements
+    const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
+    uint32_t v[kScanItems];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; k++) {
+        v[k] = (base + k) < n ? data[base + k] : 0u;
+        sum += v[k];
+    }
+    uint32_t total;
+    uint32_t run = block_exclusive_sum<uint32_t, kScanThreads>(sum, s_tmp, &total) + block_sums[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < kScanItems; k++) {
+        if ((base + k) < n) data[base + k] = run;
+        run += v[k];
+    }
+}
+
+Status exclusive_scan_u32(cph_ctx* ctx, uint32_t* data, uint64_t n) {
+    if (n == 0) return {};
+    const uint64_t nblk = (n + kScanTile - 1) / kScanTile;
+    DevBuf sums;
+    CPH_TRY(sums.alloc(&ctx->pool, nblk * sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nblk), dim3(kScanThreads), 0, ctx->stream, data, n,
+                       sums.as<uint32_t>());
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(kScanThreads), 0, ctx->stream, sums.as<uint32_t>(), nblk);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nblk), dim3(kScanThreads), 0, ctx->stream, data, n,
+                       sums.as<uint32_t>());
+    CPH_HIP_TRY(hipGetLastError());
+    return {};
+}
+
+// ---------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------
+__global__ void k_gather_u64(const uint64_t* __restrict__ src, const uint32_t* __restrict__ idx,
+                             uint64_t* __restrict__ dst, uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[idx[i]];
+}
+__global__ void k_iota_u32(uint32_t* __restrict__ dst, uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (uint32_t)i;
+}
+static unsigned grid_for(uint64_t n, int threads, unsigned cap) {
+    uint64_t b = (n + threads - 1) / threads;
+    if (b > cap) b = cap;
+    if (b == 0) b = 1;
+    return (unsigned)b;
+}
+Status gather_u64(cph_ctx* ctx, const uint64_t* src, const uint32_t* idx, uint64_t* dst, uint64_t n) {
+    if (n == 0) return {};
+    hipLaunchKernelGGL(k_gather_u64, dim3(grid_for(n, 256, 8192)), dim3(256), 0, ctx->stream, src, idx, dst, n);
+    CPH_HIP_TRY(hipGetLastError());
+    return {};
+}
+Status fill_iota_u32(cph_ctx* ctx, uint32_t* dst, uint64_t n) {
+    if (n == 0) return {};
+    hipLaunchKernelGGL(k_iota_u32, dim3(grid_for(n, 256, 8192)), dim3(256), 0, ctx->stream, dst, n);
+    CPH_HIP_TRY(hipGetLastError());
+    return {};
+}
+
+// ---------------------------------------------------------------------------------------------
+// driver
+// ---------------------------------------------------------------------------------------------
+template <class K>
+Status radix_sort_pairs(cph_ctx* ctx, K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b, bool vals_iota,
+                        uint64_t n, int bits, K** keys_out, uint32_t** vals_out, int* passes) {
+    *passes = 0;
+    K* kin = keys_a;
+    K* kout = keys_b;
+    uint32_t* vin = vals_a;
+    uint32_t* vout = vals_b;
+    bool iota = vals_iota;
+    if (n == 0 || bits <= 0) {
+        if (iota) CPH_TRY(fill_iota_u32(ctx, vin, n));
+        *keys_out = kin;
+        *vals_out = vin;
+        return {};
+    }
+    const uint64_t ntiles64 = (n + kSortTile - 1) / kSortTile;
+    const uint32_t ntiles = (uint32_t)ntiles64;
+    DevBuf counts;
+    CPH_TRY(counts.alloc(&ctx->pool, (size_t)kRadix * ntiles * sizeof(uint32_t)));
+    const size_t smem = sizeof(ScatterSmem<K>);
+    CPH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_radix_scatter<K>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    for (int shift = 0; shift < bits; shift += kRadixBits) {
+        const int nb = bits - shift < kRadixBits ? bits - shift : kRadixBits;
+        const uint32_t mask = (1u << nb) - 1u;
+        hipLaunchKernelGGL(k_radix_hist<K>, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, kin, n, shift, mask,
+                           counts.as<uint32_t>(), ntiles);
+        CPH_HIP_TRY(hipGetLastError());
+        CPH_TRY(exclusive_scan_u32(ctx, counts.as<uint32_t>(), (uint64_t)kRadix * ntiles));
+        hipLaunchKernelGGL(k_radix_scatter<K>, dim3(ntiles), dim3(kSortThreads), smem, ctx->stream, kin,
+                           iota ? (const uint32_t*)nullptr : vin, kout, vout, n, shift, mask, counts.as<uint32_t>(),
+                           ntiles);
+        CPH_HIP_TRY(hipGetLastError());
+        iota = false;
+        K* tk = kin; kin = kout; kout = tk;
+        uint32_t* tv = vin; vin = vout; vout = tv;
+        (*passes)++;
+    }
+    *keys_out = kin;
+    *vals_out = vin;
+    return {};
+}
+
+template Status radix_sort_pairs<uint32_t>(cph_ctx*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, bool, uint64_t, int,
+                                           uint32_t**, uint32_t**, int*);
+template Status radix_sort_pairs<uint64_t>(cph_ctx*, uint64_t*, uint64_t*, uint32_t*, uint32_t*, bool, uint64_t, int,
+                                           uint64_t**, uint32_t**, int*);
+
+}  // namespace cph

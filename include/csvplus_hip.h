@@ -1,0 +1,225 @@
+/*
+ * csvplus_hip.h — C ABI of libcsvplus_hip: the MI355X (gfx950) implementation
+ * of csvplus's Index-build + Join hot path.
+ *
+ * The reference (maxim2266/csvplus, one Go file) has no FFI layer; the seams a
+ * cgo shim replaces are (all citations are file:line in the reference):
+ *
+ *   sort.Sort(&index.impl)                      csvplus.go:736   -> cph_index_build
+ *   createUniqueIndex adjacent-equal scan       csvplus.go:749-753 -> cph_index_build(unique=1)
+ *   Join per-row  first() + forward scan        csvplus.go:557-563 -> cph_join_probe
+ *   Except per-row has()                        csvplus.go:599-602 -> cph_join_probe (cnt==0 rows)
+ *   indexImpl.find (Find / SubIndex bounds)     csvplus.go:870-891 -> cph_index_find
+ *
+ * Conventions
+ *   - Every function returns an int32 status (CPH_OK == 0, errors < 0) unless
+ *     noted.  cph_last_error(ctx) gives a NUL-terminated message owned by the
+ *     ctx, valid until the next call on that ctx.
+ *   - Inputs are borrowed for the duration of the call only.  Outputs
+ *     (cph_index, cph_matches) are library-owned and explicitly released.
+ *   - A cph_ctx is single-threaded (the reference has no concurrency either:
+ *     no go/sync/chan in csvplus.go).  The library calls hipSetDevice on every
+ *     entry, so a ctx may migrate between OS threads (cgo does that).
+ *   - No callbacks into the caller.  No exceptions cross the boundary.
+ *   - String columns are Arrow-style: `data` holds the concatenated raw value
+ *     bytes (no terminators, any byte value incl. NUL), `offsets` has
+ *     nrows+1 monotonically non-decreasing entries of 32 or 64 bits.
+ *     `mem` says where both arrays live: host memory (pageable or pinned) or
+ *     device memory of the ctx's GPU.
+ *   - Row ids are uint32: a single table is limited to 2^32-1 rows
+ *     (CPH_ERR_TOO_MANY_ROWS otherwise).  Go `int` row counts are 64-bit; the
+ *     shim must check.
+ *
+ * Ordering contract (csvplus.go:794-807, indexImpl.Less): rows are ordered by
+ * the tuple of key columns, each compared with strings.Compare = unsigned
+ * bytewise lexicographic, a proper prefix sorting first.  Rows with equal keys
+ * keep their input order (stable), which is one of the orders the reference's
+ * unstable sort.Sort may produce (parity class P1).
+ */
+#ifndef CSVPLUS_HIP_H
+#define CSVPLUS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPH_API __attribute__((visibility("default")))
+
+/* ---- status codes ---------------------------------------------------------- */
+enum {
+    CPH_OK                 = 0,
+    CPH_ERR_INVALID        = -1,  /* bad argument (NULL, nkeycols<=0, offset_bits...)        */
+    CPH_ERR_HIP            = -2,  /* a HIP runtime call failed; see cph_last_error           */
+    CPH_ERR_NO_DEVICE      = -3,  /* no usable GPU: the library never falls back to the CPU  */
+    CPH_ERR_DUPLICATE      = -4,  /* unique index requested and equal keys exist             */
+    CPH_ERR_TOO_MANY_ROWS  = -5,  /* nrows > 2^32-1                                          */
+    CPH_ERR_KEY_TOO_LONG   = -6,  /* sum over key columns of max value length > CPH_MAX_KEY_BYTES */
+    CPH_ERR_TOO_MANY_COLS  = -7,  /* join with more columns than the index has
+                                     (csvplus.go:548-550 panics "too many source columns")   */
+    CPH_ERR_NOMEM          = -8
+};
+
+#define CPH_MAX_KEY_BYTES 128   /* sum over key columns of the longest value, in bytes */
+#define CPH_MAX_KEY_COLS  16
+
+enum { CPH_MEM_HOST = 0, CPH_MEM_DEVICE = 1 };
+
+typedef struct cph_ctx   cph_ctx;
+typedef struct cph_index cph_index;
+
+/* One string column (or a row range of one). */
+typedef struct {
+    const uint8_t* data;        /* concatenated value bytes                               */
+    const void*    offsets;     /* nrows+1 entries; value i = data[offsets[i]..offsets[i+1]) */
+    uint64_t       nrows;
+    int32_t        offset_bits; /* 32 or 64                                               */
+    int32_t        mem;         /* CPH_MEM_HOST or CPH_MEM_DEVICE                         */
+} cph_strcol;
+
+/* One key value (for cph_index_find). Host memory. */
+typedef struct {
+    const uint8_t* data;
+    uint64_t       len;
+} cph_strval;
+
+/*
+ * Result of a probe.  All arrays live in `mem` (as requested by the caller)
+ * and stay valid until cph_matches_release.
+ *
+ *   lo[i], cnt[i]   for probe row i: the matching index rows are the sorted
+ *                   positions [lo[i], lo[i]+cnt[i]).  cnt==0 means no match
+ *                   (lo is then unspecified) — the reference's
+ *                   `for i := first(values); i<n && !cmp(i,values,false); i++`
+ *                   (csvplus.go:559) runs cnt[i] times.
+ *   probe_idx[m], build_row[m]   m < nmatches: the joined pairs in the
+ *                   reference's emission order (stream order, then ascending
+ *                   index position, csvplus.go:553-567).  probe_idx is
+ *                   probe_base + the row's position in this call; build_row is
+ *                   the ORIGINAL row id of the index row (its position in the
+ *                   table handed to cph_index_build), i.e. perm[lo+j].
+ */
+typedef struct {
+    uint64_t        nprobe;
+    uint64_t        nmatches;
+    const uint32_t* lo;
+    const uint32_t* cnt;
+    const uint64_t* probe_idx;
+    const uint32_t* build_row;
+    int32_t         mem;
+    int32_t         reserved_;
+} cph_matches;
+
+/* ---- context --------------------------------------------------------------- */
+
+/* Creates a context bound to HIP device `device_id`.  Fails with
+ * CPH_ERR_NO_DEVICE when the device does not exist (there is no CPU path). */
+CPH_API int32_t cph_ctx_create(int32_t device_id, cph_ctx** out);
+CPH_API void    cph_ctx_destroy(cph_ctx* ctx);
+CPH_API const char* cph_last_error(const cph_ctx* ctx);
+
+/* All work of this ctx is enqueued on `hip_stream` (a hipStream_t; NULL = the
+ * ctx's own stream).  Lets a host framework (torch, a Go scheduler) order the
+ * library's kernels with its own copies. */
+CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
+
+/* Blocks until everything enqueued by this ctx has finished. */
+CPH_API int32_t cph_ctx_synchronize(cph_ctx* ctx);
+
+/* Pinned (page-locked) host staging memory: cgo must not hand Go-heap pointers
+ * that C retains, and pinned buffers make H2D/D2H copies asynchronous. */
+CPH_API int32_t cph_pinned_alloc(cph_ctx* ctx, size_t bytes, void** out);
+CPH_API int32_t cph_pinned_free(cph_ctx* ctx, void* p);
+
+/* ---- index build: IndexOn / UniqueIndexOn (csvplus.go:529-537, 707-756) ----- */
+
+/*
+ * Builds the sorted index over `nkeycols` key columns (all with the same
+ * nrows), leftmost column most significant.
+ *
+ *   unique != 0  mirrors createUniqueIndex: if two rows have equal keys the
+ *                call returns CPH_ERR_DUPLICATE and *first_dup_pos is the
+ *                smallest sorted position i>=1 with rows[i-1]==rows[i] on the
+ *                key columns (the pair csvplus.go:749-753 reports; the shim
+ *                formats rows[perm[i]] into the error text of :751).  The index
+ *                is still returned so the shim can read perm[i]; it must destroy
+ *                it to mirror the reference's nil return.
+ *   unique == 0  *first_dup_pos is still filled (UINT64_MAX when all keys are
+ *                distinct); duplicates are not an error.
+ *
+ * The index stays resident on the GPU (sorted key codes + permutation).
+ */
+CPH_API int32_t cph_index_build(cph_ctx* ctx, const cph_strcol* keycols, int32_t nkeycols, int32_t unique,
+                                cph_index** out, uint64_t* first_dup_pos);
+CPH_API void    cph_index_destroy(cph_index* index);
+
+/* Number of rows / key columns of the index. */
+CPH_API uint64_t cph_index_nrows(const cph_index* index);
+CPH_API int32_t  cph_index_nkeycols(const cph_index* index);
+
+/* perm[i] = original row id of the row at sorted position i.
+ * mem = CPH_MEM_HOST: copied to library-owned pinned memory on first use;
+ * mem = CPH_MEM_DEVICE: the resident device array.  Valid until destroy. */
+CPH_API int32_t cph_index_perm(cph_index* index, int32_t mem, const uint32_t** perm, uint64_t* n);
+
+/* ---- probe: Join / Except (csvplus.go:545-608) ------------------------------ */
+
+/*
+ * Probes `nprobecols` columns (1 <= nprobecols <= index key columns; fewer =
+ * prefix join on the leading index columns, matched positionally,
+ * csvplus.go:546-550, :910) against the index.
+ *
+ *   row_sel     optional (may be NULL): nsel row numbers into the probe columns,
+ *               as uint32 (sel_bits = 32) or uint64 (sel_bits = 64) values from
+ *               which sel_base is subtracted; probe row i is then row
+ *               row_sel[i] - sel_base of the columns and nprobe = nsel.  Same
+ *               memory space as the columns.  This is how a chained Join
+ *               (README.md:56) stays on the device: the second probe passes the
+ *               first join's probe_idx array (sel_bits = 64, sel_base = the first
+ *               call's probe_base) and so probes exactly the rows the first join
+ *               emitted, in emission order.
+ *   probe_base  added to the local probe position in probe_idx (global row
+ *               number of this chunk / shard's first row).
+ *   want_pairs  0: only lo/cnt/nmatches are produced (Except, counting);
+ *               1: probe_idx/build_row are expanded too.
+ *   out_mem     where the result arrays should live.
+ */
+CPH_API int32_t cph_join_probe(cph_ctx* ctx, const cph_index* index, const cph_strcol* probecols,
+                               int32_t nprobecols, const void* row_sel, int32_t sel_bits, uint64_t sel_base,
+                               uint64_t nsel, uint64_t probe_base, int32_t want_pairs, int32_t out_mem,
+                               cph_matches** out);
+CPH_API void    cph_matches_release(cph_matches* m);
+
+/* ---- Find / SubIndex bounds (csvplus.go:870-891) ----------------------------- */
+
+/* [*lower, *upper) = sorted positions whose leading key columns equal
+ * `values` (nvalues <= key columns; 0 values = the whole index). */
+CPH_API int32_t cph_index_find(cph_ctx* ctx, const cph_index* index, const cph_strval* values, int32_t nvalues,
+                               uint64_t* lower, uint64_t* upper);
+
+/* ---- introspection (for benchmarks / roofline accounting) -------------------- */
+
+typedef struct {
+    uint64_t nrows;
+    int32_t  nkeycols;
+    int32_t  key_positions;   /* total byte positions encoded (sum of per-column max length) */
+    int32_t  code_words;      /* 64-bit (or one 32-bit) words per encoded key                */
+    int32_t  code_bits;       /* significant bits of the most significant..least words, summed */
+    int32_t  key_bytes;       /* bytes per key the sort kernels move (4 or 8)                 */
+    int32_t  sort_passes;     /* radix scatter passes executed                                 */
+    int32_t  direct_table;    /* 1 when the probe uses the direct-address table                */
+    int32_t  reserved_;
+    uint64_t table_entries;   /* entries of the direct-address table (0 if none)               */
+} cph_index_info;
+
+CPH_API int32_t cph_index_get_info(const cph_index* index, cph_index_info* info);
+
+/* Library version, e.g. "csvplus_hip 0.1 (gfx950)". */
+CPH_API const char* cph_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSVPLUS_HIP_H */

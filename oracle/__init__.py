@@ -1,0 +1,5 @@
+"""CPU oracle: TEST INFRASTRUCTURE ONLY (see csvplus_oracle.c header).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this package; nothing under csvplus_amd/ does.
+"""

@@ -1,0 +1,440 @@
+/*
+ * csvplus_oracle.c — CPU restatement of csvplus's Index-build + Join path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under csvplus_amd/ (the product) may
+ * import, link or call this file; only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg use it, and only as the checker / the reported
+ * CPU baseline.
+ *
+ * Every function cites the reference lines it restates (maxim2266/csvplus,
+ * file csvplus.go unless stated otherwise).  The reference is Go and there is
+ * no Go toolchain in this image, so the reference itself cannot be executed
+ * here.  Pinning status: the oracle is checked against the reference's only
+ * literal known-answer vector (TestIndexImpl, csvplus_test.go:198-246) and
+ * against re-statements of its structural tests on fixtures of the same shape
+ * (TestSorted :454-514, TestSimpleUniqueJoin :368-452, TestMultiIndex
+ * :573-649, TestExcept :651-693, TestErrors :826-841) — see
+ * tests/test_oracle.py.  The intra-group order of rows with EQUAL keys is not
+ * pinned by any reference test (sort.Sort is unstable); the
+ * canonical order here is the stable one (input order), and
+ * ORC_SORT_GO_PDQSORT offers an emulation of Go's pdqsort written from memory
+ * of go1.19+ src/sort/zsortinterface.go, which is UNVERIFIED (parity class P2).
+ *
+ * Rows are represented SoA: one Arrow-style string column per key column.
+ * A Go `Row` (map[string]string, :59) lookup `row[col]` becomes
+ * value(col, rowid).  createIndex guarantees all key columns exist (:723-727),
+ * so "missing" never occurs on this path.
+ */
+#include <stdint.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+typedef struct {
+    const uint8_t* data;
+    const void*    offsets;
+    uint64_t       nrows;
+    int32_t        offset_bits;
+    int32_t        mem; /* layout-compatible with cph_strcol; ignored (host only) */
+} orc_strcol;
+
+typedef struct {
+    const uint8_t* data;
+    uint64_t       len;
+} orc_strval;
+
+enum { ORC_SORT_STABLE = 0, ORC_SORT_GO_PDQSORT = 1 };
+
+static inline uint64_t col_off(const orc_strcol* c, uint64_t i) {
+    return c->offset_bits == 32 ? ((const uint32_t*)c->offsets)[i] : ((const uint64_t*)c->offsets)[i];
+}
+
+static inline void col_value(const orc_strcol* c, uint64_t row, const uint8_t** p, uint64_t* len) {
+    uint64_t b = col_off(c, row), e = col_off(c, row + 1);
+    *p = c->data + b;
+    *len = e - b;
+}
+
+/* strings.Compare (Go stdlib; call sites :798, :911): unsigned bytewise
+ * lexicographic; if one is a prefix of the other the shorter is smaller. */
+static inline int go_strings_compare(const uint8_t* a, uint64_t alen, const uint8_t* b, uint64_t blen) {
+    uint64_t n = alen < blen ? alen : blen;
+    int c = n ? memcmp(a, b, (size_t)n) : 0;
+    if (c) return c < 0 ? -1 : 1;
+    return alen < blen ? -1 : (alen > blen ? 1 : 0);
+}
+
+/* ---- the sort.Interface of indexImpl (:791-807) ---------------------------- */
+
+typedef struct {
+    const orc_strcol* cols;
+    int32_t           ncols;
+    uint32_t*         rows; /* index.rows: here row ids */
+    uint64_t          less_calls;
+} orc_index_impl;
+
+/* indexImpl.Less (:794-807): column by column strings.Compare, first
+ * non-equal column decides; all equal -> false. */
+static inline int impl_less_ids(const orc_index_impl* ix, uint32_t left, uint32_t right) {
+    for (int32_t c = 0; c < ix->ncols; c++) {
+        const uint8_t *a, *b;
+        uint64_t al, bl;
+        col_value(&ix->cols[c], left, &a, &al);
+        col_value(&ix->cols[c], right, &b, &bl);
+        switch (go_strings_compare(a, al, b, bl)) {
+        case -1: return 1;
+        case 1: return 0;
+        }
+    }
+    return 0;
+}
+static inline int impl_less(orc_index_impl* ix, int64_t i, int64_t j) {
+    ix->less_calls++;
+    return impl_less_ids(ix, ix->rows[i], ix->rows[j]);
+}
+/* indexImpl.Swap (:792) */
+static inline void impl_swap(orc_index_impl* ix, int64_t i, int64_t j) {
+    uint32_t t = ix->rows[i];
+    ix->rows[i] = ix->rows[j];
+    ix->rows[j] = t;
+}
+
+/* ---- canonical stable sort: merge sort on row ids --------------------------- */
+
+static void merge_sort(orc_index_impl* ix, uint32_t* a, uint32_t* tmp, int64_t n) {
+    if (n <= 12) { /* insertion sort, stable */
+        for (int64_t i = 1; i < n; i++) {
+            uint32_t v = a[i];
+            int64_t j = i;
+            while (j > 0 && impl_less_ids(ix, v, a[j - 1])) { a[j] = a[j - 1]; j--; }
+            a[j] = v;
+        }
+        return;
+    }
+    int64_t h = n / 2;
+    merge_sort(ix, a, tmp, h);
+    merge_sort(ix, a + h, tmp, n - h);
+    if (!impl_less_ids(ix, a[h], a[h - 1])) return; /* already ordered */
+    memcpy(tmp, a, (size_t)h * sizeof(uint32_t));
+    int64_t i = 0, j = h, k = 0;
+    while (i < h && j < n) {
+        /* take from the right run only when strictly less: stability */
+        if (impl_less_ids(ix, a[j], tmp[i])) a[k++] = a[j++]; else a[k++] = tmp[i++];
+    }
+    while (i < h) a[k++] = tmp[i++];
+}
+
+/* ---- Go's sort.Sort = pdqsort (go1.19+), restated from memory: UNVERIFIED ----
+ * Call site :736 `sort.Sort(&index.impl)`.  Kept bug-for-bug as remembered
+ * (e.g. partialInsertionSort's `j >= 1` bound). */
+
+enum { HINT_UNKNOWN = 0, HINT_INCREASING = 1, HINT_DECREASING = 2 };
+
+static int bits_len(uint64_t x) { int n = 0; while (x) { n++; x >>= 1; } return n; }
+
+static void pdq_insertion_sort(orc_index_impl* d, int64_t a, int64_t b) {
+    for (int64_t i = a + 1; i < b; i++)
+        for (int64_t j = i; j > a && impl_less(d, j, j - 1); j--) impl_swap(d, j, j - 1);
+}
+static void pdq_sift_down(orc_index_impl* d, int64_t lo, int64_t hi, int64_t first) {
+    int64_t root = lo;
+    for (;;) {
+        int64_t child = 2 * root + 1;
+        if (child >= hi) return;
+        if (child + 1 < hi && impl_less(d, first + child, first + child + 1)) child++;
+        if (!impl_less(d, first + root, first + child)) return;
+        impl_swap(d, first + root, first + child);
+        root = child;
+    }
+}
+static void pdq_heap_sort(orc_index_impl* d, int64_t a, int64_t b) {
+    int64_t first = a, lo = 0, hi = b - a;
+    for (int64_t i = (hi - 1) / 2; i >= 0; i--) pdq_sift_down(d, i, hi, first);
+    for (int64_t i = hi - 1; i >= 0; i--) {
+        impl_swap(d, first, first + i);
+        pdq_sift_down(d, lo, i, first);
+    }
+}
+static void pdq_break_patterns(orc_index_impl* d, int64_t a, int64_t b) {
+    int64_t length = b - a;
+    if (length >= 8) {
+        uint64_t random = (uint64_t)length;
+        uint64_t modulus = (uint64_t)1 << bits_len((uint64_t)length);
+        int64_t idx = a + (length / 4) * 2 - 1;
+        for (int i = 0; i < 3; i++) {
+            random ^= random << 13;
+            random ^= random >> 7;
+            random ^= random << 17;
+            int64_t other = (int64_t)(random & (modulus - 1));
+            if (other >= length) other -= length;
+            impl_swap(d, idx - 1 + i, a + other);
+        }
+    }
+}
+static void pdq_order2(orc_index_impl* d, int64_t* a, int64_t* b, int* swaps) {
+    if (impl_less(d, *b, *a)) {
+        (*swaps)++;
+        int64_t t = *a; *a = *b; *b = t;
+    }
+}
+static int64_t pdq_median(orc_index_impl* d, int64_t a, int64_t b, int64_t c, int* swaps) {
+    pdq_order2(d, &a, &b, swaps);
+    pdq_order2(d, &b, &c, swaps);
+    pdq_order2(d, &a, &b, swaps);
+    return b;
+}
+static int64_t pdq_choose_pivot(orc_index_impl* d, int64_t a, int64_t b, int* hint) {
+    int64_t l = b - a;
+    int swaps = 0;
+    int64_t i = a + l / 4 * 1, j = a + l / 4 * 2, k = a + l / 4 * 3;
+    if (l >= 8) {
+        if (l >= 50) {
+            i = pdq_median(d, i - 1, i, i + 1, &swaps);
+            j = pdq_median(d, j - 1, j, j + 1, &swaps);
+            k = pdq_median(d, k - 1, k, k + 1, &swaps);
+        }
+        j = pdq_median(d, i, j, k, &swaps);
+    }
+    *hint = swaps == 0 ? HINT_INCREASING : (swaps == 12 ? HINT_DECREASING : HINT_UNKNOWN);
+    return j;
+}
+static void pdq_reverse_range(orc_index_impl* d, int64_t a, int64_t b) {
+    int64_t i = a, j = b - 1;
+    while (i < j) { impl_swap(d, i, j); i++; j--; }
+}
+static int pdq_partial_insertion_sort(orc_index_impl* d, int64_t a, int64_t b) {
+    int64_t i = a + 1;
+    for (int step = 0; step < 5; step++) {
+        while (i < b && !impl_less(d, i, i - 1)) i++;
+        if (i == b) return 1;
+        if (b - a < 50) return 0;
+        impl_swap(d, i, i - 1);
+        if (i - a >= 2)
+            for (int64_t j = i - 1; j >= 1; j--) {
+                if (!impl_less(d, j, j - 1)) break;
+                impl_swap(d, j, j - 1);
+            }
+        if (b - i >= 2)
+            for (int64_t j = i + 1; j < b; j++) {
+                if (!impl_less(d, j, j - 1)) break;
+                impl_swap(d, j, j - 1);
+            }
+    }
+    return 0;
+}
+static int64_t pdq_partition_equal(orc_index_impl* d, int64_t a, int64_t b, int64_t pivot) {
+    impl_swap(d, a, pivot);
+    int64_t i = a + 1, j = b - 1;
+    for (;;) {
+        while (i <= j && !impl_less(d, a, i)) i++;
+        while (i <= j && impl_less(d, a, j)) j--;
+        if (i > j) break;
+        impl_swap(d, i, j);
+        i++; j--;
+    }
+    return i;
+}
+static int64_t pdq_partition(orc_index_impl* d, int64_t a, int64_t b, int64_t pivot, int* already) {
+    impl_swap(d, a, pivot);
+    int64_t i = a + 1, j = b - 1;
+    while (i <= j && impl_less(d, i, a)) i++;
+    while (i <= j && !impl_less(d, j, a)) j--;
+    if (i > j) {
+        impl_swap(d, j, a);
+        *already = 1;
+        return j;
+    }
+    impl_swap(d, i, j);
+    i++; j--;
+    for (;;) {
+        while (i <= j && impl_less(d, i, a)) i++;
+        while (i <= j && !impl_less(d, j, a)) j--;
+        if (i > j) break;
+        impl_swap(d, i, j);
+        i++; j--;
+    }
+    impl_swap(d, j, a);
+    *already = 0;
+    return j;
+}
+static void pdqsort(orc_index_impl* d, int64_t a, int64_t b, int limit) {
+    int was_balanced = 1, was_partitioned = 1;
+    for (;;) {
+        int64_t length = b - a;
+        if (length <= 12) { pdq_insertion_sort(d, a, b); return; }
+        if (limit == 0) { pdq_heap_sort(d, a, b); return; }
+        if (!was_balanced) { pdq_break_patterns(d, a, b); limit--; }
+        int hint;
+        int64_t pivot = pdq_choose_pivot(d, a, b, &hint);
+        if (hint == HINT_DECREASING) {
+            pdq_reverse_range(d, a, b);
+            pivot = (b - 1) - (pivot - a);
+            hint = HINT_INCREASING;
+        }
+        if (was_balanced && was_partitioned && hint == HINT_INCREASING)
+            if (pdq_partial_insertion_sort(d, a, b)) return;
+        if (a > 0 && !impl_less(d, a - 1, pivot)) {
+            a = pdq_partition_equal(d, a, b, pivot);
+            continue;
+        }
+        int already;
+        int64_t mid = pdq_partition(d, a, b, pivot, &already);
+        was_partitioned = already;
+        int64_t left_len = mid - a, right_len = b - mid;
+        int64_t balance_threshold = length / 8;
+        if (left_len < right_len) {
+            was_balanced = left_len >= balance_threshold;
+            pdqsort(d, a, mid, limit);
+            a = mid + 1;
+        } else {
+            was_balanced = right_len >= balance_threshold;
+            pdqsort(d, mid + 1, b, limit);
+            b = mid;
+        }
+    }
+}
+
+/* ---- createIndex (:707-738): drain rows, sort.Sort ---------------------------
+ * perm[i] = original row id of the row at sorted position i.  Returns the
+ * number of Less calls (cost-model statistic), or UINT64_MAX on error. */
+ORC_API uint64_t orc_index_build(const orc_strcol* cols, int32_t ncols, int32_t mode, uint32_t* perm) {
+    if (!cols || ncols <= 0 || !perm) return UINT64_MAX;
+    const uint64_t n = cols[0].nrows;
+    if (n > 0xFFFFFFFFull) return UINT64_MAX;
+    orc_index_impl ix = {cols, ncols, perm, 0};
+    for (uint64_t i = 0; i < n; i++) perm[i] = (uint32_t)i; /* :729 append in stream order */
+    if (n <= 1) return 0; /* sort.Sort: n <= 1 returns */
+    if (mode == ORC_SORT_GO_PDQSORT) {
+        pdqsort(&ix, 0, (int64_t)n, bits_len(n));
+    } else {
+        uint32_t* tmp = (uint32_t*)malloc((size_t)(n / 2 + 1) * sizeof(uint32_t));
+        if (!tmp) return UINT64_MAX;
+        merge_sort(&ix, perm, tmp, (int64_t)n);
+        free(tmp);
+    }
+    return ix.less_calls;
+}
+
+/* equalRows (:759-767) on two row ids */
+static inline int equal_rows(const orc_strcol* cols, int32_t ncols, uint32_t r1, uint32_t r2) {
+    for (int32_t c = 0; c < ncols; c++) {
+        const uint8_t *a, *b;
+        uint64_t al, bl;
+        col_value(&cols[c], r1, &a, &al);
+        col_value(&cols[c], r2, &b, &bl);
+        if (al != bl || (al && memcmp(a, b, (size_t)al))) return 0;
+    }
+    return 1;
+}
+
+/* createUniqueIndex adjacent scan (:742-753): first i>=1 with
+ * rows[i-1]==rows[i]; UINT64_MAX when none (or fewer than 2 rows). */
+ORC_API uint64_t orc_first_dup(const orc_strcol* cols, int32_t ncols, const uint32_t* perm) {
+    const uint64_t n = cols[0].nrows;
+    for (uint64_t i = 1; i < n; i++)
+        if (equal_rows(cols, ncols, perm[i - 1], perm[i])) return i;
+    return UINT64_MAX;
+}
+
+/* ---- indexImpl.cmp / first / has / find (:893-920, :870-891) ----------------- */
+
+/* cmp (:907-920): row i's first nvalues key columns vs values:
+ * 1 if greater, 0 if less, eq if equal. */
+static inline int impl_cmp(const orc_strcol* cols, const uint32_t* perm, uint64_t i, const orc_strval* values,
+                           int32_t nvalues, int eq) {
+    const uint32_t row = perm[i];
+    for (int32_t j = 0; j < nvalues; j++) {
+        const uint8_t* a;
+        uint64_t al;
+        col_value(&cols[j], row, &a, &al);
+        switch (go_strings_compare(a, al, values[j].data, values[j].len)) {
+        case 1: return 1;
+        case -1: return 0;
+        }
+    }
+    return eq;
+}
+
+/* sort.Search (Go stdlib; call sites :831, :881, :885, :894):
+ * smallest i in [0,n) with f(i) true, else n. */
+#define GO_SORT_SEARCH(result, n_, pred)          \
+    do {                                          \
+        uint64_t i_ = 0, j_ = (n_);               \
+        while (i_ < j_) {                         \
+            uint64_t h = (i_ + j_) >> 1;          \
+            if (!(pred)) i_ = h + 1; else j_ = h; \
+        }                                         \
+        (result) = i_;                            \
+    } while (0)
+
+/* first (:893-897) */
+static inline uint64_t impl_first(const orc_strcol* cols, const uint32_t* perm, uint64_t n, const orc_strval* values,
+                                  int32_t nvalues) {
+    uint64_t r;
+    GO_SORT_SEARCH(r, n, impl_cmp(cols, perm, h, values, nvalues, 1));
+    return r;
+}
+
+/* find (:870-891): [lower, upper) */
+ORC_API void orc_find(const orc_strcol* cols, const uint32_t* perm, const orc_strval* values, int32_t nvalues,
+                      uint64_t* lower, uint64_t* upper) {
+    const uint64_t n = cols[0].nrows;
+    if (nvalues == 0) { *lower = 0; *upper = n; return; } /* :872-874 */
+    uint64_t up, lo;
+    GO_SORT_SEARCH(up, n, impl_cmp(cols, perm, h, values, nvalues, 0));  /* :881 */
+    GO_SORT_SEARCH(lo, up, impl_cmp(cols, perm, h, values, nvalues, 1)); /* :885 */
+    *lower = lo;
+    *upper = up;
+}
+
+/* has (:899-905) */
+ORC_API int32_t orc_has(const orc_strcol* cols, const uint32_t* perm, const orc_strval* values, int32_t nvalues) {
+    const uint64_t n = cols[0].nrows;
+    uint64_t i = impl_first(cols, perm, n, values, nvalues);
+    return i < n && !impl_cmp(cols, perm, i, values, nvalues, 0);
+}
+
+/* ---- Join (:545-569) ------------------------------------------------------------
+ * For each probe row (stream order): values = SelectValues(columns) (:556),
+ * i = first(values) (:559), emit while i<n && !cmp(i,values,false).
+ *
+ * lo/cnt (nprobe entries each, may be NULL) receive first() and the number of
+ * loop iterations.  If probe_idx/build_row are non-NULL they receive up to
+ * cap pairs in emission order.  Returns the total number of matches.
+ * row_sel (optional) selects probe rows; probe_base offsets probe_idx.
+ */
+ORC_API uint64_t orc_join(const orc_strcol* bcols, int32_t nbcols, const uint32_t* perm, const orc_strcol* pcols,
+                          int32_t npcols, const uint32_t* row_sel, uint64_t nsel, uint64_t probe_base, uint32_t* lo,
+                          uint32_t* cnt, uint64_t* probe_idx, uint32_t* build_row, uint64_t cap) {
+    (void)nbcols;
+    const uint64_t n = bcols[0].nrows;
+    const uint64_t nprobe = row_sel ? nsel : pcols[0].nrows;
+    uint64_t total = 0;
+    orc_strval values[64];
+    for (uint64_t p = 0; p < nprobe; p++) {
+        const uint64_t prow = row_sel ? row_sel[p] : p;
+        for (int32_t c = 0; c < npcols; c++) col_value(&pcols[c], prow, &values[c].data, &values[c].len);
+        uint64_t first = impl_first(bcols, perm, n, values, npcols);
+        uint64_t i = first;
+        for (; i < n && !impl_cmp(bcols, perm, i, values, npcols, 0); i++) {
+            if (probe_idx && total < cap) {
+                probe_idx[total] = probe_base + p;
+                build_row[total] = perm[i];
+            }
+            total++;
+        }
+        if (lo) lo[p] = (uint32_t)first;
+        if (cnt) cnt[p] = (uint32_t)(i - first);
+    }
+    return total;
+}
+
+/* ---- digest used by parity tests (FNV-1a 64 over raw bytes) ------------------- */
+ORC_API uint64_t orc_fnv1a64(const void* p, uint64_t nbytes, uint64_t h) {
+    const uint8_t* b = (const uint8_t*)p;
+    if (h == 0) h = 0xCBF29CE484222325ull;
+    for (uint64_t i = 0; i < nbytes; i++) { h ^= b[i]; h *= 0x100000001B3ull; }
+    return h;
+}

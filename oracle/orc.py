@@ -1,0 +1,144 @@
+"""ctypes wrapper of oracle/csvplus_oracle.c (the CPU restatement of the reference).
+
+TEST INFRASTRUCTURE ONLY — the checker, never the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_DIR = Path(__file__).resolve().parent
+LIB_PATH = _DIR / "_build" / "liboracle.so"
+SORT_STABLE, SORT_GO_PDQSORT = 0, 1
+UINT64_MAX = 0xFFFFFFFFFFFFFFFF
+
+
+class orc_strcol(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("offsets", C.c_void_p), ("nrows", C.c_uint64), ("offset_bits", C.c_int32),
+                ("mem", C.c_int32)]
+
+
+class orc_strval(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("len", C.c_uint64)]
+
+
+_lib = None
+
+
+def build():
+    """gcc-compiles the C restatement (no GPU needed)."""
+    src = _DIR / "csvplus_oracle.c"
+    if LIB_PATH.exists() and LIB_PATH.stat().st_mtime >= src.stat().st_mtime:
+        return
+    LIB_PATH.parent.mkdir(exist_ok=True)
+    subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", str(src), "-o",
+                           str(LIB_PATH)])
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            build()
+        lib = C.CDLL(str(LIB_PATH))
+        P = C.c_void_p
+        lib.orc_index_build.restype = C.c_uint64
+        lib.orc_index_build.argtypes = [C.POINTER(orc_strcol), C.c_int32, C.c_int32, P]
+        lib.orc_first_dup.restype = C.c_uint64
+        lib.orc_first_dup.argtypes = [C.POINTER(orc_strcol), C.c_int32, P]
+        lib.orc_find.restype = None
+        lib.orc_find.argtypes = [C.POINTER(orc_strcol), P, C.POINTER(orc_strval), C.c_int32, C.POINTER(C.c_uint64),
+                                 C.POINTER(C.c_uint64)]
+        lib.orc_has.restype = C.c_int32
+        lib.orc_has.argtypes = [C.POINTER(orc_strcol), P, C.POINTER(orc_strval), C.c_int32]
+        lib.orc_join.restype = C.c_uint64
+        lib.orc_join.argtypes = [C.POINTER(orc_strcol), C.c_int32, P, C.POINTER(orc_strcol), C.c_int32, P, C.c_uint64,
+                                 C.c_uint64, P, P, P, P, C.c_uint64]
+        lib.orc_fnv1a64.restype = C.c_uint64
+        lib.orc_fnv1a64.argtypes = [P, C.c_uint64, C.c_uint64]
+        _lib = lib
+    return _lib
+
+
+def _cols(cols):
+    arr = (orc_strcol * len(cols))()
+    keep = []
+    for i, c in enumerate(cols):
+        data = np.ascontiguousarray(c.data)
+        offs = np.ascontiguousarray(c.offsets)
+        arr[i].data = data.ctypes.data if data.size else None
+        arr[i].offsets = offs.ctypes.data
+        arr[i].nrows = c.nrows
+        arr[i].offset_bits = c.offset_bits
+        arr[i].mem = 0
+        keep.append((data, offs))
+    return arr, keep
+
+
+def _vals(values):
+    arr = (orc_strval * max(1, len(values)))()
+    keep = []
+    for i, v in enumerate(values):
+        b = np.frombuffer(v.encode() if isinstance(v, str) else bytes(v), dtype=np.uint8)
+        keep.append(b)
+        arr[i].data = b.ctypes.data if len(b) else None
+        arr[i].len = len(b)
+    return arr, keep
+
+
+class OracleIndex:
+    """createIndex / createUniqueIndex (csvplus.go:707-756) over SoA key columns."""
+
+    def __init__(self, keycols, mode: int = SORT_STABLE):
+        self.cols = list(keycols)
+        self.n = self.cols[0].nrows
+        self._arr, self._keep = _cols(self.cols)
+        self.perm = np.empty(self.n, dtype=np.uint32)
+        self.less_calls = int(_load().orc_index_build(self._arr, len(self.cols), mode, self.perm.ctypes.data))
+        if self.less_calls == UINT64_MAX:
+            raise RuntimeError("orc_index_build failed")
+
+    def first_dup(self):
+        r = int(_load().orc_first_dup(self._arr, len(self.cols), self.perm.ctypes.data))
+        return None if r == UINT64_MAX else r
+
+    def find(self, *values):
+        v, keep = _vals(values)
+        lo, hi = C.c_uint64(), C.c_uint64()
+        _load().orc_find(self._arr, self.perm.ctypes.data, v, len(values), C.byref(lo), C.byref(hi))
+        return int(lo.value), int(hi.value)
+
+    def has(self, *values) -> bool:
+        v, keep = _vals(values)
+        return bool(_load().orc_has(self._arr, self.perm.ctypes.data, v, len(values)))
+
+    def join(self, probecols, row_sel=None, probe_base: int = 0, want_pairs: bool = True):
+        """Join (csvplus.go:545-569): returns dict(lo, cnt, probe_idx, build_row, nmatches)."""
+        parr, pkeep = _cols(probecols)
+        nprobe = len(row_sel) if row_sel is not None else probecols[0].nrows
+        sel = None
+        if row_sel is not None:
+            sel = np.ascontiguousarray(row_sel, dtype=np.uint32)
+        lo = np.empty(nprobe, dtype=np.uint32)
+        cnt = np.empty(nprobe, dtype=np.uint32)
+        lib = _load()
+        total = int(lib.orc_join(self._arr, len(self.cols), self.perm.ctypes.data, parr, len(probecols),
+                                 sel.ctypes.data if sel is not None else None, nprobe, probe_base, lo.ctypes.data,
+                                 cnt.ctypes.data, None, None, 0))
+        out = {"lo": lo, "cnt": cnt, "nmatches": total, "probe_idx": None, "build_row": None}
+        if want_pairs:
+            pidx = np.empty(total, dtype=np.uint64)
+            brow = np.empty(total, dtype=np.uint32)
+            lib.orc_join(self._arr, len(self.cols), self.perm.ctypes.data, parr, len(probecols),
+                         sel.ctypes.data if sel is not None else None, nprobe, probe_base, None, None,
+                         pidx.ctypes.data, brow.ctypes.data, total)
+            out["probe_idx"], out["build_row"] = pidx, brow
+        return out
+
+
+def fnv1a64(arr: np.ndarray, h: int = 0) -> int:
+    a = np.ascontiguousarray(arr)
+    return int(_load().orc_fnv1a64(a.ctypes.data, a.nbytes, h))
