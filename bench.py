@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py — the hot path on synthetic tables, one JSON line on rank 0.
+
+A "step" = one pass of the hot path over one batch, BASELINE.json's headline shape
+("10^8-row 3-col join"; configs[3] at one GPU): with all staged columns already
+resident in HBM,
+
+    customers.UniqueIndexOn("id")        (1e7 rows, 8-byte ids)      cph_index_build
+    products.UniqueIndexOn("prod_id")    (1e5 rows)                  cph_index_build
+    orders.Join(customers,"cust_id").Join(products,"prod_id")       cph_join_probe x2
+        over 1e8 orders rows x 3 string columns (cust_id, prod_id, qty)
+
+and, for N > 1, the probe rows are split into N contiguous ranges (strong scaling:
+the 1e8 rows are fixed), the build side is replicated, and the joined row-id triples are
+allgatherv'ed over RCCL so that every rank holds the whole list in emission order.
+
+value = joined rows per second of the whole job (max over ranks of the step time).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rows", type=int, default=100_000_000, help="orders (probe) rows, whole job")
+    ap.add_argument("--customers", type=int, default=10_000_000)
+    ap.add_argument("--products", type=int, default=100_000)
+    ap.add_argument("--exchange", choices=["allgatherv", "none"], default="allgatherv")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=4_000_000)
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from csvplus_amd import _native as N, datagen as dg
+    from csvplus_amd.dist import allgatherv
+    from csvplus_amd.engine import Engine, shard_range
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local_rank)
+    eng = Engine(local_rank)
+
+    # ---- synthetic tables (deterministic), staged to HBM before timing ------------
+    t0 = time.time()
+    begin, end = shard_range(args.rows, rank, world)
+    cust_id = dg.column(dg.SEQ_PERM, args.customers, args.customers, encoding=dg.FIXED8, seed=dg.SEED + 1)
+    prod_id = dg.column(dg.SEQ_PERM, args.products, args.products, encoding=dg.ITOA, seed=dg.SEED + 2)
+    ords = dg.orders(args.rows, args.customers, args.products, row0=begin, nrows=end - begin)
+    host_bytes = {k: v.nbytes_values() for k, v in ords.items()}
+    d_cust, d_prod = cust_id.to_device(dev), prod_id.to_device(dev)
+    d_ord = {k: v.to_device(dev) for k, v in ords.items()}   # all 3 columns live in HBM; qty rides along
+    torch.cuda.synchronize(dev)
+    gen_s = time.time() - t0
+    nloc = end - begin
+
+    def step():
+        ia = eng.index_on([d_cust], unique=True)
+        ib = eng.index_on([d_prod], unique=True)
+        res = eng.chained_join(ia, d_ord["cust_id"], ib, d_ord["prod_id"], probe_base=begin)
+        out = (res.stream_row, res.a_row, res.b_row)
+        if world > 1 and args.exchange == "allgatherv":
+            out = tuple(allgatherv(t)[0] for t in out)
+        n = int(out[0].numel())
+        info = (ia.info(), ib.info())
+        for m in res.keep:
+            m.release()
+        ia.close()
+        ib.close()
+        return n, info
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    eng.ctx.profile(True)
+    eng.ctx.profile_read(reset=True)
+    sync_all()
+    t0 = time.perf_counter()
+    joined = 0
+    for _ in range(args.steps):
+        n, info = step()
+        joined = n
+    sync_all()
+    dt = time.perf_counter() - t0
+    prof = eng.ctx.profile_read(reset=True)
+    eng.ctx.profile(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    total_joined = joined if (world == 1 or args.exchange == "allgatherv") else None
+    if total_joined is None:
+        t = torch.tensor([joined], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        total_joined = int(t.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = dt / args.steps * 1e3
+    value = total_joined / (dt / args.steps)
+
+    # ---- per-kernel roofline (HIP events recorded by the library on the ctx stream) -------------
+    # algorithmic bytes the library cannot know (value bytes of the input columns) are added here;
+    # the model is documented in DESIGN.md §"Algorithmic bytes".
+    ia_info, ib_info = info
+    K = args.steps
+    obytes = 4
+    cust_bytes, prod_bytes = cust_id.nbytes_values(), prod_id.nbytes_values()
+    extra = {
+        "k_col_stats": K * ((cust_bytes + obytes * args.customers) + (prod_bytes + obytes * args.products)),
+        "k_encode_build": K * ((cust_bytes + obytes * args.customers + ia_info["key_bytes"] * args.customers)
+                               + (prod_bytes + obytes * args.products + ib_info["key_bytes"] * args.products)),
+        # probe: key bytes + offset + 8-byte table entry + (lo,cnt) out; the chained probe also reads
+        # its 8-byte row selection
+        "k_probe_table": K * ((host_bytes["cust_id"] + obytes * nloc + 16 * nloc)
+                              + (host_bytes["prod_id"] + obytes * nloc + 16 * nloc + 8 * nloc)),
+    }
+    kernels = {}
+    for name, st in prof.items():
+        b = st["algo_bytes"] + extra.get(name, 0.0)
+        kernels[name] = {"launches": st["launches"], "total_ms": round(st["total_ms"], 4),
+                         "avg_ms": round(st["total_ms"] / max(1, st["launches"]), 5),
+                         "algo_GB": round(b / 1e9, 4),
+                         "GBps": round(b / 1e9 / (st["total_ms"] / 1e3), 1) if st["total_ms"] > 0 else None}
+    dom = max(kernels.items(), key=lambda kv: kv[1]["total_ms"]) if kernels else (None, None)
+    roofline = None
+    if dom[0]:
+        a = dom[1]["GBps"] or 0.0
+        roofline = {"bound": "hbm", "kernel": dom[0], "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(a / HBM_PEAK_GBPS, 4), "traffic": None,
+                    "avg_launch_ms": dom[1]["avg_ms"], "launches": dom[1]["launches"]}
+    build_names = ("k_col_stats", "k_encode_build", "k_radix_hist_u32", "k_radix_hist_u64", "k_radix_scatter_u32",
+                   "k_radix_scatter_u64", "exclusive_scan_u32", "k_first_dup", "k_build_table", "k_gather_u64")
+    build_ms = sum(kernels[k]["total_ms"] for k in build_names if k in kernels)
+    build_gb = sum(kernels[k]["algo_GB"] for k in build_names if k in kernels)
+    kernel_ms = sum(v["total_ms"] for v in kernels.values())
+
+    out = {
+        "metric": "joined rows/sec (IndexOn build + chained Join, 1e8-row 3-col orders)",
+        "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u8 keys -> u32 codes", "data": "synthetic",
+        "config": {"workload": "orders(1e8 x {cust_id,prod_id,qty}) JOIN customers(1e7, UniqueIndexOn id) "
+                               "JOIN products(1e5, UniqueIndexOn prod_id); configs[3] shape on 1 GPU",
+                   "rows": args.rows, "customers": args.customers, "products": args.products,
+                   "rows_this_rank": nloc, "exchange": args.exchange if world > 1 else "none (1 GPU)",
+                   "inputs": "resident in HBM before the timed region"},
+        "joined_rows_per_step": total_joined,
+        "index_build": {"GBps_algorithmic": round(build_gb / (build_ms / 1e3), 1) if build_ms else None,
+                        "kernel_ms_per_step": round(build_ms / K, 4),
+                        "customers": ia_info, "products": ib_info},
+        "kernel_ms_per_step": round(kernel_ms / K, 4),
+        "kernels": kernels,
+        "roofline": roofline,
+        "host": {"nproc": os.cpu_count(), "gpu": torch.cuda.get_device_name(dev), "datagen_s": round(gen_s, 1)},
+    }
+
+    # ---- CPU baseline: the oracle (C restatement of the reference), bounded sample ----------------
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import orc
+
+        ns = min(args.cpu_sample_rows, nloc)
+        s_cust = ords["cust_id"].slice(0, ns)
+        s_prod = ords["prod_id"].slice(0, ns)
+        t0 = time.perf_counter()
+        oa = orc.OracleIndex([cust_id])
+        ob = orc.OracleIndex([prod_id])
+        assert oa.first_dup() is None and ob.first_dup() is None
+        t_build = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        j1 = oa.join([s_cust])
+        sel = j1["probe_idx"].astype(np.uint32)
+        j2 = ob.join([s_prod], row_sel=sel)
+        t_probe = time.perf_counter() - t0
+        est = t_build + t_probe * (args.rows / ns)
+        out["cpu_baseline"] = {
+            "value": args.rows / est, "unit": "rows/s", "cores": 1, "kind": "port",
+            "sample": f"oracle (C restatement, SoA strings, comparison sort + binary-search probe; 1 thread): both "
+                      f"index builds in full ({t_build:.2f} s) + chained probe of the first {ns} of {args.rows} "
+                      f"orders rows ({t_probe:.2f} s, {j2['nmatches']} joined), probe time scaled to all rows",
+            "build_s": round(t_build, 3), "probe_sample_s": round(t_probe, 3),
+        }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from pathlib import Path
 
 import numpy as np
@@ -95,6 +96,11 @@ class cph_index_info(C.Structure):
     ]
 
 
+class cph_kernel_stat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double),
+                ("algo_bytes", C.c_double)]
+
+
 # every symbol include/csvplus_hip.h declares: (name, restype, argtypes)
 _P = C.c_void_p
 PROTOTYPES = [
@@ -104,6 +110,9 @@ PROTOTYPES = [
     ("cph_last_error", C.c_char_p, [_P]),
     ("cph_ctx_set_stream", C.c_int32, [_P, _P]),
     ("cph_ctx_synchronize", C.c_int32, [_P]),
+    ("cph_ctx_profile", C.c_int32, [_P, C.c_int32]),
+    ("cph_ctx_profile_read", C.c_int32,
+     [_P, C.POINTER(cph_kernel_stat), C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
     ("cph_pinned_alloc", C.c_int32, [_P, C.c_size_t, C.POINTER(_P)]),
     ("cph_pinned_free", C.c_int32, [_P, _P]),
     ("cph_index_build", C.c_int32,
@@ -134,6 +143,14 @@ def load_library() -> C.CDLL:
         raise NativeLibraryMissing(
             f"{path} not found: build it with `make hip` (or `python -c 'import __graft_entry__ as g; g.build()'`). "
             "csvplus_amd has no CPU fallback.")
+    # One HIP runtime per process: torch ships its own libamdhip64.so (same SONAME as
+    # /opt/rocm's).  If ours were loaded first, torch would later bind to the ROCm-tree copy
+    # and fail with "No HIP GPUs are available".  Importing torch first makes our DT_NEEDED
+    # entry resolve to the copy torch already loaded, so device pointers can be shared.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(str(path))
     for name, restype, argtypes in PROTOTYPES:
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
@@ -164,9 +181,12 @@ class Context:
                                "(csvplus_amd has no CPU fallback)")
         self.handle = h
         self.device = device
+        self._children = weakref.WeakSet()   # indexes / matches: they borrow the ctx's device pool
 
     def close(self):
         if getattr(self, "handle", None):
+            for child in list(self._children):   # library rule: release indexes and matches before the ctx
+                child.close()
             self.lib.cph_ctx_destroy(self.handle)
             self.handle = None
 
@@ -188,6 +208,18 @@ class Context:
 
     def last_error(self) -> str:
         return (self.lib.cph_last_error(self.handle) or b"").decode("utf-8", "replace")
+
+    def profile(self, enable: bool = True):
+        self._check(self.lib.cph_ctx_profile(self.handle, 1 if enable else 0))
+
+    def profile_read(self, reset: bool = True) -> dict:
+        """{kernel name: {launches, total_ms, algo_bytes}} measured with HIP events on the ctx stream."""
+        cap = 64
+        arr = (cph_kernel_stat * cap)()
+        n = C.c_int32()
+        self._check(self.lib.cph_ctx_profile_read(self.handle, arr, cap, C.byref(n), 1 if reset else 0))
+        return {arr[i].name.decode(): {"launches": int(arr[i].launches), "total_ms": float(arr[i].total_ms),
+                                       "algo_bytes": float(arr[i].algo_bytes)} for i in range(min(cap, n.value))}
 
 
 def _cols_array(cols):
@@ -212,6 +244,7 @@ class DeviceIndex:
         rc = self.lib.cph_index_build(ctx.handle, arr, len(keycols), 1 if unique else 0, C.byref(h), C.byref(dup))
         del keep
         self.handle = h if h.value else None
+        ctx._children.add(self)
         self.first_dup = None if dup.value == UINT64_MAX else int(dup.value)
         self.status = rc
         if rc not in (CPH_OK, CPH_ERR_DUPLICATE):
@@ -242,17 +275,19 @@ class DeviceIndex:
         return {k: int(getattr(inf, k)) for k, _ in cph_index_info._fields_ if k != "reserved_"}
 
     def probe(self, probecols, row_sel=None, probe_base: int = 0, want_pairs: bool = True,
-              out_mem: int = CPH_MEM_HOST) -> "Matches":
+              out_mem: int = CPH_MEM_HOST, sel_base: int = 0) -> "Matches":
+        """cph_join_probe.  row_sel: numpy uint32/uint64 array (host columns) or a tuple
+        (device_ptr, bits, count) (device columns); sel_base is subtracted from every entry."""
         arr, keep = _cols_array(probecols)
-        sel_ptr, sel_bits, sel_base, nsel = _P(0), 32, 0, 0
+        sel_ptr, sel_bits, nsel = _P(0), 32, 0
         if row_sel is not None:
             if isinstance(row_sel, np.ndarray):
                 if row_sel.dtype != np.uint64:
                     row_sel = np.ascontiguousarray(row_sel, dtype=np.uint32)
                 row_sel = np.ascontiguousarray(row_sel)
                 sel_ptr, sel_bits, nsel = _P(row_sel.ctypes.data), row_sel.dtype.itemsize * 8, len(row_sel)
-            else:  # (device pointer, bits, base, count)
-                sel_ptr, sel_bits, sel_base, nsel = _P(row_sel[0]), int(row_sel[1]), int(row_sel[2]), int(row_sel[3])
+            else:  # (device pointer, bits, count)
+                sel_ptr, sel_bits, nsel = _P(row_sel[0]), int(row_sel[1]), int(row_sel[2])
         out = C.POINTER(cph_matches)()
         rc = self.lib.cph_join_probe(self.ctx.handle, self.handle, arr, len(probecols), sel_ptr, sel_bits, sel_base,
                                      nsel, probe_base, 1 if want_pairs else 0, out_mem, C.byref(out))
@@ -292,6 +327,8 @@ class Matches:
         self.lib = lib
         self.ptr = ptr
         self.owner = owner  # keeps the index (and its ctx) alive: the arrays come from the ctx's pool
+        if owner is not None:
+            owner.ctx._children.add(self)
         m = ptr.contents
         self.nprobe = int(m.nprobe)
         self.nmatches = int(m.nmatches)
@@ -325,6 +362,8 @@ class Matches:
         if self.ptr:
             self.lib.cph_matches_release(self.ptr)
             self.ptr = None
+
+    close = release
 
     def __del__(self):
         try:

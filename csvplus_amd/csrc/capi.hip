@@ -85,6 +85,45 @@ Status ensure_pinned_scratch(cph_ctx* ctx, size_t bytes) {
     return {};
 }
 
+// ---- per-kernel timing --------------------------------------------------------------------------
+ProfScope::ProfScope(cph_ctx* ctx, const char* name, double bytes) : ctx_(ctx), bytes_(bytes) {
+    if (!ctx->profiling) return;
+    for (size_t i = 0; i < ctx->prof_stats.size(); i++)
+        if (ctx->prof_stats[i].name == name) { idx_ = (int)i; break; }
+    if (idx_ < 0) {
+        ProfStat st;
+        st.name = name;
+        ctx->prof_stats.push_back(st);
+        idx_ = (int)ctx->prof_stats.size() - 1;
+    }
+    auto get_event = [&]() -> hipEvent_t {
+        if (!ctx->prof_free_events.empty()) {
+            hipEvent_t e = ctx->prof_free_events.back();
+            ctx->prof_free_events.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    };
+    start_ = get_event();
+    if (start_) (void)hipEventRecord(start_, ctx->stream);
+}
+
+ProfScope::~ProfScope() {
+    if (!ctx_->profiling || !start_) return;
+    hipEvent_t stop = nullptr;
+    if (!ctx_->prof_free_events.empty()) {
+        stop = ctx_->prof_free_events.back();
+        ctx_->prof_free_events.pop_back();
+    } else if (hipEventCreate(&stop) != hipSuccess) {
+        stop = nullptr;
+    }
+    if (!stop) { ctx_->prof_free_events.push_back(start_); return; }
+    (void)hipEventRecord(stop, ctx_->stream);
+    ctx_->prof_pending.push_back(ProfPending{idx_, start_, stop, bytes_});
+}
+
 // ---- staging ----------------------------------------------------------------------------------
 static Status validate_cols(const cph_strcol* cols, int32_t ncols) {
     if (!cols || ncols <= 0) return {CPH_ERR_INVALID, "no key columns"};
@@ -272,6 +311,8 @@ CPH_API void cph_ctx_destroy(cph_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->pinned_scratch) (void)hipHostFree(ctx->pinned_scratch);
     for (void* p : ctx->pinned_user) (void)hipHostFree(p);
+    for (auto& p : ctx->prof_pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
+    for (hipEvent_t e : ctx->prof_free_events) (void)hipEventDestroy(e);
     hipStream_t own = ctx->own_stream ? ctx->stream : nullptr;
     ctx->pool.trim();
     if (own) (void)hipStreamDestroy(own);
@@ -301,6 +342,47 @@ CPH_API int32_t cph_ctx_synchronize(cph_ctx* ctx) {
     if (!s.ok()) return fail(ctx, s);
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return fail(ctx, {CPH_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e)});
+    return CPH_OK;
+}
+
+CPH_API int32_t cph_ctx_profile(cph_ctx* ctx, int32_t enable) {
+    Status s = enter(ctx);
+    if (!s.ok()) return fail(ctx, s);
+    ctx->profiling = enable != 0;
+    return CPH_OK;
+}
+
+CPH_API int32_t cph_ctx_profile_read(cph_ctx* ctx, cph_kernel_stat* out, int32_t cap, int32_t* n, int32_t reset) {
+    Status s = enter(ctx);
+    if (!s.ok()) return fail(ctx, s);
+    if (!n || (cap > 0 && !out)) return fail(ctx, {CPH_ERR_INVALID, "bad argument"});
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return fail(ctx, {CPH_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e)});
+    for (auto& p : ctx->prof_pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+            ProfStat& st = ctx->prof_stats[(size_t)p.name_idx];
+            st.launches++;
+            st.total_ms += ms;
+            st.bytes += p.bytes;
+        } else {
+            (void)hipGetLastError();
+        }
+        ctx->prof_free_events.push_back(p.start);
+        ctx->prof_free_events.push_back(p.stop);
+    }
+    ctx->prof_pending.clear();
+    const int32_t total = (int32_t)ctx->prof_stats.size();
+    *n = total;
+    for (int32_t i = 0; i < total && i < cap; i++) {
+        const ProfStat& st = ctx->prof_stats[(size_t)i];
+        memset(&out[i], 0, sizeof out[i]);
+        snprintf(out[i].name, sizeof out[i].name, "%s", st.name.c_str());
+        out[i].launches = st.launches;
+        out[i].total_ms = st.total_ms;
+        out[i].algo_bytes = st.bytes;
+    }
+    if (reset) ctx->prof_stats.clear();
     return CPH_OK;
 }
 

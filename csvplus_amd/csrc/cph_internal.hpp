@@ -135,6 +135,12 @@ struct CodecDevHeader {
 
 }  // namespace cph
 
+// ---- optional per-kernel timing (HIP events on the ctx stream) -------------------------------
+namespace cph {
+struct ProfPending { int name_idx; hipEvent_t start, stop; double bytes; };
+struct ProfStat { std::string name; uint64_t launches = 0; double total_ms = 0, bytes = 0; };
+}  // namespace cph
+
 // ---- the opaque C types ------------------------------------------------------------------
 struct cph_ctx {
     int device = 0;
@@ -146,6 +152,11 @@ struct cph_ctx {
     void* pinned_scratch = nullptr;
     size_t pinned_scratch_bytes = 0;
     std::vector<void*> pinned_user;
+    // profiling
+    bool profiling = false;
+    std::vector<cph::ProfPending> prof_pending;
+    std::vector<cph::ProfStat> prof_stats;
+    std::vector<hipEvent_t> prof_free_events;
 };
 
 struct cph_index {
@@ -227,5 +238,18 @@ Status index_find_device(cph_ctx* ctx, const cph_index* ix, const uint64_t* q_ex
 
 // capi.hip helpers
 Status ensure_pinned_scratch(cph_ctx* ctx, size_t bytes);
+
+// Times everything enqueued on ctx->stream during its lifetime when ctx->profiling is on
+// (two HIP events on that stream); `bytes` = algorithmic bytes of the launch.
+class ProfScope {
+public:
+    ProfScope(cph_ctx* ctx, const char* name, double bytes);
+    ~ProfScope();
+private:
+    cph_ctx* ctx_;
+    int idx_ = -1;
+    hipEvent_t start_ = nullptr;
+    double bytes_ = 0;
+};
 
 }  // namespace cph

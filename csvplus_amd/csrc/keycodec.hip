@@ -80,6 +80,7 @@ Status codec_collect_stats(cph_ctx* ctx, const DevCol* cols, int32_t ncols, std:
         uint64_t nblk = (cols[c].nrows + kStatsThreads - 1) / kStatsThreads;
         if (nblk > 2048) nblk = 2048;
         uint32_t* base = reinterpret_cast<uint32_t*>(d.as<uint8_t>() + per * (size_t)c);
+        ProfScope ps(ctx, "k_col_stats", 0);   // bytes: value bytes + offsets, added by the caller's model
         hipLaunchKernelGGL(k_col_stats, dim3((unsigned)nblk), dim3(kStatsThreads), 0, ctx->stream, cols[c], base,
                            base + 2);
         CPH_HIP_TRY(hipGetLastError());
@@ -239,6 +240,7 @@ Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec
     uint64_t nblk = (n + kEncodeThreads - 1) / kEncodeThreads;
     if (nblk > 4096) nblk = 4096;
     const size_t lds = codec_dev.bytes();
+    ProfScope ps(ctx, "k_encode_build", 0);
     if (cd.key32) {
         CPH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode_build<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

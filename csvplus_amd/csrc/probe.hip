@@ -71,12 +71,15 @@ Status index_first_dup(cph_ctx* ctx, const cph_index* ix, uint64_t* first_dup) {
     CPH_HIP_TRY(hipMemsetAsync(d.get(), 0xFF, sizeof(uint32_t), ctx->stream));
     uint64_t nblk = (n + 255) / 256;
     if (nblk > 4096) nblk = 4096;
-    if (ix->codec.key32)
-        hipLaunchKernelGGL(k_first_dup<true>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, ix->sorted_codes.get(), n,
-                           ix->codec.nwords, d.as<uint32_t>());
-    else
-        hipLaunchKernelGGL(k_first_dup<false>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, ix->sorted_codes.get(),
-                           n, ix->codec.nwords, d.as<uint32_t>());
+    {
+        ProfScope ps(ctx, "k_first_dup", (double)n * (ix->codec.key32 ? 4.0 : 8.0 * ix->codec.nwords));
+        if (ix->codec.key32)
+            hipLaunchKernelGGL(k_first_dup<true>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream,
+                               ix->sorted_codes.get(), n, ix->codec.nwords, d.as<uint32_t>());
+        else
+            hipLaunchKernelGGL(k_first_dup<false>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream,
+                               ix->sorted_codes.get(), n, ix->codec.nwords, d.as<uint32_t>());
+    }
     CPH_HIP_TRY(hipGetLastError());
     CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, d.get(), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -110,6 +113,7 @@ Status index_build_table(cph_ctx* ctx, cph_index* ix) {
     CPH_HIP_TRY(hipMemsetAsync(ix->table.get(), 0, states * sizeof(TableEntry), ctx->stream));
     uint64_t nblk = (n + 255) / 256;
     if (nblk > 8192) nblk = 8192;
+    ProfScope ps(ctx, "k_build_table", (double)n * (ix->codec.key32 ? 4.0 : 8.0) + 8.0 * (double)n);
     if (ix->codec.key32)
         hipLaunchKernelGGL(k_build_table<uint32_t>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream,
                            ix->sorted_codes.as<uint32_t>(), n, ix->table.as<TableEntry>());
@@ -278,6 +282,7 @@ static Status launch_probe(cph_ctx* ctx, const cph_index* ix, const ColsArg& arg
     const size_t lds = ix->codec_dev.bytes();
     CPH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_probe<KEY32, TABLE>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ProfScope ps(ctx, TABLE ? "k_probe_table" : "k_probe_search", 0);
     hipLaunchKernelGGL((k_probe<KEY32, TABLE>), dim3(ntiles), dim3(kProbeThreads), lds, ctx->stream, arg, ncols,
                        ix->codec_dev.as<uint8_t>(), ix->sorted_codes.get(), ix->nrows, ix->table.as<TableEntry>(),
                        row_sel, nprobe, lo, cnt, tile_sums);
@@ -310,7 +315,10 @@ Status probe_run(cph_ctx* ctx, const cph_index* ix, const DevCol* cols, int32_t 
         if (use_table) CPH_TRY((launch_probe<false, true>(ctx, ix, arg, ncols, row_sel, nprobe, lo, cnt, ts, ntiles)));
         else CPH_TRY((launch_probe<false, false>(ctx, ix, arg, ncols, row_sel, nprobe, lo, cnt, ts, ntiles)));
     }
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(256), 0, ctx->stream, ts, ntiles64);
+    {
+        ProfScope ps(ctx, "k_scan_tiles", 16.0 * (double)ntiles64);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(256), 0, ctx->stream, ts, ntiles64);
+    }
     CPH_HIP_TRY(hipGetLastError());
     CPH_TRY(ensure_pinned_scratch(ctx, sizeof(uint64_t)));
     CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, ts + ntiles64, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -319,6 +327,7 @@ Status probe_run(cph_ctx* ctx, const cph_index* ix, const DevCol* cols, int32_t 
     if (!want_pairs || out->nmatches == 0) return {};
     CPH_TRY(out->pidx.alloc(&ctx->pool, out->nmatches * sizeof(uint64_t)));
     CPH_TRY(out->brow.alloc(&ctx->pool, out->nmatches * sizeof(uint32_t)));
+    ProfScope ps(ctx, "k_expand", 8.0 * (double)nprobe + 16.0 * (double)out->nmatches);
     hipLaunchKernelGGL(k_expand, dim3(ntiles), dim3(kProbeThreads), 0, ctx->stream, lo, cnt, nprobe, ts,
                        ix->perm.as<uint32_t>(), probe_base, out->pidx.as<uint64_t>(), out->brow.as<uint32_t>());
     CPH_HIP_TRY(hipGetLastError());

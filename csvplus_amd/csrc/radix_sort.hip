@@ -229,6 +229,7 @@ Status exclusive_scan_u32(cph_ctx* ctx, uint32_t* data, uint64_t n) {
     const uint64_t nblk = (n + kScanTile - 1) / kScanTile;
     DevBuf sums;
     CPH_TRY(sums.alloc(&ctx->pool, nblk * sizeof(uint32_t)));
+    ProfScope ps(ctx, "exclusive_scan_u32", 12.0 * (double)n);
     hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nblk), dim3(kScanThreads), 0, ctx->stream, data, n,
                        sums.as<uint32_t>());
     hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(kScanThreads), 0, ctx->stream, sums.as<uint32_t>(), nblk);
@@ -258,6 +259,7 @@ static unsigned grid_for(uint64_t n, int threads, unsigned cap) {
 }
 Status gather_u64(cph_ctx* ctx, const uint64_t* src, const uint32_t* idx, uint64_t* dst, uint64_t n) {
     if (n == 0) return {};
+    ProfScope ps(ctx, "k_gather_u64", 20.0 * (double)n);
     hipLaunchKernelGGL(k_gather_u64, dim3(grid_for(n, 256, 8192)), dim3(256), 0, ctx->stream, src, idx, dst, n);
     CPH_HIP_TRY(hipGetLastError());
     return {};
@@ -297,13 +299,20 @@ Status radix_sort_pairs(cph_ctx* ctx, K* keys_a, K* keys_b, uint32_t* vals_a, ui
     for (int shift = 0; shift < bits; shift += kRadixBits) {
         const int nb = bits - shift < kRadixBits ? bits - shift : kRadixBits;
         const uint32_t mask = (1u << nb) - 1u;
+        {
+        ProfScope ps(ctx, sizeof(K) == 4 ? "k_radix_hist_u32" : "k_radix_hist_u64", (double)n * sizeof(K));
         hipLaunchKernelGGL(k_radix_hist<K>, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, kin, n, shift, mask,
                            counts.as<uint32_t>(), ntiles);
+        }
         CPH_HIP_TRY(hipGetLastError());
         CPH_TRY(exclusive_scan_u32(ctx, counts.as<uint32_t>(), (uint64_t)kRadix * ntiles));
+        {
+        ProfScope ps(ctx, sizeof(K) == 4 ? "k_radix_scatter_u32" : "k_radix_scatter_u64",
+                     (double)n * (2.0 * sizeof(K) + (iota ? 4.0 : 8.0)));
         hipLaunchKernelGGL(k_radix_scatter<K>, dim3(ntiles), dim3(kSortThreads), smem, ctx->stream, kin,
                            iota ? (const uint32_t*)nullptr : vin, kout, vout, n, shift, mask, counts.as<uint32_t>(),
                            ntiles);
+        }
         CPH_HIP_TRY(hipGetLastError());
         iota = false;
         K* tk = kin; kin = kout; kout = tk;

@@ -1,0 +1,463 @@
+// csvplus.hpp — C++ host side of the hot path, mirroring the reference's Go method set
+// (maxim2266/csvplus, csvplus.go) for Index build + Join on top of the C ABI
+// (include/csvplus_hip.h).  The Go toolchain is absent from this image, so this header is
+// what the cgo shim of INTEGRATION.md would be in Go: same names, argument meaning and
+// error behaviour.
+//
+//   Go (csvplus.go)                              here
+//   type Row map[string]string            :59    csvplus::Row
+//   Row.HasColumn/SelectValues/...      :62-161  free functions of the same names
+//   type DataSource func(RowFunc) error  :215    csvplus::DataSource
+//   TakeRows / Take                    :218,:252 csvplus::TakeRows / Take
+//   DataSource.IndexOn / UniqueIndexOn :529,:535 DataSource::IndexOn / UniqueIndexOn
+//   DataSource.Join / Except           :545,:588 DataSource::Join / Except
+//   Index.Iterate / Find / SubIndex    :618-641  Index::Iterate / Find / SubIndex
+//   DataSourceError                   :1229-1238 csvplus::DataSourceError
+//
+// Go `error` values become csvplus::Error (nil == ok()); Go panics (programmer errors:
+// empty / duplicate column lists, too many join columns, :710, :715, :549, :634) become
+// csvplus::Panic exceptions.  io.EOF keeps its role: returned from a RowFunc it stops the
+// iteration cleanly (:213-214, :238-239).
+//
+// What runs where: rows stay host-side maps exactly as in the reference; the key columns of
+// a batch are staged into pinned SoA buffers and the sort / unique check / probe run on the
+// GPU.  There is no CPU implementation of those steps here.
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "csvplus_hip.h"
+
+namespace csvplus {
+
+// ---- errors ------------------------------------------------------------------------------------
+class Error {
+public:
+    Error() = default;                                        // nil
+    explicit Error(std::string msg) : set_(true), msg_(std::move(msg)) {}
+    static Error Eof() { Error e("EOF"); e.eof_ = true; return e; }   // io.EOF
+    bool ok() const { return !set_; }
+    bool is_eof() const { return set_ && eof_; }
+    explicit operator bool() const { return set_; }           // `if (err)` == `if err != nil`
+    const std::string& message() const { return msg_; }       // err.Error()
+    // DataSourceError (:1229-1238)
+    bool is_data_source_error() const { return has_line_; }
+    uint64_t line() const { return line_; }
+    static Error DataSourceError(uint64_t line, const Error& inner) {
+        Error e("row " + std::to_string(line) + ": " + inner.message());
+        e.has_line_ = true;
+        e.line_ = line;
+        return e;
+    }
+
+private:
+    bool set_ = false, eof_ = false, has_line_ = false;
+    uint64_t line_ = 0;
+    std::string msg_;
+};
+inline const Error io_EOF = Error::Eof();
+
+struct Panic : std::logic_error {   // Go panic(...)
+    using std::logic_error::logic_error;
+};
+
+// ---- Row (:59) -----------------------------------------------------------------------------------
+using Row = std::map<std::string, std::string>;
+
+inline bool HasColumn(const Row& row, const std::string& col) { return row.count(col) != 0; }   // :62-65
+
+inline std::string quote(const std::string& s) { return "\"" + s + "\""; }   // %q for plain names
+
+// SelectValues (:138-150)
+inline Error SelectValues(const Row& row, const std::vector<std::string>& cols, std::vector<const std::string*>* out) {
+    out->resize(cols.size());
+    for (size_t i = 0; i < cols.size(); i++) {
+        auto it = row.find(cols[i]);
+        if (it == row.end()) return Error("missing column " + quote(cols[i]));
+        (*out)[i] = &it->second;
+    }
+    return Error();
+}
+
+// SelectExisting (:108-118)
+inline Row SelectExisting(const Row& row, const std::vector<std::string>& cols) {
+    Row r;
+    for (const auto& name : cols) {
+        auto it = row.find(name);
+        if (it != row.end()) r[name] = it->second;
+    }
+    return r;
+}
+
+// Row.String (:90-104): `{ "a" : "1", "b" : "2" }`, columns sorted
+inline std::string String(const Row& row) {
+    if (row.empty()) return "{}";
+    std::string s = "{ ";
+    bool first = true;
+    for (const auto& kv : row) {   // std::map iterates in sorted key order == Header()
+        if (!first) s += ", ";
+        first = false;
+        s += "\"" + kv.first + "\" : \"" + kv.second + "\"";
+    }
+    return s + " }";
+}
+
+// mergeRows (:571-583): index row first, then the stream row: the stream wins on a name collision
+inline Row mergeRows(const Row& left, const Row& right) {
+    Row r = left;
+    for (const auto& kv : right) r[kv.first] = kv.second;
+    return r;
+}
+
+using RowFunc = std::function<Error(Row)>;
+
+// ---- GPU context shared by the process (the Go API has no context argument) -------------------------
+class Gpu {
+public:
+    static Gpu& Default() {
+        static Gpu g;
+        return g;
+    }
+    cph_ctx* ctx() {
+        if (!ctx_) {
+            int dev = 0;
+            if (const char* e = std::getenv("CSVPLUS_HIP_DEVICE")) dev = std::atoi(e);
+            int32_t rc = cph_ctx_create(dev, &ctx_);
+            if (rc != CPH_OK) throw std::runtime_error("csvplus: no usable GPU (cph_ctx_create failed, status " +
+                                                       std::to_string(rc) + "); there is no CPU fallback");
+        }
+        return ctx_;
+    }
+    // The process-wide ctx is deliberately never destroyed: indexes held in static storage may
+    // outlive it during exit, and they return their device blocks to this ctx's pool.
+    // Rows read ahead per GPU probe call in Join/Except.  1 reproduces the reference's
+    // row-at-a-time order of side effects exactly.
+    size_t join_batch_rows = 8192;
+
+private:
+    cph_ctx* ctx_ = nullptr;
+};
+
+namespace detail {
+
+// Key columns of a batch of rows, staged as Arrow-style SoA in pinned host memory.
+class StagedColumns {
+public:
+    StagedColumns(cph_ctx* ctx, size_t ncols) : ctx_(ctx), data_(ncols), offs_(ncols), cols_(ncols) {}
+    StagedColumns(const StagedColumns&) = delete;
+    ~StagedColumns() {
+        for (void* p : pinned_) cph_pinned_free(ctx_, p);
+    }
+    // values[c][i] = value of key column c in row i
+    void stage(const std::vector<std::vector<const std::string*>>& values, size_t nrows) {
+        for (size_t c = 0; c < cols_.size(); c++) {
+            uint64_t total = 0;
+            for (size_t i = 0; i < nrows; i++) total += values[c][i]->size();
+            uint8_t* d = static_cast<uint8_t*>(pinned(total + 8));
+            uint64_t* o = static_cast<uint64_t*>(pinned((nrows + 1) * sizeof(uint64_t)));
+            uint64_t pos = 0;
+            for (size_t i = 0; i < nrows; i++) {
+                o[i] = pos;
+                const std::string& v = *values[c][i];
+                if (!v.empty()) std::memcpy(d + pos, v.data(), v.size());
+                pos += v.size();
+            }
+            o[nrows] = pos;
+            cols_[c].data = d;
+            cols_[c].offsets = o;
+            cols_[c].nrows = nrows;
+            cols_[c].offset_bits = 64;
+            cols_[c].mem = CPH_MEM_HOST;
+        }
+    }
+    const cph_strcol* cols() const { return cols_.data(); }
+
+private:
+    void* pinned(size_t bytes) {
+        void* p = nullptr;
+        if (cph_pinned_alloc(ctx_, bytes, &p) != CPH_OK)
+            throw std::runtime_error(std::string("csvplus: ") + cph_last_error(ctx_));
+        pinned_.push_back(p);
+        return p;
+    }
+    cph_ctx* ctx_;
+    std::vector<void*> data_, offs_;
+    std::vector<cph_strcol> cols_;
+    std::vector<void*> pinned_;
+};
+
+struct DeviceIndex {   // owns a cph_index
+    cph_index* h = nullptr;
+    ~DeviceIndex() {
+        if (h) cph_index_destroy(h);
+    }
+};
+
+// allColumnsUnique (:770-782)
+inline bool allColumnsUnique(const std::vector<std::string>& columns) {
+    std::set<std::string> s(columns.begin(), columns.end());
+    return s.size() == columns.size();
+}
+
+}  // namespace detail
+
+class DataSource;
+
+// ---- Index (:612-641) ------------------------------------------------------------------------------
+class Index {
+public:
+    // Iterate (:618-620): rows sorted on the index columns, each handed out as a copy (:230)
+    Error Iterate(const RowFunc& fn) const;
+    // Find (:625-627)
+    DataSource Find(const std::vector<std::string>& values) const;
+    // SubIndex (:632-641)
+    std::shared_ptr<Index> SubIndex(const std::vector<std::string>& values) const;
+
+    const std::vector<Row>& rows() const { return impl_rows; }
+    const std::vector<std::string>& columns() const { return impl_columns; }
+
+    // ---- indexImpl (:785-788): the sorted rows ARE the index ----
+    std::vector<Row> impl_rows;
+    std::vector<std::string> impl_columns;
+
+    // find (:870-891): [lower, upper) over impl_rows
+    std::pair<size_t, size_t> find(const std::vector<std::string>& values) const {
+        if (values.empty()) return {0, impl_rows.size()};                                  // :872-874
+        if (values.size() > impl_columns.size()) throw Panic("too many columns in indexImpl.find()");   // :876-878
+        std::vector<cph_strval> v(values.size());
+        for (size_t i = 0; i < values.size(); i++) {
+            v[i].data = reinterpret_cast<const uint8_t*>(values[i].data());
+            v[i].len = values[i].size();
+        }
+        uint64_t lo = 0, hi = 0;
+        cph_ctx* ctx = Gpu::Default().ctx();
+        if (cph_index_find(ctx, device().h, v.data(), (int32_t)v.size(), &lo, &hi) != CPH_OK)
+            throw std::runtime_error(std::string("csvplus: ") + cph_last_error(ctx));
+        return {(size_t)lo, (size_t)hi};
+    }
+
+    // The GPU-resident twin of impl_rows' key columns; built on demand for sub-indices.
+    detail::DeviceIndex& device() const {
+        if (!dev_) {
+            dev_ = std::make_shared<detail::DeviceIndex>();
+            cph_ctx* ctx = Gpu::Default().ctx();
+            std::vector<std::vector<const std::string*>> vals(impl_columns.size());
+            for (size_t c = 0; c < impl_columns.size(); c++) {
+                vals[c].resize(impl_rows.size());
+                for (size_t i = 0; i < impl_rows.size(); i++) vals[c][i] = &impl_rows[i].at(impl_columns[c]);
+            }
+            detail::StagedColumns st(ctx, impl_columns.size());
+            st.stage(vals, impl_rows.size());
+            uint64_t dup = 0;
+            int32_t rc = cph_index_build(ctx, st.cols(), (int32_t)impl_columns.size(), 0, &dev_->h, &dup);
+            if (rc != CPH_OK) throw std::runtime_error(std::string("csvplus: ") + cph_last_error(ctx));
+        }
+        return *dev_;
+    }
+    mutable std::shared_ptr<detail::DeviceIndex> dev_;
+};
+
+// ---- DataSource (:215) ---------------------------------------------------------------------------------
+class DataSource {
+public:
+    using Fn = std::function<Error(const RowFunc&)>;
+    DataSource() = default;
+    DataSource(Fn f) : fn_(std::move(f)) {}   // NOLINT: implicit like a Go func value
+    Error operator()(const RowFunc& fn) const { return fn_(fn); }
+
+    // IndexOn (:529-531) / UniqueIndexOn (:535-537): (index, error); index is null on error
+    std::pair<std::shared_ptr<Index>, Error> IndexOn(const std::vector<std::string>& columns) const {
+        return createIndex(columns, false);
+    }
+    std::pair<std::shared_ptr<Index>, Error> UniqueIndexOn(const std::vector<std::string>& columns) const {
+        return createIndex(columns, true);
+    }
+
+    // Join (:545-569).  `columns` empty = natural join on the index columns.
+    DataSource Join(std::shared_ptr<Index> index, std::vector<std::string> columns = {}) const {
+        if (columns.empty()) columns = index->impl_columns;                                  // :546-547
+        else if (columns.size() > index->impl_columns.size()) throw Panic("too many source columns in Join()");  // :548-550
+        return probeSource(std::move(index), std::move(columns), /*anti=*/false);
+    }
+
+    // Except (:588-608)
+    DataSource Except(std::shared_ptr<Index> index, std::vector<std::string> columns = {}) const {
+        if (columns.empty()) columns = index->impl_columns;
+        else if (columns.size() > index->impl_columns.size()) throw Panic("too many source columns in Except()");
+        return probeSource(std::move(index), std::move(columns), /*anti=*/true);
+    }
+
+    // ToRows (:481-490)
+    std::pair<std::vector<Row>, Error> ToRows() const {
+        std::vector<Row> rows;
+        Error err = fn_([&](Row row) { rows.push_back(std::move(row)); return Error(); });
+        return {std::move(rows), err};
+    }
+
+private:
+    Fn fn_;
+
+    // createIndex (:707-738) + createUniqueIndex (:740-756)
+    std::pair<std::shared_ptr<Index>, Error> createIndex(const std::vector<std::string>& columns, bool unique) const {
+        if (columns.empty()) throw Panic("empty column list in CreateIndex()");                    // :709-710
+        if (columns.size() > 1 && !detail::allColumnsUnique(columns))
+            throw Panic("duplicate column name(s) in CreateIndex()");                                // :714-716
+        auto index = std::make_shared<Index>();
+        index->impl_columns = columns;
+        std::vector<Row> rows;
+        // copy Rows with validation (:722-733)
+        Error err = fn_([&](Row row) {
+            for (const auto& col : columns)
+                if (!HasColumn(row, col)) return Error("missing column " + quote(col) + " while creating an index");
+            rows.push_back(std::move(row));
+            return Error();
+        });
+        if (err) return {nullptr, err};
+        if (rows.size() > 0xFFFFFFFFull) return {nullptr, Error("too many rows for a GPU index (2^32-1 max)")};
+
+        // sort (:736) on the GPU: stage key columns, build, fetch the permutation
+        cph_ctx* ctx = Gpu::Default().ctx();
+        std::vector<std::vector<const std::string*>> vals(columns.size());
+        for (size_t c = 0; c < columns.size(); c++) {
+            vals[c].resize(rows.size());
+            for (size_t i = 0; i < rows.size(); i++) vals[c][i] = &rows[i].at(columns[c]);
+        }
+        auto dev = std::make_shared<detail::DeviceIndex>();
+        uint64_t first_dup = UINT64_MAX;
+        int32_t rc;
+        {
+            detail::StagedColumns st(ctx, columns.size());
+            st.stage(vals, rows.size());
+            rc = cph_index_build(ctx, st.cols(), (int32_t)columns.size(), unique ? 1 : 0, &dev->h, &first_dup);
+        }
+        if (rc != CPH_OK && rc != CPH_ERR_DUPLICATE) return {nullptr, Error(std::string("csvplus_hip: ") + cph_last_error(ctx))};
+        const uint32_t* perm = nullptr;
+        uint64_t n = 0;
+        if (cph_index_perm(dev->h, CPH_MEM_HOST, &perm, &n) != CPH_OK)
+            return {nullptr, Error(std::string("csvplus_hip: ") + cph_last_error(ctx))};
+        if (rc == CPH_ERR_DUPLICATE) {
+            // :751  "duplicate value while creating unique index: " + rows[i].SelectExisting(columns...).String()
+            return {nullptr, Error("duplicate value while creating unique index: " +
+                                   String(SelectExisting(rows[perm[first_dup]], columns)))};
+        }
+        index->impl_rows.resize(rows.size());
+        for (size_t i = 0; i < rows.size(); i++) index->impl_rows[i] = std::move(rows[perm[i]]);
+        index->dev_ = dev;
+        return {index, Error()};
+    }
+
+    // Shared body of Join / Except: the per-row `first()` + forward scan (:557-563) / `has()` (:599-602)
+    // becomes one GPU probe per batch of stream rows.
+    DataSource probeSource(std::shared_ptr<Index> index, std::vector<std::string> columns, bool anti) const {
+        Fn src = fn_;
+        return DataSource([src, index, columns, anti](const RowFunc& fn) -> Error {
+            cph_ctx* ctx = Gpu::Default().ctx();
+            const size_t batch_rows = std::max<size_t>(1, Gpu::Default().join_batch_rows);
+            std::vector<Row> batch;
+            batch.reserve(batch_rows);
+
+            auto flush = [&]() -> Error {
+                if (batch.empty()) return Error();
+                std::vector<std::vector<const std::string*>> vals(columns.size());
+                for (auto& v : vals) v.resize(batch.size());
+                for (size_t i = 0; i < batch.size(); i++)
+                    for (size_t c = 0; c < columns.size(); c++) vals[c][i] = &batch[i].at(columns[c]);
+                cph_matches* m = nullptr;
+                {
+                    detail::StagedColumns st(ctx, columns.size());
+                    st.stage(vals, batch.size());
+                    int32_t rc = cph_join_probe(ctx, index->device().h, st.cols(), (int32_t)columns.size(), nullptr, 32,
+                                                0, 0, 0, /*want_pairs=*/0, CPH_MEM_HOST, &m);
+                    if (rc != CPH_OK) return Error(std::string("csvplus_hip: ") + cph_last_error(ctx));
+                }
+                Error err;
+                // index.impl.rows is read live at iteration time (:557), as in the reference
+                const std::vector<Row>& irows = index->impl_rows;
+                for (size_t i = 0; i < batch.size() && !err; i++) {
+                    if (anti) {
+                        if (m->cnt[i] == 0) err = fn(std::move(batch[i]));                        // :600-602
+                    } else {
+                        for (uint32_t j = 0; j < m->cnt[i] && !err; j++)                              // :559-563
+                            err = fn(mergeRows(irows[(size_t)m->lo[i] + j], batch[i]));
+                    }
+                }
+                cph_matches_release(m);
+                batch.clear();
+                return err;
+            };
+
+            Error err = src([&](Row row) -> Error {
+                std::vector<const std::string*> tmp;
+                Error e = SelectValues(row, columns, &tmp);                                       // :556 / :599
+                if (e) {
+                    // rows before this one must be delivered first, then the error surfaces
+                    Error fe = flush();
+                    return fe ? fe : e;
+                }
+                batch.push_back(std::move(row));
+                if (batch.size() >= batch_rows) return flush();
+                return Error();
+            });
+            if (err) return err;
+            err = flush();
+            // an io.EOF from `fn` in the tail batch ends the iteration cleanly, as the source
+            // would have mapped it (:238-239)
+            return err.is_eof() ? Error() : err;
+        });
+    }
+};
+
+// iterate (:225-249): clones each row, io.EOF -> nil, other errors -> DataSourceError{Line: i}
+inline Error iterate(const std::vector<Row>& rows, const RowFunc& fn) {
+    Error err;
+    size_t i = 0;
+    for (; i < rows.size(); i++) {
+        err = fn(rows[i]);   // pass-by-value parameter: the callee gets a copy (Clone, :230)
+        if (err) break;
+    }
+    if (!err) return err;
+    if (err.is_eof()) return Error();
+    return Error::DataSourceError((uint64_t)i, err);
+}
+
+// TakeRows (:218-222).  The rows are captured by value (a Go slice header copy shares the
+// backing array; here the DataSource owns a snapshot).
+inline DataSource TakeRows(std::vector<Row> rows) {
+    auto shared = std::make_shared<std::vector<Row>>(std::move(rows));
+    return DataSource([shared](const RowFunc& fn) { return iterate(*shared, fn); });
+}
+
+// Take (:252-256): anything with Iterate(fn)
+template <class T>
+inline DataSource Take(std::shared_ptr<T> src) {
+    return DataSource([src](const RowFunc& fn) { return src->Iterate(fn); });
+}
+
+inline Error Index::Iterate(const RowFunc& fn) const { return iterate(impl_rows, fn); }
+
+inline DataSource Index::Find(const std::vector<std::string>& values) const {
+    auto r = find(values);
+    return TakeRows(std::vector<Row>(impl_rows.begin() + (long)r.first, impl_rows.begin() + (long)r.second));
+}
+
+inline std::shared_ptr<Index> Index::SubIndex(const std::vector<std::string>& values) const {
+    if (values.size() >= impl_columns.size()) throw Panic("too many values in SubIndex()");   // :633-635
+    auto r = find(values);
+    auto sub = std::make_shared<Index>();
+    sub->impl_rows.assign(impl_rows.begin() + (long)r.first, impl_rows.begin() + (long)r.second);
+    sub->impl_columns.assign(impl_columns.begin() + (long)values.size(), impl_columns.end());
+    return sub;
+}
+
+}  // namespace csvplus

@@ -216,6 +216,25 @@ typedef struct {
 
 CPH_API int32_t cph_index_get_info(const cph_index* index, cph_index_info* info);
 
+/*
+ * Per-kernel timing for roofline accounting.  While enabled, every kernel launch
+ * of this ctx is bracketed by two HIP events on the ctx's stream.
+ * cph_ctx_profile_read synchronises the stream and returns, per kernel name, the
+ * number of launches, their summed duration and their summed ALGORITHMIC bytes
+ * (the per-launch byte model documented in DESIGN.md; 0 where the library cannot
+ * know the input's value bytes).  *n receives the number of distinct kernels
+ * (may exceed cap).  reset != 0 clears the statistics afterwards.
+ */
+typedef struct {
+    char     name[48];
+    uint64_t launches;
+    double   total_ms;
+    double   algo_bytes;
+} cph_kernel_stat;
+
+CPH_API int32_t cph_ctx_profile(cph_ctx* ctx, int32_t enable);
+CPH_API int32_t cph_ctx_profile_read(cph_ctx* ctx, cph_kernel_stat* out, int32_t cap, int32_t* n, int32_t reset);
+
 /* Library version, e.g. "csvplus_hip 0.1 (gfx950)". */
 CPH_API const char* cph_version(void);
 

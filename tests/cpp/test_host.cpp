@@ -1,0 +1,356 @@
+// test_host.cpp — the reference's own hot-path tests (csvplus_test.go) restated against the
+// C++ host facade (csvplus_amd/host/csvplus.hpp), which runs the sort / unique check / probe on
+// the GPU through the C ABI.  Fixtures have the reference's shape (csvplus_test.go:1207-1333)
+// with a seeded PRNG (the reference's math/rand is unseeded).  Run by tests/test_host_cpp.py
+// under `-m gpu`.
+#include <cmath>
+#include <cstdio>
+#include <iostream>
+#include <random>
+#include <sstream>
+
+#include "csvplus.hpp"
+
+using namespace csvplus;
+
+static int g_failed = 0;
+#define CHECK(cond)                                                                    \
+    do {                                                                               \
+        if (!(cond)) {                                                                 \
+            std::printf("  CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #cond);      \
+            g_failed++;                                                                \
+            return;                                                                    \
+        }                                                                              \
+    } while (0)
+
+// ---- generated test data (csvplus_test.go:1188-1333) ----------------------------------------------
+static const char* peopleNames[] = {"Amelia", "Olivia", "Emily", "Ava", "Isla", "Oliver", "Jack", "Harry", "Jacob", "Charlie"};
+static const char* peopleSurnames[] = {"Smith", "Jones", "Taylor", "Williams", "Brown", "Davies",
+                                       "Evans", "Wilson", "Thomas", "Roberts", "Johnson", "Lewis"};
+static const int kNames = 10, kSurnames = 12, numOrders = 10000;
+struct StockItem { const char* name; double price; };
+static const StockItem stockItems[] = {{"banana", 0.01}, {"apple", 0.02}, {"orange", 0.03}, {"pea", 0.04},
+                                       {"tomato", 0.05}, {"potato", 0.06}, {"cucumber", 0.07}, {"iPhone", 0.08}};
+static const int kStock = 8;
+
+struct PersonData { std::string Name, Surname; int Born; };
+struct OrderData { int custID, prodID, qty; };
+static std::vector<PersonData> peopleData;
+static std::vector<OrderData> ordersData;
+static std::vector<Row> peopleRows, ordersRows, stockRows;
+
+static void makeFixtures() {
+    std::mt19937_64 rng(20250523);
+    for (int i = 0; i < kNames; i++)
+        for (int j = 0; j < kSurnames; j++) {
+            int id = i * kSurnames + j;
+            PersonData p{peopleNames[i], peopleSurnames[j], 1916 + (int)(rng() % 90)};
+            peopleData.push_back(p);
+            peopleRows.push_back(Row{{"id", std::to_string(id)}, {"name", p.Name}, {"surname", p.Surname},
+                                     {"born", std::to_string(p.Born)}});
+        }
+    for (int i = 0; i < kStock; i++) {
+        char price[16];
+        std::snprintf(price, sizeof price, "%.2f", stockItems[i].price);
+        stockRows.push_back(Row{{"prod_id", std::to_string(i)}, {"product", stockItems[i].name}, {"price", price}});
+    }
+    for (int i = 0; i < numOrders; i++) {
+        OrderData o{(int)(rng() % (kNames * kSurnames)), (int)(rng() % kStock), (int)(rng() % 100) + 1};
+        ordersData.push_back(o);
+        ordersRows.push_back(Row{{"order_id", std::to_string(i)}, {"cust_id", std::to_string(o.custID)},
+                                 {"prod_id", std::to_string(o.prodID)}, {"qty", std::to_string(o.qty)},
+                                 {"ts", "2025-05-23T00:00:00Z"}});
+    }
+}
+
+// ---- the lazy combinators the reference's tests chain around the joins (out of scope for the
+// GPU path, so they live here as plain host helpers; csvplus.go:258-374, :492-525) ----------------
+static DataSource SelectColumns(DataSource src, std::vector<std::string> cols) {
+    return DataSource([src, cols](const RowFunc& fn) {
+        return src([&](Row row) {
+            Row r;
+            for (auto& c : cols) {
+                auto it = row.find(c);
+                if (it == row.end()) return Error("missing column " + quote(c));
+                r[c] = it->second;
+            }
+            return fn(std::move(r));
+        });
+    });
+}
+static DataSource DropColumns(DataSource src, std::vector<std::string> cols) {
+    return DataSource([src, cols](const RowFunc& fn) {
+        return src([&](Row row) {
+            for (auto& c : cols) row.erase(c);
+            return fn(std::move(row));
+        });
+    });
+}
+static DataSource Filter(DataSource src, std::function<bool(const Row&)> pred) {
+    return DataSource([src, pred](const RowFunc& fn) {
+        return src([&](Row row) { return pred(row) ? fn(std::move(row)) : Error(); });
+    });
+}
+static DataSource Map(DataSource src, std::function<Row(Row)> mf) {
+    return DataSource([src, mf](const RowFunc& fn) { return src([&](Row row) { return fn(mf(std::move(row))); }); });
+}
+static DataSource Top(DataSource src, uint64_t n) {   // csvplus.go:313-325
+    return DataSource([src, n](const RowFunc& fn) {
+        uint64_t counter = 0;
+        return src([&](Row row) {
+            if (counter++ < n) return fn(std::move(row));
+            return io_EOF;
+        });
+    });
+}
+static int atoi_s(const std::string& s) { return std::atoi(s.c_str()); }
+static bool hasSuffix(const std::string& s, const std::string& suf) {
+    return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
+}
+
+// ---- TestIndexImpl (csvplus_test.go:198-246) ------------------------------------------------------------
+static void TestIndexImpl() {
+    std::vector<Row> rows = {
+        {{"x", "1"}, {"y", "2"}, {"z", "3"}, {"junk", "zzz"}}, {{"x", "5"}, {"y", "6"}, {"z", "8"}, {"junk", "nnn"}},
+        {{"x", "0"}, {"y", "5"}, {"z", "3"}, {"junk", "xxx"}}, {{"x", "8"}, {"y", "9"}, {"z", "1"}, {"junk", "aaa"}},
+        {{"x", "7"}, {"y", "4"}, {"z", "0"}, {"junk", "bbb"}}, {{"x", "5"}, {"y", "6"}, {"z", "9"}, {"junk", "iii"}},
+        {{"x", "2"}, {"y", "6"}, {"z", "7"}, {"junk", "mmm"}},
+    };
+    auto [index, err] = TakeRows(rows).IndexOn({"x", "y", "z"});
+    CHECK(!err);
+    auto r = index->find({"1", "2", "3"});
+    CHECK(r.second - r.first == 1 && index->rows()[r.first].at("junk") == "zzz");
+    r = index->find({"5", "6", "8"});
+    CHECK(r.second - r.first == 1 && index->rows()[r.first].at("junk") == "nnn");
+    r = index->find({"5", "6"});
+    CHECK(r.second - r.first == 2);
+    for (size_t i = r.first; i < r.second; i++) CHECK(index->rows()[i].at("x") == "5" && index->rows()[i].at("y") == "6");
+    const char* want[] = {"xxx", "zzz", "mmm", "nnn", "iii", "bbb", "aaa"};
+    for (int i = 0; i < 7; i++) CHECK(index->rows()[i].at("junk") == want[i]);
+}
+
+// ---- TestSimpleUniqueJoin (csvplus_test.go:368-452) ---------------------------------------------------------
+static void TestSimpleUniqueJoin() {
+    auto people = SelectColumns(TakeRows(peopleRows), {"id", "name", "surname"});
+    auto orders = SelectColumns(TakeRows(ordersRows), {"order_id", "cust_id", "qty"});
+    auto [idIndex, err] = people.UniqueIndexOn({"id"});
+    CHECK(!err);
+    std::vector<int> qtyMap(peopleData.size(), 0);
+    uint64_t seen = 0;
+    err = orders.Join(idIndex, {"cust_id"})([&](Row row) -> Error {
+        int id = atoi_s(row.at("id")), orderID = atoi_s(row.at("order_id")), custID = atoi_s(row.at("cust_id")),
+            qty = atoi_s(row.at("qty"));
+        if (id >= (int)peopleData.size()) return Error("Invalid id");
+        if (peopleData[id].Name != row.at("name") || peopleData[id].Surname != row.at("surname"))
+            return Error("Invalid parameters associated with id");
+        if (id != custID) return Error("id != cust_id");
+        if (orderID != (int)seen) return Error("orders out of stream order");   // emission = stream order
+        if (ordersData[orderID].custID != custID || ordersData[orderID].qty != qty) return Error("bad order data");
+        if (row.size() != 6) return Error("Invalid number of columns");
+        qtyMap[id] += qty;
+        seen++;
+        return Error();
+    });
+    if (err) std::printf("  Join failed: %s\n", err.message().c_str());
+    CHECK(!err);
+    CHECK(seen == (uint64_t)numOrders);
+    std::vector<int> origMap(peopleData.size(), 0);
+    for (auto& d : ordersData) origMap[d.custID] += d.qty;
+    CHECK(qtyMap == origMap);
+}
+
+// ---- TestSorted (csvplus_test.go:454-514) ------------------------------------------------------------------------
+static void TestSorted() {
+    auto people = TakeRows(peopleRows);
+    auto [index, err] = people.UniqueIndexOn({"name", "surname"});
+    CHECK(!err);
+    for (int i = 0; i < kSurnames; i++) CHECK(index->rows()[i].at("name") == "Amelia");
+    for (int i = kSurnames; i < 2 * kSurnames; i++) CHECK(index->rows()[i].at("name") == "Ava");
+    int n = 0;
+    err = Top(Take(index), kSurnames)([&](Row row) { n++; return row.at("name") == "Amelia" ? Error() : Error("Unexpected name"); });
+    CHECK(!err && n == kSurnames);
+    std::tie(index, err) = people.UniqueIndexOn({"surname", "name"});
+    CHECK(!err);
+    for (int i = kNames; i < 2 * kNames; i++) CHECK(index->rows()[i].at("surname") == "Davies");
+}
+
+// ---- TestSimpleTotals (csvplus_test.go:516-571): natural join ---------------------------------------------------------
+static void TestSimpleTotals() {
+    auto orders = SelectColumns(TakeRows(ordersRows), {"cust_id", "prod_id", "qty"});
+    auto products = SelectColumns(TakeRows(stockRows), {"prod_id", "price"});
+    auto [prodIndex, err] = products.UniqueIndexOn({"prod_id"});
+    CHECK(!err);
+    std::vector<double> totals(peopleData.size(), 0), orig(peopleData.size(), 0);
+    err = orders.Join(prodIndex)([&](Row row) {
+        int id = atoi_s(row.at("cust_id"));
+        totals[id] = std::atof(row.at("price").c_str()) * atoi_s(row.at("qty"));
+        return Error();
+    });
+    CHECK(!err);
+    for (auto& o : ordersData) orig[o.custID] = stockItems[o.prodID].price * o.qty;
+    for (size_t i = 0; i < totals.size(); i++) CHECK(std::fabs((totals[i] - orig[i]) / totals[i]) <= 1e-6);
+}
+
+// ---- TestLongChain (csvplus_test.go:248-366) -----------------------------------------------------------------------------
+static void TestLongChain() {
+    auto [orders, err] = SelectColumns(TakeRows(ordersRows), {"order_id", "cust_id", "prod_id", "qty", "ts"}).IndexOn({"cust_id"});
+    CHECK(!err);
+    auto [products, err2] = SelectColumns(TakeRows(stockRows), {"prod_id", "product", "price"}).UniqueIndexOn({"prod_id"});
+    CHECK(!err2);
+    auto people = SelectColumns(TakeRows(peopleRows), {"id", "name", "surname", "born"});
+    int n = 0;
+    auto chain = DropColumns(
+        Top(Filter(Map(DropColumns(DropColumns(SelectColumns(Filter(people, [](const Row& r) { return atoi_s(r.at("born")) > 1970; }),
+                                                             {"id", "name", "surname"})
+                                                   .Join(orders, {"id"}),
+                                               {"ts", "order_id", "cust_id"})
+                                       .Join(products),
+                                   {"prod_id"}),
+                       [](Row row) { if (row["name"] == "Amelia") row["name"] = "Julia"; return row; }),
+                   [](const Row& r) { return r.at("surname") == "Smith"; }),
+            10),
+        {"id"});
+    Error e = chain([&](Row row) -> Error {
+        if (++n > 10) return Error("Too many rows");
+        if (row.at("surname") != "Smith") return Error("Surname \"Smith\" not found");
+        if (row.at("name") == "Amelia") return Error("Name \"Amelia\" found");
+        if (!SelectExisting(row, {"born", "ts", "order_id", "prod_id", "cust_id"}).empty()) return Error("Some deleted fields are still there");
+        if (row.size() != 5) return Error("Unexpected number of columns: " + std::to_string(row.size()));
+        return Error();
+    });
+    if (e) std::printf("  chain: %s\n", e.message().c_str());
+    CHECK(!e);
+    CHECK(n == 10);
+    // the indices are unchanged afterwards (:325-365)
+    n = 0;
+    e = Take(orders)([&](Row row) { n++; return row.size() == 5 ? Error() : Error("bad order row"); });
+    CHECK(!e && n == numOrders);
+    n = 0;
+    e = Take(products)([&](Row) { n++; return Error(); });
+    CHECK(!e && n == kStock);
+}
+
+// ---- TestMultiIndex (csvplus_test.go:573-649) -------------------------------------------------------------------------------
+static void TestMultiIndex() {
+    auto source = SelectColumns(TakeRows(peopleRows), {"id", "name", "surname"});
+    auto [index, err] = source.UniqueIndexOn({"name", "surname"});
+    CHECK(!err);
+    auto neverCalled = [](Row) { return Error("This must never be called"); };
+    CHECK(!index->Find({"xxx"})(neverCalled));
+    int cnt = 0;
+    CHECK(!index->Find({"Amelia"})([&](Row row) { cnt++; return row.at("name") == "Amelia" ? Error() : Error("bad name"); }));
+    CHECK(cnt == kSurnames);
+    for (int i = 0; i < kNames; i++) {   // self-join on each sub-index (:601-624)
+        std::map<std::string, int> surnames;
+        auto s = source.Join(index->SubIndex({peopleNames[i]}));
+        CHECK(!s([&](Row row) { surnames[row.at("surname")]++; return Error(); }));
+        CHECK((int)surnames.size() == kSurnames);
+        for (int j = 0; j < kSurnames; j++) CHECK(surnames[peopleSurnames[j]] == kNames);
+    }
+    for (auto& p : peopleData) {
+        int count = 0;
+        CHECK(!index->Find({p.Name, p.Surname})([&](Row) { count++; return Error(); }));
+        CHECK(count == 1);
+    }
+    CHECK(!index->Find({"Jack", "xxx"})(neverCalled));
+}
+
+// ---- TestExcept (csvplus_test.go:651-693) --------------------------------------------------------------------------------------
+static void TestExcept() {
+    const std::string name = "Emily";
+    auto [people, err] = Filter(SelectColumns(TakeRows(peopleRows), {"id", "name", "surname"}),
+                                [&](const Row& r) { return r.at("name") == name; }).IndexOn({"id"});
+    CHECK(!err);
+    int n = 0, m = 0;
+    Error e = SelectColumns(TakeRows(ordersRows), {"cust_id", "prod_id", "qty"}).Except(people, {"cust_id"})([&](Row row) {
+        if (peopleData[atoi_s(row.at("cust_id"))].Name == name) return Error("Cust. id somehow got through");
+        n++;
+        return Error();
+    });
+    CHECK(!e);
+    for (auto& o : ordersData) if (peopleData[o.custID].Name != name) m++;
+    CHECK(n == m);
+}
+
+// ---- TestErrors, index-related parts (csvplus_test.go:825-883) --------------------------------------------------------------------
+static void TestErrors() {
+    auto source = SelectColumns(TakeRows(peopleRows), {"id", "name", "surname"});
+    auto [ix, err] = source.IndexOn({"name", "xxx"});
+    CHECK(ix == nullptr && err && hasSuffix(err.message(), "missing column \"xxx\" while creating an index"));
+    CHECK(err.is_data_source_error() && err.line() == 0);   // iterate wraps with the 0-based row (:242-245)
+    std::tie(ix, err) = source.UniqueIndexOn({"name"});
+    CHECK(ix == nullptr && err && err.message().find("duplicate value while creating unique index:") != std::string::npos);
+    CHECK(err.message() == "duplicate value while creating unique index: { \"name\" : \"Amelia\" }");
+    bool panicked = false;
+    try { source.IndexOn({}); } catch (const Panic&) { panicked = true; }
+    CHECK(panicked);
+    panicked = false;
+    try { source.IndexOn({"id", "name", "id"}); } catch (const Panic&) { panicked = true; }
+    CHECK(panicked);
+    std::tie(ix, err) = source.IndexOn({"id"});
+    CHECK(!err);
+    panicked = false;
+    try { ix->SubIndex({"aaa", "bbb"}); } catch (const Panic&) { panicked = true; }
+    CHECK(panicked);
+    panicked = false;
+    try { source.Join(ix, {"id", "name"}); } catch (const Panic&) { panicked = true; }   // :548-550
+    CHECK(panicked);
+    // missing join column: rows before the bad one are delivered, then the error surfaces (:556, :145)
+    std::vector<Row> rows = {{{"id", "3"}}, {{"id", "4"}}, {{"nope", "1"}}, {{"id", "5"}}};
+    int delivered = 0;
+    Error e = TakeRows(rows).Join(ix)([&](Row) { delivered++; return Error(); });
+    CHECK(e && hasSuffix(e.message(), "missing column \"id\"") && delivered == 2);
+    CHECK(e.is_data_source_error() && e.line() == 2);
+}
+
+// ---- laziness across the batched boundary ------------------------------------------------------------------------
+static void TestBatchingSemantics() {
+    auto [ix, err] = SelectColumns(TakeRows(peopleRows), {"id", "name"}).UniqueIndexOn({"id"});
+    CHECK(!err);
+    auto orders = SelectColumns(TakeRows(ordersRows), {"order_id", "cust_id"});
+    std::vector<std::string> ref;
+    for (size_t batch : {(size_t)1, (size_t)7, (size_t)8192, (size_t)100000}) {
+        Gpu::Default().join_batch_rows = batch;
+        std::vector<std::string> got;
+        Error e = orders.Join(ix, {"cust_id"})([&](Row row) { got.push_back(row.at("order_id") + ":" + row.at("name")); return Error(); });
+        CHECK(!e && got.size() == (size_t)numOrders);
+        if (ref.empty()) ref = got; else CHECK(got == ref);
+        // early stop: io.EOF after 5 rows ends the whole pipeline cleanly
+        int k = 0;
+        e = orders.Join(ix, {"cust_id"})([&](Row) { return ++k == 5 ? io_EOF : Error(); });
+        CHECK(!e && k == 5);
+        // a callback error aborts and is reported through the source's DataSourceError wrapper
+        k = 0;
+        e = orders.Join(ix, {"cust_id"})([&](Row) { return ++k == 3 ? Error("boom") : Error(); });
+        CHECK(e && e.message().find("boom") != std::string::npos && k == 3);
+    }
+    Gpu::Default().join_batch_rows = 8192;
+    // stream value wins on a column-name collision (mergeRows :578-580)
+    std::vector<Row> stream = {{{"id", "7"}, {"name", "STREAM"}}};
+    Error e = TakeRows(stream).Join(ix)([&](Row row) { return row.at("name") == "STREAM" ? Error() : Error("index value won"); });
+    CHECK(!e);
+}
+
+int main() {
+    makeFixtures();
+    struct T { const char* name; void (*fn)(); };
+    const T tests[] = {{"TestIndexImpl", TestIndexImpl}, {"TestSimpleUniqueJoin", TestSimpleUniqueJoin},
+                       {"TestSorted", TestSorted}, {"TestSimpleTotals", TestSimpleTotals},
+                       {"TestLongChain", TestLongChain}, {"TestMultiIndex", TestMultiIndex},
+                       {"TestExcept", TestExcept}, {"TestErrors", TestErrors},
+                       {"TestBatchingSemantics", TestBatchingSemantics}};
+    int bad = 0;
+    for (auto& t : tests) {
+        int before = g_failed;
+        try {
+            t.fn();
+        } catch (const std::exception& e) {
+            std::printf("  exception: %s\n", e.what());
+            g_failed++;
+        }
+        std::printf("%s %s\n", g_failed == before ? "PASS" : "FAIL", t.name);
+        if (g_failed != before) bad++;
+    }
+    std::printf("%d of %zu host tests failed\n", bad, sizeof tests / sizeof tests[0]);
+    return bad ? 1 : 0;
+}

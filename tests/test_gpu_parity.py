@@ -1,0 +1,332 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle.
+
+Bar: bit-exact.  perm, first_dup, (lo,cnt) and the (probe_idx, build_row)
+pair list must equal the oracle's; for duplicate keys both sides use the canonical stable
+order (input order inside an equal-key group)."""
+import numpy as np
+import pytest
+
+from csvplus_amd import DeviceIndex, StrCol, _native as N, datagen as dg
+from oracle import orc
+from tests.helpers import (PEOPLE_NAMES, PEOPLE_SURNAMES, assert_join_equal, cols_of, orders_table, people_table,
+                           random_keys, stock_table)
+from tests.test_oracle import INDEX_IMPL_ROWS
+
+pytestmark = pytest.mark.gpu
+
+
+def check_index(ctx, keycols, unique=False):
+    """Builds on GPU + oracle and compares perm / first_dup bit-exactly; returns both."""
+    g = DeviceIndex(ctx, keycols, unique=unique)
+    o = orc.OracleIndex(keycols)
+    np.testing.assert_array_equal(g.perm(), o.perm)
+    assert g.first_dup == o.first_dup()
+    if unique:
+        assert g.status == (N.CPH_ERR_DUPLICATE if o.first_dup() is not None else N.CPH_OK)
+    return g, o
+
+
+# ---- the reference's own tests, through the GPU path ------------------------------------------
+def test_index_impl_known_answer(ctx):
+    """TestIndexImpl (csvplus_test.go:198-246)."""
+    cols = [StrCol.from_values([r[i] for r in INDEX_IMPL_ROWS]) for i in range(3)]
+    g, o = check_index(ctx, cols)
+    assert [INDEX_IMPL_ROWS[i][3] for i in g.perm()] == ["xxx", "zzz", "mmm", "nnn", "iii", "bbb", "aaa"]
+    assert g.find(b"1", b"2", b"3") == o.find("1", "2", "3") == (1, 2)
+    assert g.find(b"5", b"6", b"8") == (3, 4)
+    assert g.find(b"5", b"6") == (3, 5)
+    assert g.find() == (0, 7)
+    lo, hi = g.find(b"9")
+    assert lo == hi
+
+
+def test_sorted(ctx):
+    """TestSorted (csvplus_test.go:454-514)."""
+    p = people_table()
+    g, _ = check_index(ctx, cols_of(p, "name", "surname"), unique=True)
+    names = [p["name"][i] for i in g.perm()]
+    assert names[:12] == ["Amelia"] * 12 and names[12:24] == ["Ava"] * 12
+    g, _ = check_index(ctx, cols_of(p, "surname", "name"), unique=True)
+    assert [p["surname"][i] for i in g.perm()][10:20] == ["Davies"] * 10
+
+
+def test_simple_unique_join(ctx):
+    """TestSimpleUniqueJoin (csvplus_test.go:368-452): differently named columns, 6-column rows."""
+    p, o = people_table(), orders_table()
+    g, orc_ix = check_index(ctx, cols_of(p, "id"), unique=True)
+    m = g.probe(cols_of(o, "cust_id"))
+    assert_join_equal(m, orc_ix.join(cols_of(o, "cust_id")))
+    assert m.nmatches == len(o["cust_id"])
+    qty = np.zeros(120, dtype=np.int64)
+    for pi, br in zip(m.probe_idx, m.build_row):
+        assert p["id"][br] == o["cust_id"][pi]
+        qty[int(p["id"][br])] += int(o["qty"][pi])
+    orig = np.zeros(120, dtype=np.int64)
+    for c, q in zip(o["cust_id"], o["qty"]):
+        orig[int(c)] += int(q)
+    np.testing.assert_array_equal(qty, orig)
+
+
+def test_simple_totals_natural_join(ctx):
+    """TestSimpleTotals (csvplus_test.go:516-571): natural join on prod_id."""
+    s, o = stock_table(), orders_table()
+    g, orc_ix = check_index(ctx, cols_of(s, "prod_id"), unique=True)
+    m = g.probe(cols_of(o, "prod_id"))
+    assert_join_equal(m, orc_ix.join(cols_of(o, "prod_id")))
+    assert m.nmatches == len(o["prod_id"])
+
+
+def test_long_chain_shape(ctx):
+    """TestLongChain (csvplus_test.go:252-285): non-unique IndexOn(cust_id) as build side, then a second
+    natural join on prod_id of the joined rows (chained probe via row selection)."""
+    p, o, s = people_table(), orders_table(), stock_table()
+    g_orders, o_orders = check_index(ctx, cols_of(o, "cust_id"))
+    assert g_orders.first_dup is not None
+    m1 = g_orders.probe(cols_of(p, "id"))
+    j1 = o_orders.join(cols_of(p, "id"))
+    assert_join_equal(m1, j1)
+    assert m1.nmatches == len(o["cust_id"])
+    # second join: key prod_id comes from the INDEX side rows of join 1 (orders), so select by build_row
+    g_prod, o_prod = check_index(ctx, cols_of(s, "prod_id"), unique=True)
+    sel = m1.build_row
+    m2 = g_prod.probe(cols_of(o, "prod_id"), row_sel=sel)
+    j2 = o_prod.join(cols_of(o, "prod_id"), row_sel=sel)
+    assert_join_equal(m2, j2)
+    assert m2.nmatches == m1.nmatches
+    for k in range(0, m2.nmatches, 97):
+        order_row = sel[int(m2.probe_idx[k])]
+        assert s["prod_id"][m2.build_row[k]] == o["prod_id"][order_row]
+
+
+def test_multi_index_find_and_prefix_join(ctx):
+    """TestMultiIndex (csvplus_test.go:573-649) + prefix join (csvplus.go:546-550)."""
+    p, o = people_table(), orders_table()
+    g, oi = check_index(ctx, cols_of(p, "name", "surname"), unique=True)
+    lo, hi = g.find(b"xxx")
+    assert lo == hi
+    assert g.find(b"Amelia") == oi.find("Amelia")
+    for n, s in zip(p["name"], p["surname"]):
+        assert g.find(n.encode(), s.encode()) == oi.find(n, s)
+    lo, hi = g.find(b"Jack", b"xxx")
+    assert lo == hi
+    # self-join on the leading column only: every row matches its 12 namesakes
+    m = g.probe(cols_of(p, "name"))
+    assert_join_equal(m, oi.join(cols_of(p, "name")))
+    assert m.nmatches == 120 * 12
+    # bigger: IndexOn(cust_id, prod_id) probed with people.id (BenchmarkJoinOnBiggerMultiIndex :1161-1186)
+    g2, o2 = check_index(ctx, cols_of(o, "cust_id", "prod_id"))
+    m = g2.probe(cols_of(p, "id"))
+    assert_join_equal(m, o2.join(cols_of(p, "id")))
+    assert m.nmatches == len(o["cust_id"])
+    for c in ("0", "7", "119"):
+        assert g2.find(c.encode()) == o2.find(c)
+        assert g2.find(c.encode(), b"3") == o2.find(c, "3")
+
+
+def test_except_via_cnt(ctx):
+    """TestExcept (csvplus_test.go:651-693)."""
+    p, o = people_table(), orders_table()
+    sub = {"id": [p["id"][i] for i, n in enumerate(p["name"]) if n == "Emily"]}
+    g, oi = check_index(ctx, cols_of(sub, "id"))
+    m = g.probe(cols_of(o, "cust_id"), want_pairs=False)
+    j = oi.join(cols_of(o, "cust_id"), want_pairs=False)
+    np.testing.assert_array_equal(m.cnt, j["cnt"])
+    assert int((m.cnt == 0).sum()) == sum(1 for c in o["cust_id"] if p["name"][int(c)] != "Emily")
+
+
+def test_errors(ctx):
+    """TestErrors (csvplus_test.go:836-841) + boundary errors."""
+    p = people_table()
+    g = DeviceIndex(ctx, cols_of(p, "name"), unique=True)
+    assert g.status == N.CPH_ERR_DUPLICATE
+    assert g.first_dup == 1 and p["name"][g.perm()[g.first_dup]] == "Amelia"
+    assert "duplicate value while creating unique index" in ctx.last_error()
+    g = DeviceIndex(ctx, cols_of(p, "id"))
+    with pytest.raises(N.CphError) as e:   # csvplus.go:548-550 "too many source columns in Join()"
+        g.probe(cols_of(p, "id", "name"))
+    assert e.value.code == N.CPH_ERR_TOO_MANY_COLS
+    with pytest.raises(N.CphError) as e:
+        DeviceIndex(ctx, [StrCol.from_values([b"x" * 200, b"y"])])
+    assert e.value.code == N.CPH_ERR_KEY_TOO_LONG
+    with pytest.raises(N.CphError) as e:
+        DeviceIndex(ctx, [StrCol.from_values(["a", "b"]), StrCol.from_values(["a"])])
+    assert e.value.code == N.CPH_ERR_INVALID
+
+
+# ---- edge cases ---------------------------------------------------------
+def test_strings_compare_edge_cases(ctx):
+    keys = [b"a", b"", b"a\x00", b"ab", b"\xff", b"a\x00\x00", b"\x00", b"b", b"a", b"\xff\xff", b"a\x01"]
+    g, oi = check_index(ctx, [StrCol.from_values(keys)])
+    assert [keys[i] for i in g.perm()] == sorted(keys)
+    probe = [b"a", b"", b"zzz", b"a\x00", b"\x00\x00", b"a\x00\x00\x00", b"c", b"\xfe"]
+    assert_join_equal(g.probe([StrCol.from_values(probe)]), oi.join([StrCol.from_values(probe)]))
+
+
+def test_empty_tables(ctx):
+    g, oi = check_index(ctx, [StrCol.from_values([])])
+    m = g.probe([StrCol.from_values(["x", ""])])
+    assert m.nmatches == 0 and m.cnt.tolist() == [0, 0]
+    assert g.find(b"x") == (0, 0) and g.find() == (0, 0)
+    g, oi = check_index(ctx, [StrCol.from_values(["", "", "q"])])
+    m = g.probe([StrCol.from_values([])])
+    assert m.nprobe == 0 and m.nmatches == 0
+    assert_join_equal(g.probe([StrCol.from_values(["", "q", "x"])]), oi.join([StrCol.from_values(["", "q", "x"])]))
+    # all keys empty
+    g, oi = check_index(ctx, [StrCol.from_values(["", "", ""])])
+    assert_join_equal(g.probe([StrCol.from_values(["", "a"])]), oi.join([StrCol.from_values(["", "a"])]))
+
+
+def test_all_equal_keys(ctx):
+    keys = ["same"] * 5000
+    g, oi = check_index(ctx, [StrCol.from_values(keys)])
+    pr = [StrCol.from_values(["same", "other", "same"])]
+    assert_join_equal(g.probe(pr), oi.join(pr))
+
+
+@pytest.mark.parametrize("offset_bits", [32, 64])
+@pytest.mark.parametrize("case", ["bytes_any", "ascii_dups", "short_binary", "long_keys", "two_cols", "three_cols_dups"])
+def test_random_property(ctx, case, offset_bits):
+    rng = np.random.default_rng(hash(case) % 2**32)
+    n, m = 20000, 30000
+    if case == "bytes_any":
+        b = [random_keys(rng, n, 0, 12)]
+        p = [random_keys(rng, m // 2, 0, 12) + [b[0][i] for i in rng.integers(0, n, m - m // 2)]]
+    elif case == "ascii_dups":
+        b = [random_keys(rng, n, 1, 6, alphabet=list(b"0123456789"), distinct=3000)]
+        p = [random_keys(rng, m, 1, 6, alphabet=list(b"0123456789"))]
+    elif case == "short_binary":
+        b = [random_keys(rng, n, 0, 3, alphabet=[0, 1, 255])]
+        p = [random_keys(rng, m, 0, 4, alphabet=[0, 1, 2, 255])]
+    elif case == "long_keys":
+        b = [random_keys(rng, n, 20, 40, alphabet=list(b"abcdefghijklmnopqrstuvwxyz/#"), distinct=7000)]
+        p = [[b[0][i] for i in rng.integers(0, n, m)]]
+        p[0][::7] = random_keys(rng, len(p[0][::7]), 20, 40, alphabet=list(b"abcxyz/#"))
+    elif case == "two_cols":
+        b = [random_keys(rng, n, 0, 5, alphabet=list(b"abc"), distinct=200),
+             random_keys(rng, n, 0, 9, alphabet=list(b"0123456789"), distinct=500)]
+        idx = rng.integers(0, n, m)
+        p = [[b[0][i] for i in idx], [b[1][i] for i in rng.integers(0, n, m)]]
+    else:
+        b = [random_keys(rng, n, 1, 3, alphabet=list(b"xy"), distinct=4),
+             random_keys(rng, n, 0, 2, alphabet=list(b"01"), distinct=5),
+             random_keys(rng, n, 1, 2, alphabet=list(b"pq"), distinct=3)]
+        p = [[b[c][i] for i in rng.integers(0, n, 2000)] for c in range(3)]
+    bcols = [StrCol.from_values(x, offset_bits=offset_bits) for x in b]
+    pcols = [StrCol.from_values(x, offset_bits=offset_bits) for x in p]
+    g, oi = check_index(ctx, bcols)
+    keys = list(zip(*[[x[i] for i in g.perm()] for x in b]))
+    assert keys == sorted(keys)
+    assert_join_equal(g.probe(pcols), oi.join(pcols))
+    for k in range(1, len(bcols)):   # prefix joins on the leading k columns
+        assert_join_equal(g.probe(pcols[:k]), oi.join(pcols[:k]))
+    for r in rng.integers(0, n, 20):   # Find bounds on full and prefix tuples
+        for k in range(1, len(bcols) + 1):
+            vals = [x[r] for x in b[:k]]
+            assert g.find(*vals) == oi.find(*vals)
+
+
+def test_pdqsort_emulation_parity_class(ctx):
+    """P1: vs the emulated Go sort.Sort the key sequence and the per-key row multisets agree."""
+    o = orders_table()
+    cols = cols_of(o, "cust_id")
+    g = DeviceIndex(ctx, cols)
+    go = orc.OracleIndex(cols, orc.SORT_GO_PDQSORT)
+    gp, op = g.perm(), go.perm
+    keys_g = [o["cust_id"][i] for i in gp]
+    assert keys_g == [o["cust_id"][i] for i in op]
+    bounds = [0] + [i for i in range(1, len(keys_g)) if keys_g[i] != keys_g[i - 1]] + [len(keys_g)]
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        assert sorted(gp[a:b].tolist()) == sorted(op[a:b].tolist())
+
+
+# ---- generated tables (BASELINE.json configs, scaled to oracle-in-seconds sizes) ---------------
+@pytest.mark.parametrize("enc", [dg.FIXED8, dg.ITOA])
+def test_config1_unique_index_and_join(ctx, enc):
+    """config 1: 1e5 people + orders, UniqueIndexOn(id) then Join."""
+    n = 100_000
+    cust = dg.customers(n, encoding=enc)
+    ords = dg.orders(n, n, 1000, cust_encoding=enc)
+    g, oi = check_index(ctx, [cust["id"]], unique=True)
+    assert g.status == N.CPH_OK
+    m = g.probe([ords["cust_id"]])
+    assert_join_equal(m, oi.join([ords["cust_id"]]))
+    assert m.nmatches == n
+    info = g.info()
+    assert info["direct_table"] == 1 and info["key_bytes"] == 4
+
+
+def test_config3_varlen_duplicates(ctx):
+    """config 3 shape: variable-length 10-22 byte keys with duplicates (multi-word codes)."""
+    n = 300_000
+    keys = dg.varkeys(n, 2000)
+    g, oi = check_index(ctx, [keys])
+    assert g.info()["code_words"] >= 1
+    probe = dg.varkeys(50_000, 2500, seed=99)
+    assert_join_equal(g.probe([probe]), oi.join([probe]))
+
+
+def test_chained_join_config4_shape(ctx):
+    """config 4 shape: orders JOIN customers JOIN products, chained on the device via row selection."""
+    nc, npd, m = 50_000, 1000, 200_000
+    cust, prod = dg.customers(nc), dg.products(npd)
+    ords = dg.orders(m, nc, npd)
+    gc, oc = check_index(ctx, [cust["id"]], unique=True)
+    gp, op = check_index(ctx, [prod["prod_id"]], unique=True)
+    m1 = gc.probe([ords["cust_id"]], probe_base=1000)
+    j1 = oc.join([ords["cust_id"]], probe_base=1000)
+    assert_join_equal(m1, j1)
+    sel64 = m1.probe_idx   # uint64, base 1000: exactly what a second chained probe consumes
+    m2 = gp.probe([ords["prod_id"]], row_sel=sel64, sel_base=1000)
+    j2 = op.join([ords["prod_id"]], row_sel=(sel64 - 1000).astype(np.uint32))
+    assert_join_equal(m2, j2)
+    assert m2.nmatches == m
+
+
+def test_device_resident_inputs_and_outputs(ctx):
+    """mem = CPH_MEM_DEVICE on both sides gives the same bits as the host path."""
+    import torch
+
+    n = 60_000
+    cust = dg.customers(n)
+    ords = dg.orders(80_000, n, 100)
+    gh = DeviceIndex(ctx, [cust["id"]], unique=True)
+    gd = DeviceIndex(ctx, [cust["id"].to_device()], unique=True)
+    np.testing.assert_array_equal(gh.perm(), gd.perm())
+    mh = gh.probe([ords["cust_id"]])
+    md = gd.probe([ords["cust_id"].to_device()], out_mem=N.CPH_MEM_DEVICE)
+    assert md.nmatches == mh.nmatches
+    ptrs = md.device_ptrs()
+
+    def dev_array(ptr, count, dtype):
+        class _W:   # zero-copy view through __cuda_array_interface__
+            __cuda_array_interface__ = {"shape": (count,), "typestr": dtype, "data": (ptr, False), "version": 2}
+        return torch.as_tensor(_W(), device="cuda:0").cpu().numpy()
+
+    np.testing.assert_array_equal(dev_array(ptrs["cnt"], md.nprobe, "<i4").view(np.uint32), mh.cnt)
+    np.testing.assert_array_equal(dev_array(ptrs["probe_idx"], md.nmatches, "<i8").view(np.uint64), mh.probe_idx)
+    np.testing.assert_array_equal(dev_array(ptrs["build_row"], md.nmatches, "<i4").view(np.uint32), mh.build_row)
+
+
+def test_config2_properties_1e7(ctx):
+    """config 2 at full size (1e7 unique 8-byte keys + 1e7 probes): size-independent properties, plus the
+    oracle on a 2e5-row probe sample."""
+    n = 10_000_000
+    cust_id = dg.column(dg.SEQ_PERM, n, n, encoding=dg.FIXED8, seed=dg.SEED + 1)
+    ords = dg.column(dg.UNIFORM, n, n, encoding=dg.FIXED8, seed=dg.SEED + 3)
+    g = DeviceIndex(ctx, [cust_id], unique=True)
+    assert g.status == N.CPH_OK and g.first_dup is None
+    perm = g.perm()
+    # perm is a permutation and keys ascend: ids are fixed-width decimals, so sorted order == numeric order,
+    # and id(row) = feistel_perm(row): the sorted position of row r must be its id
+    ids = np.frombuffer(cust_id.data, dtype=np.uint8).reshape(n, 8) - ord("0")
+    val = (ids.astype(np.int64) * (10 ** np.arange(7, -1, -1, dtype=np.int64))).sum(axis=1)
+    np.testing.assert_array_equal(val[perm], np.arange(n, dtype=np.int64))
+    m = g.probe([ords])
+    assert m.nmatches == n and int(m.cnt.min()) == 1 == int(m.cnt.max())
+    np.testing.assert_array_equal(m.probe_idx, np.arange(n, dtype=np.uint64))
+    ov = (np.frombuffer(ords.data, dtype=np.uint8).reshape(n, 8) - ord("0")).astype(np.int64)
+    ov = (ov * (10 ** np.arange(7, -1, -1, dtype=np.int64))).sum(axis=1)
+    np.testing.assert_array_equal(val[m.build_row], ov)          # every pair joins equal keys
+    np.testing.assert_array_equal(m.lo.astype(np.int64), ov)      # lo == sorted position == id
+    info = g.info()
+    assert info["sort_passes"] == 3 and info["key_bytes"] == 4 and info["code_bits"] == 24
