@@ -10,34 +10,13 @@
 //   k_find          Find/SubIndex bounds (csvplus.go:870-891)
 //
 // Integer / byte work bound by HBM + cache bandwidth; no MFMA.
-#include "codec_device.hpp"
+#include "probe_device.hpp"
 
 namespace cph {
 
 constexpr int kProbeThreads = 256;
 constexpr int kProbeItems   = 8;
 constexpr int kProbeTile    = kProbeThreads * kProbeItems;   // 2048 probe rows per workgroup
-
-struct TableEntry { uint32_t lo, end; };
-
-// ---- searches over one sorted code word restricted to [lo,hi) --------------------------------
-// sort.Search shape (Go stdlib): smallest i in [lo,hi) with pred(i), else hi.
-template <class K>
-__device__ __forceinline__ uint64_t lower_bound_dev(const K* __restrict__ a, uint64_t lo, uint64_t hi, K v) {
-    while (lo < hi) {
-        const uint64_t h = (lo + hi) >> 1;
-        if (a[h] < v) lo = h + 1; else hi = h;
-    }
-    return lo;
-}
-template <class K>
-__device__ __forceinline__ uint64_t upper_bound_dev(const K* __restrict__ a, uint64_t lo, uint64_t hi, K v) {
-    while (lo < hi) {
-        const uint64_t h = (lo + hi) >> 1;
-        if (a[h] <= v) lo = h + 1; else hi = h;
-    }
-    return lo;
-}
 
 // ---------------------------------------------------------------------------------------------
 // unique check
@@ -91,13 +70,18 @@ Status index_first_dup(cph_ctx* ctx, const cph_index* ix, uint64_t* first_dup) {
 // ---------------------------------------------------------------------------------------------
 // direct-address table: entry[code] = {lo, end}; absent codes stay {0,0} (cnt 0)
 // ---------------------------------------------------------------------------------------------
-template <class K>
-__global__ void k_build_table(const K* __restrict__ codes, uint64_t n, TableEntry* __restrict__ table) {
+template <class K, bool UNIQUE>
+__global__ void k_build_table(const K* __restrict__ codes, const uint32_t* __restrict__ perm, uint64_t n,
+                              TableEntry* __restrict__ table) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const K c = codes[i];
-        if (i == 0 || codes[i - 1] != c) table[c].lo = (uint32_t)i;
-        if (i + 1 == n || codes[i + 1] != c) table[c].end = (uint32_t)(i + 1);
+        if constexpr (UNIQUE) {
+            table[c] = TableEntry{(uint32_t)i, perm[i]};
+        } else {
+            if (i == 0 || codes[i - 1] != c) table[c].a = (uint32_t)i;
+            if (i + 1 == n || codes[i + 1] != c) table[c].b = (uint32_t)(i + 1);
+        }
     }
 }
 
@@ -110,16 +94,23 @@ Status index_build_table(cph_ctx* ctx, cph_index* ix) {
     if (limit < (1ull << 20)) limit = 1ull << 20;
     if (states > limit || states > (1ull << 30)) return {};
     CPH_TRY(ix->table.alloc(&ctx->pool, states * sizeof(TableEntry)));
-    CPH_HIP_TRY(hipMemsetAsync(ix->table.get(), 0, states * sizeof(TableEntry), ctx->stream));
+    const bool uniq = ix->first_dup == UINT64_MAX;   // entry format, see probe_device.hpp
+    CPH_HIP_TRY(hipMemsetAsync(ix->table.get(), uniq ? 0xFF : 0, states * sizeof(TableEntry), ctx->stream));
     uint64_t nblk = (n + 255) / 256;
     if (nblk > 8192) nblk = 8192;
-    ProfScope ps(ctx, "k_build_table", (double)n * (ix->codec.key32 ? 4.0 : 8.0) + 8.0 * (double)n);
-    if (ix->codec.key32)
-        hipLaunchKernelGGL(k_build_table<uint32_t>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream,
-                           ix->sorted_codes.as<uint32_t>(), n, ix->table.as<TableEntry>());
-    else
-        hipLaunchKernelGGL(k_build_table<uint64_t>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream,
-                           ix->sorted_codes.as<uint64_t>(), n, ix->table.as<TableEntry>());
+    ProfScope ps(ctx, "k_build_table", (double)n * (ix->codec.key32 ? 4.0 : 8.0) + 4.0 * (double)n + 8.0 * (double)n);
+    const dim3 grid((unsigned)nblk), block(256);
+    const uint32_t* perm = ix->perm.as<uint32_t>();
+    TableEntry* tab = ix->table.as<TableEntry>();
+    if (ix->codec.key32) {
+        const uint32_t* codes = ix->sorted_codes.as<uint32_t>();
+        if (uniq) hipLaunchKernelGGL((k_build_table<uint32_t, true>), grid, block, 0, ctx->stream, codes, perm, n, tab);
+        else hipLaunchKernelGGL((k_build_table<uint32_t, false>), grid, block, 0, ctx->stream, codes, perm, n, tab);
+    } else {
+        const uint64_t* codes = ix->sorted_codes.as<uint64_t>();
+        if (uniq) hipLaunchKernelGGL((k_build_table<uint64_t, true>), grid, block, 0, ctx->stream, codes, perm, n, tab);
+        else hipLaunchKernelGGL((k_build_table<uint64_t, false>), grid, block, 0, ctx->stream, codes, perm, n, tab);
+    }
     CPH_HIP_TRY(hipGetLastError());
     ix->table_entries = states;
     return {};
@@ -132,7 +123,7 @@ template <bool KEY32, bool TABLE>
 __global__ __launch_bounds__(kProbeThreads) void k_probe(ColsArg cols, int ncols_used,
                                                         const uint8_t* __restrict__ g_codec,
                                                         const void* __restrict__ codes, uint64_t n_index,
-                                                        const TableEntry* __restrict__ table,
+                                                        const TableEntry* __restrict__ table, bool table_unique,
                                                         RowSel sel, uint64_t nprobe,
                                                         uint32_t* __restrict__ out_lo, uint32_t* __restrict__ out_cnt,
                                                         uint64_t* __restrict__ tile_sums) {
@@ -157,8 +148,13 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(ColsArg cols, int ncols
             valid = encode_key(cv, cols, ncols_used, row, [&](int, uint64_t v, int) { code = v; });
             if (valid) {
                 const TableEntry e = table[code];
-                lo = e.lo;
-                hi = e.end;
+                if (table_unique) {
+                    lo = e.a;
+                    hi = e.a == kTableAbsent ? e.a : e.a + 1;
+                } else {
+                    lo = e.a;
+                    hi = e.b;
+                }
             }
         } else {
             valid = encode_key(cv, cols, ncols_used, row, [&](int word, uint64_t v, int p) {
@@ -285,6 +281,7 @@ static Status launch_probe(cph_ctx* ctx, const cph_index* ix, const ColsArg& arg
     ProfScope ps(ctx, TABLE ? "k_probe_table" : "k_probe_search", 0);
     hipLaunchKernelGGL((k_probe<KEY32, TABLE>), dim3(ntiles), dim3(kProbeThreads), lds, ctx->stream, arg, ncols,
                        ix->codec_dev.as<uint8_t>(), ix->sorted_codes.get(), ix->nrows, ix->table.as<TableEntry>(),
+                       ix->first_dup == UINT64_MAX,
                        row_sel, nprobe, lo, cnt, tile_sums);
     CPH_HIP_TRY(hipGetLastError());
     return {};
