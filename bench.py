@@ -81,14 +81,13 @@ def main():
     def step():
         ia = eng.index_on([d_cust], unique=True)
         ib = eng.index_on([d_prod], unique=True)
-        res = eng.chained_join(ia, d_ord["cust_id"], ib, d_ord["prod_id"], probe_base=begin)
-        out = (res.stream_row, res.a_row, res.b_row)
+        res = eng.chained_join([(ia, d_ord["cust_id"]), (ib, d_ord["prod_id"])], probe_base=begin)
+        out = (res.stream_row, res.build_rows[0], res.build_rows[1])
         if world > 1 and args.exchange == "allgatherv":
             out = tuple(allgatherv(t)[0] for t in out)
         n = int(out[0].numel())
         info = (ia.info(), ib.info())
-        for m in res.keep:
-            m.release()
+        res.release()
         ia.close()
         ib.close()
         return n, info
@@ -135,16 +134,17 @@ def main():
     # the model is documented in DESIGN.md §"Algorithmic bytes".
     ia_info, ib_info = info
     K = args.steps
+    total_joined_local = joined if world == 1 or args.exchange == "none" else nloc
     obytes = 4
     cust_bytes, prod_bytes = cust_id.nbytes_values(), prod_id.nbytes_values()
     extra = {
         "k_col_stats": K * ((cust_bytes + obytes * args.customers) + (prod_bytes + obytes * args.products)),
         "k_encode_build": K * ((cust_bytes + obytes * args.customers + ia_info["key_bytes"] * args.customers)
                                + (prod_bytes + obytes * args.products + ib_info["key_bytes"] * args.products)),
-        # probe: key bytes + offset + 8-byte table entry + (lo,cnt) out; the chained probe also reads
-        # its 8-byte row selection
-        "k_probe_table": K * ((host_bytes["cust_id"] + obytes * nloc + 16 * nloc)
-                              + (host_bytes["prod_id"] + obytes * nloc + 16 * nloc + 8 * nloc)),
+        # fused chain pass, per stream row: both keys' bytes + offsets in, one 8-byte table entry per
+        # step, (8 + 4 + 4)-byte row-id triple out per joined row
+        "k_chain_unique": K * (host_bytes["cust_id"] + host_bytes["prod_id"] + 2 * obytes * nloc + 2 * 8 * nloc
+                               + 16 * total_joined_local),
     }
     kernels = {}
     for name, st in prof.items():

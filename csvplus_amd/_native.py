@@ -96,6 +96,18 @@ class cph_index_info(C.Structure):
     ]
 
 
+CPH_MAX_CHAIN = 4
+
+
+class cph_chain_step(C.Structure):
+    _fields_ = [("index", C.c_void_p), ("cols", C.POINTER(cph_strcol)), ("ncols", C.c_int32), ("reserved_", C.c_int32)]
+
+
+class cph_chain(C.Structure):
+    _fields_ = [("nrows", C.c_uint64), ("stream_row", C.c_void_p), ("build_row", C.c_void_p * CPH_MAX_CHAIN),
+                ("nsteps", C.c_int32), ("mem", C.c_int32)]
+
+
 class cph_kernel_stat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double),
                 ("algo_bytes", C.c_double)]
@@ -125,6 +137,9 @@ PROTOTYPES = [
      [_P, _P, C.POINTER(cph_strcol), C.c_int32, _P, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32,
       C.c_int32, C.POINTER(C.POINTER(cph_matches))]),
     ("cph_matches_release", None, [C.POINTER(cph_matches)]),
+    ("cph_join_chain", C.c_int32,
+     [_P, C.POINTER(cph_chain_step), C.c_int32, C.c_uint64, C.c_int32, C.POINTER(C.POINTER(cph_chain))]),
+    ("cph_chain_release", None, [C.POINTER(cph_chain)]),
     ("cph_index_find", C.c_int32,
      [_P, _P, C.POINTER(cph_strval), C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("cph_index_get_info", C.c_int32, [_P, C.POINTER(cph_index_info)]),
@@ -316,6 +331,64 @@ class DeviceIndex:
     def __del__(self):
         try:
             self.close()
+        except Exception:
+            pass
+
+
+def join_chain(ctx: Context, steps, probe_base: int = 0, out_mem: int = CPH_MEM_HOST) -> "Chain":
+    """cph_join_chain: steps = [(DeviceIndex, [stream key columns]), ...]."""
+    arr = (cph_chain_step * len(steps))()
+    keep = []
+    for i, (index, cols) in enumerate(steps):
+        carr, k = _cols_array(cols)
+        keep.append((carr, k, index))
+        arr[i].index = index.handle
+        arr[i].cols = carr
+        arr[i].ncols = len(cols)
+    out = C.POINTER(cph_chain)()
+    rc = ctx.lib.cph_join_chain(ctx.handle, arr, len(steps), probe_base, out_mem, C.byref(out))
+    del keep
+    ctx._check(rc)
+    return Chain(ctx, out, [s[0] for s in steps])
+
+
+class Chain:
+    """Result of a chained join (cph_chain): row-id tuples in emission order."""
+
+    def __init__(self, ctx: Context, ptr, owners):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.ptr = ptr
+        self.owners = owners
+        c = ptr.contents
+        self.nrows = int(c.nrows)
+        self.nsteps = int(c.nsteps)
+        self.mem = int(c.mem)
+        ctx._children.add(self)
+
+    @property
+    def stream_row(self) -> np.ndarray:
+        assert self.mem == CPH_MEM_HOST
+        return _ptr_array(self.ptr.contents.stream_row, self.nrows, np.uint64).copy()
+
+    def build_row(self, k: int) -> np.ndarray:
+        assert self.mem == CPH_MEM_HOST
+        return _ptr_array(self.ptr.contents.build_row[k], self.nrows, np.uint32).copy()
+
+    def device_ptrs(self) -> dict:
+        c = self.ptr.contents
+        return {"stream_row": int(c.stream_row or 0), "build_row": [int(c.build_row[k] or 0) for k in range(self.nsteps)]}
+
+    def release(self):
+        if self.ptr:
+            self.lib.cph_chain_release(self.ptr)
+            self.ptr = None
+
+    close = release
+
+    def __del__(self):
+        try:
+            self.release()
         except Exception:
             pass
 

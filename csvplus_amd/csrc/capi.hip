@@ -569,6 +569,81 @@ CPH_API void cph_matches_release(cph_matches* pub) {
     delete m;
 }
 
+CPH_API int32_t cph_join_chain(cph_ctx* ctx, const cph_chain_step* steps, int32_t nsteps, uint64_t probe_base,
+                               int32_t out_mem, cph_chain** out) {
+    Status s = enter(ctx);
+    if (!s.ok()) return fail(ctx, s);
+    if (!steps || !out || nsteps < 1 || nsteps > CPH_MAX_CHAIN) return fail(ctx, {CPH_ERR_INVALID, "bad chain"});
+    if (out_mem != CPH_MEM_HOST && out_mem != CPH_MEM_DEVICE) return fail(ctx, {CPH_ERR_INVALID, "bad out_mem"});
+    *out = nullptr;
+    for (int k = 0; k < nsteps; k++) {
+        if (!steps[k].index) return fail(ctx, {CPH_ERR_INVALID, "chain step without index"});
+        if (steps[k].ncols > steps[k].index->nkeycols)
+            return fail(ctx, {CPH_ERR_TOO_MANY_COLS, "too many source columns in Join()"});
+        s = validate_cols(steps[k].cols, steps[k].ncols);
+        if (!s.ok()) return fail(ctx, s);
+        if (steps[k].cols[0].nrows != steps[0].cols[0].nrows)
+            return fail(ctx, {CPH_ERR_INVALID, "chain steps must use columns of one stream table"});
+    }
+    cph_chain_impl* c = new (std::nothrow) cph_chain_impl();
+    if (!c) return fail(ctx, {CPH_ERR_NOMEM, "out of host memory"});
+    c->ctx = ctx;
+    auto run = [&]() -> Status {
+        std::vector<DevBuf> staged;
+        ChainStep cs[CPH_MAX_CHAIN];
+        for (int k = 0; k < nsteps; k++) {
+            cs[k].index = steps[k].index;
+            cs[k].ncols = steps[k].ncols;
+            CPH_TRY(stage_cols(ctx, steps[k].cols, steps[k].ncols, &staged, cs[k].cols));
+        }
+        ChainOut co;
+        CPH_TRY(chain_run(ctx, cs, nsteps, probe_base, &co));
+        c->pub.nrows = co.nrows;
+        c->pub.nsteps = nsteps;
+        c->pub.mem = out_mem;
+        const uint64_t n = co.nrows;
+        if (out_mem == CPH_MEM_DEVICE) {
+            c->d_stream = std::move(co.stream_row);
+            c->pub.stream_row = n ? c->d_stream.as<uint64_t>() : nullptr;
+            for (int k = 0; k < nsteps; k++) {
+                c->d_rows[k] = std::move(co.build_row[k]);
+                c->pub.build_row[k] = n ? c->d_rows[k].as<uint32_t>() : nullptr;
+            }
+            CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        } else if (n) {
+            auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+            const size_t b64 = a16(n * sizeof(uint64_t)), b32 = a16(n * sizeof(uint32_t));
+            CPH_HIP_TRY(hipHostMalloc(&c->h_block, b64 + (size_t)nsteps * b32, hipHostMallocDefault));
+            uint8_t* h = static_cast<uint8_t*>(c->h_block);
+            CPH_HIP_TRY(hipMemcpyAsync(h, co.stream_row.get(), n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+            c->pub.stream_row = reinterpret_cast<const uint64_t*>(h);
+            for (int k = 0; k < nsteps; k++) {
+                uint8_t* hk = h + b64 + (size_t)k * b32;
+                CPH_HIP_TRY(hipMemcpyAsync(hk, co.build_row[k].get(), n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+                c->pub.build_row[k] = reinterpret_cast<const uint32_t*>(hk);
+            }
+            CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+        return {};
+    };
+    s = run();
+    if (!s.ok()) {
+        if (c->h_block) (void)hipHostFree(c->h_block);
+        delete c;
+        return fail(ctx, s);
+    }
+    *out = &c->pub;
+    return CPH_OK;
+}
+
+CPH_API void cph_chain_release(cph_chain* pub) {
+    if (!pub) return;
+    cph_chain_impl* c = reinterpret_cast<cph_chain_impl*>(pub);
+    if (c->ctx) (void)hipSetDevice(c->ctx->device);
+    if (c->h_block) (void)hipHostFree(c->h_block);
+    delete c;
+}
+
 CPH_API int32_t cph_index_find(cph_ctx* ctx, const cph_index* ix, const cph_strval* values, int32_t nvalues,
                                uint64_t* lower, uint64_t* upper) {
     Status s = enter(ctx);

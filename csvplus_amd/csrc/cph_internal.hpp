@@ -174,6 +174,14 @@ struct cph_index {
     uint32_t* perm_host = nullptr; // pinned copy (lazy)
 };
 
+struct cph_chain_impl {
+    cph_chain pub;                 // must stay first
+    cph_ctx* ctx = nullptr;
+    cph::DevBuf d_stream;
+    cph::DevBuf d_rows[CPH_MAX_CHAIN];
+    void* h_block = nullptr;
+};
+
 struct cph_matches_impl {
     cph_matches pub;               // must stay first: the public view
     cph_ctx* ctx = nullptr;
@@ -235,6 +243,20 @@ Status probe_run(cph_ctx* ctx, const cph_index* ix, const DevCol* cols, int32_t 
                  uint64_t nprobe, uint64_t probe_base, bool want_pairs, ProbeOut* out);
 Status index_find_device(cph_ctx* ctx, const cph_index* ix, const uint64_t* q_exact, int32_t nq, uint64_t qlo,
                          uint64_t qhi, uint64_t* lower, uint64_t* upper);
+
+// chain.hip
+struct ChainStep {
+    const cph_index* index = nullptr;
+    DevCol cols[kMaxKeyCols];
+    int32_t ncols = 0;
+};
+struct ChainOut {
+    DevBuf stream_row;
+    DevBuf build_row[CPH_MAX_CHAIN];
+    uint64_t nrows = 0;
+    int32_t nsteps = 0;
+};
+Status chain_run(cph_ctx* ctx, const ChainStep* steps, int nsteps, uint64_t probe_base, ChainOut* out);
 
 // capi.hip helpers
 Status ensure_pinned_scratch(cph_ctx* ctx, size_t bytes);

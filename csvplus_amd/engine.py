@@ -9,8 +9,6 @@ from __future__ import annotations
 
 from dataclasses import dataclass
 
-import numpy as np
-
 from . import _native as N
 from .columns import StrCol
 
@@ -37,19 +35,23 @@ def device_view(ptr: int, count: int, typestr: str, owner, device):
         dt = {"<i8": torch.int64, "<i4": torch.int32}[typestr]
         return torch.empty(0, dtype=dt, device=device)
     t = torch.as_tensor(_DevArray(ptr, count, typestr, owner), device=device)
-    t._cph_owner = owner   # keep the cph_matches alive as long as the view
+    t._cph_owner = owner   # keep the library object alive as long as the view
     return t
 
 
 @dataclass
 class ChainResult:
-    """Joined rows of stream JOIN a JOIN b as row-id triples, emission order.
-    stream_row: int64 (global stream row), a_row / b_row: int32 bit patterns of uint32 row ids."""
+    """Joined rows of stream JOIN a JOIN b ... as row-id tuples, emission order.
+    stream_row: int64 (global stream row); build_rows[k]: int32 bit patterns of uint32 row ids."""
     stream_row: "object"
-    a_row: "object"
-    b_row: "object"
+    build_rows: list
     n: int
     keep: tuple = ()
+
+    def release(self):
+        for k in self.keep:
+            k.release()
+        self.keep = ()
 
 
 class Engine:
@@ -81,26 +83,13 @@ class Engine:
     def join(self, index: N.DeviceIndex, probecols, probe_base: int = 0, want_pairs: bool = True) -> N.Matches:
         return index.probe(probecols, probe_base=probe_base, want_pairs=want_pairs, out_mem=N.CPH_MEM_DEVICE)
 
-    def chained_join(self, index_a, key_a: StrCol, index_b, key_b: StrCol, probe_base: int = 0) -> ChainResult:
-        """stream.Join(a, key_a).Join(b, key_b) where both keys are columns of the STREAM table
-        (README.md:56: orders.Join(customers,"cust_id").Join(products,"prod_id")).  The second
-        probe runs over exactly the rows the first join emitted (row selection on the device);
-        mergeRows (csvplus.go:571-583) lets the stream's value win on a column-name collision,
-        so key_b of a joined row is the stream row's value."""
-        torch = self.torch
-        m1 = index_a.probe([key_a], probe_base=probe_base, out_mem=N.CPH_MEM_DEVICE)
-        p1 = m1.device_ptrs()
-        m2 = index_b.probe([key_b], row_sel=(p1["probe_idx"], 64, m1.nmatches), sel_base=probe_base,
-                           probe_base=0, out_mem=N.CPH_MEM_DEVICE)
-        p2 = m2.device_ptrs()
+    def chained_join(self, steps, probe_base: int = 0) -> ChainResult:
+        """stream.Join(i0, k0).Join(i1, k1)...  with steps = [(index, [stream key columns]), ...]
+        (README.md:56: orders.Join(customers,"cust_id").Join(products,"prod_id")).  Runs as
+        cph_join_chain; results stay on the device as torch views."""
+        ch = N.join_chain(self.ctx, [(ix, cols if isinstance(cols, (list, tuple)) else [cols]) for ix, cols in steps],
+                          probe_base=probe_base, out_mem=N.CPH_MEM_DEVICE)
+        p = ch.device_ptrs()
         dev = self.device
-        s1 = device_view(p1["probe_idx"], m1.nmatches, "<i8", m1, dev)
-        a1 = device_view(p1["build_row"], m1.nmatches, "<i4", m1, dev)
-        b2 = device_view(p2["build_row"], m2.nmatches, "<i4", m2, dev)
-        if index_b.first_dup is None and m2.nmatches == m2.nprobe:
-            # b has distinct keys (cnt <= 1) and nmatches == nprobe, so every row of join 1 matched
-            # exactly once: composition is the identity
-            return ChainResult(s1, a1, b2, m2.nmatches, keep=(m1, m2))
-        sel = device_view(p2["probe_idx"], m2.nmatches, "<i8", m2, dev)
-        return ChainResult(torch.index_select(s1, 0, sel), torch.index_select(a1, 0, sel), b2, m2.nmatches,
-                           keep=(m1, m2))
+        return ChainResult(device_view(p["stream_row"], ch.nrows, "<i8", ch, dev),
+                           [device_view(q, ch.nrows, "<i4", ch, dev) for q in p["build_row"]], ch.nrows, keep=(ch,))

@@ -192,6 +192,47 @@ CPH_API int32_t cph_join_probe(cph_ctx* ctx, const cph_index* index, const cph_s
                                cph_matches** out);
 CPH_API void    cph_matches_release(cph_matches* m);
 
+/* ---- chained Join on the device (README.md:56; csvplus.go:545-569 nested) ---- */
+
+#define CPH_MAX_CHAIN 4
+
+/* One Join of a chain: stream.Join(index, cols...).  `cols` are columns of the
+ * STREAM table (all steps see the same nrows); ncols <= the index's key columns. */
+typedef struct {
+    const cph_index*  index;
+    const cph_strcol* cols;
+    int32_t           ncols;
+    int32_t           reserved_;
+} cph_chain_step;
+
+/*
+ * Result of stream.Join(i0, c0).Join(i1, c1)...: the joined rows as row-id tuples
+ * in the reference's emission order (stream order; for one stream row the
+ * matches of step 0 ascending by index position, and for each of them the
+ * matches of step 1, ...).  stream_row[m] = probe_base + the stream row,
+ * build_row[k][m] = ORIGINAL row id of the matching row of step k's index.
+ * The host materialises row m as mergeRows(...mergeRows(index_k row, ...), stream row)
+ * (csvplus.go:571-583).  Arrays live in `mem`, valid until cph_chain_release.
+ */
+typedef struct {
+    uint64_t        nrows;
+    const uint64_t* stream_row;
+    const uint32_t* build_row[CPH_MAX_CHAIN];
+    int32_t         nsteps;
+    int32_t         mem;
+} cph_chain;
+
+/*
+ * Every key of the chain must be a column of the stream table, which is what
+ * mergeRows guarantees whenever the stream row has that column (the stream's value
+ * wins on a name collision).  A later key that exists only on an index side is
+ * chained with cph_join_probe + row_sel instead.  When every index has distinct
+ * keys over a single column the whole chain runs as ONE pass over the stream rows.
+ */
+CPH_API int32_t cph_join_chain(cph_ctx* ctx, const cph_chain_step* steps, int32_t nsteps, uint64_t probe_base,
+                               int32_t out_mem, cph_chain** out);
+CPH_API void    cph_chain_release(cph_chain* chain);
+
 /* ---- Find / SubIndex bounds (csvplus.go:870-891) ----------------------------- */
 
 /* [*lower, *upper) = sorted positions whose leading key columns equal

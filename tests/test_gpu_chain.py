@@ -1,0 +1,142 @@
+"""cph_join_chain (chained Join on the device) against the oracle's nested joins
+(csvplus.go:545-569 nested as in README.md:56)."""
+import numpy as np
+import pytest
+
+from csvplus_amd import DeviceIndex, StrCol, _native as N, datagen as dg, join_chain
+from oracle import orc
+from tests.helpers import random_keys
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_chain(indexes, keycols, probe_base=0):
+    """Nested oracle joins: returns (stream_row u64, [build_row_k u32]) in emission order."""
+    j = indexes[0].join([keycols[0]] if isinstance(keycols[0], StrCol) else keycols[0], probe_base=probe_base)
+    stream = j["probe_idx"]
+    rows = [j["build_row"]]
+    for k in range(1, len(indexes)):
+        sel = (stream - probe_base).astype(np.uint32)
+        cols = [keycols[k]] if isinstance(keycols[k], StrCol) else keycols[k]
+        jk = indexes[k].join(cols, row_sel=sel)
+        pick = jk["probe_idx"].astype(np.int64)
+        stream = stream[pick]
+        rows = [r[pick] for r in rows] + [jk["build_row"]]
+    return stream, rows
+
+
+def check_chain(ctx, build_tables, stream_keys, probe_base=0, expect_fast=None):
+    gix = [DeviceIndex(ctx, cols) for cols in build_tables]
+    oix = [orc.OracleIndex(cols) for cols in build_tables]
+    steps = [(g, k if isinstance(k, list) else [k]) for g, k in zip(gix, stream_keys)]
+    ch = join_chain(ctx, steps, probe_base=probe_base)
+    es, erows = oracle_chain(oix, [k if isinstance(k, list) else k for k in stream_keys], probe_base)
+    assert ch.nrows == len(es)
+    np.testing.assert_array_equal(ch.stream_row, es)
+    for k in range(len(gix)):
+        np.testing.assert_array_equal(ch.build_row(k), erows[k])
+    return ch
+
+
+def test_chain_unique_fast_path_config4_shape(ctx):
+    """orders JOIN customers JOIN products, all keys present: one fused pass."""
+    nc, npd, m = 50_000, 1000, 300_000
+    cust, prod = dg.customers(nc), dg.products(npd)
+    ords = dg.orders(m, nc, npd)
+    ch = check_chain(ctx, [[cust["id"]], [prod["prod_id"]]], [ords["cust_id"], ords["prod_id"]], probe_base=12345)
+    assert ch.nrows == m
+
+
+def test_chain_unique_with_misses(ctx):
+    """Inner-join semantics: rows missing in either index disappear; order stays stream order."""
+    rng = np.random.default_rng(5)
+    a = [b"%05d" % i for i in rng.permutation(20000)[:12000]]
+    b = [b"k%d" % i for i in rng.permutation(500)[:300]]
+    m = 100_000
+    ka = [b"%05d" % i for i in rng.integers(0, 20000, m)]
+    kb = [b"k%d" % i for i in rng.integers(0, 500, m)]
+    ka[::13] = [b"zz"] * len(ka[::13])          # symbols outside the alphabet
+    kb[::17] = [b"k1234567"] * len(kb[::17])     # longer than any index key
+    ch = check_chain(ctx, [[StrCol.from_values(a)], [StrCol.from_values(b)]],
+                     [StrCol.from_values(ka), StrCol.from_values(kb)])
+    assert 0 < ch.nrows < m
+
+
+@pytest.mark.parametrize("nsteps", [1, 3, 4])
+def test_chain_lengths(ctx, nsteps):
+    rng = np.random.default_rng(nsteps)
+    m = 50_000
+    builds, keys = [], []
+    for s in range(nsteps):
+        dom = 1000 * (s + 1)
+        vals = [b"%d" % i for i in rng.permutation(dom)[: dom * 3 // 4]]
+        builds.append([StrCol.from_values(vals)])
+        keys.append(StrCol.from_values([b"%d" % i for i in rng.integers(0, dom, m)]))
+    check_chain(ctx, builds, keys)
+
+
+def test_chain_search_path_sparse_codes(ctx):
+    """Distinct keys but a sparse code space (no direct table): binary-search lookups inside the fused pass."""
+    rng = np.random.default_rng(11)
+    vals = list({bytes(v) for v in random_keys(rng, 30000, 6, 9, alphabet=list(b"abcdefghijklmnopqrstuvwxyz"))})
+    ix = DeviceIndex(ctx, [StrCol.from_values(vals)])
+    assert ix.info()["direct_table"] == 0 and ix.first_dup is None
+    probe = [vals[i] for i in rng.integers(0, len(vals), 80000)]
+    probe[::9] = random_keys(rng, len(probe[::9]), 6, 9, alphabet=list(b"abcxyz"))
+    check_chain(ctx, [[StrCol.from_values(vals)]], [StrCol.from_values(probe)])
+
+
+def test_chain_general_path_duplicates(ctx):
+    """Duplicate build keys: every combination is emitted, a-matches outer, b-matches inner."""
+    rng = np.random.default_rng(3)
+    a = [b"%d" % i for i in rng.integers(0, 300, 2000)]      # ~7 dups per key
+    b = [b"p%d" % i for i in rng.integers(0, 50, 200)]       # ~4 dups per key
+    m = 5000
+    ka = [b"%d" % i for i in rng.integers(0, 330, m)]
+    kb = [b"p%d" % i for i in rng.integers(0, 55, m)]
+    ch = check_chain(ctx, [[StrCol.from_values(a)], [StrCol.from_values(b)]],
+                     [StrCol.from_values(ka), StrCol.from_values(kb)], probe_base=77)
+    assert ch.nrows > m
+
+
+def test_chain_general_path_multicolumn(ctx):
+    rng = np.random.default_rng(9)
+    a0 = [b"%d" % i for i in rng.integers(0, 40, 3000)]
+    a1 = [b"%c" % c for c in rng.integers(97, 101, 3000)]
+    b = [b"%d" % i for i in range(100)]
+    m = 8000
+    k0 = [b"%d" % i for i in rng.integers(0, 45, m)]
+    k1 = [b"%c" % c for c in rng.integers(97, 102, m)]
+    kb = [b"%d" % i for i in rng.integers(0, 120, m)]
+    check_chain(ctx, [[StrCol.from_values(a0), StrCol.from_values(a1)], [StrCol.from_values(b)]],
+                [[StrCol.from_values(k0), StrCol.from_values(k1)], StrCol.from_values(kb)])
+
+
+def test_chain_empty_and_no_match(ctx):
+    ix = DeviceIndex(ctx, [StrCol.from_values(["a", "b"])])
+    ch = join_chain(ctx, [(ix, [StrCol.from_values([])])])
+    assert ch.nrows == 0
+    ch = join_chain(ctx, [(ix, [StrCol.from_values(["x", "y", "zz"])])])
+    assert ch.nrows == 0
+    e = DeviceIndex(ctx, [StrCol.from_values([])])
+    ch = join_chain(ctx, [(e, [StrCol.from_values(["x", ""])])])
+    assert ch.nrows == 0
+
+
+def test_chain_many_tiles_lookback(ctx):
+    """5e6 rows = ~4900 tiles: exercises the decoupled look-back across many workgroups, with a
+    match rate that varies along the stream; the result must equal stream order exactly."""
+    n, m = 200_000, 5_000_000
+    cust = dg.column(dg.SEQ_PERM, n, n, encoding=dg.FIXED8, seed=1)
+    probe = dg.column(dg.UNIFORM, m, 2 * n, encoding=dg.FIXED8, seed=2)   # ~half the keys miss
+    ix = DeviceIndex(ctx, [cust], unique=True)
+    for _ in range(3):   # repeated: scheduling differs run to run, the result must not
+        ch = join_chain(ctx, [(ix, [probe])])
+        pv = (np.frombuffer(probe.data, dtype=np.uint8).reshape(m, 8) - 48).astype(np.int64)
+        pv = (pv * (10 ** np.arange(7, -1, -1, dtype=np.int64))).sum(axis=1)
+        hit = np.nonzero(pv < n)[0]
+        np.testing.assert_array_equal(ch.stream_row, hit.astype(np.uint64))
+        cv = (np.frombuffer(cust.data, dtype=np.uint8).reshape(n, 8) - 48).astype(np.int64)
+        cv = (cv * (10 ** np.arange(7, -1, -1, dtype=np.int64))).sum(axis=1)
+        np.testing.assert_array_equal(cv[ch.build_row(0)], pv[hit])
+        ch.release()

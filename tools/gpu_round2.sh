@@ -5,4 +5,4 @@ timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1
 tail -15 gpurun_out/pytest_gpu.log
 timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log
 tail -3 gpurun_out/smoke.log
-bash tools/gpu_profile.sh r01a
+bash tools/gpu_profile.sh r01b
