@@ -135,15 +135,16 @@ def main():
     ia_info, ib_info = info
     K = args.steps
     total_joined_local = joined if world == 1 or args.exchange == "none" else nloc
-    obytes = 4
+    off_c, off_p = cust_id.nbytes_offsets(), prod_id.nbytes_offsets()   # 0 for fixed-width columns
+    off_o = ords["cust_id"].nbytes_offsets() + ords["prod_id"].nbytes_offsets()
     cust_bytes, prod_bytes = cust_id.nbytes_values(), prod_id.nbytes_values()
     extra = {
-        "k_col_stats": K * ((cust_bytes + obytes * args.customers) + (prod_bytes + obytes * args.products)),
-        "k_encode_build": K * ((cust_bytes + obytes * args.customers + ia_info["key_bytes"] * args.customers)
-                               + (prod_bytes + obytes * args.products + ib_info["key_bytes"] * args.products)),
+        "k_col_stats": K * (cust_bytes + off_c + prod_bytes + off_p),
+        "k_encode_build": K * ((cust_bytes + off_c + ia_info["key_bytes"] * args.customers)
+                               + (prod_bytes + off_p + ib_info["key_bytes"] * args.products)),
         # fused chain pass, per stream row: both keys' bytes + offsets in, one 8-byte table entry per
         # step, (8 + 4 + 4)-byte row-id triple out per joined row
-        "k_chain_unique": K * (host_bytes["cust_id"] + host_bytes["prod_id"] + 2 * obytes * nloc + 2 * 8 * nloc
+        "k_chain_dense": K * (host_bytes["cust_id"] + host_bytes["prod_id"] + off_o + 2 * 8 * nloc
                                + 16 * total_joined_local),
     }
     kernels = {}

@@ -61,6 +61,8 @@ class cph_strcol(C.Structure):
         ("nrows", C.c_uint64),
         ("offset_bits", C.c_int32),
         ("mem", C.c_int32),
+        ("fixed_width", C.c_uint32),
+        ("reserved_", C.c_uint32),
     ]
 
 

@@ -129,10 +129,12 @@ static Status validate_cols(const cph_strcol* cols, int32_t ncols) {
     if (!cols || ncols <= 0) return {CPH_ERR_INVALID, "no key columns"};
     if (ncols > kMaxKeyCols) return {CPH_ERR_INVALID, "too many key columns"};
     for (int c = 0; c < ncols; c++) {
-        if (cols[c].offset_bits != 32 && cols[c].offset_bits != 64) return {CPH_ERR_INVALID, "offset_bits must be 32 or 64"};
+        if (cols[c].fixed_width == 0 && cols[c].offset_bits != 32 && cols[c].offset_bits != 64)
+            return {CPH_ERR_INVALID, "offset_bits must be 32 or 64"};
         if (cols[c].mem != CPH_MEM_HOST && cols[c].mem != CPH_MEM_DEVICE) return {CPH_ERR_INVALID, "bad mem"};
         if (cols[c].nrows != cols[0].nrows) return {CPH_ERR_INVALID, "key columns differ in row count"};
-        if (cols[c].nrows && !cols[c].offsets) return {CPH_ERR_INVALID, "offsets is NULL"};
+        if (cols[c].nrows && !cols[c].offsets && cols[c].fixed_width == 0) return {CPH_ERR_INVALID, "offsets is NULL"};
+        if (cols[c].nrows && cols[c].fixed_width && !cols[c].data) return {CPH_ERR_INVALID, "data is NULL"};
     }
     if (cols[0].nrows > 0xFFFFFFFFull) return {CPH_ERR_TOO_MANY_ROWS, "more than 2^32-1 rows"};
     return {};
@@ -145,9 +147,18 @@ static Status stage_cols(cph_ctx* ctx, const cph_strcol* cols, int32_t ncols, st
         DevCol d;
         d.nrows = cols[c].nrows;
         d.offset_bits = cols[c].offset_bits;
+        d.fixed_width = cols[c].fixed_width;
         if (cols[c].mem == CPH_MEM_DEVICE || cols[c].nrows == 0) {
             d.data = cols[c].data;
             d.offsets = cols[c].offsets;
+        } else if (cols[c].fixed_width) {
+            const size_t bytes = (size_t)cols[c].nrows * cols[c].fixed_width;
+            DevBuf bd;
+            CPH_TRY(bd.alloc(&ctx->pool, bytes + 8));
+            CPH_HIP_TRY(hipMemcpyAsync(bd.get(), cols[c].data, bytes, hipMemcpyHostToDevice, ctx->stream));
+            d.data = bd.as<uint8_t>();
+            d.offsets = nullptr;
+            storage->push_back(std::move(bd));
         } else {
             const size_t obytes = (size_t)(cols[c].nrows + 1) * (size_t)(cols[c].offset_bits / 8);
             const uint64_t first = cols[c].offset_bits == 32 ? ((const uint32_t*)cols[c].offsets)[0]

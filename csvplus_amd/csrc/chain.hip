@@ -3,37 +3,44 @@
 // case where every key comes from a column of the stream table (mergeRows, csvplus.go:571-583,
 // lets the stream's value win on a name collision, so that is the value the next Join sees).
 //
-// Fast path (k_chain_unique): every index has distinct keys, a single key column and a
-// one-word code.  One pass over the stream rows:
-//   - per row and step: encode the key with the step's codec (LUTs in LDS), look the code up in
-//     the step's direct-address table (or binary-search the sorted codes) -> build row or miss
-//   - a row is emitted iff every step matched (inner join), exactly once
-//   - output slots come from wave ballots + a tile prefix obtained by decoupled look-back over
-//     one 64-bit {flag,value} word per tile (relaxed agent-scope atomics, the data is the flag),
-//     tiles taking their number from an atomic ticket so a tile only waits for tiles that
-//     already started
-//   - each thread keeps kChainRows rows in flight: all offset loads, then all key loads, then
-//     all table loads are issued back to back (memory-level parallelism; the lookups are
-//     latency-bound otherwise)
-// Algorithmic traffic per stream row: sum over steps of (key bytes + offset) in, 8 + 4*steps
-// bytes out per joined row, one 8-byte table entry per step (random).
+// Fast path: every index has distinct keys, a single key column and a one-word code with a
+// pre-multiplied LUT.  Then a stream row joins at most once, and the output is written
+// OPTIMISTICALLY DENSE:
+//   k_chain_dense   one pass over the stream rows.  Per row and step: encode the key (one LDS
+//                   load + add per byte position), look the code up in the step's direct-address
+//                   table (or binary-search the sorted codes).  A row that matched in every step
+//                   writes its tuple at slot == its row number; the per-wave match ballots and the
+//                   per-tile match counts are recorded.  No workgroup talks to another one.
+//                   Each thread keeps kChainRows rows in flight: all offset loads, then all key
+//                   loads, then all table loads are issued back to back (the lookups are
+//                   latency-bound otherwise).
+//   k_sum_counts    total number of joined rows.
+//   if total == rows (every stream row joined — the README chain, BASELINE config 4): done, the
+//   dense arrays ARE the result in emission order;
+//   else            exclusive scan of the tile counts + k_chain_compact moves the matched tuples
+//                   to their final slots (stream order is kept: slot = matches before the row).
+// An earlier single-pass variant (decoupled look-back over an atomic tile ticket) was measured at
+// 2.3-3.7 ms per 1e8 rows: one device-wide ticket counter sustains ~88 increments/us
+// (MI355X_MICROARCH.md "dequeue"), which alone capped it.
+//
+// Algorithmic traffic per stream row: sum over steps of (key bytes + offset) in, one 8-byte table
+// entry per step (random access), 8 + 4*steps bytes out per joined row (+ the same again, read and
+// written, for the rows that survive when compaction is needed).
 //
 // General path (duplicate keys / multi-column keys / multi-word codes): probe, select, compose
 // step by step with the generic kernels of probe.hip.
+#include <cstdlib>
+
 #include "probe_device.hpp"
 
 namespace cph {
 
 constexpr int kChainThreads = 256;
 constexpr int kChainWaves   = kChainThreads / kWave;
-constexpr int kChainRows    = 4;                               // rows in flight per thread
-constexpr int kChainTile    = kChainThreads * kChainRows;      // 1024 stream rows per tile
+constexpr int kChainRows    = 4;                                   // rows in flight per thread
+constexpr int kChainTile    = kChainThreads * kChainRows;          // 1024 stream rows per tile
+constexpr int kChainMasks   = kChainRows * kChainWaves;            // ballot words per tile
 constexpr int kMaxChain     = CPH_MAX_CHAIN;
-
-constexpr uint64_t kFlagShift   = 62;
-constexpr uint64_t kFlagAgg     = 1ull << kFlagShift;
-constexpr uint64_t kFlagPrefix  = 2ull << kFlagShift;
-constexpr uint64_t kValueMask   = (1ull << kFlagShift) - 1;
 
 struct ChainStepArg {
     DevCol col;                 // the stream's key column for this step
@@ -50,185 +57,204 @@ struct ChainArgs {
     uint32_t* out_rows[kMaxChain];
 };
 
-// single-column, single-word encode from the prefetched first 16 bytes of the value
-__device__ __forceinline__ bool encode_prefetched(const CodecView& cv, const DevCol& col, uint64_t begin, uint64_t len,
-                                                  uint64_t c0, uint64_t c1, uint64_t* code) {
+// single-column, single-word encode from the prefetched first 16 bytes of the value, using the
+// codec's pre-multiplied LUT (one LDS load + add per byte position; the fast path requires it)
+template <class W>
+__device__ __forceinline__ bool encode_prefetched_w(const CodecView& cv, const DevCol& col, uint64_t begin, uint64_t len,
+                                                    uint64_t c0, uint64_t c1, uint64_t* code) {
     const int maxlen = cv.hdr->col_maxlen[0];
-    bool valid = len <= (uint64_t)maxlen;
-    uint64_t acc = 0, chunk = c0;
+    const W* lutw = reinterpret_cast<const W*>(cv.lutw);
+    W acc = 0, bad = 0;
+    uint64_t chunk = c0;
     for (int q = 0; q < maxlen; q++) {
         if ((q & 7) == 0) {
             if (q == 8) chunk = c1;
             else if (q >= 16 && (uint64_t)q < len) chunk = load_value_chunk(col.data, begin, len, q >> 3);
         }
         const int sym = (uint64_t)q < len ? (int)((chunk >> (8 * (q & 7))) & 0xFF) + 1 : 0;
-        const uint32_t r = cv.lut[q * kLutStride + sym];
-        if (r == kLutInvalid) valid = false;
-        acc += (uint64_t)r * cv.mult[q];
+        const W v = lutw[q * kLutStride + sym];
+        bad |= v;
+        acc += v;
     }
-    *code = acc;
-    return valid;
+    *code = (uint64_t)acc;
+    return len <= (uint64_t)maxlen && !(bad >> (sizeof(W) * 8 - 1));
+}
+__device__ __forceinline__ bool encode_prefetched(const CodecView& cv, const DevCol& col, uint64_t begin, uint64_t len,
+                                                  uint64_t c0, uint64_t c1, uint64_t* code) {
+    return cv.hdr->lutw_bits == 32 ? encode_prefetched_w<uint32_t>(cv, col, begin, len, c0, c1, code)
+                                   : encode_prefetched_w<uint64_t>(cv, col, begin, len, c0, c1, code);
 }
 
+// dbg: attribution switches for tools/microbench (results are wrong when set):
+//      1 = no table lookup, 2 = no encode, 4 = no output stores
 template <int S>
-__global__ __launch_bounds__(kChainThreads) void k_chain_unique(ChainArgs a, uint64_t nprobe, uint64_t probe_base,
-                                                               uint64_t* __restrict__ tile_state,
-                                                               uint32_t* __restrict__ ticket,
-                                                               uint64_t* __restrict__ out_stream,
-                                                               uint32_t* __restrict__ err_flag) {
+__global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint64_t nprobe, uint64_t probe_base,
+                                                              uint64_t ntiles, uint64_t* __restrict__ out_stream,
+                                                              uint64_t* __restrict__ masks,
+                                                              uint32_t* __restrict__ tile_counts, int dbg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    // dynamic LDS layout: [scratch 256 B][codec 0][codec 1]...   (no static LDS: keeps 16-B alignment)
-    uint32_t* s_tile = reinterpret_cast<uint32_t*>(smem);                 // [0]
-    uint32_t* s_wcnt = reinterpret_cast<uint32_t*>(smem) + 4;             // [kChainRows][kChainWaves] -> exclusive
-    uint64_t* s_base = reinterpret_cast<uint64_t*>(smem + 128);           // [0] tile's exclusive output prefix
-    if (threadIdx.x == 0) s_tile[0] = atomicAdd(ticket, 1u);
+    // dynamic LDS layout: [scratch 64 B][codec 0][codec 1]...   (no static LDS: keeps 16-B alignment)
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem);   // [kChainWaves]
     CodecView cv[S];
     {
-        uint8_t* p = smem + 256;
+        uint8_t* p = smem + 64;
 #pragma unroll
         for (int s = 0; s < S; s++) {
             cv[s] = codec_load_to_lds(a.step[s].codec, p);   // syncs inside
             p += a.step[s].codec_bytes;
         }
     }
-    __syncthreads();
-    const uint64_t tile = s_tile[0];
-    const uint64_t tile0 = tile * kChainTile;
     const int lane = lane_id(), wave = wave_id();
 
-    // ---- phase A: offsets -------------------------------------------------------------------
-    uint64_t begin[kChainRows][S];
-    uint32_t len[kChainRows][S];
-    bool in_range[kChainRows];
+#pragma unroll 1
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t tile0 = tile * kChainTile;
+        // ---- A: offsets -------------------------------------------------------------------------
+        uint64_t begin[kChainRows][S];
+        uint32_t len[kChainRows][S];
+        bool ok[kChainRows];
 #pragma unroll
-    for (int k = 0; k < kChainRows; k++) {
-        const uint64_t row = tile0 + (uint64_t)k * kChainThreads + threadIdx.x;
-        in_range[k] = row < nprobe;
+        for (int k = 0; k < kChainRows; k++) {
+            const uint64_t row = tile0 + (uint64_t)k * kChainThreads + threadIdx.x;
+            ok[k] = row < nprobe;
 #pragma unroll
-        for (int s = 0; s < S; s++) {
-            const DevCol& c = a.step[s].col;
-            const uint64_t b = in_range[k] ? load_offset(c.offsets, c.offset_bits, row) : 0;
-            const uint64_t e = in_range[k] ? load_offset(c.offsets, c.offset_bits, row + 1) : 0;
-            begin[k][s] = b;
-            const uint64_t l = e - b;
-            len[k][s] = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;
-        }
-    }
-    // ---- phase B: first 16 key bytes ------------------------------------------------------------
-    uint64_t c0[kChainRows][S], c1[kChainRows][S];
-#pragma unroll
-    for (int k = 0; k < kChainRows; k++)
-#pragma unroll
-        for (int s = 0; s < S; s++) {
-            const DevCol& c = a.step[s].col;
-            c0[k][s] = len[k][s] > 0 ? load_value_chunk(c.data, begin[k][s], len[k][s], 0) : 0;
-            c1[k][s] = len[k][s] > 8 ? load_value_chunk(c.data, begin[k][s], len[k][s], 1) : 0;
-        }
-    // ---- phase C: codes ----------------------------------------------------------------------------
-    uint64_t code[kChainRows][S];
-    bool ok[kChainRows];
-#pragma unroll
-    for (int k = 0; k < kChainRows; k++) {
-        ok[k] = in_range[k];
-#pragma unroll
-        for (int s = 0; s < S; s++)
-            ok[k] &= encode_prefetched(cv[s], a.step[s].col, begin[k][s], len[k][s], c0[k][s], c1[k][s], &code[k][s]);
-    }
-    // ---- phase D: lookups ---------------------------------------------------------------------------
-    uint32_t brow[kChainRows][S];
-#pragma unroll
-    for (int s = 0; s < S; s++) {
-        const ChainStepArg& st = a.step[s];
-        if (st.table) {
-            TableEntry e[kChainRows];
-#pragma unroll
-            for (int k = 0; k < kChainRows; k++) e[k] = ok[k] ? st.table[code[k][s]] : TableEntry{kTableAbsent, 0};
-#pragma unroll
-            for (int k = 0; k < kChainRows; k++) {
-                ok[k] &= e[k].a != kTableAbsent;
-                brow[k][s] = e[k].b;
+            for (int s = 0; s < S; s++) {
+                const DevCol& c = a.step[s].col;
+                uint64_t b = 0, l = 0;
+                if (ok[k]) value_span(c, row, &b, &l);
+                begin[k][s] = b;
+                len[k][s] = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;
             }
-        } else {
+        }
+        // ---- B: first 16 key bytes ------------------------------------------------------------------
+        uint64_t c0[kChainRows][S], c1[kChainRows][S];
 #pragma unroll
-            for (int k = 0; k < kChainRows; k++) {
-                brow[k][s] = 0;
-                if (!ok[k]) continue;
-                uint64_t lo;
-                bool hit;
-                if (st.key32) {
-                    const uint32_t* cd = reinterpret_cast<const uint32_t*>(st.codes);
-                    lo = lower_bound_dev<uint32_t>(cd, 0, st.n_index, (uint32_t)code[k][s]);
-                    hit = lo < st.n_index && cd[lo] == (uint32_t)code[k][s];
-                } else {
-                    const uint64_t* cd = reinterpret_cast<const uint64_t*>(st.codes);
-                    lo = lower_bound_dev<uint64_t>(cd, 0, st.n_index, code[k][s]);
-                    hit = lo < st.n_index && cd[lo] == code[k][s];
+        for (int k = 0; k < kChainRows; k++)
+#pragma unroll
+            for (int s = 0; s < S; s++) {
+                const DevCol& c = a.step[s].col;
+                c0[k][s] = len[k][s] > 0 ? load_value_chunk(c.data, begin[k][s], len[k][s], 0) : 0;
+                c1[k][s] = len[k][s] > 8 ? load_value_chunk(c.data, begin[k][s], len[k][s], 1) : 0;
+            }
+        // ---- C: codes ----------------------------------------------------------------------------------
+        uint64_t code[kChainRows][S];
+#pragma unroll
+        for (int k = 0; k < kChainRows; k++)
+#pragma unroll
+            for (int s = 0; s < S; s++) {
+                if (dbg & 2) code[k][s] = (c0[k][s] ^ c1[k][s]) & 1023;
+                else ok[k] &= encode_prefetched(cv[s], a.step[s].col, begin[k][s], len[k][s], c0[k][s], c1[k][s], &code[k][s]);
+            }
+        // ---- D: lookups --------------------------------------------------------------------------------
+        uint32_t brow[kChainRows][S];
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            const ChainStepArg& st = a.step[s];
+            if (st.table) {
+                TableEntry e[kChainRows];
+#pragma unroll
+                for (int k = 0; k < kChainRows; k++)
+                    e[k] = (ok[k] && !(dbg & 1)) ? st.table[code[k][s]] : TableEntry{(dbg & 1) ? 0u : kTableAbsent, 0};
+#pragma unroll
+                for (int k = 0; k < kChainRows; k++) {
+                    ok[k] &= e[k].a != kTableAbsent;
+                    brow[k][s] = e[k].b;
                 }
-                ok[k] = hit;
-                if (hit) brow[k][s] = st.perm[lo];
+            } else {
+#pragma unroll
+                for (int k = 0; k < kChainRows; k++) {
+                    brow[k][s] = 0;
+                    if (!ok[k]) continue;
+                    uint64_t lo;
+                    bool hit;
+                    if (st.key32) {
+                        const uint32_t* cd = reinterpret_cast<const uint32_t*>(st.codes);
+                        lo = lower_bound_dev<uint32_t>(cd, 0, st.n_index, (uint32_t)code[k][s]);
+                        hit = lo < st.n_index && cd[lo] == (uint32_t)code[k][s];
+                    } else {
+                        const uint64_t* cd = reinterpret_cast<const uint64_t*>(st.codes);
+                        lo = lower_bound_dev<uint64_t>(cd, 0, st.n_index, code[k][s]);
+                        hit = lo < st.n_index && cd[lo] == code[k][s];
+                    }
+                    ok[k] = hit;
+                    if (hit) brow[k][s] = st.perm[lo];
+                }
             }
         }
+        // ---- dense output + match bookkeeping ---------------------------------------------------------
+        uint32_t wave_matches = 0;
+#pragma unroll
+        for (int k = 0; k < kChainRows; k++) {
+            const uint64_t bal = __ballot(ok[k]);
+            wave_matches += (uint32_t)__popcll(bal);
+            if (lane == 0) masks[tile * kChainMasks + k * kChainWaves + wave] = bal;
+            if (ok[k] && !(dbg & 4)) {
+                const uint64_t row = tile0 + (uint64_t)k * kChainThreads + threadIdx.x;
+                out_stream[row] = probe_base + row;
+#pragma unroll
+                for (int s = 0; s < S; s++) a.out_rows[s][row] = brow[k][s];
+            }
+        }
+        if (lane == 0) s_cnt[wave] = wave_matches;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t t = 0;
+#pragma unroll
+            for (int w = 0; w < kChainWaves; w++) t += s_cnt[w];
+            tile_counts[tile] = t;
+        }
+        __syncthreads();   // s_cnt is rewritten by the next tile
     }
-    // ---- output slots: ballots inside the wave, LDS across waves, look-back across tiles ------------
+}
+
+// total = sum of the tile counts (single workgroup; ntiles ~ rows/1024)
+__global__ __launch_bounds__(1024) void k_sum_counts(const uint32_t* __restrict__ counts, uint64_t n,
+                                                    uint64_t* __restrict__ total) {
+    __shared__ uint64_t s_w[1024 / kWave];
+    uint64_t t = 0;
+    for (uint64_t i = threadIdx.x; i < n; i += 1024) t += counts[i];
+    t = wave_sum(t);
+    if (lane_id() == 0) s_w[wave_id()] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t r = 0;
+        for (int w = 0; w < 1024 / kWave; w++) r += s_w[w];
+        *total = r;
+    }
+}
+
+// Moves the matched tuples of a tile from slot == row to their final slots.
+template <int S>
+__global__ __launch_bounds__(kChainThreads) void k_chain_compact(ChainArgs dense_rows, const uint64_t* __restrict__ dense_stream,
+                                                                const uint64_t* __restrict__ masks,
+                                                                const uint32_t* __restrict__ tile_base, uint64_t ntiles,
+                                                                uint64_t* __restrict__ out_stream, ChainArgs out_rows) {
+    __shared__ uint64_t s_mask[kChainMasks];
+    __shared__ uint32_t s_pref[kChainMasks];
+    const int lane = lane_id(), wave = wave_id();
     const uint64_t lt = lanemask_lt();
-    uint32_t my_off[kChainRows];
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (threadIdx.x < kChainMasks) s_mask[threadIdx.x] = masks[tile * kChainMasks + threadIdx.x];
+        __syncthreads();
+        if (wave == 0) {
+            const uint32_t v = lane < kChainMasks ? (uint32_t)__popcll(s_mask[lane]) : 0u;
+            const uint32_t incl = wave_inclusive_sum(v);
+            if (lane < kChainMasks) s_pref[lane] = incl - v;
+        }
+        __syncthreads();
+        const uint64_t base = tile_base[tile];
 #pragma unroll
-    for (int k = 0; k < kChainRows; k++) {
-        const uint64_t bal = __ballot(ok[k]);
-        my_off[k] = (uint32_t)__popcll(bal & lt);
-        if (lane == 0) s_wcnt[k * kChainWaves + wave] = (uint32_t)__popcll(bal);
-    }
-    __syncthreads();
-    if (wave == 0) {
-        // exclusive prefix over (k, wave) in emission order; 16 values, lanes 0..15
-        uint32_t v = lane < kChainRows * kChainWaves ? s_wcnt[lane] : 0u;
-        const uint32_t incl = wave_inclusive_sum(v);
-        const uint32_t total = __shfl(incl, kWave - 1, kWave);
-        if (lane < kChainRows * kChainWaves) s_wcnt[lane] = incl - v;
-        // decoupled look-back
-        uint64_t* my_state = tile_state + tile;
-        if (lane == 0)
-            __hip_atomic_store(my_state, (tile == 0 ? kFlagPrefix : kFlagAgg) | (uint64_t)total, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        uint64_t excl = 0;
-        if (tile > 0) {
-            int64_t j = (int64_t)tile - 1 - lane;
-            uint32_t spins = 0;
-            bool failed = false;
-            for (;;) {
-                uint64_t st = j >= 0 ? __hip_atomic_load(tile_state + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                     : kFlagPrefix;   // before tile 0: prefix 0
-                while (__any((st >> kFlagShift) == 0)) {
-                    if (++spins > (1u << 24)) { failed = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                    if ((st >> kFlagShift) == 0)
-                        st = __hip_atomic_load(tile_state + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                if (failed) break;
-                const uint64_t pmask = __ballot((st >> kFlagShift) == 2);
-                const int first = pmask ? __ffsll((unsigned long long)pmask) - 1 : kWave;
-                const uint64_t v64 = lane <= first ? (st & kValueMask) : 0ull;
-                excl += wave_sum(v64);
-                if (pmask) break;
-                j -= kWave;
+        for (int k = 0; k < kChainRows; k++) {
+            const uint64_t m = s_mask[k * kChainWaves + wave];
+            if ((m >> lane) & 1ull) {
+                const uint64_t row = tile * kChainTile + (uint64_t)k * kChainThreads + threadIdx.x;
+                const uint64_t pos = base + s_pref[k * kChainWaves + wave] + (uint64_t)__popcll(m & lt);
+                out_stream[pos] = dense_stream[row];
+#pragma unroll
+                for (int s = 0; s < S; s++) out_rows.out_rows[s][pos] = dense_rows.out_rows[s][row];
             }
-            if (failed && lane == 0) atomicExch(err_flag, 1u);
         }
-        if (lane == 0) {
-            __hip_atomic_store(my_state, kFlagPrefix | ((excl + total) & kValueMask), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            s_base[0] = excl;
-        }
-    }
-    __syncthreads();
-    const uint64_t base = s_base[0];
-#pragma unroll
-    for (int k = 0; k < kChainRows; k++) {
-        if (!ok[k]) continue;
-        const uint64_t pos = base + s_wcnt[k * kChainWaves + wave] + my_off[k];
-        out_stream[pos] = probe_base + tile0 + (uint64_t)k * kChainThreads + threadIdx.x;
-#pragma unroll
-        for (int s = 0; s < S; s++) a.out_rows[s][pos] = brow[k][s];
+        __syncthreads();
     }
 }
 
@@ -249,19 +275,79 @@ static bool fast_path_ok(const ChainStep* steps, int nsteps) {
         const cph_index* ix = steps[s].index;
         if (steps[s].ncols != 1 || ix->nkeycols != 1) return false;
         if (ix->first_dup != UINT64_MAX) return false;
-        if (ix->codec.nwords != 1) return false;
+        if (ix->codec.nwords != 1 || ix->codec.npos == 0) return false;
+        if (codec_premultiplied_bits(ix->codec) == 0) return false;
     }
     return true;
 }
 
 template <int S>
-static Status launch_chain(cph_ctx* ctx, const ChainArgs& args, size_t lds, uint64_t nprobe, uint64_t probe_base,
-                           uint64_t* state, uint32_t* ticket, uint64_t* out_stream, uint32_t* err, unsigned ntiles) {
-    CPH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_unique<S>),
+static Status run_fast(cph_ctx* ctx, const ChainStep* steps, uint64_t nprobe, uint64_t probe_base, ChainOut* out) {
+    const uint64_t ntiles = (nprobe + kChainTile - 1) / kChainTile;
+    CPH_TRY(out->stream_row.alloc(&ctx->pool, nprobe * sizeof(uint64_t)));
+    ChainArgs args{};
+    size_t lds = 64;
+    for (int s = 0; s < S; s++) {
+        const cph_index* ix = steps[s].index;
+        CPH_TRY(out->build_row[s].alloc(&ctx->pool, nprobe * sizeof(uint32_t)));
+        ChainStepArg& st = args.step[s];
+        st.col = steps[s].cols[0];
+        st.codec = ix->codec_dev.as<uint8_t>();
+        st.codec_bytes = (int32_t)ix->codec_dev.bytes();
+        st.table = ix->table_entries ? ix->table.as<TableEntry>() : nullptr;
+        st.codes = ix->sorted_codes.get();
+        st.perm = ix->perm.as<uint32_t>();
+        st.n_index = ix->nrows;
+        st.key32 = ix->codec.key32 ? 1 : 0;
+        args.out_rows[s] = out->build_row[s].as<uint32_t>();
+        lds += ix->codec_dev.bytes();
+    }
+    DevBuf masks, counts, total;
+    CPH_TRY(masks.alloc(&ctx->pool, ntiles * kChainMasks * sizeof(uint64_t)));
+    CPH_TRY(counts.alloc(&ctx->pool, ntiles * sizeof(uint32_t)));
+    CPH_TRY(total.alloc(&ctx->pool, sizeof(uint64_t)));
+    const char* e = std::getenv("CPH_CHAIN_DEBUG");
+    const int dbg = e ? std::atoi(e) : 0;
+    CPH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_dense<S>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_chain_unique<S>, dim3(ntiles), dim3(kChainThreads), lds, ctx->stream, args, nprobe, probe_base,
-                       state, ticket, out_stream, err);
+    const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * 8);
+    {
+        ProfScope ps(ctx, "k_chain_dense", 0);
+        hipLaunchKernelGGL(k_chain_dense<S>, dim3(grid), dim3(kChainThreads), lds, ctx->stream, args, nprobe, probe_base,
+                           ntiles, out->stream_row.as<uint64_t>(), masks.as<uint64_t>(), counts.as<uint32_t>(), dbg);
+    }
+    {
+        ProfScope ps(ctx, "k_sum_counts", 4.0 * (double)ntiles);
+        hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(1024), 0, ctx->stream, counts.as<uint32_t>(), ntiles,
+                           total.as<uint64_t>());
+    }
     CPH_HIP_TRY(hipGetLastError());
+    CPH_TRY(ensure_pinned_scratch(ctx, sizeof(uint64_t)));
+    uint64_t* h = reinterpret_cast<uint64_t*>(ctx->pinned_scratch);
+    CPH_HIP_TRY(hipMemcpyAsync(h, total.get(), sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const uint64_t nmatch = h[0];
+    out->nrows = nmatch;
+    if (nmatch == nprobe || nmatch == 0) return {};   // dense arrays are already final / nothing to keep
+
+    // compaction: tile bases, then move the tuples
+    CPH_TRY(exclusive_scan_u32(ctx, counts.as<uint32_t>(), ntiles));
+    ChainOut fin;
+    CPH_TRY(fin.stream_row.alloc(&ctx->pool, nmatch * sizeof(uint64_t)));
+    ChainArgs fargs{};
+    for (int s = 0; s < S; s++) {
+        CPH_TRY(fin.build_row[s].alloc(&ctx->pool, nmatch * sizeof(uint32_t)));
+        fargs.out_rows[s] = fin.build_row[s].as<uint32_t>();
+    }
+    {
+        ProfScope ps(ctx, "k_chain_compact", 2.0 * (double)nmatch * (8.0 + 4.0 * S));
+        hipLaunchKernelGGL(k_chain_compact<S>, dim3(grid), dim3(kChainThreads), 0, ctx->stream, args,
+                           out->stream_row.as<uint64_t>(), masks.as<uint64_t>(), counts.as<uint32_t>(), ntiles,
+                           fin.stream_row.as<uint64_t>(), fargs);
+    }
+    CPH_HIP_TRY(hipGetLastError());
+    out->stream_row = std::move(fin.stream_row);
+    for (int s = 0; s < S; s++) out->build_row[s] = std::move(fin.build_row[s]);
     return {};
 }
 
@@ -272,54 +358,16 @@ Status chain_run(cph_ctx* ctx, const ChainStep* steps, int nsteps, uint64_t prob
     if (nprobe == 0) return {};
 
     if (fast_path_ok(steps, nsteps)) {
-        const uint64_t ntiles = (nprobe + kChainTile - 1) / kChainTile;
-        CPH_TRY(out->stream_row.alloc(&ctx->pool, nprobe * sizeof(uint64_t)));
-        ChainArgs args{};
-        size_t lds = 256;
-        for (int s = 0; s < nsteps; s++) {
-            const cph_index* ix = steps[s].index;
-            CPH_TRY(out->build_row[s].alloc(&ctx->pool, nprobe * sizeof(uint32_t)));
-            ChainStepArg& st = args.step[s];
-            st.col = steps[s].cols[0];
-            st.codec = ix->codec_dev.as<uint8_t>();
-            st.codec_bytes = (int32_t)ix->codec_dev.bytes();
-            st.table = ix->table_entries ? ix->table.as<TableEntry>() : nullptr;
-            st.codes = ix->sorted_codes.get();
-            st.perm = ix->perm.as<uint32_t>();
-            st.n_index = ix->nrows;
-            st.key32 = ix->codec.key32 ? 1 : 0;
-            args.out_rows[s] = out->build_row[s].as<uint32_t>();
-            lds += ix->codec_dev.bytes();
-        }
-        if (lds <= 160 * 1024) {
-            DevBuf state;   // [ntiles] tile words | ticket | error flag
-            CPH_TRY(state.alloc(&ctx->pool, (ntiles + 2) * sizeof(uint64_t)));
-            CPH_HIP_TRY(hipMemsetAsync(state.get(), 0, (ntiles + 2) * sizeof(uint64_t), ctx->stream));
-            uint64_t* st = state.as<uint64_t>();
-            uint32_t* ticket = reinterpret_cast<uint32_t*>(st + ntiles);
-            uint32_t* err = reinterpret_cast<uint32_t*>(st + ntiles + 1);
-            {
-                ProfScope ps(ctx, "k_chain_unique", 0);
-                switch (nsteps) {
-                case 1: CPH_TRY(launch_chain<1>(ctx, args, lds, nprobe, probe_base, st, ticket, out->stream_row.as<uint64_t>(), err, (unsigned)ntiles)); break;
-                case 2: CPH_TRY(launch_chain<2>(ctx, args, lds, nprobe, probe_base, st, ticket, out->stream_row.as<uint64_t>(), err, (unsigned)ntiles)); break;
-                case 3: CPH_TRY(launch_chain<3>(ctx, args, lds, nprobe, probe_base, st, ticket, out->stream_row.as<uint64_t>(), err, (unsigned)ntiles)); break;
-                default: CPH_TRY(launch_chain<4>(ctx, args, lds, nprobe, probe_base, st, ticket, out->stream_row.as<uint64_t>(), err, (unsigned)ntiles)); break;
-                }
+        size_t lds = 64;
+        for (int s = 0; s < nsteps; s++) lds += steps[s].index->codec_dev.bytes();
+        if (lds <= 150 * 1024) {
+            switch (nsteps) {
+            case 1: return run_fast<1>(ctx, steps, nprobe, probe_base, out);
+            case 2: return run_fast<2>(ctx, steps, nprobe, probe_base, out);
+            case 3: return run_fast<3>(ctx, steps, nprobe, probe_base, out);
+            default: return run_fast<4>(ctx, steps, nprobe, probe_base, out);
             }
-            CPH_TRY(ensure_pinned_scratch(ctx, 2 * sizeof(uint64_t)));
-            uint64_t* h = reinterpret_cast<uint64_t*>(ctx->pinned_scratch);
-            CPH_HIP_TRY(hipMemcpyAsync(h, st + ntiles - 1, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-            CPH_HIP_TRY(hipMemcpyAsync(h + 1, err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-            CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
-            if (*reinterpret_cast<const uint32_t*>(h + 1) != 0)
-                return {CPH_ERR_HIP, "chained join: tile look-back timed out"};
-            out->nrows = h[0] & kValueMask;
-            return {};
         }
-        // codecs do not fit LDS together: fall through to the general path
-        out->stream_row.reset();
-        for (int s = 0; s < nsteps; s++) out->build_row[s].reset();
     }
 
     // ---- general path: probe / select / compose, one step at a time ------------------------------------

@@ -11,12 +11,25 @@ struct ColsArg {
     DevCol c[kMaxKeyCols];
 };
 
+// [begin, begin+len) of value `row` inside col.data: no memory access for fixed-width columns.
+__device__ __forceinline__ void value_span(const DevCol& col, uint64_t row, uint64_t* begin, uint64_t* len) {
+    if (col.fixed_width) {
+        *begin = row * (uint64_t)col.fixed_width;
+        *len = col.fixed_width;
+    } else {
+        const uint64_t b = load_offset(col.offsets, col.offset_bits, row);
+        *begin = b;
+        *len = load_offset(col.offsets, col.offset_bits, row + 1) - b;
+    }
+}
+
 // View of the codec block once it sits in LDS.
 struct CodecView {
     const CodecDevHeader* hdr;
     const uint64_t* mult;
     const uint8_t* word_of;
-    const uint16_t* lut;
+    const uint16_t* lut;     // rank LUT (null when the pre-multiplied LUT is present)
+    const void* lutw;        // pre-multiplied LUT, u32 or u64 entries (hdr->lutw_bits), or null
 };
 
 // Cooperative copy of the codec block (global) into dynamic LDS; returns a view.
@@ -32,8 +45,37 @@ __device__ __forceinline__ CodecView codec_load_to_lds(const uint8_t* g_blob, ui
     v.hdr = reinterpret_cast<const CodecDevHeader*>(lds);
     v.mult = reinterpret_cast<const uint64_t*>(lds + v.hdr->mult_off);
     v.word_of = lds + v.hdr->wordof_off;
-    v.lut = reinterpret_cast<const uint16_t*>(lds + v.hdr->lut_off);
+    v.lut = v.hdr->lutw_bits ? nullptr : reinterpret_cast<const uint16_t*>(lds + v.hdr->lut_off);
+    v.lutw = v.hdr->lutw_bits ? static_cast<const void*>(lds + v.hdr->lutw_off) : nullptr;
     return v;
+}
+
+// Sum of pre-multiplied LUT entries over the leading columns: the whole (single-word) code in
+// one LDS load + add per byte position.  W = uint32_t / uint64_t; top bit = symbol not in alphabet.
+template <class W>
+__device__ __forceinline__ bool encode_key_premultiplied(const CodecView& cv, const ColsArg& cols, int ncols_used,
+                                                         uint64_t row, uint64_t* code) {
+    const W* lutw = reinterpret_cast<const W*>(cv.lutw);
+    W acc = 0, bad = 0;
+    bool valid = true;
+    for (int c = 0; c < ncols_used; c++) {
+        const DevCol& col = cols.c[c];
+        uint64_t begin, len;
+        value_span(col, row, &begin, &len);
+        const int maxlen = cv.hdr->col_maxlen[c];
+        const W* lp = lutw + cv.hdr->col_start[c] * kLutStride;
+        if (len > (uint64_t)maxlen) valid = false;
+        uint64_t chunk = 0;
+        for (int q = 0; q < maxlen; q++) {
+            if ((q & 7) == 0 && (uint64_t)q < len) chunk = load_value_chunk(col.data, begin, len, q >> 3);
+            const int sym = (uint64_t)q < len ? (int)((chunk >> (8 * (q & 7))) & 0xFF) + 1 : 0;
+            const W v = lp[q * kLutStride + sym];
+            bad |= v;
+            acc += v;
+        }
+    }
+    *code = (uint64_t)acc;
+    return valid && !(bad >> (sizeof(W) * 8 - 1));
 }
 
 // Encodes the leading `ncols_used` key columns of row `row`.
@@ -47,12 +89,19 @@ template <class Emit>
 __device__ __forceinline__ bool encode_key(const CodecView& cv, const ColsArg& cols, int ncols_used, uint64_t row,
                                            Emit&& emit) {
     const int p_end = cv.hdr->col_start[ncols_used];
+    if (cv.hdr->lutw_bits != 0) {   // single word, pre-multiplied LUT (uniform branch)
+        uint64_t code;
+        const bool valid = cv.hdr->lutw_bits == 32 ? encode_key_premultiplied<uint32_t>(cv, cols, ncols_used, row, &code)
+                                                   : encode_key_premultiplied<uint64_t>(cv, cols, ncols_used, row, &code);
+        if (p_end > 0) emit(0, code, p_end - 1);
+        return valid;
+    }
     uint64_t acc = 0;
     bool valid = true;
     for (int c = 0; c < ncols_used; c++) {
         const DevCol& col = cols.c[c];
-        const uint64_t begin = load_offset(col.offsets, col.offset_bits, row);
-        const uint64_t len = load_offset(col.offsets, col.offset_bits, row + 1) - begin;
+        uint64_t begin, len;
+        value_span(col, row, &begin, &len);
         const int maxlen = cv.hdr->col_maxlen[c];
         const int p0 = cv.hdr->col_start[c];
         if (len > (uint64_t)maxlen) valid = false;

@@ -129,8 +129,13 @@ struct CodecDevHeader {
     int32_t col_maxlen[kMaxKeyCols];
     int32_t mult_off;      // byte offsets from the start of the block
     int32_t wordof_off;
-    int32_t lut_off;
+    int32_t lut_off;       // rank LUT u16[npos][257]; 0 when the pre-multiplied LUT replaces it
     int32_t total_bytes;   // multiple of 16
+    // pre-multiplied LUT (single-word codes, when it fits): lutw[p][sym] = rank * mult[p], so the
+    // code is a plain sum of one LDS load per byte position; the top bit marks "symbol not in the
+    // alphabet".  lutw_bits = 0 (absent), 32 or 64.
+    int32_t lutw_off;
+    int32_t lutw_bits;
 };
 
 }  // namespace cph
@@ -198,6 +203,7 @@ struct DevCol {
     const void* offsets = nullptr;
     uint64_t nrows = 0;
     int32_t offset_bits = 32;
+    uint32_t fixed_width = 0;   // > 0: every value has this many bytes, offsets unused (may be null)
 };
 
 // keycodec.hip
@@ -208,6 +214,7 @@ struct ColStats {              // per column, produced by one pass over the colu
 Status codec_collect_stats(cph_ctx* ctx, const DevCol* cols, int32_t ncols, std::vector<ColStats>* out);
 Status codec_build(const std::vector<ColStats>& stats, CodecHost* codec);   // host only
 Status codec_upload(cph_ctx* ctx, const CodecHost& codec, DevBuf* dev);
+int codec_premultiplied_bits(const CodecHost& codec);   // 0 / 32 / 64
 // Encodes the build-side keys.  key32: out32[n]; else out64[nwords][n].
 Status codec_encode_build(cph_ctx* ctx, const CodecHost& codec, const DevBuf& codec_dev, const DevCol* cols,
                           uint64_t n, void* out_codes);

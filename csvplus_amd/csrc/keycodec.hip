@@ -41,8 +41,8 @@ __global__ __launch_bounds__(kStatsThreads) void k_col_stats(DevCol col, uint32_
     uint32_t mn = 0xFFFFFFFFu, mx = 0;
     const uint64_t stride = (uint64_t)gridDim.x * kStatsThreads;
     for (uint64_t row = (uint64_t)blockIdx.x * kStatsThreads + threadIdx.x; row < col.nrows; row += stride) {
-        const uint64_t begin = load_offset(col.offsets, col.offset_bits, row);
-        const uint64_t len64 = load_offset(col.offsets, col.offset_bits, row + 1) - begin;
+        uint64_t begin, len64;
+        value_span(col, row, &begin, &len64);
         const uint32_t len = len64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)len64;
         mn = len < mn ? len : mn;
         mx = len > mx ? len : mx;
@@ -171,6 +171,14 @@ Status codec_build(const std::vector<ColStats>& stats, CodecHost* codec) {
     return {};
 }
 
+// Width (32/64) of the pre-multiplied LUT the device codec block carries, 0 if none: single-word
+// codes whose table stays within 48 KiB of LDS.
+int codec_premultiplied_bits(const CodecHost& cd) {
+    if (cd.nwords != 1 || cd.npos <= 0) return 0;
+    const int bits = cd.word_states[0] <= (1ull << 31) ? 32 : 64;
+    return (size_t)cd.npos * kLutStride * (size_t)(bits / 8) <= 48 * 1024 ? bits : 0;
+}
+
 Status codec_upload(cph_ctx* ctx, const CodecHost& cd, DevBuf* dev) {
     CodecDevHeader h{};
     h.ncols = cd.ncols;
@@ -186,8 +194,18 @@ Status codec_upload(cph_ctx* ctx, const CodecHost& cd, DevBuf* dev) {
     off = align16(off + sizeof(uint64_t) * (size_t)cd.npos);
     h.wordof_off = (int32_t)off;
     off = align16(off + (size_t)cd.npos + 1);   // +1: word_of[p+1] is read at p = npos-1 only when guarded
-    h.lut_off = (int32_t)off;
-    off = align16(off + sizeof(uint16_t) * (size_t)cd.npos * kLutStride);
+    // pre-multiplied LUT when the code is a single word and the table stays small
+    const int lutw_bits = codec_premultiplied_bits(cd);
+    h.lutw_bits = lutw_bits;
+    if (lutw_bits) {
+        h.lut_off = 0;
+        h.lutw_off = (int32_t)off;
+        off = align16(off + (size_t)(lutw_bits / 8) * (size_t)cd.npos * kLutStride);
+    } else {
+        h.lutw_off = 0;
+        h.lut_off = (int32_t)off;
+        off = align16(off + sizeof(uint16_t) * (size_t)cd.npos * kLutStride);
+    }
     h.total_bytes = (int32_t)off;
 
     std::vector<uint8_t> blob(off, 0);
@@ -196,7 +214,21 @@ Status codec_upload(cph_ctx* ctx, const CodecHost& cd, DevBuf* dev) {
         memcpy(blob.data() + h.mult_off, cd.mult.data(), sizeof(uint64_t) * (size_t)cd.npos);
         for (int p = 0; p < cd.npos; p++) blob[(size_t)h.wordof_off + (size_t)p] = (uint8_t)cd.word_of[(size_t)p];
         blob[(size_t)h.wordof_off + (size_t)cd.npos] = 0xFF;
-        memcpy(blob.data() + h.lut_off, cd.lut.data(), sizeof(uint16_t) * (size_t)cd.npos * kLutStride);
+        if (lutw_bits == 32) {
+            uint32_t* w = reinterpret_cast<uint32_t*>(blob.data() + h.lutw_off);
+            for (size_t i = 0; i < (size_t)cd.npos * kLutStride; i++) {
+                const uint16_t r = cd.lut[i];
+                w[i] = r == kLutInvalid ? 0x80000000u : (uint32_t)((uint64_t)r * cd.mult[i / kLutStride]);
+            }
+        } else if (lutw_bits == 64) {
+            uint64_t* w = reinterpret_cast<uint64_t*>(blob.data() + h.lutw_off);
+            for (size_t i = 0; i < (size_t)cd.npos * kLutStride; i++) {
+                const uint16_t r = cd.lut[i];
+                w[i] = r == kLutInvalid ? 0x8000000000000000ull : (uint64_t)r * cd.mult[i / kLutStride];
+            }
+        } else {
+            memcpy(blob.data() + h.lut_off, cd.lut.data(), sizeof(uint16_t) * (size_t)cd.npos * kLutStride);
+        }
     }
     CPH_TRY(dev->alloc(&ctx->pool, off));
     CPH_TRY(ensure_pinned_scratch(ctx, off));

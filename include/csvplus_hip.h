@@ -77,6 +77,10 @@ typedef struct {
     uint64_t       nrows;
     int32_t        offset_bits; /* 32 or 64                                               */
     int32_t        mem;         /* CPH_MEM_HOST or CPH_MEM_DEVICE                         */
+    uint32_t       fixed_width; /* > 0: every value has exactly this many bytes, value i =
+                                   data[i*fixed_width ..); offsets is ignored (may be NULL).
+                                   Saves the offsets' HBM traffic and a dependent load.   */
+    uint32_t       reserved_;
 } cph_strcol;
 
 /* One key value (for cph_index_find). Host memory. */

@@ -38,7 +38,7 @@ def test_binding_covers_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
-    assert ctypes.sizeof(N.cph_strcol) == 32
+    assert ctypes.sizeof(N.cph_strcol) == 40
     assert ctypes.sizeof(N.cph_strval) == 16
     assert ctypes.sizeof(N.cph_matches) == 56
     assert ctypes.sizeof(N.cph_index_info) == 48

@@ -330,3 +330,30 @@ def test_config2_properties_1e7(ctx):
     np.testing.assert_array_equal(m.lo.astype(np.int64), ov)      # lo == sorted position == id
     info = g.info()
     assert info["sort_passes"] == 3 and info["key_bytes"] == 4 and info["code_bits"] == 24
+
+
+def test_fixed_width_columns_match_variable_path(ctx):
+    """cph_strcol.fixed_width (no offsets) must give the same bits as the same column with offsets."""
+    n, m = 30_000, 70_000
+    cust = dg.customers(n)["id"]
+    ords = dg.orders(m, n, 50)["cust_id"]
+    assert cust.fixed_width == 8 and ords.fixed_width == 8
+    gf = DeviceIndex(ctx, [cust], unique=True)
+    gv = DeviceIndex(ctx, [cust.as_variable()], unique=True)
+    np.testing.assert_array_equal(gf.perm(), gv.perm())
+    np.testing.assert_array_equal(gf.perm(), orc.OracleIndex([cust]).perm)
+    oj = orc.OracleIndex([cust]).join([ords])
+    for ix in (gf, gv):
+        for probe in (ords, ords.as_variable(), ords.to_device(), ords.as_variable().to_device()):
+            mt = ix.probe([probe])
+            assert_join_equal(mt, oj)
+    # fixed-width build side, variable-width probes of other lengths
+    probe = StrCol.from_values([b"00000007", b"7", b"000000070", b"", b"00000003"])
+    assert_join_equal(gf.probe([probe]), orc.OracleIndex([cust]).join([probe]))
+    # 3-byte fixed-width keys with NULs and high bytes
+    rng = np.random.default_rng(1)
+    keys = [bytes(rng.integers(0, 256, 3).astype(np.uint8)) for _ in range(5000)]
+    col = StrCol.from_values(keys)
+    assert col.fixed_width == 3
+    g, o = check_index(ctx, [col])
+    assert_join_equal(g.probe([col]), o.join([col]))
