@@ -60,44 +60,42 @@ struct ChainArgs {
 // single-column, single-word encode from the prefetched first 16 bytes of the value, using the
 // codec's pre-multiplied LUT (one LDS load + add per byte position; the fast path requires it)
 template <class W>
-__device__ __forceinline__ bool encode_prefetched_w(const CodecView& cv, const DevCol& col, uint64_t begin, uint64_t len,
+__device__ __forceinline__ bool encode_prefetched_w(const CodecView& cv, const DevCol& col, uint64_t begin, uint32_t len,
                                                     uint64_t c0, uint64_t c1, uint64_t* code) {
     const int maxlen = cv.hdr->col_maxlen[0];
-    const W* lutw = reinterpret_cast<const W*>(cv.lutw);
+    const CPH_LDS W* lutw = (const CPH_LDS W*)cv.lutw;
     W acc = 0, bad = 0;
     uint64_t chunk = c0;
     for (int q = 0; q < maxlen; q++) {
         if ((q & 7) == 0) {
             if (q == 8) chunk = c1;
-            else if (q >= 16 && (uint64_t)q < len) chunk = load_value_chunk(col.data, begin, len, q >> 3);
+            else if (q >= 16 && (uint32_t)q < len) chunk = load_value_chunk(col.data, begin, len, q >> 3);
         }
-        const int sym = (uint64_t)q < len ? (int)((chunk >> (8 * (q & 7))) & 0xFF) + 1 : 0;
+        const uint32_t sym = (uint32_t)q < len ? ((uint32_t)(chunk >> (8 * (q & 7))) & 0xFFu) + 1u : 0u;
         const W v = lutw[q * kLutStride + sym];
         bad |= v;
         acc += v;
     }
     *code = (uint64_t)acc;
-    return len <= (uint64_t)maxlen && !(bad >> (sizeof(W) * 8 - 1));
-}
-__device__ __forceinline__ bool encode_prefetched(const CodecView& cv, const DevCol& col, uint64_t begin, uint64_t len,
-                                                  uint64_t c0, uint64_t c1, uint64_t* code) {
-    return cv.hdr->lutw_bits == 32 ? encode_prefetched_w<uint32_t>(cv, col, begin, len, c0, c1, code)
-                                   : encode_prefetched_w<uint64_t>(cv, col, begin, len, c0, c1, code);
+    return len <= (uint32_t)maxlen && !(bad >> (sizeof(W) * 8 - 1));
 }
 
-// dbg: attribution switches for tools/microbench (results are wrong when set):
-//      1 = no table lookup, 2 = no encode, 4 = no output stores
-template <int S>
+// DBG: attribution switches for tools/microbench (results are wrong when set):
+//      dbg & 1 = no table lookup, & 2 = no encode, & 4 = no output stores.  LONG: some step's
+//      index has keys longer than 8 bytes (then bytes 8..15 are prefetched too).
+// Uniform decisions (fixed-width column? 32-bit LUT? direct table?) are hoisted out of the row
+// loops so that the kChainRows loads of a phase sit in one basic block and overlap.
+template <int S, bool LONG, bool DBG>
 __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint64_t nprobe, uint64_t probe_base,
                                                               uint64_t ntiles, uint64_t* __restrict__ out_stream,
                                                               uint64_t* __restrict__ masks,
-                                                              uint32_t* __restrict__ tile_counts, int dbg) {
+                                                              uint32_t* __restrict__ wave_counts, int dbg_flags) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    // dynamic LDS layout: [scratch 64 B][codec 0][codec 1]...   (no static LDS: keeps 16-B alignment)
-    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem);   // [kChainWaves]
+    // dynamic LDS layout: [codec 0][codec 1]...   (no static LDS: keeps 16-B alignment)
+    const int dbg = DBG ? dbg_flags : 0;
     CodecView cv[S];
     {
-        uint8_t* p = smem + 64;
+        uint8_t* p = smem;
 #pragma unroll
         for (int s = 0; s < S; s++) {
             cv[s] = codec_load_to_lds(a.step[s].codec, p);   // syncs inside
@@ -109,43 +107,83 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
 #pragma unroll 1
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint64_t tile0 = tile * kChainTile;
-        // ---- A: offsets -------------------------------------------------------------------------
-        uint64_t begin[kChainRows][S];
-        uint32_t len[kChainRows][S];
         bool ok[kChainRows];
+        uint64_t row[kChainRows];
 #pragma unroll
         for (int k = 0; k < kChainRows; k++) {
-            const uint64_t row = tile0 + (uint64_t)k * kChainThreads + threadIdx.x;
-            ok[k] = row < nprobe;
+            row[k] = tile0 + (uint64_t)k * kChainThreads + threadIdx.x;
+            ok[k] = row[k] < nprobe;
+        }
+        // ---- A: value spans ----------------------------------------------------------------------
+        uint64_t begin[kChainRows][S];
+        uint32_t len[kChainRows][S];
 #pragma unroll
-            for (int s = 0; s < S; s++) {
-                const DevCol& c = a.step[s].col;
-                uint64_t b = 0, l = 0;
-                if (ok[k]) value_span(c, row, &b, &l);
-                begin[k][s] = b;
-                len[k][s] = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;
+        for (int s = 0; s < S; s++) {
+            const DevCol& c = a.step[s].col;
+            if (c.fixed_width) {
+#pragma unroll
+                for (int k = 0; k < kChainRows; k++) {
+                    begin[k][s] = row[k] * (uint64_t)c.fixed_width;
+                    len[k][s] = ok[k] ? c.fixed_width : 0u;
+                }
+            } else if (c.offset_bits == 32) {
+                const uint32_t* off = reinterpret_cast<const uint32_t*>(c.offsets);
+                uint32_t b[kChainRows], e[kChainRows];
+#pragma unroll
+                for (int k = 0; k < kChainRows; k++) {
+                    b[k] = ok[k] ? off[row[k]] : 0u;
+                    e[k] = ok[k] ? off[row[k] + 1] : 0u;
+                }
+#pragma unroll
+                for (int k = 0; k < kChainRows; k++) {
+                    begin[k][s] = b[k];
+                    len[k][s] = e[k] - b[k];
+                }
+            } else {
+                const uint64_t* off = reinterpret_cast<const uint64_t*>(c.offsets);
+                uint64_t b[kChainRows], e[kChainRows];
+#pragma unroll
+                for (int k = 0; k < kChainRows; k++) {
+                    b[k] = ok[k] ? off[row[k]] : 0ull;
+                    e[k] = ok[k] ? off[row[k] + 1] : 0ull;
+                }
+#pragma unroll
+                for (int k = 0; k < kChainRows; k++) {
+                    begin[k][s] = b[k];
+                    const uint64_t l = e[k] - b[k];
+                    len[k][s] = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;
+                }
             }
         }
-        // ---- B: first 16 key bytes ------------------------------------------------------------------
-        uint64_t c0[kChainRows][S], c1[kChainRows][S];
+        // ---- B: first 8 (16) key bytes ---------------------------------------------------------------
+        uint64_t c0[kChainRows][S], c1[kChainRows][LONG ? S : 1];
 #pragma unroll
-        for (int k = 0; k < kChainRows; k++)
+        for (int s = 0; s < S; s++) {
+            const DevCol& c = a.step[s].col;
 #pragma unroll
-            for (int s = 0; s < S; s++) {
-                const DevCol& c = a.step[s].col;
+            for (int k = 0; k < kChainRows; k++) {
                 c0[k][s] = len[k][s] > 0 ? load_value_chunk(c.data, begin[k][s], len[k][s], 0) : 0;
-                c1[k][s] = len[k][s] > 8 ? load_value_chunk(c.data, begin[k][s], len[k][s], 1) : 0;
+                if constexpr (LONG) c1[k][s] = len[k][s] > 8 ? load_value_chunk(c.data, begin[k][s], len[k][s], 1) : 0;
             }
-        // ---- C: codes ----------------------------------------------------------------------------------
+        }
+        // ---- C: codes -----------------------------------------------------------------------------------
         uint64_t code[kChainRows][S];
 #pragma unroll
-        for (int k = 0; k < kChainRows; k++)
+        for (int s = 0; s < S; s++) {
+            const bool w32 = cv[s].hdr->lutw_bits == 32;
 #pragma unroll
-            for (int s = 0; s < S; s++) {
-                if (dbg & 2) code[k][s] = (c0[k][s] ^ c1[k][s]) & 1023;
-                else ok[k] &= encode_prefetched(cv[s], a.step[s].col, begin[k][s], len[k][s], c0[k][s], c1[k][s], &code[k][s]);
+            for (int k = 0; k < kChainRows; k++) {
+                const uint64_t hi = LONG ? c1[k][LONG ? s : 0] : 0ull;
+                if (DBG && (dbg & 2)) {
+                    code[k][s] = (c0[k][s] ^ hi) & 1023;
+                } else if (w32) {
+                    ok[k] &= encode_prefetched_w<uint32_t>(cv[s], a.step[s].col, begin[k][s], len[k][s], c0[k][s], hi, &code[k][s]);
+                } else {
+                    ok[k] &= encode_prefetched_w<uint64_t>(cv[s], a.step[s].col, begin[k][s], len[k][s], c0[k][s], hi, &code[k][s]);
+                }
             }
-        // ---- D: lookups --------------------------------------------------------------------------------
+        }
+        // ---- D: lookups ---------------------------------------------------------------------------------
         uint32_t brow[kChainRows][S];
 #pragma unroll
         for (int s = 0; s < S; s++) {
@@ -153,8 +191,10 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
             if (st.table) {
                 TableEntry e[kChainRows];
 #pragma unroll
-                for (int k = 0; k < kChainRows; k++)
-                    e[k] = (ok[k] && !(dbg & 1)) ? st.table[code[k][s]] : TableEntry{(dbg & 1) ? 0u : kTableAbsent, 0};
+                for (int k = 0; k < kChainRows; k++) {
+                    if (DBG && (dbg & 1)) e[k] = TableEntry{0u, 0u};
+                    else e[k] = ok[k] ? st.table[code[k][s]] : TableEntry{kTableAbsent, 0u};
+                }
 #pragma unroll
                 for (int k = 0; k < kChainRows; k++) {
                     ok[k] &= e[k].a != kTableAbsent;
@@ -181,33 +221,25 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
                 }
             }
         }
-        // ---- dense output + match bookkeeping ---------------------------------------------------------
+        // ---- dense output + match bookkeeping ----------------------------------------------------------
         uint32_t wave_matches = 0;
 #pragma unroll
         for (int k = 0; k < kChainRows; k++) {
             const uint64_t bal = __ballot(ok[k]);
             wave_matches += (uint32_t)__popcll(bal);
             if (lane == 0) masks[tile * kChainMasks + k * kChainWaves + wave] = bal;
-            if (ok[k] && !(dbg & 4)) {
-                const uint64_t row = tile0 + (uint64_t)k * kChainThreads + threadIdx.x;
-                out_stream[row] = probe_base + row;
+            if (ok[k] && !(DBG && (dbg & 4))) {
+                out_stream[row[k]] = probe_base + row[k];
 #pragma unroll
-                for (int s = 0; s < S; s++) a.out_rows[s][row] = brow[k][s];
+                for (int s = 0; s < S; s++) a.out_rows[s][row[k]] = brow[k][s];
             }
         }
-        if (lane == 0) s_cnt[wave] = wave_matches;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t t = 0;
-#pragma unroll
-            for (int w = 0; w < kChainWaves; w++) t += s_cnt[w];
-            tile_counts[tile] = t;
-        }
-        __syncthreads();   // s_cnt is rewritten by the next tile
+        // per-(tile, wave) match count: no workgroup-level synchronisation inside the tile loop
+        if (lane == 0) wave_counts[tile * kChainWaves + wave] = wave_matches;
     }
 }
 
-// total = sum of the tile counts (single workgroup; ntiles ~ rows/1024)
+// total = sum of the per-(tile, wave) counts (single workgroup; n ~ rows/256)
 __global__ __launch_bounds__(1024) void k_sum_counts(const uint32_t* __restrict__ counts, uint64_t n,
                                                     uint64_t* __restrict__ total) {
     __shared__ uint64_t s_w[1024 / kWave];
@@ -242,7 +274,7 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_compact(ChainArgs dense
             if (lane < kChainMasks) s_pref[lane] = incl - v;
         }
         __syncthreads();
-        const uint64_t base = tile_base[tile];
+        const uint64_t base = tile_base[tile * kChainWaves];   // scanned (tile, wave) counts: first entry of the tile
 #pragma unroll
         for (int k = 0; k < kChainRows; k++) {
             const uint64_t m = s_mask[k * kChainWaves + wave];
@@ -286,7 +318,7 @@ static Status run_fast(cph_ctx* ctx, const ChainStep* steps, uint64_t nprobe, ui
     const uint64_t ntiles = (nprobe + kChainTile - 1) / kChainTile;
     CPH_TRY(out->stream_row.alloc(&ctx->pool, nprobe * sizeof(uint64_t)));
     ChainArgs args{};
-    size_t lds = 64;
+    size_t lds = 0;
     for (int s = 0; s < S; s++) {
         const cph_index* ix = steps[s].index;
         CPH_TRY(out->build_row[s].alloc(&ctx->pool, nprobe * sizeof(uint32_t)));
@@ -304,21 +336,33 @@ static Status run_fast(cph_ctx* ctx, const ChainStep* steps, uint64_t nprobe, ui
     }
     DevBuf masks, counts, total;
     CPH_TRY(masks.alloc(&ctx->pool, ntiles * kChainMasks * sizeof(uint64_t)));
-    CPH_TRY(counts.alloc(&ctx->pool, ntiles * sizeof(uint32_t)));
+    const uint64_t ncounts = ntiles * kChainWaves;   // one match count per (tile, wave), tile-major
+    CPH_TRY(counts.alloc(&ctx->pool, ncounts * sizeof(uint32_t)));
     CPH_TRY(total.alloc(&ctx->pool, sizeof(uint64_t)));
     const char* e = std::getenv("CPH_CHAIN_DEBUG");
     const int dbg = e ? std::atoi(e) : 0;
-    CPH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_dense<S>),
+    bool long_keys = false;
+    for (int s = 0; s < S; s++) long_keys |= steps[s].index->codec.col_maxlen[0] > 8;
+    auto kernel = dbg ? (long_keys ? &k_chain_dense<S, true, true> : &k_chain_dense<S, false, true>)
+                      : (long_keys ? &k_chain_dense<S, true, false> : &k_chain_dense<S, false, false>);
+    CPH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * 8);
+    // persistent workgroups: exactly as many as are resident at once (no tail wave), each walking
+    // tiles blockIdx, blockIdx + grid, ...
+    int per_cu = 0, dev = 0, cus = 256;
+    CPH_HIP_TRY(hipGetDevice(&dev));
+    CPH_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    CPH_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kChainThreads, lds));
+    if (per_cu < 1) per_cu = 1;
+    const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)cus * (uint64_t)per_cu);
     {
         ProfScope ps(ctx, "k_chain_dense", 0);
-        hipLaunchKernelGGL(k_chain_dense<S>, dim3(grid), dim3(kChainThreads), lds, ctx->stream, args, nprobe, probe_base,
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kChainThreads), lds, ctx->stream, args, nprobe, probe_base,
                            ntiles, out->stream_row.as<uint64_t>(), masks.as<uint64_t>(), counts.as<uint32_t>(), dbg);
     }
     {
-        ProfScope ps(ctx, "k_sum_counts", 4.0 * (double)ntiles);
-        hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(1024), 0, ctx->stream, counts.as<uint32_t>(), ntiles,
+        ProfScope ps(ctx, "k_sum_counts", 4.0 * (double)ncounts);
+        hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(1024), 0, ctx->stream, counts.as<uint32_t>(), ncounts,
                            total.as<uint64_t>());
     }
     CPH_HIP_TRY(hipGetLastError());
@@ -331,7 +375,7 @@ static Status run_fast(cph_ctx* ctx, const ChainStep* steps, uint64_t nprobe, ui
     if (nmatch == nprobe || nmatch == 0) return {};   // dense arrays are already final / nothing to keep
 
     // compaction: tile bases, then move the tuples
-    CPH_TRY(exclusive_scan_u32(ctx, counts.as<uint32_t>(), ntiles));
+    CPH_TRY(exclusive_scan_u32(ctx, counts.as<uint32_t>(), ncounts));
     ChainOut fin;
     CPH_TRY(fin.stream_row.alloc(&ctx->pool, nmatch * sizeof(uint64_t)));
     ChainArgs fargs{};
@@ -358,7 +402,7 @@ Status chain_run(cph_ctx* ctx, const ChainStep* steps, int nsteps, uint64_t prob
     if (nprobe == 0) return {};
 
     if (fast_path_ok(steps, nsteps)) {
-        size_t lds = 64;
+        size_t lds = 0;
         for (int s = 0; s < nsteps; s++) lds += steps[s].index->codec_dev.bytes();
         if (lds <= 150 * 1024) {
             switch (nsteps) {

@@ -23,13 +23,17 @@ __device__ __forceinline__ void value_span(const DevCol& col, uint64_t row, uint
     }
 }
 
+// LDS-qualified pointers: without the explicit address space the compiler falls back to flat
+// loads for tables reached through a struct (seen in the ISA: flat_load instead of ds_read).
+#define CPH_LDS __attribute__((address_space(3)))
+
 // View of the codec block once it sits in LDS.
 struct CodecView {
-    const CodecDevHeader* hdr;
-    const uint64_t* mult;
-    const uint8_t* word_of;
-    const uint16_t* lut;     // rank LUT (null when the pre-multiplied LUT is present)
-    const void* lutw;        // pre-multiplied LUT, u32 or u64 entries (hdr->lutw_bits), or null
+    const CPH_LDS CodecDevHeader* hdr;
+    const CPH_LDS uint64_t* mult;
+    const CPH_LDS uint8_t* word_of;
+    const CPH_LDS uint16_t* lut;     // rank LUT (unused when the pre-multiplied LUT is present)
+    const CPH_LDS uint8_t* lutw;     // pre-multiplied LUT, u32 or u64 entries (hdr->lutw_bits)
 };
 
 // Cooperative copy of the codec block (global) into dynamic LDS; returns a view.
@@ -41,12 +45,13 @@ __device__ __forceinline__ CodecView codec_load_to_lds(const uint8_t* g_blob, ui
     uint4* dst = reinterpret_cast<uint4*>(lds);
     for (int i = threadIdx.x; i < total / 16; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
+    const CPH_LDS uint8_t* l = (const CPH_LDS uint8_t*)lds;
     CodecView v;
-    v.hdr = reinterpret_cast<const CodecDevHeader*>(lds);
-    v.mult = reinterpret_cast<const uint64_t*>(lds + v.hdr->mult_off);
-    v.word_of = lds + v.hdr->wordof_off;
-    v.lut = v.hdr->lutw_bits ? nullptr : reinterpret_cast<const uint16_t*>(lds + v.hdr->lut_off);
-    v.lutw = v.hdr->lutw_bits ? static_cast<const void*>(lds + v.hdr->lutw_off) : nullptr;
+    v.hdr = (const CPH_LDS CodecDevHeader*)l;
+    v.mult = (const CPH_LDS uint64_t*)(l + v.hdr->mult_off);
+    v.word_of = l + v.hdr->wordof_off;
+    v.lut = (const CPH_LDS uint16_t*)(l + v.hdr->lut_off);
+    v.lutw = l + v.hdr->lutw_off;
     return v;
 }
 
@@ -55,7 +60,7 @@ __device__ __forceinline__ CodecView codec_load_to_lds(const uint8_t* g_blob, ui
 template <class W>
 __device__ __forceinline__ bool encode_key_premultiplied(const CodecView& cv, const ColsArg& cols, int ncols_used,
                                                          uint64_t row, uint64_t* code) {
-    const W* lutw = reinterpret_cast<const W*>(cv.lutw);
+    const CPH_LDS W* lutw = (const CPH_LDS W*)cv.lutw;
     W acc = 0, bad = 0;
     bool valid = true;
     for (int c = 0; c < ncols_used; c++) {
@@ -63,7 +68,7 @@ __device__ __forceinline__ bool encode_key_premultiplied(const CodecView& cv, co
         uint64_t begin, len;
         value_span(col, row, &begin, &len);
         const int maxlen = cv.hdr->col_maxlen[c];
-        const W* lp = lutw + cv.hdr->col_start[c] * kLutStride;
+        const CPH_LDS W* lp = lutw + cv.hdr->col_start[c] * kLutStride;
         if (len > (uint64_t)maxlen) valid = false;
         uint64_t chunk = 0;
         for (int q = 0; q < maxlen; q++) {

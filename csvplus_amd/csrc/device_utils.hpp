@@ -84,7 +84,9 @@ __device__ __forceinline__ uint64_t load_value_chunk(const uint8_t* data, uint64
     const uint64_t first = begin + 8ull * (uint64_t)j;                       // byte offset of the chunk
     const uint64_t a = (uint64_t)(uintptr_t)data + first;                    // absolute address
     const uint64_t last = (uint64_t)(uintptr_t)data + begin + (len < 8ull * (j + 1) ? len : 8ull * (j + 1)) - 1;
-    const uint64_t* wp = reinterpret_cast<const uint64_t*>(a & ~7ull);
+    // integer -> pointer casts are generic (flat_load); the column bytes live in global memory
+    typedef const __attribute__((address_space(1))) uint64_t* global_u64_ptr;
+    const global_u64_ptr wp = (global_u64_ptr)(a & ~7ull);
     const int sh = (int)(a & 7ull) * 8;
     uint64_t w0 = wp[0];
     uint64_t v = w0 >> sh;
