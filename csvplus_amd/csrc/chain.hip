@@ -239,19 +239,20 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
     }
 }
 
-// total = sum of the per-(tile, wave) counts (single workgroup; n ~ rows/256)
-__global__ __launch_bounds__(1024) void k_sum_counts(const uint32_t* __restrict__ counts, uint64_t n,
-                                                    uint64_t* __restrict__ total) {
-    __shared__ uint64_t s_w[1024 / kWave];
+// total += sum of the per-(tile, wave) counts (grid-stride; one atomic per workgroup)
+__global__ __launch_bounds__(256) void k_sum_counts(const uint32_t* __restrict__ counts, uint64_t n,
+                                                   unsigned long long* __restrict__ total) {
+    __shared__ uint64_t s_w[256 / kWave];
     uint64_t t = 0;
-    for (uint64_t i = threadIdx.x; i < n; i += 1024) t += counts[i];
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) t += counts[i];
     t = wave_sum(t);
     if (lane_id() == 0) s_w[wave_id()] = t;
     __syncthreads();
     if (threadIdx.x == 0) {
         uint64_t r = 0;
-        for (int w = 0; w < 1024 / kWave; w++) r += s_w[w];
-        *total = r;
+        for (int w = 0; w < 256 / kWave; w++) r += s_w[w];
+        if (r) atomicAdd(total, (unsigned long long)r);
     }
 }
 
@@ -362,8 +363,10 @@ static Status run_fast(cph_ctx* ctx, const ChainStep* steps, uint64_t nprobe, ui
     }
     {
         ProfScope ps(ctx, "k_sum_counts", 4.0 * (double)ncounts);
-        hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(1024), 0, ctx->stream, counts.as<uint32_t>(), ncounts,
-                           total.as<uint64_t>());
+        CPH_HIP_TRY(hipMemsetAsync(total.get(), 0, sizeof(uint64_t), ctx->stream));
+        const unsigned sgrid = (unsigned)std::min<uint64_t>((ncounts + 255) / 256, 512);
+        hipLaunchKernelGGL(k_sum_counts, dim3(sgrid), dim3(256), 0, ctx->stream, counts.as<uint32_t>(), ncounts,
+                           total.as<unsigned long long>());
     }
     CPH_HIP_TRY(hipGetLastError());
     CPH_TRY(ensure_pinned_scratch(ctx, sizeof(uint64_t)));

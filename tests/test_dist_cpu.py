@@ -1,0 +1,95 @@
+"""N>1 path on CPU: 2-rank gloo runs of the sharding + allgatherv exchange (csvplus_amd/dist.py).
+The compute inside each shard is done by the ORACLE here (test infrastructure) — the product path
+needs a GPU; what is under test is the host logic: row ranges, counts, displacement, rank order."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from csvplus_amd import datagen as dg
+from csvplus_amd.dist import allgatherv, sharded_chained_join
+from csvplus_amd.engine import shard_range
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_shard_ranges_partition_the_stream():
+    for total in (0, 1, 7, 1000, 10**8 + 3):
+        for world in (1, 2, 3, 8):
+            r = [shard_range(total, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == total
+            assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
+            sizes = [e - b for b, e in r]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, m, nc, npd, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import orc
+
+        # uneven allgatherv, including an empty contribution
+        t = torch.arange(rank * 10, rank * 10 + (3 if rank == 0 else 0 if rank == 1 else 5), dtype=torch.int64)
+        g, counts = allgatherv(t)
+        exp = torch.cat([torch.arange(r * 10, r * 10 + (3 if r == 0 else 0 if r == 1 else 5), dtype=torch.int64)
+                         for r in range(world)])
+        assert counts == [3, 0, 5][:world] and torch.equal(g, exp)
+
+        cust = dg.column(dg.SEQ_PERM, nc, nc, encoding=dg.FIXED8, seed=dg.SEED + 1)
+        prod = dg.column(dg.SEQ_PERM, npd, npd, encoding=dg.ITOA, seed=dg.SEED + 2)
+        ia, ib = orc.OracleIndex([cust]), orc.OracleIndex([prod])
+
+        def local_join(begin, end):
+            # each rank generates ITS row range only (counter-based generator)
+            o = dg.orders(m, 2 * nc, npd, row0=begin, nrows=end - begin)   # half of the cust ids miss
+            j1 = ia.join([o["cust_id"]], probe_base=begin)
+            sel = (j1["probe_idx"] - begin).astype(np.uint32)
+            j2 = ib.join([o["prod_id"]], row_sel=sel)
+            pick = j2["probe_idx"].astype(np.int64)
+            return (torch.from_numpy(j1["probe_idx"][pick].astype(np.int64)),
+                    torch.from_numpy(j1["build_row"][pick].astype(np.int32)),
+                    torch.from_numpy(j2["build_row"].astype(np.int32)))
+
+        s, a, b, counts = sharded_chained_join(m, local_join)
+        # reference result: the whole stream on one rank
+        o = dg.orders(m, 2 * nc, npd)
+        j1 = ia.join([o["cust_id"]])
+        j2 = ib.join([o["prod_id"]], row_sel=j1["probe_idx"].astype(np.uint32))
+        pick = j2["probe_idx"].astype(np.int64)
+        assert sum(counts) == len(pick) and len(counts) == world
+        np.testing.assert_array_equal(s.numpy(), j1["probe_idx"][pick].astype(np.int64))
+        np.testing.assert_array_equal(a.numpy(), j1["build_row"][pick].astype(np.int32))
+        np.testing.assert_array_equal(b.numpy(), j2["build_row"].astype(np.int32))
+        # without the exchange every rank keeps only its shard
+        s2, _, _, c2 = sharded_chained_join(m, local_join, exchange=False)
+        begin, end = shard_range(m, rank, world)
+        assert len(c2) == 1 and ((s2.numpy() >= begin) & (s2.numpy() < end)).all()
+        q.put((rank, "ok"))
+    except Exception as e:   # noqa: BLE001
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_join_allgatherv_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 20_001, 3000, 50, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(r, "ok") for r in range(world)], results
