@@ -40,6 +40,7 @@ def parse_args():
     ap.add_argument("--products", type=int, default=100_000)
     ap.add_argument("--exchange", choices=["allgatherv", "none"], default="allgatherv")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-index-1e8", action="store_true", help="skip the extra IndexOn-at-full-size measurements")
     ap.add_argument("--cpu-sample-rows", type=int, default=4_000_000)
     return ap.parse_args()
 
@@ -186,6 +187,41 @@ def main():
         "roofline": roofline,
         "host": {"nproc": os.cpu_count(), "gpu": torch.cuda.get_device_name(dev), "datagen_s": round(gen_s, 1)},
     }
+
+    # ---- IndexOn at 1e8 rows (the other half of BASELINE's metric; reported, not part of `value`) ---
+    if world == 1 and not args.no_index_1e8:
+        def time_index(col, unique, reps):
+            d = col.to_device(dev)
+            eng.index_on([d], unique=unique).close()   # warm-up (pool, LDS attributes)
+            eng.ctx.profile(True)
+            eng.ctx.profile_read(reset=True)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                ix = eng.index_on([d], unique=unique)
+                inf = ix.info()
+                ix.close()
+            torch.cuda.synchronize(dev)
+            wall = (time.perf_counter() - t0) / reps
+            p = eng.ctx.profile_read(reset=True)
+            eng.ctx.profile(False)
+            kms = sum(v["total_ms"] for v in p.values()) / reps
+            n = col.nrows
+            # algorithmic bytes: stats + encode read the column, every pass moves (2K+8) B/row after a
+            # K B/row histogram read, first_dup reads the codes, the table (if any) takes K+12 B/row
+            K_ = inf["key_bytes"] * inf["code_words"]
+            src = col.nbytes_values() + col.nbytes_offsets()
+            algo = 2 * src + n * K_ + inf["sort_passes"] * n * (3 * inf["key_bytes"] + 8) + n * K_ \
+                + (n * (inf["key_bytes"] + 12) if inf["direct_table"] else 0)
+            return {"rows": n, "ms": round(wall * 1e3, 3), "kernel_ms": round(kms, 3), "rows_per_s": n / wall,
+                    "GBps_algorithmic": round(algo / 1e9 / wall, 1), "info": inf,
+                    "kernels_ms": {k: round(v["total_ms"] / reps, 3) for k, v in p.items()}}
+
+        n8 = args.rows
+        out["index_on_1e8"] = {
+            "unique_fixed8_ids": time_index(dg.column(dg.SEQ_PERM, n8, n8, encoding=dg.FIXED8, seed=7), True, 3),
+            "varlen_dup_keys_config3": time_index(dg.varkeys(n8), False, 2),
+        }
 
     # ---- CPU baseline: the oracle (C restatement of the reference), bounded sample ----------------
     if world == 1 and not args.no_cpu_baseline:

@@ -57,29 +57,6 @@ struct ChainArgs {
     uint32_t* out_rows[kMaxChain];
 };
 
-// single-column, single-word encode from the prefetched first 16 bytes of the value, using the
-// codec's pre-multiplied LUT (one LDS load + add per byte position; the fast path requires it)
-template <class W>
-__device__ __forceinline__ bool encode_prefetched_w(const CodecView& cv, const DevCol& col, uint64_t begin, uint32_t len,
-                                                    uint64_t c0, uint64_t c1, uint64_t* code) {
-    const int maxlen = cv.hdr->col_maxlen[0];
-    const CPH_LDS W* lutw = (const CPH_LDS W*)cv.lutw;
-    W acc = 0, bad = 0;
-    uint64_t chunk = c0;
-    for (int q = 0; q < maxlen; q++) {
-        if ((q & 7) == 0) {
-            if (q == 8) chunk = c1;
-            else if (q >= 16 && (uint32_t)q < len) chunk = load_value_chunk(col.data, begin, len, q >> 3);
-        }
-        const uint32_t sym = (uint32_t)q < len ? ((uint32_t)(chunk >> (8 * (q & 7))) & 0xFFu) + 1u : 0u;
-        const W v = lutw[q * kLutStride + sym];
-        bad |= v;
-        acc += v;
-    }
-    *code = (uint64_t)acc;
-    return len <= (uint32_t)maxlen && !(bad >> (sizeof(W) * 8 - 1));
-}
-
 // DBG: attribution switches for tools/microbench (results are wrong when set):
 //      dbg & 1 = no table lookup, & 2 = no encode, & 4 = no output stores.  LONG: some step's
 //      index has keys longer than 8 bytes (then bytes 8..15 are prefetched too).

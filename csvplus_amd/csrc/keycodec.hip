@@ -29,6 +29,7 @@ namespace cph {
 // presence bitmap of the byte values seen there.
 // ---------------------------------------------------------------------------------------------
 constexpr int kStatsThreads = 256;
+constexpr int kStatsRows = 4;
 
 __global__ __launch_bounds__(kStatsThreads) void k_col_stats(DevCol col, uint32_t* __restrict__ g_minmax,
                                                             uint32_t* __restrict__ g_mask) {
@@ -39,21 +40,36 @@ __global__ __launch_bounds__(kStatsThreads) void k_col_stats(DevCol col, uint32_
     __syncthreads();
 
     uint32_t mn = 0xFFFFFFFFu, mx = 0;
-    const uint64_t stride = (uint64_t)gridDim.x * kStatsThreads;
-    for (uint64_t row = (uint64_t)blockIdx.x * kStatsThreads + threadIdx.x; row < col.nrows; row += stride) {
-        uint64_t begin, len64;
-        value_span(col, row, &begin, &len64);
-        const uint32_t len = len64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)len64;
-        mn = len < mn ? len : mn;
-        mx = len > mx ? len : mx;
-        const int lim = len < (uint32_t)kMaxKeyBytes ? (int)len : kMaxKeyBytes;
-        uint64_t chunk = 0;
-        for (int q = 0; q < lim; q++) {
-            if ((q & 7) == 0) chunk = load_value_chunk(col.data, begin, len64, q >> 3);
-            const uint32_t b = (uint32_t)((chunk >> (8 * (q & 7))) & 0xFF);
-            const int idx = q * 8 + (int)(b >> 5);
-            const uint32_t bit = 1u << (b & 31);
-            if (!(s_mask[idx] & bit)) atomicOr(&s_mask[idx], bit);
+    // kStatsRows rows per thread and iteration: spans first, then the first 8 bytes of every row,
+    // so that the loads overlap (one row at a time left this kernel latency-bound)
+    const uint64_t stride = (uint64_t)gridDim.x * kStatsThreads * kStatsRows;
+    for (uint64_t base = (uint64_t)blockIdx.x * kStatsThreads * kStatsRows; base < col.nrows; base += stride) {
+        uint64_t begin[kStatsRows], len64[kStatsRows], c0[kStatsRows];
+#pragma unroll
+        for (int k = 0; k < kStatsRows; k++) {
+            const uint64_t row = base + (uint64_t)k * kStatsThreads + threadIdx.x;
+            begin[k] = 0;
+            len64[k] = 0;
+            if (row < col.nrows) value_span(col, row, &begin[k], &len64[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < kStatsRows; k++) c0[k] = len64[k] ? load_value_chunk(col.data, begin[k], len64[k], 0) : 0;
+#pragma unroll
+        for (int k = 0; k < kStatsRows; k++) {
+            const uint64_t row = base + (uint64_t)k * kStatsThreads + threadIdx.x;
+            if (row >= col.nrows) continue;
+            const uint32_t len = len64[k] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)len64[k];
+            mn = len < mn ? len : mn;
+            mx = len > mx ? len : mx;
+            const int lim = len < (uint32_t)kMaxKeyBytes ? (int)len : kMaxKeyBytes;
+            uint64_t chunk = c0[k];
+            for (int q = 0; q < lim; q++) {
+                if ((q & 7) == 0 && q) chunk = load_value_chunk(col.data, begin[k], len64[k], q >> 3);
+                const uint32_t b = (uint32_t)((chunk >> (8 * (q & 7))) & 0xFF);
+                const int idx = q * 8 + (int)(b >> 5);
+                const uint32_t bit = 1u << (b & 31);
+                if (!(s_mask[idx] & bit)) atomicOr(&s_mask[idx], bit);
+            }
         }
     }
     mn = wave_min(mn);
@@ -77,7 +93,7 @@ Status codec_collect_stats(cph_ctx* ctx, const DevCol* cols, int32_t ncols, std:
         CPH_HIP_TRY(hipMemsetAsync(d.as<uint8_t>() + per * (size_t)c, 0xFF, sizeof(uint32_t), ctx->stream));
     for (int c = 0; c < ncols; c++) {
         if (cols[c].nrows == 0) continue;
-        uint64_t nblk = (cols[c].nrows + kStatsThreads - 1) / kStatsThreads;
+        uint64_t nblk = (cols[c].nrows + kStatsThreads * kStatsRows - 1) / (kStatsThreads * kStatsRows);
         if (nblk > 2048) nblk = 2048;
         uint32_t* base = reinterpret_cast<uint32_t*>(d.as<uint8_t>() + per * (size_t)c);
         ProfScope ps(ctx, "k_col_stats", 0);   // bytes: value bytes + offsets, added by the caller's model
@@ -264,9 +280,64 @@ __global__ __launch_bounds__(kEncodeThreads) void k_encode_build(ColsArg cols, c
     }
 }
 
+// Fast path: one key column, single-word code, pre-multiplied LUT.  kEncodeRows rows per thread
+// and iteration with the loads grouped (spans, then key bytes), like the probe side.
+constexpr int kEncodeRows = 4;
+
+template <class W, class OUT>
+__global__ __launch_bounds__(kEncodeThreads) void k_encode_build_fast(DevCol col, const uint8_t* __restrict__ g_codec,
+                                                                     uint64_t n, OUT* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const CodecView cv = codec_load_to_lds(g_codec, smem);
+    const bool long_keys = cv.hdr->col_maxlen[0] > 8;
+    const uint64_t stride = (uint64_t)gridDim.x * kEncodeThreads * kEncodeRows;
+    for (uint64_t base = (uint64_t)blockIdx.x * kEncodeThreads * kEncodeRows; base < n; base += stride) {
+        uint64_t begin[kEncodeRows], len64[kEncodeRows], c0[kEncodeRows], c1[kEncodeRows];
+#pragma unroll
+        for (int k = 0; k < kEncodeRows; k++) {
+            const uint64_t row = base + (uint64_t)k * kEncodeThreads + threadIdx.x;
+            begin[k] = 0;
+            len64[k] = 0;
+            if (row < n) value_span(col, row, &begin[k], &len64[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < kEncodeRows; k++) {
+            c0[k] = len64[k] ? load_value_chunk(col.data, begin[k], len64[k], 0) : 0;
+            c1[k] = (long_keys && len64[k] > 8) ? load_value_chunk(col.data, begin[k], len64[k], 1) : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < kEncodeRows; k++) {
+            const uint64_t row = base + (uint64_t)k * kEncodeThreads + threadIdx.x;
+            uint64_t code;
+            encode_prefetched_w<W>(cv, col, begin[k], (uint32_t)len64[k], c0[k], c1[k], &code);
+            if (row < n) out[row] = (OUT)code;
+        }
+    }
+}
+
 Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec_dev, const DevCol* cols, uint64_t n,
                           void* out_codes) {
     if (n == 0) return {};
+    const int lutw_bits = codec_premultiplied_bits(cd);
+    if (cd.ncols == 1 && lutw_bits != 0) {
+        uint64_t nblk = (n + kEncodeThreads * kEncodeRows - 1) / (kEncodeThreads * kEncodeRows);
+        if (nblk > 4096) nblk = 4096;
+        const size_t lds = codec_dev.bytes();
+        const dim3 grid((unsigned)nblk), block(kEncodeThreads);
+        const uint8_t* blob = codec_dev.as<uint8_t>();
+        ProfScope ps(ctx, "k_encode_build", 0);
+        if (cd.key32 && lutw_bits == 32)
+            hipLaunchKernelGGL((k_encode_build_fast<uint32_t, uint32_t>), grid, block, lds, ctx->stream, cols[0], blob, n,
+                               reinterpret_cast<uint32_t*>(out_codes));
+        else if (cd.key32)
+            hipLaunchKernelGGL((k_encode_build_fast<uint64_t, uint32_t>), grid, block, lds, ctx->stream, cols[0], blob, n,
+                               reinterpret_cast<uint32_t*>(out_codes));
+        else
+            hipLaunchKernelGGL((k_encode_build_fast<uint64_t, uint64_t>), grid, block, lds, ctx->stream, cols[0], blob, n,
+                               reinterpret_cast<uint64_t*>(out_codes));
+        CPH_HIP_TRY(hipGetLastError());
+        return {};
+    }
     ColsArg arg{};
     for (int c = 0; c < cd.ncols; c++) arg.c[c] = cols[c];
     uint64_t nblk = (n + kEncodeThreads - 1) / kEncodeThreads;

@@ -1,78 +1,90 @@
 // radix_sort.hip — stable LSD radix sort of (key code, row id) pairs for IndexOn
 // (replaces sort.Sort(&index.impl), csvplus.go:736).
 //
-// 8-bit digits.  Per pass:
-//   k_radix_hist     per-tile 256-bin digit histogram (LDS atomics)      reads  K B/row
-//   exclusive scan   over the [256][ntiles] count matrix (digit-major)
+// 8- or 9-bit digits (9 when that saves a pass: 27-bit codes of 1e8 decimal ids sort in 3
+// passes).  Per pass:
+//   k_radix_hist     per-tile digit histogram (LDS atomics)                  reads  K B/row
+//   exclusive scan   over the [bins][ntiles] count matrix (digit-major)
 //   k_radix_scatter  wave-ballot digit matching -> stable ranks, tile reordered in LDS,
-//                    runs written out coalesced                          reads+writes (K+4) B/row
+//                    runs written out coalesced                              reads+writes (K+4) B/row
 // K = 4 (32-bit codes) or 8.  HBM-bound integer work: no MFMA.
 //
 // Stability matters twice: LSD needs it between passes, and the index contract is that
 // rows with equal keys keep their input order.  Ranks therefore come from
 // wave-level digit matching (`__ballot` + popcount of the lanes below), never from
 // returning LDS atomics, whose intra-instruction order is unspecified.
+#include <cstdlib>
+
 #include "cph_internal.hpp"
 #include "device_utils.hpp"
 
 namespace cph {
 
-constexpr int kSortThreads = 256;                         // 4 waves
-constexpr int kSortWaves   = kSortThreads / kWave;
 constexpr int kSortItems   = 16;                          // keys per thread
-constexpr int kSortTile    = kSortThreads * kSortItems;   // 4096 keys per workgroup
-constexpr int kRadixBits   = 8;
-constexpr int kRadix       = 1 << kRadixBits;
+// Workgroup size is a template parameter (tuning): 256 threads = 4096-key tiles (the default),
+// 512 threads = 8192-key tiles (a digit run inside a tile is twice as long, but it measured
+// slower: occupancy matters more than run length).
 
 // ---------------------------------------------------------------------------------------------
 // histogram
 // ---------------------------------------------------------------------------------------------
-template <class K>
+template <class K, int RBITS, int kSortThreads>
 __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const K* __restrict__ keys, uint64_t n, int shift,
                                                             uint32_t digit_mask, uint32_t* __restrict__ counts,
                                                             uint32_t ntiles) {
-    __shared__ uint32_t s_hist[kSortWaves][kRadix];
-    for (int i = threadIdx.x; i < kSortWaves * kRadix; i += kSortThreads) (&s_hist[0][0])[i] = 0;
+    constexpr int BINS = 1 << RBITS;
+    constexpr int kSortWaves = kSortThreads / kWave;
+    constexpr int kSortTile = kSortThreads * kSortItems;
+    __shared__ uint32_t s_hist[kSortWaves][BINS];
+    for (int i = threadIdx.x; i < kSortWaves * BINS; i += kSortThreads) (&s_hist[0][0])[i] = 0;
     __syncthreads();
     const uint64_t tile0 = (uint64_t)blockIdx.x * kSortTile;
     const int w = wave_id();
+    K key[kSortItems];
 #pragma unroll
     for (int k = 0; k < kSortItems; k++) {
         const uint64_t i = tile0 + (uint64_t)k * kSortThreads + threadIdx.x;
-        if (i < n) {
-            const uint32_t d = (uint32_t)(keys[i] >> shift) & digit_mask;
-            atomicAdd(&s_hist[w][d], 1u);
-        }
+        key[k] = i < n ? keys[i] : (K)0;
+    }
+#pragma unroll
+    for (int k = 0; k < kSortItems; k++) {
+        const uint64_t i = tile0 + (uint64_t)k * kSortThreads + threadIdx.x;
+        if (i < n) atomicAdd(&s_hist[w][(uint32_t)(key[k] >> shift) & digit_mask], 1u);
     }
     __syncthreads();
-    const int d = threadIdx.x;  // kSortThreads == kRadix
-    uint32_t c = 0;
+    for (int d = threadIdx.x; d < BINS; d += kSortThreads) {
+        uint32_t c = 0;
 #pragma unroll
-    for (int ww = 0; ww < kSortWaves; ww++) c += s_hist[ww][d];
-    counts[(uint64_t)d * ntiles + blockIdx.x] = c;
+        for (int ww = 0; ww < kSortWaves; ww++) c += s_hist[ww][d];
+        counts[(uint64_t)d * ntiles + blockIdx.x] = c;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
 // scatter
 // ---------------------------------------------------------------------------------------------
-template <class K>
+template <class K, int RBITS, int kSortThreads>
 struct ScatterSmem {
-    K keys[kSortTile];
-    uint32_t vals[kSortTile];
-    uint32_t wave_cnt[kSortWaves][kRadix];   // per-wave digit counts, then exclusive over waves
-    uint32_t digit_start[kRadix];            // first local slot of each digit's run
-    uint32_t gdelta[kRadix];                 // global position = local slot + gdelta[digit] (mod 2^32)
-    uint32_t scan_tmp[kSortWaves + 1];
+    K keys[kSortThreads * kSortItems];
+    uint32_t vals[kSortThreads * kSortItems];
+    uint32_t wave_cnt[kSortThreads / kWave][1 << RBITS];   // per-wave digit counts, then exclusive over waves
+    uint32_t digit_start[1 << RBITS];            // first local slot of each digit's run
+    uint32_t gdelta[1 << RBITS];                 // global position = local slot + gdelta[digit] (mod 2^32)
+    uint32_t scan_tmp[kSortThreads / kWave + 1];
 };
 
-template <class K>
+template <class K, int RBITS, int kSortThreads>
 __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const K* __restrict__ keys_in,
                                                                const uint32_t* __restrict__ vals_in,
                                                                K* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                                uint64_t n, int shift, uint32_t digit_mask,
                                                                const uint32_t* __restrict__ bases, uint32_t ntiles) {
+    constexpr int BINS = 1 << RBITS;
+    constexpr int kSortWaves = kSortThreads / kWave;
+    constexpr int kSortTile = kSortThreads * kSortItems;
+    constexpr int DPT = BINS > kSortThreads ? BINS / kSortThreads : 1;   // digits per (active) thread
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
-    ScatterSmem<K>& s = *reinterpret_cast<ScatterSmem<K>*>(smem_raw);
+    ScatterSmem<K, RBITS, kSortThreads>& s = *reinterpret_cast<ScatterSmem<K, RBITS, kSortThreads>*>(smem_raw);
 
     const int w = wave_id();
     const int lane = lane_id();
@@ -81,7 +93,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const K* __restr
     const uint32_t tile_n = remaining < (uint64_t)kSortTile ? (uint32_t)remaining : (uint32_t)kSortTile;
     const uint64_t lt = lanemask_lt();
 
-    for (int i = threadIdx.x; i < kSortWaves * kRadix; i += kSortThreads) (&s.wave_cnt[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < kSortWaves * BINS; i += kSortThreads) (&s.wave_cnt[0][0])[i] = 0;
     __syncthreads();
 
     // wave w owns tile slots [w*64*ITEMS, (w+1)*64*ITEMS); item k of lane l is slot base + k*64 + l,
@@ -105,7 +117,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const K* __restr
         // lanes of this wave holding the same digit
         uint64_t peers = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < kRadixBits; b++) {
+        for (int b = 0; b < RBITS; b++) {
             const bool bit = (d >> b) & 1u;
             const uint64_t m = __ballot(bit);
             peers &= bit ? m : ~m;
@@ -118,20 +130,36 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const K* __restr
     }
     __syncthreads();
 
-    // digit d = threadIdx.x: exclusive over waves, tile total, exclusive over digits
+    // thread t owns digits t*DPT .. t*DPT+DPT-1: exclusive over waves, tile totals, exclusive over digits
     {
-        const int d = threadIdx.x;
-        uint32_t run = 0;
+        const bool active = (int)threadIdx.x * DPT < BINS;   // more threads than digits: the rest idles here
+        uint32_t run[DPT];
+        uint32_t pair = 0;
 #pragma unroll
-        for (int ww = 0; ww < kSortWaves; ww++) {
-            const uint32_t c = s.wave_cnt[ww][d];
-            s.wave_cnt[ww][d] = run;
-            run += c;
+        for (int j = 0; j < DPT; j++) {
+            const int d = threadIdx.x * DPT + j;
+            uint32_t r = 0;
+            if (active)
+#pragma unroll
+            for (int ww = 0; ww < kSortWaves; ww++) {
+                const uint32_t c = s.wave_cnt[ww][d];
+                s.wave_cnt[ww][d] = r;
+                r += c;
+            }
+            run[j] = r;
+            pair += r;
         }
         uint32_t total;
-        const uint32_t start = block_exclusive_sum<uint32_t, kSortThreads>(run, s.scan_tmp, &total);
-        s.digit_start[d] = start;
-        s.gdelta[d] = bases[(uint64_t)d * ntiles + blockIdx.x] - start;
+        uint32_t start = block_exclusive_sum<uint32_t, kSortThreads>(pair, s.scan_tmp, &total);
+#pragma unroll
+        for (int j = 0; j < DPT; j++) {
+            const int d = threadIdx.x * DPT + j;
+            if (active) {
+                s.digit_start[d] = start;
+                s.gdelta[d] = bases[(uint64_t)d * ntiles + blockIdx.x] - start;
+            }
+            start += run[j];
+        }
     }
     __syncthreads();
 
@@ -273,7 +301,37 @@ Status fill_iota_u32(cph_ctx* ctx, uint32_t* dst, uint64_t n) {
 
 // ---------------------------------------------------------------------------------------------
 // driver
+// driver
 // ---------------------------------------------------------------------------------------------
+template <class K, int RBITS, int THREADS>
+static Status radix_pass(cph_ctx* ctx, const K* kin, const uint32_t* vin, K* kout, uint32_t* vout, uint64_t n, int shift,
+                         int nb, uint32_t* counts, uint32_t ntiles) {
+    constexpr int BINS = 1 << RBITS;
+    const uint32_t mask = (1u << nb) - 1u;
+    const size_t smem = sizeof(ScatterSmem<K, RBITS, THREADS>);
+    static bool attr_set = false;
+    if (!attr_set) {
+        CPH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_radix_scatter<K, RBITS, THREADS>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    {
+        ProfScope ps(ctx, sizeof(K) == 4 ? "k_radix_hist_u32" : "k_radix_hist_u64", (double)n * sizeof(K));
+        hipLaunchKernelGGL((k_radix_hist<K, RBITS, THREADS>), dim3(ntiles), dim3(THREADS), 0, ctx->stream, kin, n, shift,
+                           mask, counts, ntiles);
+    }
+    CPH_HIP_TRY(hipGetLastError());
+    CPH_TRY(exclusive_scan_u32(ctx, counts, (uint64_t)BINS * ntiles));
+    {
+        ProfScope ps(ctx, sizeof(K) == 4 ? "k_radix_scatter_u32" : "k_radix_scatter_u64",
+                     (double)n * (2.0 * sizeof(K) + (vin ? 8.0 : 4.0)));
+        hipLaunchKernelGGL((k_radix_scatter<K, RBITS, THREADS>), dim3(ntiles), dim3(THREADS), smem, ctx->stream, kin, vin,
+                           kout, vout, n, shift, mask, counts, ntiles);
+    }
+    CPH_HIP_TRY(hipGetLastError());
+    return {};
+}
+
 template <class K>
 Status radix_sort_pairs(cph_ctx* ctx, K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b, bool vals_iota,
                         uint64_t n, int bits, K** keys_out, uint32_t** vals_out, int* passes) {
@@ -289,31 +347,38 @@ Status radix_sort_pairs(cph_ctx* ctx, K* keys_a, K* keys_b, uint32_t* vals_a, ui
         *vals_out = vin;
         return {};
     }
-    const uint64_t ntiles64 = (n + kSortTile - 1) / kSortTile;
-    const uint32_t ntiles = (uint32_t)ntiles64;
+    // 9-bit digits only when they save a pass on a SMALL input (fewer launches); on large inputs a
+    // 9-bit pass costs 1.2-1.4x an 8-bit one and 8192-key tiles (512 threads) are slower than
+    // 4096-key ones (measured at 1e7/1e8 rows, tools/microbench/sort_cfg.py: 1e8 rows sort in
+    // 3.9 ms with 256,8 vs 4.2-4.4 ms with the other three).  Digit widths are balanced over passes.
+    static const char* cfg_env = std::getenv("CPH_SORT_CFG");   // tuning override: "<threads>,<rbits>"
+    int threads = 256;
+    const int p8 = (bits + 7) / 8, p9 = (bits + 8) / 9;
+    bool wide = p9 < p8 && n < (1u << 22);
+    if (cfg_env) {
+        int t = 0, r = 0;
+        if (sscanf(cfg_env, "%d,%d", &t, &r) == 2) {
+            if (t == 256 || t == 512) threads = t;
+            if (r == 8) wide = false;
+            if (r == 9) wide = true;
+        }
+    }
+    const int npass = wide ? (bits + 8) / 9 : p8;
+    const uint32_t tile = (uint32_t)threads * kSortItems;
+    const uint32_t ntiles = (uint32_t)((n + tile - 1) / tile);
     DevBuf counts;
-    CPH_TRY(counts.alloc(&ctx->pool, (size_t)kRadix * ntiles * sizeof(uint32_t)));
-    const size_t smem = sizeof(ScatterSmem<K>);
-    CPH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_radix_scatter<K>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    for (int shift = 0; shift < bits; shift += kRadixBits) {
-        const int nb = bits - shift < kRadixBits ? bits - shift : kRadixBits;
-        const uint32_t mask = (1u << nb) - 1u;
-        {
-        ProfScope ps(ctx, sizeof(K) == 4 ? "k_radix_hist_u32" : "k_radix_hist_u64", (double)n * sizeof(K));
-        hipLaunchKernelGGL(k_radix_hist<K>, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, kin, n, shift, mask,
-                           counts.as<uint32_t>(), ntiles);
-        }
-        CPH_HIP_TRY(hipGetLastError());
-        CPH_TRY(exclusive_scan_u32(ctx, counts.as<uint32_t>(), (uint64_t)kRadix * ntiles));
-        {
-        ProfScope ps(ctx, sizeof(K) == 4 ? "k_radix_scatter_u32" : "k_radix_scatter_u64",
-                     (double)n * (2.0 * sizeof(K) + (iota ? 4.0 : 8.0)));
-        hipLaunchKernelGGL(k_radix_scatter<K>, dim3(ntiles), dim3(kSortThreads), smem, ctx->stream, kin,
-                           iota ? (const uint32_t*)nullptr : vin, kout, vout, n, shift, mask, counts.as<uint32_t>(),
-                           ntiles);
-        }
-        CPH_HIP_TRY(hipGetLastError());
+    CPH_TRY(counts.alloc(&ctx->pool, (size_t)(wide ? 512 : 256) * ntiles * sizeof(uint32_t)));
+    int shift = 0;
+    for (int p = 0; p < npass; p++) {
+        const int left = bits - shift;
+        const int nb = (left + (npass - p) - 1) / (npass - p);
+        const uint32_t* v = iota ? nullptr : vin;
+        uint32_t* c = counts.as<uint32_t>();
+        if (wide && threads == 512) CPH_TRY((radix_pass<K, 9, 512>(ctx, kin, v, kout, vout, n, shift, nb, c, ntiles)));
+        else if (wide) CPH_TRY((radix_pass<K, 9, 256>(ctx, kin, v, kout, vout, n, shift, nb, c, ntiles)));
+        else if (threads == 512) CPH_TRY((radix_pass<K, 8, 512>(ctx, kin, v, kout, vout, n, shift, nb, c, ntiles)));
+        else CPH_TRY((radix_pass<K, 8, 256>(ctx, kin, v, kout, vout, n, shift, nb, c, ntiles)));
+        shift += nb;
         iota = false;
         K* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;
