@@ -162,6 +162,21 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom[0], "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(a / HBM_PEAK_GBPS, 4), "traffic": None,
                     "avg_launch_ms": dom[1]["avg_ms"], "launches": dom[1]["launches"]}
+    # HBM-side traffic of the dominant kernel: PMC counters cannot be collected inside this process;
+    # they come from the separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this
+    # same command (tools/gpu_profile.sh), whose per-kernel summary is committed under profiles/.
+    tf = ROOT / "profiles" / "traffic_latest.json"
+    if roofline and tf.exists() and args.rows == 100_000_000:
+        try:
+            tj = json.loads(tf.read_text())
+            hit = [v for k, v in tj.items() if k.startswith(roofline["kernel"])]
+            if hit and hit[0]["fetch_bytes_per_launch"] and hit[0]["write_bytes_per_launch"]:
+                roofline["traffic"] = hit[0]["fetch_bytes_per_launch"] + hit[0]["write_bytes_per_launch"]
+                roofline["traffic_note"] = ("FETCH_SIZE+WRITE_SIZE per launch (raw counters, bytes) from "
+                                            "profiles/traffic_latest.json; algorithmic bytes per launch = "
+                                            f"{dom[1]['algo_GB'] / dom[1]['launches'] * 1e9:.0f}")
+        except (ValueError, KeyError):
+            pass
     build_names = ("k_col_stats", "k_encode_build", "k_radix_hist_u32", "k_radix_hist_u64", "k_radix_scatter_u32",
                    "k_radix_scatter_u64", "exclusive_scan_u32", "k_first_dup", "k_build_table", "k_gather_u64")
     build_ms = sum(kernels[k]["total_ms"] for k in build_names if k in kernels)

@@ -252,6 +252,7 @@ static Status index_build_impl(cph_ctx* ctx, const cph_strcol* keycols, int32_t 
         CPH_TRY(codec_encode_build(ctx, cd, ix->codec_dev, dcols, n, all.get()));
         uint32_t* vcur = va.as<uint32_t>();
         uint32_t* vother = vb.as<uint32_t>();
+        uint64_t* kout = ka.as<uint64_t>();
         bool first = true;
         for (int w = nw - 1; w >= 0; w--) {
             const uint64_t* word = all.as<uint64_t>() + (uint64_t)w * n;
@@ -260,7 +261,6 @@ static Status index_build_impl(cph_ctx* ctx, const cph_strcol* keycols, int32_t 
             } else {
                 CPH_TRY(gather_u64(ctx, word, vcur, ka.as<uint64_t>(), n));
             }
-            uint64_t* kout;
             uint32_t* vout;
             CPH_TRY(radix_sort_pairs<uint64_t>(ctx, ka.as<uint64_t>(), kb.as<uint64_t>(), vcur, vother, first, n,
                                                cd.word_bits[w], &kout, &vout, &passes));
@@ -268,9 +268,12 @@ static Status index_build_impl(cph_ctx* ctx, const cph_strcol* keycols, int32_t 
             if (vout != vcur) { vother = vcur; vcur = vout; }
             first = false;
         }
+        // sorted codes, word-major: word 0 is the key output of the last sort (a streaming copy);
+        // only the less significant words need a gather through the final permutation
         DevBuf sorted;
         CPH_TRY(sorted.alloc(&ctx->pool, (size_t)nw * n * sizeof(uint64_t)));
-        for (int w = 0; w < nw; w++)
+        if (n) CPH_HIP_TRY(hipMemcpyAsync(sorted.get(), kout, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+        for (int w = 1; w < nw; w++)
             CPH_TRY(gather_u64(ctx, all.as<uint64_t>() + (uint64_t)w * n, vcur, sorted.as<uint64_t>() + (uint64_t)w * n, n));
         ix->sorted_codes = std::move(sorted);
         ix->perm = std::move(vcur == va.as<uint32_t>() ? va : vb);

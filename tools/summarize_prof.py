@@ -31,6 +31,15 @@ for f in root.glob("pmc_*/**/*counter_collection.csv"):
         c = r["Counter_Name"]
         pmc[k][c][0] += 1
         pmc[k][c][1] += float(r["Counter_Value"])
+import json
+
+traffic = {}
+for k, (n, t) in dur.items():
+    fs, ws = pmc[k].get("FETCH_SIZE"), pmc[k].get("WRITE_SIZE")
+    traffic[k] = {"calls": n, "avg_us": t / n,
+                  "fetch_bytes_per_launch": fs[1] / fs[0] * 1024 if fs else None,     # FETCH_SIZE is in KB
+                  "write_bytes_per_launch": ws[1] / ws[0] * 1024 if ws else None}
+(root / "traffic.json").write_text(json.dumps(traffic, indent=1, sort_keys=True))
 print(f"{'kernel':70s} {'calls':>6s} {'total_us':>12s} {'avg_us':>10s} {'FETCH_SIZE/launch':>18s} {'WRITE_SIZE/launch':>18s}")
 for k, (n, t) in sorted(dur.items(), key=lambda kv: -kv[1][1]):
     fs = pmc[k].get("FETCH_SIZE")
