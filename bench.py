@@ -83,10 +83,12 @@ def main():
         ia = eng.index_on([d_cust], unique=True)
         ib = eng.index_on([d_prod], unique=True)
         res = eng.chained_join([(ia, d_ord["cust_id"]), (ib, d_ord["prod_id"])], probe_base=begin)
-        out = (res.stream_row, res.build_rows[0], res.build_rows[1])
+        # stream_row is None when every order joined (the result row IS the stream row): then only
+        # the two build-row arrays exist — and only they are exchanged
+        out = tuple(t for t in (res.stream_row, res.build_rows[0], res.build_rows[1]) if t is not None)
         if world > 1 and args.exchange == "allgatherv":
             out = tuple(allgatherv(t)[0] for t in out)
-        n = int(out[0].numel())
+        n = int(out[-1].numel())
         info = (ia.info(), ib.info())
         res.release()
         ia.close()
@@ -144,9 +146,9 @@ def main():
         "k_encode_build": K * ((cust_bytes + off_c + ia_info["key_bytes"] * args.customers)
                                + (prod_bytes + off_p + ib_info["key_bytes"] * args.products)),
         # fused chain pass, per stream row: both keys' bytes + offsets in, one 8-byte table entry per
-        # step, (8 + 4 + 4)-byte row-id triple out per joined row
+        # step, two 4-byte build-row ids out per joined row (the stream row is implicit)
         "k_chain_dense": K * (host_bytes["cust_id"] + host_bytes["prod_id"] + off_o + 2 * 8 * nloc
-                               + 16 * total_joined_local),
+                               + 8 * total_joined_local),
     }
     kernels = {}
     for name, st in prof.items():

@@ -351,13 +351,14 @@ def join_chain(ctx: Context, steps, probe_base: int = 0, out_mem: int = CPH_MEM_
     rc = ctx.lib.cph_join_chain(ctx.handle, arr, len(steps), probe_base, out_mem, C.byref(out))
     del keep
     ctx._check(rc)
-    return Chain(ctx, out, [s[0] for s in steps])
+    return Chain(ctx, out, [s[0] for s in steps], probe_base)
 
 
 class Chain:
     """Result of a chained join (cph_chain): row-id tuples in emission order."""
 
-    def __init__(self, ctx: Context, ptr, owners):
+    def __init__(self, ctx: Context, ptr, owners, probe_base: int = 0):
+        self.probe_base = probe_base
         self.ctx = ctx
         self.lib = ctx.lib
         self.ptr = ptr
@@ -369,8 +370,15 @@ class Chain:
         ctx._children.add(self)
 
     @property
+    def identity(self) -> bool:
+        """True when cph_chain.stream_row is NULL: result row m IS stream row probe_base + m."""
+        return self.nrows > 0 and not self.ptr.contents.stream_row
+
+    @property
     def stream_row(self) -> np.ndarray:
         assert self.mem == CPH_MEM_HOST
+        if self.identity:
+            return np.arange(self.probe_base, self.probe_base + self.nrows, dtype=np.uint64)
         return _ptr_array(self.ptr.contents.stream_row, self.nrows, np.uint64).copy()
 
     def build_row(self, k: int) -> np.ndarray:

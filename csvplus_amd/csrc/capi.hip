@@ -85,6 +85,28 @@ Status ensure_pinned_scratch(cph_ctx* ctx, size_t bytes) {
     return {};
 }
 
+Status pinned_upload(cph_ctx* ctx, size_t bytes, void** out) {
+    const size_t need = (bytes + 63) & ~(size_t)63;
+    if (need > ctx->upload_cap) {
+        if (ctx->upload_ring) {
+            CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+            (void)hipHostFree(ctx->upload_ring);
+            ctx->upload_ring = nullptr;
+        }
+        const size_t cap = std::max<size_t>(need * 4, 1 << 20);
+        CPH_HIP_TRY(hipHostMalloc(&ctx->upload_ring, cap, hipHostMallocDefault));
+        ctx->upload_cap = cap;
+        ctx->upload_pos = 0;
+    }
+    if (ctx->upload_pos + need > ctx->upload_cap) {
+        CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));   // every earlier upload has been consumed
+        ctx->upload_pos = 0;
+    }
+    *out = static_cast<uint8_t*>(ctx->upload_ring) + ctx->upload_pos;
+    ctx->upload_pos += need;
+    return {};
+}
+
 // ---- per-kernel timing --------------------------------------------------------------------------
 ProfScope::ProfScope(cph_ctx* ctx, const char* name, double bytes) : ctx_(ctx), bytes_(bytes) {
     if (!ctx->profiling) return;
@@ -279,8 +301,10 @@ static Status index_build_impl(cph_ctx* ctx, const cph_strcol* keycols, int32_t 
         ix->perm = std::move(vcur == va.as<uint32_t>() ? va : vb);
     }
 
-    CPH_TRY(index_first_dup(ctx, ix, &ix->first_dup));
+    // adjacent-equal scan -> (device-side format choice) table build -> ONE read-back at the end
+    CPH_TRY(index_first_dup_launch(ctx, ix));
     CPH_TRY(index_build_table(ctx, ix));
+    CPH_TRY(index_first_dup_read(ctx, ix));
     // staged input copies are released here (stream-ordered reuse is safe)
     return {};
 }
@@ -324,6 +348,7 @@ CPH_API void cph_ctx_destroy(cph_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->pinned_scratch) (void)hipHostFree(ctx->pinned_scratch);
+    if (ctx->upload_ring) (void)hipHostFree(ctx->upload_ring);
     for (void* p : ctx->pinned_user) (void)hipHostFree(p);
     for (auto& p : ctx->prof_pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
     for (hipEvent_t e : ctx->prof_free_events) (void)hipEventDestroy(e);
@@ -618,7 +643,7 @@ CPH_API int32_t cph_join_chain(cph_ctx* ctx, const cph_chain_step* steps, int32_
         const uint64_t n = co.nrows;
         if (out_mem == CPH_MEM_DEVICE) {
             c->d_stream = std::move(co.stream_row);
-            c->pub.stream_row = n ? c->d_stream.as<uint64_t>() : nullptr;
+            c->pub.stream_row = (n && !co.identity) ? c->d_stream.as<uint64_t>() : nullptr;
             for (int k = 0; k < nsteps; k++) {
                 c->d_rows[k] = std::move(co.build_row[k]);
                 c->pub.build_row[k] = n ? c->d_rows[k].as<uint32_t>() : nullptr;
@@ -629,8 +654,10 @@ CPH_API int32_t cph_join_chain(cph_ctx* ctx, const cph_chain_step* steps, int32_
             const size_t b64 = a16(n * sizeof(uint64_t)), b32 = a16(n * sizeof(uint32_t));
             CPH_HIP_TRY(hipHostMalloc(&c->h_block, b64 + (size_t)nsteps * b32, hipHostMallocDefault));
             uint8_t* h = static_cast<uint8_t*>(c->h_block);
-            CPH_HIP_TRY(hipMemcpyAsync(h, co.stream_row.get(), n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-            c->pub.stream_row = reinterpret_cast<const uint64_t*>(h);
+            if (!co.identity) {
+                CPH_HIP_TRY(hipMemcpyAsync(h, co.stream_row.get(), n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+                c->pub.stream_row = reinterpret_cast<const uint64_t*>(h);
+            }
             for (int k = 0; k < nsteps; k++) {
                 uint8_t* hk = h + b64 + (size_t)k * b32;
                 CPH_HIP_TRY(hipMemcpyAsync(hk, co.build_row[k].get(), n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -16,7 +16,8 @@
 //                   latency-bound otherwise).
 //   k_sum_counts    total number of joined rows.
 //   if total == rows (every stream row joined — the README chain, BASELINE config 4): done, the
-//   dense arrays ARE the result in emission order;
+//   dense arrays ARE the result in emission order (and result row m is stream row probe_base+m, so
+//   no stream_row array is materialised at all: cph_chain.stream_row == NULL);
 //   else            exclusive scan of the tile counts + k_chain_compact moves the matched tuples
 //                   to their final slots (stream order is kept: slot = matches before the row).
 // An earlier single-pass variant (decoupled look-back over an atomic tile ticket) was measured at
@@ -24,8 +25,8 @@
 // (MI355X_MICROARCH.md "dequeue"), which alone capped it.
 //
 // Algorithmic traffic per stream row: sum over steps of (key bytes + offset) in, one 8-byte table
-// entry per step (random access), 8 + 4*steps bytes out per joined row (+ the same again, read and
-// written, for the rows that survive when compaction is needed).
+// entry per step (random access), 4*steps bytes out per joined row (when compaction is needed: the
+// same again read, plus 8 + 4*steps written per surviving row).
 //
 // General path (duplicate keys / multi-column keys / multi-word codes): probe, select, compose
 // step by step with the generic kernels of probe.hip.
@@ -64,8 +65,7 @@ struct ChainArgs {
 // loops so that the kChainRows loads of a phase sit in one basic block and overlap.
 template <int S, bool LONG, bool DBG>
 __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint64_t nprobe, uint64_t probe_base,
-                                                              uint64_t ntiles, uint64_t* __restrict__ out_stream,
-                                                              uint64_t* __restrict__ masks,
+                                                              uint64_t ntiles, uint64_t* __restrict__ masks,
                                                               uint32_t* __restrict__ wave_counts, int dbg_flags) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // dynamic LDS layout: [codec 0][codec 1]...   (no static LDS: keeps 16-B alignment)
@@ -205,8 +205,8 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
             const uint64_t bal = __ballot(ok[k]);
             wave_matches += (uint32_t)__popcll(bal);
             if (lane == 0) masks[tile * kChainMasks + k * kChainWaves + wave] = bal;
+            // the stream row of slot r is probe_base + r by construction: it is never stored here
             if (ok[k] && !(DBG && (dbg & 4))) {
-                out_stream[row[k]] = probe_base + row[k];
 #pragma unroll
                 for (int s = 0; s < S; s++) a.out_rows[s][row[k]] = brow[k][s];
             }
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void k_sum_counts(const uint32_t* __restrict__
 
 // Moves the matched tuples of a tile from slot == row to their final slots.
 template <int S>
-__global__ __launch_bounds__(kChainThreads) void k_chain_compact(ChainArgs dense_rows, const uint64_t* __restrict__ dense_stream,
+__global__ __launch_bounds__(kChainThreads) void k_chain_compact(ChainArgs dense_rows, uint64_t probe_base,
                                                                 const uint64_t* __restrict__ masks,
                                                                 const uint32_t* __restrict__ tile_base, uint64_t ntiles,
                                                                 uint64_t* __restrict__ out_stream, ChainArgs out_rows) {
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_compact(ChainArgs dense
             if ((m >> lane) & 1ull) {
                 const uint64_t row = tile * kChainTile + (uint64_t)k * kChainThreads + threadIdx.x;
                 const uint64_t pos = base + s_pref[k * kChainWaves + wave] + (uint64_t)__popcll(m & lt);
-                out_stream[pos] = dense_stream[row];
+                out_stream[pos] = probe_base + row;
 #pragma unroll
                 for (int s = 0; s < S; s++) out_rows.out_rows[s][pos] = dense_rows.out_rows[s][row];
             }
@@ -294,7 +294,6 @@ static bool fast_path_ok(const ChainStep* steps, int nsteps) {
 template <int S>
 static Status run_fast(cph_ctx* ctx, const ChainStep* steps, uint64_t nprobe, uint64_t probe_base, ChainOut* out) {
     const uint64_t ntiles = (nprobe + kChainTile - 1) / kChainTile;
-    CPH_TRY(out->stream_row.alloc(&ctx->pool, nprobe * sizeof(uint64_t)));
     ChainArgs args{};
     size_t lds = 0;
     for (int s = 0; s < S; s++) {
@@ -336,7 +335,7 @@ static Status run_fast(cph_ctx* ctx, const ChainStep* steps, uint64_t nprobe, ui
     {
         ProfScope ps(ctx, "k_chain_dense", 0);
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(kChainThreads), lds, ctx->stream, args, nprobe, probe_base,
-                           ntiles, out->stream_row.as<uint64_t>(), masks.as<uint64_t>(), counts.as<uint32_t>(), dbg);
+                           ntiles, masks.as<uint64_t>(), counts.as<uint32_t>(), dbg);
     }
     {
         ProfScope ps(ctx, "k_sum_counts", 4.0 * (double)ncounts);
@@ -352,6 +351,7 @@ static Status run_fast(cph_ctx* ctx, const ChainStep* steps, uint64_t nprobe, ui
     CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
     const uint64_t nmatch = h[0];
     out->nrows = nmatch;
+    out->identity = nmatch == nprobe;   // result row m is stream row probe_base + m: no stream_row array
     if (nmatch == nprobe || nmatch == 0) return {};   // dense arrays are already final / nothing to keep
 
     // compaction: tile bases, then move the tuples
@@ -365,8 +365,8 @@ static Status run_fast(cph_ctx* ctx, const ChainStep* steps, uint64_t nprobe, ui
     }
     {
         ProfScope ps(ctx, "k_chain_compact", 2.0 * (double)nmatch * (8.0 + 4.0 * S));
-        hipLaunchKernelGGL(k_chain_compact<S>, dim3(grid), dim3(kChainThreads), 0, ctx->stream, args,
-                           out->stream_row.as<uint64_t>(), masks.as<uint64_t>(), counts.as<uint32_t>(), ntiles,
+        hipLaunchKernelGGL(k_chain_compact<S>, dim3(grid), dim3(kChainThreads), 0, ctx->stream, args, probe_base,
+                           masks.as<uint64_t>(), counts.as<uint32_t>(), ntiles,
                            fin.stream_row.as<uint64_t>(), fargs);
     }
     CPH_HIP_TRY(hipGetLastError());

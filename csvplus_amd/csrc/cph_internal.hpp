@@ -156,6 +156,10 @@ struct cph_ctx {
     // small pinned scratch for read-backs
     void* pinned_scratch = nullptr;
     size_t pinned_scratch_bytes = 0;
+    // pinned ring for small host->device uploads (codec blocks): bump-allocated, the stream is only
+    // synchronised when the ring wraps, so an upload never stalls the pipeline
+    void* upload_ring = nullptr;
+    size_t upload_cap = 0, upload_pos = 0;
     std::vector<void*> pinned_user;
     // profiling
     bool profiling = false;
@@ -177,6 +181,7 @@ struct cph_index {
     int32_t sort_passes = 0;
     uint64_t first_dup = UINT64_MAX;
     uint32_t* perm_host = nullptr; // pinned copy (lazy)
+    cph::DevBuf first_dup_dev;     // u32 result of the adjacent-equal scan until it is read back
 };
 
 struct cph_chain_impl {
@@ -235,7 +240,8 @@ Status gather_u64(cph_ctx* ctx, const uint64_t* src, const uint32_t* idx, uint64
 Status fill_iota_u32(cph_ctx* ctx, uint32_t* dst, uint64_t n);
 
 // probe.hip
-Status index_first_dup(cph_ctx* ctx, const cph_index* ix, uint64_t* first_dup);
+Status index_first_dup_launch(cph_ctx* ctx, cph_index* ix);
+Status index_first_dup_read(cph_ctx* ctx, cph_index* ix);
 Status index_build_table(cph_ctx* ctx, cph_index* ix);
 struct ProbeOut {
     DevBuf lo, cnt, pidx, brow;
@@ -262,11 +268,13 @@ struct ChainOut {
     DevBuf build_row[CPH_MAX_CHAIN];
     uint64_t nrows = 0;
     int32_t nsteps = 0;
+    bool identity = false;     // stream_row[m] == probe_base + m for all m: stream_row is not materialised
 };
 Status chain_run(cph_ctx* ctx, const ChainStep* steps, int nsteps, uint64_t probe_base, ChainOut* out);
 
 // capi.hip helpers
 Status ensure_pinned_scratch(cph_ctx* ctx, size_t bytes);
+Status pinned_upload(cph_ctx* ctx, size_t bytes, void** out);   // staging slot valid until the ring wraps
 
 // Times everything enqueued on ctx->stream during its lifetime when ctx->profiling is on
 // (two HIP events on that stream); `bytes` = algorithmic bytes of the launch.

@@ -247,11 +247,10 @@ Status codec_upload(cph_ctx* ctx, const CodecHost& cd, DevBuf* dev) {
         }
     }
     CPH_TRY(dev->alloc(&ctx->pool, off));
-    CPH_TRY(ensure_pinned_scratch(ctx, off));
-    memcpy(ctx->pinned_scratch, blob.data(), off);
-    CPH_HIP_TRY(hipMemcpyAsync(dev->get(), ctx->pinned_scratch, off, hipMemcpyHostToDevice, ctx->stream));
-    // the pinned scratch is reused by later calls: wait for the copy
-    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    void* slot = nullptr;
+    CPH_TRY(pinned_upload(ctx, off, &slot));   // ring slot: no synchronisation needed for the copy
+    memcpy(slot, blob.data(), off);
+    CPH_HIP_TRY(hipMemcpyAsync(dev->get(), slot, off, hipMemcpyHostToDevice, ctx->stream));
     return {};
 }
 

@@ -40,43 +40,55 @@ __global__ void k_first_dup(const void* __restrict__ codes, uint64_t n, int nwor
     if (lane_id() == 0 && best != 0xFFFFFFFFu) atomicMin(result, best);
 }
 
-Status index_first_dup(cph_ctx* ctx, const cph_index* ix, uint64_t* first_dup) {
-    *first_dup = UINT64_MAX;
+// Launches the adjacent-equal scan; the result stays on the device (ix->first_dup_dev) so that
+// the table build that follows can pick its entry format without a host round trip.
+Status index_first_dup_launch(cph_ctx* ctx, cph_index* ix) {
     const uint64_t n = ix->nrows;
+    CPH_TRY(ix->first_dup_dev.alloc(&ctx->pool, sizeof(uint32_t)));
+    CPH_HIP_TRY(hipMemsetAsync(ix->first_dup_dev.get(), 0xFF, sizeof(uint32_t), ctx->stream));
     if (n < 2) return {};
-    DevBuf d;
-    CPH_TRY(d.alloc(&ctx->pool, sizeof(uint32_t)));
-    CPH_TRY(ensure_pinned_scratch(ctx, sizeof(uint32_t)));
-    CPH_HIP_TRY(hipMemsetAsync(d.get(), 0xFF, sizeof(uint32_t), ctx->stream));
     uint64_t nblk = (n + 255) / 256;
     if (nblk > 4096) nblk = 4096;
+    uint32_t* d = ix->first_dup_dev.as<uint32_t>();
     {
         ProfScope ps(ctx, "k_first_dup", (double)n * (ix->codec.key32 ? 4.0 : 8.0 * ix->codec.nwords));
         if (ix->codec.key32)
             hipLaunchKernelGGL(k_first_dup<true>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream,
-                               ix->sorted_codes.get(), n, ix->codec.nwords, d.as<uint32_t>());
+                               ix->sorted_codes.get(), n, ix->codec.nwords, d);
         else
             hipLaunchKernelGGL(k_first_dup<false>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream,
-                               ix->sorted_codes.get(), n, ix->codec.nwords, d.as<uint32_t>());
+                               ix->sorted_codes.get(), n, ix->codec.nwords, d);
     }
     CPH_HIP_TRY(hipGetLastError());
-    CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, d.get(), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    return {};
+}
+
+// Reads the scan's result back (one stream synchronisation, the last one of an index build).
+Status index_first_dup_read(cph_ctx* ctx, cph_index* ix) {
+    ix->first_dup = UINT64_MAX;
+    CPH_TRY(ensure_pinned_scratch(ctx, sizeof(uint32_t)));
+    CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, ix->first_dup_dev.get(), sizeof(uint32_t), hipMemcpyDeviceToHost,
+                               ctx->stream));
     CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
     const uint32_t r = *reinterpret_cast<const uint32_t*>(ctx->pinned_scratch);
-    if (r != 0xFFFFFFFFu) *first_dup = r;
+    if (r != 0xFFFFFFFFu) ix->first_dup = r;
+    ix->first_dup_dev.reset();
     return {};
 }
 
 // ---------------------------------------------------------------------------------------------
-// direct-address table: entry[code] = {lo, end}; absent codes stay {0,0} (cnt 0)
+// direct-address table (formats: probe_device.hpp).  Every entry starts as {absent, absent}
+// (memset 0xFF): an absent code has cnt == 0 in both formats.  The format is chosen ON THE DEVICE
+// from the first-duplicate word, so the build needs no host decision here.
 // ---------------------------------------------------------------------------------------------
-template <class K, bool UNIQUE>
+template <class K>
 __global__ void k_build_table(const K* __restrict__ codes, const uint32_t* __restrict__ perm, uint64_t n,
-                              TableEntry* __restrict__ table) {
+                              const uint32_t* __restrict__ first_dup, TableEntry* __restrict__ table) {
+    const bool unique = *first_dup == 0xFFFFFFFFu;   // uniform
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const K c = codes[i];
-        if constexpr (UNIQUE) {
+        if (unique) {
             table[c] = TableEntry{(uint32_t)i, perm[i]};
         } else {
             if (i == 0 || codes[i - 1] != c) table[c].a = (uint32_t)i;
@@ -94,23 +106,20 @@ Status index_build_table(cph_ctx* ctx, cph_index* ix) {
     if (limit < (1ull << 20)) limit = 1ull << 20;
     if (states > limit || states > (1ull << 30)) return {};
     CPH_TRY(ix->table.alloc(&ctx->pool, states * sizeof(TableEntry)));
-    const bool uniq = ix->first_dup == UINT64_MAX;   // entry format, see probe_device.hpp
-    CPH_HIP_TRY(hipMemsetAsync(ix->table.get(), uniq ? 0xFF : 0, states * sizeof(TableEntry), ctx->stream));
+    CPH_HIP_TRY(hipMemsetAsync(ix->table.get(), 0xFF, states * sizeof(TableEntry), ctx->stream));
     uint64_t nblk = (n + 255) / 256;
     if (nblk > 8192) nblk = 8192;
     ProfScope ps(ctx, "k_build_table", (double)n * (ix->codec.key32 ? 4.0 : 8.0) + 4.0 * (double)n + 8.0 * (double)n);
     const dim3 grid((unsigned)nblk), block(256);
     const uint32_t* perm = ix->perm.as<uint32_t>();
+    const uint32_t* fd = ix->first_dup_dev.as<uint32_t>();
     TableEntry* tab = ix->table.as<TableEntry>();
-    if (ix->codec.key32) {
-        const uint32_t* codes = ix->sorted_codes.as<uint32_t>();
-        if (uniq) hipLaunchKernelGGL((k_build_table<uint32_t, true>), grid, block, 0, ctx->stream, codes, perm, n, tab);
-        else hipLaunchKernelGGL((k_build_table<uint32_t, false>), grid, block, 0, ctx->stream, codes, perm, n, tab);
-    } else {
-        const uint64_t* codes = ix->sorted_codes.as<uint64_t>();
-        if (uniq) hipLaunchKernelGGL((k_build_table<uint64_t, true>), grid, block, 0, ctx->stream, codes, perm, n, tab);
-        else hipLaunchKernelGGL((k_build_table<uint64_t, false>), grid, block, 0, ctx->stream, codes, perm, n, tab);
-    }
+    if (ix->codec.key32)
+        hipLaunchKernelGGL(k_build_table<uint32_t>, grid, block, 0, ctx->stream, ix->sorted_codes.as<uint32_t>(), perm, n,
+                           fd, tab);
+    else
+        hipLaunchKernelGGL(k_build_table<uint64_t>, grid, block, 0, ctx->stream, ix->sorted_codes.as<uint64_t>(), perm, n,
+                           fd, tab);
     CPH_HIP_TRY(hipGetLastError());
     ix->table_entries = states;
     return {};

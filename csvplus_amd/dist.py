@@ -3,11 +3,14 @@ probe rows split into contiguous ranges, build side replicated, and an
 allgatherv of the per-rank match lists so that every rank ends up with the
 whole joined row-id list in the reference's emission order.
 
-RCCL has no native allgatherv.  torch.distributed's NCCL(=RCCL) backend lowers
-an all_gather with unequal output sizes to one grouped set of broadcasts, i.e.
-every rank's shard travels straight to each peer over its own xGMI link; the
-gloo backend (CPU tests) needs equal sizes, so shards are padded to the maximum
-there.
+RCCL has no native allgatherv.  The exchange is: one `all_gather` of the per-rank
+counts, then ONE grouped batch of point-to-point sends/receives
+(`batch_isend_irecv` = ncclGroupStart ... ncclSend/ncclRecv ... ncclGroupEnd):
+every rank sends its shard straight to each peer and receives each peer's shard
+into its slot of the output buffer.  On the 8-GPU xGMI mesh every pair of GPUs
+has its own link, so the N-1 transfers of a rank run concurrently, one per link —
+a ring all-gather would push (N-1)/N of the data through every single link instead.
+The same code runs on the gloo backend (CPU tests).
 """
 from __future__ import annotations
 
@@ -21,35 +24,40 @@ def allgatherv(t, group=None):
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return t, [int(t.numel())]
     world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
     n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
-    counts_t = [torch.zeros(1, dtype=torch.int64, device=t.device) for _ in range(world)]
-    dist.all_gather(counts_t, n, group=group)
-    counts = [int(c.item()) for c in counts_t]
-    total = sum(counts)
-    out = torch.empty(total, dtype=t.dtype, device=t.device)
-    backend = dist.get_backend(group)
-    if backend == "nccl":
-        views, off = [], 0
-        for c in counts:
-            views.append(out[off:off + c])
-            off += c
-        dist.all_gather(views, t.contiguous(), group=group)   # unequal sizes: grouped broadcasts
-    else:
-        mx = max(counts) if counts else 0
-        pad = torch.zeros(mx, dtype=t.dtype, device=t.device)
-        pad[: t.numel()] = t
-        bufs = [torch.empty(mx, dtype=t.dtype, device=t.device) for _ in range(world)]
-        dist.all_gather(bufs, pad, group=group)
-        off = 0
-        for c, b in zip(counts, bufs):
-            out[off:off + c] = b[:c]
-            off += c
+    counts_t = torch.zeros(world, dtype=torch.int64, device=t.device)
+    dist.all_gather_into_tensor(counts_t, n, group=group)
+    counts = [int(c) for c in counts_t.tolist()]
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c)
+    out = torch.empty(offs[-1], dtype=t.dtype, device=t.device)
+    t = t.contiguous()
+    if len(set(counts)) == 1:   # equal shards (e.g. every stream row joined): one plain ncclAllGather
+        if counts[0]:
+            dist.all_gather_into_tensor(out, t, group=group)
+        return out, counts
+    if counts[rank]:
+        out[offs[rank]:offs[rank + 1]].copy_(t)
+    ops = []
+    for peer in range(world):
+        if peer == rank:
+            continue
+        gpeer = dist.get_global_rank(group, peer) if group is not None else peer
+        if counts[rank]:
+            ops.append(dist.P2POp(dist.isend, t, gpeer, group=group))
+        if counts[peer]:
+            ops.append(dist.P2POp(dist.irecv, out[offs[peer]:offs[peer + 1]], gpeer, group=group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
     return out, counts
 
 
 def sharded_chained_join(total_stream_rows: int, local_join, group=None, exchange: bool = True):
     """Runs `local_join(begin, end)` on this rank's row range and (optionally) allgathers
-    the resulting triples.
+    the resulting tuples.
 
     local_join(begin, end) -> (stream_row, a_row, b_row) 1-D tensors for stream rows
     [begin, end), with stream_row holding GLOBAL row numbers.  Returned: the three

@@ -42,11 +42,23 @@ def device_view(ptr: int, count: int, typestr: str, owner, device):
 @dataclass
 class ChainResult:
     """Joined rows of stream JOIN a JOIN b ... as row-id tuples, emission order.
-    stream_row: int64 (global stream row); build_rows[k]: int32 bit patterns of uint32 row ids."""
+    stream_row: int64 (global stream row) or None when every stream row joined exactly once
+    (then result row m is stream row stream_base + m); build_rows[k]: int32 bit patterns of
+    uint32 row ids."""
     stream_row: "object"
     build_rows: list
     n: int
     keep: tuple = ()
+    stream_base: int = 0
+
+    def stream_rows(self):
+        """stream_row materialised (torch.arange when implicit)."""
+        if self.stream_row is not None:
+            return self.stream_row
+        import torch
+
+        dev = self.build_rows[0].device if self.build_rows else "cpu"
+        return torch.arange(self.stream_base, self.stream_base + self.n, dtype=torch.int64, device=dev)
 
     def release(self):
         for k in self.keep:
@@ -91,5 +103,6 @@ class Engine:
                           probe_base=probe_base, out_mem=N.CPH_MEM_DEVICE)
         p = ch.device_ptrs()
         dev = self.device
-        return ChainResult(device_view(p["stream_row"], ch.nrows, "<i8", ch, dev),
-                           [device_view(q, ch.nrows, "<i4", ch, dev) for q in p["build_row"]], ch.nrows, keep=(ch,))
+        stream = None if ch.identity else device_view(p["stream_row"], ch.nrows, "<i8", ch, dev)
+        return ChainResult(stream, [device_view(q, ch.nrows, "<i4", ch, dev) for q in p["build_row"]], ch.nrows,
+                           keep=(ch,), stream_base=probe_base)

@@ -213,7 +213,9 @@ typedef struct {
  * Result of stream.Join(i0, c0).Join(i1, c1)...: the joined rows as row-id tuples
  * in the reference's emission order (stream order; for one stream row the
  * matches of step 0 ascending by index position, and for each of them the
- * matches of step 1, ...).  stream_row[m] = probe_base + the stream row,
+ * matches of step 1, ...).  stream_row[m] = probe_base + the stream row
+ * (stream_row == NULL means the identity: every stream row joined exactly once, so
+ * row m of the result is stream row probe_base + m and no array is materialised),
  * build_row[k][m] = ORIGINAL row id of the matching row of step k's index.
  * The host materialises row m as mergeRows(...mergeRows(index_k row, ...), stream row)
  * (csvplus.go:571-583).  Arrays live in `mem`, valid until cph_chain_release.

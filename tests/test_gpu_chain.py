@@ -140,3 +140,19 @@ def test_chain_many_tiles_lookback(ctx):
         cv = (cv * (10 ** np.arange(7, -1, -1, dtype=np.int64))).sum(axis=1)
         np.testing.assert_array_equal(cv[ch.build_row(0)], pv[hit])
         ch.release()
+
+
+def test_chain_identity_has_no_stream_row_array(ctx):
+    """Every stream row joins exactly once: cph_chain.stream_row is NULL (row m == stream row base+m)."""
+    nc, m = 5000, 40_000
+    cust = dg.customers(nc)["id"]
+    ords = dg.orders(m, nc, 10)["cust_id"]
+    ix = DeviceIndex(ctx, [cust], unique=True)
+    ch = join_chain(ctx, [(ix, [ords])], probe_base=500)
+    assert ch.nrows == m and ch.identity
+    np.testing.assert_array_equal(ch.stream_row, np.arange(500, 500 + m, dtype=np.uint64))
+    # one missing key: the array is materialised
+    bad = StrCol.from_values([b"99999999"] + ords.values()[1:])
+    ch = join_chain(ctx, [(ix, [bad])], probe_base=500)
+    assert ch.nrows == m - 1 and not ch.identity
+    np.testing.assert_array_equal(ch.stream_row, np.arange(501, 500 + m, dtype=np.uint64))
