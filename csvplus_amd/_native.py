@@ -110,6 +110,12 @@ class cph_chain(C.Structure):
                 ("nsteps", C.c_int32), ("mem", C.c_int32)]
 
 
+class cph_stream_chunk(C.Structure):
+    _fields_ = [("probe_base", C.c_uint64), ("nrows", C.c_uint64), ("nmatches", C.c_uint64),
+                ("match_bitmap", C.c_void_p), ("build_row", C.c_void_p * CPH_MAX_CHAIN), ("nsteps", C.c_int32),
+                ("reserved_", C.c_int32)]
+
+
 class cph_kernel_stat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double),
                 ("algo_bytes", C.c_double)]
@@ -142,6 +148,11 @@ PROTOTYPES = [
     ("cph_join_chain", C.c_int32,
      [_P, C.POINTER(cph_chain_step), C.c_int32, C.c_uint64, C.c_int32, C.POINTER(C.POINTER(cph_chain))]),
     ("cph_chain_release", None, [C.POINTER(cph_chain)]),
+    ("cph_stream_join_create", C.c_int32, [_P, C.POINTER(_P), C.c_int32, C.c_int32, C.POINTER(_P)]),
+    ("cph_stream_join_destroy", None, [_P]),
+    ("cph_stream_join_submit", C.c_int32, [_P, C.POINTER(cph_strcol), C.c_uint64]),
+    ("cph_stream_join_pending", C.c_int32, [_P]),
+    ("cph_stream_join_next", C.c_int32, [_P, C.POINTER(cph_stream_chunk)]),
     ("cph_index_find", C.c_int32,
      [_P, _P, C.POINTER(cph_strval), C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("cph_index_get_info", C.c_int32, [_P, C.POINTER(cph_index_info)]),

@@ -280,7 +280,7 @@ __global__ void k_compose_u32(const uint32_t* __restrict__ src, const uint64_t* 
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[idx[i]];
 }
 
-static bool fast_path_ok(const ChainStep* steps, int nsteps) {
+bool chain_fast_path_ok(const ChainStep* steps, int nsteps) {
     for (int s = 0; s < nsteps; s++) {
         const cph_index* ix = steps[s].index;
         if (steps[s].ncols != 1 || ix->nkeycols != 1) return false;
@@ -291,14 +291,20 @@ static bool fast_path_ok(const ChainStep* steps, int nsteps) {
     return true;
 }
 
+// Enqueues the dense pass + the match total on ctx->stream; nothing here waits for the GPU.
+//   d_rows[s]  u32[nprobe]             build row of step s at slot == stream row (valid where the bit is set)
+//   d_masks    u64[ceil(nprobe/1024)*16]  bit r%64 of word r/64 == "stream row r joined" (a plain bitmap)
+//   d_counts   u32[ceil(nprobe/1024)*4]   matches per 256-row quarter... per (tile, wave), tile-major
+//   d_total    u64                     number of joined rows
 template <int S>
-static Status run_fast(cph_ctx* ctx, const ChainStep* steps, uint64_t nprobe, uint64_t probe_base, ChainOut* out) {
+static Status enqueue_dense(cph_ctx* ctx, const ChainStep* steps, uint64_t nprobe, uint64_t probe_base,
+                            uint32_t* const* d_rows, uint64_t* d_masks, uint32_t* d_counts, uint64_t* d_total,
+                            ChainArgs* args_out, unsigned* grid_out) {
     const uint64_t ntiles = (nprobe + kChainTile - 1) / kChainTile;
     ChainArgs args{};
     size_t lds = 0;
     for (int s = 0; s < S; s++) {
         const cph_index* ix = steps[s].index;
-        CPH_TRY(out->build_row[s].alloc(&ctx->pool, nprobe * sizeof(uint32_t)));
         ChainStepArg& st = args.step[s];
         st.col = steps[s].cols[0];
         st.codec = ix->codec_dev.as<uint8_t>();
@@ -308,14 +314,10 @@ static Status run_fast(cph_ctx* ctx, const ChainStep* steps, uint64_t nprobe, ui
         st.perm = ix->perm.as<uint32_t>();
         st.n_index = ix->nrows;
         st.key32 = ix->codec.key32 ? 1 : 0;
-        args.out_rows[s] = out->build_row[s].as<uint32_t>();
+        args.out_rows[s] = d_rows[s];
         lds += ix->codec_dev.bytes();
     }
-    DevBuf masks, counts, total;
-    CPH_TRY(masks.alloc(&ctx->pool, ntiles * kChainMasks * sizeof(uint64_t)));
     const uint64_t ncounts = ntiles * kChainWaves;   // one match count per (tile, wave), tile-major
-    CPH_TRY(counts.alloc(&ctx->pool, ncounts * sizeof(uint32_t)));
-    CPH_TRY(total.alloc(&ctx->pool, sizeof(uint64_t)));
     const char* e = std::getenv("CPH_CHAIN_DEBUG");
     const int dbg = e ? std::atoi(e) : 0;
     bool long_keys = false;
@@ -335,15 +337,53 @@ static Status run_fast(cph_ctx* ctx, const ChainStep* steps, uint64_t nprobe, ui
     {
         ProfScope ps(ctx, "k_chain_dense", 0);
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(kChainThreads), lds, ctx->stream, args, nprobe, probe_base,
-                           ntiles, masks.as<uint64_t>(), counts.as<uint32_t>(), dbg);
+                           ntiles, d_masks, d_counts, dbg);
     }
     {
         ProfScope ps(ctx, "k_sum_counts", 4.0 * (double)ncounts);
-        CPH_HIP_TRY(hipMemsetAsync(total.get(), 0, sizeof(uint64_t), ctx->stream));
+        CPH_HIP_TRY(hipMemsetAsync(d_total, 0, sizeof(uint64_t), ctx->stream));
         const unsigned sgrid = (unsigned)std::min<uint64_t>((ncounts + 255) / 256, 512);
-        hipLaunchKernelGGL(k_sum_counts, dim3(sgrid), dim3(256), 0, ctx->stream, counts.as<uint32_t>(), ncounts,
-                           total.as<unsigned long long>());
+        hipLaunchKernelGGL(k_sum_counts, dim3(sgrid), dim3(256), 0, ctx->stream, d_counts, ncounts,
+                           reinterpret_cast<unsigned long long*>(d_total));
     }
+    CPH_HIP_TRY(hipGetLastError());
+    if (args_out) *args_out = args;
+    if (grid_out) *grid_out = grid;
+    return {};
+}
+
+bool chain_fast_path_ok(const ChainStep* steps, int nsteps);
+
+Status chain_enqueue_dense(cph_ctx* ctx, const ChainStep* steps, int nsteps, uint64_t nprobe, uint64_t probe_base,
+                           uint32_t* const* d_rows, uint64_t* d_masks, uint32_t* d_counts, uint64_t* d_total) {
+    switch (nsteps) {
+    case 1: return enqueue_dense<1>(ctx, steps, nprobe, probe_base, d_rows, d_masks, d_counts, d_total, nullptr, nullptr);
+    case 2: return enqueue_dense<2>(ctx, steps, nprobe, probe_base, d_rows, d_masks, d_counts, d_total, nullptr, nullptr);
+    case 3: return enqueue_dense<3>(ctx, steps, nprobe, probe_base, d_rows, d_masks, d_counts, d_total, nullptr, nullptr);
+    case 4: return enqueue_dense<4>(ctx, steps, nprobe, probe_base, d_rows, d_masks, d_counts, d_total, nullptr, nullptr);
+    }
+    return {CPH_ERR_INVALID, "bad chain length"};
+}
+uint64_t chain_dense_mask_words(uint64_t nprobe) { return (nprobe + kChainTile - 1) / kChainTile * kChainMasks; }
+uint64_t chain_dense_count_words(uint64_t nprobe) { return (nprobe + kChainTile - 1) / kChainTile * kChainWaves; }
+
+template <int S>
+static Status run_fast(cph_ctx* ctx, const ChainStep* steps, uint64_t nprobe, uint64_t probe_base, ChainOut* out) {
+    const uint64_t ntiles = (nprobe + kChainTile - 1) / kChainTile;
+    const uint64_t ncounts = ntiles * kChainWaves;
+    uint32_t* rows[kMaxChain] = {nullptr};
+    for (int s = 0; s < S; s++) {
+        CPH_TRY(out->build_row[s].alloc(&ctx->pool, nprobe * sizeof(uint32_t)));
+        rows[s] = out->build_row[s].as<uint32_t>();
+    }
+    DevBuf masks, counts, total;
+    CPH_TRY(masks.alloc(&ctx->pool, ntiles * kChainMasks * sizeof(uint64_t)));
+    CPH_TRY(counts.alloc(&ctx->pool, ncounts * sizeof(uint32_t)));
+    CPH_TRY(total.alloc(&ctx->pool, sizeof(uint64_t)));
+    ChainArgs args{};
+    unsigned grid = 1;
+    CPH_TRY(enqueue_dense<S>(ctx, steps, nprobe, probe_base, rows, masks.as<uint64_t>(), counts.as<uint32_t>(),
+                             total.as<uint64_t>(), &args, &grid));
     CPH_HIP_TRY(hipGetLastError());
     CPH_TRY(ensure_pinned_scratch(ctx, sizeof(uint64_t)));
     uint64_t* h = reinterpret_cast<uint64_t*>(ctx->pinned_scratch);
@@ -381,7 +421,7 @@ Status chain_run(cph_ctx* ctx, const ChainStep* steps, int nsteps, uint64_t prob
     out->nsteps = nsteps;
     if (nprobe == 0) return {};
 
-    if (fast_path_ok(steps, nsteps)) {
+    if (chain_fast_path_ok(steps, nsteps)) {
         size_t lds = 0;
         for (int s = 0; s < nsteps; s++) lds += steps[s].index->codec_dev.bytes();
         if (lds <= 150 * 1024) {

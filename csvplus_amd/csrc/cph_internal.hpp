@@ -271,6 +271,12 @@ struct ChainOut {
     bool identity = false;     // stream_row[m] == probe_base + m for all m: stream_row is not materialised
 };
 Status chain_run(cph_ctx* ctx, const ChainStep* steps, int nsteps, uint64_t probe_base, ChainOut* out);
+// asynchronous pieces of the fast path (stream_join.hip pipelines them over several streams)
+bool chain_fast_path_ok(const ChainStep* steps, int nsteps);
+Status chain_enqueue_dense(cph_ctx* ctx, const ChainStep* steps, int nsteps, uint64_t nprobe, uint64_t probe_base,
+                           uint32_t* const* d_rows, uint64_t* d_masks, uint32_t* d_counts, uint64_t* d_total);
+uint64_t chain_dense_mask_words(uint64_t nprobe);
+uint64_t chain_dense_count_words(uint64_t nprobe);
 
 // capi.hip helpers
 Status ensure_pinned_scratch(cph_ctx* ctx, size_t bytes);

@@ -1,0 +1,235 @@
+// stream_join.hip — pipelined Join of a stream that lives in HOST memory (BASELINE config 5:
+// "streaming Join ... chunked host->device overlap on HIP streams").
+//
+// The probe side of a Join is a stream (csvplus.go:545-569 never materialises it); when it does
+// not fit or does not live in HBM it is fed chunk by chunk.  Each of the `nslots` slots owns a HIP
+// stream, device buffers and pinned result buffers; submitting a chunk enqueues, on the slot's
+// stream and without any host synchronisation,
+//       H2D of the chunk's key columns -> k_chain_dense -> k_sum_counts -> D2H of the results
+// so chunk k+1's upload, chunk k's kernels and chunk k-1's download overlap (PCIe is full duplex).
+// Results are DENSE: build_row[s][r] is valid where bit r of the match bitmap is set — no
+// device-side compaction, so nothing on the device ever waits for a host decision.
+//
+// Only chains the fused kernel accepts (distinct keys, one key column, one-word code with a
+// pre-multiplied LUT per index) can be streamed; other chains go through cph_join_chain per chunk.
+#include <new>
+
+#include "cph_internal.hpp"
+
+using namespace cph;
+
+struct cph_stream_join {
+    cph_ctx* parent = nullptr;
+    int nsteps = 0;
+    const cph_index* index[CPH_MAX_CHAIN] = {nullptr};
+    struct Slot {
+        cph_ctx sctx;                      // private stream + device pool (the kernels run on sctx.stream)
+        hipEvent_t done = nullptr;
+        bool busy = false;
+        uint64_t probe_base = 0, nrows = 0;
+        std::vector<DevBuf> d_in;          // staged key columns
+        DevBuf d_rows[CPH_MAX_CHAIN], d_masks, d_counts, d_total;
+        void* h_block = nullptr;           // pinned: rows[S] | masks | total
+        size_t h_cap = 0;
+        uint32_t* h_rows[CPH_MAX_CHAIN] = {nullptr};
+        uint64_t* h_masks = nullptr;
+        uint64_t* h_total = nullptr;
+    };
+    std::vector<Slot*> slots;
+    std::vector<int> fifo;                 // slot numbers in submission order
+};
+
+static int32_t sj_fail(cph_ctx* ctx, int32_t code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+extern "C" {
+
+CPH_API int32_t cph_stream_join_create(cph_ctx* ctx, const cph_index* const* indexes, int32_t nsteps, int32_t nslots,
+                                       cph_stream_join** out) {
+    if (!ctx || !indexes || !out || nsteps < 1 || nsteps > CPH_MAX_CHAIN || nslots < 1 || nslots > 16)
+        return sj_fail(ctx, CPH_ERR_INVALID, "bad stream-join arguments");
+    *out = nullptr;
+    if (hipSetDevice(ctx->device) != hipSuccess) return sj_fail(ctx, CPH_ERR_HIP, "hipSetDevice failed");
+    ChainStep probe[CPH_MAX_CHAIN];
+    for (int s = 0; s < nsteps; s++) {
+        if (!indexes[s]) return sj_fail(ctx, CPH_ERR_INVALID, "index is NULL");
+        probe[s].index = indexes[s];
+        probe[s].ncols = 1;
+    }
+    if (!chain_fast_path_ok(probe, nsteps))
+        return sj_fail(ctx, CPH_ERR_INVALID,
+                       "stream join needs indexes with distinct keys over one key column (use cph_join_chain per chunk)");
+    (void)hipStreamSynchronize(ctx->stream);   // the indexes were built on the parent stream
+    cph_stream_join* sj = new (std::nothrow) cph_stream_join();
+    if (!sj) return sj_fail(ctx, CPH_ERR_NOMEM, "out of host memory");
+    sj->parent = ctx;
+    sj->nsteps = nsteps;
+    for (int s = 0; s < nsteps; s++) sj->index[s] = indexes[s];
+    for (int i = 0; i < nslots; i++) {
+        auto* sl = new (std::nothrow) cph_stream_join::Slot();
+        if (!sl || hipStreamCreateWithFlags(&sl->sctx.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&sl->done, hipEventDisableTiming) != hipSuccess) {
+            delete sl;
+            cph_stream_join_destroy(sj);
+            return sj_fail(ctx, CPH_ERR_HIP, "cannot create slot stream/event");
+        }
+        sl->sctx.device = ctx->device;
+        sl->sctx.own_stream = true;
+        sj->slots.push_back(sl);
+    }
+    *out = sj;
+    return CPH_OK;
+}
+
+CPH_API void cph_stream_join_destroy(cph_stream_join* sj) {
+    if (!sj) return;
+    if (sj->parent) (void)hipSetDevice(sj->parent->device);
+    for (auto* sl : sj->slots) {
+        if (!sl) continue;
+        if (sl->sctx.stream) (void)hipStreamSynchronize(sl->sctx.stream);
+        sl->d_in.clear();
+        for (auto& b : sl->d_rows) b.reset();
+        sl->d_masks.reset();
+        sl->d_counts.reset();
+        sl->d_total.reset();
+        sl->sctx.pool.trim();
+        if (sl->h_block) (void)hipHostFree(sl->h_block);
+        if (sl->done) (void)hipEventDestroy(sl->done);
+        if (sl->sctx.stream) (void)hipStreamDestroy(sl->sctx.stream);
+        for (auto& p : sl->sctx.prof_pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
+        for (hipEvent_t e : sl->sctx.prof_free_events) (void)hipEventDestroy(e);
+        if (sl->sctx.pinned_scratch) (void)hipHostFree(sl->sctx.pinned_scratch);
+        if (sl->sctx.upload_ring) (void)hipHostFree(sl->sctx.upload_ring);
+        delete sl;
+    }
+    delete sj;
+}
+
+// step_cols[s] = the stream chunk's key column for step s (HOST memory, pinned for real overlap).
+CPH_API int32_t cph_stream_join_submit(cph_stream_join* sj, const cph_strcol* step_cols, uint64_t probe_base) {
+    if (!sj || !step_cols) return CPH_ERR_INVALID;
+    cph_ctx* pctx = sj->parent;
+    if (hipSetDevice(pctx->device) != hipSuccess) return sj_fail(pctx, CPH_ERR_HIP, "hipSetDevice failed");
+    int slot = -1;
+    for (int i = 0; i < (int)sj->slots.size(); i++)
+        if (!sj->slots[i]->busy) { slot = i; break; }
+    if (slot < 0) return sj_fail(pctx, CPH_ERR_INVALID, "no free slot: call cph_stream_join_next first");
+    auto& sl = *sj->slots[slot];
+    cph_ctx* ctx = &sl.sctx;
+    const uint64_t n = step_cols[0].nrows;
+    if (n == 0 || n > 0xFFFFFFFFull) return sj_fail(pctx, CPH_ERR_INVALID, "chunk must have 1 .. 2^32-1 rows");
+    auto run = [&]() -> Status {
+        sl.d_in.clear();
+        ChainStep steps[CPH_MAX_CHAIN];
+        for (int s = 0; s < sj->nsteps; s++) {
+            const cph_strcol& c = step_cols[s];
+            if (c.nrows != n) return {CPH_ERR_INVALID, "chunk columns differ in row count"};
+            if (c.mem != CPH_MEM_HOST) return {CPH_ERR_INVALID, "stream-join chunks are host columns"};
+            DevCol d;
+            d.nrows = n;
+            d.offset_bits = c.offset_bits;
+            d.fixed_width = c.fixed_width;
+            if (c.fixed_width) {
+                const size_t bytes = (size_t)n * c.fixed_width;
+                DevBuf bd;
+                CPH_TRY(bd.alloc(&ctx->pool, bytes + 8));
+                CPH_HIP_TRY(hipMemcpyAsync(bd.get(), c.data, bytes, hipMemcpyHostToDevice, ctx->stream));
+                d.data = bd.as<uint8_t>();
+                sl.d_in.push_back(std::move(bd));
+            } else {
+                if (c.offset_bits != 32 && c.offset_bits != 64) return {CPH_ERR_INVALID, "offset_bits must be 32 or 64"};
+                const size_t ob = (size_t)(c.offset_bits / 8);
+                const uint64_t first = ob == 4 ? ((const uint32_t*)c.offsets)[0] : ((const uint64_t*)c.offsets)[0];
+                const uint64_t last = ob == 4 ? ((const uint32_t*)c.offsets)[n] : ((const uint64_t*)c.offsets)[n];
+                if (last < first) return {CPH_ERR_INVALID, "offsets are not monotonic"};
+                DevBuf bo, bd;
+                CPH_TRY(bo.alloc(&ctx->pool, (size_t)(n + 1) * ob));
+                CPH_TRY(bd.alloc(&ctx->pool, (size_t)(last - first) + 16));
+                CPH_HIP_TRY(hipMemcpyAsync(bo.get(), c.offsets, (size_t)(n + 1) * ob, hipMemcpyHostToDevice, ctx->stream));
+                if (last > first)
+                    CPH_HIP_TRY(hipMemcpyAsync(bd.get(), c.data + first, (size_t)(last - first), hipMemcpyHostToDevice,
+                                               ctx->stream));
+                // offsets keep their absolute values: bias the data pointer instead of rewriting them
+                d.data = bd.as<uint8_t>() - first;
+                d.offsets = bo.get();
+                sl.d_in.push_back(std::move(bo));
+                sl.d_in.push_back(std::move(bd));
+            }
+            steps[s].index = sj->index[s];
+            steps[s].ncols = 1;
+            steps[s].cols[0] = d;
+        }
+        const uint64_t mw = chain_dense_mask_words(n), cw = chain_dense_count_words(n);
+        uint32_t* rows[CPH_MAX_CHAIN] = {nullptr};
+        for (int s = 0; s < sj->nsteps; s++) {
+            CPH_TRY(sl.d_rows[s].alloc(&ctx->pool, n * sizeof(uint32_t)));
+            rows[s] = sl.d_rows[s].as<uint32_t>();
+        }
+        CPH_TRY(sl.d_masks.alloc(&ctx->pool, mw * sizeof(uint64_t)));
+        CPH_TRY(sl.d_counts.alloc(&ctx->pool, cw * sizeof(uint32_t)));
+        CPH_TRY(sl.d_total.alloc(&ctx->pool, sizeof(uint64_t)));
+        CPH_TRY(chain_enqueue_dense(ctx, steps, sj->nsteps, n, probe_base, rows, sl.d_masks.as<uint64_t>(),
+                                    sl.d_counts.as<uint32_t>(), sl.d_total.as<uint64_t>()));
+        // pinned result block
+        auto a64 = [](size_t x) { return (x + 63) & ~(size_t)63; };
+        const size_t b_rows = a64(n * sizeof(uint32_t)), b_masks = a64(mw * sizeof(uint64_t));
+        const size_t need = (size_t)sj->nsteps * b_rows + b_masks + 64;
+        if (need > sl.h_cap) {
+            if (sl.h_block) (void)hipHostFree(sl.h_block);
+            sl.h_block = nullptr;
+            sl.h_cap = 0;
+            CPH_HIP_TRY(hipHostMalloc(&sl.h_block, need, hipHostMallocDefault));
+            sl.h_cap = need;
+        }
+        uint8_t* h = static_cast<uint8_t*>(sl.h_block);
+        for (int s = 0; s < sj->nsteps; s++) {
+            sl.h_rows[s] = reinterpret_cast<uint32_t*>(h + (size_t)s * b_rows);
+            CPH_HIP_TRY(hipMemcpyAsync(sl.h_rows[s], rows[s], n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        }
+        sl.h_masks = reinterpret_cast<uint64_t*>(h + (size_t)sj->nsteps * b_rows);
+        sl.h_total = reinterpret_cast<uint64_t*>(h + (size_t)sj->nsteps * b_rows + b_masks);
+        CPH_HIP_TRY(hipMemcpyAsync(sl.h_masks, sl.d_masks.get(), mw * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        CPH_HIP_TRY(hipMemcpyAsync(sl.h_total, sl.d_total.get(), sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        CPH_HIP_TRY(hipEventRecord(sl.done, ctx->stream));
+        return {};
+    };
+    Status st = run();
+    if (!st.ok()) {
+        (void)hipStreamSynchronize(ctx->stream);
+        return sj_fail(pctx, st.code, st.msg);
+    }
+    sl.busy = true;
+    sl.probe_base = probe_base;
+    sl.nrows = n;
+    sj->fifo.push_back(slot);
+    return CPH_OK;
+}
+
+CPH_API int32_t cph_stream_join_pending(const cph_stream_join* sj) { return sj ? (int32_t)sj->fifo.size() : 0; }
+
+// Waits for the OLDEST submitted chunk.  The arrays are pinned host memory owned by the slot: valid
+// until the slot is reused, i.e. until `nslots` further chunks have been submitted.
+CPH_API int32_t cph_stream_join_next(cph_stream_join* sj, cph_stream_chunk* out) {
+    if (!sj || !out) return CPH_ERR_INVALID;
+    cph_ctx* pctx = sj->parent;
+    if (sj->fifo.empty()) return sj_fail(pctx, CPH_ERR_INVALID, "no chunk in flight");
+    if (hipSetDevice(pctx->device) != hipSuccess) return sj_fail(pctx, CPH_ERR_HIP, "hipSetDevice failed");
+    const int slot = sj->fifo.front();
+    sj->fifo.erase(sj->fifo.begin());
+    auto& sl = *sj->slots[slot];
+    hipError_t e = hipEventSynchronize(sl.done);
+    sl.busy = false;
+    if (e != hipSuccess) return sj_fail(pctx, CPH_ERR_HIP, std::string("chunk failed: ") + hipGetErrorString(e));
+    memset(out, 0, sizeof *out);
+    out->probe_base = sl.probe_base;
+    out->nrows = sl.nrows;
+    out->nmatches = *sl.h_total;
+    out->match_bitmap = sl.h_masks;
+    out->nsteps = sj->nsteps;
+    for (int s = 0; s < sj->nsteps; s++) out->build_row[s] = sl.h_rows[s];
+    return CPH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+"""Pipelined Join of a host-resident stream (cph_stream_join_*): chunks are uploaded, probed and
+downloaded on several HIP streams so that PCIe transfers overlap the kernels (BASELINE config 5)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from .columns import StrCol
+
+
+class PinnedCol:
+    """A host string column whose buffers live in pinned memory (cph_pinned_alloc), so that the
+    pipeline's H2D copies are truly asynchronous."""
+
+    def __init__(self, ctx: N.Context, col: StrCol):
+        self.ctx = ctx
+        self._ptrs = []
+        data = np.ascontiguousarray(col.data)
+        self.data = self._pinned_copy(data, extra=8)
+        self.offsets = None if col.fixed_width else self._pinned_copy(np.ascontiguousarray(col.offsets))
+        self.col = StrCol(self.data, self.offsets if self.offsets is not None else col.offsets, col.nrows,
+                          col.offset_bits, N.CPH_MEM_HOST, fixed_width=col.fixed_width)
+
+    def _pinned_copy(self, arr: np.ndarray, extra: int = 0) -> np.ndarray:
+        p = C.c_void_p()
+        self.ctx._check(self.ctx.lib.cph_pinned_alloc(self.ctx.handle, arr.nbytes + extra + 8, C.byref(p)))
+        self._ptrs.append(p)
+        buf = (C.c_uint8 * (arr.nbytes + extra)).from_address(p.value)
+        out = np.frombuffer(buf, dtype=arr.dtype, count=arr.size)
+        out[:] = arr
+        return out
+
+    def free(self):
+        for p in self._ptrs:
+            self.ctx.lib.cph_pinned_free(self.ctx.handle, p)
+        self._ptrs = []
+
+
+class StreamJoin:
+    def __init__(self, ctx: N.Context, indexes, nslots: int = 3):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.indexes = list(indexes)
+        arr = (C.c_void_p * len(self.indexes))(*[ix.handle for ix in self.indexes])
+        h = C.c_void_p()
+        ctx._check(self.lib.cph_stream_join_create(ctx.handle, arr, len(self.indexes), nslots, C.byref(h)))
+        self.handle = h
+        self.nslots = nslots
+        self._keep = []
+        ctx._children.add(self)
+
+    def submit(self, step_cols, probe_base: int = 0):
+        """step_cols: one host StrCol per step.  Raises CphError(CPH_ERR_INVALID) when every slot is in flight."""
+        arr = (N.cph_strcol * len(step_cols))()
+        keep = []
+        for i, c in enumerate(step_cols):
+            sc, k = c.as_c()
+            arr[i] = sc
+            keep.append(k)
+        self.ctx._check(self.lib.cph_stream_join_submit(self.handle, arr, probe_base))
+        self._keep.append(keep)
+
+    @property
+    def pending(self) -> int:
+        return int(self.lib.cph_stream_join_pending(self.handle))
+
+    def next(self, copy: bool = True) -> dict:
+        """Waits for the oldest chunk: dict(probe_base, nrows, nmatches, bitmap(uint64), build_row[list of uint32])."""
+        ch = N.cph_stream_chunk()
+        self.ctx._check(self.lib.cph_stream_join_next(self.handle, C.byref(ch)))
+        if self._keep:
+            self._keep.pop(0)
+        n = int(ch.nrows)
+        words = (n + 1023) // 1024 * 16
+        bm = N._ptr_array(ch.match_bitmap, words, np.uint64)
+        rows = [N._ptr_array(ch.build_row[k], n, np.uint32) for k in range(int(ch.nsteps))]
+        if copy:
+            bm, rows = bm.copy(), [r.copy() for r in rows]
+        return {"probe_base": int(ch.probe_base), "nrows": n, "nmatches": int(ch.nmatches), "bitmap": bm,
+                "build_row": rows}
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.cph_stream_join_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def bitmap_to_rows(bitmap: np.ndarray, nrows: int) -> np.ndarray:
+    """Row numbers (ascending) whose bit is set."""
+    bits = np.unpackbits(bitmap.view(np.uint8), bitorder="little")[:nrows]
+    return np.nonzero(bits)[0]

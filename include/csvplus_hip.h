@@ -239,6 +239,45 @@ CPH_API int32_t cph_join_chain(cph_ctx* ctx, const cph_chain_step* steps, int32_
                                int32_t out_mem, cph_chain** out);
 CPH_API void    cph_chain_release(cph_chain* chain);
 
+/* ---- streaming Join of a host-resident stream (BASELINE config 5) -------------- */
+
+/*
+ * The probe side of a Join is a stream (csvplus.go:545-569 never materialises it).
+ * When it lives in host memory it is fed chunk by chunk through a pipeline of
+ * `nslots` slots, each with its own HIP stream: a submitted chunk's H2D copy,
+ * kernels and D2H copy are enqueued without any host synchronisation, so
+ * consecutive chunks overlap upload, compute and download.  Chains are limited to
+ * what the fused kernel accepts: every index has distinct keys over ONE key column
+ * (CPH_ERR_INVALID otherwise; use cph_join_chain per chunk for the general case).
+ *
+ * Results are DENSE per chunk: row r of the chunk joined iff bit (r % 64) of
+ * match_bitmap[r / 64] is set, and then build_row[k][r] is the original row id in
+ * index k.  Emission order is row order.  nmatches = number of set bits.
+ */
+typedef struct cph_stream_join cph_stream_join;
+
+typedef struct {
+    uint64_t        probe_base;     /* as passed to submit                              */
+    uint64_t        nrows;          /* rows of the chunk                                */
+    uint64_t        nmatches;
+    const uint64_t* match_bitmap;   /* ceil(nrows/1024)*16 words (>= nrows bits)        */
+    const uint32_t* build_row[CPH_MAX_CHAIN];
+    int32_t         nsteps;
+    int32_t         reserved_;
+} cph_stream_chunk;
+
+CPH_API int32_t cph_stream_join_create(cph_ctx* ctx, const cph_index* const* indexes, int32_t nsteps, int32_t nslots,
+                                       cph_stream_join** out);
+CPH_API void    cph_stream_join_destroy(cph_stream_join* sj);
+/* step_cols[k] = the chunk's key column for step k: HOST memory (pinned — cph_pinned_alloc —
+ * for real overlap), borrowed until the chunk has been returned by cph_stream_join_next.
+ * Fails with CPH_ERR_INVALID when all slots are in flight. */
+CPH_API int32_t cph_stream_join_submit(cph_stream_join* sj, const cph_strcol* step_cols, uint64_t probe_base);
+CPH_API int32_t cph_stream_join_pending(const cph_stream_join* sj);
+/* Waits for the OLDEST chunk in flight.  The arrays are pinned memory owned by the
+ * pipeline, valid until `nslots` further chunks have been submitted. */
+CPH_API int32_t cph_stream_join_next(cph_stream_join* sj, cph_stream_chunk* out);
+
 /* ---- Find / SubIndex bounds (csvplus.go:870-891) ----------------------------- */
 
 /* [*lower, *upper) = sorted positions whose leading key columns equal

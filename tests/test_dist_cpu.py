@@ -44,6 +44,9 @@ def _worker(rank, world, port, m, nc, npd, q):
         exp = torch.cat([torch.arange(r * 10, r * 10 + (3 if r == 0 else 0 if r == 1 else 5), dtype=torch.int64)
                          for r in range(world)])
         assert counts == [3, 0, 5][:world] and torch.equal(g, exp)
+        # equal shards take the plain all_gather path
+        g2, c2 = allgatherv(torch.full((4,), rank, dtype=torch.int32))
+        assert c2 == [4] * world and g2.tolist() == [r for r in range(world) for _ in range(4)]
 
         cust = dg.column(dg.SEQ_PERM, nc, nc, encoding=dg.FIXED8, seed=dg.SEED + 1)
         prod = dg.column(dg.SEQ_PERM, npd, npd, encoding=dg.ITOA, seed=dg.SEED + 2)

@@ -1,0 +1,74 @@
+"""cph_stream_join_*: chunked, multi-stream Join of a host-resident stream (BASELINE config 5 shape)
+against the oracle, chunk by chunk."""
+import numpy as np
+import pytest
+
+from csvplus_amd import DeviceIndex, StrCol, _native as N, datagen as dg
+from csvplus_amd.streaming import PinnedCol, StreamJoin, bitmap_to_rows
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_chunk(oix, cols, probe_base):
+    j = oix[0].join([cols[0]], probe_base=probe_base)
+    stream, rows = j["probe_idx"], [j["build_row"]]
+    for k in range(1, len(oix)):
+        jk = oix[k].join([cols[k]], row_sel=(stream - probe_base).astype(np.uint32))
+        pick = jk["probe_idx"].astype(np.int64)
+        stream, rows = stream[pick], [r[pick] for r in rows] + [jk["build_row"]]
+    return stream, rows
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_stream_join_chunks_match_oracle(ctx, pinned):
+    nc, npd = 20_000, 300
+    cust, prod = dg.customers(nc)["id"], dg.products(npd)["prod_id"]
+    gix = [DeviceIndex(ctx, [cust], unique=True), DeviceIndex(ctx, [prod], unique=True)]
+    oix = [orc.OracleIndex([cust]), orc.OracleIndex([prod])]
+    sj = StreamJoin(ctx, gix, nslots=3)
+    chunk_rows = [50_000, 1, 1024, 77_777, 1023, 200_000, 4096]
+    chunks, base = [], 0
+    for i, n in enumerate(chunk_rows):
+        o = dg.orders(10**7, 2 * nc if i % 2 else nc, npd, row0=base, nrows=n)   # odd chunks: half the keys miss
+        cols = [o["cust_id"], o["prod_id"]]
+        pins = [PinnedCol(ctx, c) for c in cols] if pinned else None
+        chunks.append((base, cols, pins))
+        base += n
+    results, submitted = [], 0
+    while len(results) < len(chunks):
+        while submitted < len(chunks) and sj.pending < sj.nslots:
+            b, cols, pins = chunks[submitted]
+            sj.submit([p.col for p in pins] if pins else cols, probe_base=b)
+            submitted += 1
+        results.append(sj.next())
+    with pytest.raises(N.CphError):
+        sj.next()
+    for (b, cols, pins), r in zip(chunks, results):
+        es, erows = oracle_chunk(oix, cols, b)
+        assert r["probe_base"] == b and r["nrows"] == cols[0].nrows and r["nmatches"] == len(es)
+        hit = bitmap_to_rows(r["bitmap"], r["nrows"])
+        np.testing.assert_array_equal(hit + b, es.astype(np.int64))
+        for k in range(2):
+            np.testing.assert_array_equal(r["build_row"][k][hit], erows[k])
+        if pins:
+            for p in pins:
+                p.free()
+    sj.close()
+
+
+def test_stream_join_slot_exhaustion_and_rejects_dup_index(ctx):
+    cust = dg.customers(1000)["id"]
+    ix = DeviceIndex(ctx, [cust], unique=True)
+    sj = StreamJoin(ctx, [ix], nslots=2)
+    col = dg.orders(5000, 1000, 10)["cust_id"]
+    sj.submit([col]); sj.submit([col])
+    with pytest.raises(N.CphError):
+        sj.submit([col])
+    a, b = sj.next(), sj.next()
+    assert a["nmatches"] == b["nmatches"] == 5000
+    sj.close()
+    dup = DeviceIndex(ctx, [StrCol.from_values(["a", "a", "b"])])
+    with pytest.raises(N.CphError) as e:
+        StreamJoin(ctx, [dup])
+    assert e.value.code == N.CPH_ERR_INVALID
