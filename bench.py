@@ -58,10 +58,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Debug aid for 1-GPU boxes: CPH_BENCH_SHARE_GPU=1 maps every rank to cuda:0 and uses the gloo
+    # backend (RCCL refuses two ranks on one device), so the N>1 control flow can be exercised.
+    share_gpu = os.environ.get("CPH_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank)
     eng = Engine(local_rank)
@@ -115,12 +123,12 @@ def main():
     prof = eng.ctx.profile_read(reset=True)
     eng.ctx.profile(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     total_joined = joined if (world == 1 or args.exchange == "allgatherv") else None
     if total_joined is None:
-        t = torch.tensor([joined], dtype=torch.int64, device=dev)
+        t = torch.tensor([joined], dtype=torch.int64, device="cpu" if share_gpu else dev)
         dist.all_reduce(t)
         total_joined = int(t.item())
 
@@ -191,7 +199,7 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "u8 keys -> u32 codes", "data": "synthetic",
         "config": {"workload": "orders(1e8 x {cust_id,prod_id,qty}) JOIN customers(1e7, UniqueIndexOn id) "
-                               "JOIN products(1e5, UniqueIndexOn prod_id); configs[3] shape on 1 GPU",
+                               "JOIN products(1e5, UniqueIndexOn prod_id); BASELINE configs[3] shape, probe rows sharded over n_gpus",
                    "rows": args.rows, "customers": args.customers, "products": args.products,
                    "rows_this_rank": nloc, "exchange": args.exchange if world > 1 else "none (1 GPU)",
                    "inputs": "resident in HBM before the timed region"},

@@ -25,6 +25,9 @@ def allgatherv(t, group=None):
         return t, [int(t.numel())]
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    if dist.get_backend(group) == "gloo" and t.is_cuda:   # debug path (several ranks sharing one GPU)
+        out, counts = allgatherv(t.cpu(), group)
+        return out.to(t.device), counts
     n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
     counts_t = torch.zeros(world, dtype=torch.int64, device=t.device)
     dist.all_gather_into_tensor(counts_t, n, group=group)
