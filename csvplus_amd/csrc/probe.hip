@@ -4,7 +4,7 @@
 //   k_build_table   direct-address table code -> [lo,end) when the code space is dense
 //   k_probe         per stream row: encode key, first()+forward scan bounds
 //                   (csvplus.go:556-559, :893-920) -> (lo,cnt), per-tile match totals
-//   k_scan_tiles    exclusive scan of the per-tile totals
+//   (exclusive_scan_u64 of the per-tile totals: radix_sort.hip)
 //   k_expand        emits (probe_idx, build_row) pairs in the reference's order:
 //                   stream order, then ascending index position (csvplus.go:559-563)
 //   k_find          Find/SubIndex bounds (csvplus.go:870-891)
@@ -196,19 +196,119 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(ColsArg cols, int ncols
     }
 }
 
-// single workgroup: tile_sums[0..m) -> exclusive prefix in place, total in tile_sums[m]
-__global__ __launch_bounds__(256) void k_scan_tiles(uint64_t* __restrict__ sums, uint64_t m) {
-    __shared__ uint64_t s_tmp[256 / kWave + 1];
-    uint64_t carry = 0;
-    for (uint64_t base = 0; base < m; base += 256) {
-        const uint64_t i = base + threadIdx.x;
-        const uint64_t v = i < m ? sums[i] : 0ull;
-        uint64_t total;
-        const uint64_t ex = block_exclusive_sum<uint64_t, 256>(v, s_tmp, &total);
-        if (i < m) sums[i] = carry + ex;
-        carry += total;
+// Fast variant for the common shape: ONE key column, single-word code with a pre-multiplied LUT.
+// Same tile geometry as k_probe (k_expand depends on it), but 4 rows are in flight per thread and
+// phase: row selection, spans, key bytes, then the lookups are issued back to back.
+constexpr int kProbeRows = 4;
+
+template <bool KEY32, bool TABLE>
+__global__ __launch_bounds__(kProbeThreads) void k_probe_fast(DevCol col, const uint8_t* __restrict__ g_codec,
+                                                             const void* __restrict__ codes, uint64_t n_index,
+                                                             const TableEntry* __restrict__ table, bool table_unique,
+                                                             RowSel sel, uint64_t nprobe,
+                                                             uint32_t* __restrict__ out_lo, uint32_t* __restrict__ out_cnt,
+                                                             uint64_t* __restrict__ tile_sums,
+                                                             uint32_t* __restrict__ out_first_row) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ uint64_t s_wsum[kProbeThreads / kWave];
+    const CodecView cv = codec_load_to_lds(g_codec, smem);
+    const bool w32 = cv.hdr->lutw_bits == 32;
+    const bool long_keys = cv.hdr->col_maxlen[0] > 8;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * kProbeTile;
+    uint64_t my_sum = 0;
+#pragma unroll 1
+    for (int ph = 0; ph < kProbeItems / kProbeRows; ph++) {
+        uint64_t i[kProbeRows], row[kProbeRows];
+        bool ok[kProbeRows];
+#pragma unroll
+        for (int k = 0; k < kProbeRows; k++) {
+            i[k] = tile0 + (uint64_t)(ph * kProbeRows + k) * kProbeThreads + threadIdx.x;
+            ok[k] = i[k] < nprobe;
+            row[k] = i[k];
+        }
+        if (sel.ptr) {
+            if (sel.bits == 32) {
+#pragma unroll
+                for (int k = 0; k < kProbeRows; k++)
+                    if (ok[k]) row[k] = (uint64_t) reinterpret_cast<const uint32_t*>(sel.ptr)[i[k]] - sel.base;
+            } else {
+#pragma unroll
+                for (int k = 0; k < kProbeRows; k++)
+                    if (ok[k]) row[k] = reinterpret_cast<const uint64_t*>(sel.ptr)[i[k]] - sel.base;
+            }
+        }
+        uint64_t begin[kProbeRows], len[kProbeRows], c0[kProbeRows], c1[kProbeRows];
+#pragma unroll
+        for (int k = 0; k < kProbeRows; k++) {
+            begin[k] = 0;
+            len[k] = 0;
+            if (ok[k]) value_span(col, row[k], &begin[k], &len[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < kProbeRows; k++) {
+            c0[k] = len[k] ? load_value_chunk(col.data, begin[k], len[k], 0) : 0;
+            c1[k] = (long_keys && len[k] > 8) ? load_value_chunk(col.data, begin[k], len[k], 1) : 0;
+        }
+        uint64_t code[kProbeRows];
+        bool valid[kProbeRows];
+#pragma unroll
+        for (int k = 0; k < kProbeRows; k++) {
+            const uint32_t l32 = len[k] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)len[k];
+            valid[k] = ok[k] && (w32 ? encode_prefetched_w<uint32_t>(cv, col, begin[k], l32, c0[k], c1[k], &code[k])
+                                     : encode_prefetched_w<uint64_t>(cv, col, begin[k], l32, c0[k], c1[k], &code[k]));
+        }
+        uint32_t lo[kProbeRows], cnt[kProbeRows], e_b[kProbeRows];
+        if constexpr (TABLE) {
+            TableEntry e[kProbeRows];
+#pragma unroll
+            for (int k = 0; k < kProbeRows; k++) e[k] = valid[k] ? table[code[k]] : TableEntry{kTableAbsent, kTableAbsent};
+#pragma unroll
+            for (int k = 0; k < kProbeRows; k++) {
+                e_b[k] = e[k].b;
+                lo[k] = e[k].a;
+                cnt[k] = table_unique ? (e[k].a != kTableAbsent ? 1u : 0u) : e[k].b - e[k].a;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kProbeRows; k++) {
+                uint64_t l = 0, h = 0;
+                if (valid[k]) {
+                    if constexpr (KEY32) {
+                        const uint32_t* a = reinterpret_cast<const uint32_t*>(codes);
+                        l = lower_bound_dev<uint32_t>(a, 0, n_index, (uint32_t)code[k]);
+                        h = upper_bound_dev<uint32_t>(a, l, n_index, (uint32_t)code[k]);
+                    } else {
+                        const uint64_t* a = reinterpret_cast<const uint64_t*>(codes);
+                        l = lower_bound_dev<uint64_t>(a, 0, n_index, code[k]);
+                        h = upper_bound_dev<uint64_t>(a, l, n_index, code[k]);
+                    }
+                }
+                lo[k] = (uint32_t)l;
+                cnt[k] = (uint32_t)(h - l);
+                e_b[k] = 0;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kProbeRows; k++) {
+            if (!ok[k]) continue;
+            out_lo[i[k]] = lo[k];
+            out_cnt[i[k]] = cnt[k];
+            if constexpr (TABLE) {
+                // duplicate-free index: the table entry already holds the build row, k_expand then
+                // needs no dependent perm[lo] gather
+                if (out_first_row) out_first_row[i[k]] = e_b[k];
+            }
+            my_sum += cnt[k];
+        }
     }
-    if (threadIdx.x == 0) sums[m] = carry;
+    my_sum = wave_sum(my_sum);
+    if (lane_id() == 0) s_wsum[wave_id()] = my_sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0;
+        for (int w = 0; w < kProbeThreads / kWave; w++) t += s_wsum[w];
+        tile_sums[blockIdx.x] = t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -217,7 +317,8 @@ __global__ __launch_bounds__(256) void k_scan_tiles(uint64_t* __restrict__ sums,
 __global__ __launch_bounds__(kProbeThreads) void k_expand(const uint32_t* __restrict__ lo_arr,
                                                          const uint32_t* __restrict__ cnt_arr, uint64_t nprobe,
                                                          const uint64_t* __restrict__ tile_base,
-                                                         const uint32_t* __restrict__ perm, uint64_t probe_base,
+                                                         const uint32_t* __restrict__ perm,
+                                                         const uint32_t* __restrict__ first_row, uint64_t probe_base,
                                                          uint64_t* __restrict__ out_pidx,
                                                          uint32_t* __restrict__ out_brow) {
     __shared__ uint64_t s_off[kProbeTile + 1];
@@ -263,7 +364,7 @@ __global__ __launch_bounds__(kProbeThreads) void k_expand(const uint32_t* __rest
             if (s_off[r + 1] != s_off[r]) {
                 const uint64_t o = out0 + s_off[r];
                 out_pidx[o] = probe_base + tile0 + r;
-                out_brow[o] = perm[s_lo[r]];
+                out_brow[o] = first_row ? first_row[tile0 + r] : perm[s_lo[r]];
             }
         }
     } else {
@@ -314,18 +415,44 @@ Status probe_run(cph_ctx* ctx, const cph_index* ix, const DevCol* cols, int32_t 
     uint32_t* lo = out->lo.as<uint32_t>();
     uint32_t* cnt = out->cnt.as<uint32_t>();
     uint64_t* ts = tiles.as<uint64_t>();
-    if (ix->codec.key32) {
+    DevBuf first_rows;
+    const bool fast = ncols == 1 && ix->codec.ncols == 1 && codec_premultiplied_bits(ix->codec) != 0;
+    if (fast) {
+        // one key column, single-word code, pre-multiplied LUT: 4 rows in flight per thread
+        const size_t lds = ix->codec_dev.bytes();
+        const uint8_t* blob = ix->codec_dev.as<uint8_t>();
+        const void* codes = ix->sorted_codes.get();
+        const TableEntry* tab = ix->table.as<TableEntry>();
+        const bool tuniq = ix->first_dup == UINT64_MAX;
+        // pairs wanted from a duplicate-free index with a table: keep the entries' build rows
+        uint32_t* first_row = nullptr;
+        if (want_pairs && use_table && tuniq) {
+            CPH_TRY(first_rows.alloc(&ctx->pool, nprobe * sizeof(uint32_t)));
+            first_row = first_rows.as<uint32_t>();
+        }
+        ProfScope ps(ctx, use_table ? "k_probe_table" : "k_probe_search", 0);
+        const dim3 grid(ntiles), block(kProbeThreads);
+        if (ix->codec.key32 && use_table)
+            hipLaunchKernelGGL((k_probe_fast<true, true>), grid, block, lds, ctx->stream, cols[0], blob, codes, ix->nrows,
+                               tab, tuniq, row_sel, nprobe, lo, cnt, ts, first_row);
+        else if (ix->codec.key32)
+            hipLaunchKernelGGL((k_probe_fast<true, false>), grid, block, lds, ctx->stream, cols[0], blob, codes, ix->nrows,
+                               tab, tuniq, row_sel, nprobe, lo, cnt, ts, first_row);
+        else if (use_table)
+            hipLaunchKernelGGL((k_probe_fast<false, true>), grid, block, lds, ctx->stream, cols[0], blob, codes, ix->nrows,
+                               tab, tuniq, row_sel, nprobe, lo, cnt, ts, first_row);
+        else
+            hipLaunchKernelGGL((k_probe_fast<false, false>), grid, block, lds, ctx->stream, cols[0], blob, codes, ix->nrows,
+                               tab, tuniq, row_sel, nprobe, lo, cnt, ts, first_row);
+        CPH_HIP_TRY(hipGetLastError());
+    } else if (ix->codec.key32) {
         if (use_table) CPH_TRY((launch_probe<true, true>(ctx, ix, arg, ncols, row_sel, nprobe, lo, cnt, ts, ntiles)));
         else CPH_TRY((launch_probe<true, false>(ctx, ix, arg, ncols, row_sel, nprobe, lo, cnt, ts, ntiles)));
     } else {
         if (use_table) CPH_TRY((launch_probe<false, true>(ctx, ix, arg, ncols, row_sel, nprobe, lo, cnt, ts, ntiles)));
         else CPH_TRY((launch_probe<false, false>(ctx, ix, arg, ncols, row_sel, nprobe, lo, cnt, ts, ntiles)));
     }
-    {
-        ProfScope ps(ctx, "k_scan_tiles", 16.0 * (double)ntiles64);
-        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(256), 0, ctx->stream, ts, ntiles64);
-    }
-    CPH_HIP_TRY(hipGetLastError());
+    CPH_TRY(exclusive_scan_u64(ctx, ts, ntiles64, ts + ntiles64));   // tile bases; the total lands behind them
     CPH_TRY(ensure_pinned_scratch(ctx, sizeof(uint64_t)));
     CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, ts + ntiles64, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -335,7 +462,8 @@ Status probe_run(cph_ctx* ctx, const cph_index* ix, const DevCol* cols, int32_t 
     CPH_TRY(out->brow.alloc(&ctx->pool, out->nmatches * sizeof(uint32_t)));
     ProfScope ps(ctx, "k_expand", 8.0 * (double)nprobe + 16.0 * (double)out->nmatches);
     hipLaunchKernelGGL(k_expand, dim3(ntiles), dim3(kProbeThreads), 0, ctx->stream, lo, cnt, nprobe, ts,
-                       ix->perm.as<uint32_t>(), probe_base, out->pidx.as<uint64_t>(), out->brow.as<uint32_t>());
+                       ix->perm.as<uint32_t>(), first_rows ? first_rows.as<uint32_t>() : (const uint32_t*)nullptr, probe_base,
+                       out->pidx.as<uint64_t>(), out->brow.as<uint32_t>());
     CPH_HIP_TRY(hipGetLastError());
     return {};
 }

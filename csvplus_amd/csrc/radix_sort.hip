@@ -197,11 +197,12 @@ constexpr int kScanThreads = 256;
 constexpr int kScanItems   = 16;
 constexpr int kScanTile    = kScanThreads * kScanItems;
 
-__global__ __launch_bounds__(kScanThreads) void k_scan_reduce(const uint32_t* __restrict__ data, uint64_t n,
-                                                             uint32_t* __restrict__ block_sums) {
-    __shared__ uint32_t s_w[kScanThreads / kWave];
+template <class T>
+__global__ __launch_bounds__(kScanThreads) void k_scan_reduce(const T* __restrict__ data, uint64_t n,
+                                                             T* __restrict__ block_sums) {
+    __shared__ T s_w[kScanThreads / kWave];
     const uint64_t base = (uint64_t)blockIdx.x * kScanTile;
-    uint32_t sum = 0;
+    T sum = 0;
 #pragma unroll
     for (int k = 0; k < kScanItems; k++) {
         const uint64_t i = base + (uint64_t)k * kScanThreads + threadIdx.x;
@@ -211,40 +212,44 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_reduce(const uint32_t* __
     if (lane_id() == 0) s_w[wave_id()] = sum;
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t t = 0;
+        T t = 0;
         for (int w = 0; w < kScanThreads / kWave; w++) t += s_w[w];
         block_sums[blockIdx.x] = t;
     }
 }
 
-// single workgroup: exclusive scan of `m` block sums in place
-__global__ __launch_bounds__(kScanThreads) void k_scan_block_sums(uint32_t* __restrict__ sums, uint64_t m) {
-    __shared__ uint32_t s_tmp[kScanThreads / kWave + 1];
-    uint32_t carry = 0;
+// single workgroup: exclusive scan of `m` block sums in place; the grand total goes to *total_out
+template <class T>
+__global__ __launch_bounds__(kScanThreads) void k_scan_block_sums(T* __restrict__ sums, uint64_t m,
+                                                                 T* __restrict__ total_out) {
+    __shared__ T s_tmp[kScanThreads / kWave + 1];
+    T carry = 0;
     for (uint64_t base = 0; base < m; base += kScanThreads) {
         const uint64_t i = base + threadIdx.x;
-        const uint32_t v = i < m ? sums[i] : 0u;
-        uint32_t total;
-        const uint32_t ex = block_exclusive_sum<uint32_t, kScanThreads>(v, s_tmp, &total);
+        const T v = i < m ? sums[i] : (T)0;
+        T total;
+        const T ex = block_exclusive_sum<T, kScanThreads>(v, s_tmp, &total);
         if (i < m) sums[i] = carry + ex;
         carry += total;
     }
+    if (threadIdx.x == 0 && total_out) *total_out = carry;
 }
 
-__global__ __launch_bounds__(kScanThreads) void k_scan_apply(uint32_t* __restrict__ data, uint64_t n,
-                                                            const uint32_t* __restrict__ block_sums) {
-    __shared__ uint32_t s_tmp[kScanThreads / kWave + 1];
+template <class T>
+__global__ __launch_bounds__(kScanThreads) void k_scan_apply(T* __restrict__ data, uint64_t n,
+                                                            const T* __restrict__ block_sums) {
+    __shared__ T s_tmp[kScanThreads / kWave + 1];
     // thread t owns kScanItems consecutive elements
     const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
-    uint32_t v[kScanItems];
-    uint32_t sum = 0;
+    T v[kScanItems];
+    T sum = 0;
 #pragma unroll
     for (int k = 0; k < kScanItems; k++) {
-        v[k] = (base + k) < n ? data[base + k] : 0u;
+        v[k] = (base + k) < n ? data[base + k] : (T)0;
         sum += v[k];
     }
-    uint32_t total;
-    uint32_t run = block_exclusive_sum<uint32_t, kScanThreads>(sum, s_tmp, &total) + block_sums[blockIdx.x];
+    T total;
+    T run = block_exclusive_sum<T, kScanThreads>(sum, s_tmp, &total) + block_sums[blockIdx.x];
 #pragma unroll
     for (int k = 0; k < kScanItems; k++) {
         if ((base + k) < n) data[base + k] = run;
@@ -252,19 +257,29 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(uint32_t* __restric
     }
 }
 
-Status exclusive_scan_u32(cph_ctx* ctx, uint32_t* data, uint64_t n) {
-    if (n == 0) return {};
+template <class T>
+static Status exclusive_scan_impl(cph_ctx* ctx, T* data, uint64_t n, T* total_out, const char* name) {
+    if (n == 0) {
+        if (total_out) CPH_HIP_TRY(hipMemsetAsync(total_out, 0, sizeof(T), ctx->stream));
+        return {};
+    }
     const uint64_t nblk = (n + kScanTile - 1) / kScanTile;
     DevBuf sums;
-    CPH_TRY(sums.alloc(&ctx->pool, nblk * sizeof(uint32_t)));
-    ProfScope ps(ctx, "exclusive_scan_u32", 12.0 * (double)n);
-    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nblk), dim3(kScanThreads), 0, ctx->stream, data, n,
-                       sums.as<uint32_t>());
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(kScanThreads), 0, ctx->stream, sums.as<uint32_t>(), nblk);
-    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nblk), dim3(kScanThreads), 0, ctx->stream, data, n,
-                       sums.as<uint32_t>());
+    CPH_TRY(sums.alloc(&ctx->pool, nblk * sizeof(T)));
+    ProfScope ps(ctx, name, 3.0 * sizeof(T) * (double)n);
+    hipLaunchKernelGGL(k_scan_reduce<T>, dim3((unsigned)nblk), dim3(kScanThreads), 0, ctx->stream, data, n, sums.as<T>());
+    hipLaunchKernelGGL(k_scan_block_sums<T>, dim3(1), dim3(kScanThreads), 0, ctx->stream, sums.as<T>(), nblk, total_out);
+    hipLaunchKernelGGL(k_scan_apply<T>, dim3((unsigned)nblk), dim3(kScanThreads), 0, ctx->stream, data, n, sums.as<T>());
     CPH_HIP_TRY(hipGetLastError());
     return {};
+}
+
+Status exclusive_scan_u32(cph_ctx* ctx, uint32_t* data, uint64_t n) {
+    return exclusive_scan_impl<uint32_t>(ctx, data, n, nullptr, "exclusive_scan_u32");
+}
+// In-place exclusive scan of 64-bit counts; *total_out (device, optional) receives the sum.
+Status exclusive_scan_u64(cph_ctx* ctx, uint64_t* data, uint64_t n, uint64_t* total_out) {
+    return exclusive_scan_impl<uint64_t>(ctx, data, n, total_out, "exclusive_scan_u64");
 }
 
 // ---------------------------------------------------------------------------------------------
