@@ -110,6 +110,14 @@ class cph_chain(C.Structure):
                 ("nsteps", C.c_int32), ("mem", C.c_int32)]
 
 
+class cph_colbuf(C.Structure):
+    _fields_ = [("col", cph_strcol), ("nbytes", C.c_uint64)]
+
+
+class cph_bytes(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("size", C.c_uint64), ("mem", C.c_int32), ("reserved_", C.c_int32)]
+
+
 class cph_stream_chunk(C.Structure):
     _fields_ = [("probe_base", C.c_uint64), ("nrows", C.c_uint64), ("nmatches", C.c_uint64),
                 ("match_bitmap", C.c_void_p), ("build_row", C.c_void_p * CPH_MAX_CHAIN), ("nsteps", C.c_int32),
@@ -153,6 +161,12 @@ PROTOTYPES = [
     ("cph_stream_join_submit", C.c_int32, [_P, C.POINTER(cph_strcol), C.c_uint64]),
     ("cph_stream_join_pending", C.c_int32, [_P]),
     ("cph_stream_join_next", C.c_int32, [_P, C.POINTER(cph_stream_chunk)]),
+    ("cph_gather_rows", C.c_int32,
+     [_P, C.POINTER(cph_strcol), _P, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(C.POINTER(cph_colbuf))]),
+    ("cph_colbuf_release", None, [C.POINTER(cph_colbuf)]),
+    ("cph_csv_write", C.c_int32,
+     [_P, C.POINTER(cph_strcol), C.c_int32, C.POINTER(cph_strval), C.c_int32, C.POINTER(C.POINTER(cph_bytes))]),
+    ("cph_bytes_release", None, [C.POINTER(cph_bytes)]),
     ("cph_index_find", C.c_int32,
      [_P, _P, C.POINTER(cph_strval), C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("cph_index_get_info", C.c_int32, [_P, C.POINTER(cph_index_info)]),

@@ -147,7 +147,7 @@ ProfScope::~ProfScope() {
 }
 
 // ---- staging ----------------------------------------------------------------------------------
-static Status validate_cols(const cph_strcol* cols, int32_t ncols) {
+Status validate_cols(const cph_strcol* cols, int32_t ncols) {
     if (!cols || ncols <= 0) return {CPH_ERR_INVALID, "no key columns"};
     if (ncols > kMaxKeyCols) return {CPH_ERR_INVALID, "too many key columns"};
     for (int c = 0; c < ncols; c++) {
@@ -163,7 +163,7 @@ static Status validate_cols(const cph_strcol* cols, int32_t ncols) {
 }
 
 // Makes the columns device resident (copies host columns into pool blocks kept in `storage`).
-static Status stage_cols(cph_ctx* ctx, const cph_strcol* cols, int32_t ncols, std::vector<DevBuf>* storage,
+Status stage_cols(cph_ctx* ctx, const cph_strcol* cols, int32_t ncols, std::vector<DevBuf>* storage,
                          DevCol* out) {
     for (int c = 0; c < ncols; c++) {
         DevCol d;

@@ -282,6 +282,9 @@ uint64_t chain_dense_count_words(uint64_t nprobe);
 // capi.hip helpers
 Status ensure_pinned_scratch(cph_ctx* ctx, size_t bytes);
 Status pinned_upload(cph_ctx* ctx, size_t bytes, void** out);   // staging slot valid until the ring wraps
+Status validate_cols(const cph_strcol* cols, int32_t ncols);
+// Makes columns device resident (host columns are copied into pool blocks kept alive by `storage`).
+Status stage_cols(cph_ctx* ctx, const cph_strcol* cols, int32_t ncols, std::vector<DevBuf>* storage, DevCol* out);
 
 // Times everything enqueued on ctx->stream during its lifetime when ctx->profiling is on
 // (two HIP events on that stream); `bytes` = algorithmic bytes of the launch.

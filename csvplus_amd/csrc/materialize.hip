@@ -1,0 +1,456 @@
+// materialize.hip — the step AFTER the path: turning row ids back into data.
+//
+//   cph_gather_rows  out[i] = col[row_ids[i] - base]: the column-wise form of mergeRows
+//                    (csvplus.go:571-583) — a joined table is the stream's columns plus, for every
+//                    index, its columns gathered through build_row; on a name collision the host
+//                    simply takes the stream's column (the stream value wins, :578-580).
+//   cph_csv_write    ToCsv (csvplus.go:379-406): header line, then every row's values in a fixed
+//                    column order through Go's encoding/csv Writer with default settings
+//                    (Comma ',', UseCRLF false).  The Writer's rules, restated from the Go
+//                    standard library (not under /root/reference): a field is quoted iff it is
+//                    `\.`, or contains the comma, '"', '\r' or '\n', or starts with a Unicode space
+//                    (unicode.IsSpace of its first rune); inside quotes '"' is doubled, nothing else
+//                    changes; records end with '\n'.
+//
+// Both are length -> exclusive scan -> copy pipelines.  The copy kernels assemble a tile's bytes in
+// LDS (byte-granular writes are cheap there) and stream them out with 16-byte stores; a tile whose
+// bytes do not fit the LDS stage falls back to direct byte stores.  HBM-bound byte work, no MFMA.
+#include <new>
+
+#include "codec_device.hpp"
+
+namespace cph {
+
+constexpr int kMatThreads = 256;
+constexpr int kMatStage   = 48 * 1024;   // LDS bytes for one tile's output
+
+struct RowIds {
+    const void* ptr = nullptr;   // null: identity
+    int32_t bits = 32;
+    uint64_t base = 0;
+};
+__device__ __forceinline__ uint64_t source_row(const RowIds& ids, uint64_t i) {
+    if (!ids.ptr) return i;
+    return (ids.bits == 32 ? (uint64_t) reinterpret_cast<const uint32_t*>(ids.ptr)[i]
+                           : reinterpret_cast<const uint64_t*>(ids.ptr)[i]) - ids.base;
+}
+
+// ---- byte sinks -------------------------------------------------------------------------------------
+struct LdsSink {
+    CPH_LDS uint8_t* p;
+    __device__ __forceinline__ void put(uint8_t b) { *p++ = b; }
+};
+struct GlobalSink {
+    uint8_t* p;
+    __device__ __forceinline__ void put(uint8_t b) { *p++ = b; }
+};
+
+template <class Sink>
+__device__ __forceinline__ void copy_value(Sink& out, const DevCol& col, uint64_t begin, uint64_t len) {
+    uint64_t chunk = 0;
+    for (uint64_t q = 0; q < len; q++) {
+        if ((q & 7) == 0) chunk = load_value_chunk(col.data, begin, len, (int)(q >> 3));
+        out.put((uint8_t)(chunk >> (8 * (q & 7))));
+    }
+}
+
+// Streams a tile's staged bytes [0, span) to out + obase.  The stage holds them at offset
+// (obase & 15), so 16-byte aligned global words are 16-byte aligned in LDS too.
+__device__ __forceinline__ void flush_stage(const CPH_LDS uint8_t* stage, uint8_t* out, uint64_t obase, uint64_t span) {
+    const uint32_t shift = (uint32_t)(obase & 15);
+    const uint64_t gend = obase + span;
+    const uint64_t astart = (obase + 15) & ~15ull;          // first aligned global address
+    const uint64_t aend = gend & ~15ull;                    // end of the aligned interior
+    if (astart >= aend) {                                    // short span: bytes only
+        for (uint64_t g = obase + threadIdx.x; g < gend; g += blockDim.x) out[g] = stage[g - obase + shift];
+        return;
+    }
+    for (uint64_t g = obase + threadIdx.x; g < astart; g += blockDim.x) out[g] = stage[g - obase + shift];
+    for (uint64_t g = aend + threadIdx.x; g < gend; g += blockDim.x) out[g] = stage[g - obase + shift];
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // builtin vector: works with address spaces
+    const CPH_LDS u32x4* src = (const CPH_LDS u32x4*)(stage + (astart - obase + shift));
+    u32x4* dst = reinterpret_cast<u32x4*>(out + astart);
+    const uint64_t nwords = (aend - astart) >> 4;
+    for (uint64_t w = threadIdx.x; w < nwords; w += blockDim.x) dst[w] = src[w];
+}
+
+// ---- gather ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kMatThreads) void k_gather_lens(DevCol col, RowIds ids, uint64_t n, uint64_t* __restrict__ lens) {
+    const uint64_t stride = (uint64_t)gridDim.x * kMatThreads;
+    for (uint64_t i = (uint64_t)blockIdx.x * kMatThreads + threadIdx.x; i < n; i += stride) {
+        uint64_t b, l;
+        value_span(col, source_row(ids, i), &b, &l);
+        lens[i] = l;
+    }
+}
+
+__global__ __launch_bounds__(kMatThreads) void k_gather_copy(DevCol col, RowIds ids, uint64_t n,
+                                                            const uint64_t* __restrict__ offs, uint8_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    CPH_LDS uint8_t* stage = (CPH_LDS uint8_t*)smem;
+    for (uint64_t t0 = (uint64_t)blockIdx.x * kMatThreads; t0 < n; t0 += (uint64_t)gridDim.x * kMatThreads) {
+        const uint64_t tend = t0 + kMatThreads < n ? t0 + kMatThreads : n;
+        const uint64_t obase = offs[t0];
+        const uint64_t span = offs[tend] - obase;
+        const uint64_t i = t0 + threadIdx.x;
+        uint64_t b = 0, l = 0;
+        if (i < tend) value_span(col, source_row(ids, i), &b, &l);
+        if (span + 16 <= (uint64_t)kMatStage) {
+            if (i < tend && l) {
+                LdsSink s{stage + (offs[i] - obase) + (obase & 15)};
+                copy_value(s, col, b, l);
+            }
+            __syncthreads();
+            flush_stage(stage, out, obase, span);
+            __syncthreads();
+        } else if (i < tend && l) {
+            GlobalSink s{out + offs[i]};
+            copy_value(s, col, b, l);
+        }
+    }
+}
+
+// ---- CSV writer ------------------------------------------------------------------------------------------
+// unicode.IsSpace of the first rune of a UTF-8 string (Go: '\t','\n','\v','\f','\r',' ', U+0085, U+00A0,
+// U+1680, U+2000-200A, U+2028, U+2029, U+202F, U+205F, U+3000)
+__device__ __forceinline__ bool first_rune_is_space(uint64_t chunk, uint64_t len) {
+    const uint32_t b0 = (uint32_t)(chunk & 0xFF), b1 = (uint32_t)((chunk >> 8) & 0xFF), b2 = (uint32_t)((chunk >> 16) & 0xFF);
+    if (b0 < 0x80) return b0 == ' ' || (b0 >= 9 && b0 <= 13);
+    if (b0 == 0xC2 && len >= 2) return b1 == 0x85 || b1 == 0xA0;
+    if (len < 3) return false;
+    if (b0 == 0xE1) return b1 == 0x9A && b2 == 0x80;
+    if (b0 == 0xE2) {
+        if (b1 == 0x80) return (b2 >= 0x80 && b2 <= 0x8A) || b2 == 0xA8 || b2 == 0xA9 || b2 == 0xAF;
+        return b1 == 0x81 && b2 == 0x9F;
+    }
+    return b0 == 0xE3 && b1 == 0x80 && b2 == 0x80;
+}
+
+// bytes the field occupies in the record + whether it is quoted (csv.Writer.fieldNeedsQuotes)
+__device__ __forceinline__ uint64_t csv_field_len(const DevCol& col, uint64_t begin, uint64_t len, bool* quoted) {
+    *quoted = false;
+    if (len == 0) return 0;
+    uint64_t chunk = 0, nquote = 0;
+    bool need = false;
+    for (uint64_t q = 0; q < len; q++) {
+        if ((q & 7) == 0) {
+            chunk = load_value_chunk(col.data, begin, len, (int)(q >> 3));
+            if (q == 0) {
+                need = first_rune_is_space(chunk, len);
+                if (len == 2 && (chunk & 0xFFFF) == (uint64_t)('\\' | ('.' << 8))) need = true;   // the field `\.`
+            }
+        }
+        const uint32_t c = (uint32_t)(chunk >> (8 * (q & 7))) & 0xFF;
+        if (c == '"') { nquote++; need = true; }
+        else if (c == ',' || c == '\r' || c == '\n') need = true;
+    }
+    *quoted = need;
+    return need ? len + 2 + nquote : len;
+}
+
+template <class Sink>
+__device__ __forceinline__ void csv_put_field(Sink& out, const DevCol& col, uint64_t begin, uint64_t len, bool quoted) {
+    if (!quoted) { copy_value(out, col, begin, len); return; }
+    out.put('"');
+    uint64_t chunk = 0;
+    for (uint64_t q = 0; q < len; q++) {
+        if ((q & 7) == 0) chunk = load_value_chunk(col.data, begin, len, (int)(q >> 3));
+        const uint8_t c = (uint8_t)(chunk >> (8 * (q & 7)));
+        if (c == '"') out.put('"');
+        out.put(c);
+    }
+    out.put('"');
+}
+
+__global__ __launch_bounds__(kMatThreads) void k_csv_lens(ColsArg cols, int ncols, uint64_t n, uint64_t* __restrict__ lens) {
+    const uint64_t stride = (uint64_t)gridDim.x * kMatThreads;
+    for (uint64_t i = (uint64_t)blockIdx.x * kMatThreads + threadIdx.x; i < n; i += stride) {
+        uint64_t total = (uint64_t)ncols;   // ncols-1 commas + '\n'
+        for (int c = 0; c < ncols; c++) {
+            uint64_t b, l;
+            bool q;
+            value_span(cols.c[c], i, &b, &l);
+            total += csv_field_len(cols.c[c], b, l, &q);
+        }
+        lens[i] = total;
+    }
+}
+
+template <class Sink>
+__device__ __forceinline__ void csv_put_record(Sink& s, const ColsArg& cols, int ncols, uint64_t row) {
+    for (int c = 0; c < ncols; c++) {
+        uint64_t b, l;
+        bool q;
+        value_span(cols.c[c], row, &b, &l);
+        csv_field_len(cols.c[c], b, l, &q);
+        if (c) s.put(',');
+        csv_put_field(s, cols.c[c], b, l, q);
+    }
+    s.put('\n');
+}
+
+__global__ __launch_bounds__(kMatThreads) void k_csv_copy(ColsArg cols, int ncols, uint64_t n,
+                                                         const uint64_t* __restrict__ offs, uint8_t* __restrict__ out,
+                                                         uint64_t out_base) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    CPH_LDS uint8_t* stage = (CPH_LDS uint8_t*)smem;
+    for (uint64_t t0 = (uint64_t)blockIdx.x * kMatThreads; t0 < n; t0 += (uint64_t)gridDim.x * kMatThreads) {
+        const uint64_t tend = t0 + kMatThreads < n ? t0 + kMatThreads : n;
+        const uint64_t obase = out_base + offs[t0];
+        const uint64_t span = offs[tend] - offs[t0];
+        const uint64_t i = t0 + threadIdx.x;
+        if (span + 16 <= (uint64_t)kMatStage) {
+            if (i < tend) {
+                LdsSink s{stage + (offs[i] - offs[t0]) + (obase & 15)};
+                csv_put_record(s, cols, ncols, i);
+            }
+            __syncthreads();
+            flush_stage(stage, out, obase, span);
+            __syncthreads();
+        } else if (i < tend) {
+            GlobalSink s{out + out_base + offs[i]};
+            csv_put_record(s, cols, ncols, i);
+        }
+    }
+}
+
+static unsigned grid_rows(uint64_t n) {
+    uint64_t b = (n + kMatThreads - 1) / kMatThreads;
+    if (b > 4096) b = 4096;
+    return (unsigned)(b ? b : 1);
+}
+
+// lens[n] -> offs[n+1] in place (offs[n] = total), total also read back
+static Status scan_lengths(cph_ctx* ctx, uint64_t* lens, uint64_t n, uint64_t* total) {
+    CPH_TRY(exclusive_scan_u64(ctx, lens, n, lens + n));
+    CPH_TRY(ensure_pinned_scratch(ctx, sizeof(uint64_t)));
+    CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, lens + n, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *total = *reinterpret_cast<const uint64_t*>(ctx->pinned_scratch);
+    return {};
+}
+
+// host restatement of the Writer's quoting for the header line (tiny; runs on the host)
+static void csv_append_field_host(std::string* out, const uint8_t* p, uint64_t len) {
+    bool need = false;
+    if (len) {
+        const uint32_t b0 = p[0], b1 = len > 1 ? p[1] : 0, b2 = len > 2 ? p[2] : 0;
+        if (b0 < 0x80) need = b0 == ' ' || (b0 >= 9 && b0 <= 13);
+        else if (b0 == 0xC2 && len >= 2) need = b1 == 0x85 || b1 == 0xA0;
+        else if (len >= 3) {
+            if (b0 == 0xE1) need = b1 == 0x9A && b2 == 0x80;
+            else if (b0 == 0xE2) need = b1 == 0x80 ? ((b2 >= 0x80 && b2 <= 0x8A) || b2 == 0xA8 || b2 == 0xA9 || b2 == 0xAF)
+                                                  : (b1 == 0x81 && b2 == 0x9F);
+            else need = b0 == 0xE3 && b1 == 0x80 && b2 == 0x80;
+        }
+        if (len == 2 && p[0] == '\\' && p[1] == '.') need = true;
+        for (uint64_t i = 0; i < len; i++) need |= p[i] == '"' || p[i] == ',' || p[i] == '\r' || p[i] == '\n';
+    }
+    if (!need) { out->append(reinterpret_cast<const char*>(p), (size_t)len); return; }
+    out->push_back('"');
+    for (uint64_t i = 0; i < len; i++) {
+        if (p[i] == '"') out->push_back('"');
+        out->push_back((char)p[i]);
+    }
+    out->push_back('"');
+}
+
+}  // namespace cph
+
+using namespace cph;
+
+struct cph_colbuf_impl {
+    cph_colbuf pub;   // first
+    cph_ctx* ctx = nullptr;
+    DevBuf d_data, d_offs;
+    void* h_block = nullptr;
+};
+struct cph_bytes_impl {
+    cph_bytes pub;    // first
+    cph_ctx* ctx = nullptr;
+    DevBuf d_data;
+    void* h_block = nullptr;
+};
+
+static int32_t mat_fail(cph_ctx* ctx, const Status& s) {
+    if (ctx) ctx->err = s.msg;
+    return s.code;
+}
+
+extern "C" {
+
+CPH_API int32_t cph_gather_rows(cph_ctx* ctx, const cph_strcol* col, const void* row_ids, int32_t id_bits, uint64_t id_base,
+                                uint64_t nrows, int32_t out_mem, cph_colbuf** out) {
+    if (!ctx || !col || !out) return CPH_ERR_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess) return mat_fail(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});
+    *out = nullptr;
+    if (row_ids && id_bits != 32 && id_bits != 64) return mat_fail(ctx, {CPH_ERR_INVALID, "id_bits must be 32 or 64"});
+    if (out_mem != CPH_MEM_HOST && out_mem != CPH_MEM_DEVICE) return mat_fail(ctx, {CPH_ERR_INVALID, "bad out_mem"});
+    Status s = validate_cols(col, 1);
+    if (!s.ok()) return mat_fail(ctx, s);
+    const uint64_t n = row_ids ? nrows : col->nrows;
+    auto* r = new (std::nothrow) cph_colbuf_impl();
+    if (!r) return mat_fail(ctx, {CPH_ERR_NOMEM, "out of host memory"});
+    r->ctx = ctx;
+    auto run = [&]() -> Status {
+        std::vector<DevBuf> staged;
+        DevCol d;
+        CPH_TRY(stage_cols(ctx, col, 1, &staged, &d));
+        RowIds ids;
+        ids.bits = id_bits;
+        ids.base = id_base;
+        DevBuf idbuf;
+        if (row_ids && n) {
+            if (col->mem == CPH_MEM_HOST) {   // ids live where the column lives
+                const size_t b = n * (size_t)(id_bits / 8);
+                CPH_TRY(idbuf.alloc(&ctx->pool, b));
+                CPH_HIP_TRY(hipMemcpyAsync(idbuf.get(), row_ids, b, hipMemcpyHostToDevice, ctx->stream));
+                ids.ptr = idbuf.get();
+            } else {
+                ids.ptr = row_ids;
+            }
+        }
+        CPH_TRY(r->d_offs.alloc(&ctx->pool, (n + 1) * sizeof(uint64_t)));
+        uint64_t* offs = r->d_offs.as<uint64_t>();
+        uint64_t total = 0;
+        if (n) {
+            {
+                ProfScope ps(ctx, "k_gather_lens", 0);
+                hipLaunchKernelGGL(k_gather_lens, dim3(grid_rows(n)), dim3(kMatThreads), 0, ctx->stream, d, ids, n, offs);
+            }
+            CPH_HIP_TRY(hipGetLastError());
+            CPH_TRY(scan_lengths(ctx, offs, n, &total));
+        } else {
+            CPH_HIP_TRY(hipMemsetAsync(offs, 0, sizeof(uint64_t), ctx->stream));
+        }
+        CPH_TRY(r->d_data.alloc(&ctx->pool, total + 16));
+        if (n && total) {
+            ProfScope ps(ctx, "k_gather_copy", 2.0 * (double)total + 16.0 * (double)n);
+            hipLaunchKernelGGL(k_gather_copy, dim3(grid_rows(n)), dim3(kMatThreads), kMatStage, ctx->stream, d, ids, n, offs,
+                               r->d_data.as<uint8_t>());
+            CPH_HIP_TRY(hipGetLastError());
+        }
+        r->pub.nbytes = total;
+        r->pub.col.nrows = n;
+        r->pub.col.offset_bits = 64;
+        r->pub.col.mem = out_mem;
+        r->pub.col.fixed_width = 0;
+        if (out_mem == CPH_MEM_DEVICE) {
+            r->pub.col.data = r->d_data.as<uint8_t>();
+            r->pub.col.offsets = offs;
+            CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        } else {
+            const size_t ob = (n + 1) * sizeof(uint64_t);
+            CPH_HIP_TRY(hipHostMalloc(&r->h_block, ob + total + 16, hipHostMallocDefault));
+            uint8_t* h = static_cast<uint8_t*>(r->h_block);
+            CPH_HIP_TRY(hipMemcpyAsync(h, offs, ob, hipMemcpyDeviceToHost, ctx->stream));
+            if (total) CPH_HIP_TRY(hipMemcpyAsync(h + ob, r->d_data.get(), total, hipMemcpyDeviceToHost, ctx->stream));
+            CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+            r->pub.col.offsets = h;
+            r->pub.col.data = h + ob;
+            r->d_data.reset();
+            r->d_offs.reset();
+        }
+        return {};
+    };
+    s = run();
+    if (!s.ok()) {
+        if (r->h_block) (void)hipHostFree(r->h_block);
+        delete r;
+        return mat_fail(ctx, s);
+    }
+    *out = &r->pub;
+    return CPH_OK;
+}
+
+CPH_API void cph_colbuf_release(cph_colbuf* pub) {
+    if (!pub) return;
+    auto* r = reinterpret_cast<cph_colbuf_impl*>(pub);
+    if (r->ctx) (void)hipSetDevice(r->ctx->device);
+    if (r->h_block) (void)hipHostFree(r->h_block);
+    delete r;
+}
+
+CPH_API int32_t cph_csv_write(cph_ctx* ctx, const cph_strcol* cols, int32_t ncols, const cph_strval* header, int32_t out_mem,
+                              cph_bytes** out) {
+    if (!ctx || !cols || !out) return CPH_ERR_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess) return mat_fail(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});
+    *out = nullptr;
+    if (out_mem != CPH_MEM_HOST && out_mem != CPH_MEM_DEVICE) return mat_fail(ctx, {CPH_ERR_INVALID, "bad out_mem"});
+    Status s = validate_cols(cols, ncols);
+    if (!s.ok()) return mat_fail(ctx, s);
+    const uint64_t n = cols[0].nrows;
+    auto* r = new (std::nothrow) cph_bytes_impl();
+    if (!r) return mat_fail(ctx, {CPH_ERR_NOMEM, "out of host memory"});
+    r->ctx = ctx;
+    auto run = [&]() -> Status {
+        std::string head;
+        if (header) {
+            for (int c = 0; c < ncols; c++) {
+                if (c) head.push_back(',');
+                csv_append_field_host(&head, header[c].data, header[c].len);
+            }
+            head.push_back('\n');
+        }
+        std::vector<DevBuf> staged;
+        ColsArg arg{};
+        CPH_TRY(stage_cols(ctx, cols, ncols, &staged, arg.c));
+        DevBuf offs;
+        CPH_TRY(offs.alloc(&ctx->pool, (n + 1) * sizeof(uint64_t)));
+        uint64_t total = 0;
+        if (n) {
+            {
+                ProfScope ps(ctx, "k_csv_lens", 0);
+                hipLaunchKernelGGL(k_csv_lens, dim3(grid_rows(n)), dim3(kMatThreads), 0, ctx->stream, arg, ncols, n,
+                                   offs.as<uint64_t>());
+            }
+            CPH_HIP_TRY(hipGetLastError());
+            CPH_TRY(scan_lengths(ctx, offs.as<uint64_t>(), n, &total));
+        }
+        const uint64_t size = head.size() + total;
+        CPH_TRY(r->d_data.alloc(&ctx->pool, size + 16));
+        if (!head.empty()) {
+            void* slot = nullptr;
+            CPH_TRY(pinned_upload(ctx, head.size(), &slot));
+            memcpy(slot, head.data(), head.size());
+            CPH_HIP_TRY(hipMemcpyAsync(r->d_data.get(), slot, head.size(), hipMemcpyHostToDevice, ctx->stream));
+        }
+        if (n) {
+            ProfScope ps(ctx, "k_csv_copy", 2.0 * (double)total + 8.0 * (double)n);
+            hipLaunchKernelGGL(k_csv_copy, dim3(grid_rows(n)), dim3(kMatThreads), kMatStage, ctx->stream, arg, ncols, n,
+                               offs.as<uint64_t>(), r->d_data.as<uint8_t>(), (uint64_t)head.size());
+            CPH_HIP_TRY(hipGetLastError());
+        }
+        r->pub.size = size;
+        r->pub.mem = out_mem;
+        if (out_mem == CPH_MEM_DEVICE) {
+            r->pub.data = r->d_data.as<uint8_t>();
+            CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        } else {
+            CPH_HIP_TRY(hipHostMalloc(&r->h_block, size + 16, hipHostMallocDefault));
+            if (size) CPH_HIP_TRY(hipMemcpyAsync(r->h_block, r->d_data.get(), size, hipMemcpyDeviceToHost, ctx->stream));
+            CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+            r->pub.data = static_cast<const uint8_t*>(r->h_block);
+            r->d_data.reset();
+        }
+        return {};
+    };
+    s = run();
+    if (!s.ok()) {
+        if (r->h_block) (void)hipHostFree(r->h_block);
+        delete r;
+        return mat_fail(ctx, s);
+    }
+    *out = &r->pub;
+    return CPH_OK;
+}
+
+CPH_API void cph_bytes_release(cph_bytes* pub) {
+    if (!pub) return;
+    auto* r = reinterpret_cast<cph_bytes_impl*>(pub);
+    if (r->ctx) (void)hipSetDevice(r->ctx->device);
+    if (r->h_block) (void)hipHostFree(r->h_block);
+    delete r;
+}
+
+}  // extern "C"

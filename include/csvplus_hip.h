@@ -278,6 +278,47 @@ CPH_API int32_t cph_stream_join_pending(const cph_stream_join* sj);
  * pipeline, valid until `nslots` further chunks have been submitted. */
 CPH_API int32_t cph_stream_join_next(cph_stream_join* sj, cph_stream_chunk* out);
 
+/* ---- materialisation: the step after the path ------------------ */
+
+/* A library-owned string column (64-bit offsets) living in col.mem. */
+typedef struct {
+    cph_strcol col;
+    uint64_t   nbytes;      /* total value bytes */
+} cph_colbuf;
+
+/* A library-owned byte buffer. */
+typedef struct {
+    const uint8_t* data;
+    uint64_t       size;
+    int32_t        mem;
+    int32_t        reserved_;
+} cph_bytes;
+
+/*
+ * out[i] = col[row_ids[i] - id_base] for i < nrows (row_ids == NULL: a plain copy of
+ * the column).  This is mergeRows (csvplus.go:571-583) column by column: a joined
+ * table consists of the stream's columns (gathered through stream_row / probe_idx,
+ * or used as they are when that is the identity) and of every index's columns
+ * gathered through build_row; on a column-name collision the caller keeps the
+ * stream's column (the stream value wins, :578-580).  row_ids are uint32
+ * (id_bits 32) or uint64 (64) and live in the same memory space as the column.
+ */
+CPH_API int32_t cph_gather_rows(cph_ctx* ctx, const cph_strcol* col, const void* row_ids, int32_t id_bits,
+                                uint64_t id_base, uint64_t nrows, int32_t out_mem, cph_colbuf** out);
+CPH_API void    cph_colbuf_release(cph_colbuf* c);
+
+/*
+ * ToCsv (csvplus.go:379-406): the canonical serialisation — a header line (when
+ * `header` != NULL: ncols names) and one record per row with the columns in the
+ * given order, formatted as Go's encoding/csv Writer does with default settings
+ * (',' separator, '\n' record end; a field is quoted iff it is `\.`, contains
+ * ',', '"', '\r' or '\n', or starts with a Unicode space; '"' is doubled inside
+ * quotes).  All columns must have the same number of rows.
+ */
+CPH_API int32_t cph_csv_write(cph_ctx* ctx, const cph_strcol* cols, int32_t ncols, const cph_strval* header,
+                              int32_t out_mem, cph_bytes** out);
+CPH_API void    cph_bytes_release(cph_bytes* b);
+
 /* ---- Find / SubIndex bounds (csvplus.go:870-891) ----------------------------- */
 
 /* [*lower, *upper) = sorted positions whose leading key columns equal

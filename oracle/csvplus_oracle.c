@@ -438,3 +438,73 @@ ORC_API uint64_t orc_fnv1a64(const void* p, uint64_t nbytes, uint64_t h) {
     for (uint64_t i = 0; i < nbytes; i++) { h ^= b[i]; h *= 0x100000001B3ull; }
     return h;
 }
+
+/* ---- ToCsv (:379-406) through Go's encoding/csv Writer, default settings ---------------------
+ * The Writer lives in the Go standard library (not under /root/reference); restated from its
+ * documented behaviour and source as remembered (go1.19+ encoding/csv/writer.go):
+ *   fieldNeedsQuotes(field): "" -> false; `\.` -> true; contains Comma, '"', '\r' or '\n' -> true;
+ *                            otherwise unicode.IsSpace(first rune).
+ *   quoted field: '"' + field with every '"' doubled + '"'   (UseCRLF = false: '\r', '\n' verbatim)
+ *   record: fields joined by Comma (','), terminated by '\n'.
+ * Parity of this restatement is additionally cross-checked against Python's csv module on the
+ * subset where both agree (tests/test_oracle.py).                                              */
+static int go_unicode_is_space_first_rune(const uint8_t* p, uint64_t len) {
+    if (!len) return 0;
+    uint32_t b0 = p[0], b1 = len > 1 ? p[1] : 0, b2 = len > 2 ? p[2] : 0;
+    if (b0 < 0x80) return b0 == ' ' || (b0 >= 9 && b0 <= 13);
+    if (b0 == 0xC2 && len >= 2) return b1 == 0x85 || b1 == 0xA0;
+    if (len < 3) return 0;
+    if (b0 == 0xE1) return b1 == 0x9A && b2 == 0x80;
+    if (b0 == 0xE2) {
+        if (b1 == 0x80) return (b2 >= 0x80 && b2 <= 0x8A) || b2 == 0xA8 || b2 == 0xA9 || b2 == 0xAF;
+        return b1 == 0x81 && b2 == 0x9F;
+    }
+    return b0 == 0xE3 && b1 == 0x80 && b2 == 0x80;
+}
+static int go_csv_field_needs_quotes(const uint8_t* p, uint64_t len) {
+    if (len == 0) return 0;
+    if (len == 2 && p[0] == '\\' && p[1] == '.') return 1;
+    for (uint64_t i = 0; i < len; i++)
+        if (p[i] == ',' || p[i] == '"' || p[i] == '\r' || p[i] == '\n') return 1;
+    return go_unicode_is_space_first_rune(p, len);
+}
+static uint64_t go_csv_put_field(uint8_t* out, uint64_t pos, uint64_t cap, const uint8_t* p, uint64_t len) {
+#define PUT(b) do { if (out && pos < cap) out[pos] = (uint8_t)(b); pos++; } while (0)
+    if (!go_csv_field_needs_quotes(p, len)) {
+        for (uint64_t i = 0; i < len; i++) PUT(p[i]);
+        return pos;
+    }
+    PUT('"');
+    for (uint64_t i = 0; i < len; i++) {
+        if (p[i] == '"') PUT('"');
+        PUT(p[i]);
+    }
+    PUT('"');
+    return pos;
+#undef PUT
+}
+/* Writes header (if nheader > 0) + all rows; returns the total size (call with out=NULL to size). */
+ORC_API uint64_t orc_csv_write(const orc_strcol* cols, int32_t ncols, const orc_strval* header, uint8_t* out, uint64_t cap) {
+    uint64_t pos = 0;
+    if (header) {
+        for (int32_t c = 0; c < ncols; c++) {
+            if (c) { if (out && pos < cap) out[pos] = ','; pos++; }
+            pos = go_csv_put_field(out, pos, cap, header[c].data, header[c].len);
+        }
+        if (out && pos < cap) out[pos] = '\n';
+        pos++;
+    }
+    const uint64_t n = cols[0].nrows;
+    for (uint64_t r = 0; r < n; r++) {
+        for (int32_t c = 0; c < ncols; c++) {
+            const uint8_t* p;
+            uint64_t len;
+            col_value(&cols[c], r, &p, &len);
+            if (c) { if (out && pos < cap) out[pos] = ','; pos++; }
+            pos = go_csv_put_field(out, pos, cap, p, len);
+        }
+        if (out && pos < cap) out[pos] = '\n';
+        pos++;
+    }
+    return pos;
+}

@@ -142,3 +142,18 @@ class OracleIndex:
 def fnv1a64(arr: np.ndarray, h: int = 0) -> int:
     a = np.ascontiguousarray(arr)
     return int(_load().orc_fnv1a64(a.ctypes.data, a.nbytes, h))
+
+
+def csv_write(cols, header=None) -> bytes:
+    """ToCsv (csvplus.go:379-406): header + rows through Go's csv.Writer rules (C restatement)."""
+    lib = _load()
+    if not hasattr(lib, "_csv_ready"):
+        lib.orc_csv_write.restype = C.c_uint64
+        lib.orc_csv_write.argtypes = [C.POINTER(orc_strcol), C.c_int32, C.POINTER(orc_strval), C.c_void_p, C.c_uint64]
+        lib._csv_ready = True
+    arr, keep = _cols(cols)
+    hv, hk = (_vals(header) if header is not None else (None, None))
+    size = int(lib.orc_csv_write(arr, len(cols), hv, None, 0))
+    buf = np.empty(size, dtype=np.uint8)
+    lib.orc_csv_write(arr, len(cols), hv, buf.ctypes.data, size)
+    return buf.tobytes()

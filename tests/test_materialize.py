@@ -1,0 +1,112 @@
+"""The step after the path: cph_gather_rows (column-wise mergeRows, csvplus.go:571-583) and
+cph_csv_write (ToCsv, csvplus.go:379-406) against the oracle's C restatement of Go's csv.Writer."""
+import csv
+import io
+
+import numpy as np
+import pytest
+
+from csvplus_amd import DeviceIndex, StrCol, datagen as dg, join_chain
+from oracle import orc
+
+NASTY = [b"", b"plain", b"a,b", b'q"uote', b'""', b"line\nbreak", b"cr\rhere", b" lead", b"trail ", b"\ttab", b"\\.", b"\\..",
+         "\u00a0nbsp".encode(), "\u2003em".encode(), "\u3000cjk".encode(), "é".encode(), b"\xc2", b"\xe2\x80", b"\xff\xfe",
+         b"x" * 100, b'"', b",", b"\n", b"1234567", b"12345678", b"123456789"]
+
+
+def table(rng, n, ncols):
+    return [[NASTY[i] for i in rng.integers(0, len(NASTY), n)] for _ in range(ncols)]
+
+
+# ---- CPU: pin the oracle's Writer restatement --------------------------------------------------------
+def test_oracle_csv_known_answers():
+    """Hand-checked records: what Go's csv.Writer produces for these fields (quoting rules of
+    encoding/csv: `\\.`, separator, quote, CR/LF, leading space)."""
+    cols = [StrCol.from_values(["a", "1,2", "\\.", "plain", ""]),
+            StrCol.from_values(["b c", 'q"uote', "line\nbreak", "\ttab", " "])]
+    out = orc.csv_write(cols, ["h1", "h,2"])
+    assert out == b'h1,"h,2"\na,b c\n"1,2","q""uote"\n"\\.","line\nbreak"\nplain,"\ttab"\n," "\n'
+    assert orc.csv_write(cols) == out.split(b"\n", 1)[1]
+
+
+def test_oracle_csv_agrees_with_python_csv_on_common_subset():
+    """Python's csv (QUOTE_MINIMAL, \\n terminator) and Go's Writer agree when no field starts with a
+    space character and none equals `\\.`."""
+    rng = np.random.default_rng(0)
+    safe = [v for v in NASTY if v[:1] not in (b" ", b"\t", b"\n", b"\r", b"\xc2", b"\xe2", b"\xe3") and v != b"\\."
+            and b"\r" not in v and all(c < 0x80 for c in v)]
+    rows = [[safe[i].decode() for i in rng.integers(0, len(safe), 3)] for _ in range(300)]
+    cols = [StrCol.from_values([r[c] for r in rows]) for c in range(3)]
+    s = io.StringIO()
+    w = csv.writer(s, lineterminator="\n")
+    w.writerow(["x", "y", "z"])
+    w.writerows(rows)
+    # Python quotes an empty single-field record; with 3 fields the outputs coincide
+    assert orc.csv_write(cols, ["x", "y", "z"]).decode() == s.getvalue()
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [0, 1, 255, 256, 257, 5000])
+def test_gather_rows_matches_numpy_take(ctx, n):
+    from csvplus_amd.materialize import gather_rows
+
+    rng = np.random.default_rng(n)
+    vals = table(rng, 777, 1)[0]
+    col = StrCol.from_values(vals)
+    ids = rng.integers(0, len(vals), n)
+    for dtype, base in ((np.uint32, 0), (np.uint64, 1000)):
+        g = gather_rows(ctx, col, (ids + base).astype(dtype), id_base=base)
+        assert g.values() == [vals[i] for i in ids]
+    assert gather_rows(ctx, col).values() == vals     # identity copy
+    big = StrCol.from_values([b"y" * 500] * 300)       # tiles beyond the LDS stage: direct byte path
+    assert gather_rows(ctx, big, np.arange(299, -1, -1, dtype=np.uint32)).values() == [b"y" * 500] * 300
+    fixed = dg.customers(1000)["id"]
+    assert fixed.fixed_width == 8
+    assert gather_rows(ctx, fixed, ids[:100].astype(np.uint32) % 1000).values() == [fixed.value(int(i) % 1000) for i in ids[:100]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,ncols", [(0, 2), (1, 1), (300, 3), (4000, 4)])
+def test_csv_write_matches_oracle(ctx, n, ncols):
+    from csvplus_amd.materialize import csv_write
+
+    rng = np.random.default_rng(n + ncols)
+    cols = [StrCol.from_values(c) for c in table(rng, n, ncols)]
+    header = ["id", "na,me", " x", 'q"'][:ncols]
+    assert csv_write(ctx, cols, header) == orc.csv_write(cols, header)
+    assert csv_write(ctx, cols) == orc.csv_write(cols)
+    dcols = [c.to_device() for c in cols]
+    assert csv_write(ctx, dcols, header) == orc.csv_write(cols, header)
+
+
+@pytest.mark.gpu
+def test_joined_table_to_csv_end_to_end(ctx):
+    """orders JOIN customers JOIN products -> gather -> ToCsv, all on the device, against the oracle join
+    materialised on the host with mergeRows semantics (stream wins on a collision: none here)."""
+    from csvplus_amd.materialize import csv_write, gather_rows
+
+    nc, npd, m = 3000, 40, 20_000
+    cust, prod = dg.customers(nc, encoding=dg.ITOA), dg.products(npd)
+    ords = dg.orders(m, nc + 500, npd, cust_encoding=dg.ITOA)      # some customers are missing
+    gi = [DeviceIndex(ctx, [cust["id"]], unique=True), DeviceIndex(ctx, [prod["prod_id"]], unique=True)]
+    ch = join_chain(ctx, [(gi[0], [ords["cust_id"]]), (gi[1], [ords["prod_id"]])])
+    s, a, b = ch.stream_row, ch.build_row(0), ch.build_row(1)
+    assert 0 < ch.nrows < m
+    out_cols = [gather_rows(ctx, ords["cust_id"], s), gather_rows(ctx, ords["qty"], s),
+                gather_rows(ctx, cust["name"], a), gather_rows(ctx, cust["surname"], a),
+                gather_rows(ctx, prod["product"], b), gather_rows(ctx, prod["price"], b)]
+    header = ["cust_id", "qty", "name", "surname", "product", "price"]
+    got = csv_write(ctx, out_cols, header)
+    # oracle: nested joins + host-side materialisation
+    oi = [orc.OracleIndex([cust["id"]]), orc.OracleIndex([prod["prod_id"]])]
+    j1 = oi[0].join([ords["cust_id"]])
+    j2 = oi[1].join([ords["prod_id"]], row_sel=j1["probe_idx"].astype(np.uint32))
+    pick = j2["probe_idx"].astype(np.int64)
+    es, ea, eb = j1["probe_idx"][pick], j1["build_row"][pick], j2["build_row"]
+    lines = [",".join(header)]
+    for r, x, y in zip(es, ea, eb):
+        lines.append(",".join([ords["cust_id"].value(int(r)).decode(), ords["qty"].value(int(r)).decode(),
+                               cust["name"].value(int(x)).decode(), cust["surname"].value(int(x)).decode(),
+                               prod["product"].value(int(y)).decode(), prod["price"].value(int(y)).decode()]))
+    assert got.decode() == "\n".join(lines) + "\n"

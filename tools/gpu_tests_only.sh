@@ -1,0 +1,3 @@
+#!/bin/bash
+export TMPDIR=/tmp
+timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -15
