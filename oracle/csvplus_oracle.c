@@ -508,3 +508,176 @@ ORC_API uint64_t orc_csv_write(const orc_strcol* cols, int32_t ncols, const orc_
     }
     return pos;
 }
+
+/* ---- CSV ingest: Go's encoding/csv Reader as configured by csvplus's Reader.Iterate
+ * (csvplus.go:1080-1146: Comma, Comment, TrimLeadingSpace, FieldsPerRecord; LazyQuotes not
+ * supported here), followed by the column selection of :1117-1131 (row[name] = line[index];
+ * a missing field is "" when numFields < 0).  The Reader lives in the Go standard library (not
+ * under /root/reference); restated from its documentation and source as remembered (go1.19+
+ * encoding/csv/reader.go, readRecord/readLine):
+ *   - input is consumed line by line; "\r\n" at a line end becomes "\n", a final "\r" at EOF is dropped
+ *   - a line that is empty, or starts with the Comment rune, is skipped (only between records)
+ *   - unquoted field: up to the next Comma; a '"' inside it is ErrBareQuote
+ *   - quoted field: "" is a literal quote; the closing quote must be followed by Comma or the end
+ *     of the line (else ErrQuote); it may span lines; EOF inside it is ErrQuote
+ *   - FieldsPerRecord 0: every record must have as many fields as the first one; > 0: exactly
+ *     that many; < 0: no check (ErrFieldCount otherwise)
+ * Output: for `ncols` requested field indices, the values of the records after the first
+ * `skip_records` ones, as SoA (two calls: sizes, then fill).                                   */
+enum { ORC_CSV_OK = 0, ORC_CSV_ERR_BARE_QUOTE = 1, ORC_CSV_ERR_QUOTE = 2, ORC_CSV_ERR_FIELD_COUNT = 3 };
+
+typedef struct {
+    uint8_t comma, comment;          /* comment 0 = none */
+    int32_t trim_leading_space;
+    int32_t fields_per_record;       /* Go semantics */
+    uint64_t skip_records;
+} orc_csv_opts;
+
+typedef struct {
+    const uint8_t* d;
+    uint64_t size, pos;
+    /* current line (normalised): bytes [lb, le) of d, followed by a virtual '\n' if has_nl */
+    uint64_t lb, le;
+    int has_nl, eof;
+} csv_lines;
+
+static int csv_read_line(csv_lines* L) {   /* returns 0 at EOF (no more bytes) */
+    if (L->pos >= L->size) { L->eof = 1; return 0; }
+    uint64_t b = L->pos, e = b;
+    while (e < L->size && L->d[e] != '\n') e++;
+    L->has_nl = e < L->size;
+    L->pos = L->has_nl ? e + 1 : e;
+    if (L->has_nl) { if (e > b && L->d[e - 1] == '\r') e--; }        /* "\r\n" -> "\n" */
+    else if (e > b && L->d[e - 1] == '\r') e--;                       /* final "\r" at EOF dropped */
+    L->lb = b;
+    L->le = e;
+    return 1;
+}
+
+static uint64_t csv_trim_left(const uint8_t* d, uint64_t p, uint64_t e) {
+    while (p < e) {
+        if (!go_unicode_is_space_first_rune(d + p, e - p)) break;
+        uint8_t b0 = d[p];
+        p += b0 < 0x80 ? 1 : (b0 < 0xE0 ? 2 : 3);
+    }
+    return p;
+}
+
+/* sink: bytes of requested columns */
+typedef struct {
+    int32_t ncols;
+    const int32_t* col_index;
+    uint64_t* lens;        /* [ncols] running length of the current field (size pass) */
+    uint8_t** out;         /* [ncols] write cursors (fill pass) or NULL */
+} csv_sink;
+
+static inline void sink_put(csv_sink* s, int field, uint8_t b) {
+    for (int32_t c = 0; c < s->ncols; c++)
+        if (s->col_index[c] == field) {
+            if (s->out) *s->out[c]++ = b;
+            s->lens[c]++;
+        }
+}
+
+/* Reads one record; returns number of fields, or -1 at EOF; *err = kind. */
+static int csv_read_record(csv_lines* L, const orc_csv_opts* o, csv_sink* s, int* err) {
+    *err = 0;
+    for (;;) {   /* skip empty and comment lines */
+        if (!csv_read_line(L)) return -1;
+        if (o->comment && L->le > L->lb && L->d[L->lb] == o->comment) continue;
+        if (L->le == L->lb) continue;
+        break;
+    }
+    const uint8_t* d = L->d;
+    uint64_t p = L->lb;
+    int field = 0;
+    for (;;) {
+        if (o->trim_leading_space) p = csv_trim_left(d, p, L->le);
+        if (p >= L->le || d[p] != '"') {   /* unquoted */
+            uint64_t i = p;
+            while (i < L->le && d[i] != o->comma) {
+                if (d[i] == '"' && !*err) *err = ORC_CSV_ERR_BARE_QUOTE;
+                i++;
+            }
+            if (*err) return field + 1;
+            for (uint64_t k = p; k < i; k++) sink_put(s, field, d[k]);
+            field++;
+            if (i < L->le) { p = i + 1; continue; }
+            return field;
+        }
+        p++;   /* quoted */
+        for (;;) {
+            uint64_t i = p;
+            while (i < L->le && d[i] != '"') i++;
+            for (uint64_t k = p; k < i; k++) sink_put(s, field, d[k]);
+            if (i < L->le) {   /* a quote */
+                p = i + 1;
+                if (p < L->le && d[p] == '"') { sink_put(s, field, '"'); p++; continue; }
+                if (p < L->le && d[p] == o->comma) { p++; field++; break; }
+                if (p == L->le) return field + 1;              /* closing quote at the end of the line */
+                *err = ORC_CSV_ERR_QUOTE;
+                return field + 1;
+            }
+            /* end of line inside the quoted field */
+            if (L->has_nl) sink_put(s, field, '\n');
+            if (!csv_read_line(L)) { *err = ORC_CSV_ERR_QUOTE; return field + 1; }   /* EOF inside quotes */
+            p = L->lb;
+        }
+    }
+}
+
+/* Pass 1 (data == NULL in outs): returns the number of output records, fills col_bytes[ncols].
+ * Pass 2: fills data/offsets (offsets: nrecords+1 uint64 per column).
+ * On a parse error *err_kind != 0 and *err_record = 0-based index of the offending record (counting
+ * every record read, header included); records before it are still produced. */
+ORC_API uint64_t orc_csv_parse(const uint8_t* data, uint64_t size, const orc_csv_opts* o, const int32_t* col_index, int32_t ncols,
+                               uint64_t* col_bytes, uint8_t** out_data, uint64_t** out_offsets, int32_t* err_kind,
+                               uint64_t* err_record) {
+    csv_lines L = {data, size, 0, 0, 0, 0, 0};
+    uint64_t lens[64];
+    uint8_t* cursors[64];
+    uint64_t totals[64];
+    csv_sink s = {ncols, col_index, lens, NULL};
+    if (out_data) {
+        for (int32_t c = 0; c < ncols; c++) cursors[c] = out_data[c];
+        s.out = cursors;
+    }
+    for (int32_t c = 0; c < ncols; c++) totals[c] = 0;
+    *err_kind = 0;
+    *err_record = 0;
+    uint64_t rec = 0, nout = 0;
+    int expected = o->fields_per_record;
+    for (;;) {
+        for (int32_t c = 0; c < ncols; c++) lens[c] = 0;
+        uint8_t* save[64];
+        if (s.out) for (int32_t c = 0; c < ncols; c++) save[c] = cursors[c];
+        int err = 0;
+        int nf = csv_read_record(&L, o, &s, &err);
+        if (nf < 0) break;
+        if (!err) {
+            if (expected == 0) expected = nf;
+            else if (expected > 0 && nf != expected) err = ORC_CSV_ERR_FIELD_COUNT;
+        }
+        if (err) {
+            if (s.out) for (int32_t c = 0; c < ncols; c++) cursors[c] = save[c];
+            *err_kind = err;
+            *err_record = rec;
+            break;
+        }
+        if (rec >= o->skip_records) {
+            for (int32_t c = 0; c < ncols; c++) {
+                if (out_offsets) out_offsets[c][nout] = totals[c];
+                totals[c] += lens[c];
+            }
+            nout++;
+        } else if (s.out) {
+            for (int32_t c = 0; c < ncols; c++) cursors[c] = save[c];   /* skipped record: drop its bytes */
+        }
+        rec++;
+    }
+    for (int32_t c = 0; c < ncols; c++) {
+        if (out_offsets) out_offsets[c][nout] = totals[c];
+        if (col_bytes) col_bytes[c] = totals[c];
+    }
+    return nout;
+}

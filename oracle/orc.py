@@ -157,3 +157,38 @@ def csv_write(cols, header=None) -> bytes:
     buf = np.empty(size, dtype=np.uint8)
     lib.orc_csv_write(arr, len(cols), hv, buf.ctypes.data, size)
     return buf.tobytes()
+
+
+class orc_csv_opts(C.Structure):
+    _fields_ = [("comma", C.c_uint8), ("comment", C.c_uint8), ("trim_leading_space", C.c_int32),
+                ("fields_per_record", C.c_int32), ("skip_records", C.c_uint64)]
+
+
+def csv_parse(data: bytes, col_index, comma=b",", comment=None, trim_leading_space=False, fields_per_record=0,
+              skip_records=0):
+    """Go csv.Reader + csvplus column selection (C restatement).  Returns (columns as lists of bytes,
+    err_kind, err_record)."""
+    from csvplus_amd.columns import StrCol
+
+    lib = _load()
+    if not hasattr(lib, "_csvp_ready"):
+        lib.orc_csv_parse.restype = C.c_uint64
+        lib.orc_csv_parse.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(orc_csv_opts), C.POINTER(C.c_int32), C.c_int32,
+                                      C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                      C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
+        lib._csvp_ready = True
+    buf = np.frombuffer(data, dtype=np.uint8)
+    o = orc_csv_opts(comma[0], comment[0] if comment else 0, 1 if trim_leading_space else 0, fields_per_record, skip_records)
+    nc = len(col_index)
+    idx = (C.c_int32 * nc)(*col_index)
+    nbytes = (C.c_uint64 * nc)()
+    ek, er = C.c_int32(), C.c_uint64()
+    p = buf.ctypes.data if len(buf) else None
+    n = int(lib.orc_csv_parse(p, len(buf), C.byref(o), idx, nc, nbytes, None, None, C.byref(ek), C.byref(er)))
+    datas = [np.empty(int(nbytes[c]) + 1, dtype=np.uint8) for c in range(nc)]
+    offs = [np.empty(n + 1, dtype=np.uint64) for _ in range(nc)]
+    dp = (C.c_void_p * nc)(*[d.ctypes.data for d in datas])
+    op = (C.c_void_p * nc)(*[x.ctypes.data for x in offs])
+    lib.orc_csv_parse(p, len(buf), C.byref(o), idx, nc, nbytes, dp, op, C.byref(ek), C.byref(er))
+    cols = [StrCol(datas[c][: int(nbytes[c])], offs[c], n, 64) for c in range(nc)]
+    return cols, int(ek.value), int(er.value)
