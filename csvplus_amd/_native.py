@@ -118,6 +118,20 @@ class cph_bytes(C.Structure):
     _fields_ = [("data", C.c_void_p), ("size", C.c_uint64), ("mem", C.c_int32), ("reserved_", C.c_int32)]
 
 
+CPH_CSV_ERR_BARE_QUOTE, CPH_CSV_ERR_QUOTE, CPH_CSV_ERR_FIELD_COUNT = 1, 2, 3
+CPH_MAX_KEY_COLS = 16
+
+
+class cph_csv_options(C.Structure):
+    _fields_ = [("comma", C.c_uint8), ("comment", C.c_uint8), ("trim_leading_space", C.c_uint8),
+                ("lazy_quotes", C.c_uint8), ("fields_per_record", C.c_int32), ("skip_records", C.c_uint64)]
+
+
+class cph_csv_table(C.Structure):
+    _fields_ = [("nrecords", C.c_uint64), ("error_record", C.c_uint64), ("error_kind", C.c_int32),
+                ("ncols", C.c_int32), ("cols", cph_strcol * CPH_MAX_KEY_COLS)]
+
+
 class cph_stream_chunk(C.Structure):
     _fields_ = [("probe_base", C.c_uint64), ("nrows", C.c_uint64), ("nmatches", C.c_uint64),
                 ("match_bitmap", C.c_void_p), ("build_row", C.c_void_p * CPH_MAX_CHAIN), ("nsteps", C.c_int32),
@@ -167,6 +181,10 @@ PROTOTYPES = [
     ("cph_csv_write", C.c_int32,
      [_P, C.POINTER(cph_strcol), C.c_int32, C.POINTER(cph_strval), C.c_int32, C.POINTER(C.POINTER(cph_bytes))]),
     ("cph_bytes_release", None, [C.POINTER(cph_bytes)]),
+    ("cph_csv_parse", C.c_int32,
+     [_P, _P, C.c_uint64, C.c_int32, C.POINTER(cph_csv_options), C.POINTER(C.c_int32), C.c_int32, C.c_int32,
+      C.POINTER(C.POINTER(cph_csv_table))]),
+    ("cph_csv_table_release", None, [C.POINTER(cph_csv_table)]),
     ("cph_index_find", C.c_int32,
      [_P, _P, C.POINTER(cph_strval), C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("cph_index_get_info", C.c_int32, [_P, C.POINTER(cph_index_info)]),

@@ -1,0 +1,175 @@
+"""The step before the path: CSV text -> SoA string columns on the GPU (cph_csv_parse), mirroring the
+reference's Reader (csvplus.go:922-1227).  The header logic (makeHeader, csvplus.go:1149-1206) runs here on
+the host over the first record only; the parse of the body is the device's."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from .columns import StrCol
+
+ERR_NAMES = {0: None, N.CPH_CSV_ERR_BARE_QUOTE: "bare \" in non-quoted field",
+             N.CPH_CSV_ERR_QUOTE: "extraneous or missing \" in quoted-field",
+             N.CPH_CSV_ERR_FIELD_COUNT: "wrong number of fields"}
+
+
+class CsvError(Exception):
+    """Mirrors csv.ParseError as csvplus reports it: kind + the record it happened in."""
+
+    def __init__(self, kind: int, record: int):
+        super().__init__(f"record {record}: {ERR_NAMES.get(kind, kind)}")
+        self.kind, self.record = kind, record
+
+
+class CsvTable:
+    """Library-owned result of cph_csv_parse.  `columns` are StrCols (host copies or zero-copy device views
+    valid until release())."""
+
+    def __init__(self, ctx, ptr, out_mem):
+        self.ctx, self.ptr = ctx, ptr
+        t = ptr.contents
+        self.nrecords, self.error_kind, self.error_record = int(t.nrecords), int(t.error_kind), int(t.error_record)
+        self.columns = []
+        for c in range(int(t.ncols)):
+            sc = t.cols[c]
+            if out_mem == N.CPH_MEM_HOST:
+                offs = N._ptr_array(sc.offsets, self.nrecords + 1, np.uint64).copy()
+                data = N._ptr_array(sc.data, int(offs[-1]), np.uint8).copy() if int(offs[-1]) else np.empty(0, np.uint8)
+                self.columns.append(StrCol(data, offs, self.nrecords, 64))
+            else:
+                self.columns.append(StrCol(_Raw(sc.data), _Raw(sc.offsets), self.nrecords, 64, N.CPH_MEM_DEVICE, fixed_width=0))
+        ctx._children.add(self)
+        if out_mem == N.CPH_MEM_HOST:
+            self.release()
+
+    def release(self):
+        if self.ptr:
+            self.ctx.lib.cph_csv_table_release(self.ptr)
+            self.ptr = None
+
+    close = release
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class _Raw:   # minimal object with data_ptr()
+    def __init__(self, p):
+        self._p = int(p or 0)
+
+    def data_ptr(self):
+        return self._p
+
+
+def csv_parse(ctx: N.Context, data, col_index, *, comma=b",", comment=None, trim_leading_space=False,
+              lazy_quotes=False, fields_per_record=0, skip_records=0, out_mem=N.CPH_MEM_HOST,
+              device_ptr=None, size=None) -> CsvTable:
+    """data: bytes / numpy uint8 (host), or pass device_ptr + size for text already in HBM."""
+    opt = N.cph_csv_options(ord(comma), ord(comment) if comment else 0, 1 if trim_leading_space else 0,
+                            1 if lazy_quotes else 0, int(fields_per_record), int(skip_records))
+    idx = (C.c_int32 * len(col_index))(*[int(i) for i in col_index])
+    out = C.POINTER(N.cph_csv_table)()
+    if device_ptr is not None:
+        ptr, n, mem, keep = C.c_void_p(int(device_ptr)), int(size), N.CPH_MEM_DEVICE, None
+    else:
+        keep = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data)
+        ptr, n, mem = C.c_void_p(keep.ctypes.data if len(keep) else 0), len(keep), N.CPH_MEM_HOST
+    ctx._check(ctx.lib.cph_csv_parse(ctx.handle, ptr, n, mem, C.byref(opt), idx, len(col_index), out_mem, C.byref(out)))
+    del keep
+    return CsvTable(ctx, out, out_mem)
+
+
+def first_record(text: bytes, comma=b",", comment=None, trim_leading_space=False):
+    """The header line, parsed on the host with Go's rules (enough of them for one record): what
+    makeHeader (csvplus.go:1149-1206) reads before the body is handed to the device."""
+    import csv
+    import io
+    pos, n = 0, len(text)
+    while pos < n:   # skip empty / comment lines
+        end = text.find(b"\n", pos)
+        line = text[pos:end if end >= 0 else n]
+        if line.rstrip(b"\r") == b"" or (comment and line.startswith(comment)):
+            pos = (end + 1) if end >= 0 else n
+            continue
+        break
+    if pos >= n:
+        return None
+    # a quoted header field may span lines: let the csv module find the record end
+    rd = csv.reader(io.StringIO(text[pos:pos + (1 << 20)].decode("utf-8", "surrogateescape"), newline=""),
+                    delimiter=comma.decode(), skipinitialspace=trim_leading_space, strict=True)
+    return [f.encode("utf-8", "surrogateescape") for f in next(rd)]
+
+
+def _b(x):
+    return x.encode() if isinstance(x, str) else bytes(x)
+
+
+def read_csv(ctx: N.Context, text: bytes, *, select=None, expect_header=None, assume_header=None, comma=b",",
+             comment=None, trim_leading_space=False, num_fields=0, out_mem=N.CPH_MEM_HOST) -> CsvTable:
+    """A csvplus Reader materialised as columns: FromFile(...)[.SelectColumns(select...) |
+    .ExpectHeader(expect_header) | .AssumeHeader(assume_header)][.NumFields(num_fields)].
+
+    Header modes as in the reference: default = every column the first record names (makeHeader,
+    csvplus.go:1159-1167, a repeated name keeps its LAST position); select = names looked up in the header
+    (SelectColumns :1009-1026); expect_header = {name: index, -1 = look the name up} (ExpectHeader :985-1003,
+    checked as makeHeader :1172-1203 does); assume_header = {name: index}, no header line (AssumeHeader
+    :963-980).  num_fields is csv.Reader.FieldsPerRecord (0 = as the first record, the header included;
+    <0 = any, short records padded with "" :1121-1122).
+    Returns the table with `.names`; `.error_kind/.error_record` report a parse error the way the reference
+    returns it after delivering the rows before it.  Header problems raise (the reference fails at line 1).
+    """
+    skip = 0
+    if assume_header is not None:
+        if not assume_header:
+            raise ValueError("Empty header spec")
+        hdr = {_b(k): int(v) for k, v in assume_header.items()}
+        if any(v < 0 for v in hdr.values()):
+            raise ValueError("header spec: negative index")
+        if num_fields >= 0:   # csvplus.go:1123-1127: an index beyond the record is an error unless padding is allowed
+            first = first_record(text, comma, comment, trim_leading_space)
+            if first is not None:
+                for nm, ix in hdr.items():
+                    if ix >= (num_fields if num_fields > 0 else len(first)):
+                        raise KeyError(f"column not found: {nm!r} ({ix})")
+    else:
+        first = first_record(text, comma, comment, trim_leading_space)
+        if first is None:
+            raise EOFError("EOF")   # io.EOF from the header read, csvplus.go:1150-1154
+        skip = 1
+        spec = None
+        if select is not None:
+            names = [_b(n) for n in select]
+            if not names:
+                raise ValueError("empty header spec")
+            if len(set(names)) != len(names):
+                raise ValueError("header spec: duplicate column name")
+            spec = {n: -1 for n in names}
+        elif expect_header is not None:
+            if not expect_header:
+                raise ValueError("empty header spec")
+            spec = {_b(k): int(v) for k, v in expect_header.items()}
+        hdr = {}
+        if spec is None:
+            for i, nm in enumerate(first):
+                hdr[nm] = i
+        else:
+            for i, nm in enumerate(first):
+                if nm in spec:
+                    if spec[nm] == -1 or spec[nm] == i:
+                        hdr[nm] = i
+                    else:
+                        raise KeyError(f"misplaced column {nm!r}: expected at pos. {spec[nm]}, but found at pos. {i}")
+            missing = [n for n in spec if n not in hdr]
+            if missing:
+                raise KeyError(("columns not found: " if len(missing) > 1 else "column not found: ")
+                               + ", ".join(m.decode("utf-8", "replace") for m in missing))
+    names = list(hdr.keys())
+    t = csv_parse(ctx, text, [hdr[n] for n in names], comma=comma, comment=comment,
+                  trim_leading_space=trim_leading_space, fields_per_record=num_fields, skip_records=skip, out_mem=out_mem)
+    t.names = names
+    return t

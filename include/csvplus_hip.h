@@ -319,6 +319,52 @@ CPH_API int32_t cph_csv_write(cph_ctx* ctx, const cph_strcol* cols, int32_t ncol
                               int32_t out_mem, cph_bytes** out);
 CPH_API void    cph_bytes_release(cph_bytes* b);
 
+/* ---- CSV ingest: bytes -> SoA string columns (csvplus.go:1080-1146) ----------- */
+/*
+ * Replaces the parse loop of Reader.Iterate (csv.NewReader + one map per line,
+ * csvplus.go:1104-1131): the caller resolves the header to FIELD INDICES
+ * (makeHeader, csvplus.go:1149-1206, stays on the host) and receives one
+ * string column per requested index.  Semantics are Go's encoding/csv Reader
+ * as csvplus configures it (csvplus.go:1088-1093): Comma, Comment,
+ * TrimLeadingSpace, FieldsPerRecord; "\r\n" -> "\n"; empty and comment lines
+ * skipped; `""` = literal quote.  LazyQuotes = 1 is rejected (CPH_ERR_INVALID),
+ * and so is a comment line that contains a '"' (Go skips it uninterpreted; the
+ * parallel quote-parity scan cannot).  A record with fewer fields than a
+ * requested index yields "" for that column — callers that want the
+ * reference's "missing column" error (csvplus.go:1121-1124) set
+ * fields_per_record > 0, as csvplus itself does with NumFields.
+ */
+enum {
+    CPH_CSV_ERR_BARE_QUOTE  = 1,  /* csv.ErrBareQuote: '"' inside an unquoted field          */
+    CPH_CSV_ERR_QUOTE       = 2,  /* csv.ErrQuote: stray or unterminated '"' in a quoted field */
+    CPH_CSV_ERR_FIELD_COUNT = 3   /* csv.ErrFieldCount                                        */
+};
+
+typedef struct {
+    uint8_t  comma;               /* Reader.delimiter (csvplus.go:1088); ASCII, not '"' '\r' '\n' */
+    uint8_t  comment;             /* Reader.comment   (csvplus.go:1089); 0 = none                 */
+    uint8_t  trim_leading_space;  /* csvplus.go:1092                                              */
+    uint8_t  lazy_quotes;         /* csvplus.go:1091; must be 0                                   */
+    int32_t  fields_per_record;   /* csv.Reader.FieldsPerRecord: >0 exact, 0 = as the first record, <0 = any */
+    uint64_t skip_records;        /* leading records to drop from the output (the header line; they are
+                                     still parsed, validated and counted in error_record)          */
+} cph_csv_options;
+
+typedef struct {
+    uint64_t   nrecords;          /* records returned: those before the first error, minus skip_records */
+    uint64_t   error_record;      /* if error_kind != 0: 0-based record index (skipped records included) */
+    int32_t    error_kind;        /* 0 or CPH_CSV_ERR_*: the first error in record order; the reference
+                                     delivers the rows before it and then fails the same way           */
+    int32_t    ncols;
+    cph_strcol cols[CPH_MAX_KEY_COLS];   /* cols[i] = field col_index[i] of every record; 64-bit offsets, in out_mem */
+} cph_csv_table;
+
+/* `data`/`size` = the whole CSV text in `mem` (CPH_MEM_HOST or CPH_MEM_DEVICE).
+ * col_index[ncols] = 0-based field indices wanted, 1 <= ncols <= CPH_MAX_KEY_COLS. */
+CPH_API int32_t cph_csv_parse(cph_ctx* ctx, const uint8_t* data, uint64_t size, int32_t mem, const cph_csv_options* opt,
+                              const int32_t* col_index, int32_t ncols, int32_t out_mem, cph_csv_table** out);
+CPH_API void    cph_csv_table_release(cph_csv_table* t);
+
 /* ---- Find / SubIndex bounds (csvplus.go:870-891) ----------------------------- */
 
 /* [*lower, *upper) = sorted positions whose leading key columns equal

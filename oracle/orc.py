@@ -185,7 +185,8 @@ def csv_parse(data: bytes, col_index, comma=b",", comment=None, trim_leading_spa
     ek, er = C.c_int32(), C.c_uint64()
     p = buf.ctypes.data if len(buf) else None
     n = int(lib.orc_csv_parse(p, len(buf), C.byref(o), idx, nc, nbytes, None, None, C.byref(ek), C.byref(er)))
-    datas = [np.empty(int(nbytes[c]) + 1, dtype=np.uint8) for c in range(nc)]
+    # the record that fails is written before it is rolled back: leave room for one whole input per column
+    datas = [np.empty(int(nbytes[c]) + len(buf) + 1, dtype=np.uint8) for c in range(nc)]
     offs = [np.empty(n + 1, dtype=np.uint64) for _ in range(nc)]
     dp = (C.c_void_p * nc)(*[d.ctypes.data for d in datas])
     op = (C.c_void_p * nc)(*[x.ctypes.data for x in offs])

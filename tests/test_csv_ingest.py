@@ -1,0 +1,209 @@
+"""CSV ingest: Reader.Iterate's parse loop (csvplus.go:1080-1146) as columns.
+
+CPU: the oracle's restatement of Go's csv.Reader is pinned to known-answer cases (tests/golden) and cross-checked
+against Python's csv module on the dialect subset where both agree.  GPU: cph_csv_parse == oracle, bit for bit,
+including the kind and record index of the first error, on hand cases, seeded random text and mutated
+(malformed) text."""
+from __future__ import annotations
+
+import csv
+import io
+
+import numpy as np
+import pytest
+
+from oracle import orc
+from tests.golden.go_csv_reader_cases import CASES
+
+WIDTH = 6   # fields compared per record (missing ones read as "")
+
+
+def oracle_records(text, opts, width=WIDTH, skip=0):
+    cols, ek, er = orc.csv_parse(text, list(range(width)), comma=opts.get("comma", b","), comment=opts.get("comment"),
+                                 trim_leading_space=opts.get("trim", False), fields_per_record=opts.get("fpr", 0),
+                                 skip_records=skip)
+    n = cols[0].nrows
+    return [[cols[c].value(r) for c in range(width)] for r in range(n)], ek, er
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_oracle_matches_go_known_answers(case):
+    _, text, opts, want, err = case
+    got, ek, er = oracle_records(text, opts)
+    assert got == [r[:WIDTH] + [b""] * (WIDTH - len(r)) for r in want]
+    assert (ek, er) == (err if err else (0, 0))
+
+
+def _gen_wellformed(rng, nrec, nfields, alphabet, crlf=False, quote_prob=0.3):
+    recs, out = [], io.BytesIO()
+    for _ in range(nrec):
+        rec = []
+        for f in range(nfields):
+            ln = int(rng.integers(0, 7))
+            v = bytes(alphabet[rng.integers(0, len(alphabet), ln)])
+            rec.append(v)
+        if nfields == 1 and rec[0] == b"":
+            rec[0] = b"x"   # a lone empty field is an empty line (skipped)
+        recs.append(rec)
+        parts = []
+        for v in rec:
+            needs = any(ch in v for ch in b',"\n\r') or v[:1] in (b" ", b"#") or rng.random() < quote_prob
+            parts.append(b'"' + v.replace(b'"', b'""') + b'"' if needs else v)
+        out.write(b",".join(parts) + (b"\r\n" if crlf else b"\n"))
+    return recs, out.getvalue()
+
+
+def test_oracle_vs_python_csv_on_common_subset():
+    rng = np.random.default_rng(7)
+    alphabet = np.frombuffer(b'ab ,"\nz1', dtype=np.uint8)   # no \r: Python keeps "\r\n" inside quotes, Go does not
+    for it in range(200):
+        nf = int(rng.integers(1, 5))
+        recs, text = _gen_wellformed(rng, int(rng.integers(0, 30)), nf, alphabet)
+        got, ek, er = oracle_records(text, {"fpr": -1}, width=nf)
+        assert (ek, er) == (0, 0)
+        py = [[f.encode() for f in row] for row in csv.reader(io.StringIO(text.decode(), newline=""), strict=True) if row]
+        assert got == recs == py, (it, text)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GPU parity
+# ---------------------------------------------------------------------------------------------------------------
+def gpu_records(ctx, text, opts, width=WIDTH, skip=0, out_mem=None):
+    from csvplus_amd import ingest
+    from csvplus_amd import _native as N
+    t = ingest.csv_parse(ctx, text, list(range(width)), comma=opts.get("comma", b","), comment=opts.get("comment"),
+                         trim_leading_space=opts.get("trim", False), fields_per_record=opts.get("fpr", 0),
+                         skip_records=skip, out_mem=N.CPH_MEM_HOST if out_mem is None else out_mem)
+    recs = [[t.columns[c].value(r) for c in range(width)] for r in range(t.nrecords)]
+    return recs, t.error_kind, t.error_record if t.error_kind else 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_gpu_known_answers(ctx, case):
+    _, text, opts, want, err = case
+    got, ek, er = gpu_records(ctx, text, opts)
+    assert got == [r[:WIDTH] + [b""] * (WIDTH - len(r)) for r in want]
+    assert (ek, er) == (err if err else (0, 0))
+
+
+@pytest.mark.gpu
+def test_gpu_random_wellformed_matches_oracle(ctx):
+    rng = np.random.default_rng(11)
+    alphabet = np.frombuffer(b'ab ,"\n\rz#\t', dtype=np.uint8)
+    for it in range(60):
+        nf = int(rng.integers(1, 6))
+        nrec = int(rng.integers(0, 4000 if it % 10 == 0 else 60))
+        _, text = _gen_wellformed(rng, nrec, nf, alphabet, crlf=bool(it & 1))
+        for opts in ({"fpr": -1}, {"fpr": 0, "trim": True}, {"fpr": nf}):
+            skip = int(rng.integers(0, 3))
+            assert gpu_records(ctx, text, opts, skip=skip) == oracle_records(text, opts, skip=skip), (it, opts)
+
+
+@pytest.mark.gpu
+def test_gpu_malformed_matches_oracle(ctx):
+    """Random byte mutations: the first error (kind, record) and every record before it must agree."""
+    rng = np.random.default_rng(13)
+    alphabet = np.frombuffer(b'ab ,"\n\rz', dtype=np.uint8)
+    junk = np.frombuffer(b'",\n\r a', dtype=np.uint8)
+    nerr = 0
+    for it in range(300):
+        nf = int(rng.integers(1, 5))
+        _, text = _gen_wellformed(rng, int(rng.integers(1, 80)), nf, alphabet, crlf=bool(it & 1))
+        buf = bytearray(text)
+        for _ in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(0, len(buf)))
+            op = int(rng.integers(0, 3))
+            if op == 0:
+                buf[pos] = int(junk[rng.integers(0, len(junk))])
+            elif op == 1:
+                del buf[pos]
+            else:
+                buf.insert(pos, int(junk[rng.integers(0, len(junk))]))
+            if not buf:
+                buf = bytearray(b"a")
+        text = bytes(buf)
+        for opts in ({"fpr": -1}, {"fpr": 0}, {"fpr": -1, "trim": True}):
+            want = oracle_records(text, opts)
+            nerr += want[1] != 0
+            assert gpu_records(ctx, text, opts) == want, (it, opts, text)
+    assert nerr > 100   # the mutations do produce errors
+
+
+@pytest.mark.gpu
+def test_gpu_comments_and_tiles(ctx):
+    """Comment lines, and records/quoted fields straddling the 4 KiB tile boundaries of the parity scan."""
+    rng = np.random.default_rng(17)
+    lines = []
+    for i in range(5000):
+        r = rng.random()
+        if r < 0.1:
+            lines.append(b"# a comment, with commas")
+        elif r < 0.15:
+            lines.append(b"")
+        elif r < 0.3:
+            lines.append(b'%d,"multi\nline ""q"" %s",x' % (i, b"y" * int(rng.integers(0, 300))))
+        else:
+            lines.append(b"%d,%s,z" % (i, b"v" * int(rng.integers(0, 40))))
+    text = b"\n".join(lines) + b"\n"
+    opts = {"comment": b"#", "fpr": 3}
+    assert gpu_records(ctx, text, opts, width=3, skip=1) == oracle_records(text, opts, width=3, skip=1)
+
+
+@pytest.mark.gpu
+def test_gpu_device_resident_text_and_output(ctx):
+    import torch
+    from csvplus_amd import ingest, materialize
+    from csvplus_amd import _native as N
+    rng = np.random.default_rng(19)
+    _, text = _gen_wellformed(rng, 20000, 4, np.frombuffer(b"abcdef,\" ", dtype=np.uint8))
+    dev = torch.frombuffer(bytearray(text), dtype=torch.uint8).to("cuda:0")
+    t = ingest.csv_parse(ctx, None, [3, 0], fields_per_record=4, out_mem=N.CPH_MEM_DEVICE, device_ptr=dev.data_ptr(), size=len(text))
+    assert t.error_kind == 0
+    want, ek, _ = orc.csv_parse(text, [3, 0], fields_per_record=4)
+    assert ek == 0 and t.nrecords == want[0].nrows
+    for c in range(2):
+        host = materialize.gather_rows(ctx, t.columns[c])   # identity gather = device -> host copy of the column
+        assert list(host.values()) == list(want[c].values())
+    t.release()
+
+
+@pytest.mark.gpu
+def test_gpu_rejects_what_it_cannot_parse(ctx):
+    from csvplus_amd import ingest
+    with pytest.raises(Exception):
+        ingest.csv_parse(ctx, b"a,b\n", [0], lazy_quotes=True)
+    with pytest.raises(Exception):
+        ingest.csv_parse(ctx, b'a,b\n# "quoted" comment\nc,d\n', [0], comment=b"#")
+
+
+@pytest.mark.gpu
+def test_read_csv_header_modes(ctx):
+    """Reader.Iterate header handling (csvplus.go:1097-1102, makeHeader :1149-1206) on the people fixture."""
+    from csvplus_amd import ingest
+    from tests.helpers import people_table
+    p = people_table()
+    text = ("id,name,surname\n" + "".join(f"{i},{n},{s}\n" for i, n, s in zip(p["id"], p["name"], p["surname"]))).encode()
+    t = ingest.read_csv(ctx, text)
+    assert t.names == [b"id", b"name", b"surname"] and t.nrecords == 120 and t.error_kind == 0
+    assert [v.decode() for v in t.columns[2].values()] == p["surname"]
+    t = ingest.read_csv(ctx, text, select=["surname", "id"])
+    assert t.names == [b"id", b"surname"] or t.names == [b"surname", b"id"]
+    assert [v.decode() for v in t.columns[t.names.index(b"id")].values()] == p["id"]
+    t = ingest.read_csv(ctx, text, expect_header={"name": 1, "surname": -1})
+    assert [v.decode() for v in t.columns[t.names.index(b"name")].values()] == p["name"]
+    with pytest.raises(KeyError):
+        ingest.read_csv(ctx, text, expect_header={"name": 2})
+    with pytest.raises(KeyError):
+        ingest.read_csv(ctx, text, select=["xxx"])
+    body = text.split(b"\n", 1)[1]
+    t = ingest.read_csv(ctx, body, assume_header={"id": 0, "surname": 2})
+    assert t.nrecords == 120 and [v.decode() for v in t.columns[t.names.index(b"surname")].values()] == p["surname"]
+    with pytest.raises(KeyError):
+        ingest.read_csv(ctx, body, assume_header={"id": 0, "zzz": 3})
+    # NumFields mismatch is reported at the record where it happens, with the rows before it delivered
+    bad = text + b"1,2\n"
+    t = ingest.read_csv(ctx, bad)
+    assert (t.error_kind, t.error_record, t.nrecords) == (3, 121, 120)
+    with pytest.raises(EOFError):
+        ingest.read_csv(ctx, b"")
