@@ -132,6 +132,10 @@ class cph_csv_table(C.Structure):
                 ("ncols", C.c_int32), ("cols", cph_strcol * CPH_MAX_KEY_COLS)]
 
 
+class cph_groups(C.Structure):
+    _fields_ = [("ngroups", C.c_uint64), ("lower", C.c_void_p), ("upper", C.c_void_p)]
+
+
 class cph_stream_chunk(C.Structure):
     _fields_ = [("probe_base", C.c_uint64), ("nrows", C.c_uint64), ("nmatches", C.c_uint64),
                 ("match_bitmap", C.c_void_p), ("build_row", C.c_void_p * CPH_MAX_CHAIN), ("nsteps", C.c_int32),
@@ -185,6 +189,11 @@ PROTOTYPES = [
      [_P, _P, C.c_uint64, C.c_int32, C.POINTER(cph_csv_options), C.POINTER(C.c_int32), C.c_int32, C.c_int32,
       C.POINTER(C.POINTER(cph_csv_table))]),
     ("cph_csv_table_release", None, [C.POINTER(cph_csv_table)]),
+    ("cph_index_dup_groups", C.c_int32, [_P, _P, C.POINTER(C.POINTER(cph_groups))]),
+    ("cph_groups_release", None, [C.POINTER(cph_groups)]),
+    ("cph_index_select", C.c_int32, [_P, _P, _P, C.c_uint64, C.POINTER(_P)]),
+    ("cph_index_save", C.c_int32, [_P, _P, C.c_char_p]),
+    ("cph_index_load", C.c_int32, [_P, C.c_char_p, C.POINTER(_P)]),
     ("cph_index_find", C.c_int32,
      [_P, _P, C.POINTER(cph_strval), C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("cph_index_get_info", C.c_int32, [_P, C.POINTER(cph_index_info)]),
@@ -367,6 +376,43 @@ class DeviceIndex:
         self.ctx._check(self.lib.cph_index_find(self.ctx.handle, self.handle, vals, len(values), C.byref(lo),
                                                 C.byref(hi)))
         return int(lo.value), int(hi.value)
+
+    @classmethod
+    def _from_handle(cls, ctx: "Context", handle) -> "DeviceIndex":
+        self = cls.__new__(cls)
+        self.ctx, self.lib, self.handle = ctx, ctx.lib, handle
+        self.first_dup, self.status = None, CPH_OK
+        ctx._children.add(self)
+        return self
+
+    def dup_groups(self):
+        """(lower, upper) uint64 arrays: every maximal run [lower, upper) of >= 2 equal keys, ascending
+        (the groups dedup, csvplus.go:810-867, hands to the resolve callback)."""
+        out = C.POINTER(cph_groups)()
+        self.ctx._check(self.lib.cph_index_dup_groups(self.ctx.handle, self.handle, C.byref(out)))
+        g = out.contents
+        n = int(g.ngroups)
+        lo = _ptr_array(g.lower, n, np.uint64).copy() if n else np.empty(0, np.uint64)
+        hi = _ptr_array(g.upper, n, np.uint64).copy() if n else np.empty(0, np.uint64)
+        self.lib.cph_groups_release(out)
+        return lo, hi
+
+    def select(self, positions) -> "DeviceIndex":
+        """New index over the given strictly ascending sorted positions (dedup's compaction)."""
+        pos = np.ascontiguousarray(positions, dtype=np.uint64)
+        h = _P()
+        self.ctx._check(self.lib.cph_index_select(self.ctx.handle, self.handle, _P(pos.ctypes.data if len(pos) else 0),
+                                                  len(pos), C.byref(h)))
+        return DeviceIndex._from_handle(self.ctx, h)
+
+    def save(self, path: str) -> None:
+        self.ctx._check(self.lib.cph_index_save(self.ctx.handle, self.handle, str(path).encode()))
+
+    @staticmethod
+    def load(ctx: "Context", path: str) -> "DeviceIndex":
+        h = _P()
+        ctx._check(ctx.lib.cph_index_load(ctx.handle, str(path).encode(), C.byref(h)))
+        return DeviceIndex._from_handle(ctx, h)
 
     def close(self):
         if getattr(self, "handle", None):

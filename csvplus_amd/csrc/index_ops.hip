@@ -1,0 +1,356 @@
+// index_ops.hip — SURVEY.md §8f rank 4: what happens to an index after it is built.
+//
+//   cph_index_dup_groups   the group boundaries ResolveDuplicates needs: dedup (csvplus.go:810-867) finds the
+//                          first adjacent-equal pair by a linear scan (:815-819, :851-855) and the end of the
+//                          group by a binary search (:828-830), one group at a time; here every maximal run of
+//                          >= 2 equal keys comes out of one pass over the sorted codes.  The resolve callback
+//                          and the compaction rule stay on the host (the shim replays :823-860 over the list).
+//   cph_index_select       the compaction itself (index.rows = index.rows[:dest], :863) for the device twin:
+//                          a new index over an ascending subset of sorted positions.
+//   cph_index_save/_load   persistence (WriteTo/LoadIndex, :655-705).  The reference gob-encodes columns +
+//                          row maps; the device index is a flat little-endian sidecar of what it holds (codec,
+//                          sorted codes, perm) — it is NOT a gob stream and carries no row payload.
+#include <cstdio>
+#include <new>
+
+#include "probe_device.hpp"
+
+namespace cph {
+
+// flags[i] = 1 when sorted position i STARTS (START=true) / ENDS a run of >= 2 equal keys
+template <bool KEY32, bool START>
+__global__ void k_group_flags(const void* __restrict__ codes, uint64_t n, int nwords, uint32_t* __restrict__ flags) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        auto eq = [&](uint64_t a, uint64_t b) {
+            if constexpr (KEY32) {
+                const uint32_t* c = reinterpret_cast<const uint32_t*>(codes);
+                return c[a] == c[b];
+            } else {
+                const uint64_t* c = reinterpret_cast<const uint64_t*>(codes);
+                for (int w = 0; w < nwords; w++)
+                    if (c[(uint64_t)w * n + a] != c[(uint64_t)w * n + b]) return false;
+                return true;
+            }
+        };
+        const bool eq_prev = i > 0 && eq(i, i - 1);
+        const bool eq_next = i + 1 < n && eq(i, i + 1);
+        flags[i] = START ? (!eq_prev && eq_next) : (eq_prev && !eq_next);
+    }
+}
+
+// out[scan[i]] = i + add   for flagged i
+__global__ void k_group_emit(const uint32_t* __restrict__ flags, const uint32_t* __restrict__ scan, uint64_t n, uint64_t add,
+                             uint64_t* __restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        if (flags[i]) out[scan[i]] = i + add;
+}
+
+__global__ void k_select_u32(const uint32_t* __restrict__ src, const uint64_t* __restrict__ pos, uint64_t n, uint32_t* __restrict__ dst) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[pos[i]];
+}
+__global__ void k_select_u64(const uint64_t* __restrict__ src, const uint64_t* __restrict__ pos, uint64_t n, uint64_t* __restrict__ dst) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[pos[i]];
+}
+// bad[0] = 1 unless pos is strictly ascending and < nrows
+__global__ void k_select_check(const uint64_t* __restrict__ pos, uint64_t n, uint64_t nrows, uint32_t* __restrict__ bad) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        if (pos[i] >= nrows || (i > 0 && pos[i - 1] >= pos[i])) atomicExch(bad, 1u);
+}
+
+static unsigned grid_rows(uint64_t n) {
+    uint64_t b = (n + 255) / 256;
+    if (b > 8192) b = 8192;
+    return (unsigned)(b ? b : 1);
+}
+
+static int32_t ops_fail(cph_ctx* ctx, const Status& s) {
+    if (ctx) ctx->err = s.msg;
+    return s.code;
+}
+
+template <class T>
+static Status read_one(cph_ctx* ctx, const T* dev, T* host) {
+    CPH_TRY(ensure_pinned_scratch(ctx, sizeof(T)));
+    CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, dev, sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    memcpy(host, ctx->pinned_scratch, sizeof(T));
+    return {};
+}
+
+// Finishes an index whose codec / sorted_codes / perm are in place: unique scan + table.
+static Status finish_index(cph_ctx* ctx, cph_index* ix) {
+    CPH_TRY(codec_upload(ctx, ix->codec, &ix->codec_dev));
+    CPH_TRY(index_first_dup_launch(ctx, ix));
+    CPH_TRY(index_build_table(ctx, ix));
+    CPH_TRY(index_first_dup_read(ctx, ix));
+    return {};
+}
+
+static size_t code_bytes(const cph_index* ix) {
+    return ix->codec.key32 ? sizeof(uint32_t) : sizeof(uint64_t) * (size_t)ix->codec.nwords;
+}
+
+}  // namespace cph
+
+using namespace cph;
+
+struct cph_groups_impl {
+    cph_groups pub;   // first
+    void* h_block = nullptr;
+};
+
+// ---- file format ------------------------------------------------------------------------------------------
+namespace {
+constexpr char kMagic[8] = {'C', 'P', 'H', 'I', 'D', 'X', '1', '\n'};
+struct FileHeader {
+    char magic[8];
+    uint64_t nrows;
+    int32_t nkeycols, ncols, npos, nwords, key32, sort_passes;
+    int32_t col_start[kMaxKeyCols + 1];
+    int32_t col_maxlen[kMaxKeyCols];
+    int32_t col_minlen[kMaxKeyCols];
+    int32_t word_bits[kMaxWords];
+    uint64_t word_states[kMaxWords];
+};
+struct FileCloser {
+    FILE* f;
+    ~FileCloser() { if (f) fclose(f); }
+};
+}  // namespace
+
+extern "C" {
+
+CPH_API int32_t cph_index_dup_groups(cph_ctx* ctx, const cph_index* ix, cph_groups** out) {
+    if (!ctx || !ix || !out) return CPH_ERR_INVALID;
+    *out = nullptr;
+    if (hipSetDevice(ctx->device) != hipSuccess) return ops_fail(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});
+    auto* g = new (std::nothrow) cph_groups_impl();
+    if (!g) return ops_fail(ctx, {CPH_ERR_NOMEM, "out of host memory"});
+    auto run = [&]() -> Status {
+        const uint64_t n = ix->nrows;
+        uint64_t ng = 0;
+        DevBuf lo, hi;
+        if (n >= 2) {
+            DevBuf flags, scan;
+            CPH_TRY(flags.alloc(&ctx->pool, n * sizeof(uint32_t)));
+            CPH_TRY(scan.alloc(&ctx->pool, n * sizeof(uint32_t)));
+            for (int pass = 0; pass < 2; pass++) {
+                {
+                    ProfScope ps(ctx, "k_group_flags", (double)n * ((double)code_bytes(ix) + 4.0));
+                    const unsigned grid = grid_rows(n);
+                    if (ix->codec.key32) {
+                        if (pass == 0) hipLaunchKernelGGL((k_group_flags<true, true>), dim3(grid), dim3(256), 0, ctx->stream, ix->sorted_codes.get(), n, ix->codec.nwords, flags.as<uint32_t>());
+                        else hipLaunchKernelGGL((k_group_flags<true, false>), dim3(grid), dim3(256), 0, ctx->stream, ix->sorted_codes.get(), n, ix->codec.nwords, flags.as<uint32_t>());
+                    } else {
+                        if (pass == 0) hipLaunchKernelGGL((k_group_flags<false, true>), dim3(grid), dim3(256), 0, ctx->stream, ix->sorted_codes.get(), n, ix->codec.nwords, flags.as<uint32_t>());
+                        else hipLaunchKernelGGL((k_group_flags<false, false>), dim3(grid), dim3(256), 0, ctx->stream, ix->sorted_codes.get(), n, ix->codec.nwords, flags.as<uint32_t>());
+                    }
+                }
+                CPH_HIP_TRY(hipMemcpyAsync(scan.get(), flags.get(), n * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+                CPH_TRY(exclusive_scan_u32(ctx, scan.as<uint32_t>(), n));
+                if (pass == 0) {
+                    uint32_t last_scan = 0, last_flag = 0;
+                    CPH_TRY(read_one(ctx, scan.as<uint32_t>() + (n - 1), &last_scan));
+                    CPH_TRY(read_one(ctx, flags.as<uint32_t>() + (n - 1), &last_flag));
+                    ng = (uint64_t)last_scan + last_flag;
+                    if (ng == 0) break;
+                    CPH_TRY(lo.alloc(&ctx->pool, ng * sizeof(uint64_t)));
+                    CPH_TRY(hi.alloc(&ctx->pool, ng * sizeof(uint64_t)));
+                }
+                hipLaunchKernelGGL(k_group_emit, dim3(grid_rows(n)), dim3(256), 0, ctx->stream, flags.as<uint32_t>(), scan.as<uint32_t>(),
+                                   n, (uint64_t)pass /* upper bound is exclusive */, (pass == 0 ? lo : hi).as<uint64_t>());
+                CPH_HIP_TRY(hipGetLastError());
+            }
+        }
+        g->pub.ngroups = ng;
+        CPH_HIP_TRY(hipHostMalloc(&g->h_block, (2 * ng + 2) * sizeof(uint64_t), hipHostMallocDefault));
+        uint64_t* h = static_cast<uint64_t*>(g->h_block);
+        if (ng) {
+            CPH_HIP_TRY(hipMemcpyAsync(h, lo.get(), ng * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+            CPH_HIP_TRY(hipMemcpyAsync(h + ng, hi.get(), ng * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+            CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+        g->pub.lower = h;
+        g->pub.upper = h + ng;
+        return {};
+    };
+    Status s = run();
+    if (!s.ok()) {
+        (void)hipStreamSynchronize(ctx->stream);
+        if (g->h_block) (void)hipHostFree(g->h_block);
+        delete g;
+        return ops_fail(ctx, s);
+    }
+    *out = &g->pub;
+    return CPH_OK;
+}
+
+CPH_API void cph_groups_release(cph_groups* pub) {
+    if (!pub) return;
+    auto* g = reinterpret_cast<cph_groups_impl*>(pub);
+    if (g->h_block) (void)hipHostFree(g->h_block);
+    delete g;
+}
+
+CPH_API int32_t cph_index_select(cph_ctx* ctx, const cph_index* ix, const uint64_t* positions, uint64_t n, cph_index** out) {
+    if (!ctx || !ix || !out || (n && !positions)) return CPH_ERR_INVALID;
+    *out = nullptr;
+    if (hipSetDevice(ctx->device) != hipSuccess) return ops_fail(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});
+    if (n > ix->nrows) return ops_fail(ctx, {CPH_ERR_INVALID, "more positions than index rows"});
+    auto* nx = new (std::nothrow) cph_index();
+    if (!nx) return ops_fail(ctx, {CPH_ERR_NOMEM, "out of host memory"});
+    auto run = [&]() -> Status {
+        nx->ctx = ctx;
+        nx->nrows = n;
+        nx->nkeycols = ix->nkeycols;
+        nx->codec = ix->codec;
+        nx->sort_passes = 0;
+        DevBuf pos, bad;
+        CPH_TRY(pos.alloc(&ctx->pool, n * sizeof(uint64_t)));
+        CPH_TRY(bad.alloc(&ctx->pool, sizeof(uint32_t)));
+        CPH_HIP_TRY(hipMemsetAsync(bad.get(), 0, sizeof(uint32_t), ctx->stream));
+        if (n) CPH_HIP_TRY(hipMemcpyAsync(pos.get(), positions, n * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+        const unsigned grid = grid_rows(n);
+        hipLaunchKernelGGL(k_select_check, dim3(grid), dim3(256), 0, ctx->stream, pos.as<uint64_t>(), n, ix->nrows, bad.as<uint32_t>());
+        uint32_t isbad = 0;
+        CPH_TRY(read_one(ctx, bad.as<uint32_t>(), &isbad));
+        if (isbad) return {CPH_ERR_INVALID, "positions must be strictly ascending sorted positions of the index"};
+        CPH_TRY(nx->perm.alloc(&ctx->pool, n * sizeof(uint32_t)));
+        CPH_TRY(nx->sorted_codes.alloc(&ctx->pool, n * code_bytes(ix)));
+        if (n) {
+            ProfScope ps(ctx, "k_select", (double)n * (8.0 + 2.0 * (4.0 + (double)code_bytes(ix))));
+            hipLaunchKernelGGL(k_select_u32, dim3(grid), dim3(256), 0, ctx->stream, ix->perm.as<uint32_t>(), pos.as<uint64_t>(), n, nx->perm.as<uint32_t>());
+            if (ix->codec.key32)
+                hipLaunchKernelGGL(k_select_u32, dim3(grid), dim3(256), 0, ctx->stream, ix->sorted_codes.as<uint32_t>(), pos.as<uint64_t>(), n, nx->sorted_codes.as<uint32_t>());
+            else
+                for (int w = 0; w < ix->codec.nwords; w++)
+                    hipLaunchKernelGGL(k_select_u64, dim3(grid), dim3(256), 0, ctx->stream, ix->sorted_codes.as<uint64_t>() + (uint64_t)w * ix->nrows,
+                                       pos.as<uint64_t>(), n, nx->sorted_codes.as<uint64_t>() + (uint64_t)w * n);
+            CPH_HIP_TRY(hipGetLastError());
+        }
+        return finish_index(ctx, nx);
+    };
+    Status s = run();
+    if (!s.ok()) {
+        (void)hipStreamSynchronize(ctx->stream);
+        delete nx;
+        return ops_fail(ctx, s);
+    }
+    *out = nx;
+    return CPH_OK;
+}
+
+CPH_API int32_t cph_index_save(cph_ctx* ctx, const cph_index* ix, const char* path) {
+    if (!ctx || !ix || !path) return CPH_ERR_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess) return ops_fail(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});
+    auto run = [&]() -> Status {
+        const CodecHost& cd = ix->codec;
+        FileHeader h{};
+        memcpy(h.magic, kMagic, 8);
+        h.nrows = ix->nrows;
+        h.nkeycols = ix->nkeycols;
+        h.ncols = cd.ncols;
+        h.npos = cd.npos;
+        h.nwords = cd.nwords;
+        h.key32 = cd.key32 ? 1 : 0;
+        h.sort_passes = ix->sort_passes;
+        memcpy(h.col_start, cd.col_start, sizeof h.col_start);
+        memcpy(h.col_maxlen, cd.col_maxlen, sizeof h.col_maxlen);
+        memcpy(h.col_minlen, cd.col_minlen, sizeof h.col_minlen);
+        memcpy(h.word_bits, cd.word_bits, sizeof h.word_bits);
+        memcpy(h.word_states, cd.word_states, sizeof h.word_states);
+        const size_t cb = (size_t)ix->nrows * code_bytes(ix), pb = (size_t)ix->nrows * sizeof(uint32_t);
+        std::vector<uint8_t> host(cb + pb);
+        if (cb) CPH_HIP_TRY(hipMemcpyAsync(host.data(), ix->sorted_codes.get(), cb, hipMemcpyDeviceToHost, ctx->stream));
+        if (pb) CPH_HIP_TRY(hipMemcpyAsync(host.data() + cb, ix->perm.get(), pb, hipMemcpyDeviceToHost, ctx->stream));
+        CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        FILE* f = fopen(path, "wb");
+        if (!f) return {CPH_ERR_INVALID, std::string("cannot create ") + path};
+        bool ok = true;
+        {
+            FileCloser fc{f};
+            auto put = [&](const void* p, size_t nb) { ok = ok && (nb == 0 || fwrite(p, 1, nb, f) == nb); };
+            put(&h, sizeof h);
+            put(cd.radix.data(), cd.radix.size() * sizeof(uint16_t));
+            put(cd.mult.data(), cd.mult.size() * sizeof(uint64_t));
+            put(cd.word_of.data(), cd.word_of.size() * sizeof(int32_t));
+            put(cd.lut.data(), cd.lut.size() * sizeof(uint16_t));
+            put(host.data(), host.size());
+            ok = ok && fflush(f) == 0;
+        }
+        if (!ok) {   // the reference removes a partially written file (csvplus.go:663-671)
+            remove(path);
+            return {CPH_ERR_INVALID, std::string("short write to ") + path};
+        }
+        return {};
+    };
+    Status s = run();
+    return s.ok() ? CPH_OK : ops_fail(ctx, s);
+}
+
+CPH_API int32_t cph_index_load(cph_ctx* ctx, const char* path, cph_index** out) {
+    if (!ctx || !path || !out) return CPH_ERR_INVALID;
+    *out = nullptr;
+    if (hipSetDevice(ctx->device) != hipSuccess) return ops_fail(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});
+    auto* ix = new (std::nothrow) cph_index();
+    if (!ix) return ops_fail(ctx, {CPH_ERR_NOMEM, "out of host memory"});
+    auto run = [&]() -> Status {
+        FILE* f = fopen(path, "rb");
+        if (!f) return {CPH_ERR_INVALID, std::string("cannot open ") + path};
+        FileCloser fc{f};
+        FileHeader h{};
+        const Status bad{CPH_ERR_INVALID, std::string(path) + ": not a csvplus_hip index file (or truncated)"};
+        if (fread(&h, 1, sizeof h, f) != sizeof h || memcmp(h.magic, kMagic, 8) != 0) return bad;
+        if (h.nrows > 0xFFFFFFFFull || h.nkeycols < 1 || h.nkeycols > kMaxKeyCols || h.ncols != h.nkeycols || h.npos < 0 ||
+            h.npos > kMaxKeyBytes || h.nwords < 1 || h.nwords > kMaxWords)
+            return bad;
+        CodecHost& cd = ix->codec;
+        cd.ncols = h.ncols;
+        cd.npos = h.npos;
+        cd.nwords = h.nwords;
+        cd.key32 = h.key32 != 0;
+        memcpy(cd.col_start, h.col_start, sizeof h.col_start);
+        memcpy(cd.col_maxlen, h.col_maxlen, sizeof h.col_maxlen);
+        memcpy(cd.col_minlen, h.col_minlen, sizeof h.col_minlen);
+        memcpy(cd.word_bits, h.word_bits, sizeof h.word_bits);
+        memcpy(cd.word_states, h.word_states, sizeof h.word_states);
+        cd.radix.resize((size_t)h.npos);
+        cd.mult.resize((size_t)h.npos);
+        cd.word_of.resize((size_t)h.npos);
+        cd.lut.resize((size_t)h.npos * 257);
+        auto get = [&](void* p, size_t nb) { return nb == 0 || fread(p, 1, nb, f) == nb; };
+        if (!get(cd.radix.data(), cd.radix.size() * sizeof(uint16_t)) || !get(cd.mult.data(), cd.mult.size() * sizeof(uint64_t)) ||
+            !get(cd.word_of.data(), cd.word_of.size() * sizeof(int32_t)) || !get(cd.lut.data(), cd.lut.size() * sizeof(uint16_t)))
+            return bad;
+        ix->ctx = ctx;
+        ix->nrows = h.nrows;
+        ix->nkeycols = h.nkeycols;
+        ix->sort_passes = h.sort_passes;
+        const size_t cb = (size_t)ix->nrows * code_bytes(ix), pb = (size_t)ix->nrows * sizeof(uint32_t);
+        std::vector<uint8_t> host(cb + pb);
+        if (!get(host.data(), host.size())) return bad;
+        uint8_t extra;
+        if (fread(&extra, 1, 1, f) != 0) return bad;   // trailing bytes
+        CPH_TRY(ix->sorted_codes.alloc(&ctx->pool, cb));
+        CPH_TRY(ix->perm.alloc(&ctx->pool, pb));
+        if (cb) CPH_HIP_TRY(hipMemcpyAsync(ix->sorted_codes.get(), host.data(), cb, hipMemcpyHostToDevice, ctx->stream));
+        if (pb) CPH_HIP_TRY(hipMemcpyAsync(ix->perm.get(), host.data() + cb, pb, hipMemcpyHostToDevice, ctx->stream));
+        CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));   // `host` is pageable and goes away
+        return finish_index(ctx, ix);
+    };
+    Status s = run();
+    if (!s.ok()) {
+        (void)hipStreamSynchronize(ctx->stream);
+        delete ix;
+        return ops_fail(ctx, s);
+    }
+    *out = ix;
+    return CPH_OK;
+}
+
+}  // extern "C"

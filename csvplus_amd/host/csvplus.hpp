@@ -12,6 +12,8 @@
 //   DataSource.IndexOn / UniqueIndexOn :529,:535 DataSource::IndexOn / UniqueIndexOn
 //   DataSource.Join / Except           :545,:588 DataSource::Join / Except
 //   Index.Iterate / Find / SubIndex    :618-641  Index::Iterate / Find / SubIndex
+//   Index.ResolveDuplicates            :643-653  Index::ResolveDuplicates (groups found on the GPU)
+//   Index.WriteTo / LoadIndex          :655-705  Index::WriteTo / LoadIndex (own binary format, not gob)
 //   DataSourceError                   :1229-1238 csvplus::DataSourceError
 //
 // Go `error` values become csvplus::Error (nil == ok()); Go panics (programmer errors:
@@ -28,6 +30,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <functional>
 #include <map>
 #include <memory>
@@ -223,6 +226,15 @@ public:
     DataSource Find(const std::vector<std::string>& values) const;
     // SubIndex (:632-641)
     std::shared_ptr<Index> SubIndex(const std::vector<std::string>& values) const;
+
+    // ResolveDuplicates (:643-653): `resolve` is called once per pack of rows with equal key, in key order;
+    // it returns one of the rows (kept as the only row with that key), an empty row (the pack is dropped) or an
+    // error (returned to the caller).  Compaction follows dedup (:810-867) to the letter.
+    using ResolveFunc = std::function<std::pair<Row, Error>(const std::vector<Row>&)>;
+    Error ResolveDuplicates(const ResolveFunc& resolve);
+    // WriteTo (:655-680) / LoadIndex (:682-705).  The reference gob-encodes columns + rows; this file is a
+    // length-prefixed little-endian dump of the same two values and is NOT readable by the Go library.
+    Error WriteTo(const std::string& fileName) const;
 
     const std::vector<Row>& rows() const { return impl_rows; }
     const std::vector<std::string>& columns() const { return impl_columns; }
@@ -458,6 +470,116 @@ inline std::shared_ptr<Index> Index::SubIndex(const std::vector<std::string>& va
     sub->impl_rows.assign(impl_rows.begin() + (long)r.first, impl_rows.begin() + (long)r.second);
     sub->impl_columns.assign(impl_columns.begin() + (long)values.size(), impl_columns.end());
     return sub;
+}
+
+// dedup (:810-867).  The adjacent-equal scans (:815-819, :851-855) and the per-group binary search (:828-830)
+// are one GPU pass over the sorted key codes (cph_index_dup_groups); the loop below replays the reference's
+// bookkeeping over that list of groups, so the surviving rows — including the reference's habit of not
+// copying the final row when the last pack ends before it (:851-859 moves rows[lower-1] only while
+// lower < len) — are exactly the reference's.
+inline Error Index::ResolveDuplicates(const ResolveFunc& resolve) {
+    cph_ctx* ctx = Gpu::Default().ctx();
+    cph_groups* g = nullptr;
+    if (cph_index_dup_groups(ctx, device().h, &g) != CPH_OK)
+        throw std::runtime_error(std::string("csvplus: ") + cph_last_error(ctx));
+    struct Release { cph_groups* g; ~Release() { cph_groups_release(g); } } rel{g};
+    if (g->ngroups == 0) return Error();                                            // :821-823
+    const size_t n = impl_rows.size();
+    size_t dest = (size_t)g->lower[0];                                              // dest = lower-1 (:825)
+    for (uint64_t k = 0; k < g->ngroups; k++) {
+        const size_t lo = (size_t)g->lower[k], hi = (size_t)g->upper[k];
+        std::vector<Row> pack(impl_rows.begin() + (long)lo, impl_rows.begin() + (long)hi);
+        auto res = resolve(pack);                                                   // :835
+        if (res.second) {                                                           // :835-837: rows stay as they are now
+            dev_.reset();
+            return res.second;
+        }
+        if (res.first.size() >= impl_columns.size()) impl_rows[dest++] = std::move(res.first);   // :842-845
+        const size_t stop = k + 1 < g->ngroups ? (size_t)g->lower[k + 1] : n - 1;   // :848-859
+        for (size_t i = hi; i < stop; i++, dest++)
+            if (dest != i) impl_rows[dest] = impl_rows[i];   // a copy, as the reference's slice assignment: the source slot keeps its row
+    }
+    impl_rows.resize(dest);                                                         // :862-864
+    dev_.reset();   // the device twin is rebuilt from the surviving rows on next use
+    return Error();
+}
+
+namespace detail {
+inline void put_u64(std::ostream& o, uint64_t v) {
+    char b[8];
+    for (int i = 0; i < 8; i++) b[i] = (char)(v >> (8 * i));
+    o.write(b, 8);
+}
+inline void put_str(std::ostream& o, const std::string& s) {
+    put_u64(o, s.size());
+    o.write(s.data(), (std::streamsize)s.size());
+}
+inline bool get_u64(std::istream& in, uint64_t* v) {
+    unsigned char b[8];
+    if (!in.read(reinterpret_cast<char*>(b), 8)) return false;
+    *v = 0;
+    for (int i = 0; i < 8; i++) *v |= (uint64_t)b[i] << (8 * i);
+    return true;
+}
+inline bool get_str(std::istream& in, std::string* s, uint64_t limit) {
+    uint64_t n;
+    if (!get_u64(in, &n) || n > limit) return false;
+    s->resize((size_t)n);
+    return n == 0 || (bool)in.read(&(*s)[0], (std::streamsize)n);
+}
+constexpr char kIndexMagic[8] = {'C', 'S', 'V', 'P', 'I', 'D', 'X', '1'};
+}  // namespace detail
+
+inline Error Index::WriteTo(const std::string& fileName) const {
+    std::ofstream f(fileName, std::ios::binary | std::ios::trunc);
+    if (!f) return Error("open " + fileName + ": cannot create file");
+    f.write(detail::kIndexMagic, 8);
+    detail::put_u64(f, impl_columns.size());                                        // enc.Encode(columns) :674
+    for (const auto& c : impl_columns) detail::put_str(f, c);
+    detail::put_u64(f, impl_rows.size());                                           // enc.Encode(rows) :675
+    for (const Row& r : impl_rows) {
+        detail::put_u64(f, r.size());
+        for (const auto& kv : r) {
+            detail::put_str(f, kv.first);
+            detail::put_str(f, kv.second);
+        }
+    }
+    f.close();
+    if (!f) {                                                                       // :663-671: no partial files
+        std::remove(fileName.c_str());
+        return Error("write " + fileName + ": short write");
+    }
+    return Error();
+}
+
+// LoadIndex (:682-705).  Like the reference it trusts the file: rows are taken to be sorted on `columns`.
+inline std::pair<std::shared_ptr<Index>, Error> LoadIndex(const std::string& fileName) {
+    std::ifstream f(fileName, std::ios::binary);
+    if (!f) return {nullptr, Error("open " + fileName + ": no such file or directory")};
+    f.seekg(0, std::ios::end);
+    const uint64_t size = (uint64_t)f.tellg();
+    f.seekg(0);
+    const Error bad(fileName + ": not a csvplus index file");
+    char magic[8];
+    if (!f.read(magic, 8) || std::memcmp(magic, detail::kIndexMagic, 8) != 0) return {nullptr, bad};
+    auto index = std::make_shared<Index>();
+    uint64_t ncols, nrows;
+    if (!detail::get_u64(f, &ncols) || ncols > size) return {nullptr, bad};
+    index->impl_columns.resize((size_t)ncols);
+    for (auto& c : index->impl_columns)
+        if (!detail::get_str(f, &c, size)) return {nullptr, bad};
+    if (!detail::get_u64(f, &nrows) || nrows > size) return {nullptr, bad};
+    index->impl_rows.resize((size_t)nrows);
+    for (Row& r : index->impl_rows) {
+        uint64_t nf;
+        if (!detail::get_u64(f, &nf) || nf > size) return {nullptr, bad};
+        for (uint64_t i = 0; i < nf; i++) {
+            std::string k, v;
+            if (!detail::get_str(f, &k, size) || !detail::get_str(f, &v, size)) return {nullptr, bad};
+            r.emplace(std::move(k), std::move(v));
+        }
+    }
+    return {index, Error()};
 }
 
 }  // namespace csvplus

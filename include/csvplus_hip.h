@@ -372,6 +372,41 @@ CPH_API void    cph_csv_table_release(cph_csv_table* t);
 CPH_API int32_t cph_index_find(cph_ctx* ctx, const cph_index* index, const cph_strval* values, int32_t nvalues,
                                uint64_t* lower, uint64_t* upper);
 
+/* ---- ResolveDuplicates support + persistence (csvplus.go:643-705, :810-867) ---- */
+
+/*
+ * Every maximal run of >= 2 equal keys, ascending: group g = sorted positions
+ * [lower[g], upper[g]).  This is what dedup (csvplus.go:810-867) discovers one
+ * group at a time — the adjacent-equal scans :815-819 / :851-855 give
+ * lower[g]+1, the sort.Search :828-830 gives upper[g].  The resolve callback
+ * and the compaction rule (:823-860, including which rows survive) stay with
+ * the caller; cph_index_select then builds the compacted index.
+ * Arrays are host memory owned by the library until cph_groups_release.
+ */
+typedef struct {
+    uint64_t        ngroups;
+    const uint64_t* lower;
+    const uint64_t* upper;
+} cph_groups;
+
+CPH_API int32_t cph_index_dup_groups(cph_ctx* ctx, const cph_index* index, cph_groups** out);
+CPH_API void    cph_groups_release(cph_groups* g);
+
+/* New index = the rows at the given sorted positions of `index` (host array,
+ * strictly ascending, < nrows; CPH_ERR_INVALID otherwise): index.rows[:dest]
+ * after dedup's in-place compaction (csvplus.go:845-863).  Row ids (perm) keep
+ * referring to the original build table. */
+CPH_API int32_t cph_index_select(cph_ctx* ctx, const cph_index* index, const uint64_t* positions, uint64_t n,
+                                 cph_index** out);
+
+/* Index.WriteTo / LoadIndex (csvplus.go:655-705) for the device index: a flat
+ * little-endian file with the key codec, sorted codes and perm.  NOT a gob
+ * stream and without row payload: the row table stays with the caller (the
+ * reference's file holds the rows because there the rows ARE the index).  A
+ * short write removes the file, as the reference does (:663-671). */
+CPH_API int32_t cph_index_save(cph_ctx* ctx, const cph_index* index, const char* path);
+CPH_API int32_t cph_index_load(cph_ctx* ctx, const char* path, cph_index** out);
+
 /* ---- introspection (for benchmarks / roofline accounting) -------------------- */
 
 typedef struct {

@@ -193,3 +193,55 @@ def csv_parse(data: bytes, col_index, comma=b",", comment=None, trim_leading_spa
     lib.orc_csv_parse(p, len(buf), C.byref(o), idx, nc, nbytes, dp, op, C.byref(ek), C.byref(er))
     cols = [StrCol(datas[c][: int(nbytes[c])], offs[c], n, 64) for c in range(nc)]
     return cols, int(ek.value), int(er.value)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# dedup (csvplus.go:810-867), restated line by line over a list of row dicts (small cases only)
+# ---------------------------------------------------------------------------------------------------------------
+def dedup_rows(rows, columns, resolve):
+    """rows: list of dicts sorted on `columns` (the index's rows).  resolve(list_of_rows) -> row dict | {} | raises.
+    Returns the new row list (index.rows[:dest], :863).  Follows the reference literally, tail rule included."""
+    rows = list(rows)
+
+    def equal_rows(a, b):                       # equalRows :759-767
+        return all(a.get(c, "") == b.get(c, "") for c in columns)
+
+    def cmp_gt(i, values):                      # cmp(i, values, false) :907-920
+        for c, v in zip(columns, values):
+            x = rows[i].get(c, "")
+            xb, vb = (x.encode() if isinstance(x, str) else x), (v.encode() if isinstance(v, str) else v)
+            if xb != vb:
+                return xb > vb
+        return False
+
+    n = len(rows)
+    lower = 1
+    while lower < n:                            # :815-819
+        if equal_rows(rows[lower - 1], rows[lower]):
+            break
+        lower += 1
+    if lower >= n:                              # :821-823
+        return rows
+    dest = lower - 1
+    while lower < n:                            # :828
+        values = [rows[lower].get(c, "") for c in columns]
+        lo_i, hi_i = 0, n - lower               # sort.Search :831-833
+        while lo_i < hi_i:
+            h = (lo_i + hi_i) >> 1
+            if not cmp_gt(lower + h, values):
+                lo_i = h + 1
+            else:
+                hi_i = h
+        upper = lower + lo_i
+        row = resolve(rows[lower - 1:upper])    # :838
+        lower = upper + 1                       # :842
+        if len(row) >= len(columns):            # :845-848
+            rows[dest] = row
+            dest += 1
+        while lower < n:                        # :851-859
+            if equal_rows(rows[lower - 1], rows[lower]):
+                break
+            rows[dest] = rows[lower - 1]
+            lower += 1
+            dest += 1
+    return rows[:dest]                          # :862-864

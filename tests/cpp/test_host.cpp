@@ -303,6 +303,98 @@ static void TestErrors() {
     CHECK(e.is_data_source_error() && e.line() == 2);
 }
 
+// ---- TestResolver (csvplus_test.go:695-752) + the resolver part of TestErrors (:843-863) ----------------------------------------
+static void TestResolver() {
+    std::vector<Row> source;
+    CHECK(!SelectColumns(TakeRows(peopleRows), {"id", "name", "surname"})([&](Row r) { source.push_back(std::move(r)); return Error(); }));
+    std::mt19937_64 rng(695);
+    for (int i = 0; i < 25; i++) {
+        std::vector<Row> src = source;
+        const Row dup = src[rng() % src.size()];
+        const int n = (int)(rng() % 100) + 1;
+        for (int j = 0; j < n; j++) {
+            size_t k = rng() % src.size();
+            src.push_back(dup);
+            std::swap(src[k], src.back());
+        }
+        auto [index, err] = TakeRows(src).IndexOn({"name", "surname"});
+        CHECK(!err);
+        int nc = 0;
+        Error e = index->ResolveDuplicates([&](const std::vector<Row>& rows) -> std::pair<Row, Error> {
+            if (++nc != 1) return {Row{}, Error("Unexpected second call to the resolution function")};
+            if ((int)rows.size() != n + 1) return {Row{}, Error("Unexpected number of duplicates")};
+            for (const Row& r : rows)
+                if (r != dup) return {Row{}, Error("Unexpected duplicate")};
+            return {rows[0], Error()};
+        });
+        CHECK(!e && nc == 1);
+        // the surviving rows: one per key, in key order; the reference's tail rule (csvplus.go:851-859) costs the
+        // final row unless the resolved pack was the last one
+        const auto& rows = index->rows();
+        const bool dupIsLast = dup.at("name") == "Olivia" && dup.at("surname") == "Wilson";   // greatest (name, surname)
+        CHECK(rows.size() == source.size() - (dupIsLast ? 0 : 1));
+        for (size_t k = 1; k < rows.size(); k++)
+            CHECK(std::make_pair(rows[k - 1].at("name"), rows[k - 1].at("surname")) < std::make_pair(rows[k].at("name"), rows[k].at("surname")));
+        // and the deduplicated index keeps working as a join target
+        size_t hits = 0;
+        CHECK(!TakeRows(source).Join(index)([&](Row) { hits++; return Error(); }));
+        CHECK(hits == rows.size());
+    }
+    // every key duplicated (TestErrors :843-863): 10 names x 12 surnames -> 10 rows, the last pack reaches the end
+    auto [byName, err] = SelectColumns(TakeRows(peopleRows), {"id", "name", "surname"}).IndexOn({"name"});
+    CHECK(!err);
+    Error e = byName->ResolveDuplicates([&](const std::vector<Row>& rows) -> std::pair<Row, Error> {
+        if ((int)rows.size() != kSurnames) return {Row{}, Error("Unexpected number of duplicate rows")};
+        return {rows[0], Error()};
+    });
+    CHECK(!e && (int)byName->rows().size() == kNames);
+    // hand-derived cases of csvplus.go:810-867: [A,A,B] -> [A]; [A,A,B,C] -> [A,B]; empty row drops the pack
+    auto keysAfter = [&](const std::string& keys, bool drop) -> std::string {
+        std::vector<Row> rows;
+        for (size_t k = 0; k < keys.size(); k++) rows.push_back(Row{{"k", std::string(1, keys[k])}, {"id", std::to_string(k)}});
+        auto [ix, er] = TakeRows(rows).IndexOn({"k"});
+        if (er) return "IndexOn failed";
+        if (ix->ResolveDuplicates([&](const std::vector<Row>& pack) -> std::pair<Row, Error> {
+                return {drop ? Row{} : pack[0], Error()};
+            }))
+            return "ResolveDuplicates failed";
+        std::string out;
+        for (const Row& r : ix->rows()) out += r.at("k");
+        return out;
+    };
+    CHECK(keysAfter("AAB", false) == "A");
+    CHECK(keysAfter("BAAC", false) == "AB");
+    CHECK(keysAfter("ABB", false) == "AB");
+    CHECK(keysAfter("CAB", false) == "ABC");
+    CHECK(keysAfter("AABCC", true) == "B");
+    // a resolver error is returned as is and stops the pass (:835-837)
+    auto [ix3, er3] = TakeRows(std::vector<Row>{{{"k", "x"}}, {{"k", "x"}}, {{"k", "y"}}, {{"k", "y"}}}).IndexOn({"k"});
+    CHECK(!er3);
+    int calls = 0;
+    e = ix3->ResolveDuplicates([&](const std::vector<Row>&) -> std::pair<Row, Error> { calls++; return {Row{}, Error("stop")}; });
+    CHECK(e && e.message() == "stop" && calls == 1 && ix3->rows().size() == 4);
+}
+
+// ---- TestIndexStore (csvplus_test.go:959-1013) ----------------------------------------------------------------------------------
+static void TestIndexStore() {
+    auto [index, err] = SelectColumns(TakeRows(peopleRows), {"id", "name", "surname"}).IndexOn({"id"});
+    CHECK(!err);
+    const std::string path = "/tmp/csvplus_amd_test_index.bin";
+    CHECK(!index->WriteTo(path));
+    auto [index2, err2] = LoadIndex(path);
+    CHECK(!err2 && index2);
+    CHECK(index2->columns() == index->columns());
+    CHECK(index2->rows() == index->rows());
+    // the loaded index is usable: Find goes through the rebuilt device twin
+    size_t found = 0;
+    CHECK(!index2->Find({"17"})([&](Row r) { found += r.at("id") == "17"; return Error(); }));
+    CHECK(found == 1);
+    std::remove(path.c_str());
+    auto [none, err3] = LoadIndex(path);
+    CHECK(none == nullptr && err3);
+    CHECK(index->WriteTo("/nonexistent-dir/x.bin"));
+}
+
 // ---- laziness across the batched boundary ------------------------------------------------------------------------
 static void TestBatchingSemantics() {
     auto [ix, err] = SelectColumns(TakeRows(peopleRows), {"id", "name"}).UniqueIndexOn({"id"});
@@ -338,6 +430,7 @@ int main() {
                        {"TestSorted", TestSorted}, {"TestSimpleTotals", TestSimpleTotals},
                        {"TestLongChain", TestLongChain}, {"TestMultiIndex", TestMultiIndex},
                        {"TestExcept", TestExcept}, {"TestErrors", TestErrors},
+                       {"TestResolver", TestResolver}, {"TestIndexStore", TestIndexStore},
                        {"TestBatchingSemantics", TestBatchingSemantics}};
     int bad = 0;
     for (auto& t : tests) {

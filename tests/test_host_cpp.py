@@ -1,6 +1,6 @@
 """Runs the C++ host-facade tests (tests/cpp/test_host.cpp): the reference's own hot-path tests
 (TestIndexImpl, TestSimpleUniqueJoin, TestSorted, TestSimpleTotals, TestLongChain, TestMultiIndex,
-TestExcept, TestErrors) restated against csvplus_amd/host/csvplus.hpp, which calls the GPU through
+TestExcept, TestErrors, TestResolver, TestIndexStore) restated against csvplus_amd/host/csvplus.hpp, which calls the GPU through
 the C ABI."""
 import subprocess
 from pathlib import Path
@@ -35,4 +35,4 @@ def test_reference_tests_through_cpp_facade():
     print(r.stdout)
     print(r.stderr)
     assert r.returncode == 0, r.stdout[-2000:]
-    assert "0 of 9 host tests failed" in r.stdout
+    assert "0 of 11 host tests failed" in r.stdout
