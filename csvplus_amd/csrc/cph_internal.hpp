@@ -236,6 +236,7 @@ template <class K>
 Status radix_sort_pairs(cph_ctx* ctx, K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b, bool vals_iota,
                         uint64_t n, int bits, K** keys_out, uint32_t** vals_out, int* passes);
 Status exclusive_scan_u32(cph_ctx* ctx, uint32_t* data, uint64_t n);
+Status exclusive_scan_u32_total(cph_ctx* ctx, uint32_t* data, uint64_t n, uint32_t* total_out);   // total_out: device
 Status exclusive_scan_u64(cph_ctx* ctx, uint64_t* data, uint64_t n, uint64_t* total_out);
 Status gather_u64(cph_ctx* ctx, const uint64_t* src, const uint32_t* idx, uint64_t* dst, uint64_t n);
 Status fill_iota_u32(cph_ctx* ctx, uint32_t* dst, uint64_t n);

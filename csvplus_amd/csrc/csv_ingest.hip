@@ -20,15 +20,18 @@
 //   5. per column: exclusive scan of the lengths -> offsets; parse again and copy the bytes
 // A bare quote flips the parity of everything after it, but everything BEFORE the first error is
 // segmented correctly, and only the first error (smallest record index) is reported.
+#include <cstdlib>
 #include <new>
 
-#include "codec_device.hpp"
+#include "lds_stage.hpp"
 
 namespace cph {
 
 constexpr int kCsvThreads = 256;
-constexpr int kCsvPerThread = 16;
-constexpr int kCsvTile = kCsvThreads * kCsvPerThread;   // 4096 bytes per workgroup iteration
+constexpr int kCsvWaves = kCsvThreads / kWave;
+constexpr int kCsvChunks = 4;                                  // 16-byte chunks per thread per tile
+constexpr int kCsvTile = kCsvThreads * 16 * kCsvChunks;       // 16 KiB per workgroup
+constexpr int kCsvStage = 16 * 1024;                          // LDS bytes for one 256-record tile (in, and out)
 
 struct CsvOpts {
     uint8_t comma, comment;   // comment 0 = none
@@ -39,73 +42,155 @@ struct CsvCols {
     int32_t index[kMaxKeyCols];
 };
 
-__device__ __forceinline__ void load16(const uint8_t* d, uint64_t size, uint64_t pos, uint8_t (&b)[kCsvPerThread], int* n) {
-    if (pos + kCsvPerThread <= size) {
-        const uint4 v = *reinterpret_cast<const uint4*>(d + pos);   // d is 16-byte aligned (host side guarantees it)
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int i = 0; i < kCsvPerThread; i++) b[i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
-        *n = kCsvPerThread;
+// ---- byte classification, 16 bytes at a time ---------------------------------------------------------------
+// bit i of the result = (byte i of w == byte of pat)
+__device__ __forceinline__ uint32_t eq_mask4(uint32_t w, uint32_t pat) {
+    const uint32_t x = w ^ pat;
+    const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);   // 0x80 in every zero byte of x
+    return (((z >> 7) * 0x01020408u) >> 24) & 0xFu;
+}
+struct ChunkMasks {
+    uint32_t quote, newline;   // 16-bit masks
+};
+// chunk at byte offset pos (multiple of 16) of the 16-byte aligned text d[0,size); bytes past size read as 0
+__device__ __forceinline__ ChunkMasks chunk_masks(const uint8_t* __restrict__ d, uint64_t size, uint64_t pos) {
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (pos + 16 <= size) {
+        const uint4 v = *reinterpret_cast<const uint4*>(d + pos);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
     } else {
-        int k = 0;
-        for (; pos + k < size && k < kCsvPerThread; k++) b[k] = d[pos + k];
-        *n = k;
+        for (uint64_t k = pos; k < size; k++) w[(k - pos) >> 2] |= (uint32_t)d[k] << (8 * ((k - pos) & 3));
     }
+    ChunkMasks m{0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        m.quote |= eq_mask4(w[i], 0x22222222u) << (4 * i);
+        m.newline |= eq_mask4(w[i], 0x0A0A0A0Au) << (4 * i);
+    }
+    return m;
+}
+// bit i = parity of the bits [0, i] of a 16-bit mask
+__device__ __forceinline__ uint32_t prefix_parity16(uint32_t q) {
+    q ^= q << 1;
+    q ^= q << 2;
+    q ^= q << 4;
+    q ^= q << 8;
+    return q & 0xFFFFu;
 }
 
-// ---- 1. quotes per tile ------------------------------------------------------------------------------
-__global__ __launch_bounds__(kCsvThreads) void k_csv_tile_quotes(const uint8_t* __restrict__ d, uint64_t size,
-                                                                uint32_t* __restrict__ tile_quotes, uint64_t ntiles) {
-    __shared__ uint32_t s_w[kCsvThreads / kWave];
-    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        uint8_t b[kCsvPerThread];
-        int n;
-        load16(d, size, t * kCsvTile + (uint64_t)threadIdx.x * kCsvPerThread, b, &n);
-        uint32_t q = 0;
-        for (int i = 0; i < n; i++) q += b[i] == '"';
-        q = wave_sum(q);
-        if (lane_id() == 0) s_w[wave_id()] = q;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t s = 0;
-            for (int w = 0; w < kCsvThreads / kWave; w++) s += s_w[w];
-            tile_quotes[t] = s;
+// One tile = kCsvChunks rounds of 256 coalesced 16-byte chunks; chunk (j, thread t) covers the bytes at
+// tile_base + (j*256 + t)*16, so text order is j-major.  Computes for every chunk of this thread the mask of
+// newlines at EVEN quote parity, the parity counted from the tile start (start_par = parity at the tile start).
+// s_par: kCsvChunks * kCsvWaves words of LDS.  Contains one __syncthreads.
+struct TileScan {
+    uint32_t even[kCsvChunks];   // newlines outside quotes (given start_par), per chunk
+    uint32_t odd[kCsvChunks];    // newlines inside quotes
+    uint32_t quotes;             // quotes in this thread's chunks
+};
+__device__ __forceinline__ TileScan scan_tile(const uint8_t* __restrict__ d, uint64_t size, uint64_t tile_base, uint32_t start_par,
+                                              uint32_t* s_par) {
+    ChunkMasks m[kCsvChunks];
+    uint32_t lane_par[kCsvChunks];
+    TileScan r;
+    r.quotes = 0;
+#pragma unroll
+    for (int j = 0; j < kCsvChunks; j++) {
+        m[j] = chunk_masks(d, size, tile_base + ((uint64_t)j * kCsvThreads + threadIdx.x) * 16);
+        const uint32_t nq = (uint32_t)__popc(m[j].quote);
+        r.quotes += nq;
+        const unsigned long long b = __ballot(nq & 1u);
+        lane_par[j] = (uint32_t)__popcll(b & lanemask_lt()) & 1u;
+        if (lane_id() == 0) s_par[j * kCsvWaves + wave_id()] = (uint32_t)__popcll(b) & 1u;
+    }
+    __syncthreads();
+    uint32_t run = start_par & 1u;
+#pragma unroll
+    for (int j = 0; j < kCsvChunks; j++) {
+        uint32_t mine = 0;
+#pragma unroll
+        for (int w = 0; w < kCsvWaves; w++) {
+            if (w == wave_id()) mine = run;
+            run ^= s_par[j * kCsvWaves + w];
         }
-        __syncthreads();
+        const uint32_t par = mine ^ lane_par[j];                       // parity at the first byte of this chunk
+        uint32_t inq = prefix_parity16(m[j].quote);                    // relative to the chunk start
+        if (par) inq ^= 0xFFFFu;
+        r.even[j] = m[j].newline & ~inq;
+        r.odd[j] = m[j].newline & inq;
+    }
+    return r;
+}
+
+// ---- 1. per tile: quotes, newlines at even / odd parity relative to the tile start ---------------------------
+__global__ __launch_bounds__(kCsvThreads) void k_csv_tile_stats(const uint8_t* __restrict__ d, uint64_t size,
+                                                               uint32_t* __restrict__ tile_quotes, uint32_t* __restrict__ tile_even,
+                                                               uint32_t* __restrict__ tile_odd) {
+    __shared__ uint32_t s_par[kCsvChunks * kCsvWaves];
+    __shared__ uint32_t s_red[3 * kCsvWaves];
+    const uint64_t t = blockIdx.x;
+    const TileScan r = scan_tile(d, size, t * kCsvTile, 0, s_par);
+    uint32_t ev = 0, od = 0;
+#pragma unroll
+    for (int j = 0; j < kCsvChunks; j++) {
+        ev += (uint32_t)__popc(r.even[j]);
+        od += (uint32_t)__popc(r.odd[j]);
+    }
+    const uint32_t q = wave_sum(r.quotes);
+    ev = wave_sum(ev);
+    od = wave_sum(od);
+    if (lane_id() == 0) {
+        s_red[wave_id()] = q;
+        s_red[kCsvWaves + wave_id()] = ev;
+        s_red[2 * kCsvWaves + wave_id()] = od;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        uint32_t s = 0;
+        for (int w = 0; w < kCsvWaves; w++) s += s_red[threadIdx.x * kCsvWaves + w];
+        (threadIdx.x == 0 ? tile_quotes : threadIdx.x == 1 ? tile_even : tile_odd)[t] = s;
     }
 }
 
-// ---- 2. record separators ('\n' outside quotes) ---------------------------------------------------------
-// WRITE = false: counts per tile; WRITE = true: positions (sep_base = exclusive scan of the counts)
-template <bool WRITE>
+// quotes_before = exclusive scan of tile_quotes.  counts[t] = separators of tile t.
+__global__ void k_csv_pick_counts(const uint32_t* __restrict__ quotes_before, const uint32_t* __restrict__ tile_even,
+                                  const uint32_t* __restrict__ tile_odd, uint64_t* __restrict__ counts, uint64_t ntiles) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < ntiles) counts[t] = (quotes_before[t] & 1u) ? tile_odd[t] : tile_even[t];
+}
+
+// ---- 2. positions of the record separators ('\n' outside quotes), in text order ----------------------------------
 __global__ __launch_bounds__(kCsvThreads) void k_csv_separators(const uint8_t* __restrict__ d, uint64_t size,
                                                                const uint32_t* __restrict__ quotes_before,
-                                                               uint32_t* __restrict__ counts,
-                                                               const uint32_t* __restrict__ sep_base,
-                                                               uint64_t* __restrict__ seps, uint64_t ntiles) {
-    __shared__ uint32_t s_tmp[kCsvThreads / kWave + 1];
-    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        uint8_t b[kCsvPerThread];
-        int n;
-        const uint64_t pos = t * kCsvTile + (uint64_t)threadIdx.x * kCsvPerThread;
-        load16(d, size, pos, b, &n);
-        uint32_t q = 0;
-        for (int i = 0; i < n; i++) q += b[i] == '"';
-        uint32_t total;
-        const uint32_t before = block_exclusive_sum<uint32_t, kCsvThreads>(q, s_tmp, &total) + quotes_before[t];
-        uint32_t par = before & 1u, cnt = 0;
-        uint32_t hit = 0;   // bitmask of separator positions among this thread's bytes
-        for (int i = 0; i < n; i++) {
-            if (b[i] == '"') par ^= 1u;
-            else if (b[i] == '\n' && par == 0) { cnt++; hit |= 1u << i; }
+                                                               const uint64_t* __restrict__ sep_base, uint64_t* __restrict__ seps) {
+    __shared__ uint32_t s_par[kCsvChunks * kCsvWaves];
+    __shared__ uint32_t s_cnt[kCsvChunks * kCsvWaves];
+    const uint64_t t = blockIdx.x;
+    const uint64_t tile_base = t * kCsvTile;
+    const TileScan r = scan_tile(d, size, tile_base, quotes_before[t], s_par);
+    uint32_t incl[kCsvChunks], cnt[kCsvChunks];
+#pragma unroll
+    for (int j = 0; j < kCsvChunks; j++) {
+        cnt[j] = (uint32_t)__popc(r.even[j]);
+        incl[j] = wave_inclusive_sum(cnt[j]);
+        if (lane_id() == kWave - 1) s_cnt[j * kCsvWaves + wave_id()] = incl[j];
+    }
+    __syncthreads();
+    uint64_t run = sep_base[t];
+#pragma unroll
+    for (int j = 0; j < kCsvChunks; j++) {
+        uint64_t mine = 0;
+#pragma unroll
+        for (int w = 0; w < kCsvWaves; w++) {
+            if (w == wave_id()) mine = run;
+            run += s_cnt[j * kCsvWaves + w];
         }
-        const uint32_t ex = block_exclusive_sum<uint32_t, kCsvThreads>(cnt, s_tmp, &total);
-        if (!WRITE) {
-            if (threadIdx.x == 0) counts[t] = total;
-        } else {
-            uint64_t o = (uint64_t)sep_base[t] + ex;
-            for (int i = 0; i < n; i++)
-                if (hit & (1u << i)) seps[o++] = pos + i;
+        uint64_t o = mine + incl[j] - cnt[j];
+        const uint64_t pos = tile_base + ((uint64_t)j * kCsvThreads + threadIdx.x) * 16;
+        uint32_t mk = r.even[j];
+        while (mk) {
+            const int b = __ffs(mk) - 1;
+            mk &= mk - 1;
+            seps[o++] = pos + b;
         }
     }
 }
@@ -120,9 +205,12 @@ __device__ __forceinline__ void segment_range(const uint8_t* d, const uint64_t* 
     *e = end;
 }
 
+// stats[0] += kept segments; stats[1] = 1 if a segment other than the last one was dropped; stats[2] = 1 if unsupported
 __global__ void k_csv_classify(const uint8_t* __restrict__ d, const uint64_t* __restrict__ seps, uint64_t nseg, CsvOpts o,
-                               uint32_t* __restrict__ keep, uint32_t* __restrict__ unsupported) {
+                               uint32_t* __restrict__ keep, unsigned long long* __restrict__ stats) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t kept = 0;
+    bool dropped_inner = false;
     for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += stride) {
         uint64_t b, e;
         segment_range(d, seps, s, &b, &e);
@@ -132,27 +220,65 @@ __global__ void k_csv_classify(const uint8_t* __restrict__ d, const uint64_t* __
             k = 0;
             // a comment is skipped WITHOUT interpreting its quotes; the parity model cannot do that
             for (uint64_t i = b; i < e; i++)
-                if (d[i] == '"') atomicExch(unsupported, 1u);
+                if (d[i] == '"') atomicExch(&stats[2], 1ull);
         }
         keep[s] = k;
+        kept += k;
+        dropped_inner |= !k && s + 1 < nseg;
+    }
+    if (__any(dropped_inner) && lane_id() == 0) atomicExch(&stats[1], 1ull);
+    __shared__ uint32_t s_kept[4];
+    kept = wave_sum(kept);
+    if (lane_id() == 0) s_kept[wave_id()] = kept;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = s_kept[0] + s_kept[1] + s_kept[2] + s_kept[3];
+        if (total) atomicAdd(&stats[0], (unsigned long long)total);
     }
 }
 
-__global__ void k_csv_compact(const uint8_t* __restrict__ d, const uint64_t* __restrict__ seps, uint64_t nseg,
-                              const uint32_t* __restrict__ keep_scan, const uint32_t* __restrict__ keep_flag,
-                              uint64_t* __restrict__ rec_b, uint64_t* __restrict__ rec_e) {
+// rec_e keeps the RAW end (a trailing '\r' is stripped by the parser, which reads it from LDS)
+__global__ void k_csv_compact(const uint64_t* __restrict__ seps, uint64_t nseg, const uint32_t* __restrict__ keep_scan,
+                              const uint32_t* __restrict__ keep_flag, uint64_t* __restrict__ rec_b, uint64_t* __restrict__ rec_e) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += stride) {
         if (!keep_flag[s]) continue;
-        uint64_t b, e;
-        segment_range(d, seps, s, &b, &e);
-        rec_b[keep_scan[s]] = b;
-        rec_e[keep_scan[s]] = e;
+        rec_b[keep_scan[s]] = s ? seps[s - 1] + 1 : 0;
+        rec_e[keep_scan[s]] = seps[s];
     }
 }
 
+// Where record r lies in the text: [b, e) with e the RAW end (the separator position, or the text size).
+// Identity mode (seps != NULL): no segment was dropped except possibly the last, so record r IS segment r.
+struct RecIndex {
+    const uint64_t* seps;
+    const uint64_t* rec_b;
+    const uint64_t* rec_e;
+    __device__ __forceinline__ void get(uint64_t r, uint64_t* b, uint64_t* e) const {
+        if (seps) {
+            *b = r ? seps[r - 1] + 1 : 0;
+            *e = seps[r];
+        } else {
+            *b = rec_b[r];
+            *e = rec_e[r];
+        }
+    }
+};
+
 // ---- 4. the sequential field parser (one record) ---------------------------------------------------------------
-__device__ __forceinline__ bool rune_is_space_at(const uint8_t* d, uint64_t p, uint64_t e, int* len) {
+// Text sources: global memory, or the tile's bytes staged in LDS (addressed by their global offset).
+struct GlobalSrc {
+    const uint8_t* d;
+    __device__ __forceinline__ uint8_t operator[](uint64_t p) const { return d[p]; }
+};
+struct LdsSrc {
+    const CPH_LDS uint8_t* s;   // holds the text from global offset `base` on
+    uint64_t base;
+    __device__ __forceinline__ uint8_t operator[](uint64_t p) const { return s[p - base]; }
+};
+
+template <class Src>
+__device__ __forceinline__ bool rune_is_space_at(const Src& d, uint64_t p, uint64_t e, int* len) {
     const uint32_t b0 = d[p], b1 = p + 1 < e ? d[p + 1] : 0, b2 = p + 2 < e ? d[p + 2] : 0;
     *len = b0 < 0x80 ? 1 : (b0 < 0xE0 ? 2 : 3);
     if (b0 < 0x80) return b0 == ' ' || (b0 >= 9 && b0 <= 13);
@@ -169,10 +295,10 @@ __device__ __forceinline__ bool rune_is_space_at(const uint8_t* d, uint64_t p, u
 enum { kCsvOk = 0, kCsvBareQuote = CPH_CSV_ERR_BARE_QUOTE, kCsvQuote = CPH_CSV_ERR_QUOTE,
        kCsvFieldCount = CPH_CSV_ERR_FIELD_COUNT };
 
-// Sink: put(field, byte).  Returns the number of fields; *err = kind of the first problem.
-template <class Sink>
-__device__ __forceinline__ int csv_parse_record(const uint8_t* __restrict__ d, uint64_t b, uint64_t e, const CsvOpts& o, Sink& s,
-                                                int* err) {
+// Sink: begin(field) ... put(byte)* ... end(field) for every COMPLETE field.  Returns the number of fields;
+// *err = kind of the first problem (the field it happens in is never end()ed).
+template <class Src, class Sink>
+__device__ __forceinline__ int csv_parse_record(const Src& d, uint64_t b, uint64_t e, const CsvOpts& o, Sink& s, int* err) {
     uint64_t p = b;
     int field = 0;
     *err = kCsvOk;
@@ -185,65 +311,192 @@ __device__ __forceinline__ int csv_parse_record(const uint8_t* __restrict__ d, u
         if (p >= e || d[p] != '"') {   // unquoted field
             uint64_t i = p;
             bool bare = false;
-            while (i < e && d[i] != o.comma) {
-                bare |= d[i] == '"';
+            while (i < e) {
+                const uint8_t c = d[i];
+                if (c == o.comma) break;
+                bare |= c == '"';
                 i++;
             }
             if (bare) { *err = kCsvBareQuote; return field + 1; }
-            for (uint64_t k = p; k < i; k++) s.put(field, d[k]);
+            s.begin(field);
+            if (s.wanted())
+                for (uint64_t k = p; k < i; k++) s.put(d[k]);
+            else
+                s.skip(i - p);
+            s.end(field);
             field++;
             if (i < e) { p = i + 1; continue; }
             return field;
         }
         p++;   // quoted field
+        s.begin(field);
         for (;;) {
-            while (p < e && d[p] != '"') {
+            while (p < e) {
                 const uint8_t c = d[p];
+                if (c == '"') break;
                 if (c == '\r' && p + 1 < e && d[p + 1] == '\n') { p++; continue; }   // "\r\n" -> "\n" inside quotes
-                s.put(field, c);
+                s.put(c);
                 p++;
             }
             if (p >= e) { *err = kCsvQuote; return field + 1; }   // no closing quote before the record ends
             p++;
-            if (p < e && d[p] == '"') { s.put(field, '"'); p++; continue; }
-            if (p < e && d[p] == o.comma) { p++; field++; break; }
-            if (p == e) return field + 1;
+            if (p < e && d[p] == '"') { s.put('"'); p++; continue; }
+            if (p < e && d[p] == o.comma) { p++; s.end(field); field++; break; }
+            if (p == e) { s.end(field); return field + 1; }
             *err = kCsvQuote;
             return field + 1;
         }
     }
 }
 
+// length of every wanted field -> lens[c][r] (no per-thread arrays: the store happens when the field ends)
+template <class OT>
 struct LenSink {
     const CsvCols* cols;
-    uint64_t len[kMaxKeyCols];
-    __device__ __forceinline__ void put(int field, uint8_t) {
+    OT* lens;            // column c, this record: lens[c * stride]
+    uint64_t stride;
+    uint64_t flen;
+    __device__ __forceinline__ void begin(int) { flen = 0; }
+    __device__ __forceinline__ bool wanted() const { return false; }
+    __device__ __forceinline__ void skip(uint64_t n) { flen += n; }
+    __device__ __forceinline__ void put(uint8_t) { flen++; }
+    __device__ __forceinline__ void end(int field) {
         for (int c = 0; c < cols->ncols; c++)
-            if (cols->index[c] == field) len[c]++;
-    }
-};
-struct CopySink {
-    const CsvCols* cols;
-    uint8_t* out[kMaxKeyCols];
-    __device__ __forceinline__ void put(int field, uint8_t b) {
-        for (int c = 0; c < cols->ncols; c++)
-            if (cols->index[c] == field) *out[c]++ = b;
+            if (cols->index[c] == field) lens[(uint64_t)c * stride] = (OT)flen;
     }
 };
 
-__global__ void k_csv_fields(const uint8_t* __restrict__ d, const uint64_t* __restrict__ rec_b, const uint64_t* __restrict__ rec_e,
-                             uint64_t nrec, CsvOpts o, CsvCols cols, uint64_t* __restrict__ lens /* [ncols][nrec] */,
-                             uint32_t* __restrict__ nfields, unsigned long long* __restrict__ err_key) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrec; r += stride) {
-        LenSink s;
-        s.cols = &cols;
-        for (int c = 0; c < cols.ncols; c++) s.len[c] = 0;
-        int err;
-        const int nf = csv_parse_record(d, rec_b[r], rec_e[r], o, s, &err);
-        nfields[r] = (uint32_t)nf;
-        for (int c = 0; c < cols.ncols; c++) lens[(uint64_t)c * nrec + r] = s.len[c];
-        if (err) atomicMin(err_key, ((unsigned long long)r << 3) | (unsigned long long)err);
+// bytes of every wanted field -> its column.  DestFn(c) = where column c's value of this record starts.
+template <class Ptr, class DestFn>
+struct CopySink {
+    const CsvCols* cols;
+    DestFn dest;
+    Ptr cur;
+    uint32_t want;      // columns that take the current field
+    uint64_t k;         // bytes of the current field so far
+    __device__ __forceinline__ void begin(int field) {
+        want = 0;
+        k = 0;
+        for (int c = 0; c < cols->ncols; c++)
+            if (cols->index[c] == field) want |= 1u << c;
+        if (want) cur = dest(__ffs(want) - 1);
+    }
+    __device__ __forceinline__ bool wanted() const { return want != 0; }
+    __device__ __forceinline__ void skip(uint64_t) {}
+    __device__ __forceinline__ void put(uint8_t b) {
+        if (!want) return;
+        cur[k] = b;
+        uint32_t more = want & (want - 1);   // the same field requested by several columns: rare
+        while (more) {
+            dest(__ffs(more) - 1)[k] = b;
+            more &= more - 1;
+        }
+        k++;
+    }
+    __device__ __forceinline__ void end(int) {}
+};
+
+constexpr int kCsvMaskHalves = kCsvStage / 16 + 8;   // one 16-bit mask per staged 16-byte chunk (+ slack for 64-bit reads)
+
+// Stages the text [gb, ge) (gb multiple of 16) into LDS with coalesced 16-byte loads, and with it one bit per
+// byte for "is the delimiter" / "is a quote": bit j of the 64-bit word w of a mask = byte gb + 64*w + j.
+__device__ __forceinline__ void stage_text(const uint8_t* __restrict__ d, uint64_t size, uint64_t gb, uint64_t ge, uint8_t comma,
+                                           CPH_LDS uint8_t* stage, CPH_LDS uint16_t* comma_mask, CPH_LDS uint16_t* quote_mask) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t cpat = 0x01010101u * comma;
+    for (uint64_t off = (uint64_t)threadIdx.x * 16; gb + off < ge; off += (uint64_t)kCsvThreads * 16) {
+        u32x4 v = {0, 0, 0, 0};
+        if (gb + off + 16 <= size) {
+            v = *reinterpret_cast<const u32x4*>(d + gb + off);
+        } else {
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (uint64_t q = gb + off; q < size; q++) w[(q - gb - off) >> 2] |= (uint32_t)d[q] << (8 * ((q - gb - off) & 3));
+            v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+        }
+        *(CPH_LDS u32x4*)(stage + off) = v;
+        comma_mask[off >> 4] = (uint16_t)(eq_mask4(v.x, cpat) | eq_mask4(v.y, cpat) << 4 | eq_mask4(v.z, cpat) << 8 | eq_mask4(v.w, cpat) << 12);
+        quote_mask[off >> 4] = (uint16_t)(eq_mask4(v.x, 0x22222222u) | eq_mask4(v.y, 0x22222222u) << 4 | eq_mask4(v.z, 0x22222222u) << 8 |
+                                          eq_mask4(v.w, 0x22222222u) << 12);
+    }
+}
+
+// first set bit at a position in [p, e) of a staged mask (positions relative to the stage start), or e
+__device__ __forceinline__ uint32_t next_set(const CPH_LDS uint64_t* mask, uint32_t p, uint32_t e) {
+    uint32_t w = p >> 6;
+    uint64_t m = mask[w] & (~0ull << (p & 63));
+    while (m == 0) {
+        w++;
+        if (w * 64 >= e) return e;
+        m = mask[w];
+    }
+    const uint32_t pos = w * 64 + (uint32_t)__ffsll((long long)m) - 1;
+    return pos < e ? pos : e;
+}
+
+// A record without any quote (and no TrimLeadingSpace): its fields are the runs between delimiters.
+template <class Sink>
+__device__ __forceinline__ int csv_split_plain(const LdsSrc& src, const CPH_LDS uint64_t* comma_mask, uint64_t b, uint64_t e, Sink& s) {
+    uint32_t p = (uint32_t)(b - src.base);
+    const uint32_t end = (uint32_t)(e - src.base);
+    int field = 0;
+    for (;;) {
+        const uint32_t c = p < end ? next_set(comma_mask, p, end) : end;
+        s.begin(field);
+        if (s.wanted())
+            for (uint32_t k = p; k < c; k++) s.put(src.s[k]);
+        else
+            s.skip(c - p);
+        s.end(field);
+        field++;
+        if (c >= end) return field;
+        p = c + 1;
+    }
+}
+
+// One tile = 256 consecutive records, one per thread.  Every thread first loads its own record bounds (one
+// global latency for the whole tile: the tile's text range is thread 0's begin .. the last thread's end).
+template <class OT>
+__global__ __launch_bounds__(kCsvThreads) void k_csv_fields(const uint8_t* __restrict__ d, uint64_t size, RecIndex ri, uint64_t nrec,
+                                                           CsvOpts o, CsvCols cols, OT* __restrict__ lens /* [ncols][nrec+1] */,
+                                                           uint32_t* __restrict__ nfields, unsigned long long* __restrict__ err_key) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[kCsvStage + 16];
+    __shared__ __attribute__((aligned(16))) uint16_t s_cm[kCsvMaskHalves], s_qm[kCsvMaskHalves];
+    __shared__ uint64_t s_range[2];
+    CPH_LDS uint8_t* stage = (CPH_LDS uint8_t*)s_in;
+    for (uint64_t r0 = (uint64_t)blockIdx.x * kCsvThreads; r0 < nrec; r0 += (uint64_t)gridDim.x * kCsvThreads) {
+        const uint64_t rend = r0 + kCsvThreads < nrec ? r0 + kCsvThreads : nrec;
+        const uint64_t r = r0 + threadIdx.x;
+        uint64_t b = 0, e = 0;
+        if (r < rend) {
+            ri.get(r, &b, &e);
+            if (threadIdx.x == 0) s_range[0] = b & ~15ull;
+            if (r == rend - 1) s_range[1] = e;
+        }
+        __syncthreads();
+        const uint64_t gb = s_range[0], ge = s_range[1];
+        const bool staged = ge - gb <= (uint64_t)kCsvStage;
+        if (staged) stage_text(d, size, gb, ge, o.comma, stage, (CPH_LDS uint16_t*)s_cm, (CPH_LDS uint16_t*)s_qm);
+        __syncthreads();
+        if (r < rend) {
+            LenSink<OT> s{&cols, lens + r, nrec + 1, 0};
+            int err = 0, nf;
+            if (staged) {
+                const LdsSrc src{stage, gb};
+                if (e > b && src[e - 1] == '\r') e--;
+                if (!o.trim && next_set((const CPH_LDS uint64_t*)s_qm, (uint32_t)(b - gb), (uint32_t)(e - gb)) == (uint32_t)(e - gb))
+                    nf = csv_split_plain(src, (const CPH_LDS uint64_t*)s_cm, b, e, s);
+                else
+                    nf = csv_parse_record(src, b, e, o, s, &err);
+            } else {
+                const GlobalSrc src{d};
+                if (e > b && src[e - 1] == '\r') e--;
+                nf = csv_parse_record(src, b, e, o, s, &err);
+            }
+            nfields[r] = (uint32_t)nf;
+            for (int c = 0; c < cols.ncols; c++)   // a record with fewer fields: the value is ""
+                if (cols.index[c] >= nf || err) lens[(uint64_t)c * (nrec + 1) + r] = 0;
+            if (err) atomicMin(err_key, ((unsigned long long)r << 3) | (unsigned long long)err);
+        }
     }
 }
 
@@ -255,16 +508,96 @@ __global__ void k_csv_check_counts(const uint32_t* __restrict__ nfields, uint64_
         if (nfields[r] != expected) atomicMin(err_key, ((unsigned long long)r << 3) | (unsigned long long)kCsvFieldCount);
 }
 
-__global__ void k_csv_copy_fields(const uint8_t* __restrict__ d, const uint64_t* __restrict__ rec_b,
-                                  const uint64_t* __restrict__ rec_e, uint64_t first, uint64_t nout, CsvOpts o, CsvCols cols,
-                                  const uint64_t* __restrict__ offs /* [ncols][nout+1] */, uint8_t* const* __restrict__ out_data) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nout; r += stride) {
-        CopySink s;
-        s.cols = &cols;
-        for (int c = 0; c < cols.ncols; c++) s.out[c] = out_data[c] + offs[(uint64_t)c * (nout + 1) + r];
-        int err;
-        csv_parse_record(d, rec_b[first + r], rec_e[first + r], o, s, &err);
+// offs: column c's offsets start at offs + c * stride (nout + 1 entries, the exclusive scan of the lengths);
+// output record r is input record first + r.
+template <class OT>
+struct GlobalDest {
+    uint8_t* const* out_data;
+    const OT* offs;
+    uint64_t stride, r;
+    __device__ __forceinline__ uint8_t* operator()(int c) const { return out_data[c] + offs[(uint64_t)c * stride + r]; }
+};
+struct LdsDest {
+    CPH_LDS uint8_t* stage;
+    const CPH_LDS uint32_t* colstart;    // start of column c's region (already shifted by obase & 15)
+    const CPH_LDS uint32_t* off32;       // low 32 bits of offs[c][r0 + i] at [c * (kCsvThreads + 1) + i]
+    uint32_t i;                          // this thread's record within the tile
+    __device__ __forceinline__ CPH_LDS uint8_t* operator()(int c) const {
+        const CPH_LDS uint32_t* oc = off32 + c * (kCsvThreads + 1);
+        return stage + colstart[c] + (oc[i] - oc[0]);   // modular difference: a tile's span is far below 4 GiB
+    }
+};
+
+// dynamic LDS: text stage | output stage | delimiter mask | quote mask | off32[ncols][257]
+template <class OT>
+__global__ __launch_bounds__(kCsvThreads) void k_csv_copy_fields(const uint8_t* __restrict__ d, uint64_t size, RecIndex ri, uint64_t first,
+                                                                uint64_t nout, CsvOpts o, CsvCols cols, const OT* __restrict__ offs,
+                                                                uint64_t stride, uint8_t* const* __restrict__ out_data) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ uint32_t s_colstart[kMaxKeyCols];
+    __shared__ uint64_t s_obase[kMaxKeyCols];
+    __shared__ uint64_t s_range[2];
+    constexpr uint32_t kOutCap = kCsvStage + 32 * kMaxKeyCols;
+    CPH_LDS uint8_t* stage = (CPH_LDS uint8_t*)smem;
+    CPH_LDS uint8_t* ostage = stage + (kCsvStage + 16);
+    CPH_LDS uint16_t* cmask = (CPH_LDS uint16_t*)(ostage + kOutCap);
+    CPH_LDS uint16_t* qmask = cmask + kCsvMaskHalves;
+    CPH_LDS uint32_t* off32 = (CPH_LDS uint32_t*)(qmask + kCsvMaskHalves);
+    for (uint64_t r0 = (uint64_t)blockIdx.x * kCsvThreads; r0 < nout; r0 += (uint64_t)gridDim.x * kCsvThreads) {
+        const uint64_t rend = r0 + kCsvThreads < nout ? r0 + kCsvThreads : nout;
+        const uint32_t nt = (uint32_t)(rend - r0);
+        const uint64_t r = r0 + threadIdx.x;
+        uint64_t b = 0, e = 0;
+        if (r < rend) {
+            ri.get(first + r, &b, &e);
+            if (threadIdx.x == 0) s_range[0] = b & ~15ull;
+            if (r == rend - 1) s_range[1] = e;
+        }
+        for (int c = 0; c < cols.ncols; c++) {   // independent loads: one latency for all columns
+            const OT* oc = offs + (uint64_t)c * stride + r0;
+            if (threadIdx.x <= nt - 1) off32[c * (kCsvThreads + 1) + threadIdx.x] = (uint32_t)oc[threadIdx.x];
+            if (threadIdx.x == 0) {
+                off32[c * (kCsvThreads + 1) + nt] = (uint32_t)oc[nt];
+                s_obase[c] = oc[0];
+            }
+        }
+        __syncthreads();
+        const uint64_t gb = s_range[0], ge = s_range[1];
+        uint32_t pos = 0;
+        bool fits = ge - gb <= (uint64_t)kCsvStage;
+        for (int c = 0; c < cols.ncols && fits; c++) {
+            const uint32_t span = off32[c * (kCsvThreads + 1) + nt] - off32[c * (kCsvThreads + 1)];
+            if (threadIdx.x == 0) s_colstart[c] = pos + (uint32_t)(s_obase[c] & 15);
+            if (span > kOutCap || pos + ((span + 31) & ~15u) > kOutCap) fits = false;
+            pos += (span + 31) & ~15u;
+        }
+        if (fits) stage_text(d, size, gb, ge, o.comma, stage, cmask, qmask);
+        __syncthreads();
+        if (r < rend) {
+            int err;
+            if (fits) {
+                const LdsSrc src{stage, gb};
+                if (e > b && src[e - 1] == '\r') e--;
+                CopySink<CPH_LDS uint8_t*, LdsDest> s{
+                    &cols, LdsDest{ostage, (const CPH_LDS uint32_t*)s_colstart, off32, (uint32_t)threadIdx.x}, nullptr, 0, 0};
+                if (!o.trim && next_set((const CPH_LDS uint64_t*)qmask, (uint32_t)(b - gb), (uint32_t)(e - gb)) == (uint32_t)(e - gb))
+                    csv_split_plain(src, (const CPH_LDS uint64_t*)cmask, b, e, s);
+                else
+                    csv_parse_record(src, b, e, o, s, &err);
+            } else {
+                const GlobalSrc src{d};
+                if (e > b && src[e - 1] == '\r') e--;
+                CopySink<uint8_t*, GlobalDest<OT>> s{&cols, GlobalDest<OT>{out_data, offs, stride, r}, nullptr, 0, 0};
+                csv_parse_record(src, b, e, o, s, &err);
+            }
+        }
+        __syncthreads();
+        if (fits)
+            for (int c = 0; c < cols.ncols; c++) {
+                const uint32_t span = off32[c * (kCsvThreads + 1) + nt] - off32[c * (kCsvThreads + 1)];
+                flush_stage(ostage + (s_colstart[c] - (uint32_t)(s_obase[c] & 15)), out_data[c], s_obase[c], span);
+            }
+        __syncthreads();
     }
 }
 
@@ -334,76 +667,97 @@ CPH_API int32_t cph_csv_parse(cph_ctx* ctx, const uint8_t* data, uint64_t size, 
             d = staged.as<uint8_t>();
         }
         uint64_t nrec = 0;
-        DevBuf rec_b, rec_e, lens, nfields, errk;
+        DevBuf rec_b, rec_e, nfields, errk, seps_keep;
+        RecIndex ri{nullptr, nullptr, nullptr};
         uint64_t first = 0, nout = 0;
         t->pub.error_kind = 0;
         t->pub.error_record = 0;
         if (size) {
             const uint64_t ntiles = (size + kCsvTile - 1) / kCsvTile;
-            const unsigned tgrid = (unsigned)std::min<uint64_t>(ntiles, 4096);
-            DevBuf tq, cnt;
+            if (ntiles > 0x7FFFFFFFull) return {CPH_ERR_INVALID, "text too large"};
+            DevBuf tq, tev, tod, cnt;
             CPH_TRY(tq.alloc(&ctx->pool, ntiles * sizeof(uint32_t)));
-            CPH_TRY(cnt.alloc(&ctx->pool, (ntiles + 1) * sizeof(uint32_t)));
+            CPH_TRY(tev.alloc(&ctx->pool, ntiles * sizeof(uint32_t)));
+            CPH_TRY(tod.alloc(&ctx->pool, ntiles * sizeof(uint32_t)));
+            CPH_TRY(cnt.alloc(&ctx->pool, (ntiles + 1) * sizeof(uint64_t)));
             {
-                ProfScope ps(ctx, "k_csv_tile_quotes", (double)size);
-                hipLaunchKernelGGL(k_csv_tile_quotes, dim3(tgrid), dim3(kCsvThreads), 0, ctx->stream, d, size, tq.as<uint32_t>(), ntiles);
+                ProfScope ps(ctx, "k_csv_tile_stats", (double)size);
+                hipLaunchKernelGGL(k_csv_tile_stats, dim3((unsigned)ntiles), dim3(kCsvThreads), 0, ctx->stream, d, size,
+                                   tq.as<uint32_t>(), tev.as<uint32_t>(), tod.as<uint32_t>());
             }
-            CPH_TRY(exclusive_scan_u32(ctx, tq.as<uint32_t>(), ntiles));
-            {
-                ProfScope ps(ctx, "k_csv_separators", (double)size);
-                hipLaunchKernelGGL(k_csv_separators<false>, dim3(tgrid), dim3(kCsvThreads), 0, ctx->stream, d, size,
-                                   tq.as<uint32_t>(), cnt.as<uint32_t>(), (const uint32_t*)nullptr, (uint64_t*)nullptr, ntiles);
-            }
-            // total number of separators: last count + its exclusive prefix
-            uint32_t last_cnt = 0, last_ex = 0;
-            CPH_TRY(read_back(ctx, cnt.as<uint32_t>() + (ntiles - 1), &last_cnt));
-            CPH_TRY(exclusive_scan_u32(ctx, cnt.as<uint32_t>(), ntiles));
-            CPH_TRY(read_back(ctx, cnt.as<uint32_t>() + (ntiles - 1), &last_ex));
-            const uint64_t nsep = (uint64_t)last_ex + last_cnt;
+            CPH_TRY(exclusive_scan_u32(ctx, tq.as<uint32_t>(), ntiles));   // mod 2^32 keeps the parity
+            hipLaunchKernelGGL(k_csv_pick_counts, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, ctx->stream, tq.as<uint32_t>(),
+                               tev.as<uint32_t>(), tod.as<uint32_t>(), cnt.as<uint64_t>(), ntiles);
+            CPH_TRY(exclusive_scan_u64(ctx, cnt.as<uint64_t>(), ntiles, cnt.as<uint64_t>() + ntiles));
+            uint64_t nsep = 0;
+            CPH_TRY(read_back(ctx, cnt.as<uint64_t>() + ntiles, &nsep));
             const uint64_t nseg = nsep + 1;   // the bytes after the last separator (possibly none) form the last segment
+            if (nseg > 0xFFFFFFFFull) return {CPH_ERR_TOO_MANY_ROWS, "more than 2^32-1 lines"};
             DevBuf seps;
             CPH_TRY(seps.alloc(&ctx->pool, nseg * sizeof(uint64_t)));
             {
                 ProfScope ps(ctx, "k_csv_separators", (double)size + 8.0 * (double)nsep);
-                hipLaunchKernelGGL(k_csv_separators<true>, dim3(tgrid), dim3(kCsvThreads), 0, ctx->stream, d, size,
-                                   tq.as<uint32_t>(), (uint32_t*)nullptr, cnt.as<uint32_t>(), seps.as<uint64_t>(), ntiles);
+                hipLaunchKernelGGL(k_csv_separators, dim3((unsigned)ntiles), dim3(kCsvThreads), 0, ctx->stream, d, size,
+                                   tq.as<uint32_t>(), cnt.as<uint64_t>(), seps.as<uint64_t>());
             }
             hipLaunchKernelGGL(k_csv_set_u64, dim3(1), dim3(1), 0, ctx->stream, seps.as<uint64_t>() + nsep, size);
-            // classify + compact
-            DevBuf keep, keep_flag, unsup;
-            CPH_TRY(keep.alloc(&ctx->pool, nseg * sizeof(uint32_t)));
+            // classify; compact only when a line in the middle of the text was dropped (blank / comment)
+            DevBuf keep_flag, stats;
             CPH_TRY(keep_flag.alloc(&ctx->pool, nseg * sizeof(uint32_t)));
-            CPH_TRY(unsup.alloc(&ctx->pool, sizeof(uint32_t)));
-            CPH_HIP_TRY(hipMemsetAsync(unsup.get(), 0, sizeof(uint32_t), ctx->stream));
-            hipLaunchKernelGGL(k_csv_classify, dim3(grid_for_rows(nseg)), dim3(256), 0, ctx->stream, d, seps.as<uint64_t>(), nseg, o,
-                               keep_flag.as<uint32_t>(), unsup.as<uint32_t>());
-            CPH_HIP_TRY(hipMemcpyAsync(keep.get(), keep_flag.get(), nseg * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
-            uint32_t last_flag = 0, last_scan = 0, unsupported = 0;
-            CPH_TRY(read_back(ctx, keep_flag.as<uint32_t>() + (nseg - 1), &last_flag));
-            CPH_TRY(exclusive_scan_u32(ctx, keep.as<uint32_t>(), nseg));
-            CPH_TRY(read_back(ctx, keep.as<uint32_t>() + (nseg - 1), &last_scan));
-            CPH_TRY(read_back(ctx, unsup.as<uint32_t>(), &unsupported));
-            if (unsupported) return {CPH_ERR_INVALID, "comment line containing a quote: not supported by the GPU parser"};
-            nrec = (uint64_t)last_scan + last_flag;
+            CPH_TRY(stats.alloc(&ctx->pool, 3 * sizeof(unsigned long long)));
+            CPH_HIP_TRY(hipMemsetAsync(stats.get(), 0, 3 * sizeof(unsigned long long), ctx->stream));
+            {
+                ProfScope ps(ctx, "k_csv_classify", 13.0 * (double)nseg);
+                hipLaunchKernelGGL(k_csv_classify, dim3(std::min(grid_for_rows(nseg), 2048u)), dim3(256), 0, ctx->stream, d, seps.as<uint64_t>(), nseg, o,
+                                   keep_flag.as<uint32_t>(), stats.as<unsigned long long>());
+            }
+            CPH_TRY(ensure_pinned_scratch(ctx, 3 * sizeof(unsigned long long)));
+            CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, stats.get(), 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+            CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+            const unsigned long long* hs = static_cast<const unsigned long long*>(ctx->pinned_scratch);
+            nrec = hs[0];
+            const bool dropped_inner = hs[1] != 0;
+            if (hs[2]) return {CPH_ERR_INVALID, "comment line containing a quote: not supported by the GPU parser"};
             if (nrec > 0xFFFFFFFFull) return {CPH_ERR_TOO_MANY_ROWS, "more than 2^32-1 records"};
-            CPH_TRY(rec_b.alloc(&ctx->pool, (nrec + 1) * sizeof(uint64_t)));
-            CPH_TRY(rec_e.alloc(&ctx->pool, (nrec + 1) * sizeof(uint64_t)));
-            hipLaunchKernelGGL(k_csv_compact, dim3(grid_for_rows(nseg)), dim3(256), 0, ctx->stream, d, seps.as<uint64_t>(), nseg,
-                               keep.as<uint32_t>(), keep_flag.as<uint32_t>(), rec_b.as<uint64_t>(), rec_e.as<uint64_t>());
+            if (!dropped_inner) {
+                ri.seps = seps.as<uint64_t>();   // record r is segment r
+                seps_keep = std::move(seps);
+            } else {
+                DevBuf keep;
+                CPH_TRY(keep.alloc(&ctx->pool, nseg * sizeof(uint32_t)));
+                CPH_HIP_TRY(hipMemcpyAsync(keep.get(), keep_flag.get(), nseg * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+                CPH_TRY(exclusive_scan_u32(ctx, keep.as<uint32_t>(), nseg));
+                CPH_TRY(rec_b.alloc(&ctx->pool, (nrec + 1) * sizeof(uint64_t)));
+                CPH_TRY(rec_e.alloc(&ctx->pool, (nrec + 1) * sizeof(uint64_t)));
+                ProfScope ps(ctx, "k_csv_compact", 32.0 * (double)nseg);
+                hipLaunchKernelGGL(k_csv_compact, dim3(grid_for_rows(nseg)), dim3(256), 0, ctx->stream, seps.as<uint64_t>(), nseg,
+                                   keep.as<uint32_t>(), keep_flag.as<uint32_t>(), rec_b.as<uint64_t>(), rec_e.as<uint64_t>());
+                ri.rec_b = rec_b.as<uint64_t>();
+                ri.rec_e = rec_e.as<uint64_t>();
+            }
             CPH_HIP_TRY(hipGetLastError());
         }
-        // fields: lengths, counts, first error
+        // fields: lengths (written where the offsets will be), counts, first error.  Offsets are 32-bit
+        // whenever the text is smaller than 4 GiB (no column can then be larger).
+        const char* force64 = getenv("CPH_CSV_OFFSETS64");   // test hook for the >= 4 GiB code path
+        const bool off32 = size < (1ull << 32) && !(force64 && force64[0] == '1');
+        const size_t osz = off32 ? sizeof(uint32_t) : sizeof(uint64_t);
+        const uint64_t stride = nrec + 1;
+        CPH_TRY(t->d_offs.alloc(&ctx->pool, (size_t)ncols * stride * osz));
+        uint8_t* offs_all = t->d_offs.as<uint8_t>();
         uint64_t good = nrec;   // records before the first error
         if (nrec) {
-            CPH_TRY(lens.alloc(&ctx->pool, (size_t)ncols * (nrec + 1) * sizeof(uint64_t)));
             CPH_TRY(nfields.alloc(&ctx->pool, nrec * sizeof(uint32_t)));
             CPH_TRY(errk.alloc(&ctx->pool, sizeof(unsigned long long)));
             CPH_HIP_TRY(hipMemsetAsync(errk.get(), 0xFF, sizeof(unsigned long long), ctx->stream));
             {
-                ProfScope ps(ctx, "k_csv_fields", (double)size);
-                hipLaunchKernelGGL(k_csv_fields, dim3(grid_for_rows(nrec)), dim3(256), 0, ctx->stream, d, rec_b.as<uint64_t>(),
-                                   rec_e.as<uint64_t>(), nrec, o, cc, lens.as<uint64_t>(), nfields.as<uint32_t>(),
-                                   errk.as<unsigned long long>());
+                ProfScope ps(ctx, "k_csv_fields", (double)size + (double)nrec * (12.0 + (double)osz * ncols));
+                if (off32)
+                    hipLaunchKernelGGL(k_csv_fields<uint32_t>, dim3(grid_for_rows(nrec)), dim3(kCsvThreads), 0, ctx->stream, d, size, ri, nrec, o,
+                                       cc, reinterpret_cast<uint32_t*>(offs_all), nfields.as<uint32_t>(), errk.as<unsigned long long>());
+                else
+                    hipLaunchKernelGGL(k_csv_fields<uint64_t>, dim3(grid_for_rows(nrec)), dim3(kCsvThreads), 0, ctx->stream, d, size, ri, nrec, o,
+                                       cc, reinterpret_cast<uint64_t*>(offs_all), nfields.as<uint32_t>(), errk.as<unsigned long long>());
             }
             if (opt->fields_per_record >= 0)
                 hipLaunchKernelGGL(k_csv_check_counts, dim3(grid_for_rows(nrec)), dim3(256), 0, ctx->stream, nfields.as<uint32_t>(),
@@ -419,24 +773,26 @@ CPH_API int32_t cph_csv_parse(cph_ctx* ctx, const uint8_t* data, uint64_t size, 
         }
         first = std::min<uint64_t>(opt->skip_records, good);
         nout = good - first;
-        // offsets + copy
+        // offsets (in place, over the records that are returned) + copy
         t->pub.nrecords = nout;
         t->pub.ncols = ncols;
-        CPH_TRY(t->d_offs.alloc(&ctx->pool, (size_t)ncols * (nout + 1) * sizeof(uint64_t)));
-        uint64_t* offs = t->d_offs.as<uint64_t>();
         std::vector<uint64_t> totals((size_t)ncols, 0);
+        auto col_offs = [&](int c) { return offs_all + ((uint64_t)c * stride + first) * osz; };
         for (int c = 0; c < ncols; c++) {
-            uint64_t* oc = offs + (uint64_t)c * (nout + 1);
-            if (nout) {
-                CPH_HIP_TRY(hipMemcpyAsync(oc, lens.as<uint64_t>() + (uint64_t)c * nrec + first, nout * sizeof(uint64_t),
-                                           hipMemcpyDeviceToDevice, ctx->stream));
-                CPH_TRY(exclusive_scan_u64(ctx, oc, nout, oc + nout));
-                CPH_TRY(read_back(ctx, oc + nout, &totals[(size_t)c]));
-            } else {
-                CPH_HIP_TRY(hipMemsetAsync(oc, 0, sizeof(uint64_t), ctx->stream));
-            }
-            CPH_TRY(t->d_data[c].alloc(&ctx->pool, totals[(size_t)c] + 16));
+            if (!nout) CPH_HIP_TRY(hipMemsetAsync(col_offs(c), 0, osz, ctx->stream));
+            else if (off32) CPH_TRY(exclusive_scan_u32_total(ctx, reinterpret_cast<uint32_t*>(col_offs(c)), nout, reinterpret_cast<uint32_t*>(col_offs(c)) + nout));
+            else CPH_TRY(exclusive_scan_u64(ctx, reinterpret_cast<uint64_t*>(col_offs(c)), nout, reinterpret_cast<uint64_t*>(col_offs(c)) + nout));
         }
+        if (nout) {
+            CPH_TRY(ensure_pinned_scratch(ctx, (size_t)ncols * sizeof(uint64_t)));
+            uint8_t* hs = static_cast<uint8_t*>(ctx->pinned_scratch);
+            for (int c = 0; c < ncols; c++)
+                CPH_HIP_TRY(hipMemcpyAsync(hs + (size_t)c * osz, col_offs(c) + nout * osz, osz, hipMemcpyDeviceToHost, ctx->stream));
+            CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+            for (int c = 0; c < ncols; c++)
+                totals[(size_t)c] = off32 ? (uint64_t) reinterpret_cast<const uint32_t*>(hs)[c] : reinterpret_cast<const uint64_t*>(hs)[c];
+        }
+        for (int c = 0; c < ncols; c++) CPH_TRY(t->d_data[c].alloc(&ctx->pool, totals[(size_t)c] + 16));
         if (nout) {
             DevBuf ptrs;
             CPH_TRY(ptrs.alloc(&ctx->pool, (size_t)ncols * sizeof(uint8_t*)));
@@ -444,40 +800,49 @@ CPH_API int32_t cph_csv_parse(cph_ctx* ctx, const uint8_t* data, uint64_t size, 
             CPH_TRY(pinned_upload(ctx, (size_t)ncols * sizeof(uint8_t*), &slot));
             for (int c = 0; c < ncols; c++) static_cast<uint8_t**>(slot)[c] = t->d_data[c].as<uint8_t>();
             CPH_HIP_TRY(hipMemcpyAsync(ptrs.get(), slot, (size_t)ncols * sizeof(uint8_t*), hipMemcpyHostToDevice, ctx->stream));
-            ProfScope ps(ctx, "k_csv_copy_fields", 2.0 * (double)size);
-            hipLaunchKernelGGL(k_csv_copy_fields, dim3(grid_for_rows(nout)), dim3(256), 0, ctx->stream, d, rec_b.as<uint64_t>(),
-                               rec_e.as<uint64_t>(), first, nout, o, cc, offs, ptrs.as<uint8_t*>());
+            double out_bytes = 0;
+            for (int c = 0; c < ncols; c++) out_bytes += (double)totals[(size_t)c];
+            ProfScope ps(ctx, "k_csv_copy_fields", (double)size + out_bytes + (double)nout * (8.0 + (double)osz * ncols));
+            const size_t smem = (size_t)(kCsvStage + 16) + (size_t)(kCsvStage + 32 * kMaxKeyCols) + 2 * kCsvMaskHalves * sizeof(uint16_t) +
+                                (size_t)ncols * (kCsvThreads + 1) * sizeof(uint32_t);
+            if (off32)
+                hipLaunchKernelGGL(k_csv_copy_fields<uint32_t>, dim3(grid_for_rows(nout)), dim3(kCsvThreads), smem, ctx->stream, d, size, ri, first,
+                                   nout, o, cc, reinterpret_cast<const uint32_t*>(offs_all) + first, stride, ptrs.as<uint8_t*>());
+            else
+                hipLaunchKernelGGL(k_csv_copy_fields<uint64_t>, dim3(grid_for_rows(nout)), dim3(kCsvThreads), smem, ctx->stream, d, size, ri, first,
+                                   nout, o, cc, reinterpret_cast<const uint64_t*>(offs_all) + first, stride, ptrs.as<uint8_t*>());
             CPH_HIP_TRY(hipGetLastError());
-            CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));   // ptrs / staged input are released on return
         }
         // publish
         if (out_mem == CPH_MEM_DEVICE) {
             for (int c = 0; c < ncols; c++) {
                 cph_strcol& sc = t->pub.cols[c];
                 sc.data = t->d_data[c].as<uint8_t>();
-                sc.offsets = offs + (uint64_t)c * (nout + 1);
+                sc.offsets = col_offs(c);
                 sc.nrows = nout;
-                sc.offset_bits = 64;
+                sc.offset_bits = off32 ? 32 : 64;
                 sc.mem = CPH_MEM_DEVICE;
                 sc.fixed_width = 0;
             }
             CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
         } else {
-            size_t need = (size_t)ncols * (nout + 1) * sizeof(uint64_t);
+            const size_t ocol = (((nout + 1) * osz) + 15) & ~(size_t)15;
+            size_t need = (size_t)ncols * ocol;
             for (int c = 0; c < ncols; c++) need += (totals[(size_t)c] + 15) & ~(size_t)15;
             CPH_HIP_TRY(hipHostMalloc(&t->h_block, need + 16, hipHostMallocDefault));
             uint8_t* h = static_cast<uint8_t*>(t->h_block);
-            CPH_HIP_TRY(hipMemcpyAsync(h, offs, (size_t)ncols * (nout + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-            size_t pos = (size_t)ncols * (nout + 1) * sizeof(uint64_t);
+            for (int c = 0; c < ncols; c++)
+                CPH_HIP_TRY(hipMemcpyAsync(h + (size_t)c * ocol, col_offs(c), (nout + 1) * osz, hipMemcpyDeviceToHost, ctx->stream));
+            size_t pos = (size_t)ncols * ocol;
             for (int c = 0; c < ncols; c++) {
                 cph_strcol& sc = t->pub.cols[c];
-                sc.offsets = h + (size_t)c * (nout + 1) * sizeof(uint64_t);
+                sc.offsets = h + (size_t)c * ocol;
                 sc.data = h + pos;
                 if (totals[(size_t)c])
                     CPH_HIP_TRY(hipMemcpyAsync(h + pos, t->d_data[c].get(), totals[(size_t)c], hipMemcpyDeviceToHost, ctx->stream));
                 pos += (totals[(size_t)c] + 15) & ~(size_t)15;
                 sc.nrows = nout;
-                sc.offset_bits = 64;
+                sc.offset_bits = off32 ? 32 : 64;
                 sc.mem = CPH_MEM_HOST;
                 sc.fixed_width = 0;
                 t->d_data[c].reset();

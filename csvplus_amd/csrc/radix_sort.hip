@@ -277,6 +277,9 @@ static Status exclusive_scan_impl(cph_ctx* ctx, T* data, uint64_t n, T* total_ou
 Status exclusive_scan_u32(cph_ctx* ctx, uint32_t* data, uint64_t n) {
     return exclusive_scan_impl<uint32_t>(ctx, data, n, nullptr, "exclusive_scan_u32");
 }
+Status exclusive_scan_u32_total(cph_ctx* ctx, uint32_t* data, uint64_t n, uint32_t* total_out) {
+    return exclusive_scan_impl<uint32_t>(ctx, data, n, total_out, "exclusive_scan_u32");
+}
 // In-place exclusive scan of 64-bit counts; *total_out (device, optional) receives the sum.
 Status exclusive_scan_u64(cph_ctx* ctx, uint64_t* data, uint64_t n, uint64_t* total_out) {
     return exclusive_scan_impl<uint64_t>(ctx, data, n, total_out, "exclusive_scan_u64");

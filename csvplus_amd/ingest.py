@@ -34,12 +34,13 @@ class CsvTable:
         self.columns = []
         for c in range(int(t.ncols)):
             sc = t.cols[c]
+            bits = int(sc.offset_bits)
             if out_mem == N.CPH_MEM_HOST:
-                offs = N._ptr_array(sc.offsets, self.nrecords + 1, np.uint64).copy()
+                offs = N._ptr_array(sc.offsets, self.nrecords + 1, np.uint32 if bits == 32 else np.uint64).copy()
                 data = N._ptr_array(sc.data, int(offs[-1]), np.uint8).copy() if int(offs[-1]) else np.empty(0, np.uint8)
-                self.columns.append(StrCol(data, offs, self.nrecords, 64))
+                self.columns.append(StrCol(data, offs, self.nrecords, bits))
             else:
-                self.columns.append(StrCol(_Raw(sc.data), _Raw(sc.offsets), self.nrecords, 64, N.CPH_MEM_DEVICE, fixed_width=0))
+                self.columns.append(StrCol(_Raw(sc.data), _Raw(sc.offsets), self.nrecords, bits, N.CPH_MEM_DEVICE, fixed_width=0))
         ctx._children.add(self)
         if out_mem == N.CPH_MEM_HOST:
             self.release()

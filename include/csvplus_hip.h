@@ -356,7 +356,8 @@ typedef struct {
     int32_t    error_kind;        /* 0 or CPH_CSV_ERR_*: the first error in record order; the reference
                                      delivers the rows before it and then fails the same way           */
     int32_t    ncols;
-    cph_strcol cols[CPH_MAX_KEY_COLS];   /* cols[i] = field col_index[i] of every record; 64-bit offsets, in out_mem */
+    cph_strcol cols[CPH_MAX_KEY_COLS];   /* cols[i] = field col_index[i] of every record, in out_mem; offsets are
+                                            32-bit when the text is smaller than 4 GiB, else 64-bit */
 } cph_csv_table;
 
 /* `data`/`size` = the whole CSV text in `mem` (CPH_MEM_HOST or CPH_MEM_DEVICE).

@@ -151,6 +151,21 @@ def test_gpu_comments_and_tiles(ctx):
 
 
 @pytest.mark.gpu
+def test_gpu_64bit_offsets_path(ctx, monkeypatch):
+    """Texts of 4 GiB and more get 64-bit offsets; CPH_CSV_OFFSETS64=1 forces that code path on a small text."""
+    monkeypatch.setenv("CPH_CSV_OFFSETS64", "1")
+    rng = np.random.default_rng(21)
+    _, text = _gen_wellformed(rng, 3000, 3, np.frombuffer(b'ab ,"\n\rz', dtype=np.uint8), crlf=True)
+    from csvplus_amd import ingest
+    t = ingest.csv_parse(ctx, text, [0, 2], fields_per_record=3, skip_records=2)
+    assert t.columns[0].offset_bits == 64
+    for opts in ({"fpr": 3}, {"fpr": -1, "trim": True}):
+        assert gpu_records(ctx, text, opts, skip=1) == oracle_records(text, opts, skip=1)
+    bad = text[:2000] + b'x"y\n' + text[2000:]
+    assert gpu_records(ctx, bad, {"fpr": -1}) == oracle_records(bad, {"fpr": -1})
+
+
+@pytest.mark.gpu
 def test_gpu_device_resident_text_and_output(ctx):
     import torch
     from csvplus_amd import ingest, materialize
