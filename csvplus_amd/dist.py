@@ -15,13 +15,14 @@ The same code runs on the gloo backend (CPU tests).
 from __future__ import annotations
 
 
-def allgatherv(t, group=None):
+def allgatherv(t, group=None, single_rank_shortcut: bool = True):
     """Concatenation over ranks (rank order) of 1-D tensor `t`, whose length may differ per rank.
-    Returns (gathered, counts)."""
+    Returns (gathered, counts).  single_rank_shortcut=False sends a 1-rank group through the collectives
+    too (used by the 1-GPU RCCL smoke test)."""
     import torch
     import torch.distributed as dist
 
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and single_rank_shortcut):
         return t, [int(t.numel())]
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
