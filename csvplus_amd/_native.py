@@ -132,6 +132,10 @@ class cph_csv_table(C.Structure):
                 ("ncols", C.c_int32), ("cols", cph_strcol * CPH_MAX_KEY_COLS)]
 
 
+class cph_rowsel(C.Structure):
+    _fields_ = [("ids", C.c_void_p), ("bits", C.c_int32), ("reserved_", C.c_int32), ("base", C.c_uint64)]
+
+
 class cph_groups(C.Structure):
     _fields_ = [("ngroups", C.c_uint64), ("lower", C.c_void_p), ("upper", C.c_void_p)]
 
@@ -184,6 +188,9 @@ PROTOTYPES = [
     ("cph_colbuf_release", None, [C.POINTER(cph_colbuf)]),
     ("cph_csv_write", C.c_int32,
      [_P, C.POINTER(cph_strcol), C.c_int32, C.POINTER(cph_strval), C.c_int32, C.POINTER(C.POINTER(cph_bytes))]),
+    ("cph_csv_write_rows", C.c_int32,
+     [_P, C.POINTER(cph_strcol), C.POINTER(cph_rowsel), C.c_int32, C.c_uint64, C.POINTER(cph_strval), C.c_int32,
+      C.POINTER(C.POINTER(cph_bytes))]),
     ("cph_bytes_release", None, [C.POINTER(cph_bytes)]),
     ("cph_csv_parse", C.c_int32,
      [_P, _P, C.c_uint64, C.c_int32, C.POINTER(cph_csv_options), C.POINTER(C.c_int32), C.c_int32, C.c_int32,

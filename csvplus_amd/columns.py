@@ -77,6 +77,11 @@ class StrCol:
             return StrCol(self.data[begin * w:end * w], offs, end - begin, self.offset_bits, fixed_width=w)
         return StrCol(self.data, self.offsets[begin:end + 1], end - begin, self.offset_bits, fixed_width=0)
 
+    def head(self, n: int) -> "StrCol":
+        """The first n rows, sharing the buffers (host or device)."""
+        assert 0 <= n <= self.nrows
+        return StrCol(self.data, self.offsets, n, self.offset_bits, self.mem, fixed_width=self.fixed_width)
+
     def nbytes_values(self) -> int:
         if self.nrows == 0:
             return 0

@@ -106,23 +106,32 @@ __device__ __forceinline__ bool first_rune_is_space(uint64_t chunk, uint64_t len
     return b0 == 0xE3 && b1 == 0x80 && b2 == 0x80;
 }
 
-// bytes the field occupies in the record + whether it is quoted (csv.Writer.fieldNeedsQuotes)
+// 0x80 in every byte of w that equals the byte replicated in pat
+__device__ __forceinline__ uint64_t eq_mask8(uint64_t w, uint64_t pat) {
+    const uint64_t x = w ^ pat, k = 0x7F7F7F7F7F7F7F7Full;
+    return ~(((x & k) + k) | x | k);
+}
+
+// bytes the field occupies in the record + whether it is quoted (csv.Writer.fieldNeedsQuotes), 8 bytes at a time
 __device__ __forceinline__ uint64_t csv_field_len(const DevCol& col, uint64_t begin, uint64_t len, bool* quoted) {
     *quoted = false;
     if (len == 0) return 0;
-    uint64_t chunk = 0, nquote = 0;
+    uint64_t nquote = 0;
     bool need = false;
-    for (uint64_t q = 0; q < len; q++) {
-        if ((q & 7) == 0) {
-            chunk = load_value_chunk(col.data, begin, len, (int)(q >> 3));
-            if (q == 0) {
-                need = first_rune_is_space(chunk, len);
-                if (len == 2 && (chunk & 0xFFFF) == (uint64_t)('\\' | ('.' << 8))) need = true;   // the field `\.`
-            }
+    const int nchunks = (int)((len + 7) >> 3);
+    for (int j = 0; j < nchunks; j++) {
+        const uint64_t chunk = load_value_chunk(col.data, begin, len, j);
+        if (j == 0) {
+            need = first_rune_is_space(chunk, len);
+            if (len == 2 && (chunk & 0xFFFF) == (uint64_t)('\\' | ('.' << 8))) need = true;   // the field `\.`
         }
-        const uint32_t c = (uint32_t)(chunk >> (8 * (q & 7))) & 0xFF;
-        if (c == '"') { nquote++; need = true; }
-        else if (c == ',' || c == '\r' || c == '\n') need = true;
+        const uint64_t nb = len - 8ull * (uint64_t)j;                                         // valid bytes in this chunk
+        const uint64_t valid = nb >= 8 ? ~0ull : ((1ull << (8 * nb)) - 1);
+        const uint64_t q = eq_mask8(chunk, 0x2222222222222222ull) & valid;
+        const uint64_t sp = (eq_mask8(chunk, 0x2C2C2C2C2C2C2C2Cull) | eq_mask8(chunk, 0x0D0D0D0D0D0D0D0Dull) |
+                             eq_mask8(chunk, 0x0A0A0A0A0A0A0A0Aull)) & valid;
+        nquote += (uint64_t)__popcll(q);
+        need |= (q | sp) != 0;
     }
     *quoted = need;
     return need ? len + 2 + nquote : len;
@@ -142,36 +151,46 @@ __device__ __forceinline__ void csv_put_field(Sink& out, const DevCol& col, uint
     out.put('"');
 }
 
-__global__ __launch_bounds__(kMatThreads) void k_csv_lens(ColsArg cols, int ncols, uint64_t n, uint64_t* __restrict__ lens) {
+// Per column: which row of the column feeds output row i (NULL ids: row i itself).  This is mergeRows
+// (csvplus.go:571-583) folded into the writer: the joined row's fields are read straight from the tables
+// through the row-id tuples of the join.
+struct ColIds {
+    RowIds ids[kMaxKeyCols];
+};
+
+// lens[i] = bytes of record i; qflags[i] bit c = field c is quoted (the copy pass does not look again)
+__global__ __launch_bounds__(kMatThreads) void k_csv_lens(ColsArg cols, ColIds ids, int ncols, uint64_t n, uint64_t* __restrict__ lens,
+                                                         uint16_t* __restrict__ qflags) {
     const uint64_t stride = (uint64_t)gridDim.x * kMatThreads;
     for (uint64_t i = (uint64_t)blockIdx.x * kMatThreads + threadIdx.x; i < n; i += stride) {
         uint64_t total = (uint64_t)ncols;   // ncols-1 commas + '\n'
+        uint32_t flags = 0;
         for (int c = 0; c < ncols; c++) {
             uint64_t b, l;
             bool q;
-            value_span(cols.c[c], i, &b, &l);
+            value_span(cols.c[c], source_row(ids.ids[c], i), &b, &l);
             total += csv_field_len(cols.c[c], b, l, &q);
+            flags |= (uint32_t)q << c;
         }
         lens[i] = total;
+        qflags[i] = (uint16_t)flags;
     }
 }
 
 template <class Sink>
-__device__ __forceinline__ void csv_put_record(Sink& s, const ColsArg& cols, int ncols, uint64_t row) {
+__device__ __forceinline__ void csv_put_record(Sink& s, const ColsArg& cols, const ColIds& ids, int ncols, uint64_t row, uint32_t flags) {
     for (int c = 0; c < ncols; c++) {
         uint64_t b, l;
-        bool q;
-        value_span(cols.c[c], row, &b, &l);
-        csv_field_len(cols.c[c], b, l, &q);
+        value_span(cols.c[c], source_row(ids.ids[c], row), &b, &l);
         if (c) s.put(',');
-        csv_put_field(s, cols.c[c], b, l, q);
+        csv_put_field(s, cols.c[c], b, l, (flags >> c) & 1u);
     }
     s.put('\n');
 }
 
-__global__ __launch_bounds__(kMatThreads) void k_csv_copy(ColsArg cols, int ncols, uint64_t n,
-                                                         const uint64_t* __restrict__ offs, uint8_t* __restrict__ out,
-                                                         uint64_t out_base) {
+__global__ __launch_bounds__(kMatThreads) void k_csv_copy(ColsArg cols, ColIds ids, int ncols, uint64_t n,
+                                                         const uint64_t* __restrict__ offs, const uint16_t* __restrict__ qflags,
+                                                         uint8_t* __restrict__ out, uint64_t out_base) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     CPH_LDS uint8_t* stage = (CPH_LDS uint8_t*)smem;
     for (uint64_t t0 = (uint64_t)blockIdx.x * kMatThreads; t0 < n; t0 += (uint64_t)gridDim.x * kMatThreads) {
@@ -182,14 +201,14 @@ __global__ __launch_bounds__(kMatThreads) void k_csv_copy(ColsArg cols, int ncol
         if (span + 16 <= (uint64_t)kMatStage) {
             if (i < tend) {
                 LdsSink s{stage + (offs[i] - offs[t0]) + (obase & 15)};
-                csv_put_record(s, cols, ncols, i);
+                csv_put_record(s, cols, ids, ncols, i, qflags[i]);
             }
             __syncthreads();
             flush_stage(stage, out, obase, span);
             __syncthreads();
         } else if (i < tend) {
             GlobalSink s{out + out_base + offs[i]};
-            csv_put_record(s, cols, ncols, i);
+            csv_put_record(s, cols, ids, ncols, i, qflags[i]);
         }
     }
 }
@@ -351,15 +370,21 @@ CPH_API void cph_colbuf_release(cph_colbuf* pub) {
     delete r;
 }
 
-CPH_API int32_t cph_csv_write(cph_ctx* ctx, const cph_strcol* cols, int32_t ncols, const cph_strval* header, int32_t out_mem,
-                              cph_bytes** out) {
+CPH_API int32_t cph_csv_write_rows(cph_ctx* ctx, const cph_strcol* cols, const cph_rowsel* sel, int32_t ncols, uint64_t nrows,
+                                   const cph_strval* header, int32_t out_mem, cph_bytes** out) {
     if (!ctx || !cols || !out) return CPH_ERR_INVALID;
     if (hipSetDevice(ctx->device) != hipSuccess) return mat_fail(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});
     *out = nullptr;
     if (out_mem != CPH_MEM_HOST && out_mem != CPH_MEM_DEVICE) return mat_fail(ctx, {CPH_ERR_INVALID, "bad out_mem"});
-    Status s = validate_cols(cols, ncols);
-    if (!s.ok()) return mat_fail(ctx, s);
-    const uint64_t n = cols[0].nrows;
+    if (ncols < 1 || ncols > CPH_MAX_KEY_COLS) return mat_fail(ctx, {CPH_ERR_INVALID, "1..16 columns"});
+    for (int c = 0; c < ncols; c++) {
+        Status s = validate_cols(cols + c, 1);
+        if (!s.ok()) return mat_fail(ctx, s);
+        const bool ident = !sel || !sel[c].ids;
+        if (ident && nrows && cols[c].nrows != nrows) return mat_fail(ctx, {CPH_ERR_INVALID, "a column without row ids must have nrows rows"});
+        if (!ident && sel[c].bits != 32 && sel[c].bits != 64) return mat_fail(ctx, {CPH_ERR_INVALID, "row id bits must be 32 or 64"});
+    }
+    const uint64_t n = nrows;
     auto* r = new (std::nothrow) cph_bytes_impl();
     if (!r) return mat_fail(ctx, {CPH_ERR_NOMEM, "out of host memory"});
     r->ctx = ctx;
@@ -374,15 +399,32 @@ CPH_API int32_t cph_csv_write(cph_ctx* ctx, const cph_strcol* cols, int32_t ncol
         }
         std::vector<DevBuf> staged;
         ColsArg arg{};
-        CPH_TRY(stage_cols(ctx, cols, ncols, &staged, arg.c));
-        DevBuf offs;
+        ColIds ids{};
+        for (int c = 0; c < ncols; c++) {
+            CPH_TRY(stage_cols(ctx, cols + c, 1, &staged, &arg.c[c]));
+            if (sel && sel[c].ids && n) {
+                ids.ids[c].bits = sel[c].bits;
+                ids.ids[c].base = sel[c].base;
+                if (cols[c].mem == CPH_MEM_HOST) {   // the ids live where the column lives
+                    const size_t b = n * (size_t)(sel[c].bits / 8);
+                    staged.emplace_back();
+                    CPH_TRY(staged.back().alloc(&ctx->pool, b));
+                    CPH_HIP_TRY(hipMemcpyAsync(staged.back().get(), sel[c].ids, b, hipMemcpyHostToDevice, ctx->stream));
+                    ids.ids[c].ptr = staged.back().get();
+                } else {
+                    ids.ids[c].ptr = sel[c].ids;
+                }
+            }
+        }
+        DevBuf offs, qflags;
         CPH_TRY(offs.alloc(&ctx->pool, (n + 1) * sizeof(uint64_t)));
+        CPH_TRY(qflags.alloc(&ctx->pool, (n + 1) * sizeof(uint16_t)));
         uint64_t total = 0;
         if (n) {
             {
                 ProfScope ps(ctx, "k_csv_lens", 0);
-                hipLaunchKernelGGL(k_csv_lens, dim3(grid_rows(n)), dim3(kMatThreads), 0, ctx->stream, arg, ncols, n,
-                                   offs.as<uint64_t>());
+                hipLaunchKernelGGL(k_csv_lens, dim3(grid_rows(n)), dim3(kMatThreads), 0, ctx->stream, arg, ids, ncols, n,
+                                   offs.as<uint64_t>(), qflags.as<uint16_t>());
             }
             CPH_HIP_TRY(hipGetLastError());
             CPH_TRY(scan_lengths(ctx, offs.as<uint64_t>(), n, &total));
@@ -396,9 +438,9 @@ CPH_API int32_t cph_csv_write(cph_ctx* ctx, const cph_strcol* cols, int32_t ncol
             CPH_HIP_TRY(hipMemcpyAsync(r->d_data.get(), slot, head.size(), hipMemcpyHostToDevice, ctx->stream));
         }
         if (n) {
-            ProfScope ps(ctx, "k_csv_copy", 2.0 * (double)total + 8.0 * (double)n);
-            hipLaunchKernelGGL(k_csv_copy, dim3(grid_rows(n)), dim3(kMatThreads), kMatStage, ctx->stream, arg, ncols, n,
-                               offs.as<uint64_t>(), r->d_data.as<uint8_t>(), (uint64_t)head.size());
+            ProfScope ps(ctx, "k_csv_copy", 2.0 * (double)total + 10.0 * (double)n);
+            hipLaunchKernelGGL(k_csv_copy, dim3(grid_rows(n)), dim3(kMatThreads), kMatStage, ctx->stream, arg, ids, ncols, n,
+                               offs.as<uint64_t>(), qflags.as<uint16_t>(), r->d_data.as<uint8_t>(), (uint64_t)head.size());
             CPH_HIP_TRY(hipGetLastError());
         }
         r->pub.size = size;
@@ -415,14 +457,21 @@ CPH_API int32_t cph_csv_write(cph_ctx* ctx, const cph_strcol* cols, int32_t ncol
         }
         return {};
     };
-    s = run();
+    Status s = run();
     if (!s.ok()) {
+        (void)hipStreamSynchronize(ctx->stream);
         if (r->h_block) (void)hipHostFree(r->h_block);
         delete r;
         return mat_fail(ctx, s);
     }
     *out = &r->pub;
     return CPH_OK;
+}
+
+CPH_API int32_t cph_csv_write(cph_ctx* ctx, const cph_strcol* cols, int32_t ncols, const cph_strval* header, int32_t out_mem,
+                              cph_bytes** out) {
+    if (!cols || ncols < 1) return CPH_ERR_INVALID;
+    return cph_csv_write_rows(ctx, cols, nullptr, ncols, cols[0].nrows, header, out_mem, out);
 }
 
 CPH_API void cph_bytes_release(cph_bytes* pub) {

@@ -76,8 +76,37 @@ class ColBuf:
             pass
 
 
-def csv_write(ctx: N.Context, cols, header=None) -> bytes:
-    """ToCsv: header (list of names or None) + rows of `cols` (same memory space), Go csv.Writer format."""
+class DeviceBytes:
+    """cph_bytes kept in HBM (valid until release())."""
+
+    def __init__(self, ctx, ptr):
+        self.ctx, self.ptr = ctx, ptr
+        self.size, self.data_ptr = int(ptr.contents.size), int(ptr.contents.data or 0)
+        ctx._children.add(self)
+
+    def __len__(self):
+        return self.size
+
+    def release(self):
+        if self.ptr:
+            self.ctx.lib.cph_bytes_release(self.ptr)
+            self.ptr = None
+
+    close = release
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+def csv_write(ctx: N.Context, cols, header=None, out_mem: int = N.CPH_MEM_HOST, row_ids=None, nrows=None):
+    """ToCsv: header (list of names or None) + rows of `cols`, Go csv.Writer format.
+    row_ids (optional, one entry per column): None = the column's own rows, else the rows of that column feeding
+    the output (numpy uint32/uint64 for host columns, (device_ptr, bits, count[, base]) for device columns) —
+    Join(...).ToCsv(...) fused: mergeRows happens inside the writer (cph_csv_write_rows).
+    Returns bytes (out_mem HOST) or a DeviceBytes handle (DEVICE)."""
     arr = (N.cph_strcol * len(cols))()
     keep = []
     for i, c in enumerate(cols):
@@ -92,8 +121,29 @@ def csv_write(ctx: N.Context, cols, header=None) -> bytes:
             keep.append(b)
             hv[i].data = b.ctypes.data if len(b) else None
             hv[i].len = len(b)
+    sel = None
+    n = cols[0].nrows if nrows is None else int(nrows)
+    if row_ids is not None:
+        sel = (N.cph_rowsel * len(cols))()
+        for i, ids in enumerate(row_ids):
+            if ids is None:
+                continue
+            if isinstance(ids, np.ndarray):
+                if ids.dtype != np.uint64:
+                    ids = ids.astype(np.uint32)
+                ids = np.ascontiguousarray(ids)
+                keep.append(ids)
+                sel[i].ids, sel[i].bits = ids.ctypes.data if len(ids) else None, ids.dtype.itemsize * 8
+                cnt = len(ids)
+            else:
+                sel[i].ids, sel[i].bits, cnt = int(ids[0]) or None, int(ids[1]), int(ids[2])
+                sel[i].base = int(ids[3]) if len(ids) > 3 else 0
+            if nrows is None:
+                n = cnt
     out = C.POINTER(N.cph_bytes)()
-    ctx._check(ctx.lib.cph_csv_write(ctx.handle, arr, len(cols), hv, N.CPH_MEM_HOST, C.byref(out)))
+    ctx._check(ctx.lib.cph_csv_write_rows(ctx.handle, arr, sel, len(cols), n, hv, out_mem, C.byref(out)))
+    if out_mem == N.CPH_MEM_DEVICE:
+        return DeviceBytes(ctx, out)
     res = N._ptr_array(out.contents.data, int(out.contents.size), np.uint8).tobytes()
     ctx.lib.cph_bytes_release(out)
     return res

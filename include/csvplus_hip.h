@@ -317,6 +317,24 @@ CPH_API void    cph_colbuf_release(cph_colbuf* c);
  */
 CPH_API int32_t cph_csv_write(cph_ctx* ctx, const cph_strcol* cols, int32_t ncols, const cph_strval* header,
                               int32_t out_mem, cph_bytes** out);
+
+/*
+ * Join(...).ToCsv(...) without materialising the joined table: output row i takes field c from row
+ * sel[c].ids[i] - sel[c].base of cols[c] (sel == NULL or sel[c].ids == NULL: row i itself, and then
+ * cols[c].nrows must equal nrows unless nrows is 0).  This is mergeRows (csvplus.go:571-583) folded into the writer:
+ * the caller lists, per output column, the table it comes from (for a name present on both sides the
+ * stream's column, :578-580) and the row-id array of that table from cph_join_chain / cph_join_probe.
+ * Row ids live in the same memory space as their column and must be < cols[c].nrows.
+ */
+typedef struct {
+    const void* ids;      /* uint32 or uint64 row ids, nrows entries; NULL = identity */
+    int32_t     bits;     /* 32 or 64 */
+    int32_t     reserved_;
+    uint64_t    base;     /* subtracted from every id (e.g. the probe_base of a chunk) */
+} cph_rowsel;
+
+CPH_API int32_t cph_csv_write_rows(cph_ctx* ctx, const cph_strcol* cols, const cph_rowsel* sel, int32_t ncols, uint64_t nrows,
+                                   const cph_strval* header, int32_t out_mem, cph_bytes** out);
 CPH_API void    cph_bytes_release(cph_bytes* b);
 
 /* ---- CSV ingest: bytes -> SoA string columns (csvplus.go:1080-1146) ----------- */

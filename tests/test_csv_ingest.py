@@ -222,3 +222,49 @@ def test_read_csv_header_modes(ctx):
     assert (t.error_kind, t.error_record, t.nrecords) == (3, 121, 120)
     with pytest.raises(EOFError):
         ingest.read_csv(ctx, b"")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("missing", [0, 500])
+def test_pipeline_csv_to_csv(ctx, missing, fused):
+    """The README chain end to end (README.md:33-66): three CSV files in, the joined CSV out, every stage on the
+    device (csvplus_amd.pipeline), byte-compared with the same pipeline run through the oracle's pieces."""
+    from csvplus_amd import datagen as dg
+    from csvplus_amd import pipeline
+    nc, npd, m = 3000, 40, 20_000
+    cust, prod = dg.customers(nc, encoding=dg.ITOA), dg.products(npd)
+    ords = dg.orders(m, nc + missing, npd, cust_encoding=dg.ITOA)
+    # make a few values need quoting so that the reader and the writer both leave their fast paths
+    names = cust["name"].values()
+    names[5], names[77] = b'Ann "Annie", Jr', b"multi\nline"
+    from csvplus_amd import StrCol
+    cust = dict(cust, name=StrCol.from_values(names))
+    files = {"customers": orc.csv_write([cust["id"], cust["name"], cust["surname"]], ["id", "name", "surname"]),
+             "products": orc.csv_write([prod["prod_id"], prod["product"], prod["price"]], ["prod_id", "product", "price"]),
+             "orders": orc.csv_write([ords["cust_id"], ords["prod_id"], ords["qty"]], ["cust_id", "prod_id", "qty"])}
+    # device pipeline
+    tc = pipeline.read_table(ctx, files["customers"])
+    tp = pipeline.read_table(ctx, files["products"])
+    to = pipeline.read_table(ctx, files["orders"], select=["cust_id", "prod_id", "qty"])
+    out_cols = [("cust_id", to, "cust_id"), ("qty", to, "qty"), ("name", tc, "name"), ("surname", tc, "surname"),
+                ("product", tp, "product"), ("price", tp, "price")]
+    got = pipeline.join_to_csv(ctx, to, [(tc, "id", "cust_id"), (tp, "prod_id", "prod_id")], out_cols, fused=fused)
+    # oracle pipeline
+    def parse(text, idx):
+        cols, ek, _ = orc.csv_parse(text, idx, skip_records=1)
+        assert ek == 0
+        return cols
+    oc, op, oo = parse(files["customers"], [0, 1, 2]), parse(files["products"], [0, 1, 2]), parse(files["orders"], [0, 1, 2])
+    j1 = orc.OracleIndex([oc[0]]).join([oo[0]])
+    j2 = orc.OracleIndex([op[0]]).join([oo[1]], row_sel=j1["probe_idx"].astype(np.uint32))
+    pick = j2["probe_idx"].astype(np.int64)
+    es, ea, eb = j1["probe_idx"][pick], j1["build_row"][pick], j2["build_row"]
+    assert (len(es) < m) == bool(missing)
+    want_cols = [StrCol.from_values([oo[0].value(int(r)) for r in es]), StrCol.from_values([oo[2].value(int(r)) for r in es]),
+                 StrCol.from_values([oc[1].value(int(x)) for x in ea]), StrCol.from_values([oc[2].value(int(x)) for x in ea]),
+                 StrCol.from_values([op[1].value(int(y)) for y in eb]), StrCol.from_values([op[2].value(int(y)) for y in eb])]
+    want = orc.csv_write(want_cols, [n for n, _, _ in out_cols])
+    assert got == want
+    for t in (tc, tp, to):
+        t.release()

@@ -110,3 +110,23 @@ def test_joined_table_to_csv_end_to_end(ctx):
                                cust["name"].value(int(x)).decode(), cust["surname"].value(int(x)).decode(),
                                prod["product"].value(int(y)).decode(), prod["price"].value(int(y)).decode()]))
     assert got.decode() == "\n".join(lines) + "\n"
+
+
+@pytest.mark.gpu
+def test_csv_write_rows_fused_equals_gather_then_write(ctx):
+    """cph_csv_write_rows (mergeRows folded into ToCsv) == gather every column, then cph_csv_write == oracle,
+    with host columns + host row ids, uint32 and uint64 ids, an id base, and nasty values."""
+    from csvplus_amd.materialize import csv_write
+    rng = np.random.default_rng(31)
+    a = StrCol.from_values([b"x", b'q"q', b"", b" lead", b"a,b", b"line\nbreak", b"\\.", b"plain", b"\xc2\xa0nbsp"])
+    b = StrCol.from_values([b"%d" % i for i in range(50)])
+    n = 4000
+    ia = rng.integers(0, a.nrows, n).astype(np.uint32)
+    ib = (rng.integers(0, b.nrows, n) + 1000).astype(np.uint64)
+    s = StrCol.from_values([b"row%d" % i for i in range(n)])
+    got = csv_write(ctx, [s, a, b], ["s", "a", "b"], row_ids=[None, ia, ib - 1000])
+    want = orc.csv_write([s, StrCol.from_values([a.value(int(i)) for i in ia]),
+                          StrCol.from_values([b.value(int(i) - 1000) for i in ib])], ["s", "a", "b"])
+    assert got == want
+    # no rows at all: the header only
+    assert csv_write(ctx, [s.head(0), a, b], ["s", "a", "b"], row_ids=[None, ia[:0], ib[:0]], nrows=0) == b"s,a,b\n"
