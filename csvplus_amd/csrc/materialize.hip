@@ -113,14 +113,16 @@ __device__ __forceinline__ uint64_t eq_mask8(uint64_t w, uint64_t pat) {
 }
 
 // bytes the field occupies in the record + whether it is quoted (csv.Writer.fieldNeedsQuotes), 8 bytes at a time
-__device__ __forceinline__ uint64_t csv_field_len(const DevCol& col, uint64_t begin, uint64_t len, bool* quoted) {
+// chunk0 = the value's first 8-byte chunk (already loaded by the caller, so that the loads of all the columns
+// of a record are in flight together)
+__device__ __forceinline__ uint64_t csv_field_len(const DevCol& col, uint64_t begin, uint64_t len, uint64_t chunk0, bool* quoted) {
     *quoted = false;
     if (len == 0) return 0;
     uint64_t nquote = 0;
     bool need = false;
     const int nchunks = (int)((len + 7) >> 3);
     for (int j = 0; j < nchunks; j++) {
-        const uint64_t chunk = load_value_chunk(col.data, begin, len, j);
+        const uint64_t chunk = j == 0 ? chunk0 : load_value_chunk(col.data, begin, len, j);
         if (j == 0) {
             need = first_rune_is_space(chunk, len);
             if (len == 2 && (chunk & 0xFFFF) == (uint64_t)('\\' | ('.' << 8))) need = true;   // the field `\.`
@@ -138,17 +140,16 @@ __device__ __forceinline__ uint64_t csv_field_len(const DevCol& col, uint64_t be
 }
 
 template <class Sink>
-__device__ __forceinline__ void csv_put_field(Sink& out, const DevCol& col, uint64_t begin, uint64_t len, bool quoted) {
-    if (!quoted) { copy_value(out, col, begin, len); return; }
-    out.put('"');
-    uint64_t chunk = 0;
+__device__ __forceinline__ void csv_put_field(Sink& out, const DevCol& col, uint64_t begin, uint64_t len, uint64_t chunk0, bool quoted) {
+    if (quoted) out.put('"');
+    uint64_t chunk = chunk0;
     for (uint64_t q = 0; q < len; q++) {
-        if ((q & 7) == 0) chunk = load_value_chunk(col.data, begin, len, (int)(q >> 3));
+        if ((q & 7) == 0 && q) chunk = load_value_chunk(col.data, begin, len, (int)(q >> 3));
         const uint8_t c = (uint8_t)(chunk >> (8 * (q & 7)));
-        if (c == '"') out.put('"');
+        if (quoted && c == '"') out.put('"');
         out.put(c);
     }
-    out.put('"');
+    if (quoted) out.put('"');
 }
 
 // Per column: which row of the column feeds output row i (NULL ids: row i itself).  This is mergeRows
@@ -158,36 +159,76 @@ struct ColIds {
     RowIds ids[kMaxKeyCols];
 };
 
+// One record's fields: row ids, then offsets, then the first chunk of every value — three rounds of independent
+// loads instead of a dependent chain per column.  NC > 0: compile-time column count (arrays stay in registers);
+// NC == 0: any count up to kMaxKeyCols, one column at a time.
+template <int NC>
+struct RecordFields {
+    uint64_t b[NC ? NC : 1], l[NC ? NC : 1], c0[NC ? NC : 1];
+    __device__ __forceinline__ void load(const ColsArg& cols, const ColIds& ids, uint64_t i) {
+        uint64_t row[NC ? NC : 1];
+#pragma unroll
+        for (int c = 0; c < NC; c++) row[c] = source_row(ids.ids[c], i);
+#pragma unroll
+        for (int c = 0; c < NC; c++) value_span(cols.c[c], row[c], &b[c], &l[c]);
+#pragma unroll
+        for (int c = 0; c < NC; c++) c0[c] = l[c] ? load_value_chunk(cols.c[c].data, b[c], l[c], 0) : 0;
+    }
+};
+
 // lens[i] = bytes of record i; qflags[i] bit c = field c is quoted (the copy pass does not look again)
+template <int NC>
 __global__ __launch_bounds__(kMatThreads) void k_csv_lens(ColsArg cols, ColIds ids, int ncols, uint64_t n, uint64_t* __restrict__ lens,
                                                          uint16_t* __restrict__ qflags) {
     const uint64_t stride = (uint64_t)gridDim.x * kMatThreads;
     for (uint64_t i = (uint64_t)blockIdx.x * kMatThreads + threadIdx.x; i < n; i += stride) {
         uint64_t total = (uint64_t)ncols;   // ncols-1 commas + '\n'
         uint32_t flags = 0;
-        for (int c = 0; c < ncols; c++) {
-            uint64_t b, l;
-            bool q;
-            value_span(cols.c[c], source_row(ids.ids[c], i), &b, &l);
-            total += csv_field_len(cols.c[c], b, l, &q);
-            flags |= (uint32_t)q << c;
+        if constexpr (NC > 0) {
+            RecordFields<NC> f;
+            f.load(cols, ids, i);
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                bool q;
+                total += csv_field_len(cols.c[c], f.b[c], f.l[c], f.c0[c], &q);
+                flags |= (uint32_t)q << c;
+            }
+        } else {
+            for (int c = 0; c < ncols; c++) {
+                uint64_t b, l;
+                bool q;
+                value_span(cols.c[c], source_row(ids.ids[c], i), &b, &l);
+                total += csv_field_len(cols.c[c], b, l, l ? load_value_chunk(cols.c[c].data, b, l, 0) : 0, &q);
+                flags |= (uint32_t)q << c;
+            }
         }
         lens[i] = total;
         qflags[i] = (uint16_t)flags;
     }
 }
 
-template <class Sink>
+template <int NC, class Sink>
 __device__ __forceinline__ void csv_put_record(Sink& s, const ColsArg& cols, const ColIds& ids, int ncols, uint64_t row, uint32_t flags) {
-    for (int c = 0; c < ncols; c++) {
-        uint64_t b, l;
-        value_span(cols.c[c], source_row(ids.ids[c], row), &b, &l);
-        if (c) s.put(',');
-        csv_put_field(s, cols.c[c], b, l, (flags >> c) & 1u);
+    if constexpr (NC > 0) {
+        RecordFields<NC> f;
+        f.load(cols, ids, row);
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            if (c) s.put(',');
+            csv_put_field(s, cols.c[c], f.b[c], f.l[c], f.c0[c], (flags >> c) & 1u);
+        }
+    } else {
+        for (int c = 0; c < ncols; c++) {
+            uint64_t b, l;
+            value_span(cols.c[c], source_row(ids.ids[c], row), &b, &l);
+            if (c) s.put(',');
+            csv_put_field(s, cols.c[c], b, l, l ? load_value_chunk(cols.c[c].data, b, l, 0) : 0, (flags >> c) & 1u);
+        }
     }
     s.put('\n');
 }
 
+template <int NC>
 __global__ __launch_bounds__(kMatThreads) void k_csv_copy(ColsArg cols, ColIds ids, int ncols, uint64_t n,
                                                          const uint64_t* __restrict__ offs, const uint16_t* __restrict__ qflags,
                                                          uint8_t* __restrict__ out, uint64_t out_base) {
@@ -201,17 +242,31 @@ __global__ __launch_bounds__(kMatThreads) void k_csv_copy(ColsArg cols, ColIds i
         if (span + 16 <= (uint64_t)kMatStage) {
             if (i < tend) {
                 LdsSink s{stage + (offs[i] - offs[t0]) + (obase & 15)};
-                csv_put_record(s, cols, ids, ncols, i, qflags[i]);
+                csv_put_record<NC>(s, cols, ids, ncols, i, qflags[i]);
             }
             __syncthreads();
             flush_stage(stage, out, obase, span);
             __syncthreads();
         } else if (i < tend) {
             GlobalSink s{out + out_base + offs[i]};
-            csv_put_record(s, cols, ids, ncols, i, qflags[i]);
+            csv_put_record<NC>(s, cols, ids, ncols, i, qflags[i]);
         }
     }
 }
+
+// launches kernel<NC> for ncols in 1..8, the generic kernel<0> above that
+#define CPH_CSV_DISPATCH(KERNEL, NCOLS, GRID, SMEM, STREAM, ...)                                                     \
+    switch (NCOLS) {                                                                                                 \
+        case 1: hipLaunchKernelGGL(KERNEL<1>, GRID, dim3(kMatThreads), SMEM, STREAM, __VA_ARGS__); break;            \
+        case 2: hipLaunchKernelGGL(KERNEL<2>, GRID, dim3(kMatThreads), SMEM, STREAM, __VA_ARGS__); break;            \
+        case 3: hipLaunchKernelGGL(KERNEL<3>, GRID, dim3(kMatThreads), SMEM, STREAM, __VA_ARGS__); break;            \
+        case 4: hipLaunchKernelGGL(KERNEL<4>, GRID, dim3(kMatThreads), SMEM, STREAM, __VA_ARGS__); break;            \
+        case 5: hipLaunchKernelGGL(KERNEL<5>, GRID, dim3(kMatThreads), SMEM, STREAM, __VA_ARGS__); break;            \
+        case 6: hipLaunchKernelGGL(KERNEL<6>, GRID, dim3(kMatThreads), SMEM, STREAM, __VA_ARGS__); break;            \
+        case 7: hipLaunchKernelGGL(KERNEL<7>, GRID, dim3(kMatThreads), SMEM, STREAM, __VA_ARGS__); break;            \
+        case 8: hipLaunchKernelGGL(KERNEL<8>, GRID, dim3(kMatThreads), SMEM, STREAM, __VA_ARGS__); break;            \
+        default: hipLaunchKernelGGL(KERNEL<0>, GRID, dim3(kMatThreads), SMEM, STREAM, __VA_ARGS__); break;           \
+    }
 
 static unsigned grid_rows(uint64_t n) {
     uint64_t b = (n + kMatThreads - 1) / kMatThreads;
@@ -423,8 +478,8 @@ CPH_API int32_t cph_csv_write_rows(cph_ctx* ctx, const cph_strcol* cols, const c
         if (n) {
             {
                 ProfScope ps(ctx, "k_csv_lens", 0);
-                hipLaunchKernelGGL(k_csv_lens, dim3(grid_rows(n)), dim3(kMatThreads), 0, ctx->stream, arg, ids, ncols, n,
-                                   offs.as<uint64_t>(), qflags.as<uint16_t>());
+                CPH_CSV_DISPATCH(k_csv_lens, ncols, dim3(grid_rows(n)), 0, ctx->stream, arg, ids, ncols, n, offs.as<uint64_t>(),
+                                 qflags.as<uint16_t>());
             }
             CPH_HIP_TRY(hipGetLastError());
             CPH_TRY(scan_lengths(ctx, offs.as<uint64_t>(), n, &total));
@@ -439,8 +494,8 @@ CPH_API int32_t cph_csv_write_rows(cph_ctx* ctx, const cph_strcol* cols, const c
         }
         if (n) {
             ProfScope ps(ctx, "k_csv_copy", 2.0 * (double)total + 10.0 * (double)n);
-            hipLaunchKernelGGL(k_csv_copy, dim3(grid_rows(n)), dim3(kMatThreads), kMatStage, ctx->stream, arg, ids, ncols, n,
-                               offs.as<uint64_t>(), qflags.as<uint16_t>(), r->d_data.as<uint8_t>(), (uint64_t)head.size());
+            CPH_CSV_DISPATCH(k_csv_copy, ncols, dim3(grid_rows(n)), kMatStage, ctx->stream, arg, ids, ncols, n, offs.as<uint64_t>(),
+                             qflags.as<uint16_t>(), r->d_data.as<uint8_t>(), (uint64_t)head.size());
             CPH_HIP_TRY(hipGetLastError());
         }
         r->pub.size = size;
