@@ -165,40 +165,50 @@ struct ColIds {
 template <int NC>
 struct RecordFields {
     uint64_t b[NC ? NC : 1], l[NC ? NC : 1], c0[NC ? NC : 1];
-    __device__ __forceinline__ void load(const ColsArg& cols, const ColIds& ids, uint64_t i) {
+    // data_mask bit c: the bytes of column c are needed (a RAW column's length pass needs only its offsets)
+    __device__ __forceinline__ void load(const ColsArg& cols, const ColIds& ids, uint64_t i, uint32_t data_mask) {
         uint64_t row[NC ? NC : 1];
 #pragma unroll
         for (int c = 0; c < NC; c++) row[c] = source_row(ids.ids[c], i);
 #pragma unroll
         for (int c = 0; c < NC; c++) value_span(cols.c[c], row[c], &b[c], &l[c]);
 #pragma unroll
-        for (int c = 0; c < NC; c++) c0[c] = l[c] ? load_value_chunk(cols.c[c].data, b[c], l[c], 0) : 0;
+        for (int c = 0; c < NC; c++) c0[c] = (l[c] && ((data_mask >> c) & 1u)) ? load_value_chunk(cols.c[c].data, b[c], l[c], 0) : 0;
     }
+};
+
+// What the writer kernels are told besides the columns.  raw_mask bit c: column c already holds CSV text (a
+// pre-rendered fragment of several fields): it is copied as it is, never quoted.  newline: records end in '\n'
+// (off when rendering fragments).
+struct CsvMode {
+    uint32_t raw_mask;
+    uint32_t newline;
 };
 
 // lens[i] = bytes of record i; qflags[i] bit c = field c is quoted (the copy pass does not look again)
 template <int NC>
-__global__ __launch_bounds__(kMatThreads) void k_csv_lens(ColsArg cols, ColIds ids, int ncols, uint64_t n, uint64_t* __restrict__ lens,
-                                                         uint16_t* __restrict__ qflags) {
+__global__ __launch_bounds__(kMatThreads) void k_csv_lens(ColsArg cols, ColIds ids, int ncols, CsvMode mode, uint64_t n,
+                                                         uint64_t* __restrict__ lens, uint16_t* __restrict__ qflags) {
     const uint64_t stride = (uint64_t)gridDim.x * kMatThreads;
     for (uint64_t i = (uint64_t)blockIdx.x * kMatThreads + threadIdx.x; i < n; i += stride) {
-        uint64_t total = (uint64_t)ncols;   // ncols-1 commas + '\n'
+        uint64_t total = (uint64_t)(ncols - 1) + mode.newline;   // commas + '\n'
         uint32_t flags = 0;
         if constexpr (NC > 0) {
             RecordFields<NC> f;
-            f.load(cols, ids, i);
+            f.load(cols, ids, i, ~mode.raw_mask);
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                bool q;
-                total += csv_field_len(cols.c[c], f.b[c], f.l[c], f.c0[c], &q);
+                bool q = false;
+                total += ((mode.raw_mask >> c) & 1u) ? f.l[c] : csv_field_len(cols.c[c], f.b[c], f.l[c], f.c0[c], &q);
                 flags |= (uint32_t)q << c;
             }
         } else {
             for (int c = 0; c < ncols; c++) {
                 uint64_t b, l;
-                bool q;
+                bool q = false;
                 value_span(cols.c[c], source_row(ids.ids[c], i), &b, &l);
-                total += csv_field_len(cols.c[c], b, l, l ? load_value_chunk(cols.c[c].data, b, l, 0) : 0, &q);
+                if ((mode.raw_mask >> c) & 1u) total += l;
+                else total += csv_field_len(cols.c[c], b, l, l ? load_value_chunk(cols.c[c].data, b, l, 0) : 0, &q);
                 flags |= (uint32_t)q << c;
             }
         }
@@ -208,10 +218,11 @@ __global__ __launch_bounds__(kMatThreads) void k_csv_lens(ColsArg cols, ColIds i
 }
 
 template <int NC, class Sink>
-__device__ __forceinline__ void csv_put_record(Sink& s, const ColsArg& cols, const ColIds& ids, int ncols, uint64_t row, uint32_t flags) {
+__device__ __forceinline__ void csv_put_record(Sink& s, const ColsArg& cols, const ColIds& ids, int ncols, CsvMode mode, uint64_t row,
+                                               uint32_t flags) {
     if constexpr (NC > 0) {
         RecordFields<NC> f;
-        f.load(cols, ids, row);
+        f.load(cols, ids, row, ~0u);
 #pragma unroll
         for (int c = 0; c < NC; c++) {
             if (c) s.put(',');
@@ -225,11 +236,11 @@ __device__ __forceinline__ void csv_put_record(Sink& s, const ColsArg& cols, con
             csv_put_field(s, cols.c[c], b, l, l ? load_value_chunk(cols.c[c].data, b, l, 0) : 0, (flags >> c) & 1u);
         }
     }
-    s.put('\n');
+    if (mode.newline) s.put('\n');
 }
 
 template <int NC>
-__global__ __launch_bounds__(kMatThreads) void k_csv_copy(ColsArg cols, ColIds ids, int ncols, uint64_t n,
+__global__ __launch_bounds__(kMatThreads) void k_csv_copy(ColsArg cols, ColIds ids, int ncols, CsvMode mode, uint64_t n,
                                                          const uint64_t* __restrict__ offs, const uint16_t* __restrict__ qflags,
                                                          uint8_t* __restrict__ out, uint64_t out_base) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -242,14 +253,14 @@ __global__ __launch_bounds__(kMatThreads) void k_csv_copy(ColsArg cols, ColIds i
         if (span + 16 <= (uint64_t)kMatStage) {
             if (i < tend) {
                 LdsSink s{stage + (offs[i] - offs[t0]) + (obase & 15)};
-                csv_put_record<NC>(s, cols, ids, ncols, i, qflags[i]);
+                csv_put_record<NC>(s, cols, ids, ncols, mode, i, qflags[i]);
             }
             __syncthreads();
             flush_stage(stage, out, obase, span);
             __syncthreads();
         } else if (i < tend) {
             GlobalSink s{out + out_base + offs[i]};
-            csv_put_record<NC>(s, cols, ids, ncols, i, qflags[i]);
+            csv_put_record<NC>(s, cols, ids, ncols, mode, i, qflags[i]);
         }
     }
 }
@@ -307,6 +318,37 @@ static void csv_append_field_host(std::string* out, const uint8_t* p, uint64_t l
         out->push_back((char)p[i]);
     }
     out->push_back('"');
+}
+
+// The two writer passes over n records of `ncols` columns: lengths -> exclusive scan -> copy.  data_out gets
+// head_bytes + total bytes (the first head_bytes are left for the caller: the header line); offs_out the n+1
+// record offsets relative to the end of the header.
+static Status csv_render(cph_ctx* ctx, const ColsArg& arg, const ColIds& ids, int ncols, CsvMode mode, uint64_t n, uint64_t head_bytes,
+                         DevBuf* offs_out, DevBuf* data_out, uint64_t* total_out) {
+    DevBuf qflags;
+    CPH_TRY(offs_out->alloc(&ctx->pool, (n + 1) * sizeof(uint64_t)));
+    CPH_TRY(qflags.alloc(&ctx->pool, (n + 1) * sizeof(uint16_t)));
+    uint64_t total = 0;
+    if (n) {
+        {
+            ProfScope ps(ctx, mode.newline ? "k_csv_lens" : "k_csv_lens(fragments)", 0);
+            CPH_CSV_DISPATCH(k_csv_lens, ncols, dim3(grid_rows(n)), 0, ctx->stream, arg, ids, ncols, mode, n, offs_out->as<uint64_t>(),
+                             qflags.as<uint16_t>());
+        }
+        CPH_HIP_TRY(hipGetLastError());
+        CPH_TRY(scan_lengths(ctx, offs_out->as<uint64_t>(), n, &total));
+    } else {
+        CPH_HIP_TRY(hipMemsetAsync(offs_out->get(), 0, sizeof(uint64_t), ctx->stream));
+    }
+    CPH_TRY(data_out->alloc(&ctx->pool, head_bytes + total + 16));
+    if (n) {
+        ProfScope ps(ctx, mode.newline ? "k_csv_copy" : "k_csv_copy(fragments)", 2.0 * (double)total + 10.0 * (double)n);
+        CPH_CSV_DISPATCH(k_csv_copy, ncols, dim3(grid_rows(n)), kMatStage, ctx->stream, arg, ids, ncols, mode, n, offs_out->as<uint64_t>(),
+                         qflags.as<uint16_t>(), data_out->as<uint8_t>(), head_bytes);
+        CPH_HIP_TRY(hipGetLastError());
+    }
+    *total_out = total;
+    return {};
 }
 
 }  // namespace cph
@@ -471,32 +513,53 @@ CPH_API int32_t cph_csv_write_rows(cph_ctx* ctx, const cph_strcol* cols, const c
                 }
             }
         }
-        DevBuf offs, qflags;
-        CPH_TRY(offs.alloc(&ctx->pool, (n + 1) * sizeof(uint64_t)));
-        CPH_TRY(qflags.alloc(&ctx->pool, (n + 1) * sizeof(uint16_t)));
-        uint64_t total = 0;
-        if (n) {
-            {
-                ProfScope ps(ctx, "k_csv_lens", 0);
-                CPH_CSV_DISPATCH(k_csv_lens, ncols, dim3(grid_rows(n)), 0, ctx->stream, arg, ids, ncols, n, offs.as<uint64_t>(),
-                                 qflags.as<uint16_t>());
+        // Columns that come from the same table through the same row ids, next to each other in the output, and
+        // from a table much smaller than the output (every table row is used several times): render the fragment
+        // "f1,f2,.." of each TABLE row once, then copy fragments.  The random fetches per output row drop from
+        // (offsets + bytes) per field and pass to one descriptor (+ the bytes in the copy pass) per table.
+        ColsArg farg{};
+        ColIds fids{};
+        CsvMode fmode{0, 1};
+        int nf = 0;
+        std::vector<DevBuf> frag_store;
+        for (int c = 0; c < ncols;) {
+            int e = c + 1;
+            const bool reusable = ids.ids[c].ptr && arg.c[c].nrows * 2 <= n;
+            while (reusable && e < ncols && ids.ids[e].ptr == ids.ids[c].ptr && ids.ids[e].bits == ids.ids[c].bits &&
+                   ids.ids[e].base == ids.ids[c].base && arg.c[e].nrows == arg.c[c].nrows)
+                e++;
+            if (e - c >= 2) {
+                ColsArg garg{};
+                ColIds gids{};
+                for (int k = c; k < e; k++) garg.c[k - c] = arg.c[k];
+                DevBuf foffs, fdata;
+                uint64_t ftotal = 0;
+                CPH_TRY(csv_render(ctx, garg, gids, e - c, CsvMode{0, 0}, arg.c[c].nrows, 0, &foffs, &fdata, &ftotal));
+                farg.c[nf].data = fdata.as<uint8_t>();
+                farg.c[nf].offsets = foffs.get();
+                farg.c[nf].nrows = arg.c[c].nrows;
+                farg.c[nf].offset_bits = 64;
+                farg.c[nf].fixed_width = 0;
+                fmode.raw_mask |= 1u << nf;
+                frag_store.push_back(std::move(foffs));
+                frag_store.push_back(std::move(fdata));
+            } else {
+                farg.c[nf] = arg.c[c];
+                e = c + 1;
             }
-            CPH_HIP_TRY(hipGetLastError());
-            CPH_TRY(scan_lengths(ctx, offs.as<uint64_t>(), n, &total));
+            fids.ids[nf] = ids.ids[c];
+            nf++;
+            c = e;
         }
+        DevBuf offs;
+        uint64_t total = 0;
+        CPH_TRY(csv_render(ctx, farg, fids, nf, fmode, n, head.size(), &offs, &r->d_data, &total));
         const uint64_t size = head.size() + total;
-        CPH_TRY(r->d_data.alloc(&ctx->pool, size + 16));
         if (!head.empty()) {
             void* slot = nullptr;
             CPH_TRY(pinned_upload(ctx, head.size(), &slot));
             memcpy(slot, head.data(), head.size());
             CPH_HIP_TRY(hipMemcpyAsync(r->d_data.get(), slot, head.size(), hipMemcpyHostToDevice, ctx->stream));
-        }
-        if (n) {
-            ProfScope ps(ctx, "k_csv_copy", 2.0 * (double)total + 10.0 * (double)n);
-            CPH_CSV_DISPATCH(k_csv_copy, ncols, dim3(grid_rows(n)), kMatStage, ctx->stream, arg, ids, ncols, n, offs.as<uint64_t>(),
-                             qflags.as<uint16_t>(), r->d_data.as<uint8_t>(), (uint64_t)head.size());
-            CPH_HIP_TRY(hipGetLastError());
         }
         r->pub.size = size;
         r->pub.mem = out_mem;
