@@ -20,7 +20,7 @@ all: hip datagen oracle host
 hip: $(LIBDIR)/libcsvplus_hip.so
 datagen: $(LIBDIR)/libcph_datagen.so
 oracle: oracle/_build/liboracle.so
-host: tests/cpp/test_host
+host: tests/cpp/test_host tests/c/abi_demo
 
 $(LIBDIR)/obj/%.o: $(CSRC)/%.hip $(HIP_HDRS)
 	@mkdir -p $(LIBDIR)/obj
@@ -40,7 +40,10 @@ oracle/_build/liboracle.so: oracle/csvplus_oracle.c
 tests/cpp/test_host: tests/cpp/test_host.cpp csvplus_amd/host/csvplus.hpp include/csvplus_hip.h $(LIBDIR)/libcsvplus_hip.so
 	$(CXX) -O2 -std=c++17 -Wall -Iinclude -Icsvplus_amd/host $< -L$(LIBDIR) -lcsvplus_hip -Wl,-rpath,'$$ORIGIN/../../csvplus_amd/lib' -o $@
 
+tests/c/abi_demo: tests/c/abi_demo.c include/csvplus_hip.h $(LIBDIR)/libcsvplus_hip.so
+	$(CC) -O2 -std=c99 -Wall -Wextra -Iinclude $< -L$(LIBDIR) -lcsvplus_hip -Wl,-rpath,'$$ORIGIN/../../csvplus_amd/lib' -o $@
+
 clean:
-	rm -rf $(LIBDIR) oracle/_build tests/cpp/test_host
+	rm -rf $(LIBDIR) oracle/_build tests/cpp/test_host tests/c/abi_demo
 
 .PHONY: all hip datagen oracle host clean

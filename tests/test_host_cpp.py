@@ -36,3 +36,25 @@ def test_reference_tests_through_cpp_facade():
     print(r.stderr)
     assert r.returncode == 0, r.stdout[-2000:]
     assert "0 of 11 host tests failed" in r.stdout
+
+
+C_DEMO = ROOT / "tests" / "c" / "abi_demo"
+
+
+def test_plain_c_consumer_builds_and_fails_loudly_without_gpu():
+    """The header is C99 and the library links from plain C (what cgo does); without a GPU the program reports it."""
+    import torch
+
+    subprocess.check_call(["make", "-C", str(ROOT), "host"])
+    assert C_DEMO.exists()
+    if not torch.cuda.is_available():
+        r = subprocess.run([str(C_DEMO)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 2 and "no usable GPU" in r.stdout
+
+
+@pytest.mark.gpu
+def test_plain_c_consumer_on_gpu():
+    subprocess.check_call(["make", "-C", str(ROOT), "host"])
+    r = subprocess.run([str(C_DEMO)], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "WRONG" not in r.stdout and r.stdout.count(" ok") == 4
