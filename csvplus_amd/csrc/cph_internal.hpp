@@ -287,6 +287,29 @@ Status validate_cols(const cph_strcol* cols, int32_t ncols);
 // Makes columns device resident (host columns are copied into pool blocks kept alive by `storage`).
 Status stage_cols(cph_ctx* ctx, const cph_strcol* cols, int32_t ncols, std::vector<DevBuf>* storage, DevCol* out);
 
+// Records the error text on the ctx and returns the status code (every extern "C" entry point ends through this).
+inline int32_t fail_with(cph_ctx* ctx, const Status& s) {
+    if (ctx) ctx->err = s.msg;
+    return s.code;
+}
+
+// One value device -> host through the ctx's pinned scratch; synchronises the stream.
+template <class T>
+Status read_device_value(cph_ctx* ctx, const T* dev, T* host) {
+    CPH_TRY(ensure_pinned_scratch(ctx, sizeof(T)));
+    CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, dev, sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    memcpy(host, ctx->pinned_scratch, sizeof(T));
+    return {};
+}
+
+// Grid for a grid-stride loop of 256-thread workgroups over n items.
+inline unsigned grid_for_items(uint64_t n, unsigned cap = 8192) {
+    uint64_t b = (n + 255) / 256;
+    if (b > cap) b = cap;
+    return (unsigned)(b ? b : 1);
+}
+
 // Times everything enqueued on ctx->stream during its lifetime when ctx->profiling is on
 // (two HIP events on that stream); `bytes` = algorithmic bytes of the launch.
 class ProfScope {

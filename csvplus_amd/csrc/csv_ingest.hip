@@ -603,21 +603,6 @@ __global__ __launch_bounds__(kCsvThreads) void k_csv_copy_fields(const uint8_t* 
 
 __global__ void k_csv_set_u64(uint64_t* p, uint64_t v) { *p = v; }
 
-static unsigned grid_for_rows(uint64_t n) {
-    uint64_t b = (n + 255) / 256;
-    if (b > 8192) b = 8192;
-    return (unsigned)(b ? b : 1);
-}
-
-template <class T>
-static Status read_back(cph_ctx* ctx, const T* dev, T* host) {
-    CPH_TRY(ensure_pinned_scratch(ctx, sizeof(T)));
-    CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, dev, sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
-    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    memcpy(host, ctx->pinned_scratch, sizeof(T));
-    return {};
-}
-
 }  // namespace cph
 
 using namespace cph;
@@ -629,28 +614,23 @@ struct cph_csv_table_impl {
     void* h_block = nullptr;
 };
 
-static int32_t csv_fail(cph_ctx* ctx, const Status& s) {
-    if (ctx) ctx->err = s.msg;
-    return s.code;
-}
-
 extern "C" {
 
 CPH_API int32_t cph_csv_parse(cph_ctx* ctx, const uint8_t* data, uint64_t size, int32_t mem, const cph_csv_options* opt,
                               const int32_t* col_index, int32_t ncols, int32_t out_mem, cph_csv_table** out) {
     if (!ctx || !out || !opt || !col_index || ncols < 1 || ncols > CPH_MAX_KEY_COLS || (size && !data)) return CPH_ERR_INVALID;
-    if (hipSetDevice(ctx->device) != hipSuccess) return csv_fail(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail_with(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});
     *out = nullptr;
     if ((mem != CPH_MEM_HOST && mem != CPH_MEM_DEVICE) || (out_mem != CPH_MEM_HOST && out_mem != CPH_MEM_DEVICE))
-        return csv_fail(ctx, {CPH_ERR_INVALID, "bad memory space"});
-    if (opt->lazy_quotes) return csv_fail(ctx, {CPH_ERR_INVALID, "LazyQuotes is not supported by the GPU parser"});
+        return fail_with(ctx, {CPH_ERR_INVALID, "bad memory space"});
+    if (opt->lazy_quotes) return fail_with(ctx, {CPH_ERR_INVALID, "LazyQuotes is not supported by the GPU parser"});
     if (opt->comma == '"' || opt->comma == '\n' || opt->comma == '\r' || opt->comma == 0 || opt->comma >= 0x80 ||
         opt->comment >= 0x80 || (opt->comment && opt->comment == opt->comma))
-        return csv_fail(ctx, {CPH_ERR_INVALID, "unsupported delimiter / comment character"});
+        return fail_with(ctx, {CPH_ERR_INVALID, "unsupported delimiter / comment character"});
     for (int c = 0; c < ncols; c++)
-        if (col_index[c] < 0) return csv_fail(ctx, {CPH_ERR_INVALID, "negative field index"});
+        if (col_index[c] < 0) return fail_with(ctx, {CPH_ERR_INVALID, "negative field index"});
     auto* t = new (std::nothrow) cph_csv_table_impl();
-    if (!t) return csv_fail(ctx, {CPH_ERR_NOMEM, "out of host memory"});
+    if (!t) return fail_with(ctx, {CPH_ERR_NOMEM, "out of host memory"});
     t->ctx = ctx;
     auto run = [&]() -> Status {
         CsvOpts o{opt->comma, opt->comment, opt->trim_leading_space ? 1 : 0};
@@ -690,7 +670,7 @@ CPH_API int32_t cph_csv_parse(cph_ctx* ctx, const uint8_t* data, uint64_t size, 
                                tev.as<uint32_t>(), tod.as<uint32_t>(), cnt.as<uint64_t>(), ntiles);
             CPH_TRY(exclusive_scan_u64(ctx, cnt.as<uint64_t>(), ntiles, cnt.as<uint64_t>() + ntiles));
             uint64_t nsep = 0;
-            CPH_TRY(read_back(ctx, cnt.as<uint64_t>() + ntiles, &nsep));
+            CPH_TRY(read_device_value(ctx, cnt.as<uint64_t>() + ntiles, &nsep));
             const uint64_t nseg = nsep + 1;   // the bytes after the last separator (possibly none) form the last segment
             if (nseg > 0xFFFFFFFFull) return {CPH_ERR_TOO_MANY_ROWS, "more than 2^32-1 lines"};
             DevBuf seps;
@@ -708,7 +688,7 @@ CPH_API int32_t cph_csv_parse(cph_ctx* ctx, const uint8_t* data, uint64_t size, 
             CPH_HIP_TRY(hipMemsetAsync(stats.get(), 0, 3 * sizeof(unsigned long long), ctx->stream));
             {
                 ProfScope ps(ctx, "k_csv_classify", 13.0 * (double)nseg);
-                hipLaunchKernelGGL(k_csv_classify, dim3(std::min(grid_for_rows(nseg), 2048u)), dim3(256), 0, ctx->stream, d, seps.as<uint64_t>(), nseg, o,
+                hipLaunchKernelGGL(k_csv_classify, dim3(std::min(grid_for_items(nseg), 2048u)), dim3(256), 0, ctx->stream, d, seps.as<uint64_t>(), nseg, o,
                                    keep_flag.as<uint32_t>(), stats.as<unsigned long long>());
             }
             CPH_TRY(ensure_pinned_scratch(ctx, 3 * sizeof(unsigned long long)));
@@ -730,7 +710,7 @@ CPH_API int32_t cph_csv_parse(cph_ctx* ctx, const uint8_t* data, uint64_t size, 
                 CPH_TRY(rec_b.alloc(&ctx->pool, (nrec + 1) * sizeof(uint64_t)));
                 CPH_TRY(rec_e.alloc(&ctx->pool, (nrec + 1) * sizeof(uint64_t)));
                 ProfScope ps(ctx, "k_csv_compact", 32.0 * (double)nseg);
-                hipLaunchKernelGGL(k_csv_compact, dim3(grid_for_rows(nseg)), dim3(256), 0, ctx->stream, seps.as<uint64_t>(), nseg,
+                hipLaunchKernelGGL(k_csv_compact, dim3(grid_for_items(nseg)), dim3(256), 0, ctx->stream, seps.as<uint64_t>(), nseg,
                                    keep.as<uint32_t>(), keep_flag.as<uint32_t>(), rec_b.as<uint64_t>(), rec_e.as<uint64_t>());
                 ri.rec_b = rec_b.as<uint64_t>();
                 ri.rec_e = rec_e.as<uint64_t>();
@@ -753,18 +733,18 @@ CPH_API int32_t cph_csv_parse(cph_ctx* ctx, const uint8_t* data, uint64_t size, 
             {
                 ProfScope ps(ctx, "k_csv_fields", (double)size + (double)nrec * (12.0 + (double)osz * ncols));
                 if (off32)
-                    hipLaunchKernelGGL(k_csv_fields<uint32_t>, dim3(grid_for_rows(nrec)), dim3(kCsvThreads), 0, ctx->stream, d, size, ri, nrec, o,
+                    hipLaunchKernelGGL(k_csv_fields<uint32_t>, dim3(grid_for_items(nrec)), dim3(kCsvThreads), 0, ctx->stream, d, size, ri, nrec, o,
                                        cc, reinterpret_cast<uint32_t*>(offs_all), nfields.as<uint32_t>(), errk.as<unsigned long long>());
                 else
-                    hipLaunchKernelGGL(k_csv_fields<uint64_t>, dim3(grid_for_rows(nrec)), dim3(kCsvThreads), 0, ctx->stream, d, size, ri, nrec, o,
+                    hipLaunchKernelGGL(k_csv_fields<uint64_t>, dim3(grid_for_items(nrec)), dim3(kCsvThreads), 0, ctx->stream, d, size, ri, nrec, o,
                                        cc, reinterpret_cast<uint64_t*>(offs_all), nfields.as<uint32_t>(), errk.as<unsigned long long>());
             }
             if (opt->fields_per_record >= 0)
-                hipLaunchKernelGGL(k_csv_check_counts, dim3(grid_for_rows(nrec)), dim3(256), 0, ctx->stream, nfields.as<uint32_t>(),
+                hipLaunchKernelGGL(k_csv_check_counts, dim3(grid_for_items(nrec)), dim3(256), 0, ctx->stream, nfields.as<uint32_t>(),
                                    nrec, opt->fields_per_record, errk.as<unsigned long long>());
             CPH_HIP_TRY(hipGetLastError());
             unsigned long long key = 0;
-            CPH_TRY(read_back(ctx, errk.as<unsigned long long>(), &key));
+            CPH_TRY(read_device_value(ctx, errk.as<unsigned long long>(), &key));
             if (key != ~0ull) {
                 t->pub.error_kind = (int32_t)(key & 7);
                 t->pub.error_record = key >> 3;
@@ -806,10 +786,10 @@ CPH_API int32_t cph_csv_parse(cph_ctx* ctx, const uint8_t* data, uint64_t size, 
             const size_t smem = (size_t)(kCsvStage + 16) + (size_t)(kCsvStage + 32 * kMaxKeyCols) + 2 * kCsvMaskHalves * sizeof(uint16_t) +
                                 (size_t)ncols * (kCsvThreads + 1) * sizeof(uint32_t);
             if (off32)
-                hipLaunchKernelGGL(k_csv_copy_fields<uint32_t>, dim3(grid_for_rows(nout)), dim3(kCsvThreads), smem, ctx->stream, d, size, ri, first,
+                hipLaunchKernelGGL(k_csv_copy_fields<uint32_t>, dim3(grid_for_items(nout)), dim3(kCsvThreads), smem, ctx->stream, d, size, ri, first,
                                    nout, o, cc, reinterpret_cast<const uint32_t*>(offs_all) + first, stride, ptrs.as<uint8_t*>());
             else
-                hipLaunchKernelGGL(k_csv_copy_fields<uint64_t>, dim3(grid_for_rows(nout)), dim3(kCsvThreads), smem, ctx->stream, d, size, ri, first,
+                hipLaunchKernelGGL(k_csv_copy_fields<uint64_t>, dim3(grid_for_items(nout)), dim3(kCsvThreads), smem, ctx->stream, d, size, ri, first,
                                    nout, o, cc, reinterpret_cast<const uint64_t*>(offs_all) + first, stride, ptrs.as<uint8_t*>());
             CPH_HIP_TRY(hipGetLastError());
         }
@@ -857,7 +837,7 @@ CPH_API int32_t cph_csv_parse(cph_ctx* ctx, const uint8_t* data, uint64_t size, 
         (void)hipStreamSynchronize(ctx->stream);
         if (t->h_block) (void)hipHostFree(t->h_block);
         delete t;
-        return csv_fail(ctx, s);
+        return fail_with(ctx, s);
     }
     *out = &t->pub;
     return CPH_OK;

@@ -62,26 +62,6 @@ __global__ void k_select_check(const uint64_t* __restrict__ pos, uint64_t n, uin
         if (pos[i] >= nrows || (i > 0 && pos[i - 1] >= pos[i])) atomicExch(bad, 1u);
 }
 
-static unsigned grid_rows(uint64_t n) {
-    uint64_t b = (n + 255) / 256;
-    if (b > 8192) b = 8192;
-    return (unsigned)(b ? b : 1);
-}
-
-static int32_t ops_fail(cph_ctx* ctx, const Status& s) {
-    if (ctx) ctx->err = s.msg;
-    return s.code;
-}
-
-template <class T>
-static Status read_one(cph_ctx* ctx, const T* dev, T* host) {
-    CPH_TRY(ensure_pinned_scratch(ctx, sizeof(T)));
-    CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, dev, sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
-    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    memcpy(host, ctx->pinned_scratch, sizeof(T));
-    return {};
-}
-
 // Finishes an index whose codec / sorted_codes / perm are in place: unique scan + table.
 static Status finish_index(cph_ctx* ctx, cph_index* ix) {
     CPH_TRY(codec_upload(ctx, ix->codec, &ix->codec_dev));
@@ -128,9 +108,9 @@ extern "C" {
 CPH_API int32_t cph_index_dup_groups(cph_ctx* ctx, const cph_index* ix, cph_groups** out) {
     if (!ctx || !ix || !out) return CPH_ERR_INVALID;
     *out = nullptr;
-    if (hipSetDevice(ctx->device) != hipSuccess) return ops_fail(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail_with(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});
     auto* g = new (std::nothrow) cph_groups_impl();
-    if (!g) return ops_fail(ctx, {CPH_ERR_NOMEM, "out of host memory"});
+    if (!g) return fail_with(ctx, {CPH_ERR_NOMEM, "out of host memory"});
     auto run = [&]() -> Status {
         const uint64_t n = ix->nrows;
         uint64_t ng = 0;
@@ -142,7 +122,7 @@ CPH_API int32_t cph_index_dup_groups(cph_ctx* ctx, const cph_index* ix, cph_grou
             for (int pass = 0; pass < 2; pass++) {
                 {
                     ProfScope ps(ctx, "k_group_flags", (double)n * ((double)code_bytes(ix) + 4.0));
-                    const unsigned grid = grid_rows(n);
+                    const unsigned grid = grid_for_items(n);
                     if (ix->codec.key32) {
                         if (pass == 0) hipLaunchKernelGGL((k_group_flags<true, true>), dim3(grid), dim3(256), 0, ctx->stream, ix->sorted_codes.get(), n, ix->codec.nwords, flags.as<uint32_t>());
                         else hipLaunchKernelGGL((k_group_flags<true, false>), dim3(grid), dim3(256), 0, ctx->stream, ix->sorted_codes.get(), n, ix->codec.nwords, flags.as<uint32_t>());
@@ -155,14 +135,14 @@ CPH_API int32_t cph_index_dup_groups(cph_ctx* ctx, const cph_index* ix, cph_grou
                 CPH_TRY(exclusive_scan_u32(ctx, scan.as<uint32_t>(), n));
                 if (pass == 0) {
                     uint32_t last_scan = 0, last_flag = 0;
-                    CPH_TRY(read_one(ctx, scan.as<uint32_t>() + (n - 1), &last_scan));
-                    CPH_TRY(read_one(ctx, flags.as<uint32_t>() + (n - 1), &last_flag));
+                    CPH_TRY(read_device_value(ctx, scan.as<uint32_t>() + (n - 1), &last_scan));
+                    CPH_TRY(read_device_value(ctx, flags.as<uint32_t>() + (n - 1), &last_flag));
                     ng = (uint64_t)last_scan + last_flag;
                     if (ng == 0) break;
                     CPH_TRY(lo.alloc(&ctx->pool, ng * sizeof(uint64_t)));
                     CPH_TRY(hi.alloc(&ctx->pool, ng * sizeof(uint64_t)));
                 }
-                hipLaunchKernelGGL(k_group_emit, dim3(grid_rows(n)), dim3(256), 0, ctx->stream, flags.as<uint32_t>(), scan.as<uint32_t>(),
+                hipLaunchKernelGGL(k_group_emit, dim3(grid_for_items(n)), dim3(256), 0, ctx->stream, flags.as<uint32_t>(), scan.as<uint32_t>(),
                                    n, (uint64_t)pass /* upper bound is exclusive */, (pass == 0 ? lo : hi).as<uint64_t>());
                 CPH_HIP_TRY(hipGetLastError());
             }
@@ -184,7 +164,7 @@ CPH_API int32_t cph_index_dup_groups(cph_ctx* ctx, const cph_index* ix, cph_grou
         (void)hipStreamSynchronize(ctx->stream);
         if (g->h_block) (void)hipHostFree(g->h_block);
         delete g;
-        return ops_fail(ctx, s);
+        return fail_with(ctx, s);
     }
     *out = &g->pub;
     return CPH_OK;
@@ -200,10 +180,10 @@ CPH_API void cph_groups_release(cph_groups* pub) {
 CPH_API int32_t cph_index_select(cph_ctx* ctx, const cph_index* ix, const uint64_t* positions, uint64_t n, cph_index** out) {
     if (!ctx || !ix || !out || (n && !positions)) return CPH_ERR_INVALID;
     *out = nullptr;
-    if (hipSetDevice(ctx->device) != hipSuccess) return ops_fail(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});
-    if (n > ix->nrows) return ops_fail(ctx, {CPH_ERR_INVALID, "more positions than index rows"});
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail_with(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});
+    if (n > ix->nrows) return fail_with(ctx, {CPH_ERR_INVALID, "more positions than index rows"});
     auto* nx = new (std::nothrow) cph_index();
-    if (!nx) return ops_fail(ctx, {CPH_ERR_NOMEM, "out of host memory"});
+    if (!nx) return fail_with(ctx, {CPH_ERR_NOMEM, "out of host memory"});
     auto run = [&]() -> Status {
         nx->ctx = ctx;
         nx->nrows = n;
@@ -215,10 +195,10 @@ CPH_API int32_t cph_index_select(cph_ctx* ctx, const cph_index* ix, const uint64
         CPH_TRY(bad.alloc(&ctx->pool, sizeof(uint32_t)));
         CPH_HIP_TRY(hipMemsetAsync(bad.get(), 0, sizeof(uint32_t), ctx->stream));
         if (n) CPH_HIP_TRY(hipMemcpyAsync(pos.get(), positions, n * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-        const unsigned grid = grid_rows(n);
+        const unsigned grid = grid_for_items(n);
         hipLaunchKernelGGL(k_select_check, dim3(grid), dim3(256), 0, ctx->stream, pos.as<uint64_t>(), n, ix->nrows, bad.as<uint32_t>());
         uint32_t isbad = 0;
-        CPH_TRY(read_one(ctx, bad.as<uint32_t>(), &isbad));
+        CPH_TRY(read_device_value(ctx, bad.as<uint32_t>(), &isbad));
         if (isbad) return {CPH_ERR_INVALID, "positions must be strictly ascending sorted positions of the index"};
         CPH_TRY(nx->perm.alloc(&ctx->pool, n * sizeof(uint32_t)));
         CPH_TRY(nx->sorted_codes.alloc(&ctx->pool, n * code_bytes(ix)));
@@ -239,7 +219,7 @@ CPH_API int32_t cph_index_select(cph_ctx* ctx, const cph_index* ix, const uint64
     if (!s.ok()) {
         (void)hipStreamSynchronize(ctx->stream);
         delete nx;
-        return ops_fail(ctx, s);
+        return fail_with(ctx, s);
     }
     *out = nx;
     return CPH_OK;
@@ -247,7 +227,7 @@ CPH_API int32_t cph_index_select(cph_ctx* ctx, const cph_index* ix, const uint64
 
 CPH_API int32_t cph_index_save(cph_ctx* ctx, const cph_index* ix, const char* path) {
     if (!ctx || !ix || !path) return CPH_ERR_INVALID;
-    if (hipSetDevice(ctx->device) != hipSuccess) return ops_fail(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail_with(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});
     auto run = [&]() -> Status {
         const CodecHost& cd = ix->codec;
         FileHeader h{};
@@ -290,15 +270,15 @@ CPH_API int32_t cph_index_save(cph_ctx* ctx, const cph_index* ix, const char* pa
         return {};
     };
     Status s = run();
-    return s.ok() ? CPH_OK : ops_fail(ctx, s);
+    return s.ok() ? CPH_OK : fail_with(ctx, s);
 }
 
 CPH_API int32_t cph_index_load(cph_ctx* ctx, const char* path, cph_index** out) {
     if (!ctx || !path || !out) return CPH_ERR_INVALID;
     *out = nullptr;
-    if (hipSetDevice(ctx->device) != hipSuccess) return ops_fail(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail_with(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});
     auto* ix = new (std::nothrow) cph_index();
-    if (!ix) return ops_fail(ctx, {CPH_ERR_NOMEM, "out of host memory"});
+    if (!ix) return fail_with(ctx, {CPH_ERR_NOMEM, "out of host memory"});
     auto run = [&]() -> Status {
         FILE* f = fopen(path, "rb");
         if (!f) return {CPH_ERR_INVALID, std::string("cannot open ") + path};
@@ -347,7 +327,7 @@ CPH_API int32_t cph_index_load(cph_ctx* ctx, const char* path, cph_index** out) 
     if (!s.ok()) {
         (void)hipStreamSynchronize(ctx->stream);
         delete ix;
-        return ops_fail(ctx, s);
+        return fail_with(ctx, s);
     }
     *out = ix;
     return CPH_OK;

@@ -368,25 +368,20 @@ struct cph_bytes_impl {
     void* h_block = nullptr;
 };
 
-static int32_t mat_fail(cph_ctx* ctx, const Status& s) {
-    if (ctx) ctx->err = s.msg;
-    return s.code;
-}
-
 extern "C" {
 
 CPH_API int32_t cph_gather_rows(cph_ctx* ctx, const cph_strcol* col, const void* row_ids, int32_t id_bits, uint64_t id_base,
                                 uint64_t nrows, int32_t out_mem, cph_colbuf** out) {
     if (!ctx || !col || !out) return CPH_ERR_INVALID;
-    if (hipSetDevice(ctx->device) != hipSuccess) return mat_fail(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail_with(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});
     *out = nullptr;
-    if (row_ids && id_bits != 32 && id_bits != 64) return mat_fail(ctx, {CPH_ERR_INVALID, "id_bits must be 32 or 64"});
-    if (out_mem != CPH_MEM_HOST && out_mem != CPH_MEM_DEVICE) return mat_fail(ctx, {CPH_ERR_INVALID, "bad out_mem"});
+    if (row_ids && id_bits != 32 && id_bits != 64) return fail_with(ctx, {CPH_ERR_INVALID, "id_bits must be 32 or 64"});
+    if (out_mem != CPH_MEM_HOST && out_mem != CPH_MEM_DEVICE) return fail_with(ctx, {CPH_ERR_INVALID, "bad out_mem"});
     Status s = validate_cols(col, 1);
-    if (!s.ok()) return mat_fail(ctx, s);
+    if (!s.ok()) return fail_with(ctx, s);
     const uint64_t n = row_ids ? nrows : col->nrows;
     auto* r = new (std::nothrow) cph_colbuf_impl();
-    if (!r) return mat_fail(ctx, {CPH_ERR_NOMEM, "out of host memory"});
+    if (!r) return fail_with(ctx, {CPH_ERR_NOMEM, "out of host memory"});
     r->ctx = ctx;
     auto run = [&]() -> Status {
         std::vector<DevBuf> staged;
@@ -453,7 +448,7 @@ CPH_API int32_t cph_gather_rows(cph_ctx* ctx, const cph_strcol* col, const void*
     if (!s.ok()) {
         if (r->h_block) (void)hipHostFree(r->h_block);
         delete r;
-        return mat_fail(ctx, s);
+        return fail_with(ctx, s);
     }
     *out = &r->pub;
     return CPH_OK;
@@ -470,20 +465,20 @@ CPH_API void cph_colbuf_release(cph_colbuf* pub) {
 CPH_API int32_t cph_csv_write_rows(cph_ctx* ctx, const cph_strcol* cols, const cph_rowsel* sel, int32_t ncols, uint64_t nrows,
                                    const cph_strval* header, int32_t out_mem, cph_bytes** out) {
     if (!ctx || !cols || !out) return CPH_ERR_INVALID;
-    if (hipSetDevice(ctx->device) != hipSuccess) return mat_fail(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail_with(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});
     *out = nullptr;
-    if (out_mem != CPH_MEM_HOST && out_mem != CPH_MEM_DEVICE) return mat_fail(ctx, {CPH_ERR_INVALID, "bad out_mem"});
-    if (ncols < 1 || ncols > CPH_MAX_KEY_COLS) return mat_fail(ctx, {CPH_ERR_INVALID, "1..16 columns"});
+    if (out_mem != CPH_MEM_HOST && out_mem != CPH_MEM_DEVICE) return fail_with(ctx, {CPH_ERR_INVALID, "bad out_mem"});
+    if (ncols < 1 || ncols > CPH_MAX_KEY_COLS) return fail_with(ctx, {CPH_ERR_INVALID, "1..16 columns"});
     for (int c = 0; c < ncols; c++) {
         Status s = validate_cols(cols + c, 1);
-        if (!s.ok()) return mat_fail(ctx, s);
+        if (!s.ok()) return fail_with(ctx, s);
         const bool ident = !sel || !sel[c].ids;
-        if (ident && nrows && cols[c].nrows != nrows) return mat_fail(ctx, {CPH_ERR_INVALID, "a column without row ids must have nrows rows"});
-        if (!ident && sel[c].bits != 32 && sel[c].bits != 64) return mat_fail(ctx, {CPH_ERR_INVALID, "row id bits must be 32 or 64"});
+        if (ident && nrows && cols[c].nrows != nrows) return fail_with(ctx, {CPH_ERR_INVALID, "a column without row ids must have nrows rows"});
+        if (!ident && sel[c].bits != 32 && sel[c].bits != 64) return fail_with(ctx, {CPH_ERR_INVALID, "row id bits must be 32 or 64"});
     }
     const uint64_t n = nrows;
     auto* r = new (std::nothrow) cph_bytes_impl();
-    if (!r) return mat_fail(ctx, {CPH_ERR_NOMEM, "out of host memory"});
+    if (!r) return fail_with(ctx, {CPH_ERR_NOMEM, "out of host memory"});
     r->ctx = ctx;
     auto run = [&]() -> Status {
         std::string head;
@@ -580,7 +575,7 @@ CPH_API int32_t cph_csv_write_rows(cph_ctx* ctx, const cph_strcol* cols, const c
         (void)hipStreamSynchronize(ctx->stream);
         if (r->h_block) (void)hipHostFree(r->h_block);
         delete r;
-        return mat_fail(ctx, s);
+        return fail_with(ctx, s);
     }
     *out = &r->pub;
     return CPH_OK;
