@@ -11,13 +11,18 @@
 // record order is reported with its record index; the records before it are returned, as the
 // reference delivers them before failing.
 //
-// Parallel structure:
-//   1. quotes per 4 KiB tile -> exclusive scan -> quote parity at every tile start
-//   2. record separators = '\n' at even parity: count per tile, scan, write their positions
-//   3. classify the segments between separators (drop empty and comment lines), compact -> records
-//   4. one thread per record runs the sequential field parser (Go readRecord's state machine,
-//      restated): field count, validation, unescaped length of every wanted field
-//   5. per column: exclusive scan of the lengths -> offsets; parse again and copy the bytes
+// Parallel structure (text resident in HBM, 16-byte aligned):
+//   1. k_csv_tile_stats: per 16 KiB tile the number of quotes and of newlines at even / odd quote parity
+//      (SWAR byte masks, ballot prefix parity) -> scans over tiles give the parity at every tile start and the
+//      number of record separators before it
+//   2. k_csv_separators: positions of the newlines outside quotes, in text order
+//   3. k_csv_classify: blank and comment lines; when none was dropped inside the text, record r IS segment r
+//      (no compaction), otherwise k_csv_compact
+//   4. k_csv_fields: 256 records per workgroup, their text staged in LDS together with delimiter / quote
+//      bitmasks; a record without quotes is split with bit scans, any other runs Go readRecord's state
+//      machine; field count, first error, lengths of the wanted fields
+//   5. per column: exclusive scan of the lengths -> offsets; k_csv_copy_fields parses again and assembles
+//      each column's bytes of the tile in LDS, then streams them out
 // A bare quote flips the parity of everything after it, but everything BEFORE the first error is
 // segmented correctly, and only the first error (smallest record index) is reported.
 #include <cstdlib>

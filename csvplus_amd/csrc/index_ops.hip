@@ -302,11 +302,37 @@ CPH_API int32_t cph_index_load(cph_ctx* ctx, const char* path, cph_index** out) 
         cd.radix.resize((size_t)h.npos);
         cd.mult.resize((size_t)h.npos);
         cd.word_of.resize((size_t)h.npos);
-        cd.lut.resize((size_t)h.npos * 257);
+        cd.lut.resize((size_t)h.npos * kLutStride);
         auto get = [&](void* p, size_t nb) { return nb == 0 || fread(p, 1, nb, f) == nb; };
         if (!get(cd.radix.data(), cd.radix.size() * sizeof(uint16_t)) || !get(cd.mult.data(), cd.mult.size() * sizeof(uint64_t)) ||
             !get(cd.word_of.data(), cd.word_of.size() * sizeof(int32_t)) || !get(cd.lut.data(), cd.lut.size() * sizeof(uint16_t)))
             return bad;
+        // the codec drives device-side table walks: refuse values a well-formed file cannot contain
+        if (cd.col_start[0] != 0 || cd.col_start[cd.ncols] != cd.npos) return bad;
+        for (int c = 0; c < cd.ncols; c++)
+            if (cd.col_start[c + 1] < cd.col_start[c] || cd.col_maxlen[c] != cd.col_start[c + 1] - cd.col_start[c] ||
+                cd.col_minlen[c] < 0 || cd.col_minlen[c] > cd.col_maxlen[c])
+                return bad;
+        for (int p = 0; p < cd.npos; p++)
+            if (cd.word_of[(size_t)p] < 0 || cd.word_of[(size_t)p] >= cd.nwords || cd.radix[(size_t)p] < 1 || cd.radix[(size_t)p] > 257) return bad;
+        for (size_t i = 0; i < cd.lut.size(); i++)
+            if (cd.lut[i] != kLutInvalid && cd.lut[i] >= cd.radix[i / kLutStride]) return bad;
+        {   // weights and state counts must be the ones codec_build derives from the radices
+            int p = cd.npos - 1;
+            for (int w = cd.nwords - 1; w >= 0; w--) {
+                unsigned __int128 m = 1;
+                for (; p >= 0 && cd.word_of[(size_t)p] == w; p--) {
+                    if (cd.mult[(size_t)p] != (uint64_t)m) return bad;
+                    m *= cd.radix[(size_t)p];
+                    if (m > ((unsigned __int128)1 << 63)) return bad;
+                }
+                if (cd.word_states[w] != (uint64_t)m) return bad;
+            }
+            if (p != -1) return bad;   // word_of must be non-decreasing along the positions
+        }
+        for (int w = 0; w < cd.nwords; w++)
+            if (cd.word_bits[w] < 0 || cd.word_bits[w] > 64) return bad;
+        if (cd.key32 && (cd.nwords != 1 || cd.word_bits[0] > 32)) return bad;
         ix->ctx = ctx;
         ix->nrows = h.nrows;
         ix->nkeycols = h.nkeycols;
