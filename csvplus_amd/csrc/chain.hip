@@ -70,6 +70,7 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // dynamic LDS layout: [codec 0][codec 1]...   (no static LDS: keeps 16-B alignment)
     const int dbg = DBG ? dbg_flags : 0;
+    const bool nt = DBG && (dbg & 8);   // experiment: non-temporal stream loads / result stores
     CodecView cv[S];
     {
         uint8_t* p = smem;
@@ -108,8 +109,13 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
                 uint32_t b[kChainRows], e[kChainRows];
 #pragma unroll
                 for (int k = 0; k < kChainRows; k++) {
-                    b[k] = ok[k] ? off[row[k]] : 0u;
-                    e[k] = ok[k] ? off[row[k] + 1] : 0u;
+                    if (DBG && nt) {
+                        b[k] = ok[k] ? __builtin_nontemporal_load(&off[row[k]]) : 0u;
+                        e[k] = ok[k] ? __builtin_nontemporal_load(&off[row[k] + 1]) : 0u;
+                    } else {
+                        b[k] = ok[k] ? off[row[k]] : 0u;
+                        e[k] = ok[k] ? off[row[k] + 1] : 0u;
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < kChainRows; k++) {
@@ -139,7 +145,8 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
             const DevCol& c = a.step[s].col;
 #pragma unroll
             for (int k = 0; k < kChainRows; k++) {
-                c0[k][s] = len[k][s] > 0 ? load_value_chunk(c.data, begin[k][s], len[k][s], 0) : 0;
+                if (DBG && nt) c0[k][s] = len[k][s] > 0 ? load_value_chunk<true>(c.data, begin[k][s], len[k][s], 0) : 0;
+                else c0[k][s] = len[k][s] > 0 ? load_value_chunk(c.data, begin[k][s], len[k][s], 0) : 0;
                 if constexpr (LONG) c1[k][s] = len[k][s] > 8 ? load_value_chunk(c.data, begin[k][s], len[k][s], 1) : 0;
             }
         }
@@ -208,7 +215,10 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
             // the stream row of slot r is probe_base + r by construction: it is never stored here
             if (ok[k] && !(DBG && (dbg & 4))) {
 #pragma unroll
-                for (int s = 0; s < S; s++) a.out_rows[s][row[k]] = brow[k][s];
+                for (int s = 0; s < S; s++) {
+                    if (DBG && nt) __builtin_nontemporal_store(brow[k][s], &a.out_rows[s][row[k]]);
+                    else a.out_rows[s][row[k]] = brow[k][s];
+                }
             }
         }
         // per-(tile, wave) match count: no workgroup-level synchronisation inside the tile loop

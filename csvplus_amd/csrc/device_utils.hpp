@@ -80,6 +80,8 @@ __device__ __forceinline__ T block_exclusive_sum(T v, T* smem, T* total) {
 // chunk j of a value = its bytes [8j, 8j+8) packed little-endian (byte 8j in bits 0..7); bytes
 // past the end of the value are unspecified.  Only the aligned 8-byte words that contain at
 // least one byte of the value are touched, so no load can cross into an unmapped page.
+// NT: non-temporal loads (the bytes are streamed once; keeps the caches for data that is re-used).
+template <bool NT = false>
 __device__ __forceinline__ uint64_t load_value_chunk(const uint8_t* data, uint64_t begin, uint64_t len, int j) {
     const uint64_t first = begin + 8ull * (uint64_t)j;                       // byte offset of the chunk
     const uint64_t a = (uint64_t)(uintptr_t)data + first;                    // absolute address
@@ -88,9 +90,9 @@ __device__ __forceinline__ uint64_t load_value_chunk(const uint8_t* data, uint64
     typedef const __attribute__((address_space(1))) uint64_t* global_u64_ptr;
     const global_u64_ptr wp = (global_u64_ptr)(a & ~7ull);
     const int sh = (int)(a & 7ull) * 8;
-    uint64_t w0 = wp[0];
+    uint64_t w0 = NT ? __builtin_nontemporal_load(&wp[0]) : wp[0];
     uint64_t v = w0 >> sh;
-    if (sh != 0 && (last & ~7ull) != (a & ~7ull)) v |= wp[1] << (64 - sh);
+    if (sh != 0 && (last & ~7ull) != (a & ~7ull)) v |= (NT ? __builtin_nontemporal_load(&wp[1]) : wp[1]) << (64 - sh);
     return v;
 }
 
