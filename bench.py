@@ -197,7 +197,8 @@ def main():
         "metric": "joined rows/sec (IndexOn build + chained Join, 1e8-row 3-col orders)",
         "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "u8 keys -> u32 codes", "data": "synthetic",
+        "dtype": "u32", "dtype_note": "byte-string keys (u8) re-coded to order-preserving u32 codes; integer work only",
+        "data": "synthetic",
         "config": {"workload": "orders(1e8 x {cust_id,prod_id,qty}) JOIN customers(1e7, UniqueIndexOn id) "
                                "JOIN products(1e5, UniqueIndexOn prod_id); BASELINE configs[3] shape, probe rows sharded over n_gpus",
                    "rows": args.rows, "customers": args.customers, "products": args.products,
