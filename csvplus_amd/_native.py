@@ -93,7 +93,7 @@ class cph_index_info(C.Structure):
         ("key_bytes", C.c_int32),
         ("sort_passes", C.c_int32),
         ("direct_table", C.c_int32),
-        ("reserved_", C.c_int32),
+        ("dict_entries", C.c_int32),
         ("table_entries", C.c_uint64),
     ]
 

@@ -231,6 +231,7 @@ static Status index_build_impl(cph_ctx* ctx, const cph_strcol* keycols, int32_t 
     std::vector<ColStats> stats;
     CPH_TRY(codec_collect_stats(ctx, dcols, nkeycols, &stats));
     CPH_TRY(codec_build(stats, &ix->codec));
+    CPH_TRY(codec_try_groups(ctx, dcols, nkeycols, n, &ix->codec));   // only acts on codes of several words
     CPH_TRY(codec_upload(ctx, ix->codec, &ix->codec_dev));
     const CodecHost& cd = ix->codec;
 
@@ -724,6 +725,7 @@ CPH_API int32_t cph_index_get_info(const cph_index* ix, cph_index_info* info) {
     info->sort_passes = ix->sort_passes;
     info->direct_table = ix->table_entries ? 1 : 0;
     info->table_entries = ix->table_entries;
+    info->dict_entries = (int32_t)ix->codec.dict.size();
     return CPH_OK;
 }
 

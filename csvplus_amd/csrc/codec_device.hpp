@@ -34,6 +34,11 @@ struct CodecView {
     const CPH_LDS uint8_t* word_of;
     const CPH_LDS uint16_t* lut;     // rank LUT (unused when the pre-multiplied LUT is present)
     const CPH_LDS uint8_t* lutw;     // pre-multiplied LUT, u32 or u64 entries (hdr->lutw_bits)
+    // dictionary-coded groups (hdr->ngroups != 0): see CodecHost
+    const CPH_LDS uint8_t* unit;
+    const CPH_LDS int32_t* dict_off;
+    const CPH_LDS int32_t* dict_len;
+    const CPH_LDS uint64_t* dict;
 };
 
 // Cooperative copy of the codec block (global) into dynamic LDS; returns a view.
@@ -52,6 +57,10 @@ __device__ __forceinline__ CodecView codec_load_to_lds(const uint8_t* g_blob, ui
     v.word_of = l + v.hdr->wordof_off;
     v.lut = (const CPH_LDS uint16_t*)(l + v.hdr->lut_off);
     v.lutw = l + v.hdr->lutw_off;
+    v.unit = l + v.hdr->unit_off;
+    v.dict_off = (const CPH_LDS int32_t*)(l + v.hdr->dictoff_off);
+    v.dict_len = (const CPH_LDS int32_t*)(l + v.hdr->dictlen_off);
+    v.dict = (const CPH_LDS uint64_t*)(l + v.hdr->dict_off);
     return v;
 }
 
@@ -106,6 +115,65 @@ __device__ __forceinline__ bool encode_prefetched_w(const CodecView& cv, const D
     return len <= (uint32_t)maxlen && !(bad >> (sizeof(W) * 8 - 1));
 }
 
+// encode_key for a codec with dictionary-coded groups: a head position takes the rank of the joint symbol of its
+// group (binary search in the LDS dictionary), the absorbed positions behind it contribute nothing.
+template <class Emit>
+__device__ __forceinline__ bool encode_key_groups(const CodecView& cv, const ColsArg& cols, int ncols_used, uint64_t row,
+                                                  Emit&& emit) {
+    const int p_end = cv.hdr->col_start[ncols_used];
+    uint64_t acc = 0;
+    bool valid = true;
+    for (int c = 0; c < ncols_used; c++) {
+        const DevCol& col = cols.c[c];
+        uint64_t begin, len;
+        value_span(col, row, &begin, &len);
+        const int maxlen = cv.hdr->col_maxlen[c];
+        const int p0 = cv.hdr->col_start[c];
+        if (len > (uint64_t)maxlen) valid = false;
+        uint64_t chunk = 0;
+        int chunk_idx = -1;
+        auto sym_at = [&](int q) -> uint32_t {   // 0 = pad, 1 + byte
+            if ((uint64_t)q >= len) return 0u;
+            if ((q >> 3) != chunk_idx) {
+                chunk_idx = q >> 3;
+                chunk = load_value_chunk(col.data, begin, len, chunk_idx);
+            }
+            return ((uint32_t)(chunk >> (8 * (q & 7))) & 0xFFu) + 1u;
+        };
+        for (int q = 0; q < maxlen; q++) {
+            const int p = p0 + q;
+            const uint32_t kind = cv.unit[p];
+            uint64_t r = 0;
+            if (kind == kUnitHead) {
+                uint64_t joint = 0;
+                for (int i = 0; i < kGroupSpan && q + i < maxlen; i++) {
+                    if (i && cv.unit[p + i] != kUnitAbsorbed) break;
+                    joint |= (uint64_t)sym_at(q + i) << (9 * (kGroupSpan - 1 - i));
+                }
+                const CPH_LDS uint64_t* d = cv.dict + cv.dict_off[p];
+                int lo = 0, hi = cv.dict_len[p];
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (d[mid] < joint) lo = mid + 1;
+                    else hi = mid;
+                }
+                if (lo < cv.dict_len[p] && d[lo] == joint) r = (uint64_t)lo;
+                else valid = false;
+            } else if (kind == kUnitPos) {
+                const uint32_t rr = cv.lut[p * kLutStride + (int)sym_at(q)];
+                if (rr == kLutInvalid) valid = false;
+                r = rr;
+            }
+            acc += r * cv.mult[p];
+            if (p + 1 == p_end || cv.word_of[p + 1] != cv.word_of[p]) {
+                emit((int)cv.word_of[p], acc, p);
+                acc = 0;
+            }
+        }
+    }
+    return valid;
+}
+
 // Encodes the leading `ncols_used` key columns of row `row`.
 //   emit(word, value, last_pos) is called once per (possibly partial, for a prefix of
 //   the columns) code word, most significant word first; last_pos is the last byte
@@ -124,6 +192,7 @@ __device__ __forceinline__ bool encode_key(const CodecView& cv, const ColsArg& c
         if (p_end > 0) emit(0, code, p_end - 1);
         return valid;
     }
+    if (cv.hdr->ngroups != 0) return encode_key_groups(cv, cols, ncols_used, row, emit);   // uniform branch
     uint64_t acc = 0;
     bool valid = true;
     for (int c = 0; c < ncols_used; c++) {

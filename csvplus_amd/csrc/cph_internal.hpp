@@ -116,7 +116,19 @@ struct CodecHost {
     std::vector<uint64_t> mult;             // [npos] weight inside its word
     std::vector<int32_t>  word_of;          // [npos]
     std::vector<uint16_t> lut;              // [npos][257] rank or kLutInvalid
+    // Dictionary-coded groups (only used when the per-position code would need several words): a group is up
+    // to kGroupSpan consecutive byte positions of one column whose JOINT symbol (9 bits per position, 63 bits)
+    // takes few distinct values in the build table.  The head position carries radix = #distinct and the rank
+    // comes from a binary search in `dict`; the positions behind it are absorbed (radix 1, every symbol ok).
+    std::vector<uint8_t>  unit;             // [npos] kUnitPos / kUnitHead / kUnitAbsorbed (empty: no groups)
+    std::vector<int32_t>  dict_off;         // [npos] head: first entry of its dictionary in `dict`
+    std::vector<int32_t>  dict_len;         // [npos] head: number of entries
+    std::vector<uint64_t> dict;             // sorted joint symbols of all heads
+    bool has_groups() const { return !unit.empty(); }
 };
+constexpr int kGroupSpan = 7;               // positions per group: 7 x 9 bits = 63
+constexpr int kGroupDictMax = 4096;         // dictionary entries per index (32 KiB of LDS)
+enum : uint8_t { kUnitPos = 0, kUnitHead = 1, kUnitAbsorbed = 2 };
 
 // Device-side codec block, laid out for one cooperative copy into LDS:
 //   header (CodecDevHeader) | mult[npos] u64 | word_of[npos] u8 (padded) | lut[npos*257] u16
@@ -136,6 +148,13 @@ struct CodecDevHeader {
     // alphabet".  lutw_bits = 0 (absent), 32 or 64.
     int32_t lutw_off;
     int32_t lutw_bits;
+    // dictionary-coded groups (all 0 when there are none): unit u8[npos], dict_off/dict_len i32[npos], dict u64[]
+    int32_t ngroups;
+    int32_t unit_off;
+    int32_t dictoff_off;
+    int32_t dictlen_off;
+    int32_t dict_off;
+    int32_t pad_[3];
 };
 
 }  // namespace cph
@@ -218,6 +237,9 @@ struct ColStats {              // per column, produced by one pass over the colu
 };
 Status codec_collect_stats(cph_ctx* ctx, const DevCol* cols, int32_t ncols, std::vector<ColStats>* out);
 Status codec_build(const std::vector<ColStats>& stats, CodecHost* codec);   // host only
+// When the per-position code needs several words: one more pass over the key columns collects the distinct
+// joint symbols of every 7-position group; groups with few of them are dictionary-coded (codec rebuilt in place).
+Status codec_try_groups(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t n, CodecHost* codec);
 Status codec_upload(cph_ctx* ctx, const CodecHost& codec, DevBuf* dev);
 int codec_premultiplied_bits(const CodecHost& codec);   // 0 / 32 / 64
 // Encodes the build-side keys.  key32: out32[n]; else out64[nwords][n].

@@ -86,11 +86,12 @@ struct cph_groups_impl {
 
 // ---- file format ------------------------------------------------------------------------------------------
 namespace {
-constexpr char kMagic[8] = {'C', 'P', 'H', 'I', 'D', 'X', '1', '\n'};
+constexpr char kMagic[8] = {'C', 'P', 'H', 'I', 'D', 'X', '2', '\n'};
 struct FileHeader {
     char magic[8];
     uint64_t nrows;
     int32_t nkeycols, ncols, npos, nwords, key32, sort_passes;
+    int32_t has_groups, ndict;   // dictionary-coded groups: unit/dict_off/dict_len per position + ndict entries
     int32_t col_start[kMaxKeyCols + 1];
     int32_t col_maxlen[kMaxKeyCols];
     int32_t col_minlen[kMaxKeyCols];
@@ -239,6 +240,8 @@ CPH_API int32_t cph_index_save(cph_ctx* ctx, const cph_index* ix, const char* pa
         h.nwords = cd.nwords;
         h.key32 = cd.key32 ? 1 : 0;
         h.sort_passes = ix->sort_passes;
+        h.has_groups = cd.has_groups() ? 1 : 0;
+        h.ndict = (int32_t)cd.dict.size();
         memcpy(h.col_start, cd.col_start, sizeof h.col_start);
         memcpy(h.col_maxlen, cd.col_maxlen, sizeof h.col_maxlen);
         memcpy(h.col_minlen, cd.col_minlen, sizeof h.col_minlen);
@@ -260,6 +263,12 @@ CPH_API int32_t cph_index_save(cph_ctx* ctx, const cph_index* ix, const char* pa
             put(cd.mult.data(), cd.mult.size() * sizeof(uint64_t));
             put(cd.word_of.data(), cd.word_of.size() * sizeof(int32_t));
             put(cd.lut.data(), cd.lut.size() * sizeof(uint16_t));
+            if (cd.has_groups()) {
+                put(cd.unit.data(), cd.unit.size());
+                put(cd.dict_off.data(), cd.dict_off.size() * sizeof(int32_t));
+                put(cd.dict_len.data(), cd.dict_len.size() * sizeof(int32_t));
+                put(cd.dict.data(), cd.dict.size() * sizeof(uint64_t));
+            }
             put(host.data(), host.size());
             ok = ok && fflush(f) == 0;
         }
@@ -307,6 +316,29 @@ CPH_API int32_t cph_index_load(cph_ctx* ctx, const char* path, cph_index** out) 
         if (!get(cd.radix.data(), cd.radix.size() * sizeof(uint16_t)) || !get(cd.mult.data(), cd.mult.size() * sizeof(uint64_t)) ||
             !get(cd.word_of.data(), cd.word_of.size() * sizeof(int32_t)) || !get(cd.lut.data(), cd.lut.size() * sizeof(uint16_t)))
             return bad;
+        if (h.has_groups) {
+            if (h.ndict < 1 || h.ndict > kGroupDictMax) return bad;
+            cd.unit.resize((size_t)h.npos);
+            cd.dict_off.resize((size_t)h.npos);
+            cd.dict_len.resize((size_t)h.npos);
+            cd.dict.resize((size_t)h.ndict);
+            if (!get(cd.unit.data(), cd.unit.size()) || !get(cd.dict_off.data(), cd.dict_off.size() * sizeof(int32_t)) ||
+                !get(cd.dict_len.data(), cd.dict_len.size() * sizeof(int32_t)) || !get(cd.dict.data(), cd.dict.size() * sizeof(uint64_t)))
+                return bad;
+            for (int p = 0; p < cd.npos; p++) {
+                const uint8_t u = cd.unit[(size_t)p];
+                if (u == kUnitHead) {
+                    const int64_t off = cd.dict_off[(size_t)p], len = cd.dict_len[(size_t)p];
+                    if (off < 0 || len < 1 || off + len > h.ndict || cd.radix[(size_t)p] != len) return bad;
+                    for (int64_t i = off + 1; i < off + len; i++)
+                        if (cd.dict[(size_t)i - 1] >= cd.dict[(size_t)i]) return bad;
+                } else if (u == kUnitAbsorbed) {
+                    if (p == 0 || cd.unit[(size_t)p - 1] == kUnitPos || cd.radix[(size_t)p] != 1) return bad;
+                } else if (u != kUnitPos) {
+                    return bad;
+                }
+            }
+        }
         // the codec drives device-side table walks: refuse values a well-formed file cannot contain
         if (cd.col_start[0] != 0 || cd.col_start[cd.ncols] != cd.npos) return bad;
         for (int c = 0; c < cd.ncols; c++)
@@ -314,7 +346,9 @@ CPH_API int32_t cph_index_load(cph_ctx* ctx, const char* path, cph_index** out) 
                 cd.col_minlen[c] < 0 || cd.col_minlen[c] > cd.col_maxlen[c])
                 return bad;
         for (int p = 0; p < cd.npos; p++)
-            if (cd.word_of[(size_t)p] < 0 || cd.word_of[(size_t)p] >= cd.nwords || cd.radix[(size_t)p] < 1 || cd.radix[(size_t)p] > 257) return bad;
+            if (cd.word_of[(size_t)p] < 0 || cd.word_of[(size_t)p] >= cd.nwords || cd.radix[(size_t)p] < 1 ||
+                cd.radix[(size_t)p] > ((cd.has_groups() && cd.unit[(size_t)p] == kUnitHead) ? kGroupDictMax : 257))
+                return bad;
         for (size_t i = 0; i < cd.lut.size(); i++)
             if (cd.lut[i] != kLutInvalid && cd.lut[i] >= cd.radix[i / kLutStride]) return bad;
         {   // weights and state counts must be the ones codec_build derives from the radices

@@ -20,6 +20,9 @@
 //
 // A probe key containing a symbol outside alphabet_p (or longer than the column's longest
 // value) cannot equal any index key: it is "invalid" and matches nothing.
+#include <algorithm>
+#include <cmath>
+
 #include "codec_device.hpp"
 
 namespace cph {
@@ -120,6 +123,41 @@ static int bits_needed(uint64_t states) {  // bits to represent values 0..states
     return b;
 }
 
+// radices -> weights, word boundaries (words of < 2^63 states, most significant first), key32
+static Status codec_split_words(CodecHost* codec) {
+    CodecHost& cd = *codec;
+    const int npos = cd.npos;
+    for (int w = 0; w < kMaxWords; w++) { cd.word_bits[w] = 0; cd.word_states[w] = 0; }
+    const unsigned __int128 kLimit = (unsigned __int128)1 << 63;
+    int w = 0;
+    unsigned __int128 prod = 1;
+    int word_first = 0;
+    auto close_word = [&](int first, int last_excl, int word, unsigned __int128 states) {
+        uint64_t m = 1;
+        for (int p = last_excl - 1; p >= first; p--) {
+            cd.mult[(size_t)p] = m;
+            cd.word_of[(size_t)p] = word;
+            m *= cd.radix[(size_t)p];
+        }
+        cd.word_states[word] = (uint64_t)states;
+        cd.word_bits[word] = bits_needed((uint64_t)states);
+    };
+    for (int p = 0; p < npos; p++) {
+        if (prod * cd.radix[(size_t)p] > kLimit) {
+            if (w + 1 >= kMaxWords) return {CPH_ERR_KEY_TOO_LONG, "key needs too many code words"};
+            close_word(word_first, p, w, prod);
+            w++;
+            word_first = p;
+            prod = 1;
+        }
+        prod *= cd.radix[(size_t)p];
+    }
+    close_word(word_first, npos, w, prod);
+    cd.nwords = w + 1;
+    cd.key32 = (cd.nwords == 1 && cd.word_states[0] <= (1ull << 32));
+    return {};
+}
+
 Status codec_build(const std::vector<ColStats>& stats, CodecHost* codec) {
     CodecHost& cd = *codec;
     cd = CodecHost{};
@@ -156,41 +194,177 @@ Status codec_build(const std::vector<ColStats>& stats, CodecHost* codec) {
             cd.radix[(size_t)p] = rank;   // >= 1 because q < maxlen
         }
     }
-    // split positions into words of < 2^63 states, most significant first
-    const unsigned __int128 kLimit = (unsigned __int128)1 << 63;
-    int w = 0;
-    unsigned __int128 prod = 1;
-    int word_first = 0;
-    auto close_word = [&](int first, int last_excl, int word, unsigned __int128 states) {
-        uint64_t m = 1;
-        for (int p = last_excl - 1; p >= first; p--) {
-            cd.mult[(size_t)p] = m;
-            cd.word_of[(size_t)p] = word;
-            m *= cd.radix[(size_t)p];
+    return codec_split_words(&cd);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dictionary-coded groups.  Per-position alphabets price every position independently: a key like
+// "Smith/Amelia#12345" costs ~4-5 bits for each of its 18 positions although its first bytes take
+// only a hundred distinct values.  When the per-position code does not fit one word, one more pass
+// over the key columns collects, for every group of kGroupSpan consecutive positions of a column,
+// the set of JOINT symbols (9 bits per position: 0 = pad, 1 + byte) that occur — in a small
+// open-addressing table per group, given up as soon as it holds more than kGroupDictMax entries.
+// A group with few distinct joint symbols is then coded by its rank in the sorted set (the order
+// of joint symbols is the lexicographic order of the positions, so codes stay order preserving).
+// ---------------------------------------------------------------------------------------------
+constexpr int kGroupSlots = 16384;            // slots of one group's hash set (power of two)
+constexpr int kGroupMaxGroups = kMaxKeyBytes / kGroupSpan + kMaxKeyCols + 1;
+constexpr uint64_t kGroupEmpty = ~0ull;
+constexpr uint32_t kGroupOverflow = 0x40000000u;
+
+struct GroupLayout {
+    int32_t ngroups;
+    int32_t col[kGroupMaxGroups];     // key column of group g
+    int32_t q0[kGroupMaxGroups];      // first byte offset within the column
+    int32_t span[kGroupMaxGroups];    // positions in the group (1..kGroupSpan)
+};
+
+__device__ __forceinline__ uint64_t group_hash(uint64_t x) {
+    x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 32; x *= 0x94D049BB133111EBull;
+    return x ^ (x >> 29);
+}
+
+__global__ __launch_bounds__(256) void k_group_stats(ColsArg cols, GroupLayout lay, uint64_t n, uint64_t* __restrict__ slots,
+                                                    uint32_t* __restrict__ counts) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t row = (uint64_t)blockIdx.x * 256 + threadIdx.x; row < n; row += stride) {
+        int cur_col = -1;
+        uint64_t begin = 0, len = 0, chunk = 0;
+        int chunk_idx = -1;
+        for (int g = 0; g < lay.ngroups; g++) {
+            if (counts[g] > (uint32_t)kGroupDictMax) continue;   // given up already (a stale read only costs work)
+            if (lay.col[g] != cur_col) {
+                cur_col = lay.col[g];
+                value_span(cols.c[cur_col], row, &begin, &len);
+                chunk_idx = -1;
+            }
+            uint64_t sym = 0;
+            for (int i = 0; i < lay.span[g]; i++) {
+                const int q = lay.q0[g] + i;
+                uint64_t s9 = 0;
+                if ((uint64_t)q < len) {
+                    if ((q >> 3) != chunk_idx) {
+                        chunk_idx = q >> 3;
+                        chunk = load_value_chunk(cols.c[cur_col].data, begin, len, chunk_idx);
+                    }
+                    s9 = ((chunk >> (8 * (q & 7))) & 0xFF) + 1;
+                }
+                sym |= s9 << (9 * (kGroupSpan - 1 - i));
+            }
+            uint64_t* tab = slots + (uint64_t)g * kGroupSlots;
+            uint32_t h = (uint32_t)group_hash(sym) & (kGroupSlots - 1);
+            int probes = 0;
+            for (;; h = (h + 1) & (kGroupSlots - 1)) {
+                const uint64_t cur = tab[h];
+                if (cur == sym) break;
+                if (cur == kGroupEmpty) {
+                    const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&tab[h]), (unsigned long long)kGroupEmpty,
+                                                    (unsigned long long)sym);
+                    if (prev == kGroupEmpty) { atomicAdd(&counts[g], 1u); break; }
+                    if (prev == sym) break;
+                }
+                if (++probes > 128) { atomicOr(&counts[g], kGroupOverflow); break; }   // crowded: too many distinct
+            }
         }
-        cd.word_states[word] = (uint64_t)states;
-        cd.word_bits[word] = bits_needed((uint64_t)states);
-    };
-    for (int p = 0; p < npos; p++) {
-        if (prod * cd.radix[(size_t)p] > kLimit) {
-            if (w + 1 >= kMaxWords) return {CPH_ERR_KEY_TOO_LONG, "key needs too many code words"};
-            close_word(word_first, p, w, prod);
-            w++;
-            word_first = p;
-            prod = 1;
-        }
-        prod *= cd.radix[(size_t)p];
     }
-    close_word(word_first, npos, w, prod);
-    cd.nwords = w + 1;
-    cd.key32 = (cd.nwords == 1 && cd.word_states[0] <= (1ull << 32));
+}
+
+Status codec_try_groups(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t n, CodecHost* codec) {
+    CodecHost& cd = *codec;
+    if (cd.nwords < 2 || n == 0) return {};
+    GroupLayout lay{};
+    for (int c = 0; c < cd.ncols; c++)
+        for (int q0 = 0; q0 < cd.col_maxlen[c]; q0 += kGroupSpan) {
+            const int span = std::min(kGroupSpan, cd.col_maxlen[c] - q0);
+            if (span < 2 || lay.ngroups >= kGroupMaxGroups) continue;
+            lay.col[lay.ngroups] = c;
+            lay.q0[lay.ngroups] = q0;
+            lay.span[lay.ngroups] = span;
+            lay.ngroups++;
+        }
+    if (lay.ngroups == 0) return {};
+    const int ng = lay.ngroups;
+    DevBuf slots, counts;
+    CPH_TRY(slots.alloc(&ctx->pool, (size_t)ng * kGroupSlots * sizeof(uint64_t)));
+    CPH_TRY(counts.alloc(&ctx->pool, (size_t)ng * sizeof(uint32_t)));
+    CPH_HIP_TRY(hipMemsetAsync(slots.get(), 0xFF, (size_t)ng * kGroupSlots * sizeof(uint64_t), ctx->stream));
+    CPH_HIP_TRY(hipMemsetAsync(counts.get(), 0, (size_t)ng * sizeof(uint32_t), ctx->stream));
+    ColsArg arg{};
+    for (int c = 0; c < ncols; c++) arg.c[c] = cols[c];
+    {
+        ProfScope ps(ctx, "k_group_stats", 0);
+        uint64_t nblk = (n + 255) / 256;
+        if (nblk > 4096) nblk = 4096;
+        hipLaunchKernelGGL(k_group_stats, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, arg, lay, n, slots.as<uint64_t>(),
+                           counts.as<uint32_t>());
+        CPH_HIP_TRY(hipGetLastError());
+    }
+    std::vector<uint32_t> hcount((size_t)ng);
+    CPH_TRY(ensure_pinned_scratch(ctx, (size_t)ng * sizeof(uint32_t)));
+    CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, counts.get(), (size_t)ng * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    memcpy(hcount.data(), ctx->pinned_scratch, (size_t)ng * sizeof(uint32_t));
+
+    // candidates: bits saved by coding the group through a dictionary instead of position by position
+    struct Cand { int g; double saved; uint32_t count; };
+    std::vector<Cand> cands;
+    for (int g = 0; g < ng; g++) {
+        if (hcount[(size_t)g] == 0 || hcount[(size_t)g] > (uint32_t)kGroupDictMax) continue;
+        double bits_pos = 0;
+        const int p0 = cd.col_start[lay.col[g]] + lay.q0[g];
+        for (int i = 0; i < lay.span[g]; i++) bits_pos += std::log2((double)cd.radix[(size_t)(p0 + i)]);
+        const double saved = bits_pos - std::log2((double)hcount[(size_t)g]);
+        if (saved >= 1.0) cands.push_back({g, saved, hcount[(size_t)g]});
+    }
+    std::sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.saved > b.saved; });
+    CodecHost trial = cd;
+    trial.unit.assign((size_t)cd.npos, kUnitPos);
+    trial.dict_off.assign((size_t)cd.npos, 0);
+    trial.dict_len.assign((size_t)cd.npos, 0);
+    trial.dict.clear();
+    std::vector<uint64_t> table((size_t)kGroupSlots);
+    int chosen = 0;
+    for (const Cand& cnd : cands) {
+        if (trial.dict.size() + cnd.count > (size_t)kGroupDictMax) continue;
+        CPH_HIP_TRY(hipMemcpyAsync(table.data(), slots.as<uint64_t>() + (size_t)cnd.g * kGroupSlots, kGroupSlots * sizeof(uint64_t),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+        CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        std::vector<uint64_t> syms;
+        for (uint64_t v : table)
+            if (v != kGroupEmpty) syms.push_back(v);
+        if (syms.size() != cnd.count) return {CPH_ERR_HIP, "group dictionary: entry count mismatch"};
+        std::sort(syms.begin(), syms.end());
+        const int p0 = cd.col_start[lay.col[cnd.g]] + lay.q0[cnd.g];
+        trial.unit[(size_t)p0] = kUnitHead;
+        trial.dict_off[(size_t)p0] = (int32_t)trial.dict.size();
+        trial.dict_len[(size_t)p0] = (int32_t)syms.size();
+        trial.radix[(size_t)p0] = (uint16_t)syms.size();
+        for (int s = 0; s < kLutStride; s++) trial.lut[(size_t)p0 * kLutStride + (size_t)s] = kLutInvalid;   // never consulted
+        for (int i = 1; i < lay.span[cnd.g]; i++) {
+            trial.unit[(size_t)(p0 + i)] = kUnitAbsorbed;
+            trial.radix[(size_t)(p0 + i)] = 1;
+            for (int s = 0; s < kLutStride; s++) trial.lut[(size_t)(p0 + i) * kLutStride + (size_t)s] = 0;
+        }
+        trial.dict.insert(trial.dict.end(), syms.begin(), syms.end());
+        chosen++;
+    }
+    if (!chosen) return {};
+    CPH_TRY(codec_split_words(&trial));
+    // worth it only if it removes radix passes (8 bits per pass) or a whole word
+    auto passes = [](const CodecHost& c) {
+        int p = 0;
+        for (int w = 0; w < c.nwords; w++) p += (c.word_bits[w] + 7) / 8;
+        return p;
+    };
+    if (trial.nwords < cd.nwords || passes(trial) < passes(cd)) cd = std::move(trial);
     return {};
 }
 
 // Width (32/64) of the pre-multiplied LUT the device codec block carries, 0 if none: single-word
 // codes whose table stays within 48 KiB of LDS.
 int codec_premultiplied_bits(const CodecHost& cd) {
-    if (cd.nwords != 1 || cd.npos <= 0) return 0;
+    if (cd.nwords != 1 || cd.npos <= 0 || cd.has_groups()) return 0;
     const int bits = cd.word_states[0] <= (1ull << 31) ? 32 : 64;
     return (size_t)cd.npos * kLutStride * (size_t)(bits / 8) <= 48 * 1024 ? bits : 0;
 }
@@ -222,10 +396,28 @@ Status codec_upload(cph_ctx* ctx, const CodecHost& cd, DevBuf* dev) {
         h.lut_off = (int32_t)off;
         off = align16(off + sizeof(uint16_t) * (size_t)cd.npos * kLutStride);
     }
+    if (cd.has_groups()) {
+        h.ngroups = 0;
+        for (int p = 0; p < cd.npos; p++) h.ngroups += cd.unit[(size_t)p] == kUnitHead;
+        h.unit_off = (int32_t)off;
+        off = align16(off + (size_t)cd.npos);
+        h.dictoff_off = (int32_t)off;
+        off = align16(off + sizeof(int32_t) * (size_t)cd.npos);
+        h.dictlen_off = (int32_t)off;
+        off = align16(off + sizeof(int32_t) * (size_t)cd.npos);
+        h.dict_off = (int32_t)off;
+        off = align16(off + sizeof(uint64_t) * cd.dict.size());
+    }
     h.total_bytes = (int32_t)off;
 
     std::vector<uint8_t> blob(off, 0);
     memcpy(blob.data(), &h, sizeof h);
+    if (cd.has_groups()) {
+        memcpy(blob.data() + h.unit_off, cd.unit.data(), (size_t)cd.npos);
+        memcpy(blob.data() + h.dictoff_off, cd.dict_off.data(), sizeof(int32_t) * (size_t)cd.npos);
+        memcpy(blob.data() + h.dictlen_off, cd.dict_len.data(), sizeof(int32_t) * (size_t)cd.npos);
+        memcpy(blob.data() + h.dict_off, cd.dict.data(), sizeof(uint64_t) * cd.dict.size());
+    }
     if (cd.npos) {
         memcpy(blob.data() + h.mult_off, cd.mult.data(), sizeof(uint64_t) * (size_t)cd.npos);
         for (int p = 0; p < cd.npos; p++) blob[(size_t)h.wordof_off + (size_t)p] = (uint8_t)cd.word_of[(size_t)p];
@@ -367,15 +559,35 @@ bool codec_encode_values_host(const CodecHost& cd, const cph_strval* values, int
     *qlo = 0;
     *qhi = 0;
     const int p_end = cd.col_start[nvalues];
+    const bool groups = cd.has_groups();
     uint64_t acc = 0;
     for (int c = 0; c < nvalues; c++) {
         if (values[c].len > (uint64_t)cd.col_maxlen[c]) return false;
         for (int q = 0; q < cd.col_maxlen[c]; q++) {
-            const int sym = (uint64_t)q < values[c].len ? (int)values[c].data[q] + 1 : 0;
             const int p = cd.col_start[c] + q;
-            const uint16_t r = cd.lut[(size_t)p * kLutStride + (size_t)sym];
-            if (r == kLutInvalid) return false;
-            acc += (uint64_t)r * cd.mult[(size_t)p];
+            uint64_t r;
+            const uint8_t kind = groups ? cd.unit[(size_t)p] : kUnitPos;
+            if (kind == kUnitAbsorbed) {
+                r = 0;
+            } else if (kind == kUnitHead) {
+                uint64_t sym = 0;
+                for (int i = 0; i < kGroupSpan && q + i < cd.col_maxlen[c]; i++) {
+                    if (i && cd.unit[(size_t)(p + i)] != kUnitAbsorbed) break;
+                    const uint64_t s9 = (uint64_t)(q + i) < values[c].len ? (uint64_t)values[c].data[q + i] + 1 : 0;
+                    sym |= s9 << (9 * (kGroupSpan - 1 - i));
+                }
+                const uint64_t* d0 = cd.dict.data() + cd.dict_off[(size_t)p];
+                const uint64_t* d1 = d0 + cd.dict_len[(size_t)p];
+                const uint64_t* it = std::lower_bound(d0, d1, sym);
+                if (it == d1 || *it != sym) return false;
+                r = (uint64_t)(it - d0);
+            } else {
+                const int sym = (uint64_t)q < values[c].len ? (int)values[c].data[q] + 1 : 0;
+                const uint16_t rr = cd.lut[(size_t)p * kLutStride + (size_t)sym];
+                if (rr == kLutInvalid) return false;
+                r = rr;
+            }
+            acc += r * cd.mult[(size_t)p];
             if (p + 1 == p_end || cd.word_of[(size_t)p + 1] != cd.word_of[(size_t)p]) {
                 if (p + 1 == p_end) {
                     *qlo = acc;

@@ -437,7 +437,7 @@ typedef struct {
     int32_t  key_bytes;       /* bytes per key the sort kernels move (4 or 8)                 */
     int32_t  sort_passes;     /* radix scatter passes executed                                 */
     int32_t  direct_table;    /* 1 when the probe uses the direct-address table                */
-    int32_t  reserved_;
+    int32_t  dict_entries;    /* entries of the group dictionaries (0: per-position alphabets only)  */
     uint64_t table_entries;   /* entries of the direct-address table (0 if none)               */
 } cph_index_info;
 
