@@ -39,6 +39,9 @@ struct CodecView {
     const CPH_LDS int32_t* dict_off;
     const CPH_LDS int32_t* dict_len;
     const CPH_LDS uint64_t* dict;
+    const CPH_LDS int32_t* hash_off;
+    const CPH_LDS int32_t* hash_bits;
+    const CPH_LDS uint16_t* hash;
 };
 
 // Cooperative copy of the codec block (global) into dynamic LDS; returns a view.
@@ -61,6 +64,9 @@ __device__ __forceinline__ CodecView codec_load_to_lds(const uint8_t* g_blob, ui
     v.dict_off = (const CPH_LDS int32_t*)(l + v.hdr->dictoff_off);
     v.dict_len = (const CPH_LDS int32_t*)(l + v.hdr->dictlen_off);
     v.dict = (const CPH_LDS uint64_t*)(l + v.hdr->dict_off);
+    v.hash_off = (const CPH_LDS int32_t*)(l + v.hdr->hashoff_off);
+    v.hash_bits = (const CPH_LDS int32_t*)(l + v.hdr->hashbits_off);
+    v.hash = (const CPH_LDS uint16_t*)(l + v.hdr->hash_off);
     return v;
 }
 
@@ -115,8 +121,54 @@ __device__ __forceinline__ bool encode_prefetched_w(const CodecView& cv, const D
     return len <= (uint32_t)maxlen && !(bad >> (sizeof(W) * 8 - 1));
 }
 
+// The first 24 bytes of a value, fetched with three independent loads right after its span (two dependent
+// memory round trips per value instead of one per 8-byte chunk).  LONGV = false: the caller guarantees that no
+// offset beyond 23 is asked for (all key columns are at most 24 bytes long), and chunk selection is branch-free;
+// LONGV = true: later chunks come from memory on demand.
+template <bool LONGV = true>
+struct ValueHeadT {
+    uint64_t begin = 0, len = 0, c0 = 0, c1 = 0, c2 = 0;
+    __device__ __forceinline__ void span(const DevCol& col, uint64_t row) { value_span(col, row, &begin, &len); }
+    __device__ __forceinline__ void chunks(const DevCol& col) {
+        c0 = len > 0 ? load_value_chunk(col.data, begin, len, 0) : 0;
+        c1 = len > 8 ? load_value_chunk(col.data, begin, len, 1) : 0;
+        c2 = len > 16 ? load_value_chunk(col.data, begin, len, 2) : 0;
+    }
+    __device__ __forceinline__ void load(const DevCol& col, uint64_t row) {
+        span(col, row);
+        chunks(col);
+    }
+    // bytes [8j, 8j+8) of the value (unspecified past its end; 0 when the chunk lies entirely past it)
+    __device__ __forceinline__ uint64_t chunk(const DevCol& col, int j) const {
+        if constexpr (LONGV) {
+            if (8ull * (uint64_t)j >= len) return 0;
+            return j == 0 ? c0 : j == 1 ? c1 : j == 2 ? c2 : load_value_chunk(col.data, begin, len, j);
+        } else {
+            return j == 0 ? c0 : j == 1 ? c1 : j == 2 ? c2 : 0;   // c1 / c2 are 0 when the value ends before them
+        }
+    }
+    // symbol at byte offset q: 0 = pad (the value ended), 1 + byte otherwise
+    __device__ __forceinline__ uint32_t sym(const DevCol& col, int q) const {
+        const uint32_t b = ((uint32_t)(chunk(col, q >> 3) >> (8 * (q & 7))) & 0xFFu) + 1u;
+        return (uint64_t)q < len ? b : 0u;
+    }
+    // the value's bytes from offset q on, little-endian (byte i = value byte q + i), at least 7 of them
+    __device__ __forceinline__ uint64_t window(const DevCol& col, int q) const {
+        const int sh = (q & 7) * 8;
+        const uint64_t lo = chunk(col, q >> 3);
+        if (sh == 0) return lo;
+        return (lo >> sh) | (chunk(col, (q >> 3) + 1) << (64 - sh));
+    }
+    // raw key (group_raw) of the group of `span` positions starting at offset q
+    __device__ __forceinline__ uint64_t raw(const DevCol& col, int q, int span) const {
+        const uint64_t nvalid = len > (uint64_t)q ? (len - (uint64_t)q < (uint64_t)span ? len - (uint64_t)q : (uint64_t)span) : 0;
+        return group_raw(window(col, q), nvalid);
+    }
+};
+using ValueHead = ValueHeadT<true>;
+
 // encode_key for a codec with dictionary-coded groups: a head position takes the rank of the joint symbol of its
-// group (binary search in the LDS dictionary), the absorbed positions behind it contribute nothing.
+// group's raw key (hash lookup in the LDS dictionary), the absorbed positions behind it contribute nothing.
 template <class Emit>
 __device__ __forceinline__ bool encode_key_groups(const CodecView& cv, const ColsArg& cols, int ncols_used, uint64_t row,
                                                   Emit&& emit) {
@@ -130,37 +182,34 @@ __device__ __forceinline__ bool encode_key_groups(const CodecView& cv, const Col
         const int maxlen = cv.hdr->col_maxlen[c];
         const int p0 = cv.hdr->col_start[c];
         if (len > (uint64_t)maxlen) valid = false;
-        uint64_t chunk = 0;
-        int chunk_idx = -1;
-        auto sym_at = [&](int q) -> uint32_t {   // 0 = pad, 1 + byte
-            if ((uint64_t)q >= len) return 0u;
-            if ((q >> 3) != chunk_idx) {
-                chunk_idx = q >> 3;
-                chunk = load_value_chunk(col.data, begin, len, chunk_idx);
-            }
-            return ((uint32_t)(chunk >> (8 * (q & 7))) & 0xFFu) + 1u;
-        };
+        ValueHead v;
+        v.begin = begin;
+        v.len = len;
+        v.chunks(col);
         for (int q = 0; q < maxlen; q++) {
             const int p = p0 + q;
             const uint32_t kind = cv.unit[p];
             uint64_t r = 0;
             if (kind == kUnitHead) {
-                uint64_t joint = 0;
-                for (int i = 0; i < kGroupSpan && q + i < maxlen; i++) {
-                    if (i && cv.unit[p + i] != kUnitAbsorbed) break;
-                    joint |= (uint64_t)sym_at(q + i) << (9 * (kGroupSpan - 1 - i));
-                }
+                int span = 1;
+                while (span < kGroupSpan && q + span < maxlen && cv.unit[p + span] == kUnitAbsorbed) span++;
+                const uint64_t joint = v.raw(col, q, span);
+                // hash lookup: rank + 1 at the slot, verified against the dictionary entry
                 const CPH_LDS uint64_t* d = cv.dict + cv.dict_off[p];
-                int lo = 0, hi = cv.dict_len[p];
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (d[mid] < joint) lo = mid + 1;
-                    else hi = mid;
+                const CPH_LDS uint16_t* ht = cv.hash + cv.hash_off[p];
+                const int bits = cv.hash_bits[p];
+                const uint32_t mask = (1u << bits) - 1u;
+                uint32_t sl = bits ? group_slot(joint, bits) : 0u;
+                bool found = false;
+                for (;;) {
+                    const uint32_t e = ht[sl];
+                    if (e == 0) break;
+                    if (d[e - 1] == joint) { r = (uint64_t)(e - 1); found = true; break; }
+                    sl = (sl + 1) & mask;
                 }
-                if (lo < cv.dict_len[p] && d[lo] == joint) r = (uint64_t)lo;
-                else valid = false;
+                if (!found) valid = false;
             } else if (kind == kUnitPos) {
-                const uint32_t rr = cv.lut[p * kLutStride + (int)sym_at(q)];
+                const uint32_t rr = cv.lut[p * kLutStride + (int)v.sym(col, q)];
                 if (rr == kLutInvalid) valid = false;
                 r = rr;
             }

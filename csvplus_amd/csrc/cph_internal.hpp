@@ -117,16 +117,17 @@ struct CodecHost {
     std::vector<int32_t>  word_of;          // [npos]
     std::vector<uint16_t> lut;              // [npos][257] rank or kLutInvalid
     // Dictionary-coded groups (only used when the per-position code would need several words): a group is up
-    // to kGroupSpan consecutive byte positions of one column whose JOINT symbol (9 bits per position, 63 bits)
-    // takes few distinct values in the build table.  The head position carries radix = #distinct and the rank
-    // comes from a binary search in `dict`; the positions behind it are absorbed (radix 1, every symbol ok).
+    // to kGroupSpan consecutive byte positions of one column whose bytes JOINTLY take few distinct values in the
+    // build table.  The head position carries radix = #distinct; its rank is the index of the window's raw key
+    // (group_raw) in `dict`, which lists the raw keys in the order of their position tuples (group_order_key);
+    // the positions behind the head are absorbed (radix 1, every symbol ok).
     std::vector<uint8_t>  unit;             // [npos] kUnitPos / kUnitHead / kUnitAbsorbed (empty: no groups)
     std::vector<int32_t>  dict_off;         // [npos] head: first entry of its dictionary in `dict`
     std::vector<int32_t>  dict_len;         // [npos] head: number of entries
-    std::vector<uint64_t> dict;             // sorted joint symbols of all heads
+    std::vector<uint64_t> dict;             // raw keys of all heads, each head's in rank order
     bool has_groups() const { return !unit.empty(); }
 };
-constexpr int kGroupSpan = 7;               // positions per group: 7 x 9 bits = 63
+constexpr int kGroupSpan = 7;               // positions per group: 7 bytes + a length fit one 64-bit raw key
 constexpr int kGroupDictMax = 4096;         // dictionary entries per index (32 KiB of LDS)
 enum : uint8_t { kUnitPos = 0, kUnitHead = 1, kUnitAbsorbed = 2 };
 
@@ -154,8 +155,33 @@ struct CodecDevHeader {
     int32_t dictoff_off;
     int32_t dictlen_off;
     int32_t dict_off;
-    int32_t pad_[3];
+    // open-addressing lookup of a raw key: slot = group_slot(raw, hash_bits[p]); hash u16[] holds rank + 1
+    // (0 = empty) at hash_off[p] + slot, verified against dict[]; built by codec_upload
+    int32_t hashoff_off;   // i32[npos]
+    int32_t hashbits_off;  // i32[npos]
+    int32_t hash_off;      // u16[]
 };
+#if defined(__HIPCC__)
+#define CPH_HD __host__ __device__
+#else
+#define CPH_HD
+#endif
+// Slot of a raw key in a head's hash table of 2^bits slots (host and device must agree).
+CPH_HD inline uint32_t group_slot(uint64_t raw, int bits) { return (uint32_t)((raw * 0x9E3779B97F4A7C15ull) >> (64 - bits)); }
+// Raw key of a group window: `window` holds the value's bytes from the group's first position on (byte i of the
+// window = value byte q0 + i, anything past the value's end), nvalid = how many of the group's positions the value
+// still covers (0..span <= 7).  Injective in (nvalid, the valid bytes): cheap to form, used for equality only.
+CPH_HD inline uint64_t group_raw(uint64_t window, uint64_t nvalid) {
+    return (window & ((1ull << (8 * nvalid)) - 1ull)) | (nvalid << 56);
+}
+// Order key of a raw key: 9 bits per position (0 = the value ended, 1 + byte), first position on top — compares
+// like the tuple of the group's position symbols, i.e. like strings.Compare on that stretch of the key.
+CPH_HD inline uint64_t group_order_key(uint64_t raw, int span) {
+    const int nvalid = (int)(raw >> 56);
+    uint64_t k = 0;
+    for (int i = 0; i < span && i < nvalid; i++) k |= (((raw >> (8 * i)) & 0xFFull) + 1ull) << (9 * (kGroupSpan - 1 - i));
+    return k;
+}
 
 }  // namespace cph
 

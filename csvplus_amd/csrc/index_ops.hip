@@ -330,8 +330,13 @@ CPH_API int32_t cph_index_load(cph_ctx* ctx, const char* path, cph_index** out) 
                 if (u == kUnitHead) {
                     const int64_t off = cd.dict_off[(size_t)p], len = cd.dict_len[(size_t)p];
                     if (off < 0 || len < 1 || off + len > h.ndict || cd.radix[(size_t)p] != len) return bad;
-                    for (int64_t i = off + 1; i < off + len; i++)
-                        if (cd.dict[(size_t)i - 1] >= cd.dict[(size_t)i]) return bad;
+                    int span = 1;
+                    while (span < kGroupSpan && p + span < cd.npos && cd.unit[(size_t)(p + span)] == kUnitAbsorbed) span++;
+                    for (int64_t i = off; i < off + len; i++) {   // raw keys: well formed, in strict tuple order
+                        const uint64_t raw = cd.dict[(size_t)i], nvalid = raw >> 56;
+                        if (nvalid > (uint64_t)span || raw != group_raw(raw, nvalid)) return bad;
+                        if (i > off && group_order_key(cd.dict[(size_t)i - 1], span) >= group_order_key(raw, span)) return bad;
+                    }
                 } else if (u == kUnitAbsorbed) {
                     if (p == 0 || cd.unit[(size_t)p - 1] == kUnitPos || cd.radix[(size_t)p] != 1) return bad;
                 } else if (u != kUnitPos) {

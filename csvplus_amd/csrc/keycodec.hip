@@ -202,21 +202,31 @@ Status codec_build(const std::vector<ColStats>& stats, CodecHost* codec) {
 // "Smith/Amelia#12345" costs ~4-5 bits for each of its 18 positions although its first bytes take
 // only a hundred distinct values.  When the per-position code does not fit one word, one more pass
 // over the key columns collects, for every group of kGroupSpan consecutive positions of a column,
-// the set of JOINT symbols (9 bits per position: 0 = pad, 1 + byte) that occur — in a small
-// open-addressing table per group, given up as soon as it holds more than kGroupDictMax entries.
-// A group with few distinct joint symbols is then coded by its rank in the sorted set (the order
-// of joint symbols is the lexicographic order of the positions, so codes stay order preserving).
+// the set of byte windows (raw keys: the valid bytes + their count, group_raw) that occur — in a
+// small open-addressing table per group, given up as soon as it holds more than kGroupDictMax
+// entries.  A group with few distinct windows is then coded by the rank of its window among them,
+// ranked by the tuple of position symbols (group_order_key), so codes stay order preserving.
 // ---------------------------------------------------------------------------------------------
 constexpr int kGroupSlots = 16384;            // slots of one group's hash set (power of two)
-constexpr int kGroupMaxGroups = kMaxKeyBytes / kGroupSpan + kMaxKeyCols + 1;
 constexpr uint64_t kGroupEmpty = ~0ull;
 constexpr uint32_t kGroupOverflow = 0x40000000u;
 
+// Candidate groups: every window of kGroupSpan positions ("base") is examined as a whole and as its two halves
+// (4 + 3 positions), all in the same pass: variable-length fields shift what follows them, and a half often
+// stays low-cardinality where the whole window does not.
+constexpr int kGroupMaxBases = kMaxKeyBytes / kGroupSpan + kMaxKeyCols + 1;
+constexpr int kGroupMaxTables = 3 * kGroupMaxBases;
+constexpr int kGroupHalf = 4;                 // positions of the first half
+constexpr int kGroupRows = 4;                 // rows per thread and iteration in k_group_stats
+
 struct GroupLayout {
-    int32_t ngroups;
-    int32_t col[kGroupMaxGroups];     // key column of group g
-    int32_t q0[kGroupMaxGroups];      // first byte offset within the column
-    int32_t span[kGroupMaxGroups];    // positions in the group (1..kGroupSpan)
+    int32_t nbases, ntables;
+    int32_t col[kGroupMaxBases];      // key column of the base window
+    int32_t q0[kGroupMaxBases];       // first byte offset within the column
+    int32_t span[kGroupMaxBases];     // positions in the window (2..kGroupSpan)
+    int32_t tab_base[kGroupMaxTables];    // table t examines base tab_base[t] ...
+    int32_t tab_first[kGroupMaxTables];   // ... from its position tab_first[t] ...
+    int32_t tab_span[kGroupMaxTables];    // ... over tab_span[t] positions
 };
 
 __device__ __forceinline__ uint64_t group_hash(uint64_t x) {
@@ -225,46 +235,72 @@ __device__ __forceinline__ uint64_t group_hash(uint64_t x) {
     return x ^ (x >> 29);
 }
 
-__global__ __launch_bounds__(256) void k_group_stats(ColsArg cols, GroupLayout lay, uint64_t n, uint64_t* __restrict__ slots,
-                                                    uint32_t* __restrict__ counts) {
-    const uint64_t stride = (uint64_t)gridDim.x * 256;
-    for (uint64_t row = (uint64_t)blockIdx.x * 256 + threadIdx.x; row < n; row += stride) {
-        int cur_col = -1;
-        uint64_t begin = 0, len = 0, chunk = 0;
-        int chunk_idx = -1;
-        for (int g = 0; g < lay.ngroups; g++) {
-            if (counts[g] > (uint32_t)kGroupDictMax) continue;   // given up already (a stale read only costs work)
-            if (lay.col[g] != cur_col) {
-                cur_col = lay.col[g];
-                value_span(cols.c[cur_col], row, &begin, &len);
-                chunk_idx = -1;
-            }
-            uint64_t sym = 0;
-            for (int i = 0; i < lay.span[g]; i++) {
-                const int q = lay.q0[g] + i;
-                uint64_t s9 = 0;
-                if ((uint64_t)q < len) {
-                    if ((q >> 3) != chunk_idx) {
-                        chunk_idx = q >> 3;
-                        chunk = load_value_chunk(cols.c[cur_col].data, begin, len, chunk_idx);
-                    }
-                    s9 = ((chunk >> (8 * (q & 7))) & 0xFF) + 1;
+__device__ __forceinline__ void group_insert(uint64_t* tab, uint32_t* count, uint64_t sym, uint32_t hash) {
+    uint32_t h = hash & (kGroupSlots - 1);
+    int probes = 0;
+    for (;; h = (h + 1) & (kGroupSlots - 1)) {
+        const uint64_t cur = tab[h];
+        if (cur == sym) return;
+        if (cur == kGroupEmpty) {
+            const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&tab[h]), (unsigned long long)kGroupEmpty,
+                                            (unsigned long long)sym);
+            if (prev == kGroupEmpty) { atomicAdd(count, 1u); return; }
+            if (prev == sym) return;
+        }
+        if (++probes > 128) { atomicOr(count, kGroupOverflow); return; }   // crowded: too many distinct symbols
+    }
+}
+
+// examines rows 0, step, 2*step, ... (< n).  Each workgroup keeps a direct-mapped cache of the symbols it has
+// already seen per table in LDS (cache_bits: log2 entries per table; dynamic LDS = ntables << (cache_bits + 3)):
+// almost every row repeats a known symbol and never leaves the CU.
+template <bool LONGV>
+__global__ __launch_bounds__(256) void k_group_stats(ColsArg cols, GroupLayout lay, uint64_t n, uint64_t step, int cache_bits,
+                                                    uint64_t* __restrict__ slots, uint32_t* __restrict__ counts) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    CPH_LDS uint64_t* seen = (CPH_LDS uint64_t*)smem;
+    const uint32_t cache_n = 1u << cache_bits;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)lay.ntables * cache_n; i += 256) seen[i] = kGroupEmpty;
+    __syncthreads();
+    // kGroupRows rows per thread and iteration, their loads issued together (one row at a time is latency-bound)
+    const uint64_t stride = (uint64_t)gridDim.x * 256 * kGroupRows;
+    const uint64_t nsel = (n + step - 1) / step;
+    for (uint64_t base = (uint64_t)blockIdx.x * 256 * kGroupRows; base < nsel; base += stride) {
+        int cur_col = -1, cur_base = -1;
+        ValueHeadT<LONGV> v[kGroupRows];
+        uint64_t win[kGroupRows];   // the value's bytes from the base window's first position on
+        bool live[kGroupRows];
+#pragma unroll
+        for (int k = 0; k < kGroupRows; k++) live[k] = base + (uint64_t)k * 256 + threadIdx.x < nsel;
+        for (int t = 0; t < lay.ntables; t++) {
+            const int g = lay.tab_base[t];
+            if (g != cur_base) {
+                cur_base = g;
+                if (lay.col[g] != cur_col) {
+                    cur_col = lay.col[g];
+#pragma unroll
+                    for (int k = 0; k < kGroupRows; k++)
+                        if (live[k]) v[k].span(cols.c[cur_col], (base + (uint64_t)k * 256 + threadIdx.x) * step);
+#pragma unroll
+                    for (int k = 0; k < kGroupRows; k++)
+                        if (live[k]) v[k].chunks(cols.c[cur_col]);
                 }
-                sym |= s9 << (9 * (kGroupSpan - 1 - i));
+#pragma unroll
+                for (int k = 0; k < kGroupRows; k++) win[k] = live[k] ? v[k].window(cols.c[cur_col], lay.q0[g]) : 0;
             }
-            uint64_t* tab = slots + (uint64_t)g * kGroupSlots;
-            uint32_t h = (uint32_t)group_hash(sym) & (kGroupSlots - 1);
-            int probes = 0;
-            for (;; h = (h + 1) & (kGroupSlots - 1)) {
-                const uint64_t cur = tab[h];
-                if (cur == sym) break;
-                if (cur == kGroupEmpty) {
-                    const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&tab[h]), (unsigned long long)kGroupEmpty,
-                                                    (unsigned long long)sym);
-                    if (prev == kGroupEmpty) { atomicAdd(&counts[g], 1u); break; }
-                    if (prev == sym) break;
-                }
-                if (++probes > 128) { atomicOr(&counts[g], kGroupOverflow); break; }   // crowded: too many distinct
+#pragma unroll
+            for (int k = 0; k < kGroupRows; k++) {
+                if (!live[k]) continue;
+                // raw key of the sub-window (group_raw): its bytes still covered by the value + how many they are
+                const uint64_t q = (uint64_t)(lay.q0[g] + lay.tab_first[t]);
+                const uint64_t left = v[k].len > q ? v[k].len - q : 0;
+                const uint64_t sym = group_raw(win[k] >> (8 * lay.tab_first[t]), left < (uint64_t)lay.tab_span[t] ? left : (uint64_t)lay.tab_span[t]);
+                const uint64_t hs = group_hash(sym);
+                CPH_LDS uint64_t* mine = seen + ((uint32_t)t << cache_bits) + ((uint32_t)(hs >> 32) & (cache_n - 1));
+                if (*mine == sym) continue;                          // seen by this workgroup: already in the table
+                if (counts[t] > (uint32_t)kGroupDictMax) continue;   // given up already (a stale read only costs work)
+                group_insert(slots + (uint64_t)t * kGroupSlots, &counts[t], sym, (uint32_t)hs);
+                *mine = sym;   // racing writers store whole symbols they inserted: any survivor is a valid entry
             }
         }
     }
@@ -277,45 +313,107 @@ Status codec_try_groups(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_
     for (int c = 0; c < cd.ncols; c++)
         for (int q0 = 0; q0 < cd.col_maxlen[c]; q0 += kGroupSpan) {
             const int span = std::min(kGroupSpan, cd.col_maxlen[c] - q0);
-            if (span < 2 || lay.ngroups >= kGroupMaxGroups) continue;
-            lay.col[lay.ngroups] = c;
-            lay.q0[lay.ngroups] = q0;
-            lay.span[lay.ngroups] = span;
-            lay.ngroups++;
+            if (span < 2 || lay.nbases >= kGroupMaxBases) continue;
+            const int g = lay.nbases++;
+            lay.col[g] = c;
+            lay.q0[g] = q0;
+            lay.span[g] = span;
+            auto add = [&](int first, int sp) {
+                if (sp < 2) return;
+                lay.tab_base[lay.ntables] = g;
+                lay.tab_first[lay.ntables] = first;
+                lay.tab_span[lay.ntables] = sp;
+                lay.ntables++;
+            };
+            add(0, span);
+            if (span > kGroupHalf) {
+                add(0, kGroupHalf);
+                add(kGroupHalf, span - kGroupHalf);
+            }
         }
-    if (lay.ngroups == 0) return {};
-    const int ng = lay.ngroups;
-    DevBuf slots, counts;
-    CPH_TRY(slots.alloc(&ctx->pool, (size_t)ng * kGroupSlots * sizeof(uint64_t)));
-    CPH_TRY(counts.alloc(&ctx->pool, (size_t)ng * sizeof(uint32_t)));
-    CPH_HIP_TRY(hipMemsetAsync(slots.get(), 0xFF, (size_t)ng * kGroupSlots * sizeof(uint64_t), ctx->stream));
-    CPH_HIP_TRY(hipMemsetAsync(counts.get(), 0, (size_t)ng * sizeof(uint32_t), ctx->stream));
+    if (lay.ntables == 0) return {};
     ColsArg arg{};
     for (int c = 0; c < ncols; c++) arg.c[c] = cols[c];
-    {
-        ProfScope ps(ctx, "k_group_stats", 0);
-        uint64_t nblk = (n + 255) / 256;
-        if (nblk > 4096) nblk = 4096;
-        hipLaunchKernelGGL(k_group_stats, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, arg, lay, n, slots.as<uint64_t>(),
-                           counts.as<uint32_t>());
-        CPH_HIP_TRY(hipGetLastError());
-    }
-    std::vector<uint32_t> hcount((size_t)ng);
-    CPH_TRY(ensure_pinned_scratch(ctx, (size_t)ng * sizeof(uint32_t)));
-    CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, counts.get(), (size_t)ng * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    memcpy(hcount.data(), ctx->pinned_scratch, (size_t)ng * sizeof(uint32_t));
-
-    // candidates: bits saved by coding the group through a dictionary instead of position by position
-    struct Cand { int g; double saved; uint32_t count; };
-    std::vector<Cand> cands;
-    for (int g = 0; g < ng; g++) {
-        if (hcount[(size_t)g] == 0 || hcount[(size_t)g] > (uint32_t)kGroupDictMax) continue;
+    bool long_values = false;   // any key column with values of more than 24 bytes
+    for (int c = 0; c < cd.ncols; c++) long_values |= cd.col_maxlen[c] > 24;
+    DevBuf slots, counts;
+    std::vector<uint32_t> hcount;
+    // one stats pass over every `step`-th row with the tables of `l`
+    auto run_pass = [&](const GroupLayout& l, uint64_t step) -> Status {
+        const int nt = l.ntables;
+        CPH_TRY(slots.alloc(&ctx->pool, (size_t)nt * kGroupSlots * sizeof(uint64_t)));
+        CPH_TRY(counts.alloc(&ctx->pool, (size_t)nt * sizeof(uint32_t)));
+        CPH_HIP_TRY(hipMemsetAsync(slots.get(), 0xFF, (size_t)nt * kGroupSlots * sizeof(uint64_t), ctx->stream));
+        CPH_HIP_TRY(hipMemsetAsync(counts.get(), 0, (size_t)nt * sizeof(uint32_t), ctx->stream));
+        {
+            ProfScope ps(ctx, "k_group_stats", 0);
+            uint64_t nblk = ((n + step - 1) / step + 256 * kGroupRows - 1) / (256 * kGroupRows);
+            if (nblk > 2048) nblk = 2048;
+            int cache_bits = 10;                                    // at most 32 KiB of LDS shared by the tables
+            while (cache_bits > 5 && ((size_t)nt << (cache_bits + 3)) > 32 * 1024) cache_bits--;
+            if (long_values)
+                hipLaunchKernelGGL(k_group_stats<true>, dim3((unsigned)nblk), dim3(256), (size_t)nt << (cache_bits + 3), ctx->stream, arg, l, n,
+                                   step, cache_bits, slots.as<uint64_t>(), counts.as<uint32_t>());
+            else
+                hipLaunchKernelGGL(k_group_stats<false>, dim3((unsigned)nblk), dim3(256), (size_t)nt << (cache_bits + 3), ctx->stream, arg, l, n,
+                                   step, cache_bits, slots.as<uint64_t>(), counts.as<uint32_t>());
+            CPH_HIP_TRY(hipGetLastError());
+        }
+        hcount.assign((size_t)nt, 0);
+        CPH_TRY(ensure_pinned_scratch(ctx, (size_t)nt * sizeof(uint32_t)));
+        CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, counts.get(), (size_t)nt * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        memcpy(hcount.data(), ctx->pinned_scratch, (size_t)nt * sizeof(uint32_t));
+        return {};
+    };
+    auto saved_bits = [&](const GroupLayout& l, int t) -> double {   // < 0: unusable
+        if (hcount[(size_t)t] == 0 || hcount[(size_t)t] > (uint32_t)kGroupDictMax) return -1.0;
+        const int g = l.tab_base[t];
+        const int p0 = cd.col_start[l.col[g]] + l.q0[g] + l.tab_first[t];
         double bits_pos = 0;
-        const int p0 = cd.col_start[lay.col[g]] + lay.q0[g];
-        for (int i = 0; i < lay.span[g]; i++) bits_pos += std::log2((double)cd.radix[(size_t)(p0 + i)]);
-        const double saved = bits_pos - std::log2((double)hcount[(size_t)g]);
-        if (saved >= 1.0) cands.push_back({g, saved, hcount[(size_t)g]});
+        for (int i = 0; i < l.tab_span[t]; i++) bits_pos += std::log2((double)cd.radix[(size_t)(p0 + i)]);
+        return bits_pos - std::log2((double)hcount[(size_t)t]);
+    };
+    // A sample first (about a million rows): it prunes the windows that are hopeless or not worth a dictionary and
+    // picks, per base window, between the whole and its halves, so that the exact pass over all rows probes few tables.
+    const uint64_t step = n > (1ull << 21) ? n >> 20 : 1;
+    if (step > 1) {
+        CPH_TRY(run_pass(lay, step));
+        GroupLayout pruned = lay;
+        pruned.ntables = 0;
+        for (int t = 0; t < lay.ntables;) {
+            const int g = lay.tab_base[t];
+            int t_end = t;
+            while (t_end < lay.ntables && lay.tab_base[t_end] == g) t_end++;
+            const double whole = saved_bits(lay, t);
+            double halves = 0;
+            for (int k = t + 1; k < t_end; k++) halves += std::max(0.0, saved_bits(lay, k) >= 1.5 ? saved_bits(lay, k) : 0.0);
+            auto keep = [&](int k) {
+                pruned.tab_base[pruned.ntables] = lay.tab_base[k];
+                pruned.tab_first[pruned.ntables] = lay.tab_first[k];
+                pruned.tab_span[pruned.ntables] = lay.tab_span[k];
+                pruned.ntables++;
+            };
+            if (whole >= 1.5 && whole >= halves) keep(t);
+            else
+                for (int k = t + 1; k < t_end; k++)
+                    if (saved_bits(lay, k) >= 1.5) keep(k);
+            t = t_end;
+        }
+        if (pruned.ntables == 0) return {};
+        lay = pruned;
+    }
+    CPH_TRY(run_pass(lay, 1));
+    const int ng = lay.ntables;
+
+    // candidates: bits saved by coding the window through a dictionary instead of position by position
+    struct Cand { int t; int p0; int span; double saved; uint32_t count; };
+    std::vector<Cand> cands;
+    for (int t = 0; t < ng; t++) {
+        const double saved = saved_bits(lay, t);
+        if (saved < 1.0) continue;
+        const int g = lay.tab_base[t];
+        cands.push_back({t, cd.col_start[lay.col[g]] + lay.q0[g] + lay.tab_first[t], lay.tab_span[t], saved, hcount[(size_t)t]});
     }
     std::sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.saved > b.saved; });
     CodecHost trial = cd;
@@ -324,26 +422,33 @@ Status codec_try_groups(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_
     trial.dict_len.assign((size_t)cd.npos, 0);
     trial.dict.clear();
     std::vector<uint64_t> table((size_t)kGroupSlots);
+    std::vector<uint8_t> taken((size_t)cd.npos, 0);
     int chosen = 0;
     for (const Cand& cnd : cands) {
         if (trial.dict.size() + cnd.count > (size_t)kGroupDictMax) continue;
-        CPH_HIP_TRY(hipMemcpyAsync(table.data(), slots.as<uint64_t>() + (size_t)cnd.g * kGroupSlots, kGroupSlots * sizeof(uint64_t),
+        bool overlap = false;
+        for (int i = 0; i < cnd.span; i++) overlap |= taken[(size_t)(cnd.p0 + i)] != 0;
+        if (overlap) continue;   // a whole window and its halves exclude each other
+        CPH_HIP_TRY(hipMemcpyAsync(table.data(), slots.as<uint64_t>() + (size_t)cnd.t * kGroupSlots, kGroupSlots * sizeof(uint64_t),
                                    hipMemcpyDeviceToHost, ctx->stream));
         CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
         std::vector<uint64_t> syms;
         for (uint64_t v : table)
             if (v != kGroupEmpty) syms.push_back(v);
         if (syms.size() != cnd.count) return {CPH_ERR_HIP, "group dictionary: entry count mismatch"};
-        std::sort(syms.begin(), syms.end());
-        const int p0 = cd.col_start[lay.col[cnd.g]] + lay.q0[cnd.g];
+        const int span = cnd.span;   // rank order = order of the position tuples, not of the raw keys
+        std::sort(syms.begin(), syms.end(), [span](uint64_t a, uint64_t b) { return group_order_key(a, span) < group_order_key(b, span); });
+        const int p0 = cnd.p0;
         trial.unit[(size_t)p0] = kUnitHead;
         trial.dict_off[(size_t)p0] = (int32_t)trial.dict.size();
         trial.dict_len[(size_t)p0] = (int32_t)syms.size();
         trial.radix[(size_t)p0] = (uint16_t)syms.size();
         for (int s = 0; s < kLutStride; s++) trial.lut[(size_t)p0 * kLutStride + (size_t)s] = kLutInvalid;   // never consulted
-        for (int i = 1; i < lay.span[cnd.g]; i++) {
+        taken[(size_t)p0] = 1;
+        for (int i = 1; i < cnd.span; i++) {
             trial.unit[(size_t)(p0 + i)] = kUnitAbsorbed;
             trial.radix[(size_t)(p0 + i)] = 1;
+            taken[(size_t)(p0 + i)] = 1;
             for (int s = 0; s < kLutStride; s++) trial.lut[(size_t)(p0 + i) * kLutStride + (size_t)s] = 0;
         }
         trial.dict.insert(trial.dict.end(), syms.begin(), syms.end());
@@ -407,6 +512,15 @@ Status codec_upload(cph_ctx* ctx, const CodecHost& cd, DevBuf* dev) {
         off = align16(off + sizeof(int32_t) * (size_t)cd.npos);
         h.dict_off = (int32_t)off;
         off = align16(off + sizeof(uint64_t) * cd.dict.size());
+        h.hashoff_off = (int32_t)off;
+        off = align16(off + sizeof(int32_t) * (size_t)cd.npos);
+        h.hashbits_off = (int32_t)off;
+        off = align16(off + sizeof(int32_t) * (size_t)cd.npos);
+        h.hash_off = (int32_t)off;
+        size_t slots = 0;
+        for (int p = 0; p < cd.npos; p++)
+            if (cd.unit[(size_t)p] == kUnitHead) slots += (size_t)1 << (bits_needed((uint64_t)cd.dict_len[(size_t)p] * 4) + 0);
+        off = align16(off + sizeof(uint16_t) * slots);
     }
     h.total_bytes = (int32_t)off;
 
@@ -417,6 +531,24 @@ Status codec_upload(cph_ctx* ctx, const CodecHost& cd, DevBuf* dev) {
         memcpy(blob.data() + h.dictoff_off, cd.dict_off.data(), sizeof(int32_t) * (size_t)cd.npos);
         memcpy(blob.data() + h.dictlen_off, cd.dict_len.data(), sizeof(int32_t) * (size_t)cd.npos);
         memcpy(blob.data() + h.dict_off, cd.dict.data(), sizeof(uint64_t) * cd.dict.size());
+        // per head: a hash table of >= 4x its entries (load <= 0.25: ~1.15 probes per lookup)
+        int32_t* hoff = reinterpret_cast<int32_t*>(blob.data() + h.hashoff_off);
+        int32_t* hbits = reinterpret_cast<int32_t*>(blob.data() + h.hashbits_off);
+        uint16_t* hash = reinterpret_cast<uint16_t*>(blob.data() + h.hash_off);
+        size_t base = 0;
+        for (int p = 0; p < cd.npos; p++) {
+            if (cd.unit[(size_t)p] != kUnitHead) continue;
+            const int bits = bits_needed((uint64_t)cd.dict_len[(size_t)p] * 4);
+            const uint32_t mask = (1u << bits) - 1u;
+            hoff[p] = (int32_t)base;
+            hbits[p] = bits;
+            for (int32_t r = 0; r < cd.dict_len[(size_t)p]; r++) {
+                uint32_t sl = bits ? group_slot(cd.dict[(size_t)(cd.dict_off[(size_t)p] + r)], bits) : 0u;
+                while (hash[base + sl]) sl = (sl + 1) & mask;
+                hash[base + sl] = (uint16_t)(r + 1);
+            }
+            base += (size_t)1 << bits;
+        }
     }
     if (cd.npos) {
         memcpy(blob.data() + h.mult_off, cd.mult.data(), sizeof(uint64_t) * (size_t)cd.npos);
@@ -506,6 +638,90 @@ __global__ __launch_bounds__(kEncodeThreads) void k_encode_build_fast(DevCol col
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Build-side encode for single-word codes with dictionary-coded groups: the codec is flattened into
+// a short list of units (one per plain position, one per group) so that a row costs one descriptor
+// load per unit instead of the unit / weight / word bookkeeping of every byte position.
+// ---------------------------------------------------------------------------------------------
+struct PlanUnit {
+    uint32_t col, q0, span;     // key column, first byte offset, positions (1 for a plain position)
+    uint32_t head;              // 1: group head (dictionary), 0: plain position (rank LUT)
+    uint32_t off;               // plain: first LUT entry of the position; head: first dictionary entry
+    uint32_t hash_off, hash_bits;
+    uint32_t pad_;
+    uint64_t mult;
+    uint64_t pad2_;
+};
+static_assert(sizeof(PlanUnit) == 48, "PlanUnit is copied to LDS as 16-byte words");
+
+template <class OUT, bool LONGV>
+__global__ __launch_bounds__(kEncodeThreads) void k_encode_build_plan(ColsArg cols, const uint8_t* __restrict__ g_codec,
+                                                                     const PlanUnit* __restrict__ g_plan, int nunits, uint64_t n,
+                                                                     OUT* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const CodecView cv = codec_load_to_lds(g_codec, smem);
+    CPH_LDS PlanUnit* plan = (CPH_LDS PlanUnit*)(smem + cv.hdr->total_bytes);
+    {
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // builtin vector: assignable across address spaces
+        const u32x4* src = reinterpret_cast<const u32x4*>(g_plan);
+        CPH_LDS u32x4* dst = (CPH_LDS u32x4*)plan;
+        for (int i = threadIdx.x; i < nunits * (int)(sizeof(PlanUnit) / 16); i += kEncodeThreads) dst[i] = src[i];
+    }
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * kEncodeThreads * kEncodeRows;
+    for (uint64_t base = (uint64_t)blockIdx.x * kEncodeThreads * kEncodeRows; base < n; base += stride) {
+        uint64_t acc[kEncodeRows];
+        ValueHeadT<LONGV> v[kEncodeRows];
+        bool live[kEncodeRows];
+#pragma unroll
+        for (int k = 0; k < kEncodeRows; k++) {
+            acc[k] = 0;
+            live[k] = base + (uint64_t)k * kEncodeThreads + threadIdx.x < n;
+        }
+        uint32_t cur_col = 0xFFFFFFFFu;
+        for (int u = 0; u < nunits; u++) {
+            const uint32_t col = plan[u].col, q0 = plan[u].q0;
+            if (col != cur_col) {   // spans of all rows first, then their chunks: the loads overlap
+                cur_col = col;
+#pragma unroll
+                for (int k = 0; k < kEncodeRows; k++)
+                    if (live[k]) v[k].span(cols.c[col], base + (uint64_t)k * kEncodeThreads + threadIdx.x);
+#pragma unroll
+                for (int k = 0; k < kEncodeRows; k++)
+                    if (live[k]) v[k].chunks(cols.c[col]);
+            }
+            const uint64_t mult = plan[u].mult;
+            if (plan[u].head) {
+                const CPH_LDS uint64_t* d = cv.dict + plan[u].off;
+                const CPH_LDS uint16_t* ht = cv.hash + plan[u].hash_off;
+                const int bits = (int)plan[u].hash_bits;
+                const uint32_t mask = (1u << bits) - 1u;
+                const int span = (int)plan[u].span;
+#pragma unroll
+                for (int k = 0; k < kEncodeRows; k++) {
+                    if (!live[k]) continue;
+                    const uint64_t raw = v[k].raw(cols.c[col], (int)q0, span);
+                    uint32_t sl = group_slot(raw, bits);
+                    uint32_t e = ht[sl];
+                    while (e != 0 && d[e - 1] != raw) {   // every build key is in its dictionary: the probe ends on a hit
+                        sl = (sl + 1) & mask;
+                        e = ht[sl];
+                    }
+                    acc[k] += (uint64_t)(e ? e - 1 : 0) * mult;
+                }
+            } else {
+                const CPH_LDS uint16_t* lp = cv.lut + plan[u].off;
+#pragma unroll
+                for (int k = 0; k < kEncodeRows; k++)
+                    if (live[k]) acc[k] += (uint64_t)lp[v[k].sym(cols.c[col], (int)q0)] * mult;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kEncodeRows; k++)
+            if (live[k]) out[base + (uint64_t)k * kEncodeThreads + threadIdx.x] = (OUT)acc[k];
+    }
+}
+
 Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec_dev, const DevCol* cols, uint64_t n,
                           void* out_codes) {
     if (n == 0) return {};
@@ -533,6 +749,58 @@ Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec
     for (int c = 0; c < cd.ncols; c++) arg.c[c] = cols[c];
     uint64_t nblk = (n + kEncodeThreads - 1) / kEncodeThreads;
     if (nblk > 4096) nblk = 4096;
+    if (cd.has_groups() && cd.nwords == 1) {
+        nblk = (n + kEncodeThreads * kEncodeRows - 1) / (kEncodeThreads * kEncodeRows);
+        if (nblk > 4096) nblk = 4096;
+        std::vector<PlanUnit> plan;
+        // the hash tables sit in the device block in head order (codec_upload): recompute their offsets the same way
+        size_t hbase = 0;
+        for (int c = 0; c < cd.ncols; c++)
+            for (int q = 0; q < cd.col_maxlen[c]; q++) {
+                const int p = cd.col_start[c] + q;
+                if (cd.unit[(size_t)p] == kUnitAbsorbed) continue;
+                PlanUnit u{};
+                u.col = (uint32_t)c;
+                u.q0 = (uint32_t)q;
+                u.mult = cd.mult[(size_t)p];
+                if (cd.unit[(size_t)p] == kUnitHead) {
+                    u.head = 1;
+                    u.span = 1;
+                    while (q + (int)u.span < cd.col_maxlen[c] && cd.unit[(size_t)(p + (int)u.span)] == kUnitAbsorbed) u.span++;
+                    u.off = (uint32_t)cd.dict_off[(size_t)p];
+                    u.hash_bits = (uint32_t)bits_needed((uint64_t)cd.dict_len[(size_t)p] * 4);
+                    u.hash_off = (uint32_t)hbase;
+                    hbase += (size_t)1 << u.hash_bits;
+                } else {
+                    u.span = 1;
+                    u.off = (uint32_t)(p * kLutStride);
+                }
+                plan.push_back(u);
+            }
+        DevBuf dplan;
+        const size_t pbytes = plan.size() * sizeof(PlanUnit);
+        CPH_TRY(dplan.alloc(&ctx->pool, pbytes));
+        void* slot = nullptr;
+        CPH_TRY(pinned_upload(ctx, pbytes, &slot));
+        memcpy(slot, plan.data(), pbytes);
+        CPH_HIP_TRY(hipMemcpyAsync(dplan.get(), slot, pbytes, hipMemcpyHostToDevice, ctx->stream));
+        const size_t lds = codec_dev.bytes() + pbytes;
+        ProfScope ps(ctx, "k_encode_build", 0);
+        bool long_values = false;
+        for (int c = 0; c < cd.ncols; c++) long_values |= cd.col_maxlen[c] > 24;
+        auto launch = [&](auto kernel, auto* out) -> Status {
+            CPH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kernel, dim3((unsigned)nblk), dim3(kEncodeThreads), lds, ctx->stream, arg, codec_dev.as<uint8_t>(),
+                               dplan.as<PlanUnit>(), (int)plan.size(), n, out);
+            return {};
+        };
+        if (cd.key32 && long_values) CPH_TRY(launch(&k_encode_build_plan<uint32_t, true>, reinterpret_cast<uint32_t*>(out_codes)));
+        else if (cd.key32) CPH_TRY(launch(&k_encode_build_plan<uint32_t, false>, reinterpret_cast<uint32_t*>(out_codes)));
+        else if (long_values) CPH_TRY(launch(&k_encode_build_plan<uint64_t, true>, reinterpret_cast<uint64_t*>(out_codes)));
+        else CPH_TRY(launch(&k_encode_build_plan<uint64_t, false>, reinterpret_cast<uint64_t*>(out_codes)));
+        CPH_HIP_TRY(hipGetLastError());
+        return {};
+    }
     const size_t lds = codec_dev.bytes();
     ProfScope ps(ctx, "k_encode_build", 0);
     if (cd.key32) {
@@ -570,16 +838,16 @@ bool codec_encode_values_host(const CodecHost& cd, const cph_strval* values, int
             if (kind == kUnitAbsorbed) {
                 r = 0;
             } else if (kind == kUnitHead) {
-                uint64_t sym = 0;
-                for (int i = 0; i < kGroupSpan && q + i < cd.col_maxlen[c]; i++) {
-                    if (i && cd.unit[(size_t)(p + i)] != kUnitAbsorbed) break;
-                    const uint64_t s9 = (uint64_t)(q + i) < values[c].len ? (uint64_t)values[c].data[q + i] + 1 : 0;
-                    sym |= s9 << (9 * (kGroupSpan - 1 - i));
-                }
+                int span = 1;
+                while (span < kGroupSpan && q + span < cd.col_maxlen[c] && cd.unit[(size_t)(p + span)] == kUnitAbsorbed) span++;
+                uint64_t window = 0, nvalid = 0;
+                for (int i = 0; i < span && (uint64_t)(q + i) < values[c].len; i++, nvalid++)
+                    window |= (uint64_t)values[c].data[q + i] << (8 * i);
+                const uint64_t sym = group_raw(window, nvalid);
                 const uint64_t* d0 = cd.dict.data() + cd.dict_off[(size_t)p];
                 const uint64_t* d1 = d0 + cd.dict_len[(size_t)p];
-                const uint64_t* it = std::lower_bound(d0, d1, sym);
-                if (it == d1 || *it != sym) return false;
+                const uint64_t* it = std::find(d0, d1, sym);   // a few lookups per Find: a scan of <= 4096 entries
+                if (it == d1) return false;
                 r = (uint64_t)(it - d0);
             } else {
                 const int sym = (uint64_t)q < values[c].len ? (int)values[c].data[q] + 1 : 0;
