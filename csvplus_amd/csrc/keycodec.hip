@@ -519,7 +519,7 @@ Status codec_upload(cph_ctx* ctx, const CodecHost& cd, DevBuf* dev) {
         h.hash_off = (int32_t)off;
         size_t slots = 0;
         for (int p = 0; p < cd.npos; p++)
-            if (cd.unit[(size_t)p] == kUnitHead) slots += (size_t)1 << (bits_needed((uint64_t)cd.dict_len[(size_t)p] * 4) + 0);
+            if (cd.unit[(size_t)p] == kUnitHead) slots += (size_t)1 << (bits_needed((uint64_t)cd.dict_len[(size_t)p] * 2) + 0);
         off = align16(off + sizeof(uint16_t) * slots);
     }
     h.total_bytes = (int32_t)off;
@@ -531,14 +531,14 @@ Status codec_upload(cph_ctx* ctx, const CodecHost& cd, DevBuf* dev) {
         memcpy(blob.data() + h.dictoff_off, cd.dict_off.data(), sizeof(int32_t) * (size_t)cd.npos);
         memcpy(blob.data() + h.dictlen_off, cd.dict_len.data(), sizeof(int32_t) * (size_t)cd.npos);
         memcpy(blob.data() + h.dict_off, cd.dict.data(), sizeof(uint64_t) * cd.dict.size());
-        // per head: a hash table of >= 4x its entries (load <= 0.25: ~1.15 probes per lookup)
+        // per head: a hash table of >= 2x its entries (load <= 0.5: ~1.5 probes per lookup)
         int32_t* hoff = reinterpret_cast<int32_t*>(blob.data() + h.hashoff_off);
         int32_t* hbits = reinterpret_cast<int32_t*>(blob.data() + h.hashbits_off);
         uint16_t* hash = reinterpret_cast<uint16_t*>(blob.data() + h.hash_off);
         size_t base = 0;
         for (int p = 0; p < cd.npos; p++) {
             if (cd.unit[(size_t)p] != kUnitHead) continue;
-            const int bits = bits_needed((uint64_t)cd.dict_len[(size_t)p] * 4);
+            const int bits = bits_needed((uint64_t)cd.dict_len[(size_t)p] * 2);
             const uint32_t mask = (1u << bits) - 1u;
             hoff[p] = (int32_t)base;
             hbits[p] = bits;
@@ -768,7 +768,7 @@ Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec
                     u.span = 1;
                     while (q + (int)u.span < cd.col_maxlen[c] && cd.unit[(size_t)(p + (int)u.span)] == kUnitAbsorbed) u.span++;
                     u.off = (uint32_t)cd.dict_off[(size_t)p];
-                    u.hash_bits = (uint32_t)bits_needed((uint64_t)cd.dict_len[(size_t)p] * 4);
+                    u.hash_bits = (uint32_t)bits_needed((uint64_t)cd.dict_len[(size_t)p] * 2);
                     u.hash_off = (uint32_t)hbase;
                     hbase += (size_t)1 << u.hash_bits;
                 } else {
