@@ -164,6 +164,31 @@ struct ValueHeadT {
         const uint64_t nvalid = len > (uint64_t)q ? (len - (uint64_t)q < (uint64_t)span ? len - (uint64_t)q : (uint64_t)span) : 0;
         return group_raw(window(col, q), nvalid);
     }
+    // The same with the chunk index J = q >> 3 known at compile time (q < 24): no selection code at all.  Callers
+    // branch once on J per (uniform) position and then run these for all their rows.
+    template <int J>
+    __device__ __forceinline__ uint64_t ck() const {
+        if constexpr (J == 0) return c0;
+        else if constexpr (J == 1) return c1;
+        else if constexpr (J == 2) return c2;
+        else return 0;
+    }
+    template <int J>
+    __device__ __forceinline__ uint32_t sym_j(int q) const {
+        const uint32_t b = ((uint32_t)(ck<J>() >> (8 * (q & 7))) & 0xFFu) + 1u;
+        return (uint64_t)q < len ? b : 0u;
+    }
+    template <int J>
+    __device__ __forceinline__ uint64_t window_j(int q) const {
+        const int sh = (q & 7) * 8;
+        return sh == 0 ? ck<J>() : (ck<J>() >> sh) | (ck<J + 1>() << (64 - sh));
+    }
+    template <int J>
+    __device__ __forceinline__ uint64_t raw_j(int q, int span) const {
+        const uint32_t l32 = len > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)len;
+        const uint32_t left = l32 > (uint32_t)q ? l32 - (uint32_t)q : 0u;
+        return group_raw(window_j<J>(q), (uint64_t)(left < (uint32_t)span ? left : (uint32_t)span));
+    }
 };
 using ValueHead = ValueHeadT<true>;
 

@@ -691,29 +691,44 @@ __global__ __launch_bounds__(kEncodeThreads) void k_encode_build_plan(ColsArg co
                     if (live[k]) v[k].chunks(cols.c[col]);
             }
             const uint64_t mult = plan[u].mult;
-            if (plan[u].head) {
-                const CPH_LDS uint64_t* d = cv.dict + plan[u].off;
-                const CPH_LDS uint16_t* ht = cv.hash + plan[u].hash_off;
-                const int bits = (int)plan[u].hash_bits;
-                const uint32_t mask = (1u << bits) - 1u;
-                const int span = (int)plan[u].span;
+            // J = index of the 8-byte chunk the unit starts in: uniform, so one branch per unit selects code in
+            // which the chunk registers are named at compile time (LONGV: generic accessors)
+            auto unit_rows = [&](auto raw_of, auto sym_of) {
+                if (plan[u].head) {
+                    const CPH_LDS uint64_t* d = cv.dict + plan[u].off;
+                    const CPH_LDS uint16_t* ht = cv.hash + plan[u].hash_off;
+                    const int bits = (int)plan[u].hash_bits;
+                    const uint32_t mask = (1u << bits) - 1u;
+                    const int span = (int)plan[u].span;
 #pragma unroll
-                for (int k = 0; k < kEncodeRows; k++) {
-                    if (!live[k]) continue;
-                    const uint64_t raw = v[k].raw(cols.c[col], (int)q0, span);
-                    uint32_t sl = group_slot(raw, bits);
-                    uint32_t e = ht[sl];
-                    while (e != 0 && d[e - 1] != raw) {   // every build key is in its dictionary: the probe ends on a hit
-                        sl = (sl + 1) & mask;
-                        e = ht[sl];
+                    for (int k = 0; k < kEncodeRows; k++) {
+                        if (!live[k]) continue;
+                        const uint64_t raw = raw_of(v[k], (int)q0, span);
+                        uint32_t sl = group_slot(raw, bits);
+                        uint32_t e = ht[sl];
+                        while (e != 0 && d[e - 1] != raw) {   // every build key is in its dictionary: the probe ends on a hit
+                            sl = (sl + 1) & mask;
+                            e = ht[sl];
+                        }
+                        acc[k] += (uint64_t)(e ? e - 1 : 0) * mult;
                     }
-                    acc[k] += (uint64_t)(e ? e - 1 : 0) * mult;
-                }
-            } else {
-                const CPH_LDS uint16_t* lp = cv.lut + plan[u].off;
+                } else {
+                    const CPH_LDS uint16_t* lp = cv.lut + plan[u].off;
 #pragma unroll
-                for (int k = 0; k < kEncodeRows; k++)
-                    if (live[k]) acc[k] += (uint64_t)lp[v[k].sym(cols.c[col], (int)q0)] * mult;
+                    for (int k = 0; k < kEncodeRows; k++)
+                        if (live[k]) acc[k] += (uint64_t)lp[sym_of(v[k], (int)q0)] * mult;
+                }
+            };
+            using V = ValueHeadT<LONGV>;
+            const DevCol& dc = cols.c[col];
+            if constexpr (LONGV) {
+                unit_rows([&](const V& x, int q, int sp) { return x.raw(dc, q, sp); }, [&](const V& x, int q) { return x.sym(dc, q); });
+            } else {
+                switch (q0 >> 3) {
+                    case 0: unit_rows([](const V& x, int q, int sp) { return x.template raw_j<0>(q, sp); }, [](const V& x, int q) { return x.template sym_j<0>(q); }); break;
+                    case 1: unit_rows([](const V& x, int q, int sp) { return x.template raw_j<1>(q, sp); }, [](const V& x, int q) { return x.template sym_j<1>(q); }); break;
+                    default: unit_rows([](const V& x, int q, int sp) { return x.template raw_j<2>(q, sp); }, [](const V& x, int q) { return x.template sym_j<2>(q); }); break;
+                }
             }
         }
 #pragma unroll
