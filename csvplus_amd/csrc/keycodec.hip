@@ -652,22 +652,22 @@ struct PlanUnit {
     uint64_t mult;
     uint64_t pad2_;
 };
-static_assert(sizeof(PlanUnit) == 48, "PlanUnit is copied to LDS as 16-byte words");
+constexpr int kPlanMaxUnits = 40;
+// The plan travels as a kernel argument: the unit loop is uniform, so its fields are scalar loads from the
+// kernarg segment instead of LDS traffic + VGPR->SGPR moves.
+struct PlanArg {
+    int32_t nunits;
+    int32_t pad_[3];
+    PlanUnit u[kPlanMaxUnits];
+};
 
 template <class OUT, bool LONGV>
-__global__ __launch_bounds__(kEncodeThreads) void k_encode_build_plan(ColsArg cols, const uint8_t* __restrict__ g_codec,
-                                                                     const PlanUnit* __restrict__ g_plan, int nunits, uint64_t n,
-                                                                     OUT* __restrict__ out) {
+__global__ __launch_bounds__(kEncodeThreads) void k_encode_build_plan(ColsArg cols, const uint8_t* __restrict__ g_codec, const PlanArg pa,
+                                                                     uint64_t n, OUT* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const CodecView cv = codec_load_to_lds(g_codec, smem);
-    CPH_LDS PlanUnit* plan = (CPH_LDS PlanUnit*)(smem + cv.hdr->total_bytes);
-    {
-        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // builtin vector: assignable across address spaces
-        const u32x4* src = reinterpret_cast<const u32x4*>(g_plan);
-        CPH_LDS u32x4* dst = (CPH_LDS u32x4*)plan;
-        for (int i = threadIdx.x; i < nunits * (int)(sizeof(PlanUnit) / 16); i += kEncodeThreads) dst[i] = src[i];
-    }
-    __syncthreads();
+    const PlanUnit* plan = pa.u;
+    const int nunits = pa.nunits;
     const uint64_t stride = (uint64_t)gridDim.x * kEncodeThreads * kEncodeRows;
     for (uint64_t base = (uint64_t)blockIdx.x * kEncodeThreads * kEncodeRows; base < n; base += stride) {
         uint64_t acc[kEncodeRows];
@@ -764,7 +764,9 @@ Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec
     for (int c = 0; c < cd.ncols; c++) arg.c[c] = cols[c];
     uint64_t nblk = (n + kEncodeThreads - 1) / kEncodeThreads;
     if (nblk > 4096) nblk = 4096;
-    if (cd.has_groups() && cd.nwords == 1) {
+    int plan_units = 0;
+    for (int p = 0; p < cd.npos && cd.has_groups(); p++) plan_units += cd.unit[(size_t)p] != kUnitAbsorbed;
+    if (cd.has_groups() && cd.nwords == 1 && plan_units <= kPlanMaxUnits) {
         nblk = (n + kEncodeThreads * kEncodeRows - 1) / (kEncodeThreads * kEncodeRows);
         if (nblk > 4096) nblk = 4096;
         std::vector<PlanUnit> plan;
@@ -792,21 +794,16 @@ Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec
                 }
                 plan.push_back(u);
             }
-        DevBuf dplan;
-        const size_t pbytes = plan.size() * sizeof(PlanUnit);
-        CPH_TRY(dplan.alloc(&ctx->pool, pbytes));
-        void* slot = nullptr;
-        CPH_TRY(pinned_upload(ctx, pbytes, &slot));
-        memcpy(slot, plan.data(), pbytes);
-        CPH_HIP_TRY(hipMemcpyAsync(dplan.get(), slot, pbytes, hipMemcpyHostToDevice, ctx->stream));
-        const size_t lds = codec_dev.bytes() + pbytes;
+        const size_t lds = codec_dev.bytes();
+        PlanArg pa{};
+        pa.nunits = (int32_t)plan.size();
+        for (size_t i = 0; i < plan.size(); i++) pa.u[i] = plan[i];
         ProfScope ps(ctx, "k_encode_build", 0);
         bool long_values = false;
         for (int c = 0; c < cd.ncols; c++) long_values |= cd.col_maxlen[c] > 24;
         auto launch = [&](auto kernel, auto* out) -> Status {
             CPH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kernel, dim3((unsigned)nblk), dim3(kEncodeThreads), lds, ctx->stream, arg, codec_dev.as<uint8_t>(),
-                               dplan.as<PlanUnit>(), (int)plan.size(), n, out);
+            hipLaunchKernelGGL(kernel, dim3((unsigned)nblk), dim3(kEncodeThreads), lds, ctx->stream, arg, codec_dev.as<uint8_t>(), pa, n, out);
             return {};
         };
         if (cd.key32 && long_values) CPH_TRY(launch(&k_encode_build_plan<uint32_t, true>, reinterpret_cast<uint32_t*>(out_codes)));

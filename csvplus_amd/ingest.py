@@ -170,7 +170,28 @@ def read_csv(ctx: N.Context, text: bytes, *, select=None, expect_header=None, as
                 raise KeyError(("columns not found: " if len(missing) > 1 else "column not found: ")
                                + ", ".join(m.decode("utf-8", "replace") for m in missing))
     names = list(hdr.keys())
-    t = csv_parse(ctx, text, [hdr[n] for n in names], comma=comma, comment=comment,
-                  trim_leading_space=trim_leading_space, fields_per_record=num_fields, skip_records=skip, out_mem=out_mem)
+    parts = []
+    for i in range(0, len(names), N.CPH_MAX_KEY_COLS):   # the C ABI takes up to 16 columns per call
+        batch = names[i:i + N.CPH_MAX_KEY_COLS]
+        parts.append(csv_parse(ctx, text, [hdr[n] for n in batch], comma=comma, comment=comment,
+                               trim_leading_space=trim_leading_space, fields_per_record=num_fields, skip_records=skip,
+                               out_mem=out_mem))
+    t = parts[0] if len(parts) == 1 else CsvTableGroup(parts)
     t.names = names
     return t
+
+
+class CsvTableGroup:
+    """More than CPH_MAX_KEY_COLS columns: the text was parsed once per batch of columns (every batch reports the
+    same records and the same first error)."""
+
+    def __init__(self, parts):
+        self.parts = parts
+        self.nrecords, self.error_kind, self.error_record = parts[0].nrecords, parts[0].error_kind, parts[0].error_record
+        self.columns = [c for p in parts for c in p.columns]
+
+    def release(self):
+        for p in self.parts:
+            p.release()
+
+    close = release

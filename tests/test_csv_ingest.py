@@ -268,3 +268,14 @@ def test_pipeline_csv_to_csv(ctx, missing, fused):
     assert got == want
     for t in (tc, tp, to):
         t.release()
+
+
+@pytest.mark.gpu
+def test_read_csv_more_than_16_columns(ctx):
+    from csvplus_amd import ingest
+    ncol, nrow = 37, 500
+    header = ",".join(f"c{i}" for i in range(ncol))
+    body = "".join(",".join(f"v{r}_{c}" for c in range(ncol)) + "\n" for r in range(nrow))
+    t = ingest.read_csv(ctx, (header + "\n" + body).encode())
+    assert len(t.columns) == ncol and t.nrecords == nrow and t.error_kind == 0
+    assert t.names[36] == b"c36" and t.columns[36].value(499) == b"v499_36" and t.columns[16].value(0) == b"v0_16"
