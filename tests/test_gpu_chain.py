@@ -156,3 +156,31 @@ def test_chain_identity_has_no_stream_row_array(ctx):
     ch = join_chain(ctx, [(ix, [bad])], probe_base=500)
     assert ch.nrows == m - 1 and not ch.identity
     np.testing.assert_array_equal(ch.stream_row, np.arange(501, 500 + m, dtype=np.uint64))
+
+
+def test_config4_properties_3e7(ctx):
+    """BASELINE config 4 shape at 3e7 orders x 1e7 customers x 1e5 products (the oracle would need minutes): checked
+    through size-independent properties — every order joins exactly once, in stream order, and the customer /
+    product row it is paired with carries exactly the order's key bytes (verified with numpy on the host)."""
+    m, nc, npd = 30_000_000, 10_000_000, 100_000
+    cust, prod = dg.customers(nc), dg.products(npd)            # FIXED8 ids, ITOA product ids
+    ords = dg.orders(m, nc, npd)
+    ia, ib = DeviceIndex(ctx, [cust["id"]], unique=True), DeviceIndex(ctx, [prod["prod_id"]], unique=True)
+    assert ia.status == 0 and ib.status == 0
+    ch = join_chain(ctx, [(ia, [ords["cust_id"]]), (ib, [ords["prod_id"]])])
+    assert ch.nrows == m and ch.identity                       # row i of the result IS order i
+    a, b = ch.build_row(0).astype(np.int64), ch.build_row(1).astype(np.int64)
+    # customers: fixed 8-byte ids -> compare the key bytes as one u64 per row
+    cid = cust["id"].data[: nc * 8].view(np.uint64)
+    oid = ords["cust_id"].data[: m * 8].view(np.uint64)
+    assert np.array_equal(cid[a], oid)
+    # products: variable-length decimal ids -> same length and same bytes (zero-padded to 8)
+    def padded(col):
+        offs = col.offsets.astype(np.int64)
+        lens = np.diff(offs)
+        out = np.zeros((col.nrows, 8), dtype=np.uint8)
+        out[np.repeat(np.arange(col.nrows), lens), np.arange(offs[-1]) - np.repeat(offs[:-1], lens)] = col.data[: offs[-1]]
+        return out.view(np.uint64).ravel(), lens
+    pw, pl = padded(prod["prod_id"])
+    ow, ol = padded(ords["prod_id"])
+    assert np.array_equal(pw[b], ow) and np.array_equal(pl[b], ol)

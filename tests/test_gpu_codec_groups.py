@@ -87,3 +87,41 @@ def test_high_cardinality_falls_back_to_positions(ctx):
     vals = random_keys(rng, 60_000, 20, 30)     # every 7-byte group has ~60000 distinct joint symbols
     g, o, info = _check(ctx, [StrCol.from_values(vals)], [StrCol.from_values(vals[:2000])], expect_groups=False)
     assert info["dict_entries"] == 0 and info["code_words"] >= 2
+
+
+def test_config3_properties_1e7(ctx):
+    """BASELINE config 3 at 1e7 rows (the sample-then-prune statistics pass only runs above 2^21 rows): the result
+    is checked through size-independent properties computed with numpy on the host — perm is a permutation, keys are
+    non-decreasing along it, equal keys keep input order, first_dup is the first adjacent-equal pair, and find() of
+    sampled keys returns exactly their run."""
+    n = 10_000_000
+    keys = dg.varkeys(n)
+    g = DeviceIndex(ctx, [keys])
+    info = g.info()
+    assert info["dict_entries"] > 0 and info["code_words"] == 1, info
+    perm = g.perm().astype(np.int64)
+    assert np.array_equal(np.sort(perm), np.arange(n))
+    # keys as zero-padded 24-byte rows -> three big-endian words per key (config-3 keys hold no NUL byte and are
+    # at most 22 bytes long, so zero padding orders exactly like strings.Compare)
+    offs = keys.offsets.astype(np.int64)
+    lens = np.diff(offs)
+    assert lens.max() <= 24 and keys.data[: offs[-1]].min() > 0
+    padded = np.zeros((n, 24), dtype=np.uint8)
+    row_of = np.repeat(np.arange(n), lens)
+    col_of = np.arange(offs[-1]) - np.repeat(offs[:-1], lens)
+    padded[row_of, col_of] = keys.data[: offs[-1]]
+    words = padded.view(">u8").astype(np.uint64)[perm]          # (n, 3) in sorted order
+    a, b = words[:-1], words[1:]
+    lt = (a[:, 0] < b[:, 0]) | ((a[:, 0] == b[:, 0]) & ((a[:, 1] < b[:, 1]) | ((a[:, 1] == b[:, 1]) & (a[:, 2] < b[:, 2]))))
+    eq = (a == b).all(axis=1)
+    assert bool((lt | eq).all())                                  # sorted
+    assert bool((perm[1:][eq] > perm[:-1][eq]).all())             # stable inside equal-key runs
+    first = int(np.argmax(eq)) + 1 if eq.any() else None
+    assert g.first_dup == first
+    # find(): the run of a sampled key is exactly where that key sits in the sorted sequence
+    starts = np.flatnonzero(np.concatenate(([True], ~eq)))        # first position of every run
+    for s in starts[:: max(1, len(starts) // 25)][:25]:
+        r = int(perm[s])
+        lo, hi = g.find(keys.value(r))
+        nxt = starts[np.searchsorted(starts, s) + 1] if s != starts[-1] else n
+        assert (lo, hi) == (int(s), int(nxt))
