@@ -462,8 +462,9 @@ __device__ __forceinline__ int csv_split_plain(const LdsSrc& src, const CPH_LDS 
 // global latency for the whole tile: the tile's text range is thread 0's begin .. the last thread's end).
 template <class OT>
 __global__ __launch_bounds__(kCsvThreads) void k_csv_fields(const uint8_t* __restrict__ d, uint64_t size, RecIndex ri, uint64_t nrec,
-                                                           CsvOpts o, CsvCols cols, OT* __restrict__ lens /* [ncols][nrec+1] */,
-                                                           uint32_t* __restrict__ nfields, unsigned long long* __restrict__ err_key) {
+                                                           CsvOpts o, CsvCols cols, OT* __restrict__ lens /* column c at lens + c * lens_stride */,
+                                                           uint64_t lens_stride, uint32_t* __restrict__ nfields,
+                                                           unsigned long long* __restrict__ err_key) {
     __shared__ __attribute__((aligned(16))) uint8_t s_in[kCsvStage + 16];
     __shared__ __attribute__((aligned(16))) uint16_t s_cm[kCsvMaskHalves], s_qm[kCsvMaskHalves];
     __shared__ uint64_t s_range[2];
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(kCsvThreads) void k_csv_fields(const uint8_t* __res
         if (staged) stage_text(d, size, gb, ge, o.comma, stage, (CPH_LDS uint16_t*)s_cm, (CPH_LDS uint16_t*)s_qm);
         __syncthreads();
         if (r < rend) {
-            LenSink<OT> s{&cols, lens + r, nrec + 1, 0};
+            LenSink<OT> s{&cols, lens + r, lens_stride, 0};
             int err = 0, nf;
             if (staged) {
                 const LdsSrc src{stage, gb};
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(kCsvThreads) void k_csv_fields(const uint8_t* __res
             }
             nfields[r] = (uint32_t)nf;
             for (int c = 0; c < cols.ncols; c++)   // a record with fewer fields: the value is ""
-                if (cols.index[c] >= nf || err) lens[(uint64_t)c * (nrec + 1) + r] = 0;
+                if (cols.index[c] >= nf || err) lens[(uint64_t)c * lens_stride + r] = 0;
             if (err) atomicMin(err_key, ((unsigned long long)r << 3) | (unsigned long long)err);
         }
     }
@@ -727,9 +728,12 @@ CPH_API int32_t cph_csv_parse(cph_ctx* ctx, const uint8_t* data, uint64_t size, 
         const char* force64 = getenv("CPH_CSV_OFFSETS64");   // test hook for the >= 4 GiB code path
         const bool off32 = size < (1ull << 32) && !(force64 && force64[0] == '1');
         const size_t osz = off32 ? sizeof(uint32_t) : sizeof(uint64_t);
-        const uint64_t stride = nrec + 1;
-        CPH_TRY(t->d_offs.alloc(&ctx->pool, (size_t)ncols * stride * osz));
-        uint8_t* offs_all = t->d_offs.as<uint8_t>();
+        // column c's entries start `lead` elements into its stride so that the first RETURNED record (index
+        // skip_records) lands on a 16-byte boundary: the offset scans then move 16-byte vectors
+        const uint64_t lead = (4 - (opt->skip_records & 3)) & 3;
+        const uint64_t stride = (nrec + 1 + lead + 3) & ~3ull;
+        CPH_TRY(t->d_offs.alloc(&ctx->pool, (size_t)ncols * stride * osz + 64));
+        uint8_t* offs_all = t->d_offs.as<uint8_t>() + lead * osz;
         uint64_t good = nrec;   // records before the first error
         if (nrec) {
             CPH_TRY(nfields.alloc(&ctx->pool, nrec * sizeof(uint32_t)));
@@ -739,10 +743,10 @@ CPH_API int32_t cph_csv_parse(cph_ctx* ctx, const uint8_t* data, uint64_t size, 
                 ProfScope ps(ctx, "k_csv_fields", (double)size + (double)nrec * (12.0 + (double)osz * ncols));
                 if (off32)
                     hipLaunchKernelGGL(k_csv_fields<uint32_t>, dim3(grid_for_items(nrec)), dim3(kCsvThreads), 0, ctx->stream, d, size, ri, nrec, o,
-                                       cc, reinterpret_cast<uint32_t*>(offs_all), nfields.as<uint32_t>(), errk.as<unsigned long long>());
+                                       cc, reinterpret_cast<uint32_t*>(offs_all), stride, nfields.as<uint32_t>(), errk.as<unsigned long long>());
                 else
                     hipLaunchKernelGGL(k_csv_fields<uint64_t>, dim3(grid_for_items(nrec)), dim3(kCsvThreads), 0, ctx->stream, d, size, ri, nrec, o,
-                                       cc, reinterpret_cast<uint64_t*>(offs_all), nfields.as<uint32_t>(), errk.as<unsigned long long>());
+                                       cc, reinterpret_cast<uint64_t*>(offs_all), stride, nfields.as<uint32_t>(), errk.as<unsigned long long>());
             }
             if (opt->fields_per_record >= 0)
                 hipLaunchKernelGGL(k_csv_check_counts, dim3(grid_for_items(nrec)), dim3(256), 0, ctx->stream, nfields.as<uint32_t>(),
