@@ -22,7 +22,7 @@
 namespace cph {
 
 constexpr int kMatThreads = 256;
-constexpr int kMatStage   = 48 * 1024;   // LDS bytes for one tile's output
+constexpr int kMatStage   = 16 * 1024;   // LDS bytes for one tile's output (small: more workgroups per CU hide the barriers)
 
 struct RowIds {
     const void* ptr = nullptr;   // null: identity
@@ -239,28 +239,80 @@ __device__ __forceinline__ void csv_put_record(Sink& s, const ColsArg& cols, con
     if (mode.newline) s.put('\n');
 }
 
+constexpr int kCsvCopyRows = 1;   // records per thread and tile in k_csv_copy (2 with a larger stage measured the same: the kernel waits on its barriers, so small tiles / more workgroups per CU win)
+
 template <int NC>
 __global__ __launch_bounds__(kMatThreads) void k_csv_copy(ColsArg cols, ColIds ids, int ncols, CsvMode mode, uint64_t n,
                                                          const uint64_t* __restrict__ offs, const uint16_t* __restrict__ qflags,
                                                          uint8_t* __restrict__ out, uint64_t out_base) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     CPH_LDS uint8_t* stage = (CPH_LDS uint8_t*)smem;
-    for (uint64_t t0 = (uint64_t)blockIdx.x * kMatThreads; t0 < n; t0 += (uint64_t)gridDim.x * kMatThreads) {
-        const uint64_t tend = t0 + kMatThreads < n ? t0 + kMatThreads : n;
+    constexpr uint64_t kTile = (uint64_t)kMatThreads * kCsvCopyRows;
+    for (uint64_t t0 = (uint64_t)blockIdx.x * kTile; t0 < n; t0 += (uint64_t)gridDim.x * kTile) {
+        const uint64_t tend = t0 + kTile < n ? t0 + kTile : n;
         const uint64_t obase = out_base + offs[t0];
         const uint64_t span = offs[tend] - offs[t0];
-        const uint64_t i = t0 + threadIdx.x;
-        if (span + 16 <= (uint64_t)kMatStage) {
-            if (i < tend) {
-                LdsSink s{stage + (offs[i] - offs[t0]) + (obase & 15)};
-                csv_put_record<NC>(s, cols, ids, ncols, mode, i, qflags[i]);
+        const bool staged = span + 16 <= (uint64_t)kMatStage;
+        if constexpr (NC > 0) {
+            // row ids, then offsets, then first chunks of all the records of this thread: three rounds of loads
+            uint64_t row[kCsvCopyRows][NC], b[kCsvCopyRows][NC], l[kCsvCopyRows][NC], c0[kCsvCopyRows][NC];
+            bool live[kCsvCopyRows];
+#pragma unroll
+            for (int k = 0; k < kCsvCopyRows; k++) {
+                const uint64_t i = t0 + (uint64_t)k * kMatThreads + threadIdx.x;
+                live[k] = i < tend;
+#pragma unroll
+                for (int c = 0; c < NC; c++) row[k][c] = live[k] ? source_row(ids.ids[c], i) : 0;
             }
+#pragma unroll
+            for (int k = 0; k < kCsvCopyRows; k++)
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    b[k][c] = l[k][c] = 0;
+                    if (live[k]) value_span(cols.c[c], row[k][c], &b[k][c], &l[k][c]);
+                }
+#pragma unroll
+            for (int k = 0; k < kCsvCopyRows; k++)
+#pragma unroll
+                for (int c = 0; c < NC; c++) c0[k][c] = l[k][c] ? load_value_chunk(cols.c[c].data, b[k][c], l[k][c], 0) : 0;
+#pragma unroll
+            for (int k = 0; k < kCsvCopyRows; k++) {
+                if (!live[k]) continue;
+                const uint64_t i = t0 + (uint64_t)k * kMatThreads + threadIdx.x;
+                const uint32_t flags = qflags[i];
+                auto put_all = [&](auto& s) {
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        if (c) s.put(',');
+                        csv_put_field(s, cols.c[c], b[k][c], l[k][c], c0[k][c], (flags >> c) & 1u);
+                    }
+                    if (mode.newline) s.put('\n');
+                };
+                if (staged) {
+                    LdsSink s{stage + (offs[i] - offs[t0]) + (obase & 15)};
+                    put_all(s);
+                } else {
+                    GlobalSink s{out + out_base + offs[i]};
+                    put_all(s);
+                }
+            }
+        } else {
+            for (int k = 0; k < kCsvCopyRows; k++) {
+                const uint64_t i = t0 + (uint64_t)k * kMatThreads + threadIdx.x;
+                if (i >= tend) continue;
+                if (staged) {
+                    LdsSink s{stage + (offs[i] - offs[t0]) + (obase & 15)};
+                    csv_put_record<0>(s, cols, ids, ncols, mode, i, qflags[i]);
+                } else {
+                    GlobalSink s{out + out_base + offs[i]};
+                    csv_put_record<0>(s, cols, ids, ncols, mode, i, qflags[i]);
+                }
+            }
+        }
+        if (staged) {
             __syncthreads();
             flush_stage(stage, out, obase, span);
             __syncthreads();
-        } else if (i < tend) {
-            GlobalSink s{out + out_base + offs[i]};
-            csv_put_record<NC>(s, cols, ids, ncols, mode, i, qflags[i]);
         }
     }
 }
@@ -343,7 +395,7 @@ static Status csv_render(cph_ctx* ctx, const ColsArg& arg, const ColIds& ids, in
     CPH_TRY(data_out->alloc(&ctx->pool, head_bytes + total + 16));
     if (n) {
         ProfScope ps(ctx, mode.newline ? "k_csv_copy" : "k_csv_copy(fragments)", 2.0 * (double)total + 10.0 * (double)n);
-        CPH_CSV_DISPATCH(k_csv_copy, ncols, dim3(grid_rows(n)), kMatStage, ctx->stream, arg, ids, ncols, mode, n, offs_out->as<uint64_t>(),
+        CPH_CSV_DISPATCH(k_csv_copy, ncols, dim3(grid_rows((n + kCsvCopyRows - 1) / kCsvCopyRows)), kMatStage, ctx->stream, arg, ids, ncols, mode, n, offs_out->as<uint64_t>(),
                          qflags.as<uint16_t>(), data_out->as<uint8_t>(), head_bytes);
         CPH_HIP_TRY(hipGetLastError());
     }
