@@ -36,7 +36,8 @@ constexpr int kCsvThreads = 256;
 constexpr int kCsvWaves = kCsvThreads / kWave;
 constexpr int kCsvChunks = 4;                                  // 16-byte chunks per thread per tile
 constexpr int kCsvTile = kCsvThreads * 16 * kCsvChunks;       // 16 KiB per workgroup
-constexpr int kCsvStage = 16 * 1024;                          // LDS bytes for one 256-record tile (in, and out)
+constexpr int kCsvStageMax = 32 * 1024;                       // LDS bytes for one 256-record tile (in, and out): the host picks
+constexpr int kCsvStageMin = 8 * 1024;                        // the smallest power of two that holds 1.5x an average tile
 
 struct CsvOpts {
     uint8_t comma, comment;   // comment 0 = none
@@ -401,7 +402,8 @@ struct CopySink {
     __device__ __forceinline__ void end(int) {}
 };
 
-constexpr int kCsvMaskHalves = kCsvStage / 16 + 8;   // one 16-bit mask per staged 16-byte chunk (+ slack for 64-bit reads)
+// one 16-bit mask per staged 16-byte chunk (+ slack for 64-bit reads)
+__host__ __device__ constexpr int csv_mask_halves(int stage) { return stage / 16 + 8; }
 
 // Stages the text [gb, ge) (gb multiple of 16) into LDS with coalesced 16-byte loads, and with it one bit per
 // byte for "is the delimiter" / "is a quote": bit j of the 64-bit word w of a mask = byte gb + 64*w + j.
@@ -464,11 +466,13 @@ template <class OT>
 __global__ __launch_bounds__(kCsvThreads) void k_csv_fields(const uint8_t* __restrict__ d, uint64_t size, RecIndex ri, uint64_t nrec,
                                                            CsvOpts o, CsvCols cols, OT* __restrict__ lens /* column c at lens + c * lens_stride */,
                                                            uint64_t lens_stride, uint32_t* __restrict__ nfields,
-                                                           unsigned long long* __restrict__ err_key) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_in[kCsvStage + 16];
-    __shared__ __attribute__((aligned(16))) uint16_t s_cm[kCsvMaskHalves], s_qm[kCsvMaskHalves];
+                                                           unsigned long long* __restrict__ err_key, int stage_bytes) {
+    // dynamic LDS: text stage (stage_bytes + 16) | delimiter mask | quote mask
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ uint64_t s_range[2];
-    CPH_LDS uint8_t* stage = (CPH_LDS uint8_t*)s_in;
+    CPH_LDS uint8_t* stage = (CPH_LDS uint8_t*)smem;
+    CPH_LDS uint16_t* s_cm = (CPH_LDS uint16_t*)(stage + stage_bytes + 16);
+    CPH_LDS uint16_t* s_qm = s_cm + csv_mask_halves(stage_bytes);
     for (uint64_t r0 = (uint64_t)blockIdx.x * kCsvThreads; r0 < nrec; r0 += (uint64_t)gridDim.x * kCsvThreads) {
         const uint64_t rend = r0 + kCsvThreads < nrec ? r0 + kCsvThreads : nrec;
         const uint64_t r = r0 + threadIdx.x;
@@ -480,8 +484,8 @@ __global__ __launch_bounds__(kCsvThreads) void k_csv_fields(const uint8_t* __res
         }
         __syncthreads();
         const uint64_t gb = s_range[0], ge = s_range[1];
-        const bool staged = ge - gb <= (uint64_t)kCsvStage;
-        if (staged) stage_text(d, size, gb, ge, o.comma, stage, (CPH_LDS uint16_t*)s_cm, (CPH_LDS uint16_t*)s_qm);
+        const bool staged = ge - gb <= (uint64_t)stage_bytes;
+        if (staged) stage_text(d, size, gb, ge, o.comma, stage, s_cm, s_qm);
         __syncthreads();
         if (r < rend) {
             LenSink<OT> s{&cols, lens + r, lens_stride, 0};
@@ -538,17 +542,17 @@ struct LdsDest {
 template <class OT>
 __global__ __launch_bounds__(kCsvThreads) void k_csv_copy_fields(const uint8_t* __restrict__ d, uint64_t size, RecIndex ri, uint64_t first,
                                                                 uint64_t nout, CsvOpts o, CsvCols cols, const OT* __restrict__ offs,
-                                                                uint64_t stride, uint8_t* const* __restrict__ out_data) {
+                                                                uint64_t stride, uint8_t* const* __restrict__ out_data, int stage_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ uint32_t s_colstart[kMaxKeyCols];
     __shared__ uint64_t s_obase[kMaxKeyCols];
     __shared__ uint64_t s_range[2];
-    constexpr uint32_t kOutCap = kCsvStage + 32 * kMaxKeyCols;
+    const uint32_t kOutCap = (uint32_t)stage_bytes + 32 * kMaxKeyCols;
     CPH_LDS uint8_t* stage = (CPH_LDS uint8_t*)smem;
-    CPH_LDS uint8_t* ostage = stage + (kCsvStage + 16);
+    CPH_LDS uint8_t* ostage = stage + (stage_bytes + 16);
     CPH_LDS uint16_t* cmask = (CPH_LDS uint16_t*)(ostage + kOutCap);
-    CPH_LDS uint16_t* qmask = cmask + kCsvMaskHalves;
-    CPH_LDS uint32_t* off32 = (CPH_LDS uint32_t*)(qmask + kCsvMaskHalves);
+    CPH_LDS uint16_t* qmask = cmask + csv_mask_halves(stage_bytes);
+    CPH_LDS uint32_t* off32 = (CPH_LDS uint32_t*)(qmask + csv_mask_halves(stage_bytes));
     for (uint64_t r0 = (uint64_t)blockIdx.x * kCsvThreads; r0 < nout; r0 += (uint64_t)gridDim.x * kCsvThreads) {
         const uint64_t rend = r0 + kCsvThreads < nout ? r0 + kCsvThreads : nout;
         const uint32_t nt = (uint32_t)(rend - r0);
@@ -570,7 +574,7 @@ __global__ __launch_bounds__(kCsvThreads) void k_csv_copy_fields(const uint8_t* 
         __syncthreads();
         const uint64_t gb = s_range[0], ge = s_range[1];
         uint32_t pos = 0;
-        bool fits = ge - gb <= (uint64_t)kCsvStage;
+        bool fits = ge - gb <= (uint64_t)stage_bytes;
         for (int c = 0; c < cols.ncols && fits; c++) {
             const uint32_t span = off32[c * (kCsvThreads + 1) + nt] - off32[c * (kCsvThreads + 1)];
             if (threadIdx.x == 0) s_colstart[c] = pos + (uint32_t)(s_obase[c] & 15);
@@ -735,18 +739,26 @@ CPH_API int32_t cph_csv_parse(cph_ctx* ctx, const uint8_t* data, uint64_t size, 
         CPH_TRY(t->d_offs.alloc(&ctx->pool, (size_t)ncols * stride * osz + 64));
         uint8_t* offs_all = t->d_offs.as<uint8_t>() + lead * osz;
         uint64_t good = nrec;   // records before the first error
+        // LDS stage of the record-parallel kernels: the smallest power of two holding 1.5x an average 256-record tile
+        // (small stages leave room for more workgroups per CU; tiles that do not fit are parsed from global memory)
+        int stage_bytes = kCsvStageMin;
+        if (nrec)
+            while (stage_bytes < kCsvStageMax && (double)stage_bytes < 1.5 * 256.0 * (double)size / (double)nrec) stage_bytes *= 2;
         if (nrec) {
             CPH_TRY(nfields.alloc(&ctx->pool, nrec * sizeof(uint32_t)));
             CPH_TRY(errk.alloc(&ctx->pool, sizeof(unsigned long long)));
             CPH_HIP_TRY(hipMemsetAsync(errk.get(), 0xFF, sizeof(unsigned long long), ctx->stream));
             {
                 ProfScope ps(ctx, "k_csv_fields", (double)size + (double)nrec * (12.0 + (double)osz * ncols));
+                const size_t fsmem = (size_t)stage_bytes + 16 + 2 * (size_t)csv_mask_halves(stage_bytes) * sizeof(uint16_t);
                 if (off32)
-                    hipLaunchKernelGGL(k_csv_fields<uint32_t>, dim3(grid_for_items(nrec)), dim3(kCsvThreads), 0, ctx->stream, d, size, ri, nrec, o,
-                                       cc, reinterpret_cast<uint32_t*>(offs_all), stride, nfields.as<uint32_t>(), errk.as<unsigned long long>());
+                    hipLaunchKernelGGL(k_csv_fields<uint32_t>, dim3(grid_for_items(nrec)), dim3(kCsvThreads), fsmem, ctx->stream, d, size, ri, nrec,
+                                       o, cc, reinterpret_cast<uint32_t*>(offs_all), stride, nfields.as<uint32_t>(), errk.as<unsigned long long>(),
+                                       stage_bytes);
                 else
-                    hipLaunchKernelGGL(k_csv_fields<uint64_t>, dim3(grid_for_items(nrec)), dim3(kCsvThreads), 0, ctx->stream, d, size, ri, nrec, o,
-                                       cc, reinterpret_cast<uint64_t*>(offs_all), stride, nfields.as<uint32_t>(), errk.as<unsigned long long>());
+                    hipLaunchKernelGGL(k_csv_fields<uint64_t>, dim3(grid_for_items(nrec)), dim3(kCsvThreads), fsmem, ctx->stream, d, size, ri, nrec,
+                                       o, cc, reinterpret_cast<uint64_t*>(offs_all), stride, nfields.as<uint32_t>(), errk.as<unsigned long long>(),
+                                       stage_bytes);
             }
             if (opt->fields_per_record >= 0)
                 hipLaunchKernelGGL(k_csv_check_counts, dim3(grid_for_items(nrec)), dim3(256), 0, ctx->stream, nfields.as<uint32_t>(),
@@ -792,14 +804,16 @@ CPH_API int32_t cph_csv_parse(cph_ctx* ctx, const uint8_t* data, uint64_t size, 
             double out_bytes = 0;
             for (int c = 0; c < ncols; c++) out_bytes += (double)totals[(size_t)c];
             ProfScope ps(ctx, "k_csv_copy_fields", (double)size + out_bytes + (double)nout * (8.0 + (double)osz * ncols));
-            const size_t smem = (size_t)(kCsvStage + 16) + (size_t)(kCsvStage + 32 * kMaxKeyCols) + 2 * kCsvMaskHalves * sizeof(uint16_t) +
-                                (size_t)ncols * (kCsvThreads + 1) * sizeof(uint32_t);
+            const size_t smem = (size_t)(stage_bytes + 16) + (size_t)(stage_bytes + 32 * kMaxKeyCols) +
+                                2 * (size_t)csv_mask_halves(stage_bytes) * sizeof(uint16_t) + (size_t)ncols * (kCsvThreads + 1) * sizeof(uint32_t);
+            CPH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_csv_copy_fields<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            CPH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_csv_copy_fields<uint64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             if (off32)
                 hipLaunchKernelGGL(k_csv_copy_fields<uint32_t>, dim3(grid_for_items(nout)), dim3(kCsvThreads), smem, ctx->stream, d, size, ri, first,
-                                   nout, o, cc, reinterpret_cast<const uint32_t*>(offs_all) + first, stride, ptrs.as<uint8_t*>());
+                                   nout, o, cc, reinterpret_cast<const uint32_t*>(offs_all) + first, stride, ptrs.as<uint8_t*>(), stage_bytes);
             else
                 hipLaunchKernelGGL(k_csv_copy_fields<uint64_t>, dim3(grid_for_items(nout)), dim3(kCsvThreads), smem, ctx->stream, d, size, ri, first,
-                                   nout, o, cc, reinterpret_cast<const uint64_t*>(offs_all) + first, stride, ptrs.as<uint8_t*>());
+                                   nout, o, cc, reinterpret_cast<const uint64_t*>(offs_all) + first, stride, ptrs.as<uint8_t*>(), stage_bytes);
             CPH_HIP_TRY(hipGetLastError());
         }
         // publish
