@@ -38,8 +38,8 @@ namespace cph {
 
 constexpr int kChainThreads = 256;
 constexpr int kChainWaves   = kChainThreads / kWave;
-constexpr int kChainRows    = 4;                                   // rows in flight per thread
-constexpr int kChainTile    = kChainThreads * kChainRows;          // 1024 stream rows per tile
+constexpr int kChainRows    = 3;                                   // rows in flight per thread (2: 3.57 ms, 3: 2.65, 4: 2.79, 6: 2.87, 8: 3.11 at 1e8 rows)
+constexpr int kChainTile    = kChainThreads * kChainRows;          // stream rows per tile
 constexpr int kChainMasks   = kChainRows * kChainWaves;            // ballot words per tile
 constexpr int kMaxChain     = CPH_MAX_CHAIN;
 
@@ -303,8 +303,8 @@ bool chain_fast_path_ok(const ChainStep* steps, int nsteps) {
 
 // Enqueues the dense pass + the match total on ctx->stream; nothing here waits for the GPU.
 //   d_rows[s]  u32[nprobe]             build row of step s at slot == stream row (valid where the bit is set)
-//   d_masks    u64[ceil(nprobe/1024)*16]  bit r%64 of word r/64 == "stream row r joined" (a plain bitmap)
-//   d_counts   u32[ceil(nprobe/1024)*4]   matches per 256-row quarter... per (tile, wave), tile-major
+//   d_masks    u64[chain_dense_mask_words(nprobe)]  bit r%64 of word r/64 == "stream row r joined" (a plain bitmap)
+//   d_counts   u32[chain_dense_count_words(nprobe)] matches per (tile, wave), tile-major
 //   d_total    u64                     number of joined rows
 template <int S>
 static Status enqueue_dense(cph_ctx* ctx, const ChainStep* steps, uint64_t nprobe, uint64_t probe_base,

@@ -1,0 +1,28 @@
+#!/bin/bash
+# kChainRows sweep: rebuilds chain.o on the box for each value (the checkout there is a scratch copy)
+export TMPDIR=/tmp
+cp csvplus_amd/csrc/chain.hip /tmp/chain.orig
+for R in 4 2 3 6 8; do
+  sed "s/constexpr int kChainRows    = 4; /constexpr int kChainRows    = $R; /" /tmp/chain.orig > csvplus_amd/csrc/chain.hip
+  make hip > /tmp/make_$R.log 2>&1 || { echo "build failed for rows=$R"; tail -5 /tmp/make_$R.log; continue; }
+  timeout 300 python - <<PY
+import sys
+sys.path.insert(0, '.')
+from csvplus_amd import datagen as dg
+from csvplus_amd.engine import Engine
+eng = Engine(0); dev = eng.device
+M, NC, NP = 100_000_000, 10_000_000, 100_000
+cust = dg.column(dg.SEQ_PERM, NC, NC, encoding=dg.FIXED8, seed=dg.SEED + 1).to_device(dev)
+prod = dg.column(dg.SEQ_PERM, NP, NP, encoding=dg.ITOA, seed=dg.SEED + 2).to_device(dev)
+o = dg.orders(M, NC, NP)
+oc, op = o["cust_id"].to_device(dev), o["prod_id"].to_device(dev)
+ia = eng.index_on([cust], unique=True); ib = eng.index_on([prod], unique=True)
+steps = [(ia, oc), (ib, op)]
+r = eng.chained_join(steps); assert r.n == M; r.release()
+eng.ctx.profile(True); eng.ctx.profile_read(reset=True)
+for _ in range(5): eng.chained_join(steps).release()
+p = eng.ctx.profile_read(reset=True)
+print("rows=$R k_chain_dense %.3f ms" % (p['k_chain_dense']['total_ms'] / 5), flush=True)
+PY
+done
+cp /tmp/chain.orig csvplus_amd/csrc/chain.hip
