@@ -1,10 +1,12 @@
 #!/bin/bash
-# kChainRows sweep: rebuilds chain.o on the box for each value (the checkout there is a scratch copy)
+# chain-kernel tuning sweep (threads per workgroup x rows in flight per thread): rebuilds chain.o on the box
+# for each setting (the checkout there is a scratch copy).  usage: tools/gpu_chain_rows.sh "256,3 128,3 512,3"
 export TMPDIR=/tmp
 cp csvplus_amd/csrc/chain.hip /tmp/chain.orig
-for R in 4 2 3 6 8; do
-  sed "s/constexpr int kChainRows    = 4; /constexpr int kChainRows    = $R; /" /tmp/chain.orig > csvplus_amd/csrc/chain.hip
-  make hip > /tmp/make_$R.log 2>&1 || { echo "build failed for rows=$R"; tail -5 /tmp/make_$R.log; continue; }
+for cfg in ${1:-"256,3 256,4 256,2 256,6"}; do
+  T=${cfg%,*}; R=${cfg#*,}
+  sed -E "s/constexpr int kChainRows    = [0-9]+; /constexpr int kChainRows    = $R; /; s/constexpr int kChainThreads = [0-9]+;/constexpr int kChainThreads = $T;/" /tmp/chain.orig > csvplus_amd/csrc/chain.hip
+  make hip > /tmp/make_$T_$R.log 2>&1 || { echo "build failed for $cfg"; tail -5 /tmp/make_$T_$R.log; continue; }
   timeout 300 python - <<PY
 import sys
 sys.path.insert(0, '.')
@@ -22,7 +24,7 @@ r = eng.chained_join(steps); assert r.n == M; r.release()
 eng.ctx.profile(True); eng.ctx.profile_read(reset=True)
 for _ in range(5): eng.chained_join(steps).release()
 p = eng.ctx.profile_read(reset=True)
-print("rows=$R k_chain_dense %.3f ms" % (p['k_chain_dense']['total_ms'] / 5), flush=True)
+print("threads,rows=$cfg k_chain_dense %.3f ms" % (p['k_chain_dense']['total_ms'] / 5), flush=True)
 PY
 done
 cp /tmp/chain.orig csvplus_amd/csrc/chain.hip
