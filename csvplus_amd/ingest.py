@@ -110,17 +110,51 @@ def _b(x):
     return x.encode() if isinstance(x, str) else bytes(x)
 
 
+def resolve_header(first, *, select=None, expect_header=None):
+    """makeHeader (csvplus.go:1149-1206) on the first record `first` (list of bytes): name -> field index.
+    No spec: every name, a repeated name keeps its LAST position (:1159-1167).  select = SelectColumns names
+    (:1009-1026, each looked up); expect_header = {name: index, -1 = look the name up} (:985-1003): a name found at
+    another position is an error (:1176-1181), names that never occur are reported together (:1186-1202)."""
+    if not first:
+        raise ValueError("empty header")                       # :1156-1158
+    spec = None
+    if select is not None:
+        names = [_b(n) for n in select]
+        if not names:
+            raise ValueError("empty header spec")              # panic :1010-1012
+        if len(set(names)) != len(names):
+            raise ValueError("header spec: duplicate column name")   # panic :1017-1019
+        spec = {n: -1 for n in names}
+    elif expect_header is not None:
+        if not expect_header:
+            raise ValueError("empty header spec")              # panic :986-988
+        spec = {_b(k): int(v) for k, v in expect_header.items()}
+    hdr = {}
+    if spec is None:
+        for i, nm in enumerate(first):
+            hdr[nm] = i
+        return hdr
+    for i, nm in enumerate(first):
+        if nm in spec:
+            if spec[nm] == -1 or spec[nm] == i:
+                hdr[nm] = i
+            else:
+                raise KeyError(f"misplaced column {nm!r}: expected at pos. {spec[nm]}, but found at pos. {i}")
+    missing = [n for n in spec if n not in hdr]
+    if missing:
+        raise KeyError(("columns not found: " if len(missing) > 1 else "column not found: ")
+                       + ", ".join(m.decode("utf-8", "replace") for m in missing))
+    return hdr
+
+
 def read_csv(ctx: N.Context, text: bytes, *, select=None, expect_header=None, assume_header=None, comma=b",",
              comment=None, trim_leading_space=False, num_fields=0, out_mem=N.CPH_MEM_HOST) -> CsvTable:
     """A csvplus Reader materialised as columns: FromFile(...)[.SelectColumns(select...) |
     .ExpectHeader(expect_header) | .AssumeHeader(assume_header)][.NumFields(num_fields)].
 
-    Header modes as in the reference: default = every column the first record names (makeHeader,
-    csvplus.go:1159-1167, a repeated name keeps its LAST position); select = names looked up in the header
-    (SelectColumns :1009-1026); expect_header = {name: index, -1 = look the name up} (ExpectHeader :985-1003,
-    checked as makeHeader :1172-1203 does); assume_header = {name: index}, no header line (AssumeHeader
-    :963-980).  num_fields is csv.Reader.FieldsPerRecord (0 = as the first record, the header included;
-    <0 = any, short records padded with "" :1121-1122).
+    Header modes as in the reference (resolve_header; assume_header = {name: index}, no header line: AssumeHeader
+    :963-980).  num_fields is csv.Reader.FieldsPerRecord (0 = as the first record, the header included; <0 = any,
+    short records padded with "" :1121-1122).
     Returns the table with `.names`; `.error_kind/.error_record` report a parse error the way the reference
     returns it after delivering the rows before it.  Header problems raise (the reference fails at line 1).
     """
@@ -142,33 +176,7 @@ def read_csv(ctx: N.Context, text: bytes, *, select=None, expect_header=None, as
         if first is None:
             raise EOFError("EOF")   # io.EOF from the header read, csvplus.go:1150-1154
         skip = 1
-        spec = None
-        if select is not None:
-            names = [_b(n) for n in select]
-            if not names:
-                raise ValueError("empty header spec")
-            if len(set(names)) != len(names):
-                raise ValueError("header spec: duplicate column name")
-            spec = {n: -1 for n in names}
-        elif expect_header is not None:
-            if not expect_header:
-                raise ValueError("empty header spec")
-            spec = {_b(k): int(v) for k, v in expect_header.items()}
-        hdr = {}
-        if spec is None:
-            for i, nm in enumerate(first):
-                hdr[nm] = i
-        else:
-            for i, nm in enumerate(first):
-                if nm in spec:
-                    if spec[nm] == -1 or spec[nm] == i:
-                        hdr[nm] = i
-                    else:
-                        raise KeyError(f"misplaced column {nm!r}: expected at pos. {spec[nm]}, but found at pos. {i}")
-            missing = [n for n in spec if n not in hdr]
-            if missing:
-                raise KeyError(("columns not found: " if len(missing) > 1 else "column not found: ")
-                               + ", ".join(m.decode("utf-8", "replace") for m in missing))
+        hdr = resolve_header(first, select=select, expect_header=expect_header)
     names = list(hdr.keys())
     parts = []
     for i in range(0, len(names), N.CPH_MAX_KEY_COLS):   # the C ABI takes up to 16 columns per call

@@ -279,3 +279,28 @@ def test_read_csv_more_than_16_columns(ctx):
     t = ingest.read_csv(ctx, (header + "\n" + body).encode())
     assert len(t.columns) == ncol and t.nrecords == nrow and t.error_kind == 0
     assert t.names[36] == b"c36" and t.columns[36].value(499) == b"v499_36" and t.columns[16].value(0) == b"v0_16"
+
+
+# ---- header logic on the host (no GPU): makeHeader, csvplus.go:1149-1206 -----------------------------------------
+def test_resolve_header_like_makeHeader():
+    from csvplus_amd.ingest import first_record, resolve_header
+    first = [b"id", b"name", b"surname", b"name"]
+    assert resolve_header(first) == {b"id": 0, b"name": 3, b"surname": 2}            # a repeated name keeps its last position
+    assert resolve_header(first, select=["surname", "id"]) == {b"id": 0, b"surname": 2}
+    assert resolve_header(first, expect_header={"id": 0, "surname": -1}) == {b"id": 0, b"surname": 2}
+    with pytest.raises(KeyError, match="misplaced column"):
+        resolve_header(first, expect_header={"surname": 1})
+    with pytest.raises(KeyError, match="column not found: zip"):
+        resolve_header(first, select=["id", "zip"])
+    with pytest.raises(KeyError, match="columns not found: "):
+        resolve_header(first, select=["zip", "born"])
+    with pytest.raises(ValueError):
+        resolve_header(first, select=[])
+    with pytest.raises(ValueError):
+        resolve_header(first, select=["id", "id"])
+    with pytest.raises(ValueError):
+        resolve_header([])
+    # the header record itself: comments and blank lines before it are skipped, quoted names may span lines
+    assert first_record(b"# c\n\n\"a\nb\",c\r\nx,y\n", comment=b"#") == [b"a\nb", b"c"]
+    assert first_record(b"\n\n") is None
+    assert first_record(b" a, b\n", trim_leading_space=True) == [b"a", b"b"]
