@@ -159,6 +159,7 @@ PROTOTYPES = [
     ("cph_ctx_destroy", None, [_P]),
     ("cph_last_error", C.c_char_p, [_P]),
     ("cph_ctx_set_stream", C.c_int32, [_P, _P]),
+    ("cph_ctx_set_debug", C.c_int32, [_P, C.c_int32]),
     ("cph_ctx_synchronize", C.c_int32, [_P]),
     ("cph_ctx_profile", C.c_int32, [_P, C.c_int32]),
     ("cph_ctx_profile_read", C.c_int32,
@@ -278,6 +279,10 @@ class Context:
 
     def set_stream(self, stream_handle: int | None):
         self._check(self.lib.cph_ctx_set_stream(self.handle, _P(stream_handle or 0)))
+
+    def set_debug(self, chain_flags: int):
+        """Attribution switches of the chained-join kernel (measurement only: results are wrong when set)."""
+        self._check(self.lib.cph_ctx_set_debug(self.handle, int(chain_flags)))
 
     def synchronize(self):
         self._check(self.lib.cph_ctx_synchronize(self.handle))

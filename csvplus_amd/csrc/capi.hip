@@ -71,6 +71,33 @@ DevicePool::~DevicePool() {
     live_.clear();
 }
 
+Status device_cus(cph_ctx* ctx, int* cus) {
+    if (ctx->cus <= 0) {
+        int v = 0;
+        CPH_HIP_TRY(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device));
+        ctx->cus = v > 0 ? v : 1;
+    }
+    *cus = ctx->cus;
+    return {};
+}
+
+Status kernel_setup(cph_ctx* ctx, const void* fn, int threads, size_t lds, int* blocks_per_cu) {
+    for (const auto& k : ctx->kernel_cfg)
+        if (k.fn == fn && k.lds == lds) {
+            if (blocks_per_cu) *blocks_per_cu = k.blocks_per_cu;
+            return {};
+        }
+    if (lds > 0) CPH_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0;
+    CPH_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds));
+    if (per_cu < 1) per_cu = 1;
+    // the attribute is a high-water mark per function: remember the largest request so that a smaller one
+    // later does not lower it under a concurrent user of the same ctx's other indexes
+    ctx->kernel_cfg.push_back({fn, lds, per_cu});
+    if (blocks_per_cu) *blocks_per_cu = per_cu;
+    return {};
+}
+
 Status ensure_pinned_scratch(cph_ctx* ctx, size_t bytes) {
     if (ctx->pinned_scratch_bytes >= bytes) return {};
     if (ctx->pinned_scratch) {
@@ -357,6 +384,12 @@ CPH_API void cph_ctx_destroy(cph_ctx* ctx) {
     ctx->pool.trim();
     if (own) (void)hipStreamDestroy(own);
     delete ctx;
+}
+
+CPH_API int32_t cph_ctx_set_debug(cph_ctx* ctx, int32_t chain_flags) {
+    if (!ctx) return CPH_ERR_INVALID;
+    ctx->chain_debug = chain_flags;
+    return CPH_OK;
 }
 
 CPH_API const char* cph_last_error(const cph_ctx* ctx) { return ctx ? ctx->err.c_str() : "ctx is NULL"; }

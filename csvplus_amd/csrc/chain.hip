@@ -30,7 +30,7 @@
 //
 // General path (duplicate keys / multi-column keys / multi-word codes): probe, select, compose
 // step by step with the generic kernels of probe.hip.
-#include <cstdlib>
+#include <type_traits>
 
 #include "probe_device.hpp"
 
@@ -38,15 +38,16 @@ namespace cph {
 
 constexpr int kChainThreads = 256;
 constexpr int kChainWaves   = kChainThreads / kWave;
-constexpr int kChainRows    = 3;                                   // rows in flight per thread (2: 3.57 ms, 3: 2.65, 4: 2.79, 6: 2.87, 8: 3.11 at 1e8 rows)
-constexpr int kChainTile    = kChainThreads * kChainRows;          // stream rows per tile
-constexpr int kChainMasks   = kChainRows * kChainWaves;            // ballot words per tile
+constexpr int kChainRows    = 8;                                   // rows in flight per lane
+constexpr int kWaveTile     = kWave * kChainRows;                  // consecutive stream rows owned by one wave
+constexpr int kChainTile    = kChainThreads * kChainRows;          // stream rows per workgroup tile
+constexpr int kChainMasks   = kChainRows * kChainWaves;            // ballot words per tile (a plain bitmap: word r/64)
 constexpr int kMaxChain     = CPH_MAX_CHAIN;
 
 struct ChainStepArg {
     DevCol col;                 // the stream's key column for this step
     const uint8_t* codec;       // codec block of the step's index (global memory)
-    const TableEntry* table;    // unique-format direct table, or nullptr -> binary search
+    const uint32_t* rowtab;     // code -> build row (0xFFFFFFFF: absent), or nullptr -> binary search
     const void* codes;          // sorted codes (u32 if key32 else u64)
     const uint32_t* perm;
     uint64_t n_index;
@@ -58,19 +59,102 @@ struct ChainArgs {
     uint32_t* out_rows[kMaxChain];
 };
 
+// Bytes [8j, 8j+8) of a value, little-endian, with ONE load and WITHOUT any branch.  Bytes past the end of the
+// value are unspecified.  Only the aligned 8-byte words that hold at least one byte of the value are touched
+// (the rule of load_value_chunk, device_utils.hpp: no load can run into an unmapped page): a chunk that sits
+// inside one aligned word is read as that word and shifted; a chunk that straddles two words is read with one
+// UNALIGNED 8-byte load at its first byte (gfx9 global loads take any byte address), which stays inside those
+// two words; a chunk that lies entirely past the value reads the word at `base8` (the caller guarantees it is
+// readable).  Straight-line code matters here: with a branch per row every key fetch ends in its own s_waitcnt
+// and the kChainRows loads of a lane no longer overlap.
+//   base8 = a wave-uniform, 8-byte aligned pointer;  x + delta = byte offset of the VALUE from base8 (x is what a
+//   lane keeps per row: one 32-bit register when B = u32; the 64-bit address only lives until the load is issued).
+template <class B>
+__device__ __forceinline__ uint64_t load_chunk_nobranch(const uint8_t* base8, uint32_t delta, B x, uint32_t len, uint32_t j) {
+    typedef const __attribute__((address_space(1))) uint8_t* global_u8_ptr;
+    typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+    typedef const __attribute__((address_space(1))) u64_unaligned* global_u64u_ptr;
+    const uint32_t off = 8u * j;
+    const bool has = len > off;
+    const uint32_t left = len - off;
+    const uint32_t nb = has ? (left < 8u ? left : 8u) : 1u;
+    const uint64_t a = has ? (uint64_t)x + (delta + off) : 0ull;
+    const uint32_t a7 = (uint32_t)a & 7u;
+    const bool straddles = a7 + nb > 8u;
+    const uint64_t w = *(global_u64u_ptr)((global_u8_ptr)base8 + (straddles ? a : a & ~7ull));
+    return w >> (straddles ? 0u : a7 * 8u);
+}
+
+// One LDS load + add per byte position for kChainRows rows at once (pre-multiplied LUT, codec_device.hpp); the
+// byte positions are walked with compile-time shifts.  Positions 16.. (rare) fetch their chunk on demand.
+template <class W, class B, class CW, bool LONG>
+__device__ __forceinline__ void encode_rows(const CodecView& cv, const uint8_t* base8, uint32_t delta, const B (&x)[kChainRows],
+                                            const uint32_t (&len)[kChainRows], const uint64_t (&c0)[kChainRows],
+                                            const uint64_t (&c1)[kChainRows], CW (&code)[kChainRows], uint32_t* okmask) {
+    const int maxlen = cv.hdr->col_maxlen[0];
+    const CPH_LDS W* lutw = (const CPH_LDS W*)cv.lutw;
+    W acc[kChainRows], bad[kChainRows];
+#pragma unroll
+    for (int k = 0; k < kChainRows; k++) { acc[k] = 0; bad[k] = 0; }
+    const int nchunks = (maxlen + 7) >> 3;
+#pragma unroll 1
+    for (int j = 0; j < nchunks; j++) {
+        uint64_t cur[kChainRows];
+        if (j == 0) {
+#pragma unroll
+            for (int k = 0; k < kChainRows; k++) cur[k] = c0[k];
+        } else if (LONG && j == 1) {
+#pragma unroll
+            for (int k = 0; k < kChainRows; k++) cur[k] = c1[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < kChainRows; k++) cur[k] = load_chunk_nobranch<B>(base8, delta, x[k], len[k], (uint32_t)j);
+        }
+        const int qn = maxlen - 8 * j < 8 ? maxlen - 8 * j : 8;
+        const CPH_LDS W* lp = lutw + (8 * j) * kLutStride;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            if (b < qn) {   // uniform
+#pragma unroll
+                for (int k = 0; k < kChainRows; k++) {
+                    const uint32_t half = b < 4 ? (uint32_t)cur[k] : (uint32_t)(cur[k] >> 32);
+                    const uint32_t byte = (half >> (8 * (b & 3))) & 0xFFu;
+                    const uint32_t sym = (uint32_t)(8 * j + b) < len[k] ? byte + 1u : 0u;
+                    const W v = lp[b * kLutStride + sym];
+                    bad[k] |= v;
+                    acc[k] += v;
+                }
+            }
+        }
+    }
+    uint32_t m = *okmask;
+#pragma unroll
+    for (int k = 0; k < kChainRows; k++) {
+        code[k] = (CW)acc[k];
+        const bool good = len[k] <= (uint32_t)maxlen && !(bad[k] >> (sizeof(W) * 8 - 1));
+        if (!good) m &= ~(1u << k);
+    }
+    *okmask = m;
+}
+
 // DBG: attribution switches for tools/microbench (results are wrong when set):
 //      dbg & 1 = no table lookup, & 2 = no encode, & 4 = no output stores.  LONG: some step's
-//      index has keys longer than 8 bytes (then bytes 8..15 are prefetched too).
-// Uniform decisions (fixed-width column? 32-bit LUT? direct table?) are hoisted out of the row
-// loops so that the kChainRows loads of a phase sit in one basic block and overlap.
-template <int S, bool LONG, bool DBG>
+//      index has keys longer than 8 bytes (then bytes 8..15 are prefetched too).  WIDE: 64-bit value
+//      offsets or 64-bit codes somewhere in the chain (otherwise both stay in one 32-bit register).
+// A wave owns kWaveTile consecutive stream rows: row(k, lane) = wave base + 64 k + lane, so every memory
+// instruction of a phase covers 64 neighbouring rows.  Each phase — value spans, key bytes, LUT walk, table
+// lookups — is straight-line code over all kChainRows rows and all S steps: rows past the end are clamped to the
+// last row and unmatched codes to entry 0 (results masked afterwards) instead of being branched around, so the
+// kChainRows * S loads of a phase are in flight together.  No workgroup-level synchronisation in the tile loop.
+template <int S, bool LONG, bool WIDE, bool DBG>
 __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint64_t nprobe, uint64_t probe_base,
                                                               uint64_t ntiles, uint64_t* __restrict__ masks,
                                                               uint32_t* __restrict__ wave_counts, int dbg_flags) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // dynamic LDS layout: [codec 0][codec 1]...   (no static LDS: keeps 16-B alignment)
+    using B = std::conditional_t<WIDE, uint64_t, uint32_t>;    // byte offset of a value from its (uniform) base
+    using CW = std::conditional_t<WIDE, uint64_t, uint32_t>;   // key code
     const int dbg = DBG ? dbg_flags : 0;
-    const bool nt = DBG && (dbg & 8);   // experiment: non-temporal stream loads / result stores
     CodecView cv[S];
     {
         uint8_t* p = smem;
@@ -80,148 +164,160 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
             p += a.step[s].codec_bytes;
         }
     }
-    const int lane = lane_id(), wave = wave_id();
+    const int lane = lane_id();
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(wave_id());
 
 #pragma unroll 1
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint64_t tile0 = tile * kChainTile;
-        bool ok[kChainRows];
-        uint64_t row[kChainRows];
+        const uint64_t wbase = tile * kChainTile + (uint64_t)wave * kWaveTile;   // wave-uniform
+        // rows of this lane relative to wbase, clamped to the last stream row (whole wave-tiles past the end
+        // re-read row nprobe-1 and are masked)
+        const uint64_t left = nprobe > wbase ? nprobe - wbase : 0;
+        const uint32_t nvalid = left > (uint64_t)kWaveTile ? (uint32_t)kWaveTile : (uint32_t)left;   // uniform
+        const uint64_t rbase = nvalid ? wbase : nprobe - 1;   // first row this wave reads
+        const uint32_t rmax = nvalid ? nvalid - 1 : 0;
+        uint32_t okm = 0;                       // bit k: row k of this lane is (still) joined
+        uint32_t rel[kChainRows];
 #pragma unroll
         for (int k = 0; k < kChainRows; k++) {
-            row[k] = tile0 + (uint64_t)k * kChainThreads + threadIdx.x;
-            ok[k] = row[k] < nprobe;
+            const uint32_t r = (uint32_t)(k * kWave + lane);
+            okm |= (r < nvalid ? 1u : 0u) << k;
+            rel[k] = r < rmax ? r : rmax;
         }
         // ---- A: value spans ----------------------------------------------------------------------
-        uint64_t begin[kChainRows][S];
-        uint32_t len[kChainRows][S];
+        const uint8_t* base8[S];                // uniform, 8-byte aligned
+        uint32_t delta[S];                      // uniform, 0..7
+        B x[S][kChainRows];                     // value start as a byte offset from base8[s] + delta[s]
+        uint32_t len[S][kChainRows];
 #pragma unroll
         for (int s = 0; s < S; s++) {
             const DevCol& c = a.step[s].col;
             if (c.fixed_width) {
+                const uint64_t p = (uint64_t)(uintptr_t)c.data + rbase * (uint64_t)c.fixed_width;
+                base8[s] = (const uint8_t*)(uintptr_t)(p & ~7ull);
+                delta[s] = (uint32_t)(p & 7ull);
 #pragma unroll
                 for (int k = 0; k < kChainRows; k++) {
-                    begin[k][s] = row[k] * (uint64_t)c.fixed_width;
-                    len[k][s] = ok[k] ? c.fixed_width : 0u;
+                    x[s][k] = (B)rel[k] * c.fixed_width;   // < kWaveTile * 2^32 / ... : fixed widths are validated < 2^16
+                    len[s][k] = c.fixed_width;
                 }
             } else if (c.offset_bits == 32) {
-                const uint32_t* off = reinterpret_cast<const uint32_t*>(c.offsets);
+                const uint64_t p = (uint64_t)(uintptr_t)c.data;
+                base8[s] = (const uint8_t*)(uintptr_t)(p & ~7ull);
+                delta[s] = (uint32_t)(p & 7ull);
+                const uint32_t* off = reinterpret_cast<const uint32_t*>(c.offsets) + rbase;
                 uint32_t b[kChainRows], e[kChainRows];
 #pragma unroll
                 for (int k = 0; k < kChainRows; k++) {
-                    if (DBG && nt) {
-                        b[k] = ok[k] ? __builtin_nontemporal_load(&off[row[k]]) : 0u;
-                        e[k] = ok[k] ? __builtin_nontemporal_load(&off[row[k] + 1]) : 0u;
-                    } else {
-                        b[k] = ok[k] ? off[row[k]] : 0u;
-                        e[k] = ok[k] ? off[row[k] + 1] : 0u;
-                    }
+                    b[k] = off[rel[k]];
+                    e[k] = off[rel[k] + 1];
                 }
 #pragma unroll
                 for (int k = 0; k < kChainRows; k++) {
-                    begin[k][s] = b[k];
-                    len[k][s] = e[k] - b[k];
+                    x[s][k] = b[k];
+                    len[s][k] = e[k] - b[k];
                 }
             } else {
-                const uint64_t* off = reinterpret_cast<const uint64_t*>(c.offsets);
-                uint64_t b[kChainRows], e[kChainRows];
+                if constexpr (WIDE) {
+                    const uint64_t p = (uint64_t)(uintptr_t)c.data;
+                    base8[s] = (const uint8_t*)(uintptr_t)(p & ~7ull);
+                    delta[s] = (uint32_t)(p & 7ull);
+                    const uint64_t* off = reinterpret_cast<const uint64_t*>(c.offsets) + rbase;
+                    uint64_t b[kChainRows], e[kChainRows];
 #pragma unroll
-                for (int k = 0; k < kChainRows; k++) {
-                    b[k] = ok[k] ? off[row[k]] : 0ull;
-                    e[k] = ok[k] ? off[row[k] + 1] : 0ull;
-                }
+                    for (int k = 0; k < kChainRows; k++) {
+                        b[k] = off[rel[k]];
+                        e[k] = off[rel[k] + 1];
+                    }
 #pragma unroll
-                for (int k = 0; k < kChainRows; k++) {
-                    begin[k][s] = b[k];
-                    const uint64_t l = e[k] - b[k];
-                    len[k][s] = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;
+                    for (int k = 0; k < kChainRows; k++) {
+                        x[s][k] = b[k];
+                        const uint64_t l = e[k] - b[k];
+                        len[s][k] = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;
+                    }
+                } else {   // not reachable: the host picks WIDE for 64-bit offsets
+                    base8[s] = a.step[s].codec;
+                    delta[s] = 0;
+#pragma unroll
+                    for (int k = 0; k < kChainRows; k++) { x[s][k] = 0; len[s][k] = 0; }
                 }
             }
         }
         // ---- B: first 8 (16) key bytes ---------------------------------------------------------------
-        uint64_t c0[kChainRows][S], c1[kChainRows][LONG ? S : 1];
+        uint64_t c0[S][kChainRows], c1[LONG ? S : 1][kChainRows];
 #pragma unroll
         for (int s = 0; s < S; s++) {
-            const DevCol& c = a.step[s].col;
 #pragma unroll
             for (int k = 0; k < kChainRows; k++) {
-                if (DBG && nt) c0[k][s] = len[k][s] > 0 ? load_value_chunk<true>(c.data, begin[k][s], len[k][s], 0) : 0;
-                else c0[k][s] = len[k][s] > 0 ? load_value_chunk(c.data, begin[k][s], len[k][s], 0) : 0;
-                if constexpr (LONG) c1[k][s] = len[k][s] > 8 ? load_value_chunk(c.data, begin[k][s], len[k][s], 1) : 0;
+                c0[s][k] = load_chunk_nobranch<B>(base8[s], delta[s], x[s][k], len[s][k], 0);
+                if constexpr (LONG) c1[s][k] = load_chunk_nobranch<B>(base8[s], delta[s], x[s][k], len[s][k], 1);
             }
         }
         // ---- C: codes -----------------------------------------------------------------------------------
-        uint64_t code[kChainRows][S];
+        CW code[S][kChainRows];
 #pragma unroll
         for (int s = 0; s < S; s++) {
-            const bool w32 = cv[s].hdr->lutw_bits == 32;
+            if (DBG && (dbg & 2)) {
 #pragma unroll
-            for (int k = 0; k < kChainRows; k++) {
-                const uint64_t hi = LONG ? c1[k][LONG ? s : 0] : 0ull;
-                if (DBG && (dbg & 2)) {
-                    code[k][s] = (c0[k][s] ^ hi) & 1023;
-                } else if (w32) {
-                    ok[k] &= encode_prefetched_w<uint32_t>(cv[s], a.step[s].col, begin[k][s], len[k][s], c0[k][s], hi, &code[k][s]);
-                } else {
-                    ok[k] &= encode_prefetched_w<uint64_t>(cv[s], a.step[s].col, begin[k][s], len[k][s], c0[k][s], hi, &code[k][s]);
-                }
+                for (int k = 0; k < kChainRows; k++) code[s][k] = (CW)((c0[s][k] ^ (LONG ? c1[LONG ? s : 0][k] : 0ull)) & 1023);
+            } else if (!WIDE || cv[s].hdr->lutw_bits == 32) {
+                encode_rows<uint32_t, B, CW, LONG>(cv[s], base8[s], delta[s], x[s], len[s], c0[s], c1[LONG ? s : 0], code[s], &okm);
+            } else {
+                encode_rows<uint64_t, B, CW, LONG>(cv[s], base8[s], delta[s], x[s], len[s], c0[s], c1[LONG ? s : 0], code[s], &okm);
             }
         }
         // ---- D: lookups ---------------------------------------------------------------------------------
-        uint32_t brow[kChainRows][S];
+        uint32_t brow[S][kChainRows];
 #pragma unroll
         for (int s = 0; s < S; s++) {
             const ChainStepArg& st = a.step[s];
-            if (st.table) {
-                TableEntry e[kChainRows];
+            if (st.rowtab) {
 #pragma unroll
                 for (int k = 0; k < kChainRows; k++) {
-                    if (DBG && (dbg & 1)) e[k] = TableEntry{0u, 0u};
-                    else e[k] = ok[k] ? st.table[code[k][s]] : TableEntry{kTableAbsent, 0u};
-                }
-#pragma unroll
-                for (int k = 0; k < kChainRows; k++) {
-                    ok[k] &= e[k].a != kTableAbsent;
-                    brow[k][s] = e[k].b;
+                    const CW cidx = (okm >> k) & 1u ? code[s][k] : (CW)0;   // entry 0 always exists
+                    brow[s][k] = (DBG && (dbg & 1)) ? 0u : st.rowtab[cidx];
                 }
             } else {
 #pragma unroll
                 for (int k = 0; k < kChainRows; k++) {
-                    brow[k][s] = 0;
-                    if (!ok[k]) continue;
+                    brow[s][k] = kTableAbsent;
+                    if (!((okm >> k) & 1u)) continue;
                     uint64_t lo;
                     bool hit;
                     if (st.key32) {
                         const uint32_t* cd = reinterpret_cast<const uint32_t*>(st.codes);
-                        lo = lower_bound_dev<uint32_t>(cd, 0, st.n_index, (uint32_t)code[k][s]);
-                        hit = lo < st.n_index && cd[lo] == (uint32_t)code[k][s];
+                        lo = lower_bound_dev<uint32_t>(cd, 0, st.n_index, (uint32_t)code[s][k]);
+                        hit = lo < st.n_index && cd[lo] == (uint32_t)code[s][k];
                     } else {
                         const uint64_t* cd = reinterpret_cast<const uint64_t*>(st.codes);
-                        lo = lower_bound_dev<uint64_t>(cd, 0, st.n_index, code[k][s]);
-                        hit = lo < st.n_index && cd[lo] == code[k][s];
+                        lo = lower_bound_dev<uint64_t>(cd, 0, st.n_index, (uint64_t)code[s][k]);
+                        hit = lo < st.n_index && cd[lo] == (uint64_t)code[s][k];
                     }
-                    ok[k] = hit;
-                    if (hit) brow[k][s] = st.perm[lo];
+                    if (hit) brow[s][k] = st.perm[lo];
                 }
             }
         }
+#pragma unroll
+        for (int s = 0; s < S; s++)
+#pragma unroll
+            for (int k = 0; k < kChainRows; k++)
+                if (brow[s][k] == kTableAbsent) okm &= ~(1u << k);
         // ---- dense output + match bookkeeping ----------------------------------------------------------
         uint32_t wave_matches = 0;
+        const uint64_t mword = (tile * kChainWaves + wave) * kChainRows;   // == wbase / 64
 #pragma unroll
         for (int k = 0; k < kChainRows; k++) {
-            const uint64_t bal = __ballot(ok[k]);
+            const bool ok = (okm >> k) & 1u;
+            const uint64_t bal = __ballot(ok);
             wave_matches += (uint32_t)__popcll(bal);
-            if (lane == 0) masks[tile * kChainMasks + k * kChainWaves + wave] = bal;
+            if (lane == 0) masks[mword + k] = bal;
             // the stream row of slot r is probe_base + r by construction: it is never stored here
-            if (ok[k] && !(DBG && (dbg & 4))) {
+            if (ok && !(DBG && (dbg & 4))) {
 #pragma unroll
-                for (int s = 0; s < S; s++) {
-                    if (DBG && nt) __builtin_nontemporal_store(brow[k][s], &a.out_rows[s][row[k]]);
-                    else a.out_rows[s][row[k]] = brow[k][s];
-                }
+                for (int s = 0; s < S; s++) (a.out_rows[s] + wbase)[rel[k]] = brow[s][k];
             }
         }
-        // per-(tile, wave) match count: no workgroup-level synchronisation inside the tile loop
+        // per-(tile, wave) match count
         if (lane == 0) wave_counts[tile * kChainWaves + wave] = wave_matches;
     }
 }
@@ -243,38 +339,30 @@ __global__ __launch_bounds__(256) void k_sum_counts(const uint32_t* __restrict__
     }
 }
 
-// Moves the matched tuples of a tile from slot == row to their final slots.
+// Moves the matched tuples of a wave's rows from slot == row to their final slots (wave_base = the exclusive scan
+// of the (tile, wave) counts).  Wave-local: no LDS, no barrier.
 template <int S>
 __global__ __launch_bounds__(kChainThreads) void k_chain_compact(ChainArgs dense_rows, uint64_t probe_base,
                                                                 const uint64_t* __restrict__ masks,
-                                                                const uint32_t* __restrict__ tile_base, uint64_t ntiles,
+                                                                const uint32_t* __restrict__ wave_base, uint64_t ntiles,
                                                                 uint64_t* __restrict__ out_stream, ChainArgs out_rows) {
-    __shared__ uint64_t s_mask[kChainMasks];
-    __shared__ uint32_t s_pref[kChainMasks];
     const int lane = lane_id(), wave = wave_id();
     const uint64_t lt = lanemask_lt();
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        if (threadIdx.x < kChainMasks) s_mask[threadIdx.x] = masks[tile * kChainMasks + threadIdx.x];
-        __syncthreads();
-        if (wave == 0) {
-            const uint32_t v = lane < kChainMasks ? (uint32_t)__popcll(s_mask[lane]) : 0u;
-            const uint32_t incl = wave_inclusive_sum(v);
-            if (lane < kChainMasks) s_pref[lane] = incl - v;
-        }
-        __syncthreads();
-        const uint64_t base = tile_base[tile * kChainWaves];   // scanned (tile, wave) counts: first entry of the tile
+        const uint64_t wt = tile * kChainWaves + wave;
+        uint64_t pos = wave_base[wt];
 #pragma unroll
         for (int k = 0; k < kChainRows; k++) {
-            const uint64_t m = s_mask[k * kChainWaves + wave];
+            const uint64_t m = masks[wt * kChainRows + k];
             if ((m >> lane) & 1ull) {
-                const uint64_t row = tile * kChainTile + (uint64_t)k * kChainThreads + threadIdx.x;
-                const uint64_t pos = base + s_pref[k * kChainWaves + wave] + (uint64_t)__popcll(m & lt);
-                out_stream[pos] = probe_base + row;
+                const uint64_t row = wt * kWaveTile + (uint64_t)k * kWave + lane;
+                const uint64_t p = pos + (uint64_t)__popcll(m & lt);
+                out_stream[p] = probe_base + row;
 #pragma unroll
-                for (int s = 0; s < S; s++) out_rows.out_rows[s][pos] = dense_rows.out_rows[s][row];
+                for (int s = 0; s < S; s++) out_rows.out_rows[s][p] = dense_rows.out_rows[s][row];
             }
+            pos += (uint64_t)__popcll(m);
         }
-        __syncthreads();
     }
 }
 
@@ -319,7 +407,7 @@ static Status enqueue_dense(cph_ctx* ctx, const ChainStep* steps, uint64_t nprob
         st.col = steps[s].cols[0];
         st.codec = ix->codec_dev.as<uint8_t>();
         st.codec_bytes = (int32_t)ix->codec_dev.bytes();
-        st.table = ix->table_entries ? ix->table.as<TableEntry>() : nullptr;
+        st.rowtab = ix->table_entries ? ix->rowtab.as<uint32_t>() : nullptr;
         st.codes = ix->sorted_codes.get();
         st.perm = ix->perm.as<uint32_t>();
         st.n_index = ix->nrows;
@@ -328,21 +416,30 @@ static Status enqueue_dense(cph_ctx* ctx, const ChainStep* steps, uint64_t nprob
         lds += ix->codec_dev.bytes();
     }
     const uint64_t ncounts = ntiles * kChainWaves;   // one match count per (tile, wave), tile-major
-    const char* e = std::getenv("CPH_CHAIN_DEBUG");
-    const int dbg = e ? std::atoi(e) : 0;
-    bool long_keys = false;
-    for (int s = 0; s < S; s++) long_keys |= steps[s].index->codec.col_maxlen[0] > 8;
-    auto kernel = dbg ? (long_keys ? &k_chain_dense<S, true, true> : &k_chain_dense<S, false, true>)
-                      : (long_keys ? &k_chain_dense<S, true, false> : &k_chain_dense<S, false, false>);
-    CPH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int dbg = ctx->chain_debug;
+    bool long_keys = false, wide = false;
+    for (int s = 0; s < S; s++) {
+        const cph_index* ix = steps[s].index;
+        const DevCol& c = steps[s].cols[0];
+        long_keys |= ix->codec.col_maxlen[0] > 8;
+        // 32-bit registers for value offsets and codes need: 32-bit offsets (addresses are formed in 64 bits at the
+        // load), a 32-bit pre-multiplied LUT, a code that fits 32 bits
+        wide |= codec_premultiplied_bits(ix->codec) != 32 || !ix->codec.key32;
+        if (!c.fixed_width) wide |= c.offset_bits != 32;
+        else wide |= c.fixed_width > 0xFFFFu;
+    }
+    using KernelFn = void (*)(ChainArgs, uint64_t, uint64_t, uint64_t, uint64_t*, uint32_t*, int);
+    static const KernelFn variants[2][2][2] = {
+        {{&k_chain_dense<S, false, false, false>, &k_chain_dense<S, false, false, true>},
+         {&k_chain_dense<S, false, true, false>, &k_chain_dense<S, false, true, true>}},
+        {{&k_chain_dense<S, true, false, false>, &k_chain_dense<S, true, false, true>},
+         {&k_chain_dense<S, true, true, false>, &k_chain_dense<S, true, true, true>}}};
+    const KernelFn kernel = variants[long_keys ? 1 : 0][wide ? 1 : 0][dbg ? 1 : 0];
     // persistent workgroups: exactly as many as are resident at once (no tail wave), each walking
     // tiles blockIdx, blockIdx + grid, ...
-    int per_cu = 0, dev = 0, cus = 256;
-    CPH_HIP_TRY(hipGetDevice(&dev));
-    CPH_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    CPH_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kChainThreads, lds));
-    if (per_cu < 1) per_cu = 1;
+    int per_cu = 1, cus = 256;
+    CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(kernel), kChainThreads, lds, &per_cu));
+    CPH_TRY(device_cus(ctx, &cus));
     const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)cus * (uint64_t)per_cu);
     {
         ProfScope ps(ctx, "k_chain_dense", 0);

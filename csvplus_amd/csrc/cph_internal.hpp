@@ -206,6 +206,11 @@ struct cph_ctx {
     void* upload_ring = nullptr;
     size_t upload_cap = 0, upload_pos = 0;
     std::vector<void*> pinned_user;
+    // per-ctx launch state (a process may hold one ctx per device: nothing of this may be static)
+    int cus = 0;                   // compute units of `device` (0: not queried yet)
+    int chain_debug = 0;           // attribution switches of the chained-join kernel (cph_ctx_set_debug)
+    struct KernelCfg { const void* fn; size_t lds; int blocks_per_cu; };
+    std::vector<KernelCfg> kernel_cfg;   // kernels whose dynamic-LDS attribute / occupancy were set up on this device
     // profiling
     bool profiling = false;
     std::vector<cph::ProfPending> prof_pending;
@@ -222,6 +227,8 @@ struct cph_index {
     cph::DevBuf sorted_codes;      // key32: u32[n]; else u64[nwords][n] word-major
     cph::DevBuf perm;              // u32[n]
     cph::DevBuf table;             // direct-address table {lo,end} u32x2 [table_entries] (optional)
+    cph::DevBuf rowtab;            // duplicate-free index: u32[table_entries], code -> build row (0xFFFFFFFF: absent);
+                                   // 4-byte entries for the chained-join kernel (half the random-access footprint)
     uint64_t table_entries = 0;
     int32_t sort_passes = 0;
     uint64_t first_dup = UINT64_MAX;
@@ -350,6 +357,10 @@ Status read_device_value(cph_ctx* ctx, const T* dev, T* host) {
     memcpy(host, ctx->pinned_scratch, sizeof(T));
     return {};
 }
+
+// Dynamic-LDS attribute + resident workgroups per CU of a kernel, set up once per (ctx, kernel, lds size).
+Status kernel_setup(cph_ctx* ctx, const void* fn, int threads, size_t lds, int* blocks_per_cu);
+Status device_cus(cph_ctx* ctx, int* cus);
 
 // Grid for a grid-stride loop of 256-thread workgroups over n items.
 inline unsigned grid_for_items(uint64_t n, unsigned cap = 8192) {

@@ -83,13 +83,16 @@ Status index_first_dup_read(cph_ctx* ctx, cph_index* ix) {
 // ---------------------------------------------------------------------------------------------
 template <class K>
 __global__ void k_build_table(const K* __restrict__ codes, const uint32_t* __restrict__ perm, uint64_t n,
-                              const uint32_t* __restrict__ first_dup, TableEntry* __restrict__ table) {
+                              const uint32_t* __restrict__ first_dup, TableEntry* __restrict__ table,
+                              uint32_t* __restrict__ rowtab) {
     const bool unique = *first_dup == 0xFFFFFFFFu;   // uniform
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const K c = codes[i];
         if (unique) {
-            table[c] = TableEntry{(uint32_t)i, perm[i]};
+            const uint32_t r = perm[i];
+            table[c] = TableEntry{(uint32_t)i, r};
+            rowtab[c] = r;
         } else {
             if (i == 0 || codes[i - 1] != c) table[c].a = (uint32_t)i;
             if (i + 1 == n || codes[i + 1] != c) table[c].b = (uint32_t)(i + 1);
@@ -106,20 +109,23 @@ Status index_build_table(cph_ctx* ctx, cph_index* ix) {
     if (limit < (1ull << 20)) limit = 1ull << 20;
     if (states > limit || states > (1ull << 30)) return {};
     CPH_TRY(ix->table.alloc(&ctx->pool, states * sizeof(TableEntry)));
+    CPH_TRY(ix->rowtab.alloc(&ctx->pool, states * sizeof(uint32_t)));
     CPH_HIP_TRY(hipMemsetAsync(ix->table.get(), 0xFF, states * sizeof(TableEntry), ctx->stream));
+    CPH_HIP_TRY(hipMemsetAsync(ix->rowtab.get(), 0xFF, states * sizeof(uint32_t), ctx->stream));
     uint64_t nblk = (n + 255) / 256;
     if (nblk > 8192) nblk = 8192;
-    ProfScope ps(ctx, "k_build_table", (double)n * (ix->codec.key32 ? 4.0 : 8.0) + 4.0 * (double)n + 8.0 * (double)n);
+    ProfScope ps(ctx, "k_build_table", (double)n * (ix->codec.key32 ? 4.0 : 8.0) + 4.0 * (double)n + 12.0 * (double)n);
     const dim3 grid((unsigned)nblk), block(256);
     const uint32_t* perm = ix->perm.as<uint32_t>();
     const uint32_t* fd = ix->first_dup_dev.as<uint32_t>();
     TableEntry* tab = ix->table.as<TableEntry>();
+    uint32_t* rtab = ix->rowtab.as<uint32_t>();
     if (ix->codec.key32)
         hipLaunchKernelGGL(k_build_table<uint32_t>, grid, block, 0, ctx->stream, ix->sorted_codes.as<uint32_t>(), perm, n,
-                           fd, tab);
+                           fd, tab, rtab);
     else
         hipLaunchKernelGGL(k_build_table<uint64_t>, grid, block, 0, ctx->stream, ix->sorted_codes.as<uint64_t>(), perm, n,
-                           fd, tab);
+                           fd, tab, rtab);
     CPH_HIP_TRY(hipGetLastError());
     ix->table_entries = states;
     return {};

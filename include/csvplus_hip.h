@@ -129,6 +129,11 @@ CPH_API const char* cph_last_error(const cph_ctx* ctx);
  * library's kernels with its own copies. */
 CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
 
+/* Measurement hook (tools/microbench): attribution switches of the chained-join kernel — bit 0 skips the
+ * table lookups, bit 1 the key encode, bit 2 the result stores.  Results are WRONG while any bit is set;
+ * 0 (the default) is the product path.  Per ctx, so two devices in one process never share it. */
+CPH_API int32_t cph_ctx_set_debug(cph_ctx* ctx, int32_t chain_flags);
+
 /* Blocks until everything enqueued by this ctx has finished. */
 CPH_API int32_t cph_ctx_synchronize(cph_ctx* ctx);
 

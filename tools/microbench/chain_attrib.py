@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Attribution of the fused chain kernel's time: CPH_CHAIN_DEBUG switches off the table lookup (1),
-the encode (2) and the output stores (4).  One process per setting (the flag is read per launch)."""
+"""Attribution of the fused chain kernel's time: ctx.set_debug switches off the table lookup (1),
+the encode (2) and the output stores (4).  The flag is per ctx."""
 import os, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
@@ -17,7 +17,7 @@ oc, op = o["cust_id"].to_device(dev), o["prod_id"].to_device(dev)
 ia = eng.index_on([cust], unique=True); ib = eng.index_on([prod], unique=True)
 for name, steps in (("cust", [(ia, oc)]), ("prod", [(ib, op)]), ("cust+prod", [(ia, oc), (ib, op)])):
     for dbg in (0, 1, 2, 3, 4, 5, 7):
-        os.environ["CPH_CHAIN_DEBUG"] = str(dbg)
+        eng.ctx.set_debug(dbg)
         eng.chained_join(steps).release()
         eng.ctx.profile(True); eng.ctx.profile_read(reset=True)
         for _ in range(3):
@@ -25,4 +25,4 @@ for name, steps in (("cust", [(ia, oc)]), ("prod", [(ib, op)]), ("cust+prod", [(
         p = eng.ctx.profile_read(reset=True); eng.ctx.profile(False)
         print(f"{name:10s} dbg={dbg} (skip{' lookup' if dbg & 1 else ''}{' encode' if dbg & 2 else ''}{' stores' if dbg & 4 else ''}) "
               f"k_chain_dense {p['k_chain_dense']['total_ms'] / 3:.3f} ms", flush=True)
-os.environ["CPH_CHAIN_DEBUG"] = "0"
+eng.ctx.set_debug(0)
