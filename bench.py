@@ -42,7 +42,55 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-index-1e8", action="store_true", help="skip the extra IndexOn-at-full-size measurements")
     ap.add_argument("--cpu-sample-rows", type=int, default=4_000_000)
+    ap.add_argument("--no-verify", action="store_true", help="skip the full-size checks of the timed outputs")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the pinned-host -> pinned-host scope (cph_stream_join_*)")
+    ap.add_argument("--verify-sample", type=int, default=100_000)
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the two rocprofv3 --pmc child runs (FETCH_SIZE, WRITE_SIZE) behind roofline.traffic")
     return ap.parse_args()
+
+
+def measure_traffic(kernel_prefix, args):
+    """HBM-side bytes per launch of one kernel: two child runs of this same script under
+    `rocprofv3 --kernel-trace --pmc <counter>` (one counter per run, never combined with other trace domains:
+    MI355X_MICROARCH.md "rocprofv3 PMC slots").  Returns (dict, note) or (None, reason)."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    vals = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="cph_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+               sys.executable, str(ROOT / "bench.py"), "--steps", "2", "--warmup", "1", "--rows", str(args.rows),
+               "--customers", str(args.customers), "--products", str(args.products), "--no-cpu-baseline",
+               "--no-index-1e8", "--no-verify", "--no-e2e", "--no-traffic"]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300,
+                           check=True)
+            n, tot = 0, 0.0
+            for f in Path(d).rglob("*counter_collection.csv"):
+                for r in csv.DictReader(open(f)):
+                    name = r["Kernel_Name"]
+                    for pfx in ("void cph::", "cph::"):
+                        if name.startswith(pfx):
+                            name = name[len(pfx):]
+                    if name.startswith(kernel_prefix) and r["Counter_Name"] == counter:
+                        n += 1
+                        tot += float(r["Counter_Value"])
+            if n == 0:
+                return None, f"no {counter} rows for {kernel_prefix}"
+            vals[counter] = tot / n * 1024.0   # the counters are reported in KB
+        except (subprocess.SubprocessError, OSError, KeyError, ValueError) as e:
+            return None, f"{counter} pass failed: {type(e).__name__}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return vals, "measured in this run"
 
 
 def main():
@@ -153,11 +201,15 @@ def main():
         "k_col_stats": K * (cust_bytes + off_c + prod_bytes + off_p),
         "k_encode_build": K * ((cust_bytes + off_c + ia_info["key_bytes"] * args.customers)
                                + (prod_bytes + off_p + ib_info["key_bytes"] * args.products)),
-        # fused chain pass, per stream row: both keys' bytes + offsets in, one 8-byte table entry per
+        # fused chain pass, per stream row: both keys' bytes + offsets in, one 4-byte table entry per
         # step, two 4-byte build-row ids out per joined row (the stream row is implicit)
-        "k_chain_dense": K * (host_bytes["cust_id"] + host_bytes["prod_id"] + off_o + 2 * 8 * nloc
+        "k_chain_dense": K * (host_bytes["cust_id"] + host_bytes["prod_id"] + off_o + 2 * 4 * nloc
                                + 8 * total_joined_local),
     }
+    # compulsory bytes (SURVEY.md §8d "useful"): every input read once, each table read once (not one entry per
+    # probe), every output written once
+    useful = {"k_chain_dense": K * (host_bytes["cust_id"] + host_bytes["prod_id"] + off_o
+                                    + 4 * (ia_info["table_entries"] + ib_info["table_entries"]) + 8 * total_joined_local)}
     kernels = {}
     for name, st in prof.items():
         b = st["algo_bytes"] + extra.get(name, 0.0)
@@ -171,22 +223,33 @@ def main():
         a = dom[1]["GBps"] or 0.0
         roofline = {"bound": "hbm", "kernel": dom[0], "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(a / HBM_PEAK_GBPS, 4), "traffic": None,
-                    "avg_launch_ms": dom[1]["avg_ms"], "launches": dom[1]["launches"]}
-    # HBM-side traffic of the dominant kernel: PMC counters cannot be collected inside this process;
-    # they come from the separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this
-    # same command (tools/gpu_profile.sh), whose per-kernel summary is committed under profiles/.
-    tf = ROOT / "profiles" / "traffic_latest.json"
-    if roofline and tf.exists() and args.rows == 100_000_000:
-        try:
-            tj = json.loads(tf.read_text())
-            hit = [v for k, v in tj.items() if k.startswith(roofline["kernel"])]
-            if hit and hit[0]["fetch_bytes_per_launch"] and hit[0]["write_bytes_per_launch"]:
-                roofline["traffic"] = hit[0]["fetch_bytes_per_launch"] + hit[0]["write_bytes_per_launch"]
-                roofline["traffic_note"] = ("FETCH_SIZE+WRITE_SIZE per launch (raw counters, bytes) from "
-                                            "profiles/traffic_latest.json; algorithmic bytes per launch = "
-                                            f"{dom[1]['algo_GB'] / dom[1]['launches'] * 1e9:.0f}")
-        except (ValueError, KeyError):
-            pass
+                    "avg_launch_ms": dom[1]["avg_ms"], "launches": dom[1]["launches"],
+                    "algorithmic_bytes_per_launch": round(dom[1]["algo_GB"] * 1e9 / dom[1]["launches"])}
+        if dom[0] in useful and dom[1]["total_ms"] > 0:
+            ub = useful[dom[0]] / dom[1]["launches"]
+            roofline["useful_bytes_per_launch"] = round(ub)
+            roofline["useful"] = round(ub / 1e9 / (dom[1]["avg_ms"] / 1e3) / HBM_PEAK_GBPS, 4)
+        # the whole step (every kernel + host gaps) against the same peak
+        step_bytes = sum(v["algo_GB"] for v in kernels.values()) * 1e9 / K
+        roofline["step_frac"] = round(step_bytes / 1e9 / (ms_per_step / 1e3) / HBM_PEAK_GBPS, 4)
+    # HBM-side traffic of the dominant kernel: PMC counters cannot be collected inside this process, so
+    # two child runs of this script under `rocprofv3 --pmc` (one counter each) measure them NOW, on this box.
+    # gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE tallies a 128-byte request of a wide coalesced
+    # stream as 64 bytes; profiles/r02_pmc_calibration.txt (tools/microbench/pmc_calib.hip) measures the factor
+    # for this kernel's access classes — streamed 4/8-byte-per-lane reads are under-counted 2x, random 4-byte
+    # gathers and WRITE_SIZE are exact — so corrected = FETCH + (streamed input bytes that reached HBM once) + WRITE.
+    if roofline and world == 1 and not args.no_traffic:
+        vals, note = measure_traffic(roofline["kernel"], args)
+        if vals:
+            streamed_in = (host_bytes["cust_id"] + host_bytes["prod_id"] + off_o) if roofline["kernel"] == "k_chain_dense" else 0
+            raw = vals["FETCH_SIZE"] + vals["WRITE_SIZE"]
+            roofline["traffic"] = round(raw + streamed_in / 2)
+            roofline["traffic_raw"] = {"FETCH_SIZE": round(vals["FETCH_SIZE"]), "WRITE_SIZE": round(vals["WRITE_SIZE"])}
+            roofline["traffic_note"] = ("bytes per launch; FETCH_SIZE + WRITE_SIZE from two rocprofv3 --pmc child runs of "
+                                        "this command, + half of the streamed input bytes (gfx950 counts a coalesced "
+                                        "stream's 128-byte requests as 64: profiles/r02_pmc_calibration.txt)")
+        else:
+            roofline["traffic_note"] = f"not measured: {note}"
     build_names = ("k_col_stats", "k_encode_build", "k_radix_hist_u32", "k_radix_hist_u64", "k_radix_scatter_u32",
                    "k_radix_scatter_u64", "exclusive_scan_u32", "k_first_dup", "k_build_table", "k_gather_u64")
     build_ms = sum(kernels[k]["total_ms"] for k in build_names if k in kernels)
@@ -214,6 +277,86 @@ def main():
         "host": {"nproc": os.cpu_count(), "gpu": torch.cuda.get_device_name(dev), "datagen_s": round(gen_s, 1)},
     }
 
+    # ---- full-size verification of what was just timed (outside the timed region) ----------------
+    gpu_prefix = None
+    if world == 1 and not args.no_verify:
+        from csvplus_amd import verify as V
+
+        t0 = time.perf_counter()
+        ia = eng.index_on([d_cust], unique=True)
+        ib = eng.index_on([d_prod], unique=True)
+        res = eng.chained_join([(ia, d_ord["cust_id"]), (ib, d_ord["prod_id"])], probe_base=begin)
+        all_joined = res.n == nloc and res.stream_row is None
+        ver = {"joined_rows": res.n, "every_stream_row_joined_once": all_joined}
+        if all_joined:
+            rows = V.sample_rows(nloc, args.verify_sample)
+            idx = torch.from_numpy(rows).to(dev)
+            b0 = res.build_rows[0][idx].cpu().numpy()
+            b1 = res.build_rows[1][idx].cpu().numpy()
+            ver["sample_rows"] = int(rows.size)
+            # csvplus.go:553-567: the emitted build row is the one whose key equals the stream row's key
+            ver["cust_key_mismatches"] = V.check_join_sample(ords["cust_id"], cust_id, b0, rows)
+            ver["prod_key_mismatches"] = V.check_join_sample(ords["prod_id"], prod_id, b1, rows)
+            ver["digest_cust_rows"] = f"{V.digest_u64(res.build_rows[0]):016x}"
+            ver["digest_prod_rows"] = f"{V.digest_u64(res.build_rows[1]):016x}"
+            ns = min(args.cpu_sample_rows, nloc)
+            gpu_prefix = (res.build_rows[0][:ns].cpu().numpy().view(np.uint32).copy(),
+                          res.build_rows[1][:ns].cpu().numpy().view(np.uint32).copy())
+        # the two indexes of the step: perm is a permutation, keys ascend through it, ties keep input order
+        for name, ix, col in (("customers", ia, d_cust), ("products", ib, d_prod)):
+            from csvplus_amd.engine import device_view
+            perm = device_view(ix.perm_device_ptr(), ix.nrows, "<i4", ix, dev)
+            ver[f"index_{name}"] = V.check_index_order(col, perm)
+        ok = all_joined and ver.get("cust_key_mismatches") == 0 and ver.get("prod_key_mismatches") == 0 \
+            and all(ver[f"index_{n_}"].get("ok") for n_ in ("customers", "products"))
+        res.release(); ia.close(); ib.close()
+        ver["seconds"] = round(time.perf_counter() - t0, 2)
+        out["verified"] = bool(ok)
+        out["verify"] = ver
+
+    # ---- end-to-end C-ABI scope: pinned host SoA in -> pinned host row ids out (PCIe inclusive) ----
+    # cph_stream_join_*: 2^24-row chunks of the same orders table, H2D / kernel / D2H of consecutive chunks
+    # overlapped on the pipeline's HIP streams.  Reported beside `value`, never part of it.
+    if world == 1 and not args.no_e2e:
+        from csvplus_amd.streaming import PinnedCol, StreamJoin
+
+        ia = eng.index_on([d_cust], unique=True)
+        ib = eng.index_on([d_prod], unique=True)
+        pc = [PinnedCol(eng.ctx, ords["cust_id"]), PinnedCol(eng.ctx, ords["prod_id"])]
+        chunk = 1 << 24
+        bounds = [(b, min(b + chunk, nloc)) for b in range(0, nloc, chunk)]
+        chunks = [[c.col.slice(b, e) for c in pc] for b, e in bounds]
+        nslots = 2
+        best = None
+        for rep in range(3):
+            sj = StreamJoin(eng.ctx, [ia, ib], nslots=nslots)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            sub = done = 0
+            joined_e2e = 0
+            while done < len(chunks):
+                while sub < len(chunks) and sj.pending < nslots:
+                    sj.submit(chunks[sub], probe_base=bounds[sub][0])
+                    sub += 1
+                r = sj.next(copy=False)
+                joined_e2e += r["nmatches"]
+                done += 1
+            dt_e2e = time.perf_counter() - t0
+            sj.close()
+            if best is None or dt_e2e < best:
+                best = dt_e2e
+        h2d = host_bytes["cust_id"] + host_bytes["prod_id"] + off_o
+        d2h = 8 * nloc + nloc // 8
+        out["e2e_pinned_host"] = {
+            "scope": "pinned host key columns in -> pinned host build-row ids + match bitmap out (cph_stream_join_*), "
+                     "indexes already built; PCIe inclusive",
+            "rows": nloc, "chunk_rows": chunk, "slots": nslots, "ms": round(best * 1e3, 2),
+            "rows_per_s": nloc / best, "joined": joined_e2e,
+            "h2d_GBps": round(h2d / best / 1e9, 1), "d2h_GBps": round(d2h / best / 1e9, 1)}
+        for c in pc:
+            c.free()
+        ia.close(); ib.close()
+
     # ---- IndexOn at 1e8 rows (the other half of BASELINE's metric; reported, not part of `value`) ---
     if world == 1 and not args.no_index_1e8:
         def time_index(col, unique, reps):
@@ -231,6 +374,14 @@ def main():
             wall = (time.perf_counter() - t0) / reps
             p = eng.ctx.profile_read(reset=True)
             eng.ctx.profile(False)
+            check = None
+            if not args.no_verify:
+                from csvplus_amd import verify as V
+                from csvplus_amd.engine import device_view
+                ix = eng.index_on([d], unique=unique)
+                check = V.check_index_order(d, device_view(ix.perm_device_ptr(), ix.nrows, "<i4", ix, dev))
+                ix.close()
+                torch.cuda.empty_cache()
             kms = sum(v["total_ms"] for v in p.values()) / reps
             n = col.nrows
             # algorithmic bytes: stats + encode read the column, every pass moves (2K+8) B/row after a
@@ -239,8 +390,12 @@ def main():
             src = col.nbytes_values() + col.nbytes_offsets()
             algo = 2 * src + n * K_ + inf["sort_passes"] * n * (3 * inf["key_bytes"] + 8) + n * K_ \
                 + (n * (inf["key_bytes"] + 12) if inf["direct_table"] else 0)
+            compulsory = src + n * (K_ + 4)    # the column read once, sorted codes + perm written once
             return {"rows": n, "ms": round(wall * 1e3, 3), "kernel_ms": round(kms, 3), "rows_per_s": n / wall,
-                    "GBps_algorithmic": round(algo / 1e9 / wall, 1), "info": inf,
+                    "GBps_algorithmic": round(algo / 1e9 / wall, 1),
+                    "frac_pass_model": round(algo / 1e9 / wall / HBM_PEAK_GBPS, 4),
+                    "frac_compulsory": round(compulsory / 1e9 / wall / HBM_PEAK_GBPS, 4),
+                    "verified": (check or {}).get("ok"), "verify": check, "info": inf,
                     "kernels_ms": {k: round(v["total_ms"] / reps, 3) for k, v in p.items()}}
 
         n8 = args.rows
@@ -267,6 +422,14 @@ def main():
         j2 = ob.join([s_prod], row_sel=sel)
         t_probe = time.perf_counter() - t0
         est = t_build + t_probe * (args.rows / ns)
+        if gpu_prefix is not None:
+            # bit-exact comparison of the first `ns` result rows of the timed configuration with the oracle
+            eq = bool(j1["nmatches"] == ns and j2["nmatches"] == ns
+                      and np.array_equal(j1["build_row"].astype(np.uint32), gpu_prefix[0][:ns])
+                      and np.array_equal(j2["build_row"].astype(np.uint32), gpu_prefix[1][:ns]))
+            out.setdefault("verify", {})["oracle_prefix_rows"] = ns
+            out["verify"]["oracle_prefix_bit_exact"] = eq
+            out["verified"] = bool(out.get("verified")) and eq
         out["cpu_baseline"] = {
             "value": args.rows / est, "unit": "rows/s", "cores": 1, "kind": "port",
             "sample": f"oracle (C restatement, SoA strings, comparison sort + binary-search probe; 1 thread): both "

@@ -37,6 +37,7 @@ struct cph_stream_join {
     };
     std::vector<Slot*> slots;
     std::vector<int> fifo;                 // slot numbers in submission order
+    uint64_t submit_seq = 0;               // chunks submitted so far: chunk k uses slot k % nslots
 };
 
 static int32_t sj_fail(cph_ctx* ctx, int32_t code, const std::string& msg) {
@@ -112,10 +113,10 @@ CPH_API int32_t cph_stream_join_submit(cph_stream_join* sj, const cph_strcol* st
     if (!sj || !step_cols) return CPH_ERR_INVALID;
     cph_ctx* pctx = sj->parent;
     if (hipSetDevice(pctx->device) != hipSuccess) return sj_fail(pctx, CPH_ERR_HIP, "hipSetDevice failed");
-    int slot = -1;
-    for (int i = 0; i < (int)sj->slots.size(); i++)
-        if (!sj->slots[i]->busy) { slot = i; break; }
-    if (slot < 0) return sj_fail(pctx, CPH_ERR_INVALID, "no free slot: call cph_stream_join_next first");
+    // round robin: the arrays cph_stream_join_next handed out for chunk k stay untouched until chunk k + nslots
+    // is submitted (the lifetime the header promises), whatever order the caller interleaves next / submit in
+    const int slot = (int)(sj->submit_seq % sj->slots.size());
+    if (sj->slots[slot]->busy) return sj_fail(pctx, CPH_ERR_INVALID, "no free slot: call cph_stream_join_next first");
     auto& sl = *sj->slots[slot];
     cph_ctx* ctx = &sl.sctx;
     const uint64_t n = step_cols[0].nrows;
@@ -201,6 +202,7 @@ CPH_API int32_t cph_stream_join_submit(cph_stream_join* sj, const cph_strcol* st
         return sj_fail(pctx, st.code, st.msg);
     }
     sl.busy = true;
+    sj->submit_seq++;
     sl.probe_base = probe_base;
     sl.nrows = n;
     sj->fifo.push_back(slot);

@@ -280,7 +280,10 @@ CPH_API void    cph_stream_join_destroy(cph_stream_join* sj);
 CPH_API int32_t cph_stream_join_submit(cph_stream_join* sj, const cph_strcol* step_cols, uint64_t probe_base);
 CPH_API int32_t cph_stream_join_pending(const cph_stream_join* sj);
 /* Waits for the OLDEST chunk in flight.  The arrays are pinned memory owned by the
- * pipeline, valid until `nslots` further chunks have been submitted. */
+ * pipeline.  Slots are used round robin — chunk number k (counting submissions from 0)
+ * lives in slot k % nslots — so the arrays of chunk k stay valid until chunk k + nslots
+ * is SUBMITTED: a caller that keeps at most nslots - 1 chunks in flight can read a
+ * returned chunk while the following ones are being processed. */
 CPH_API int32_t cph_stream_join_next(cph_stream_join* sj, cph_stream_chunk* out);
 
 /* ---- materialisation: the step after the path ------------------ */

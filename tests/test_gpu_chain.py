@@ -184,3 +184,43 @@ def test_config4_properties_3e7(ctx):
     pw, pl = padded(prod["prod_id"])
     ow, ol = padded(ords["prod_id"])
     assert np.array_equal(pw[b], ow) and np.array_equal(pl[b], ol)
+
+
+def test_config4_full_size_1e8(ctx):
+    """The configuration bench.py times, at its full size: 1e8 orders x 1e7 customers x 1e5 products with the
+    columns resident in HBM.  Every order joins exactly once; ALL customer pairings are checked on the device
+    (fixed 8-byte keys: one u64 compare per row), the variable-length product keys on a 2e5-row sample, both
+    indexes through verify.check_index_order (permutation, ascending keys, stable ties)."""
+    import torch
+
+    from csvplus_amd import verify as V
+    from csvplus_amd.engine import Engine, device_view
+
+    m, nc, npd = 100_000_000, 10_000_000, 100_000
+    eng = Engine(0)
+    dev = eng.device
+    cust_id = dg.column(dg.SEQ_PERM, nc, nc, encoding=dg.FIXED8, seed=dg.SEED + 1)
+    prod_id = dg.column(dg.SEQ_PERM, npd, npd, encoding=dg.ITOA, seed=dg.SEED + 2)
+    ords = dg.orders(m, nc, npd)
+    d_cust, d_prod = cust_id.to_device(dev), prod_id.to_device(dev)
+    d_oc, d_op = ords["cust_id"].to_device(dev), ords["prod_id"].to_device(dev)
+    ia, ib = eng.index_on([d_cust], unique=True), eng.index_on([d_prod], unique=True)
+    for ix, col in ((ia, d_cust), (ib, d_prod)):
+        r = V.check_index_order(col, device_view(ix.perm_device_ptr(), ix.nrows, "<i4", ix, dev))
+        assert r["ok"], r
+    res = eng.chained_join([(ia, d_oc), (ib, d_op)])
+    assert res.n == m and res.stream_row is None
+    # customers, every row: key of the paired customer == the order's cust_id (csvplus.go:553-567)
+    ck = d_cust.data[: nc * 8].view(torch.int64)
+    ok_ = d_oc.data[: m * 8].view(torch.int64)
+    a = res.build_rows[0].to(torch.int64) & 0xFFFFFFFF
+    assert bool((a < nc).all().item())
+    assert bool((ck[a] == ok_).all().item())
+    del a
+    rows = V.sample_rows(m, 200_000, seed=7)
+    b = res.build_rows[1][torch.from_numpy(rows).to(dev)].cpu().numpy()
+    assert V.check_join_sample(ords["prod_id"], prod_id, b, rows) == 0
+    res.release()
+    ia.close()
+    ib.close()
+    eng.close()

@@ -72,3 +72,30 @@ def test_stream_join_slot_exhaustion_and_rejects_dup_index(ctx):
     with pytest.raises(N.CphError) as e:
         StreamJoin(ctx, [dup])
     assert e.value.code == N.CPH_ERR_INVALID
+
+
+def test_stream_join_returned_chunk_survives_later_submits(ctx):
+    """The lifetime the header promises for a chunk handed out WITHOUT a copy: chunk k's pinned arrays are reused
+    by chunk k + nslots only (slots are taken round robin).  A caller with nslots = 3 that keeps two chunks in
+    flight reads chunk k while k+1 and k+2 run — the next -> submit -> process order a cgo caller would use."""
+    nc = 5_000
+    cust = dg.customers(nc)["id"]
+    ix = DeviceIndex(ctx, [cust], unique=True)
+    oix = orc.OracleIndex([cust])
+    sj = StreamJoin(ctx, [ix], nslots=3)
+    n = 60_000
+    cols = [dg.orders(10**6, 2 * nc, 10, row0=i * n, nrows=n)["cust_id"] for i in range(5)]
+    expect = [oix.join([c], probe_base=i * n) for i, c in enumerate(cols)]
+    sj.submit([cols[0]], probe_base=0)
+    sj.submit([cols[1]], probe_base=n)
+    for k in range(5):
+        r = sj.next(copy=False)                       # views of the slot's pinned arrays
+        if k + 2 < 5:
+            sj.submit([cols[k + 2]], probe_base=(k + 2) * n)   # submitted BEFORE chunk k is read
+        import time
+        time.sleep(0.05)                               # let the new chunk run: it must not touch chunk k's arrays
+        hit = bitmap_to_rows(r["bitmap"].copy(), r["nrows"])
+        np.testing.assert_array_equal(hit + k * n, expect[k]["probe_idx"].astype(np.int64))
+        np.testing.assert_array_equal(r["build_row"][0][hit], expect[k]["build_row"])
+        assert r["nmatches"] == expect[k]["nmatches"]
+    sj.close()

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 cp csvplus_amd/csrc/chain.hip /tmp/chain.orig
 for cfg in ${1:-"256,3 256,4 256,2 256,6"}; do
   T=${cfg%,*}; R=${cfg#*,}
-  sed -E "s/constexpr int kChainRows    = [0-9]+; /constexpr int kChainRows    = $R; /; s/constexpr int kChainThreads = [0-9]+;/constexpr int kChainThreads = $T;/" /tmp/chain.orig > csvplus_amd/csrc/chain.hip
+  sed -E "s/constexpr int kChainRows    = [0-9]+;/constexpr int kChainRows    = $R;/; s/constexpr int kChainThreads = [0-9]+;/constexpr int kChainThreads = $T;/" /tmp/chain.orig > csvplus_amd/csrc/chain.hip
   make hip > /tmp/make_$T_$R.log 2>&1 || { echo "build failed for $cfg"; tail -5 /tmp/make_$T_$R.log; continue; }
   timeout 300 python - <<PY
 import sys
