@@ -5,8 +5,8 @@ A "step" = one pass of the hot path over one batch, BASELINE.json's headline sha
 ("10^8-row 3-col join"; configs[3] at one GPU): with all staged columns already
 resident in HBM,
 
-    customers.UniqueIndexOn("id")        (1e7 rows, 8-byte ids)      cph_index_build
-    products.UniqueIndexOn("prod_id")    (1e5 rows)                  cph_index_build
+    customers.UniqueIndexOn("id")        (1e7 rows, 8-byte ids)      } cph_index_build_many
+    products.UniqueIndexOn("prod_id")    (1e5 rows)                  } (one batch of two builds)
     orders.Join(customers,"cust_id").Join(products,"prod_id")       cph_join_probe x2
         over 1e8 orders rows x 3 string columns (cust_id, prod_id, qty)
 
@@ -136,8 +136,8 @@ def main():
     nloc = end - begin
 
     def step():
-        ia = eng.index_on([d_cust], unique=True)
-        ib = eng.index_on([d_prod], unique=True)
+        # both build sides as one batch (cph_index_build_many): their host round trips are shared
+        ia, ib = eng.index_on_many([[d_cust], [d_prod]], unique=True)
         res = eng.chained_join([(ia, d_ord["cust_id"]), (ib, d_ord["prod_id"])], probe_base=begin)
         # stream_row is None when every order joined (the result row IS the stream row): then only
         # the two build-row arrays exist — and only they are exchanged
@@ -283,8 +283,7 @@ def main():
         from csvplus_amd import verify as V
 
         t0 = time.perf_counter()
-        ia = eng.index_on([d_cust], unique=True)
-        ib = eng.index_on([d_prod], unique=True)
+        ia, ib = eng.index_on_many([[d_cust], [d_prod]], unique=True)
         res = eng.chained_join([(ia, d_ord["cust_id"]), (ib, d_ord["prod_id"])], probe_base=begin)
         all_joined = res.n == nloc and res.stream_row is None
         ver = {"joined_rows": res.n, "every_stream_row_joined_once": all_joined}

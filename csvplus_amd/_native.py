@@ -101,6 +101,10 @@ class cph_index_info(C.Structure):
 CPH_MAX_CHAIN = 4
 
 
+class cph_index_spec(C.Structure):
+    _fields_ = [("keycols", C.POINTER(cph_strcol)), ("nkeycols", C.c_int32), ("unique", C.c_int32)]
+
+
 class cph_chain_step(C.Structure):
     _fields_ = [("index", C.c_void_p), ("cols", C.POINTER(cph_strcol)), ("ncols", C.c_int32), ("reserved_", C.c_int32)]
 
@@ -159,7 +163,7 @@ PROTOTYPES = [
     ("cph_ctx_destroy", None, [_P]),
     ("cph_last_error", C.c_char_p, [_P]),
     ("cph_ctx_set_stream", C.c_int32, [_P, _P]),
-    ("cph_ctx_set_debug", C.c_int32, [_P, C.c_int32]),
+    ("cph_ctx_set_option", C.c_int32, [_P, C.c_char_p, C.c_int64]),
     ("cph_ctx_synchronize", C.c_int32, [_P]),
     ("cph_ctx_profile", C.c_int32, [_P, C.c_int32]),
     ("cph_ctx_profile_read", C.c_int32,
@@ -168,6 +172,8 @@ PROTOTYPES = [
     ("cph_pinned_free", C.c_int32, [_P, _P]),
     ("cph_index_build", C.c_int32,
      [_P, C.POINTER(cph_strcol), C.c_int32, C.c_int32, C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    ("cph_index_build_many", C.c_int32,
+     [_P, C.POINTER(cph_index_spec), C.c_int32, C.POINTER(_P), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),
     ("cph_index_destroy", None, [_P]),
     ("cph_index_nrows", C.c_uint64, [_P]),
     ("cph_index_nkeycols", C.c_int32, [_P]),
@@ -280,9 +286,13 @@ class Context:
     def set_stream(self, stream_handle: int | None):
         self._check(self.lib.cph_ctx_set_stream(self.handle, _P(stream_handle or 0)))
 
+    def set_option(self, name: str, value: int):
+        """Measurement / tuning knobs of this ctx (include/csvplus_hip.h: cph_ctx_set_option)."""
+        self._check(self.lib.cph_ctx_set_option(self.handle, name.encode(), int(value)))
+
     def set_debug(self, chain_flags: int):
         """Attribution switches of the chained-join kernel (measurement only: results are wrong when set)."""
-        self._check(self.lib.cph_ctx_set_debug(self.handle, int(chain_flags)))
+        self.set_option("chain_debug", chain_flags)
 
     def synchronize(self):
         self._check(self.lib.cph_ctx_synchronize(self.handle))
@@ -330,6 +340,42 @@ class DeviceIndex:
         self.status = rc
         if rc not in (CPH_OK, CPH_ERR_DUPLICATE):
             ctx._check(rc)
+
+    @staticmethod
+    def build_many(ctx: "Context", specs) -> list:
+        """specs: [(keycols, unique), ...] -> [DeviceIndex, ...] through cph_index_build_many (one batch: the
+        builds share their two host round trips).  Raises for any status other than OK / DUPLICATE; a unique
+        spec with equal keys comes back with .status == CPH_ERR_DUPLICATE like the single build."""
+        k = len(specs)
+        arr = (cph_index_spec * k)()
+        keep = []
+        for i, (cols, unique) in enumerate(specs):
+            ca, kp = _cols_array(cols)
+            keep.append((ca, kp))
+            arr[i].keycols = ca
+            arr[i].nkeycols = len(cols)
+            arr[i].unique = 1 if unique else 0
+        outs = (_P * k)()
+        dups = (C.c_uint64 * k)()
+        sts = (C.c_int32 * k)()
+        rc = ctx.lib.cph_index_build_many(ctx.handle, arr, k, outs, dups, sts)
+        del keep
+        res = []
+        for i in range(k):
+            ix = DeviceIndex.__new__(DeviceIndex)
+            ix.ctx, ix.lib = ctx, ctx.lib
+            ix.handle = _P(outs[i]) if outs[i] else None
+            ix.first_dup = None if dups[i] == UINT64_MAX else int(dups[i])
+            ix.status = int(sts[i])
+            ctx._children.add(ix)
+            res.append(ix)
+        bad = [r for r in res if r.status not in (CPH_OK, CPH_ERR_DUPLICATE)]
+        if bad or (rc not in (CPH_OK, CPH_ERR_DUPLICATE)):
+            msg = ctx.last_error()
+            for r in res:
+                r.close()
+            raise CphError(bad[0].status if bad else rc, msg)
+        return res
 
     @property
     def nrows(self) -> int:

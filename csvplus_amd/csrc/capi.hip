@@ -243,20 +243,89 @@ static Status enter(cph_ctx* ctx) {
 }
 
 // ---- IndexOn ------------------------------------------------------------------------------------
-static Status index_build_impl(cph_ctx* ctx, const cph_strcol* keycols, int32_t nkeycols, cph_index* ix) {
-    CPH_TRY(validate_cols(keycols, nkeycols));
-    const uint64_t n = keycols[0].nrows;
-    ix->ctx = ctx;
-    ix->nrows = n;
-    ix->nkeycols = nkeycols;
-
+// One index build in three phases, so that a batch of builds (cph_index_build_many) shares its two host round
+// trips: (1) stage the columns, enqueue the alphabet statistics  | sync: statistics of every index |
+// (2) codec on the host, encode + sort + adjacent-equal scan enqueued  | sync: first duplicate of every index |
+// (3) table decision.
+struct BuildJob {
+    cph_index* ix = nullptr;
+    int32_t nkeycols = 0;
     std::vector<DevBuf> staged;
     DevCol dcols[kMaxKeyCols];
-    CPH_TRY(stage_cols(ctx, keycols, nkeycols, &staged, dcols));
+    DevBuf stats_dev;
+    size_t scratch_off = 0;      // where this job's read-backs land in ctx->pinned_scratch
+};
 
-    // K0: alphabets -> codec
+static Status build_phase1(cph_ctx* ctx, const cph_strcol* keycols, int32_t nkeycols, BuildJob* job) {
+    CPH_TRY(validate_cols(keycols, nkeycols));
+    cph_index* ix = job->ix;
+    ix->ctx = ctx;
+    ix->nrows = keycols[0].nrows;
+    ix->nkeycols = nkeycols;
+    job->nkeycols = nkeycols;
+    CPH_TRY(stage_cols(ctx, keycols, nkeycols, &job->staged, job->dcols));
+    CPH_TRY(codec_stats_launch(ctx, job->dcols, nkeycols, &job->stats_dev));   // K0: alphabets
+    return {};
+}
+
+static Status build_phase2(cph_ctx* ctx, BuildJob* job, const void* stats_host);
+
+// Runs a batch of jobs whose phase 1 succeeded (ok[i]); status[i] receives each job's outcome.
+static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Status>& status) {
+    const size_t nj = jobs.size();
+    auto fail_all = [&](const Status& s) {
+        for (size_t i = 0; i < nj; i++)
+            if (status[i].ok()) status[i] = s;
+    };
+    // ---- sync 1: statistics ----
+    size_t total = 0;
+    for (size_t i = 0; i < nj; i++) {
+        jobs[i].scratch_off = total;
+        total += sizeof(ColStats) * (size_t)jobs[i].nkeycols;
+    }
+    Status s = ensure_pinned_scratch(ctx, total > 64 ? total : 64);
+    if (!s.ok()) return fail_all(s);
+    uint8_t* h = static_cast<uint8_t*>(ctx->pinned_scratch);
+    for (size_t i = 0; i < nj; i++) {
+        if (!status[i].ok()) continue;
+        hipError_t e = hipMemcpyAsync(h + jobs[i].scratch_off, jobs[i].stats_dev.get(), sizeof(ColStats) * (size_t)jobs[i].nkeycols,
+                                      hipMemcpyDeviceToHost, ctx->stream);
+        if (e != hipSuccess) status[i] = {CPH_ERR_HIP, std::string("statistics read-back: ") + hipGetErrorString(e)};
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail_all({CPH_ERR_HIP, "hipStreamSynchronize failed"});
+    // the host copies must survive phase 2 (which may reuse the scratch): take them out
+    std::vector<std::vector<uint8_t>> stats_host(nj);
+    for (size_t i = 0; i < nj; i++)
+        if (status[i].ok()) stats_host[i].assign(h + jobs[i].scratch_off, h + jobs[i].scratch_off + sizeof(ColStats) * (size_t)jobs[i].nkeycols);
+    for (size_t i = 0; i < nj; i++)
+        if (status[i].ok()) status[i] = build_phase2(ctx, &jobs[i], stats_host[i].data());
+    // ---- sync 2: first duplicates ----
+    s = ensure_pinned_scratch(ctx, sizeof(uint32_t) * nj + 64);
+    if (!s.ok()) return fail_all(s);
+    uint32_t* fd = static_cast<uint32_t*>(ctx->pinned_scratch);
+    for (size_t i = 0; i < nj; i++) {
+        if (!status[i].ok()) continue;
+        hipError_t e = hipMemcpyAsync(&fd[i], jobs[i].ix->first_dup_dev.get(), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+        if (e != hipSuccess) status[i] = {CPH_ERR_HIP, std::string("first-duplicate read-back: ") + hipGetErrorString(e)};
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail_all({CPH_ERR_HIP, "hipStreamSynchronize failed"});
+    for (size_t i = 0; i < nj; i++) {
+        if (!status[i].ok()) continue;
+        cph_index* ix = jobs[i].ix;
+        ix->first_dup = fd[i] != 0xFFFFFFFFu ? (uint64_t)fd[i] : UINT64_MAX;
+        ix->first_dup_dev.reset();
+        index_plan_table(ix);
+    }
+    // staged input copies are released with the jobs (stream-ordered reuse is safe)
+}
+
+static Status build_phase2(cph_ctx* ctx, BuildJob* job, const void* stats_host) {
+    cph_index* ix = job->ix;
+    const uint64_t n = ix->nrows;
+    const int32_t nkeycols = job->nkeycols;
+    const DevCol* dcols = job->dcols;
     std::vector<ColStats> stats;
-    CPH_TRY(codec_collect_stats(ctx, dcols, nkeycols, &stats));
+    codec_stats_finish(dcols, nkeycols, stats_host, &stats);
     CPH_TRY(codec_build(stats, &ix->codec));
     CPH_TRY(codec_try_groups(ctx, dcols, nkeycols, n, &ix->codec));   // only acts on codes of several words
     CPH_TRY(codec_upload(ctx, ix->codec, &ix->codec_dev));
@@ -268,29 +337,35 @@ static Status index_build_impl(cph_ctx* ctx, const cph_strcol* keycols, int32_t 
     ix->sort_passes = 0;
     int passes = 0;
 
-    if (cd.key32) {
-        DevBuf ka, kb;
-        CPH_TRY(ka.alloc(&ctx->pool, n * sizeof(uint32_t)));
-        CPH_TRY(kb.alloc(&ctx->pool, n * sizeof(uint32_t)));
-        CPH_TRY(codec_encode_build(ctx, cd, ix->codec_dev, dcols, n, ka.get()));
-        uint32_t* kout;
+    if (cd.nwords == 1) {
+        // single-word codes: the encode kernel leaves the first radix pass's histogram behind when it can
+        const size_t kb_ = cd.key32 ? sizeof(uint32_t) : sizeof(uint64_t);
+        DevBuf ka, kb, counts;
+        CPH_TRY(ka.alloc(&ctx->pool, n * kb_));
+        CPH_TRY(kb.alloc(&ctx->pool, n * kb_));
+        const RadixPlan plan = radix_plan(ctx, n, cd.word_bits[0]);
+        EncodeHist eh;
+        if (plan.npass > 0) {
+            CPH_TRY(counts.alloc(&ctx->pool, plan.count_words() * sizeof(uint32_t)));
+            eh.tile_rows = plan.tile;
+            eh.digit_mask = (1u << plan.nb0) - 1u;
+            eh.bins = 1u << plan.rbits;
+            eh.counts = counts.as<uint32_t>();
+        }
+        CPH_TRY(codec_encode_build(ctx, cd, ix->codec_dev, dcols, n, ka.get(), &eh));
         uint32_t* vout;
-        CPH_TRY(radix_sort_pairs<uint32_t>(ctx, ka.as<uint32_t>(), kb.as<uint32_t>(), va.as<uint32_t>(),
-                                           vb.as<uint32_t>(), true, n, cd.word_bits[0], &kout, &vout, &passes));
+        if (cd.key32) {
+            uint32_t* kout;
+            CPH_TRY(radix_sort_pairs<uint32_t>(ctx, ka.as<uint32_t>(), kb.as<uint32_t>(), va.as<uint32_t>(), vb.as<uint32_t>(),
+                                               true, n, cd.word_bits[0], &kout, &vout, &passes, eh.counts, eh.done));
+            ix->sorted_codes = std::move(kout == ka.as<uint32_t>() ? ka : kb);
+        } else {
+            uint64_t* kout;
+            CPH_TRY(radix_sort_pairs<uint64_t>(ctx, ka.as<uint64_t>(), kb.as<uint64_t>(), va.as<uint32_t>(), vb.as<uint32_t>(),
+                                               true, n, cd.word_bits[0], &kout, &vout, &passes, eh.counts, eh.done));
+            ix->sorted_codes = std::move(kout == ka.as<uint64_t>() ? ka : kb);
+        }
         ix->sort_passes = passes;
-        ix->sorted_codes = std::move(kout == ka.as<uint32_t>() ? ka : kb);
-        ix->perm = std::move(vout == va.as<uint32_t>() ? va : vb);
-    } else if (cd.nwords == 1) {
-        DevBuf ka, kb;
-        CPH_TRY(ka.alloc(&ctx->pool, n * sizeof(uint64_t)));
-        CPH_TRY(kb.alloc(&ctx->pool, n * sizeof(uint64_t)));
-        CPH_TRY(codec_encode_build(ctx, cd, ix->codec_dev, dcols, n, ka.get()));
-        uint64_t* kout;
-        uint32_t* vout;
-        CPH_TRY(radix_sort_pairs<uint64_t>(ctx, ka.as<uint64_t>(), kb.as<uint64_t>(), va.as<uint32_t>(),
-                                           vb.as<uint32_t>(), true, n, cd.word_bits[0], &kout, &vout, &passes));
-        ix->sort_passes = passes;
-        ix->sorted_codes = std::move(kout == ka.as<uint64_t>() ? ka : kb);
         ix->perm = std::move(vout == va.as<uint32_t>() ? va : vb);
     } else {
         // multi-word codes: LSD over the words, least significant word first
@@ -329,12 +404,18 @@ static Status index_build_impl(cph_ctx* ctx, const cph_strcol* keycols, int32_t 
         ix->perm = std::move(vcur == va.as<uint32_t>() ? va : vb);
     }
 
-    // adjacent-equal scan -> (device-side format choice) table build -> ONE read-back at the end
+    // adjacent-equal scan; its result is read back by build_run together with the other jobs'
     CPH_TRY(index_first_dup_launch(ctx, ix));
-    CPH_TRY(index_build_table(ctx, ix));
-    CPH_TRY(index_first_dup_read(ctx, ix));
-    // staged input copies are released here (stream-ordered reuse is safe)
     return {};
+}
+
+static Status index_build_impl(cph_ctx* ctx, const cph_strcol* keycols, int32_t nkeycols, cph_index* ix) {
+    std::vector<BuildJob> jobs(1);
+    std::vector<Status> st(1);
+    jobs[0].ix = ix;
+    st[0] = build_phase1(ctx, keycols, nkeycols, &jobs[0]);
+    if (st[0].ok()) build_run(ctx, jobs, st);
+    return st[0];
 }
 
 }  // namespace cph
@@ -386,9 +467,13 @@ CPH_API void cph_ctx_destroy(cph_ctx* ctx) {
     delete ctx;
 }
 
-CPH_API int32_t cph_ctx_set_debug(cph_ctx* ctx, int32_t chain_flags) {
-    if (!ctx) return CPH_ERR_INVALID;
-    ctx->chain_debug = chain_flags;
+CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value) {
+    if (!ctx || !name) return CPH_ERR_INVALID;
+    const std::string k(name);
+    if (k == "chain_debug") ctx->chain_debug = (int)value;
+    else if (k == "sort_threads") ctx->sort_threads = (int)value;
+    else if (k == "sort_rbits") ctx->sort_rbits = (int)value;
+    else return fail_with(ctx, {CPH_ERR_INVALID, "unknown option: " + k});
     return CPH_OK;
 }
 
@@ -503,6 +588,45 @@ CPH_API int32_t cph_index_build(cph_ctx* ctx, const cph_strcol* keycols, int32_t
                  (unsigned long long)ix->first_dup);
         return fail(ctx, {CPH_ERR_DUPLICATE, b});
     }
+    return CPH_OK;
+}
+
+CPH_API int32_t cph_index_build_many(cph_ctx* ctx, const cph_index_spec* specs, int32_t nspecs, cph_index** out,
+                                     uint64_t* first_dup_pos, int32_t* status) {
+    Status s = enter(ctx);
+    if (!s.ok()) return fail(ctx, s);
+    if (!specs || !out || nspecs < 1 || nspecs > 64) return fail(ctx, {CPH_ERR_INVALID, "bad cph_index_build_many arguments"});
+    std::vector<BuildJob> jobs((size_t)nspecs);
+    std::vector<Status> st((size_t)nspecs);
+    for (int i = 0; i < nspecs; i++) {
+        out[i] = nullptr;
+        if (first_dup_pos) first_dup_pos[i] = UINT64_MAX;
+        jobs[i].ix = new (std::nothrow) cph_index();
+        if (!jobs[i].ix) st[i] = {CPH_ERR_NOMEM, "out of host memory"};
+        else st[i] = build_phase1(ctx, specs[i].keycols, specs[i].nkeycols, &jobs[i]);
+    }
+    build_run(ctx, jobs, st);
+    int32_t rc = CPH_OK;
+    std::string msg;
+    for (int i = 0; i < nspecs; i++) {
+        cph_index* ix = jobs[i].ix;
+        if (st[i].ok() && specs[i].unique && ix->first_dup != UINT64_MAX) {
+            char b[160];
+            snprintf(b, sizeof b, "index %d: duplicate value while creating unique index (sorted position %llu)", i,
+                     (unsigned long long)ix->first_dup);
+            st[i] = {CPH_ERR_DUPLICATE, b};
+        }
+        const bool keep = st[i].ok() || st[i].code == CPH_ERR_DUPLICATE;   // like cph_index_build: the index is returned
+        if (keep) {
+            out[i] = ix;
+            if (first_dup_pos) first_dup_pos[i] = ix->first_dup;
+        } else {
+            delete ix;
+        }
+        if (status) status[i] = st[i].code;
+        if (!st[i].ok() && rc == CPH_OK) { rc = st[i].code; msg = st[i].msg; }
+    }
+    if (rc != CPH_OK) return fail(ctx, {rc, msg});
     return CPH_OK;
 }
 

@@ -59,84 +59,6 @@ struct ChainArgs {
     uint32_t* out_rows[kMaxChain];
 };
 
-// Bytes [8j, 8j+8) of a value, little-endian, with ONE load and WITHOUT any branch.  Bytes past the end of the
-// value are unspecified.  Only the aligned 8-byte words that hold at least one byte of the value are touched
-// (the rule of load_value_chunk, device_utils.hpp: no load can run into an unmapped page): a chunk that sits
-// inside one aligned word is read as that word and shifted; a chunk that straddles two words is read with one
-// UNALIGNED 8-byte load at its first byte (gfx9 global loads take any byte address), which stays inside those
-// two words; a chunk that lies entirely past the value reads the word at `base8` (the caller guarantees it is
-// readable).  Straight-line code matters here: with a branch per row every key fetch ends in its own s_waitcnt
-// and the kChainRows loads of a lane no longer overlap.
-//   base8 = a wave-uniform, 8-byte aligned pointer;  x + delta = byte offset of the VALUE from base8 (x is what a
-//   lane keeps per row: one 32-bit register when B = u32; the 64-bit address only lives until the load is issued).
-template <class B>
-__device__ __forceinline__ uint64_t load_chunk_nobranch(const uint8_t* base8, uint32_t delta, B x, uint32_t len, uint32_t j) {
-    typedef const __attribute__((address_space(1))) uint8_t* global_u8_ptr;
-    typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
-    typedef const __attribute__((address_space(1))) u64_unaligned* global_u64u_ptr;
-    const uint32_t off = 8u * j;
-    const bool has = len > off;
-    const uint32_t left = len - off;
-    const uint32_t nb = has ? (left < 8u ? left : 8u) : 1u;
-    const uint64_t a = has ? (uint64_t)x + (delta + off) : 0ull;
-    const uint32_t a7 = (uint32_t)a & 7u;
-    const bool straddles = a7 + nb > 8u;
-    const uint64_t w = *(global_u64u_ptr)((global_u8_ptr)base8 + (straddles ? a : a & ~7ull));
-    return w >> (straddles ? 0u : a7 * 8u);
-}
-
-// One LDS load + add per byte position for kChainRows rows at once (pre-multiplied LUT, codec_device.hpp); the
-// byte positions are walked with compile-time shifts.  Positions 16.. (rare) fetch their chunk on demand.
-template <class W, class B, class CW, bool LONG>
-__device__ __forceinline__ void encode_rows(const CodecView& cv, const uint8_t* base8, uint32_t delta, const B (&x)[kChainRows],
-                                            const uint32_t (&len)[kChainRows], const uint64_t (&c0)[kChainRows],
-                                            const uint64_t (&c1)[kChainRows], CW (&code)[kChainRows], uint32_t* okmask) {
-    const int maxlen = cv.hdr->col_maxlen[0];
-    const CPH_LDS W* lutw = (const CPH_LDS W*)cv.lutw;
-    W acc[kChainRows], bad[kChainRows];
-#pragma unroll
-    for (int k = 0; k < kChainRows; k++) { acc[k] = 0; bad[k] = 0; }
-    const int nchunks = (maxlen + 7) >> 3;
-#pragma unroll 1
-    for (int j = 0; j < nchunks; j++) {
-        uint64_t cur[kChainRows];
-        if (j == 0) {
-#pragma unroll
-            for (int k = 0; k < kChainRows; k++) cur[k] = c0[k];
-        } else if (LONG && j == 1) {
-#pragma unroll
-            for (int k = 0; k < kChainRows; k++) cur[k] = c1[k];
-        } else {
-#pragma unroll
-            for (int k = 0; k < kChainRows; k++) cur[k] = load_chunk_nobranch<B>(base8, delta, x[k], len[k], (uint32_t)j);
-        }
-        const int qn = maxlen - 8 * j < 8 ? maxlen - 8 * j : 8;
-        const CPH_LDS W* lp = lutw + (8 * j) * kLutStride;
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            if (b < qn) {   // uniform
-#pragma unroll
-                for (int k = 0; k < kChainRows; k++) {
-                    const uint32_t half = b < 4 ? (uint32_t)cur[k] : (uint32_t)(cur[k] >> 32);
-                    const uint32_t byte = (half >> (8 * (b & 3))) & 0xFFu;
-                    const uint32_t sym = (uint32_t)(8 * j + b) < len[k] ? byte + 1u : 0u;
-                    const W v = lp[b * kLutStride + sym];
-                    bad[k] |= v;
-                    acc[k] += v;
-                }
-            }
-        }
-    }
-    uint32_t m = *okmask;
-#pragma unroll
-    for (int k = 0; k < kChainRows; k++) {
-        code[k] = (CW)acc[k];
-        const bool good = len[k] <= (uint32_t)maxlen && !(bad[k] >> (sizeof(W) * 8 - 1));
-        if (!good) m &= ~(1u << k);
-    }
-    *okmask = m;
-}
-
 // DBG: attribution switches for tools/microbench (results are wrong when set):
 //      dbg & 1 = no table lookup, & 2 = no encode, & 4 = no output stores.  LONG: some step's
 //      index has keys longer than 8 bytes (then bytes 8..15 are prefetched too).  WIDE: 64-bit value
@@ -170,87 +92,20 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
 #pragma unroll 1
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint64_t wbase = tile * kChainTile + (uint64_t)wave * kWaveTile;   // wave-uniform
-        // rows of this lane relative to wbase, clamped to the last stream row (whole wave-tiles past the end
-        // re-read row nprobe-1 and are masked)
-        const uint64_t left = nprobe > wbase ? nprobe - wbase : 0;
-        const uint32_t nvalid = left > (uint64_t)kWaveTile ? (uint32_t)kWaveTile : (uint32_t)left;   // uniform
-        const uint64_t rbase = nvalid ? wbase : nprobe - 1;   // first row this wave reads
-        const uint32_t rmax = nvalid ? nvalid - 1 : 0;
-        uint32_t okm = 0;                       // bit k: row k of this lane is (still) joined
-        uint32_t rel[kChainRows];
-#pragma unroll
-        for (int k = 0; k < kChainRows; k++) {
-            const uint32_t r = (uint32_t)(k * kWave + lane);
-            okm |= (r < nvalid ? 1u : 0u) << k;
-            rel[k] = r < rmax ? r : rmax;
-        }
+        const WaveRows<kChainRows> wr = wave_rows<kChainRows>(wbase, nprobe);
+        uint32_t okm = wr.okm;                  // bit k: row k of this lane is (still) joined
         // ---- A: value spans ----------------------------------------------------------------------
-        const uint8_t* base8[S];                // uniform, 8-byte aligned
-        uint32_t delta[S];                      // uniform, 0..7
-        B x[S][kChainRows];                     // value start as a byte offset from base8[s] + delta[s]
-        uint32_t len[S][kChainRows];
+        WaveSpans<kChainRows, B> sp[S];
 #pragma unroll
-        for (int s = 0; s < S; s++) {
-            const DevCol& c = a.step[s].col;
-            if (c.fixed_width) {
-                const uint64_t p = (uint64_t)(uintptr_t)c.data + rbase * (uint64_t)c.fixed_width;
-                base8[s] = (const uint8_t*)(uintptr_t)(p & ~7ull);
-                delta[s] = (uint32_t)(p & 7ull);
-#pragma unroll
-                for (int k = 0; k < kChainRows; k++) {
-                    x[s][k] = (B)rel[k] * c.fixed_width;   // < kWaveTile * 2^32 / ... : fixed widths are validated < 2^16
-                    len[s][k] = c.fixed_width;
-                }
-            } else if (c.offset_bits == 32) {
-                const uint64_t p = (uint64_t)(uintptr_t)c.data;
-                base8[s] = (const uint8_t*)(uintptr_t)(p & ~7ull);
-                delta[s] = (uint32_t)(p & 7ull);
-                const uint32_t* off = reinterpret_cast<const uint32_t*>(c.offsets) + rbase;
-                uint32_t b[kChainRows], e[kChainRows];
-#pragma unroll
-                for (int k = 0; k < kChainRows; k++) {
-                    b[k] = off[rel[k]];
-                    e[k] = off[rel[k] + 1];
-                }
-#pragma unroll
-                for (int k = 0; k < kChainRows; k++) {
-                    x[s][k] = b[k];
-                    len[s][k] = e[k] - b[k];
-                }
-            } else {
-                if constexpr (WIDE) {
-                    const uint64_t p = (uint64_t)(uintptr_t)c.data;
-                    base8[s] = (const uint8_t*)(uintptr_t)(p & ~7ull);
-                    delta[s] = (uint32_t)(p & 7ull);
-                    const uint64_t* off = reinterpret_cast<const uint64_t*>(c.offsets) + rbase;
-                    uint64_t b[kChainRows], e[kChainRows];
-#pragma unroll
-                    for (int k = 0; k < kChainRows; k++) {
-                        b[k] = off[rel[k]];
-                        e[k] = off[rel[k] + 1];
-                    }
-#pragma unroll
-                    for (int k = 0; k < kChainRows; k++) {
-                        x[s][k] = b[k];
-                        const uint64_t l = e[k] - b[k];
-                        len[s][k] = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;
-                    }
-                } else {   // not reachable: the host picks WIDE for 64-bit offsets
-                    base8[s] = a.step[s].codec;
-                    delta[s] = 0;
-#pragma unroll
-                    for (int k = 0; k < kChainRows; k++) { x[s][k] = 0; len[s][k] = 0; }
-                }
-            }
-        }
+        for (int s = 0; s < S; s++) wave_spans<kChainRows, B>(a.step[s].col, wr, &sp[s]);
         // ---- B: first 8 (16) key bytes ---------------------------------------------------------------
         uint64_t c0[S][kChainRows], c1[LONG ? S : 1][kChainRows];
 #pragma unroll
         for (int s = 0; s < S; s++) {
 #pragma unroll
             for (int k = 0; k < kChainRows; k++) {
-                c0[s][k] = load_chunk_nobranch<B>(base8[s], delta[s], x[s][k], len[s][k], 0);
-                if constexpr (LONG) c1[s][k] = load_chunk_nobranch<B>(base8[s], delta[s], x[s][k], len[s][k], 1);
+                c0[s][k] = sp[s].chunk(k, 0);
+                if constexpr (LONG) c1[s][k] = sp[s].chunk(k, 1);
             }
         }
         // ---- C: codes -----------------------------------------------------------------------------------
@@ -261,9 +116,9 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
 #pragma unroll
                 for (int k = 0; k < kChainRows; k++) code[s][k] = (CW)((c0[s][k] ^ (LONG ? c1[LONG ? s : 0][k] : 0ull)) & 1023);
             } else if (!WIDE || cv[s].hdr->lutw_bits == 32) {
-                encode_rows<uint32_t, B, CW, LONG>(cv[s], base8[s], delta[s], x[s], len[s], c0[s], c1[LONG ? s : 0], code[s], &okm);
+                encode_rows<kChainRows, uint32_t, B, CW, LONG>(cv[s], sp[s], c0[s], c1[LONG ? s : 0], code[s], &okm);
             } else {
-                encode_rows<uint64_t, B, CW, LONG>(cv[s], base8[s], delta[s], x[s], len[s], c0[s], c1[LONG ? s : 0], code[s], &okm);
+                encode_rows<kChainRows, uint64_t, B, CW, LONG>(cv[s], sp[s], c0[s], c1[LONG ? s : 0], code[s], &okm);
             }
         }
         // ---- D: lookups ---------------------------------------------------------------------------------
@@ -314,7 +169,7 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
             // the stream row of slot r is probe_base + r by construction: it is never stored here
             if (ok && !(DBG && (dbg & 4))) {
 #pragma unroll
-                for (int s = 0; s < S; s++) (a.out_rows[s] + wbase)[rel[k]] = brow[s][k];
+                for (int s = 0; s < S; s++) (a.out_rows[s] + wr.rbase)[wr.rel[k]] = brow[s][k];
             }
         }
         // per-(tile, wave) match count
@@ -407,7 +262,8 @@ static Status enqueue_dense(cph_ctx* ctx, const ChainStep* steps, uint64_t nprob
         st.col = steps[s].cols[0];
         st.codec = ix->codec_dev.as<uint8_t>();
         st.codec_bytes = (int32_t)ix->codec_dev.bytes();
-        st.rowtab = ix->table_entries ? ix->rowtab.as<uint32_t>() : nullptr;
+        CPH_TRY(index_ensure_rowtab(ctx, ix));   // no-op once built (on the index's own ctx: see stream_join.hip)
+        st.rowtab = ix->rowtab ? ix->rowtab.as<uint32_t>() : nullptr;
         st.codes = ix->sorted_codes.get();
         st.perm = ix->perm.as<uint32_t>();
         st.n_index = ix->nrows;
@@ -425,8 +281,7 @@ static Status enqueue_dense(cph_ctx* ctx, const ChainStep* steps, uint64_t nprob
         // 32-bit registers for value offsets and codes need: 32-bit offsets (addresses are formed in 64 bits at the
         // load), a 32-bit pre-multiplied LUT, a code that fits 32 bits
         wide |= codec_premultiplied_bits(ix->codec) != 32 || !ix->codec.key32;
-        if (!c.fixed_width) wide |= c.offset_bits != 32;
-        else wide |= c.fixed_width > 0xFFFFu;
+        wide |= !col_is_narrow(c);
     }
     using KernelFn = void (*)(ChainArgs, uint64_t, uint64_t, uint64_t, uint64_t*, uint32_t*, int);
     static const KernelFn variants[2][2][2] = {

@@ -121,6 +121,152 @@ __device__ __forceinline__ bool encode_prefetched_w(const CodecView& cv, const D
     return len <= (uint32_t)maxlen && !(bad >> (sizeof(W) * 8 - 1));
 }
 
+// ---- wave-tile access pattern of the row-parallel kernels (chain, build encode, statistics) ---------------------
+// A wave owns R * 64 consecutive rows: row(k, lane) = wbase + 64 k + lane, so every memory instruction of a phase
+// covers 64 neighbouring rows.  Everything is straight-line code: rows past the end are CLAMPED to the last existing
+// row (their results are masked by `okm`) instead of being branched around, so that the R loads a lane issues in a
+// phase are in flight together — a divergent branch per row puts an s_waitcnt between them.
+template <int R>
+struct WaveRows {
+    uint64_t rbase;      // first row this wave reads (wave-uniform)
+    uint32_t nvalid;     // rows of the wave-tile that exist (wave-uniform)
+    uint32_t rel[R];     // row k of this lane = rbase + rel[k]
+    uint32_t okm;        // bit k: row k exists
+};
+template <int R>
+__device__ __forceinline__ WaveRows<R> wave_rows(uint64_t wbase, uint64_t nrows /* >= 1 */) {
+    WaveRows<R> w;
+    const uint64_t left = nrows > wbase ? nrows - wbase : 0;
+    w.nvalid = left > (uint64_t)(R * kWave) ? (uint32_t)(R * kWave) : (uint32_t)left;
+    w.rbase = w.nvalid ? wbase : nrows - 1;
+    const uint32_t rmax = w.nvalid ? w.nvalid - 1 : 0;
+    w.okm = 0;
+    const uint32_t lane = (uint32_t)lane_id();
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        const uint32_t r = (uint32_t)k * kWave + lane;
+        w.okm |= (r < w.nvalid ? 1u : 0u) << k;
+        w.rel[k] = r < rmax ? r : rmax;
+    }
+    return w;
+}
+
+// Value spans of a wave's rows in one column.  B = uint32_t keeps one register per row (needs 32-bit offsets or a
+// fixed-width column); B = uint64_t handles every column.  The value of row k starts base8 + delta + x[k].
+template <int R, class B>
+struct WaveSpans {
+    const uint8_t* base8;   // wave-uniform, 8-byte aligned
+    uint32_t delta;         // wave-uniform, 0..7
+    B x[R];
+    uint32_t len[R];        // clamped to 2^32-1
+    __device__ __forceinline__ uint64_t chunk(int k, uint32_t j) const {   // bytes [8j, 8j+8) of row k's value
+        return load_chunk_nobranch<B>(base8, delta, x[k], len[k], j);
+    }
+};
+template <int R, class B>
+__device__ __forceinline__ void wave_spans(const DevCol& c, const WaveRows<R>& wr, WaveSpans<R, B>* sp) {
+    if (c.fixed_width) {
+        const uint64_t p = (uint64_t)(uintptr_t)c.data + wr.rbase * (uint64_t)c.fixed_width;
+        sp->base8 = (const uint8_t*)(uintptr_t)(p & ~7ull);
+        sp->delta = (uint32_t)(p & 7ull);
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            sp->x[k] = (B)wr.rel[k] * c.fixed_width;
+            sp->len[k] = c.fixed_width;
+        }
+        return;
+    }
+    const uint64_t p = (uint64_t)(uintptr_t)c.data;
+    sp->base8 = (const uint8_t*)(uintptr_t)(p & ~7ull);
+    sp->delta = (uint32_t)(p & 7ull);
+    if (c.offset_bits == 32) {
+        const uint32_t* off = reinterpret_cast<const uint32_t*>(c.offsets) + wr.rbase;
+        uint32_t b[R], e[R];
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            b[k] = off[wr.rel[k]];
+            e[k] = off[wr.rel[k] + 1];
+        }
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            sp->x[k] = b[k];
+            sp->len[k] = e[k] - b[k];
+        }
+    } else if constexpr (sizeof(B) == 8) {
+        const uint64_t* off = reinterpret_cast<const uint64_t*>(c.offsets) + wr.rbase;
+        uint64_t b[R], e[R];
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            b[k] = off[wr.rel[k]];
+            e[k] = off[wr.rel[k] + 1];
+        }
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            sp->x[k] = b[k];
+            const uint64_t l = e[k] - b[k];
+            sp->len[k] = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;
+        }
+    } else {   // not reachable: the host picks B = uint64_t for 64-bit offsets
+#pragma unroll
+        for (int k = 0; k < R; k++) { sp->x[k] = 0; sp->len[k] = 0; }
+    }
+}
+// true when a column can be walked with B = uint32_t
+inline bool col_is_narrow(const DevCol& c) { return c.fixed_width ? c.fixed_width <= 0xFFFFu : c.offset_bits == 32; }
+
+// Single-column, single-word encode of a wave's rows: one LDS load + add per byte position (pre-multiplied LUT),
+// the positions walked with compile-time shifts, R rows per position so that the LDS loads overlap.  c0 / c1 = the
+// prefetched bytes 0..7 / 8..15 of every row (c1 only read when LONG); later chunks are fetched on demand.  Clears
+// the okm bit of a row whose key cannot occur in the index (symbol outside the alphabet, value too long).
+template <int R, class W, class B, class CW, bool LONG>
+__device__ __forceinline__ void encode_rows(const CodecView& cv, const WaveSpans<R, B>& sp, const uint64_t (&c0)[R],
+                                            const uint64_t (&c1)[R], CW (&code)[R], uint32_t* okmask) {
+    const int maxlen = cv.hdr->col_maxlen[0];
+    const CPH_LDS W* lutw = (const CPH_LDS W*)cv.lutw;
+    W acc[R], bad[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) { acc[k] = 0; bad[k] = 0; }
+    const int nchunks = (maxlen + 7) >> 3;
+#pragma unroll 1
+    for (int j = 0; j < nchunks; j++) {
+        uint64_t cur[R];
+        if (j == 0) {
+#pragma unroll
+            for (int k = 0; k < R; k++) cur[k] = c0[k];
+        } else if (LONG && j == 1) {
+#pragma unroll
+            for (int k = 0; k < R; k++) cur[k] = c1[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < R; k++) cur[k] = sp.chunk(k, (uint32_t)j);
+        }
+        const int qn = maxlen - 8 * j < 8 ? maxlen - 8 * j : 8;
+        const CPH_LDS W* lp = lutw + (8 * j) * kLutStride;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            if (b < qn) {   // uniform
+#pragma unroll
+                for (int k = 0; k < R; k++) {
+                    const uint32_t half = b < 4 ? (uint32_t)cur[k] : (uint32_t)(cur[k] >> 32);
+                    const uint32_t byte = (half >> (8 * (b & 3))) & 0xFFu;
+                    const uint32_t sym = (uint32_t)(8 * j + b) < sp.len[k] ? byte + 1u : 0u;
+                    const W v = lp[b * kLutStride + sym];
+                    bad[k] |= v;
+                    acc[k] += v;
+                }
+            }
+        }
+    }
+    uint32_t m = *okmask;
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        code[k] = (CW)acc[k];
+        const bool good = sp.len[k] <= (uint32_t)maxlen && !(bad[k] >> (sizeof(W) * 8 - 1));
+        if (!good) m &= ~(1u << k);
+    }
+    *okmask = m;
+}
+
 // The first 24 bytes of a value, fetched with three independent loads right after its span (two dependent
 // memory round trips per value instead of one per 8-byte chunk).  LONGV = false: the caller guarantees that no
 // offset beyond 23 is asked for (all key columns are at most 24 bytes long), and chunk selection is branch-free;

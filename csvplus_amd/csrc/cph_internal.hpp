@@ -208,7 +208,8 @@ struct cph_ctx {
     std::vector<void*> pinned_user;
     // per-ctx launch state (a process may hold one ctx per device: nothing of this may be static)
     int cus = 0;                   // compute units of `device` (0: not queried yet)
-    int chain_debug = 0;           // attribution switches of the chained-join kernel (cph_ctx_set_debug)
+    int chain_debug = 0;           // attribution switches of the chained-join kernel (cph_ctx_set_option)
+    int sort_threads = 0, sort_rbits = 0;   // radix-sort tuning overrides (0: automatic)
     struct KernelCfg { const void* fn; size_t lds; int blocks_per_cu; };
     std::vector<KernelCfg> kernel_cfg;   // kernels whose dynamic-LDS attribute / occupancy were set up on this device
     // profiling
@@ -226,10 +227,11 @@ struct cph_index {
     cph::DevBuf codec_dev;         // CodecDevHeader block
     cph::DevBuf sorted_codes;      // key32: u32[n]; else u64[nwords][n] word-major
     cph::DevBuf perm;              // u32[n]
-    cph::DevBuf table;             // direct-address table {lo,end} u32x2 [table_entries] (optional)
+    // direct-address tables over the code space, built by the first Join that can use them (probe.hip)
+    cph::DevBuf table;             // {lo,row} / {lo,end} u32x2 [table_entries]: generic probe
     cph::DevBuf rowtab;            // duplicate-free index: u32[table_entries], code -> build row (0xFFFFFFFF: absent);
                                    // 4-byte entries for the chained-join kernel (half the random-access footprint)
-    uint64_t table_entries = 0;
+    uint64_t table_entries = 0;    // != 0: the code space is dense enough for a table (decided at build time)
     int32_t sort_passes = 0;
     uint64_t first_dup = UINT64_MAX;
     uint32_t* perm_host = nullptr; // pinned copy (lazy)
@@ -269,6 +271,9 @@ struct ColStats {              // per column, produced by one pass over the colu
     uint32_t mask[kMaxKeyBytes][8];   // presence bitmap of byte values per position
 };
 Status codec_collect_stats(cph_ctx* ctx, const DevCol* cols, int32_t ncols, std::vector<ColStats>* out);
+// the same in two halves, so that several indexes share one stream synchronisation (cph_index_build_many)
+Status codec_stats_launch(cph_ctx* ctx, const DevCol* cols, int32_t ncols, DevBuf* dev_stats);
+void codec_stats_finish(const DevCol* cols, int32_t ncols, const void* host_copy, std::vector<ColStats>* out);
 Status codec_build(const std::vector<ColStats>& stats, CodecHost* codec);   // host only
 // When the per-position code needs several words: one more pass over the key columns collects the distinct
 // joint symbols of every 7-position group; groups with few of them are dictionary-coded (codec rebuilt in place).
@@ -276,8 +281,17 @@ Status codec_try_groups(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_
 Status codec_upload(cph_ctx* ctx, const CodecHost& codec, DevBuf* dev);
 int codec_premultiplied_bits(const CodecHost& codec);   // 0 / 32 / 64
 // Encodes the build-side keys.  key32: out32[n]; else out64[nwords][n].
+// hist (optional): the sort's first-pass histogram request; `done` tells the caller whether the encode kernel
+// produced it (only the single-column fast path does).
+struct EncodeHist {
+    uint32_t tile_rows = 0;       // keys per sort tile
+    uint32_t digit_mask = 0;      // (1 << bits of the first digit) - 1
+    uint32_t bins = 0;            // digits per pass of the sort (256 or 512 >= digit_mask + 1)
+    uint32_t* counts = nullptr;   // device [bins][ntiles], digit-major
+    bool done = false;
+};
 Status codec_encode_build(cph_ctx* ctx, const CodecHost& codec, const DevBuf& codec_dev, const DevCol* cols,
-                          uint64_t n, void* out_codes);
+                          uint64_t n, void* out_codes, const EncodeHist* hist = nullptr);
 // Host-side encoding of literal values (cph_index_find).  Returns false when a
 // value cannot occur in the index (symbol outside the alphabet / too long).
 bool codec_encode_values_host(const CodecHost& codec, const cph_strval* values, int32_t nvalues,
@@ -287,9 +301,19 @@ bool codec_encode_values_host(const CodecHost& codec, const cph_strval* values, 
 // Stable LSD radix sort of (key,val) pairs over key bits [0,bits).  keys_in may be
 // clobbered.  vals_in == nullptr means vals = 0..n-1.  On return *keys_out/*vals_out
 // point at whichever of the two buffer pairs holds the result.
+struct RadixPlan {
+    int npass = 0, threads = 256, rbits = 8;
+    uint32_t tile = 4096, ntiles = 0;
+    int nb0 = 0;                  // bits of the first (least significant) digit
+    size_t count_words() const { return ((size_t)1 << rbits) * ntiles; }
+};
+RadixPlan radix_plan(const cph_ctx* ctx, uint64_t n, int bits);
+// counts (optional): a device buffer of plan.count_words() u32 the caller allocated; first_hist_done = it already
+// holds the first pass's per-tile digit histogram (codec_encode_build produced it).
 template <class K>
 Status radix_sort_pairs(cph_ctx* ctx, K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b, bool vals_iota,
-                        uint64_t n, int bits, K** keys_out, uint32_t** vals_out, int* passes);
+                        uint64_t n, int bits, K** keys_out, uint32_t** vals_out, int* passes,
+                        uint32_t* counts = nullptr, bool first_hist_done = false);
 Status exclusive_scan_u32(cph_ctx* ctx, uint32_t* data, uint64_t n);
 Status exclusive_scan_u32_total(cph_ctx* ctx, uint32_t* data, uint64_t n, uint32_t* total_out);   // total_out: device
 Status exclusive_scan_u64(cph_ctx* ctx, uint64_t* data, uint64_t n, uint64_t* total_out);
@@ -299,7 +323,9 @@ Status fill_iota_u32(cph_ctx* ctx, uint32_t* dst, uint64_t n);
 // probe.hip
 Status index_first_dup_launch(cph_ctx* ctx, cph_index* ix);
 Status index_first_dup_read(cph_ctx* ctx, cph_index* ix);
-Status index_build_table(cph_ctx* ctx, cph_index* ix);
+void index_plan_table(cph_index* ix);                               // host decision only (table_entries)
+Status index_ensure_table(cph_ctx* ctx, const cph_index* ix);       // 8-byte entries, built on first use
+Status index_ensure_rowtab(cph_ctx* ctx, const cph_index* ix);      // 4-byte build rows (duplicate-free indexes)
 struct ProbeOut {
     DevBuf lo, cnt, pidx, brow;
     uint64_t nprobe = 0, nmatches = 0;

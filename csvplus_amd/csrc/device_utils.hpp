@@ -96,6 +96,32 @@ __device__ __forceinline__ uint64_t load_value_chunk(const uint8_t* data, uint64
     return v;
 }
 
+// Bytes [8j, 8j+8) of a value, little-endian, with ONE load and WITHOUT any branch.  Bytes past the end of the
+// value are unspecified.  Only the aligned 8-byte words that hold at least one byte of the value are touched
+// (the rule of load_value_chunk above: no load can run into an unmapped page): a chunk that sits
+// inside one aligned word is read as that word and shifted; a chunk that straddles two words is read with one
+// UNALIGNED 8-byte load at its first byte (gfx9 global loads take any byte address), which stays inside those
+// two words; a chunk that lies entirely past the value reads the word at `base8` (the caller guarantees it is
+// readable).  Straight-line code matters here: with a branch per row every key fetch ends in its own s_waitcnt
+// and the loads a lane issues for its rows no longer overlap.
+//   base8 = a wave-uniform, 8-byte aligned pointer;  x + delta = byte offset of the VALUE from base8 (x is what a
+//   lane keeps per row: one 32-bit register when B = u32; the 64-bit address only lives until the load is issued).
+template <class B>
+__device__ __forceinline__ uint64_t load_chunk_nobranch(const uint8_t* base8, uint32_t delta, B x, uint32_t len, uint32_t j) {
+    typedef const __attribute__((address_space(1))) uint8_t* global_u8_ptr;
+    typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+    typedef const __attribute__((address_space(1))) u64_unaligned* global_u64u_ptr;
+    const uint32_t off = 8u * j;
+    const bool has = len > off;
+    const uint32_t left = len - off;
+    const uint32_t nb = has ? (left < 8u ? left : 8u) : 1u;
+    const uint64_t a = has ? (uint64_t)x + (delta + off) : 0ull;
+    const uint32_t a7 = (uint32_t)a & 7u;
+    const bool straddles = a7 + nb > 8u;
+    const uint64_t w = *(global_u64u_ptr)((global_u8_ptr)base8 + (straddles ? a : a & ~7ull));
+    return w >> (straddles ? 0u : a7 * 8u);
+}
+
 __device__ __forceinline__ uint64_t load_offset(const void* offsets, int offset_bits, uint64_t i) {
     return offset_bits == 32 ? (uint64_t) reinterpret_cast<const uint32_t*>(offsets)[i]
                              : reinterpret_cast<const uint64_t*>(offsets)[i];

@@ -62,12 +62,12 @@ __global__ void k_select_check(const uint64_t* __restrict__ pos, uint64_t n, uin
         if (pos[i] >= nrows || (i > 0 && pos[i - 1] >= pos[i])) atomicExch(bad, 1u);
 }
 
-// Finishes an index whose codec / sorted_codes / perm are in place: unique scan + table.
+// Finishes an index whose codec / sorted_codes / perm are in place: unique scan + table decision.
 static Status finish_index(cph_ctx* ctx, cph_index* ix) {
     CPH_TRY(codec_upload(ctx, ix->codec, &ix->codec_dev));
     CPH_TRY(index_first_dup_launch(ctx, ix));
-    CPH_TRY(index_build_table(ctx, ix));
     CPH_TRY(index_first_dup_read(ctx, ix));
+    index_plan_table(ix);
     return {};
 }
 

@@ -32,8 +32,10 @@ namespace cph {
 // presence bitmap of the byte values seen there.
 // ---------------------------------------------------------------------------------------------
 constexpr int kStatsThreads = 256;
-constexpr int kStatsRows = 4;
+constexpr int kStatsRows = 8;     // rows per lane and wave-tile (codec_device.hpp: wave_rows / wave_spans)
 
+// B = uint32_t: 32-bit offsets or fixed width (one register per row); uint64_t: any column.
+template <class B>
 __global__ __launch_bounds__(kStatsThreads) void k_col_stats(DevCol col, uint32_t* __restrict__ g_minmax,
                                                             uint32_t* __restrict__ g_mask) {
     __shared__ uint32_t s_mask[kMaxKeyBytes * 8];
@@ -43,35 +45,42 @@ __global__ __launch_bounds__(kStatsThreads) void k_col_stats(DevCol col, uint32_
     __syncthreads();
 
     uint32_t mn = 0xFFFFFFFFu, mx = 0;
-    // kStatsRows rows per thread and iteration: spans first, then the first 8 bytes of every row,
-    // so that the loads overlap (one row at a time left this kernel latency-bound)
-    const uint64_t stride = (uint64_t)gridDim.x * kStatsThreads * kStatsRows;
-    for (uint64_t base = (uint64_t)blockIdx.x * kStatsThreads * kStatsRows; base < col.nrows; base += stride) {
-        uint64_t begin[kStatsRows], len64[kStatsRows], c0[kStatsRows];
+    constexpr uint64_t kTile = (uint64_t)kStatsRows * kWave;
+    const uint64_t nwt = (col.nrows + kTile - 1) / kTile;
+    const uint64_t wstride = (uint64_t)gridDim.x * (kStatsThreads / kWave);
+    for (uint64_t wt = (uint64_t)blockIdx.x * (kStatsThreads / kWave) + wave_id(); wt < nwt; wt += wstride) {
+        const WaveRows<kStatsRows> wr = wave_rows<kStatsRows>(wt * kTile, col.nrows);
+        WaveSpans<kStatsRows, B> sp;
+        wave_spans<kStatsRows, B>(col, wr, &sp);
+        uint64_t cur[kStatsRows];
 #pragma unroll
-        for (int k = 0; k < kStatsRows; k++) {
-            const uint64_t row = base + (uint64_t)k * kStatsThreads + threadIdx.x;
-            begin[k] = 0;
-            len64[k] = 0;
-            if (row < col.nrows) value_span(col, row, &begin[k], &len64[k]);
+        for (int k = 0; k < kStatsRows; k++) cur[k] = sp.chunk(k, 0);
+        uint32_t lmax = 0;
+#pragma unroll
+        for (int k = 0; k < kStatsRows; k++) {   // clamped rows repeat an existing row: harmless for statistics
+            mn = sp.len[k] < mn ? sp.len[k] : mn;
+            lmax = sp.len[k] > lmax ? sp.len[k] : lmax;
         }
+        mx = lmax > mx ? lmax : mx;
+        lmax = wave_max(lmax);
+        const int lim = lmax < (uint32_t)kMaxKeyBytes ? (int)lmax : kMaxKeyBytes;   // wave-uniform
+        for (int j = 0; 8 * j < lim; j++) {
+            if (j) {
 #pragma unroll
-        for (int k = 0; k < kStatsRows; k++) c0[k] = len64[k] ? load_value_chunk(col.data, begin[k], len64[k], 0) : 0;
+                for (int k = 0; k < kStatsRows; k++) cur[k] = sp.chunk(k, (uint32_t)j);
+            }
 #pragma unroll
-        for (int k = 0; k < kStatsRows; k++) {
-            const uint64_t row = base + (uint64_t)k * kStatsThreads + threadIdx.x;
-            if (row >= col.nrows) continue;
-            const uint32_t len = len64[k] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)len64[k];
-            mn = len < mn ? len : mn;
-            mx = len > mx ? len : mx;
-            const int lim = len < (uint32_t)kMaxKeyBytes ? (int)len : kMaxKeyBytes;
-            uint64_t chunk = c0[k];
-            for (int q = 0; q < lim; q++) {
-                if ((q & 7) == 0 && q) chunk = load_value_chunk(col.data, begin[k], len64[k], q >> 3);
-                const uint32_t b = (uint32_t)((chunk >> (8 * (q & 7))) & 0xFF);
-                const int idx = q * 8 + (int)(b >> 5);
-                const uint32_t bit = 1u << (b & 31);
-                if (!(s_mask[idx] & bit)) atomicOr(&s_mask[idx], bit);
+            for (int b = 0; b < 8; b++) {
+                const int q = 8 * j + b;
+                if (q >= lim) break;   // uniform
+#pragma unroll
+                for (int k = 0; k < kStatsRows; k++) {
+                    const uint32_t half = b < 4 ? (uint32_t)cur[k] : (uint32_t)(cur[k] >> 32);
+                    const uint32_t byte = (half >> (8 * (b & 3))) & 0xFFu;
+                    const int idx = q * 8 + (int)(byte >> 5);
+                    const uint32_t bit = 1u << (byte & 31);
+                    if ((uint32_t)q < sp.len[k] && !(s_mask[idx] & bit)) atomicOr(&s_mask[idx], bit);
+                }
             }
         }
     }
@@ -84,31 +93,49 @@ __global__ __launch_bounds__(kStatsThreads) void k_col_stats(DevCol col, uint32_
     if (threadIdx.x == 0) { atomicMin(&g_minmax[0], s_min); atomicMax(&g_minmax[1], s_max); }
 }
 
-Status codec_collect_stats(cph_ctx* ctx, const DevCol* cols, int32_t ncols, std::vector<ColStats>* out) {
-    out->assign((size_t)ncols, ColStats{});
+// Enqueues the statistics pass of every column; the results stay on the device (block d: ColStats per column).
+Status codec_stats_launch(cph_ctx* ctx, const DevCol* cols, int32_t ncols, DevBuf* d) {
     const size_t per = sizeof(ColStats);
-    DevBuf d;
-    CPH_TRY(d.alloc(&ctx->pool, per * (size_t)ncols));
-    CPH_TRY(ensure_pinned_scratch(ctx, per * (size_t)ncols));
+    CPH_TRY(d->alloc(&ctx->pool, per * (size_t)ncols));
     // init: minlen = 0xFFFFFFFF, everything else 0
-    CPH_HIP_TRY(hipMemsetAsync(d.get(), 0, per * (size_t)ncols, ctx->stream));
+    CPH_HIP_TRY(hipMemsetAsync(d->get(), 0, per * (size_t)ncols, ctx->stream));
     for (int c = 0; c < ncols; c++)
-        CPH_HIP_TRY(hipMemsetAsync(d.as<uint8_t>() + per * (size_t)c, 0xFF, sizeof(uint32_t), ctx->stream));
+        CPH_HIP_TRY(hipMemsetAsync(d->as<uint8_t>() + per * (size_t)c, 0xFF, sizeof(uint32_t), ctx->stream));
+    int cus = 256;
+    CPH_TRY(device_cus(ctx, &cus));
     for (int c = 0; c < ncols; c++) {
         if (cols[c].nrows == 0) continue;
-        uint64_t nblk = (cols[c].nrows + kStatsThreads * kStatsRows - 1) / (kStatsThreads * kStatsRows);
-        if (nblk > 2048) nblk = 2048;
-        uint32_t* base = reinterpret_cast<uint32_t*>(d.as<uint8_t>() + per * (size_t)c);
+        const uint64_t rows_per_block = (uint64_t)kStatsThreads * kStatsRows;
+        uint64_t nblk = (cols[c].nrows + rows_per_block - 1) / rows_per_block;
+        if (nblk > (uint64_t)cus * 8) nblk = (uint64_t)cus * 8;
+        uint32_t* base = reinterpret_cast<uint32_t*>(d->as<uint8_t>() + per * (size_t)c);
         ProfScope ps(ctx, "k_col_stats", 0);   // bytes: value bytes + offsets, added by the caller's model
-        hipLaunchKernelGGL(k_col_stats, dim3((unsigned)nblk), dim3(kStatsThreads), 0, ctx->stream, cols[c], base,
-                           base + 2);
+        if (col_is_narrow(cols[c]))
+            hipLaunchKernelGGL(k_col_stats<uint32_t>, dim3((unsigned)nblk), dim3(kStatsThreads), 0, ctx->stream, cols[c],
+                               base, base + 2);
+        else
+            hipLaunchKernelGGL(k_col_stats<uint64_t>, dim3((unsigned)nblk), dim3(kStatsThreads), 0, ctx->stream, cols[c],
+                               base, base + 2);
         CPH_HIP_TRY(hipGetLastError());
     }
-    CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, d.get(), per * (size_t)ncols, hipMemcpyDeviceToHost, ctx->stream));
-    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    memcpy(out->data(), ctx->pinned_scratch, per * (size_t)ncols);
+    return {};
+}
+// After the stream has been synchronised on a copy of `d` into `host` (ncols * sizeof(ColStats) bytes).
+void codec_stats_finish(const DevCol* cols, int32_t ncols, const void* host, std::vector<ColStats>* out) {
+    out->assign((size_t)ncols, ColStats{});
+    memcpy(out->data(), host, sizeof(ColStats) * (size_t)ncols);
     for (int c = 0; c < ncols; c++)
         if (cols[c].nrows == 0) { (*out)[c].minlen = 0; (*out)[c].maxlen = 0; }
+}
+
+Status codec_collect_stats(cph_ctx* ctx, const DevCol* cols, int32_t ncols, std::vector<ColStats>* out) {
+    const size_t bytes = sizeof(ColStats) * (size_t)ncols;
+    DevBuf d;
+    CPH_TRY(codec_stats_launch(ctx, cols, ncols, &d));
+    CPH_TRY(ensure_pinned_scratch(ctx, bytes));
+    CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, d.get(), bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    codec_stats_finish(cols, ncols, ctx->pinned_scratch, out);
     return {};
 }
 
@@ -603,37 +630,55 @@ __global__ __launch_bounds__(kEncodeThreads) void k_encode_build(ColsArg cols, c
     }
 }
 
-// Fast path: one key column, single-word code, pre-multiplied LUT.  kEncodeRows rows per thread
-// and iteration with the loads grouped (spans, then key bytes), like the probe side.
-constexpr int kEncodeRows = 4;
+// Fast path: one key column, single-word code, pre-multiplied LUT.  Wave-tile access pattern (codec_device.hpp);
+// a workgroup walks whole SORT tiles (tile_rows = the radix sort's keys per tile) and, when `counts` is given,
+// leaves the first radix pass's per-tile digit histogram behind — the sort then skips its own histogram pass
+// over the codes (radix_sort.hip: counts[digit * ntiles + tile]).
+constexpr int kEncodeRows = 4;       // the dictionary-group kernel below
+constexpr int kEncodeFastRows = 8;   // rows per lane and wave-tile
 
-template <class W, class OUT>
+template <class W, class OUT, class B, bool LONG>
 __global__ __launch_bounds__(kEncodeThreads) void k_encode_build_fast(DevCol col, const uint8_t* __restrict__ g_codec,
-                                                                     uint64_t n, OUT* __restrict__ out) {
+                                                                     uint64_t n, OUT* __restrict__ out, uint32_t tile_rows,
+                                                                     uint32_t ntiles, uint32_t* __restrict__ counts,
+                                                                     uint32_t digit_mask, uint32_t bins, int codec_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const CodecView cv = codec_load_to_lds(g_codec, smem);
-    const bool long_keys = cv.hdr->col_maxlen[0] > 8;
-    const uint64_t stride = (uint64_t)gridDim.x * kEncodeThreads * kEncodeRows;
-    for (uint64_t base = (uint64_t)blockIdx.x * kEncodeThreads * kEncodeRows; base < n; base += stride) {
-        uint64_t begin[kEncodeRows], len64[kEncodeRows], c0[kEncodeRows], c1[kEncodeRows];
-#pragma unroll
-        for (int k = 0; k < kEncodeRows; k++) {
-            const uint64_t row = base + (uint64_t)k * kEncodeThreads + threadIdx.x;
-            begin[k] = 0;
-            len64[k] = 0;
-            if (row < n) value_span(col, row, &begin[k], &len64[k]);
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + codec_bytes);   // [bins], only when counts != nullptr
+    constexpr uint32_t kTile = kEncodeFastRows * kWave;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(wave_id());
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (counts) {
+            for (uint32_t d = threadIdx.x; d < bins; d += kEncodeThreads) s_hist[d] = 0;
+            __syncthreads();
         }
+        const uint64_t tile0 = (uint64_t)tile * tile_rows;
+        for (uint32_t w0 = wave * kTile; w0 < tile_rows; w0 += (kEncodeThreads / kWave) * kTile) {
+            if (tile0 + w0 >= n) break;   // wave-uniform
+            const WaveRows<kEncodeFastRows> wr = wave_rows<kEncodeFastRows>(tile0 + w0, n);
+            WaveSpans<kEncodeFastRows, B> sp;
+            wave_spans<kEncodeFastRows, B>(col, wr, &sp);
+            uint64_t c0[kEncodeFastRows], c1[kEncodeFastRows];
 #pragma unroll
-        for (int k = 0; k < kEncodeRows; k++) {
-            c0[k] = len64[k] ? load_value_chunk(col.data, begin[k], len64[k], 0) : 0;
-            c1[k] = (long_keys && len64[k] > 8) ? load_value_chunk(col.data, begin[k], len64[k], 1) : 0;
+            for (int k = 0; k < kEncodeFastRows; k++) {
+                c0[k] = sp.chunk(k, 0);
+                c1[k] = LONG ? sp.chunk(k, 1) : 0;
+            }
+            OUT code[kEncodeFastRows];
+            uint32_t okm = wr.okm;   // every build key encodes: only the existence bits matter here
+            encode_rows<kEncodeFastRows, W, B, OUT, LONG>(cv, sp, c0, c1, code, &okm);
+#pragma unroll
+            for (int k = 0; k < kEncodeFastRows; k++) {
+                if ((wr.okm >> k) & 1u) {
+                    (out + wr.rbase)[wr.rel[k]] = code[k];
+                    if (counts) atomicAdd(&s_hist[(uint32_t)code[k] & digit_mask], 1u);
+                }
+            }
         }
-#pragma unroll
-        for (int k = 0; k < kEncodeRows; k++) {
-            const uint64_t row = base + (uint64_t)k * kEncodeThreads + threadIdx.x;
-            uint64_t code;
-            encode_prefetched_w<W>(cv, col, begin[k], (uint32_t)len64[k], c0[k], c1[k], &code);
-            if (row < n) out[row] = (OUT)code;
+        if (counts) {
+            __syncthreads();
+            for (uint32_t d = threadIdx.x; d < bins; d += kEncodeThreads) counts[(uint64_t)d * ntiles + tile] = s_hist[d];
+            __syncthreads();
         }
     }
 }
@@ -738,28 +783,53 @@ __global__ __launch_bounds__(kEncodeThreads) void k_encode_build_plan(ColsArg co
 }
 
 Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec_dev, const DevCol* cols, uint64_t n,
-                          void* out_codes) {
+                          void* out_codes, const EncodeHist* hist) {
     if (n == 0) return {};
     const int lutw_bits = codec_premultiplied_bits(cd);
     if (cd.ncols == 1 && lutw_bits != 0) {
-        uint64_t nblk = (n + kEncodeThreads * kEncodeRows - 1) / (kEncodeThreads * kEncodeRows);
-        if (nblk > 4096) nblk = 4096;
-        const size_t lds = codec_dev.bytes();
-        const dim3 grid((unsigned)nblk), block(kEncodeThreads);
+        // tiles = the sort's tiles when it asked for the first pass's histogram, else 4096 rows
+        const bool want_hist = hist && hist->counts;
+        const uint32_t tile_rows = want_hist ? hist->tile_rows : 4096u;
+        const uint64_t ntiles64 = (n + tile_rows - 1) / tile_rows;
+        const uint32_t ntiles = (uint32_t)ntiles64;
+        const uint32_t mask = want_hist ? hist->digit_mask : 0u;
+        const size_t codec_bytes = codec_dev.bytes();
+        const uint32_t bins = want_hist ? hist->bins : 0u;
+        const size_t lds = codec_bytes + (size_t)bins * sizeof(uint32_t);
         const uint8_t* blob = codec_dev.as<uint8_t>();
-        ProfScope ps(ctx, "k_encode_build", 0);
-        if (cd.key32 && lutw_bits == 32)
-            hipLaunchKernelGGL((k_encode_build_fast<uint32_t, uint32_t>), grid, block, lds, ctx->stream, cols[0], blob, n,
-                               reinterpret_cast<uint32_t*>(out_codes));
-        else if (cd.key32)
-            hipLaunchKernelGGL((k_encode_build_fast<uint64_t, uint32_t>), grid, block, lds, ctx->stream, cols[0], blob, n,
-                               reinterpret_cast<uint32_t*>(out_codes));
-        else
-            hipLaunchKernelGGL((k_encode_build_fast<uint64_t, uint64_t>), grid, block, lds, ctx->stream, cols[0], blob, n,
-                               reinterpret_cast<uint64_t*>(out_codes));
+        const bool narrow = col_is_narrow(cols[0]);
+        const bool long_keys = cd.col_maxlen[0] > 8;
+        using Fn32 = void (*)(DevCol, const uint8_t*, uint64_t, uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t, uint32_t, int);
+        using Fn64 = void (*)(DevCol, const uint8_t*, uint64_t, uint64_t*, uint32_t, uint32_t, uint32_t*, uint32_t, uint32_t, int);
+        int per_cu = 1, cus = 256;
+        CPH_TRY(device_cus(ctx, &cus));
+        ProfScope ps(ctx, "k_encode_build", 4.0 * (double)bins * (double)ntiles);
+        auto launch = [&](auto fn, auto* out) -> Status {
+            CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(fn), kEncodeThreads, lds, &per_cu));
+            const unsigned grid = (unsigned)std::min<uint64_t>(ntiles64, (uint64_t)cus * (uint64_t)per_cu);
+            hipLaunchKernelGGL(fn, dim3(grid), dim3(kEncodeThreads), lds, ctx->stream, cols[0], blob, n, out, tile_rows, ntiles,
+                               want_hist ? hist->counts : nullptr, mask, bins, (int)codec_bytes);
+            return {};
+        };
+        if (cd.key32) {
+            uint32_t* o = reinterpret_cast<uint32_t*>(out_codes);
+            Fn32 fn;
+            if (lutw_bits == 32)
+                fn = narrow ? (long_keys ? &k_encode_build_fast<uint32_t, uint32_t, uint32_t, true> : &k_encode_build_fast<uint32_t, uint32_t, uint32_t, false>)
+                            : (long_keys ? &k_encode_build_fast<uint32_t, uint32_t, uint64_t, true> : &k_encode_build_fast<uint32_t, uint32_t, uint64_t, false>);
+            else
+                fn = long_keys ? &k_encode_build_fast<uint64_t, uint32_t, uint64_t, true> : &k_encode_build_fast<uint64_t, uint32_t, uint64_t, false>;
+            CPH_TRY(launch(fn, o));
+        } else {
+            uint64_t* o = reinterpret_cast<uint64_t*>(out_codes);
+            Fn64 fn = long_keys ? &k_encode_build_fast<uint64_t, uint64_t, uint64_t, true> : &k_encode_build_fast<uint64_t, uint64_t, uint64_t, false>;
+            CPH_TRY(launch(fn, o));
+        }
         CPH_HIP_TRY(hipGetLastError());
+        if (hist) const_cast<EncodeHist*>(hist)->done = want_hist;
         return {};
     }
+    if (hist) const_cast<EncodeHist*>(hist)->done = false;
     ColsArg arg{};
     for (int c = 0; c < cd.ncols; c++) arg.c[c] = cols[c];
     uint64_t nblk = (n + kEncodeThreads - 1) / kEncodeThreads;

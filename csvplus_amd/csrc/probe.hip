@@ -40,8 +40,7 @@ __global__ void k_first_dup(const void* __restrict__ codes, uint64_t n, int nwor
     if (lane_id() == 0 && best != 0xFFFFFFFFu) atomicMin(result, best);
 }
 
-// Launches the adjacent-equal scan; the result stays on the device (ix->first_dup_dev) so that
-// the table build that follows can pick its entry format without a host round trip.
+// Launches the adjacent-equal scan; the result stays on the device (ix->first_dup_dev) until it is read back.
 Status index_first_dup_launch(cph_ctx* ctx, cph_index* ix) {
     const uint64_t n = ix->nrows;
     CPH_TRY(ix->first_dup_dev.alloc(&ctx->pool, sizeof(uint32_t)));
@@ -77,57 +76,84 @@ Status index_first_dup_read(cph_ctx* ctx, cph_index* ix) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// direct-address table (formats: probe_device.hpp).  Every entry starts as {absent, absent}
-// (memset 0xFF): an absent code has cnt == 0 in both formats.  The format is chosen ON THE DEVICE
-// from the first-duplicate word, so the build needs no host decision here.
+// direct-address tables (formats: probe_device.hpp).  They are acceleration structures of Join, not part of the
+// Index (csvplus.go:612-614: the sorted rows ARE the index), so IndexOn only decides whether the code space is
+// dense enough (table_entries) and the first Join that can use one builds it, on the index's ctx stream:
+//   table   {lo,row} / {lo,end} 8-byte entries  — generic probe (needs lo and cnt)
+//   rowtab  4-byte build row                    — chained join over a duplicate-free index
+// Every entry starts as absent (memset 0xFF).
 // ---------------------------------------------------------------------------------------------
 template <class K>
-__global__ void k_build_table(const K* __restrict__ codes, const uint32_t* __restrict__ perm, uint64_t n,
-                              const uint32_t* __restrict__ first_dup, TableEntry* __restrict__ table,
-                              uint32_t* __restrict__ rowtab) {
-    const bool unique = *first_dup == 0xFFFFFFFFu;   // uniform
+__global__ void k_build_table(const K* __restrict__ codes, const uint32_t* __restrict__ perm, uint64_t n, bool unique,
+                              TableEntry* __restrict__ table) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const K c = codes[i];
         if (unique) {
-            const uint32_t r = perm[i];
-            table[c] = TableEntry{(uint32_t)i, r};
-            rowtab[c] = r;
+            table[c] = TableEntry{(uint32_t)i, perm[i]};
         } else {
             if (i == 0 || codes[i - 1] != c) table[c].a = (uint32_t)i;
             if (i + 1 == n || codes[i + 1] != c) table[c].b = (uint32_t)(i + 1);
         }
     }
 }
+template <class K>
+__global__ void k_build_rowtab(const K* __restrict__ codes, const uint32_t* __restrict__ perm, uint64_t n,
+                               uint32_t* __restrict__ rowtab) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) rowtab[codes[i]] = perm[i];
+}
 
-Status index_build_table(cph_ctx* ctx, cph_index* ix) {
+// Decides (host only) whether the index gets direct tables: single-word code with a dense code space.
+void index_plan_table(cph_index* ix) {
     ix->table_entries = 0;
     const uint64_t n = ix->nrows;
-    if (n == 0 || ix->codec.nwords != 1) return {};
+    if (n == 0 || ix->codec.nwords != 1) return;
     const uint64_t states = ix->codec.word_states[0];
     uint64_t limit = 8 * n;
     if (limit < (1ull << 20)) limit = 1ull << 20;
-    if (states > limit || states > (1ull << 30)) return {};
-    CPH_TRY(ix->table.alloc(&ctx->pool, states * sizeof(TableEntry)));
-    CPH_TRY(ix->rowtab.alloc(&ctx->pool, states * sizeof(uint32_t)));
-    CPH_HIP_TRY(hipMemsetAsync(ix->table.get(), 0xFF, states * sizeof(TableEntry), ctx->stream));
-    CPH_HIP_TRY(hipMemsetAsync(ix->rowtab.get(), 0xFF, states * sizeof(uint32_t), ctx->stream));
-    uint64_t nblk = (n + 255) / 256;
-    if (nblk > 8192) nblk = 8192;
-    ProfScope ps(ctx, "k_build_table", (double)n * (ix->codec.key32 ? 4.0 : 8.0) + 4.0 * (double)n + 12.0 * (double)n);
-    const dim3 grid((unsigned)nblk), block(256);
-    const uint32_t* perm = ix->perm.as<uint32_t>();
-    const uint32_t* fd = ix->first_dup_dev.as<uint32_t>();
-    TableEntry* tab = ix->table.as<TableEntry>();
-    uint32_t* rtab = ix->rowtab.as<uint32_t>();
-    if (ix->codec.key32)
-        hipLaunchKernelGGL(k_build_table<uint32_t>, grid, block, 0, ctx->stream, ix->sorted_codes.as<uint32_t>(), perm, n,
-                           fd, tab, rtab);
-    else
-        hipLaunchKernelGGL(k_build_table<uint64_t>, grid, block, 0, ctx->stream, ix->sorted_codes.as<uint64_t>(), perm, n,
-                           fd, tab, rtab);
-    CPH_HIP_TRY(hipGetLastError());
+    if (states > limit || states > (1ull << 30)) return;
     ix->table_entries = states;
+}
+
+Status index_ensure_table(cph_ctx* ctx, const cph_index* cix) {
+    cph_index* ix = const_cast<cph_index*>(cix);   // a cache inside the index; a ctx is single-threaded
+    if (!ix->table_entries || ix->table) return {};
+    const uint64_t n = ix->nrows, states = ix->table_entries;
+    DevBuf t;
+    CPH_TRY(t.alloc(&ctx->pool, states * sizeof(TableEntry)));
+    CPH_HIP_TRY(hipMemsetAsync(t.get(), 0xFF, states * sizeof(TableEntry), ctx->stream));
+    ProfScope ps(ctx, "k_build_table", (double)n * (ix->codec.key32 ? 4.0 : 8.0) + 4.0 * (double)n + 8.0 * (double)n);
+    const dim3 grid(grid_for_items(n)), block(256);
+    const bool unique = ix->first_dup == UINT64_MAX;
+    if (ix->codec.key32)
+        hipLaunchKernelGGL(k_build_table<uint32_t>, grid, block, 0, ctx->stream, ix->sorted_codes.as<uint32_t>(),
+                           ix->perm.as<uint32_t>(), n, unique, t.as<TableEntry>());
+    else
+        hipLaunchKernelGGL(k_build_table<uint64_t>, grid, block, 0, ctx->stream, ix->sorted_codes.as<uint64_t>(),
+                           ix->perm.as<uint32_t>(), n, unique, t.as<TableEntry>());
+    CPH_HIP_TRY(hipGetLastError());
+    ix->table = std::move(t);
+    return {};
+}
+
+Status index_ensure_rowtab(cph_ctx* ctx, const cph_index* cix) {
+    cph_index* ix = const_cast<cph_index*>(cix);
+    if (!ix->table_entries || ix->rowtab || ix->first_dup != UINT64_MAX) return {};
+    const uint64_t n = ix->nrows, states = ix->table_entries;
+    DevBuf t;
+    CPH_TRY(t.alloc(&ctx->pool, states * sizeof(uint32_t)));
+    CPH_HIP_TRY(hipMemsetAsync(t.get(), 0xFF, states * sizeof(uint32_t), ctx->stream));
+    ProfScope ps(ctx, "k_build_table", (double)n * (ix->codec.key32 ? 4.0 : 8.0) + 4.0 * (double)n + 4.0 * (double)n);
+    const dim3 grid(grid_for_items(n)), block(256);
+    if (ix->codec.key32)
+        hipLaunchKernelGGL(k_build_rowtab<uint32_t>, grid, block, 0, ctx->stream, ix->sorted_codes.as<uint32_t>(),
+                           ix->perm.as<uint32_t>(), n, t.as<uint32_t>());
+    else
+        hipLaunchKernelGGL(k_build_rowtab<uint64_t>, grid, block, 0, ctx->stream, ix->sorted_codes.as<uint64_t>(),
+                           ix->perm.as<uint32_t>(), n, t.as<uint32_t>());
+    CPH_HIP_TRY(hipGetLastError());
+    ix->rowtab = std::move(t);
     return {};
 }
 
@@ -418,6 +444,7 @@ Status probe_run(cph_ctx* ctx, const cph_index* ix, const DevCol* cols, int32_t 
     for (int c = 0; c < ncols; c++) arg.c[c] = cols[c];
     const bool full_key = ncols == ix->codec.ncols;
     const bool use_table = ix->table_entries != 0 && full_key;
+    if (use_table) CPH_TRY(index_ensure_table(ctx, ix));
     uint32_t* lo = out->lo.as<uint32_t>();
     uint32_t* cnt = out->cnt.as<uint32_t>();
     uint64_t* ts = tiles.as<uint64_t>();

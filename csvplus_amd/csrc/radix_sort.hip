@@ -13,8 +13,6 @@
 // rows with equal keys keep their input order.  Ranks therefore come from
 // wave-level digit matching (`__ballot` + popcount of the lanes below), never from
 // returning LDS atomics, whose intra-instruction order is unspecified.
-#include <cstdlib>
-
 #include "cph_internal.hpp"
 #include "device_utils.hpp"
 
@@ -341,26 +339,20 @@ Status fill_iota_u32(cph_ctx* ctx, uint32_t* dst, uint64_t n) {
 
 // ---------------------------------------------------------------------------------------------
 // driver
-// driver
 // ---------------------------------------------------------------------------------------------
 template <class K, int RBITS, int THREADS>
 static Status radix_pass(cph_ctx* ctx, const K* kin, const uint32_t* vin, K* kout, uint32_t* vout, uint64_t n, int shift,
-                         int nb, uint32_t* counts, uint32_t ntiles) {
+                         int nb, uint32_t* counts, uint32_t ntiles, bool hist_done) {
     constexpr int BINS = 1 << RBITS;
     const uint32_t mask = (1u << nb) - 1u;
     const size_t smem = sizeof(ScatterSmem<K, RBITS, THREADS>);
-    static bool attr_set = false;
-    if (!attr_set) {
-        CPH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_radix_scatter<K, RBITS, THREADS>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
-    }
-    {
+    CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_radix_scatter<K, RBITS, THREADS>), THREADS, smem, nullptr));
+    if (!hist_done) {
         ProfScope ps(ctx, sizeof(K) == 4 ? "k_radix_hist_u32" : "k_radix_hist_u64", (double)n * sizeof(K));
         hipLaunchKernelGGL((k_radix_hist<K, RBITS, THREADS>), dim3(ntiles), dim3(THREADS), 0, ctx->stream, kin, n, shift,
                            mask, counts, ntiles);
+        CPH_HIP_TRY(hipGetLastError());
     }
-    CPH_HIP_TRY(hipGetLastError());
     CPH_TRY(exclusive_scan_u32(ctx, counts, (uint64_t)BINS * ntiles));
     {
         ProfScope ps(ctx, sizeof(K) == 4 ? "k_radix_scatter_u32" : "k_radix_scatter_u64",
@@ -372,9 +364,31 @@ static Status radix_pass(cph_ctx* ctx, const K* kin, const uint32_t* vin, K* kou
     return {};
 }
 
+// 9-bit digits only when they save a pass on a SMALL input (fewer launches); on large inputs a
+// 9-bit pass costs 1.2-1.4x an 8-bit one and 8192-key tiles (512 threads) are slower than
+// 4096-key ones (measured at 1e7/1e8 rows, tools/microbench/sort_cfg.py: 1e8 rows sort in
+// 3.9 ms with 256,8 vs 4.2-4.4 ms with the other three).  Digit widths are balanced over passes.
+// ctx->sort_threads / sort_rbits (cph_ctx_set_option) override the choice for tuning sweeps.
+RadixPlan radix_plan(const cph_ctx* ctx, uint64_t n, int bits) {
+    RadixPlan p;
+    if (n == 0 || bits <= 0) return p;
+    const int p8 = (bits + 7) / 8, p9 = (bits + 8) / 9;
+    bool wide = p9 < p8 && n < (1u << 22);
+    if (ctx->sort_threads == 256 || ctx->sort_threads == 512) p.threads = ctx->sort_threads;
+    if (ctx->sort_rbits == 8) wide = false;
+    if (ctx->sort_rbits == 9) wide = true;
+    p.rbits = wide ? 9 : 8;
+    p.npass = wide ? p9 : p8;
+    p.tile = (uint32_t)p.threads * kSortItems;
+    p.ntiles = (uint32_t)((n + p.tile - 1) / p.tile);
+    p.nb0 = (bits + p.npass - 1) / p.npass;
+    return p;
+}
+
 template <class K>
 Status radix_sort_pairs(cph_ctx* ctx, K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b, bool vals_iota,
-                        uint64_t n, int bits, K** keys_out, uint32_t** vals_out, int* passes) {
+                        uint64_t n, int bits, K** keys_out, uint32_t** vals_out, int* passes, uint32_t* counts_in,
+                        bool first_hist_done) {
     *passes = 0;
     K* kin = keys_a;
     K* kout = keys_b;
@@ -387,37 +401,27 @@ Status radix_sort_pairs(cph_ctx* ctx, K* keys_a, K* keys_b, uint32_t* vals_a, ui
         *vals_out = vin;
         return {};
     }
-    // 9-bit digits only when they save a pass on a SMALL input (fewer launches); on large inputs a
-    // 9-bit pass costs 1.2-1.4x an 8-bit one and 8192-key tiles (512 threads) are slower than
-    // 4096-key ones (measured at 1e7/1e8 rows, tools/microbench/sort_cfg.py: 1e8 rows sort in
-    // 3.9 ms with 256,8 vs 4.2-4.4 ms with the other three).  Digit widths are balanced over passes.
-    static const char* cfg_env = std::getenv("CPH_SORT_CFG");   // tuning override: "<threads>,<rbits>"
-    int threads = 256;
-    const int p8 = (bits + 7) / 8, p9 = (bits + 8) / 9;
-    bool wide = p9 < p8 && n < (1u << 22);
-    if (cfg_env) {
-        int t = 0, r = 0;
-        if (sscanf(cfg_env, "%d,%d", &t, &r) == 2) {
-            if (t == 256 || t == 512) threads = t;
-            if (r == 8) wide = false;
-            if (r == 9) wide = true;
-        }
-    }
-    const int npass = wide ? (bits + 8) / 9 : p8;
-    const uint32_t tile = (uint32_t)threads * kSortItems;
-    const uint32_t ntiles = (uint32_t)((n + tile - 1) / tile);
+    const RadixPlan plan = radix_plan(ctx, n, bits);
+    const int npass = plan.npass, threads = plan.threads;
+    const bool wide = plan.rbits == 9;
+    const uint32_t ntiles = plan.ntiles;
     DevBuf counts;
-    CPH_TRY(counts.alloc(&ctx->pool, (size_t)(wide ? 512 : 256) * ntiles * sizeof(uint32_t)));
+    uint32_t* c = counts_in;
+    if (!c) {
+        CPH_TRY(counts.alloc(&ctx->pool, plan.count_words() * sizeof(uint32_t)));
+        c = counts.as<uint32_t>();
+        first_hist_done = false;
+    }
     int shift = 0;
     for (int p = 0; p < npass; p++) {
         const int left = bits - shift;
         const int nb = (left + (npass - p) - 1) / (npass - p);
         const uint32_t* v = iota ? nullptr : vin;
-        uint32_t* c = counts.as<uint32_t>();
-        if (wide && threads == 512) CPH_TRY((radix_pass<K, 9, 512>(ctx, kin, v, kout, vout, n, shift, nb, c, ntiles)));
-        else if (wide) CPH_TRY((radix_pass<K, 9, 256>(ctx, kin, v, kout, vout, n, shift, nb, c, ntiles)));
-        else if (threads == 512) CPH_TRY((radix_pass<K, 8, 512>(ctx, kin, v, kout, vout, n, shift, nb, c, ntiles)));
-        else CPH_TRY((radix_pass<K, 8, 256>(ctx, kin, v, kout, vout, n, shift, nb, c, ntiles)));
+        const bool hd = p == 0 && first_hist_done;
+        if (wide && threads == 512) CPH_TRY((radix_pass<K, 9, 512>(ctx, kin, v, kout, vout, n, shift, nb, c, ntiles, hd)));
+        else if (wide) CPH_TRY((radix_pass<K, 9, 256>(ctx, kin, v, kout, vout, n, shift, nb, c, ntiles, hd)));
+        else if (threads == 512) CPH_TRY((radix_pass<K, 8, 512>(ctx, kin, v, kout, vout, n, shift, nb, c, ntiles, hd)));
+        else CPH_TRY((radix_pass<K, 8, 256>(ctx, kin, v, kout, vout, n, shift, nb, c, ntiles, hd)));
         shift += nb;
         iota = false;
         K* tk = kin; kin = kout; kout = tk;
@@ -430,8 +434,8 @@ Status radix_sort_pairs(cph_ctx* ctx, K* keys_a, K* keys_b, uint32_t* vals_a, ui
 }
 
 template Status radix_sort_pairs<uint32_t>(cph_ctx*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, bool, uint64_t, int,
-                                           uint32_t**, uint32_t**, int*);
+                                           uint32_t**, uint32_t**, int*, uint32_t*, bool);
 template Status radix_sort_pairs<uint64_t>(cph_ctx*, uint64_t*, uint64_t*, uint32_t*, uint32_t*, bool, uint64_t, int,
-                                           uint64_t**, uint32_t**, int*);
+                                           uint64_t**, uint32_t**, int*, uint32_t*, bool);
 
 }  // namespace cph

@@ -62,7 +62,13 @@ CPH_API int32_t cph_stream_join_create(cph_ctx* ctx, const cph_index* const* ind
     if (!chain_fast_path_ok(probe, nsteps))
         return sj_fail(ctx, CPH_ERR_INVALID,
                        "stream join needs indexes with distinct keys over one key column (use cph_join_chain per chunk)");
-    (void)hipStreamSynchronize(ctx->stream);   // the indexes were built on the parent stream
+    // the slots run on their own streams: build the indexes' lookup tables now, on the parent stream they were
+    // built on, and wait for it once
+    for (int s = 0; s < nsteps; s++) {
+        Status st = index_ensure_rowtab(ctx, indexes[s]);
+        if (!st.ok()) return sj_fail(ctx, st.code, st.msg);
+    }
+    (void)hipStreamSynchronize(ctx->stream);
     cph_stream_join* sj = new (std::nothrow) cph_stream_join();
     if (!sj) return sj_fail(ctx, CPH_ERR_NOMEM, "out of host memory");
     sj->parent = ctx;

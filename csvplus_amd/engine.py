@@ -91,6 +91,16 @@ class Engine:
             raise N.CphError(N.CPH_ERR_DUPLICATE, self.ctx.last_error())
         return ix
 
+    def index_on_many(self, specs, unique: bool = False) -> list:
+        """Several IndexOn / UniqueIndexOn calls as one batch (cph_index_build_many): specs = [keycols, ...]."""
+        res = N.DeviceIndex.build_many(self.ctx, [(cols, unique) for cols in specs])
+        if unique and any(ix.status == N.CPH_ERR_DUPLICATE for ix in res):
+            msg = self.ctx.last_error()
+            for ix in res:
+                ix.close()
+            raise N.CphError(N.CPH_ERR_DUPLICATE, msg)
+        return res
+
     # ---- Join ----------------------------------------------------------------------------------
     def join(self, index: N.DeviceIndex, probecols, probe_base: int = 0, want_pairs: bool = True) -> N.Matches:
         return index.probe(probecols, probe_base=probe_base, want_pairs=want_pairs, out_mem=N.CPH_MEM_DEVICE)

@@ -129,10 +129,13 @@ CPH_API const char* cph_last_error(const cph_ctx* ctx);
  * library's kernels with its own copies. */
 CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
 
-/* Measurement hook (tools/microbench): attribution switches of the chained-join kernel — bit 0 skips the
- * table lookups, bit 1 the key encode, bit 2 the result stores.  Results are WRONG while any bit is set;
- * 0 (the default) is the product path.  Per ctx, so two devices in one process never share it. */
-CPH_API int32_t cph_ctx_set_debug(cph_ctx* ctx, int32_t chain_flags);
+/* Measurement / tuning knobs (tools/microbench), per ctx — two devices in one process never share them:
+ *   "chain_debug"   attribution switches of the chained-join kernel: bit 0 skips the table lookups, bit 1 the
+ *                   key encode, bit 2 the result stores.  Results are WRONG while any bit is set; 0 = product path.
+ *   "sort_threads"  256 / 512: workgroup size of the radix sort (0 = automatic)
+ *   "sort_rbits"    8 / 9: digit width of the radix sort (0 = automatic)
+ * Unknown names fail with CPH_ERR_INVALID. */
+CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value);
 
 /* Blocks until everything enqueued by this ctx has finished. */
 CPH_API int32_t cph_ctx_synchronize(cph_ctx* ctx);
@@ -162,6 +165,21 @@ CPH_API int32_t cph_pinned_free(cph_ctx* ctx, void* p);
  */
 CPH_API int32_t cph_index_build(cph_ctx* ctx, const cph_strcol* keycols, int32_t nkeycols, int32_t unique,
                                 cph_index** out, uint64_t* first_dup_pos);
+/*
+ * Several IndexOn calls as one batch (the two build sides of orders.Join(customers).Join(products),
+ * README.md:56): the same results as nspecs calls of cph_index_build, but the batch pays the build's two
+ * host round trips (key statistics, first duplicate) ONCE instead of once per index, and the kernels of the
+ * different indexes queue back to back.  out[i] / first_dup_pos[i] / status[i] are per index (status and
+ * first_dup_pos may be NULL); the return value is the first non-OK status (CPH_ERR_DUPLICATE for a `unique`
+ * spec with equal keys — that index is still returned, as by cph_index_build).
+ */
+typedef struct cph_index_spec {
+    const cph_strcol* keycols;
+    int32_t           nkeycols;
+    int32_t           unique;
+} cph_index_spec;
+CPH_API int32_t cph_index_build_many(cph_ctx* ctx, const cph_index_spec* specs, int32_t nspecs, cph_index** out,
+                                     uint64_t* first_dup_pos, int32_t* status);
 CPH_API void    cph_index_destroy(cph_index* index);
 
 /* Number of rows / key columns of the index. */

@@ -357,3 +357,33 @@ def test_fixed_width_columns_match_variable_path(ctx):
     assert col.fixed_width == 3
     g, o = check_index(ctx, [col])
     assert_join_equal(g.probe([col]), o.join([col]))
+
+
+def test_index_build_many_matches_single_builds(ctx):
+    """cph_index_build_many = the same indexes as separate cph_index_build calls (one batch, two host round trips):
+    perm bit-exact vs the oracle for mixed shapes, a duplicate in a `unique` spec reported per index."""
+    rng = np.random.default_rng(5)
+    tables = [
+        [dg.customers(30_000)["id"]],                                   # fixed 8-byte unique ids
+        [dg.products(700)["prod_id"]],                                  # variable-length decimal ids
+        [StrCol.from_values(random_keys(rng, 5_000, 0, 30, alphabet=np.frombuffer(b"ab\x00\xff", dtype=np.uint8), distinct=300))],   # heavy duplicates, NUL / high bytes
+        [StrCol.from_values([b"k%d" % (i % 50) for i in range(2000)]), StrCol.from_values([b"%d" % (i % 7) for i in range(2000)])],
+        [StrCol.from_values([])],
+    ]
+    many = DeviceIndex.build_many(ctx, [(t, False) for t in tables])
+    for t, ix in zip(tables, many):
+        o = orc.OracleIndex(t)
+        np.testing.assert_array_equal(ix.perm(), o.perm)
+        single = DeviceIndex(ctx, t)
+        np.testing.assert_array_equal(ix.perm(), single.perm())
+        assert ix.first_dup == single.first_dup == o.first_dup()
+        single.close()
+    for ix in many:
+        ix.close()
+    # unique: index 1 has duplicates -> its status is DUPLICATE, the others are fine; all are returned
+    specs = [(tables[0], True), (tables[2], True), (tables[1], True)]
+    res = DeviceIndex.build_many(ctx, specs)
+    assert [r.status for r in res] == [0, N.CPH_ERR_DUPLICATE, 0]
+    assert res[1].first_dup == orc.OracleIndex(tables[2]).first_dup()
+    for r in res:
+        r.close()

@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
-"""IndexOn kernel times for sort configurations (CPH_SORT_CFG=<threads>,<rbits>), one process each."""
-import os, subprocess, sys
+"""IndexOn kernel times for sort configurations (ctx options sort_threads / sort_rbits)."""
+import sys
 from pathlib import Path
-ROOT = Path(__file__).resolve().parents[2]
-if len(sys.argv) > 1 and sys.argv[1] == "child":
-    sys.path.insert(0, str(ROOT))
-    import torch
-    from csvplus_amd import datagen as dg
-    from csvplus_amd.engine import Engine
-    eng = Engine(0)
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+from csvplus_amd import datagen as dg
+from csvplus_amd.engine import Engine
+
+eng = Engine(0)
+for threads, rbits in ((256, 8), (512, 8), (256, 9), (512, 9)):
+    eng.ctx.set_option("sort_threads", threads)
+    eng.ctx.set_option("sort_rbits", rbits)
+    print(f"sort_threads={threads} sort_rbits={rbits}", flush=True)
     for n in (100_000, 10_000_000, 100_000_000):
         col = dg.column(dg.SEQ_PERM, n, n, encoding=dg.FIXED8, seed=7).to_device(eng.device)
         eng.index_on([col], unique=True).close()
@@ -20,7 +22,3 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         print(f"  n={n:>11} passes={inf['sort_passes']} total {tot:7.3f} ms | " +
               " ".join(f"{k.replace('k_radix_','').replace('exclusive_','')}={v['total_ms'] / 3:.3f}" for k, v in p.items()), flush=True)
         del col
-else:
-    for cfg in ("256,8", "512,8", "256,9", "512,9"):
-        print("CPH_SORT_CFG=" + cfg, flush=True)
-        subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ, CPH_SORT_CFG=cfg))

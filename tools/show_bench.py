@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Condensed view of a bench.py JSON line: tools/show_bench.py gpurun_out/bench_x.json"""
+import json
+import sys
+
+d = json.load(open(sys.argv[1]))
+r = d.get("roofline") or {}
+print("value %.3e %s | ms_per_step %.3f | kernel_ms %.3f | frac %.4f useful %s step_frac %s | verified %s" % (
+    d["value"], d["unit"], d["ms_per_step"], d["kernel_ms_per_step"], r.get("frac", 0), r.get("useful"), r.get("step_frac"),
+    d.get("verified")))
+if r.get("traffic"):
+    print("traffic %.3e (raw %s) algorithmic %.3e" % (r["traffic"], r.get("traffic_raw"), r.get("algorithmic_bytes_per_launch", 0)))
+for k, v in d["kernels"].items():
+    print(f"  {k:28s} {v['avg_ms']:9.4f} ms x {v['launches']:4d}  {v['GBps']} GB/s")
+for k, v in (d.get("index_on_1e8") or {}).items():
+    print(k, "ms", v["ms"], "kernel_ms", v["kernel_ms"], "pass", v.get("frac_pass_model"), "verified", v.get("verified"))
+    print("    ", v["kernels_ms"])
+for k in ("e2e_pinned_host", "cpu_baseline"):
+    if k in d:
+        print(k, {a: b for a, b in d[k].items() if a not in ("scope", "sample")})
