@@ -11,7 +11,7 @@ CXX     ?= g++
 
 LIBDIR  = csvplus_amd/lib
 CSRC    = csvplus_amd/csrc
-HIP_SRCS = $(CSRC)/capi.hip $(CSRC)/keycodec.hip $(CSRC)/radix_sort.hip $(CSRC)/probe.hip $(CSRC)/chain.hip $(CSRC)/stream_join.hip $(CSRC)/materialize.hip $(CSRC)/csv_ingest.hip $(CSRC)/index_ops.hip
+HIP_SRCS = $(CSRC)/capi.hip $(CSRC)/keycodec.hip $(CSRC)/radix_sort.hip $(CSRC)/probe.hip $(CSRC)/chain.hip $(CSRC)/stream_join.hip $(CSRC)/materialize.hip $(CSRC)/csv_ingest.hip $(CSRC)/index_ops.hip $(CSRC)/dist.hip
 HIP_OBJS = $(patsubst $(CSRC)/%.hip,$(LIBDIR)/obj/%.o,$(HIP_SRCS))
 HIP_HDRS = $(CSRC)/cph_internal.hpp $(CSRC)/device_utils.hpp $(CSRC)/codec_device.hpp $(CSRC)/probe_device.hpp $(CSRC)/lds_stage.hpp include/csvplus_hip.h
 
@@ -27,7 +27,7 @@ $(LIBDIR)/obj/%.o: $(CSRC)/%.hip $(HIP_HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIBDIR)/libcsvplus_hip.so: $(HIP_OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(HIP_OBJS) -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(HIP_OBJS) -ldl -o $@
 
 $(LIBDIR)/libcph_datagen.so: $(CSRC)/datagen.c
 	@mkdir -p $(LIBDIR)

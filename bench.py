@@ -11,8 +11,9 @@ resident in HBM,
         over 1e8 orders rows x 3 string columns (cust_id, prod_id, qty)
 
 and, for N > 1, the probe rows are split into N contiguous ranges (strong scaling:
-the 1e8 rows are fixed), the build side is replicated, and the joined row-id triples are
-allgatherv'ed over RCCL so that every rank holds the whole list in emission order.
+the 1e8 rows are fixed), the build side is replicated, and the joined row-id lists are
+allgatherv'ed over RCCL behind the C ABI (cph_dist_chain_allgather) so that every rank holds the
+whole list in emission order.
 
 value = joined rows per second of the whole job (max over ranks of the step time).
 """
@@ -100,7 +101,7 @@ def main():
     import torch.distributed as dist
 
     from csvplus_amd import _native as N, datagen as dg
-    from csvplus_amd.dist import allgatherv
+    from csvplus_amd.dist import allgatherv_many, chain_allgather, connect
     from csvplus_amd.engine import Engine, shard_range
 
     rank = int(os.environ.get("RANK", "0"))
@@ -121,6 +122,9 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank)
     eng = Engine(local_rank)
+    # the exchange runs behind the C ABI (cph_dist_*: RCCL); torch.distributed only ships the communicator id.
+    # Debug mode with several ranks on one GPU (gloo): the torch transport of csvplus_amd/dist.py instead.
+    cdist = connect(eng.ctx) if (world > 1 and not share_gpu and args.exchange == "allgatherv") else None
 
     # ---- synthetic tables (deterministic), staged to HBM before timing ------------
     t0 = time.time()
@@ -142,9 +146,14 @@ def main():
         # stream_row is None when every order joined (the result row IS the stream row): then only
         # the two build-row arrays exist — and only they are exchanged
         out = tuple(t for t in (res.stream_row, res.build_rows[0], res.build_rows[1]) if t is not None)
-        if world > 1 and args.exchange == "allgatherv":
-            out = tuple(allgatherv(t)[0] for t in out)
-        n = int(out[-1].numel())
+        if cdist is not None:          # one count exchange + one grouped batch for all arrays (cph_dist_chain_allgather)
+            gres, _ = chain_allgather(cdist, res, dev)
+            n = gres.n
+            gres.release()
+        elif world > 1 and args.exchange == "allgatherv":
+            n = int(allgatherv_many(out)[0][-1].numel())
+        else:
+            n = int(out[-1].numel())
         info = (ia.info(), ib.info())
         res.release()
         ia.close()

@@ -144,6 +144,16 @@ class cph_groups(C.Structure):
     _fields_ = [("ngroups", C.c_uint64), ("lower", C.c_void_p), ("upper", C.c_void_p)]
 
 
+CPH_DIST_ID_BYTES = 128
+CPH_MAX_GATHER = 8
+
+
+class cph_gathered(C.Structure):
+    _fields_ = [("total", C.c_uint64), ("narrays", C.c_int32), ("nranks", C.c_int32),
+                ("counts", C.POINTER(C.c_uint64)), ("displs", C.POINTER(C.c_uint64)),
+                ("data", C.c_void_p * CPH_MAX_GATHER)]
+
+
 class cph_stream_chunk(C.Structure):
     _fields_ = [("probe_base", C.c_uint64), ("nrows", C.c_uint64), ("nmatches", C.c_uint64),
                 ("match_bitmap", C.c_void_p), ("build_row", C.c_void_p * CPH_MAX_CHAIN), ("nsteps", C.c_int32),
@@ -175,6 +185,18 @@ PROTOTYPES = [
     ("cph_index_build_many", C.c_int32,
      [_P, C.POINTER(cph_index_spec), C.c_int32, C.POINTER(_P), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),
     ("cph_index_destroy", None, [_P]),
+    ("cph_dist_unique_id", C.c_int32, [_P, C.POINTER(C.c_uint8)]),
+    ("cph_dist_create", C.c_int32, [_P, C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.POINTER(_P)]),
+    ("cph_dist_create_loopback", C.c_int32, [_P, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    ("cph_dist_destroy", None, [_P]),
+    ("cph_dist_rank", C.c_int32, [_P]),
+    ("cph_dist_size", C.c_int32, [_P]),
+    ("cph_dist_allgatherv", C.c_int32,
+     [_P, C.POINTER(_P), C.POINTER(C.c_int32), C.c_int32, C.c_uint64, C.POINTER(C.POINTER(cph_gathered))]),
+    ("cph_gathered_release", None, [C.POINTER(cph_gathered)]),
+    ("cph_dist_chain_allgather", C.c_int32,
+     [_P, C.POINTER(cph_chain), C.c_uint64, C.POINTER(C.POINTER(cph_gathered)), C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
+    ("cph_dist_index_broadcast", C.c_int32, [_P, _P, C.c_int32, C.POINTER(_P)]),
     ("cph_index_nrows", C.c_uint64, [_P]),
     ("cph_index_nkeycols", C.c_int32, [_P]),
     ("cph_index_perm", C.c_int32, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_uint64)]),
@@ -546,6 +568,101 @@ class Chain:
     def __del__(self):
         try:
             self.release()
+        except Exception:
+            pass
+
+
+class Gathered:
+    """Result of an exchange (cph_gathered): device arrays of this rank's ctx + host counts / displacements."""
+
+    def __init__(self, ctx: Context, ptr, identity=None, stream_base: int = 0):
+        self.ctx, self.lib, self.ptr = ctx, ctx.lib, ptr
+        g = ptr.contents
+        self.total = int(g.total)
+        self.narrays = int(g.narrays)
+        self.counts = [int(g.counts[r]) for r in range(int(g.nranks))]
+        self.displs = [int(g.displs[r]) for r in range(int(g.nranks))]
+        self.data_ptrs = [int(g.data[a] or 0) for a in range(self.narrays)]
+        self.identity = identity
+        self.stream_base = stream_base
+        ctx._children.add(self)
+
+    def release(self):
+        if self.ptr:
+            self.lib.cph_gathered_release(self.ptr)
+            self.ptr = None
+
+    close = release
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class Dist:
+    """The communicator of the sharded Join (cph_dist): RCCL, or the in-process loopback used by the tests."""
+
+    def __init__(self, ctx: Context, handle):
+        self.ctx, self.lib, self.handle = ctx, ctx.lib, handle
+        self.rank = int(self.lib.cph_dist_rank(handle))
+        self.size = int(self.lib.cph_dist_size(handle))
+        ctx._children.add(self)
+
+    @staticmethod
+    def unique_id(ctx: Context) -> bytes:
+        buf = (C.c_uint8 * CPH_DIST_ID_BYTES)()
+        ctx._check(ctx.lib.cph_dist_unique_id(ctx.handle, buf))
+        return bytes(buf)
+
+    @staticmethod
+    def create(ctx: Context, uid: bytes, rank: int, nranks: int) -> "Dist":
+        assert len(uid) == CPH_DIST_ID_BYTES
+        buf = (C.c_uint8 * CPH_DIST_ID_BYTES).from_buffer_copy(uid)
+        h = _P()
+        ctx._check(ctx.lib.cph_dist_create(ctx.handle, buf, rank, nranks, C.byref(h)))
+        return Dist(ctx, h)
+
+    @staticmethod
+    def loopback(ctx: Context, group: str, rank: int, nranks: int) -> "Dist":
+        h = _P()
+        ctx._check(ctx.lib.cph_dist_create_loopback(ctx.handle, group.encode(), rank, nranks, C.byref(h)))
+        return Dist(ctx, h)
+
+    def allgatherv(self, ptrs, elem_bytes, count: int) -> Gathered:
+        k = len(ptrs)
+        pa = (_P * k)(*[_P(p or 0) for p in ptrs])
+        ea = (C.c_int32 * k)(*elem_bytes)
+        out = C.POINTER(cph_gathered)()
+        self.ctx._check(self.lib.cph_dist_allgatherv(self.handle, pa, ea, k, count, C.byref(out)))
+        return Gathered(self.ctx, out)
+
+    def chain_allgather(self, chain: "Chain") -> Gathered:
+        out = C.POINTER(cph_gathered)()
+        ident = C.c_int32(0)
+        base = C.c_uint64(0)
+        self.ctx._check(self.lib.cph_dist_chain_allgather(self.handle, chain.ptr, chain.probe_base, C.byref(out),
+                                                          C.byref(ident), C.byref(base)))
+        return Gathered(self.ctx, out, identity=bool(ident.value), stream_base=int(base.value))
+
+    def index_broadcast(self, index, root: int = 0):
+        """Root passes its DeviceIndex and gets it back; the other ranks pass None and receive an equal index."""
+        h = _P()
+        self.ctx._check(self.lib.cph_dist_index_broadcast(self.handle, index.handle if index is not None else None, root,
+                                                          C.byref(h)))
+        if self.rank == root:
+            return index
+        return DeviceIndex._from_handle(self.ctx, h)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.cph_dist_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass
 

@@ -261,6 +261,7 @@ static Status build_phase1(cph_ctx* ctx, const cph_strcol* keycols, int32_t nkey
     cph_index* ix = job->ix;
     ix->ctx = ctx;
     ix->nrows = keycols[0].nrows;
+    ix->table_rows = ix->nrows;
     ix->nkeycols = nkeycols;
     job->nkeycols = nkeycols;
     CPH_TRY(stage_cols(ctx, keycols, nkeycols, &job->staged, job->dcols));

@@ -222,6 +222,7 @@ struct cph_ctx {
 struct cph_index {
     cph_ctx* ctx = nullptr;
     uint64_t nrows = 0;
+    uint64_t table_rows = 0;       // rows of the table the index was built over (perm values are < table_rows)
     int32_t nkeycols = 0;
     cph::CodecHost codec;
     cph::DevBuf codec_dev;         // CodecDevHeader block
@@ -339,6 +340,13 @@ Status probe_run(cph_ctx* ctx, const cph_index* ix, const DevCol* cols, int32_t 
                  uint64_t nprobe, uint64_t probe_base, bool want_pairs, ProbeOut* out);
 Status index_find_device(cph_ctx* ctx, const cph_index* ix, const uint64_t* q_exact, int32_t nq, uint64_t qlo,
                          uint64_t qhi, uint64_t* lower, uint64_t* upper);
+
+// index_ops.hip: an index as descriptor (host bytes) + sorted codes + perm (device arrays)
+void index_desc_serialize(const cph_index* ix, std::vector<uint8_t>* out);
+bool index_desc_size(const uint8_t* p, size_t n, size_t* need);     // from the first sizeof(header) bytes
+bool index_desc_parse(const uint8_t* p, size_t n, cph_index* ix);
+Status index_adopt_payload(cph_ctx* ctx, cph_index* ix);            // validate the device arrays, finish the index
+size_t index_code_bytes(const cph_index* ix);                       // bytes of sorted codes per row
 
 // chain.hip
 struct ChainStep {

@@ -62,6 +62,72 @@ __global__ void k_select_check(const uint64_t* __restrict__ pos, uint64_t n, uin
         if (pos[i] >= nrows || (i > 0 && pos[i - 1] >= pos[i])) atomicExch(bad, 1u);
 }
 
+// Payload check of an index that did not come out of this process's own sort (a file, a broadcast): every code
+// word below its word's state count, code tuples non-decreasing, perm values distinct and < table_rows.  A crafted
+// or corrupted payload would otherwise drive the table builds and the callers' gathers out of bounds.
+//   bad[0] = 1 on any violation;  seen = bitmap of table_rows bits, zeroed by the caller
+template <bool KEY32>
+__global__ void k_validate_payload(const void* __restrict__ codes, const uint32_t* __restrict__ perm, uint64_t n, int nwords,
+                                   const uint64_t* __restrict__ word_states, uint64_t table_rows,
+                                   uint32_t* __restrict__ seen, uint32_t* __restrict__ bad) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    bool wrong = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if constexpr (KEY32) {
+            const uint32_t* c = reinterpret_cast<const uint32_t*>(codes);
+            if ((uint64_t)c[i] >= word_states[0]) wrong = true;
+            if (i > 0 && c[i - 1] > c[i]) wrong = true;
+        } else {
+            const uint64_t* c = reinterpret_cast<const uint64_t*>(codes);
+            bool decided = false;
+            for (int w = 0; w < nwords; w++) {
+                const uint64_t v = c[(uint64_t)w * n + i];
+                if (v >= word_states[w]) wrong = true;
+                if (i > 0 && !decided) {
+                    const uint64_t u = c[(uint64_t)w * n + i - 1];
+                    if (u > v) wrong = true;
+                    if (u != v) decided = true;
+                }
+            }
+        }
+        const uint32_t r = perm[i];
+        if ((uint64_t)r >= table_rows) wrong = true;
+        else if (atomicOr(&seen[r >> 5], 1u << (r & 31)) & (1u << (r & 31))) wrong = true;
+    }
+    if (wrong) atomicExch(bad, 1u);
+}
+
+static Status index_validate_payload(cph_ctx* ctx, const cph_index* ix) {
+    const uint64_t n = ix->nrows;
+    if (n == 0) return {};
+    if (ix->table_rows < n || ix->table_rows > 0xFFFFFFFFull) return {CPH_ERR_INVALID, "index payload: bad table row count"};
+    DevBuf seen, bad, states;
+    const size_t words = (size_t)((ix->table_rows + 31) / 32);
+    CPH_TRY(seen.alloc(&ctx->pool, words * sizeof(uint32_t)));
+    CPH_TRY(bad.alloc(&ctx->pool, sizeof(uint32_t)));
+    CPH_TRY(states.alloc(&ctx->pool, sizeof(uint64_t) * kMaxWords));
+    CPH_HIP_TRY(hipMemsetAsync(seen.get(), 0, words * sizeof(uint32_t), ctx->stream));
+    CPH_HIP_TRY(hipMemsetAsync(bad.get(), 0, sizeof(uint32_t), ctx->stream));
+    void* up = nullptr;
+    CPH_TRY(pinned_upload(ctx, sizeof(uint64_t) * kMaxWords, &up));
+    memcpy(up, ix->codec.word_states, sizeof(uint64_t) * kMaxWords);
+    CPH_HIP_TRY(hipMemcpyAsync(states.get(), up, sizeof(uint64_t) * kMaxWords, hipMemcpyHostToDevice, ctx->stream));
+    const unsigned grid = grid_for_items(n);
+    if (ix->codec.key32)
+        hipLaunchKernelGGL(k_validate_payload<true>, dim3(grid), dim3(256), 0, ctx->stream, ix->sorted_codes.get(),
+                           ix->perm.as<uint32_t>(), n, ix->codec.nwords, states.as<uint64_t>(), ix->table_rows,
+                           seen.as<uint32_t>(), bad.as<uint32_t>());
+    else
+        hipLaunchKernelGGL(k_validate_payload<false>, dim3(grid), dim3(256), 0, ctx->stream, ix->sorted_codes.get(),
+                           ix->perm.as<uint32_t>(), n, ix->codec.nwords, states.as<uint64_t>(), ix->table_rows,
+                           seen.as<uint32_t>(), bad.as<uint32_t>());
+    CPH_HIP_TRY(hipGetLastError());
+    uint32_t isbad = 0;
+    CPH_TRY(read_device_value(ctx, bad.as<uint32_t>(), &isbad));
+    if (isbad) return {CPH_ERR_INVALID, "index payload is corrupt: codes out of range or out of order, or perm is not a set of row ids"};
+    return {};
+}
+
 // Finishes an index whose codec / sorted_codes / perm are in place: unique scan + table decision.
 static Status finish_index(cph_ctx* ctx, cph_index* ix) {
     CPH_TRY(codec_upload(ctx, ix->codec, &ix->codec_dev));
@@ -75,6 +141,181 @@ static size_t code_bytes(const cph_index* ix) {
     return ix->codec.key32 ? sizeof(uint32_t) : sizeof(uint64_t) * (size_t)ix->codec.nwords;
 }
 
+
+// ---- index descriptor: everything of an index except its two device arrays -----------------------------------
+// (header + codec tables, little endian).  Shared by the file format (cph_index_save/_load) and by the broadcast
+// of a built index to the other ranks (dist.hip): both move descriptor, sorted codes, perm.
+constexpr char kMagic[8] = {'C', 'P', 'H', 'I', 'D', 'X', '3', '\n'};
+struct FileHeader {
+    char magic[8];
+    uint64_t nrows;
+    uint64_t table_rows;         // rows of the table the index was built over: perm values are < table_rows
+    int32_t nkeycols, ncols, npos, nwords, key32, sort_passes;
+    int32_t has_groups, ndict;   // dictionary-coded groups: unit/dict_off/dict_len per position + ndict entries
+    int32_t col_start[kMaxKeyCols + 1];
+    int32_t col_maxlen[kMaxKeyCols];
+    int32_t col_minlen[kMaxKeyCols];
+    int32_t word_bits[kMaxWords];
+    uint64_t word_states[kMaxWords];
+};
+
+void index_desc_serialize(const cph_index* ix, std::vector<uint8_t>* out) {
+    const CodecHost& cd = ix->codec;
+    FileHeader h{};
+    memcpy(h.magic, kMagic, 8);
+    h.nrows = ix->nrows;
+    h.table_rows = ix->table_rows;
+    h.nkeycols = ix->nkeycols;
+    h.ncols = cd.ncols;
+    h.npos = cd.npos;
+    h.nwords = cd.nwords;
+    h.key32 = cd.key32 ? 1 : 0;
+    h.sort_passes = ix->sort_passes;
+    h.has_groups = cd.has_groups() ? 1 : 0;
+    h.ndict = (int32_t)cd.dict.size();
+    memcpy(h.col_start, cd.col_start, sizeof h.col_start);
+    memcpy(h.col_maxlen, cd.col_maxlen, sizeof h.col_maxlen);
+    memcpy(h.col_minlen, cd.col_minlen, sizeof h.col_minlen);
+    memcpy(h.word_bits, cd.word_bits, sizeof h.word_bits);
+    memcpy(h.word_states, cd.word_states, sizeof h.word_states);
+    out->clear();
+    auto put = [&](const void* p, size_t nb) {
+        const uint8_t* b = static_cast<const uint8_t*>(p);
+        out->insert(out->end(), b, b + nb);
+    };
+    put(&h, sizeof h);
+    put(cd.radix.data(), cd.radix.size() * sizeof(uint16_t));
+    put(cd.mult.data(), cd.mult.size() * sizeof(uint64_t));
+    put(cd.word_of.data(), cd.word_of.size() * sizeof(int32_t));
+    put(cd.lut.data(), cd.lut.size() * sizeof(uint16_t));
+    if (cd.has_groups()) {
+        put(cd.unit.data(), cd.unit.size());
+        put(cd.dict_off.data(), cd.dict_off.size() * sizeof(int32_t));
+        put(cd.dict_len.data(), cd.dict_len.size() * sizeof(int32_t));
+        put(cd.dict.data(), cd.dict.size() * sizeof(uint64_t));
+    }
+}
+
+static bool header_ok(const FileHeader& h) {
+    return memcmp(h.magic, kMagic, 8) == 0 && h.nrows <= 0xFFFFFFFFull && h.table_rows <= 0xFFFFFFFFull &&
+           h.table_rows >= h.nrows && h.nkeycols >= 1 && h.nkeycols <= kMaxKeyCols && h.ncols == h.nkeycols && h.npos >= 0 &&
+           h.npos <= kMaxKeyBytes && h.nwords >= 1 && h.nwords <= kMaxWords &&
+           (!h.has_groups || (h.ndict >= 1 && h.ndict <= kGroupDictMax));
+}
+
+// Size of the whole descriptor, from its (validated) header.
+bool index_desc_size(const uint8_t* p, size_t n, size_t* need) {
+    if (n < sizeof(FileHeader)) return false;
+    FileHeader h;
+    memcpy(&h, p, sizeof h);
+    if (!header_ok(h)) return false;
+    size_t sz = sizeof h + (size_t)h.npos * (sizeof(uint16_t) + sizeof(uint64_t) + sizeof(int32_t)) +
+                (size_t)h.npos * kLutStride * sizeof(uint16_t);
+    if (h.has_groups) sz += (size_t)h.npos * (1 + 2 * sizeof(int32_t)) + (size_t)h.ndict * sizeof(uint64_t);
+    *need = sz;
+    return true;
+}
+
+// Fills ix->codec / nrows / nkeycols / sort_passes / table_rows from a descriptor; false when it is not one a
+// well-formed writer can have produced (the codec drives device-side table walks).
+bool index_desc_parse(const uint8_t* p, size_t n, cph_index* ix) {
+    size_t need = 0;
+    if (!index_desc_size(p, n, &need) || need != n) return false;
+    FileHeader h;
+    memcpy(&h, p, sizeof h);
+    size_t at = sizeof h;
+    auto get = [&](void* dst, size_t nb) {
+        memcpy(dst, p + at, nb);
+        at += nb;
+    };
+    CodecHost& cd = ix->codec;
+    cd = CodecHost{};
+    cd.ncols = h.ncols;
+    cd.npos = h.npos;
+    cd.nwords = h.nwords;
+    cd.key32 = h.key32 != 0;
+    memcpy(cd.col_start, h.col_start, sizeof h.col_start);
+    memcpy(cd.col_maxlen, h.col_maxlen, sizeof h.col_maxlen);
+    memcpy(cd.col_minlen, h.col_minlen, sizeof h.col_minlen);
+    memcpy(cd.word_bits, h.word_bits, sizeof h.word_bits);
+    memcpy(cd.word_states, h.word_states, sizeof h.word_states);
+    cd.radix.resize((size_t)h.npos);
+    cd.mult.resize((size_t)h.npos);
+    cd.word_of.resize((size_t)h.npos);
+    cd.lut.resize((size_t)h.npos * kLutStride);
+    get(cd.radix.data(), cd.radix.size() * sizeof(uint16_t));
+    get(cd.mult.data(), cd.mult.size() * sizeof(uint64_t));
+    get(cd.word_of.data(), cd.word_of.size() * sizeof(int32_t));
+    get(cd.lut.data(), cd.lut.size() * sizeof(uint16_t));
+    if (h.has_groups) {
+        cd.unit.resize((size_t)h.npos);
+        cd.dict_off.resize((size_t)h.npos);
+        cd.dict_len.resize((size_t)h.npos);
+        cd.dict.resize((size_t)h.ndict);
+        get(cd.unit.data(), cd.unit.size());
+        get(cd.dict_off.data(), cd.dict_off.size() * sizeof(int32_t));
+        get(cd.dict_len.data(), cd.dict_len.size() * sizeof(int32_t));
+        get(cd.dict.data(), cd.dict.size() * sizeof(uint64_t));
+        for (int q = 0; q < cd.npos; q++) {
+            const uint8_t u = cd.unit[(size_t)q];
+            if (u == kUnitHead) {
+                const int64_t off = cd.dict_off[(size_t)q], len = cd.dict_len[(size_t)q];
+                if (off < 0 || len < 1 || off + len > h.ndict || cd.radix[(size_t)q] != len) return false;
+                int span = 1;
+                while (span < kGroupSpan && q + span < cd.npos && cd.unit[(size_t)(q + span)] == kUnitAbsorbed) span++;
+                for (int64_t i = off; i < off + len; i++) {   // raw keys: well formed, in strict tuple order
+                    const uint64_t raw = cd.dict[(size_t)i], nvalid = raw >> 56;
+                    if (nvalid > (uint64_t)span || raw != group_raw(raw, nvalid)) return false;
+                    if (i > off && group_order_key(cd.dict[(size_t)i - 1], span) >= group_order_key(raw, span)) return false;
+                }
+            } else if (u == kUnitAbsorbed) {
+                if (q == 0 || cd.unit[(size_t)q - 1] == kUnitPos || cd.radix[(size_t)q] != 1) return false;
+            } else if (u != kUnitPos) {
+                return false;
+            }
+        }
+    }
+    if (cd.col_start[0] != 0 || cd.col_start[cd.ncols] != cd.npos) return false;
+    for (int c = 0; c < cd.ncols; c++)
+        if (cd.col_start[c + 1] < cd.col_start[c] || cd.col_maxlen[c] != cd.col_start[c + 1] - cd.col_start[c] ||
+            cd.col_minlen[c] < 0 || cd.col_minlen[c] > cd.col_maxlen[c])
+            return false;
+    for (int q = 0; q < cd.npos; q++)
+        if (cd.word_of[(size_t)q] < 0 || cd.word_of[(size_t)q] >= cd.nwords || cd.radix[(size_t)q] < 1 ||
+            cd.radix[(size_t)q] > ((cd.has_groups() && cd.unit[(size_t)q] == kUnitHead) ? kGroupDictMax : 257))
+            return false;
+    for (size_t i = 0; i < cd.lut.size(); i++)
+        if (cd.lut[i] != kLutInvalid && cd.lut[i] >= cd.radix[i / kLutStride]) return false;
+    {   // weights and state counts must be the ones codec_build derives from the radices
+        int q = cd.npos - 1;
+        for (int w = cd.nwords - 1; w >= 0; w--) {
+            unsigned __int128 m = 1;
+            for (; q >= 0 && cd.word_of[(size_t)q] == w; q--) {
+                if (cd.mult[(size_t)q] != (uint64_t)m) return false;
+                m *= cd.radix[(size_t)q];
+                if (m > ((unsigned __int128)1 << 63)) return false;
+            }
+            if (cd.word_states[w] != (uint64_t)m) return false;
+        }
+        if (q != -1) return false;   // word_of must be non-decreasing along the positions
+    }
+    for (int w = 0; w < cd.nwords; w++)
+        if (cd.word_bits[w] < 0 || cd.word_bits[w] > 64) return false;
+    if (cd.key32 && (cd.nwords != 1 || cd.word_bits[0] > 32)) return false;
+    ix->nrows = h.nrows;
+    ix->table_rows = h.table_rows;
+    ix->nkeycols = h.nkeycols;
+    ix->sort_passes = h.sort_passes;
+    return true;
+}
+
+// An index received as descriptor + device arrays (file, broadcast): payload check, unique scan, table decision.
+Status index_adopt_payload(cph_ctx* ctx, cph_index* ix) {
+    CPH_TRY(index_validate_payload(ctx, ix));
+    return finish_index(ctx, ix);
+}
+size_t index_code_bytes(const cph_index* ix) { return code_bytes(ix); }
+
 }  // namespace cph
 
 using namespace cph;
@@ -84,20 +325,7 @@ struct cph_groups_impl {
     void* h_block = nullptr;
 };
 
-// ---- file format ------------------------------------------------------------------------------------------
 namespace {
-constexpr char kMagic[8] = {'C', 'P', 'H', 'I', 'D', 'X', '2', '\n'};
-struct FileHeader {
-    char magic[8];
-    uint64_t nrows;
-    int32_t nkeycols, ncols, npos, nwords, key32, sort_passes;
-    int32_t has_groups, ndict;   // dictionary-coded groups: unit/dict_off/dict_len per position + ndict entries
-    int32_t col_start[kMaxKeyCols + 1];
-    int32_t col_maxlen[kMaxKeyCols];
-    int32_t col_minlen[kMaxKeyCols];
-    int32_t word_bits[kMaxWords];
-    uint64_t word_states[kMaxWords];
-};
 struct FileCloser {
     FILE* f;
     ~FileCloser() { if (f) fclose(f); }
@@ -189,6 +417,7 @@ CPH_API int32_t cph_index_select(cph_ctx* ctx, const cph_index* ix, const uint64
         nx->ctx = ctx;
         nx->nrows = n;
         nx->nkeycols = ix->nkeycols;
+        nx->table_rows = ix->table_rows;
         nx->codec = ix->codec;
         nx->sort_passes = 0;
         DevBuf pos, bad;
@@ -230,23 +459,8 @@ CPH_API int32_t cph_index_save(cph_ctx* ctx, const cph_index* ix, const char* pa
     if (!ctx || !ix || !path) return CPH_ERR_INVALID;
     if (hipSetDevice(ctx->device) != hipSuccess) return fail_with(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});
     auto run = [&]() -> Status {
-        const CodecHost& cd = ix->codec;
-        FileHeader h{};
-        memcpy(h.magic, kMagic, 8);
-        h.nrows = ix->nrows;
-        h.nkeycols = ix->nkeycols;
-        h.ncols = cd.ncols;
-        h.npos = cd.npos;
-        h.nwords = cd.nwords;
-        h.key32 = cd.key32 ? 1 : 0;
-        h.sort_passes = ix->sort_passes;
-        h.has_groups = cd.has_groups() ? 1 : 0;
-        h.ndict = (int32_t)cd.dict.size();
-        memcpy(h.col_start, cd.col_start, sizeof h.col_start);
-        memcpy(h.col_maxlen, cd.col_maxlen, sizeof h.col_maxlen);
-        memcpy(h.col_minlen, cd.col_minlen, sizeof h.col_minlen);
-        memcpy(h.word_bits, cd.word_bits, sizeof h.word_bits);
-        memcpy(h.word_states, cd.word_states, sizeof h.word_states);
+        std::vector<uint8_t> desc;
+        index_desc_serialize(ix, &desc);
         const size_t cb = (size_t)ix->nrows * code_bytes(ix), pb = (size_t)ix->nrows * sizeof(uint32_t);
         std::vector<uint8_t> host(cb + pb);
         if (cb) CPH_HIP_TRY(hipMemcpyAsync(host.data(), ix->sorted_codes.get(), cb, hipMemcpyDeviceToHost, ctx->stream));
@@ -255,23 +469,11 @@ CPH_API int32_t cph_index_save(cph_ctx* ctx, const cph_index* ix, const char* pa
         FILE* f = fopen(path, "wb");
         if (!f) return {CPH_ERR_INVALID, std::string("cannot create ") + path};
         bool ok = true;
-        {
-            FileCloser fc{f};
-            auto put = [&](const void* p, size_t nb) { ok = ok && (nb == 0 || fwrite(p, 1, nb, f) == nb); };
-            put(&h, sizeof h);
-            put(cd.radix.data(), cd.radix.size() * sizeof(uint16_t));
-            put(cd.mult.data(), cd.mult.size() * sizeof(uint64_t));
-            put(cd.word_of.data(), cd.word_of.size() * sizeof(int32_t));
-            put(cd.lut.data(), cd.lut.size() * sizeof(uint16_t));
-            if (cd.has_groups()) {
-                put(cd.unit.data(), cd.unit.size());
-                put(cd.dict_off.data(), cd.dict_off.size() * sizeof(int32_t));
-                put(cd.dict_len.data(), cd.dict_len.size() * sizeof(int32_t));
-                put(cd.dict.data(), cd.dict.size() * sizeof(uint64_t));
-            }
-            put(host.data(), host.size());
-            ok = ok && fflush(f) == 0;
-        }
+        auto put = [&](const void* p, size_t nb) { ok = ok && (nb == 0 || fwrite(p, 1, nb, f) == nb); };
+        put(desc.data(), desc.size());
+        put(host.data(), host.size());
+        ok = ok && fflush(f) == 0;
+        ok = (fclose(f) == 0) && ok;   // an error that only shows on close (full disk, NFS) is a failed save too
         if (!ok) {   // the reference removes a partially written file (csvplus.go:663-671)
             remove(path);
             return {CPH_ERR_INVALID, std::string("short write to ") + path};
@@ -292,93 +494,20 @@ CPH_API int32_t cph_index_load(cph_ctx* ctx, const char* path, cph_index** out) 
         FILE* f = fopen(path, "rb");
         if (!f) return {CPH_ERR_INVALID, std::string("cannot open ") + path};
         FileCloser fc{f};
-        FileHeader h{};
         const Status bad{CPH_ERR_INVALID, std::string(path) + ": not a csvplus_hip index file (or truncated)"};
-        if (fread(&h, 1, sizeof h, f) != sizeof h || memcmp(h.magic, kMagic, 8) != 0) return bad;
-        if (h.nrows > 0xFFFFFFFFull || h.nkeycols < 1 || h.nkeycols > kMaxKeyCols || h.ncols != h.nkeycols || h.npos < 0 ||
-            h.npos > kMaxKeyBytes || h.nwords < 1 || h.nwords > kMaxWords)
+        // the descriptor's size follows from its header: read the header, then the rest of the descriptor
+        std::vector<uint8_t> desc(sizeof(FileHeader));
+        if (fread(desc.data(), 1, desc.size(), f) != desc.size()) return bad;
+        size_t need = 0;
+        if (!index_desc_size(desc.data(), desc.size(), &need)) return bad;
+        desc.resize(need);
+        if (need > sizeof(FileHeader) && fread(desc.data() + sizeof(FileHeader), 1, need - sizeof(FileHeader), f) != need - sizeof(FileHeader))
             return bad;
-        CodecHost& cd = ix->codec;
-        cd.ncols = h.ncols;
-        cd.npos = h.npos;
-        cd.nwords = h.nwords;
-        cd.key32 = h.key32 != 0;
-        memcpy(cd.col_start, h.col_start, sizeof h.col_start);
-        memcpy(cd.col_maxlen, h.col_maxlen, sizeof h.col_maxlen);
-        memcpy(cd.col_minlen, h.col_minlen, sizeof h.col_minlen);
-        memcpy(cd.word_bits, h.word_bits, sizeof h.word_bits);
-        memcpy(cd.word_states, h.word_states, sizeof h.word_states);
-        cd.radix.resize((size_t)h.npos);
-        cd.mult.resize((size_t)h.npos);
-        cd.word_of.resize((size_t)h.npos);
-        cd.lut.resize((size_t)h.npos * kLutStride);
-        auto get = [&](void* p, size_t nb) { return nb == 0 || fread(p, 1, nb, f) == nb; };
-        if (!get(cd.radix.data(), cd.radix.size() * sizeof(uint16_t)) || !get(cd.mult.data(), cd.mult.size() * sizeof(uint64_t)) ||
-            !get(cd.word_of.data(), cd.word_of.size() * sizeof(int32_t)) || !get(cd.lut.data(), cd.lut.size() * sizeof(uint16_t)))
-            return bad;
-        if (h.has_groups) {
-            if (h.ndict < 1 || h.ndict > kGroupDictMax) return bad;
-            cd.unit.resize((size_t)h.npos);
-            cd.dict_off.resize((size_t)h.npos);
-            cd.dict_len.resize((size_t)h.npos);
-            cd.dict.resize((size_t)h.ndict);
-            if (!get(cd.unit.data(), cd.unit.size()) || !get(cd.dict_off.data(), cd.dict_off.size() * sizeof(int32_t)) ||
-                !get(cd.dict_len.data(), cd.dict_len.size() * sizeof(int32_t)) || !get(cd.dict.data(), cd.dict.size() * sizeof(uint64_t)))
-                return bad;
-            for (int p = 0; p < cd.npos; p++) {
-                const uint8_t u = cd.unit[(size_t)p];
-                if (u == kUnitHead) {
-                    const int64_t off = cd.dict_off[(size_t)p], len = cd.dict_len[(size_t)p];
-                    if (off < 0 || len < 1 || off + len > h.ndict || cd.radix[(size_t)p] != len) return bad;
-                    int span = 1;
-                    while (span < kGroupSpan && p + span < cd.npos && cd.unit[(size_t)(p + span)] == kUnitAbsorbed) span++;
-                    for (int64_t i = off; i < off + len; i++) {   // raw keys: well formed, in strict tuple order
-                        const uint64_t raw = cd.dict[(size_t)i], nvalid = raw >> 56;
-                        if (nvalid > (uint64_t)span || raw != group_raw(raw, nvalid)) return bad;
-                        if (i > off && group_order_key(cd.dict[(size_t)i - 1], span) >= group_order_key(raw, span)) return bad;
-                    }
-                } else if (u == kUnitAbsorbed) {
-                    if (p == 0 || cd.unit[(size_t)p - 1] == kUnitPos || cd.radix[(size_t)p] != 1) return bad;
-                } else if (u != kUnitPos) {
-                    return bad;
-                }
-            }
-        }
-        // the codec drives device-side table walks: refuse values a well-formed file cannot contain
-        if (cd.col_start[0] != 0 || cd.col_start[cd.ncols] != cd.npos) return bad;
-        for (int c = 0; c < cd.ncols; c++)
-            if (cd.col_start[c + 1] < cd.col_start[c] || cd.col_maxlen[c] != cd.col_start[c + 1] - cd.col_start[c] ||
-                cd.col_minlen[c] < 0 || cd.col_minlen[c] > cd.col_maxlen[c])
-                return bad;
-        for (int p = 0; p < cd.npos; p++)
-            if (cd.word_of[(size_t)p] < 0 || cd.word_of[(size_t)p] >= cd.nwords || cd.radix[(size_t)p] < 1 ||
-                cd.radix[(size_t)p] > ((cd.has_groups() && cd.unit[(size_t)p] == kUnitHead) ? kGroupDictMax : 257))
-                return bad;
-        for (size_t i = 0; i < cd.lut.size(); i++)
-            if (cd.lut[i] != kLutInvalid && cd.lut[i] >= cd.radix[i / kLutStride]) return bad;
-        {   // weights and state counts must be the ones codec_build derives from the radices
-            int p = cd.npos - 1;
-            for (int w = cd.nwords - 1; w >= 0; w--) {
-                unsigned __int128 m = 1;
-                for (; p >= 0 && cd.word_of[(size_t)p] == w; p--) {
-                    if (cd.mult[(size_t)p] != (uint64_t)m) return bad;
-                    m *= cd.radix[(size_t)p];
-                    if (m > ((unsigned __int128)1 << 63)) return bad;
-                }
-                if (cd.word_states[w] != (uint64_t)m) return bad;
-            }
-            if (p != -1) return bad;   // word_of must be non-decreasing along the positions
-        }
-        for (int w = 0; w < cd.nwords; w++)
-            if (cd.word_bits[w] < 0 || cd.word_bits[w] > 64) return bad;
-        if (cd.key32 && (cd.nwords != 1 || cd.word_bits[0] > 32)) return bad;
+        if (!index_desc_parse(desc.data(), desc.size(), ix)) return bad;
         ix->ctx = ctx;
-        ix->nrows = h.nrows;
-        ix->nkeycols = h.nkeycols;
-        ix->sort_passes = h.sort_passes;
         const size_t cb = (size_t)ix->nrows * code_bytes(ix), pb = (size_t)ix->nrows * sizeof(uint32_t);
         std::vector<uint8_t> host(cb + pb);
-        if (!get(host.data(), host.size())) return bad;
+        if (host.size() && fread(host.data(), 1, host.size(), f) != host.size()) return bad;
         uint8_t extra;
         if (fread(&extra, 1, 1, f) != 0) return bad;   // trailing bytes
         CPH_TRY(ix->sorted_codes.alloc(&ctx->pool, cb));
@@ -386,6 +515,7 @@ CPH_API int32_t cph_index_load(cph_ctx* ctx, const char* path, cph_index** out) 
         if (cb) CPH_HIP_TRY(hipMemcpyAsync(ix->sorted_codes.get(), host.data(), cb, hipMemcpyHostToDevice, ctx->stream));
         if (pb) CPH_HIP_TRY(hipMemcpyAsync(ix->perm.get(), host.data() + cb, pb, hipMemcpyHostToDevice, ctx->stream));
         CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));   // `host` is pageable and goes away
+        CPH_TRY(index_validate_payload(ctx, ix));
         return finish_index(ctx, ix);
     };
     Status s = run();

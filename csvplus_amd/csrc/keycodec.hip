@@ -35,12 +35,18 @@ constexpr int kStatsThreads = 256;
 constexpr int kStatsRows = 8;     // rows per lane and wave-tile (codec_device.hpp: wave_rows / wave_spans)
 
 // B = uint32_t: 32-bit offsets or fixed width (one register per row); uint64_t: any column.
+// Presence is recorded as one BYTE flag per (position, byte value) in LDS with plain stores — no read-test-atomic
+// per key byte: this kernel is bound by instruction issue, not by HBM — and folded into the 256-bit masks once per
+// workgroup at the end.
 template <class B>
 __global__ __launch_bounds__(kStatsThreads) void k_col_stats(DevCol col, uint32_t* __restrict__ g_minmax,
                                                             uint32_t* __restrict__ g_mask) {
-    __shared__ uint32_t s_mask[kMaxKeyBytes * 8];
+    __shared__ __attribute__((aligned(16))) uint8_t s_flag[kMaxKeyBytes * 256];
     __shared__ uint32_t s_min, s_max;
-    for (int i = threadIdx.x; i < kMaxKeyBytes * 8; i += kStatsThreads) s_mask[i] = 0;
+    {
+        uint4* z = reinterpret_cast<uint4*>(s_flag);
+        for (int i = threadIdx.x; i < kMaxKeyBytes * 256 / 16; i += kStatsThreads) z[i] = make_uint4(0, 0, 0, 0);
+    }
     if (threadIdx.x == 0) { s_min = 0xFFFFFFFFu; s_max = 0; }
     __syncthreads();
 
@@ -77,9 +83,7 @@ __global__ __launch_bounds__(kStatsThreads) void k_col_stats(DevCol col, uint32_
                 for (int k = 0; k < kStatsRows; k++) {
                     const uint32_t half = b < 4 ? (uint32_t)cur[k] : (uint32_t)(cur[k] >> 32);
                     const uint32_t byte = (half >> (8 * (b & 3))) & 0xFFu;
-                    const int idx = q * 8 + (int)(byte >> 5);
-                    const uint32_t bit = 1u << (byte & 31);
-                    if ((uint32_t)q < sp.len[k] && !(s_mask[idx] & bit)) atomicOr(&s_mask[idx], bit);
+                    if ((uint32_t)q < sp.len[k]) s_flag[q * 256 + (int)byte] = 1;
                 }
             }
         }
@@ -88,8 +92,17 @@ __global__ __launch_bounds__(kStatsThreads) void k_col_stats(DevCol col, uint32_
     mx = wave_max(mx);
     if (lane_id() == 0) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); }
     __syncthreads();
-    for (int i = threadIdx.x; i < kMaxKeyBytes * 8; i += kStatsThreads)
-        if (s_mask[i]) atomicOr(&g_mask[i], s_mask[i]);
+    const int npos = s_max < (uint32_t)kMaxKeyBytes ? (int)s_max : kMaxKeyBytes;
+    for (int i = threadIdx.x; i < npos * 8; i += kStatsThreads) {   // mask word i = flags [32 i, 32 i + 32)
+        const uint32_t* f = reinterpret_cast<const uint32_t*>(s_flag + 32 * i);
+        uint32_t bits = 0;
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            const uint32_t v = f[w];   // four flags (0 / 1 each)
+            bits |= ((v & 1u) | ((v >> 7) & 2u) | ((v >> 14) & 4u) | ((v >> 21) & 8u)) << (4 * w);
+        }
+        if (bits) atomicOr(&g_mask[i], bits);
+    }
     if (threadIdx.x == 0) { atomicMin(&g_minmax[0], s_min); atomicMax(&g_minmax[1], s_max); }
 }
 

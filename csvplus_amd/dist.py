@@ -1,71 +1,117 @@
-"""Multi-GPU exchange for the sharded Join: one process per GPU,
-probe rows split into contiguous ranges, build side replicated, and an
-allgatherv of the per-rank match lists so that every rank ends up with the
-whole joined row-id list in the reference's emission order.
+"""Multi-GPU exchange for the sharded Join: one process per GPU, probe rows split into
+contiguous ranges, build side replicated (or broadcast), and an allgatherv of the per-rank row-id lists so
+that every rank ends up with the whole joined list in the reference's emission order.
 
-RCCL has no native allgatherv.  The exchange is: one `all_gather` of the per-rank
-counts, then ONE grouped batch of point-to-point sends/receives
-(`batch_isend_irecv` = ncclGroupStart ... ncclSend/ncclRecv ... ncclGroupEnd):
-every rank sends its shard straight to each peer and receives each peer's shard
-into its slot of the output buffer.  On the 8-GPU xGMI mesh every pair of GPUs
-has its own link, so the N-1 transfers of a rank run concurrently, one per link —
-a ring all-gather would push (N-1)/N of the data through every single link instead.
-The same code runs on the gloo backend (CPU tests).
+The exchange itself lives behind the C ABI (`cph_dist_*`, csrc/dist.hip: RCCL count all-gather + ONE
+grouped send/recv batch for all arrays of a result).  This module is the thin host side:
+
+  connect(ctx)            ships RCCL's unique id from rank 0 to the other ranks over whatever
+                          torch.distributed group the launcher set up, then cph_dist_create
+  chain_allgather(...)    ChainResult of this rank -> ChainResult of the whole stream (torch views of the
+                          library's gathered device arrays)
+
+`allgatherv_many` is the same exchange written against torch.distributed (count all_gather + one
+batch_isend_irecv for all tensors).  It is the transport of the CPU tests (gloo) and of the debug mode in
+which several ranks share one GPU — RCCL refuses that — never of a real multi-GPU run.
 """
 from __future__ import annotations
 
+from . import _native as N
 
-def allgatherv(t, group=None, single_rank_shortcut: bool = True):
-    """Concatenation over ranks (rank order) of 1-D tensor `t`, whose length may differ per rank.
-    Returns (gathered, counts).  single_rank_shortcut=False sends a 1-rank group through the collectives
-    too (used by the 1-GPU RCCL smoke test)."""
+
+def connect(ctx: N.Context, group=None) -> N.Dist:
+    """One cph_dist per rank.  torch.distributed is used for exactly one thing: moving the 128-byte id."""
+    import torch.distributed as dist
+
+    if not dist.is_initialized():
+        return N.Dist.create(ctx, N.Dist.unique_id(ctx), 0, 1)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    box = [N.Dist.unique_id(ctx) if rank == 0 else None]
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    dist.broadcast_object_list(box, src=src, group=group)
+    return N.Dist.create(ctx, box[0], rank, world)
+
+
+def chain_allgather(d: N.Dist, res, device):
+    """res: engine.ChainResult of this rank's row range -> ChainResult of all ranks' rows, emission order.
+    Returns (ChainResult, counts)."""
+    from .engine import ChainResult, device_view
+
+    ch = res.keep[0]
+    g = d.chain_allgather(ch)
+    ptrs = g.data_ptrs
+    if g.identity:
+        stream, rows = None, ptrs
+    else:
+        stream, rows = device_view(ptrs[0], g.total, "<i8", g, device), ptrs[1:]
+    out = ChainResult(stream, [device_view(p, g.total, "<i4", g, device) for p in rows], g.total, keep=(g,),
+                      stream_base=g.stream_base if g.identity else 0)
+    return out, g.counts
+
+
+# ---- the same exchange over torch.distributed (gloo on CPU; debug) ----------------------------------------------
+def allgatherv_many(ts, group=None, single_rank_shortcut: bool = True):
+    """Concatenation over ranks (rank order) of 1-D tensors that all have the SAME length on a rank (the
+    arrays of one join result).  One count exchange and one grouped send/recv batch for all of them.
+    Returns ([gathered...], counts)."""
     import torch
     import torch.distributed as dist
 
+    ts = list(ts)
+    n_local = int(ts[0].numel())
+    assert all(int(t.numel()) == n_local for t in ts)
     if not dist.is_initialized() or (dist.get_world_size(group) == 1 and single_rank_shortcut):
-        return t, [int(t.numel())]
+        return ts, [n_local]
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    if dist.get_backend(group) == "gloo" and t.is_cuda:   # debug path (several ranks sharing one GPU)
-        out, counts = allgatherv(t.cpu(), group)
-        return out.to(t.device), counts
-    n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
-    counts_t = torch.zeros(world, dtype=torch.int64, device=t.device)
-    dist.all_gather_into_tensor(counts_t, n, group=group)
-    counts = [int(c) for c in counts_t.tolist()]
+    if dist.get_backend(group) == "gloo" and ts[0].is_cuda:   # debug path (several ranks sharing one GPU)
+        outs, counts = allgatherv_many([t.cpu() for t in ts], group)
+        return [o.to(ts[0].device) for o in outs], counts
+    dev = ts[0].device
+    counts_t = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts_t, torch.tensor([n_local], dtype=torch.int64, device=dev), group=group)
+    counts = [int(c) for c in counts_t.tolist()]   # the one host wait of the exchange
     offs = [0]
     for c in counts:
         offs.append(offs[-1] + c)
-    out = torch.empty(offs[-1], dtype=t.dtype, device=t.device)
-    t = t.contiguous()
-    if len(set(counts)) == 1:   # equal shards (e.g. every stream row joined): one plain ncclAllGather
+    outs = [torch.empty(offs[-1], dtype=t.dtype, device=dev) for t in ts]
+    ts = [t.contiguous() for t in ts]
+    if len(set(counts)) == 1:   # equal shards (e.g. every stream row joined): plain all-gathers
         if counts[0]:
-            dist.all_gather_into_tensor(out, t, group=group)
-        return out, counts
-    if counts[rank]:
-        out[offs[rank]:offs[rank + 1]].copy_(t)
+            for o, t in zip(outs, ts):
+                dist.all_gather_into_tensor(o, t, group=group)
+        return outs, counts
     ops = []
-    for peer in range(world):
-        if peer == rank:
-            continue
-        gpeer = dist.get_global_rank(group, peer) if group is not None else peer
+    for o, t in zip(outs, ts):
         if counts[rank]:
-            ops.append(dist.P2POp(dist.isend, t, gpeer, group=group))
-        if counts[peer]:
-            ops.append(dist.P2POp(dist.irecv, out[offs[peer]:offs[peer + 1]], gpeer, group=group))
+            o[offs[rank]:offs[rank + 1]].copy_(t)
+        for peer in range(world):
+            if peer == rank:
+                continue
+            gpeer = dist.get_global_rank(group, peer) if group is not None else peer
+            if counts[rank]:
+                ops.append(dist.P2POp(dist.isend, t, gpeer, group=group))
+            if counts[peer]:
+                ops.append(dist.P2POp(dist.irecv, o[offs[peer]:offs[peer + 1]], gpeer, group=group))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
-    return out, counts
+    return outs, counts
+
+
+def allgatherv(t, group=None, single_rank_shortcut: bool = True):
+    """One tensor through allgatherv_many: (gathered, counts)."""
+    outs, counts = allgatherv_many([t], group, single_rank_shortcut)
+    return outs[0], counts
 
 
 def sharded_chained_join(total_stream_rows: int, local_join, group=None, exchange: bool = True):
-    """Runs `local_join(begin, end)` on this rank's row range and (optionally) allgathers
-    the resulting tuples.
+    """Runs `local_join(begin, end)` on this rank's row range and (optionally) allgathers the resulting tuples
+    over torch.distributed.
 
-    local_join(begin, end) -> (stream_row, a_row, b_row) 1-D tensors for stream rows
-    [begin, end), with stream_row holding GLOBAL row numbers.  Returned: the three
-    gathered tensors (emission order of the whole stream) and the per-rank counts."""
+    local_join(begin, end) -> (stream_row, a_row, b_row) 1-D tensors for stream rows [begin, end), with
+    stream_row holding GLOBAL row numbers.  Returned: the three gathered tensors (emission order of the whole
+    stream) and the per-rank counts."""
     import torch.distributed as dist
 
     from .engine import shard_range
@@ -76,7 +122,5 @@ def sharded_chained_join(total_stream_rows: int, local_join, group=None, exchang
     s, a, b = local_join(begin, end)
     if not exchange or world == 1:
         return s, a, b, [int(s.numel())]
-    gs, counts = allgatherv(s, group)
-    ga, _ = allgatherv(a, group)
-    gb, _ = allgatherv(b, group)
+    (gs, ga, gb), counts = allgatherv_many([s, a, b], group)
     return gs, ga, gb, counts

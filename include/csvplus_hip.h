@@ -262,6 +262,61 @@ CPH_API int32_t cph_join_chain(cph_ctx* ctx, const cph_chain_step* steps, int32_
                                int32_t out_mem, cph_chain** out);
 CPH_API void    cph_chain_release(cph_chain* chain);
 
+/* ---- multi-GPU: the exchange step of the row-range sharded Join ----- */
+
+/*
+ * One process (rank) per GPU joins a contiguous range of the stream rows against replicated build
+ * sides; concatenating the per-rank row-id lists in rank order gives the reference's emission order
+ * (stream order, csvplus.go:553-567).  A cph_dist wraps the communicator that moves those lists:
+ * RCCL over xGMI (librccl.so is loaded on first use — the library does not link against it).
+ *   rank 0:  cph_dist_unique_id(ctx, id)  -> ship the CPH_DIST_ID_BYTES bytes to every rank by any side
+ *            channel the host program has (a Go host: its own RPC; torch: broadcast_object_list)
+ *   all:     cph_dist_create(ctx, id, rank, nranks, &d)            (collective: ncclCommInitRank)
+ * Every call below is collective: all ranks call it, in the same order, each on its own ctx.
+ * Work is enqueued on the ctx's stream; the only host wait is for 24 bytes of counts per rank.
+ */
+#define CPH_DIST_ID_BYTES 128
+#define CPH_MAX_GATHER    8
+typedef struct cph_dist cph_dist;
+
+CPH_API int32_t cph_dist_unique_id(cph_ctx* ctx, uint8_t* id /* CPH_DIST_ID_BYTES */);
+CPH_API int32_t cph_dist_create(cph_ctx* ctx, const uint8_t* id, int32_t rank, int32_t nranks, cph_dist** out);
+/* Test transport: the `nranks` ranks of `group` are THREADS of this process (one ctx each) sharing a GPU;
+ * the collectives rendezvous in host memory and copy device to device.  Same code path above the transport. */
+CPH_API int32_t cph_dist_create_loopback(cph_ctx* ctx, const char* group, int32_t rank, int32_t nranks, cph_dist** out);
+CPH_API void    cph_dist_destroy(cph_dist* d);
+CPH_API int32_t cph_dist_rank(const cph_dist* d);
+CPH_API int32_t cph_dist_size(const cph_dist* d);
+
+/* Result of an allgatherv: data[a] (device memory of this rank's ctx, library-owned) holds `total`
+ * elements of array a — rank 0's, then rank 1's, ...; counts / displs (host) say where each rank's begin.
+ * Valid in stream order on the ctx's stream (cph_ctx_synchronize before reading from the host). */
+typedef struct {
+    uint64_t        total;
+    int32_t         narrays, nranks;
+    const uint64_t* counts;
+    const uint64_t* displs;
+    void*           data[CPH_MAX_GATHER];
+} cph_gathered;
+
+/* allgatherv of `narrays` device arrays that all hold `count` elements on this rank (elem_bytes[a] each):
+ * ONE count exchange and ONE grouped send/recv batch for all arrays. */
+CPH_API int32_t cph_dist_allgatherv(cph_dist* d, const void* const* send, const int32_t* elem_bytes, int32_t narrays,
+                                    uint64_t count, cph_gathered** out);
+CPH_API void    cph_gathered_release(cph_gathered* g);
+
+/* The same for a chain result in device memory (cph_join_chain(..., probe_base, CPH_MEM_DEVICE)): gathers
+ * build_row[0..nsteps) — data[0..nsteps) when *identity == 1: every rank's rows are its whole contiguous range,
+ * so gathered row m is stream row *stream_base + m — or stream_row first (data[0], uint64) and the build rows
+ * behind it (data[1..nsteps]) when some stream row of some rank did not join. */
+CPH_API int32_t cph_dist_chain_allgather(cph_dist* d, const cph_chain* chain, uint64_t probe_base, cph_gathered** out,
+                                         int32_t* identity, uint64_t* stream_base);
+
+/* Build side, option B: rank `root` built `root_index` (others pass NULL); every other rank
+ * receives an equal index (*out; NULL on the root) — descriptor, sorted codes and perm travel by ncclBroadcast
+ * (12 bytes per row for one-word 64-bit codes) instead of every rank sorting the same table. */
+CPH_API int32_t cph_dist_index_broadcast(cph_dist* d, const cph_index* root_index, int32_t root, cph_index** out);
+
 /* ---- streaming Join of a host-resident stream (BASELINE config 5) -------------- */
 
 /*

@@ -1,0 +1,178 @@
+"""The exchange behind the C ABI (cph_dist_*, csrc/dist.hip).
+
+  * RCCL transport with ONE rank through the C entry points on the GPU box (unique id, ncclCommInitRank,
+    count all-gather, grouped exchange, broadcast): catches loading / dtype / initialisation problems.
+  * The multi-rank control flow (counts, displacements, unequal and empty shards, the identity rule, index
+    broadcast) through the in-process loopback transport: the ranks are THREADS, each with its own ctx,
+    sharing the one GPU — same code above the transport as a real N-GPU run.  Every rank's gathered result
+    is compared with the oracle's join over the WHOLE stream (csvplus.go:553-567: stream order).
+N > 1 over real xGMI links is not reachable from here and stays unmeasured.
+"""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from csvplus_amd import Context, DeviceIndex, _native as N, datagen as dg, join_chain
+from csvplus_amd.engine import shard_range
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+
+def dev_array(ptr, n, dtype):
+    """Host copy of a device array of the library."""
+    if n == 0 or not ptr:
+        return np.empty(0, dtype=dtype)
+    from csvplus_amd.engine import device_view
+
+    t = device_view(ptr, n, {np.uint32: "<i4", np.uint64: "<i8"}[dtype], None, torch.device("cuda", 0))
+    return t.cpu().numpy().view(dtype).copy()
+
+
+def oracle_whole(cust, prod, ords_cols):
+    oa, ob = orc.OracleIndex([cust]), orc.OracleIndex([prod])
+    j1 = oa.join([ords_cols[0]])
+    j2 = ob.join([ords_cols[1]], row_sel=j1["probe_idx"].astype(np.uint32))
+    pick = j2["probe_idx"].astype(np.int64)
+    return j1["probe_idx"][pick].astype(np.uint64), j1["build_row"][pick], j2["build_row"]
+
+
+def run_ranks(world, fn):
+    """fn(rank) on `world` threads; re-raises the first failure."""
+    errs = [None] * world
+
+    def body(r):
+        try:
+            fn(r)
+        except BaseException as e:   # noqa: BLE001
+            errs[r] = e
+
+    ths = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=600)
+    for e in errs:
+        if e is not None:
+            raise e
+
+
+def test_rccl_single_rank_through_the_c_abi(ctx):
+    d = N.Dist.create(ctx, N.Dist.unique_id(ctx), 0, 1)
+    assert (d.rank, d.size) == (0, 1)
+    a = torch.arange(1000, dtype=torch.int64, device="cuda") * 3
+    b = torch.arange(1000, dtype=torch.int32, device="cuda") + 7
+    torch.cuda.synchronize()
+    g = d.allgatherv([a.data_ptr(), b.data_ptr()], [8, 4], 1000)
+    ctx.synchronize()
+    assert g.total == 1000 and g.counts == [1000] and g.displs == [0]
+    np.testing.assert_array_equal(dev_array(g.data_ptrs[0], 1000, np.uint64), a.cpu().numpy().view(np.uint64))
+    np.testing.assert_array_equal(dev_array(g.data_ptrs[1], 1000, np.uint32), b.cpu().numpy().view(np.uint32))
+    g.release()
+    g = d.allgatherv([0, 0], [8, 4], 0)   # empty contribution
+    assert g.total == 0
+    g.release()
+    # a chain result (identity and not), and the root side of an index broadcast
+    cust, prod = dg.customers(5000)["id"], dg.products(80)["prod_id"]
+    ia, ib = DeviceIndex(ctx, [cust], unique=True), DeviceIndex(ctx, [prod], unique=True)
+    for domain in (5000, 10000):   # every row joins / about half of them
+        o = dg.orders(30_000, domain, 80)
+        cols = [o["cust_id"], o["prod_id"]]
+        ch = join_chain(ctx, [(ia, [cols[0]]), (ib, [cols[1]])], probe_base=1000, out_mem=N.CPH_MEM_DEVICE)
+        g = d.chain_allgather(ch)
+        ctx.synchronize()
+        es, ea, eb = oracle_whole(cust, prod, cols)
+        assert g.total == len(es) and g.identity == (domain == 5000)
+        if g.identity:
+            assert g.stream_base == 1000
+            rows = g.data_ptrs
+        else:
+            np.testing.assert_array_equal(dev_array(g.data_ptrs[0], g.total, np.uint64), es + 1000)
+            rows = g.data_ptrs[1:]
+        np.testing.assert_array_equal(dev_array(rows[0], g.total, np.uint32), ea)
+        np.testing.assert_array_equal(dev_array(rows[1], g.total, np.uint32), eb)
+        g.release()
+        ch.release()
+    assert d.index_broadcast(ia, root=0) is ia
+    d.close()
+
+
+@pytest.mark.parametrize("world,domain_factor", [(2, 1), (3, 2), (3, 1)])
+def test_loopback_sharded_chain_matches_oracle(world, domain_factor):
+    """Each rank joins its contiguous row range against replicated indexes; the gathered lists of EVERY rank
+    equal the oracle's join over the whole stream.  domain_factor 2: half of the customer ids miss (unequal
+    counts, explicit stream rows); rank 1 of 3 additionally gets rows that never join (an empty contribution)."""
+    m, nc, npd = 50_001, 4000, 60
+    cust, prod = dg.customers(nc)["id"], dg.products(npd)["prod_id"]
+    o = dg.orders(m, nc * domain_factor, npd)
+    cols = [o["cust_id"], o["prod_id"]]
+    empty_rank = 1 if (world == 3 and domain_factor == 2) else None
+    if empty_rank is not None:   # that rank's customers all miss: ids from a disjoint domain
+        b, e = shard_range(m, empty_rank, world)
+        miss = dg.column(dg.UNIFORM, m, nc, encoding=dg.FIXED8, base=50_000_000, seed=99)
+        vals = cols[0].values()
+        vals[b:e] = miss.values()[b:e]
+        from csvplus_amd import StrCol
+        cols[0] = StrCol.from_values(vals)
+    es, ea, eb = oracle_whole(cust, prod, cols)
+    group = f"chain-{world}-{domain_factor}"
+
+    def rank_body(r):
+        ctx = Context(0)
+        d = N.Dist.loopback(ctx, group, r, world)
+        ia, ib = DeviceIndex(ctx, [cust], unique=True), DeviceIndex(ctx, [prod], unique=True)
+        b, e = shard_range(m, r, world)
+        ch = join_chain(ctx, [(ia, [cols[0].slice(b, e)]), (ib, [cols[1].slice(b, e)])], probe_base=b,
+                        out_mem=N.CPH_MEM_DEVICE)
+        if empty_rank == r:
+            assert ch.nrows == 0
+        g = d.chain_allgather(ch)
+        ctx.synchronize()
+        assert g.total == len(es) and sum(g.counts) == g.total and len(g.counts) == world
+        assert g.identity == (domain_factor == 1)
+        if g.identity:
+            assert g.stream_base == 0 and g.total == m
+            rows = g.data_ptrs
+        else:
+            np.testing.assert_array_equal(dev_array(g.data_ptrs[0], g.total, np.uint64), es)
+            rows = g.data_ptrs[1:]
+        np.testing.assert_array_equal(dev_array(rows[0], g.total, np.uint32), ea)
+        np.testing.assert_array_equal(dev_array(rows[1], g.total, np.uint32), eb)
+        g.release()
+        ch.release()
+        d.close()
+        ctx.close()
+
+    run_ranks(world, rank_body)
+
+
+def test_loopback_index_broadcast_option_b():
+    """Build side option B: rank 0 sorts, ranks 1..2 receive descriptor + sorted codes + perm and join with it."""
+    world, nc = 3, 20_000
+    cust = dg.customers(nc)["id"]
+    varkeys = dg.varkeys(30_000)                      # duplicate keys, dictionary-coded groups in the codec
+    probe = dg.orders(10_000, 2 * nc, 10)["cust_id"]
+    ou, ov = orc.OracleIndex([cust]), orc.OracleIndex([varkeys])
+    ej = ou.join([probe])
+
+    def rank_body(r):
+        ctx = Context(0)
+        d = N.Dist.loopback(ctx, "bcast", r, world)
+        for col, oix, unique in ((cust, ou, True), (varkeys, ov, False)):
+            mine = DeviceIndex(ctx, [col], unique=unique) if r == 0 else None
+            ix = d.index_broadcast(mine, root=0)
+            assert ix.nrows == col.nrows
+            np.testing.assert_array_equal(ix.perm(), oix.perm)
+            assert ix.info()["code_bits"] > 0
+            if unique:
+                mt = ix.probe([probe])
+                np.testing.assert_array_equal(mt.probe_idx, ej["probe_idx"])
+                np.testing.assert_array_equal(mt.build_row, ej["build_row"])
+                mt.release()
+            ix.close()
+        d.close()
+        ctx.close()
+
+    run_ranks(world, rank_body)

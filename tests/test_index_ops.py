@@ -177,3 +177,41 @@ def test_gpu_save_load_roundtrip(ctx, tmp_path, shape):
     for name in ("short.cph", "magic.cph", "missing.cph"):
         with pytest.raises(Exception):
             N.DeviceIndex.load(ctx, str(tmp_path / name))
+
+
+@pytest.mark.gpu
+def test_gpu_load_rejects_corrupt_payload(ctx, tmp_path):
+    """A well-formed descriptor followed by a damaged payload (codes outside the codec's state space or out of
+    order, perm that is not a set of row ids) must be refused: it would otherwise drive table builds and the
+    caller's gathers out of bounds (the reference's gob decode is memory-safe, csvplus.go:693-702)."""
+    from csvplus_amd import StrCol
+    from csvplus_amd import _native as N
+    n = 4000
+    col = StrCol.from_values([b"%05d" % ((i * 7919) % n) for i in range(n)])
+    ix = _build(ctx, [col])
+    assert ix.info()["key_bytes"] == 4
+    path = tmp_path / "index.cph"
+    ix.save(str(path))
+    raw = bytearray(path.read_bytes())
+    payload = len(raw) - n * 8            # u32 codes, then u32 perm
+    codes = np.frombuffer(bytes(raw[payload:payload + 4 * n]), dtype=np.uint32).copy()
+    perm = np.frombuffer(bytes(raw[payload + 4 * n:]), dtype=np.uint32).copy()
+    assert sorted(perm.tolist()) == list(range(n)) and (np.diff(codes.astype(np.int64)) >= 0).all()
+
+    def variant(name, c, p):
+        out = bytearray(raw)
+        out[payload:payload + 4 * n] = c.astype(np.uint32).tobytes()
+        out[payload + 4 * n:] = p.astype(np.uint32).tobytes()
+        f = tmp_path / name
+        f.write_bytes(bytes(out))
+        return str(f)
+
+    N.DeviceIndex.load(ctx, variant("same.cph", codes, perm)).close()       # the untouched payload loads
+    big = codes.copy(); big[-1] = 0xFFFFFFF0                                 # code beyond the state space
+    swapped = codes.copy(); swapped[[10, 2000]] = swapped[[2000, 10]]       # not sorted
+    dup = perm.copy(); dup[5] = dup[6]                                      # a row id twice
+    far = perm.copy(); far[0] = n + 12345                                   # row id outside the table
+    for name, c, p in (("big.cph", big, perm), ("swapped.cph", swapped, perm), ("dup.cph", codes, dup), ("far.cph", codes, far)):
+        with pytest.raises(N.CphError) as e:
+            N.DeviceIndex.load(ctx, variant(name, c, p))
+        assert e.value.code == N.CPH_ERR_INVALID, name
