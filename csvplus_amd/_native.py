@@ -23,12 +23,10 @@ CPH_ERR_HIP = -2
 CPH_ERR_NO_DEVICE = -3
 CPH_ERR_DUPLICATE = -4
 CPH_ERR_TOO_MANY_ROWS = -5
-CPH_ERR_KEY_TOO_LONG = -6
 CPH_ERR_TOO_MANY_COLS = -7
 CPH_ERR_NOMEM = -8
 CPH_MEM_HOST = 0
 CPH_MEM_DEVICE = 1
-CPH_MAX_KEY_BYTES = 128
 UINT64_MAX = 0xFFFFFFFFFFFFFFFF
 
 _STATUS_NAMES = {
@@ -37,7 +35,6 @@ _STATUS_NAMES = {
     CPH_ERR_NO_DEVICE: "CPH_ERR_NO_DEVICE",
     CPH_ERR_DUPLICATE: "CPH_ERR_DUPLICATE",
     CPH_ERR_TOO_MANY_ROWS: "CPH_ERR_TOO_MANY_ROWS",
-    CPH_ERR_KEY_TOO_LONG: "CPH_ERR_KEY_TOO_LONG",
     CPH_ERR_TOO_MANY_COLS: "CPH_ERR_TOO_MANY_COLS",
     CPH_ERR_NOMEM: "CPH_ERR_NOMEM",
 }

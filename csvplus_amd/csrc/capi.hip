@@ -320,6 +320,110 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
     // staged input copies are released with the jobs (stream-ordered reuse is safe)
 }
 
+// Stable LSD sort over `nw` 64-bit code words per row (all[w][n], word 0 most significant; bits[w] significant
+// bits each): least significant word first, the later words gathered through the permutation so far.  Leaves the
+// sorted words (word-major) and the permutation in the index.
+static Status sort_words_lsd(cph_ctx* ctx, cph_index* ix, const uint64_t* all, int nw, const int* bits, uint64_t n, DevBuf& va,
+                             DevBuf& vb) {
+    DevBuf ka, kb;
+    CPH_TRY(ka.alloc(&ctx->pool, n * sizeof(uint64_t)));
+    CPH_TRY(kb.alloc(&ctx->pool, n * sizeof(uint64_t)));
+    uint32_t* vcur = va.as<uint32_t>();
+    uint32_t* vother = vb.as<uint32_t>();
+    uint64_t* kout = ka.as<uint64_t>();
+    bool first = true;
+    int passes = 0;
+    ix->sort_passes = 0;
+    for (int w = nw - 1; w >= 0; w--) {
+        const uint64_t* word = all + (uint64_t)w * n;
+        if (first) {
+            if (n) CPH_HIP_TRY(hipMemcpyAsync(ka.get(), word, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+        } else {
+            CPH_TRY(gather_u64(ctx, word, vcur, ka.as<uint64_t>(), n));
+        }
+        uint32_t* vout;
+        CPH_TRY(radix_sort_pairs<uint64_t>(ctx, ka.as<uint64_t>(), kb.as<uint64_t>(), vcur, vother, first, n, bits[w], &kout, &vout,
+                                           &passes));
+        ix->sort_passes += passes;
+        if (vout != vcur) { vother = vcur; vcur = vout; }
+        first = false;
+    }
+    // sorted codes, word-major: word 0 is the key output of the last sort (a streaming copy);
+    // only the less significant words need a gather through the final permutation
+    DevBuf sorted;
+    CPH_TRY(sorted.alloc(&ctx->pool, (size_t)nw * n * sizeof(uint64_t)));
+    if (n) CPH_HIP_TRY(hipMemcpyAsync(sorted.get(), kout, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+    for (int w = 1; w < nw; w++) CPH_TRY(gather_u64(ctx, all + (uint64_t)w * n, vcur, sorted.as<uint64_t>() + (uint64_t)w * n, n));
+    ix->sorted_codes = std::move(sorted);
+    ix->perm = std::move(vcur == va.as<uint32_t>() ? va : vb);
+    return {};
+}
+
+// Segment view of a staged key column for one window.
+static DevCol window_col(const DevCol* cols, const cph_key_window& w, int s) {
+    DevCol v = cols[w.seg_col[s]];
+    v.skip = w.seg_skip[s];
+    v.take = w.seg_take[s];
+    return v;
+}
+
+// Keys whose columns need more than kMaxKeyBytes byte positions: the positions (column-major) are cut into windows
+// of at most kMaxKeyBytes, every window gets its own codec over its column segments, and the rows are sorted LSD
+// over all the windows' words — the order Less (csvplus.go:794-807) defines has no length limit, only the tuned
+// single-window paths do.
+static Status build_multi_window(cph_ctx* ctx, BuildJob* job, const std::vector<ColStats>& raw) {
+    cph_index* ix = job->ix;
+    const uint64_t n = ix->nrows;
+    std::vector<cph_key_window>& W = ix->windows;
+    W.clear();
+    W.emplace_back();
+    uint32_t room = kMaxKeyBytes;
+    for (int c = 0; c < job->nkeycols; c++) {
+        uint32_t left = raw[(size_t)c].maxlen, skip = 0;
+        do {
+            if (room == 0 || W.back().nseg == kMaxKeyCols) {
+                W.emplace_back();
+                room = kMaxKeyBytes;
+            }
+            cph_key_window& w = W.back();
+            const uint32_t t = left < room ? left : room;
+            w.seg_col[w.nseg] = c;
+            w.seg_skip[w.nseg] = skip;
+            w.seg_take[w.nseg] = t == left ? 0xFFFFFFFFu : t;   // the column's last segment runs to the end of the value
+            w.nseg++;
+            skip += t;
+            left -= t;
+            room -= t;
+        } while (left > 0);
+    }
+    int total_words = 0;
+    for (auto& w : W) {
+        DevCol v[kMaxKeyCols];
+        for (int s = 0; s < w.nseg; s++) v[s] = window_col(job->dcols, w, s);
+        std::vector<ColStats> st;
+        CPH_TRY(codec_collect_stats(ctx, v, w.nseg, &st));
+        CPH_TRY(codec_build(st, &w.codec));
+        w.codec.key32 = false;   // window words are always stored as 64-bit words
+        CPH_TRY(codec_upload(ctx, w.codec, &w.codec_dev));
+        w.word_base = total_words;
+        total_words += w.codec.nwords;
+    }
+    ix->codec = W[0].codec;
+    DevBuf all, va, vb;
+    CPH_TRY(all.alloc(&ctx->pool, (size_t)total_words * n * sizeof(uint64_t)));
+    CPH_TRY(va.alloc(&ctx->pool, n * sizeof(uint32_t)));
+    CPH_TRY(vb.alloc(&ctx->pool, n * sizeof(uint32_t)));
+    std::vector<int> bits((size_t)total_words);
+    for (auto& w : W) {
+        DevCol v[kMaxKeyCols];
+        for (int s = 0; s < w.nseg; s++) v[s] = window_col(job->dcols, w, s);
+        CPH_TRY(codec_encode_build(ctx, w.codec, w.codec_dev, v, n, all.as<uint64_t>() + (uint64_t)w.word_base * n));
+        for (int k = 0; k < w.codec.nwords; k++) bits[(size_t)(w.word_base + k)] = w.codec.word_bits[k];
+    }
+    CPH_TRY(sort_words_lsd(ctx, ix, all.as<uint64_t>(), total_words, bits.data(), n, va, vb));
+    return index_first_dup_launch(ctx, ix);
+}
+
 static Status build_phase2(cph_ctx* ctx, BuildJob* job, const void* stats_host) {
     cph_index* ix = job->ix;
     const uint64_t n = ix->nrows;
@@ -327,6 +431,9 @@ static Status build_phase2(cph_ctx* ctx, BuildJob* job, const void* stats_host) 
     const DevCol* dcols = job->dcols;
     std::vector<ColStats> stats;
     codec_stats_finish(dcols, nkeycols, stats_host, &stats);
+    uint64_t positions = 0;
+    for (const auto& s : stats) positions += s.maxlen;
+    if (positions > (uint64_t)kMaxKeyBytes) return build_multi_window(ctx, job, stats);
     CPH_TRY(codec_build(stats, &ix->codec));
     CPH_TRY(codec_try_groups(ctx, dcols, nkeycols, n, &ix->codec));   // only acts on codes of several words
     CPH_TRY(codec_upload(ctx, ix->codec, &ix->codec_dev));
@@ -335,7 +442,6 @@ static Status build_phase2(cph_ctx* ctx, BuildJob* job, const void* stats_host) 
     DevBuf va, vb;
     CPH_TRY(va.alloc(&ctx->pool, n * sizeof(uint32_t)));
     CPH_TRY(vb.alloc(&ctx->pool, n * sizeof(uint32_t)));
-    ix->sort_passes = 0;
     int passes = 0;
 
     if (cd.nwords == 1) {
@@ -370,39 +476,10 @@ static Status build_phase2(cph_ctx* ctx, BuildJob* job, const void* stats_host) 
         ix->perm = std::move(vout == va.as<uint32_t>() ? va : vb);
     } else {
         // multi-word codes: LSD over the words, least significant word first
-        const int nw = cd.nwords;
-        DevBuf all, ka, kb;
-        CPH_TRY(all.alloc(&ctx->pool, (size_t)nw * n * sizeof(uint64_t)));
-        CPH_TRY(ka.alloc(&ctx->pool, n * sizeof(uint64_t)));
-        CPH_TRY(kb.alloc(&ctx->pool, n * sizeof(uint64_t)));
+        DevBuf all;
+        CPH_TRY(all.alloc(&ctx->pool, (size_t)cd.nwords * n * sizeof(uint64_t)));
         CPH_TRY(codec_encode_build(ctx, cd, ix->codec_dev, dcols, n, all.get()));
-        uint32_t* vcur = va.as<uint32_t>();
-        uint32_t* vother = vb.as<uint32_t>();
-        uint64_t* kout = ka.as<uint64_t>();
-        bool first = true;
-        for (int w = nw - 1; w >= 0; w--) {
-            const uint64_t* word = all.as<uint64_t>() + (uint64_t)w * n;
-            if (first) {
-                if (n) CPH_HIP_TRY(hipMemcpyAsync(ka.get(), word, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
-            } else {
-                CPH_TRY(gather_u64(ctx, word, vcur, ka.as<uint64_t>(), n));
-            }
-            uint32_t* vout;
-            CPH_TRY(radix_sort_pairs<uint64_t>(ctx, ka.as<uint64_t>(), kb.as<uint64_t>(), vcur, vother, first, n,
-                                               cd.word_bits[w], &kout, &vout, &passes));
-            ix->sort_passes += passes;
-            if (vout != vcur) { vother = vcur; vcur = vout; }
-            first = false;
-        }
-        // sorted codes, word-major: word 0 is the key output of the last sort (a streaming copy);
-        // only the less significant words need a gather through the final permutation
-        DevBuf sorted;
-        CPH_TRY(sorted.alloc(&ctx->pool, (size_t)nw * n * sizeof(uint64_t)));
-        if (n) CPH_HIP_TRY(hipMemcpyAsync(sorted.get(), kout, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
-        for (int w = 1; w < nw; w++)
-            CPH_TRY(gather_u64(ctx, all.as<uint64_t>() + (uint64_t)w * n, vcur, sorted.as<uint64_t>() + (uint64_t)w * n, n));
-        ix->sorted_codes = std::move(sorted);
-        ix->perm = std::move(vcur == va.as<uint32_t>() ? va : vb);
+        CPH_TRY(sort_words_lsd(ctx, ix, all.as<uint64_t>(), cd.nwords, cd.word_bits, n, va, vb));
     }
 
     // adjacent-equal scan; its result is read back by build_run together with the other jobs'
@@ -856,15 +933,51 @@ CPH_API int32_t cph_index_find(cph_ctx* ctx, const cph_index* ix, const cph_strv
         *upper = ix->nrows;
         return CPH_OK;
     }
-    uint64_t q_exact[kMaxWords];
+    std::vector<uint64_t> q_exact;
     int32_t nq = 0;
     uint64_t qlo = 0, qhi = 0;
-    if (!codec_encode_values_host(ix->codec, values, nvalues, q_exact, &nq, &qlo, &qhi)) {
+    bool present = true;
+    if (ix->windows.empty()) {
+        q_exact.resize(kMaxWords);
+        present = codec_encode_values_host(ix->codec, values, nvalues, q_exact.data(), &nq, &qlo, &qhi);
+    } else {
+        // long keys: every window encodes its segments of the values; all words are exact except the last word of
+        // the last window the values reach, which may be a range (prefix of the key columns)
+        bool pending = false;
+        uint64_t plo = 0, phi = 0;
+        for (const cph_key_window& w : ix->windows) {
+            cph_strval seg[kMaxKeyCols];
+            int used = 0;
+            for (int k = 0; k < w.nseg && w.seg_col[k] < nvalues; k++, used++) {
+                const cph_strval& v = values[w.seg_col[k]];
+                const uint64_t sk = v.len < (uint64_t)w.seg_skip[k] ? v.len : (uint64_t)w.seg_skip[k];
+                uint64_t ln = v.len - sk;
+                if (w.seg_take[k] != 0xFFFFFFFFu && ln > (uint64_t)w.seg_take[k]) ln = w.seg_take[k];
+                seg[used].data = v.data ? v.data + sk : nullptr;
+                seg[used].len = ln;
+            }
+            if (used == 0) break;
+            uint64_t qw[kMaxWords], wlo = 0, whi = 0;
+            int32_t nqw = 0;
+            if (!codec_encode_values_host(w.codec, seg, used, qw, &nqw, &wlo, &whi)) { present = false; break; }
+            if (nqw == 0) continue;                       // a window without byte positions (empty columns)
+            if (pending) q_exact.push_back(plo);          // the previous window was complete: its last word is exact
+            for (int k = 0; k + 1 < nqw; k++) q_exact.push_back(qw[k]);
+            plo = wlo;
+            phi = whi;
+            pending = true;
+        }
+        nq = pending ? (int32_t)q_exact.size() + 1 : 0;
+        qlo = plo;
+        qhi = phi;
+        q_exact.push_back(0);
+    }
+    if (!present) {
         *lower = 0;
         *upper = 0;   // empty: the values cannot occur in the index
         return CPH_OK;
     }
-    s = index_find_device(ctx, ix, q_exact, nq, qlo, qhi, lower, upper);
+    s = index_find_device(ctx, ix, q_exact.data(), nq, qlo, qhi, lower, upper);
     if (!s.ok()) return fail(ctx, s);
     return CPH_OK;
 }
@@ -874,10 +987,18 @@ CPH_API int32_t cph_index_get_info(const cph_index* ix, cph_index_info* info) {
     memset(info, 0, sizeof *info);
     info->nrows = ix->nrows;
     info->nkeycols = ix->nkeycols;
-    info->key_positions = ix->codec.npos;
-    info->code_words = ix->codec.nwords;
-    int bits = 0;
-    for (int w = 0; w < ix->codec.nwords; w++) bits += ix->codec.word_bits[w];
+    int bits = 0, npos = ix->codec.npos;
+    if (ix->windows.empty()) {
+        for (int w = 0; w < ix->codec.nwords; w++) bits += ix->codec.word_bits[w];
+    } else {
+        npos = 0;
+        for (const auto& kw : ix->windows) {
+            npos += kw.codec.npos;
+            for (int w = 0; w < kw.codec.nwords; w++) bits += kw.codec.word_bits[w];
+        }
+    }
+    info->key_positions = npos;
+    info->code_words = ix->total_words();
     info->code_bits = bits;
     info->key_bytes = ix->codec.key32 ? 4 : 8;
     info->sort_passes = ix->sort_passes;

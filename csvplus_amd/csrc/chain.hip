@@ -238,7 +238,7 @@ bool chain_fast_path_ok(const ChainStep* steps, int nsteps) {
         const cph_index* ix = steps[s].index;
         if (steps[s].ncols != 1 || ix->nkeycols != 1) return false;
         if (ix->first_dup != UINT64_MAX) return false;
-        if (ix->codec.nwords != 1 || ix->codec.npos == 0) return false;
+        if (ix->codec.nwords != 1 || ix->codec.npos == 0 || !ix->windows.empty()) return false;
         if (codec_premultiplied_bits(ix->codec) == 0) return false;
     }
     return true;

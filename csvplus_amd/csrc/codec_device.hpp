@@ -11,16 +11,23 @@ struct ColsArg {
     DevCol c[kMaxKeyCols];
 };
 
-// [begin, begin+len) of value `row` inside col.data: no memory access for fixed-width columns.
+// [begin, begin+len) of value `row` inside col.data (of the column's SEGMENT when the column is one: DevCol.skip /
+// .take): no memory access for fixed-width columns.
 __device__ __forceinline__ void value_span(const DevCol& col, uint64_t row, uint64_t* begin, uint64_t* len) {
+    uint64_t b, l;
     if (col.fixed_width) {
-        *begin = row * (uint64_t)col.fixed_width;
-        *len = col.fixed_width;
+        b = row * (uint64_t)col.fixed_width;
+        l = col.fixed_width;
     } else {
-        const uint64_t b = load_offset(col.offsets, col.offset_bits, row);
-        *begin = b;
-        *len = load_offset(col.offsets, col.offset_bits, row + 1) - b;
+        b = load_offset(col.offsets, col.offset_bits, row);
+        l = load_offset(col.offsets, col.offset_bits, row + 1) - b;
     }
+    const uint64_t s = l < (uint64_t)col.skip ? l : (uint64_t)col.skip;
+    b += s;
+    l -= s;
+    if (col.take != 0xFFFFFFFFu && l > (uint64_t)col.take) l = col.take;
+    *begin = b;
+    *len = l;
 }
 
 // LDS-qualified pointers: without the explicit address space the compiler falls back to flat
@@ -163,8 +170,27 @@ struct WaveSpans {
         return load_chunk_nobranch<B>(base8, delta, x[k], len[k], j);
     }
 };
+// SEG: the column is a window segment (DevCol.skip / .take) — only the statistics pass of multi-window keys asks for it
+template <int R, class B, bool SEG = false>
+__device__ __forceinline__ void wave_spans(const DevCol& c, const WaveRows<R>& wr, WaveSpans<R, B>* sp);
 template <int R, class B>
+__device__ __forceinline__ void wave_spans_whole(const DevCol& c, const WaveRows<R>& wr, WaveSpans<R, B>* sp);
+template <int R, class B, bool SEG>
 __device__ __forceinline__ void wave_spans(const DevCol& c, const WaveRows<R>& wr, WaveSpans<R, B>* sp) {
+    wave_spans_whole<R, B>(c, wr, sp);
+    if constexpr (SEG) {
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const uint32_t s = sp->len[k] < c.skip ? sp->len[k] : c.skip;
+            sp->x[k] += (B)s;
+            uint32_t l = sp->len[k] - s;
+            if (c.take != 0xFFFFFFFFu && l > c.take) l = c.take;
+            sp->len[k] = l;
+        }
+    }
+}
+template <int R, class B>
+__device__ __forceinline__ void wave_spans_whole(const DevCol& c, const WaveRows<R>& wr, WaveSpans<R, B>* sp) {
     if (c.fixed_width) {
         const uint64_t p = (uint64_t)(uintptr_t)c.data + wr.rbase * (uint64_t)c.fixed_width;
         sp->base8 = (const uint8_t*)(uintptr_t)(p & ~7ull);

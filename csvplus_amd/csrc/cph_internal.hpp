@@ -14,11 +14,13 @@
 namespace cph {
 
 // ---- limits / launch geometry ------------------------------------------------
-constexpr int kMaxKeyBytes = CPH_MAX_KEY_BYTES;  // total encoded byte positions
+constexpr int kMaxKeyBytes = 128;                // byte positions one codec (one key WINDOW) covers; longer keys take
+                                                 // several windows (cph_index::windows)
 constexpr int kMaxKeyCols  = CPH_MAX_KEY_COLS;
 constexpr int kLutStride   = 257;                // symbols per position: pad + 256 byte values
 constexpr uint16_t kLutInvalid = 0xFFFF;
-constexpr int kMaxWords    = 16;                 // code words per key (each < 2^63 states)
+constexpr int kMaxWords    = 20;                 // code words per window (each < 2^63 states; 128 positions of a
+                                                 // full 257-symbol alphabet need 19)
 
 // ---- error plumbing ------------------------------------------------------------
 struct Status {
@@ -219,14 +221,33 @@ struct cph_ctx {
     std::vector<hipEvent_t> prof_free_events;
 };
 
+// One window of at most kMaxKeyBytes key byte positions (positions run column-major over the key columns, so a
+// window is a list of column SEGMENTS).  Keys that fit one window — every key the tuned paths ever see — have
+// cph_index::windows empty and live in cph_index::codec alone.
+struct cph_key_window {
+    cph::CodecHost codec;          // built over the window's segments as if they were the key columns
+    cph::DevBuf codec_dev;
+    int32_t nseg = 0;
+    int32_t seg_col[CPH_MAX_KEY_COLS] = {0};
+    uint32_t seg_skip[CPH_MAX_KEY_COLS] = {0}, seg_take[CPH_MAX_KEY_COLS] = {0};   // take 0xFFFFFFFF: the column's last segment
+    int32_t word_base = 0;         // its first word in sorted_codes (windows and words in significance order)
+};
+
 struct cph_index {
     cph_ctx* ctx = nullptr;
     uint64_t nrows = 0;
     uint64_t table_rows = 0;       // rows of the table the index was built over (perm values are < table_rows)
     int32_t nkeycols = 0;
-    cph::CodecHost codec;
-    cph::DevBuf codec_dev;         // CodecDevHeader block
-    cph::DevBuf sorted_codes;      // key32: u32[n]; else u64[nwords][n] word-major
+    cph::CodecHost codec;          // single-window keys: THE codec; several windows: a copy of windows[0].codec
+    cph::DevBuf codec_dev;         // CodecDevHeader block (single-window keys)
+    std::vector<cph_key_window> windows;   // non-empty only when the key columns need more than kMaxKeyBytes positions
+    int32_t total_words() const {
+        if (windows.empty()) return codec.nwords;
+        int32_t t = 0;
+        for (const auto& w : windows) t += w.codec.nwords;
+        return t;
+    }
+    cph::DevBuf sorted_codes;      // key32: u32[n]; else u64[total_words()][n] word-major
     cph::DevBuf perm;              // u32[n]
     // direct-address tables over the code space, built by the first Join that can use them (probe.hip)
     cph::DevBuf table;             // {lo,row} / {lo,end} u32x2 [table_entries]: generic probe
@@ -264,6 +285,11 @@ struct DevCol {
     uint64_t nrows = 0;
     int32_t offset_bits = 32;
     uint32_t fixed_width = 0;   // > 0: every value has this many bytes, offsets unused (may be null)
+    // segment of the values a key WINDOW looks at (keys longer than kMaxKeyBytes positions): bytes [skip, skip+take)
+    // of every value.  take == 0xFFFFFFFF: to the end of the value (the column's last segment: a value longer than
+    // the build side's longest stays longer than the window's maxlen and is recognised as absent).
+    uint32_t skip = 0, take = 0xFFFFFFFFu;
+    bool segmented() const { return skip != 0 || take != 0xFFFFFFFFu; }
 };
 
 // keycodec.hip

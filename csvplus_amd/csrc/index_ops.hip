@@ -103,23 +103,31 @@ static Status index_validate_payload(cph_ctx* ctx, const cph_index* ix) {
     if (ix->table_rows < n || ix->table_rows > 0xFFFFFFFFull) return {CPH_ERR_INVALID, "index payload: bad table row count"};
     DevBuf seen, bad, states;
     const size_t words = (size_t)((ix->table_rows + 31) / 32);
+    const int tw = ix->total_words();
     CPH_TRY(seen.alloc(&ctx->pool, words * sizeof(uint32_t)));
     CPH_TRY(bad.alloc(&ctx->pool, sizeof(uint32_t)));
-    CPH_TRY(states.alloc(&ctx->pool, sizeof(uint64_t) * kMaxWords));
+    CPH_TRY(states.alloc(&ctx->pool, sizeof(uint64_t) * (size_t)tw));
     CPH_HIP_TRY(hipMemsetAsync(seen.get(), 0, words * sizeof(uint32_t), ctx->stream));
     CPH_HIP_TRY(hipMemsetAsync(bad.get(), 0, sizeof(uint32_t), ctx->stream));
     void* up = nullptr;
-    CPH_TRY(pinned_upload(ctx, sizeof(uint64_t) * kMaxWords, &up));
-    memcpy(up, ix->codec.word_states, sizeof(uint64_t) * kMaxWords);
-    CPH_HIP_TRY(hipMemcpyAsync(states.get(), up, sizeof(uint64_t) * kMaxWords, hipMemcpyHostToDevice, ctx->stream));
+    CPH_TRY(pinned_upload(ctx, sizeof(uint64_t) * (size_t)tw, &up));
+    {
+        uint64_t* st = static_cast<uint64_t*>(up);
+        if (ix->windows.empty()) {
+            memcpy(st, ix->codec.word_states, sizeof(uint64_t) * (size_t)tw);
+        } else {
+            for (const auto& w : ix->windows) memcpy(st + w.word_base, w.codec.word_states, sizeof(uint64_t) * (size_t)w.codec.nwords);
+        }
+    }
+    CPH_HIP_TRY(hipMemcpyAsync(states.get(), up, sizeof(uint64_t) * (size_t)tw, hipMemcpyHostToDevice, ctx->stream));
     const unsigned grid = grid_for_items(n);
     if (ix->codec.key32)
         hipLaunchKernelGGL(k_validate_payload<true>, dim3(grid), dim3(256), 0, ctx->stream, ix->sorted_codes.get(),
-                           ix->perm.as<uint32_t>(), n, ix->codec.nwords, states.as<uint64_t>(), ix->table_rows,
+                           ix->perm.as<uint32_t>(), n, tw, states.as<uint64_t>(), ix->table_rows,
                            seen.as<uint32_t>(), bad.as<uint32_t>());
     else
         hipLaunchKernelGGL(k_validate_payload<false>, dim3(grid), dim3(256), 0, ctx->stream, ix->sorted_codes.get(),
-                           ix->perm.as<uint32_t>(), n, ix->codec.nwords, states.as<uint64_t>(), ix->table_rows,
+                           ix->perm.as<uint32_t>(), n, tw, states.as<uint64_t>(), ix->table_rows,
                            seen.as<uint32_t>(), bad.as<uint32_t>());
     CPH_HIP_TRY(hipGetLastError());
     uint32_t isbad = 0;
@@ -138,7 +146,7 @@ static Status finish_index(cph_ctx* ctx, cph_index* ix) {
 }
 
 static size_t code_bytes(const cph_index* ix) {
-    return ix->codec.key32 ? sizeof(uint32_t) : sizeof(uint64_t) * (size_t)ix->codec.nwords;
+    return ix->codec.key32 ? sizeof(uint32_t) : sizeof(uint64_t) * (size_t)ix->total_words();
 }
 
 
@@ -353,11 +361,11 @@ CPH_API int32_t cph_index_dup_groups(cph_ctx* ctx, const cph_index* ix, cph_grou
                     ProfScope ps(ctx, "k_group_flags", (double)n * ((double)code_bytes(ix) + 4.0));
                     const unsigned grid = grid_for_items(n);
                     if (ix->codec.key32) {
-                        if (pass == 0) hipLaunchKernelGGL((k_group_flags<true, true>), dim3(grid), dim3(256), 0, ctx->stream, ix->sorted_codes.get(), n, ix->codec.nwords, flags.as<uint32_t>());
-                        else hipLaunchKernelGGL((k_group_flags<true, false>), dim3(grid), dim3(256), 0, ctx->stream, ix->sorted_codes.get(), n, ix->codec.nwords, flags.as<uint32_t>());
+                        if (pass == 0) hipLaunchKernelGGL((k_group_flags<true, true>), dim3(grid), dim3(256), 0, ctx->stream, ix->sorted_codes.get(), n, ix->total_words(), flags.as<uint32_t>());
+                        else hipLaunchKernelGGL((k_group_flags<true, false>), dim3(grid), dim3(256), 0, ctx->stream, ix->sorted_codes.get(), n, ix->total_words(), flags.as<uint32_t>());
                     } else {
-                        if (pass == 0) hipLaunchKernelGGL((k_group_flags<false, true>), dim3(grid), dim3(256), 0, ctx->stream, ix->sorted_codes.get(), n, ix->codec.nwords, flags.as<uint32_t>());
-                        else hipLaunchKernelGGL((k_group_flags<false, false>), dim3(grid), dim3(256), 0, ctx->stream, ix->sorted_codes.get(), n, ix->codec.nwords, flags.as<uint32_t>());
+                        if (pass == 0) hipLaunchKernelGGL((k_group_flags<false, true>), dim3(grid), dim3(256), 0, ctx->stream, ix->sorted_codes.get(), n, ix->total_words(), flags.as<uint32_t>());
+                        else hipLaunchKernelGGL((k_group_flags<false, false>), dim3(grid), dim3(256), 0, ctx->stream, ix->sorted_codes.get(), n, ix->total_words(), flags.as<uint32_t>());
                     }
                 }
                 CPH_HIP_TRY(hipMemcpyAsync(scan.get(), flags.get(), n * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
@@ -420,6 +428,17 @@ CPH_API int32_t cph_index_select(cph_ctx* ctx, const cph_index* ix, const uint64
         nx->table_rows = ix->table_rows;
         nx->codec = ix->codec;
         nx->sort_passes = 0;
+        for (const auto& w : ix->windows) {   // a long-key index keeps its windows (their device blocks are re-uploaded)
+            nx->windows.emplace_back();
+            cph_key_window& nw = nx->windows.back();
+            nw.codec = w.codec;
+            nw.nseg = w.nseg;
+            memcpy(nw.seg_col, w.seg_col, sizeof nw.seg_col);
+            memcpy(nw.seg_skip, w.seg_skip, sizeof nw.seg_skip);
+            memcpy(nw.seg_take, w.seg_take, sizeof nw.seg_take);
+            nw.word_base = w.word_base;
+            CPH_TRY(codec_upload(ctx, nw.codec, &nw.codec_dev));
+        }
         DevBuf pos, bad;
         CPH_TRY(pos.alloc(&ctx->pool, n * sizeof(uint64_t)));
         CPH_TRY(bad.alloc(&ctx->pool, sizeof(uint32_t)));
@@ -438,7 +457,7 @@ CPH_API int32_t cph_index_select(cph_ctx* ctx, const cph_index* ix, const uint64
             if (ix->codec.key32)
                 hipLaunchKernelGGL(k_select_u32, dim3(grid), dim3(256), 0, ctx->stream, ix->sorted_codes.as<uint32_t>(), pos.as<uint64_t>(), n, nx->sorted_codes.as<uint32_t>());
             else
-                for (int w = 0; w < ix->codec.nwords; w++)
+                for (int w = 0; w < ix->total_words(); w++)
                     hipLaunchKernelGGL(k_select_u64, dim3(grid), dim3(256), 0, ctx->stream, ix->sorted_codes.as<uint64_t>() + (uint64_t)w * ix->nrows,
                                        pos.as<uint64_t>(), n, nx->sorted_codes.as<uint64_t>() + (uint64_t)w * n);
             CPH_HIP_TRY(hipGetLastError());
@@ -459,6 +478,8 @@ CPH_API int32_t cph_index_save(cph_ctx* ctx, const cph_index* ix, const char* pa
     if (!ctx || !ix || !path) return CPH_ERR_INVALID;
     if (hipSetDevice(ctx->device) != hipSuccess) return fail_with(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});
     auto run = [&]() -> Status {
+        if (!ix->windows.empty())
+            return {CPH_ERR_INVALID, "saving an index whose keys span several codec windows (> 128 key bytes) is not implemented"};
         std::vector<uint8_t> desc;
         index_desc_serialize(ix, &desc);
         const size_t cb = (size_t)ix->nrows * code_bytes(ix), pb = (size_t)ix->nrows * sizeof(uint32_t);

@@ -38,7 +38,7 @@ constexpr int kStatsRows = 8;     // rows per lane and wave-tile (codec_device.h
 // Presence is recorded as one BYTE flag per (position, byte value) in LDS with plain stores — no read-test-atomic
 // per key byte: this kernel is bound by instruction issue, not by HBM — and folded into the 256-bit masks once per
 // workgroup at the end.
-template <class B>
+template <class B, bool SEG>
 __global__ __launch_bounds__(kStatsThreads) void k_col_stats(DevCol col, uint32_t* __restrict__ g_minmax,
                                                             uint32_t* __restrict__ g_mask) {
     __shared__ __attribute__((aligned(16))) uint8_t s_flag[kMaxKeyBytes * 256];
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(kStatsThreads) void k_col_stats(DevCol col, uint32_
     for (uint64_t wt = (uint64_t)blockIdx.x * (kStatsThreads / kWave) + wave_id(); wt < nwt; wt += wstride) {
         const WaveRows<kStatsRows> wr = wave_rows<kStatsRows>(wt * kTile, col.nrows);
         WaveSpans<kStatsRows, B> sp;
-        wave_spans<kStatsRows, B>(col, wr, &sp);
+        wave_spans<kStatsRows, B, SEG>(col, wr, &sp);
         uint64_t cur[kStatsRows];
 #pragma unroll
         for (int k = 0; k < kStatsRows; k++) cur[k] = sp.chunk(k, 0);
@@ -123,12 +123,13 @@ Status codec_stats_launch(cph_ctx* ctx, const DevCol* cols, int32_t ncols, DevBu
         if (nblk > (uint64_t)cus * 8) nblk = (uint64_t)cus * 8;
         uint32_t* base = reinterpret_cast<uint32_t*>(d->as<uint8_t>() + per * (size_t)c);
         ProfScope ps(ctx, "k_col_stats", 0);   // bytes: value bytes + offsets, added by the caller's model
-        if (col_is_narrow(cols[c]))
-            hipLaunchKernelGGL(k_col_stats<uint32_t>, dim3((unsigned)nblk), dim3(kStatsThreads), 0, ctx->stream, cols[c],
-                               base, base + 2);
+        const dim3 grid((unsigned)nblk), block(kStatsThreads);
+        if (cols[c].segmented())   // a window segment of a long key: generic offsets
+            hipLaunchKernelGGL((k_col_stats<uint64_t, true>), grid, block, 0, ctx->stream, cols[c], base, base + 2);
+        else if (col_is_narrow(cols[c]))
+            hipLaunchKernelGGL((k_col_stats<uint32_t, false>), grid, block, 0, ctx->stream, cols[c], base, base + 2);
         else
-            hipLaunchKernelGGL(k_col_stats<uint64_t>, dim3((unsigned)nblk), dim3(kStatsThreads), 0, ctx->stream, cols[c],
-                               base, base + 2);
+            hipLaunchKernelGGL((k_col_stats<uint64_t, false>), grid, block, 0, ctx->stream, cols[c], base, base + 2);
         CPH_HIP_TRY(hipGetLastError());
     }
     return {};
@@ -184,7 +185,7 @@ static Status codec_split_words(CodecHost* codec) {
     };
     for (int p = 0; p < npos; p++) {
         if (prod * cd.radix[(size_t)p] > kLimit) {
-            if (w + 1 >= kMaxWords) return {CPH_ERR_KEY_TOO_LONG, "key needs too many code words"};
+            if (w + 1 >= kMaxWords) return {CPH_ERR_INVALID, "internal: a key window needs too many code words"};
             close_word(word_first, p, w, prod);
             w++;
             word_first = p;
@@ -210,9 +211,9 @@ Status codec_build(const std::vector<ColStats>& stats, CodecHost* codec) {
         cd.col_minlen[c] = (int32_t)stats[c].minlen;
         if ((uint64_t)npos + stats[c].maxlen > (uint64_t)kMaxKeyBytes) {
             char b[160];
-            snprintf(b, sizeof b, "key too long: key columns need more than %d byte positions (column %d has a %u-byte value)",
+            snprintf(b, sizeof b, "internal: a key window needs more than %d byte positions (segment %d has %u bytes)",
                      kMaxKeyBytes, c, stats[c].maxlen);
-            return {CPH_ERR_KEY_TOO_LONG, b};
+            return {CPH_ERR_INVALID, b};
         }
         npos += (int)stats[c].maxlen;
     }
@@ -799,7 +800,7 @@ Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec
                           void* out_codes, const EncodeHist* hist) {
     if (n == 0) return {};
     const int lutw_bits = codec_premultiplied_bits(cd);
-    if (cd.ncols == 1 && lutw_bits != 0) {
+    if (cd.ncols == 1 && lutw_bits != 0 && !cols[0].segmented()) {
         // tiles = the sort's tiles when it asked for the first pass's histogram, else 4096 rows
         const bool want_hist = hist && hist->counts;
         const uint32_t tile_rows = want_hist ? hist->tile_rows : 4096u;

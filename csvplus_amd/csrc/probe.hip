@@ -50,13 +50,13 @@ Status index_first_dup_launch(cph_ctx* ctx, cph_index* ix) {
     if (nblk > 4096) nblk = 4096;
     uint32_t* d = ix->first_dup_dev.as<uint32_t>();
     {
-        ProfScope ps(ctx, "k_first_dup", (double)n * (ix->codec.key32 ? 4.0 : 8.0 * ix->codec.nwords));
+        ProfScope ps(ctx, "k_first_dup", (double)n * (ix->codec.key32 ? 4.0 : 8.0 * ix->total_words()));
         if (ix->codec.key32)
             hipLaunchKernelGGL(k_first_dup<true>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream,
-                               ix->sorted_codes.get(), n, ix->codec.nwords, d);
+                               ix->sorted_codes.get(), n, ix->total_words(), d);
         else
             hipLaunchKernelGGL(k_first_dup<false>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream,
-                               ix->sorted_codes.get(), n, ix->codec.nwords, d);
+                               ix->sorted_codes.get(), n, ix->total_words(), d);
     }
     CPH_HIP_TRY(hipGetLastError());
     return {};
@@ -108,7 +108,7 @@ __global__ void k_build_rowtab(const K* __restrict__ codes, const uint32_t* __re
 void index_plan_table(cph_index* ix) {
     ix->table_entries = 0;
     const uint64_t n = ix->nrows;
-    if (n == 0 || ix->codec.nwords != 1) return;
+    if (n == 0 || ix->codec.nwords != 1 || !ix->windows.empty()) return;
     const uint64_t states = ix->codec.word_states[0];
     uint64_t limit = 8 * n;
     if (limit < (1ull << 20)) limit = 1ull << 20;
@@ -414,6 +414,104 @@ __global__ __launch_bounds__(kProbeThreads) void k_expand(const uint32_t* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// keys longer than one codec window (cph_index::windows): the bounds of every probe row are narrowed window by
+// window, each launch encoding the row's column segments of ONE window with that window's codec and searching that
+// window's words (csvplus.go:893-920 compares whole strings: no length limit).  Generic and unhurried: the tuned
+// paths never see such keys.
+// ---------------------------------------------------------------------------------------------
+template <bool FIRST>
+__global__ __launch_bounds__(kProbeThreads) void k_probe_window(ColsArg cols, int ncols_used, const uint8_t* __restrict__ g_codec,
+                                                               const uint64_t* __restrict__ codes, uint64_t n_index, RowSel sel,
+                                                               uint64_t nprobe, uint32_t* __restrict__ lo_io,
+                                                               uint32_t* __restrict__ hi_io) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const CodecView cv = codec_load_to_lds(g_codec, smem);
+    const int p_end = cv.hdr->col_start[ncols_used];
+    const uint64_t stride = (uint64_t)gridDim.x * kProbeThreads;
+    for (uint64_t i = (uint64_t)blockIdx.x * kProbeThreads + threadIdx.x; i < nprobe; i += stride) {
+        uint64_t row = i;
+        if (sel.ptr)
+            row = (sel.bits == 32 ? (uint64_t) reinterpret_cast<const uint32_t*>(sel.ptr)[i]
+                                  : reinterpret_cast<const uint64_t*>(sel.ptr)[i]) - sel.base;
+        uint64_t lo = FIRST ? 0 : lo_io[i], hi = FIRST ? n_index : hi_io[i];
+        if (lo < hi) {
+            const bool valid = encode_key(cv, cols, ncols_used, row, [&](int word, uint64_t v, int p) {
+                const uint64_t vhi = (p + 1 == p_end) ? v + cv.mult[p] - 1 : v;
+                const uint64_t* a = codes + (uint64_t)word * n_index;
+                const uint64_t l2 = lower_bound_dev<uint64_t>(a, lo, hi, v);
+                hi = upper_bound_dev<uint64_t>(a, l2, hi, vhi);
+                lo = l2;
+            });
+            if (!valid) hi = lo;
+        }
+        lo_io[i] = (uint32_t)lo;
+        hi_io[i] = (uint32_t)hi;
+    }
+}
+
+// hi -> cnt = hi - lo, and the per-tile match totals k_expand's scan starts from (tile = kProbeTile rows)
+__global__ __launch_bounds__(kProbeThreads) void k_bounds_to_counts(const uint32_t* __restrict__ lo, uint32_t* __restrict__ hi_cnt,
+                                                                   uint64_t nprobe, uint64_t* __restrict__ tile_sums) {
+    __shared__ uint64_t s_wsum[kProbeThreads / kWave];
+    const uint64_t tile0 = (uint64_t)blockIdx.x * kProbeTile;
+    uint64_t my_sum = 0;
+    for (int k = 0; k < kProbeItems; k++) {
+        const uint64_t i = tile0 + (uint64_t)k * kProbeThreads + threadIdx.x;
+        if (i >= nprobe) break;
+        const uint32_t c = hi_cnt[i] - lo[i];
+        hi_cnt[i] = c;
+        my_sum += c;
+    }
+    my_sum = wave_sum(my_sum);
+    if (lane_id() == 0) s_wsum[wave_id()] = my_sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0;
+        for (int w = 0; w < kProbeThreads / kWave; w++) t += s_wsum[w];
+        tile_sums[blockIdx.x] = t;
+    }
+}
+
+static Status probe_windows(cph_ctx* ctx, const cph_index* ix, const DevCol* cols, int32_t ncols, RowSel row_sel, uint64_t nprobe,
+                            uint32_t* lo, uint32_t* cnt, uint64_t* tile_sums, unsigned ntiles) {
+    bool first = true;
+    for (const cph_key_window& w : ix->windows) {
+        ColsArg arg{};
+        int used = 0;
+        for (int s = 0; s < w.nseg; s++) {
+            if (w.seg_col[s] >= ncols) break;   // a prefix join compares the leading columns only (csvplus.go:910)
+            arg.c[used] = cols[w.seg_col[s]];
+            arg.c[used].skip = w.seg_skip[s];
+            arg.c[used].take = w.seg_take[s];
+            used++;
+        }
+        if (used == 0) break;
+        const size_t lds = w.codec_dev.bytes();
+        const uint64_t* codes = ix->sorted_codes.as<uint64_t>() + (uint64_t)w.word_base * ix->nrows;
+        const unsigned grid = grid_for_items(nprobe);
+        ProfScope ps(ctx, "k_probe_window", 0);
+        if (first) {
+            CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_probe_window<true>), kProbeThreads, lds, nullptr));
+            hipLaunchKernelGGL(k_probe_window<true>, dim3(grid), dim3(kProbeThreads), lds, ctx->stream, arg, used,
+                               w.codec_dev.as<uint8_t>(), codes, ix->nrows, row_sel, nprobe, lo, cnt);
+        } else {
+            CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_probe_window<false>), kProbeThreads, lds, nullptr));
+            hipLaunchKernelGGL(k_probe_window<false>, dim3(grid), dim3(kProbeThreads), lds, ctx->stream, arg, used,
+                               w.codec_dev.as<uint8_t>(), codes, ix->nrows, row_sel, nprobe, lo, cnt);
+        }
+        CPH_HIP_TRY(hipGetLastError());
+        first = false;
+    }
+    if (first) {   // no key column at all cannot happen (ncols >= 1), but keep the arrays defined
+        CPH_HIP_TRY(hipMemsetAsync(lo, 0, nprobe * sizeof(uint32_t), ctx->stream));
+        CPH_HIP_TRY(hipMemsetAsync(cnt, 0, nprobe * sizeof(uint32_t), ctx->stream));
+    }
+    hipLaunchKernelGGL(k_bounds_to_counts, dim3(ntiles), dim3(kProbeThreads), 0, ctx->stream, lo, cnt, nprobe, tile_sums);
+    CPH_HIP_TRY(hipGetLastError());
+    return {};
+}
+
 template <bool KEY32, bool TABLE>
 static Status launch_probe(cph_ctx* ctx, const cph_index* ix, const ColsArg& arg, int ncols, RowSel row_sel,
                            uint64_t nprobe, uint32_t* lo, uint32_t* cnt, uint64_t* tile_sums, unsigned ntiles) {
@@ -442,15 +540,17 @@ Status probe_run(cph_ctx* ctx, const cph_index* ix, const DevCol* cols, int32_t 
     CPH_TRY(tiles.alloc(&ctx->pool, (ntiles64 + 1) * sizeof(uint64_t)));
     ColsArg arg{};
     for (int c = 0; c < ncols; c++) arg.c[c] = cols[c];
-    const bool full_key = ncols == ix->codec.ncols;
-    const bool use_table = ix->table_entries != 0 && full_key;
+    const bool full_key = ncols == ix->nkeycols;
+    const bool use_table = ix->table_entries != 0 && full_key && ix->windows.empty();
     if (use_table) CPH_TRY(index_ensure_table(ctx, ix));
     uint32_t* lo = out->lo.as<uint32_t>();
     uint32_t* cnt = out->cnt.as<uint32_t>();
     uint64_t* ts = tiles.as<uint64_t>();
     DevBuf first_rows;
-    const bool fast = ncols == 1 && ix->codec.ncols == 1 && codec_premultiplied_bits(ix->codec) != 0;
-    if (fast) {
+    const bool fast = ncols == 1 && ix->codec.ncols == 1 && codec_premultiplied_bits(ix->codec) != 0 && ix->windows.empty();
+    if (!ix->windows.empty()) {
+        CPH_TRY(probe_windows(ctx, ix, cols, ncols, row_sel, nprobe, lo, cnt, ts, ntiles));
+    } else if (fast) {
         // one key column, single-word code, pre-multiplied LUT: 4 rows in flight per thread
         const size_t lds = ix->codec_dev.bytes();
         const uint8_t* blob = ix->codec_dev.as<uint8_t>();

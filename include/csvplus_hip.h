@@ -56,13 +56,12 @@ enum {
     CPH_ERR_NO_DEVICE      = -3,  /* no usable GPU: the library never falls back to the CPU  */
     CPH_ERR_DUPLICATE      = -4,  /* unique index requested and equal keys exist             */
     CPH_ERR_TOO_MANY_ROWS  = -5,  /* nrows > 2^32-1                                          */
-    CPH_ERR_KEY_TOO_LONG   = -6,  /* sum over key columns of max value length > CPH_MAX_KEY_BYTES */
+    /* -6 is retired: key length is unlimited (keys beyond 128 byte positions are cut into codec windows) */
     CPH_ERR_TOO_MANY_COLS  = -7,  /* join with more columns than the index has
                                      (csvplus.go:548-550 panics "too many source columns")   */
     CPH_ERR_NOMEM          = -8
 };
 
-#define CPH_MAX_KEY_BYTES 128   /* sum over key columns of the longest value, in bytes */
 #define CPH_MAX_KEY_COLS  16
 
 enum { CPH_MEM_HOST = 0, CPH_MEM_DEVICE = 1 };

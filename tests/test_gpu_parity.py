@@ -145,9 +145,8 @@ def test_errors(ctx):
     with pytest.raises(N.CphError) as e:   # csvplus.go:548-550 "too many source columns in Join()"
         g.probe(cols_of(p, "id", "name"))
     assert e.value.code == N.CPH_ERR_TOO_MANY_COLS
-    with pytest.raises(N.CphError) as e:
-        DeviceIndex(ctx, [StrCol.from_values([b"x" * 200, b"y"])])
-    assert e.value.code == N.CPH_ERR_KEY_TOO_LONG
+    long_ix = DeviceIndex(ctx, [StrCol.from_values([b"x" * 200, b"y"])])   # no key-length limit (csvplus.go:794-807)
+    assert long_ix.perm().tolist() == [0, 1] and long_ix.info()["key_positions"] == 200
     with pytest.raises(N.CphError) as e:
         DeviceIndex(ctx, [StrCol.from_values(["a", "b"]), StrCol.from_values(["a"])])
     assert e.value.code == N.CPH_ERR_INVALID
@@ -387,3 +386,57 @@ def test_index_build_many_matches_single_builds(ctx):
     assert res[1].first_dup == orc.OracleIndex(tables[2]).first_dup()
     for r in res:
         r.close()
+
+
+def long_keys(rng, n, max_len, alphabet, distinct, shared_prefix):
+    """Keys up to max_len bytes; many share a long prefix so that the order is decided deep inside the key."""
+    pool = []
+    base = alphabet[rng.integers(0, len(alphabet), max_len)].tobytes()
+    for _ in range(distinct):
+        ln = int(rng.integers(0, max_len + 1))
+        k = bytearray(base[:ln]) if rng.random() < shared_prefix else bytearray(alphabet[rng.integers(0, len(alphabet), ln)].tobytes())
+        for _ in range(int(rng.integers(0, 3))):   # a few point mutations, often far behind byte 128
+            if ln:
+                k[int(rng.integers(0, ln))] = int(alphabet[rng.integers(0, len(alphabet))])
+        pool.append(bytes(k))
+    return [pool[i] for i in rng.integers(0, distinct, n)]
+
+
+@pytest.mark.parametrize("seed,max_len,ncols", [(1, 300, 1), (2, 1000, 1), (3, 260, 2), (4, 129, 1), (5, 400, 3)])
+def test_keys_longer_than_one_codec_window(ctx, seed, max_len, ncols):
+    """Keys of 0..1000 bytes: beyond 128 byte positions the key columns are cut into codec windows (SURVEY.md §7
+    "hard parts").  Index order, duplicates, Join, prefix Join, Except and Find against the oracle."""
+    rng = np.random.default_rng(seed)
+    alphabet = np.frombuffer(b"ab\x00\xffz", dtype=np.uint8)
+    n, m = 3000, 4000
+    build_vals = [long_keys(rng, n, max_len if c == 0 else max_len // 3, alphabet, n // 3, 0.8) for c in range(ncols)]
+    build = [StrCol.from_values(v) for v in build_vals]
+    g, o = DeviceIndex(ctx, build), orc.OracleIndex(build)
+    assert g.info()["key_positions"] > 128 or max(len(v) for v in build_vals[0]) <= 128
+    np.testing.assert_array_equal(g.perm(), o.perm)
+    assert g.first_dup == o.first_dup()
+    # probes: half taken from the build side (mutated sometimes), half fresh
+    for k in range(1, ncols + 1):
+        probe_vals = []
+        for c in range(k):
+            src = build_vals[c]
+            pv = [src[int(i)] if rng.random() < 0.6 else long_keys(rng, 1, max_len, alphabet, 1, 0.5)[0] for i in rng.integers(0, n, m)]
+            pv[0] = src[0] + b"a"            # longer than anything at that prefix
+            pv[1] = src[1][: len(src[1]) // 2]
+            probe_vals.append(pv)
+        probe = [StrCol.from_values(v) for v in probe_vals]
+        mt, ej = g.probe(probe), o.join(probe)
+        assert_join_equal(mt, ej)
+        mt.release()
+        for i in range(0, 40):
+            vals = [probe_vals[c][i] for c in range(k)]
+            glo, ghi = g.find(*vals)
+            olo, ohi = o.find(*vals)
+            assert ghi - glo == ohi - olo and (glo == olo or ghi == glo), (k, i)   # an empty range has no position
+    # dup groups and select keep working on multi-window codes
+    lo, hi = g.dup_groups()
+    sel = g.select(sorted(set(range(0, n, 3))))
+    assert sel.nrows == len(range(0, n, 3))
+    np.testing.assert_array_equal(sel.perm(), g.perm()[::3])
+    sel.close()
+    g.close()
