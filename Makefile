@@ -43,7 +43,21 @@ tests/cpp/test_host: tests/cpp/test_host.cpp csvplus_amd/host/csvplus.hpp includ
 tests/c/abi_demo: tests/c/abi_demo.c include/csvplus_hip.h $(LIBDIR)/libcsvplus_hip.so
 	$(CC) -O2 -std=c99 -Wall -Wextra -Iinclude $< -L$(LIBDIR) -lcsvplus_hip -Wl,-rpath,'$$ORIGIN/../../csvplus_amd/lib' -o $@
 
+# ---- sanitizer builds (CPU side only: the checker, the data generator, the host facade's own code) ----------
+# tests/test_asan.py runs them; findings abort the run.  The device side has its own canaries: cph_ctx_set_option
+# "pool_guard" (tools/gpu_guard.sh runs the whole GPU suite under it).
+SAN = -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -g -O1
+asan: oracle/_build/oracle_fuzz_asan oracle/_build/datagen_asan
+
+oracle/_build/oracle_fuzz_asan: tests/c/oracle_fuzz.c oracle/csvplus_oracle.c
+	@mkdir -p oracle/_build
+	$(CC) $(SAN) -Wall tests/c/oracle_fuzz.c -o $@
+
+oracle/_build/datagen_asan: tests/c/datagen_check.c $(CSRC)/datagen.c
+	@mkdir -p oracle/_build
+	$(CC) $(SAN) -fopenmp -Wall tests/c/datagen_check.c -o $@
+
 clean:
 	rm -rf $(LIBDIR) oracle/_build tests/cpp/test_host tests/c/abi_demo
 
-.PHONY: all hip datagen oracle host clean
+.PHONY: all hip datagen oracle host asan clean

@@ -10,8 +10,14 @@
 namespace cph {
 
 // ---- DevicePool ------------------------------------------------------------------------------
+// Guard mode (cph_ctx_set_option "pool_guard"): every block carries kGuardBytes of 0xA5 behind the bytes its user
+// asked for; release() waits for the device and checks that nobody wrote there.  A debugging aid for the kernels'
+// bounds (canaries) — synchronous, so never on in a measured run.
+constexpr size_t kGuardBytes = 256;
+constexpr uint8_t kGuardByte = 0xA5;
+
 Status DevicePool::alloc(size_t bytes, void** out) {
-    const size_t want = (bytes + 255) & ~(size_t)255;
+    const size_t want = (bytes + (guard ? kGuardBytes : 0) + 255) & ~(size_t)255;
     int best = -1;
     for (int i = 0; i < (int)free_.size(); i++) {
         if (free_[i].cap >= want && free_[i].cap <= want * 2 + (1u << 20)) {
@@ -38,17 +44,43 @@ Status DevicePool::alloc(size_t bytes, void** out) {
             return {CPH_ERR_NOMEM, buf};
         }
         n_hipmalloc++;
-        b = Block{p, want};
+        b = Block{p, want, 0};
     }
+    b.user = guard ? bytes : 0;
+    b.guarded = guard;
+    if (guard && hipMemset(static_cast<uint8_t*>(b.p) + bytes, kGuardByte, kGuardBytes) != hipSuccess) (void)hipGetLastError();
     live_.push_back(b);
     bytes_live += b.cap;
     *out = b.p;
     return {};
 }
 
+void DevicePool::check_block(const Block& b) {
+    if (!b.guarded) return;
+    uint8_t h[kGuardBytes];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, static_cast<uint8_t*>(b.p) + b.user, kGuardBytes, hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    for (size_t i = 0; i < kGuardBytes; i++)
+        if (h[i] != kGuardByte) {
+            if (guard_violations++ == 0) {
+                char buf[160];
+                snprintf(buf, sizeof buf, "pool guard: byte %zu behind a %zu-byte block was overwritten (0x%02x)", i, b.user, h[i]);
+                first_violation = buf;
+            }
+            return;
+        }
+}
+
+void DevicePool::check_live() {
+    for (const auto& b : live_) check_block(b);
+}
+
 void DevicePool::release(void* p) {
     for (size_t i = 0; i < live_.size(); i++) {
         if (live_[i].p == p) {
+            check_block(live_[i]);
             bytes_live -= live_[i].cap;
             bytes_cached += live_[i].cap;
             free_.push_back(live_[i]);
@@ -551,6 +583,15 @@ CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value
     if (k == "chain_debug") ctx->chain_debug = (int)value;
     else if (k == "sort_threads") ctx->sort_threads = (int)value;
     else if (k == "sort_rbits") ctx->sort_rbits = (int)value;
+    else if (k == "pool_guard") ctx->pool.guard = value != 0;
+    else if (k == "pool_guard_check") {
+        ctx->pool.check_live();
+        if (ctx->pool.guard_violations) {
+            char b[64];
+            snprintf(b, sizeof b, " (%llu blocks)", (unsigned long long)ctx->pool.guard_violations);
+            return fail_with(ctx, {CPH_ERR_INVALID, ctx->pool.first_violation + b});
+        }
+    }
     else return fail_with(ctx, {CPH_ERR_INVALID, "unknown option: " + k});
     return CPH_OK;
 }

@@ -57,9 +57,15 @@ public:
     void   trim();             // hipFree everything cached
     ~DevicePool();
     size_t bytes_live = 0, bytes_cached = 0, n_hipmalloc = 0;
+    // guard mode (debugging aid): canary bytes behind every block, verified at release
+    bool guard = false;
+    uint64_t guard_violations = 0;
+    std::string first_violation;
+    void check_live();
 
 private:
-    struct Block { void* p; size_t cap; };
+    struct Block { void* p; size_t cap; size_t user; bool guarded = false; };
+    void check_block(const Block& b);
     std::vector<Block> free_;
     std::vector<Block> live_;
 };

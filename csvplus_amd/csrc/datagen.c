@@ -72,6 +72,7 @@ static inline uint64_t bounded(uint64_t r, uint64_t n) {
  * with cycle walking. */
 static uint64_t feistel_perm(uint64_t x, uint64_t n, uint64_t seed) {
     if (n <= 1) return 0;
+    if (x >= n) x %= n;   /* rows past the domain wrap around (cycle walking would never return for them) */
     int bits = 0;
     while (((uint64_t)1 << bits) < n) bits++;
     if (bits & 1) bits++;

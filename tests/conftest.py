@@ -32,5 +32,10 @@ def ctx():
     from csvplus_amd import Context
 
     c = Context(0)
+    guard = os.environ.get("CPH_POOL_GUARD") == "1"   # whole-suite canary run: tools/gpu_guard.sh
+    if guard:
+        c.set_option("pool_guard", 1)
     yield c
+    if guard:
+        c.set_option("pool_guard_check", 0)   # raises CphError if any canary behind a device block was overwritten
     c.close()
