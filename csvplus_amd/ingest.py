@@ -85,25 +85,114 @@ def csv_parse(ctx: N.Context, data, col_index, *, comma=b",", comment=None, trim
     return CsvTable(ctx, out, out_mem)
 
 
+class CsvError(ValueError):
+    """A parse error in the first record, with Go's error kinds (encoding/csv: ErrBareQuote, ErrQuote)."""
+
+    def __init__(self, kind: str, line: int):
+        super().__init__(f"record on line {line}: {kind}")
+        self.kind, self.line = kind, line
+
+
+_GO_SPACES = {0x09, 0x0A, 0x0B, 0x0C, 0x0D, 0x20, 0x85, 0xA0, 0x1680, 0x2028, 0x2029, 0x202F, 0x205F, 0x3000} | set(
+    range(0x2000, 0x200B))
+
+
+def _trim_left_go(line: bytes) -> bytes:
+    """strings.TrimLeftFunc(line, unicode.IsSpace) on UTF-8 bytes (an invalid byte is RuneError: not a space)."""
+    i, n = 0, len(line)
+    while i < n:
+        b0 = line[i]
+        if b0 < 0x80:
+            cp, w = b0, 1
+        else:
+            w = 2 if b0 >> 5 == 0b110 else 3 if b0 >> 4 == 0b1110 else 4 if b0 >> 3 == 0b11110 else 0
+            try:
+                cp = ord(line[i:i + w].decode("utf-8")) if w else -1
+            except UnicodeDecodeError:
+                cp = -1
+        if cp not in _GO_SPACES:
+            break
+        i += w
+    return line[i:]
+
+
 def first_record(text: bytes, comma=b",", comment=None, trim_leading_space=False):
-    """The header line, parsed on the host with Go's rules (enough of them for one record): what
-    makeHeader (csvplus.go:1149-1206) reads before the body is handed to the device."""
-    import csv
-    import io
-    pos, n = 0, len(text)
-    while pos < n:   # skip empty / comment lines
+    """The first record of `text` by the rules of Go's encoding/csv Reader.readRecord — the record makeHeader
+    (csvplus.go:1149-1206) reads before the body is handed to the device.  Line endings: "\r\n" counts as "\n",
+    a final "\r" before EOF is dropped; lines that are empty after that, or start with the comment rune, are
+    skipped ("\r\r\n" is NOT empty: it is the record ["\r"]); a quote inside an unquoted field is ErrBareQuote,
+    anything but a separator or the line end behind a closing quote is ErrQuote, a quoted field may span lines.
+    Returns the list of fields (bytes), or None at EOF.  Raises CsvError."""
+    pos, n, lineno = 0, len(text), 0
+    sep = comma[0]
+
+    def read_line():
+        nonlocal pos, lineno
+        if pos >= n:
+            return None
         end = text.find(b"\n", pos)
-        line = text[pos:end if end >= 0 else n]
-        if line.rstrip(b"\r") == b"" or (comment and line.startswith(comment)):
-            pos = (end + 1) if end >= 0 else n
+        if end < 0:
+            line, pos = text[pos:], n
+            if line.endswith(b"\r"):
+                line = line[:-1]          # a trailing "\r" before EOF is dropped
+        else:
+            line, pos = text[pos:end + 1], end + 1
+            if line.endswith(b"\r\n"):
+                line = line[:-2] + b"\n"
+        lineno += 1
+        return line
+
+    while True:
+        line = read_line()
+        if line is None:
+            return None
+        if comment and line.startswith(comment):
+            continue
+        if line in (b"\n", b""):
             continue
         break
-    if pos >= n:
-        return None
-    # a quoted header field may span lines: let the csv module find the record end
-    rd = csv.reader(io.StringIO(text[pos:pos + (1 << 20)].decode("utf-8", "surrogateescape"), newline=""),
-                    delimiter=comma.decode(), skipinitialspace=trim_leading_space, strict=True)
-    return [f.encode("utf-8", "surrogateescape") for f in next(rd)]
+    rec_line = lineno
+    fields = []
+    while True:
+        if trim_leading_space:
+            line = _trim_left_go(line)
+        if not line.startswith(b'"'):                       # unquoted field
+            i = line.find(comma)
+            field = line[:i] if i >= 0 else line[:len(line) - (1 if line.endswith(b"\n") else 0)]
+            if b'"' in field:
+                raise CsvError("bare \" in non-quoted field", rec_line)
+            fields.append(field)
+            if i >= 0:
+                line = line[i + 1:]
+                continue
+            return fields
+        line = line[1:]                                     # quoted field
+        buf = bytearray()
+        while True:
+            i = line.find(b'"')
+            if i >= 0:
+                buf += line[:i]
+                line = line[i + 1:]
+                if line[:1] == b'"':                       # "" -> one quote
+                    buf += b'"'
+                    line = line[1:]
+                elif line[:1] and line[0] == sep:            # closing quote, next field
+                    line = line[1:]
+                    fields.append(bytes(buf))
+                    break
+                elif line in (b"", b"\n"):                  # closing quote at the end of the line
+                    fields.append(bytes(buf))
+                    return fields
+                else:
+                    raise CsvError("extraneous or missing \" in quoted-field", rec_line)
+            elif line:                                       # the field continues on the next line
+                buf += line
+                nxt = read_line()
+                if nxt is None:                              # EOF inside quotes
+                    raise CsvError("extraneous or missing \" in quoted-field", rec_line)
+                line = nxt
+            else:
+                raise CsvError("extraneous or missing \" in quoted-field", rec_line)
 
 
 def _b(x):
@@ -148,7 +237,7 @@ def resolve_header(first, *, select=None, expect_header=None):
 
 
 def read_csv(ctx: N.Context, text: bytes, *, select=None, expect_header=None, assume_header=None, comma=b",",
-             comment=None, trim_leading_space=False, num_fields=0, out_mem=N.CPH_MEM_HOST) -> CsvTable:
+             comment=None, trim_leading_space=False, lazy_quotes=False, num_fields=0, out_mem=N.CPH_MEM_HOST) -> CsvTable:
     """A csvplus Reader materialised as columns: FromFile(...)[.SelectColumns(select...) |
     .ExpectHeader(expect_header) | .AssumeHeader(assume_header)][.NumFields(num_fields)].
 
@@ -158,6 +247,8 @@ def read_csv(ctx: N.Context, text: bytes, *, select=None, expect_header=None, as
     Returns the table with `.names`; `.error_kind/.error_record` report a parse error the way the reference
     returns it after delivering the rows before it.  Header problems raise (the reference fails at line 1).
     """
+    if lazy_quotes:   # Reader.LazyQuotes (csvplus.go:1040-1043): the device parser has no lazy mode
+        raise NotImplementedError("LazyQuotes is not supported by the device CSV reader")
     skip = 0
     if assume_header is not None:
         if not assume_header:

@@ -53,51 +53,54 @@ def join_to_csv(ctx: N.Context, stream: Table, steps, out_columns, timings: dict
             ctx.synchronize()
             timings[name] = timings.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
 
-    t0 = time.perf_counter()
-    indices = []
-    for tab, key, _ in steps:
-        ix = N.DeviceIndex(ctx, [tab[key]], unique=True)
-        if ix.status == N.CPH_ERR_DUPLICATE:
-            raise ValueError(f"duplicate value while creating unique index on {key!r} (sorted position {ix.first_dup})")
-        indices.append(ix)
-    lap("index_ms", t0)
-    t0 = time.perf_counter()
-    ch = N.join_chain(ctx, [(ix, [stream[skey]]) for ix, (_, _, skey) in zip(indices, steps)], out_mem=N.CPH_MEM_DEVICE)
-    ptrs = ch.device_ptrs()
-    n = ch.nrows
-    lap("join_ms", t0)
-    t0 = time.perf_counter()
-    from .materialize import csv_write
-    tabs = [t for t, _, _ in steps]
-    cols, ids = [], []
-    for _, tab, col in out_columns:
-        cols.append(tab[col])
-        if tab is stream:
-            ids.append(None if ch.identity or n == 0 else (ptrs["stream_row"], 64, n))
-        else:
-            ids.append((ptrs["build_row"][tabs.index(tab)], 32, n))
-    if n == 0:
-        cols, ids = [c.head(0) for c in cols], [None] * len(cols)
-    if fused:
-        # mergeRows inside the writer: fields are read through the row-id tuples, nothing is materialised
-        text = csv_write(ctx, cols, [name for name, _, _ in out_columns], out_mem=out_mem, row_ids=ids, nrows=n)
-        lap("to_csv_ms", t0)
-    else:
-        bufs, gcols = [], []
-        for c, i in zip(cols, ids):
-            if i is None and c.nrows == n:
-                gcols.append(c)
-                continue
-            cb = gather_rows(ctx, c, i, out_mem=N.CPH_MEM_DEVICE)
-            bufs.append(cb)
-            gcols.append(cb.as_device_strcol())
-        lap("gather_ms", t0)
+    indices, ch, bufs = [], None, []
+    try:   # whatever fails below, the indexes, the chain and the gathered columns go back to the ctx pool
         t0 = time.perf_counter()
-        text = csv_write(ctx, gcols, [name for name, _, _ in out_columns], out_mem=out_mem)
-        lap("to_csv_ms", t0)
+        for tab, key, _ in steps:
+            ix = N.DeviceIndex(ctx, [tab[key]], unique=True)
+            indices.append(ix)
+            if ix.status == N.CPH_ERR_DUPLICATE:
+                raise ValueError(f"duplicate value while creating unique index on {key!r} (sorted position {ix.first_dup})")
+        lap("index_ms", t0)
+        t0 = time.perf_counter()
+        ch = N.join_chain(ctx, [(ix, [stream[skey]]) for ix, (_, _, skey) in zip(indices, steps)], out_mem=N.CPH_MEM_DEVICE)
+        ptrs = ch.device_ptrs()
+        n = ch.nrows
+        lap("join_ms", t0)
+        t0 = time.perf_counter()
+        from .materialize import csv_write
+        tabs = [t for t, _, _ in steps]
+        cols, ids = [], []
+        for _, tab, col in out_columns:
+            cols.append(tab[col])
+            if tab is stream:
+                ids.append(None if ch.identity or n == 0 else (ptrs["stream_row"], 64, n))
+            else:
+                ids.append((ptrs["build_row"][tabs.index(tab)], 32, n))
+        if n == 0:
+            cols, ids = [c.head(0) for c in cols], [None] * len(cols)
+        if fused:
+            # mergeRows inside the writer: fields are read through the row-id tuples, nothing is materialised
+            text = csv_write(ctx, cols, [name for name, _, _ in out_columns], out_mem=out_mem, row_ids=ids, nrows=n)
+            lap("to_csv_ms", t0)
+        else:
+            gcols = []
+            for c, i in zip(cols, ids):
+                if i is None and c.nrows == n:
+                    gcols.append(c)
+                    continue
+                cb = gather_rows(ctx, c, i, out_mem=N.CPH_MEM_DEVICE)
+                bufs.append(cb)
+                gcols.append(cb.as_device_strcol())
+            lap("gather_ms", t0)
+            t0 = time.perf_counter()
+            text = csv_write(ctx, gcols, [name for name, _, _ in out_columns], out_mem=out_mem)
+            lap("to_csv_ms", t0)
+        return text
+    finally:
         for cb in bufs:
             cb.release()
-    ch.release()
-    for ix in indices:
-        ix.close()
-    return text
+        if ch is not None:
+            ch.release()
+        for ix in indices:
+            ix.close()

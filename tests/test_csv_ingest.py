@@ -304,3 +304,33 @@ def test_resolve_header_like_makeHeader():
     assert first_record(b"# c\n\n\"a\nb\",c\r\nx,y\n", comment=b"#") == [b"a\nb", b"c"]
     assert first_record(b"\n\n") is None
     assert first_record(b" a, b\n", trim_leading_space=True) == [b"a", b"b"]
+
+
+def test_first_record_follows_go_reader_rules():
+    """ingest.first_record (the header line, parsed on the host) against the oracle's restatement of Go's
+    readRecord on the first record of random, mostly malformed texts: same fields or the same error kind.
+    Includes the cases Python's csv module gets differently ("\\r\\r\\n" is the record ["\\r"], a bare quote in an
+    unquoted field is an error, TrimLeadingSpace trims Unicode spaces, a lone "\\r" does not end a record)."""
+    from csvplus_amd.ingest import CsvError, first_record
+
+    rng = np.random.default_rng(41)
+    alphabet = np.frombuffer(b'ab ,"\n\r#\t', dtype=np.uint8)
+    texts = [b"\r\r\nx\n", b'x"y,z\n', b"a\rb,c\n", b"\xc2\xa0a,\xe3\x80\x80b\n", b'"a\r\nb",c\r\n', b"a,b\r", b"", b"\n\n", b'"abc',
+             b"#c\n\n a,\tb\n"]
+    texts += [alphabet[rng.integers(0, len(alphabet), int(rng.integers(0, 40)))].tobytes() for _ in range(3000)]
+    kinds = {1: "bare", 2: "extraneous"}
+    for t in texts:
+        for trim in (False, True):
+            try:
+                got = first_record(t, comment=b"#", trim_leading_space=trim)
+            except CsvError as e:
+                got = ("ERR", e.kind.split()[0])
+            cols, ek, er = orc.csv_parse(t, list(range(12)), comment=b"#", trim_leading_space=trim, fields_per_record=-1)
+            if ek and er == 0:
+                assert got == ("ERR", kinds[ek]), (t, trim, got)
+            elif cols[0].nrows == 0:
+                assert got is None, (t, trim, got)
+            else:
+                want = [c.value(0) for c in cols]
+                assert isinstance(got, list) and len(got) <= 12, (t, trim, got)
+                assert want[:len(got)] == got and all(v == b"" for v in want[len(got):]), (t, trim, got, want)
