@@ -19,7 +19,7 @@ all: hip datagen oracle host
 
 hip: $(LIBDIR)/libcsvplus_hip.so
 datagen: $(LIBDIR)/libcph_datagen.so
-oracle: oracle/_build/liboracle.so
+oracle: oracle/_build/liboracle.so oracle/_build/libfaithful.so
 host: tests/cpp/test_host tests/c/abi_demo
 
 $(LIBDIR)/obj/%.o: $(CSRC)/%.hip $(HIP_HDRS)
@@ -36,6 +36,10 @@ $(LIBDIR)/libcph_datagen.so: $(CSRC)/datagen.c
 oracle/_build/liboracle.so: oracle/csvplus_oracle.c
 	@mkdir -p oracle/_build
 	$(CC) -O2 -fPIC -shared -fvisibility=hidden -Wall $< -o $@
+
+oracle/_build/libfaithful.so: oracle/faithful.cpp
+	@mkdir -p oracle/_build
+	$(CXX) -O2 -std=c++17 -fopenmp -fPIC -shared -fvisibility=hidden -Wall $< -o $@
 
 tests/cpp/test_host: tests/cpp/test_host.cpp csvplus_amd/host/csvplus.hpp include/csvplus_hip.h $(LIBDIR)/libcsvplus_hip.so
 	$(CXX) -O2 -std=c++17 -Wall -Iinclude -Icsvplus_amd/host $< -L$(LIBDIR) -lcsvplus_hip -Wl,-rpath,'$$ORIGIN/../../csvplus_amd/lib' -o $@

@@ -245,3 +245,57 @@ def dedup_rows(rows, columns, resolve):
             lower += 1
             dest += 1
     return rows[:dest]                          # :862-864
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baselines with the reference's cost model (oracle/faithful.cpp): bench.py's cpu_baseline leg only
+# ---------------------------------------------------------------------------------------------------------------
+_fth = None
+
+
+def _load_faithful():
+    global _fth
+    if _fth is None:
+        path = Path(__file__).resolve().parent / "_build" / "libfaithful.so"
+        if not path.exists():
+            raise ImportError(f"{path} not found: run `make oracle`")
+        lib = C.CDLL(str(path))
+        lib.fth_chain_join.restype = C.c_uint64
+        lib.fth_lean_mt_join.restype = C.c_uint64
+        lib.fth_max_threads.restype = C.c_int
+        _fth = lib
+    return _fth
+
+
+def faithful_chain_join(cust: dict, cust_key: str, prod: dict, prod_key: str, ords: dict, ord_cust: str, ord_prod: str):
+    """Map-per-row restatement of orders.Join(customers, cust).Join(products, prod) (single thread).
+    Tables are {name: StrCol}.  Returns dict(joined, checksum, rows_s, index_s, join_s)."""
+    lib = _load_faithful()
+
+    def pack(tab):
+        names = list(tab.keys())
+        arr, keep = _cols([tab[n] for n in names])
+        cn = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        return arr, cn, len(names), keep
+
+    ca, cn, cc, k1 = pack(cust)
+    pa, pn, pc, k2 = pack(prod)
+    oa, on, oc, k3 = pack(ords)
+    times = (C.c_double * 3)()
+    chk = C.c_uint64()
+    joined = int(lib.fth_chain_join(ca, cn, cc, cust_key.encode(), pa, pn, pc, prod_key.encode(), oa, on, oc, ord_cust.encode(),
+                                    ord_prod.encode(), times, C.byref(chk)))
+    del k1, k2, k3
+    return {"joined": joined, "checksum": int(chk.value), "rows_s": times[0], "index_s": times[1], "join_s": times[2]}
+
+
+def lean_mt_join(build, probe, threads: int = 0):
+    """Lean SoA unique join on `threads` cores (0 = all).  Returns (build_row uint32[m], joined, sort_s, probe_s, threads)."""
+    lib = _load_faithful()
+    ba, k1 = _cols([build])
+    pa, k2 = _cols([probe])
+    out = np.empty(probe.nrows, dtype=np.uint32)
+    times = (C.c_double * 2)()
+    joined = int(lib.fth_lean_mt_join(ba, pa, int(threads), out.ctypes.data_as(C.c_void_p), times))
+    del k1, k2
+    return out, joined, times[0], times[1], (threads or int(lib.fth_max_threads()))

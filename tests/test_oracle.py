@@ -164,3 +164,28 @@ def test_empty_and_single():
     assert j["nmatches"] == 0 and j["cnt"].tolist() == [0, 0]
     ix = orc.OracleIndex([StrCol.from_values([""])])
     assert ix.join([StrCol.from_values(["x", ""])])["cnt"].tolist() == [0, 1]
+
+
+def test_cost_model_baselines_agree_with_the_oracle():
+    """oracle/faithful.cpp (bench.py's cpu_baseline variants): the map-per-row restatement and the all-cores lean
+    join must produce the oracle's results — they are only allowed to differ in what they cost."""
+    from csvplus_amd import datagen as dg
+
+    nc, npd, m = 3000, 40, 20_000
+    cust, prod = dg.customers(nc), dg.products(npd)
+    ords = dg.orders(m, 2 * nc, npd)                       # half of the customer ids miss
+    oa, ob = orc.OracleIndex([cust["id"]]), orc.OracleIndex([prod["prod_id"]])
+    j1 = oa.join([ords["cust_id"]])
+    j2 = ob.join([ords["prod_id"]], row_sel=j1["probe_idx"].astype(np.uint32))
+    r = orc.faithful_chain_join(cust, "id", prod, "prod_id", ords, "cust_id", "prod_id")
+    assert r["joined"] == j2["nmatches"] and r["checksum"] > 0
+    rows, joined, _, _, threads = orc.lean_mt_join(cust["id"], ords["cust_id"], threads=2)
+    assert joined == j1["nmatches"] and threads == 2
+    hit = rows != 0xFFFFFFFF
+    np.testing.assert_array_equal(np.nonzero(hit)[0].astype(np.uint64), j1["probe_idx"])
+    np.testing.assert_array_equal(rows[hit], j1["build_row"])
+    # a duplicate key makes the faithful UniqueIndexOn fail like the reference (:751)
+    dup = {"id": cust["id"].slice(0, 10), "name": cust["name"].slice(0, 10)}
+    from csvplus_amd import StrCol
+    dup["id"] = StrCol.from_values([b"00000001"] * 10)
+    assert orc.faithful_chain_join(dup, "id", prod, "prod_id", ords, "cust_id", "prod_id")["joined"] == 2**64 - 1

@@ -17,4 +17,6 @@ for k, v in (d.get("index_on_1e8") or {}).items():
     print("    ", v["kernels_ms"])
 for k in ("e2e_pinned_host", "cpu_baseline"):
     if k in d:
-        print(k, {a: b for a, b in d[k].items() if a not in ("scope", "sample")})
+        print(k, {a: b for a, b in d[k].items() if a not in ("scope", "sample", "variants")})
+for k, v in ((d.get("cpu_baseline") or {}).get("variants") or {}).items():
+    print("   ", k, {a: b for a, b in v.items() if a != "sample"})
