@@ -306,6 +306,20 @@ struct ValueHeadT {
         c1 = len > 8 ? load_value_chunk(col.data, begin, len, 1) : 0;
         c2 = len > 16 ? load_value_chunk(col.data, begin, len, 2) : 0;
     }
+    // the same three chunks without a branch (one load each, device_utils.hpp: load_chunk_nobranch), zero when the
+    // value ends before them: the caller's rows then overlap their loads instead of waiting one by one
+    __device__ __forceinline__ void chunks_nobranch(const DevCol& col) {
+        const uint64_t p = (uint64_t)(uintptr_t)col.data;
+        const uint8_t* base8 = (const uint8_t*)(uintptr_t)(p & ~7ull);
+        const uint32_t delta = (uint32_t)(p & 7ull);
+        const uint32_t l32 = len > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)len;
+        const uint64_t a = load_chunk_nobranch<uint64_t>(base8, delta, begin, l32, 0);
+        const uint64_t b = load_chunk_nobranch<uint64_t>(base8, delta, begin, l32, 1);
+        const uint64_t c = load_chunk_nobranch<uint64_t>(base8, delta, begin, l32, 2);
+        c0 = l32 > 0 ? a : 0;
+        c1 = l32 > 8 ? b : 0;
+        c2 = l32 > 16 ? c : 0;
+    }
     __device__ __forceinline__ void load(const DevCol& col, uint64_t row) {
         span(col, row);
         chunks(col);

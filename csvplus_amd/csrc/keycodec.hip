@@ -319,12 +319,15 @@ __global__ __launch_bounds__(256) void k_group_stats(ColsArg cols, GroupLayout l
                 cur_base = g;
                 if (lay.col[g] != cur_col) {
                     cur_col = lay.col[g];
+                    // rows past the end re-read the last selected row (their symbols are never inserted): no branch
+                    // around the loads, so the kGroupRows rows of a lane are in flight together
 #pragma unroll
-                    for (int k = 0; k < kGroupRows; k++)
-                        if (live[k]) v[k].span(cols.c[cur_col], (base + (uint64_t)k * 256 + threadIdx.x) * step);
+                    for (int k = 0; k < kGroupRows; k++) {
+                        const uint64_t i = base + (uint64_t)k * 256 + threadIdx.x;
+                        v[k].span(cols.c[cur_col], (i < nsel ? i : nsel - 1) * step);
+                    }
 #pragma unroll
-                    for (int k = 0; k < kGroupRows; k++)
-                        if (live[k]) v[k].chunks(cols.c[cur_col]);
+                    for (int k = 0; k < kGroupRows; k++) v[k].chunks_nobranch(cols.c[cur_col]);
                 }
 #pragma unroll
                 for (int k = 0; k < kGroupRows; k++) win[k] = live[k] ? v[k].window(cols.c[cur_col], lay.q0[g]) : 0;
@@ -743,11 +746,12 @@ __global__ __launch_bounds__(kEncodeThreads) void k_encode_build_plan(ColsArg co
             if (col != cur_col) {   // spans of all rows first, then their chunks: the loads overlap
                 cur_col = col;
 #pragma unroll
-                for (int k = 0; k < kEncodeRows; k++)
-                    if (live[k]) v[k].span(cols.c[col], base + (uint64_t)k * kEncodeThreads + threadIdx.x);
+                for (int k = 0; k < kEncodeRows; k++) {   // rows past the end re-read the last row (never stored)
+                    const uint64_t i = base + (uint64_t)k * kEncodeThreads + threadIdx.x;
+                    v[k].span(cols.c[col], i < n ? i : n - 1);
+                }
 #pragma unroll
-                for (int k = 0; k < kEncodeRows; k++)
-                    if (live[k]) v[k].chunks(cols.c[col]);
+                for (int k = 0; k < kEncodeRows; k++) v[k].chunks_nobranch(cols.c[col]);
             }
             const uint64_t mult = plan[u].mult;
             // J = index of the 8-byte chunk the unit starts in: uniform, so one branch per unit selects code in

@@ -252,34 +252,36 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe_fast(DevCol col, const 
     for (int ph = 0; ph < kProbeItems / kProbeRows; ph++) {
         uint64_t i[kProbeRows], row[kProbeRows];
         bool ok[kProbeRows];
+        // straight-line loads: slots past the end re-read the last probe row (their results are never stored), so the
+        // kProbeRows loads of every phase are in flight together (a branch per row would put a wait between them)
 #pragma unroll
         for (int k = 0; k < kProbeRows; k++) {
             i[k] = tile0 + (uint64_t)(ph * kProbeRows + k) * kProbeThreads + threadIdx.x;
             ok[k] = i[k] < nprobe;
-            row[k] = i[k];
+            row[k] = ok[k] ? i[k] : nprobe - 1;
         }
         if (sel.ptr) {
             if (sel.bits == 32) {
 #pragma unroll
-                for (int k = 0; k < kProbeRows; k++)
-                    if (ok[k]) row[k] = (uint64_t) reinterpret_cast<const uint32_t*>(sel.ptr)[i[k]] - sel.base;
+                for (int k = 0; k < kProbeRows; k++) row[k] = (uint64_t) reinterpret_cast<const uint32_t*>(sel.ptr)[row[k]] - sel.base;
             } else {
 #pragma unroll
-                for (int k = 0; k < kProbeRows; k++)
-                    if (ok[k]) row[k] = reinterpret_cast<const uint64_t*>(sel.ptr)[i[k]] - sel.base;
+                for (int k = 0; k < kProbeRows; k++) row[k] = reinterpret_cast<const uint64_t*>(sel.ptr)[row[k]] - sel.base;
             }
         }
         uint64_t begin[kProbeRows], len[kProbeRows], c0[kProbeRows], c1[kProbeRows];
 #pragma unroll
-        for (int k = 0; k < kProbeRows; k++) {
-            begin[k] = 0;
-            len[k] = 0;
-            if (ok[k]) value_span(col, row[k], &begin[k], &len[k]);
-        }
+        for (int k = 0; k < kProbeRows; k++) value_span(col, row[k], &begin[k], &len[k]);
+        {
+            const uint64_t p = (uint64_t)(uintptr_t)col.data;
+            const uint8_t* base8 = (const uint8_t*)(uintptr_t)(p & ~7ull);
+            const uint32_t delta = (uint32_t)(p & 7ull);
 #pragma unroll
-        for (int k = 0; k < kProbeRows; k++) {
-            c0[k] = len[k] ? load_value_chunk(col.data, begin[k], len[k], 0) : 0;
-            c1[k] = (long_keys && len[k] > 8) ? load_value_chunk(col.data, begin[k], len[k], 1) : 0;
+            for (int k = 0; k < kProbeRows; k++) {
+                const uint32_t l32 = len[k] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)len[k];
+                c0[k] = load_chunk_nobranch<uint64_t>(base8, delta, begin[k], l32, 0);
+                c1[k] = long_keys ? load_chunk_nobranch<uint64_t>(base8, delta, begin[k], l32, 1) : 0;
+            }
         }
         uint64_t code[kProbeRows];
         bool valid[kProbeRows];
@@ -293,9 +295,10 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe_fast(DevCol col, const 
         if constexpr (TABLE) {
             TableEntry e[kProbeRows];
 #pragma unroll
-            for (int k = 0; k < kProbeRows; k++) e[k] = valid[k] ? table[code[k]] : TableEntry{kTableAbsent, kTableAbsent};
+            for (int k = 0; k < kProbeRows; k++) e[k] = table[valid[k] ? code[k] : 0];   // entry 0 always exists
 #pragma unroll
             for (int k = 0; k < kProbeRows; k++) {
+                if (!valid[k]) e[k] = TableEntry{kTableAbsent, kTableAbsent};
                 e_b[k] = e[k].b;
                 lo[k] = e[k].a;
                 cnt[k] = table_unique ? (e[k].a != kTableAbsent ? 1u : 0u) : e[k].b - e[k].a;
