@@ -375,7 +375,8 @@ Status index_find_device(cph_ctx* ctx, const cph_index* ix, const uint64_t* q_ex
 
 // index_ops.hip: an index as descriptor (host bytes) + sorted codes + perm (device arrays)
 void index_desc_serialize(const cph_index* ix, std::vector<uint8_t>* out);
-bool index_desc_size(const uint8_t* p, size_t n, size_t* need);     // from the first sizeof(header) bytes
+size_t index_desc_header_bytes();                                   // bytes index_desc_size needs to see
+bool index_desc_size(const uint8_t* p, size_t n, size_t* need);     // size of the whole descriptor, from its header
 bool index_desc_parse(const uint8_t* p, size_t n, cph_index* ix);
 Status index_adopt_payload(cph_ctx* ctx, cph_index* ix);            // validate the device arrays, finish the index
 size_t index_code_bytes(const cph_index* ix);                       // bytes of sorted codes per row

@@ -509,8 +509,6 @@ CPH_API int32_t cph_dist_index_broadcast(cph_dist* d, const cph_index* root_inde
     if (hipSetDevice(ctx->device) != hipSuccess) return fail_with(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});
     const bool is_root = d->t->rank() == root;
     if (is_root && !root_index) return fail_with(ctx, {CPH_ERR_INVALID, "the root rank must pass its index"});
-    if (is_root && !root_index->windows.empty())
-        return fail_with(ctx, {CPH_ERR_INVALID, "broadcasting an index whose keys span several codec windows (> 128 key bytes) is not implemented"});
     cph_index* nx = nullptr;
     auto run = [&]() -> Status {
         // 1. descriptor size, 2. descriptor, 3. sorted codes, 4. perm — all through device buffers

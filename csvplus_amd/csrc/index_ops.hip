@@ -138,7 +138,9 @@ static Status index_validate_payload(cph_ctx* ctx, const cph_index* ix) {
 
 // Finishes an index whose codec / sorted_codes / perm are in place: unique scan + table decision.
 static Status finish_index(cph_ctx* ctx, cph_index* ix) {
-    CPH_TRY(codec_upload(ctx, ix->codec, &ix->codec_dev));
+    if (ix->windows.empty()) CPH_TRY(codec_upload(ctx, ix->codec, &ix->codec_dev));
+    for (auto& w : ix->windows)
+        if (!w.codec_dev) CPH_TRY(codec_upload(ctx, w.codec, &w.codec_dev));
     CPH_TRY(index_first_dup_launch(ctx, ix));
     CPH_TRY(index_first_dup_read(ctx, ix));
     index_plan_table(ix);
@@ -151,14 +153,27 @@ static size_t code_bytes(const cph_index* ix) {
 
 
 // ---- index descriptor: everything of an index except its two device arrays -----------------------------------
-// (header + codec tables, little endian).  Shared by the file format (cph_index_save/_load) and by the broadcast
-// of a built index to the other ranks (dist.hip): both move descriptor, sorted codes, perm.
-constexpr char kMagic[8] = {'C', 'P', 'H', 'I', 'D', 'X', '3', '\n'};
-struct FileHeader {
+// (little endian).  Shared by the file format (cph_index_save/_load) and by the broadcast of a built index to the
+// other ranks (dist.hip): both move descriptor, sorted codes, perm.
+//   IndexHeader | nwindows == 0:  CodecBlock                          (keys within one codec window)
+//               | nwindows  > 0:  nwindows x (WindowHeader, CodecBlock)   
+//   CodecBlock = CodecHeader + radix u16[npos] + mult u64[npos] + word_of i32[npos] + lut u16[npos*257]
+//                [+ unit u8[npos] + dict_off i32[npos] + dict_len i32[npos] + dict u64[ndict]   when has_groups]
+constexpr char kMagic[8] = {'C', 'P', 'H', 'I', 'D', 'X', '4', '\n'};
+struct IndexHeader {
     char magic[8];
+    uint64_t desc_bytes;         // size of the whole descriptor, this header included
     uint64_t nrows;
     uint64_t table_rows;         // rows of the table the index was built over: perm values are < table_rows
-    int32_t nkeycols, ncols, npos, nwords, key32, sort_passes;
+    int32_t nkeycols, sort_passes, nwindows, reserved_;
+};
+struct WindowHeader {
+    int32_t nseg, word_base;
+    int32_t seg_col[kMaxKeyCols];
+    uint32_t seg_skip[kMaxKeyCols], seg_take[kMaxKeyCols];
+};
+struct CodecHeader {
+    int32_t ncols, npos, nwords, key32;
     int32_t has_groups, ndict;   // dictionary-coded groups: unit/dict_off/dict_len per position + ndict entries
     int32_t col_start[kMaxKeyCols + 1];
     int32_t col_maxlen[kMaxKeyCols];
@@ -166,19 +181,19 @@ struct FileHeader {
     int32_t word_bits[kMaxWords];
     uint64_t word_states[kMaxWords];
 };
+constexpr size_t kMaxDescBytes = (size_t)64 << 20;
 
-void index_desc_serialize(const cph_index* ix, std::vector<uint8_t>* out) {
-    const CodecHost& cd = ix->codec;
-    FileHeader h{};
-    memcpy(h.magic, kMagic, 8);
-    h.nrows = ix->nrows;
-    h.table_rows = ix->table_rows;
-    h.nkeycols = ix->nkeycols;
+static void put_bytes(std::vector<uint8_t>* out, const void* p, size_t nb) {
+    const uint8_t* b = static_cast<const uint8_t*>(p);
+    out->insert(out->end(), b, b + nb);
+}
+
+static void codec_block_serialize(const CodecHost& cd, std::vector<uint8_t>* out) {
+    CodecHeader h{};
     h.ncols = cd.ncols;
     h.npos = cd.npos;
     h.nwords = cd.nwords;
     h.key32 = cd.key32 ? 1 : 0;
-    h.sort_passes = ix->sort_passes;
     h.has_groups = cd.has_groups() ? 1 : 0;
     h.ndict = (int32_t)cd.dict.size();
     memcpy(h.col_start, cd.col_start, sizeof h.col_start);
@@ -186,57 +201,70 @@ void index_desc_serialize(const cph_index* ix, std::vector<uint8_t>* out) {
     memcpy(h.col_minlen, cd.col_minlen, sizeof h.col_minlen);
     memcpy(h.word_bits, cd.word_bits, sizeof h.word_bits);
     memcpy(h.word_states, cd.word_states, sizeof h.word_states);
-    out->clear();
-    auto put = [&](const void* p, size_t nb) {
-        const uint8_t* b = static_cast<const uint8_t*>(p);
-        out->insert(out->end(), b, b + nb);
-    };
-    put(&h, sizeof h);
-    put(cd.radix.data(), cd.radix.size() * sizeof(uint16_t));
-    put(cd.mult.data(), cd.mult.size() * sizeof(uint64_t));
-    put(cd.word_of.data(), cd.word_of.size() * sizeof(int32_t));
-    put(cd.lut.data(), cd.lut.size() * sizeof(uint16_t));
+    put_bytes(out, &h, sizeof h);
+    put_bytes(out, cd.radix.data(), cd.radix.size() * sizeof(uint16_t));
+    put_bytes(out, cd.mult.data(), cd.mult.size() * sizeof(uint64_t));
+    put_bytes(out, cd.word_of.data(), cd.word_of.size() * sizeof(int32_t));
+    put_bytes(out, cd.lut.data(), cd.lut.size() * sizeof(uint16_t));
     if (cd.has_groups()) {
-        put(cd.unit.data(), cd.unit.size());
-        put(cd.dict_off.data(), cd.dict_off.size() * sizeof(int32_t));
-        put(cd.dict_len.data(), cd.dict_len.size() * sizeof(int32_t));
-        put(cd.dict.data(), cd.dict.size() * sizeof(uint64_t));
+        put_bytes(out, cd.unit.data(), cd.unit.size());
+        put_bytes(out, cd.dict_off.data(), cd.dict_off.size() * sizeof(int32_t));
+        put_bytes(out, cd.dict_len.data(), cd.dict_len.size() * sizeof(int32_t));
+        put_bytes(out, cd.dict.data(), cd.dict.size() * sizeof(uint64_t));
     }
 }
 
-static bool header_ok(const FileHeader& h) {
-    return memcmp(h.magic, kMagic, 8) == 0 && h.nrows <= 0xFFFFFFFFull && h.table_rows <= 0xFFFFFFFFull &&
-           h.table_rows >= h.nrows && h.nkeycols >= 1 && h.nkeycols <= kMaxKeyCols && h.ncols == h.nkeycols && h.npos >= 0 &&
-           h.npos <= kMaxKeyBytes && h.nwords >= 1 && h.nwords <= kMaxWords &&
-           (!h.has_groups || (h.ndict >= 1 && h.ndict <= kGroupDictMax));
+void index_desc_serialize(const cph_index* ix, std::vector<uint8_t>* out) {
+    out->clear();
+    IndexHeader h{};
+    memcpy(h.magic, kMagic, 8);
+    h.nrows = ix->nrows;
+    h.table_rows = ix->table_rows;
+    h.nkeycols = ix->nkeycols;
+    h.sort_passes = ix->sort_passes;
+    h.nwindows = (int32_t)ix->windows.size();
+    put_bytes(out, &h, sizeof h);
+    if (ix->windows.empty()) {
+        codec_block_serialize(ix->codec, out);
+    } else {
+        for (const cph_key_window& w : ix->windows) {
+            WindowHeader wh{};
+            wh.nseg = w.nseg;
+            wh.word_base = w.word_base;
+            memcpy(wh.seg_col, w.seg_col, sizeof wh.seg_col);
+            memcpy(wh.seg_skip, w.seg_skip, sizeof wh.seg_skip);
+            memcpy(wh.seg_take, w.seg_take, sizeof wh.seg_take);
+            put_bytes(out, &wh, sizeof wh);
+            codec_block_serialize(w.codec, out);
+        }
+    }
+    const uint64_t total = out->size();
+    memcpy(out->data() + offsetof(IndexHeader, desc_bytes), &total, sizeof total);
 }
 
-// Size of the whole descriptor, from its (validated) header.
+// Size of the whole descriptor, from its first sizeof(IndexHeader) bytes.
+size_t index_desc_header_bytes() { return sizeof(IndexHeader); }
 bool index_desc_size(const uint8_t* p, size_t n, size_t* need) {
-    if (n < sizeof(FileHeader)) return false;
-    FileHeader h;
+    if (n < sizeof(IndexHeader)) return false;
+    IndexHeader h;
     memcpy(&h, p, sizeof h);
-    if (!header_ok(h)) return false;
-    size_t sz = sizeof h + (size_t)h.npos * (sizeof(uint16_t) + sizeof(uint64_t) + sizeof(int32_t)) +
-                (size_t)h.npos * kLutStride * sizeof(uint16_t);
-    if (h.has_groups) sz += (size_t)h.npos * (1 + 2 * sizeof(int32_t)) + (size_t)h.ndict * sizeof(uint64_t);
-    *need = sz;
+    if (memcmp(h.magic, kMagic, 8) != 0 || h.desc_bytes < sizeof h + sizeof(CodecHeader) || h.desc_bytes > kMaxDescBytes) return false;
+    *need = (size_t)h.desc_bytes;
     return true;
 }
 
-// Fills ix->codec / nrows / nkeycols / sort_passes / table_rows from a descriptor; false when it is not one a
-// well-formed writer can have produced (the codec drives device-side table walks).
-bool index_desc_parse(const uint8_t* p, size_t n, cph_index* ix) {
-    size_t need = 0;
-    if (!index_desc_size(p, n, &need) || need != n) return false;
-    FileHeader h;
-    memcpy(&h, p, sizeof h);
-    size_t at = sizeof h;
-    auto get = [&](void* dst, size_t nb) {
-        memcpy(dst, p + at, nb);
-        at += nb;
-    };
-    CodecHost& cd = ix->codec;
+// One codec block at p[*at ..): fills cd, advances *at; false when it is not one a well-formed writer can have
+// produced (the codec drives device-side table walks).
+static bool codec_block_parse(const uint8_t* p, size_t n, size_t* at, CodecHost* out) {
+    auto have = [&](size_t nb) { return nb <= n - *at; };
+    if (!have(sizeof(CodecHeader))) return false;
+    CodecHeader h;
+    memcpy(&h, p + *at, sizeof h);
+    *at += sizeof h;
+    if (h.ncols < 1 || h.ncols > kMaxKeyCols || h.npos < 0 || h.npos > kMaxKeyBytes || h.nwords < 1 || h.nwords > kMaxWords ||
+        (h.has_groups && (h.ndict < 1 || h.ndict > kGroupDictMax)))
+        return false;
+    CodecHost& cd = *out;
     cd = CodecHost{};
     cd.ncols = h.ncols;
     cd.npos = h.npos;
@@ -247,23 +275,27 @@ bool index_desc_parse(const uint8_t* p, size_t n, cph_index* ix) {
     memcpy(cd.col_minlen, h.col_minlen, sizeof h.col_minlen);
     memcpy(cd.word_bits, h.word_bits, sizeof h.word_bits);
     memcpy(cd.word_states, h.word_states, sizeof h.word_states);
+    auto get = [&](void* dst, size_t nb) {
+        if (!have(nb)) return false;
+        memcpy(dst, p + *at, nb);
+        *at += nb;
+        return true;
+    };
     cd.radix.resize((size_t)h.npos);
     cd.mult.resize((size_t)h.npos);
     cd.word_of.resize((size_t)h.npos);
     cd.lut.resize((size_t)h.npos * kLutStride);
-    get(cd.radix.data(), cd.radix.size() * sizeof(uint16_t));
-    get(cd.mult.data(), cd.mult.size() * sizeof(uint64_t));
-    get(cd.word_of.data(), cd.word_of.size() * sizeof(int32_t));
-    get(cd.lut.data(), cd.lut.size() * sizeof(uint16_t));
+    if (!get(cd.radix.data(), cd.radix.size() * sizeof(uint16_t)) || !get(cd.mult.data(), cd.mult.size() * sizeof(uint64_t)) ||
+        !get(cd.word_of.data(), cd.word_of.size() * sizeof(int32_t)) || !get(cd.lut.data(), cd.lut.size() * sizeof(uint16_t)))
+        return false;
     if (h.has_groups) {
         cd.unit.resize((size_t)h.npos);
         cd.dict_off.resize((size_t)h.npos);
         cd.dict_len.resize((size_t)h.npos);
         cd.dict.resize((size_t)h.ndict);
-        get(cd.unit.data(), cd.unit.size());
-        get(cd.dict_off.data(), cd.dict_off.size() * sizeof(int32_t));
-        get(cd.dict_len.data(), cd.dict_len.size() * sizeof(int32_t));
-        get(cd.dict.data(), cd.dict.size() * sizeof(uint64_t));
+        if (!get(cd.unit.data(), cd.unit.size()) || !get(cd.dict_off.data(), cd.dict_off.size() * sizeof(int32_t)) ||
+            !get(cd.dict_len.data(), cd.dict_len.size() * sizeof(int32_t)) || !get(cd.dict.data(), cd.dict.size() * sizeof(uint64_t)))
+            return false;
         for (int q = 0; q < cd.npos; q++) {
             const uint8_t u = cd.unit[(size_t)q];
             if (u == kUnitHead) {
@@ -310,6 +342,47 @@ bool index_desc_parse(const uint8_t* p, size_t n, cph_index* ix) {
     for (int w = 0; w < cd.nwords; w++)
         if (cd.word_bits[w] < 0 || cd.word_bits[w] > 64) return false;
     if (cd.key32 && (cd.nwords != 1 || cd.word_bits[0] > 32)) return false;
+    return true;
+}
+
+// Fills ix->codec / windows / nrows / nkeycols / sort_passes / table_rows from a descriptor.
+bool index_desc_parse(const uint8_t* p, size_t n, cph_index* ix) {
+    size_t need = 0;
+    if (!index_desc_size(p, n, &need) || need != n) return false;
+    IndexHeader h;
+    memcpy(&h, p, sizeof h);
+    if (h.nrows > 0xFFFFFFFFull || h.table_rows > 0xFFFFFFFFull || h.table_rows < h.nrows || h.nkeycols < 1 ||
+        h.nkeycols > kMaxKeyCols || h.nwindows < 0 || h.nwindows > 4096 || h.nwindows == 1)
+        return false;
+    size_t at = sizeof h;
+    ix->windows.clear();
+    if (h.nwindows == 0) {
+        if (!codec_block_parse(p, n, &at, &ix->codec) || ix->codec.ncols != h.nkeycols) return false;
+    } else {
+        int words = 0, last_col = 0;
+        for (int k = 0; k < h.nwindows; k++) {
+            if (sizeof(WindowHeader) > n - at) return false;
+            WindowHeader wh;
+            memcpy(&wh, p + at, sizeof wh);
+            at += sizeof wh;
+            if (wh.nseg < 1 || wh.nseg > kMaxKeyCols || wh.word_base != words) return false;
+            ix->windows.emplace_back();
+            cph_key_window& w = ix->windows.back();
+            w.nseg = wh.nseg;
+            w.word_base = wh.word_base;
+            memcpy(w.seg_col, wh.seg_col, sizeof w.seg_col);
+            memcpy(w.seg_skip, wh.seg_skip, sizeof w.seg_skip);
+            memcpy(w.seg_take, wh.seg_take, sizeof w.seg_take);
+            for (int s = 0; s < w.nseg; s++) {   // segments run through the key columns in order
+                if (w.seg_col[s] < last_col || w.seg_col[s] >= h.nkeycols) return false;
+                last_col = w.seg_col[s];
+            }
+            if (!codec_block_parse(p, n, &at, &w.codec) || w.codec.ncols != w.nseg || w.codec.key32) return false;
+            words += w.codec.nwords;
+        }
+        ix->codec = ix->windows[0].codec;
+    }
+    if (at != n) return false;
     ix->nrows = h.nrows;
     ix->table_rows = h.table_rows;
     ix->nkeycols = h.nkeycols;
@@ -478,8 +551,6 @@ CPH_API int32_t cph_index_save(cph_ctx* ctx, const cph_index* ix, const char* pa
     if (!ctx || !ix || !path) return CPH_ERR_INVALID;
     if (hipSetDevice(ctx->device) != hipSuccess) return fail_with(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});
     auto run = [&]() -> Status {
-        if (!ix->windows.empty())
-            return {CPH_ERR_INVALID, "saving an index whose keys span several codec windows (> 128 key bytes) is not implemented"};
         std::vector<uint8_t> desc;
         index_desc_serialize(ix, &desc);
         const size_t cb = (size_t)ix->nrows * code_bytes(ix), pb = (size_t)ix->nrows * sizeof(uint32_t);
@@ -517,13 +588,13 @@ CPH_API int32_t cph_index_load(cph_ctx* ctx, const char* path, cph_index** out) 
         FileCloser fc{f};
         const Status bad{CPH_ERR_INVALID, std::string(path) + ": not a csvplus_hip index file (or truncated)"};
         // the descriptor's size follows from its header: read the header, then the rest of the descriptor
-        std::vector<uint8_t> desc(sizeof(FileHeader));
+        const size_t hb = index_desc_header_bytes();
+        std::vector<uint8_t> desc(hb);
         if (fread(desc.data(), 1, desc.size(), f) != desc.size()) return bad;
         size_t need = 0;
         if (!index_desc_size(desc.data(), desc.size(), &need)) return bad;
         desc.resize(need);
-        if (need > sizeof(FileHeader) && fread(desc.data() + sizeof(FileHeader), 1, need - sizeof(FileHeader), f) != need - sizeof(FileHeader))
-            return bad;
+        if (need > hb && fread(desc.data() + hb, 1, need - hb, f) != need - hb) return bad;
         if (!index_desc_parse(desc.data(), desc.size(), ix)) return bad;
         ix->ctx = ctx;
         const size_t cb = (size_t)ix->nrows * code_bytes(ix), pb = (size_t)ix->nrows * sizeof(uint32_t);

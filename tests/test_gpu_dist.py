@@ -153,6 +153,10 @@ def test_loopback_index_broadcast_option_b():
     world, nc = 3, 20_000
     cust = dg.customers(nc)["id"]
     varkeys = dg.varkeys(30_000)                      # duplicate keys, dictionary-coded groups in the codec
+    from csvplus_amd import StrCol
+    rng = np.random.default_rng(8)
+    longcol = StrCol.from_values([bytes(rng.integers(97, 100, int(rng.integers(0, 300)), dtype=np.uint8)) for _ in range(4000)])
+    ol = orc.OracleIndex([longcol])                   # keys beyond one codec window: the windows travel too
     probe = dg.orders(10_000, 2 * nc, 10)["cust_id"]
     ou, ov = orc.OracleIndex([cust]), orc.OracleIndex([varkeys])
     ej = ou.join([probe])
@@ -160,7 +164,7 @@ def test_loopback_index_broadcast_option_b():
     def rank_body(r):
         ctx = Context(0)
         d = N.Dist.loopback(ctx, "bcast", r, world)
-        for col, oix, unique in ((cust, ou, True), (varkeys, ov, False)):
+        for col, oix, unique in ((cust, ou, True), (varkeys, ov, False), (longcol, ol, False)):
             mine = DeviceIndex(ctx, [col], unique=unique) if r == 0 else None
             ix = d.index_broadcast(mine, root=0)
             assert ix.nrows == col.nrows

@@ -403,7 +403,7 @@ def long_keys(rng, n, max_len, alphabet, distinct, shared_prefix):
 
 
 @pytest.mark.parametrize("seed,max_len,ncols", [(1, 300, 1), (2, 1000, 1), (3, 260, 2), (4, 129, 1), (5, 400, 3)])
-def test_keys_longer_than_one_codec_window(ctx, seed, max_len, ncols):
+def test_keys_longer_than_one_codec_window(ctx, seed, max_len, ncols, tmp_path):
     """Keys of 0..1000 bytes: beyond 128 byte positions the key columns are cut into codec windows (SURVEY.md §7
     "hard parts").  Index order, duplicates, Join, prefix Join, Except and Find against the oracle."""
     rng = np.random.default_rng(seed)
@@ -439,4 +439,13 @@ def test_keys_longer_than_one_codec_window(ctx, seed, max_len, ncols):
     assert sel.nrows == len(range(0, n, 3))
     np.testing.assert_array_equal(sel.perm(), g.perm()[::3])
     sel.close()
+    # persistence keeps the windows: the loaded index sorts and probes like the built one
+    path = tmp_path / "long.cph"
+    g.save(str(path))
+    ld = DeviceIndex.load(ctx, str(path))
+    np.testing.assert_array_equal(ld.perm(), o.perm)
+    probe = [StrCol.from_values(v[:500]) for v in build_vals]
+    assert_join_equal(ld.probe(probe), o.join(probe))
+    assert ld.info() == g.info()
+    ld.close()
     g.close()
