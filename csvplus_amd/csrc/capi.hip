@@ -558,6 +558,18 @@ CPH_API int32_t cph_ctx_create(int32_t device_id, cph_ctx** out) {
         return CPH_ERR_HIP;
     }
     ctx->own_stream = true;
+    // one-shot users should not pay the lazy code-object loads (tens of ms) and the first pinned allocations
+    // inside their first call: do them here
+    warm_keycodec();
+    warm_radix_sort();
+    warm_probe();
+    warm_chain();
+    warm_materialize();
+    warm_csv_ingest();
+    warm_index_ops();
+    (void)ensure_pinned_scratch(ctx, 1 << 16);
+    void* ring = nullptr;
+    (void)pinned_upload(ctx, 64, &ring);
     *out = ctx;
     return CPH_OK;
 }

@@ -402,6 +402,15 @@ Status chain_enqueue_dense(cph_ctx* ctx, const ChainStep* steps, int nsteps, uin
 uint64_t chain_dense_mask_words(uint64_t nprobe);
 uint64_t chain_dense_count_words(uint64_t nprobe);
 
+// every translation unit with kernels: forces its code object to load (called once per process from cph_ctx_create)
+void warm_keycodec();
+void warm_radix_sort();
+void warm_probe();
+void warm_chain();
+void warm_materialize();
+void warm_csv_ingest();
+void warm_index_ops();
+
 // capi.hip helpers
 Status ensure_pinned_scratch(cph_ctx* ctx, size_t bytes);
 Status pinned_upload(cph_ctx* ctx, size_t bytes, void** out);   // staging slot valid until the ring wraps

