@@ -101,7 +101,7 @@ def main():
     import torch.distributed as dist
 
     from csvplus_amd import _native as N, datagen as dg
-    from csvplus_amd.dist import allgatherv_many, chain_allgather, connect
+    from csvplus_amd.dist import allgatherv_many, connect
     from csvplus_amd.engine import Engine, shard_range
 
     rank = int(os.environ.get("RANK", "0"))
@@ -139,26 +139,35 @@ def main():
     gen_s = time.time() - t0
     nloc = end - begin
 
+    step_info = {}
+
     def step():
         # both build sides as one batch (cph_index_build_many): their host round trips are shared
         ia, ib = eng.index_on_many([[d_cust], [d_prod]], unique=True)
-        res = eng.chained_join([(ia, d_ord["cust_id"]), (ib, d_ord["prod_id"])], probe_base=begin)
-        # stream_row is None when every order joined (the result row IS the stream row): then only
-        # the two build-row arrays exist — and only they are exchanged
-        out = tuple(t for t in (res.stream_row, res.build_rows[0], res.build_rows[1]) if t is not None)
+        # the chained join straight through the binding (cph_join_chain, results left in HBM): the timed loop holds
+        # no torch views of the result — it needs the row count only.  stream_row is NULL when every order joined
+        # (the result row IS the stream row): then only the two build-row arrays exist, and only they are exchanged.
+        ch = N.join_chain(eng.ctx, [(ia, [d_ord["cust_id"]]), (ib, [d_ord["prod_id"]])], probe_base=begin,
+                          out_mem=N.CPH_MEM_DEVICE)
         if cdist is not None:          # one count exchange + one grouped batch for all arrays (cph_dist_chain_allgather)
-            gres, _ = chain_allgather(cdist, res, dev)
-            n = gres.n
-            gres.release()
+            g = cdist.chain_allgather(ch)
+            n = g.total
+            g.release()
         elif world > 1 and args.exchange == "allgatherv":
-            n = int(allgatherv_many(out)[0][-1].numel())
+            from csvplus_amd.engine import device_view
+            p = ch.device_ptrs()
+            ts = [device_view(q, ch.nrows, "<i4", ch, dev) for q in p["build_row"]]
+            if not ch.identity:
+                ts.insert(0, device_view(p["stream_row"], ch.nrows, "<i8", ch, dev))
+            n = int(allgatherv_many(ts)[0][-1].numel())
         else:
-            n = int(out[-1].numel())
-        info = (ia.info(), ib.info())
-        res.release()
+            n = ch.nrows
+        if not step_info:
+            step_info["info"] = (ia.info(), ib.info())
+        ch.release()
         ia.close()
         ib.close()
-        return n, info
+        return n, step_info["info"]
 
     def sync_all():
         if world > 1:

@@ -121,7 +121,7 @@ Status codec_stats_launch(cph_ctx* ctx, const DevCol* cols, int32_t ncols, DevBu
         if (cols[c].nrows == 0) continue;
         const uint64_t rows_per_block = (uint64_t)kStatsThreads * kStatsRows;
         uint64_t nblk = (cols[c].nrows + rows_per_block - 1) / rows_per_block;
-        if (nblk > (uint64_t)cus * 2) nblk = (uint64_t)cus * 2;   // few workgroups: each ends with up to 8 * maxlen global atomics on the same words
+        if (nblk > (uint64_t)cus * 4) nblk = (uint64_t)cus * 4;   // resident workgroups only: each ends with up to 8 * maxlen global atomics on the same words
         uint32_t* base = reinterpret_cast<uint32_t*>(d->as<uint8_t>() + per * (size_t)c);
         ProfScope ps(ctx, "k_col_stats", 0);   // bytes: value bytes + offsets, added by the caller's model
         const dim3 grid((unsigned)nblk), block(kStatsThreads);
@@ -726,20 +726,29 @@ struct PlanArg {
 
 template <class OUT, bool LONGV>
 __global__ __launch_bounds__(kEncodeThreads) void k_encode_build_plan(ColsArg cols, const uint8_t* __restrict__ g_codec, const PlanArg pa,
-                                                                     uint64_t n, OUT* __restrict__ out) {
+                                                                     uint64_t n, OUT* __restrict__ out, uint32_t tile_rows,
+                                                                     uint32_t ntiles, uint32_t* __restrict__ counts,
+                                                                     uint32_t digit_mask, uint32_t bins, int codec_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const CodecView cv = codec_load_to_lds(g_codec, smem);
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + codec_bytes);   // [bins]: the sort's first-pass histogram of a tile
     const PlanUnit* plan = pa.u;
     const int nunits = pa.nunits;
-    const uint64_t stride = (uint64_t)gridDim.x * kEncodeThreads * kEncodeRows;
-    for (uint64_t base = (uint64_t)blockIdx.x * kEncodeThreads * kEncodeRows; base < n; base += stride) {
+    // a workgroup walks whole SORT tiles (tile_rows keys), like k_encode_build_fast
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      if (counts) {
+          for (uint32_t d = threadIdx.x; d < bins; d += kEncodeThreads) s_hist[d] = 0;
+          __syncthreads();
+      }
+      const uint64_t tile_end = (uint64_t)(tile + 1) * tile_rows < n ? (uint64_t)(tile + 1) * tile_rows : n;
+      for (uint64_t base = (uint64_t)tile * tile_rows; base < tile_end; base += (uint64_t)kEncodeThreads * kEncodeRows) {
         uint64_t acc[kEncodeRows];
         ValueHeadT<LONGV> v[kEncodeRows];
         bool live[kEncodeRows];
 #pragma unroll
         for (int k = 0; k < kEncodeRows; k++) {
             acc[k] = 0;
-            live[k] = base + (uint64_t)k * kEncodeThreads + threadIdx.x < n;
+            live[k] = base + (uint64_t)k * kEncodeThreads + threadIdx.x < tile_end;
         }
         uint32_t cur_col = 0xFFFFFFFFu;
         for (int u = 0; u < nunits; u++) {
@@ -797,7 +806,16 @@ __global__ __launch_bounds__(kEncodeThreads) void k_encode_build_plan(ColsArg co
         }
 #pragma unroll
         for (int k = 0; k < kEncodeRows; k++)
-            if (live[k]) out[base + (uint64_t)k * kEncodeThreads + threadIdx.x] = (OUT)acc[k];
+            if (live[k]) {
+                out[base + (uint64_t)k * kEncodeThreads + threadIdx.x] = (OUT)acc[k];
+                if (counts) atomicAdd(&s_hist[(uint32_t)acc[k] & digit_mask], 1u);
+            }
+      }
+      if (counts) {
+          __syncthreads();
+          for (uint32_t d = threadIdx.x; d < bins; d += kEncodeThreads) counts[(uint64_t)d * ntiles + tile] = s_hist[d];
+          __syncthreads();
+      }
     }
 }
 
@@ -856,8 +874,12 @@ Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec
     int plan_units = 0;
     for (int p = 0; p < cd.npos && cd.has_groups(); p++) plan_units += cd.unit[(size_t)p] != kUnitAbsorbed;
     if (cd.has_groups() && cd.nwords == 1 && plan_units <= kPlanMaxUnits) {
-        nblk = (n + kEncodeThreads * kEncodeRows - 1) / (kEncodeThreads * kEncodeRows);
-        if (nblk > 4096) nblk = 4096;
+        // tiles = the sort's tiles when it asked for the first pass's histogram, else 4096 rows
+        const bool want_hist = hist && hist->counts;
+        const uint32_t tile_rows = want_hist ? hist->tile_rows : 4096u;
+        const uint32_t ntiles = (uint32_t)((n + tile_rows - 1) / tile_rows);
+        const uint32_t hbins = want_hist ? hist->bins : 0u, hmask = want_hist ? hist->digit_mask : 0u;
+        nblk = ntiles < 4096u ? ntiles : 4096u;
         std::vector<PlanUnit> plan;
         // the hash tables sit in the device block in head order (codec_upload): recompute their offsets the same way
         size_t hbase = 0;
@@ -883,7 +905,8 @@ Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec
                 }
                 plan.push_back(u);
             }
-        const size_t lds = codec_dev.bytes();
+        const size_t codec_bytes = codec_dev.bytes();
+        const size_t lds = codec_bytes + (size_t)hbins * sizeof(uint32_t);
         PlanArg pa{};
         pa.nunits = (int32_t)plan.size();
         for (size_t i = 0; i < plan.size(); i++) pa.u[i] = plan[i];
@@ -891,8 +914,9 @@ Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec
         bool long_values = false;
         for (int c = 0; c < cd.ncols; c++) long_values |= cd.col_maxlen[c] > 24;
         auto launch = [&](auto kernel, auto* out) -> Status {
-            CPH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kernel, dim3((unsigned)nblk), dim3(kEncodeThreads), lds, ctx->stream, arg, codec_dev.as<uint8_t>(), pa, n, out);
+            CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(kernel), kEncodeThreads, lds, nullptr));
+            hipLaunchKernelGGL(kernel, dim3((unsigned)nblk), dim3(kEncodeThreads), lds, ctx->stream, arg, codec_dev.as<uint8_t>(), pa, n, out,
+                               tile_rows, ntiles, want_hist ? hist->counts : nullptr, hmask, hbins, (int)codec_bytes);
             return {};
         };
         if (cd.key32 && long_values) CPH_TRY(launch(&k_encode_build_plan<uint32_t, true>, reinterpret_cast<uint32_t*>(out_codes)));
@@ -900,6 +924,7 @@ Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec
         else if (long_values) CPH_TRY(launch(&k_encode_build_plan<uint64_t, true>, reinterpret_cast<uint64_t*>(out_codes)));
         else CPH_TRY(launch(&k_encode_build_plan<uint64_t, false>, reinterpret_cast<uint64_t*>(out_codes)));
         CPH_HIP_TRY(hipGetLastError());
+        if (hist) const_cast<EncodeHist*>(hist)->done = want_hist;
         return {};
     }
     const size_t lds = codec_dev.bytes();
