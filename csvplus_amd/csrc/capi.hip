@@ -595,6 +595,7 @@ CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value
     if (k == "chain_debug") ctx->chain_debug = (int)value;
     else if (k == "sort_threads") ctx->sort_threads = (int)value;
     else if (k == "sort_rbits") ctx->sort_rbits = (int)value;
+    else if (k == "sort_xcd_tiles") ctx->sort_xcd_tiles = value != 0;
     else if (k == "pool_guard") ctx->pool.guard = value != 0;
     else if (k == "pool_guard_check") {
         ctx->pool.check_live();

@@ -218,6 +218,7 @@ struct cph_ctx {
     int cus = 0;                   // compute units of `device` (0: not queried yet)
     int chain_debug = 0;           // attribution switches of the chained-join kernel (cph_ctx_set_option)
     int sort_threads = 0, sort_rbits = 0;   // radix-sort tuning overrides (0: automatic)
+    int sort_xcd_tiles = 1;        // scatter: contiguous tile ranges per XCD (radix_sort.hip)
     struct KernelCfg { const void* fn; size_t lds; int blocks_per_cu; };
     std::vector<KernelCfg> kernel_cfg;   // kernels whose dynamic-LDS attribute / occupancy were set up on this device
     // profiling

@@ -665,7 +665,11 @@ __global__ __launch_bounds__(kEncodeThreads) void k_encode_build_fast(DevCol col
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + codec_bytes);   // [bins], only when counts != nullptr
     constexpr uint32_t kTile = kEncodeFastRows * kWave;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(wave_id());
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // the workgroups of XCD x (= blockIdx % 8, observed placement) walk the contiguous tile range x: neighbouring tiles
+    // share the sectors of the count matrix (and of nothing else), so they should write through the same L2
+    const uint32_t per_xcd = (ntiles + 7) / 8, xcd = blockIdx.x & 7u;
+    const uint32_t t_end = (xcd + 1) * per_xcd < ntiles ? (xcd + 1) * per_xcd : ntiles;
+    for (uint32_t tile = xcd * per_xcd + (blockIdx.x >> 3); tile < t_end; tile += gridDim.x >> 3) {
         if (counts) {
             for (uint32_t d = threadIdx.x; d < bins; d += kEncodeThreads) s_hist[d] = 0;
             __syncthreads();
@@ -735,7 +739,9 @@ __global__ __launch_bounds__(kEncodeThreads) void k_encode_build_plan(ColsArg co
     const PlanUnit* plan = pa.u;
     const int nunits = pa.nunits;
     // a workgroup walks whole SORT tiles (tile_rows keys), like k_encode_build_fast
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const uint32_t per_xcd = (ntiles + 7) / 8, xcd = blockIdx.x & 7u;   // XCD-contiguous tile ranges (k_encode_build_fast)
+    const uint32_t t_end = (xcd + 1) * per_xcd < ntiles ? (xcd + 1) * per_xcd : ntiles;
+    for (uint32_t tile = xcd * per_xcd + (blockIdx.x >> 3); tile < t_end; tile += gridDim.x >> 3) {
       if (counts) {
           for (uint32_t d = threadIdx.x; d < bins; d += kEncodeThreads) s_hist[d] = 0;
           __syncthreads();
@@ -843,7 +849,8 @@ Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec
         ProfScope ps(ctx, "k_encode_build", 4.0 * (double)bins * (double)ntiles);
         auto launch = [&](auto fn, auto* out) -> Status {
             CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(fn), kEncodeThreads, lds, &per_cu));
-            const unsigned grid = (unsigned)std::min<uint64_t>(ntiles64, (uint64_t)cus * (uint64_t)per_cu);
+            unsigned grid = (unsigned)std::min<uint64_t>(ntiles64, (uint64_t)cus * (uint64_t)per_cu);
+            grid = (grid + 7u) & ~7u;   // the kernel splits its tiles over blockIdx % 8
             hipLaunchKernelGGL(fn, dim3(grid), dim3(kEncodeThreads), lds, ctx->stream, cols[0], blob, n, out, tile_rows, ntiles,
                                want_hist ? hist->counts : nullptr, mask, bins, (int)codec_bytes);
             return {};
@@ -880,6 +887,7 @@ Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec
         const uint32_t ntiles = (uint32_t)((n + tile_rows - 1) / tile_rows);
         const uint32_t hbins = want_hist ? hist->bins : 0u, hmask = want_hist ? hist->digit_mask : 0u;
         nblk = ntiles < 4096u ? ntiles : 4096u;
+        nblk = (nblk + 7) & ~(uint64_t)7;   // the kernel splits its tiles over blockIdx % 8
         std::vector<PlanUnit> plan;
         // the hash tables sit in the device block in head order (codec_upload): recompute their offsets the same way
         size_t hbase = 0;

@@ -29,14 +29,17 @@ constexpr int kSortItems   = 16;                          // keys per thread
 template <class K, int RBITS, int kSortThreads>
 __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const K* __restrict__ keys, uint64_t n, int shift,
                                                             uint32_t digit_mask, uint32_t* __restrict__ counts,
-                                                            uint32_t ntiles) {
+                                                            uint32_t ntiles, uint32_t tiles_per_xcd) {
     constexpr int BINS = 1 << RBITS;
     constexpr int kSortWaves = kSortThreads / kWave;
     constexpr int kSortTile = kSortThreads * kSortItems;
     __shared__ uint32_t s_hist[kSortWaves][BINS];
+    // XCD-contiguous tiles like k_radix_scatter: 16 neighbouring tiles share every 64-byte sector of the count matrix
+    const uint32_t tile = tiles_per_xcd ? (blockIdx.x & 7u) * tiles_per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+    if (tile >= ntiles) return;
     for (int i = threadIdx.x; i < kSortWaves * BINS; i += kSortThreads) (&s_hist[0][0])[i] = 0;
     __syncthreads();
-    const uint64_t tile0 = (uint64_t)blockIdx.x * kSortTile;
+    const uint64_t tile0 = (uint64_t)tile * kSortTile;
     const int w = wave_id();
     K key[kSortItems];
 #pragma unroll
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const K* __restrict
         uint32_t c = 0;
 #pragma unroll
         for (int ww = 0; ww < kSortWaves; ww++) c += s_hist[ww][d];
-        counts[(uint64_t)d * ntiles + blockIdx.x] = c;
+        counts[(uint64_t)d * ntiles + tile] = c;
     }
 }
 
@@ -76,7 +79,8 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const K* __restr
                                                                const uint32_t* __restrict__ vals_in,
                                                                K* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                                uint64_t n, int shift, uint32_t digit_mask,
-                                                               const uint32_t* __restrict__ bases, uint32_t ntiles) {
+                                                               const uint32_t* __restrict__ bases, uint32_t ntiles,
+                                                               uint32_t tiles_per_xcd) {
     constexpr int BINS = 1 << RBITS;
     constexpr int kSortWaves = kSortThreads / kWave;
     constexpr int kSortTile = kSortThreads * kSortItems;
@@ -84,9 +88,14 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const K* __restr
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
     ScatterSmem<K, RBITS, kSortThreads>& s = *reinterpret_cast<ScatterSmem<K, RBITS, kSortThreads>*>(smem_raw);
 
+    // XCD-aware tile mapping (tiles_per_xcd != 0): workgroup b runs on XCD b % 8 (observed placement), so giving
+    // XCD x the CONTIGUOUS tiles [x * tiles_per_xcd, (x+1) * tiles_per_xcd) makes neighbouring tiles — whose runs of
+    // one digit are neighbours in the output — write through the same L2, which can then merge their partial sectors
+    const uint32_t tile = tiles_per_xcd ? (blockIdx.x & 7u) * tiles_per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+    if (tile >= ntiles) return;
     const int w = wave_id();
     const int lane = lane_id();
-    const uint64_t tile0 = (uint64_t)blockIdx.x * kSortTile;
+    const uint64_t tile0 = (uint64_t)tile * kSortTile;
     const uint64_t remaining = n - tile0;
     const uint32_t tile_n = remaining < (uint64_t)kSortTile ? (uint32_t)remaining : (uint32_t)kSortTile;
     const uint64_t lt = lanemask_lt();
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const K* __restr
             const int d = threadIdx.x * DPT + j;
             if (active) {
                 s.digit_start[d] = start;
-                s.gdelta[d] = bases[(uint64_t)d * ntiles + blockIdx.x] - start;
+                s.gdelta[d] = bases[(uint64_t)d * ntiles + tile] - start;
             }
             start += run[j];
         }
@@ -349,16 +358,18 @@ static Status radix_pass(cph_ctx* ctx, const K* kin, const uint32_t* vin, K* kou
     CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_radix_scatter<K, RBITS, THREADS>), THREADS, smem, nullptr));
     if (!hist_done) {
         ProfScope ps(ctx, sizeof(K) == 4 ? "k_radix_hist_u32" : "k_radix_hist_u64", (double)n * sizeof(K));
-        hipLaunchKernelGGL((k_radix_hist<K, RBITS, THREADS>), dim3(ntiles), dim3(THREADS), 0, ctx->stream, kin, n, shift,
-                           mask, counts, ntiles);
+        const uint32_t hper = ctx->sort_xcd_tiles && ntiles >= 64 ? (ntiles + 7) / 8 : 0;
+        hipLaunchKernelGGL((k_radix_hist<K, RBITS, THREADS>), dim3(hper ? hper * 8 : ntiles), dim3(THREADS), 0, ctx->stream, kin, n,
+                           shift, mask, counts, ntiles, hper);
         CPH_HIP_TRY(hipGetLastError());
     }
     CPH_TRY(exclusive_scan_u32(ctx, counts, (uint64_t)BINS * ntiles));
     {
         ProfScope ps(ctx, sizeof(K) == 4 ? "k_radix_scatter_u32" : "k_radix_scatter_u64",
                      (double)n * (2.0 * sizeof(K) + (vin ? 8.0 : 4.0)));
-        hipLaunchKernelGGL((k_radix_scatter<K, RBITS, THREADS>), dim3(ntiles), dim3(THREADS), smem, ctx->stream, kin, vin,
-                           kout, vout, n, shift, mask, counts, ntiles);
+        const uint32_t per_xcd = ctx->sort_xcd_tiles && ntiles >= 64 ? (ntiles + 7) / 8 : 0;
+        hipLaunchKernelGGL((k_radix_scatter<K, RBITS, THREADS>), dim3(per_xcd ? per_xcd * 8 : ntiles), dim3(THREADS), smem, ctx->stream,
+                           kin, vin, kout, vout, n, shift, mask, counts, ntiles, per_xcd);
     }
     CPH_HIP_TRY(hipGetLastError());
     return {};

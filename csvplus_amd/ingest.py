@@ -228,7 +228,8 @@ def resolve_header(first, *, select=None, expect_header=None):
             if spec[nm] == -1 or spec[nm] == i:
                 hdr[nm] = i
             else:
-                raise KeyError(f"misplaced column {nm!r}: expected at pos. {spec[nm]}, but found at pos. {i}")
+                q = '"' + nm.decode("utf-8", "replace").replace("\\", "\\\\").replace('"', '\\"') + '"'   # Go %q for plain names
+                raise KeyError(f"misplaced column {q}: expected at pos. {spec[nm]}, but found at pos. {i}")
     missing = [n for n in spec if n not in hdr]
     if missing:
         raise KeyError(("columns not found: " if len(missing) > 1 else "column not found: ")
