@@ -25,7 +25,18 @@ Status DevicePool::alloc(size_t bytes, void** out) {
         }
     }
     Block b;
-    if (best >= 0) {
+    bool from_slab = false;
+    for (size_t i = 0; i < slab_free_.size(); i++)   // first fit in the reserved slab
+        if (slab_free_[i].second >= want) {
+            b = Block{slab_ + slab_free_[i].first, want, 0};
+            b.in_slab = true;
+            if (slab_free_[i].second == want) slab_free_.erase(slab_free_.begin() + (long)i);
+            else slab_free_[i] = {slab_free_[i].first + want, slab_free_[i].second - want};
+            from_slab = true;
+            break;
+        }
+    if (from_slab) {
+    } else if (best >= 0) {
         b = free_[best];
         free_.erase(free_.begin() + best);
         bytes_cached -= b.cap;
@@ -82,13 +93,43 @@ void DevicePool::release(void* p) {
         if (live_[i].p == p) {
             check_block(live_[i]);
             bytes_live -= live_[i].cap;
-            bytes_cached += live_[i].cap;
-            free_.push_back(live_[i]);
+            if (live_[i].in_slab) {   // back into the slab's free list: keep it sorted by offset and coalesced
+                const size_t off = (size_t)(static_cast<uint8_t*>(p) - slab_), len = live_[i].cap;
+                size_t k = 0;
+                while (k < slab_free_.size() && slab_free_[k].first < off) k++;
+                slab_free_.insert(slab_free_.begin() + (long)k, {off, len});
+                if (k + 1 < slab_free_.size() && slab_free_[k].first + slab_free_[k].second == slab_free_[k + 1].first) {
+                    slab_free_[k].second += slab_free_[k + 1].second;
+                    slab_free_.erase(slab_free_.begin() + (long)k + 1);
+                }
+                if (k > 0 && slab_free_[k - 1].first + slab_free_[k - 1].second == slab_free_[k].first) {
+                    slab_free_[k - 1].second += slab_free_[k].second;
+                    slab_free_.erase(slab_free_.begin() + (long)k);
+                }
+            } else {
+                bytes_cached += live_[i].cap;
+                free_.push_back(live_[i]);
+            }
             live_[i] = live_.back();
             live_.pop_back();
             return;
         }
     }
+}
+
+Status DevicePool::reserve(size_t bytes) {
+    if (slab_) return {CPH_ERR_INVALID, "the pool already has a reserved slab"};
+    bytes = (bytes + 255) & ~(size_t)255;
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return {CPH_ERR_NOMEM, "hipMalloc of the reserved slab failed"};
+    }
+    (void)hipMemset(p, 0, bytes);   // touch it now: page the memory in before the first timed call
+    slab_ = static_cast<uint8_t*>(p);
+    slab_bytes_ = bytes;
+    slab_free_.assign(1, {0, bytes});
+    return {};
 }
 
 void DevicePool::trim() {
@@ -99,8 +140,10 @@ void DevicePool::trim() {
 
 DevicePool::~DevicePool() {
     trim();
-    for (auto& b : live_) (void)hipFree(b.p);
+    for (auto& b : live_)
+        if (!b.in_slab) (void)hipFree(b.p);
     live_.clear();
+    if (slab_) (void)hipFree(slab_);
 }
 
 Status device_cus(cph_ctx* ctx, int* cus) {
@@ -232,6 +275,14 @@ Status stage_cols(cph_ctx* ctx, const cph_strcol* cols, int32_t ncols, std::vect
         if (cols[c].mem == CPH_MEM_DEVICE || cols[c].nrows == 0) {
             d.data = cols[c].data;
             d.offsets = cols[c].offsets;
+            if (!d.data) {   // a column of empty values may come without a data buffer: the branch-free value loads
+                             // (device_utils.hpp: load_chunk_nobranch) read ONE word at the column base for them
+                if (!ctx->safe_words) {
+                    CPH_TRY(ctx->safe_words.alloc(&ctx->pool, 64));
+                    CPH_HIP_TRY(hipMemsetAsync(ctx->safe_words.get(), 0, 64, ctx->stream));
+                }
+                d.data = ctx->safe_words.as<uint8_t>();
+            }
         } else if (cols[c].fixed_width) {
             const size_t bytes = (size_t)cols[c].nrows * cols[c].fixed_width;
             DevBuf bd;
@@ -597,6 +648,12 @@ CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value
     else if (k == "sort_rbits") ctx->sort_rbits = (int)value;
     else if (k == "sort_xcd_tiles") ctx->sort_xcd_tiles = value != 0;
     else if (k == "pool_guard") ctx->pool.guard = value != 0;
+    else if (k == "pool_reserve_mb") {
+        if (value <= 0) return fail_with(ctx, {CPH_ERR_INVALID, "pool_reserve_mb must be positive"});
+        if (hipSetDevice(ctx->device) != hipSuccess) return fail_with(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});
+        Status rs = ctx->pool.reserve((size_t)value << 20);
+        if (!rs.ok()) return fail_with(ctx, rs);
+    }
     else if (k == "pool_guard_check") {
         ctx->pool.check_live();
         if (ctx->pool.guard_violations) {

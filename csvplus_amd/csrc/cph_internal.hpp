@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/csvplus_hip.h"
@@ -57,6 +58,10 @@ public:
     void   trim();             // hipFree everything cached
     ~DevicePool();
     size_t bytes_live = 0, bytes_cached = 0, n_hipmalloc = 0;
+    // Optional slab (cph_ctx_set_option "pool_reserve_mb"): ONE hipMalloc up front, blocks carved out of it first-fit
+    // and coalesced on release — a one-shot caller then pays no hipMalloc (tens of ms per GB on a cold device) inside
+    // its first call.  Requests the slab cannot serve fall through to the per-size cache below.
+    Status reserve(size_t bytes);
     // guard mode (debugging aid): canary bytes behind every block, verified at release
     bool guard = false;
     uint64_t guard_violations = 0;
@@ -64,8 +69,11 @@ public:
     void check_live();
 
 private:
-    struct Block { void* p; size_t cap; size_t user; bool guarded = false; };
+    struct Block { void* p; size_t cap; size_t user; bool guarded = false; bool in_slab = false; };
     void check_block(const Block& b);
+    uint8_t* slab_ = nullptr;
+    size_t slab_bytes_ = 0;
+    std::vector<std::pair<size_t, size_t>> slab_free_;   // (offset, length), sorted by offset, coalesced
     std::vector<Block> free_;
     std::vector<Block> live_;
 };
@@ -214,6 +222,7 @@ struct cph_ctx {
     void* upload_ring = nullptr;
     size_t upload_cap = 0, upload_pos = 0;
     std::vector<void*> pinned_user;
+    cph::DevBuf safe_words;        // 64 readable device bytes: the data base of columns that come without a buffer
     // per-ctx launch state (a process may hold one ctx per device: nothing of this may be static)
     int cus = 0;                   // compute units of `device` (0: not queried yet)
     int chain_debug = 0;           // attribution switches of the chained-join kernel (cph_ctx_set_option)

@@ -162,6 +162,15 @@ struct ColIds {
 // One record's fields: row ids, then offsets, then the first chunk of every value — three rounds of independent
 // loads instead of a dependent chain per column.  NC > 0: compile-time column count (arrays stay in registers);
 // NC == 0: any count up to kMaxKeyCols, one column at a time.
+// The first 8 bytes of a value with ONE unconditional load (device_utils.hpp: load_chunk_nobranch): the loads of a
+// record's columns overlap instead of each waiting behind the branch of the one before.
+__device__ __forceinline__ uint64_t first_chunk_nobranch(const DevCol& col, uint64_t begin, uint64_t len) {
+    const uint64_t p = (uint64_t)(uintptr_t)col.data;
+    const uint32_t l32 = len > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)len;
+    const uint64_t v = load_chunk_nobranch<uint64_t>((const uint8_t*)(uintptr_t)(p & ~7ull), (uint32_t)(p & 7ull), begin, l32, 0);
+    return l32 ? v : 0;
+}
+
 template <int NC>
 struct RecordFields {
     uint64_t b[NC ? NC : 1], l[NC ? NC : 1], c0[NC ? NC : 1];
@@ -173,7 +182,8 @@ struct RecordFields {
 #pragma unroll
         for (int c = 0; c < NC; c++) value_span(cols.c[c], row[c], &b[c], &l[c]);
 #pragma unroll
-        for (int c = 0; c < NC; c++) c0[c] = (l[c] && ((data_mask >> c) & 1u)) ? load_value_chunk(cols.c[c].data, b[c], l[c], 0) : 0;
+        for (int c = 0; c < NC; c++)
+            c0[c] = ((data_mask >> c) & 1u) ? first_chunk_nobranch(cols.c[c], b[c], l[c]) : 0;   // data_mask is uniform
     }
 };
 
@@ -257,24 +267,23 @@ __global__ __launch_bounds__(kMatThreads) void k_csv_copy(ColsArg cols, ColIds i
             // row ids, then offsets, then first chunks of all the records of this thread: three rounds of loads
             uint64_t row[kCsvCopyRows][NC], b[kCsvCopyRows][NC], l[kCsvCopyRows][NC], c0[kCsvCopyRows][NC];
             bool live[kCsvCopyRows];
+            // threads past the tile's end re-read its last record (never written): no branch around any load, so the
+            // NC row ids, then the NC spans, then the NC first chunks of a thread are each in flight together
 #pragma unroll
             for (int k = 0; k < kCsvCopyRows; k++) {
                 const uint64_t i = t0 + (uint64_t)k * kMatThreads + threadIdx.x;
                 live[k] = i < tend;
 #pragma unroll
-                for (int c = 0; c < NC; c++) row[k][c] = live[k] ? source_row(ids.ids[c], i) : 0;
+                for (int c = 0; c < NC; c++) row[k][c] = source_row(ids.ids[c], live[k] ? i : tend - 1);
             }
 #pragma unroll
             for (int k = 0; k < kCsvCopyRows; k++)
 #pragma unroll
-                for (int c = 0; c < NC; c++) {
-                    b[k][c] = l[k][c] = 0;
-                    if (live[k]) value_span(cols.c[c], row[k][c], &b[k][c], &l[k][c]);
-                }
+                for (int c = 0; c < NC; c++) value_span(cols.c[c], row[k][c], &b[k][c], &l[k][c]);
 #pragma unroll
             for (int k = 0; k < kCsvCopyRows; k++)
 #pragma unroll
-                for (int c = 0; c < NC; c++) c0[k][c] = l[k][c] ? load_value_chunk(cols.c[c].data, b[k][c], l[k][c], 0) : 0;
+                for (int c = 0; c < NC; c++) c0[k][c] = first_chunk_nobranch(cols.c[c], b[k][c], l[k][c]);
 #pragma unroll
             for (int k = 0; k < kCsvCopyRows; k++) {
                 if (!live[k]) continue;

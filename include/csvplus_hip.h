@@ -134,6 +134,9 @@ CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
  *   "sort_threads"  256 / 512: workgroup size of the radix sort (0 = automatic)
  *   "sort_rbits"    8 / 9: digit width of the radix sort (0 = automatic)
  *   "sort_xcd_tiles" 0 / 1: the scatter kernel gives every XCD a contiguous range of tiles (default 1)
+ *   "pool_reserve_mb"  reserves ONE device slab of that many MiB now; later requests are carved out of it first
+ *                   (first fit, coalesced on release) and only fall back to hipMalloc when it cannot serve them —
+ *                   a one-shot caller pays its device allocations here, not inside its first call
  *   "pool_guard"    1: every device block the ctx allocates from now on carries 256 canary bytes behind the bytes
  *                   its user asked for, verified (after a device synchronisation) when the block is released
  *   "pool_guard_check"  verifies the canaries of all live blocks now; CPH_ERR_INVALID + the first violation's

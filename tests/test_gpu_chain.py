@@ -224,3 +224,32 @@ def test_config4_full_size_1e8(ctx):
     ia.close()
     ib.close()
     eng.close()
+
+
+def test_device_column_without_a_data_buffer(ctx):
+    """A device-resident column whose values are all empty may come with data == NULL (only offsets): the
+    branch-free value loads must not touch address 0 — the library substitutes a readable base."""
+    import torch
+
+    class NullData:
+        def data_ptr(self):
+            return 0
+
+    n = 5000
+    offs = torch.zeros(n + 1, dtype=torch.int32, device="cuda").view(torch.uint8)
+    empty = StrCol(NullData(), offs, n, 32, N.CPH_MEM_DEVICE, fixed_width=0)
+    cust = dg.customers(1000)["id"]
+    ix = DeviceIndex(ctx, [cust], unique=True)
+    ch = join_chain(ctx, [(ix, [empty])])
+    assert ch.nrows == 0
+    ch.release()
+    m = ix.probe([empty])
+    assert m.nmatches == 0
+    m.release()
+    ex = DeviceIndex(ctx, [empty])                 # all keys equal "": one group, input order kept
+    assert ex.perm().tolist() == list(range(n)) and ex.first_dup == 1
+    mm = ex.probe([StrCol.from_values(["", "x"])])
+    assert mm.cnt.tolist() == [n, 0]
+    mm.release()
+    ex.close()
+    ix.close()

@@ -59,3 +59,39 @@ def test_pool_guard_reports_an_overrun():
     ch.release()
     ix.close()
     ctx.close()
+
+
+def test_reserved_slab_serves_the_same_results():
+    """cph_ctx_set_option "pool_reserve_mb": blocks carved first-fit out of one slab (and coalesced on release) — the
+    hot path on a slab-backed ctx, with the canaries on, gives the oracle's results; requests larger than the slab fall
+    through to hipMalloc."""
+    from oracle import orc
+    ctx = Context(0)
+    ctx.set_option("pool_reserve_mb", 64)
+    ctx.set_option("pool_guard", 1)
+    cust, prod = dg.customers(40_000)["id"], dg.products(300)["prod_id"]
+    oa, ob = orc.OracleIndex([cust]), orc.OracleIndex([prod])
+    for rep in range(3):
+        ia, ib = DeviceIndex.build_many(ctx, [([cust], True), ([prod], True)])
+        np.testing.assert_array_equal(ia.perm(), oa.perm)
+        o = dg.orders(200_000 + 777 * rep, 80_000, 300)
+        ch = join_chain(ctx, [(ia, [o["cust_id"]]), (ib, [o["prod_id"]])])
+        j1 = oa.join([o["cust_id"]])
+        j2 = ob.join([o["prod_id"]], row_sel=j1["probe_idx"].astype(np.uint32))
+        pick = j2["probe_idx"].astype(np.int64)
+        np.testing.assert_array_equal(ch.stream_row, j1["probe_idx"][pick])
+        np.testing.assert_array_equal(ch.build_row(0), j1["build_row"][pick])
+        np.testing.assert_array_equal(ch.build_row(1), j2["build_row"])
+        ch.release()
+        ia.close()
+        ib.close()
+    big = dg.orders(30_000_000, 80_000, 300)["cust_id"]     # 240 MB of keys: beyond the 64 MiB slab
+    ia = DeviceIndex(ctx, [cust], unique=True)
+    m = ia.probe([big], want_pairs=False)
+    assert m.nprobe == 30_000_000
+    m.release()
+    ia.close()
+    ctx.set_option("pool_guard_check", 0)
+    with pytest.raises(N.CphError):
+        ctx.set_option("pool_reserve_mb", 16)      # one slab per ctx
+    ctx.close()

@@ -12,6 +12,9 @@ from csvplus_amd.engine import Engine
 M = int(float(sys.argv[1])) if len(sys.argv) > 1 else 50_000_000
 NC, NP = 10_000_000, 100_000
 eng = Engine(0); ctx = eng.ctx; dev = eng.device
+if len(sys.argv) > 2:   # reserve a device slab up front (MiB): the first repetition then pays no hipMalloc
+    ctx.set_option("pool_reserve_mb", int(sys.argv[2]))
+    print(f"pool_reserve_mb = {sys.argv[2]}", flush=True)
 
 
 def to_device_csv(cols, names):
