@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <vector>
 #include <type_traits>
+#include <chrono>
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -500,6 +501,60 @@ int main(int argc, char** argv) {
             run2(std::integral_constant<int, 128>{}, P, layout);
             run2(std::integral_constant<int, 256>{}, P, layout);
         }
+    }
+
+    // ---- design 2, passes overlapped: row blocks pipelined over three streams --------------------------------
+    // A(b) -> B(b) -> C(b) per row block b; A / C are HBM-bound, B is bound by the L2->L1 path: do they overlap?
+    {
+        constexpr int CAP = 128;
+        const int P = 16;
+        const uint32_t pscale = (uint32_t)((((uint64_t)P << 32) + T - 1) / T);
+        std::vector<uint32_t> lo(65, 0);
+        for (int p = 0; p <= P; p++) lo[p] = (uint32_t)((((uint64_t)p << 32) + pscale - 1) / pscale);
+        lo[0] = 0;
+        uint32_t* d_lo2;
+        CK(hipMalloc(&d_lo2, 65 * 4));
+        CK(hipMemcpy(d_lo2, lo.data(), 65 * 4, hipMemcpyHostToDevice));
+        const size_t cs = (size_t)P * CAP + 64, ps = CAP;
+        const size_t ldsA = 4 * (64 + P * CAP) * 4;
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_passA2<CAP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA));
+        hipStream_t sA, sB, sC;
+        CK(hipStreamCreateWithFlags(&sA, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sB, hipStreamNonBlocking));
+        CK(hipStreamCreateWithFlags(&sC, hipStreamNonBlocking));
+        for (int K : {1, 2, 4, 8}) {
+            for (unsigned gAC : {2048u, 1024u, 512u}) {
+                for (unsigned gB : {2048u, 1024u}) {
+                    const uint32_t per = (nchunks + K - 1) / K;
+                    std::vector<hipEvent_t> eA(K), eB(K);
+                    for (int b = 0; b < K; b++) { CK(hipEventCreateWithFlags(&eA[b], hipEventDisableTiming)); CK(hipEventCreateWithFlags(&eB[b], hipEventDisableTiming)); }
+                    auto run_once = [&](bool overlapped) {
+                        for (int b = 0; b < K; b++) {
+                            const uint32_t c0 = b * per, nb = c0 + per <= nchunks ? per : nchunks - c0;
+                            uint32_t* staged = seg + (size_t)c0 * cs;
+                            uint32_t* res = seg + (size_t)nchunks * cs + (size_t)c0 * cs;
+                            uint32_t* cnt = counts + (size_t)c0 * P * 2;   // this block's chunk-major + slice-major counts
+                            hipStream_t a = overlapped ? sA : sA, bs = overlapped ? sB : sA, c = overlapped ? sC : sA;
+                            hipLaunchKernelGGL((k_passA2<CAP>), dim3(gAC), dim3(256), ldsA, a, codes + (size_t)c0 * kChunk, nb, T, P, pscale, d_lo2, staged, cnt, cs, ps);
+                            if (overlapped) { CK(hipEventRecord(eA[b], a)); CK(hipStreamWaitEvent(bs, eA[b], 0)); }
+                            hipLaunchKernelGGL((k_passB2<CAP, 4>), dim3(gB), dim3(256), 0, bs, staged, cnt, nb, table, P, d_lo2, res, cs, ps);
+                            if (overlapped) { CK(hipEventRecord(eB[b], bs)); CK(hipStreamWaitEvent(c, eB[b], 0)); }
+                            hipLaunchKernelGGL((k_passC2<CAP>), dim3(gAC), dim3(256), 0, c, staged, res, cnt, nb, P, out + (size_t)c0 * kChunk, cs, ps);
+                        }
+                    };
+                    float t[2];
+                    for (int ov = 0; ov < 2; ov++) {
+                        run_once(ov); CK(hipDeviceSynchronize());
+                        auto h0 = std::chrono::steady_clock::now();
+                        for (int r = 0; r < 5; r++) run_once(ov);
+                        CK(hipDeviceSynchronize());
+                        t[ov] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - h0).count() / 5;
+                    }
+                    printf("overlap  K=%d row blocks, grids A/C %4u B %4u : serial %6.3f ms  three streams %6.3f ms\n", K, gAC, gB, t[0], t[1]);
+                    for (int b = 0; b < K; b++) { CK(hipEventDestroy(eA[b])); CK(hipEventDestroy(eB[b])); }
+                }
+            }
+        }
+        check("overlapped A2+B2+C2");
     }
     std::vector<uint32_t> h(128);
     CK(hipMemcpy(h.data(), xcc, 512, hipMemcpyDeviceToHost));
