@@ -173,6 +173,7 @@ PROTOTYPES = [
     ("cph_ctx_set_option", C.c_int32, [_P, C.c_char_p, C.c_int64]),
     ("cph_ctx_synchronize", C.c_int32, [_P]),
     ("cph_ctx_profile", C.c_int32, [_P, C.c_int32]),
+    ("cph_ctx_profile_only", C.c_int32, [_P, C.c_char_p]),
     ("cph_ctx_profile_read", C.c_int32,
      [_P, C.POINTER(cph_kernel_stat), C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
     ("cph_pinned_alloc", C.c_int32, [_P, C.c_size_t, C.POINTER(_P)]),
@@ -321,6 +322,10 @@ class Context:
 
     def profile(self, enable: bool = True):
         self._check(self.lib.cph_ctx_profile(self.handle, 1 if enable else 0))
+
+    def profile_only(self, kernel_name):
+        """Times only the launches of one kernel (None: off): cph_ctx_profile_only."""
+        self._check(self.lib.cph_ctx_profile_only(self.handle, kernel_name.encode() if kernel_name else None))
 
     def profile_read(self, reset: bool = True) -> dict:
         """{kernel name: {launches, total_ms, algo_bytes}} measured with HIP events on the ctx stream."""

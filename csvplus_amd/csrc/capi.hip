@@ -212,6 +212,7 @@ Status pinned_upload(cph_ctx* ctx, size_t bytes, void** out) {
 // ---- per-kernel timing --------------------------------------------------------------------------
 ProfScope::ProfScope(cph_ctx* ctx, const char* name, double bytes) : ctx_(ctx), bytes_(bytes) {
     if (!ctx->profiling) return;
+    if (!ctx->prof_only.empty() && ctx->prof_only != name) return;   // the pair of events costs ~10 us of stream time
     for (size_t i = 0; i < ctx->prof_stats.size(); i++)
         if (ctx->prof_stats[i].name == name) { idx_ = (int)i; break; }
     if (idx_ < 0) {
@@ -696,6 +697,15 @@ CPH_API int32_t cph_ctx_profile(cph_ctx* ctx, int32_t enable) {
     Status s = enter(ctx);
     if (!s.ok()) return fail(ctx, s);
     ctx->profiling = enable != 0;
+    ctx->prof_only.clear();
+    return CPH_OK;
+}
+
+CPH_API int32_t cph_ctx_profile_only(cph_ctx* ctx, const char* kernel_name) {
+    Status s = enter(ctx);
+    if (!s.ok()) return fail(ctx, s);
+    ctx->profiling = kernel_name != nullptr;
+    ctx->prof_only = kernel_name ? kernel_name : "";
     return CPH_OK;
 }
 

@@ -232,6 +232,7 @@ struct cph_ctx {
     std::vector<KernelCfg> kernel_cfg;   // kernels whose dynamic-LDS attribute / occupancy were set up on this device
     // profiling
     bool profiling = false;
+    std::string prof_only;         // non-empty: only launches of this kernel are timed (cph_ctx_profile_only)
     std::vector<cph::ProfPending> prof_pending;
     std::vector<cph::ProfStat> prof_stats;
     std::vector<hipEvent_t> prof_free_events;

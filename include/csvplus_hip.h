@@ -548,6 +548,10 @@ typedef struct {
 } cph_kernel_stat;
 
 CPH_API int32_t cph_ctx_profile(cph_ctx* ctx, int32_t enable);
+/* The two events around a launch cost ~10 us of stream time each: a loop of many short kernels measurably slows
+ * down under cph_ctx_profile.  This variant times ONLY the launches of `kernel_name` (NULL: profiling off), so a
+ * benchmark can time its dominant kernel inside the timed region without disturbing the region. */
+CPH_API int32_t cph_ctx_profile_only(cph_ctx* ctx, const char* kernel_name);
 CPH_API int32_t cph_ctx_profile_read(cph_ctx* ctx, cph_kernel_stat* out, int32_t cap, int32_t* n, int32_t reset);
 
 /* Library version, e.g. "csvplus_hip 0.1 (gfx950)". */

@@ -253,3 +253,30 @@ def test_device_column_without_a_data_buffer(ctx):
     mm.release()
     ex.close()
     ix.close()
+
+
+def test_profile_only_times_one_kernel(ctx):
+    """cph_ctx_profile_only: HIP events around ONE kernel's launches (bench.py's timed region), nothing else."""
+    cust, prod = dg.customers(20_000)["id"], dg.products(50)["prod_id"]
+    o = dg.orders(100_000, 20_000, 50)
+
+    def one():
+        ia, ib = DeviceIndex(ctx, [cust], unique=True), DeviceIndex(ctx, [prod], unique=True)
+        ch = join_chain(ctx, [(ia, [o["cust_id"]]), (ib, [o["prod_id"]])], out_mem=N.CPH_MEM_DEVICE)
+        n = ch.nrows
+        ch.release(); ia.close(); ib.close()
+        return n
+
+    one()
+    ctx.profile(True)
+    ctx.profile_read(reset=True)
+    assert one() == 100_000
+    full = ctx.profile_read(reset=True)
+    assert "k_chain_dense" in full and len(full) > 3
+    ctx.profile_only("k_chain_dense")
+    one(); one()
+    only = ctx.profile_read(reset=True)
+    assert list(only) == ["k_chain_dense"] and only["k_chain_dense"]["launches"] == 2 and only["k_chain_dense"]["total_ms"] > 0
+    ctx.profile(False)
+    one()
+    assert ctx.profile_read(reset=True) == {}
