@@ -338,6 +338,7 @@ struct BuildJob {
     DevCol dcols[kMaxKeyCols];
     DevBuf stats_dev;
     size_t scratch_off = 0;      // where this job's read-backs land in ctx->pinned_scratch
+    GroupSpec spec;              // speculative dictionaries (codec_try_groups)
 };
 
 static Status build_phase1(cph_ctx* ctx, const cph_strcol* keycols, int32_t nkeycols, BuildJob* job) {
@@ -354,6 +355,7 @@ static Status build_phase1(cph_ctx* ctx, const cph_strcol* keycols, int32_t nkey
 }
 
 static Status build_phase2(cph_ctx* ctx, BuildJob* job, const void* stats_host);
+static Status build_encode_sort(cph_ctx* ctx, BuildJob* job);
 
 // Runs a batch of jobs whose phase 1 succeeded (ok[i]); status[i] receives each job's outcome.
 static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Status>& status) {
@@ -519,8 +521,16 @@ static Status build_phase2(cph_ctx* ctx, BuildJob* job, const void* stats_host) 
     for (const auto& s : stats) positions += s.maxlen;
     if (positions > (uint64_t)kMaxKeyBytes) return build_multi_window(ctx, job, stats);
     CPH_TRY(codec_build(stats, &ix->codec));
-    CPH_TRY(codec_try_groups(ctx, dcols, nkeycols, n, &ix->codec));   // only acts on codes of several words
+    CPH_TRY(codec_try_groups(ctx, dcols, nkeycols, n, &ix->codec, &job->spec));   // only acts on codes of several words
     CPH_TRY(codec_upload(ctx, ix->codec, &ix->codec_dev));
+    return build_encode_sort(ctx, job);
+}
+
+// Encode with the index's codec, sort, launch the adjacent-equal scan.
+static Status build_encode_sort(cph_ctx* ctx, BuildJob* job) {
+    cph_index* ix = job->ix;
+    const uint64_t n = ix->nrows;
+    const DevCol* dcols = job->dcols;
     const CodecHost& cd = ix->codec;
 
     DevBuf va, vb;
@@ -543,7 +553,27 @@ static Status build_phase2(cph_ctx* ctx, BuildJob* job, const void* stats_host) 
             eh.bins = 1u << plan.rbits;
             eh.counts = counts.as<uint32_t>();
         }
-        CPH_TRY(codec_encode_build(ctx, cd, ix->codec_dev, dcols, n, ka.get(), &eh));
+        CPH_TRY(codec_encode_build(ctx, cd, ix->codec_dev, dcols, n, ka.get(), &eh, &job->spec));
+        if (job->spec.active) {
+            // speculative dictionaries (from a sample of the rows): did the encode kernel meet a window they lack?  Then
+            // it has added every such window to the device sets: rebuild the codec from the now complete sets and encode
+            // again.  (One more synchronisation, in exchange for the exact statistics pass over all rows.)
+            uint32_t miss = 0;
+            CPH_TRY(read_device_value(ctx, job->spec.miss.as<uint32_t>(), &miss));
+            job->spec.active = false;
+            if (miss) {
+                const int bits_before = cd.word_bits[0];
+                CPH_TRY(codec_groups_complete(ctx, dcols, job->nkeycols, n, miss, &job->spec, &ix->codec));
+                CPH_TRY(codec_upload(ctx, ix->codec, &ix->codec_dev));
+                // the same single-word shape (the usual outcome: a few more dictionary entries): encode into the same
+                // buffers; anything else starts over with the new codec
+                if (cd.nwords != 1 || cd.word_bits[0] != bits_before || radix_plan(ctx, n, cd.word_bits[0]).npass != plan.npass) {
+                    ka.reset(); kb.reset(); counts.reset(); va.reset(); vb.reset();
+                    return build_encode_sort(ctx, job);
+                }
+                CPH_TRY(codec_encode_build(ctx, cd, ix->codec_dev, dcols, n, ka.get(), &eh, nullptr));
+            }
+        }
         uint32_t* vout;
         if (cd.key32) {
             uint32_t* kout;
@@ -648,6 +678,10 @@ CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value
     else if (k == "sort_threads") ctx->sort_threads = (int)value;
     else if (k == "sort_rbits") ctx->sort_rbits = (int)value;
     else if (k == "sort_xcd_tiles") ctx->sort_xcd_tiles = value != 0;
+    else if (k == "codec_debug") ctx->codec_debug = value != 0;
+    else if (k == "plan_threads") ctx->plan_threads = (int)value;
+    else if (k == "gstats_threads") ctx->gstats_threads = (int)value;
+    else if (k == "speculative_groups") ctx->speculative_groups = value < 0 || value > 2 ? 1 : (int)value;   // 0 never, 1 when the sample shows no rare value, 2 always
     else if (k == "pool_guard") ctx->pool.guard = value != 0;
     else if (k == "pool_reserve_mb") {
         if (value <= 0) return fail_with(ctx, {CPH_ERR_INVALID, "pool_reserve_mb must be positive"});

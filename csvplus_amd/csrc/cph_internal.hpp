@@ -228,6 +228,10 @@ struct cph_ctx {
     int chain_debug = 0;           // attribution switches of the chained-join kernel (cph_ctx_set_option)
     int sort_threads = 0, sort_rbits = 0;   // radix-sort tuning overrides (0: automatic)
     int sort_xcd_tiles = 1;        // scatter: contiguous tile ranges per XCD (radix_sort.hip)
+    int codec_debug = 0;           // prints the window choice of codec_try_groups to stderr
+    int plan_threads = 0, gstats_threads = 0;   // tuning: workgroup sizes of k_encode_build_plan / k_group_stats (0: default)
+    int speculative_groups = 1;    // dictionaries of large inputs from a sample, completed by the encode kernel (keycodec.hip):
+                                   // 0 never, 1 when the sample holds no value seen only once, 2 always
     struct KernelCfg { const void* fn; size_t lds; int blocks_per_cu; };
     std::vector<KernelCfg> kernel_cfg;   // kernels whose dynamic-LDS attribute / occupancy were set up on this device
     // profiling
@@ -321,7 +325,23 @@ void codec_stats_finish(const DevCol* cols, int32_t ncols, const void* host_copy
 Status codec_build(const std::vector<ColStats>& stats, CodecHost* codec);   // host only
 // When the per-position code needs several words: one more pass over the key columns collects the distinct
 // joint symbols of every 7-position group; groups with few of them are dictionary-coded (codec rebuilt in place).
-Status codec_try_groups(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t n, CodecHost* codec);
+// On large inputs the dictionaries can be SPECULATIVE (spec != nullptr): they are taken from a sample of the rows, the
+// encode kernel adds every window it does not find to the device sets and raises `miss`; the caller reads the flag
+// with its next synchronisation and, when it is set, calls codec_groups_complete (the sets are complete by then: every
+// row's windows were either found or inserted) and encodes again.  A sample that saw every window — the usual case for
+// low-cardinality fields — saves the exact pass over all rows.
+struct GroupChoice { int t, p0, span; double saved; uint32_t count; uint32_t tab; };   // tab: window descriptor (keycodec.hip)
+struct GroupSpec {
+    bool active = false;
+    DevBuf slots, counts, miss;          // per table: hash set [kGroupSlots] u64, entry count u32; miss: rows with an unknown window (u32)
+    std::vector<GroupChoice> chosen;     // the tables behind the codec's group heads
+    CodecHost plain;                     // the codec without groups
+};
+Status codec_try_groups(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t n, CodecHost* codec, GroupSpec* spec = nullptr);
+// missed = the encode kernel's count of rows with an unknown window; at or above kSpecGiveUp the kernel stopped
+// early and the exact pass over all rows runs first.
+constexpr uint32_t kSpecGiveUp = 1u << 16;
+Status codec_groups_complete(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t n, uint32_t missed, GroupSpec* spec, CodecHost* codec);
 Status codec_upload(cph_ctx* ctx, const CodecHost& codec, DevBuf* dev);
 int codec_premultiplied_bits(const CodecHost& codec);   // 0 / 32 / 64
 // Encodes the build-side keys.  key32: out32[n]; else out64[nwords][n].
@@ -335,7 +355,7 @@ struct EncodeHist {
     bool done = false;
 };
 Status codec_encode_build(cph_ctx* ctx, const CodecHost& codec, const DevBuf& codec_dev, const DevCol* cols,
-                          uint64_t n, void* out_codes, const EncodeHist* hist = nullptr);
+                          uint64_t n, void* out_codes, const EncodeHist* hist = nullptr, const GroupSpec* spec = nullptr);
 // Host-side encoding of literal values (cph_index_find).  Returns false when a
 // value cannot occur in the index (symbol outside the alphabet / too long).
 bool codec_encode_values_host(const CodecHost& codec, const cph_strval* values, int32_t nvalues,

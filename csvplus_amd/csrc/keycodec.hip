@@ -242,43 +242,41 @@ Status codec_build(const std::vector<ColStats>& stats, CodecHost* codec) {
 // ---------------------------------------------------------------------------------------------
 // Dictionary-coded groups.  Per-position alphabets price every position independently: a key like
 // "Smith/Amelia#12345" costs ~4-5 bits for each of its 18 positions although its first bytes take
-// only a hundred distinct values.  When the per-position code does not fit one word, one more pass
-// over the key columns collects, for every group of kGroupSpan consecutive positions of a column,
-// the set of byte windows (raw keys: the valid bytes + their count, group_raw) that occur — in a
-// small open-addressing table per group, given up as soon as it holds more than kGroupDictMax
-// entries.  A group with few distinct windows is then coded by the rank of its window among them,
-// ranked by the tuple of position symbols (group_order_key), so codes stay order preserving.
+// only a hundred distinct values.  When the per-position code does not fit one word, the set of
+// byte windows (raw keys: the valid bytes + their count, group_raw) that occur is collected for
+// EVERY window of 2..kGroupSpan consecutive positions of a column:
+//   k_group_sample   one workgroup per candidate window, its set in LDS (same geometry as the device
+//                    sets), over a sample of the rows (all of them when there are few); windows
+//                    with more than kGroupDictMax values drop out after a few thousand rows
+//   (host)           the partition of the positions into windows / plain positions that needs the
+//                    fewest code bits within the dictionary capacity (a small dynamic programme)
+//   k_group_stats    large inputs: the exact sets of the chosen windows, over all rows — or none at all,
+//                    when the sample shows no rare value (speculative dictionaries, GroupSpec)
+// A chosen window is coded by the rank of its raw key among the set, ranked by the tuple of position
+// symbols (group_order_key), so codes stay order preserving.
 // ---------------------------------------------------------------------------------------------
-constexpr int kGroupSlots = 16384;            // slots of one group's hash set (power of two)
+constexpr int kGroupSlotBits = 14;
+constexpr int kGroupSlots = 1 << kGroupSlotBits;   // slots of one window's hash set
+constexpr int kPlanMaxUnits = 40;             // units (plain positions + group heads) k_encode_build_plan takes
 constexpr uint64_t kGroupEmpty = ~0ull;
 constexpr uint32_t kGroupOverflow = 0x40000000u;
-
-// Candidate groups: every window of kGroupSpan positions ("base") is examined as a whole and as its two halves
-// (4 + 3 positions), all in the same pass: variable-length fields shift what follows them, and a half often
-// stays low-cardinality where the whole window does not.
-constexpr int kGroupMaxBases = kMaxKeyBytes / kGroupSpan + kMaxKeyCols + 1;
-constexpr int kGroupMaxTables = 3 * kGroupMaxBases;
-constexpr int kGroupHalf = 4;                 // positions of the first half
+constexpr int kGroupMaxTables = (kGroupSpan - 1) * kMaxKeyBytes;   // candidate windows: every start, spans 2..kGroupSpan
+constexpr int kGroupMaxChosen = kMaxKeyBytes / 2;                   // windows of one partition
 constexpr int kGroupRows = 4;                 // rows per thread and iteration in k_group_stats
+constexpr int kSampleThreads = 1024;
+constexpr int kSampleRows = 4;                // rows per thread and iteration in k_group_sample
 
-struct GroupLayout {
-    int32_t nbases, ntables;
-    int32_t col[kGroupMaxBases];      // key column of the base window
-    int32_t q0[kGroupMaxBases];       // first byte offset within the column
-    int32_t span[kGroupMaxBases];     // positions in the window (2..kGroupSpan)
-    int32_t tab_base[kGroupMaxTables];    // table t examines base tab_base[t] ...
-    int32_t tab_first[kGroupMaxTables];   // ... from its position tab_first[t] ...
-    int32_t tab_span[kGroupMaxTables];    // ... over tab_span[t] positions
-};
+// window descriptor: key column | first byte offset << 8 | positions << 16
+__host__ __device__ constexpr uint32_t group_tab(int col, int q0, int span) { return (uint32_t)col | (uint32_t)q0 << 8 | (uint32_t)span << 16; }
+__host__ __device__ constexpr int tab_col(uint32_t t) { return (int)(t & 0xFFu); }
+__host__ __device__ constexpr int tab_q0(uint32_t t) { return (int)((t >> 8) & 0xFFu); }
+__host__ __device__ constexpr int tab_span(uint32_t t) { return (int)(t >> 16); }
 
-__device__ __forceinline__ uint64_t group_hash(uint64_t x) {
-    x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull;
-    x ^= x >> 32; x *= 0x94D049BB133111EBull;
-    return x ^ (x >> 29);
-}
+// slot of a raw key in a window's set (LDS or device memory: the same geometry, so a set can move between them)
+__device__ __forceinline__ uint32_t group_set_slot(uint64_t sym) { return (uint32_t)((sym * 0x9E3779B97F4A7C15ull) >> (64 - kGroupSlotBits)); }
 
-__device__ __forceinline__ void group_insert(uint64_t* tab, uint32_t* count, uint64_t sym, uint32_t hash) {
-    uint32_t h = hash & (kGroupSlots - 1);
+__device__ __forceinline__ void group_insert(uint64_t* tab, uint32_t* count, uint64_t sym) {
+    uint32_t h = group_set_slot(sym);
     int probes = 0;
     for (;; h = (h + 1) & (kGroupSlots - 1)) {
         const uint64_t cur = tab[h];
@@ -293,174 +291,165 @@ __device__ __forceinline__ void group_insert(uint64_t* tab, uint32_t* count, uin
     }
 }
 
-// examines rows 0, step, 2*step, ... (< n).  Each workgroup keeps a direct-mapped cache of the symbols it has
-// already seen per table in LDS (cache_bits: log2 entries per table; dynamic LDS = ntables << (cache_bits + 3)):
-// almost every row repeats a known symbol and never leaves the CU.
-template <bool LONGV>
-__global__ __launch_bounds__(256) void k_group_stats(ColsArg cols, GroupLayout lay, uint64_t n, uint64_t step, int cache_bits,
+// The sampled rows (0, step, 2*step, ... < n) made dense: for sampled row j and key column c, data[c] + j * width[c]
+// holds the value's first bytes, zero padded (width = the column's longest value rounded up to 8, + 8: an 8-byte read
+// at any position stays inside the row), and lens[c][j] its length.  Every candidate window's workgroup then streams
+// these few MiB instead of gathering the rows from the column again.
+struct StageArg {
+    uint8_t* data[kMaxKeyCols];
+    uint32_t* lens[kMaxKeyCols];
+    uint32_t width[kMaxKeyCols];
+    int32_t ncols;
+};
+__global__ __launch_bounds__(256) void k_group_stage(ColsArg cols, StageArg st, uint64_t step, uint64_t nsel) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < nsel; j += stride)
+        for (int c = 0; c < st.ncols; c++) {
+            uint64_t b, l;
+            value_span(cols.c[c], j * step, &b, &l);
+            st.lens[c][j] = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;
+            uint64_t* dst = reinterpret_cast<uint64_t*>(st.data[c] + j * st.width[c]);
+            for (uint32_t k = 0; k < st.width[c] / 8; k++) {
+                uint64_t w = 0;
+                if (8ull * k < l) {
+                    w = load_value_chunk(cols.c[c].data, b, l, (int)k);
+                    const uint64_t nb = l - 8ull * k;
+                    if (nb < 8) w &= (1ull << (8 * nb)) - 1;
+                }
+                dst[k] = w;
+            }
+        }
+}
+
+// One workgroup per candidate window over the staged sample.  counts[t] = distinct raw keys (kGroupOverflow set:
+// more than kGroupDictMax, the set is not written); singles[t] = those seen exactly once — the Good-Turing estimate
+// of how much of the data the sample has NOT seen; slots[t] = the set.
+__global__ __launch_bounds__(kSampleThreads) void k_group_sample(StageArg st, const uint32_t* __restrict__ tabs, uint64_t nsel,
+                                                                uint64_t* __restrict__ slots, uint32_t* __restrict__ counts,
+                                                                uint32_t* __restrict__ singles) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    CPH_LDS uint64_t* set = (CPH_LDS uint64_t*)smem;
+    CPH_LDS uint8_t* twice = (CPH_LDS uint8_t*)(smem + (size_t)kGroupSlots * sizeof(uint64_t));
+    __shared__ uint32_t s_count, s_single;
+    typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+    const uint32_t tab = tabs[blockIdx.x];
+    const int c = tab_col(tab);
+    const uint32_t q0 = (uint32_t)tab_q0(tab), span = (uint32_t)tab_span(tab), width = st.width[c];
+    const uint8_t* __restrict__ data = st.data[c];
+    const uint32_t* __restrict__ lens = st.lens[c];
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kGroupSlots; i += kSampleThreads) { set[i] = kGroupEmpty; twice[i] = 0; }
+    if (threadIdx.x == 0) { s_count = 0; s_single = 0; }
+    __syncthreads();
+    for (uint64_t base = 0; base < nsel; base += (uint64_t)kSampleThreads * kSampleRows) {
+        if (s_count > (uint32_t)kGroupDictMax) break;   // every wave leaves within an iteration
+        uint64_t win[kSampleRows];
+        uint32_t len[kSampleRows];
+#pragma unroll
+        for (int k = 0; k < kSampleRows; k++) {   // rows past the end re-read the last one: no branch around the loads
+            const uint64_t i = base + (uint64_t)k * kSampleThreads + threadIdx.x;
+            const uint64_t j = i < nsel ? i : nsel - 1;
+            len[k] = lens[j];
+            win[k] = *reinterpret_cast<const u64_unaligned*>(data + j * width + q0);
+        }
+#pragma unroll
+        for (int k = 0; k < kSampleRows; k++) {
+            if (base + (uint64_t)k * kSampleThreads + threadIdx.x >= nsel) continue;
+            const uint32_t left = len[k] > q0 ? len[k] - q0 : 0u;
+            const uint64_t sym = group_raw(win[k], (uint64_t)(left < span ? left : span));
+            uint32_t h = group_set_slot(sym);
+            for (int probes = 0; probes < kGroupSlots; probes++, h = (h + 1) & (kGroupSlots - 1)) {
+                const uint64_t cur = set[h];
+                if (cur == sym) { twice[h] = 1; break; }
+                if (cur == kGroupEmpty) {
+                    const uint64_t prev = atomicCAS((unsigned long long*)&set[h], (unsigned long long)kGroupEmpty, (unsigned long long)sym);
+                    if (prev == kGroupEmpty) { atomicAdd(&s_count, 1u); break; }
+                    if (prev == sym) { twice[h] = 1; break; }
+                }
+                if (s_count > (uint32_t)kGroupDictMax) break;
+            }
+        }
+    }
+    __syncthreads();
+    const bool over = s_count > (uint32_t)kGroupDictMax;
+    uint32_t once = 0;
+    if (!over)
+        for (uint32_t i = threadIdx.x; i < (uint32_t)kGroupSlots; i += kSampleThreads) {
+            const uint64_t e = set[i];
+            slots[(uint64_t)blockIdx.x * kGroupSlots + i] = e;
+            once += e != kGroupEmpty && !twice[i];
+        }
+    once = wave_sum(once);
+    if (lane_id() == 0 && once) atomicAdd(&s_single, once);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        counts[blockIdx.x] = over ? (s_count | kGroupOverflow) : s_count;
+        singles[blockIdx.x] = s_single;
+    }
+}
+
+// The windows one exact pass examines: descriptor + which device set (slots / counts index) collects it.
+struct GroupLayout {
+    int32_t ntables;
+    uint32_t tab[kGroupMaxChosen];
+    int32_t set[kGroupMaxChosen];
+};
+
+// Every row's window goes into its device set (which k_group_sample has pre-filled).  Each workgroup keeps a
+// direct-mapped cache of the symbols it has already seen per table in LDS (cache_bits: log2 entries per table;
+// dynamic LDS = ntables << (cache_bits + 3)): almost every row repeats a known symbol and never leaves the CU.
+template <bool LONGV, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_group_stats(ColsArg cols, GroupLayout lay, uint64_t n, int cache_bits,
                                                     uint64_t* __restrict__ slots, uint32_t* __restrict__ counts) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     CPH_LDS uint64_t* seen = (CPH_LDS uint64_t*)smem;
     const uint32_t cache_n = 1u << cache_bits;
-    for (uint32_t i = threadIdx.x; i < (uint32_t)lay.ntables * cache_n; i += 256) seen[i] = kGroupEmpty;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)lay.ntables * cache_n; i += THREADS) seen[i] = kGroupEmpty;
     __syncthreads();
     // kGroupRows rows per thread and iteration, their loads issued together (one row at a time is latency-bound)
-    const uint64_t stride = (uint64_t)gridDim.x * 256 * kGroupRows;
-    const uint64_t nsel = (n + step - 1) / step;
-    for (uint64_t base = (uint64_t)blockIdx.x * 256 * kGroupRows; base < nsel; base += stride) {
-        int cur_col = -1, cur_base = -1;
+    const uint64_t stride = (uint64_t)gridDim.x * THREADS * kGroupRows;
+    for (uint64_t base = (uint64_t)blockIdx.x * THREADS * kGroupRows; base < n; base += stride) {
+        int cur_col = -1;
         ValueHeadT<LONGV> v[kGroupRows];
-        uint64_t win[kGroupRows];   // the value's bytes from the base window's first position on
         bool live[kGroupRows];
 #pragma unroll
-        for (int k = 0; k < kGroupRows; k++) live[k] = base + (uint64_t)k * 256 + threadIdx.x < nsel;
+        for (int k = 0; k < kGroupRows; k++) live[k] = base + (uint64_t)k * THREADS + threadIdx.x < n;
         for (int t = 0; t < lay.ntables; t++) {
-            const int g = lay.tab_base[t];
-            if (g != cur_base) {
-                cur_base = g;
-                if (lay.col[g] != cur_col) {
-                    cur_col = lay.col[g];
-                    // rows past the end re-read the last selected row (their symbols are never inserted): no branch
-                    // around the loads, so the kGroupRows rows of a lane are in flight together
+            const uint32_t tab = lay.tab[t];
+            const int q0 = tab_q0(tab), span = tab_span(tab);
+            if (tab_col(tab) != cur_col) {
+                cur_col = tab_col(tab);
+                // rows past the end re-read the last row (their symbols are never inserted): no branch around the
+                // loads, so the kGroupRows rows of a lane are in flight together
 #pragma unroll
-                    for (int k = 0; k < kGroupRows; k++) {
-                        const uint64_t i = base + (uint64_t)k * 256 + threadIdx.x;
-                        v[k].span(cols.c[cur_col], (i < nsel ? i : nsel - 1) * step);
-                    }
-#pragma unroll
-                    for (int k = 0; k < kGroupRows; k++) v[k].chunks_nobranch(cols.c[cur_col]);
+                for (int k = 0; k < kGroupRows; k++) {
+                    const uint64_t i = base + (uint64_t)k * THREADS + threadIdx.x;
+                    v[k].span(cols.c[cur_col], i < n ? i : n - 1);
                 }
 #pragma unroll
-                for (int k = 0; k < kGroupRows; k++) win[k] = live[k] ? v[k].window(cols.c[cur_col], lay.q0[g]) : 0;
+                for (int k = 0; k < kGroupRows; k++) v[k].chunks_nobranch(cols.c[cur_col]);
             }
+            const int set = lay.set[t];
 #pragma unroll
             for (int k = 0; k < kGroupRows; k++) {
                 if (!live[k]) continue;
-                // raw key of the sub-window (group_raw): its bytes still covered by the value + how many they are
-                const uint64_t q = (uint64_t)(lay.q0[g] + lay.tab_first[t]);
-                const uint64_t left = v[k].len > q ? v[k].len - q : 0;
-                const uint64_t sym = group_raw(win[k] >> (8 * lay.tab_first[t]), left < (uint64_t)lay.tab_span[t] ? left : (uint64_t)lay.tab_span[t]);
-                const uint64_t hs = group_hash(sym);
-                CPH_LDS uint64_t* mine = seen + ((uint32_t)t << cache_bits) + ((uint32_t)(hs >> 32) & (cache_n - 1));
-                if (*mine == sym) continue;                          // seen by this workgroup: already in the table
-                if (counts[t] > (uint32_t)kGroupDictMax) continue;   // given up already (a stale read only costs work)
-                group_insert(slots + (uint64_t)t * kGroupSlots, &counts[t], sym, (uint32_t)hs);
+                const uint64_t left = v[k].len > (uint64_t)q0 ? v[k].len - (uint64_t)q0 : 0;
+                const uint64_t sym = group_raw(v[k].window(cols.c[cur_col], q0), left < (uint64_t)span ? left : (uint64_t)span);
+                const uint64_t hs = sym * 0x9E3779B97F4A7C15ull;
+                CPH_LDS uint64_t* mine = seen + ((uint32_t)t << cache_bits) + ((uint32_t)(hs >> 40) & (cache_n - 1));
+                if (*mine == sym) continue;                            // seen by this workgroup: already in the set
+                if (counts[set] > (uint32_t)kGroupDictMax) continue;   // given up already (a stale read only costs work)
+                group_insert(slots + (uint64_t)set * kGroupSlots, &counts[set], sym);
                 *mine = sym;   // racing writers store whole symbols they inserted: any survivor is a valid entry
             }
         }
     }
 }
 
-Status codec_try_groups(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t n, CodecHost* codec) {
-    CodecHost& cd = *codec;
-    if (cd.nwords < 2 || n == 0) return {};
-    GroupLayout lay{};
-    for (int c = 0; c < cd.ncols; c++)
-        for (int q0 = 0; q0 < cd.col_maxlen[c]; q0 += kGroupSpan) {
-            const int span = std::min(kGroupSpan, cd.col_maxlen[c] - q0);
-            if (span < 2 || lay.nbases >= kGroupMaxBases) continue;
-            const int g = lay.nbases++;
-            lay.col[g] = c;
-            lay.q0[g] = q0;
-            lay.span[g] = span;
-            auto add = [&](int first, int sp) {
-                if (sp < 2) return;
-                lay.tab_base[lay.ntables] = g;
-                lay.tab_first[lay.ntables] = first;
-                lay.tab_span[lay.ntables] = sp;
-                lay.ntables++;
-            };
-            add(0, span);
-            if (span > kGroupHalf) {
-                add(0, kGroupHalf);
-                add(kGroupHalf, span - kGroupHalf);
-            }
-        }
-    if (lay.ntables == 0) return {};
-    ColsArg arg{};
-    for (int c = 0; c < ncols; c++) arg.c[c] = cols[c];
-    bool long_values = false;   // any key column with values of more than 24 bytes
-    for (int c = 0; c < cd.ncols; c++) long_values |= cd.col_maxlen[c] > 24;
-    DevBuf slots, counts;
-    std::vector<uint32_t> hcount;
-    // one stats pass over every `step`-th row with the tables of `l`
-    auto run_pass = [&](const GroupLayout& l, uint64_t step) -> Status {
-        const int nt = l.ntables;
-        CPH_TRY(slots.alloc(&ctx->pool, (size_t)nt * kGroupSlots * sizeof(uint64_t)));
-        CPH_TRY(counts.alloc(&ctx->pool, (size_t)nt * sizeof(uint32_t)));
-        CPH_HIP_TRY(hipMemsetAsync(slots.get(), 0xFF, (size_t)nt * kGroupSlots * sizeof(uint64_t), ctx->stream));
-        CPH_HIP_TRY(hipMemsetAsync(counts.get(), 0, (size_t)nt * sizeof(uint32_t), ctx->stream));
-        {
-            ProfScope ps(ctx, "k_group_stats", 0);
-            uint64_t nblk = ((n + step - 1) / step + 256 * kGroupRows - 1) / (256 * kGroupRows);
-            if (nblk > 2048) nblk = 2048;
-            int cache_bits = 10;                                    // at most 32 KiB of LDS shared by the tables
-            while (cache_bits > 5 && ((size_t)nt << (cache_bits + 3)) > 32 * 1024) cache_bits--;
-            if (long_values)
-                hipLaunchKernelGGL(k_group_stats<true>, dim3((unsigned)nblk), dim3(256), (size_t)nt << (cache_bits + 3), ctx->stream, arg, l, n,
-                                   step, cache_bits, slots.as<uint64_t>(), counts.as<uint32_t>());
-            else
-                hipLaunchKernelGGL(k_group_stats<false>, dim3((unsigned)nblk), dim3(256), (size_t)nt << (cache_bits + 3), ctx->stream, arg, l, n,
-                                   step, cache_bits, slots.as<uint64_t>(), counts.as<uint32_t>());
-            CPH_HIP_TRY(hipGetLastError());
-        }
-        hcount.assign((size_t)nt, 0);
-        CPH_TRY(ensure_pinned_scratch(ctx, (size_t)nt * sizeof(uint32_t)));
-        CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, counts.get(), (size_t)nt * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
-        memcpy(hcount.data(), ctx->pinned_scratch, (size_t)nt * sizeof(uint32_t));
-        return {};
-    };
-    auto saved_bits = [&](const GroupLayout& l, int t) -> double {   // < 0: unusable
-        if (hcount[(size_t)t] == 0 || hcount[(size_t)t] > (uint32_t)kGroupDictMax) return -1.0;
-        const int g = l.tab_base[t];
-        const int p0 = cd.col_start[l.col[g]] + l.q0[g] + l.tab_first[t];
-        double bits_pos = 0;
-        for (int i = 0; i < l.tab_span[t]; i++) bits_pos += std::log2((double)cd.radix[(size_t)(p0 + i)]);
-        return bits_pos - std::log2((double)hcount[(size_t)t]);
-    };
-    // A sample first (about a million rows): it prunes the windows that are hopeless or not worth a dictionary and
-    // picks, per base window, between the whole and its halves, so that the exact pass over all rows probes few tables.
-    const uint64_t step = n > (1ull << 21) ? n >> 20 : 1;
-    if (step > 1) {
-        CPH_TRY(run_pass(lay, step));
-        GroupLayout pruned = lay;
-        pruned.ntables = 0;
-        for (int t = 0; t < lay.ntables;) {
-            const int g = lay.tab_base[t];
-            int t_end = t;
-            while (t_end < lay.ntables && lay.tab_base[t_end] == g) t_end++;
-            const double whole = saved_bits(lay, t);
-            double halves = 0;
-            for (int k = t + 1; k < t_end; k++) halves += std::max(0.0, saved_bits(lay, k) >= 1.5 ? saved_bits(lay, k) : 0.0);
-            auto keep = [&](int k) {
-                pruned.tab_base[pruned.ntables] = lay.tab_base[k];
-                pruned.tab_first[pruned.ntables] = lay.tab_first[k];
-                pruned.tab_span[pruned.ntables] = lay.tab_span[k];
-                pruned.ntables++;
-            };
-            if (whole >= 1.5 && whole >= halves) keep(t);
-            else
-                for (int k = t + 1; k < t_end; k++)
-                    if (saved_bits(lay, k) >= 1.5) keep(k);
-            t = t_end;
-        }
-        if (pruned.ntables == 0) return {};
-        lay = pruned;
-    }
-    CPH_TRY(run_pass(lay, 1));
-    const int ng = lay.ntables;
-
-    // candidates: bits saved by coding the window through a dictionary instead of position by position
-    struct Cand { int t; int p0; int span; double saved; uint32_t count; };
-    std::vector<Cand> cands;
-    for (int t = 0; t < ng; t++) {
-        const double saved = saved_bits(lay, t);
-        if (saved < 1.0) continue;
-        const int g = lay.tab_base[t];
-        cands.push_back({t, cd.col_start[lay.col[g]] + lay.q0[g] + lay.tab_first[t], lay.tab_span[t], saved, hcount[(size_t)t]});
-    }
-    std::sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.saved > b.saved; });
+// The dictionary codec built from the device sets of the candidate tables (best saving first; a whole window and its
+// halves exclude each other).  *chosen lists the tables that became group heads; none: *trial is not usable.
+static Status groups_build_trial(cph_ctx* ctx, const CodecHost& cd, const uint64_t* slots_dev, std::vector<GroupChoice> cands,
+                                 CodecHost* trial_out, std::vector<GroupChoice>* chosen) {
+    std::sort(cands.begin(), cands.end(), [](const GroupChoice& a, const GroupChoice& b) { return a.saved > b.saved; });
     CodecHost trial = cd;
     trial.unit.assign((size_t)cd.npos, kUnitPos);
     trial.dict_off.assign((size_t)cd.npos, 0);
@@ -468,13 +457,13 @@ Status codec_try_groups(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_
     trial.dict.clear();
     std::vector<uint64_t> table((size_t)kGroupSlots);
     std::vector<uint8_t> taken((size_t)cd.npos, 0);
-    int chosen = 0;
-    for (const Cand& cnd : cands) {
+    chosen->clear();
+    for (const GroupChoice& cnd : cands) {
         if (trial.dict.size() + cnd.count > (size_t)kGroupDictMax) continue;
         bool overlap = false;
         for (int i = 0; i < cnd.span; i++) overlap |= taken[(size_t)(cnd.p0 + i)] != 0;
         if (overlap) continue;   // a whole window and its halves exclude each other
-        CPH_HIP_TRY(hipMemcpyAsync(table.data(), slots.as<uint64_t>() + (size_t)cnd.t * kGroupSlots, kGroupSlots * sizeof(uint64_t),
+        CPH_HIP_TRY(hipMemcpyAsync(table.data(), slots_dev + (size_t)cnd.t * kGroupSlots, kGroupSlots * sizeof(uint64_t),
                                    hipMemcpyDeviceToHost, ctx->stream));
         CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
         std::vector<uint64_t> syms;
@@ -497,17 +486,248 @@ Status codec_try_groups(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_
             for (int s = 0; s < kLutStride; s++) trial.lut[(size_t)(p0 + i) * kLutStride + (size_t)s] = 0;
         }
         trial.dict.insert(trial.dict.end(), syms.begin(), syms.end());
-        chosen++;
+        chosen->push_back(cnd);
     }
-    if (!chosen) return {};
+    if (chosen->empty()) return {};
     CPH_TRY(codec_split_words(&trial));
-    // worth it only if it removes radix passes (8 bits per pass) or a whole word
-    auto passes = [](const CodecHost& c) {
-        int p = 0;
-        for (int w = 0; w < c.nwords; w++) p += (c.word_bits[w] + 7) / 8;
-        return p;
+    *trial_out = std::move(trial);
+    return {};
+}
+
+// radix passes (8 bits each) the sort of a codec's words takes: a dictionary is worth it only if it removes one, or a word
+static int codec_sort_passes(const CodecHost& c) {
+    int p = 0;
+    for (int w = 0; w < c.nwords; w++) p += (c.word_bits[w] + 7) / 8;
+    return p;
+}
+static bool codec_uses_plan_kernel(const CodecHost& c) {   // k_encode_build_plan: single-word codes with groups
+    int units = 0;
+    for (int p = 0; p < c.npos; p++) units += c.unit[(size_t)p] != kUnitAbsorbed;
+    return c.has_groups() && c.nwords == 1 && units <= kPlanMaxUnits;
+}
+static double group_saved_bits(const CodecHost& cd, int p0, int span, uint32_t count) {   // < 0: unusable
+    if (count == 0 || count > (uint32_t)kGroupDictMax) return -1.0;
+    double bits_pos = 0;
+    for (int i = 0; i < span; i++) bits_pos += std::log2((double)cd.radix[(size_t)(p0 + i)]);
+    return bits_pos - std::log2((double)count);
+}
+
+// The exact pass: every row's window of the chosen candidates goes into its device set (pre-filled by the sample).
+static Status run_group_stats(cph_ctx* ctx, const DevCol* cols, int32_t ncols, const CodecHost& cd, uint64_t n,
+                              const std::vector<GroupChoice>& picked, uint64_t* slots, uint32_t* counts) {
+    ColsArg arg{};
+    for (int c = 0; c < ncols; c++) arg.c[c] = cols[c];
+    bool long_values = false;   // any key column with values of more than 24 bytes
+    for (int c = 0; c < cd.ncols; c++) long_values |= cd.col_maxlen[c] > 24;
+    GroupLayout lay{};
+    for (const GroupChoice& c : picked) {
+        if (lay.ntables >= kGroupMaxChosen) return {CPH_ERR_INVALID, "too many dictionary windows"};
+        lay.tab[lay.ntables] = c.tab;
+        lay.set[lay.ntables] = c.t;
+        lay.ntables++;
+    }
+    ProfScope ps(ctx, "k_group_stats", 0);
+    const int threads = ctx->gstats_threads == 256 || ctx->gstats_threads == 1024 ? ctx->gstats_threads : 512;
+    uint64_t nblk = (n + (uint64_t)threads * kGroupRows - 1) / ((uint64_t)threads * kGroupRows);
+    const uint64_t cap = 2048u * 256u / (unsigned)threads;
+    if (nblk > cap) nblk = cap;
+    int cache_bits = 10;                                    // at most 32 KiB of LDS shared by the tables
+    while (cache_bits > 3 && ((size_t)lay.ntables << (cache_bits + 3)) > 32 * 1024) cache_bits--;
+    const size_t lds = (size_t)lay.ntables << (cache_bits + 3);
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3((unsigned)nblk), dim3(threads), lds, ctx->stream, arg, lay, n, cache_bits, slots, counts);
     };
-    if (trial.nwords < cd.nwords || passes(trial) < passes(cd)) cd = std::move(trial);
+    if (long_values) {
+        if (threads == 256) launch(&k_group_stats<true, 256>);
+        else if (threads == 512) launch(&k_group_stats<true, 512>);
+        else launch(&k_group_stats<true, 1024>);
+    } else {
+        if (threads == 256) launch(&k_group_stats<false, 256>);
+        else if (threads == 512) launch(&k_group_stats<false, 512>);
+        else launch(&k_group_stats<false, 1024>);
+    }
+    CPH_HIP_TRY(hipGetLastError());
+    return {};
+}
+
+// After a speculative encode reported a miss: the device sets of the chosen tables now hold every window that occurs
+// (found in the sample or inserted by the encode kernel).  Rebuilds the codec from them; a table that outgrew
+// kGroupDictMax is dropped, and when nothing is left (or worth it) the codec without groups comes back.
+Status codec_groups_complete(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t n, uint32_t missed, GroupSpec* spec, CodecHost* codec) {
+    const size_t nt = spec->counts.bytes() / sizeof(uint32_t);
+    if (missed >= kSpecGiveUp)   // the encode kernel stopped early: rows it never looked at may hold unknown windows too
+        CPH_TRY(run_group_stats(ctx, cols, ncols, spec->plain, n, spec->chosen, spec->slots.as<uint64_t>(), spec->counts.as<uint32_t>()));
+    std::vector<uint32_t> hcount(nt);
+    CPH_HIP_TRY(hipMemcpyAsync(hcount.data(), spec->counts.get(), nt * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const CodecHost& cd = spec->plain;
+    std::vector<GroupChoice> cands;
+    for (const GroupChoice& c : spec->chosen) {
+        const double saved = group_saved_bits(cd, c.p0, c.span, hcount[(size_t)c.t]);
+        if (saved >= 1.0) cands.push_back({c.t, c.p0, c.span, saved, hcount[(size_t)c.t], c.tab});
+    }
+    CodecHost trial;
+    std::vector<GroupChoice> chosen;
+    CPH_TRY(groups_build_trial(ctx, cd, spec->slots.as<uint64_t>(), cands, &trial, &chosen));
+    if (!chosen.empty() && (trial.nwords < cd.nwords || codec_sort_passes(trial) < codec_sort_passes(cd))) *codec = std::move(trial);
+    else *codec = cd;
+    spec->active = false;
+    return {};
+}
+
+Status codec_try_groups(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t n, CodecHost* codec, GroupSpec* spec) {
+    CodecHost& cd = *codec;
+    if (spec) spec->active = false;
+    if (cd.nwords < 2 || n == 0) return {};
+    // candidate windows, in position order
+    std::vector<uint32_t> tabs;
+    for (int c = 0; c < cd.ncols; c++)
+        for (int q0 = 0; q0 + 2 <= cd.col_maxlen[c]; q0++)
+            for (int span = 2; span <= kGroupSpan && q0 + span <= cd.col_maxlen[c]; span++) tabs.push_back(group_tab(c, q0, span));
+    const int nt = (int)tabs.size();
+    if (nt == 0 || nt > kGroupMaxTables) return {};
+    ColsArg arg{};
+    for (int c = 0; c < ncols; c++) arg.c[c] = cols[c];
+
+    // ---- the sample: every candidate window over (about) 2^18 rows ----
+    const uint64_t step = n > (1ull << 19) ? n >> 18 : 1;
+    DevBuf slots, counts, singles, tabs_dev;
+    CPH_TRY(slots.alloc(&ctx->pool, (size_t)nt * kGroupSlots * sizeof(uint64_t)));
+    CPH_TRY(counts.alloc(&ctx->pool, (size_t)nt * sizeof(uint32_t)));
+    CPH_TRY(singles.alloc(&ctx->pool, (size_t)nt * sizeof(uint32_t)));
+    CPH_TRY(tabs_dev.alloc(&ctx->pool, (size_t)nt * sizeof(uint32_t)));
+    void* up = nullptr;
+    CPH_TRY(pinned_upload(ctx, (size_t)nt * sizeof(uint32_t), &up));
+    memcpy(up, tabs.data(), (size_t)nt * sizeof(uint32_t));
+    CPH_HIP_TRY(hipMemcpyAsync(tabs_dev.get(), up, (size_t)nt * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    const uint64_t nsel = (n + step - 1) / step;
+    StageArg st{};
+    st.ncols = cd.ncols;
+    std::vector<DevBuf> stage_bufs((size_t)cd.ncols * 2);
+    for (int c = 0; c < cd.ncols; c++) {
+        st.width[c] = (uint32_t)((cd.col_maxlen[c] + 7) / 8 * 8 + 8);
+        CPH_TRY(stage_bufs[(size_t)2 * c].alloc(&ctx->pool, nsel * st.width[c] + 16));
+        CPH_TRY(stage_bufs[(size_t)2 * c + 1].alloc(&ctx->pool, nsel * sizeof(uint32_t)));
+        st.data[c] = stage_bufs[(size_t)2 * c].as<uint8_t>();
+        st.lens[c] = stage_bufs[(size_t)2 * c + 1].as<uint32_t>();
+    }
+    {
+        ProfScope ps(ctx, "k_group_stage", 0);
+        uint64_t nblk = (nsel + 255) / 256;
+        if (nblk > 4096) nblk = 4096;
+        hipLaunchKernelGGL(k_group_stage, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, arg, st, step, nsel);
+        CPH_HIP_TRY(hipGetLastError());
+    }
+    {
+        ProfScope ps(ctx, "k_group_sample", 0);
+        const size_t lds = (size_t)kGroupSlots * (sizeof(uint64_t) + 1);
+        CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_group_sample), kSampleThreads, lds, nullptr));
+        hipLaunchKernelGGL(k_group_sample, dim3((unsigned)nt), dim3(kSampleThreads), lds, ctx->stream, st, tabs_dev.as<uint32_t>(), nsel,
+                           slots.as<uint64_t>(), counts.as<uint32_t>(), singles.as<uint32_t>());
+        CPH_HIP_TRY(hipGetLastError());
+    }
+    std::vector<uint32_t> hcount((size_t)nt), hsingle((size_t)nt);
+    auto read_counts = [&]() -> Status {
+        CPH_TRY(ensure_pinned_scratch(ctx, 2 * (size_t)nt * sizeof(uint32_t)));
+        uint8_t* h = static_cast<uint8_t*>(ctx->pinned_scratch);
+        CPH_HIP_TRY(hipMemcpyAsync(h, counts.get(), (size_t)nt * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        CPH_HIP_TRY(hipMemcpyAsync(h + (size_t)nt * sizeof(uint32_t), singles.get(), (size_t)nt * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        memcpy(hcount.data(), h, (size_t)nt * sizeof(uint32_t));
+        memcpy(hsingle.data(), h + (size_t)nt * sizeof(uint32_t), (size_t)nt * sizeof(uint32_t));
+        return {};
+    };
+    CPH_TRY(read_counts());
+
+    // ---- the partition with the fewest code bits whose dictionaries fit: dp[p][e] over positions p (from the end)
+    //      and dictionary entries still available e (in units of kQuant) ----
+    constexpr int kQuant = 16, kLevels = kGroupDictMax / kQuant + 1;
+    auto pos_of = [&](uint32_t tab) { return cd.col_start[tab_col(tab)] + tab_q0(tab); };
+    // sampled: the counts come from a sample — a window many of whose values were seen only once is far from saturated
+    // (its true set is much larger than the count says, Good-Turing again) and stays out
+    auto choose = [&](const std::vector<uint8_t>& allowed, bool sampled) {
+        std::vector<std::vector<int>> starts((size_t)cd.npos);   // tables by first position
+        for (int t = 0; t < nt; t++)
+            if (allowed[(size_t)t] && !(sampled && hsingle[(size_t)t] * 8u > hcount[(size_t)t]) &&
+                group_saved_bits(cd, pos_of(tabs[(size_t)t]), tab_span(tabs[(size_t)t]), hcount[(size_t)t]) >= 1.0)
+                starts[(size_t)pos_of(tabs[(size_t)t])].push_back(t);
+        std::vector<double> dp((size_t)(cd.npos + 1) * kLevels, 0.0);
+        std::vector<int> pick((size_t)(cd.npos + 1) * kLevels, -1);
+        for (int p = cd.npos - 1; p >= 0; p--)
+            for (int e = 0; e < kLevels; e++) {
+                double best = dp[(size_t)(p + 1) * kLevels + e] + std::log2((double)cd.radix[(size_t)p]);
+                int bt = -1;
+                for (int t : starts[(size_t)p]) {
+                    const int need = ((int)hcount[(size_t)t] + kQuant - 1) / kQuant;
+                    if (need > e) continue;
+                    const double v = dp[(size_t)(p + tab_span(tabs[(size_t)t])) * kLevels + (e - need)] + std::log2((double)hcount[(size_t)t]);
+                    if (v < best - 1e-9) { best = v; bt = t; }
+                }
+                dp[(size_t)p * kLevels + e] = best;
+                pick[(size_t)p * kLevels + e] = bt;
+            }
+        // What the sort pays for is whole radix passes (8 bits), what the encode kernels pay for is dictionary size (LDS
+        // footprint, probe length): among the partitions that reach the fewest passes, take the one with the fewest entries.
+        const double min_bits = dp[(size_t)kLevels - 1];
+        const double target = 8.0 * std::ceil((min_bits - 1e-6) / 8.0) + 1e-6;
+        int e = kLevels - 1;
+        while (e > 0 && dp[(size_t)(e - 1)] <= target) e--;
+        std::vector<GroupChoice> out;
+        for (int p = 0; p < cd.npos;) {
+            const int t = pick[(size_t)p * kLevels + e];
+            if (t < 0) { p++; continue; }
+            const int sp = tab_span(tabs[(size_t)t]);
+            out.push_back({t, p, sp, group_saved_bits(cd, p, sp, hcount[(size_t)t]), hcount[(size_t)t], tabs[(size_t)t]});
+            e -= ((int)hcount[(size_t)t] + kQuant - 1) / kQuant;
+            p += sp;
+        }
+        return out;
+    };
+    auto better = [&](const CodecHost& trial) { return trial.nwords < cd.nwords || codec_sort_passes(trial) < codec_sort_passes(cd); };
+    std::vector<GroupChoice> picked = choose(std::vector<uint8_t>((size_t)nt, 1), step > 1);
+    auto debug = [&](const char* what) {
+        if (!ctx->codec_debug) return;
+        fprintf(stderr, "codec_try_groups %s (sample step %llu):", what, (unsigned long long)step);
+        for (const GroupChoice& c : picked) fprintf(stderr, " [p%d+%d n=%u once=%u]", c.p0, c.span, hcount[(size_t)c.t], hsingle[(size_t)c.t]);
+        fprintf(stderr, "\n");
+    };
+    debug("sample");
+    if (picked.empty() || (int)picked.size() > kGroupMaxChosen) return {};
+    CodecHost trial;
+    std::vector<GroupChoice> chosen;
+    if (step > 1) {
+        // Large input: the sets so far come from a sample.  No value seen only once in any chosen window: the sample very
+        // likely holds every window there is (Good-Turing: the unseen share of the rows is about singles / sample size), so
+        // the sets can serve as dictionaries right away — the encode kernel completes them should it meet an unknown
+        // window (GroupSpec).  Otherwise: the exact sets of the chosen windows, over all rows.
+        uint32_t rare = 0;
+        for (const GroupChoice& c : picked) rare += hsingle[(size_t)c.t];
+        if (spec && ctx->speculative_groups == 1 ? rare == 0 : (spec && ctx->speculative_groups == 2)) {
+            CPH_TRY(groups_build_trial(ctx, cd, slots.as<uint64_t>(), picked, &trial, &chosen));
+            if (!chosen.empty() && better(trial) && codec_uses_plan_kernel(trial)) {
+                CPH_TRY(spec->miss.alloc(&ctx->pool, sizeof(uint32_t)));
+                CPH_HIP_TRY(hipMemsetAsync(spec->miss.get(), 0, sizeof(uint32_t), ctx->stream));
+                spec->slots = std::move(slots);
+                spec->counts = std::move(counts);
+                spec->chosen = chosen;
+                spec->plain = cd;
+                spec->active = true;
+                cd = std::move(trial);
+                return {};
+            }
+        }
+        CPH_TRY(run_group_stats(ctx, cols, ncols, cd, n, picked, slots.as<uint64_t>(), counts.as<uint32_t>()));
+        CPH_TRY(read_counts());
+        // exact counts now; a window that outgrew the capacity drops out and the rest is partitioned again (among the
+        // windows whose sets are exact: the chosen ones)
+        std::vector<uint8_t> allowed((size_t)nt, 0);
+        for (const GroupChoice& c : picked) allowed[(size_t)c.t] = 1;
+        picked = choose(allowed, false);
+        debug("exact");
+        if (picked.empty()) return {};
+    }
+    CPH_TRY(groups_build_trial(ctx, cd, slots.as<uint64_t>(), picked, &trial, &chosen));
+    if (!chosen.empty() && better(trial)) cd = std::move(trial);
     return {};
 }
 
@@ -715,11 +935,10 @@ struct PlanUnit {
     uint32_t head;              // 1: group head (dictionary), 0: plain position (rank LUT)
     uint32_t off;               // plain: first LUT entry of the position; head: first dictionary entry
     uint32_t hash_off, hash_bits;
-    uint32_t pad_;
+    uint32_t table;             // head, speculative dictionaries: the device set that collects the windows not found
     uint64_t mult;
     uint64_t pad2_;
 };
-constexpr int kPlanMaxUnits = 40;
 // The plan travels as a kernel argument: the unit loop is uniform, so its fields are scalar loads from the
 // kernarg segment instead of LDS traffic + VGPR->SGPR moves.
 struct PlanArg {
@@ -728,11 +947,16 @@ struct PlanArg {
     PlanUnit u[kPlanMaxUnits];
 };
 
-template <class OUT, bool LONGV>
-__global__ __launch_bounds__(kEncodeThreads) void k_encode_build_plan(ColsArg cols, const uint8_t* __restrict__ g_codec, const PlanArg pa,
+// SPEC: the dictionaries come from a sample (GroupSpec): a window that is not found goes into its table's device set
+// (g_slots / g_counts, the sets k_group_stats filled) and raises *g_miss; the row's code is then meaningless and the
+// caller encodes again with the completed dictionaries.
+template <class OUT, bool LONGV, bool SPEC, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_encode_build_plan(ColsArg cols, const uint8_t* __restrict__ g_codec, const PlanArg pa,
                                                                      uint64_t n, OUT* __restrict__ out, uint32_t tile_rows,
                                                                      uint32_t ntiles, uint32_t* __restrict__ counts,
-                                                                     uint32_t digit_mask, uint32_t bins, int codec_bytes) {
+                                                                     uint32_t digit_mask, uint32_t bins, int codec_bytes,
+                                                                     uint64_t* __restrict__ g_slots, uint32_t* __restrict__ g_counts,
+                                                                     uint32_t* __restrict__ g_miss) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const CodecView cv = codec_load_to_lds(g_codec, smem);
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + codec_bytes);   // [bins]: the sort's first-pass histogram of a tile
@@ -741,20 +965,28 @@ __global__ __launch_bounds__(kEncodeThreads) void k_encode_build_plan(ColsArg co
     // a workgroup walks whole SORT tiles (tile_rows keys), like k_encode_build_fast
     const uint32_t per_xcd = (ntiles + 7) / 8, xcd = blockIdx.x & 7u;   // XCD-contiguous tile ranges (k_encode_build_fast)
     const uint32_t t_end = (xcd + 1) * per_xcd < ntiles ? (xcd + 1) * per_xcd : ntiles;
+    __shared__ uint32_t s_giveup;
     for (uint32_t tile = xcd * per_xcd + (blockIdx.x >> 3); tile < t_end; tile += gridDim.x >> 3) {
+      if constexpr (SPEC) {   // too many rows with unknown windows: the sample was no good, stop (the caller runs the exact pass)
+          if (threadIdx.x == 0) s_giveup = *(volatile uint32_t*)g_miss >= kSpecGiveUp;
+          __syncthreads();
+          if (s_giveup) return;
+          __syncthreads();
+      }
       if (counts) {
-          for (uint32_t d = threadIdx.x; d < bins; d += kEncodeThreads) s_hist[d] = 0;
+          for (uint32_t d = threadIdx.x; d < bins; d += THREADS) s_hist[d] = 0;
           __syncthreads();
       }
       const uint64_t tile_end = (uint64_t)(tile + 1) * tile_rows < n ? (uint64_t)(tile + 1) * tile_rows : n;
-      for (uint64_t base = (uint64_t)tile * tile_rows; base < tile_end; base += (uint64_t)kEncodeThreads * kEncodeRows) {
+      for (uint64_t base = (uint64_t)tile * tile_rows; base < tile_end; base += (uint64_t)THREADS * kEncodeRows) {
         uint64_t acc[kEncodeRows];
         ValueHeadT<LONGV> v[kEncodeRows];
         bool live[kEncodeRows];
+        uint32_t missed = 0;   // SPEC: rows of this lane with an unknown window
 #pragma unroll
         for (int k = 0; k < kEncodeRows; k++) {
             acc[k] = 0;
-            live[k] = base + (uint64_t)k * kEncodeThreads + threadIdx.x < tile_end;
+            live[k] = base + (uint64_t)k * THREADS + threadIdx.x < tile_end;
         }
         uint32_t cur_col = 0xFFFFFFFFu;
         for (int u = 0; u < nunits; u++) {
@@ -763,7 +995,7 @@ __global__ __launch_bounds__(kEncodeThreads) void k_encode_build_plan(ColsArg co
                 cur_col = col;
 #pragma unroll
                 for (int k = 0; k < kEncodeRows; k++) {   // rows past the end re-read the last row (never stored)
-                    const uint64_t i = base + (uint64_t)k * kEncodeThreads + threadIdx.x;
+                    const uint64_t i = base + (uint64_t)k * THREADS + threadIdx.x;
                     v[k].span(cols.c[col], i < n ? i : n - 1);
                 }
 #pragma unroll
@@ -789,6 +1021,14 @@ __global__ __launch_bounds__(kEncodeThreads) void k_encode_build_plan(ColsArg co
                             sl = (sl + 1) & mask;
                             e = ht[sl];
                         }
+                        if constexpr (SPEC) {
+                            if (e == 0) {   // not in the sample's dictionary
+                                const uint32_t t = plan[u].table;
+                                if (g_counts[t] <= (uint32_t)kGroupDictMax)
+                                    group_insert(g_slots + (uint64_t)t * kGroupSlots, &g_counts[t], raw);
+                                missed |= 1u << k;
+                            }
+                        }
                         acc[k] += (uint64_t)(e ? e - 1 : 0) * mult;
                     }
                 } else {
@@ -810,23 +1050,27 @@ __global__ __launch_bounds__(kEncodeThreads) void k_encode_build_plan(ColsArg co
                 }
             }
         }
+        if constexpr (SPEC) {
+            const uint32_t m = wave_sum((uint32_t)__popc(missed));
+            if (m && lane_id() == 0) atomicAdd(g_miss, m);
+        }
 #pragma unroll
         for (int k = 0; k < kEncodeRows; k++)
             if (live[k]) {
-                out[base + (uint64_t)k * kEncodeThreads + threadIdx.x] = (OUT)acc[k];
+                out[base + (uint64_t)k * THREADS + threadIdx.x] = (OUT)acc[k];
                 if (counts) atomicAdd(&s_hist[(uint32_t)acc[k] & digit_mask], 1u);
             }
       }
       if (counts) {
           __syncthreads();
-          for (uint32_t d = threadIdx.x; d < bins; d += kEncodeThreads) counts[(uint64_t)d * ntiles + tile] = s_hist[d];
+          for (uint32_t d = threadIdx.x; d < bins; d += THREADS) counts[(uint64_t)d * ntiles + tile] = s_hist[d];
           __syncthreads();
       }
     }
 }
 
 Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec_dev, const DevCol* cols, uint64_t n,
-                          void* out_codes, const EncodeHist* hist) {
+                          void* out_codes, const EncodeHist* hist, const GroupSpec* spec) {
     if (n == 0) return {};
     const int lutw_bits = codec_premultiplied_bits(cd);
     if (cd.ncols == 1 && lutw_bits != 0 && !cols[0].segmented()) {
@@ -907,6 +1151,12 @@ Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec
                     u.hash_bits = (uint32_t)bits_needed((uint64_t)cd.dict_len[(size_t)p] * 2);
                     u.hash_off = (uint32_t)hbase;
                     hbase += (size_t)1 << u.hash_bits;
+                    if (spec && spec->active) {
+                        bool found = false;
+                        for (const GroupChoice& gc : spec->chosen)
+                            if (gc.p0 == p) { u.table = (uint32_t)gc.t; found = true; }
+                        if (!found) return {CPH_ERR_INVALID, "speculative dictionaries: a group head without its table"};
+                    }
                 } else {
                     u.span = 1;
                     u.off = (uint32_t)(p * kLutStride);
@@ -921,16 +1171,30 @@ Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec
         ProfScope ps(ctx, "k_encode_build", 0);
         bool long_values = false;
         for (int c = 0; c < cd.ncols; c++) long_values |= cd.col_maxlen[c] > 24;
+        const bool speculative = spec && spec->active;
+        // workgroup size: 256 measured best at 1e8 rows (1.56 ms; 512: 1.74, 1024: 1.97 — tools/microbench/config3.py)
+        const int threads = ctx->plan_threads == 512 || ctx->plan_threads == 1024 ? ctx->plan_threads : 256;
         auto launch = [&](auto kernel, auto* out) -> Status {
-            CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(kernel), kEncodeThreads, lds, nullptr));
-            hipLaunchKernelGGL(kernel, dim3((unsigned)nblk), dim3(kEncodeThreads), lds, ctx->stream, arg, codec_dev.as<uint8_t>(), pa, n, out,
-                               tile_rows, ntiles, want_hist ? hist->counts : nullptr, hmask, hbins, (int)codec_bytes);
+            CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(kernel), threads, lds, nullptr));
+            hipLaunchKernelGGL(kernel, dim3((unsigned)nblk), dim3(threads), lds, ctx->stream, arg, codec_dev.as<uint8_t>(), pa, n, out,
+                               tile_rows, ntiles, want_hist ? hist->counts : nullptr, hmask, hbins, (int)codec_bytes,
+                               speculative ? spec->slots.as<uint64_t>() : nullptr, speculative ? spec->counts.as<uint32_t>() : nullptr,
+                               speculative ? spec->miss.as<uint32_t>() : nullptr);
             return {};
         };
-        if (cd.key32 && long_values) CPH_TRY(launch(&k_encode_build_plan<uint32_t, true>, reinterpret_cast<uint32_t*>(out_codes)));
-        else if (cd.key32) CPH_TRY(launch(&k_encode_build_plan<uint32_t, false>, reinterpret_cast<uint32_t*>(out_codes)));
-        else if (long_values) CPH_TRY(launch(&k_encode_build_plan<uint64_t, true>, reinterpret_cast<uint64_t*>(out_codes)));
-        else CPH_TRY(launch(&k_encode_build_plan<uint64_t, false>, reinterpret_cast<uint64_t*>(out_codes)));
+        auto pick_threads = [&](auto* out, auto longv, auto specv) -> Status {
+            using O = std::remove_pointer_t<decltype(out)>;
+            constexpr bool L = decltype(longv)::value, S = decltype(specv)::value;
+            if (threads == 256) return launch(&k_encode_build_plan<O, L, S, 256>, out);
+            if (threads == 512) return launch(&k_encode_build_plan<O, L, S, 512>, out);
+            return launch(&k_encode_build_plan<O, L, S, 1024>, out);
+        };
+        auto pick = [&](auto* out) -> Status {
+            if (speculative) return long_values ? pick_threads(out, std::true_type{}, std::true_type{}) : pick_threads(out, std::false_type{}, std::true_type{});
+            return long_values ? pick_threads(out, std::true_type{}, std::false_type{}) : pick_threads(out, std::false_type{}, std::false_type{});
+        };
+        if (cd.key32) CPH_TRY(pick(reinterpret_cast<uint32_t*>(out_codes)));
+        else CPH_TRY(pick(reinterpret_cast<uint64_t*>(out_codes)));
         CPH_HIP_TRY(hipGetLastError());
         if (hist) const_cast<EncodeHist*>(hist)->done = want_hist;
         return {};

@@ -125,3 +125,54 @@ def test_config3_properties_1e7(ctx):
         lo, hi = g.find(keys.value(r))
         nxt = starts[np.searchsorted(starts, s) + 1] if s != starts[-1] else n
         assert (lo, hi) == (int(s), int(nxt))
+
+
+def _launches(ctx):
+    return {k: v["launches"] for k, v in ctx.profile_read(reset=True).items()}
+
+
+def test_speculative_dictionaries_hit_and_miss(ctx):
+    """Large inputs: the window sets come from a sample of the rows (every `step`-th).  Exact mode runs one pass over all
+    rows for the chosen windows (k_group_stats); speculative mode uses the sample's sets as dictionaries and lets the
+    encode kernel complete them when it meets a window the sample did not hold (GroupSpec, keycodec.hip) — then the
+    encode runs twice.  Every mode must give the oracle's permutation, on data whose rare windows sit only in rows
+    the sample never reads."""
+    n = (1 << 21) + 150_001                       # step = n >> 18 = 8: the sample reads rows 0, 8, 16, ...
+    base = dg.varkeys(n, 1000)
+    vals = base.values()
+    odd = list(range(1, n, 104_730))              # odd rows only: never sampled
+    miss_vals = list(vals)
+    for i, r in enumerate(odd):
+        miss_vals[r] = b"Qwertz/Xavier#%d" % (i % 7)
+    miss_col = StrCol.from_values(miss_vals)
+    probe = dg.varkeys(20_000, 1500, seed=dg.SEED + 5)
+    try:
+        for col, has_unseen in ((base, False), (miss_col, True)):
+            o = orc.OracleIndex([col])
+            bits = {}
+            for mode in (2, 0, 1):                # always speculative / exact / decided by the sample's singletons
+                ctx.set_option("speculative_groups", mode)
+                ctx.profile(True)
+                ctx.profile_read(reset=True)
+                g = DeviceIndex(ctx, [col])
+                runs = _launches(ctx)
+                ctx.profile(False)
+                info = g.info()
+                assert info["dict_entries"] > 0 and info["code_words"] == 1, info
+                bits[mode] = info["code_bits"]
+                assert runs["k_group_sample"] == 1, runs
+                if mode == 2:
+                    assert "k_group_stats" not in runs, runs
+                    if has_unseen:
+                        assert runs["k_encode_build"] == 2, runs      # the first encode met unknown windows
+                if mode == 0:
+                    assert runs["k_group_stats"] == 1 and runs["k_encode_build"] == 1, runs
+                np.testing.assert_array_equal(g.perm(), o.perm)
+                assert g.first_dup == o.first_dup()
+                assert_join_equal(g.probe([probe]), o.join([probe]))
+                for v in (col.value(1), col.value(odd[3]), b"Qwertz/Xavier#3", b"Nobody/None#0"):
+                    assert same_bounds(g.find(v), o.find(v))
+                g.close()
+            assert bits[2] <= bits[0] + 1, bits
+    finally:
+        ctx.set_option("speculative_groups", 1)
