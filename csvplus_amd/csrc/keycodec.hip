@@ -394,9 +394,10 @@ struct GroupLayout {
     int32_t set[kGroupMaxChosen];
 };
 
-// Every row's window goes into its device set (which k_group_sample has pre-filled).  Each workgroup keeps a
-// direct-mapped cache of the symbols it has already seen per table in LDS (cache_bits: log2 entries per table;
-// dynamic LDS = ntables << (cache_bits + 3)): almost every row repeats a known symbol and never leaves the CU.
+// Every row's window goes into its device set (which k_group_sample has pre-filled).  Each workgroup keeps the
+// symbols it has already met per table in an LDS hash set (cache_bits: log2 slots per table; dynamic LDS =
+// ntables << (cache_bits + 3)): almost every row repeats a known symbol and never leaves the CU.  (A direct-mapped
+// cache thrashed: two frequent symbols sharing an entry sent every one of their rows to the device set.)
 template <bool LONGV, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_group_stats(ColsArg cols, GroupLayout lay, uint64_t n, int cache_bits,
                                                     uint64_t* __restrict__ slots, uint32_t* __restrict__ counts) {
@@ -434,12 +435,19 @@ __global__ __launch_bounds__(THREADS) void k_group_stats(ColsArg cols, GroupLayo
                 if (!live[k]) continue;
                 const uint64_t left = v[k].len > (uint64_t)q0 ? v[k].len - (uint64_t)q0 : 0;
                 const uint64_t sym = group_raw(v[k].window(cols.c[cur_col], q0), left < (uint64_t)span ? left : (uint64_t)span);
+                // the workgroup's own set of the symbols it has met (open addressing in LDS, insert only)
                 const uint64_t hs = sym * 0x9E3779B97F4A7C15ull;
-                CPH_LDS uint64_t* mine = seen + ((uint32_t)t << cache_bits) + ((uint32_t)(hs >> 40) & (cache_n - 1));
-                if (*mine == sym) continue;                            // seen by this workgroup: already in the set
+                CPH_LDS uint64_t* mine = seen + ((uint32_t)t << cache_bits);
+                uint32_t h = (uint32_t)(hs >> 40) & (cache_n - 1);
+                uint64_t cur = mine[h];
+                for (int pr = 0; pr < 6 && cur != sym && cur != kGroupEmpty; pr++) {
+                    h = (h + 1) & (cache_n - 1);
+                    cur = mine[h];
+                }
+                if (cur == sym) continue;                              // met before: already in the device set
                 if (counts[set] > (uint32_t)kGroupDictMax) continue;   // given up already (a stale read only costs work)
                 group_insert(slots + (uint64_t)set * kGroupSlots, &counts[set], sym);
-                *mine = sym;   // racing writers store whole symbols they inserted: any survivor is a valid entry
+                if (cur == kGroupEmpty) atomicCAS((unsigned long long*)&mine[h], (unsigned long long)kGroupEmpty, (unsigned long long)sym);
             }
         }
     }
@@ -531,8 +539,11 @@ static Status run_group_stats(cph_ctx* ctx, const DevCol* cols, int32_t ncols, c
     uint64_t nblk = (n + (uint64_t)threads * kGroupRows - 1) / ((uint64_t)threads * kGroupRows);
     const uint64_t cap = 2048u * 256u / (unsigned)threads;
     if (nblk > cap) nblk = cap;
-    int cache_bits = 10;                                    // at most 32 KiB of LDS shared by the tables
-    while (cache_bits > 3 && ((size_t)lay.ntables << (cache_bits + 3)) > 32 * 1024) cache_bits--;
+    uint32_t most = 1;
+    for (const GroupChoice& c : picked) most = std::max(most, c.count);
+    int cache_bits = 6;                                     // >= 4 slots per expected symbol, at most 64 KiB of LDS for all tables
+    while (cache_bits < 13 && (1u << cache_bits) < 4u * most) cache_bits++;
+    while (cache_bits > 3 && ((size_t)lay.ntables << (cache_bits + 3)) > 64 * 1024) cache_bits--;
     const size_t lds = (size_t)lay.ntables << (cache_bits + 3);
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3((unsigned)nblk), dim3(threads), lds, ctx->stream, arg, lay, n, cache_bits, slots, counts);
