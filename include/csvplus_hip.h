@@ -134,6 +134,11 @@ CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
  *   "sort_threads"  256 / 512: workgroup size of the radix sort (0 = automatic)
  *   "sort_rbits"    8 / 9: digit width of the radix sort (0 = automatic)
  *   "sort_xcd_tiles" 0 / 1: the scatter kernel gives every XCD a contiguous range of tiles (default 1)
+ *   "speculative_groups"  dictionary windows of long keys on large inputs: 0 = always the exact pass over all rows,
+ *                   1 = dictionaries straight from the row sample when it holds no value seen only once (default),
+ *                   2 = always from the sample (the encode kernel completes them; a test hook)
+ *   "plan_threads" / "gstats_threads"  workgroup sizes of the dictionary encode / window statistics kernels (0 = default)
+ *   "codec_debug"   1: the window choice of every index build is printed to stderr
  *   "pool_reserve_mb"  reserves ONE device slab of that many MiB now; later requests are carved out of it first
  *                   (first fit, coalesced on release) and only fall back to hipMalloc when it cannot serve them —
  *                   a one-shot caller pays its device allocations here, not inside its first call
