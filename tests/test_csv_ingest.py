@@ -382,3 +382,73 @@ def test_reference_reader_and_writer_tests(ctx):
         with pytest.raises(KeyError) as e:
             ingest.read_csv(ctx, text, expect_header={"name": 1, "surname": pos})
         assert f'misplaced column "surname": expected at pos. {pos}, but found at pos. 2' in str(e.value)
+
+
+def _gen_unquoted(rng, nrec, nf, crlf_prob, blank_prob, trailing_nl, alphabet=b"abc xyz0123456789#\t;"):
+    """Text without any quote: `nrec` records of `nf` fields (empty fields included), line ends "\\n" or "\\r\\n",
+    blank lines ("\\n", "\\r\\n") sprinkled in, stray '\\r' inside fields."""
+    al = np.frombuffer(alphabet, dtype=np.uint8)
+    out = bytearray()
+    for r in range(nrec):
+        while rng.random() < blank_prob:
+            out += b"\r\n" if rng.random() < 0.5 else b"\n"
+        fields = []
+        for f in range(nf):
+            ln = int(rng.integers(0, 9)) if rng.random() < 0.9 else int(rng.integers(20, 70))
+            v = al[rng.integers(0, len(al), ln)].tobytes()
+            if rng.random() < 0.03:
+                v += b"\r"                      # a '\r' that is data unless it ends the line before "\n"
+            fields.append(v)
+        if nf == 1 and fields[0] in (b"", b"\r"):
+            fields[0] = b"q"                    # an empty single-field line would be a blank line
+        out += b",".join(fields)
+        last = r == nrec - 1
+        if not last or trailing_nl:
+            out += b"\r\n" if rng.random() < crlf_prob else b"\n"
+    return bytes(out)
+
+
+@pytest.mark.gpu
+def test_gpu_unquoted_texts_match_oracle(ctx):
+    """Texts without quotes, the bulk of real CSV: line-end styles, blank lines, a missing final newline, a final lone
+    '\r', stray '\r' inside fields, empty fields, records crossing the scan tiles, skipped header records, column subsets."""
+    from csvplus_amd import ingest
+    from csvplus_amd import _native as N
+    rng = np.random.default_rng(77)
+    for it in range(70):
+        nf = int(rng.integers(1, 7))
+        nrec = int(rng.integers(1, 60)) if it % 7 else int(rng.integers(3000, 9000))     # the large ones span several tiles
+        text = _gen_unquoted(rng, nrec, nf, crlf_prob=[0.0, 1.0, 0.4][it % 3], blank_prob=0.05 if it % 2 else 0.0,
+                             trailing_nl=bool(it % 5))
+        if it % 11 == 0:
+            text += b"\r"                                                                  # dropped, or a lone-'\r' last line
+        want_cols = sorted(rng.choice(nf, size=int(rng.integers(1, nf + 1)), replace=False).tolist())
+        skip = int(rng.integers(0, 3))
+        fpr = [0, -1, nf][it % 3]
+        ocols, oek, oer = orc.csv_parse(text, want_cols, fields_per_record=fpr, skip_records=skip)
+        t = ingest.csv_parse(ctx, text, want_cols, fields_per_record=fpr, skip_records=skip, out_mem=N.CPH_MEM_HOST)
+        got = [[t.columns[c].value(r) for c in range(len(want_cols))] for r in range(t.nrecords)]
+        want = [[ocols[c].value(r) for c in range(len(want_cols))] for r in range(ocols[0].nrows)]
+        assert (got, t.error_kind) == (want, oek), (it, nf, want_cols, skip, fpr, text[:200])
+
+
+@pytest.mark.gpu
+def test_gpu_small_mixed_cases_match_oracle(ctx):
+    """A quoted field among plain records, comment lines, ragged records, a line longer than a scan tile, a wanted field
+    beyond the records, a field-count error."""
+    from csvplus_amd import ingest
+    from csvplus_amd import _native as N
+    cases = [
+        (b"a,b\nc,\"d\"\ne,f\n", {}, [0, 1]),
+        (b"a,b\n#x,y\nc,d\n", {"comment": b"#"}, [0, 1]),
+        (b"a,b\nc\nd,e,f\n", {"fields_per_record": -1}, [0, 1, 2]),
+        (b"a,b\n" + b"x" * 40_000 + b",y\nc,d\n", {}, [0, 1]),
+        (b"a,b\nc,d\n", {"fields_per_record": -1}, [0, 3]),
+        (b"a,b\nc,d,e\n", {}, [0, 1]),                                  # ErrFieldCount at record 1
+    ]
+    for text, kw, cols in cases:
+        ocols, oek, oer = orc.csv_parse(text, cols, **kw)
+        t = ingest.csv_parse(ctx, text, cols, out_mem=N.CPH_MEM_HOST, **kw)
+        got = [[t.columns[c].value(r) for c in range(len(cols))] for r in range(t.nrecords)]
+        assert got == [[ocols[c].value(r) for c in range(len(cols))] for r in range(ocols[0].nrows)]
+        assert (t.error_kind, t.error_record if t.error_kind else 0) == (oek, oer if oek else 0)

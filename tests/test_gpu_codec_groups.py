@@ -176,3 +176,38 @@ def test_speculative_dictionaries_hit_and_miss(ctx):
             assert bits[2] <= bits[0] + 1, bits
     finally:
         ctx.set_option("speculative_groups", 1)
+
+
+@pytest.mark.parametrize("seed", [51, 52, 53])
+def test_sampled_window_choice_on_multicolumn_long_keys(ctx, seed):
+    """Above 2^19 rows the candidate windows are judged on a SAMPLE of the rows (k_group_stage / k_group_sample) and only the
+    chosen ones are completed over all rows (k_group_stats).  Random 2-3 column keys with low-cardinality fields of up to
+    40 bytes (values longer than 24 bytes take the long-value code paths), rare values included: order, first duplicate,
+    joins with absent keys and prefix joins must match the oracle."""
+    rng = np.random.default_rng(seed)
+    n = (1 << 19) + 40_000 + seed
+    ncols = 2 + seed % 2
+    cols, probes = [], []
+    for c in range(ncols):
+        lo, hi = [(3, 12), (20, 40), (0, 9)][c]
+        pool = random_keys(rng, 40 + 30 * c, lo, hi, alphabet=np.frombuffer(b"abcdefgh/#0123456789", np.uint8))
+        rare = random_keys(rng, 25, lo, hi, alphabet=np.frombuffer(b"xyz", np.uint8))     # a handful of rows each
+        pick = rng.integers(0, len(pool), n)
+        vals = [pool[i] for i in pick]
+        for j, r in enumerate(rng.integers(0, n, 60)):
+            vals[int(r)] = rare[j % len(rare)]
+        cols.append(StrCol.from_values(vals))
+        pv = [vals[int(i)] for i in rng.integers(0, n, 3000)] + random_keys(rng, 300, lo, hi, alphabet=np.frombuffer(b"abcxyz", np.uint8))
+        probes.append(StrCol.from_values(pv))
+    g = DeviceIndex(ctx, cols)
+    o = orc.OracleIndex(cols)
+    info = g.info()
+    np.testing.assert_array_equal(g.perm(), o.perm)
+    assert g.first_dup == o.first_dup()
+    assert_join_equal(g.probe(probes), o.join(probes))
+    assert_join_equal(g.probe(probes[:1]), o.join(probes[:1]))
+    for r in (0, 12345, n - 1):
+        vs = [c.value(r) for c in cols]
+        assert g.find(*vs) == o.find(*vs) and g.find(vs[0]) == o.find(vs[0])
+    assert info["code_words"] >= 1
+    g.close()
