@@ -677,6 +677,7 @@ CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value
     if (k == "chain_debug") ctx->chain_debug = (int)value;
     else if (k == "sort_threads") ctx->sort_threads = (int)value;
     else if (k == "sort_rbits") ctx->sort_rbits = (int)value;
+    else if (k == "sort_digit_stream") ctx->sort_digit_stream = value != 0;
     else if (k == "sort_xcd_tiles") ctx->sort_xcd_tiles = value != 0;
     else if (k == "codec_debug") ctx->codec_debug = value != 0;
     else if (k == "plan_threads") ctx->plan_threads = (int)value;

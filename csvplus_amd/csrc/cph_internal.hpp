@@ -227,6 +227,7 @@ struct cph_ctx {
     int cus = 0;                   // compute units of `device` (0: not queried yet)
     int chain_debug = 0;           // attribution switches of the chained-join kernel (cph_ctx_set_option)
     int sort_threads = 0, sort_rbits = 0;   // radix-sort tuning overrides (0: automatic)
+    int sort_digit_stream = 1;     // scatter writes the next pass's digits as a byte stream for its histogram (radix_sort.hip)
     int sort_xcd_tiles = 1;        // scatter: contiguous tile ranges per XCD (radix_sort.hip)
     int codec_debug = 0;           // prints the window choice of codec_try_groups to stderr
     int plan_threads = 0, gstats_threads = 0;   // tuning: workgroup sizes of k_encode_build_plan / k_group_stats (0: default)

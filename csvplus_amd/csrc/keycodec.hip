@@ -463,20 +463,35 @@ static Status groups_build_trial(cph_ctx* ctx, const CodecHost& cd, const uint64
     trial.dict_off.assign((size_t)cd.npos, 0);
     trial.dict_len.assign((size_t)cd.npos, 0);
     trial.dict.clear();
-    std::vector<uint64_t> table((size_t)kGroupSlots);
     std::vector<uint8_t> taken((size_t)cd.npos, 0);
     chosen->clear();
+    // which candidates make it (capacity, overlap) is decided on the counts alone: fetch all their sets with ONE synchronisation
+    std::vector<GroupChoice> take;
+    size_t entries = 0;
     for (const GroupChoice& cnd : cands) {
-        if (trial.dict.size() + cnd.count > (size_t)kGroupDictMax) continue;
+        if (entries + cnd.count > (size_t)kGroupDictMax) continue;
         bool overlap = false;
         for (int i = 0; i < cnd.span; i++) overlap |= taken[(size_t)(cnd.p0 + i)] != 0;
         if (overlap) continue;   // a whole window and its halves exclude each other
-        CPH_HIP_TRY(hipMemcpyAsync(table.data(), slots_dev + (size_t)cnd.t * kGroupSlots, kGroupSlots * sizeof(uint64_t),
-                                   hipMemcpyDeviceToHost, ctx->stream));
-        CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < cnd.span; i++) taken[(size_t)(cnd.p0 + i)] = 1;
+        entries += cnd.count;
+        take.push_back(cnd);
+    }
+    if (take.empty()) return {};
+    CPH_TRY(ensure_pinned_scratch(ctx, take.size() * (size_t)kGroupSlots * sizeof(uint64_t)));
+    const uint64_t* tables = static_cast<const uint64_t*>(ctx->pinned_scratch);
+    for (size_t k = 0; k < take.size(); k++)
+        CPH_HIP_TRY(hipMemcpyAsync(static_cast<uint64_t*>(ctx->pinned_scratch) + k * (size_t)kGroupSlots,
+                                   slots_dev + (size_t)take[k].t * kGroupSlots, kGroupSlots * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                   ctx->stream));
+    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (size_t k = 0; k < take.size(); k++) {
+        const GroupChoice& cnd = take[k];
+        const uint64_t* table_b = tables + k * (size_t)kGroupSlots;
+        const uint64_t* table_e = table_b + kGroupSlots;
         std::vector<uint64_t> syms;
-        for (uint64_t v : table)
-            if (v != kGroupEmpty) syms.push_back(v);
+        for (const uint64_t* v = table_b; v != table_e; v++)
+            if (*v != kGroupEmpty) syms.push_back(*v);
         if (syms.size() != cnd.count) return {CPH_ERR_HIP, "group dictionary: entry count mismatch"};
         const int span = cnd.span;   // rank order = order of the position tuples, not of the raw keys
         std::sort(syms.begin(), syms.end(), [span](uint64_t a, uint64_t b) { return group_order_key(a, span) < group_order_key(b, span); });
@@ -486,11 +501,9 @@ static Status groups_build_trial(cph_ctx* ctx, const CodecHost& cd, const uint64
         trial.dict_len[(size_t)p0] = (int32_t)syms.size();
         trial.radix[(size_t)p0] = (uint16_t)syms.size();
         for (int s = 0; s < kLutStride; s++) trial.lut[(size_t)p0 * kLutStride + (size_t)s] = kLutInvalid;   // never consulted
-        taken[(size_t)p0] = 1;
         for (int i = 1; i < cnd.span; i++) {
             trial.unit[(size_t)(p0 + i)] = kUnitAbsorbed;
             trial.radix[(size_t)(p0 + i)] = 1;
-            taken[(size_t)(p0 + i)] = 1;
             for (int s = 0; s < kLutStride; s++) trial.lut[(size_t)(p0 + i) * kLutStride + (size_t)s] = 0;
         }
         trial.dict.insert(trial.dict.end(), syms.begin(), syms.end());

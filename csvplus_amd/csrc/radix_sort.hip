@@ -61,6 +61,40 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const K* __restrict
     }
 }
 
+// The same histogram from the DIGIT STREAM the previous pass's scatter left behind (one byte per key, in this pass's
+// input order): 1 byte read per key instead of the 4- or 8-byte key.
+template <int kSortThreads>
+__global__ __launch_bounds__(kSortThreads) void k_radix_hist_bytes(const uint8_t* __restrict__ digits, uint64_t n,
+                                                                  uint32_t* __restrict__ counts, uint32_t ntiles, uint32_t tiles_per_xcd) {
+    constexpr int BINS = 256;
+    constexpr int kSortWaves = kSortThreads / kWave;
+    constexpr int kSortTile = kSortThreads * kSortItems;
+    __shared__ uint32_t s_hist[kSortWaves][BINS];
+    const uint32_t tile = tiles_per_xcd ? (blockIdx.x & 7u) * tiles_per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+    if (tile >= ntiles) return;
+    for (int i = threadIdx.x; i < kSortWaves * BINS; i += kSortThreads) (&s_hist[0][0])[i] = 0;
+    __syncthreads();
+    const uint64_t tile0 = (uint64_t)tile * kSortTile;   // a multiple of 16; `digits` is 16-byte aligned
+    const int w = wave_id();
+    const uint64_t first = tile0 + (uint64_t)threadIdx.x * kSortItems;   // kSortItems == 16 bytes per thread
+    static_assert(kSortItems == 16, "one 16-byte load per thread");
+    if (first + kSortItems <= n) {
+        const uint4 v = *reinterpret_cast<const uint4*>(digits + first);
+        const uint32_t q[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 16; k++) atomicAdd(&s_hist[w][(q[k >> 2] >> (8 * (k & 3))) & 0xFFu], 1u);
+    } else {
+        for (uint64_t i = first; i < n && i < first + kSortItems; i++) atomicAdd(&s_hist[w][digits[i]], 1u);
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < BINS; d += kSortThreads) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int ww = 0; ww < kSortWaves; ww++) c += s_hist[ww][d];
+        counts[(uint64_t)d * ntiles + tile] = c;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // scatter
 // ---------------------------------------------------------------------------------------------
@@ -80,7 +114,8 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const K* __restr
                                                                K* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                                uint64_t n, int shift, uint32_t digit_mask,
                                                                const uint32_t* __restrict__ bases, uint32_t ntiles,
-                                                               uint32_t tiles_per_xcd) {
+                                                               uint32_t tiles_per_xcd, uint8_t* __restrict__ next_digits,
+                                                               int next_shift, uint32_t next_mask) {
     constexpr int BINS = 1 << RBITS;
     constexpr int kSortWaves = kSortThreads / kWave;
     constexpr int kSortTile = kSortThreads * kSortItems;
@@ -193,6 +228,8 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const K* __restr
             const uint32_t g = i + s.gdelta[d];
             keys_out[g] = kk;
             vals_out[g] = s.vals[i];
+            // the next pass's digit of every key, in the next pass's input order: its histogram reads 1 byte per key
+            if (next_digits) next_digits[g] = (uint8_t)((uint32_t)(kk >> next_shift) & next_mask);
         }
     }
 }
@@ -351,25 +388,33 @@ Status fill_iota_u32(cph_ctx* ctx, uint32_t* dst, uint64_t n) {
 // ---------------------------------------------------------------------------------------------
 template <class K, int RBITS, int THREADS>
 static Status radix_pass(cph_ctx* ctx, const K* kin, const uint32_t* vin, K* kout, uint32_t* vout, uint64_t n, int shift,
-                         int nb, uint32_t* counts, uint32_t ntiles, bool hist_done) {
+                         int nb, uint32_t* counts, uint32_t ntiles, bool hist_done, const uint8_t* digits_in, uint8_t* digits_out,
+                         int next_shift, int next_nb) {
     constexpr int BINS = 1 << RBITS;
     const uint32_t mask = (1u << nb) - 1u;
     const size_t smem = sizeof(ScatterSmem<K, RBITS, THREADS>);
     CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_radix_scatter<K, RBITS, THREADS>), THREADS, smem, nullptr));
     if (!hist_done) {
-        ProfScope ps(ctx, sizeof(K) == 4 ? "k_radix_hist_u32" : "k_radix_hist_u64", (double)n * sizeof(K));
         const uint32_t hper = ctx->sort_xcd_tiles && ntiles >= 64 ? (ntiles + 7) / 8 : 0;
-        hipLaunchKernelGGL((k_radix_hist<K, RBITS, THREADS>), dim3(hper ? hper * 8 : ntiles), dim3(THREADS), 0, ctx->stream, kin, n,
-                           shift, mask, counts, ntiles, hper);
+        if (digits_in && RBITS == 8) {
+            ProfScope ps(ctx, sizeof(K) == 4 ? "k_radix_hist_u32" : "k_radix_hist_u64", (double)n);
+            hipLaunchKernelGGL((k_radix_hist_bytes<THREADS>), dim3(hper ? hper * 8 : ntiles), dim3(THREADS), 0, ctx->stream, digits_in, n,
+                               counts, ntiles, hper);
+        } else {
+            ProfScope ps(ctx, sizeof(K) == 4 ? "k_radix_hist_u32" : "k_radix_hist_u64", (double)n * sizeof(K));
+            hipLaunchKernelGGL((k_radix_hist<K, RBITS, THREADS>), dim3(hper ? hper * 8 : ntiles), dim3(THREADS), 0, ctx->stream, kin, n,
+                               shift, mask, counts, ntiles, hper);
+        }
         CPH_HIP_TRY(hipGetLastError());
     }
     CPH_TRY(exclusive_scan_u32(ctx, counts, (uint64_t)BINS * ntiles));
     {
         ProfScope ps(ctx, sizeof(K) == 4 ? "k_radix_scatter_u32" : "k_radix_scatter_u64",
-                     (double)n * (2.0 * sizeof(K) + (vin ? 8.0 : 4.0)));
+                     (double)n * (2.0 * sizeof(K) + (vin ? 8.0 : 4.0) + (digits_out ? 1.0 : 0.0)));
         const uint32_t per_xcd = ctx->sort_xcd_tiles && ntiles >= 64 ? (ntiles + 7) / 8 : 0;
         hipLaunchKernelGGL((k_radix_scatter<K, RBITS, THREADS>), dim3(per_xcd ? per_xcd * 8 : ntiles), dim3(THREADS), smem, ctx->stream,
-                           kin, vin, kout, vout, n, shift, mask, counts, ntiles, per_xcd);
+                           kin, vin, kout, vout, n, shift, mask, counts, ntiles, per_xcd, digits_out, next_shift,
+                           digits_out ? (1u << next_nb) - 1u : 0u);
     }
     CPH_HIP_TRY(hipGetLastError());
     return {};
@@ -423,16 +468,29 @@ Status radix_sort_pairs(cph_ctx* ctx, K* keys_a, K* keys_b, uint32_t* vals_a, ui
         c = counts.as<uint32_t>();
         first_hist_done = false;
     }
+    // Digit stream: the scatter of pass p also writes, for every key, the digit pass p+1 will sort on (one byte, in the
+    // output order = pass p+1's input order), so that pass p+1's histogram reads n bytes instead of n keys.  8-bit digits
+    // of 64-bit keys on large inputs only: measured at 1e8 rows (tools/microbench/sort_stream.py) the five later histograms of
+    // config 3 drop from 1.03 to 0.59 ms (now bound by their LDS atomics) while the scatters' byte stores cost 0.26 ms —
+    // 8.65 -> 8.47 ms; with 32-bit keys the two cancel (2.66 -> 2.65 ms), so they keep reading their keys.
+    DevBuf digit_stream;
+    const bool stream_digits = sizeof(K) == 8 && !wide && npass >= 2 && n >= (1u << 20) && ctx->sort_digit_stream;
+    if (stream_digits) CPH_TRY(digit_stream.alloc(&ctx->pool, n + 16));
+    uint8_t* dg = stream_digits ? digit_stream.as<uint8_t>() : nullptr;
     int shift = 0;
     for (int p = 0; p < npass; p++) {
         const int left = bits - shift;
         const int nb = (left + (npass - p) - 1) / (npass - p);
+        const int left_next = left - nb, pass_next = npass - p - 1;
+        const int nb_next = pass_next > 0 ? (left_next + pass_next - 1) / pass_next : 0;
         const uint32_t* v = iota ? nullptr : vin;
         const bool hd = p == 0 && first_hist_done;
-        if (wide && threads == 512) CPH_TRY((radix_pass<K, 9, 512>(ctx, kin, v, kout, vout, n, shift, nb, c, ntiles, hd)));
-        else if (wide) CPH_TRY((radix_pass<K, 9, 256>(ctx, kin, v, kout, vout, n, shift, nb, c, ntiles, hd)));
-        else if (threads == 512) CPH_TRY((radix_pass<K, 8, 512>(ctx, kin, v, kout, vout, n, shift, nb, c, ntiles, hd)));
-        else CPH_TRY((radix_pass<K, 8, 256>(ctx, kin, v, kout, vout, n, shift, nb, c, ntiles, hd)));
+        const uint8_t* din = p > 0 ? dg : nullptr;
+        uint8_t* dout = pass_next > 0 ? dg : nullptr;
+        if (wide && threads == 512) CPH_TRY((radix_pass<K, 9, 512>(ctx, kin, v, kout, vout, n, shift, nb, c, ntiles, hd, nullptr, nullptr, 0, 0)));
+        else if (wide) CPH_TRY((radix_pass<K, 9, 256>(ctx, kin, v, kout, vout, n, shift, nb, c, ntiles, hd, nullptr, nullptr, 0, 0)));
+        else if (threads == 512) CPH_TRY((radix_pass<K, 8, 512>(ctx, kin, v, kout, vout, n, shift, nb, c, ntiles, hd, din, dout, shift + nb, nb_next)));
+        else CPH_TRY((radix_pass<K, 8, 256>(ctx, kin, v, kout, vout, n, shift, nb, c, ntiles, hd, din, dout, shift + nb, nb_next)));
         shift += nb;
         iota = false;
         K* tk = kin; kin = kout; kout = tk;
