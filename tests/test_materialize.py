@@ -130,3 +130,24 @@ def test_csv_write_rows_fused_equals_gather_then_write(ctx):
     assert got == want
     # no rows at all: the header only
     assert csv_write(ctx, [s.head(0), a, b], ["s", "a", "b"], row_ids=[None, ia[:0], ib[:0]], nrows=0) == b"s,a,b\n"
+
+
+@pytest.mark.gpu
+def test_csv_write_many_tiles_and_oversized_records(ctx):
+    """Several hundred 256-record tiles, quoted and empty values, gathered columns through 32- and 64-bit row ids, and records
+    larger than a tile's LDS stage (they are written to global memory directly)."""
+    from csvplus_amd.materialize import csv_write
+    rng = np.random.default_rng(97)
+    n = 100_000
+    alphabet = np.frombuffer(b'ab ,"\n\rz#\t0123456789', dtype=np.uint8)
+    stream = [alphabet[rng.integers(0, len(alphabet), int(rng.integers(0, 12)))].tobytes() for _ in range(n)]
+    for r in (5, 40_000, 99_999):
+        stream[r] = b"x" * 20_000 + b'"' + b"y" * 3000          # larger than the 16 KiB stage
+    small = [alphabet[rng.integers(0, len(alphabet), int(rng.integers(0, 20)))].tobytes() for _ in range(700)]
+    nums = [b"%d" % i for i in range(5000)]
+    s, a, b = StrCol.from_values(stream), StrCol.from_values(small), StrCol.from_values(nums)
+    ia = rng.integers(0, a.nrows, n).astype(np.uint32)
+    ib = rng.integers(0, b.nrows, n).astype(np.uint64)
+    want = orc.csv_write([s, StrCol.from_values([small[int(i)] for i in ia]), StrCol.from_values([nums[int(i)] for i in ib]), s],
+                         ["s", "a", "b", "s2"])
+    assert csv_write(ctx, [s, a, b, s], ["s", "a", "b", "s2"], row_ids=[None, ia, ib, None]) == want
