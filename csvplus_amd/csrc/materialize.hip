@@ -28,6 +28,9 @@ struct RowIds {
     const void* ptr = nullptr;   // null: identity
     int32_t bits = 32;
     uint64_t base = 0;
+    // CSV writer, gathered columns: the length pass leaves (begin | length << 32) of the value it looked up per OUTPUT row
+    // here, and the copy pass reads that stream instead of fetching row id + offsets again (one random sector less per row)
+    uint64_t* stash = nullptr;
 };
 __device__ __forceinline__ uint64_t source_row(const RowIds& ids, uint64_t i) {
     if (!ids.ptr) return i;
@@ -61,6 +64,7 @@ __global__ __launch_bounds__(kMatThreads) void k_gather_lens(DevCol col, RowIds 
         uint64_t b, l;
         value_span(col, source_row(ids, i), &b, &l);
         lens[i] = l;
+        if (ids.stash) ids.stash[i] = b | (l << 32);   // for the copy pass: no second trip through row id and offsets
     }
 }
 
@@ -74,7 +78,10 @@ __global__ __launch_bounds__(kMatThreads) void k_gather_copy(DevCol col, RowIds 
         const uint64_t span = offs[tend] - obase;
         const uint64_t i = t0 + threadIdx.x;
         uint64_t b = 0, l = 0;
-        if (i < tend) value_span(col, source_row(ids, i), &b, &l);
+        if (i < tend) {
+            if (ids.stash) { const uint64_t v = ids.stash[i]; b = v & 0xFFFFFFFFull; l = v >> 32; }
+            else value_span(col, source_row(ids, i), &b, &l);
+        }
         if (span + 16 <= (uint64_t)kMatStage) {
             if (i < tend && l) {
                 LdsSink s{stage + (offs[i] - obase) + (obase & 15)};
@@ -211,6 +218,7 @@ __global__ __launch_bounds__(kMatThreads) void k_csv_lens(ColsArg cols, ColIds i
                 bool q = false;
                 total += ((mode.raw_mask >> c) & 1u) ? f.l[c] : csv_field_len(cols.c[c], f.b[c], f.l[c], f.c0[c], &q);
                 flags |= (uint32_t)q << c;
+                if (ids.ids[c].stash) ids.ids[c].stash[i] = f.b[c] | (f.l[c] << 32);   // uniform branch
             }
         } else {
             for (int c = 0; c < ncols; c++) {
@@ -274,12 +282,16 @@ __global__ __launch_bounds__(kMatThreads) void k_csv_copy(ColsArg cols, ColIds i
                 const uint64_t i = t0 + (uint64_t)k * kMatThreads + threadIdx.x;
                 live[k] = i < tend;
 #pragma unroll
-                for (int c = 0; c < NC; c++) row[k][c] = source_row(ids.ids[c], live[k] ? i : tend - 1);
+                for (int c = 0; c < NC; c++)   // a stashed column: the (begin, length) the length pass found, read as a stream
+                    row[k][c] = ids.ids[c].stash ? ids.ids[c].stash[live[k] ? i : tend - 1] : source_row(ids.ids[c], live[k] ? i : tend - 1);
             }
 #pragma unroll
             for (int k = 0; k < kCsvCopyRows; k++)
 #pragma unroll
-                for (int c = 0; c < NC; c++) value_span(cols.c[c], row[k][c], &b[k][c], &l[k][c]);
+                for (int c = 0; c < NC; c++) {
+                    if (ids.ids[c].stash) { b[k][c] = row[k][c] & 0xFFFFFFFFull; l[k][c] = row[k][c] >> 32; }
+                    else value_span(cols.c[c], row[k][c], &b[k][c], &l[k][c]);
+                }
 #pragma unroll
             for (int k = 0; k < kCsvCopyRows; k++)
 #pragma unroll
@@ -384,9 +396,19 @@ static void csv_append_field_host(std::string* out, const uint8_t* p, uint64_t l
 // The two writer passes over n records of `ncols` columns: lengths -> exclusive scan -> copy.  data_out gets
 // head_bytes + total bytes (the first head_bytes are left for the caller: the header line); offs_out the n+1
 // record offsets relative to the end of the header.
-static Status csv_render(cph_ctx* ctx, const ColsArg& arg, const ColIds& ids, int ncols, CsvMode mode, uint64_t n, uint64_t head_bytes,
-                         DevBuf* offs_out, DevBuf* data_out, uint64_t* total_out) {
+static Status csv_render(cph_ctx* ctx, const ColsArg& arg, const ColIds& ids_in, int ncols, CsvMode mode, uint64_t n, uint64_t head_bytes,
+                         DevBuf* offs_out, DevBuf* data_out, uint64_t* total_out, const uint64_t* col_bytes = nullptr) {
     DevBuf qflags;
+    // gathered columns whose bytes lie within 4 GiB: (begin, length) travels from the length pass to the copy pass
+    ColIds ids = ids_in;
+    std::vector<DevBuf> stashes;
+    for (int c = 0; c < ncols && ncols <= 8 && n && col_bytes; c++) {   // col_bytes[c]: bytes of the column's values, 0 = unknown
+        if (!ids.ids[c].ptr || arg.c[c].fixed_width) continue;
+        if (col_bytes[c] == 0 || col_bytes[c] >= (1ull << 32)) continue;
+        stashes.emplace_back();
+        CPH_TRY(stashes.back().alloc(&ctx->pool, n * sizeof(uint64_t)));
+        ids.ids[c].stash = stashes.back().as<uint64_t>();
+    }
     CPH_TRY(offs_out->alloc(&ctx->pool, (n + 1) * sizeof(uint64_t)));
     CPH_TRY(qflags.alloc(&ctx->pool, (n + 1) * sizeof(uint16_t)));
     uint64_t total = 0;
@@ -465,6 +487,13 @@ CPH_API int32_t cph_gather_rows(cph_ctx* ctx, const cph_strcol* col, const void*
         CPH_TRY(r->d_offs.alloc(&ctx->pool, (n + 1) * sizeof(uint64_t)));
         uint64_t* offs = r->d_offs.as<uint64_t>();
         uint64_t total = 0;
+        // a gathered variable-length column with 32-bit offsets (its bytes lie within 4 GiB): the length pass hands
+        // (begin, length) to the copy pass as a stream
+        DevBuf stash;
+        if (n && ids.ptr && !d.fixed_width && d.offset_bits == 32) {
+            CPH_TRY(stash.alloc(&ctx->pool, n * sizeof(uint64_t)));
+            ids.stash = stash.as<uint64_t>();
+        }
         if (n) {
             {
                 ProfScope ps(ctx, "k_gather_lens", 0);
@@ -578,6 +607,7 @@ CPH_API int32_t cph_csv_write_rows(cph_ctx* ctx, const cph_strcol* cols, const c
         CsvMode fmode{0, 1};
         int nf = 0;
         std::vector<DevBuf> frag_store;
+        uint64_t fbytes[kMaxKeyCols] = {};   // bytes of a fragment column (known here: it was just rendered)
         for (int c = 0; c < ncols;) {
             int e = c + 1;
             const bool reusable = ids.ids[c].ptr && arg.c[c].nrows * 2 <= n;
@@ -597,6 +627,7 @@ CPH_API int32_t cph_csv_write_rows(cph_ctx* ctx, const cph_strcol* cols, const c
                 farg.c[nf].offset_bits = 64;
                 farg.c[nf].fixed_width = 0;
                 fmode.raw_mask |= 1u << nf;
+                fbytes[nf] = ftotal;
                 frag_store.push_back(std::move(foffs));
                 frag_store.push_back(std::move(fdata));
             } else {
@@ -609,7 +640,7 @@ CPH_API int32_t cph_csv_write_rows(cph_ctx* ctx, const cph_strcol* cols, const c
         }
         DevBuf offs;
         uint64_t total = 0;
-        CPH_TRY(csv_render(ctx, farg, fids, nf, fmode, n, head.size(), &offs, &r->d_data, &total));
+        CPH_TRY(csv_render(ctx, farg, fids, nf, fmode, n, head.size(), &offs, &r->d_data, &total, fbytes));
         const uint64_t size = head.size() + total;
         if (!head.empty()) {
             void* slot = nullptr;
