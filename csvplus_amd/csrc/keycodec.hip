@@ -411,16 +411,13 @@ __global__ __launch_bounds__(THREADS) void k_group_stats(ColsArg cols, GroupLayo
     for (uint64_t base = (uint64_t)blockIdx.x * THREADS * kGroupRows; base < n; base += stride) {
         int cur_col = -1;
         ValueHeadT<LONGV> v[kGroupRows];
-        bool live[kGroupRows];
-#pragma unroll
-        for (int k = 0; k < kGroupRows; k++) live[k] = base + (uint64_t)k * THREADS + threadIdx.x < n;
         for (int t = 0; t < lay.ntables; t++) {
             const uint32_t tab = lay.tab[t];
             const int q0 = tab_q0(tab), span = tab_span(tab);
             if (tab_col(tab) != cur_col) {
                 cur_col = tab_col(tab);
-                // rows past the end re-read the last row (their symbols are never inserted): no branch around the
-                // loads, so the kGroupRows rows of a lane are in flight together
+                // rows past the end re-read the last row: no branch around the loads, so the kGroupRows rows of a lane
+                // are in flight together
 #pragma unroll
                 for (int k = 0; k < kGroupRows; k++) {
                     const uint64_t i = base + (uint64_t)k * THREADS + threadIdx.x;
@@ -430,24 +427,30 @@ __global__ __launch_bounds__(THREADS) void k_group_stats(ColsArg cols, GroupLayo
                 for (int k = 0; k < kGroupRows; k++) v[k].chunks_nobranch(cols.c[cur_col]);
             }
             const int set = lay.set[t];
+            // straight-line first probe for all rows (rows past the end are copies of the last row: inserting its symbols
+            // again changes nothing); only symbols the workgroup has not met yet take the slow path
+            CPH_LDS uint64_t* mine = seen + ((uint32_t)t << cache_bits);
+            uint64_t sym[kGroupRows], cur[kGroupRows];
+            uint32_t h[kGroupRows];
 #pragma unroll
             for (int k = 0; k < kGroupRows; k++) {
-                if (!live[k]) continue;
                 const uint64_t left = v[k].len > (uint64_t)q0 ? v[k].len - (uint64_t)q0 : 0;
-                const uint64_t sym = group_raw(v[k].window(cols.c[cur_col], q0), left < (uint64_t)span ? left : (uint64_t)span);
-                // the workgroup's own set of the symbols it has met (open addressing in LDS, insert only)
-                const uint64_t hs = sym * 0x9E3779B97F4A7C15ull;
-                CPH_LDS uint64_t* mine = seen + ((uint32_t)t << cache_bits);
-                uint32_t h = (uint32_t)(hs >> 40) & (cache_n - 1);
-                uint64_t cur = mine[h];
-                for (int pr = 0; pr < 6 && cur != sym && cur != kGroupEmpty; pr++) {
-                    h = (h + 1) & (cache_n - 1);
-                    cur = mine[h];
+                sym[k] = group_raw(v[k].window(cols.c[cur_col], q0), left < (uint64_t)span ? left : (uint64_t)span);
+                h[k] = (uint32_t)((sym[k] * 0x9E3779B97F4A7C15ull) >> 40) & (cache_n - 1);
+            }
+#pragma unroll
+            for (int k = 0; k < kGroupRows; k++) cur[k] = mine[h[k]];
+#pragma unroll
+            for (int k = 0; k < kGroupRows; k++) {
+                if (cur[k] == sym[k]) continue;                        // met before: already in the device set
+                for (int pr = 0; pr < 6 && cur[k] != sym[k] && cur[k] != kGroupEmpty; pr++) {
+                    h[k] = (h[k] + 1) & (cache_n - 1);
+                    cur[k] = mine[h[k]];
                 }
-                if (cur == sym) continue;                              // met before: already in the device set
+                if (cur[k] == sym[k]) continue;
                 if (counts[set] > (uint32_t)kGroupDictMax) continue;   // given up already (a stale read only costs work)
-                group_insert(slots + (uint64_t)set * kGroupSlots, &counts[set], sym);
-                if (cur == kGroupEmpty) atomicCAS((unsigned long long*)&mine[h], (unsigned long long)kGroupEmpty, (unsigned long long)sym);
+                group_insert(slots + (uint64_t)set * kGroupSlots, &counts[set], sym[k]);
+                if (cur[k] == kGroupEmpty) atomicCAS((unsigned long long*)&mine[h[k]], (unsigned long long)kGroupEmpty, (unsigned long long)sym[k]);
             }
         }
     }
@@ -1035,31 +1038,41 @@ __global__ __launch_bounds__(THREADS) void k_encode_build_plan(ColsArg cols, con
                     const int bits = (int)plan[u].hash_bits;
                     const uint32_t mask = (1u << bits) - 1u;
                     const int span = (int)plan[u].span;
+                    // straight-line for all rows (rows past the end are copies of the last row, never stored): the hash slots,
+                    // then the dictionary entries of the rows are fetched together; only a collision loops
+                    uint64_t raw[kEncodeRows];
+                    uint32_t sl[kEncodeRows], e[kEncodeRows];
 #pragma unroll
                     for (int k = 0; k < kEncodeRows; k++) {
-                        if (!live[k]) continue;
-                        const uint64_t raw = raw_of(v[k], (int)q0, span);
-                        uint32_t sl = group_slot(raw, bits);
-                        uint32_t e = ht[sl];
-                        while (e != 0 && d[e - 1] != raw) {   // every build key is in its dictionary: the probe ends on a hit
-                            sl = (sl + 1) & mask;
-                            e = ht[sl];
+                        raw[k] = raw_of(v[k], (int)q0, span);
+                        sl[k] = group_slot(raw[k], bits);
+                    }
+#pragma unroll
+                    for (int k = 0; k < kEncodeRows; k++) e[k] = ht[sl[k]];
+                    uint64_t held[kEncodeRows];
+#pragma unroll
+                    for (int k = 0; k < kEncodeRows; k++) held[k] = d[e[k] ? e[k] - 1 : 0];
+#pragma unroll
+                    for (int k = 0; k < kEncodeRows; k++) {
+                        while (e[k] != 0 && held[k] != raw[k]) {   // another key's slot: every build key is in its dictionary, the probe ends on a hit
+                            sl[k] = (sl[k] + 1) & mask;
+                            e[k] = ht[sl[k]];
+                            held[k] = d[e[k] ? e[k] - 1 : 0];
                         }
                         if constexpr (SPEC) {
-                            if (e == 0) {   // not in the sample's dictionary
+                            if (e[k] == 0 && live[k]) {   // not in the sample's dictionary
                                 const uint32_t t = plan[u].table;
                                 if (g_counts[t] <= (uint32_t)kGroupDictMax)
-                                    group_insert(g_slots + (uint64_t)t * kGroupSlots, &g_counts[t], raw);
+                                    group_insert(g_slots + (uint64_t)t * kGroupSlots, &g_counts[t], raw[k]);
                                 missed |= 1u << k;
                             }
                         }
-                        acc[k] += (uint64_t)(e ? e - 1 : 0) * mult;
+                        acc[k] += (uint64_t)(e[k] ? e[k] - 1 : 0) * mult;
                     }
                 } else {
                     const CPH_LDS uint16_t* lp = cv.lut + plan[u].off;
 #pragma unroll
-                    for (int k = 0; k < kEncodeRows; k++)
-                        if (live[k]) acc[k] += (uint64_t)lp[sym_of(v[k], (int)q0)] * mult;
+                    for (int k = 0; k < kEncodeRows; k++) acc[k] += (uint64_t)lp[sym_of(v[k], (int)q0)] * mult;
                 }
             };
             using V = ValueHeadT<LONGV>;
