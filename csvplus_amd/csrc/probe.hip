@@ -110,7 +110,9 @@ void index_plan_table(cph_index* ix) {
     const uint64_t n = ix->nrows;
     if (n == 0 || ix->codec.nwords != 1 || !ix->windows.empty()) return;
     const uint64_t states = ix->codec.word_states[0];
-    uint64_t limit = 8 * n;
+    // up to 24 table entries per row: decimal ids without padding ("0".."1199999": 11 symbols per position, 19.5 M codes
+    // for 1.2 M keys) stay on the one-load path — a binary-searched probe of 1e8 rows costs 16 ms, the table 2-3 ms
+    uint64_t limit = 24 * n;
     if (limit < (1ull << 20)) limit = 1ull << 20;
     if (states > limit || states > (1ull << 30)) return;
     ix->table_entries = states;
