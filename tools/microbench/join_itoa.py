@@ -15,3 +15,16 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(5):
     m = gp.probe([d_cust], out_mem=N.CPH_MEM_DEVICE); n = m.nmatches; m.release()
 torch.cuda.synchronize(); print("JoinOnSmallSingleIndex 1e8 ITOA ids: %.3f ms, %d matches" % ((time.perf_counter() - t0) / 5 * 1e3, n))
+# the chained join of the bench with reference-style (unpadded) ids on both sides
+from csvplus_amd import join_chain
+prod = dg.products(100_000)
+d_pid = prod["prod_id"].to_device(eng.device)
+orders2 = dg.orders(100_000_000, 1_200_000, 100_000, cust_encoding=dg.ITOA)
+d_c2, d_p2 = orders2["cust_id"].to_device(eng.device), orders2["prod_id"].to_device(eng.device)
+gq = DeviceIndex(ctx, [d_pid], unique=True)
+for _ in range(2):
+    ch = join_chain(ctx, [(gp, [d_c2]), (gq, [d_p2])], out_mem=N.CPH_MEM_DEVICE); ch.release()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(5):
+    ch = join_chain(ctx, [(gp, [d_c2]), (gq, [d_p2])], out_mem=N.CPH_MEM_DEVICE); n = ch.nrows; ch.release()
+torch.cuda.synchronize(); print("chained join 1e8 rows, unpadded ids: %.3f ms, %d rows" % ((time.perf_counter() - t0) / 5 * 1e3, n))
