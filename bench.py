@@ -124,7 +124,25 @@ def main():
     eng = Engine(local_rank)
     # the exchange runs behind the C ABI (cph_dist_*: RCCL); torch.distributed only ships the communicator id.
     # Debug mode with several ranks on one GPU (gloo): the torch transport of csvplus_amd/dist.py instead.
-    cdist = connect(eng.ctx) if (world > 1 and not share_gpu and args.exchange == "allgatherv") else None
+    cdist, transport = None, "none"
+    if world > 1 and args.exchange == "allgatherv":
+        transport = "torch.distributed (debug: ranks share one GPU)"
+        if not share_gpu:
+            ok, why = 1, ""
+            try:
+                cdist = connect(eng.ctx)
+            except Exception as e:   # noqa: BLE001 — the run continues over torch's process group, and says so
+                ok, why = 0, f"{type(e).__name__}: {e}"
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # one decision for all ranks
+            if int(flag.item()):
+                transport = "cph_dist_* (RCCL behind the C ABI)"
+            else:
+                if cdist is not None:
+                    cdist.close()
+                cdist = None
+                transport = "torch.distributed NCCL process group (cph_dist_create failed on a rank" + (f": {why}" if why else "") + ")"
+                print(f"[bench] rank {rank}: {transport}", file=sys.stderr)
 
     # ---- synthetic tables (deterministic), staged to HBM before timing ------------
     t0 = time.time()
@@ -305,6 +323,7 @@ def main():
                                "JOIN products(1e5, UniqueIndexOn prod_id); BASELINE configs[3] shape, probe rows sharded over n_gpus",
                    "rows": args.rows, "customers": args.customers, "products": args.products,
                    "rows_this_rank": nloc, "exchange": args.exchange if world > 1 else "none (1 GPU)",
+                   "exchange_transport": transport,
                    "inputs": "resident in HBM before the timed region"},
         "joined_rows_per_step": total_joined,
         "index_build": {"GBps_algorithmic": round(build_gb / (build_ms / 1e3), 1) if build_ms else None,
