@@ -264,6 +264,7 @@ constexpr int kGroupMaxTables = (kGroupSpan - 1) * kMaxKeyBytes;   // candidate 
 constexpr int kGroupMaxChosen = kMaxKeyBytes / 2;                   // windows of one partition
 constexpr int kGroupRows = 4;                 // rows per thread and iteration in k_group_stats
 constexpr int kSampleThreads = 1024;
+constexpr uint32_t kGroupSeenOften = 16;      // a value the sample holds this often is "common"
 constexpr int kSampleRows = 4;                // rows per thread and iteration in k_group_sample
 
 // window descriptor: key column | first byte offset << 8 | positions << 16
@@ -322,14 +323,27 @@ __global__ __launch_bounds__(256) void k_group_stage(ColsArg cols, StageArg st, 
 }
 
 // One workgroup per candidate window over the staged sample.  counts[t] = distinct raw keys (kGroupOverflow set:
-// more than kGroupDictMax, the set is not written); singles[t] = those seen exactly once — the Good-Turing estimate
-// of how much of the data the sample has NOT seen; slots[t] = the set.
+// more than kGroupDictMax, the set is not written); singles[t] = those the sample holds fewer than kGroupSeenOften
+// times — values that rare say that the sample is far from having seen everything (Good-Turing: the unseen share of
+// the rows is about (values seen once) / (sample size)); slots[t] = the set.
 __global__ __launch_bounds__(kSampleThreads) void k_group_sample(StageArg st, const uint32_t* __restrict__ tabs, uint64_t nsel,
                                                                 uint64_t* __restrict__ slots, uint32_t* __restrict__ counts,
                                                                 uint32_t* __restrict__ singles) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     CPH_LDS uint64_t* set = (CPH_LDS uint64_t*)smem;
-    CPH_LDS uint8_t* twice = (CPH_LDS uint8_t*)(smem + (size_t)kGroupSlots * sizeof(uint64_t));
+    // one byte per slot: how often the value was met again, saturating at kGroupSeenOften (CAS on the 32-bit word holding it:
+    // a plain add could carry into the neighbouring slot's byte when thousands of rows share a value)
+    CPH_LDS uint32_t* seen4 = (CPH_LDS uint32_t*)(smem + (size_t)kGroupSlots * sizeof(uint64_t));
+    auto met_again = [&](uint32_t h) {
+        CPH_LDS uint32_t* w = seen4 + (h >> 2);
+        const uint32_t sh = 8u * (h & 3u);
+        uint32_t old = *w;
+        while (((old >> sh) & 0xFFu) < kGroupSeenOften) {
+            const uint32_t was = atomicCAS((unsigned int*)w, old, old + (1u << sh));
+            if (was == old) break;
+            old = was;
+        }
+    };
     __shared__ uint32_t s_count, s_single;
     typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
     const uint32_t tab = tabs[blockIdx.x];
@@ -337,7 +351,8 @@ __global__ __launch_bounds__(kSampleThreads) void k_group_sample(StageArg st, co
     const uint32_t q0 = (uint32_t)tab_q0(tab), span = (uint32_t)tab_span(tab), width = st.width[c];
     const uint8_t* __restrict__ data = st.data[c];
     const uint32_t* __restrict__ lens = st.lens[c];
-    for (uint32_t i = threadIdx.x; i < (uint32_t)kGroupSlots; i += kSampleThreads) { set[i] = kGroupEmpty; twice[i] = 0; }
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kGroupSlots; i += kSampleThreads) set[i] = kGroupEmpty;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kGroupSlots / 4; i += kSampleThreads) seen4[i] = 0;
     if (threadIdx.x == 0) { s_count = 0; s_single = 0; }
     __syncthreads();
     for (uint64_t base = 0; base < nsel; base += (uint64_t)kSampleThreads * kSampleRows) {
@@ -359,11 +374,11 @@ __global__ __launch_bounds__(kSampleThreads) void k_group_sample(StageArg st, co
             uint32_t h = group_set_slot(sym);
             for (int probes = 0; probes < kGroupSlots; probes++, h = (h + 1) & (kGroupSlots - 1)) {
                 const uint64_t cur = set[h];
-                if (cur == sym) { twice[h] = 1; break; }
+                if (cur == sym) { met_again(h); break; }
                 if (cur == kGroupEmpty) {
                     const uint64_t prev = atomicCAS((unsigned long long*)&set[h], (unsigned long long)kGroupEmpty, (unsigned long long)sym);
                     if (prev == kGroupEmpty) { atomicAdd(&s_count, 1u); break; }
-                    if (prev == sym) { twice[h] = 1; break; }
+                    if (prev == sym) { met_again(h); break; }
                 }
                 if (s_count > (uint32_t)kGroupDictMax) break;
             }
@@ -376,7 +391,7 @@ __global__ __launch_bounds__(kSampleThreads) void k_group_sample(StageArg st, co
         for (uint32_t i = threadIdx.x; i < (uint32_t)kGroupSlots; i += kSampleThreads) {
             const uint64_t e = set[i];
             slots[(uint64_t)blockIdx.x * kGroupSlots + i] = e;
-            once += e != kGroupEmpty && !twice[i];
+            once += e != kGroupEmpty && ((seen4[i >> 2] >> (8u * (i & 3u))) & 0xFFu) + 1u < kGroupSeenOften;
         }
     once = wave_sum(once);
     if (lane_id() == 0 && once) atomicAdd(&s_single, once);
@@ -670,12 +685,12 @@ Status codec_try_groups(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_
     //      and dictionary entries still available e (in units of kQuant) ----
     constexpr int kQuant = 16, kLevels = kGroupDictMax / kQuant + 1;
     auto pos_of = [&](uint32_t tab) { return cd.col_start[tab_col(tab)] + tab_q0(tab); };
-    // sampled: the counts come from a sample — a window many of whose values were seen only once is far from saturated
-    // (its true set is much larger than the count says, Good-Turing again) and stays out
+    // sampled: the counts come from a sample — a window many of whose values the sample holds only a few times is far from
+    // saturated (its true set is much larger than the count says) and stays out
     auto choose = [&](const std::vector<uint8_t>& allowed, bool sampled) {
         std::vector<std::vector<int>> starts((size_t)cd.npos);   // tables by first position
         for (int t = 0; t < nt; t++)
-            if (allowed[(size_t)t] && !(sampled && hsingle[(size_t)t] * 8u > hcount[(size_t)t]) &&
+            if (allowed[(size_t)t] && !(sampled && hsingle[(size_t)t] * 3u > hcount[(size_t)t]) &&
                 group_saved_bits(cd, pos_of(tabs[(size_t)t]), tab_span(tabs[(size_t)t]), hcount[(size_t)t]) >= 1.0)
                 starts[(size_t)pos_of(tabs[(size_t)t])].push_back(t);
         std::vector<double> dp((size_t)(cd.npos + 1) * kLevels, 0.0);
@@ -715,7 +730,7 @@ Status codec_try_groups(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_
     auto debug = [&](const char* what) {
         if (!ctx->codec_debug) return;
         fprintf(stderr, "codec_try_groups %s (sample step %llu):", what, (unsigned long long)step);
-        for (const GroupChoice& c : picked) fprintf(stderr, " [p%d+%d n=%u once=%u]", c.p0, c.span, hcount[(size_t)c.t], hsingle[(size_t)c.t]);
+        for (const GroupChoice& c : picked) fprintf(stderr, " [p%d+%d n=%u rare=%u]", c.p0, c.span, hcount[(size_t)c.t], hsingle[(size_t)c.t]);
         fprintf(stderr, "\n");
     };
     debug("sample");
@@ -723,10 +738,12 @@ Status codec_try_groups(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_
     CodecHost trial;
     std::vector<GroupChoice> chosen;
     if (step > 1) {
-        // Large input: the sets so far come from a sample.  No value seen only once in any chosen window: the sample very
-        // likely holds every window there is (Good-Turing: the unseen share of the rows is about singles / sample size), so
-        // the sets can serve as dictionaries right away — the encode kernel completes them should it meet an unknown
-        // window (GroupSpec).  Otherwise: the exact sets of the chosen windows, over all rows.
+        // Large input: the sets so far come from a sample.  Every value of every chosen window common in the sample (met
+        // kGroupSeenOften times or more): a closed vocabulary, the sample very likely holds every window there is, and the
+        // sets can serve as dictionaries right away — the encode kernel completes them should it meet an unknown window
+        // (GroupSpec).  Otherwise (any rare value: where there is one, the other 99.7 % of the rows hold more): the exact
+        // sets of the chosen windows, over all rows.  ("No value seen exactly once" was not enough: at 5e7 config-3 rows the
+        // sample showed none, the rows held unknown windows, and the encode ran twice.)
         uint32_t rare = 0;
         for (const GroupChoice& c : picked) rare += hsingle[(size_t)c.t];
         if (spec && ctx->speculative_groups == 1 ? rare == 0 : (spec && ctx->speculative_groups == 2)) {
