@@ -16,6 +16,14 @@ allgatherv'ed over RCCL behind the C ABI (cph_dist_chain_allgather) so that ever
 whole list in emission order.
 
 value = joined rows per second of the whole job (max over ranks of the step time).
+
+Launching: `python bench.py --gpus N` works as a plain command — without a launcher's WORLD_SIZE in the
+environment it starts its own N ranks (one per visible GPU) under torch.distributed.run on 127.0.0.1; under a
+launcher (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) it is one of the ranks.
+For N > 1 the exchange that is timed is ALWAYS cph_dist_* (RCCL behind the C ABI): if the communicator cannot
+be created on some rank, every rank exits non-zero — there is no silent fallback to another transport.  (The
+one exception is the explicitly requested debug mode CPH_BENCH_SHARE_GPU=1, several ranks on one GPU over gloo,
+which RCCL itself refuses; its line says so.)
 """
 import argparse
 import json
@@ -48,7 +56,67 @@ def parse_args():
     ap.add_argument("--verify-sample", type=int, default=100_000)
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the two rocprofv3 --pmc child runs (FETCH_SIZE, WRITE_SIZE) behind roofline.traffic")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous only: every rank joins the process group (gloo when no GPU is visible) and rank 0 "
+                         "prints which ranks it saw; no compute (what tests/test_bench_launch.py drives on CPU)")
     return ap.parse_args()
+
+
+EXIT_USAGE, EXIT_NO_GPUS, EXIT_NO_RCCL = 2, 2, 3
+
+
+def fatal(msg, code=EXIT_USAGE):
+    print(f"bench.py: {msg}", file=sys.stderr, flush=True)
+    sys.exit(code)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` as a plain command: start N ranks of this script, one per visible GPU, under
+    torch.distributed.run (the launcher the driver would use) and hand its exit code on."""
+    import socket
+    import subprocess
+
+    share_gpu = os.environ.get("CPH_BENCH_SHARE_GPU") == "1"
+    if not args.launch_check and not share_gpu:
+        import torch
+
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            fatal(f"--gpus {args.gpus} needs {args.gpus} visible GPUs, this machine shows {have}: one rank per GPU over RCCL "
+                  f"(CPH_BENCH_SHARE_GPU=1 runs the ranks on one GPU as a control-flow check over gloo — not an RCCL measurement)",
+                  EXIT_NO_GPUS)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(args, rank, world):
+    """Every rank joins the process group and contributes its rank; rank 0 prints what it saw."""
+    import torch
+    import torch.distributed as dist
+
+    backend = "nccl" if (torch.cuda.is_available() and torch.cuda.device_count() >= world
+                         and os.environ.get("CPH_BENCH_SHARE_GPU") != "1") else "gloo"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend)
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))) if backend == "nccl" else torch.device("cpu")
+        seen = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(seen, torch.tensor([rank], dtype=torch.int64, device=dev))
+        ranks = [int(t.item()) for t in seen]
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        ranks = [0]
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": args.gpus, "world": world, "ranks_seen": ranks,
+                          "backend": backend if world > 1 else "none"}), flush=True)
 
 
 def measure_traffic(kernel_prefix, args):
@@ -96,6 +164,15 @@ def measure_traffic(kernel_prefix, args):
 
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        fatal("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))       # plain command: start the ranks ourselves
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        fatal(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ.get('WORLD_SIZE')} ranks: "
+              f"use --nproc-per-node {args.gpus}, or run `python bench.py --gpus {args.gpus}` without a launcher")
+    if args.launch_check:
+        return launch_check(args, int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -112,6 +189,9 @@ def main():
     share_gpu = os.environ.get("CPH_BENCH_SHARE_GPU") == "1"
     if share_gpu:
         local_rank = 0
+    if not torch.cuda.is_available() or (not share_gpu and torch.cuda.device_count() <= local_rank):
+        fatal(f"rank {rank}: no GPU for local rank {local_rank} ({torch.cuda.device_count() if torch.cuda.is_available() else 0} "
+              f"visible); csvplus_amd has no CPU path", EXIT_NO_GPUS)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -119,30 +199,34 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank)
     eng = Engine(local_rank)
-    # the exchange runs behind the C ABI (cph_dist_*: RCCL); torch.distributed only ships the communicator id.
-    # Debug mode with several ranks on one GPU (gloo): the torch transport of csvplus_amd/dist.py instead.
-    cdist, transport = None, "none"
+    # the exchange runs behind the C ABI (cph_dist_*: RCCL); torch.distributed only ships the communicator id (and
+    # provides the barrier / max-over-ranks of the timing contract).  If the communicator cannot be created on ANY rank
+    # the whole job stops with a non-zero exit code: a scaling curve is a measurement of cph_dist_* or it is nothing.
+    # Debug mode with several ranks on one GPU (CPH_BENCH_SHARE_GPU=1, gloo): the torch transport of csvplus_amd/dist.py.
+    cdist, transport, rccl_nranks = None, "none", None
     if world > 1 and args.exchange == "allgatherv":
-        transport = "torch.distributed (debug: ranks share one GPU)"
-        if not share_gpu:
+        if share_gpu:
+            transport = "torch.distributed gloo (DEBUG: ranks share one GPU; not an RCCL measurement)"
+        else:
             ok, why = 1, ""
             try:
                 cdist = connect(eng.ctx)
-            except Exception as e:   # noqa: BLE001 — the run continues over torch's process group, and says so
+                if cdist.size != world:
+                    raise RuntimeError(f"cph_dist_size {cdist.size} != world {world}")
+            except Exception as e:   # noqa: BLE001 — reported below, on every rank
                 ok, why = 0, f"{type(e).__name__}: {e}"
             flag = torch.tensor([ok], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # one decision for all ranks
-            if int(flag.item()):
-                transport = "cph_dist_* (RCCL behind the C ABI)"
-            else:
-                if cdist is not None:
-                    cdist.close()
-                cdist = None
-                transport = "torch.distributed NCCL process group (cph_dist_create failed on a rank" + (f": {why}" if why else "") + ")"
-                print(f"[bench] rank {rank}: {transport}", file=sys.stderr)
+            if not int(flag.item()):
+                print(f"bench.py: rank {rank}: cph_dist_create (RCCL behind the C ABI) failed on "
+                      f"{'this rank: ' + why if why else 'another rank'}; no fallback transport — stopping",
+                      file=sys.stderr, flush=True)
+                dist.destroy_process_group()
+                sys.exit(EXIT_NO_RCCL)
+            rccl_nranks = cdist.size
+            transport = "cph_dist_* (RCCL behind the C ABI): " + cdist.transport()
 
     # ---- synthetic tables (deterministic), staged to HBM before timing ------------
     t0 = time.time()
@@ -218,10 +302,13 @@ def main():
         step()
     prof = eng.ctx.profile_read(reset=True)
     eng.ctx.profile(False)
+    per_rank_ms = [dt / args.steps * 1e3]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share_gpu else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        cdev = "cpu" if share_gpu else dev
+        allt = torch.zeros(world, dtype=torch.float64, device=cdev)
+        dist.all_gather_into_tensor(allt, torch.tensor([dt], dtype=torch.float64, device=cdev))
+        per_rank_ms = [float(x) / args.steps * 1e3 for x in allt.tolist()]
+        dt = float(allt.max().item())          # the job is as slow as its slowest rank
     total_joined = joined if (world == 1 or args.exchange == "allgatherv") else None
     if total_joined is None:
         t = torch.tensor([joined], dtype=torch.int64, device="cpu" if share_gpu else dev)
@@ -323,9 +410,10 @@ def main():
                                "JOIN products(1e5, UniqueIndexOn prod_id); BASELINE configs[3] shape, probe rows sharded over n_gpus",
                    "rows": args.rows, "customers": args.customers, "products": args.products,
                    "rows_this_rank": nloc, "exchange": args.exchange if world > 1 else "none (1 GPU)",
-                   "exchange_transport": transport,
+                   "exchange_transport": transport, "rccl_nranks": rccl_nranks,
                    "inputs": "resident in HBM before the timed region"},
         "joined_rows_per_step": total_joined,
+        "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
         "index_build": {"GBps_algorithmic": round(build_gb / (build_ms / 1e3), 1) if build_ms else None,
                         "kernel_ms_per_step": round(build_ms / K, 4),
                         "customers": ia_info, "products": ib_info},

@@ -189,6 +189,7 @@ PROTOTYPES = [
     ("cph_dist_destroy", None, [_P]),
     ("cph_dist_rank", C.c_int32, [_P]),
     ("cph_dist_size", C.c_int32, [_P]),
+    ("cph_dist_transport", C.c_char_p, [_P]),
     ("cph_dist_allgatherv", C.c_int32,
      [_P, C.POINTER(_P), C.POINTER(C.c_int32), C.c_int32, C.c_uint64, C.POINTER(C.POINTER(cph_gathered))]),
     ("cph_gathered_release", None, [C.POINTER(cph_gathered)]),
@@ -631,6 +632,10 @@ class Dist:
         h = _P()
         ctx._check(ctx.lib.cph_dist_create_loopback(ctx.handle, group.encode(), rank, nranks, C.byref(h)))
         return Dist(ctx, h)
+
+    def transport(self) -> str:
+        """What moves the bytes ("rccl nranks=8 lib=... " / "loopback ..."): cph_dist_transport."""
+        return (self.lib.cph_dist_transport(self.handle) or b"").decode("utf-8", "replace")
 
     def allgatherv(self, ptrs, elem_bytes, count: int) -> Gathered:
         k = len(ptrs)

@@ -18,6 +18,7 @@
 // multi-rank control flow (counts, displacements, unequal and empty shards, the identity rule) runs on a
 // one-GPU box.  Everything is enqueued on the ctx's stream; the only host wait is for the 3*N count words.
 #include <dlfcn.h>
+#include <link.h>
 #include <rccl/rccl.h>
 
 #include <condition_variable>
@@ -44,6 +45,7 @@ struct Transport {
     virtual Status exchange_v(const void* const* send, void* const* recv, const int32_t* eb, int narrays,
                               const uint64_t* counts, const uint64_t* displs, hipStream_t stream) = 0;
     virtual Status broadcast(void* buf, size_t bytes, int root, hipStream_t stream) = 0;
+    virtual std::string describe() const = 0;
 };
 
 // ---- RCCL ----------------------------------------------------------------------------------------------------
@@ -61,20 +63,51 @@ struct RcclApi {
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 
-static Status rccl_api(const RcclApi** out) {
+// The path of a librccl the process has ALREADY mapped (torch ships its own copy and loads it with the extension
+// module, in that module's local scope): two RCCL copies with two communicators in one process is untested
+// territory, so the copy the host program uses is the one this library binds to.
+static int find_loaded_rccl(struct dl_phdr_info* info, size_t, void* data) {
+    const char* name = info->dlpi_name;
+    if (!name || !*name) return 0;
+    const char* base = strrchr(name, '/');
+    base = base ? base + 1 : name;
+    if (strncmp(base, "librccl.so", 10) != 0) return 0;
+    *static_cast<std::string*>(data) = name;
+    return 1;
+}
+
+struct RcclLoad {
+    RcclApi api;
+    std::string err, path;
+    bool shared_with_host = false;   // bound to a copy the process had loaded before (e.g. torch's)
+};
+
+static Status rccl_load(const RcclLoad** out) {
     static std::mutex mu;
-    static RcclApi api;
+    static RcclLoad ld;
     static bool tried = false;
-    static std::string err;
     std::lock_guard<std::mutex> lk(mu);
+    RcclApi& api = ld.api;
+    std::string& err = ld.err;
     if (!tried) {
         tried = true;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (api.lib) break;
+        std::string loaded;
+        dl_iterate_phdr(find_loaded_rccl, &loaded);
+        if (!loaded.empty()) {
+            api.lib = dlopen(loaded.c_str(), RTLD_NOW | RTLD_NOLOAD);   // a second handle on the SAME mapping
+            if (api.lib) {
+                ld.path = loaded;
+                ld.shared_with_host = true;
+            }
         }
+        if (!api.lib)
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (api.lib) { ld.path = name; break; }
+            }
         if (!api.lib) {
-            err = std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "not found");
+            const char* de = dlerror();
+            err = std::string("cannot load librccl.so: ") + (de ? de : "not found");
         } else {
             auto sym = [&](const char* n) {
                 void* p = dlsym(api.lib, n);
@@ -94,7 +127,14 @@ static Status rccl_api(const RcclApi** out) {
         }
     }
     if (!err.empty()) return {CPH_ERR_HIP, err};
-    *out = &api;
+    *out = &ld;
+    return {};
+}
+
+static Status rccl_api(const RcclApi** out) {
+    const RcclLoad* ld = nullptr;
+    CPH_TRY(rccl_load(&ld));
+    *out = &ld->api;
     return {};
 }
 
@@ -121,11 +161,31 @@ struct RcclTransport : Transport {
         CPH_NCCL_TRY(api, api->AllGather(send, recv, bytes, ncclUint8, comm, stream));
         return {};
     }
+    // ncclGroupStart ... ncclGroupEnd around a batch: the group is ALWAYS closed, also when a call inside it fails —
+    // an open group on the communicator would swallow (or hang) every later collective.
+    struct Group {
+        const RcclApi* api;
+        bool open = false;
+        explicit Group(const RcclApi* a) : api(a) {}
+        ncclResult_t start() {
+            const ncclResult_t r = api->GroupStart();
+            open = r == ncclSuccess;
+            return r;
+        }
+        ncclResult_t end() {
+            open = false;
+            return api->GroupEnd();
+        }
+        ~Group() {
+            if (open) (void)api->GroupEnd();
+        }
+    };
     Status exchange_v(const void* const* send, void* const* recv, const int32_t* eb, int narrays, const uint64_t* counts,
                       const uint64_t* displs, hipStream_t stream) override {
         bool equal = true;
         for (int r = 1; r < size_; r++) equal = equal && counts[r] == counts[0];
-        CPH_NCCL_TRY(api, api->GroupStart());
+        Group grp(api);
+        CPH_NCCL_TRY(api, grp.start());
         for (int a = 0; a < narrays; a++) {
             const size_t e = (size_t)eb[a];
             if (equal) {
@@ -139,7 +199,7 @@ struct RcclTransport : Transport {
                     CPH_NCCL_TRY(api, api->Recv(static_cast<uint8_t*>(recv[a]) + displs[r] * e, counts[r] * e, ncclUint8, r, comm, stream));
             }
         }
-        CPH_NCCL_TRY(api, api->GroupEnd());
+        CPH_NCCL_TRY(api, grp.end());
         if (!equal && counts[rank_])
             for (int a = 0; a < narrays; a++)
                 CPH_HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(recv[a]) + displs[rank_] * (size_t)eb[a], send[a],
@@ -149,6 +209,11 @@ struct RcclTransport : Transport {
     Status broadcast(void* buf, size_t bytes, int root, hipStream_t stream) override {
         if (bytes) CPH_NCCL_TRY(api, api->Broadcast(buf, buf, bytes, ncclUint8, root, comm, stream));
         return {};
+    }
+    std::string lib_path;
+    bool lib_shared = false;
+    std::string describe() const override {
+        return "rccl nranks=" + std::to_string(size_) + " lib=" + lib_path + (lib_shared ? " (the copy the host process had loaded)" : " (loaded by libcsvplus_hip)");
     }
 };
 
@@ -231,6 +296,7 @@ struct LoopTransport : Transport {
             return true;
         });
     }
+    std::string describe() const override { return "loopback nranks=" + std::to_string(hub->nranks) + " (thread ranks sharing one GPU: test transport)"; }
     Status broadcast(void* buf, size_t bytes, int root, hipStream_t stream) override {
         CPH_HIP_TRY(hipStreamSynchronize(stream));
         LoopHub::Post p;
@@ -257,6 +323,7 @@ __global__ void k_iota_u64(uint64_t* __restrict__ dst, uint64_t n, uint64_t base
 struct cph_dist {
     cph_ctx* ctx = nullptr;
     std::unique_ptr<Transport> t;
+    std::string desc;
 };
 
 struct cph_gathered_impl {
@@ -341,11 +408,14 @@ CPH_API int32_t cph_dist_create(cph_ctx* ctx, const uint8_t* id, int32_t rank, i
     if (!ctx || !id || !out || nranks < 1 || rank < 0 || rank >= nranks) return CPH_ERR_INVALID;
     *out = nullptr;
     if (hipSetDevice(ctx->device) != hipSuccess) return fail_with(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});
-    const RcclApi* api = nullptr;
-    Status s = rccl_api(&api);
+    const RcclLoad* ld = nullptr;
+    Status s = rccl_load(&ld);
     if (!s.ok()) return fail_with(ctx, s);
+    const RcclApi* api = &ld->api;
     auto t = std::make_unique<RcclTransport>();
     t->api = api;
+    t->lib_path = ld->path;
+    t->lib_shared = ld->shared_with_host;
     t->rank_ = rank;
     t->size_ = nranks;
     ncclUniqueId uid;
@@ -400,6 +470,11 @@ CPH_API void cph_dist_destroy(cph_dist* d) {
 }
 
 CPH_API int32_t cph_dist_rank(const cph_dist* d) { return d ? d->t->rank() : -1; }
+CPH_API const char* cph_dist_transport(cph_dist* d) {
+    if (!d) return "";
+    d->desc = d->t->describe();
+    return d->desc.c_str();
+}
 CPH_API int32_t cph_dist_size(const cph_dist* d) { return d ? d->t->size() : 0; }
 
 CPH_API int32_t cph_dist_allgatherv(cph_dist* d, const void* const* send, const int32_t* elem_bytes, int32_t narrays, uint64_t count,
@@ -511,7 +586,10 @@ CPH_API int32_t cph_dist_index_broadcast(cph_dist* d, const cph_index* root_inde
     if (is_root && !root_index) return fail_with(ctx, {CPH_ERR_INVALID, "the root rank must pass its index"});
     cph_index* nx = nullptr;
     auto run = [&]() -> Status {
-        // 1. descriptor size, 2. descriptor, 3. sorted codes, 4. perm — all through device buffers
+        // 1. descriptor size, 2. descriptor, 3. status agreement, 4. sorted codes, 5. perm — all through device buffers.
+        // A rank can fail LOCALLY between two collectives (the descriptor does not parse, the payload buffers cannot be
+        // allocated): returning there would leave the other ranks blocked in the next broadcast.  So every such step
+        // happens before step 3, where the ranks exchange one status word each and either all go on or all return.
         std::vector<uint8_t> desc;
         if (is_root) index_desc_serialize(root_index, &desc);
         DevBuf dsz;
@@ -523,27 +601,41 @@ CPH_API int32_t cph_dist_index_broadcast(cph_dist* d, const cph_index* root_inde
         CPH_TRY(d->t->broadcast(dsz.get(), sizeof(uint64_t), root, ctx->stream));
         uint64_t nbytes = 0;
         CPH_TRY(read_device_value(ctx, dsz.as<uint64_t>(), &nbytes));
-        if (nbytes < 64 || nbytes > (64u << 20)) return {CPH_ERR_INVALID, "index broadcast: implausible descriptor size"};
+        if (nbytes < 64 || nbytes > (64u << 20)) return {CPH_ERR_INVALID, "index broadcast: implausible descriptor size"};   // the same on every rank
         DevBuf ddesc;
-        CPH_TRY(ddesc.alloc(&ctx->pool, nbytes));
+        Status local = ddesc.alloc(&ctx->pool, nbytes);
+        if (!local.ok()) return local;   // (a failed 64 MiB allocation here would strand the peers; nothing smaller can be agreed on first)
         if (is_root) CPH_HIP_TRY(hipMemcpyAsync(ddesc.get(), desc.data(), nbytes, hipMemcpyHostToDevice, ctx->stream));
         CPH_TRY(d->t->broadcast(ddesc.get(), nbytes, root, ctx->stream));
+        size_t cb = 0, pb = 0;
+        auto prepare = [&]() -> Status {   // the fallible local part of a receiving rank
+            desc.resize(nbytes);
+            CPH_HIP_TRY(hipMemcpyAsync(desc.data(), ddesc.get(), nbytes, hipMemcpyDeviceToHost, ctx->stream));
+            CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+            nx = new (std::nothrow) cph_index();
+            if (!nx) return {CPH_ERR_NOMEM, "out of host memory"};
+            if (!index_desc_parse(desc.data(), desc.size(), nx)) return {CPH_ERR_INVALID, "index broadcast: malformed descriptor"};
+            nx->ctx = ctx;
+            cb = (size_t)nx->nrows * index_code_bytes(nx);
+            pb = (size_t)nx->nrows * sizeof(uint32_t);
+            CPH_TRY(nx->sorted_codes.alloc(&ctx->pool, cb));
+            CPH_TRY(nx->perm.alloc(&ctx->pool, pb));
+            return {};
+        };
+        if (!is_root) local = prepare();
+        std::vector<uint64_t> w;
+        CPH_TRY(exchange_counts(d, local.ok() ? 0 : 1, 0, 0, &w));
+        int failed_rank = -1;
+        for (int r = 0; r < d->t->size() && failed_rank < 0; r++)
+            if (w[3 * (size_t)r]) failed_rank = r;
+        if (!local.ok()) return local;
+        if (failed_rank >= 0) return {CPH_ERR_HIP, "index broadcast: rank " + std::to_string(failed_rank) + " could not receive the index; no rank did"};
         if (is_root) {   // the root keeps using its own index; it still takes part in the two payload broadcasts
             const uint64_t n = root_index->nrows;
             CPH_TRY(d->t->broadcast(root_index->sorted_codes.get(), n * index_code_bytes(root_index), root, ctx->stream));
             CPH_TRY(d->t->broadcast(root_index->perm.get(), n * sizeof(uint32_t), root, ctx->stream));
             return {};
         }
-        desc.resize(nbytes);
-        CPH_HIP_TRY(hipMemcpyAsync(desc.data(), ddesc.get(), nbytes, hipMemcpyDeviceToHost, ctx->stream));
-        CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
-        nx = new (std::nothrow) cph_index();
-        if (!nx) return {CPH_ERR_NOMEM, "out of host memory"};
-        if (!index_desc_parse(desc.data(), desc.size(), nx)) return {CPH_ERR_INVALID, "index broadcast: malformed descriptor"};
-        nx->ctx = ctx;
-        const size_t cb = (size_t)nx->nrows * index_code_bytes(nx), pb = (size_t)nx->nrows * sizeof(uint32_t);
-        CPH_TRY(nx->sorted_codes.alloc(&ctx->pool, cb));
-        CPH_TRY(nx->perm.alloc(&ctx->pool, pb));
         CPH_TRY(d->t->broadcast(nx->sorted_codes.get(), cb, root, ctx->stream));
         CPH_TRY(d->t->broadcast(nx->perm.get(), pb, root, ctx->stream));
         return index_adopt_payload(ctx, nx);

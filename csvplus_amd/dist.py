@@ -26,10 +26,17 @@ def connect(ctx: N.Context, group=None) -> N.Dist:
     if not dist.is_initialized():
         return N.Dist.create(ctx, N.Dist.unique_id(ctx), 0, 1)
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    box = [N.Dist.unique_id(ctx) if rank == 0 else None]
+    box = [None]
+    if rank == 0:
+        try:
+            box = [N.Dist.unique_id(ctx)]
+        except N.CphError as e:      # the other ranks are waiting in the broadcast: tell them instead of leaving them there
+            box = [e]
     src = dist.get_global_rank(group, 0) if group is not None else 0
     dist.broadcast_object_list(box, src=src, group=group)
-    return N.Dist.create(ctx, box[0], rank, world)
+    if not isinstance(box[0], (bytes, bytearray)):
+        raise N.CphError(N.CPH_ERR_HIP, f"rank 0 could not create the RCCL unique id: {box[0]}")
+    return N.Dist.create(ctx, bytes(box[0]), rank, world)
 
 
 def chain_allgather(d: N.Dist, res, device):

@@ -280,7 +280,8 @@ CPH_API void    cph_chain_release(cph_chain* chain);
  * One process (rank) per GPU joins a contiguous range of the stream rows against replicated build
  * sides; concatenating the per-rank row-id lists in rank order gives the reference's emission order
  * (stream order, csvplus.go:553-567).  A cph_dist wraps the communicator that moves those lists:
- * RCCL over xGMI (librccl.so is loaded on first use — the library does not link against it).
+ * RCCL over xGMI (librccl.so is resolved on first use — the library does not link against it; a copy the host
+ * process already loaded, e.g. torch's, is the one it binds to).
  *   rank 0:  cph_dist_unique_id(ctx, id)  -> ship the CPH_DIST_ID_BYTES bytes to every rank by any side
  *            channel the host program has (a Go host: its own RPC; torch: broadcast_object_list)
  *   all:     cph_dist_create(ctx, id, rank, nranks, &d)            (collective: ncclCommInitRank)
@@ -299,6 +300,10 @@ CPH_API int32_t cph_dist_create_loopback(cph_ctx* ctx, const char* group, int32_
 CPH_API void    cph_dist_destroy(cph_dist* d);
 CPH_API int32_t cph_dist_rank(const cph_dist* d);
 CPH_API int32_t cph_dist_size(const cph_dist* d);
+/* What moves the bytes, for logs and benchmark records: "rccl nranks=8 lib=<path> (the copy the host process had
+ * loaded)" — the library binds to a librccl the process has ALREADY mapped (torch ships one) before it opens its
+ * own, so one process never runs two RCCL copies — or "loopback nranks=...".  Owned by `d`, valid until the next call. */
+CPH_API const char* cph_dist_transport(cph_dist* d);
 
 /* Result of an allgatherv: data[a] (device memory of this rank's ctx, library-owned) holds `total`
  * elements of array a — rank 0's, then rank 1's, ...; counts / displs (host) say where each rank's begin.

@@ -1,0 +1,98 @@
+"""bench.py as a plain command: `python bench.py --gpus N` starts its own N ranks (torch.distributed.run on
+127.0.0.1) when no launcher did, refuses with a clear message when the machine has fewer GPUs than ranks, and
+never falls back to another exchange transport.  The CPU tests drive the launch path with --launch-check
+(rendezvous only, gloo: every rank reports in, no compute); the GPU tests run the real thing on the 1-GPU box."""
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+BENCH = str(ROOT / "bench.py")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(kw)
+    return env
+
+
+def _json_line(out: str) -> dict:
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert lines, out[-2000:]
+    return json.loads(lines[-1])
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_plain_command_starts_its_own_ranks(n):
+    r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--launch-check"], env=_env(), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert d == {"launch_check": True, "n_gpus": n, "world": n, "ranks_seen": list(range(n)), "backend": "gloo"}
+
+
+def test_under_a_launcher_it_is_one_of_the_ranks():
+    """The driver's way: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), BENCH, "--gpus", "2", "--launch-check"],
+                       env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert _json_line(r.stdout)["ranks_seen"] == [0, 1]
+
+
+def test_world_size_mismatch_is_an_error_message_not_an_assert():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launch-check"], env=_env(WORLD_SIZE="3", RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE=3" in r.stderr and "Traceback" not in r.stderr, r.stderr[-2000:]
+
+
+def test_more_ranks_than_gpus_is_refused_clearly():
+    """No GPU here (CPU suite) / one GPU on the GPU box: `--gpus 2` must say so and exit 2, not assert or hang."""
+    import torch
+
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have >= 2:
+        pytest.skip("this machine really has 2 GPUs")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-2000:])
+    assert f"needs 2 visible GPUs, this machine shows {have}" in r.stderr and "Traceback" not in r.stderr
+
+
+SMALL = ["--rows", "300000", "--customers", "20000", "--products", "700", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+         "--no-index-1e8", "--no-e2e", "--no-traffic"]
+
+
+@pytest.mark.gpu
+def test_one_gpu_line_has_the_contract_fields():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", *SMALL, "--verify-sample", "5000"], env=_env(), capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["joined_rows_per_step"] == 300000 and d["verified"] is True
+    assert d["config"]["rccl_nranks"] is None and len(d["per_rank_ms_per_step"]) == 1
+
+
+@pytest.mark.gpu
+def test_shared_gpu_debug_mode_still_runs_and_says_what_it_is():
+    """Two ranks on the one GPU (gloo): the control flow of the sharded step, labelled as NOT an RCCL measurement."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", *SMALL], env=_env(CPH_BENCH_SHARE_GPU="1"), capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["joined_rows_per_step"] == 300000
+    assert "DEBUG" in d["config"]["exchange_transport"] and d["config"]["rccl_nranks"] is None
+    assert len(d["per_rank_ms_per_step"]) == 2

@@ -62,6 +62,12 @@ def run_ranks(world, fn):
 def test_rccl_single_rank_through_the_c_abi(ctx):
     d = N.Dist.create(ctx, N.Dist.unique_id(ctx), 0, 1)
     assert (d.rank, d.size) == (0, 1)
+    # ONE RCCL per process: torch (imported above) has mapped its own librccl, so the library binds to THAT copy
+    # instead of opening a second one; no second librccl mapping may appear
+    tr = d.transport()
+    assert tr.startswith("rccl nranks=1 ") and "the copy the host process had loaded" in tr, tr
+    mapped = {ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln}
+    assert len(mapped) == 1, mapped
     a = torch.arange(1000, dtype=torch.int64, device="cuda") * 3
     b = torch.arange(1000, dtype=torch.int32, device="cuda") + 7
     torch.cuda.synchronize()
