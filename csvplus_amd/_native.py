@@ -92,6 +92,9 @@ class cph_index_info(C.Structure):
         ("direct_table", C.c_int32),
         ("dict_entries", C.c_int32),
         ("table_entries", C.c_uint64),
+        ("lookup_built", C.c_int32),
+        ("hash_mode", C.c_int32),
+        ("hash_bytes", C.c_uint64),
     ]
 
 
@@ -232,6 +235,7 @@ PROTOTYPES = [
     ("cph_index_find", C.c_int32,
      [_P, _P, C.POINTER(cph_strval), C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("cph_index_get_info", C.c_int32, [_P, C.POINTER(cph_index_info)]),
+    ("cph_index_prepare_join", C.c_int32, [_P, C.c_int32]),
 ]
 
 _lib = None
@@ -425,6 +429,10 @@ class DeviceIndex:
         if rc != CPH_OK:
             raise CphError(rc, "cph_index_get_info")
         return {k: int(getattr(inf, k)) for k, _ in cph_index_info._fields_ if k != "reserved_"}
+
+    def prepare_join(self, chained: bool = False) -> None:
+        """Builds the Join lookup structure (direct table / hash table) now instead of inside the first Join."""
+        self.ctx._check(self.lib.cph_index_prepare_join(self.handle, 1 if chained else 0))
 
     def probe(self, probecols, row_sel=None, probe_base: int = 0, want_pairs: bool = True,
               out_mem: int = CPH_MEM_HOST, sel_base: int = 0) -> "Matches":

@@ -162,12 +162,15 @@ Status kernel_setup(cph_ctx* ctx, const void* fn, int threads, size_t lds, int* 
             if (blocks_per_cu) *blocks_per_cu = k.blocks_per_cu;
             return {};
         }
-    if (lds > 0) CPH_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // the attribute is a high-water mark per function: only ever raise it, so that a smaller request later (another
+    // index's smaller codec block) cannot lower it under an earlier, larger user of the same kernel
+    size_t high = 0;
+    for (const auto& k : ctx->kernel_cfg)
+        if (k.fn == fn && k.lds > high) high = k.lds;
+    if (lds > high) CPH_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 0;
     CPH_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds));
     if (per_cu < 1) per_cu = 1;
-    // the attribute is a high-water mark per function: remember the largest request so that a smaller one
-    // later does not lower it under a concurrent user of the same ctx's other indexes
     ctx->kernel_cfg.push_back({fn, lds, per_cu});
     if (blocks_per_cu) *blocks_per_cu = per_cu;
     return {};
@@ -680,6 +683,7 @@ CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value
     else if (k == "sort_digit_stream") ctx->sort_digit_stream = value != 0;
     else if (k == "sort_xcd_tiles") ctx->sort_xcd_tiles = value != 0;
     else if (k == "codec_debug") ctx->codec_debug = value != 0;
+    else if (k == "join_hash") ctx->join_hash = value != 0;
     else if (k == "plan_threads") ctx->plan_threads = (int)value;
     else if (k == "gstats_threads") ctx->gstats_threads = (int)value;
     else if (k == "speculative_groups") ctx->speculative_groups = value < 0 || value > 2 ? 1 : (int)value;   // 0 never, 1 when the sample shows no rare value, 2 always
@@ -1161,6 +1165,23 @@ CPH_API int32_t cph_index_get_info(const cph_index* ix, cph_index_info* info) {
     info->direct_table = ix->table_entries ? 1 : 0;
     info->table_entries = ix->table_entries;
     info->dict_entries = (int32_t)ix->codec.dict.size();
+    info->lookup_built = (ix->table ? 1 : 0) | (ix->rowtab ? 2 : 0) | (ix->hash_mode ? 4 : 0);
+    info->hash_mode = ix->hash_mode;
+    info->hash_bytes = (uint64_t)ix->hash_sectors * 64;
+    return CPH_OK;
+}
+
+CPH_API int32_t cph_index_prepare_join(cph_index* ix, int32_t chained) {
+    if (!ix || !ix->ctx) return CPH_ERR_INVALID;
+    cph_ctx* ctx = ix->ctx;
+    Status s = enter(ctx);
+    if (!s.ok()) return fail(ctx, s);
+    if (ix->nrows == 0) return CPH_OK;
+    if (ix->table_entries && ix->windows.empty()) {
+        s = chained && ix->first_dup == UINT64_MAX ? index_ensure_rowtab(ctx, ix) : index_ensure_table(ctx, ix);
+    }
+    if (s.ok() && !ix->table && !ix->rowtab) s = index_ensure_hash(ctx, ix);
+    if (!s.ok()) return fail(ctx, s);
     return CPH_OK;
 }
 

@@ -47,7 +47,10 @@ constexpr int kMaxChain     = CPH_MAX_CHAIN;
 struct ChainStepArg {
     DevCol col;                 // the stream's key column for this step
     const uint8_t* codec;       // codec block of the step's index (global memory)
-    const uint32_t* rowtab;     // code -> build row (0xFFFFFFFF: absent), or nullptr -> binary search
+    const uint32_t* rowtab;     // code -> build row (0xFFFFFFFF: absent), or nullptr
+    const uint4* hash;          // no rowtab: hash table over the codes (hash_device.hpp, kHashK1 entries), or nullptr -> binary search
+    uint32_t hash_sectors;
+    uint32_t reserved_;
     const void* codes;          // sorted codes (u32 if key32 else u64)
     const uint32_t* perm;
     uint64_t n_index;
@@ -131,6 +134,30 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
                 for (int k = 0; k < kChainRows; k++) {
                     const CW cidx = (okm >> k) & 1u ? code[s][k] : (CW)0;   // entry 0 always exists
                     brow[s][k] = (DBG && (dbg & 1)) ? 0u : st.rowtab[cidx];
+                }
+            } else if (st.hash) {
+                // sparse code space: the home sectors of 4 rows at a time are loaded together (16 x 16 bytes in flight
+                // per lane); entry.aux is the build row (duplicate-free index)
+                const HashView hv{st.hash, st.hash_sectors};
+#pragma unroll
+                for (int g = 0; g < kChainRows; g += 4) {
+                    HashSector sc[4];
+                    uint32_t home[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        home[k] = hash_home(hash_one((uint64_t)code[s][g + k]), hv.nsectors);
+                        sc[k] = hash_load_sector(hv, (okm >> (g + k)) & 1u ? home[k] : 0u);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        uint32_t l, a;
+                        bool more;
+                        bool hit = hash_match16(sc[k], (uint64_t)code[s][g + k], &l, &a, &more);
+                        const bool live = (okm >> (g + k)) & 1u;
+                        if (live && more) hit = hash_continue16(hv, home[k], (uint64_t)code[s][g + k], &l, &a);   // rare
+                        brow[s][g + k] = (hit && live && !(DBG && (dbg & 1))) ? a : kTableAbsent;
+                        if (DBG && (dbg & 1)) brow[s][g + k] = 0u;
+                    }
                 }
             } else {
 #pragma unroll
@@ -262,8 +289,19 @@ static Status enqueue_dense(cph_ctx* ctx, const ChainStep* steps, uint64_t nprob
         st.col = steps[s].cols[0];
         st.codec = ix->codec_dev.as<uint8_t>();
         st.codec_bytes = (int32_t)ix->codec_dev.bytes();
-        CPH_TRY(index_ensure_rowtab(ctx, ix));   // no-op once built (on the index's own ctx: see stream_join.hip)
+        // lookup structure of the step, built on first use (on the index's own ctx; other ctxs wait for it): the
+        // 4-byte row table over a dense code space, else the hash table, else (allocation failed) the sorted codes
+        CPH_TRY(index_ensure_rowtab(ctx, ix));
         st.rowtab = ix->rowtab ? ix->rowtab.as<uint32_t>() : nullptr;
+        st.hash = nullptr;
+        st.hash_sectors = 0;
+        if (!st.rowtab && index_wants_hash(ix)) {
+            CPH_TRY(index_ensure_hash(ctx, ix));
+            if (ix->hash_mode == kHashK1) {
+                st.hash = ix->hash.as<uint4>();
+                st.hash_sectors = ix->hash_sectors;
+            }
+        }
         st.codes = ix->sorted_codes.get();
         st.perm = ix->perm.as<uint32_t>();
         st.n_index = ix->nrows;

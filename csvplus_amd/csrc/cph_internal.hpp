@@ -229,6 +229,7 @@ struct cph_ctx {
     int sort_threads = 0, sort_rbits = 0;   // radix-sort tuning overrides (0: automatic)
     int sort_digit_stream = 1;     // scatter writes the next pass's digits as a byte stream for its histogram (radix_sort.hip)
     int sort_xcd_tiles = 1;        // scatter: contiguous tile ranges per XCD (radix_sort.hip)
+    int join_hash = 1;             // 0: indexes of this ctx never get a hash table (A/B switch: sorted search instead)
     int codec_debug = 0;           // prints the window choice of codec_try_groups to stderr
     int plan_threads = 0, gstats_threads = 0;   // tuning: workgroup sizes of k_encode_build_plan / k_group_stats (0: default)
     int speculative_groups = 1;    // dictionaries of large inputs from a sample, completed by the encode kernel (keycodec.hip):
@@ -276,6 +277,17 @@ struct cph_index {
     cph::DevBuf rowtab;            // duplicate-free index: u32[table_entries], code -> build row (0xFFFFFFFF: absent);
                                    // 4-byte entries for the chained-join kernel (half the random-access footprint)
     uint64_t table_entries = 0;    // != 0: the code space is dense enough for a table (decided at build time)
+    // hash table over the codes for every other index (hash_device.hpp), built by the first full-key Join
+    cph::DevBuf hash;              // hash_sectors x 64 bytes
+    uint32_t hash_sectors = 0;
+    int32_t hash_mode = 0;         // kHashNone until built, then kHashK1 / kHashK2 / kHashTag
+    bool accel_failed = false;     // a lookup structure could not be allocated (or tags collided): sorted search from now on
+    // Lookup structures are built on the INDEX's ctx (its stream, its pool: they live and die with the index); the
+    // event is recorded behind the newest one, and a Join running on another ctx makes its stream wait for it.
+    hipEvent_t accel_ready = nullptr;
+    ~cph_index() {
+        if (accel_ready) (void)hipEventDestroy(accel_ready);
+    }
     int32_t sort_passes = 0;
     uint64_t first_dup = UINT64_MAX;
     uint32_t* perm_host = nullptr; // pinned copy (lazy)
@@ -389,8 +401,13 @@ Status fill_iota_u32(cph_ctx* ctx, uint32_t* dst, uint64_t n);
 Status index_first_dup_launch(cph_ctx* ctx, cph_index* ix);
 Status index_first_dup_read(cph_ctx* ctx, cph_index* ix);
 void index_plan_table(cph_index* ix);                               // host decision only (table_entries)
-Status index_ensure_table(cph_ctx* ctx, const cph_index* ix);       // 8-byte entries, built on first use
+// Lookup structures of Join, built on first use ON THE INDEX'S CTX (ix->ctx: its stream and pool); `ctx` is the
+// caller's: when it is another one its stream is made to wait for the build.  An allocation failure is not an
+// error: the index is marked (accel_failed) and the callers use the sorted search.
+Status index_ensure_table(cph_ctx* ctx, const cph_index* ix);       // 8-byte entries {lo,row} / {lo,end}
 Status index_ensure_rowtab(cph_ctx* ctx, const cph_index* ix);      // 4-byte build rows (duplicate-free indexes)
+Status index_ensure_hash(cph_ctx* ctx, const cph_index* ix);        // hash table over the codes (hash_device.hpp)
+bool index_wants_hash(const cph_index* ix);                         // no direct table planned and rows to look up
 struct ProbeOut {
     DevBuf lo, cnt, pidx, brow;
     uint64_t nprobe = 0, nmatches = 0;

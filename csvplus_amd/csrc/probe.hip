@@ -118,58 +118,271 @@ void index_plan_table(cph_index* ix) {
     ix->table_entries = states;
 }
 
+// Where an index's lookup structures are built: on the ctx the index belongs to — its pool (the blocks live and die
+// with the index, whatever ctx happened to run the first Join) and its stream.  accel_done() records the event other
+// ctxs order themselves behind; accel_wait() is that ordering (a no-op for the index's own ctx: same stream).
+static cph_ctx* accel_ctx(cph_ctx* ctx, const cph_index* ix) { return ix->ctx ? ix->ctx : ctx; }
+static Status accel_done(cph_ctx* bctx, cph_index* ix) {
+    if (!ix->accel_ready) CPH_HIP_TRY(hipEventCreateWithFlags(&ix->accel_ready, hipEventDisableTiming));
+    CPH_HIP_TRY(hipEventRecord(ix->accel_ready, bctx->stream));
+    return {};
+}
+static Status accel_wait(cph_ctx* ctx, const cph_index* ix) {
+    if (ix->accel_ready && ctx != ix->ctx && ctx->stream != accel_ctx(ctx, ix)->stream)
+        CPH_HIP_TRY(hipStreamWaitEvent(ctx->stream, ix->accel_ready, 0));
+    return {};
+}
+// A lookup structure that cannot be allocated is not an error of the Join: the sorted codes still answer every probe.
+static bool accel_alloc(cph_ctx* bctx, cph_index* ix, DevBuf* buf, size_t bytes) {
+    Status s = buf->alloc(&bctx->pool, bytes);
+    if (s.ok()) return true;
+    ix->accel_failed = true;
+    ix->table_entries = 0;
+    return false;
+}
+
 Status index_ensure_table(cph_ctx* ctx, const cph_index* cix) {
     cph_index* ix = const_cast<cph_index*>(cix);   // a cache inside the index; a ctx is single-threaded
-    if (!ix->table_entries || ix->table) return {};
+    if (!ix->table_entries || ix->accel_failed) return {};
+    if (ix->table) return accel_wait(ctx, ix);
+    cph_ctx* bctx = accel_ctx(ctx, ix);
     const uint64_t n = ix->nrows, states = ix->table_entries;
     DevBuf t;
-    CPH_TRY(t.alloc(&ctx->pool, states * sizeof(TableEntry)));
-    CPH_HIP_TRY(hipMemsetAsync(t.get(), 0xFF, states * sizeof(TableEntry), ctx->stream));
-    ProfScope ps(ctx, "k_build_table", (double)n * (ix->codec.key32 ? 4.0 : 8.0) + 4.0 * (double)n + 8.0 * (double)n);
-    const dim3 grid(grid_for_items(n)), block(256);
-    const bool unique = ix->first_dup == UINT64_MAX;
-    if (ix->codec.key32)
-        hipLaunchKernelGGL(k_build_table<uint32_t>, grid, block, 0, ctx->stream, ix->sorted_codes.as<uint32_t>(),
-                           ix->perm.as<uint32_t>(), n, unique, t.as<TableEntry>());
-    else
-        hipLaunchKernelGGL(k_build_table<uint64_t>, grid, block, 0, ctx->stream, ix->sorted_codes.as<uint64_t>(),
-                           ix->perm.as<uint32_t>(), n, unique, t.as<TableEntry>());
-    CPH_HIP_TRY(hipGetLastError());
+    if (!accel_alloc(bctx, ix, &t, states * sizeof(TableEntry))) return {};
+    CPH_HIP_TRY(hipMemsetAsync(t.get(), 0xFF, states * sizeof(TableEntry), bctx->stream));
+    {
+        ProfScope ps(bctx, "k_build_table", (double)n * (ix->codec.key32 ? 4.0 : 8.0) + 4.0 * (double)n + 8.0 * (double)n);
+        const dim3 grid(grid_for_items(n)), block(256);
+        const bool unique = ix->first_dup == UINT64_MAX;
+        if (ix->codec.key32)
+            hipLaunchKernelGGL(k_build_table<uint32_t>, grid, block, 0, bctx->stream, ix->sorted_codes.as<uint32_t>(),
+                               ix->perm.as<uint32_t>(), n, unique, t.as<TableEntry>());
+        else
+            hipLaunchKernelGGL(k_build_table<uint64_t>, grid, block, 0, bctx->stream, ix->sorted_codes.as<uint64_t>(),
+                               ix->perm.as<uint32_t>(), n, unique, t.as<TableEntry>());
+        CPH_HIP_TRY(hipGetLastError());
+    }
     ix->table = std::move(t);
-    return {};
+    CPH_TRY(accel_done(bctx, ix));
+    return accel_wait(ctx, ix);
 }
 
 Status index_ensure_rowtab(cph_ctx* ctx, const cph_index* cix) {
     cph_index* ix = const_cast<cph_index*>(cix);
-    if (!ix->table_entries || ix->rowtab || ix->first_dup != UINT64_MAX) return {};
+    if (!ix->table_entries || ix->accel_failed || ix->first_dup != UINT64_MAX) return {};
+    if (ix->rowtab) return accel_wait(ctx, ix);
+    cph_ctx* bctx = accel_ctx(ctx, ix);
     const uint64_t n = ix->nrows, states = ix->table_entries;
     DevBuf t;
-    CPH_TRY(t.alloc(&ctx->pool, states * sizeof(uint32_t)));
-    CPH_HIP_TRY(hipMemsetAsync(t.get(), 0xFF, states * sizeof(uint32_t), ctx->stream));
-    ProfScope ps(ctx, "k_build_table", (double)n * (ix->codec.key32 ? 4.0 : 8.0) + 4.0 * (double)n + 4.0 * (double)n);
-    const dim3 grid(grid_for_items(n)), block(256);
-    if (ix->codec.key32)
-        hipLaunchKernelGGL(k_build_rowtab<uint32_t>, grid, block, 0, ctx->stream, ix->sorted_codes.as<uint32_t>(),
-                           ix->perm.as<uint32_t>(), n, t.as<uint32_t>());
-    else
-        hipLaunchKernelGGL(k_build_rowtab<uint64_t>, grid, block, 0, ctx->stream, ix->sorted_codes.as<uint64_t>(),
-                           ix->perm.as<uint32_t>(), n, t.as<uint32_t>());
-    CPH_HIP_TRY(hipGetLastError());
+    if (!accel_alloc(bctx, ix, &t, states * sizeof(uint32_t))) return {};
+    CPH_HIP_TRY(hipMemsetAsync(t.get(), 0xFF, states * sizeof(uint32_t), bctx->stream));
+    {
+        ProfScope ps(bctx, "k_build_table", (double)n * (ix->codec.key32 ? 4.0 : 8.0) + 4.0 * (double)n + 4.0 * (double)n);
+        const dim3 grid(grid_for_items(n)), block(256);
+        if (ix->codec.key32)
+            hipLaunchKernelGGL(k_build_rowtab<uint32_t>, grid, block, 0, bctx->stream, ix->sorted_codes.as<uint32_t>(),
+                               ix->perm.as<uint32_t>(), n, t.as<uint32_t>());
+        else
+            hipLaunchKernelGGL(k_build_rowtab<uint64_t>, grid, block, 0, bctx->stream, ix->sorted_codes.as<uint64_t>(),
+                               ix->perm.as<uint32_t>(), n, t.as<uint32_t>());
+        CPH_HIP_TRY(hipGetLastError());
+    }
     ix->rowtab = std::move(t);
-    return {};
+    CPH_TRY(accel_done(bctx, ix));
+    return accel_wait(ctx, ix);
+}
+
+// ---------------------------------------------------------------------------------------------
+// hash table over the codes (hash_device.hpp): one entry per distinct key
+// ---------------------------------------------------------------------------------------------
+struct CodesView {
+    const void* p;
+    uint64_t n;
+    int32_t nwords;
+    int32_t key32;
+};
+__device__ __forceinline__ uint64_t code_word(const CodesView& c, int w, uint64_t i) {
+    return c.key32 ? (uint64_t) reinterpret_cast<const uint32_t*>(c.p)[i] : reinterpret_cast<const uint64_t*>(c.p)[(uint64_t)w * c.n + i];
+}
+__device__ __forceinline__ bool codes_equal(const CodesView& c, uint64_t i, uint64_t j) {
+    bool eq = true;
+    for (int w = 0; w < c.nwords && eq; w++) eq = code_word(c, w, i) == code_word(c, w, j);
+    return eq;
+}
+__device__ __forceinline__ uint64_t codes_hash(const CodesView& c, uint64_t i) {
+    uint64_t s = kHashSeed;
+    for (int w = 0; w < c.nwords; w++) s = hash_step(s, code_word(c, w, i));
+    return hash_finish(s);
+}
+
+// Claims the first empty slot of the probe sequence (a slot is claimed by a CAS on its first 8 bytes and never given
+// back, which is what lets a lookup stop at a sector with an empty slot).  Returns the claimed entry.  TAG mode: a
+// claimed slot that already holds this very tag belongs to a DIFFERENT key (only distinct keys are inserted).
+template <int MODE>
+__device__ __forceinline__ uint4* hash_claim(uint4* sectors, uint32_t nsectors, uint64_t h, uint64_t key, uint32_t* collision) {
+    constexpr int kSlots = MODE == kHashK2 ? 2 : 4, kStride = MODE == kHashK2 ? 2 : 1;
+    uint32_t s = hash_home(h, nsectors);
+    for (;;) {
+        uint4* sec = sectors + (uint64_t)s * 4;
+        for (int j = 0; j < kSlots; j++) {
+            unsigned long long* kp = reinterpret_cast<unsigned long long*>(sec + j * kStride);
+            unsigned long long cur = __hip_atomic_load(kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == kHashEmpty) cur = atomicCAS(kp, (unsigned long long)kHashEmpty, (unsigned long long)key);
+            if (cur == kHashEmpty) return sec + j * kStride;
+            if (MODE == kHashTag && cur == key) *collision = 1u;
+        }
+        s = s + 1 == nsectors ? 0 : s + 1;
+    }
+}
+
+// heads of the runs of equal keys insert {key, lo, aux}; aux = perm[lo] for a duplicate-free index (0 otherwise:
+// k_hash_set_ends fills in the end of the run)
+template <int MODE>
+__global__ void k_hash_build(CodesView cv, const uint32_t* __restrict__ perm, bool unique, uint4* __restrict__ sectors,
+                             uint32_t nsectors, uint32_t* __restrict__ collision) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cv.n; i += stride) {
+        if (i != 0 && codes_equal(cv, i, i - 1)) continue;
+        const uint32_t aux = unique ? perm[i] : 0u;
+        if constexpr (MODE == kHashK1) {
+            const uint64_t c = code_word(cv, 0, i);
+            uint4* e = hash_claim<MODE>(sectors, nsectors, hash_one(c), c, collision);
+            e->z = (uint32_t)i;
+            e->w = aux;
+        } else if constexpr (MODE == kHashK2) {
+            const uint64_t w0 = code_word(cv, 0, i), w1 = code_word(cv, 1, i);
+            uint4* e = hash_claim<MODE>(sectors, nsectors, hash_two(w0, w1), w0, collision);
+            e[0].z = (uint32_t)w1;
+            e[0].w = (uint32_t)(w1 >> 32);
+            e[1].x = (uint32_t)i;
+            e[1].y = aux;
+        } else {
+            const uint64_t h = codes_hash(cv, i);
+            uint4* e = hash_claim<MODE>(sectors, nsectors, h, hash_tag(h), collision);
+            e->z = (uint32_t)i;
+            e->w = aux;
+        }
+    }
+}
+
+// index with duplicate keys: the LAST row of every run looks its key up and stores the end of the run
+template <int MODE>
+__global__ void k_hash_set_ends(CodesView cv, uint4* __restrict__ sectors, uint32_t nsectors) {
+    constexpr int kSlots = MODE == kHashK2 ? 2 : 4, kStride = MODE == kHashK2 ? 2 : 1;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cv.n; i += stride) {
+        if (i + 1 != cv.n && codes_equal(cv, i, i + 1)) continue;
+        uint64_t h, key, w1 = 0;
+        if constexpr (MODE == kHashK1) {
+            key = code_word(cv, 0, i);
+            h = hash_one(key);
+        } else if constexpr (MODE == kHashK2) {
+            key = code_word(cv, 0, i);
+            w1 = code_word(cv, 1, i);
+            h = hash_two(key, w1);
+        } else {
+            h = codes_hash(cv, i);
+            key = hash_tag(h);
+        }
+        uint32_t s = hash_home(h, nsectors);
+        bool done = false;
+        while (!done) {
+            uint4* sec = sectors + (uint64_t)s * 4;
+            for (int j = 0; j < kSlots && !done; j++) {
+                uint4* e = sec + j * kStride;
+                const uint64_t k = hash_key_of(*e);
+                if (k == kHashEmpty) done = true;   // cannot happen for a key that was inserted
+                if (k != key) continue;
+                if constexpr (MODE == kHashK2) {
+                    if (((uint64_t)e->z | ((uint64_t)e->w << 32)) != w1) continue;
+                    e[1].y = (uint32_t)(i + 1);
+                } else {
+                    // TAG: distinct keys have distinct tags (checked by the build), so the tag identifies the run
+                    e->w = (uint32_t)(i + 1);
+                }
+                done = true;
+            }
+            s = s + 1 == nsectors ? 0 : s + 1;
+        }
+    }
+}
+
+bool index_wants_hash(const cph_index* ix) { return ix->nrows != 0 && ix->table_entries == 0; }
+
+Status index_ensure_hash(cph_ctx* ctx, const cph_index* cix) {
+    cph_index* ix = const_cast<cph_index*>(cix);
+    if (!index_wants_hash(ix) || ix->accel_failed) return {};
+    if (ix->hash_mode != kHashNone) return accel_wait(ctx, ix);
+    cph_ctx* bctx = accel_ctx(ctx, ix);
+    if (!bctx->join_hash) return {};   // A/B switch of the index's ctx
+    const uint64_t n = ix->nrows;
+    const int nw = ix->total_words();
+    const int mode = !ix->windows.empty() ? kHashTag : nw == 1 ? kHashK1 : nw == 2 ? kHashK2 : kHashTag;
+    // load factor <= 0.5 with one slot per ROW (the number of distinct keys is not known): n / 2 sectors of 4 slots,
+    // n sectors of 2 slots
+    uint64_t nsec = mode == kHashK2 ? n : (n + 1) / 2;
+    if (nsec < 1) nsec = 1;
+    if (nsec > 0xFFFFFFFFull) nsec = 0xFFFFFFFFull;
+    DevBuf t, flag;
+    if (!accel_alloc(bctx, ix, &t, nsec * 64)) return {};
+    CPH_TRY(flag.alloc(&bctx->pool, sizeof(uint32_t)));
+    CPH_HIP_TRY(hipMemsetAsync(t.get(), 0xFF, nsec * 64, bctx->stream));
+    CPH_HIP_TRY(hipMemsetAsync(flag.get(), 0, sizeof(uint32_t), bctx->stream));
+    const CodesView cv{ix->sorted_codes.get(), n, ix->codec.key32 ? 1 : nw, ix->codec.key32 ? 1 : 0};
+    const bool unique = ix->first_dup == UINT64_MAX;
+    const dim3 grid(grid_for_items(n)), block(256);
+    uint4* sec = t.as<uint4>();
+    uint32_t* fl = flag.as<uint32_t>();
+    {
+        ProfScope ps(bctx, "k_hash_build", (double)n * (8.0 * nw + 4.0) + 64.0 * (double)n);
+        if (mode == kHashK1) hipLaunchKernelGGL(k_hash_build<kHashK1>, grid, block, 0, bctx->stream, cv, ix->perm.as<uint32_t>(), unique, sec, (uint32_t)nsec, fl);
+        else if (mode == kHashK2) hipLaunchKernelGGL(k_hash_build<kHashK2>, grid, block, 0, bctx->stream, cv, ix->perm.as<uint32_t>(), unique, sec, (uint32_t)nsec, fl);
+        else hipLaunchKernelGGL(k_hash_build<kHashTag>, grid, block, 0, bctx->stream, cv, ix->perm.as<uint32_t>(), unique, sec, (uint32_t)nsec, fl);
+        if (!unique) {
+            if (mode == kHashK1) hipLaunchKernelGGL(k_hash_set_ends<kHashK1>, grid, block, 0, bctx->stream, cv, sec, (uint32_t)nsec);
+            else if (mode == kHashK2) hipLaunchKernelGGL(k_hash_set_ends<kHashK2>, grid, block, 0, bctx->stream, cv, sec, (uint32_t)nsec);
+            else hipLaunchKernelGGL(k_hash_set_ends<kHashTag>, grid, block, 0, bctx->stream, cv, sec, (uint32_t)nsec);
+        }
+        CPH_HIP_TRY(hipGetLastError());
+    }
+    if (mode == kHashTag) {
+        // two distinct keys with one 64-bit tag (about n^2 / 2^65: 3e-6 at 1e7 rows): no hash table for this index
+        uint32_t collided = 0;
+        CPH_TRY(read_device_value(bctx, fl, &collided));
+        if (collided) {
+            ix->accel_failed = true;
+            return {};
+        }
+    }
+    ix->hash = std::move(t);
+    ix->hash_sectors = (uint32_t)nsec;
+    ix->hash_mode = mode;
+    CPH_TRY(accel_done(bctx, ix));
+    return accel_wait(ctx, ix);
 }
 
 // ---------------------------------------------------------------------------------------------
 // probe
 // ---------------------------------------------------------------------------------------------
-template <bool KEY32, bool TABLE>
+enum : int { kLookSearch = 0, kLookTable = 1, kLookHash = 2 };
+
+// What a probe kernel needs to look a key up other than by searching the sorted codes.
+struct LookupArg {
+    const TableEntry* table = nullptr;   // kLookTable
+    HashView hash;                       // kLookHash
+    int32_t hash_mode = kHashNone;
+    int32_t unique = 0;                  // the index has no duplicate keys: entries carry {lo, build row}
+};
+
+template <bool KEY32, int LOOKUP>
 __global__ __launch_bounds__(kProbeThreads) void k_probe(ColsArg cols, int ncols_used,
                                                         const uint8_t* __restrict__ g_codec,
                                                         const void* __restrict__ codes, uint64_t n_index,
-                                                        const TableEntry* __restrict__ table, bool table_unique,
+                                                        LookupArg look,
                                                         RowSel sel, uint64_t nprobe,
                                                         uint32_t* __restrict__ out_lo, uint32_t* __restrict__ out_cnt,
-                                                        uint64_t* __restrict__ tile_sums) {
+                                                        uint64_t* __restrict__ tile_sums,
+                                                        uint32_t* __restrict__ out_first_row) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ uint64_t s_wsum[kProbeThreads / kWave];
     const CodecView cv = codec_load_to_lds(g_codec, smem);
@@ -185,18 +398,52 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(ColsArg cols, int ncols
             row = (sel.bits == 32 ? (uint64_t) reinterpret_cast<const uint32_t*>(sel.ptr)[i]
                                   : reinterpret_cast<const uint64_t*>(sel.ptr)[i]) - sel.base;
         uint64_t lo = 0, hi = n_index;
+        uint32_t first_row = kTableAbsent;
         bool valid;
-        if constexpr (TABLE) {
+        if constexpr (LOOKUP == kLookTable) {
             uint64_t code = 0;
             valid = encode_key(cv, cols, ncols_used, row, [&](int, uint64_t v, int) { code = v; });
             if (valid) {
-                const TableEntry e = table[code];
-                if (table_unique) {
+                const TableEntry e = look.table[code];
+                if (look.unique) {
                     lo = e.a;
                     hi = e.a == kTableAbsent ? e.a : e.a + 1;
+                    first_row = e.b;
                 } else {
                     lo = e.a;
                     hi = e.b;
+                }
+            }
+        } else if constexpr (LOOKUP == kLookHash) {
+            // full-key probe through the hash table (hash_device.hpp): the words of the code, most significant first
+            uint64_t w0 = 0, w1 = 0, hs = kHashSeed;
+            valid = encode_key(cv, cols, ncols_used, row, [&](int word, uint64_t v, int) {
+                if (word == 0) w0 = v;
+                if (word == 1) w1 = v;
+                hs = hash_step(hs, v);
+            });
+            lo = hi = 0;
+            if (valid) {
+                uint32_t l = 0, a = 0;
+                bool hit;
+                if (look.hash_mode == kHashK1) {
+                    hit = hash_find16(look.hash, hash_one(w0), w0, &l, &a);
+                } else if (look.hash_mode == kHashK2) {
+                    hit = hash_find32(look.hash, hash_two(w0, w1), w0, w1, &l, &a);
+                } else {
+                    const uint64_t h = hash_finish(hs);
+                    hit = hash_find16(look.hash, h, hash_tag(h), &l, &a);
+                    if (hit) {   // a tag is not the key: compare the words with the sorted codes of the run it names
+                        const uint64_t* cw = reinterpret_cast<const uint64_t*>(codes);
+                        bool same = true;
+                        encode_key(cv, cols, ncols_used, row, [&](int word, uint64_t v, int) { same = same && cw[(uint64_t)word * n_index + l] == v; });
+                        hit = same;
+                    }
+                }
+                if (hit) {
+                    lo = l;
+                    hi = look.unique ? (uint64_t)l + 1 : (uint64_t)a;
+                    first_row = a;
                 }
             }
         } else {
@@ -218,6 +465,7 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(ColsArg cols, int ncols
         const uint32_t cnt = valid ? (uint32_t)(hi - lo) : 0u;
         out_lo[i] = (uint32_t)lo;
         out_cnt[i] = cnt;
+        if (LOOKUP != kLookSearch && out_first_row) out_first_row[i] = first_row;
         my_sum += cnt;
     }
     my_sum = wave_sum(my_sum);
@@ -235,10 +483,10 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(ColsArg cols, int ncols
 // phase: row selection, spans, key bytes, then the lookups are issued back to back.
 constexpr int kProbeRows = 4;
 
-template <bool KEY32, bool TABLE>
+template <bool KEY32, int LOOKUP>
 __global__ __launch_bounds__(kProbeThreads) void k_probe_fast(DevCol col, const uint8_t* __restrict__ g_codec,
                                                              const void* __restrict__ codes, uint64_t n_index,
-                                                             const TableEntry* __restrict__ table, bool table_unique,
+                                                             LookupArg look,
                                                              RowSel sel, uint64_t nprobe,
                                                              uint32_t* __restrict__ out_lo, uint32_t* __restrict__ out_cnt,
                                                              uint64_t* __restrict__ tile_sums,
@@ -294,7 +542,9 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe_fast(DevCol col, const 
                                      : encode_prefetched_w<uint64_t>(cv, col, begin[k], l32, c0[k], c1[k], &code[k]));
         }
         uint32_t lo[kProbeRows], cnt[kProbeRows], e_b[kProbeRows];
-        if constexpr (TABLE) {
+        const bool table_unique = look.unique != 0;
+        if constexpr (LOOKUP == kLookTable) {
+            const TableEntry* __restrict__ table = look.table;
             TableEntry e[kProbeRows];
 #pragma unroll
             for (int k = 0; k < kProbeRows; k++) e[k] = table[valid[k] ? code[k] : 0];   // entry 0 always exists
@@ -304,6 +554,26 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe_fast(DevCol col, const 
                 e_b[k] = e[k].b;
                 lo[k] = e[k].a;
                 cnt[k] = table_unique ? (e[k].a != kTableAbsent ? 1u : 0u) : e[k].b - e[k].a;
+            }
+        } else if constexpr (LOOKUP == kLookHash) {
+            // one-word codes through the hash table: the home sectors of the kProbeRows rows are loaded together
+            HashSector sc[kProbeRows];
+            uint32_t home[kProbeRows];
+#pragma unroll
+            for (int k = 0; k < kProbeRows; k++) {
+                home[k] = hash_home(hash_one(code[k]), look.hash.nsectors);
+                sc[k] = hash_load_sector(look.hash, valid[k] ? home[k] : 0u);
+            }
+#pragma unroll
+            for (int k = 0; k < kProbeRows; k++) {
+                uint32_t l, a;
+                bool more;
+                bool hit = hash_match16(sc[k], code[k], &l, &a, &more);
+                if (valid[k] && more) hit = hash_continue16(look.hash, home[k], code[k], &l, &a);   // full home sector: rare
+                hit = hit && valid[k];
+                lo[k] = hit ? l : kTableAbsent;
+                cnt[k] = hit ? (table_unique ? 1u : a - l) : 0u;
+                e_b[k] = hit ? a : kTableAbsent;
             }
         } else {
 #pragma unroll
@@ -330,8 +600,8 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe_fast(DevCol col, const 
             if (!ok[k]) continue;
             out_lo[i[k]] = lo[k];
             out_cnt[i[k]] = cnt[k];
-            if constexpr (TABLE) {
-                // duplicate-free index: the table entry already holds the build row, k_expand then
+            if constexpr (LOOKUP != kLookSearch) {
+                // duplicate-free index: the table / hash entry already holds the build row, k_expand then
                 // needs no dependent perm[lo] gather
                 if (out_first_row) out_first_row[i[k]] = e_b[k];
             }
@@ -478,19 +748,135 @@ __global__ __launch_bounds__(kProbeThreads) void k_bounds_to_counts(const uint32
     }
 }
 
-static Status probe_windows(cph_ctx* ctx, const cph_index* ix, const DevCol* cols, int32_t ncols, RowSel row_sel, uint64_t nprobe,
-                            uint32_t* lo, uint32_t* cnt, uint64_t* tile_sums, unsigned ntiles) {
+// ---- the same keys through the hash table (full-key probes): no search at all ------------------------------------
+// pass A, per window: fold the window's code words into the row's running hash (state[i]; ok[i] = the key can occur)
+template <bool FIRST>
+__global__ __launch_bounds__(kProbeThreads) void k_window_hash(ColsArg cols, int ncols_used, const uint8_t* __restrict__ g_codec,
+                                                              RowSel sel, uint64_t nprobe, uint64_t* __restrict__ state,
+                                                              uint32_t* __restrict__ ok) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const CodecView cv = codec_load_to_lds(g_codec, smem);
+    const uint64_t stride = (uint64_t)gridDim.x * kProbeThreads;
+    for (uint64_t i = (uint64_t)blockIdx.x * kProbeThreads + threadIdx.x; i < nprobe; i += stride) {
+        if (!FIRST && !ok[i]) continue;
+        uint64_t row = i;
+        if (sel.ptr)
+            row = (sel.bits == 32 ? (uint64_t) reinterpret_cast<const uint32_t*>(sel.ptr)[i]
+                                  : reinterpret_cast<const uint64_t*>(sel.ptr)[i]) - sel.base;
+        uint64_t hs = FIRST ? kHashSeed : state[i];
+        const bool valid = encode_key(cv, cols, ncols_used, row, [&](int, uint64_t v, int) { hs = hash_step(hs, v); });
+        state[i] = hs;
+        ok[i] = valid ? 1u : 0u;
+    }
+}
+// pass B: tag lookup -> candidate run [lo, hi)
+__global__ __launch_bounds__(kProbeThreads) void k_window_lookup(HashView hv, bool unique, uint64_t nprobe,
+                                                                const uint64_t* __restrict__ state, const uint32_t* __restrict__ ok,
+                                                                uint32_t* __restrict__ lo_out, uint32_t* __restrict__ hi_out) {
+    const uint64_t stride = (uint64_t)gridDim.x * kProbeThreads;
+    for (uint64_t i = (uint64_t)blockIdx.x * kProbeThreads + threadIdx.x; i < nprobe; i += stride) {
+        uint32_t l = 0, a = 0;
+        bool hit = false;
+        if (ok[i]) {
+            const uint64_t h = hash_finish(state[i]);
+            hit = hash_find16(hv, h, hash_tag(h), &l, &a);
+        }
+        lo_out[i] = hit ? l : 0u;
+        hi_out[i] = hit ? (unique ? l + 1u : a) : 0u;
+    }
+}
+// pass C, per window: a tag is not the key — compare the window's words with the sorted codes of the candidate run
+__global__ __launch_bounds__(kProbeThreads) void k_window_verify(ColsArg cols, int ncols_used, const uint8_t* __restrict__ g_codec,
+                                                                const uint64_t* __restrict__ codes, uint64_t n_index, RowSel sel,
+                                                                uint64_t nprobe, const uint32_t* __restrict__ lo_in,
+                                                                uint32_t* __restrict__ hi_io) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const CodecView cv = codec_load_to_lds(g_codec, smem);
+    const uint64_t stride = (uint64_t)gridDim.x * kProbeThreads;
+    for (uint64_t i = (uint64_t)blockIdx.x * kProbeThreads + threadIdx.x; i < nprobe; i += stride) {
+        const uint32_t lo = lo_in[i];
+        if (hi_io[i] <= lo) continue;
+        uint64_t row = i;
+        if (sel.ptr)
+            row = (sel.bits == 32 ? (uint64_t) reinterpret_cast<const uint32_t*>(sel.ptr)[i]
+                                  : reinterpret_cast<const uint64_t*>(sel.ptr)[i]) - sel.base;
+        bool same = true;
+        const bool valid = encode_key(cv, cols, ncols_used, row, [&](int word, uint64_t v, int) {
+            same = same && codes[(uint64_t)word * n_index + lo] == v;
+        });
+        if (!valid || !same) hi_io[i] = lo;
+    }
+}
+
+static ColsArg window_cols(const cph_key_window& w, const DevCol* cols, int32_t ncols, int* used_out) {
+    ColsArg arg{};
+    int used = 0;
+    for (int s = 0; s < w.nseg; s++) {
+        if (w.seg_col[s] >= ncols) break;   // a prefix join compares the leading columns only (csvplus.go:910)
+        arg.c[used] = cols[w.seg_col[s]];
+        arg.c[used].skip = w.seg_skip[s];
+        arg.c[used].take = w.seg_take[s];
+        used++;
+    }
+    *used_out = used;
+    return arg;
+}
+
+static Status probe_windows_hash(cph_ctx* ctx, const cph_index* ix, const DevCol* cols, int32_t ncols, RowSel row_sel,
+                                 uint64_t nprobe, uint32_t* lo, uint32_t* cnt, uint64_t* tile_sums, unsigned ntiles) {
+    DevBuf state, ok;
+    CPH_TRY(state.alloc(&ctx->pool, nprobe * sizeof(uint64_t)));
+    CPH_TRY(ok.alloc(&ctx->pool, nprobe * sizeof(uint32_t)));
+    const unsigned grid = grid_for_items(nprobe);
     bool first = true;
     for (const cph_key_window& w : ix->windows) {
-        ColsArg arg{};
         int used = 0;
-        for (int s = 0; s < w.nseg; s++) {
-            if (w.seg_col[s] >= ncols) break;   // a prefix join compares the leading columns only (csvplus.go:910)
-            arg.c[used] = cols[w.seg_col[s]];
-            arg.c[used].skip = w.seg_skip[s];
-            arg.c[used].take = w.seg_take[s];
-            used++;
+        const ColsArg arg = window_cols(w, cols, ncols, &used);
+        const size_t lds = w.codec_dev.bytes();
+        ProfScope ps(ctx, "k_window_hash", 0);
+        if (first) {
+            CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_window_hash<true>), kProbeThreads, lds, nullptr));
+            hipLaunchKernelGGL(k_window_hash<true>, dim3(grid), dim3(kProbeThreads), lds, ctx->stream, arg, used,
+                               w.codec_dev.as<uint8_t>(), row_sel, nprobe, state.as<uint64_t>(), ok.as<uint32_t>());
+        } else {
+            CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_window_hash<false>), kProbeThreads, lds, nullptr));
+            hipLaunchKernelGGL(k_window_hash<false>, dim3(grid), dim3(kProbeThreads), lds, ctx->stream, arg, used,
+                               w.codec_dev.as<uint8_t>(), row_sel, nprobe, state.as<uint64_t>(), ok.as<uint32_t>());
         }
+        CPH_HIP_TRY(hipGetLastError());
+        first = false;
+    }
+    {
+        ProfScope ps(ctx, "k_window_lookup", 0);
+        const HashView hv{ix->hash.as<uint4>(), ix->hash_sectors};
+        hipLaunchKernelGGL(k_window_lookup, dim3(grid), dim3(kProbeThreads), 0, ctx->stream, hv, ix->first_dup == UINT64_MAX, nprobe,
+                           state.as<uint64_t>(), ok.as<uint32_t>(), lo, cnt);
+        CPH_HIP_TRY(hipGetLastError());
+    }
+    for (const cph_key_window& w : ix->windows) {
+        int used = 0;
+        const ColsArg arg = window_cols(w, cols, ncols, &used);
+        const size_t lds = w.codec_dev.bytes();
+        const uint64_t* codes = ix->sorted_codes.as<uint64_t>() + (uint64_t)w.word_base * ix->nrows;
+        ProfScope ps(ctx, "k_window_verify", 0);
+        CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_window_verify), kProbeThreads, lds, nullptr));
+        hipLaunchKernelGGL(k_window_verify, dim3(grid), dim3(kProbeThreads), lds, ctx->stream, arg, used, w.codec_dev.as<uint8_t>(),
+                           codes, ix->nrows, row_sel, nprobe, lo, cnt);
+        CPH_HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_bounds_to_counts, dim3(ntiles), dim3(kProbeThreads), 0, ctx->stream, lo, cnt, nprobe, tile_sums);
+    CPH_HIP_TRY(hipGetLastError());
+    return {};
+}
+
+static Status probe_windows(cph_ctx* ctx, const cph_index* ix, const DevCol* cols, int32_t ncols, RowSel row_sel, uint64_t nprobe,
+                            uint32_t* lo, uint32_t* cnt, uint64_t* tile_sums, unsigned ntiles) {
+    if (ncols == ix->nkeycols && ix->hash_mode == kHashTag)
+        return probe_windows_hash(ctx, ix, cols, ncols, row_sel, nprobe, lo, cnt, tile_sums, ntiles);
+    bool first = true;
+    for (const cph_key_window& w : ix->windows) {
+        int used = 0;
+        const ColsArg arg = window_cols(w, cols, ncols, &used);
         if (used == 0) break;
         const size_t lds = w.codec_dev.bytes();
         const uint64_t* codes = ix->sorted_codes.as<uint64_t>() + (uint64_t)w.word_base * ix->nrows;
@@ -517,17 +903,30 @@ static Status probe_windows(cph_ctx* ctx, const cph_index* ix, const DevCol* col
     return {};
 }
 
-template <bool KEY32, bool TABLE>
-static Status launch_probe(cph_ctx* ctx, const cph_index* ix, const ColsArg& arg, int ncols, RowSel row_sel,
-                           uint64_t nprobe, uint32_t* lo, uint32_t* cnt, uint64_t* tile_sums, unsigned ntiles) {
+static const char* look_name(int look) { return look == kLookTable ? "k_probe_table" : look == kLookHash ? "k_probe_hash" : "k_probe_search"; }
+
+template <bool KEY32, int LOOKUP>
+static Status launch_probe(cph_ctx* ctx, const cph_index* ix, const ColsArg& arg, int ncols, const LookupArg& look, RowSel row_sel,
+                           uint64_t nprobe, uint32_t* lo, uint32_t* cnt, uint64_t* tile_sums, unsigned ntiles, uint32_t* first_row) {
     const size_t lds = ix->codec_dev.bytes();
-    CPH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_probe<KEY32, TABLE>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    ProfScope ps(ctx, TABLE ? "k_probe_table" : "k_probe_search", 0);
-    hipLaunchKernelGGL((k_probe<KEY32, TABLE>), dim3(ntiles), dim3(kProbeThreads), lds, ctx->stream, arg, ncols,
-                       ix->codec_dev.as<uint8_t>(), ix->sorted_codes.get(), ix->nrows, ix->table.as<TableEntry>(),
-                       ix->first_dup == UINT64_MAX,
-                       row_sel, nprobe, lo, cnt, tile_sums);
+    CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_probe<KEY32, LOOKUP>), kProbeThreads, lds, nullptr));
+    ProfScope ps(ctx, look_name(LOOKUP), 0);
+    hipLaunchKernelGGL((k_probe<KEY32, LOOKUP>), dim3(ntiles), dim3(kProbeThreads), lds, ctx->stream, arg, ncols,
+                       ix->codec_dev.as<uint8_t>(), ix->sorted_codes.get(), ix->nrows, look, row_sel, nprobe, lo, cnt, tile_sums,
+                       first_row);
+    CPH_HIP_TRY(hipGetLastError());
+    return {};
+}
+
+template <bool KEY32, int LOOKUP>
+static Status launch_probe_fast(cph_ctx* ctx, const cph_index* ix, const DevCol& col, const LookupArg& look, RowSel row_sel,
+                                uint64_t nprobe, uint32_t* lo, uint32_t* cnt, uint64_t* tile_sums, unsigned ntiles, uint32_t* first_row) {
+    const size_t lds = ix->codec_dev.bytes();
+    CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_probe_fast<KEY32, LOOKUP>), kProbeThreads, lds, nullptr));
+    ProfScope ps(ctx, look_name(LOOKUP), 0);
+    hipLaunchKernelGGL((k_probe_fast<KEY32, LOOKUP>), dim3(ntiles), dim3(kProbeThreads), lds, ctx->stream, col,
+                       ix->codec_dev.as<uint8_t>(), ix->sorted_codes.get(), ix->nrows, look, row_sel, nprobe, lo, cnt, tile_sums,
+                       first_row);
     CPH_HIP_TRY(hipGetLastError());
     return {};
 }
@@ -545,51 +944,56 @@ Status probe_run(cph_ctx* ctx, const cph_index* ix, const DevCol* cols, int32_t 
     CPH_TRY(tiles.alloc(&ctx->pool, (ntiles64 + 1) * sizeof(uint64_t)));
     ColsArg arg{};
     for (int c = 0; c < ncols; c++) arg.c[c] = cols[c];
+    // How a probe row finds its keys: a FULL-key probe looks them up — direct-address table when the code space is
+    // dense, hash table otherwise (both built by the first Join that wants them; when that fails, or for a PREFIX
+    // join, which needs the order of the codes: csvplus.go:910) — the sorted codes are searched.
     const bool full_key = ncols == ix->nkeycols;
-    const bool use_table = ix->table_entries != 0 && full_key && ix->windows.empty();
-    if (use_table) CPH_TRY(index_ensure_table(ctx, ix));
+    int lookup = kLookSearch;
+    if (full_key && ix->nrows) {
+        if (ix->table_entries != 0 && ix->windows.empty()) {
+            CPH_TRY(index_ensure_table(ctx, ix));
+            if (ix->table) lookup = kLookTable;
+        }
+        if (lookup == kLookSearch && index_wants_hash(ix)) {
+            CPH_TRY(index_ensure_hash(ctx, ix));
+            if (ix->hash_mode != kHashNone) lookup = kLookHash;
+        }
+    }
+    LookupArg look;
+    look.table = ix->table.as<TableEntry>();
+    look.hash = HashView{ix->hash.as<uint4>(), ix->hash_sectors};
+    look.hash_mode = ix->hash_mode;
+    look.unique = ix->first_dup == UINT64_MAX ? 1 : 0;
     uint32_t* lo = out->lo.as<uint32_t>();
     uint32_t* cnt = out->cnt.as<uint32_t>();
     uint64_t* ts = tiles.as<uint64_t>();
     DevBuf first_rows;
+    uint32_t* first_row = nullptr;
+    // pairs wanted from a duplicate-free index: the table / hash entries carry the build rows, keep them
+    if (want_pairs && lookup != kLookSearch && look.unique && ix->windows.empty()) {
+        CPH_TRY(first_rows.alloc(&ctx->pool, nprobe * sizeof(uint32_t)));
+        first_row = first_rows.as<uint32_t>();
+    }
     const bool fast = ncols == 1 && ix->codec.ncols == 1 && codec_premultiplied_bits(ix->codec) != 0 && ix->windows.empty();
+    const bool k32 = ix->codec.key32;
+#define CPH_PROBE_DISPATCH(FN, ...)                                                                           \
+    do {                                                                                                      \
+        if (k32 && lookup == kLookTable) CPH_TRY((FN<true, kLookTable>(__VA_ARGS__)));                        \
+        else if (k32 && lookup == kLookHash) CPH_TRY((FN<true, kLookHash>(__VA_ARGS__)));                     \
+        else if (k32) CPH_TRY((FN<true, kLookSearch>(__VA_ARGS__)));                                          \
+        else if (lookup == kLookTable) CPH_TRY((FN<false, kLookTable>(__VA_ARGS__)));                         \
+        else if (lookup == kLookHash) CPH_TRY((FN<false, kLookHash>(__VA_ARGS__)));                           \
+        else CPH_TRY((FN<false, kLookSearch>(__VA_ARGS__)));                                                  \
+    } while (0)
     if (!ix->windows.empty()) {
         CPH_TRY(probe_windows(ctx, ix, cols, ncols, row_sel, nprobe, lo, cnt, ts, ntiles));
     } else if (fast) {
         // one key column, single-word code, pre-multiplied LUT: 4 rows in flight per thread
-        const size_t lds = ix->codec_dev.bytes();
-        const uint8_t* blob = ix->codec_dev.as<uint8_t>();
-        const void* codes = ix->sorted_codes.get();
-        const TableEntry* tab = ix->table.as<TableEntry>();
-        const bool tuniq = ix->first_dup == UINT64_MAX;
-        // pairs wanted from a duplicate-free index with a table: keep the entries' build rows
-        uint32_t* first_row = nullptr;
-        if (want_pairs && use_table && tuniq) {
-            CPH_TRY(first_rows.alloc(&ctx->pool, nprobe * sizeof(uint32_t)));
-            first_row = first_rows.as<uint32_t>();
-        }
-        ProfScope ps(ctx, use_table ? "k_probe_table" : "k_probe_search", 0);
-        const dim3 grid(ntiles), block(kProbeThreads);
-        if (ix->codec.key32 && use_table)
-            hipLaunchKernelGGL((k_probe_fast<true, true>), grid, block, lds, ctx->stream, cols[0], blob, codes, ix->nrows,
-                               tab, tuniq, row_sel, nprobe, lo, cnt, ts, first_row);
-        else if (ix->codec.key32)
-            hipLaunchKernelGGL((k_probe_fast<true, false>), grid, block, lds, ctx->stream, cols[0], blob, codes, ix->nrows,
-                               tab, tuniq, row_sel, nprobe, lo, cnt, ts, first_row);
-        else if (use_table)
-            hipLaunchKernelGGL((k_probe_fast<false, true>), grid, block, lds, ctx->stream, cols[0], blob, codes, ix->nrows,
-                               tab, tuniq, row_sel, nprobe, lo, cnt, ts, first_row);
-        else
-            hipLaunchKernelGGL((k_probe_fast<false, false>), grid, block, lds, ctx->stream, cols[0], blob, codes, ix->nrows,
-                               tab, tuniq, row_sel, nprobe, lo, cnt, ts, first_row);
-        CPH_HIP_TRY(hipGetLastError());
-    } else if (ix->codec.key32) {
-        if (use_table) CPH_TRY((launch_probe<true, true>(ctx, ix, arg, ncols, row_sel, nprobe, lo, cnt, ts, ntiles)));
-        else CPH_TRY((launch_probe<true, false>(ctx, ix, arg, ncols, row_sel, nprobe, lo, cnt, ts, ntiles)));
+        CPH_PROBE_DISPATCH(launch_probe_fast, ctx, ix, cols[0], look, row_sel, nprobe, lo, cnt, ts, ntiles, first_row);
     } else {
-        if (use_table) CPH_TRY((launch_probe<false, true>(ctx, ix, arg, ncols, row_sel, nprobe, lo, cnt, ts, ntiles)));
-        else CPH_TRY((launch_probe<false, false>(ctx, ix, arg, ncols, row_sel, nprobe, lo, cnt, ts, ntiles)));
+        CPH_PROBE_DISPATCH(launch_probe, ctx, ix, arg, ncols, look, row_sel, nprobe, lo, cnt, ts, ntiles, first_row);
     }
+#undef CPH_PROBE_DISPATCH
     CPH_TRY(exclusive_scan_u64(ctx, ts, ntiles64, ts + ntiles64));   // tile bases; the total lands behind them
     CPH_TRY(ensure_pinned_scratch(ctx, sizeof(uint64_t)));
     CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, ts + ntiles64, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -600,7 +1004,7 @@ Status probe_run(cph_ctx* ctx, const cph_index* ix, const DevCol* cols, int32_t 
     CPH_TRY(out->brow.alloc(&ctx->pool, out->nmatches * sizeof(uint32_t)));
     ProfScope ps(ctx, "k_expand", 8.0 * (double)nprobe + 16.0 * (double)out->nmatches);
     hipLaunchKernelGGL(k_expand, dim3(ntiles), dim3(kProbeThreads), 0, ctx->stream, lo, cnt, nprobe, ts,
-                       ix->perm.as<uint32_t>(), first_rows ? first_rows.as<uint32_t>() : (const uint32_t*)nullptr, probe_base,
+                       ix->perm.as<uint32_t>(), first_row ? first_row : (const uint32_t*)nullptr, probe_base,
                        out->pidx.as<uint64_t>(), out->brow.as<uint32_t>());
     CPH_HIP_TRY(hipGetLastError());
     return {};

@@ -2,6 +2,7 @@
 #pragma once
 
 #include "codec_device.hpp"
+#include "hash_device.hpp"
 
 namespace cph {
 

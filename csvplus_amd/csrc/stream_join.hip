@@ -66,9 +66,12 @@ CPH_API int32_t cph_stream_join_create(cph_ctx* ctx, const cph_index* const* ind
     // built on, and wait for it once
     for (int s = 0; s < nsteps; s++) {
         Status st = index_ensure_rowtab(ctx, indexes[s]);
+        if (st.ok() && !indexes[s]->rowtab) st = index_ensure_hash(ctx, indexes[s]);   // sparse code space: the hash table
         if (!st.ok()) return sj_fail(ctx, st.code, st.msg);
     }
     (void)hipStreamSynchronize(ctx->stream);
+    for (int s = 0; s < nsteps; s++)
+        if (indexes[s]->ctx) (void)hipStreamSynchronize(indexes[s]->ctx->stream);   // built on the index's own ctx
     cph_stream_join* sj = new (std::nothrow) cph_stream_join();
     if (!sj) return sj_fail(ctx, CPH_ERR_NOMEM, "out of host memory");
     sj->parent = ctx;

@@ -138,6 +138,8 @@ CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
  *                   1 = dictionaries straight from the row sample when it holds no value seen only once (default),
  *                   2 = always from the sample (the encode kernel completes them; a test hook)
  *   "plan_threads" / "gstats_threads"  workgroup sizes of the dictionary encode / window statistics kernels (0 = default)
+ *   "join_hash"     0: indexes built on this ctx never get a hash table — their sparse-key Joins binary-search the
+ *                   sorted codes as before (A/B switch for measurements and for the fallback's tests; default 1)
  *   "codec_debug"   1: the window choice of every index build is printed to stderr
  *   "pool_reserve_mb"  reserves ONE device slab of that many MiB now; later requests are carved out of it first
  *                   (first fit, coalesced on release) and only fall back to hipMalloc when it cannot serve them —
@@ -536,10 +538,32 @@ typedef struct {
     int32_t  sort_passes;     /* radix scatter passes executed                                 */
     int32_t  direct_table;    /* 1 when the probe uses the direct-address table                */
     int32_t  dict_entries;    /* entries of the group dictionaries (0: per-position alphabets only)  */
-    uint64_t table_entries;   /* entries of the direct-address table (0 if none)               */
+    uint64_t table_entries;   /* entries of the direct-address table (0 if none planned)       */
+    int32_t  lookup_built;    /* lookup structures BUILT so far (bits): 1 = 8-byte table, 2 = 4-byte row table,
+                                 4 = hash table.  direct_table / table_entries only say one is PLANNED: the
+                                 structures are built by the first Join that uses them (or cph_index_prepare_join) */
+    int32_t  hash_mode;       /* 0 none; 1 one code word per entry, 2 two words, 3 64-bit tag + verification     */
+    uint64_t hash_bytes;      /* size of the hash table                                                         */
 } cph_index_info;
 
 CPH_API int32_t cph_index_get_info(const cph_index* index, cph_index_info* info);
+
+/*
+ * Join looks a probe row's key up in a structure that is not part of the Index (csvplus.go:612-614: the sorted rows
+ * ARE the index) and is therefore built by the first Join that wants it: a direct-address table over the key codes
+ * when the code space is dense (<= 24 codes per row), a hash table over the codes otherwise (one 64-byte sector per
+ * probe row for any key: random ids, hashes, several columns, keys of any length); a PREFIX join (fewer columns than
+ * the index has, csvplus.go:546-550) needs the order and searches the sorted codes, as does every Join when the
+ * structure cannot be allocated.  This call builds the structure NOW — `chained` != 0: the one cph_join_chain /
+ * cph_stream_join use (4-byte row table for a duplicate-free index), else the one cph_join_probe uses — so that
+ * the first Join does not pay for it.
+ *
+ * Sharing an index between ctxs: the structures are built on the INDEX's ctx (its stream, its pool) whatever ctx
+ * runs the Join, and a Join on another ctx of the same device orders its stream behind that build.  A ctx is
+ * single-threaded: two threads with a ctx each may join against one index at the same time only once its lookup
+ * structure exists — call cph_index_prepare_join first.
+ */
+CPH_API int32_t cph_index_prepare_join(cph_index* index, int32_t chained);
 
 /*
  * Per-kernel timing for roofline accounting.  While enabled, every kernel launch

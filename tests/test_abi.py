@@ -41,7 +41,24 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(N.cph_strcol) == 40
     assert ctypes.sizeof(N.cph_strval) == 16
     assert ctypes.sizeof(N.cph_matches) == 56
-    assert ctypes.sizeof(N.cph_index_info) == 48
+    assert ctypes.sizeof(N.cph_index_info) == 64
+
+
+def test_struct_sizes_against_the_compiled_header(tmp_path):
+    """sizeof of every struct the binding mirrors, as gcc sees include/csvplus_hip.h."""
+    import subprocess
+
+    names = ["cph_strcol", "cph_strval", "cph_matches", "cph_index_info", "cph_index_spec", "cph_chain_step", "cph_chain",
+             "cph_colbuf", "cph_bytes", "cph_csv_options", "cph_csv_table", "cph_rowsel", "cph_groups", "cph_gathered",
+             "cph_stream_chunk", "cph_kernel_stat"]
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "csvplus_hip.h"\nint main(void){'
+                   + "".join(f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}\n")
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-std=c99", "-I", str(ROOT / "include"), str(src), "-o", str(exe)])
+    out = dict(ln.split() for ln in subprocess.check_output([str(exe)], text=True).splitlines())
+    for n in names:
+        assert ctypes.sizeof(getattr(N, n)) == int(out[n]), (n, ctypes.sizeof(getattr(N, n)), out[n])
 
 
 def test_version_string():

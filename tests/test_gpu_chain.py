@@ -76,7 +76,7 @@ def test_chain_lengths(ctx, nsteps):
 
 
 def test_chain_search_path_sparse_codes(ctx):
-    """Distinct keys but a sparse code space (no direct table): binary-search lookups inside the fused pass."""
+    """Distinct keys but a sparse code space (no direct table): hash-table lookups inside the fused pass."""
     rng = np.random.default_rng(11)
     vals = list({bytes(v) for v in random_keys(rng, 30000, 6, 9, alphabet=list(b"abcdefghijklmnopqrstuvwxyz"))})
     ix = DeviceIndex(ctx, [StrCol.from_values(vals)])
@@ -84,6 +84,12 @@ def test_chain_search_path_sparse_codes(ctx):
     probe = [vals[i] for i in rng.integers(0, len(vals), 80000)]
     probe[::9] = random_keys(rng, len(probe[::9]), 6, 9, alphabet=list(b"abcxyz"))
     check_chain(ctx, [[StrCol.from_values(vals)]], [StrCol.from_values(probe)])
+    # the same with the hash probe switched off on a second ctx: the sorted-search fallback inside the fused kernel
+    from csvplus_amd import Context
+    c2 = Context(0)
+    c2.set_option("join_hash", 0)
+    check_chain(c2, [[StrCol.from_values(vals)]], [StrCol.from_values(probe)])
+    c2.close()
 
 
 def test_chain_general_path_duplicates(ctx):
