@@ -56,6 +56,9 @@ def parse_args():
     ap.add_argument("--verify-sample", type=int, default=100_000)
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the two rocprofv3 --pmc child runs (FETCH_SIZE, WRITE_SIZE) behind roofline.traffic")
+    ap.add_argument("--no-calibration", action="store_true",
+                    help="skip the in-run box calibration (plain 4-byte gather into a table of the customers row table's size, "
+                         "streaming copy) behind roofline.gather_ceiling_ms / copy_TBps")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous only: every rank joins the process group (gloo when no GPU is visible) and rank 0 "
                          "prints which ranks it saw; no compute (what tests/test_bench_launch.py drives on CPU)")
@@ -375,7 +378,26 @@ def main():
             roofline["useful"] = round(ub / 1e9 / (dom[1]["avg_ms"] / 1e3) / HBM_PEAK_GBPS, 4)
         # the whole step (every kernel + host gaps) against the same peak
         step_bytes = sum(v["algo_GB"] * 1e9 / (args.steps if v.get("timed_region") else K) for v in kernels.values())
+        roofline["step_algorithmic_bytes"] = round(step_bytes)
         roofline["step_frac"] = round(step_bytes / 1e9 / (ms_per_step / 1e3) / HBM_PEAK_GBPS, 4)
+        # The ceiling of THIS box for the kernel's dominant access pattern, measured now: the chained join makes one
+        # random 4-byte lookup per stream row into the customers row table (4 bytes per code: too big for any L2) and
+        # one into the small products table; a plain gather out[i] = table[idx[i]] of as many lookups into a table of
+        # the same size — no keys to decode, 4 B index in, 4 B value out — is the floor of the customers step alone
+        # (cph_calibrate; the kernel also streams ~25 B of key bytes per row and does the second lookup).
+        if world == 1 and not args.no_calibration and roofline["kernel"] == "k_chain_dense":
+            tb = max(4 * ia_info["table_entries"], 1 << 20)
+            g_ms = eng.ctx.calibrate("gather", tb, nloc, 5)
+            c_bytes = 1 << 30
+            c_ms = eng.ctx.calibrate("copy", c_bytes, 0, 5)
+            roofline["gather_ceiling_ms"] = round(g_ms, 4)
+            roofline["gather_ceiling"] = {"table_bytes": tb, "lookups": nloc, "ms": round(g_ms, 4),
+                                          "Glookups_per_s": round(nloc / g_ms / 1e6, 1),
+                                          "kernel_over_ceiling": round(dom[1]["avg_ms"] / g_ms, 3),
+                                          "what": "plain 4-byte gather, same number of lookups, table of the customers row table's size, "
+                                                  "measured in this run (cph_calibrate): the floor of the customers step of k_chain_dense"}
+            roofline["copy_TBps"] = round(2 * c_bytes / (c_ms / 1e3) / 1e12, 3)
+            roofline["copy_note"] = "streaming copy of 1 GiB, read + written bytes per second, measured in this run"
     # HBM-side traffic of the dominant kernel: PMC counters cannot be collected inside this process, so
     # two child runs of this script under `rocprofv3 --pmc` (one counter each) measure them NOW, on this box.
     # gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE tallies a 128-byte request of a wide coalesced
@@ -532,17 +554,26 @@ def main():
                 torch.cuda.empty_cache()
             kms = sum(v["total_ms"] for v in p.values())
             n = col.nrows
-            # algorithmic bytes: stats + encode read the column, every pass moves (2K+8) B/row after a
-            # K B/row histogram read, first_dup reads the codes, the table (if any) takes K+12 B/row
+            # ALGORITHMIC bytes of the build = what the kernels that RAN move (pass model): the library
+            # records the bytes of every sort / scan / scan-for-duplicates launch itself (radix histogram: K bytes per
+            # key, 1 byte with the digit stream; scatter: 2K+8 [+1 digit byte], first pass 2K+4; first_dup: K*w; a
+            # direct table or hash table only if a kernel built one — IndexOn alone builds none); added here are the
+            # passes over the SOURCE column, whose bytes the library cannot know: statistics (k_col_stats, and
+            # k_group_stats when dictionary windows are completed over all rows) and the encode, which also writes the
+            # n*K code bytes.  Every term is printed so that the fraction can be recomputed from the line alone.
             K_ = inf["key_bytes"] * inf["code_words"]
             src = col.nbytes_values() + col.nbytes_offsets()
-            algo = 2 * src + n * K_ + inf["sort_passes"] * n * (3 * inf["key_bytes"] + 8) + n * K_ \
-                + (n * (inf["key_bytes"] + 12) if inf["direct_table"] else 0)
+            src_readers = {k: p[k]["launches"] for k in ("k_col_stats", "k_group_stats", "k_encode_build") if k in p}
+            lib_bytes = {k: v["algo_bytes"] for k, v in p.items() if v["algo_bytes"] > 0}
+            algo = src * sum(src_readers.values()) + n * K_ * src_readers.get("k_encode_build", 1) + sum(lib_bytes.values())
             compulsory = src + n * (K_ + 4)    # the column read once, sorted codes + perm written once
             return {"rows": n, "ms": round(wall * 1e3, 3), "kernel_ms": round(kms, 3), "rows_per_s": n / wall,
                     "GBps_algorithmic": round(algo / 1e9 / wall, 1),
                     "frac_pass_model": round(algo / 1e9 / wall / HBM_PEAK_GBPS, 4),
                     "frac_compulsory": round(compulsory / 1e9 / wall / HBM_PEAK_GBPS, 4),
+                    "algorithmic_bytes": round(algo), "compulsory_bytes": round(compulsory),
+                    "byte_terms": {"source_bytes": src, "source_reads": src_readers, "code_bytes_written": n * K_,
+                                   "library_kernels": {k: round(v) for k, v in lib_bytes.items()}},
                     "verified": (check or {}).get("ok"), "verify": check, "info": inf,
                     "kernels_ms": {k: round(v["total_ms"], 3) for k, v in p.items()}}
 
@@ -551,6 +582,54 @@ def main():
             "unique_fixed8_ids": time_index(dg.column(dg.SEQ_PERM, n8, n8, encoding=dg.FIXED8, seed=7), True, 3),
             "varlen_dup_keys_config3": time_index(dg.varkeys(n8), False, 2),
         }
+
+        # IndexOn(1e8) + Join(1e8): what the north star's 40 % is quoted on — bytes and milliseconds of the 1e8-row
+        # index build and of the bench step (two build-side indexes + the chained Join of 1e8 stream rows) SUMMED
+        if roofline and "step_algorithmic_bytes" in roofline:
+            comb = {}
+            for name, r in out["index_on_1e8"].items():
+                if not isinstance(r, dict) or "algorithmic_bytes" not in r:
+                    continue
+                bts = r["algorithmic_bytes"] + roofline["step_algorithmic_bytes"]
+                ms = r["ms"] + ms_per_step
+                comb[name + "_plus_step"] = {"ms": round(ms, 3), "algorithmic_bytes": bts,
+                                             "GBps": round(bts / 1e9 / (ms / 1e3), 1),
+                                             "frac": round(bts / 1e9 / (ms / 1e3) / HBM_PEAK_GBPS, 4),
+                                             "index_ms": r["ms"], "step_ms": round(ms_per_step, 3)}
+            comb["note"] = ("IndexOn over 1e8 rows (index_on_1e8.*: wall ms, pass-model bytes) + one bench step (2 index builds + "
+                            "chained Join of 1e8 rows: ms_per_step, roofline.step_algorithmic_bytes), summed; frac = bytes / ms / 8 TB/s")
+            out["index_plus_join_1e8"] = comb
+
+        # IndexOn end to end through the C ABI as a cgo caller sees createIndex (csvplus.go:707-738): key column in PINNED
+        # HOST memory in -> host perm out (cph_index_build on host columns + cph_index_perm(HOST)); PCIe inclusive
+        if not args.no_e2e:
+            from csvplus_amd.streaming import PinnedCol
+
+            def time_index_host(col, unique, reps):
+                pc = PinnedCol(eng.ctx, col)
+                ix = N.DeviceIndex(eng.ctx, [pc.col], unique=unique)   # warm-up: device pool, pinned perm block
+                ix.perm_host_view()
+                ix.close()
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    ix = N.DeviceIndex(eng.ctx, [pc.col], unique=unique)
+                    pv = ix.perm_host_view()
+                    first, last = int(pv[0]), int(pv[-1])
+                    ix.close()
+                wall = (time.perf_counter() - t0) / reps
+                pc.free()
+                h2d = col.nbytes_values() + col.nbytes_offsets()
+                d2h = 4 * col.nrows
+                return {"rows": col.nrows, "ms": round(wall * 1e3, 2), "rows_per_s": col.nrows / wall,
+                        "h2d_bytes": h2d, "d2h_bytes": d2h, "pcie_GBps": round((h2d + d2h) / wall / 1e9, 1),
+                        "perm_first_last": [first, last]}
+
+            out["index_on_1e8"]["e2e_pinned_host"] = {
+                "scope": "key column in pinned host memory -> host perm (cph_index_build on host columns + cph_index_perm(HOST)); "
+                         "PCIe inclusive: upload, build and download run one after the other",
+                "unique_fixed8_ids": time_index_host(dg.column(dg.SEQ_PERM, n8, n8, encoding=dg.FIXED8, seed=7), True, 2),
+                "varlen_dup_keys_config3": time_index_host(dg.varkeys(n8), False, 2)}
 
     # ---- CPU baseline: the oracle (C restatement of the reference), bounded sample ----------------
     if world == 1 and not args.no_cpu_baseline:

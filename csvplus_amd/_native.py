@@ -234,8 +234,11 @@ PROTOTYPES = [
     ("cph_index_load", C.c_int32, [_P, C.c_char_p, C.POINTER(_P)]),
     ("cph_index_find", C.c_int32,
      [_P, _P, C.POINTER(cph_strval), C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("cph_index_find_many", C.c_int32,
+     [_P, _P, C.POINTER(cph_strval), C.c_int32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("cph_index_get_info", C.c_int32, [_P, C.POINTER(cph_index_info)]),
     ("cph_index_prepare_join", C.c_int32, [_P, C.c_int32]),
+    ("cph_calibrate", C.c_int32, [_P, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(C.c_double)]),
 ]
 
 _lib = None
@@ -324,6 +327,12 @@ class Context:
 
     def last_error(self) -> str:
         return (self.lib.cph_last_error(self.handle) or b"").decode("utf-8", "replace")
+
+    def calibrate(self, kind: str, nbytes: int, n: int = 0, reps: int = 5) -> float:
+        """ms per launch of the box calibration kernels (cph_calibrate): kind "copy" or "gather"."""
+        ms = C.c_double()
+        self._check(self.lib.cph_calibrate(self.handle, {"copy": 0, "gather": 1}[kind], nbytes, n, reps, C.byref(ms)))
+        return float(ms.value)
 
     def profile(self, enable: bool = True):
         self._check(self.lib.cph_ctx_profile(self.handle, 1 if enable else 0))
@@ -417,6 +426,13 @@ class DeviceIndex:
         self.ctx._check(self.lib.cph_index_perm(self.handle, CPH_MEM_HOST, C.byref(p), C.byref(n)))
         return _ptr_array(p.value, int(n.value), np.uint32).copy()
 
+    def perm_host_view(self) -> np.ndarray:
+        """The library's pinned host copy of perm WITHOUT another copy (valid until the index is closed)."""
+        p = _P()
+        n = C.c_uint64()
+        self.ctx._check(self.lib.cph_index_perm(self.handle, CPH_MEM_HOST, C.byref(p), C.byref(n)))
+        return _ptr_array(p.value, int(n.value), np.uint32)
+
     def perm_device_ptr(self) -> int:
         p = _P()
         n = C.c_uint64()
@@ -467,6 +483,29 @@ class DeviceIndex:
         self.ctx._check(self.lib.cph_index_find(self.ctx.handle, self.handle, vals, len(values), C.byref(lo),
                                                 C.byref(hi)))
         return int(lo.value), int(hi.value)
+
+    def find_many(self, keys) -> tuple:
+        """keys: list of tuples of bytes (all of the same arity <= key columns) -> (lower, upper) uint64 arrays:
+        cph_index_find_many, one launch for the whole batch."""
+        keys = [k if isinstance(k, (tuple, list)) else (k,) for k in keys]
+        nkeys = len(keys)
+        nvalues = len(keys[0]) if nkeys else 0
+        assert all(len(k) == nvalues for k in keys)
+        vals = (cph_strval * max(1, nkeys * nvalues))()
+        blob = b"".join(bytes(v) for k in keys for v in k)
+        buf = np.frombuffer(blob, dtype=np.uint8) if blob else np.zeros(1, np.uint8)
+        off = 0
+        for i, k in enumerate(keys):
+            for j, v in enumerate(k):
+                ln = len(v)
+                vals[i * nvalues + j].data = buf.ctypes.data + off if ln else None
+                vals[i * nvalues + j].len = ln
+                off += ln
+        lo = np.zeros(max(1, nkeys), dtype=np.uint64)
+        hi = np.zeros(max(1, nkeys), dtype=np.uint64)
+        self.ctx._check(self.lib.cph_index_find_many(self.ctx.handle, self.handle, vals, nvalues, nkeys,
+                                                     lo.ctypes.data_as(C.POINTER(C.c_uint64)), hi.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return lo[:nkeys], hi[:nkeys]
 
     @classmethod
     def _from_handle(cls, ctx: "Context", handle) -> "DeviceIndex":

@@ -190,6 +190,42 @@ Status ensure_pinned_scratch(cph_ctx* ctx, size_t bytes) {
     return {};
 }
 
+Status pinned_cache_get(cph_ctx* ctx, size_t bytes, void** out, size_t* cap) {
+    int best = -1;
+    for (int i = 0; i < (int)ctx->pinned_cache.size(); i++)
+        if (ctx->pinned_cache[i].second >= bytes && (best < 0 || ctx->pinned_cache[i].second < ctx->pinned_cache[best].second)) best = i;
+    if (best >= 0) {
+        *out = ctx->pinned_cache[best].first;
+        *cap = ctx->pinned_cache[best].second;
+        ctx->pinned_cache.erase(ctx->pinned_cache.begin() + best);
+        return {};
+    }
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 4, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        for (auto& b : ctx->pinned_cache) (void)hipHostFree(b.first);   // give the cached blocks back and retry once
+        ctx->pinned_cache.clear();
+        e = hipHostMalloc(&p, bytes ? bytes : 4, hipHostMallocDefault);
+    }
+    if (e != hipSuccess) return {CPH_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)};
+    *out = p;
+    *cap = bytes ? bytes : 4;
+    return {};
+}
+
+void pinned_cache_put(cph_ctx* ctx, void* p, size_t cap) {
+    if (!p) return;
+    ctx->pinned_cache.push_back({p, cap});
+    while (ctx->pinned_cache.size() > 2) {   // keep the two largest
+        size_t small = 0;
+        for (size_t i = 1; i < ctx->pinned_cache.size(); i++)
+            if (ctx->pinned_cache[i].second < ctx->pinned_cache[small].second) small = i;
+        (void)hipHostFree(ctx->pinned_cache[small].first);
+        ctx->pinned_cache.erase(ctx->pinned_cache.begin() + (long)small);
+    }
+}
+
 Status pinned_upload(cph_ctx* ctx, size_t bytes, void** out) {
     const size_t need = (bytes + 63) & ~(size_t)63;
     if (need > ctx->upload_cap) {
@@ -666,6 +702,7 @@ CPH_API void cph_ctx_destroy(cph_ctx* ctx) {
     if (ctx->pinned_scratch) (void)hipHostFree(ctx->pinned_scratch);
     if (ctx->upload_ring) (void)hipHostFree(ctx->upload_ring);
     for (void* p : ctx->pinned_user) (void)hipHostFree(p);
+    for (auto& b : ctx->pinned_cache) (void)hipHostFree(b.first);
     for (auto& p : ctx->prof_pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
     for (hipEvent_t e : ctx->prof_free_events) (void)hipEventDestroy(e);
     hipStream_t own = ctx->own_stream ? ctx->stream : nullptr;
@@ -871,7 +908,10 @@ CPH_API int32_t cph_index_build_many(cph_ctx* ctx, const cph_index_spec* specs, 
 CPH_API void cph_index_destroy(cph_index* ix) {
     if (!ix) return;
     if (ix->ctx) (void)hipSetDevice(ix->ctx->device);
-    if (ix->perm_host) (void)hipHostFree(ix->perm_host);
+    if (ix->perm_host) {
+        if (ix->ctx) pinned_cache_put(ix->ctx, ix->perm_host, ix->perm_host_cap);
+        else (void)hipHostFree(ix->perm_host);
+    }
     delete ix;
 }
 
@@ -891,10 +931,11 @@ CPH_API int32_t cph_index_perm(cph_index* ix, int32_t mem, const uint32_t** perm
     if (!ix->perm_host) {
         const size_t bytes = (size_t)ix->nrows * sizeof(uint32_t);
         void* p = nullptr;
-        hipError_t e = hipHostMalloc(&p, bytes ? bytes : 4, hipHostMallocDefault);
-        if (e != hipSuccess) return fail(ctx, {CPH_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)});
+        size_t cap = 0;
+        s = pinned_cache_get(ctx, bytes, &p, &cap);
+        if (!s.ok()) return fail(ctx, s);
         if (bytes) {
-            e = hipMemcpyAsync(p, ix->perm.get(), bytes, hipMemcpyDeviceToHost, ctx->stream);
+            hipError_t e = hipMemcpyAsync(p, ix->perm.get(), bytes, hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
             if (e != hipSuccess) {
                 (void)hipHostFree(p);
@@ -902,6 +943,7 @@ CPH_API int32_t cph_index_perm(cph_index* ix, int32_t mem, const uint32_t** perm
             }
         }
         ix->perm_host = static_cast<uint32_t*>(p);
+        ix->perm_host_cap = cap;
     }
     *perm = ix->perm_host;
     return CPH_OK;
@@ -1081,6 +1123,51 @@ CPH_API void cph_chain_release(cph_chain* pub) {
     delete c;
 }
 
+// Literal key values -> the query k_find / k_find_many answer: q_exact[0 .. nq-2] are words that must match exactly,
+// [qlo, qhi] is the range of the last word the values reach (a prefix of the key columns leaves its low positions
+// open).  Returns false when the values cannot occur in the index (a byte outside an alphabet, a value too long).
+static bool find_query(const cph_index* ix, const cph_strval* values, int32_t nvalues, std::vector<uint64_t>* q_exact, int32_t* nq,
+                       uint64_t* qlo, uint64_t* qhi) {
+    q_exact->clear();
+    *nq = 0;
+    *qlo = *qhi = 0;
+    if (ix->windows.empty()) {
+        q_exact->resize(kMaxWords);
+        return codec_encode_values_host(ix->codec, values, nvalues, q_exact->data(), nq, qlo, qhi);
+    }
+    // long keys: every window encodes its segments of the values; all words are exact except the last word of
+    // the last window the values reach, which may be a range (prefix of the key columns)
+    bool pending = false;
+    uint64_t plo = 0, phi = 0;
+    for (const cph_key_window& w : ix->windows) {
+        cph_strval seg[kMaxKeyCols];
+        int used = 0;
+        for (int k = 0; k < w.nseg && w.seg_col[k] < nvalues; k++, used++) {
+            const cph_strval& v = values[w.seg_col[k]];
+            const uint64_t sk = v.len < (uint64_t)w.seg_skip[k] ? v.len : (uint64_t)w.seg_skip[k];
+            uint64_t ln = v.len - sk;
+            if (w.seg_take[k] != 0xFFFFFFFFu && ln > (uint64_t)w.seg_take[k]) ln = w.seg_take[k];
+            seg[used].data = v.data ? v.data + sk : nullptr;
+            seg[used].len = ln;
+        }
+        if (used == 0) break;
+        uint64_t qw[kMaxWords], wlo = 0, whi = 0;
+        int32_t nqw = 0;
+        if (!codec_encode_values_host(w.codec, seg, used, qw, &nqw, &wlo, &whi)) return false;
+        if (nqw == 0) continue;                       // a window without byte positions (empty columns)
+        if (pending) q_exact->push_back(plo);         // the previous window was complete: its last word is exact
+        for (int k = 0; k + 1 < nqw; k++) q_exact->push_back(qw[k]);
+        plo = wlo;
+        phi = whi;
+        pending = true;
+    }
+    *nq = pending ? (int32_t)q_exact->size() + 1 : 0;
+    *qlo = plo;
+    *qhi = phi;
+    q_exact->push_back(0);
+    return true;
+}
+
 CPH_API int32_t cph_index_find(cph_ctx* ctx, const cph_index* ix, const cph_strval* values, int32_t nvalues,
                                uint64_t* lower, uint64_t* upper) {
     Status s = enter(ctx);
@@ -1096,48 +1183,46 @@ CPH_API int32_t cph_index_find(cph_ctx* ctx, const cph_index* ix, const cph_strv
     std::vector<uint64_t> q_exact;
     int32_t nq = 0;
     uint64_t qlo = 0, qhi = 0;
-    bool present = true;
-    if (ix->windows.empty()) {
-        q_exact.resize(kMaxWords);
-        present = codec_encode_values_host(ix->codec, values, nvalues, q_exact.data(), &nq, &qlo, &qhi);
-    } else {
-        // long keys: every window encodes its segments of the values; all words are exact except the last word of
-        // the last window the values reach, which may be a range (prefix of the key columns)
-        bool pending = false;
-        uint64_t plo = 0, phi = 0;
-        for (const cph_key_window& w : ix->windows) {
-            cph_strval seg[kMaxKeyCols];
-            int used = 0;
-            for (int k = 0; k < w.nseg && w.seg_col[k] < nvalues; k++, used++) {
-                const cph_strval& v = values[w.seg_col[k]];
-                const uint64_t sk = v.len < (uint64_t)w.seg_skip[k] ? v.len : (uint64_t)w.seg_skip[k];
-                uint64_t ln = v.len - sk;
-                if (w.seg_take[k] != 0xFFFFFFFFu && ln > (uint64_t)w.seg_take[k]) ln = w.seg_take[k];
-                seg[used].data = v.data ? v.data + sk : nullptr;
-                seg[used].len = ln;
-            }
-            if (used == 0) break;
-            uint64_t qw[kMaxWords], wlo = 0, whi = 0;
-            int32_t nqw = 0;
-            if (!codec_encode_values_host(w.codec, seg, used, qw, &nqw, &wlo, &whi)) { present = false; break; }
-            if (nqw == 0) continue;                       // a window without byte positions (empty columns)
-            if (pending) q_exact.push_back(plo);          // the previous window was complete: its last word is exact
-            for (int k = 0; k + 1 < nqw; k++) q_exact.push_back(qw[k]);
-            plo = wlo;
-            phi = whi;
-            pending = true;
-        }
-        nq = pending ? (int32_t)q_exact.size() + 1 : 0;
-        qlo = plo;
-        qhi = phi;
-        q_exact.push_back(0);
-    }
-    if (!present) {
+    if (!find_query(ix, values, nvalues, &q_exact, &nq, &qlo, &qhi)) {
         *lower = 0;
         *upper = 0;   // empty: the values cannot occur in the index
         return CPH_OK;
     }
     s = index_find_device(ctx, ix, q_exact.data(), nq, qlo, qhi, lower, upper);
+    if (!s.ok()) return fail(ctx, s);
+    return CPH_OK;
+}
+
+CPH_API int32_t cph_index_find_many(cph_ctx* ctx, const cph_index* ix, const cph_strval* values, int32_t nvalues, uint64_t nkeys,
+                                    uint64_t* lower, uint64_t* upper) {
+    Status s = enter(ctx);
+    if (!s.ok()) return fail(ctx, s);
+    if (!ix || nvalues < 0 || (nkeys && (!lower || !upper)) || (nvalues && nkeys && !values))
+        return fail(ctx, {CPH_ERR_INVALID, "bad argument"});
+    if (nvalues > ix->nkeycols) return fail(ctx, {CPH_ERR_TOO_MANY_COLS, "too many columns in indexImpl.find()"});
+    if (nkeys == 0) return CPH_OK;
+    if (nvalues == 0 || ix->nrows == 0) {   // csvplus.go:872-874: no values = the whole index
+        for (uint64_t k = 0; k < nkeys; k++) {
+            lower[k] = 0;
+            upper[k] = nvalues == 0 ? ix->nrows : 0;
+        }
+        return CPH_OK;
+    }
+    if (nkeys > (1ull << 28)) return fail(ctx, {CPH_ERR_INVALID, "cph_index_find_many: at most 2^28 keys per call"});
+    // query block per key: stride words = [nq | q_exact ... | qlo | qhi]; nq = 0 marks "cannot occur"
+    const size_t stride = (size_t)ix->total_words() + 2;
+    std::vector<uint64_t> host(stride * nkeys, 0), q_exact;
+    for (uint64_t k = 0; k < nkeys; k++) {
+        int32_t nq = 0;
+        uint64_t qlo = 0, qhi = 0;
+        uint64_t* h = host.data() + stride * k;
+        if (!find_query(ix, values + (size_t)k * (size_t)nvalues, nvalues, &q_exact, &nq, &qlo, &qhi) || nq <= 0) continue;
+        h[0] = (uint64_t)nq;
+        for (int i = 0; i + 1 < nq; i++) h[1 + i] = q_exact[(size_t)i];
+        h[nq] = qlo;
+        h[nq + 1] = qhi;
+    }
+    s = index_find_many_device(ctx, ix, host.data(), stride, nkeys, lower, upper);
     if (!s.ok()) return fail(ctx, s);
     return CPH_OK;
 }

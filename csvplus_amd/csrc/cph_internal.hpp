@@ -222,6 +222,9 @@ struct cph_ctx {
     void* upload_ring = nullptr;
     size_t upload_cap = 0, upload_pos = 0;
     std::vector<void*> pinned_user;
+    // pinned blocks of released host-side results (cph_index_perm copies), reused by the next one of a fitting size:
+    // page-locking 400 MB costs tens of milliseconds, a caller that builds index after index should pay it once
+    std::vector<std::pair<void*, size_t>> pinned_cache;
     cph::DevBuf safe_words;        // 64 readable device bytes: the data base of columns that come without a buffer
     // per-ctx launch state (a process may hold one ctx per device: nothing of this may be static)
     int cus = 0;                   // compute units of `device` (0: not queried yet)
@@ -280,7 +283,7 @@ struct cph_index {
     // hash table over the codes for every other index (hash_device.hpp), built by the first full-key Join
     cph::DevBuf hash;              // hash_sectors x 64 bytes
     uint32_t hash_sectors = 0;
-    int32_t hash_mode = 0;         // kHashNone until built, then kHashK1 / kHashK2 / kHashTag
+    int32_t hash_mode = 0;         // kHashNone until built, then kHashK1 / kHashK3 / kHashTag
     bool accel_failed = false;     // a lookup structure could not be allocated (or tags collided): sorted search from now on
     // Lookup structures are built on the INDEX's ctx (its stream, its pool: they live and die with the index); the
     // event is recorded behind the newest one, and a Join running on another ctx makes its stream wait for it.
@@ -291,6 +294,7 @@ struct cph_index {
     int32_t sort_passes = 0;
     uint64_t first_dup = UINT64_MAX;
     uint32_t* perm_host = nullptr; // pinned copy (lazy)
+    size_t perm_host_cap = 0;
     cph::DevBuf first_dup_dev;     // u32 result of the adjacent-equal scan until it is read back
 };
 
@@ -421,6 +425,10 @@ Status probe_run(cph_ctx* ctx, const cph_index* ix, const DevCol* cols, int32_t 
                  uint64_t nprobe, uint64_t probe_base, bool want_pairs, ProbeOut* out);
 Status index_find_device(cph_ctx* ctx, const cph_index* ix, const uint64_t* q_exact, int32_t nq, uint64_t qlo,
                          uint64_t qhi, uint64_t* lower, uint64_t* upper);
+// nkeys query blocks of `stride` words each ([nq | exact words | qlo | qhi], nq = 0: the key cannot occur): one upload,
+// one launch, one download
+Status index_find_many_device(cph_ctx* ctx, const cph_index* ix, const uint64_t* queries, size_t stride, uint64_t nkeys,
+                              uint64_t* lower, uint64_t* upper);
 
 // index_ops.hip: an index as descriptor (host bytes) + sorted codes + perm (device arrays)
 void index_desc_serialize(const cph_index* ix, std::vector<uint8_t>* out);
@@ -462,6 +470,8 @@ void warm_index_ops();
 
 // capi.hip helpers
 Status ensure_pinned_scratch(cph_ctx* ctx, size_t bytes);
+Status pinned_cache_get(cph_ctx* ctx, size_t bytes, void** out, size_t* cap);   // a cached block of >= bytes, or a new one
+void pinned_cache_put(cph_ctx* ctx, void* p, size_t cap);                        // back into the cache (at most 2 blocks kept)
 Status pinned_upload(cph_ctx* ctx, size_t bytes, void** out);   // staging slot valid until the ring wraps
 Status validate_cols(const cph_strcol* cols, int32_t ncols);
 // Makes columns device resident (host columns are copied into pool blocks kept alive by `storage`).

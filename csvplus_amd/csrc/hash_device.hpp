@@ -17,8 +17,9 @@
 //
 // Three entry formats (cph_index::hash_mode):
 //   kHashK1   one code word:    {u64 code, u32 lo, u32 aux}                       exact, 16 bytes
-//   kHashK2   two code words:   {u64 w0, u64 w1, u32 lo, u32 aux, 8 spare}        exact, 32 bytes
-//   kHashTag  anything longer (3+ words, several key windows): {u64 tag, u32 lo, u32 aux} with tag = the 64-bit
+//   kHashK3   two or three code words (up to 189 bits: UUIDs, 16 random bytes, two id columns):
+//                               {u64 w0, u64 w1, u64 w2, u32 lo, u32 aux}         exact, 32 bytes
+//   kHashTag  anything longer (4+ words, several key windows): {u64 tag, u32 lo, u32 aux} with tag = the 64-bit
 //             hash of all words; a tag match is VERIFIED against the sorted codes at lo (word by word), so the
 //             result is exact; the build makes sure no two distinct index keys share a tag (else no hash table)
 // Prefix joins (fewer probe columns than the index has) need the ORDER of the codes and stay on the sorted path.
@@ -29,7 +30,7 @@
 
 namespace cph {
 
-enum : int32_t { kHashNone = 0, kHashK1 = 1, kHashK2 = 2, kHashTag = 3 };
+enum : int32_t { kHashNone = 0, kHashK1 = 1, kHashK3 = 2, kHashTag = 3 };
 constexpr uint64_t kHashEmpty = ~0ull;            // no code word (< 2^63) and no tag (top bit cleared) equals it
 constexpr uint32_t kHashAbsent = 0xFFFFFFFFu;
 
@@ -37,10 +38,9 @@ struct HashEntry16 {            // kHashK1 / kHashTag: 4 per sector
     uint64_t key;
     uint32_t lo, aux;
 };
-struct HashEntry32 {            // kHashK2: 2 per sector
-    uint64_t w0, w1;
+struct HashEntry32 {            // kHashK3: 2 per sector (w2 = 0 for two-word codes)
+    uint64_t w0, w1, w2;
     uint32_t lo, aux;
-    uint64_t spare;
 };
 static_assert(sizeof(HashEntry16) == 16 && sizeof(HashEntry32) == 32, "entry layout");
 
@@ -63,7 +63,6 @@ constexpr uint64_t kHashSeed = 0x9E3779B97F4A7C15ull;
 CPH_HD inline uint64_t hash_step(uint64_t s, uint64_t word) { return (s ^ word) * 0x9FB21C651E98DF25ull + 0x2545F4914F6CDD1Dull; }
 CPH_HD inline uint64_t hash_finish(uint64_t s) { return hash_fmix(s); }
 CPH_HD inline uint64_t hash_one(uint64_t code) { return hash_finish(hash_step(kHashSeed, code)); }
-CPH_HD inline uint64_t hash_two(uint64_t w0, uint64_t w1) { return hash_finish(hash_step(hash_step(kHashSeed, w0), w1)); }
 CPH_HD inline uint64_t hash_tag(uint64_t h) { return h & 0x7FFFFFFFFFFFFFFFull; }
 CPH_HD inline uint32_t hash_home(uint64_t h, uint32_t nsectors) { return (uint32_t)(((h >> 32) * (uint64_t)nsectors) >> 32); }
 
@@ -104,17 +103,19 @@ __device__ __forceinline__ bool hash_match16(const HashSector& sc, uint64_t key,
     *more = !hit && !empty;
     return hit;
 }
-// 32-byte entries keyed by two words
-__device__ __forceinline__ bool hash_match32(const HashSector& sc, uint64_t w0, uint64_t w1, uint32_t* lo, uint32_t* aux, bool* more) {
+// 32-byte entries keyed by up to three words
+__device__ __forceinline__ bool hash_match32(const HashSector& sc, uint64_t w0, uint64_t w1, uint64_t w2, uint32_t* lo, uint32_t* aux,
+                                             bool* more) {
     bool hit = false, empty = false;
     uint32_t l = kHashAbsent, a = kHashAbsent;
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const uint64_t k0 = hash_key_of(sc.e[2 * j]);
         const uint64_t k1 = (uint64_t)sc.e[2 * j].z | ((uint64_t)sc.e[2 * j].w << 32);
-        const bool m = k0 == w0 && k1 == w1;
-        l = m ? sc.e[2 * j + 1].x : l;
-        a = m ? sc.e[2 * j + 1].y : a;
+        const uint64_t k2 = hash_key_of(sc.e[2 * j + 1]);
+        const bool m = k0 == w0 && k1 == w1 && k2 == w2;
+        l = m ? sc.e[2 * j + 1].z : l;
+        a = m ? sc.e[2 * j + 1].w : a;
         hit |= m;
         empty |= k0 == kHashEmpty;
     }
@@ -135,12 +136,12 @@ __device__ __forceinline__ bool hash_find16(const HashView& hv, uint64_t h, uint
         s = s + 1 == hv.nsectors ? 0 : s + 1;
     }
 }
-__device__ __forceinline__ bool hash_find32(const HashView& hv, uint64_t h, uint64_t w0, uint64_t w1, uint32_t* lo, uint32_t* aux) {
+__device__ __forceinline__ bool hash_find32(const HashView& hv, uint64_t h, uint64_t w0, uint64_t w1, uint64_t w2, uint32_t* lo, uint32_t* aux) {
     uint32_t s = hash_home(h, hv.nsectors);
     for (;;) {
         const HashSector sc = hash_load_sector(hv, s);
         bool more;
-        if (hash_match32(sc, w0, w1, lo, aux, &more)) return true;
+        if (hash_match32(sc, w0, w1, w2, lo, aux, &more)) return true;
         if (!more) return false;
         s = s + 1 == hv.nsectors ? 0 : s + 1;
     }
@@ -152,6 +153,17 @@ __device__ __forceinline__ bool hash_continue16(const HashView& hv, uint32_t hom
         const HashSector sc = hash_load_sector(hv, s);
         bool more;
         if (hash_match16(sc, key, lo, aux, &more)) return true;
+        if (!more) return false;
+        s = s + 1 == hv.nsectors ? 0 : s + 1;
+    }
+}
+__device__ __forceinline__ bool hash_continue32(const HashView& hv, uint32_t home, uint64_t w0, uint64_t w1, uint64_t w2, uint32_t* lo,
+                                                uint32_t* aux) {
+    uint32_t s = home + 1 == hv.nsectors ? 0 : home + 1;
+    for (;;) {
+        const HashSector sc = hash_load_sector(hv, s);
+        bool more;
+        if (hash_match32(sc, w0, w1, w2, lo, aux, &more)) return true;
         if (!more) return false;
         s = s + 1 == hv.nsectors ? 0 : s + 1;
     }

@@ -220,7 +220,7 @@ __device__ __forceinline__ uint64_t codes_hash(const CodesView& c, uint64_t i) {
 // claimed slot that already holds this very tag belongs to a DIFFERENT key (only distinct keys are inserted).
 template <int MODE>
 __device__ __forceinline__ uint4* hash_claim(uint4* sectors, uint32_t nsectors, uint64_t h, uint64_t key, uint32_t* collision) {
-    constexpr int kSlots = MODE == kHashK2 ? 2 : 4, kStride = MODE == kHashK2 ? 2 : 1;
+    constexpr int kSlots = MODE == kHashK3 ? 2 : 4, kStride = MODE == kHashK3 ? 2 : 1;
     uint32_t s = hash_home(h, nsectors);
     for (;;) {
         uint4* sec = sectors + (uint64_t)s * 4;
@@ -249,13 +249,15 @@ __global__ void k_hash_build(CodesView cv, const uint32_t* __restrict__ perm, bo
             uint4* e = hash_claim<MODE>(sectors, nsectors, hash_one(c), c, collision);
             e->z = (uint32_t)i;
             e->w = aux;
-        } else if constexpr (MODE == kHashK2) {
-            const uint64_t w0 = code_word(cv, 0, i), w1 = code_word(cv, 1, i);
-            uint4* e = hash_claim<MODE>(sectors, nsectors, hash_two(w0, w1), w0, collision);
+        } else if constexpr (MODE == kHashK3) {
+            const uint64_t w0 = code_word(cv, 0, i), w1 = code_word(cv, 1, i), w2 = cv.nwords > 2 ? code_word(cv, 2, i) : 0ull;
+            uint4* e = hash_claim<MODE>(sectors, nsectors, codes_hash(cv, i), w0, collision);
             e[0].z = (uint32_t)w1;
             e[0].w = (uint32_t)(w1 >> 32);
-            e[1].x = (uint32_t)i;
-            e[1].y = aux;
+            e[1].x = (uint32_t)w2;
+            e[1].y = (uint32_t)(w2 >> 32);
+            e[1].z = (uint32_t)i;
+            e[1].w = aux;
         } else {
             const uint64_t h = codes_hash(cv, i);
             uint4* e = hash_claim<MODE>(sectors, nsectors, h, hash_tag(h), collision);
@@ -268,18 +270,19 @@ __global__ void k_hash_build(CodesView cv, const uint32_t* __restrict__ perm, bo
 // index with duplicate keys: the LAST row of every run looks its key up and stores the end of the run
 template <int MODE>
 __global__ void k_hash_set_ends(CodesView cv, uint4* __restrict__ sectors, uint32_t nsectors) {
-    constexpr int kSlots = MODE == kHashK2 ? 2 : 4, kStride = MODE == kHashK2 ? 2 : 1;
+    constexpr int kSlots = MODE == kHashK3 ? 2 : 4, kStride = MODE == kHashK3 ? 2 : 1;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cv.n; i += stride) {
         if (i + 1 != cv.n && codes_equal(cv, i, i + 1)) continue;
-        uint64_t h, key, w1 = 0;
+        uint64_t h, key, w1 = 0, w2 = 0;
         if constexpr (MODE == kHashK1) {
             key = code_word(cv, 0, i);
             h = hash_one(key);
-        } else if constexpr (MODE == kHashK2) {
+        } else if constexpr (MODE == kHashK3) {
             key = code_word(cv, 0, i);
             w1 = code_word(cv, 1, i);
-            h = hash_two(key, w1);
+            w2 = cv.nwords > 2 ? code_word(cv, 2, i) : 0ull;
+            h = codes_hash(cv, i);
         } else {
             h = codes_hash(cv, i);
             key = hash_tag(h);
@@ -293,9 +296,9 @@ __global__ void k_hash_set_ends(CodesView cv, uint4* __restrict__ sectors, uint3
                 const uint64_t k = hash_key_of(*e);
                 if (k == kHashEmpty) done = true;   // cannot happen for a key that was inserted
                 if (k != key) continue;
-                if constexpr (MODE == kHashK2) {
-                    if (((uint64_t)e->z | ((uint64_t)e->w << 32)) != w1) continue;
-                    e[1].y = (uint32_t)(i + 1);
+                if constexpr (MODE == kHashK3) {
+                    if (((uint64_t)e->z | ((uint64_t)e->w << 32)) != w1 || hash_key_of(e[1]) != w2) continue;
+                    e[1].w = (uint32_t)(i + 1);
                 } else {
                     // TAG: distinct keys have distinct tags (checked by the build), so the tag identifies the run
                     e->w = (uint32_t)(i + 1);
@@ -317,10 +320,10 @@ Status index_ensure_hash(cph_ctx* ctx, const cph_index* cix) {
     if (!bctx->join_hash) return {};   // A/B switch of the index's ctx
     const uint64_t n = ix->nrows;
     const int nw = ix->total_words();
-    const int mode = !ix->windows.empty() ? kHashTag : nw == 1 ? kHashK1 : nw == 2 ? kHashK2 : kHashTag;
+    const int mode = !ix->windows.empty() ? kHashTag : nw == 1 ? kHashK1 : nw <= 3 ? kHashK3 : kHashTag;
     // load factor <= 0.5 with one slot per ROW (the number of distinct keys is not known): n / 2 sectors of 4 slots,
     // n sectors of 2 slots
-    uint64_t nsec = mode == kHashK2 ? n : (n + 1) / 2;
+    uint64_t nsec = mode == kHashK3 ? n : (n + 1) / 2;
     if (nsec < 1) nsec = 1;
     if (nsec > 0xFFFFFFFFull) nsec = 0xFFFFFFFFull;
     DevBuf t, flag;
@@ -336,11 +339,11 @@ Status index_ensure_hash(cph_ctx* ctx, const cph_index* cix) {
     {
         ProfScope ps(bctx, "k_hash_build", (double)n * (8.0 * nw + 4.0) + 64.0 * (double)n);
         if (mode == kHashK1) hipLaunchKernelGGL(k_hash_build<kHashK1>, grid, block, 0, bctx->stream, cv, ix->perm.as<uint32_t>(), unique, sec, (uint32_t)nsec, fl);
-        else if (mode == kHashK2) hipLaunchKernelGGL(k_hash_build<kHashK2>, grid, block, 0, bctx->stream, cv, ix->perm.as<uint32_t>(), unique, sec, (uint32_t)nsec, fl);
+        else if (mode == kHashK3) hipLaunchKernelGGL(k_hash_build<kHashK3>, grid, block, 0, bctx->stream, cv, ix->perm.as<uint32_t>(), unique, sec, (uint32_t)nsec, fl);
         else hipLaunchKernelGGL(k_hash_build<kHashTag>, grid, block, 0, bctx->stream, cv, ix->perm.as<uint32_t>(), unique, sec, (uint32_t)nsec, fl);
         if (!unique) {
             if (mode == kHashK1) hipLaunchKernelGGL(k_hash_set_ends<kHashK1>, grid, block, 0, bctx->stream, cv, sec, (uint32_t)nsec);
-            else if (mode == kHashK2) hipLaunchKernelGGL(k_hash_set_ends<kHashK2>, grid, block, 0, bctx->stream, cv, sec, (uint32_t)nsec);
+            else if (mode == kHashK3) hipLaunchKernelGGL(k_hash_set_ends<kHashK3>, grid, block, 0, bctx->stream, cv, sec, (uint32_t)nsec);
             else hipLaunchKernelGGL(k_hash_set_ends<kHashTag>, grid, block, 0, bctx->stream, cv, sec, (uint32_t)nsec);
         }
         CPH_HIP_TRY(hipGetLastError());
@@ -389,6 +392,77 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(ColsArg cols, int ncols
     const int p_end = cv.hdr->col_start[ncols_used];
     const uint64_t tile0 = (uint64_t)blockIdx.x * kProbeTile;
     uint64_t my_sum = 0;
+    if constexpr (LOOKUP == kLookHash) {
+        // Full-key probe through the hash table (hash_device.hpp).  kHashRows rows per phase: their keys are encoded
+        // one after the other (the generic encoder walks columns and byte positions), then the home sectors of all of
+        // them are loaded together — the random accesses are what the kernel waits for.
+        constexpr int kHashRows = 4;
+        const uint64_t* cw = reinterpret_cast<const uint64_t*>(codes);
+#pragma unroll 1
+        for (int ph = 0; ph < kProbeItems / kHashRows; ph++) {
+            uint64_t i[kHashRows], w0[kHashRows], w1[kHashRows], w2[kHashRows], h[kHashRows];
+            bool ok[kHashRows], valid[kHashRows];
+#pragma unroll
+            for (int k = 0; k < kHashRows; k++) {
+                i[k] = tile0 + (uint64_t)(ph * kHashRows + k) * kProbeThreads + threadIdx.x;
+                ok[k] = i[k] < nprobe;
+                uint64_t row = ok[k] ? i[k] : nprobe - 1;
+                if (sel.ptr)
+                    row = (sel.bits == 32 ? (uint64_t) reinterpret_cast<const uint32_t*>(sel.ptr)[row]
+                                          : reinterpret_cast<const uint64_t*>(sel.ptr)[row]) - sel.base;
+                uint64_t a0 = 0, a1 = 0, a2 = 0, hs = kHashSeed;
+                valid[k] = encode_key(cv, cols, ncols_used, row, [&](int word, uint64_t v, int) {
+                    a0 = word == 0 ? v : a0;
+                    a1 = word == 1 ? v : a1;
+                    a2 = word == 2 ? v : a2;
+                    hs = hash_step(hs, v);
+                }) && ok[k];
+                w0[k] = a0;
+                w1[k] = a1;
+                w2[k] = a2;
+                h[k] = look.hash_mode == kHashK1 ? hash_one(a0) : hash_finish(hs);
+            }
+            HashSector sc[kHashRows];
+            uint32_t home[kHashRows];
+#pragma unroll
+            for (int k = 0; k < kHashRows; k++) {
+                home[k] = hash_home(h[k], look.hash.nsectors);
+                sc[k] = hash_load_sector(look.hash, valid[k] ? home[k] : 0u);
+            }
+#pragma unroll
+            for (int k = 0; k < kHashRows; k++) {
+                uint32_t l = 0, a = 0;
+                bool hit = false, more = false;
+                if (look.hash_mode == kHashK1) {
+                    hit = hash_match16(sc[k], w0[k], &l, &a, &more);
+                    if (valid[k] && more) hit = hash_continue16(look.hash, home[k], w0[k], &l, &a);   // full home sector: rare
+                } else if (look.hash_mode == kHashK3) {
+                    hit = hash_match32(sc[k], w0[k], w1[k], w2[k], &l, &a, &more);
+                    if (valid[k] && more) hit = hash_continue32(look.hash, home[k], w0[k], w1[k], w2[k], &l, &a);
+                } else {
+                    hit = hash_match16(sc[k], hash_tag(h[k]), &l, &a, &more);
+                    if (valid[k] && more) hit = hash_continue16(look.hash, home[k], hash_tag(h[k]), &l, &a);
+                    if (hit && valid[k]) {   // a tag is not the key: compare the words with the sorted codes of the run it names
+                        uint64_t row = i[k];
+                        if (sel.ptr)
+                            row = (sel.bits == 32 ? (uint64_t) reinterpret_cast<const uint32_t*>(sel.ptr)[row]
+                                                  : reinterpret_cast<const uint64_t*>(sel.ptr)[row]) - sel.base;
+                        bool same = true;
+                        encode_key(cv, cols, ncols_used, row, [&](int word, uint64_t v, int) { same = same && cw[(uint64_t)word * n_index + l] == v; });
+                        hit = same;
+                    }
+                }
+                hit = hit && valid[k];
+                if (ok[k]) {
+                    const uint32_t cnt = hit ? (look.unique ? 1u : a - l) : 0u;
+                    out_lo[i[k]] = hit ? l : 0u;
+                    out_cnt[i[k]] = cnt;
+                    if (out_first_row) out_first_row[i[k]] = hit ? a : kTableAbsent;
+                    my_sum += cnt;
+                }
+            }
+        }
+    } else {
 #pragma unroll 1
     for (int k = 0; k < kProbeItems; k++) {
         const uint64_t i = tile0 + (uint64_t)k * kProbeThreads + threadIdx.x;
@@ -414,38 +488,6 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(ColsArg cols, int ncols
                     hi = e.b;
                 }
             }
-        } else if constexpr (LOOKUP == kLookHash) {
-            // full-key probe through the hash table (hash_device.hpp): the words of the code, most significant first
-            uint64_t w0 = 0, w1 = 0, hs = kHashSeed;
-            valid = encode_key(cv, cols, ncols_used, row, [&](int word, uint64_t v, int) {
-                if (word == 0) w0 = v;
-                if (word == 1) w1 = v;
-                hs = hash_step(hs, v);
-            });
-            lo = hi = 0;
-            if (valid) {
-                uint32_t l = 0, a = 0;
-                bool hit;
-                if (look.hash_mode == kHashK1) {
-                    hit = hash_find16(look.hash, hash_one(w0), w0, &l, &a);
-                } else if (look.hash_mode == kHashK2) {
-                    hit = hash_find32(look.hash, hash_two(w0, w1), w0, w1, &l, &a);
-                } else {
-                    const uint64_t h = hash_finish(hs);
-                    hit = hash_find16(look.hash, h, hash_tag(h), &l, &a);
-                    if (hit) {   // a tag is not the key: compare the words with the sorted codes of the run it names
-                        const uint64_t* cw = reinterpret_cast<const uint64_t*>(codes);
-                        bool same = true;
-                        encode_key(cv, cols, ncols_used, row, [&](int word, uint64_t v, int) { same = same && cw[(uint64_t)word * n_index + l] == v; });
-                        hit = same;
-                    }
-                }
-                if (hit) {
-                    lo = l;
-                    hi = look.unique ? (uint64_t)l + 1 : (uint64_t)a;
-                    first_row = a;
-                }
-            }
         } else {
             valid = encode_key(cv, cols, ncols_used, row, [&](int word, uint64_t v, int p) {
                 const uint64_t vhi = (p + 1 == p_end) ? v + cv.mult[p] - 1 : v;
@@ -467,6 +509,7 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(ColsArg cols, int ncols
         out_cnt[i] = cnt;
         if (LOOKUP != kLookSearch && out_first_row) out_first_row[i] = first_row;
         my_sum += cnt;
+    }
     }
     my_sum = wave_sum(my_sum);
     if (lane_id() == 0) s_wsum[wave_id()] = my_sum;
@@ -1064,6 +1107,65 @@ Status index_find_device(cph_ctx* ctx, const cph_index* ix, const uint64_t* q_ex
     CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
     *lower = h[0];
     *upper = h[1];
+    return {};
+}
+
+// Many Find calls in one launch: thread k answers query block k (layout: cph_index_find_many).
+template <bool KEY32>
+__global__ void k_find_many(const void* __restrict__ codes, uint64_t n, const uint64_t* __restrict__ queries, size_t stride,
+                            uint64_t nkeys, uint64_t* __restrict__ result) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nkeys) return;
+    const uint64_t* q = queries + stride * k;
+    const int nq = (int)q[0];
+    uint64_t lo = 0, hi = nq ? n : 0;
+    for (int w = 0; w < nq; w++) {
+        const uint64_t vlo = q[1 + w];
+        const uint64_t vhi = (w + 1 == nq) ? q[2 + w] : vlo;
+        if constexpr (KEY32) {
+            const uint32_t* a = reinterpret_cast<const uint32_t*>(codes);
+            const uint64_t l2 = lower_bound_dev<uint32_t>(a, lo, hi, (uint32_t)vlo);
+            hi = upper_bound_dev<uint32_t>(a, l2, hi, (uint32_t)vhi);
+            lo = l2;
+        } else {
+            const uint64_t* a = reinterpret_cast<const uint64_t*>(codes) + (uint64_t)w * n;
+            const uint64_t l2 = lower_bound_dev<uint64_t>(a, lo, hi, vlo);
+            hi = upper_bound_dev<uint64_t>(a, l2, hi, vhi);
+            lo = l2;
+        }
+    }
+    result[2 * k] = lo;
+    result[2 * k + 1] = hi;
+}
+
+Status index_find_many_device(cph_ctx* ctx, const cph_index* ix, const uint64_t* queries, size_t stride, uint64_t nkeys,
+                              uint64_t* lower, uint64_t* upper) {
+    const size_t qbytes = stride * nkeys * sizeof(uint64_t), rbytes = 2 * nkeys * sizeof(uint64_t);
+    DevBuf dq, dr;
+    CPH_TRY(dq.alloc(&ctx->pool, qbytes));
+    CPH_TRY(dr.alloc(&ctx->pool, rbytes));
+    CPH_TRY(ensure_pinned_scratch(ctx, qbytes > rbytes ? qbytes : rbytes));
+    memcpy(ctx->pinned_scratch, queries, qbytes);
+    CPH_HIP_TRY(hipMemcpyAsync(dq.get(), ctx->pinned_scratch, qbytes, hipMemcpyHostToDevice, ctx->stream));
+    {
+        ProfScope ps(ctx, "k_find_many", 0);
+        const dim3 grid((unsigned)((nkeys + 127) / 128)), block(128);
+        if (ix->codec.key32)
+            hipLaunchKernelGGL(k_find_many<true>, grid, block, 0, ctx->stream, ix->sorted_codes.get(), ix->nrows, dq.as<uint64_t>(), stride,
+                               nkeys, dr.as<uint64_t>());
+        else
+            hipLaunchKernelGGL(k_find_many<false>, grid, block, 0, ctx->stream, ix->sorted_codes.get(), ix->nrows, dq.as<uint64_t>(), stride,
+                               nkeys, dr.as<uint64_t>());
+        CPH_HIP_TRY(hipGetLastError());
+    }
+    // the download is ordered behind the kernel, which is ordered behind the upload: one wait for everything
+    CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, dr.get(), rbytes, hipMemcpyDeviceToHost, ctx->stream));
+    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const uint64_t* r = reinterpret_cast<const uint64_t*>(ctx->pinned_scratch);
+    for (uint64_t k = 0; k < nkeys; k++) {
+        lower[k] = r[2 * k];
+        upper[k] = r[2 * k + 1];
+    }
     return {};
 }
 

@@ -491,6 +491,12 @@ CPH_API void    cph_csv_table_release(cph_csv_table* t);
 CPH_API int32_t cph_index_find(cph_ctx* ctx, const cph_index* index, const cph_strval* values, int32_t nvalues,
                                uint64_t* lower, uint64_t* upper);
 
+/* Many Find / SubIndex calls at once (csvplus.go:625-641 in a loop, e.g. BenchmarkSearchSmallSingleIndex,
+ * csvplus_test.go:1104-1116): key k is values[k * nvalues .. (k + 1) * nvalues); lower[k] / upper[k] as cph_index_find.
+ * One upload, ONE kernel launch and one download for the whole batch instead of a launch and two waits per key. */
+CPH_API int32_t cph_index_find_many(cph_ctx* ctx, const cph_index* index, const cph_strval* values, int32_t nvalues,
+                                    uint64_t nkeys, uint64_t* lower, uint64_t* upper);
+
 /* ---- ResolveDuplicates support + persistence (csvplus.go:643-705, :810-867) ---- */
 
 /*
@@ -587,6 +593,15 @@ CPH_API int32_t cph_ctx_profile(cph_ctx* ctx, int32_t enable);
  * benchmark can time its dominant kernel inside the timed region without disturbing the region. */
 CPH_API int32_t cph_ctx_profile_only(cph_ctx* ctx, const char* kernel_name);
 CPH_API int32_t cph_ctx_profile_read(cph_ctx* ctx, cph_kernel_stat* out, int32_t cap, int32_t* n, int32_t reset);
+
+/*
+ * What this box's memory system sustains for the two access patterns the Join kernels are made of (a measurement
+ * utility, not part of the hot path): kind 0 = streaming copy, `bytes` read + `bytes` written with 16 bytes per lane;
+ * kind 1 = random gather of 4-byte entries, `n` lookups into a table of `bytes` bytes, 4 lookups in flight per thread,
+ * the indices (4 B) streamed in and the values (4 B) streamed out — one direct-table step of the chained-join kernel
+ * without any key decoding.  *ms = average of `reps` launches after two warm-up launches (HIP events on the ctx stream).
+ */
+CPH_API int32_t cph_calibrate(cph_ctx* ctx, int32_t kind, uint64_t bytes, uint64_t n, int32_t reps, double* ms);
 
 /* Library version, e.g. "csvplus_hip 0.1 (gfx950)". */
 CPH_API const char* cph_version(void);

@@ -71,7 +71,7 @@ def test_one_word_codes_random_alnum(ctx, dups):
 
 @pytest.mark.parametrize("dups", [False, True])
 def test_two_word_codes_random_alnum62(ctx, dups):
-    """12 random [A-Za-z0-9] characters: 62^12 ~ 2^71 -> two code words, both kept in the entry (kHashK2)."""
+    """12 random [A-Za-z0-9] characters: 62^12 ~ 2^71 -> two code words, both kept in the entry (kHashK3)."""
     rng = np.random.default_rng(201 + dups)
     n, m = 50_000, 120_000
     build = fixed_random(rng, n, 12, ALNUM62)
@@ -83,8 +83,8 @@ def test_two_word_codes_random_alnum62(ctx, dups):
 
 
 @pytest.mark.parametrize("dups", [False, True])
-def test_random_16_byte_keys_take_the_tag_path(ctx, dups):
-    """16 random BYTES (UUID-like, NUL and 0xFF included): three code words -> 64-bit tags, verified against the codes."""
+def test_random_16_byte_keys_three_words(ctx, dups):
+    """16 random BYTES (UUID-like, NUL and 0xFF included): three code words, still carried by the entry (kHashK3)."""
     rng = np.random.default_rng(301 + dups)
     n, m = 40_000, 100_000
     build = [rng.integers(0, 256, 16, dtype=np.uint8).tobytes() for _ in range(n)]
@@ -92,8 +92,22 @@ def test_random_16_byte_keys_take_the_tag_path(ctx, dups):
         build = [build[i] for i in rng.integers(0, n // 5, n)]
     near = [b[:15] + bytes([b[15] ^ 1]) for b in build[:3000]] + [b[:8] for b in build[:500]] + [b"", b"\x00" * 16]
     probe = probe_mix(rng, build, m, near)
+    g, o, mt = check_hash_join(ctx, [StrCol.from_values(build)], [StrCol.from_values(probe)], 2, unique_expected=not dups)
+    assert g.info()["code_words"] == 3
+
+
+@pytest.mark.parametrize("dups", [False, True])
+def test_random_30_byte_keys_take_the_tag_path(ctx, dups):
+    """20-30 random bytes: four or five code words -> 64-bit tags in the table, verified against the sorted codes."""
+    rng = np.random.default_rng(351 + dups)
+    n, m = 30_000, 80_000
+    build = [rng.integers(0, 256, int(rng.integers(20, 31)), dtype=np.uint8).tobytes() for _ in range(n)]
+    if dups:
+        build = [build[i] for i in rng.integers(0, n // 5, n)]
+    near = [b[:-1] + bytes([b[-1] ^ 1]) for b in build[:3000]] + [b[:8] for b in build[:500]] + [b + b"\x00" for b in build[:500]] + [b""]
+    probe = probe_mix(rng, build, m, near)
     g, o, mt = check_hash_join(ctx, [StrCol.from_values(build)], [StrCol.from_values(probe)], 3, unique_expected=not dups)
-    assert g.info()["code_words"] >= 3
+    assert g.info()["code_words"] >= 4
 
 
 def test_two_column_keys(ctx):

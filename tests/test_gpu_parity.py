@@ -222,6 +222,17 @@ def test_random_property(ctx, case, offset_bits):
         for k in range(1, len(bcols) + 1):
             vals = [x[r] for x in b[:k]]
             assert g.find(*vals) == oi.find(*vals)
+    # the same through cph_index_find_many: 500 keys of every arity in one launch (present, absent, unencodable)
+    for k in range(1, len(bcols) + 1):
+        rows = rng.integers(0, n, 400)
+        keys = [tuple(x[r] for x in b[:k]) for r in rows]
+        keys += [tuple(x[i] for x in p[:k]) for i in rng.integers(0, len(p[0]), 100)] if len(p) >= k else []
+        keys += [tuple([b"\x07\xfe?"] * k), tuple([b""] * k)]
+        lo, hi = g.find_many(keys)
+        for j, key in enumerate(keys):
+            olo, ohi = oi.find(*key)
+            assert hi[j] - lo[j] == ohi - olo and (ohi == olo or lo[j] == olo), (k, j, key)
+    assert g.find_many([()])[1][0] == n and len(g.find_many([])[0]) == 0
 
 
 def test_pdqsort_emulation_parity_class(ctx):
@@ -433,6 +444,10 @@ def test_keys_longer_than_one_codec_window(ctx, seed, max_len, ncols, tmp_path):
             glo, ghi = g.find(*vals)
             olo, ohi = o.find(*vals)
             assert ghi - glo == ohi - olo and (glo == olo or ghi == glo), (k, i)   # an empty range has no position
+        mlo, mhi = g.find_many([tuple(probe_vals[c][i] for c in range(k)) for i in range(0, 200)])
+        for i in range(0, 200):
+            olo, ohi = o.find(*[probe_vals[c][i] for c in range(k)])
+            assert mhi[i] - mlo[i] == ohi - olo and (ohi == olo or mlo[i] == olo), (k, i)
     # dup groups and select keep working on multi-window codes
     lo, hi = g.dup_groups()
     sel = g.select(sorted(set(range(0, n, 3))))

@@ -4,8 +4,9 @@ random 12-character alphanumerics, through cph_join_probe an
 the hash table (default) and with it switched off (ctx option join_hash = 0: the sorted search it replaces).
 
   [a-z0-9]     36^12 < 2^63  -> one code word  (hash entries carry the code: kHashK1)
-  [A-Za-z0-9]  62^12 ~ 2^71  -> two code words (both in the entry: kHashK2)
-  16 random bytes            -> three code words (64-bit tag + verification against the sorted codes: kHashTag)
+  [A-Za-z0-9]  62^12 ~ 2^71  -> two code words (both in the entry: kHashK3)
+  16 random bytes            -> three code words (all in the entry: kHashK3)
+  28 random bytes            -> four+ code words (64-bit tag + verification against the sorted codes: kHashTag)
 
 Results are spot-checked against numpy: the build row a probe row reports carries the probe row's bytes."""
 import sys
@@ -91,4 +92,5 @@ def run(name, alphabet, width):
 run("[a-z0-9] x 12 (one word)", A36, 12)
 run("[A-Za-z0-9] x 12 (two words)", A62, 12)
 if NB <= 10_000_000:
-    run("16 random bytes (three words, tags)", A256, 16)
+    run("16 random bytes (three words)", A256, 16)
+    run("28 random bytes (tags + verification)", A256, 28)
