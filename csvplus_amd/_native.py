@@ -95,6 +95,8 @@ class cph_index_info(C.Structure):
         ("lookup_built", C.c_int32),
         ("hash_mode", C.c_int32),
         ("hash_bytes", C.c_uint64),
+        ("build_path", C.c_int32),
+        ("reserved_", C.c_int32),
     ]
 
 

@@ -378,6 +378,8 @@ struct BuildJob {
     DevBuf stats_dev;
     size_t scratch_off = 0;      // where this job's read-backs land in ctx->pinned_scratch
     GroupSpec spec;              // speculative dictionaries (codec_try_groups)
+    bool small = false;          // one-launch build (small_build.hip): no statistics pass, no second synchronisation
+    SmallBufs sbufs;
 };
 
 static Status build_phase1(cph_ctx* ctx, const cph_strcol* keycols, int32_t nkeycols, BuildJob* job) {
@@ -389,7 +391,8 @@ static Status build_phase1(cph_ctx* ctx, const cph_strcol* keycols, int32_t nkey
     ix->nkeycols = nkeycols;
     job->nkeycols = nkeycols;
     CPH_TRY(stage_cols(ctx, keycols, nkeycols, &job->staged, job->dcols));
-    CPH_TRY(codec_stats_launch(ctx, job->dcols, nkeycols, &job->stats_dev));   // K0: alphabets
+    job->small = small_build_applies(ctx, job->dcols, nkeycols, ix->nrows);   // launched by build_run (needs its result slot)
+    if (!job->small) CPH_TRY(codec_stats_launch(ctx, job->dcols, nkeycols, &job->stats_dev));   // K0: alphabets
     return {};
 }
 
@@ -403,17 +406,25 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
         for (size_t i = 0; i < nj; i++)
             if (status[i].ok()) status[i] = s;
     };
-    // ---- sync 1: statistics ----
+    // ---- sync 1: statistics (general path) / the whole result (one-launch builds of small tables) ----
     size_t total = 0;
+    bool any_general = false;
     for (size_t i = 0; i < nj; i++) {
         jobs[i].scratch_off = total;
-        total += sizeof(ColStats) * (size_t)jobs[i].nkeycols;
+        total += jobs[i].small ? sizeof(SmallResult) : sizeof(ColStats) * (size_t)jobs[i].nkeycols;
+        total = (total + 63) & ~(size_t)63;
+        if (status[i].ok() && !jobs[i].small) any_general = true;
     }
     Status s = ensure_pinned_scratch(ctx, total > 64 ? total : 64);
     if (!s.ok()) return fail_all(s);
     uint8_t* h = static_cast<uint8_t*>(ctx->pinned_scratch);
     for (size_t i = 0; i < nj; i++) {
         if (!status[i].ok()) continue;
+        if (jobs[i].small) {
+            status[i] = small_build_launch(ctx, jobs[i].dcols, jobs[i].nkeycols, jobs[i].ix->nrows, &jobs[i].sbufs,
+                                           reinterpret_cast<SmallResult*>(h + jobs[i].scratch_off));
+            continue;
+        }
         hipError_t e = hipMemcpyAsync(h + jobs[i].scratch_off, jobs[i].stats_dev.get(), sizeof(ColStats) * (size_t)jobs[i].nkeycols,
                                       hipMemcpyDeviceToHost, ctx->stream);
         if (e != hipSuccess) status[i] = {CPH_ERR_HIP, std::string("statistics read-back: ") + hipGetErrorString(e)};
@@ -421,26 +432,51 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail_all({CPH_ERR_HIP, "hipStreamSynchronize failed"});
     // the host copies must survive phase 2 (which may reuse the scratch): take them out
     std::vector<std::vector<uint8_t>> stats_host(nj);
-    for (size_t i = 0; i < nj; i++)
-        if (status[i].ok()) stats_host[i].assign(h + jobs[i].scratch_off, h + jobs[i].scratch_off + sizeof(ColStats) * (size_t)jobs[i].nkeycols);
-    for (size_t i = 0; i < nj; i++)
-        if (status[i].ok()) status[i] = build_phase2(ctx, &jobs[i], stats_host[i].data());
-    // ---- sync 2: first duplicates ----
-    s = ensure_pinned_scratch(ctx, sizeof(uint32_t) * nj + 64);
-    if (!s.ok()) return fail_all(s);
-    uint32_t* fd = static_cast<uint32_t*>(ctx->pinned_scratch);
+    std::vector<size_t> retry;   // small-table candidates whose key needs the general path after all
     for (size_t i = 0; i < nj; i++) {
         if (!status[i].ok()) continue;
-        hipError_t e = hipMemcpyAsync(&fd[i], jobs[i].ix->first_dup_dev.get(), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
-        if (e != hipSuccess) status[i] = {CPH_ERR_HIP, std::string("first-duplicate read-back: ") + hipGetErrorString(e)};
+        if (jobs[i].small) {
+            const SmallResult res = *reinterpret_cast<const SmallResult*>(h + jobs[i].scratch_off);
+            bool not_small = false;
+            status[i] = small_build_finish(ctx, jobs[i].ix, jobs[i].nkeycols, &jobs[i].sbufs, &res, &not_small);
+            jobs[i].sbufs = SmallBufs{};
+            if (status[i].ok() && not_small) retry.push_back(i);
+            else if (status[i].ok()) index_plan_table(jobs[i].ix);
+            continue;
+        }
+        stats_host[i].assign(h + jobs[i].scratch_off, h + jobs[i].scratch_off + sizeof(ColStats) * (size_t)jobs[i].nkeycols);
     }
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail_all({CPH_ERR_HIP, "hipStreamSynchronize failed"});
-    for (size_t i = 0; i < nj; i++) {
-        if (!status[i].ok()) continue;
-        cph_index* ix = jobs[i].ix;
-        ix->first_dup = fd[i] != 0xFFFFFFFFu ? (uint64_t)fd[i] : UINT64_MAX;
-        ix->first_dup_dev.reset();
-        index_plan_table(ix);
+    for (size_t i = 0; i < nj; i++)
+        if (status[i].ok() && !jobs[i].small) status[i] = build_phase2(ctx, &jobs[i], stats_host[i].data());
+    // ---- sync 2: first duplicates ----
+    if (any_general) {
+        s = ensure_pinned_scratch(ctx, sizeof(uint32_t) * nj + 64);
+        if (!s.ok()) return fail_all(s);
+        uint32_t* fd = static_cast<uint32_t*>(ctx->pinned_scratch);
+        for (size_t i = 0; i < nj; i++) {
+            if (!status[i].ok() || jobs[i].small) continue;
+            hipError_t e = hipMemcpyAsync(&fd[i], jobs[i].ix->first_dup_dev.get(), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+            if (e != hipSuccess) status[i] = {CPH_ERR_HIP, std::string("first-duplicate read-back: ") + hipGetErrorString(e)};
+        }
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail_all({CPH_ERR_HIP, "hipStreamSynchronize failed"});
+        for (size_t i = 0; i < nj; i++) {
+            if (!status[i].ok() || jobs[i].small) continue;
+            cph_index* ix = jobs[i].ix;
+            ix->first_dup = fd[i] != 0xFFFFFFFFu ? (uint64_t)fd[i] : UINT64_MAX;
+            ix->first_dup_dev.reset();
+            index_plan_table(ix);
+        }
+    }
+    // keys the one-workgroup build could not take (more than kSmallMaxPos byte positions, codes of several words)
+    for (size_t i : retry) {
+        std::vector<BuildJob> one;
+        one.push_back(std::move(jobs[i]));
+        std::vector<Status> st1(1);
+        one[0].small = false;
+        st1[0] = codec_stats_launch(ctx, one[0].dcols, one[0].nkeycols, &one[0].stats_dev);
+        if (st1[0].ok()) build_run(ctx, one, st1);
+        status[i] = st1[0];
+        jobs[i] = std::move(one[0]);
     }
     // staged input copies are released with the jobs (stream-ordered reuse is safe)
 }
@@ -688,6 +724,7 @@ CPH_API int32_t cph_ctx_create(int32_t device_id, cph_ctx** out) {
     warm_materialize();
     warm_csv_ingest();
     warm_index_ops();
+    warm_small_build();
     (void)ensure_pinned_scratch(ctx, 1 << 16);
     void* ring = nullptr;
     (void)pinned_upload(ctx, 64, &ring);
@@ -721,6 +758,7 @@ CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value
     else if (k == "sort_xcd_tiles") ctx->sort_xcd_tiles = value != 0;
     else if (k == "codec_debug") ctx->codec_debug = value != 0;
     else if (k == "join_hash") ctx->join_hash = value != 0;
+    else if (k == "small_build_rows") ctx->small_build_rows = value < 0 ? 0 : value > (1 << 20) ? (1 << 20) : (int)value;
     else if (k == "plan_threads") ctx->plan_threads = (int)value;
     else if (k == "gstats_threads") ctx->gstats_threads = (int)value;
     else if (k == "speculative_groups") ctx->speculative_groups = value < 0 || value > 2 ? 1 : (int)value;   // 0 never, 1 when the sample shows no rare value, 2 always
@@ -1253,6 +1291,7 @@ CPH_API int32_t cph_index_get_info(const cph_index* ix, cph_index_info* info) {
     info->lookup_built = (ix->table ? 1 : 0) | (ix->rowtab ? 2 : 0) | (ix->hash_mode ? 4 : 0);
     info->hash_mode = ix->hash_mode;
     info->hash_bytes = (uint64_t)ix->hash_sectors * 64;
+    info->build_path = ix->small_built ? 1 : 0;
     return CPH_OK;
 }
 

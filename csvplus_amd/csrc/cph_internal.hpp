@@ -232,6 +232,7 @@ struct cph_ctx {
     int sort_threads = 0, sort_rbits = 0;   // radix-sort tuning overrides (0: automatic)
     int sort_digit_stream = 1;     // scatter writes the next pass's digits as a byte stream for its histogram (radix_sort.hip)
     int sort_xcd_tiles = 1;        // scatter: contiguous tile ranges per XCD (radix_sort.hip)
+    int small_build_rows = 8192;   // tables of at most this many rows (<= 16384) are indexed by ONE launch of one workgroup (small_build.hip); 0: never
     int join_hash = 1;             // 0: indexes of this ctx never get a hash table (A/B switch: sorted search instead)
     int codec_debug = 0;           // prints the window choice of codec_try_groups to stderr
     int plan_threads = 0, gstats_threads = 0;   // tuning: workgroup sizes of k_encode_build_plan / k_group_stats (0: default)
@@ -292,6 +293,7 @@ struct cph_index {
         if (accel_ready) (void)hipEventDestroy(accel_ready);
     }
     int32_t sort_passes = 0;
+    bool small_built = false;      // built by the one-launch path (small_build.hip)
     uint64_t first_dup = UINT64_MAX;
     uint32_t* perm_host = nullptr; // pinned copy (lazy)
     size_t perm_host_cap = 0;
@@ -467,6 +469,25 @@ void warm_chain();
 void warm_materialize();
 void warm_csv_ingest();
 void warm_index_ops();
+void warm_small_build();
+
+// small_build.hip: IndexOn of a small table in one launch (one workgroup) and one synchronisation
+constexpr int kSmallMaxPos = 64;              // byte positions of the key the one-workgroup build takes
+enum : uint32_t { kSmallBuilt = 0, kSmallNotSmall = 1, kSmallPending = 0xFFFFFFFFu };
+struct SmallResult {                          // written by k_small_build into pinned host memory
+    uint32_t status;                          // kSmallBuilt / kSmallNotSmall (too many positions, code of several words)
+    uint32_t first_dup;                       // first sorted position equal to its predecessor, 0xFFFFFFFF: none
+    uint32_t bits, key32, passes;
+    uint32_t minlen[kMaxKeyCols], maxlen[kMaxKeyCols];
+    uint32_t mask[kSmallMaxPos][8];           // ColStats::mask of the positions, column-major
+    uint64_t t[10];                           // wall_clock64() at the phase boundaries (ctx option codec_debug prints them)
+};
+struct SmallBufs {
+    DevBuf ka, kb, va, vb, sorted, perm;
+};
+bool small_build_applies(const cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t n);
+Status small_build_launch(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t n, SmallBufs* bufs, SmallResult* res);
+Status small_build_finish(cph_ctx* ctx, cph_index* ix, int32_t ncols, SmallBufs* bufs, const SmallResult* res, bool* not_small);
 
 // capi.hip helpers
 Status ensure_pinned_scratch(cph_ctx* ctx, size_t bytes);

@@ -1080,11 +1080,61 @@ __global__ void k_find(const void* __restrict__ codes, uint64_t n, const uint64_
     result[1] = hi;
 }
 
+// One Find with the query in the KERNEL ARGUMENTS and the answer written straight into pinned host memory: one
+// launch and one synchronisation, nothing to upload or download (queries of up to kFindArgWords words: every key of
+// one codec window).
+constexpr int kFindArgWords = 8;
+struct FindQuery {
+    int32_t nq;
+    uint64_t q[kFindArgWords + 1];   // layout as below
+};
+template <bool KEY32>
+__global__ void k_find_args(const void* __restrict__ codes, uint64_t n, const FindQuery fq, uint64_t* result_host) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int nq = fq.nq;
+    uint64_t lo = 0, hi = n;
+    for (int w = 0; w < nq; w++) {
+        const uint64_t vlo = (w + 1 == nq) ? fq.q[nq - 1] : fq.q[w];
+        const uint64_t vhi = (w + 1 == nq) ? fq.q[nq] : fq.q[w];
+        if constexpr (KEY32) {
+            const uint32_t* a = reinterpret_cast<const uint32_t*>(codes);
+            const uint64_t l2 = lower_bound_dev<uint32_t>(a, lo, hi, (uint32_t)vlo);
+            hi = upper_bound_dev<uint32_t>(a, l2, hi, (uint32_t)vhi);
+            lo = l2;
+        } else {
+            const uint64_t* a = reinterpret_cast<const uint64_t*>(codes) + (uint64_t)w * n;
+            const uint64_t l2 = lower_bound_dev<uint64_t>(a, lo, hi, vlo);
+            hi = upper_bound_dev<uint64_t>(a, l2, hi, vhi);
+            lo = l2;
+        }
+    }
+    result_host[0] = lo;
+    result_host[1] = hi;
+    __threadfence_system();
+}
+
 // q layout: q_exact[0..nq-2], then qlo at [nq-1], qhi at [nq]
 Status index_find_device(cph_ctx* ctx, const cph_index* ix, const uint64_t* q_exact, int32_t nq, uint64_t qlo,
                          uint64_t qhi, uint64_t* lower, uint64_t* upper) {
     const uint64_t n = ix->nrows;
     if (nq == 0 || n == 0) { *lower = 0; *upper = n; return {}; }
+    if (nq <= kFindArgWords) {
+        CPH_TRY(ensure_pinned_scratch(ctx, 2 * sizeof(uint64_t)));
+        uint64_t* h = reinterpret_cast<uint64_t*>(ctx->pinned_scratch);
+        FindQuery fq;
+        fq.nq = nq;
+        for (int i = 0; i + 1 < nq; i++) fq.q[i] = q_exact[i];
+        fq.q[nq - 1] = qlo;
+        fq.q[nq] = qhi;
+        h[0] = h[1] = ~0ull;
+        if (ix->codec.key32) hipLaunchKernelGGL(k_find_args<true>, dim3(1), dim3(64), 0, ctx->stream, ix->sorted_codes.get(), n, fq, h);
+        else hipLaunchKernelGGL(k_find_args<false>, dim3(1), dim3(64), 0, ctx->stream, ix->sorted_codes.get(), n, fq, h);
+        CPH_HIP_TRY(hipGetLastError());
+        CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        *lower = h[0];
+        *upper = h[1];
+        return {};
+    }
     DevBuf d;
     const size_t qbytes = sizeof(uint64_t) * (size_t)(nq + 1);
     CPH_TRY(d.alloc(&ctx->pool, qbytes + 2 * sizeof(uint64_t)));
@@ -1102,11 +1152,11 @@ Status index_find_device(cph_ctx* ctx, const cph_index* ix, const uint64_t* q_ex
         hipLaunchKernelGGL(k_find<false>, dim3(1), dim3(64), 0, ctx->stream, ix->sorted_codes.get(), n, d.as<uint64_t>(),
                            nq, dres);
     CPH_HIP_TRY(hipGetLastError());
-    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));   // h (input) consumed
-    CPH_HIP_TRY(hipMemcpyAsync(h, dres, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    // the download is ordered behind the kernel, which is ordered behind the upload: one wait for everything
+    CPH_HIP_TRY(hipMemcpyAsync(h + nq + 1, dres, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    *lower = h[0];
-    *upper = h[1];
+    *lower = h[nq + 1];
+    *upper = h[nq + 2];
     return {};
 }
 

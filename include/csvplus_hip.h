@@ -548,8 +548,11 @@ typedef struct {
     int32_t  lookup_built;    /* lookup structures BUILT so far (bits): 1 = 8-byte table, 2 = 4-byte row table,
                                  4 = hash table.  direct_table / table_entries only say one is PLANNED: the
                                  structures are built by the first Join that uses them (or cph_index_prepare_join) */
-    int32_t  hash_mode;       /* 0 none; 1 one code word per entry, 2 two words, 3 64-bit tag + verification     */
+    int32_t  hash_mode;       /* 0 none; 1 one code word per entry, 2 up to three words, 3 64-bit tag + verification */
     uint64_t hash_bytes;      /* size of the hash table                                                         */
+    int32_t  build_path;      /* 0: general path (statistics, host codec, encode, multi-launch radix sort);
+                                 1: the one-launch build of small tables (ctx option "small_build_rows", default 8192) */
+    int32_t  reserved_;
 } cph_index_info;
 
 CPH_API int32_t cph_index_get_info(const cph_index* index, cph_index_info* info);

@@ -39,3 +39,13 @@ def ctx():
     if guard:
         c.set_option("pool_guard_check", 0)   # raises CphError if any canary behind a device block was overwritten
     c.close()
+
+
+@pytest.fixture(params=["small_path", "general_path"])
+def both_build_paths(ctx, request):
+    """Runs a test twice: with the one-launch build of small tables (small_build.hip; up to 16384 rows here, 8192 by default)
+    and with it switched off, so that the general path (statistics, host codec, multi-launch radix sort) keeps being
+    checked on the same small inputs."""
+    ctx.set_option("small_build_rows", 16384 if request.param == "small_path" else 0)
+    yield request.param
+    ctx.set_option("small_build_rows", 8192)

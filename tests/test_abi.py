@@ -41,7 +41,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(N.cph_strcol) == 40
     assert ctypes.sizeof(N.cph_strval) == 16
     assert ctypes.sizeof(N.cph_matches) == 56
-    assert ctypes.sizeof(N.cph_index_info) == 64
+    assert ctypes.sizeof(N.cph_index_info) == 72
 
 
 def test_struct_sizes_against_the_compiled_header(tmp_path):

@@ -8,7 +8,7 @@ from csvplus_amd import DeviceIndex, StrCol, join_chain
 from oracle import orc
 from tests.helpers import assert_join_equal
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("both_build_paths")]
 
 value = st.one_of(
     st.binary(min_size=0, max_size=6),

@@ -12,7 +12,7 @@ from tests.helpers import (PEOPLE_NAMES, PEOPLE_SURNAMES, assert_join_equal, col
                            random_keys, stock_table)
 from tests.test_oracle import INDEX_IMPL_ROWS
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("both_build_paths")]
 
 
 def check_index(ctx, keycols, unique=False):
@@ -464,3 +464,28 @@ def test_keys_longer_than_one_codec_window(ctx, seed, max_len, ncols, tmp_path):
     assert ld.info() == g.info()
     ld.close()
     g.close()
+
+
+def test_small_table_build_path(ctx, both_build_paths):
+    """The one-launch build (small_build.hip) takes tables of <= small_build_rows rows whose per-position code fits one
+    word; everything else reports "not small" from the device and goes through the general path — same results."""
+    small_on = both_build_paths == "small_path"
+    rng = np.random.default_rng(77)
+    cases = {
+        "people_ids": ([StrCol.from_values(people_table()["id"])], True),
+        "name_surname": (cols_of(people_table(), "name", "surname"), True),
+        "orders_two_cols_10000": (cols_of(orders_table(), "cust_id", "prod_id"), True),
+        "one_row": ([StrCol.from_values([b"x"])], True),
+        "all_empty_values": ([StrCol.from_values([b""] * 100)], True),
+        "fixed_width": ([StrCol.from_values([b"%08d" % int(x) for x in rng.permutation(5000)])], True),
+        "variable_offsets64": ([StrCol.from_values([b"%d" % int(x) for x in rng.integers(0, 5000, 7000)], offset_bits=64)], True),
+        "65_positions": ([StrCol.from_values([bytes([65 + (i % 3)]) * (1 + i % 65) for i in range(300)])], False),
+        "two_code_words": ([StrCol.from_values(random_keys(rng, 3000, 14, 14, alphabet=list(range(48, 112))))], False),
+        "above_the_row_limit": ([StrCol.from_values([b"%d" % int(x) for x in rng.integers(0, 1000, 20000)])], False),
+    }
+    for name, (cols, expect_small) in cases.items():
+        g, o = check_index(ctx, cols)
+        assert g.info()["build_path"] == (1 if small_on and expect_small else 0), name
+        pr = [StrCol.from_values([c.value(i) for i in rng.integers(0, c.nrows, 500)] + [b"zz", b""]) for c in cols]
+        assert_join_equal(g.probe(pr), o.join(pr))
+        g.close()

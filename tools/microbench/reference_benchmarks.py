@@ -34,7 +34,7 @@ def fmt(s):
     return f"{s * 1e6:10.1f} us" if s < 1e-3 else f"{s * 1e3:10.3f} ms"
 
 
-print(f"{'benchmark':<34}{'rows':>12}  {'GPU (C ABI)':>14}  {'lean C port, 1 thread':>22}")
+print(f"{'benchmark':<44}{'rows':>12}  {'GPU (C ABI)':>14}  {'lean C port, 1 thread':>22}")
 for s in scales:
     npeople, norders = 120 * s, 10_000 * s
     people = dg.customers(npeople, encoding=dg.ITOA)
@@ -55,6 +55,14 @@ for s in scales:
     rows.append(("SearchSmallSingleIndex (Find)", npeople, timed(lambda: gp.find(b"0")), timed(lambda: op.find(b"0"))))
     rows.append(("SearchBiggerMultiIndex (Find)", norders, timed(lambda: gm.find(b"0", b"0")), timed(lambda: om.find(b"0", b"0"))))
 
+    # the same searches 1000 at a time through cph_index_find_many (one launch per batch): time per key
+    ids = [(people["id"].value(int(i)),) for i in range(0, npeople, max(1, npeople // 1000))][:1000]
+    pairs = [(orders["cust_id"].value(int(i)), orders["prod_id"].value(int(i))) for i in range(0, norders, max(1, norders // 1000))][:1000]
+    rows.append((f"  ... {len(ids)} keys per find_many, per key", npeople, timed(lambda: gp.find_many(ids)) / len(ids),
+                 timed(lambda: [op.find(*k) for k in ids], max_reps=20) / len(ids)))
+    rows.append((f"  ... {len(pairs)} keys per find_many, per key", norders, timed(lambda: gm.find_many(pairs)) / len(pairs),
+                 timed(lambda: [om.find(*k) for k in pairs], max_reps=20) / len(pairs)))
+
     def gpu_join(ix, col):
         m = ix.probe([col], out_mem=N.CPH_MEM_DEVICE)
         m.release()
@@ -64,6 +72,6 @@ for s in scales:
     rows.append(("JoinOnBiggerMultiIndex (prefix)", npeople, timed(lambda: gpu_join(gm, d_id)),
                  timed(lambda: om.join([people["id"]]), max_reps=5)))
     for name, n, g, c in rows:
-        print(f"{name:<34}{n:>12}  {fmt(g):>14}  {fmt(c):>22}", flush=True)
+        print(f"{name:<44}{n:>12}  {fmt(g):>14}  {fmt(c):>22}", flush=True)
     gp.close(); gm.close()
     print()
