@@ -3,6 +3,8 @@
 // Find bounds (csvplus.go:870-891).  No CPU fallback anywhere: without a GPU every entry
 // point fails with CPH_ERR_NO_DEVICE / CPH_ERR_HIP.
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <new>
 
 #include "cph_internal.hpp"
@@ -162,12 +164,20 @@ Status kernel_setup(cph_ctx* ctx, const void* fn, int threads, size_t lds, int* 
             if (blocks_per_cu) *blocks_per_cu = k.blocks_per_cu;
             return {};
         }
-    // the attribute is a high-water mark per function: only ever raise it, so that a smaller request later (another
-    // index's smaller codec block) cannot lower it under an earlier, larger user of the same kernel
-    size_t high = 0;
-    for (const auto& k : ctx->kernel_cfg)
-        if (k.fn == fn && k.lds > high) high = k.lds;
-    if (lds > high) CPH_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // hipFuncAttributeMaxDynamicSharedMemorySize is state of the (device, function) pair, shared by every ctx and
+    // thread of the process: it is a high-water mark that is only ever RAISED, so that a smaller request (another
+    // index's smaller codec block, another ctx, a stream-join worker thread) cannot lower it under an earlier,
+    // larger user of the same kernel
+    {
+        static std::mutex g_mu;
+        static std::map<std::pair<int, const void*>, size_t> g_high;
+        std::lock_guard<std::mutex> lk(g_mu);
+        size_t& high = g_high[{ctx->device, fn}];
+        if (lds > high) {
+            CPH_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            high = lds;
+        }
+    }
     int per_cu = 0;
     CPH_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds));
     if (per_cu < 1) per_cu = 1;

@@ -10,9 +10,21 @@
 // Results are DENSE: build_row[s][r] is valid where bit r of the match bitmap is set — no
 // device-side compaction, so nothing on the device ever waits for a host decision.
 //
-// Only chains the fused kernel accepts (distinct keys, one key column, one-word code with a
-// pre-multiplied LUT per index) can be streamed; other chains go through cph_join_chain per chunk.
+// Chains the fused kernel accepts (distinct keys, one key column, one-word code with a pre-multiplied
+// LUT per index) run as above: nothing on the host ever waits inside a chunk.
+//
+// Every OTHER chain (cph_stream_join_create_general: duplicate keys on the build side — TestLongChain's
+// shape, csvplus_test.go:248-366 —, several key columns, prefix joins, codes of several words, keys of
+// any length) has a result whose size is only known once the chunk has been probed, so the general
+// chain (chain.hip: chain_run = probe / expand / compose per step) needs host decisions inside a
+// chunk.  There each slot owns a WORKER THREAD as well: the thread stages the chunk, runs the general
+// chain on the slot's stream and pool, and copies the pair list into the slot's pinned block; its
+// stream synchronisations block that thread only, so the uploads, kernels and downloads of the
+// other slots' chunks go on meanwhile.  Lookup structures of the indexes are built once, in create.
+#include <condition_variable>
+#include <mutex>
 #include <new>
+#include <thread>
 
 #include "cph_internal.hpp"
 
@@ -34,7 +46,19 @@ struct cph_stream_join {
         uint32_t* h_rows[CPH_MAX_CHAIN] = {nullptr};
         uint64_t* h_masks = nullptr;
         uint64_t* h_total = nullptr;
+        // general mode: a worker thread per slot
+        std::thread worker;
+        std::mutex mu;
+        std::condition_variable cv;
+        bool has_job = false, job_done = false, quit = false;
+        std::vector<cph_strcol> job_cols;
+        Status job_status;
+        uint64_t r_matches = 0;
+        const uint64_t* r_stream = nullptr;
     };
+    bool general = false;
+    int ncols[CPH_MAX_CHAIN] = {1, 1, 1, 1};
+    int total_cols = 0;
     std::vector<Slot*> slots;
     std::vector<int> fifo;                 // slot numbers in submission order
     uint64_t submit_seq = 0;               // chunks submitted so far: chunk k uses slot k % nslots
@@ -45,10 +69,114 @@ static int32_t sj_fail(cph_ctx* ctx, int32_t code, const std::string& msg) {
     return code;
 }
 
+
+// A chunk's key column (host, offsets may start anywhere in the column's buffer) made device resident on the slot's
+// stream: only the chunk's bytes [first, last) travel, the data pointer is biased so that the offsets stay valid.
+static Status stage_chunk_col(cph_ctx* ctx, const cph_strcol& c, uint64_t n, std::vector<DevBuf>* keep, DevCol* out) {
+    if (c.nrows != n) return {CPH_ERR_INVALID, "chunk columns differ in row count"};
+    if (c.mem != CPH_MEM_HOST) return {CPH_ERR_INVALID, "stream-join chunks are host columns"};
+    DevCol d;
+    d.nrows = n;
+    d.offset_bits = c.offset_bits;
+    d.fixed_width = c.fixed_width;
+    if (c.fixed_width) {
+        if (!c.data) return {CPH_ERR_INVALID, "data is NULL"};
+        const size_t bytes = (size_t)n * c.fixed_width;
+        DevBuf bd;
+        CPH_TRY(bd.alloc(&ctx->pool, bytes + 8));
+        CPH_HIP_TRY(hipMemcpyAsync(bd.get(), c.data, bytes, hipMemcpyHostToDevice, ctx->stream));
+        d.data = bd.as<uint8_t>();
+        keep->push_back(std::move(bd));
+    } else {
+        if (c.offset_bits != 32 && c.offset_bits != 64) return {CPH_ERR_INVALID, "offset_bits must be 32 or 64"};
+        if (!c.offsets) return {CPH_ERR_INVALID, "offsets is NULL"};
+        const size_t ob = (size_t)(c.offset_bits / 8);
+        const uint64_t first = ob == 4 ? ((const uint32_t*)c.offsets)[0] : ((const uint64_t*)c.offsets)[0];
+        const uint64_t last = ob == 4 ? ((const uint32_t*)c.offsets)[n] : ((const uint64_t*)c.offsets)[n];
+        if (last < first) return {CPH_ERR_INVALID, "offsets are not monotonic"};
+        if (last > first && !c.data) return {CPH_ERR_INVALID, "data is NULL"};
+        DevBuf bo, bd;
+        CPH_TRY(bo.alloc(&ctx->pool, (size_t)(n + 1) * ob));
+        CPH_TRY(bd.alloc(&ctx->pool, (size_t)(last - first) + 16));
+        CPH_HIP_TRY(hipMemcpyAsync(bo.get(), c.offsets, (size_t)(n + 1) * ob, hipMemcpyHostToDevice, ctx->stream));
+        if (last > first)
+            CPH_HIP_TRY(hipMemcpyAsync(bd.get(), c.data + first, (size_t)(last - first), hipMemcpyHostToDevice, ctx->stream));
+        // offsets keep their absolute values: bias the data pointer instead of rewriting them
+        d.data = bd.as<uint8_t>() - first;
+        d.offsets = bo.get();
+        keep->push_back(std::move(bo));
+        keep->push_back(std::move(bd));
+    }
+    *out = d;
+    return {};
+}
+
+// General mode, on the slot's worker thread: stage, run the general chain, bring the pair list to the pinned block.
+static Status general_chunk(cph_stream_join* sj, cph_stream_join::Slot& sl) {
+    cph_ctx* ctx = &sl.sctx;
+    CPH_HIP_TRY(hipSetDevice(ctx->device));
+    const uint64_t n = sl.nrows;
+    std::vector<DevBuf> staged;
+    ChainStep cs[CPH_MAX_CHAIN];
+    int ci = 0;
+    for (int k = 0; k < sj->nsteps; k++) {
+        cs[k].index = sj->index[k];
+        cs[k].ncols = sj->ncols[k];
+        for (int c = 0; c < sj->ncols[k]; c++, ci++) CPH_TRY(stage_chunk_col(ctx, sl.job_cols[(size_t)ci], n, &staged, &cs[k].cols[c]));
+    }
+    ChainOut co;
+    CPH_TRY(chain_run(ctx, cs, sj->nsteps, sl.probe_base, &co));
+    const uint64_t m = co.nrows;
+    auto a64 = [](size_t x) { return (x + 63) & ~(size_t)63; };
+    const size_t b64 = a64(m * sizeof(uint64_t)), b32 = a64(m * sizeof(uint32_t));
+    const size_t need = b64 + (size_t)sj->nsteps * b32 + 64;
+    if (need > sl.h_cap) {
+        if (sl.h_block) (void)hipHostFree(sl.h_block);
+        sl.h_block = nullptr;
+        sl.h_cap = 0;
+        const size_t cap = need + need / 4;   // pair lists of later chunks vary in size: leave head room, page-locking is slow
+        CPH_HIP_TRY(hipHostMalloc(&sl.h_block, cap, hipHostMallocDefault));
+        sl.h_cap = cap;
+    }
+    uint8_t* h = static_cast<uint8_t*>(sl.h_block);
+    sl.r_matches = m;
+    sl.r_stream = nullptr;
+    for (int k = 0; k < sj->nsteps; k++) sl.h_rows[k] = nullptr;
+    if (m) {
+        if (!co.identity) {
+            CPH_HIP_TRY(hipMemcpyAsync(h, co.stream_row.get(), m * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+            sl.r_stream = reinterpret_cast<const uint64_t*>(h);
+        }
+        for (int k = 0; k < sj->nsteps; k++) {
+            sl.h_rows[k] = reinterpret_cast<uint32_t*>(h + b64 + (size_t)k * b32);
+            CPH_HIP_TRY(hipMemcpyAsync(sl.h_rows[k], co.build_row[k].get(), m * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        }
+    }
+    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return {};
+}
+
+static void slot_worker(cph_stream_join* sj, cph_stream_join::Slot* sl) {
+    for (;;) {
+        std::unique_lock<std::mutex> lk(sl->mu);
+        sl->cv.wait(lk, [&] { return sl->has_job || sl->quit; });
+        if (sl->quit) return;
+        sl->has_job = false;
+        lk.unlock();
+        Status st = general_chunk(sj, *sl);
+        if (!st.ok()) (void)hipStreamSynchronize(sl->sctx.stream);
+        lk.lock();
+        sl->job_status = st;
+        sl->job_done = true;
+        lk.unlock();
+        sl->cv.notify_all();
+    }
+}
+
 extern "C" {
 
-CPH_API int32_t cph_stream_join_create(cph_ctx* ctx, const cph_index* const* indexes, int32_t nsteps, int32_t nslots,
-                                       cph_stream_join** out) {
+static int32_t stream_join_create(cph_ctx* ctx, const cph_index* const* indexes, const int32_t* ncols, int32_t nsteps, int32_t nslots,
+                                  bool general_ok, cph_stream_join** out) {
     if (!ctx || !indexes || !out || nsteps < 1 || nsteps > CPH_MAX_CHAIN || nslots < 1 || nslots > 16)
         return sj_fail(ctx, CPH_ERR_INVALID, "bad stream-join arguments");
     *out = nullptr;
@@ -57,16 +185,27 @@ CPH_API int32_t cph_stream_join_create(cph_ctx* ctx, const cph_index* const* ind
     for (int s = 0; s < nsteps; s++) {
         if (!indexes[s]) return sj_fail(ctx, CPH_ERR_INVALID, "index is NULL");
         probe[s].index = indexes[s];
-        probe[s].ncols = 1;
+        probe[s].ncols = ncols ? ncols[s] : 1;
+        if (probe[s].ncols < 1) return sj_fail(ctx, CPH_ERR_INVALID, "a chain step needs at least one key column");
+        if (probe[s].ncols > indexes[s]->nkeycols) return sj_fail(ctx, CPH_ERR_TOO_MANY_COLS, "too many source columns in Join()");
     }
-    if (!chain_fast_path_ok(probe, nsteps))
+    size_t lds = 0;
+    for (int s = 0; s < nsteps; s++) lds += indexes[s]->codec_dev.bytes();
+    const bool fast = chain_fast_path_ok(probe, nsteps) && lds <= 150 * 1024;   // what chain_run sends through the fused kernel
+    if (!fast && !general_ok)
         return sj_fail(ctx, CPH_ERR_INVALID,
-                       "stream join needs indexes with distinct keys over one key column (use cph_join_chain per chunk)");
-    // the slots run on their own streams: build the indexes' lookup tables now, on the parent stream they were
-    // built on, and wait for it once
+                       "stream join needs indexes with distinct keys over one key column (cph_stream_join_create_general takes any chain)");
+    // the slots run on their own streams (and, in general mode, threads): build the indexes' lookup structures now,
+    // on the stream they belong to, and wait for it once — afterwards the indexes are only read
     for (int s = 0; s < nsteps; s++) {
-        Status st = index_ensure_rowtab(ctx, indexes[s]);
-        if (st.ok() && !indexes[s]->rowtab) st = index_ensure_hash(ctx, indexes[s]);   // sparse code space: the hash table
+        Status st;
+        if (fast) {
+            st = index_ensure_rowtab(ctx, indexes[s]);
+            if (st.ok() && !indexes[s]->rowtab) st = index_ensure_hash(ctx, indexes[s]);   // sparse code space: the hash table
+        } else if (probe[s].ncols == indexes[s]->nkeycols && indexes[s]->nrows) {   // a prefix join searches the sorted codes
+            if (indexes[s]->table_entries != 0 && indexes[s]->windows.empty()) st = index_ensure_table(ctx, indexes[s]);
+            if (st.ok() && !indexes[s]->table && index_wants_hash(indexes[s])) st = index_ensure_hash(ctx, indexes[s]);
+        }
         if (!st.ok()) return sj_fail(ctx, st.code, st.msg);
     }
     (void)hipStreamSynchronize(ctx->stream);
@@ -76,7 +215,12 @@ CPH_API int32_t cph_stream_join_create(cph_ctx* ctx, const cph_index* const* ind
     if (!sj) return sj_fail(ctx, CPH_ERR_NOMEM, "out of host memory");
     sj->parent = ctx;
     sj->nsteps = nsteps;
-    for (int s = 0; s < nsteps; s++) sj->index[s] = indexes[s];
+    sj->general = !fast;
+    for (int s = 0; s < nsteps; s++) {
+        sj->index[s] = indexes[s];
+        sj->ncols[s] = probe[s].ncols;
+        sj->total_cols += probe[s].ncols;
+    }
     for (int i = 0; i < nslots; i++) {
         auto* sl = new (std::nothrow) cph_stream_join::Slot();
         if (!sl || hipStreamCreateWithFlags(&sl->sctx.stream, hipStreamNonBlocking) != hipSuccess ||
@@ -87,10 +231,23 @@ CPH_API int32_t cph_stream_join_create(cph_ctx* ctx, const cph_index* const* ind
         }
         sl->sctx.device = ctx->device;
         sl->sctx.own_stream = true;
+        sl->sctx.join_hash = ctx->join_hash;
         sj->slots.push_back(sl);
+        if (sj->general) sl->worker = std::thread(slot_worker, sj, sl);
     }
     *out = sj;
     return CPH_OK;
+}
+
+CPH_API int32_t cph_stream_join_create(cph_ctx* ctx, const cph_index* const* indexes, int32_t nsteps, int32_t nslots,
+                                       cph_stream_join** out) {
+    return stream_join_create(ctx, indexes, nullptr, nsteps, nslots, false, out);
+}
+
+CPH_API int32_t cph_stream_join_create_general(cph_ctx* ctx, const cph_index* const* indexes, const int32_t* ncols, int32_t nsteps,
+                                               int32_t nslots, cph_stream_join** out) {
+    if (!ncols) return sj_fail(ctx, CPH_ERR_INVALID, "ncols is NULL");
+    return stream_join_create(ctx, indexes, ncols, nsteps, nslots, true, out);
 }
 
 CPH_API void cph_stream_join_destroy(cph_stream_join* sj) {
@@ -98,6 +255,14 @@ CPH_API void cph_stream_join_destroy(cph_stream_join* sj) {
     if (sj->parent) (void)hipSetDevice(sj->parent->device);
     for (auto* sl : sj->slots) {
         if (!sl) continue;
+        if (sl->worker.joinable()) {
+            {
+                std::lock_guard<std::mutex> lk(sl->mu);
+                sl->quit = true;
+            }
+            sl->cv.notify_all();
+            sl->worker.join();
+        }
         if (sl->sctx.stream) (void)hipStreamSynchronize(sl->sctx.stream);
         sl->d_in.clear();
         for (auto& b : sl->d_rows) b.reset();
@@ -130,43 +295,27 @@ CPH_API int32_t cph_stream_join_submit(cph_stream_join* sj, const cph_strcol* st
     cph_ctx* ctx = &sl.sctx;
     const uint64_t n = step_cols[0].nrows;
     if (n == 0 || n > 0xFFFFFFFFull) return sj_fail(pctx, CPH_ERR_INVALID, "chunk must have 1 .. 2^32-1 rows");
+    if (sj->general) {   // hand the chunk to the slot's worker thread
+        {
+            std::lock_guard<std::mutex> lk(sl.mu);
+            sl.job_cols.assign(step_cols, step_cols + sj->total_cols);
+            sl.probe_base = probe_base;
+            sl.nrows = n;
+            sl.job_done = false;
+            sl.has_job = true;
+        }
+        sl.cv.notify_all();
+        sl.busy = true;
+        sj->submit_seq++;
+        sj->fifo.push_back(slot);
+        return CPH_OK;
+    }
     auto run = [&]() -> Status {
         sl.d_in.clear();
         ChainStep steps[CPH_MAX_CHAIN];
         for (int s = 0; s < sj->nsteps; s++) {
-            const cph_strcol& c = step_cols[s];
-            if (c.nrows != n) return {CPH_ERR_INVALID, "chunk columns differ in row count"};
-            if (c.mem != CPH_MEM_HOST) return {CPH_ERR_INVALID, "stream-join chunks are host columns"};
             DevCol d;
-            d.nrows = n;
-            d.offset_bits = c.offset_bits;
-            d.fixed_width = c.fixed_width;
-            if (c.fixed_width) {
-                const size_t bytes = (size_t)n * c.fixed_width;
-                DevBuf bd;
-                CPH_TRY(bd.alloc(&ctx->pool, bytes + 8));
-                CPH_HIP_TRY(hipMemcpyAsync(bd.get(), c.data, bytes, hipMemcpyHostToDevice, ctx->stream));
-                d.data = bd.as<uint8_t>();
-                sl.d_in.push_back(std::move(bd));
-            } else {
-                if (c.offset_bits != 32 && c.offset_bits != 64) return {CPH_ERR_INVALID, "offset_bits must be 32 or 64"};
-                const size_t ob = (size_t)(c.offset_bits / 8);
-                const uint64_t first = ob == 4 ? ((const uint32_t*)c.offsets)[0] : ((const uint64_t*)c.offsets)[0];
-                const uint64_t last = ob == 4 ? ((const uint32_t*)c.offsets)[n] : ((const uint64_t*)c.offsets)[n];
-                if (last < first) return {CPH_ERR_INVALID, "offsets are not monotonic"};
-                DevBuf bo, bd;
-                CPH_TRY(bo.alloc(&ctx->pool, (size_t)(n + 1) * ob));
-                CPH_TRY(bd.alloc(&ctx->pool, (size_t)(last - first) + 16));
-                CPH_HIP_TRY(hipMemcpyAsync(bo.get(), c.offsets, (size_t)(n + 1) * ob, hipMemcpyHostToDevice, ctx->stream));
-                if (last > first)
-                    CPH_HIP_TRY(hipMemcpyAsync(bd.get(), c.data + first, (size_t)(last - first), hipMemcpyHostToDevice,
-                                               ctx->stream));
-                // offsets keep their absolute values: bias the data pointer instead of rewriting them
-                d.data = bd.as<uint8_t>() - first;
-                d.offsets = bo.get();
-                sl.d_in.push_back(std::move(bo));
-                sl.d_in.push_back(std::move(bd));
-            }
+            CPH_TRY(stage_chunk_col(ctx, step_cols[s], n, &sl.d_in, &d));
             steps[s].index = sj->index[s];
             steps[s].ncols = 1;
             steps[s].cols[0] = d;
@@ -230,6 +379,26 @@ CPH_API int32_t cph_stream_join_next(cph_stream_join* sj, cph_stream_chunk* out)
     const int slot = sj->fifo.front();
     sj->fifo.erase(sj->fifo.begin());
     auto& sl = *sj->slots[slot];
+    if (sj->general) {
+        Status st;
+        {
+            std::unique_lock<std::mutex> lk(sl.mu);
+            sl.cv.wait(lk, [&] { return sl.job_done; });
+            st = sl.job_status;
+        }
+        sl.busy = false;
+        if (!st.ok()) return sj_fail(pctx, st.code, st.msg);
+        memset(out, 0, sizeof *out);
+        out->probe_base = sl.probe_base;
+        out->nrows = sl.nrows;
+        out->nmatches = sl.r_matches;
+        out->match_bitmap = nullptr;
+        out->nsteps = sj->nsteps;
+        out->dense = 0;
+        out->stream_row = sl.r_stream;
+        for (int s = 0; s < sj->nsteps; s++) out->build_row[s] = sl.h_rows[s];
+        return CPH_OK;
+    }
     hipError_t e = hipEventSynchronize(sl.done);
     sl.busy = false;
     if (e != hipSuccess) return sj_fail(pctx, CPH_ERR_HIP, std::string("chunk failed: ") + hipGetErrorString(e));
@@ -239,6 +408,8 @@ CPH_API int32_t cph_stream_join_next(cph_stream_join* sj, cph_stream_chunk* out)
     out->nmatches = *sl.h_total;
     out->match_bitmap = sl.h_masks;
     out->nsteps = sj->nsteps;
+    out->dense = 1;
+    out->stream_row = nullptr;
     for (int s = 0; s < sj->nsteps; s++) out->build_row[s] = sl.h_rows[s];
     return CPH_OK;
 }

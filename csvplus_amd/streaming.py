@@ -39,20 +39,28 @@ class PinnedCol:
 
 
 class StreamJoin:
-    def __init__(self, ctx: N.Context, indexes, nslots: int = 3):
+    def __init__(self, ctx: N.Context, indexes, nslots: int = 3, ncols=None):
+        """ncols=None: the fused-kernel pipeline (cph_stream_join_create: distinct keys, one key column per index).
+        ncols=[columns of the stream per step]: any chain (cph_stream_join_create_general), results as pair lists
+        unless the chain qualifies for the fused kernel."""
         self.ctx = ctx
         self.lib = ctx.lib
         self.indexes = list(indexes)
         arr = (C.c_void_p * len(self.indexes))(*[ix.handle for ix in self.indexes])
         h = C.c_void_p()
-        ctx._check(self.lib.cph_stream_join_create(ctx.handle, arr, len(self.indexes), nslots, C.byref(h)))
+        if ncols is None:
+            ctx._check(self.lib.cph_stream_join_create(ctx.handle, arr, len(self.indexes), nslots, C.byref(h)))
+        else:
+            assert len(ncols) == len(self.indexes)
+            nc = (C.c_int32 * len(ncols))(*[int(x) for x in ncols])
+            ctx._check(self.lib.cph_stream_join_create_general(ctx.handle, arr, nc, len(self.indexes), nslots, C.byref(h)))
         self.handle = h
         self.nslots = nslots
         self._keep = []
         ctx._children.add(self)
 
     def submit(self, step_cols, probe_base: int = 0):
-        """step_cols: one host StrCol per step.  Raises CphError(CPH_ERR_INVALID) when every slot is in flight."""
+        """step_cols: the steps' key columns one after the other (one host StrCol per step in the fused mode).  Raises CphError(CPH_ERR_INVALID) when every slot is in flight."""
         arr = (N.cph_strcol * len(step_cols))()
         keep = []
         for i, c in enumerate(step_cols):
@@ -73,12 +81,23 @@ class StreamJoin:
         if self._keep:
             self._keep.pop(0)
         n = int(ch.nrows)
+        if not ch.dense:   # pair lists (general chains): cph_chain's layout
+            m = int(ch.nmatches)
+            rows = [N._ptr_array(ch.build_row[k], m, np.uint32) if m else np.zeros(0, np.uint32) for k in range(int(ch.nsteps))]
+            sr = N._ptr_array(ch.stream_row, m, np.uint64) if (m and ch.stream_row) else None
+            if copy:
+                rows = [r.copy() for r in rows]
+                sr = sr.copy() if sr is not None else None
+            if sr is None:
+                sr = np.arange(int(ch.probe_base), int(ch.probe_base) + m, dtype=np.uint64)
+            return {"probe_base": int(ch.probe_base), "nrows": n, "nmatches": m, "dense": False, "stream_row": sr,
+                    "build_row": rows}
         words = (n + 1023) // 1024 * 16
         bm = N._ptr_array(ch.match_bitmap, words, np.uint64)
         rows = [N._ptr_array(ch.build_row[k], n, np.uint32) for k in range(int(ch.nsteps))]
         if copy:
             bm, rows = bm.copy(), [r.copy() for r in rows]
-        return {"probe_base": int(ch.probe_base), "nrows": n, "nmatches": int(ch.nmatches), "bitmap": bm,
+        return {"probe_base": int(ch.probe_base), "nrows": n, "nmatches": int(ch.nmatches), "dense": True, "bitmap": bm,
                 "build_row": rows}
 
     def close(self):

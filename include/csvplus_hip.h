@@ -341,15 +341,26 @@ CPH_API int32_t cph_dist_index_broadcast(cph_dist* d, const cph_index* root_inde
 /*
  * The probe side of a Join is a stream (csvplus.go:545-569 never materialises it).
  * When it lives in host memory it is fed chunk by chunk through a pipeline of
- * `nslots` slots, each with its own HIP stream: a submitted chunk's H2D copy,
- * kernels and D2H copy are enqueued without any host synchronisation, so
- * consecutive chunks overlap upload, compute and download.  Chains are limited to
- * what the fused kernel accepts: every index has distinct keys over ONE key column
- * (CPH_ERR_INVALID otherwise; use cph_join_chain per chunk for the general case).
+ * `nslots` slots, each with its own HIP stream, so that consecutive chunks overlap
+ * upload, compute and download.
  *
- * Results are DENSE per chunk: row r of the chunk joined iff bit (r % 64) of
- * match_bitmap[r / 64] is set, and then build_row[k][r] is the original row id in
- * index k.  Emission order is row order.  nmatches = number of set bits.
+ * cph_stream_join_create — chains the fused kernel accepts (every index has distinct
+ * keys over ONE key column; CPH_ERR_INVALID otherwise): a submitted chunk's H2D copy,
+ * kernels and D2H copy are enqueued without any host synchronisation.  Results are
+ * DENSE per chunk (cph_stream_chunk.dense = 1): row r of the chunk joined iff bit
+ * (r % 64) of match_bitmap[r / 64] is set, and then build_row[k][r] is the original
+ * row id in index k.  Emission order is row order.  nmatches = number of set bits.
+ *
+ * cph_stream_join_create_general — ANY chain cph_join_chain takes (duplicate keys on
+ * the build side, several key columns per step, prefix joins, keys of any length):
+ * ncols[k] stream columns are step k's key, submit() takes the steps' columns one
+ * after the other (ncols[0] + ncols[1] + ... columns).  The size of such a result is
+ * only known after the probe, so every slot also owns a worker thread that runs the
+ * general chain on the slot's stream; the pipeline overlaps across slots as before.
+ * Results are PAIR LISTS per chunk (dense = 0), exactly cph_chain's layout:
+ * nmatches joined rows in the reference's emission order, stream_row[m] (NULL: the
+ * identity probe_base + m) and build_row[k][m]; match_bitmap is NULL.  A chain the
+ * fused kernel accepts runs in the dense mode here as well.
  */
 typedef struct cph_stream_join cph_stream_join;
 
@@ -360,11 +371,14 @@ typedef struct {
     const uint64_t* match_bitmap;   /* ceil(nrows/1024)*16 words (>= nrows bits)        */
     const uint32_t* build_row[CPH_MAX_CHAIN];
     int32_t         nsteps;
-    int32_t         reserved_;
+    int32_t         dense;          /* 1: bitmap + one build row per chunk row; 0: pair lists of nmatches rows */
+    const uint64_t* stream_row;     /* dense = 0: probe_base + chunk row of every joined row (NULL: identity)  */
 } cph_stream_chunk;
 
 CPH_API int32_t cph_stream_join_create(cph_ctx* ctx, const cph_index* const* indexes, int32_t nsteps, int32_t nslots,
                                        cph_stream_join** out);
+CPH_API int32_t cph_stream_join_create_general(cph_ctx* ctx, const cph_index* const* indexes, const int32_t* ncols,
+                                               int32_t nsteps, int32_t nslots, cph_stream_join** out);
 CPH_API void    cph_stream_join_destroy(cph_stream_join* sj);
 /* step_cols[k] = the chunk's key column for step k: HOST memory (pinned — cph_pinned_alloc —
  * for real overlap), borrowed until the chunk has been returned by cph_stream_join_next.

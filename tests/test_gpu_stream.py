@@ -99,3 +99,79 @@ def test_stream_join_returned_chunk_survives_later_submits(ctx):
         np.testing.assert_array_equal(r["build_row"][0][hit], expect[k]["build_row"])
         assert r["nmatches"] == expect[k]["nmatches"]
     sj.close()
+
+
+def oracle_chain_general(oix, step_cols, probe_base):
+    """The chain as nested Joins (csvplus.go:545-569): (stream_row, [build_row per step]) in emission order."""
+    j = oix[0].join(step_cols[0], probe_base=probe_base)
+    stream, rows = j["probe_idx"], [j["build_row"]]
+    for k in range(1, len(oix)):
+        jk = oix[k].join(step_cols[k], row_sel=(stream - probe_base).astype(np.uint32))
+        pick = jk["probe_idx"].astype(np.int64)
+        stream, rows = stream[pick], [r[pick] for r in rows] + [jk["build_row"]]
+    return stream, rows
+
+
+@pytest.mark.parametrize("shape", ["dup_build_side", "two_column_key_and_prefix", "long_keys_two_words"])
+def test_stream_join_general_chains(ctx, shape):
+    """cph_stream_join_create_general: chains the fused kernel rejects (TestLongChain's duplicate build side,
+    csvplus_test.go:248-366; several key columns; a prefix join; multi-word codes), streamed chunk by chunk from ONE
+    host table (chunks are row ranges: offsets do not start at 0) and compared with the oracle per chunk."""
+    rng = np.random.default_rng({"dup_build_side": 5, "two_column_key_and_prefix": 6, "long_keys_two_words": 7}[shape])
+    n_stream = 120_000
+    if shape == "dup_build_side":
+        # orders-like build side: many rows per customer; second step against a duplicate-free table
+        b0 = [StrCol.from_values([b"%d" % int(x) for x in rng.integers(0, 300, 2000)])]
+        b1 = [StrCol.from_values([b"p%03d" % i for i in range(50)])]
+        s0 = [StrCol.from_values([b"%d" % int(x) for x in rng.integers(0, 400, n_stream)])]
+        s1 = [StrCol.from_values([b"p%03d" % int(x) for x in rng.integers(0, 60, n_stream)])]
+        ncols = [1, 1]
+    elif shape == "two_column_key_and_prefix":
+        names = [b"amelia", b"olivia", b"jack", b"harry", b"isla"]
+        b0 = [StrCol.from_values([names[int(i)] for i in rng.integers(0, 5, 3000)]),
+              StrCol.from_values([b"%d" % int(x) for x in rng.integers(0, 40, 3000)])]
+        b1 = [StrCol.from_values([b"%d" % int(x) for x in rng.integers(0, 30, 500)]),
+              StrCol.from_values([b"x%d" % int(x) for x in rng.integers(0, 9, 500)])]
+        s0 = [StrCol.from_values([names[int(i)] if i < 5 else b"nobody" for i in rng.integers(0, 6, n_stream)]),
+              StrCol.from_values([b"%d" % int(x) for x in rng.integers(0, 45, n_stream)])]
+        s1 = [StrCol.from_values([b"%d" % int(x) for x in rng.integers(0, 33, n_stream)])]   # prefix of b1's key
+        ncols = [2, 1]
+    else:
+        pool = [bytes(rng.integers(97, 123, int(rng.integers(18, 30)), dtype=np.uint8)) for _ in range(4000)]
+        b0 = [StrCol.from_values([pool[int(i)] for i in rng.integers(0, 3000, 6000)])]
+        b1 = [StrCol.from_values([b"%d" % i for i in range(100)])]
+        s0 = [StrCol.from_values([pool[int(i)] for i in rng.integers(0, 4000, n_stream)])]
+        s1 = [StrCol.from_values([b"%d" % int(x) for x in rng.integers(0, 100, n_stream)])]
+        ncols = [1, 1]
+    gix = [DeviceIndex(ctx, b0), DeviceIndex(ctx, b1)]
+    oix = [orc.OracleIndex(b0), orc.OracleIndex(b1)]
+    sj = StreamJoin(ctx, gix, nslots=3, ncols=ncols)
+    bounds = [0, 1, 5000, 5001, 40_000, 90_000, 119_999, n_stream]
+    chunks = [(bounds[i], [[c.slice(bounds[i], bounds[i + 1]) for c in s0], [c.slice(bounds[i], bounds[i + 1]) for c in s1]])
+              for i in range(len(bounds) - 1)]
+    results, submitted = [], 0
+    while len(results) < len(chunks):
+        while submitted < len(chunks) and sj.pending < sj.nslots:
+            b, sc = chunks[submitted]
+            sj.submit(sc[0] + sc[1], probe_base=b)
+            submitted += 1
+        results.append(sj.next())
+    total = 0
+    for (b, sc), r in zip(chunks, results):
+        es, erows = oracle_chain_general(oix, sc, b)
+        assert not r["dense"] and r["probe_base"] == b and r["nrows"] == sc[0][0].nrows
+        assert r["nmatches"] == len(es), (shape, b)
+        np.testing.assert_array_equal(r["stream_row"], es)
+        for k in range(2):
+            np.testing.assert_array_equal(r["build_row"][k], erows[k])
+        total += len(es)
+    assert total > 0
+    sj.close()
+    # the plain constructor still refuses such chains, the general one runs fused-kernel chains in the dense mode
+    with pytest.raises(N.CphError):
+        StreamJoin(ctx, gix)
+    u = DeviceIndex(ctx, [StrCol.from_values([b"%d" % i for i in range(100)])], unique=True)
+    sj2 = StreamJoin(ctx, [u], nslots=2, ncols=[1])
+    sj2.submit([s1[0].slice(0, 1000)] if shape != "two_column_key_and_prefix" else [s0[1].slice(0, 1000)])
+    assert sj2.next()["dense"]
+    sj2.close()
