@@ -20,7 +20,7 @@ all: hip datagen oracle host
 hip: $(LIBDIR)/libcsvplus_hip.so
 datagen: $(LIBDIR)/libcph_datagen.so
 oracle: oracle/_build/liboracle.so oracle/_build/libfaithful.so
-host: tests/cpp/test_host tests/c/abi_demo
+host: tests/cpp/test_host tests/c/abi_demo tests/c/libnccl_standin.so
 
 $(LIBDIR)/obj/%.o: $(CSRC)/%.hip $(HIP_HDRS)
 	@mkdir -p $(LIBDIR)/obj
@@ -47,6 +47,10 @@ tests/cpp/test_host: tests/cpp/test_host.cpp csvplus_amd/host/csvplus.hpp includ
 tests/c/abi_demo: tests/c/abi_demo.c include/csvplus_hip.h $(LIBDIR)/libcsvplus_hip.so
 	$(CC) -O2 -std=c99 -Wall -Wextra -Iinclude $< -L$(LIBDIR) -lcsvplus_hip -Wl,-rpath,'$$ORIGIN/../../csvplus_amd/lib' -o $@
 
+# NCCL's entry points for thread ranks sharing one GPU (test infrastructure: the RCCL transport of csrc/dist.hip with 2 and 3 ranks)
+tests/c/libnccl_standin.so: tests/c/nccl_standin.cpp
+	$(HIPCC) -O2 -std=c++17 -fPIC -shared $< -o $@
+
 # ---- sanitizer builds (CPU side only: the checker, the data generator, the host facade's own code) ----------
 # tests/test_asan.py runs them; findings abort the run.  The device side has its own canaries: cph_ctx_set_option
 # "pool_guard" (tools/gpu_guard.sh runs the whole GPU suite under it).
@@ -62,6 +66,6 @@ oracle/_build/datagen_asan: tests/c/datagen_check.c $(CSRC)/datagen.c
 	$(CC) $(SAN) -fopenmp -Wall tests/c/datagen_check.c -o $@
 
 clean:
-	rm -rf $(LIBDIR) oracle/_build tests/cpp/test_host tests/c/abi_demo
+	rm -rf $(LIBDIR) oracle/_build tests/cpp/test_host tests/c/abi_demo tests/c/libnccl_standin.so
 
 .PHONY: all hip datagen oracle host asan clean

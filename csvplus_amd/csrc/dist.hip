@@ -91,8 +91,19 @@ static Status rccl_load(const RcclLoad** out) {
     std::string& err = ld.err;
     if (!tried) {
         tried = true;
+        // CPH_RCCL_LIBRARY=<path>: this very library, no search (a particular RCCL build; the tests' stand-in whose
+        // ranks are threads sharing one GPU, tests/c/nccl_standin.cpp)
+        const char* forced = getenv("CPH_RCCL_LIBRARY");
+        if (forced && *forced) {
+            api.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+            if (api.lib) ld.path = forced;
+            else {
+                const char* de = dlerror();
+                err = std::string("CPH_RCCL_LIBRARY: cannot load ") + forced + ": " + (de ? de : "?");
+            }
+        }
         std::string loaded;
-        dl_iterate_phdr(find_loaded_rccl, &loaded);
+        if (!api.lib && err.empty()) dl_iterate_phdr(find_loaded_rccl, &loaded);
         if (!loaded.empty()) {
             api.lib = dlopen(loaded.c_str(), RTLD_NOW | RTLD_NOLOAD);   // a second handle on the SAME mapping
             if (api.lib) {
@@ -100,14 +111,16 @@ static Status rccl_load(const RcclLoad** out) {
                 ld.shared_with_host = true;
             }
         }
-        if (!api.lib)
+        if (!api.lib && err.empty())
             for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
                 api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
                 if (api.lib) { ld.path = name; break; }
             }
         if (!api.lib) {
-            const char* de = dlerror();
-            err = std::string("cannot load librccl.so: ") + (de ? de : "not found");
+            if (err.empty()) {
+                const char* de = dlerror();
+                err = std::string("cannot load librccl.so: ") + (de ? de : "not found");
+            }
         } else {
             auto sym = [&](const char* n) {
                 void* p = dlsym(api.lib, n);

@@ -304,7 +304,8 @@ CPH_API int32_t cph_dist_rank(const cph_dist* d);
 CPH_API int32_t cph_dist_size(const cph_dist* d);
 /* What moves the bytes, for logs and benchmark records: "rccl nranks=8 lib=<path> (the copy the host process had
  * loaded)" — the library binds to a librccl the process has ALREADY mapped (torch ships one) before it opens its
- * own, so one process never runs two RCCL copies — or "loopback nranks=...".  Owned by `d`, valid until the next call. */
+ * own, so one process never runs two RCCL copies — or "loopback nranks=...".  Owned by `d`, valid until the next call.
+ * Environment: CPH_RCCL_LIBRARY=<path> makes the library bind to exactly that file (a particular RCCL build). */
 CPH_API const char* cph_dist_transport(cph_dist* d);
 
 /* Result of an allgatherv: data[a] (device memory of this rank's ctx, library-owned) holds `total`

@@ -105,8 +105,16 @@ def test_rccl_single_rank_through_the_c_abi(ctx):
     d.close()
 
 
+def loopback_factory(group, world):
+    return lambda ctx, r: N.Dist.loopback(ctx, group, r, world)
+
+
 @pytest.mark.parametrize("world,domain_factor", [(2, 1), (3, 2), (3, 1)])
 def test_loopback_sharded_chain_matches_oracle(world, domain_factor):
+    run_sharded_chain(world, domain_factor, loopback_factory(f"chain-{world}-{domain_factor}", world))
+
+
+def run_sharded_chain(world, domain_factor, make_dist, expect_transport="loopback"):
     """Each rank joins its contiguous row range against replicated indexes; the gathered lists of EVERY rank
     equal the oracle's join over the whole stream.  domain_factor 2: half of the customer ids miss (unequal
     counts, explicit stream rows); rank 1 of 3 additionally gets rows that never join (an empty contribution)."""
@@ -123,11 +131,11 @@ def test_loopback_sharded_chain_matches_oracle(world, domain_factor):
         from csvplus_amd import StrCol
         cols[0] = StrCol.from_values(vals)
     es, ea, eb = oracle_whole(cust, prod, cols)
-    group = f"chain-{world}-{domain_factor}"
 
     def rank_body(r):
         ctx = Context(0)
-        d = N.Dist.loopback(ctx, group, r, world)
+        d = make_dist(ctx, r)
+        assert d.transport().startswith(expect_transport), d.transport()
         ia, ib = DeviceIndex(ctx, [cust], unique=True), DeviceIndex(ctx, [prod], unique=True)
         b, e = shard_range(m, r, world)
         ch = join_chain(ctx, [(ia, [cols[0].slice(b, e)]), (ib, [cols[1].slice(b, e)])], probe_base=b,
@@ -155,8 +163,12 @@ def test_loopback_sharded_chain_matches_oracle(world, domain_factor):
 
 
 def test_loopback_index_broadcast_option_b():
+    run_index_broadcast(3, loopback_factory("bcast", 3))
+
+
+def run_index_broadcast(world, make_dist):
     """Build side option B: rank 0 sorts, ranks 1..2 receive descriptor + sorted codes + perm and join with it."""
-    world, nc = 3, 20_000
+    nc = 20_000
     cust = dg.customers(nc)["id"]
     varkeys = dg.varkeys(30_000)                      # duplicate keys, dictionary-coded groups in the codec
     from csvplus_amd import StrCol
@@ -169,7 +181,7 @@ def test_loopback_index_broadcast_option_b():
 
     def rank_body(r):
         ctx = Context(0)
-        d = N.Dist.loopback(ctx, "bcast", r, world)
+        d = make_dist(ctx, r)
         for col, oix, unique in ((cust, ou, True), (varkeys, ov, False), (longcol, ol, False)):
             mine = DeviceIndex(ctx, [col], unique=unique) if r == 0 else None
             ix = d.index_broadcast(mine, root=0)
