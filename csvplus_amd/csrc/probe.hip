@@ -377,7 +377,7 @@ struct LookupArg {
     int32_t unique = 0;                  // the index has no duplicate keys: entries carry {lo, build row}
 };
 
-template <bool KEY32, int LOOKUP>
+template <bool KEY32, int LOOKUP, int HROWS = 4>
 __global__ __launch_bounds__(kProbeThreads) void k_probe(ColsArg cols, int ncols_used,
                                                         const uint8_t* __restrict__ g_codec,
                                                         const void* __restrict__ codes, uint64_t n_index,
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(ColsArg cols, int ncols
         // Full-key probe through the hash table (hash_device.hpp).  kHashRows rows per phase: their keys are encoded
         // one after the other (the generic encoder walks columns and byte positions), then the home sectors of all of
         // them are loaded together — the random accesses are what the kernel waits for.
-        constexpr int kHashRows = 4;
+        constexpr int kHashRows = HROWS;
         const uint64_t* cw = reinterpret_cast<const uint64_t*>(codes);
 #pragma unroll 1
         for (int ph = 0; ph < kProbeItems / kHashRows; ph++) {
@@ -952,11 +952,18 @@ template <bool KEY32, int LOOKUP>
 static Status launch_probe(cph_ctx* ctx, const cph_index* ix, const ColsArg& arg, int ncols, const LookupArg& look, RowSel row_sel,
                            uint64_t nprobe, uint32_t* lo, uint32_t* cnt, uint64_t* tile_sums, unsigned ntiles, uint32_t* first_row) {
     const size_t lds = ix->codec_dev.bytes();
-    CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_probe<KEY32, LOOKUP>), kProbeThreads, lds, nullptr));
     ProfScope ps(ctx, look_name(LOOKUP), 0);
-    hipLaunchKernelGGL((k_probe<KEY32, LOOKUP>), dim3(ntiles), dim3(kProbeThreads), lds, ctx->stream, arg, ncols,
-                       ix->codec_dev.as<uint8_t>(), ix->sorted_codes.get(), ix->nrows, look, row_sel, nprobe, lo, cnt, tile_sums,
-                       first_row);
+    if (LOOKUP == kLookHash && ctx->probe_hash_rows != 4) {   // rows per phase of the hash probe (tuning: registers against loads in flight)
+        CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_probe<KEY32, LOOKUP, 2>), kProbeThreads, lds, nullptr));
+        hipLaunchKernelGGL((k_probe<KEY32, LOOKUP, 2>), dim3(ntiles), dim3(kProbeThreads), lds, ctx->stream, arg, ncols,
+                           ix->codec_dev.as<uint8_t>(), ix->sorted_codes.get(), ix->nrows, look, row_sel, nprobe, lo, cnt, tile_sums,
+                           first_row);
+    } else {
+        CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_probe<KEY32, LOOKUP, 4>), kProbeThreads, lds, nullptr));
+        hipLaunchKernelGGL((k_probe<KEY32, LOOKUP, 4>), dim3(ntiles), dim3(kProbeThreads), lds, ctx->stream, arg, ncols,
+                           ix->codec_dev.as<uint8_t>(), ix->sorted_codes.get(), ix->nrows, look, row_sel, nprobe, lo, cnt, tile_sums,
+                           first_row);
+    }
     CPH_HIP_TRY(hipGetLastError());
     return {};
 }

@@ -20,8 +20,9 @@ import torch
 from csvplus_amd import Context, DeviceIndex, StrCol, _native as N, join_chain
 from csvplus_amd.engine import Engine, device_view
 
-NB = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
-MP = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000_000
+_a = [a for a in sys.argv[1:] if not a.startswith("--")]
+NB = int(_a[0]) if len(_a) > 0 else 10_000_000
+MP = int(_a[1]) if len(_a) > 1 else 100_000_000
 eng = Engine(0)
 dev = eng.device
 A36 = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz0123456789", dtype=np.uint8)
@@ -72,6 +73,10 @@ def run(name, alphabet, width):
               f"bits={inf['code_bits']} unique={ix.first_dup is None} hash_mode={inf['hash_mode']} hash_MB={inf['hash_bytes'] / 1e6:.0f}", flush=True)
         reps = 3 if hash_on else 2
         timed("cph_join_probe bounds only", ctx, lambda: ix.probe([d_probe], want_pairs=False, out_mem=N.CPH_MEM_DEVICE).release(), reps)
+        if hash_on and inf["code_words"] > 1 and "--rows-ab" in sys.argv:   # generic kernel: rows per phase, A/B on this box
+            ctx.set_option("probe_hash_rows", 2)
+            timed("cph_join_probe bounds only (2 rows per phase)", ctx, lambda: ix.probe([d_probe], want_pairs=False, out_mem=N.CPH_MEM_DEVICE).release(), reps)
+            ctx.set_option("probe_hash_rows", 4)
         timed("cph_join_probe + pairs", ctx, lambda: ix.probe([d_probe], out_mem=N.CPH_MEM_DEVICE).release(), reps)
         if ix.first_dup is None and inf["code_words"] == 1:
             timed("cph_join_chain (1 step, fused kernel)", ctx, lambda: join_chain(ctx, [(ix, [d_probe])], out_mem=N.CPH_MEM_DEVICE).release(), reps)
