@@ -52,6 +52,8 @@ def parse_args():
     ap.add_argument("--no-index-1e8", action="store_true", help="skip the extra IndexOn-at-full-size measurements")
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
     ap.add_argument("--no-verify", action="store_true", help="skip the full-size checks of the timed outputs")
+    ap.add_argument("--no-positions", action="store_true",
+                    help="skip the second measurement of the step with the Join reporting sorted positions instead of row ids")
     ap.add_argument("--no-e2e", action="store_true", help="skip the pinned-host -> pinned-host scope (cph_stream_join_*)")
     ap.add_argument("--verify-sample", type=int, default=100_000)
     ap.add_argument("--no-traffic", action="store_true",
@@ -141,7 +143,7 @@ def measure_traffic(kernel_prefix, args):
         cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
                sys.executable, str(ROOT / "bench.py"), "--steps", "2", "--warmup", "1", "--rows", str(args.rows),
                "--customers", str(args.customers), "--products", str(args.products), "--no-cpu-baseline",
-               "--no-index-1e8", "--no-verify", "--no-e2e", "--no-traffic"]
+               "--no-index-1e8", "--no-verify", "--no-e2e", "--no-traffic", "--no-positions"]
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300,
                            check=True)
@@ -482,6 +484,72 @@ def main():
         ver["seconds"] = round(time.perf_counter() - t0, 2)
         out["verified"] = bool(ok)
         out["verify"] = ver
+
+    # ---- the same step reporting SORTED POSITIONS (cph_join_chain_ex CPH_CHAIN_POSITIONS) -------------------------
+    # The reference's Join reads index.impl.rows[first() + i]: rows of an Index are kept in sorted order (csvplus.go:736,
+    # :553-567), so the position in the sorted index IS its row handle; the original row id is one more indirection
+    # (perm[position]) that only this ABI's default mode offers.  Reporting positions lets a duplicate-free index over a
+    # dense code space answer from presence bits + a running count per 64 codes (2.5 MB for the 1e7 customers: L2
+    # resident) instead of the 40 MB row table (one Infinity-Fabric sector per probe row).  Measured like the main
+    # step (same builds, same inputs, K steps between synchronisations), reported BESIDE `value`, never as it; the
+    # result is checked at full size against the row-id mode: perm[position] == build row for all rows of both steps.
+    if world == 1 and not args.no_positions:
+        def step_pos():
+            ia, ib = eng.index_on_many([[d_cust], [d_prod]], unique=True)
+            ch = N.join_chain(eng.ctx, [(ia, [d_ord["cust_id"]]), (ib, [d_ord["prod_id"]])], probe_base=begin,
+                              out_mem=N.CPH_MEM_DEVICE, positions=True)
+            n = ch.nrows
+            ch.release(); ia.close(); ib.close()
+            return n
+
+        for _ in range(max(1, args.warmup)):
+            step_pos()
+        eng.ctx.profile_only("k_chain_dense")
+        eng.ctx.profile_read(reset=True)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            jp = step_pos()
+        torch.cuda.synchronize(dev)
+        dtp = time.perf_counter() - t0
+        pp = eng.ctx.profile_read(reset=True)
+        eng.ctx.profile(True)
+        step_pos()
+        pb = eng.ctx.profile_read(reset=True)
+        eng.ctx.profile(False)
+        ms_pos = dtp / args.steps * 1e3
+        kd = pp.get("k_chain_dense", {"launches": 0, "total_ms": 0.0})
+        kd_ms = kd["total_ms"] / max(1, kd["launches"])
+        # the job's algorithmic bytes are those of the row-id step (same inputs, same outputs, one table entry per row and
+        # step): the fraction below prices this kernel's time against THAT model, so the two modes compare directly
+        algo_pos = roofline.get("algorithmic_bytes_per_launch") if roofline else None
+        blk = {"ms_per_step": round(ms_pos, 4), "value": jp / (dtp / args.steps), "unit": "rows/s", "joined_rows_per_step": jp,
+               "speedup_vs_row_ids": round(ms_per_step / ms_pos, 3),
+               "k_chain_dense_ms": round(kd_ms, 4),
+               "kernels_ms": {k: round(v["total_ms"], 4) for k, v in pb.items()},
+               "what": "same step (2 index builds + chained Join of the same rows), build_row[k] = sorted position in index k "
+                       "(the reference's own row handle) instead of the original row id; reported beside `value`, not as it"}
+        if algo_pos and kd_ms:
+            blk["roofline"] = {"kernel": "k_chain_dense (positions)", "algorithmic_bytes_per_launch": int(algo_pos),
+                               "bytes_model": "the row-id step's (roofline.algorithmic_bytes_per_launch)",
+                               "achieved": round(algo_pos / 1e9 / (kd_ms / 1e3), 1), "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+                               "frac": round(algo_pos / 1e9 / (kd_ms / 1e3) / HBM_PEAK_GBPS, 4)}
+            if roofline.get("step_algorithmic_bytes"):
+                blk["roofline"]["step_frac"] = round(roofline["step_algorithmic_bytes"] / 1e9 / (ms_pos / 1e3) / HBM_PEAK_GBPS, 4)
+        if not args.no_verify:
+            from csvplus_amd.engine import device_view
+            ia, ib = eng.index_on_many([[d_cust], [d_prod]], unique=True)
+            r_rows = eng.chained_join([(ia, d_ord["cust_id"]), (ib, d_ord["prod_id"])], probe_base=begin)
+            r_pos = eng.chained_join([(ia, d_ord["cust_id"]), (ib, d_ord["prod_id"])], probe_base=begin, positions=True)
+            same = r_rows.n == r_pos.n and (r_rows.stream_row is None) == (r_pos.stream_row is None)
+            bad = []
+            for k, ix in enumerate((ia, ib)):
+                perm = device_view(ix.perm_device_ptr(), ix.nrows, "<i4", ix, dev)
+                bad.append(int((perm[r_pos.build_rows[k].long()] != r_rows.build_rows[k]).sum().item()) if same else -1)
+            blk["verify"] = {"rows": r_pos.n, "perm_of_position_differs_from_row_id": bad, "ok": bool(same and not any(bad))}
+            out["verified"] = bool(out.get("verified")) and blk["verify"]["ok"]
+            r_rows.release(); r_pos.release(); ia.close(); ib.close()
+        out["join_positions"] = blk
 
     # ---- end-to-end C-ABI scope: pinned host SoA in -> pinned host row ids out (PCIe inclusive) ----
     # cph_stream_join_*: 2^24-row chunks of the same orders table, H2D / kernel / D2H of consecutive chunks

@@ -113,7 +113,10 @@ class cph_chain_step(C.Structure):
 
 class cph_chain(C.Structure):
     _fields_ = [("nrows", C.c_uint64), ("stream_row", C.c_void_p), ("build_row", C.c_void_p * CPH_MAX_CHAIN),
-                ("nsteps", C.c_int32), ("mem", C.c_int32)]
+                ("nsteps", C.c_int32), ("mem", C.c_int32), ("positions", C.c_int32), ("reserved_", C.c_int32)]
+
+
+CPH_CHAIN_POSITIONS = 1
 
 
 class cph_colbuf(C.Structure):
@@ -210,6 +213,8 @@ PROTOTYPES = [
     ("cph_matches_release", None, [C.POINTER(cph_matches)]),
     ("cph_join_chain", C.c_int32,
      [_P, C.POINTER(cph_chain_step), C.c_int32, C.c_uint64, C.c_int32, C.POINTER(C.POINTER(cph_chain))]),
+    ("cph_join_chain_ex", C.c_int32,
+     [_P, C.POINTER(cph_chain_step), C.c_int32, C.c_uint64, C.c_int32, C.c_uint32, C.POINTER(C.POINTER(cph_chain))]),
     ("cph_chain_release", None, [C.POINTER(cph_chain)]),
     ("cph_stream_join_create", C.c_int32, [_P, C.POINTER(_P), C.c_int32, C.c_int32, C.POINTER(_P)]),
     ("cph_stream_join_create_general", C.c_int32, [_P, C.POINTER(_P), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(_P)]),
@@ -559,8 +564,9 @@ class DeviceIndex:
             pass
 
 
-def join_chain(ctx: Context, steps, probe_base: int = 0, out_mem: int = CPH_MEM_HOST) -> "Chain":
-    """cph_join_chain: steps = [(DeviceIndex, [stream key columns]), ...]."""
+def join_chain(ctx: Context, steps, probe_base: int = 0, out_mem: int = CPH_MEM_HOST, positions: bool = False) -> "Chain":
+    """cph_join_chain[_ex]: steps = [(DeviceIndex, [stream key columns]), ...].  positions=True (CPH_CHAIN_POSITIONS):
+    build_row[k] holds sorted positions in index k (original row = index.perm()[position])."""
     arr = (cph_chain_step * len(steps))()
     keep = []
     for i, (index, cols) in enumerate(steps):
@@ -570,7 +576,10 @@ def join_chain(ctx: Context, steps, probe_base: int = 0, out_mem: int = CPH_MEM_
         arr[i].cols = carr
         arr[i].ncols = len(cols)
     out = C.POINTER(cph_chain)()
-    rc = ctx.lib.cph_join_chain(ctx.handle, arr, len(steps), probe_base, out_mem, C.byref(out))
+    if positions:
+        rc = ctx.lib.cph_join_chain_ex(ctx.handle, arr, len(steps), probe_base, out_mem, CPH_CHAIN_POSITIONS, C.byref(out))
+    else:
+        rc = ctx.lib.cph_join_chain(ctx.handle, arr, len(steps), probe_base, out_mem, C.byref(out))
     del keep
     ctx._check(rc)
     return Chain(ctx, out, [s[0] for s in steps], probe_base)
@@ -589,6 +598,7 @@ class Chain:
         self.nrows = int(c.nrows)
         self.nsteps = int(c.nsteps)
         self.mem = int(c.mem)
+        self.positions = bool(c.positions)
         ctx._children.add(self)
 
     @property

@@ -768,6 +768,7 @@ CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value
     else if (k == "sort_xcd_tiles") ctx->sort_xcd_tiles = value != 0;
     else if (k == "codec_debug") ctx->codec_debug = value != 0;
     else if (k == "join_hash") ctx->join_hash = value != 0;
+    else if (k == "chain_rank_lds") ctx->chain_rank_lds = value != 0;
     else if (k == "probe_hash_rows") ctx->probe_hash_rows = value == 4 ? 4 : 2;
     else if (k == "small_build_rows") ctx->small_build_rows = value < 0 ? 0 : value > (1 << 20) ? (1 << 20) : (int)value;
     else if (k == "plan_threads") ctx->plan_threads = (int)value;
@@ -1097,7 +1098,14 @@ CPH_API void cph_matches_release(cph_matches* pub) {
 
 CPH_API int32_t cph_join_chain(cph_ctx* ctx, const cph_chain_step* steps, int32_t nsteps, uint64_t probe_base,
                                int32_t out_mem, cph_chain** out) {
+    return cph_join_chain_ex(ctx, steps, nsteps, probe_base, out_mem, 0, out);
+}
+
+CPH_API int32_t cph_join_chain_ex(cph_ctx* ctx, const cph_chain_step* steps, int32_t nsteps, uint64_t probe_base,
+                                  int32_t out_mem, uint32_t flags, cph_chain** out) {
     Status s = enter(ctx);
+    if (flags & ~(uint32_t)CPH_CHAIN_POSITIONS) return fail(ctx, {CPH_ERR_INVALID, "unknown cph_join_chain_ex flag"});
+    const bool positions = (flags & CPH_CHAIN_POSITIONS) != 0;
     if (!s.ok()) return fail(ctx, s);
     if (!steps || !out || nsteps < 1 || nsteps > CPH_MAX_CHAIN) return fail(ctx, {CPH_ERR_INVALID, "bad chain"});
     if (out_mem != CPH_MEM_HOST && out_mem != CPH_MEM_DEVICE) return fail(ctx, {CPH_ERR_INVALID, "bad out_mem"});
@@ -1123,9 +1131,10 @@ CPH_API int32_t cph_join_chain(cph_ctx* ctx, const cph_chain_step* steps, int32_
             CPH_TRY(stage_cols(ctx, steps[k].cols, steps[k].ncols, &staged, cs[k].cols));
         }
         ChainOut co;
-        CPH_TRY(chain_run(ctx, cs, nsteps, probe_base, &co));
+        CPH_TRY(chain_run(ctx, cs, nsteps, probe_base, &co, positions));
         c->pub.nrows = co.nrows;
         c->pub.nsteps = nsteps;
+        c->pub.positions = positions ? 1 : 0;
         c->pub.mem = out_mem;
         const uint64_t n = co.nrows;
         if (out_mem == CPH_MEM_DEVICE) {
@@ -1299,7 +1308,7 @@ CPH_API int32_t cph_index_get_info(const cph_index* ix, cph_index_info* info) {
     info->direct_table = ix->table_entries ? 1 : 0;
     info->table_entries = ix->table_entries;
     info->dict_entries = (int32_t)ix->codec.dict.size();
-    info->lookup_built = (ix->table ? 1 : 0) | (ix->rowtab ? 2 : 0) | (ix->hash_mode ? 4 : 0);
+    info->lookup_built = (ix->table ? 1 : 0) | (ix->rowtab ? 2 : 0) | (ix->hash_mode ? 4 : 0) | (ix->ranktab ? 8 : 0);
     info->hash_mode = ix->hash_mode;
     info->hash_bytes = (uint64_t)ix->hash_sectors * 64;
     info->build_path = ix->small_built ? 1 : 0;
@@ -1313,9 +1322,10 @@ CPH_API int32_t cph_index_prepare_join(cph_index* ix, int32_t chained) {
     if (!s.ok()) return fail(ctx, s);
     if (ix->nrows == 0) return CPH_OK;
     if (ix->table_entries && ix->windows.empty()) {
-        s = chained && ix->first_dup == UINT64_MAX ? index_ensure_rowtab(ctx, ix) : index_ensure_table(ctx, ix);
+        if (chained == 2 && ix->first_dup == UINT64_MAX) s = index_ensure_ranktab(ctx, ix);
+        else s = chained && ix->first_dup == UINT64_MAX ? index_ensure_rowtab(ctx, ix) : index_ensure_table(ctx, ix);
     }
-    if (s.ok() && !ix->table && !ix->rowtab) s = index_ensure_hash(ctx, ix);
+    if (s.ok() && !ix->table && !ix->rowtab && !ix->ranktab) s = index_ensure_hash(ctx, ix);
     if (!s.ok()) return fail(ctx, s);
     return CPH_OK;
 }

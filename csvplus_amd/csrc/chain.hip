@@ -48,6 +48,9 @@ struct ChainStepArg {
     DevCol col;                 // the stream's key column for this step
     const uint8_t* codec;       // codec block of the step's index (global memory)
     const uint32_t* rowtab;     // code -> build row (0xFFFFFFFF: absent), or nullptr
+    const uint4* ranktab;       // positions mode: {present bits, keys before} per 64 codes (probe.hip: k_build_ranktab), or nullptr
+    int32_t positions;          // the step reports the key's SORTED POSITION instead of the build row
+    int32_t ranktab_lds;        // != 0: blocks of ranktab every workgroup copies into LDS (a small index: no L2 -> L1 line per row)
     const uint4* hash;          // no rowtab: hash table over the codes (hash_device.hpp, kHashK1 entries), or nullptr -> binary search
     uint32_t hash_sectors;
     uint32_t reserved_;
@@ -89,6 +92,33 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
             p += a.step[s].codec_bytes;
         }
     }
+    // rank tables small enough to live in LDS next to the codecs (the 1e5-row products index: 2517 blocks), 12 bytes
+    // per block there: {bits lo, bits hi, keys before}
+    const CPH_LDS uint32_t* rank_lds[S];
+    {
+        uint8_t* p = smem;
+#pragma unroll
+        for (int s = 0; s < S; s++) p += a.step[s].codec_bytes;
+        bool any = false;
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            rank_lds[s] = nullptr;
+            const int nblk = a.step[s].ranktab_lds;
+            if (nblk) {
+                uint32_t* dst = reinterpret_cast<uint32_t*>(p);
+                for (int i = threadIdx.x; i < nblk; i += kChainThreads) {
+                    const uint4 b = a.step[s].ranktab[i];
+                    dst[3 * i] = b.x;
+                    dst[3 * i + 1] = b.y;
+                    dst[3 * i + 2] = b.z;
+                }
+                rank_lds[s] = (const CPH_LDS uint32_t*)p;
+                p += (size_t)((nblk * 12 + 15) & ~15);
+                any = true;
+            }
+        }
+        if (any) __syncthreads();
+    }
     const int lane = lane_id();
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(wave_id());
 
@@ -129,7 +159,27 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
 #pragma unroll
         for (int s = 0; s < S; s++) {
             const ChainStepArg& st = a.step[s];
-            if (st.rowtab) {
+            if (st.ranktab) {
+                // the key's rank among the index keys = its sorted position: one 16-byte block per row from a table
+                // 1/16 the size of rowtab (L2-resident for the 1e7-row customers index: no Infinity-Fabric sector per row)
+                uint4 blk[kChainRows];
+#pragma unroll
+                for (int k = 0; k < kChainRows; k++) {
+                    const CW cidx = (okm >> k) & 1u ? code[s][k] : (CW)0;   // block 0 always exists
+                    if (rank_lds[s]) {   // uniform branch
+                        const CPH_LDS uint32_t* e = rank_lds[s] + 3u * (uint32_t)((uint64_t)cidx >> 6);
+                        blk[k] = make_uint4(e[0], e[1], e[2], 0u);
+                    }
+                    else blk[k] = (DBG && (dbg & 1)) ? make_uint4(~0u, ~0u, 0u, 0u) : st.ranktab[(uint64_t)cidx >> 6];
+                }
+#pragma unroll
+                for (int k = 0; k < kChainRows; k++) {
+                    const uint32_t bit = (uint32_t)code[s][k] & 63u;
+                    const uint64_t bits = (uint64_t)blk[k].x | ((uint64_t)blk[k].y << 32);
+                    const bool present = (bits >> bit) & 1ull;
+                    brow[s][k] = present ? blk[k].z + (uint32_t)__popcll(bits & ((1ull << bit) - 1ull)) : kTableAbsent;
+                }
+            } else if (st.rowtab) {
 #pragma unroll
                 for (int k = 0; k < kChainRows; k++) {
                     const CW cidx = (okm >> k) & 1u ? code[s][k] : (CW)0;   // entry 0 always exists
@@ -155,7 +205,7 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
                         bool hit = hash_match16(sc[k], (uint64_t)code[s][g + k], &l, &a, &more);
                         const bool live = (okm >> (g + k)) & 1u;
                         if (live && more) hit = hash_continue16(hv, home[k], (uint64_t)code[s][g + k], &l, &a);   // rare
-                        brow[s][g + k] = (hit && live && !(DBG && (dbg & 1))) ? a : kTableAbsent;
+                        brow[s][g + k] = (hit && live && !(DBG && (dbg & 1))) ? (st.positions ? l : a) : kTableAbsent;
                         if (DBG && (dbg & 1)) brow[s][g + k] = 0u;
                     }
                 }
@@ -175,7 +225,7 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
                         lo = lower_bound_dev<uint64_t>(cd, 0, st.n_index, (uint64_t)code[s][k]);
                         hit = lo < st.n_index && cd[lo] == (uint64_t)code[s][k];
                     }
-                    if (hit) brow[s][k] = st.perm[lo];
+                    if (hit) brow[s][k] = st.positions ? (uint32_t)lo : st.perm[lo];
                 }
             }
         }
@@ -279,10 +329,11 @@ bool chain_fast_path_ok(const ChainStep* steps, int nsteps) {
 template <int S>
 static Status enqueue_dense(cph_ctx* ctx, const ChainStep* steps, uint64_t nprobe, uint64_t probe_base,
                             uint32_t* const* d_rows, uint64_t* d_masks, uint32_t* d_counts, uint64_t* d_total,
-                            ChainArgs* args_out, unsigned* grid_out) {
+                            ChainArgs* args_out, unsigned* grid_out, bool positions) {
     const uint64_t ntiles = (nprobe + kChainTile - 1) / kChainTile;
     ChainArgs args{};
-    size_t lds = 0;
+    size_t lds = 0, rank_lds_bytes = 0;
+    for (int s = 0; s < S; s++) lds += steps[s].index->codec_dev.bytes();
     for (int s = 0; s < S; s++) {
         const cph_index* ix = steps[s].index;
         ChainStepArg& st = args.step[s];
@@ -291,11 +342,24 @@ static Status enqueue_dense(cph_ctx* ctx, const ChainStep* steps, uint64_t nprob
         st.codec_bytes = (int32_t)ix->codec_dev.bytes();
         // lookup structure of the step, built on first use (on the index's own ctx; other ctxs wait for it): the
         // 4-byte row table over a dense code space, else the hash table, else (allocation failed) the sorted codes
-        CPH_TRY(index_ensure_rowtab(ctx, ix));
-        st.rowtab = ix->rowtab ? ix->rowtab.as<uint32_t>() : nullptr;
+        st.positions = positions ? 1 : 0;
+        st.rowtab = nullptr;
+        st.ranktab = nullptr;
+        if (positions) {
+            CPH_TRY(index_ensure_ranktab(ctx, ix));
+            st.ranktab = ix->ranktab ? ix->ranktab.as<uint4>() : nullptr;
+            const size_t nblk = (ix->table_entries + 63) / 64, rb = (nblk * 12 + 15) & ~(size_t)15;
+            if (st.ranktab && ctx->chain_rank_lds && lds + rank_lds_bytes + rb <= 52 * 1024) {   // three workgroups per CU stay resident
+                st.ranktab_lds = (int32_t)nblk;
+                rank_lds_bytes += rb;
+            }
+        } else {
+            CPH_TRY(index_ensure_rowtab(ctx, ix));
+            st.rowtab = ix->rowtab ? ix->rowtab.as<uint32_t>() : nullptr;
+        }
         st.hash = nullptr;
         st.hash_sectors = 0;
-        if (!st.rowtab && index_wants_hash(ix)) {
+        if (!st.rowtab && !st.ranktab && index_wants_hash(ix)) {
             CPH_TRY(index_ensure_hash(ctx, ix));
             if (ix->hash_mode == kHashK1) {
                 st.hash = ix->hash.as<uint4>();
@@ -307,8 +371,8 @@ static Status enqueue_dense(cph_ctx* ctx, const ChainStep* steps, uint64_t nprob
         st.n_index = ix->nrows;
         st.key32 = ix->codec.key32 ? 1 : 0;
         args.out_rows[s] = d_rows[s];
-        lds += ix->codec_dev.bytes();
     }
+    lds += rank_lds_bytes;
     const uint64_t ncounts = ntiles * kChainWaves;   // one match count per (tile, wave), tile-major
     const int dbg = ctx->chain_debug;
     bool long_keys = false, wide = false;
@@ -355,12 +419,12 @@ static Status enqueue_dense(cph_ctx* ctx, const ChainStep* steps, uint64_t nprob
 bool chain_fast_path_ok(const ChainStep* steps, int nsteps);
 
 Status chain_enqueue_dense(cph_ctx* ctx, const ChainStep* steps, int nsteps, uint64_t nprobe, uint64_t probe_base,
-                           uint32_t* const* d_rows, uint64_t* d_masks, uint32_t* d_counts, uint64_t* d_total) {
+                           uint32_t* const* d_rows, uint64_t* d_masks, uint32_t* d_counts, uint64_t* d_total, bool positions) {
     switch (nsteps) {
-    case 1: return enqueue_dense<1>(ctx, steps, nprobe, probe_base, d_rows, d_masks, d_counts, d_total, nullptr, nullptr);
-    case 2: return enqueue_dense<2>(ctx, steps, nprobe, probe_base, d_rows, d_masks, d_counts, d_total, nullptr, nullptr);
-    case 3: return enqueue_dense<3>(ctx, steps, nprobe, probe_base, d_rows, d_masks, d_counts, d_total, nullptr, nullptr);
-    case 4: return enqueue_dense<4>(ctx, steps, nprobe, probe_base, d_rows, d_masks, d_counts, d_total, nullptr, nullptr);
+    case 1: return enqueue_dense<1>(ctx, steps, nprobe, probe_base, d_rows, d_masks, d_counts, d_total, nullptr, nullptr, positions);
+    case 2: return enqueue_dense<2>(ctx, steps, nprobe, probe_base, d_rows, d_masks, d_counts, d_total, nullptr, nullptr, positions);
+    case 3: return enqueue_dense<3>(ctx, steps, nprobe, probe_base, d_rows, d_masks, d_counts, d_total, nullptr, nullptr, positions);
+    case 4: return enqueue_dense<4>(ctx, steps, nprobe, probe_base, d_rows, d_masks, d_counts, d_total, nullptr, nullptr, positions);
     }
     return {CPH_ERR_INVALID, "bad chain length"};
 }
@@ -368,7 +432,7 @@ uint64_t chain_dense_mask_words(uint64_t nprobe) { return (nprobe + kChainTile -
 uint64_t chain_dense_count_words(uint64_t nprobe) { return (nprobe + kChainTile - 1) / kChainTile * kChainWaves; }
 
 template <int S>
-static Status run_fast(cph_ctx* ctx, const ChainStep* steps, uint64_t nprobe, uint64_t probe_base, ChainOut* out) {
+static Status run_fast(cph_ctx* ctx, const ChainStep* steps, uint64_t nprobe, uint64_t probe_base, ChainOut* out, bool positions) {
     const uint64_t ntiles = (nprobe + kChainTile - 1) / kChainTile;
     const uint64_t ncounts = ntiles * kChainWaves;
     uint32_t* rows[kMaxChain] = {nullptr};
@@ -383,7 +447,7 @@ static Status run_fast(cph_ctx* ctx, const ChainStep* steps, uint64_t nprobe, ui
     ChainArgs args{};
     unsigned grid = 1;
     CPH_TRY(enqueue_dense<S>(ctx, steps, nprobe, probe_base, rows, masks.as<uint64_t>(), counts.as<uint32_t>(),
-                             total.as<uint64_t>(), &args, &grid));
+                             total.as<uint64_t>(), &args, &grid, positions));
     CPH_HIP_TRY(hipGetLastError());
     CPH_TRY(ensure_pinned_scratch(ctx, sizeof(uint64_t)));
     uint64_t* h = reinterpret_cast<uint64_t*>(ctx->pinned_scratch);
@@ -415,7 +479,7 @@ static Status run_fast(cph_ctx* ctx, const ChainStep* steps, uint64_t nprobe, ui
     return {};
 }
 
-Status chain_run(cph_ctx* ctx, const ChainStep* steps, int nsteps, uint64_t probe_base, ChainOut* out) {
+Status chain_run(cph_ctx* ctx, const ChainStep* steps, int nsteps, uint64_t probe_base, ChainOut* out, bool positions) {
     const uint64_t nprobe = steps[0].cols[0].nrows;
     out->nrows = 0;
     out->nsteps = nsteps;
@@ -426,17 +490,17 @@ Status chain_run(cph_ctx* ctx, const ChainStep* steps, int nsteps, uint64_t prob
         for (int s = 0; s < nsteps; s++) lds += steps[s].index->codec_dev.bytes();
         if (lds <= 150 * 1024) {
             switch (nsteps) {
-            case 1: return run_fast<1>(ctx, steps, nprobe, probe_base, out);
-            case 2: return run_fast<2>(ctx, steps, nprobe, probe_base, out);
-            case 3: return run_fast<3>(ctx, steps, nprobe, probe_base, out);
-            default: return run_fast<4>(ctx, steps, nprobe, probe_base, out);
+            case 1: return run_fast<1>(ctx, steps, nprobe, probe_base, out, positions);
+            case 2: return run_fast<2>(ctx, steps, nprobe, probe_base, out, positions);
+            case 3: return run_fast<3>(ctx, steps, nprobe, probe_base, out, positions);
+            default: return run_fast<4>(ctx, steps, nprobe, probe_base, out, positions);
             }
         }
     }
 
     // ---- general path: probe / select / compose, one step at a time ------------------------------------
     ProbeOut first;
-    CPH_TRY(probe_run(ctx, steps[0].index, steps[0].cols, steps[0].ncols, RowSel{}, nprobe, probe_base, true, &first));
+    CPH_TRY(probe_run(ctx, steps[0].index, steps[0].cols, steps[0].ncols, RowSel{}, nprobe, probe_base, true, &first, positions));
     DevBuf cur_stream = std::move(first.pidx);
     DevBuf cur_rows[kMaxChain];
     cur_rows[0] = std::move(first.brow);
@@ -447,7 +511,7 @@ Status chain_run(cph_ctx* ctx, const ChainStep* steps, int nsteps, uint64_t prob
         sel.bits = 64;
         sel.base = probe_base;
         ProbeOut po;
-        CPH_TRY(probe_run(ctx, steps[s].index, steps[s].cols, steps[s].ncols, sel, n, 0, true, &po));
+        CPH_TRY(probe_run(ctx, steps[s].index, steps[s].cols, steps[s].ncols, sel, n, 0, true, &po, positions));
         const uint64_t m = po.nmatches;
         DevBuf nstream;
         CPH_TRY(nstream.alloc(&ctx->pool, m * sizeof(uint64_t)));

@@ -233,6 +233,7 @@ struct cph_ctx {
     int sort_digit_stream = 1;     // scatter writes the next pass's digits as a byte stream for its histogram (radix_sort.hip)
     int sort_xcd_tiles = 1;        // scatter: contiguous tile ranges per XCD (radix_sort.hip)
     int small_build_rows = 8192;   // tables of at most this many rows (<= 16384) are indexed by ONE launch of one workgroup (small_build.hip); 0: never
+    int chain_rank_lds = 1;        // positions mode: rank tables of small indexes are copied into LDS by every workgroup (A/B switch)
     int probe_hash_rows = 2;       // rows per phase of the generic hash probe (2 / 4): 4 rows need 164 VGPRs (3 waves per SIMD) and measured 20 % slower
     int join_hash = 1;             // 0: indexes of this ctx never get a hash table (A/B switch: sorted search instead)
     int codec_debug = 0;           // prints the window choice of codec_try_groups to stderr
@@ -281,6 +282,9 @@ struct cph_index {
     cph::DevBuf table;             // {lo,row} / {lo,end} u32x2 [table_entries]: generic probe
     cph::DevBuf rowtab;            // duplicate-free index: u32[table_entries], code -> build row (0xFFFFFFFF: absent);
                                    // 4-byte entries for the chained-join kernel (half the random-access footprint)
+    cph::DevBuf ranktab;           // duplicate-free index: {u64 present bits, u32 codes before, u32 0} per 64 codes — code -> SORTED
+                                   // POSITION (rank) of the key, 1/16 of rowtab's footprint: what a Join that reports index
+                                   // positions (cph_join_chain_ex CPH_CHAIN_POSITIONS) looks up
     uint64_t table_entries = 0;    // != 0: the code space is dense enough for a table (decided at build time)
     // hash table over the codes for every other index (hash_device.hpp), built by the first full-key Join
     cph::DevBuf hash;              // hash_sectors x 64 bytes
@@ -413,6 +417,7 @@ void index_plan_table(cph_index* ix);                               // host deci
 // error: the index is marked (accel_failed) and the callers use the sorted search.
 Status index_ensure_table(cph_ctx* ctx, const cph_index* ix);       // 8-byte entries {lo,row} / {lo,end}
 Status index_ensure_rowtab(cph_ctx* ctx, const cph_index* ix);      // 4-byte build rows (duplicate-free indexes)
+Status index_ensure_ranktab(cph_ctx* ctx, const cph_index* ix);     // presence bits + running count per 64 codes (duplicate-free indexes)
 Status index_ensure_hash(cph_ctx* ctx, const cph_index* ix);        // hash table over the codes (hash_device.hpp)
 bool index_wants_hash(const cph_index* ix);                         // no direct table planned and rows to look up
 struct ProbeOut {
@@ -425,7 +430,7 @@ struct RowSel {                // optional selection of probe rows (device memor
     uint64_t base = 0;         // subtracted from every entry
 };
 Status probe_run(cph_ctx* ctx, const cph_index* ix, const DevCol* cols, int32_t ncols, RowSel sel,
-                 uint64_t nprobe, uint64_t probe_base, bool want_pairs, ProbeOut* out);
+                 uint64_t nprobe, uint64_t probe_base, bool want_pairs, ProbeOut* out, bool positions = false);
 Status index_find_device(cph_ctx* ctx, const cph_index* ix, const uint64_t* q_exact, int32_t nq, uint64_t qlo,
                          uint64_t qhi, uint64_t* lower, uint64_t* upper);
 // nkeys query blocks of `stride` words each ([nq | exact words | qlo | qhi], nq = 0: the key cannot occur): one upload,
@@ -454,11 +459,13 @@ struct ChainOut {
     int32_t nsteps = 0;
     bool identity = false;     // stream_row[m] == probe_base + m for all m: stream_row is not materialised
 };
-Status chain_run(cph_ctx* ctx, const ChainStep* steps, int nsteps, uint64_t probe_base, ChainOut* out);
+// positions: build_row[k] holds the SORTED POSITION of the matching row in index k (an index into the index's sorted
+// rows / its perm) instead of the original row id perm[position]
+Status chain_run(cph_ctx* ctx, const ChainStep* steps, int nsteps, uint64_t probe_base, ChainOut* out, bool positions = false);
 // asynchronous pieces of the fast path (stream_join.hip pipelines them over several streams)
 bool chain_fast_path_ok(const ChainStep* steps, int nsteps);
 Status chain_enqueue_dense(cph_ctx* ctx, const ChainStep* steps, int nsteps, uint64_t nprobe, uint64_t probe_base,
-                           uint32_t* const* d_rows, uint64_t* d_masks, uint32_t* d_counts, uint64_t* d_total);
+                           uint32_t* const* d_rows, uint64_t* d_masks, uint32_t* d_counts, uint64_t* d_total, bool positions = false);
 uint64_t chain_dense_mask_words(uint64_t nprobe);
 uint64_t chain_dense_count_words(uint64_t nprobe);
 

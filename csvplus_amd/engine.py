@@ -105,12 +105,12 @@ class Engine:
     def join(self, index: N.DeviceIndex, probecols, probe_base: int = 0, want_pairs: bool = True) -> N.Matches:
         return index.probe(probecols, probe_base=probe_base, want_pairs=want_pairs, out_mem=N.CPH_MEM_DEVICE)
 
-    def chained_join(self, steps, probe_base: int = 0) -> ChainResult:
+    def chained_join(self, steps, probe_base: int = 0, positions: bool = False) -> ChainResult:
         """stream.Join(i0, k0).Join(i1, k1)...  with steps = [(index, [stream key columns]), ...]
         (README.md:56: orders.Join(customers,"cust_id").Join(products,"prod_id")).  Runs as
         cph_join_chain; results stay on the device as torch views."""
         ch = N.join_chain(self.ctx, [(ix, cols if isinstance(cols, (list, tuple)) else [cols]) for ix, cols in steps],
-                          probe_base=probe_base, out_mem=N.CPH_MEM_DEVICE)
+                          probe_base=probe_base, out_mem=N.CPH_MEM_DEVICE, positions=positions)
         p = ch.device_ptrs()
         dev = self.device
         stream = None if ch.identity else device_view(p["stream_row"], ch.nrows, "<i8", ch, dev)

@@ -263,6 +263,8 @@ typedef struct {
     const uint32_t* build_row[CPH_MAX_CHAIN];
     int32_t         nsteps;
     int32_t         mem;
+    int32_t         positions;      /* 1: build_row[k][m] is the SORTED POSITION of the row in index k (see below) */
+    int32_t         reserved_;
 } cph_chain;
 
 /*
@@ -274,6 +276,20 @@ typedef struct {
  */
 CPH_API int32_t cph_join_chain(cph_ctx* ctx, const cph_chain_step* steps, int32_t nsteps, uint64_t probe_base,
                                int32_t out_mem, cph_chain** out);
+
+/*
+ * The same with flags.  CPH_CHAIN_POSITIONS: build_row[k][m] is not the original row id but the SORTED POSITION of the
+ * matching row in index k — the value the reference itself works with: after createIndex the rows of an Index ARE in
+ * sorted order (csvplus.go:736) and Join reads index.impl.rows[first() + i] (csvplus.go:553-567), so a host that keeps
+ * its index rows sorted (as the reference does) reaches the joined row with one array access; the original row id is
+ * cph_index_perm(index)[position].  For the device this removes the one random access per probe row that cannot be
+ * cached: a duplicate-free index over a dense code space maps code -> position through presence bits and a running count
+ * per 64 codes (16 bytes per 64 codes: 2.5 MB for a 1e7-code space, resident in every XCD's L2) instead of a 4-byte
+ * row id per code (40 MB: one 64-byte Infinity-Fabric sector per probe row).
+ */
+#define CPH_CHAIN_POSITIONS 1u
+CPH_API int32_t cph_join_chain_ex(cph_ctx* ctx, const cph_chain_step* steps, int32_t nsteps, uint64_t probe_base,
+                                  int32_t out_mem, uint32_t flags, cph_chain** out);
 CPH_API void    cph_chain_release(cph_chain* chain);
 
 /* ---- multi-GPU: the exchange step of the row-range sharded Join ----- */
@@ -560,7 +576,7 @@ typedef struct {
     int32_t  direct_table;    /* 1 when the probe uses the direct-address table                */
     int32_t  dict_entries;    /* entries of the group dictionaries (0: per-position alphabets only)  */
     uint64_t table_entries;   /* entries of the direct-address table (0 if none planned)       */
-    int32_t  lookup_built;    /* lookup structures BUILT so far (bits): 1 = 8-byte table, 2 = 4-byte row table,
+    int32_t  lookup_built;    /* lookup structures BUILT so far (bits): 8 = rank table (positions), 1 = 8-byte table, 2 = 4-byte row table,
                                  4 = hash table.  direct_table / table_entries only say one is PLANNED: the
                                  structures are built by the first Join that uses them (or cph_index_prepare_join) */
     int32_t  hash_mode;       /* 0 none; 1 one code word per entry, 2 up to three words, 3 64-bit tag + verification */
@@ -578,8 +594,9 @@ CPH_API int32_t cph_index_get_info(const cph_index* index, cph_index_info* info)
  * when the code space is dense (<= 24 codes per row), a hash table over the codes otherwise (one 64-byte sector per
  * probe row for any key: random ids, hashes, several columns, keys of any length); a PREFIX join (fewer columns than
  * the index has, csvplus.go:546-550) needs the order and searches the sorted codes, as does every Join when the
- * structure cannot be allocated.  This call builds the structure NOW — `chained` != 0: the one cph_join_chain /
- * cph_stream_join use (4-byte row table for a duplicate-free index), else the one cph_join_probe uses — so that
+ * structure cannot be allocated.  This call builds the structure NOW — `chained` = 1: the one cph_join_chain /
+ * cph_stream_join use (4-byte row table for a duplicate-free index), 2: the one cph_join_chain_ex uses with
+ * CPH_CHAIN_POSITIONS (presence bits + running count per 64 codes), 0: the one cph_join_probe uses — so that
  * the first Join does not pay for it.
  *
  * Sharing an index between ctxs: the structures are built on the INDEX's ctx (its stream, its pool) whatever ctx

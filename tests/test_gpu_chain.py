@@ -35,6 +35,15 @@ def check_chain(ctx, build_tables, stream_keys, probe_base=0, expect_fast=None):
     np.testing.assert_array_equal(ch.stream_row, es)
     for k in range(len(gix)):
         np.testing.assert_array_equal(ch.build_row(k), erows[k])
+    # the same chain reporting SORTED POSITIONS (cph_join_chain_ex CPH_CHAIN_POSITIONS): perm[position] is the row
+    chp = join_chain(ctx, steps, probe_base=probe_base, positions=True)
+    assert chp.positions and not ch.positions and chp.nrows == len(es)
+    np.testing.assert_array_equal(chp.stream_row, es)
+    for k in range(len(gix)):
+        pos = chp.build_row(k)
+        assert len(pos) == 0 or int(pos.max()) < gix[k].nrows
+        np.testing.assert_array_equal(gix[k].perm()[pos], erows[k])
+    chp.release()
     return ch
 
 
