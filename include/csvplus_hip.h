@@ -135,7 +135,8 @@ CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
  *   "sort_rbits"    8 / 9: digit width of the radix sort (0 = automatic)
  *   "sort_xcd_tiles" 0 / 1: the scatter kernel gives every XCD a contiguous range of tiles (default 1)
  *   "speculative_groups"  dictionary windows of long keys on large inputs: 0 = always the exact pass over all rows,
- *                   1 = dictionaries straight from the row sample when it holds no value seen only once (default),
+ *                   1 = dictionaries straight from the row sample when every value of every chosen window is COMMON in it
+ *                   (met 16 times or more: a closed vocabulary; default),
  *                   2 = always from the sample (the encode kernel completes them; a test hook)
  *   "plan_threads" / "gstats_threads"  workgroup sizes of the dictionary encode / window statistics kernels (0 = default)
  *   "join_hash"     0: indexes built on this ctx never get a hash table — their sparse-key Joins binary-search the
