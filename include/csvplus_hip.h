@@ -141,7 +141,11 @@ CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
  *   "plan_threads" / "gstats_threads"  workgroup sizes of the dictionary encode / window statistics kernels (0 = default)
  *   "join_hash"     0: indexes built on this ctx never get a hash table — their sparse-key Joins binary-search the
  *                   sorted codes as before (A/B switch for measurements and for the fallback's tests; default 1)
- *   "codec_debug"   1: the window choice of every index build is printed to stderr
+ *   "codec_debug"   1: the window choice of every index build (and the phase times of a one-launch build) go to stderr
+ *   "small_build_rows"  tables of at most this many rows (default 8192, at most 16384) are indexed by ONE launch of one
+ *                   workgroup and one synchronisation (small_build.hip); 0 = always the general path
+ *   "probe_hash_rows"  2 / 4: rows per phase of the generic hash probe (default 2)
+ *   "chain_rank_lds"  0 / 1: a Join that reports positions copies the rank tables of small indexes into LDS (default 1)
  *   "pool_reserve_mb"  reserves ONE device slab of that many MiB now; later requests are carved out of it first
  *                   (first fit, coalesced on release) and only fall back to hipMalloc when it cannot serve them —
  *                   a one-shot caller pays its device allocations here, not inside its first call
