@@ -13,10 +13,20 @@ if r.get("traffic"):
 for k, v in d["kernels"].items():
     print(f"  {k:28s} {v['avg_ms']:9.4f} ms x {v['launches']:4d}  {v['GBps']} GB/s")
 for k, v in (d.get("index_on_1e8") or {}).items():
+    if "kernel_ms" not in v:
+        print(k, {a: ({x: y for x, y in b.items() if x in ("ms", "pcie_GBps")} if isinstance(b, dict) else b) for a, b in v.items() if a != "scope"})
+        continue
     print(k, "ms", v["ms"], "kernel_ms", v["kernel_ms"], "pass", v.get("frac_pass_model"), "verified", v.get("verified"))
     print("    ", v["kernels_ms"])
+jp = d.get("join_positions")
+if jp:
+    print("join_positions ms_per_step %.3f (x%.2f) k_chain_dense %.3f ms frac %s verified %s" % (
+        jp["ms_per_step"], jp["speedup_vs_row_ids"], jp["k_chain_dense_ms"], (jp.get("roofline") or {}).get("frac"), (jp.get("verify") or {}).get("ok")))
+gc = r.get("gather_ceiling")
+if gc:
+    print("gather ceiling %.3f ms (%s G lookups/s), kernel / ceiling %s, copy %s TB/s" % (gc["ms"], gc["Glookups_per_s"], gc["kernel_over_ceiling"], r.get("copy_TBps")))
 for k in ("e2e_pinned_host", "cpu_baseline"):
     if k in d:
-        print(k, {a: b for a, b in d[k].items() if a not in ("scope", "sample", "variants")})
+        print(k, {a: b for a, b in d[k].items() if a not in ("scope", "sample", "variants", "extrapolated_full_size")})
 for k, v in ((d.get("cpu_baseline") or {}).get("variants") or {}).items():
     print("   ", k, {a: b for a, b in v.items() if a != "sample"})
