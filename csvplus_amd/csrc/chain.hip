@@ -48,9 +48,9 @@ struct ChainStepArg {
     DevCol col;                 // the stream's key column for this step
     const uint8_t* codec;       // codec block of the step's index (global memory)
     const uint32_t* rowtab;     // code -> build row (0xFFFFFFFF: absent), or nullptr
-    const uint4* ranktab;       // positions mode: {present bits, keys before} per 64 codes (probe.hip: k_build_ranktab), or nullptr
+    const uint2* ranktab;       // positions mode: {present bits, keys before} per 32 codes (probe.hip: k_build_ranktab), or nullptr
     int32_t positions;          // the step reports the key's SORTED POSITION instead of the build row
-    int32_t ranktab_lds;        // != 0: blocks of ranktab every workgroup copies into LDS (a small index: no L2 -> L1 line per row)
+    int32_t ranktab_lds;        // != 0: PAIRS of blocks of ranktab every workgroup copies into LDS (a small index: no L2 -> L1 line per row)
     const uint4* hash;          // no rowtab: hash table over the codes (hash_device.hpp, kHashK1 entries), or nullptr -> binary search
     uint32_t hash_sectors;
     uint32_t reserved_;
@@ -106,11 +106,11 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
             const int nblk = a.step[s].ranktab_lds;
             if (nblk) {
                 uint32_t* dst = reinterpret_cast<uint32_t*>(p);
-                for (int i = threadIdx.x; i < nblk; i += kChainThreads) {
-                    const uint4 b = a.step[s].ranktab[i];
-                    dst[3 * i] = b.x;
-                    dst[3 * i + 1] = b.y;
-                    dst[3 * i + 2] = b.z;
+                for (int i = threadIdx.x; i < nblk; i += kChainThreads) {   // two 32-code blocks -> {bits, bits, keys before}
+                    const uint2 b0 = a.step[s].ranktab[2 * i], b1 = a.step[s].ranktab[2 * i + 1];
+                    dst[3 * i] = b0.x;
+                    dst[3 * i + 1] = b1.x;
+                    dst[3 * i + 2] = b0.x ? b0.y : b1.y;   // an empty block carries no count: the pair's keys all sit in the other one
                 }
                 rank_lds[s] = (const CPH_LDS uint32_t*)p;
                 p += (size_t)((nblk * 12 + 15) & ~15);
@@ -160,24 +160,32 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
         for (int s = 0; s < S; s++) {
             const ChainStepArg& st = a.step[s];
             if (st.ranktab) {
-                // the key's rank among the index keys = its sorted position: one 16-byte block per row from a table
-                // 1/16 the size of rowtab (L2-resident for the 1e7-row customers index: no Infinity-Fabric sector per row)
-                uint4 blk[kChainRows];
+                // the key's rank among the index keys = its sorted position: one 8-byte block per row from a table
+                // 1/16 the size of rowtab (L2-resident for the 1e7-row customers index: no Infinity-Fabric sector per
+                // row), or 12 bytes per 64 codes from LDS
+                if (rank_lds[s]) {   // uniform branch
 #pragma unroll
-                for (int k = 0; k < kChainRows; k++) {
-                    const CW cidx = (okm >> k) & 1u ? code[s][k] : (CW)0;   // block 0 always exists
-                    if (rank_lds[s]) {   // uniform branch
+                    for (int k = 0; k < kChainRows; k++) {
+                        const CW cidx = (okm >> k) & 1u ? code[s][k] : (CW)0;
                         const CPH_LDS uint32_t* e = rank_lds[s] + 3u * (uint32_t)((uint64_t)cidx >> 6);
-                        blk[k] = make_uint4(e[0], e[1], e[2], 0u);
+                        const uint32_t bit = (uint32_t)cidx & 63u;
+                        const uint64_t bits = (uint64_t)e[0] | ((uint64_t)e[1] << 32);
+                        const bool present = (bits >> bit) & 1ull;
+                        brow[s][k] = present ? e[2] + (uint32_t)__popcll(bits & ((1ull << bit) - 1ull)) : kTableAbsent;
                     }
-                    else blk[k] = (DBG && (dbg & 1)) ? make_uint4(~0u, ~0u, 0u, 0u) : st.ranktab[(uint64_t)cidx >> 6];
-                }
+                } else {
+                    uint2 blk[kChainRows];
 #pragma unroll
-                for (int k = 0; k < kChainRows; k++) {
-                    const uint32_t bit = (uint32_t)code[s][k] & 63u;
-                    const uint64_t bits = (uint64_t)blk[k].x | ((uint64_t)blk[k].y << 32);
-                    const bool present = (bits >> bit) & 1ull;
-                    brow[s][k] = present ? blk[k].z + (uint32_t)__popcll(bits & ((1ull << bit) - 1ull)) : kTableAbsent;
+                    for (int k = 0; k < kChainRows; k++) {
+                        const CW cidx = (okm >> k) & 1u ? code[s][k] : (CW)0;   // block 0 always exists
+                        blk[k] = (DBG && (dbg & 1)) ? make_uint2(~0u, 0u) : st.ranktab[(uint64_t)cidx >> 5];
+                    }
+#pragma unroll
+                    for (int k = 0; k < kChainRows; k++) {
+                        const uint32_t bit = (uint32_t)code[s][k] & 31u;
+                        const bool present = (blk[k].x >> bit) & 1u;
+                        brow[s][k] = present ? blk[k].y + (uint32_t)__popc(blk[k].x & ((1u << bit) - 1u)) : kTableAbsent;
+                    }
                 }
             } else if (st.rowtab) {
 #pragma unroll
@@ -347,8 +355,8 @@ static Status enqueue_dense(cph_ctx* ctx, const ChainStep* steps, uint64_t nprob
         st.ranktab = nullptr;
         if (positions) {
             CPH_TRY(index_ensure_ranktab(ctx, ix));
-            st.ranktab = ix->ranktab ? ix->ranktab.as<uint4>() : nullptr;
-            const size_t nblk = (ix->table_entries + 63) / 64, rb = (nblk * 12 + 15) & ~(size_t)15;
+            st.ranktab = ix->ranktab ? ix->ranktab.as<uint2>() : nullptr;
+            const size_t nblk = ranktab_blocks(ix->table_entries) / 2, rb = (nblk * 12 + 15) & ~(size_t)15;
             if (st.ranktab && ctx->chain_rank_lds && lds + rank_lds_bytes + rb <= 52 * 1024) {   // three workgroups per CU stay resident
                 st.ranktab_lds = (int32_t)nblk;
                 rank_lds_bytes += rb;

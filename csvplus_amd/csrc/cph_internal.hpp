@@ -282,7 +282,7 @@ struct cph_index {
     cph::DevBuf table;             // {lo,row} / {lo,end} u32x2 [table_entries]: generic probe
     cph::DevBuf rowtab;            // duplicate-free index: u32[table_entries], code -> build row (0xFFFFFFFF: absent);
                                    // 4-byte entries for the chained-join kernel (half the random-access footprint)
-    cph::DevBuf ranktab;           // duplicate-free index: {u64 present bits, u32 codes before, u32 0} per 64 codes — code -> SORTED
+    cph::DevBuf ranktab;           // duplicate-free index: {u32 present bits, u32 keys before} per 32 codes — code -> SORTED
                                    // POSITION (rank) of the key, 1/16 of rowtab's footprint: what a Join that reports index
                                    // positions (cph_join_chain_ex CPH_CHAIN_POSITIONS) looks up
     uint64_t table_entries = 0;    // != 0: the code space is dense enough for a table (decided at build time)
@@ -417,7 +417,8 @@ void index_plan_table(cph_index* ix);                               // host deci
 // error: the index is marked (accel_failed) and the callers use the sorted search.
 Status index_ensure_table(cph_ctx* ctx, const cph_index* ix);       // 8-byte entries {lo,row} / {lo,end}
 Status index_ensure_rowtab(cph_ctx* ctx, const cph_index* ix);      // 4-byte build rows (duplicate-free indexes)
-Status index_ensure_ranktab(cph_ctx* ctx, const cph_index* ix);     // presence bits + running count per 64 codes (duplicate-free indexes)
+Status index_ensure_ranktab(cph_ctx* ctx, const cph_index* ix);     // presence bits + running count per 32 codes (duplicate-free indexes)
+inline uint64_t ranktab_blocks(uint64_t table_entries) { return ((table_entries + 31) / 32 + 1) & ~1ull; }   // 32-code blocks, an even number of them
 Status index_ensure_hash(cph_ctx* ctx, const cph_index* ix);        // hash table over the codes (hash_device.hpp)
 bool index_wants_hash(const cph_index* ix);                         // no direct table planned and rows to look up
 struct ProbeOut {

@@ -192,14 +192,15 @@ Status index_ensure_rowtab(cph_ctx* ctx, const cph_index* cix) {
     return accel_wait(ctx, ix);
 }
 
-// Rank table of a duplicate-free index over a dense code space: block b = codes [64 b, 64 b + 64) holds their presence
-// bits and the number of index keys below 64 b.  sorted position of code c = before + popcount(bits below c's bit):
-// 16 bytes per 64 codes (a 1e7-code space: 2.5 MB, resident in every XCD's L2) where rowtab spends 256.
+// Rank table of a duplicate-free index over a dense code space: block b = codes [32 b, 32 b + 32) holds their presence
+// bits and the number of index keys below 32 b.  sorted position of code c = before + popcount(bits below c's bit):
+// 8 bytes per 32 codes (a 1e7-code space: 2.5 MB, resident in every XCD's L2) where rowtab spends 128, and ONE 8-byte
+// load per lookup.
 template <class K>
-__global__ void k_build_ranktab(const K* __restrict__ codes, uint64_t n, uint4* __restrict__ blocks) {
+__global__ void k_build_ranktab(const K* __restrict__ codes, uint64_t n, uint2* __restrict__ blocks) {
     // The codes are sorted and distinct, so the keys of one block are neighbours: a wave ORs the presence bits of its
     // lanes segment by segment (shuffles), and only the first lane of every segment touches memory — one atomicOr per
-    // (wave, block) instead of one per key (64 neighbouring keys fighting over one word cost 0.66 ms per 1e7 keys).
+    // (wave, block) instead of one per key (neighbouring keys fighting over one word cost 0.66 ms per 1e7 keys).
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t rounds = (n + stride - 1) / stride;
     const int lane = lane_id();
@@ -207,19 +208,19 @@ __global__ void k_build_ranktab(const K* __restrict__ codes, uint64_t n, uint4* 
         const uint64_t i = r * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
         const bool valid = i < n;
         const uint64_t c = valid ? (uint64_t)codes[i] : ~0ull;
-        const uint64_t b = valid ? c >> 6 : ~0ull;            // invalid lanes form their own segment at the end
-        uint64_t bits = valid ? 1ull << (c & 63) : 0ull;
+        const uint64_t b = valid ? c >> 5 : ~0ull;            // invalid lanes form their own segment at the end
+        uint32_t bits = valid ? 1u << (c & 31) : 0u;
 #pragma unroll
         for (int d = 1; d < kWave; d <<= 1) {
             const uint64_t ob = __shfl_down(b, d, kWave);
-            const uint64_t obits = __shfl_down(bits, d, kWave);
+            const uint32_t obits = __shfl_down(bits, d, kWave);
             if (lane + d < kWave && ob == b) bits |= obits;
         }
         const uint64_t pb = __shfl_up(b, 1, kWave);
         const bool head = valid && (lane == 0 || pb != b);
         if (head) {
-            atomicOr(reinterpret_cast<unsigned long long*>(&blocks[b]), (unsigned long long)bits);
-            if (i == 0 || ((uint64_t)codes[i - 1] >> 6) != b) blocks[b].z = (uint32_t)i;   // the block's first key: i keys lie below
+            atomicOr(&blocks[b].x, bits);
+            if (i == 0 || ((uint64_t)codes[i - 1] >> 5) != b) blocks[b].y = (uint32_t)i;   // the block's first key: i keys lie below
         }
     }
 }
@@ -229,17 +230,17 @@ Status index_ensure_ranktab(cph_ctx* ctx, const cph_index* cix) {
     if (!ix->table_entries || ix->accel_failed || ix->first_dup != UINT64_MAX || !ix->windows.empty()) return {};
     if (ix->ranktab) return accel_wait(ctx, ix);
     cph_ctx* bctx = accel_ctx(ctx, ix);
-    const uint64_t n = ix->nrows, nblocks = (ix->table_entries + 63) / 64;
+    const uint64_t n = ix->nrows, nblocks = ranktab_blocks(ix->table_entries);
     DevBuf t;
-    if (!accel_alloc(bctx, ix, &t, nblocks * sizeof(uint4))) return {};
-    CPH_HIP_TRY(hipMemsetAsync(t.get(), 0, nblocks * sizeof(uint4), bctx->stream));
+    if (!accel_alloc(bctx, ix, &t, nblocks * sizeof(uint2))) return {};
+    CPH_HIP_TRY(hipMemsetAsync(t.get(), 0, nblocks * sizeof(uint2), bctx->stream));
     {
-        ProfScope ps(bctx, "k_build_ranktab", (double)n * (ix->codec.key32 ? 4.0 : 8.0) + 2.0 * 16.0 * (double)nblocks);
+        ProfScope ps(bctx, "k_build_ranktab", (double)n * (ix->codec.key32 ? 4.0 : 8.0) + 2.0 * 8.0 * (double)nblocks);
         const dim3 grid(grid_for_items(n)), block(256);
         if (ix->codec.key32)
-            hipLaunchKernelGGL(k_build_ranktab<uint32_t>, grid, block, 0, bctx->stream, ix->sorted_codes.as<uint32_t>(), n, t.as<uint4>());
+            hipLaunchKernelGGL(k_build_ranktab<uint32_t>, grid, block, 0, bctx->stream, ix->sorted_codes.as<uint32_t>(), n, t.as<uint2>());
         else
-            hipLaunchKernelGGL(k_build_ranktab<uint64_t>, grid, block, 0, bctx->stream, ix->sorted_codes.as<uint64_t>(), n, t.as<uint4>());
+            hipLaunchKernelGGL(k_build_ranktab<uint64_t>, grid, block, 0, bctx->stream, ix->sorted_codes.as<uint64_t>(), n, t.as<uint2>());
         CPH_HIP_TRY(hipGetLastError());
     }
     ix->ranktab = std::move(t);
