@@ -423,12 +423,13 @@ Status index_ensure_hash(cph_ctx* ctx, const cph_index* cix) {
 // ---------------------------------------------------------------------------------------------
 // probe
 // ---------------------------------------------------------------------------------------------
-enum : int { kLookSearch = 0, kLookTable = 1, kLookHash = 2 };
+enum : int { kLookSearch = 0, kLookTable = 1, kLookHash = 2, kLookRank = 3 };
 
 // What a probe kernel needs to look a key up other than by searching the sorted codes.
 struct LookupArg {
     const TableEntry* table = nullptr;   // kLookTable
     HashView hash;                       // kLookHash
+    const uint2* rank = nullptr;         // kLookRank: presence bits + keys before per 32 codes (duplicate-free index, dense code space)
     int32_t hash_mode = kHashNone;
     int32_t unique = 0;                  // the index has no duplicate keys: entries carry {lo, build row}
 };
@@ -544,6 +545,18 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(ColsArg cols, int ncols
                     hi = e.b;
                 }
             }
+        } else if constexpr (LOOKUP == kLookRank) {
+            uint64_t code = 0;
+            valid = encode_key(cv, cols, ncols_used, row, [&](int, uint64_t v, int) { code = v; });
+            lo = hi = 0;
+            if (valid) {
+                const uint2 e = look.rank[code >> 5];
+                const uint32_t bit = (uint32_t)code & 31u;
+                if ((e.x >> bit) & 1u) {
+                    lo = e.y + (uint32_t)__popc(e.x & ((1u << bit) - 1u));
+                    hi = lo + 1;
+                }
+            }
         } else {
             valid = encode_key(cv, cols, ncols_used, row, [&](int word, uint64_t v, int p) {
                 const uint64_t vhi = (p + 1 == p_end) ? v + cv.mult[p] - 1 : v;
@@ -563,7 +576,7 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(ColsArg cols, int ncols
         const uint32_t cnt = valid ? (uint32_t)(hi - lo) : 0u;
         out_lo[i] = (uint32_t)lo;
         out_cnt[i] = cnt;
-        if (LOOKUP != kLookSearch && out_first_row) out_first_row[i] = first_row;
+        if (LOOKUP != kLookSearch && LOOKUP != kLookRank && out_first_row) out_first_row[i] = first_row;
         my_sum += cnt;
     }
     }
@@ -654,6 +667,18 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe_fast(DevCol col, const 
                 lo[k] = e[k].a;
                 cnt[k] = table_unique ? (e[k].a != kTableAbsent ? 1u : 0u) : e[k].b - e[k].a;
             }
+        } else if constexpr (LOOKUP == kLookRank) {
+            uint2 e[kProbeRows];
+#pragma unroll
+            for (int k = 0; k < kProbeRows; k++) e[k] = look.rank[(valid[k] ? code[k] : 0) >> 5];   // block 0 always exists
+#pragma unroll
+            for (int k = 0; k < kProbeRows; k++) {
+                const uint32_t bit = (uint32_t)code[k] & 31u;
+                const bool hit = valid[k] && ((e[k].x >> bit) & 1u);
+                lo[k] = hit ? e[k].y + (uint32_t)__popc(e[k].x & ((1u << bit) - 1u)) : kTableAbsent;
+                cnt[k] = hit ? 1u : 0u;
+                e_b[k] = kTableAbsent;
+            }
         } else if constexpr (LOOKUP == kLookHash) {
             // one-word codes through the hash table: the home sectors of the kProbeRows rows are loaded together
             HashSector sc[kProbeRows];
@@ -699,7 +724,7 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe_fast(DevCol col, const 
             if (!ok[k]) continue;
             out_lo[i[k]] = lo[k];
             out_cnt[i[k]] = cnt[k];
-            if constexpr (LOOKUP != kLookSearch) {
+            if constexpr (LOOKUP != kLookSearch && LOOKUP != kLookRank) {
                 // duplicate-free index: the table / hash entry already holds the build row, k_expand then
                 // needs no dependent perm[lo] gather
                 if (out_first_row) out_first_row[i[k]] = e_b[k];
@@ -1002,7 +1027,7 @@ static Status probe_windows(cph_ctx* ctx, const cph_index* ix, const DevCol* col
     return {};
 }
 
-static const char* look_name(int look) { return look == kLookTable ? "k_probe_table" : look == kLookHash ? "k_probe_hash" : "k_probe_search"; }
+static const char* look_name(int look) { return look == kLookTable ? "k_probe_table" : look == kLookHash ? "k_probe_hash" : look == kLookRank ? "k_probe_rank" : "k_probe_search"; }
 
 template <bool KEY32, int LOOKUP>
 static Status launch_probe(cph_ctx* ctx, const cph_index* ix, const ColsArg& arg, int ncols, const LookupArg& look, RowSel row_sel,
@@ -1056,7 +1081,13 @@ Status probe_run(cph_ctx* ctx, const cph_index* ix, const DevCol* cols, int32_t 
     const bool full_key = ncols == ix->nkeycols;
     int lookup = kLookSearch;
     if (full_key && ix->nrows) {
-        if (ix->table_entries != 0 && ix->windows.empty()) {
+        // a duplicate-free index asked for bounds only (Except, has, counts) or for sorted positions needs no row id:
+        // the rank table (8 bytes per 32 codes: L2-resident up to ~1e7 codes) answers instead of the 8-byte-per-code table
+        if (ix->table_entries != 0 && ix->windows.empty() && ix->first_dup == UINT64_MAX && (!want_pairs || positions)) {
+            CPH_TRY(index_ensure_ranktab(ctx, ix));
+            if (ix->ranktab) lookup = kLookRank;
+        }
+        if (lookup == kLookSearch && ix->table_entries != 0 && ix->windows.empty()) {
             CPH_TRY(index_ensure_table(ctx, ix));
             if (ix->table) lookup = kLookTable;
         }
@@ -1067,6 +1098,7 @@ Status probe_run(cph_ctx* ctx, const cph_index* ix, const DevCol* cols, int32_t 
     }
     LookupArg look;
     look.table = ix->table.as<TableEntry>();
+    look.rank = ix->ranktab.as<uint2>();
     look.hash = HashView{ix->hash.as<uint4>(), ix->hash_sectors};
     look.hash_mode = ix->hash_mode;
     look.unique = ix->first_dup == UINT64_MAX ? 1 : 0;
@@ -1076,7 +1108,7 @@ Status probe_run(cph_ctx* ctx, const cph_index* ix, const DevCol* cols, int32_t 
     DevBuf first_rows;
     uint32_t* first_row = nullptr;
     // pairs wanted from a duplicate-free index: the table / hash entries carry the build rows, keep them
-    if (want_pairs && !positions && lookup != kLookSearch && look.unique && ix->windows.empty()) {
+    if (want_pairs && !positions && lookup != kLookSearch && lookup != kLookRank && look.unique && ix->windows.empty()) {
         CPH_TRY(first_rows.alloc(&ctx->pool, nprobe * sizeof(uint32_t)));
         first_row = first_rows.as<uint32_t>();
     }
@@ -1084,7 +1116,9 @@ Status probe_run(cph_ctx* ctx, const cph_index* ix, const DevCol* cols, int32_t 
     const bool k32 = ix->codec.key32;
 #define CPH_PROBE_DISPATCH(FN, ...)                                                                           \
     do {                                                                                                      \
-        if (k32 && lookup == kLookTable) CPH_TRY((FN<true, kLookTable>(__VA_ARGS__)));                        \
+        if (k32 && lookup == kLookRank) CPH_TRY((FN<true, kLookRank>(__VA_ARGS__)));                          \
+        else if (lookup == kLookRank) CPH_TRY((FN<false, kLookRank>(__VA_ARGS__)));                           \
+        else if (k32 && lookup == kLookTable) CPH_TRY((FN<true, kLookTable>(__VA_ARGS__)));                   \
         else if (k32 && lookup == kLookHash) CPH_TRY((FN<true, kLookHash>(__VA_ARGS__)));                     \
         else if (k32) CPH_TRY((FN<true, kLookSearch>(__VA_ARGS__)));                                          \
         else if (lookup == kLookTable) CPH_TRY((FN<false, kLookTable>(__VA_ARGS__)));                         \

@@ -8,7 +8,7 @@ import pytest
 
 from csvplus_amd import DeviceIndex, StrCol, _native as N, datagen as dg
 from oracle import orc
-from tests.helpers import (PEOPLE_NAMES, PEOPLE_SURNAMES, assert_join_equal, cols_of, orders_table, people_table,
+from tests.helpers import (PEOPLE_NAMES, PEOPLE_SURNAMES, assert_bounds_equal, assert_join_equal, cols_of, orders_table, people_table,
                            random_keys, stock_table)
 from tests.test_oracle import INDEX_IMPL_ROWS
 
@@ -216,6 +216,7 @@ def test_random_property(ctx, case, offset_bits):
     keys = list(zip(*[[x[i] for i in g.perm()] for x in b]))
     assert keys == sorted(keys)
     assert_join_equal(g.probe(pcols), oi.join(pcols))
+    assert_bounds_equal(g, pcols, oi.join(pcols))
     for k in range(1, len(bcols)):   # prefix joins on the leading k columns
         assert_join_equal(g.probe(pcols[:k]), oi.join(pcols[:k]))
     for r in rng.integers(0, n, 20):   # Find bounds on full and prefix tuples
@@ -261,6 +262,8 @@ def test_config1_unique_index_and_join(ctx, enc):
     m = g.probe([ords["cust_id"]])
     assert_join_equal(m, oi.join([ords["cust_id"]]))
     assert m.nmatches == n
+    assert_bounds_equal(g, [ords["cust_id"]], oi.join([ords["cust_id"]]))   # bounds only: through the rank table
+    assert g.info()["lookup_built"] & 8
     info = g.info()
     assert info["direct_table"] == 1 and info["key_bytes"] == 4
 
@@ -488,4 +491,5 @@ def test_small_table_build_path(ctx, both_build_paths):
         assert g.info()["build_path"] == (1 if small_on and expect_small else 0), name
         pr = [StrCol.from_values([c.value(i) for i in rng.integers(0, c.nrows, 500)] + [b"zz", b""]) for c in cols]
         assert_join_equal(g.probe(pr), o.join(pr))
+        assert_bounds_equal(g, pr, o.join(pr))
         g.close()
