@@ -493,3 +493,26 @@ def test_small_table_build_path(ctx, both_build_paths):
         assert_join_equal(g.probe(pr), o.join(pr))
         assert_bounds_equal(g, pr, o.join(pr))
         g.close()
+
+
+def test_build_many_mixes_one_launch_and_general_jobs(ctx):
+    """One cph_index_build_many batch with a small table (one-launch build), a table above the limit (general path), a
+    small table whose key needs two code words (reports back, then the general path) and a duplicate in a unique spec."""
+    ctx.set_option("small_build_rows", 8192)
+    rng = np.random.default_rng(91)
+    cols = [
+        [StrCol.from_values([b"%d" % int(x) for x in rng.permutation(5000)])],                       # small
+        [StrCol.from_values([b"%07d" % int(x) for x in rng.permutation(30000)])],                    # general
+        [StrCol.from_values(random_keys(rng, 2000, 14, 14, alphabet=list(range(48, 112))))],         # small candidate, 2 words
+        [StrCol.from_values([b"a", b"b", b"a", b"c"])],                                             # small, duplicate
+    ]
+    res = DeviceIndex.build_many(ctx, [(c, i == 3) for i, c in enumerate(cols)])
+    assert [r.info()["build_path"] for r in res] == [1, 0, 0, 1]
+    assert res[3].status == N.CPH_ERR_DUPLICATE and res[3].first_dup == 1
+    for r, c in zip(res, cols):
+        o = orc.OracleIndex(c)
+        np.testing.assert_array_equal(r.perm(), o.perm)
+        assert r.first_dup == o.first_dup()
+        pr = [StrCol.from_values([c[0].value(i) for i in rng.integers(0, c[0].nrows, 300)] + [b"nope"])]
+        assert_join_equal(r.probe(pr), o.join(pr))
+        r.close()
