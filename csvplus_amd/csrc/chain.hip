@@ -63,6 +63,9 @@ struct ChainStepArg {
 struct ChainArgs {
     ChainStepArg step[kMaxChain];
     uint32_t* out_rows[kMaxChain];
+    int32_t nt_streams;         // the stream's offsets / key bytes are loaded and the results stored non-temporally: they pass
+                                // through once and must not push the lookup tables out of the L2
+    int32_t reserved_;
 };
 
 // DBG: attribution switches for tools/microbench (results are wrong when set):
@@ -130,15 +133,18 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
         // ---- A: value spans ----------------------------------------------------------------------
         WaveSpans<kChainRows, B> sp[S];
 #pragma unroll
-        for (int s = 0; s < S; s++) wave_spans<kChainRows, B>(a.step[s].col, wr, &sp[s]);
+        for (int s = 0; s < S; s++) {
+            if (a.nt_streams) wave_spans<kChainRows, B, false, true>(a.step[s].col, wr, &sp[s]);   // uniform branch
+            else wave_spans<kChainRows, B>(a.step[s].col, wr, &sp[s]);
+        }
         // ---- B: first 8 (16) key bytes ---------------------------------------------------------------
         uint64_t c0[S][kChainRows], c1[LONG ? S : 1][kChainRows];
 #pragma unroll
         for (int s = 0; s < S; s++) {
 #pragma unroll
             for (int k = 0; k < kChainRows; k++) {
-                c0[s][k] = sp[s].chunk(k, 0);
-                if constexpr (LONG) c1[s][k] = sp[s].chunk(k, 1);
+                c0[s][k] = a.nt_streams ? sp[s].chunk_nt(k, 0) : sp[s].chunk(k, 0);
+                if constexpr (LONG) c1[s][k] = a.nt_streams ? sp[s].chunk_nt(k, 1) : sp[s].chunk(k, 1);
             }
         }
         // ---- C: codes -----------------------------------------------------------------------------------
@@ -254,7 +260,10 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
             // the stream row of slot r is probe_base + r by construction: it is never stored here
             if (ok && !(DBG && (dbg & 4))) {
 #pragma unroll
-                for (int s = 0; s < S; s++) (a.out_rows[s] + wr.rbase)[wr.rel[k]] = brow[s][k];
+                for (int s = 0; s < S; s++) {
+                    if (a.nt_streams) __builtin_nontemporal_store(brow[s][k], a.out_rows[s] + wr.rbase + wr.rel[k]);
+                    else (a.out_rows[s] + wr.rbase)[wr.rel[k]] = brow[s][k];
+                }
             }
         }
         // per-(tile, wave) match count
@@ -381,6 +390,7 @@ static Status enqueue_dense(cph_ctx* ctx, const ChainStep* steps, uint64_t nprob
         args.out_rows[s] = d_rows[s];
     }
     lds += rank_lds_bytes;
+    args.nt_streams = ctx->chain_nt_streams == 1 || (ctx->chain_nt_streams == 2 && positions) ? 1 : 0;
     const uint64_t ncounts = ntiles * kChainWaves;   // one match count per (tile, wave), tile-major
     const int dbg = ctx->chain_debug;
     bool long_keys = false, wide = false;

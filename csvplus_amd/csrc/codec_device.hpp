@@ -169,15 +169,18 @@ struct WaveSpans {
     __device__ __forceinline__ uint64_t chunk(int k, uint32_t j) const {   // bytes [8j, 8j+8) of row k's value
         return load_chunk_nobranch<B>(base8, delta, x[k], len[k], j);
     }
+    __device__ __forceinline__ uint64_t chunk_nt(int k, uint32_t j) const {   // the same with a non-temporal load
+        return load_chunk_nobranch<B, true>(base8, delta, x[k], len[k], j);
+    }
 };
 // SEG: the column is a window segment (DevCol.skip / .take) — only the statistics pass of multi-window keys asks for it
-template <int R, class B, bool SEG = false>
+template <int R, class B, bool SEG = false, bool NT = false>
 __device__ __forceinline__ void wave_spans(const DevCol& c, const WaveRows<R>& wr, WaveSpans<R, B>* sp);
-template <int R, class B>
+template <int R, class B, bool NT = false>
 __device__ __forceinline__ void wave_spans_whole(const DevCol& c, const WaveRows<R>& wr, WaveSpans<R, B>* sp);
-template <int R, class B, bool SEG>
+template <int R, class B, bool SEG, bool NT>
 __device__ __forceinline__ void wave_spans(const DevCol& c, const WaveRows<R>& wr, WaveSpans<R, B>* sp) {
-    wave_spans_whole<R, B>(c, wr, sp);
+    wave_spans_whole<R, B, NT>(c, wr, sp);
     if constexpr (SEG) {
 #pragma unroll
         for (int k = 0; k < R; k++) {
@@ -189,7 +192,7 @@ __device__ __forceinline__ void wave_spans(const DevCol& c, const WaveRows<R>& w
         }
     }
 }
-template <int R, class B>
+template <int R, class B, bool NT>
 __device__ __forceinline__ void wave_spans_whole(const DevCol& c, const WaveRows<R>& wr, WaveSpans<R, B>* sp) {
     if (c.fixed_width) {
         const uint64_t p = (uint64_t)(uintptr_t)c.data + wr.rbase * (uint64_t)c.fixed_width;
@@ -210,8 +213,8 @@ __device__ __forceinline__ void wave_spans_whole(const DevCol& c, const WaveRows
         uint32_t b[R], e[R];
 #pragma unroll
         for (int k = 0; k < R; k++) {
-            b[k] = off[wr.rel[k]];
-            e[k] = off[wr.rel[k] + 1];
+            b[k] = NT ? __builtin_nontemporal_load(&off[wr.rel[k]]) : off[wr.rel[k]];
+            e[k] = NT ? __builtin_nontemporal_load(&off[wr.rel[k] + 1]) : off[wr.rel[k] + 1];
         }
 #pragma unroll
         for (int k = 0; k < R; k++) {

@@ -106,7 +106,7 @@ __device__ __forceinline__ uint64_t load_value_chunk(const uint8_t* data, uint64
 // and the loads a lane issues for its rows no longer overlap.
 //   base8 = a wave-uniform, 8-byte aligned pointer;  x + delta = byte offset of the VALUE from base8 (x is what a
 //   lane keeps per row: one 32-bit register when B = u32; the 64-bit address only lives until the load is issued).
-template <class B>
+template <class B, bool NT = false>
 __device__ __forceinline__ uint64_t load_chunk_nobranch(const uint8_t* base8, uint32_t delta, B x, uint32_t len, uint32_t j) {
     typedef const __attribute__((address_space(1))) uint8_t* global_u8_ptr;
     typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
@@ -118,7 +118,10 @@ __device__ __forceinline__ uint64_t load_chunk_nobranch(const uint8_t* base8, ui
     const uint64_t a = has ? (uint64_t)x + (delta + off) : 0ull;
     const uint32_t a7 = (uint32_t)a & 7u;
     const bool straddles = a7 + nb > 8u;
-    const uint64_t w = *(global_u64u_ptr)((global_u8_ptr)base8 + (straddles ? a : a & ~7ull));
+    const global_u64u_ptr wp = (global_u64u_ptr)((global_u8_ptr)base8 + (straddles ? a : a & ~7ull));
+    // NT: the bytes are streamed once — marked for early eviction so that they do not push re-used data (lookup tables)
+    // out of the L2
+    const uint64_t w = NT ? __builtin_nontemporal_load(wp) : *wp;
     return w >> (straddles ? 0u : a7 * 8u);
 }
 

@@ -8,7 +8,8 @@ for cfg in ${1:-"256,3 256,4 256,2 256,6"}; do
   sed -E "s/constexpr int kChainRows    = [0-9]+;/constexpr int kChainRows    = $R;/; s/constexpr int kChainThreads = [0-9]+;/constexpr int kChainThreads = $T;/" /tmp/chain.orig > csvplus_amd/csrc/chain.hip
   make hip > /tmp/make_$T_$R.log 2>&1 || { echo "build failed for $cfg"; tail -5 /tmp/make_$T_$R.log; continue; }
   timeout 300 python - <<PY
-import sys
+import sys, os
+POS = os.environ.get("CHAIN_POS", "0") == "1"
 sys.path.insert(0, '.')
 from csvplus_amd import datagen as dg
 from csvplus_amd.engine import Engine
@@ -20,11 +21,11 @@ o = dg.orders(M, NC, NP)
 oc, op = o["cust_id"].to_device(dev), o["prod_id"].to_device(dev)
 ia = eng.index_on([cust], unique=True); ib = eng.index_on([prod], unique=True)
 steps = [(ia, oc), (ib, op)]
-r = eng.chained_join(steps); assert r.n == M; r.release()
+r = eng.chained_join(steps, positions=POS); assert r.n == M; r.release()
 eng.ctx.profile(True); eng.ctx.profile_read(reset=True)
-for _ in range(5): eng.chained_join(steps).release()
+for _ in range(5): eng.chained_join(steps, positions=POS).release()
 p = eng.ctx.profile_read(reset=True)
-print("threads,rows=$cfg k_chain_dense %.3f ms" % (p['k_chain_dense']['total_ms'] / 5), flush=True)
+print(("positions " if POS else "row ids   ") + "threads,rows=$cfg k_chain_dense %.3f ms" % (p['k_chain_dense']['total_ms'] / 5), flush=True)
 PY
 done
 cp /tmp/chain.orig csvplus_amd/csrc/chain.hip

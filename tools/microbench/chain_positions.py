@@ -33,4 +33,7 @@ def run(label, positions, **opts):
 for rep in range(2):
     run("row ids (4-byte row table, 40 MB)", False)
     run("positions, rank tables in global memory / L2", True, chain_rank_lds=0)
-    run("positions, products rank table (25 KB) in LDS", True, chain_rank_lds=1)
+    run("positions, products rank table (30 KB) in LDS", True, chain_rank_lds=1)
+    run("positions, LDS + non-temporal streams", True, chain_rank_lds=1, chain_nt_streams=1)
+    run("row ids, non-temporal streams", False, chain_nt_streams=1)
+    ctx.set_option("chain_nt_streams", 0)
