@@ -567,13 +567,15 @@ def main():
         ia = eng.index_on([d_cust], unique=True)
         ib = eng.index_on([d_prod], unique=True)
         pc = [PinnedCol(eng.ctx, ords["cust_id"]), PinnedCol(eng.ctx, ords["prod_id"])]
-        chunk = 1 << 24
+        chunk = 1 << 23
         bounds = [(b, min(b + chunk, nloc)) for b in range(0, nloc, chunk)]
         chunks = [[c.col.slice(b, e) for c in pc] for b, e in bounds]
         nslots, inflight = 4, 2   # 2 chunks in flight over 4 slot streams (even counts: odd ones measured ~25% slower)
         best = None
-        for rep in range(3):
-            sj = StreamJoin(eng.ctx, [ia, ib], nslots=nslots)
+        # ONE pipeline for all repetitions: the first pass page-locks the slots' result blocks and sizes their device
+        # buffers (a long-running caller pays that once), the best of the following passes is reported
+        sj = StreamJoin(eng.ctx, [ia, ib], nslots=nslots)
+        for rep in range(4):
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
             sub = done = 0
@@ -586,14 +588,14 @@ def main():
                 joined_e2e += r["nmatches"]
                 done += 1
             dt_e2e = time.perf_counter() - t0
-            sj.close()
-            if best is None or dt_e2e < best:
+            if rep > 0 and (best is None or dt_e2e < best):
                 best = dt_e2e
+        sj.close()
         h2d = host_bytes["cust_id"] + host_bytes["prod_id"] + off_o
         d2h = 8 * nloc + nloc // 8
         out["e2e_pinned_host"] = {
             "scope": "pinned host key columns in -> pinned host build-row ids + match bitmap out (cph_stream_join_*), "
-                     "indexes already built; PCIe inclusive",
+                     "indexes already built; PCIe inclusive; one pipeline reused, first pass (page-locking of the result blocks) not counted",
             "rows": nloc, "chunk_rows": chunk, "slots": nslots, "in_flight": inflight, "ms": round(best * 1e3, 2),
             "rows_per_s": nloc / best, "joined": joined_e2e,
             "h2d_GBps": round(h2d / best / 1e9, 1), "d2h_GBps": round(d2h / best / 1e9, 1)}

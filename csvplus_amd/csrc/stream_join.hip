@@ -321,16 +321,6 @@ CPH_API int32_t cph_stream_join_submit(cph_stream_join* sj, const cph_strcol* st
             steps[s].cols[0] = d;
         }
         const uint64_t mw = chain_dense_mask_words(n), cw = chain_dense_count_words(n);
-        uint32_t* rows[CPH_MAX_CHAIN] = {nullptr};
-        for (int s = 0; s < sj->nsteps; s++) {
-            CPH_TRY(sl.d_rows[s].alloc(&ctx->pool, n * sizeof(uint32_t)));
-            rows[s] = sl.d_rows[s].as<uint32_t>();
-        }
-        CPH_TRY(sl.d_masks.alloc(&ctx->pool, mw * sizeof(uint64_t)));
-        CPH_TRY(sl.d_counts.alloc(&ctx->pool, cw * sizeof(uint32_t)));
-        CPH_TRY(sl.d_total.alloc(&ctx->pool, sizeof(uint64_t)));
-        CPH_TRY(chain_enqueue_dense(ctx, steps, sj->nsteps, n, probe_base, rows, sl.d_masks.as<uint64_t>(),
-                                    sl.d_counts.as<uint32_t>(), sl.d_total.as<uint64_t>()));
         // pinned result block
         auto a64 = [](size_t x) { return (x + 63) & ~(size_t)63; };
         const size_t b_rows = a64(n * sizeof(uint32_t)), b_masks = a64(mw * sizeof(uint64_t));
@@ -343,10 +333,29 @@ CPH_API int32_t cph_stream_join_submit(cph_stream_join* sj, const cph_strcol* st
             sl.h_cap = need;
         }
         uint8_t* h = static_cast<uint8_t*>(sl.h_block);
+        // Row ids either go to device buffers and travel by a D2H copy behind the kernel, or (ctx option
+        // "stream_zero_copy_out") the kernel stores them straight into the pinned block: posted PCIe writes issued by the
+        // CUs, which leaves the copy engine to the NEXT chunk's upload — on boxes where one engine serves both directions
+        // the two transfers otherwise take turns
+        const bool zero_copy = pctx->stream_zero_copy_out != 0;
+        uint32_t* rows[CPH_MAX_CHAIN] = {nullptr};
         for (int s = 0; s < sj->nsteps; s++) {
             sl.h_rows[s] = reinterpret_cast<uint32_t*>(h + (size_t)s * b_rows);
-            CPH_HIP_TRY(hipMemcpyAsync(sl.h_rows[s], rows[s], n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            if (zero_copy) {
+                rows[s] = sl.h_rows[s];
+            } else {
+                CPH_TRY(sl.d_rows[s].alloc(&ctx->pool, n * sizeof(uint32_t)));
+                rows[s] = sl.d_rows[s].as<uint32_t>();
+            }
         }
+        CPH_TRY(sl.d_masks.alloc(&ctx->pool, mw * sizeof(uint64_t)));
+        CPH_TRY(sl.d_counts.alloc(&ctx->pool, cw * sizeof(uint32_t)));
+        CPH_TRY(sl.d_total.alloc(&ctx->pool, sizeof(uint64_t)));
+        CPH_TRY(chain_enqueue_dense(ctx, steps, sj->nsteps, n, probe_base, rows, sl.d_masks.as<uint64_t>(),
+                                    sl.d_counts.as<uint32_t>(), sl.d_total.as<uint64_t>()));
+        if (!zero_copy)
+            for (int s = 0; s < sj->nsteps; s++)
+                CPH_HIP_TRY(hipMemcpyAsync(sl.h_rows[s], rows[s], n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         sl.h_masks = reinterpret_cast<uint64_t*>(h + (size_t)sj->nsteps * b_rows);
         sl.h_total = reinterpret_cast<uint64_t*>(h + (size_t)sj->nsteps * b_rows + b_masks);
         CPH_HIP_TRY(hipMemcpyAsync(sl.h_masks, sl.d_masks.get(), mw * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
