@@ -570,7 +570,7 @@ def main():
         chunk = 1 << 23
         bounds = [(b, min(b + chunk, nloc)) for b in range(0, nloc, chunk)]
         chunks = [[c.col.slice(b, e) for c in pc] for b, e in bounds]
-        nslots, inflight = 4, 2   # 2 chunks in flight over 4 slot streams (even counts: odd ones measured ~25% slower)
+        nslots, inflight = 2, 2   # two slots, both in flight: the best of 1-4 slots on every box measured (profiles/r03_stream_join_pcie.txt)
         best = None
         # ONE pipeline for all repetitions: the first pass page-locks the slots' result blocks and sizes their device
         # buffers (a long-running caller pays that once), the best of the following passes is reported

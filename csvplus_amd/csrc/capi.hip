@@ -768,6 +768,7 @@ CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value
     else if (k == "sort_xcd_tiles") ctx->sort_xcd_tiles = value != 0;
     else if (k == "codec_debug") ctx->codec_debug = value != 0;
     else if (k == "join_hash") ctx->join_hash = value != 0;
+    else if (k == "stream_role_streams") ctx->stream_role_streams = value != 0;
     else if (k == "stream_zero_copy_out") ctx->stream_zero_copy_out = value != 0;
     else if (k == "chain_nt_streams") ctx->chain_nt_streams = value < 0 || value > 2 ? 0 : (int)value;
     else if (k == "chain_rank_lds") ctx->chain_rank_lds = value != 0;

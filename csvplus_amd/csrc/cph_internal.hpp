@@ -233,6 +233,7 @@ struct cph_ctx {
     int sort_digit_stream = 1;     // scatter writes the next pass's digits as a byte stream for its histogram (radix_sort.hip)
     int sort_xcd_tiles = 1;        // scatter: contiguous tile ranges per XCD (radix_sort.hip)
     int small_build_rows = 8192;   // tables of at most this many rows (<= 16384) are indexed by ONE launch of one workgroup (small_build.hip); 0: never
+    int stream_role_streams = 0;   // cph_stream_join (fused mode): 1 = one stream for all uploads, one for all downloads; 0 (default, faster at 2 and 4 slots): everything of a slot on its own stream
     int stream_zero_copy_out = 0;  // cph_stream_join (fused mode): the kernel stores the row ids straight into the slot's pinned block
     int chain_nt_streams = 0;      // chained join: non-temporal loads / stores for the stream's bytes and the results (0 never, 1 always, 2 positions mode)
     int chain_rank_lds = 1;        // positions mode: rank tables of small indexes are copied into LDS by every workgroup (A/B switch)

@@ -36,7 +36,7 @@ struct cph_stream_join {
     const cph_index* index[CPH_MAX_CHAIN] = {nullptr};
     struct Slot {
         cph_ctx sctx;                      // private stream + device pool (the kernels run on sctx.stream)
-        hipEvent_t done = nullptr;
+        hipEvent_t done = nullptr, uploaded = nullptr, computed = nullptr;
         bool busy = false;
         uint64_t probe_base = 0, nrows = 0;
         std::vector<DevBuf> d_in;          // staged key columns
@@ -56,6 +56,10 @@ struct cph_stream_join {
         uint64_t r_matches = 0;
         const uint64_t* r_stream = nullptr;
     };
+    // fused mode: ALL uploads go through one stream and all downloads through another (the slots' own streams carry the
+    // kernels), chained by events — each direction then keeps one copy engine busy back to back whatever the number of
+    // slots (with a slot's upload, kernels and download on ONE stream per slot, odd slot counts ran 25 % slower)
+    hipStream_t up = nullptr, down = nullptr;
     bool general = false;
     int ncols[CPH_MAX_CHAIN] = {1, 1, 1, 1};
     int total_cols = 0;
@@ -72,7 +76,9 @@ static int32_t sj_fail(cph_ctx* ctx, int32_t code, const std::string& msg) {
 
 // A chunk's key column (host, offsets may start anywhere in the column's buffer) made device resident on the slot's
 // stream: only the chunk's bytes [first, last) travel, the data pointer is biased so that the offsets stay valid.
-static Status stage_chunk_col(cph_ctx* ctx, const cph_strcol& c, uint64_t n, std::vector<DevBuf>* keep, DevCol* out) {
+static Status stage_chunk_col(cph_ctx* ctx, const cph_strcol& c, uint64_t n, std::vector<DevBuf>* keep, DevCol* out,
+                              hipStream_t copy_stream = nullptr) {
+    const hipStream_t cs = copy_stream ? copy_stream : ctx->stream;
     if (c.nrows != n) return {CPH_ERR_INVALID, "chunk columns differ in row count"};
     if (c.mem != CPH_MEM_HOST) return {CPH_ERR_INVALID, "stream-join chunks are host columns"};
     DevCol d;
@@ -84,7 +90,7 @@ static Status stage_chunk_col(cph_ctx* ctx, const cph_strcol& c, uint64_t n, std
         const size_t bytes = (size_t)n * c.fixed_width;
         DevBuf bd;
         CPH_TRY(bd.alloc(&ctx->pool, bytes + 8));
-        CPH_HIP_TRY(hipMemcpyAsync(bd.get(), c.data, bytes, hipMemcpyHostToDevice, ctx->stream));
+        CPH_HIP_TRY(hipMemcpyAsync(bd.get(), c.data, bytes, hipMemcpyHostToDevice, cs));
         d.data = bd.as<uint8_t>();
         keep->push_back(std::move(bd));
     } else {
@@ -98,9 +104,9 @@ static Status stage_chunk_col(cph_ctx* ctx, const cph_strcol& c, uint64_t n, std
         DevBuf bo, bd;
         CPH_TRY(bo.alloc(&ctx->pool, (size_t)(n + 1) * ob));
         CPH_TRY(bd.alloc(&ctx->pool, (size_t)(last - first) + 16));
-        CPH_HIP_TRY(hipMemcpyAsync(bo.get(), c.offsets, (size_t)(n + 1) * ob, hipMemcpyHostToDevice, ctx->stream));
+        CPH_HIP_TRY(hipMemcpyAsync(bo.get(), c.offsets, (size_t)(n + 1) * ob, hipMemcpyHostToDevice, cs));
         if (last > first)
-            CPH_HIP_TRY(hipMemcpyAsync(bd.get(), c.data + first, (size_t)(last - first), hipMemcpyHostToDevice, ctx->stream));
+            CPH_HIP_TRY(hipMemcpyAsync(bd.get(), c.data + first, (size_t)(last - first), hipMemcpyHostToDevice, cs));
         // offsets keep their absolute values: bias the data pointer instead of rewriting them
         d.data = bd.as<uint8_t>() - first;
         d.offsets = bo.get();
@@ -224,7 +230,9 @@ static int32_t stream_join_create(cph_ctx* ctx, const cph_index* const* indexes,
     for (int i = 0; i < nslots; i++) {
         auto* sl = new (std::nothrow) cph_stream_join::Slot();
         if (!sl || hipStreamCreateWithFlags(&sl->sctx.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&sl->done, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&sl->done, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&sl->uploaded, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&sl->computed, hipEventDisableTiming) != hipSuccess) {
             delete sl;
             cph_stream_join_destroy(sj);
             return sj_fail(ctx, CPH_ERR_HIP, "cannot create slot stream/event");
@@ -234,6 +242,12 @@ static int32_t stream_join_create(cph_ctx* ctx, const cph_index* const* indexes,
         sl->sctx.join_hash = ctx->join_hash;
         sj->slots.push_back(sl);
         if (sj->general) sl->worker = std::thread(slot_worker, sj, sl);
+    }
+    if (!sj->general && ctx->stream_role_streams &&
+        (hipStreamCreateWithFlags(&sj->up, hipStreamNonBlocking) != hipSuccess ||
+         hipStreamCreateWithFlags(&sj->down, hipStreamNonBlocking) != hipSuccess)) {
+        cph_stream_join_destroy(sj);
+        return sj_fail(ctx, CPH_ERR_HIP, "cannot create the upload / download streams");
     }
     *out = sj;
     return CPH_OK;
@@ -253,6 +267,8 @@ CPH_API int32_t cph_stream_join_create_general(cph_ctx* ctx, const cph_index* co
 CPH_API void cph_stream_join_destroy(cph_stream_join* sj) {
     if (!sj) return;
     if (sj->parent) (void)hipSetDevice(sj->parent->device);
+    if (sj->up) (void)hipStreamSynchronize(sj->up);
+    if (sj->down) (void)hipStreamSynchronize(sj->down);
     for (auto* sl : sj->slots) {
         if (!sl) continue;
         if (sl->worker.joinable()) {
@@ -272,6 +288,8 @@ CPH_API void cph_stream_join_destroy(cph_stream_join* sj) {
         sl->sctx.pool.trim();
         if (sl->h_block) (void)hipHostFree(sl->h_block);
         if (sl->done) (void)hipEventDestroy(sl->done);
+        if (sl->uploaded) (void)hipEventDestroy(sl->uploaded);
+        if (sl->computed) (void)hipEventDestroy(sl->computed);
         if (sl->sctx.stream) (void)hipStreamDestroy(sl->sctx.stream);
         for (auto& p : sl->sctx.prof_pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
         for (hipEvent_t e : sl->sctx.prof_free_events) (void)hipEventDestroy(e);
@@ -279,6 +297,8 @@ CPH_API void cph_stream_join_destroy(cph_stream_join* sj) {
         if (sl->sctx.upload_ring) (void)hipHostFree(sl->sctx.upload_ring);
         delete sl;
     }
+    if (sj->up) { (void)hipStreamSynchronize(sj->up); (void)hipStreamDestroy(sj->up); }
+    if (sj->down) { (void)hipStreamSynchronize(sj->down); (void)hipStreamDestroy(sj->down); }
     delete sj;
 }
 
@@ -315,10 +335,14 @@ CPH_API int32_t cph_stream_join_submit(cph_stream_join* sj, const cph_strcol* st
         ChainStep steps[CPH_MAX_CHAIN];
         for (int s = 0; s < sj->nsteps; s++) {
             DevCol d;
-            CPH_TRY(stage_chunk_col(ctx, step_cols[s], n, &sl.d_in, &d));
+            CPH_TRY(stage_chunk_col(ctx, step_cols[s], n, &sl.d_in, &d, sj->up));
             steps[s].index = sj->index[s];
             steps[s].ncols = 1;
             steps[s].cols[0] = d;
+        }
+        if (sj->up) {   // the slot's kernels start when the chunk has arrived
+            CPH_HIP_TRY(hipEventRecord(sl.uploaded, sj->up));
+            CPH_HIP_TRY(hipStreamWaitEvent(ctx->stream, sl.uploaded, 0));
         }
         const uint64_t mw = chain_dense_mask_words(n), cw = chain_dense_count_words(n);
         // pinned result block
@@ -353,14 +377,20 @@ CPH_API int32_t cph_stream_join_submit(cph_stream_join* sj, const cph_strcol* st
         CPH_TRY(sl.d_total.alloc(&ctx->pool, sizeof(uint64_t)));
         CPH_TRY(chain_enqueue_dense(ctx, steps, sj->nsteps, n, probe_base, rows, sl.d_masks.as<uint64_t>(),
                                     sl.d_counts.as<uint32_t>(), sl.d_total.as<uint64_t>()));
+        hipStream_t ds = ctx->stream;
+        if (sj->down) {   // the downloads queue up behind one another on their own stream, each behind its chunk's kernels
+            CPH_HIP_TRY(hipEventRecord(sl.computed, ctx->stream));
+            CPH_HIP_TRY(hipStreamWaitEvent(sj->down, sl.computed, 0));
+            ds = sj->down;
+        }
         if (!zero_copy)
             for (int s = 0; s < sj->nsteps; s++)
-                CPH_HIP_TRY(hipMemcpyAsync(sl.h_rows[s], rows[s], n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+                CPH_HIP_TRY(hipMemcpyAsync(sl.h_rows[s], rows[s], n * sizeof(uint32_t), hipMemcpyDeviceToHost, ds));
         sl.h_masks = reinterpret_cast<uint64_t*>(h + (size_t)sj->nsteps * b_rows);
         sl.h_total = reinterpret_cast<uint64_t*>(h + (size_t)sj->nsteps * b_rows + b_masks);
-        CPH_HIP_TRY(hipMemcpyAsync(sl.h_masks, sl.d_masks.get(), mw * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-        CPH_HIP_TRY(hipMemcpyAsync(sl.h_total, sl.d_total.get(), sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-        CPH_HIP_TRY(hipEventRecord(sl.done, ctx->stream));
+        CPH_HIP_TRY(hipMemcpyAsync(sl.h_masks, sl.d_masks.get(), mw * sizeof(uint64_t), hipMemcpyDeviceToHost, ds));
+        CPH_HIP_TRY(hipMemcpyAsync(sl.h_total, sl.d_total.get(), sizeof(uint64_t), hipMemcpyDeviceToHost, ds));
+        CPH_HIP_TRY(hipEventRecord(sl.done, ds));
         return {};
     };
     Status st = run();

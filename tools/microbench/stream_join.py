@@ -20,8 +20,8 @@ for i in range(nbuf):
     o = dg.orders(10**9, NC, NP, row0=i * chunk, nrows=chunk)
     bufs.append(([PinnedCol(ctx, o["cust_id"]), PinnedCol(ctx, o["prod_id"])],
                  o["cust_id"].nbytes_values() + o["prod_id"].nbytes_values() + o["prod_id"].nbytes_offsets()))
-for zc, slots in [(z, k) for z in (0, 1) for k in (1, 2, 3, 4)]:
-    ctx.set_option("stream_zero_copy_out", zc)
+for zc, slots in [(z, k) for z in (1, 0) for k in (1, 2, 3, 4)]:
+    ctx.set_option("stream_role_streams", zc)
     sj = StreamJoin(ctx, [ia, ib], nslots=slots)
     nchunks = max(slots + 1, total_rows // chunk)
     t0 = time.perf_counter()
@@ -38,6 +38,6 @@ for zc, slots in [(z, k) for z in (0, 1) for k in (1, 2, 3, 4)]:
     dt = time.perf_counter() - t0
     rows = nchunks * chunk
     d2h = rows * 8 + rows // 8
-    print(f"zero_copy_out={zc} slots={slots}: {rows:.3e} rows in {dt * 1e3:8.1f} ms -> {rows / dt / 1e9:6.2f} G rows/s | "
+    print(f"role_streams={zc} slots={slots}: {rows:.3e} rows in {dt * 1e3:8.1f} ms -> {rows / dt / 1e9:6.2f} G rows/s | "
           f"H2D {h2d / dt / 1e9:5.1f} GB/s  D2H {d2h / dt / 1e9:5.1f} GB/s | joined {joined:.3e}", flush=True)
     sj.close()
