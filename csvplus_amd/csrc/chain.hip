@@ -155,9 +155,11 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
 #pragma unroll
                 for (int k = 0; k < kChainRows; k++) code[s][k] = (CW)((c0[s][k] ^ (LONG ? c1[LONG ? s : 0][k] : 0ull)) & 1023);
             } else if (!WIDE || cv[s].hdr->lutw_bits == 32) {
-                encode_rows<kChainRows, uint32_t, B, CW, LONG>(cv[s], sp[s], c0[s], c1[LONG ? s : 0], code[s], &okm);
+                encode_rows<kChainRows, uint32_t, B, CW, LONG>(cv[s], sp[s], c0[s], c1[LONG ? s : 0], code[s], &okm,
+                                                               a.step[s].col.fixed_width != 0 && (int)a.step[s].col.fixed_width == cv[s].hdr->col_maxlen[0]);
             } else {
-                encode_rows<kChainRows, uint64_t, B, CW, LONG>(cv[s], sp[s], c0[s], c1[LONG ? s : 0], code[s], &okm);
+                encode_rows<kChainRows, uint64_t, B, CW, LONG>(cv[s], sp[s], c0[s], c1[LONG ? s : 0], code[s], &okm,
+                                                               a.step[s].col.fixed_width != 0 && (int)a.step[s].col.fixed_width == cv[s].hdr->col_maxlen[0]);
             }
         }
         // ---- D: lookups ---------------------------------------------------------------------------------

@@ -247,9 +247,31 @@ inline bool col_is_narrow(const DevCol& c) { return c.fixed_width ? c.fixed_widt
 // the positions walked with compile-time shifts, R rows per position so that the LDS loads overlap.  c0 / c1 = the
 // prefetched bytes 0..7 / 8..15 of every row (c1 only read when LONG); later chunks are fetched on demand.  Clears
 // the okm bit of a row whose key cannot occur in the index (symbol outside the alphabet, value too long).
+// One position of encode_rows for all R rows.  FIXED: every row's value covers the position (a fixed-width column:
+// no length compare / select).  32-bit LUT entries are accumulated with a SATURATING add: valid entries sum to less than
+// 2^31, an entry with the top bit set ("not in the alphabet") pushes the sum there and saturation keeps it there however
+// many follow, so no separate OR of the entries is needed; 64-bit entries keep the OR.
+template <int R, class W, class B, bool FIXED>
+__device__ __forceinline__ void encode_position(const CPH_LDS W* lp, int b, uint32_t pos, const WaveSpans<R, B>& sp, const uint64_t (&cur)[R],
+                                                W (&acc)[R], W (&bad)[R]) {
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        const uint32_t half = b < 4 ? (uint32_t)cur[k] : (uint32_t)(cur[k] >> 32);
+        const uint32_t byte = (half >> (8 * (b & 3))) & 0xFFu;
+        const uint32_t sym = FIXED ? byte + 1u : (pos < sp.len[k] ? byte + 1u : 0u);
+        const W v = lp[b * kLutStride + sym];
+        if constexpr (sizeof(W) == 4) {
+            acc[k] = __builtin_elementwise_add_sat(acc[k], v);
+        } else {
+            bad[k] |= v;
+            acc[k] += v;
+        }
+    }
+}
+
 template <int R, class W, class B, class CW, bool LONG>
 __device__ __forceinline__ void encode_rows(const CodecView& cv, const WaveSpans<R, B>& sp, const uint64_t (&c0)[R],
-                                            const uint64_t (&c1)[R], CW (&code)[R], uint32_t* okmask) {
+                                            const uint64_t (&c1)[R], CW (&code)[R], uint32_t* okmask, bool fixed = false) {
     const int maxlen = cv.hdr->col_maxlen[0];
     const CPH_LDS W* lutw = (const CPH_LDS W*)cv.lutw;
     W acc[R], bad[R];
@@ -271,26 +293,22 @@ __device__ __forceinline__ void encode_rows(const CodecView& cv, const WaveSpans
         }
         const int qn = maxlen - 8 * j < 8 ? maxlen - 8 * j : 8;
         const CPH_LDS W* lp = lutw + (8 * j) * kLutStride;
+        if (fixed) {   // wave-uniform: the column is fixed-width and as wide as the index's longest key
 #pragma unroll
-        for (int b = 0; b < 8; b++) {
-            if (b < qn) {   // uniform
+            for (int b = 0; b < 8; b++)
+                if (b < qn) encode_position<R, W, B, true>(lp, b, (uint32_t)(8 * j + b), sp, cur, acc, bad);
+        } else {
 #pragma unroll
-                for (int k = 0; k < R; k++) {
-                    const uint32_t half = b < 4 ? (uint32_t)cur[k] : (uint32_t)(cur[k] >> 32);
-                    const uint32_t byte = (half >> (8 * (b & 3))) & 0xFFu;
-                    const uint32_t sym = (uint32_t)(8 * j + b) < sp.len[k] ? byte + 1u : 0u;
-                    const W v = lp[b * kLutStride + sym];
-                    bad[k] |= v;
-                    acc[k] += v;
-                }
-            }
+            for (int b = 0; b < 8; b++)
+                if (b < qn) encode_position<R, W, B, false>(lp, b, (uint32_t)(8 * j + b), sp, cur, acc, bad);
         }
     }
     uint32_t m = *okmask;
 #pragma unroll
     for (int k = 0; k < R; k++) {
         code[k] = (CW)acc[k];
-        const bool good = sp.len[k] <= (uint32_t)maxlen && !(bad[k] >> (sizeof(W) * 8 - 1));
+        const W flag = sizeof(W) == 4 ? acc[k] : bad[k];
+        const bool good = sp.len[k] <= (uint32_t)maxlen && !(flag >> (sizeof(W) * 8 - 1));
         if (!good) m &= ~(1u << k);
     }
     *okmask = m;

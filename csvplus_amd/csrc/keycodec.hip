@@ -952,7 +952,8 @@ __global__ __launch_bounds__(kEncodeThreads) void k_encode_build_fast(DevCol col
             }
             OUT code[kEncodeFastRows];
             uint32_t okm = wr.okm;   // every build key encodes: only the existence bits matter here
-            encode_rows<kEncodeFastRows, W, B, OUT, LONG>(cv, sp, c0, c1, code, &okm);
+            encode_rows<kEncodeFastRows, W, B, OUT, LONG>(cv, sp, c0, c1, code, &okm,
+                                                          col.fixed_width != 0 && (int)col.fixed_width == cv.hdr->col_maxlen[0]);
 #pragma unroll
             for (int k = 0; k < kEncodeFastRows; k++) {
                 if ((wr.okm >> k) & 1u) {
