@@ -6,7 +6,7 @@ from hypothesis import HealthCheck, given, settings, strategies as st
 
 from csvplus_amd import DeviceIndex, StrCol, join_chain
 from oracle import orc
-from tests.helpers import assert_join_equal
+from tests.helpers import assert_bounds_equal, assert_join_equal
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("both_build_paths")]
 
@@ -43,6 +43,7 @@ def test_index_join_find_match_oracle(ctx, t):
     assert g.first_dup == o.first_dup()
     for k in range(1, len(bcols) + 1):
         assert_join_equal(g.probe(pcols[:k]), o.join(pcols[:k]))
+        assert_bounds_equal(g, pcols[:k], o.join(pcols[:k]))   # bounds only: the rank table when the index has distinct keys
     for r in range(min(5, len(build[0]))):
         for k in range(1, len(bcols) + 1):
             vals = [build[c][r] for c in range(k)]
@@ -53,4 +54,15 @@ def test_index_join_find_match_oracle(ctx, t):
         np.testing.assert_array_equal(ch.stream_row, j["probe_idx"])
         np.testing.assert_array_equal(ch.build_row(0), j["build_row"])
         ch.release()
+    if probe[0]:   # the chain reporting sorted positions, on 1-3 key columns: perm[position] is the oracle's row
+        chp = join_chain(ctx, [(g, pcols)], positions=True)
+        j = o.join(pcols)
+        np.testing.assert_array_equal(chp.stream_row, j["probe_idx"])
+        np.testing.assert_array_equal(g.perm()[chp.build_row(0)] if chp.nrows else np.zeros(0, np.uint32), j["build_row"])
+        chp.release()
+    keys = [tuple(build[c][r] for c in range(len(bcols))) for r in range(min(8, len(build[0])))]
+    if keys:
+        lo, hi = g.find_many(keys)
+        for (a, b), key in zip(zip(lo, hi), keys):
+            assert (int(a), int(b)) == o.find(*key)
     g.close()
