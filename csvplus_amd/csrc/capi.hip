@@ -1270,15 +1270,17 @@ CPH_API int32_t cph_index_find_many(cph_ctx* ctx, const cph_index* ix, const cph
         return CPH_OK;
     }
     if (nkeys > (1ull << 28)) return fail(ctx, {CPH_ERR_INVALID, "cph_index_find_many: at most 2^28 keys per call"});
-    // query block per key: stride words = [nq | q_exact ... | qlo | qhi]; nq = 0 marks "cannot occur"
+    // query block per key: stride words = [nq | q_exact ... | qlo | qhi]; nq = ~0 marks "cannot occur"
     const size_t stride = (size_t)ix->total_words() + 2;
     std::vector<uint64_t> host(stride * nkeys, 0), q_exact;
     for (uint64_t k = 0; k < nkeys; k++) {
         int32_t nq = 0;
         uint64_t qlo = 0, qhi = 0;
         uint64_t* h = host.data() + stride * k;
-        if (!find_query(ix, values + (size_t)k * (size_t)nvalues, nvalues, &q_exact, &nq, &qlo, &qhi) || nq <= 0) continue;
-        h[0] = (uint64_t)nq;
+        h[0] = ~0ull;   // "cannot occur" until the values encode
+        if (!find_query(ix, values + (size_t)k * (size_t)nvalues, nvalues, &q_exact, &nq, &qlo, &qhi)) continue;
+        h[0] = (uint64_t)(nq > 0 ? nq : 0);   // 0 words (a key of no byte positions: all values empty): the whole index
+        if (nq <= 0) continue;
         for (int i = 0; i + 1 < nq; i++) h[1 + i] = q_exact[(size_t)i];
         h[nq] = qlo;
         h[nq + 1] = qhi;

@@ -437,7 +437,7 @@ Status probe_run(cph_ctx* ctx, const cph_index* ix, const DevCol* cols, int32_t 
                  uint64_t nprobe, uint64_t probe_base, bool want_pairs, ProbeOut* out, bool positions = false);
 Status index_find_device(cph_ctx* ctx, const cph_index* ix, const uint64_t* q_exact, int32_t nq, uint64_t qlo,
                          uint64_t qhi, uint64_t* lower, uint64_t* upper);
-// nkeys query blocks of `stride` words each ([nq | exact words | qlo | qhi], nq = 0: the key cannot occur): one upload,
+// nkeys query blocks of `stride` words each ([nq | exact words | qlo | qhi], nq = ~0: the key cannot occur, nq = 0: every row matches): one upload,
 // one launch, one download
 Status index_find_many_device(cph_ctx* ctx, const cph_index* ix, const uint64_t* queries, size_t stride, uint64_t nkeys,
                               uint64_t* lower, uint64_t* upper);

@@ -1264,8 +1264,9 @@ __global__ void k_find_many(const void* __restrict__ codes, uint64_t n, const ui
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nkeys) return;
     const uint64_t* q = queries + stride * k;
-    const int nq = (int)q[0];
-    uint64_t lo = 0, hi = nq ? n : 0;
+    const bool absent = q[0] == ~0ull;   // the values cannot occur in the index; nq = 0 with a valid query: every row matches
+    const int nq = absent ? 0 : (int)q[0];
+    uint64_t lo = 0, hi = absent ? 0 : n;
     for (int w = 0; w < nq; w++) {
         const uint64_t vlo = q[1 + w];
         const uint64_t vhi = (w + 1 == nq) ? q[2 + w] : vlo;

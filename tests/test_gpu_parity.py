@@ -482,6 +482,10 @@ def test_small_table_build_path(ctx, both_build_paths):
         "all_empty_values": ([StrCol.from_values([b""] * 100)], True),
         "fixed_width": ([StrCol.from_values([b"%08d" % int(x) for x in rng.permutation(5000)])], True),
         "variable_offsets64": ([StrCol.from_values([b"%d" % int(x) for x in rng.integers(0, 5000, 7000)], offset_bits=64)], True),
+        "full_capacity_16384_dups": ([StrCol.from_values([b"k%d" % int(x) for x in rng.integers(0, 3000, 16384)])], True),
+        "one_below_capacity": ([StrCol.from_values([b"%05d" % int(x) for x in rng.permutation(16383)])], True),
+        "one_above_capacity": ([StrCol.from_values([b"%05d" % int(x) for x in rng.permutation(16385)])], False),
+        "63_bit_codes": ([StrCol.from_values([bytes(rng.integers(97, 123, 13, dtype=np.uint8)) for _ in range(4000)])], True),
         "65_positions": ([StrCol.from_values([bytes([65 + (i % 3)]) * (1 + i % 65) for i in range(300)])], False),
         "two_code_words": ([StrCol.from_values(random_keys(rng, 3000, 14, 14, alphabet=list(range(48, 112))))], False),
         "above_the_row_limit": ([StrCol.from_values([b"%d" % int(x) for x in rng.integers(0, 1000, 20000)])], False),
