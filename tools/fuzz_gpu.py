@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the HIP path against the oracle on random tables (sizes 1..20000, 1-3 key columns, random alphabets
+and lengths, duplicates or not): IndexOn (both build paths), Join (pairs / bounds only), chain (row ids / sorted positions),
+Find / find_many.  usage: tools/fuzz_gpu.py [seconds] [seed]"""
+import sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import numpy as np
+from csvplus_amd import Context, DeviceIndex, StrCol, join_chain
+from oracle import orc
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
+rng = np.random.default_rng(seed)
+ctx = Context(0)
+print("seed", seed, flush=True)
+
+
+def rand_col(n, distinct, alphabet, lo, hi):
+    pool = [bytes(alphabet[rng.integers(0, len(alphabet), int(rng.integers(lo, hi + 1)))]) for _ in range(distinct)]
+    return [pool[int(i)] for i in rng.integers(0, distinct, n)], pool
+
+
+ALPHAS = [np.frombuffer(b"0123456789", np.uint8), np.frombuffer(b"abcxyz", np.uint8), np.arange(256, dtype=np.uint8),
+          np.frombuffer(b"\x00\xffA", np.uint8), np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789", np.uint8)]
+t_end = time.time() + budget
+cases = 0
+while time.time() < t_end:
+    n = int(rng.choice([1, 2, 63, 64, 65, 500, 4096, 8192, 8193, 16384, 16385, 20000])) if rng.random() < 0.5 else int(rng.integers(1, 20000))
+    ncols = int(rng.integers(1, 4))
+    unique_wanted = rng.random() < 0.4
+    build, pools = [], []
+    for c in range(ncols):
+        a = ALPHAS[int(rng.integers(0, len(ALPHAS)))]
+        lo = int(rng.integers(0, 4)); hi = lo + int(rng.integers(0, 12))
+        distinct = n * 4 if (unique_wanted and c == 0) else int(rng.integers(1, max(2, n)))
+        if unique_wanted and c == 0:
+            vals = [b"%d" % int(x) for x in rng.permutation(n * 3)[:n]] if rng.random() < 0.5 else [b"%07d" % int(x) for x in rng.permutation(n)]
+            pool = vals
+        else:
+            vals, pool = rand_col(n, distinct, a, lo, hi)
+        build.append(vals); pools.append(pool)
+    m = int(rng.integers(1, 30000))
+    probe = []
+    for c in range(ncols):
+        pv = [pools[c][int(i)] for i in rng.integers(0, len(pools[c]), m)]
+        for j in rng.integers(0, m, m // 10):
+            pv[int(j)] = pv[int(j)] + b"!" if rng.random() < 0.5 else pv[int(j)][:-1]
+        probe.append(pv)
+    bcols = [StrCol.from_values(v) for v in build]
+    pcols = [StrCol.from_values(v) for v in probe]
+    o = orc.OracleIndex(bcols)
+    for limit in (16384, 0):
+        ctx.set_option("small_build_rows", limit)
+        g = DeviceIndex(ctx, bcols)
+        tag = (seed, cases, n, ncols, m, limit, g.info()["build_path"])
+        assert np.array_equal(g.perm(), o.perm), tag
+        assert g.first_dup == o.first_dup(), tag
+        for k in range(1, ncols + 1):
+            oj = o.join(pcols[:k])
+            mt = g.probe(pcols[:k])
+            assert np.array_equal(mt.cnt, oj["cnt"]) and mt.nmatches == oj["nmatches"], tag
+            assert np.array_equal(mt.probe_idx, oj["probe_idx"]) and np.array_equal(mt.build_row, oj["build_row"]), tag
+            mt.release()
+            mb = g.probe(pcols[:k], want_pairs=False)
+            nz = mb.cnt > 0
+            assert np.array_equal(mb.cnt, oj["cnt"]) and np.array_equal(mb.lo[nz], oj["lo"][nz]), tag
+            mb.release()
+        oj = o.join(pcols)
+        for pos in (False, True):
+            ch = join_chain(ctx, [(g, pcols)], probe_base=7, positions=pos)
+            assert ch.nrows == oj["nmatches"] and np.array_equal(ch.stream_row, oj["probe_idx"] + 7), tag
+            rows = ch.build_row(0)
+            if pos and ch.nrows:
+                rows = g.perm()[rows]
+            assert np.array_equal(rows, oj["build_row"]), (tag, pos)
+            ch.release()
+        keys = [tuple(build[c][int(r)] for c in range(ncols)) for r in rng.integers(0, n, 50)] + [tuple(probe[c][int(r)] for c in range(ncols)) for r in rng.integers(0, m, 50)]
+        lo_, hi_ = g.find_many(keys)
+        for (a_, b_), key in zip(zip(lo_, hi_), keys):
+            ol, oh = o.find(*key)
+            assert int(b_) - int(a_) == oh - ol and (oh == ol or int(a_) == ol), (tag, key)
+        g.close()
+    cases += 1
+ctx.set_option("small_build_rows", 8192)
+print("FUZZ_OK cases", cases, "seed", seed, flush=True)
