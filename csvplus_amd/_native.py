@@ -162,7 +162,7 @@ class cph_gathered(C.Structure):
 class cph_stream_chunk(C.Structure):
     _fields_ = [("probe_base", C.c_uint64), ("nrows", C.c_uint64), ("nmatches", C.c_uint64),
                 ("match_bitmap", C.c_void_p), ("build_row", C.c_void_p * CPH_MAX_CHAIN), ("nsteps", C.c_int32),
-                ("dense", C.c_int32), ("stream_row", C.c_void_p)]
+                ("dense", C.c_int32), ("stream_row", C.c_void_p), ("positions", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class cph_kernel_stat(C.Structure):
@@ -218,6 +218,7 @@ PROTOTYPES = [
     ("cph_chain_release", None, [C.POINTER(cph_chain)]),
     ("cph_stream_join_create", C.c_int32, [_P, C.POINTER(_P), C.c_int32, C.c_int32, C.POINTER(_P)]),
     ("cph_stream_join_create_general", C.c_int32, [_P, C.POINTER(_P), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(_P)]),
+    ("cph_stream_join_set_positions", C.c_int32, [_P, C.c_int32]),
     ("cph_stream_join_destroy", None, [_P]),
     ("cph_stream_join_submit", C.c_int32, [_P, C.POINTER(cph_strcol), C.c_uint64]),
     ("cph_stream_join_pending", C.c_int32, [_P]),

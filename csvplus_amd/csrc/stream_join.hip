@@ -61,6 +61,7 @@ struct cph_stream_join {
     // slots (with a slot's upload, kernels and download on ONE stream per slot, odd slot counts ran 25 % slower)
     hipStream_t up = nullptr, down = nullptr;
     bool general = false;
+    bool positions = false;                // build_row[k] = sorted position in index k (cph_stream_join_set_positions)
     int ncols[CPH_MAX_CHAIN] = {1, 1, 1, 1};
     int total_cols = 0;
     std::vector<Slot*> slots;
@@ -131,7 +132,7 @@ static Status general_chunk(cph_stream_join* sj, cph_stream_join::Slot& sl) {
         for (int c = 0; c < sj->ncols[k]; c++, ci++) CPH_TRY(stage_chunk_col(ctx, sl.job_cols[(size_t)ci], n, &staged, &cs[k].cols[c]));
     }
     ChainOut co;
-    CPH_TRY(chain_run(ctx, cs, sj->nsteps, sl.probe_base, &co));
+    CPH_TRY(chain_run(ctx, cs, sj->nsteps, sl.probe_base, &co, sj->positions));
     const uint64_t m = co.nrows;
     auto a64 = [](size_t x) { return (x + 63) & ~(size_t)63; };
     const size_t b64 = a64(m * sizeof(uint64_t)), b32 = a64(m * sizeof(uint32_t));
@@ -264,6 +265,24 @@ CPH_API int32_t cph_stream_join_create_general(cph_ctx* ctx, const cph_index* co
     return stream_join_create(ctx, indexes, ncols, nsteps, nslots, true, out);
 }
 
+CPH_API int32_t cph_stream_join_set_positions(cph_stream_join* sj, int32_t on) {
+    if (!sj) return CPH_ERR_INVALID;
+    cph_ctx* ctx = sj->parent;
+    if (!sj->fifo.empty() || sj->submit_seq != 0) return sj_fail(ctx, CPH_ERR_INVALID, "cph_stream_join_set_positions: call before the first submit");
+    if (hipSetDevice(ctx->device) != hipSuccess) return sj_fail(ctx, CPH_ERR_HIP, "hipSetDevice failed");
+    if (on && !sj->general) {   // the fused kernel then looks positions up in the rank tables: build them now, once
+        for (int s = 0; s < sj->nsteps; s++) {
+            Status st = index_ensure_ranktab(ctx, sj->index[s]);
+            if (!st.ok()) return sj_fail(ctx, st.code, st.msg);
+        }
+        (void)hipStreamSynchronize(ctx->stream);
+        for (int s = 0; s < sj->nsteps; s++)
+            if (sj->index[s]->ctx) (void)hipStreamSynchronize(sj->index[s]->ctx->stream);
+    }
+    sj->positions = on != 0;
+    return CPH_OK;
+}
+
 CPH_API void cph_stream_join_destroy(cph_stream_join* sj) {
     if (!sj) return;
     if (sj->parent) (void)hipSetDevice(sj->parent->device);
@@ -376,7 +395,7 @@ CPH_API int32_t cph_stream_join_submit(cph_stream_join* sj, const cph_strcol* st
         CPH_TRY(sl.d_counts.alloc(&ctx->pool, cw * sizeof(uint32_t)));
         CPH_TRY(sl.d_total.alloc(&ctx->pool, sizeof(uint64_t)));
         CPH_TRY(chain_enqueue_dense(ctx, steps, sj->nsteps, n, probe_base, rows, sl.d_masks.as<uint64_t>(),
-                                    sl.d_counts.as<uint32_t>(), sl.d_total.as<uint64_t>()));
+                                    sl.d_counts.as<uint32_t>(), sl.d_total.as<uint64_t>(), sj->positions));
         hipStream_t ds = ctx->stream;
         if (sj->down) {   // the downloads queue up behind one another on their own stream, each behind its chunk's kernels
             CPH_HIP_TRY(hipEventRecord(sl.computed, ctx->stream));
@@ -434,6 +453,7 @@ CPH_API int32_t cph_stream_join_next(cph_stream_join* sj, cph_stream_chunk* out)
         out->match_bitmap = nullptr;
         out->nsteps = sj->nsteps;
         out->dense = 0;
+        out->positions = sj->positions ? 1 : 0;
         out->stream_row = sl.r_stream;
         for (int s = 0; s < sj->nsteps; s++) out->build_row[s] = sl.h_rows[s];
         return CPH_OK;
@@ -448,6 +468,7 @@ CPH_API int32_t cph_stream_join_next(cph_stream_join* sj, cph_stream_chunk* out)
     out->match_bitmap = sl.h_masks;
     out->nsteps = sj->nsteps;
     out->dense = 1;
+    out->positions = sj->positions ? 1 : 0;
     out->stream_row = nullptr;
     for (int s = 0; s < sj->nsteps; s++) out->build_row[s] = sl.h_rows[s];
     return CPH_OK;

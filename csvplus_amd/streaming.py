@@ -39,7 +39,7 @@ class PinnedCol:
 
 
 class StreamJoin:
-    def __init__(self, ctx: N.Context, indexes, nslots: int = 3, ncols=None):
+    def __init__(self, ctx: N.Context, indexes, nslots: int = 3, ncols=None, positions: bool = False):
         """ncols=None: the fused-kernel pipeline (cph_stream_join_create: distinct keys, one key column per index).
         ncols=[columns of the stream per step]: any chain (cph_stream_join_create_general), results as pair lists
         unless the chain qualifies for the fused kernel."""
@@ -55,6 +55,9 @@ class StreamJoin:
             nc = (C.c_int32 * len(ncols))(*[int(x) for x in ncols])
             ctx._check(self.lib.cph_stream_join_create_general(ctx.handle, arr, nc, len(self.indexes), nslots, C.byref(h)))
         self.handle = h
+        if positions:
+            ctx._check(self.lib.cph_stream_join_set_positions(h, 1))
+        self.positions = positions
         self.nslots = nslots
         self._keep = []
         ctx._children.add(self)

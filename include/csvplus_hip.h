@@ -395,12 +395,17 @@ typedef struct {
     int32_t         nsteps;
     int32_t         dense;          /* 1: bitmap + one build row per chunk row; 0: pair lists of nmatches rows */
     const uint64_t* stream_row;     /* dense = 0: probe_base + chunk row of every joined row (NULL: identity)  */
+    int32_t         positions;      /* 1: build_row[k] holds sorted positions in index k (cph_stream_join_set_positions) */
+    int32_t         reserved_;
 } cph_stream_chunk;
 
 CPH_API int32_t cph_stream_join_create(cph_ctx* ctx, const cph_index* const* indexes, int32_t nsteps, int32_t nslots,
                                        cph_stream_join** out);
 CPH_API int32_t cph_stream_join_create_general(cph_ctx* ctx, const cph_index* const* indexes, const int32_t* ncols,
                                                int32_t nsteps, int32_t nslots, cph_stream_join** out);
+/* on != 0: every later chunk reports SORTED POSITIONS in build_row[k] instead of original row ids (CPH_CHAIN_POSITIONS,
+ * see cph_join_chain_ex).  Call before the first submit. */
+CPH_API int32_t cph_stream_join_set_positions(cph_stream_join* sj, int32_t on);
 CPH_API void    cph_stream_join_destroy(cph_stream_join* sj);
 /* step_cols[k] = the chunk's key column for step k: HOST memory (pinned — cph_pinned_alloc —
  * for real overlap), borrowed until the chunk has been returned by cph_stream_join_next.

@@ -175,3 +175,37 @@ def test_stream_join_general_chains(ctx, shape):
     sj2.submit([s1[0].slice(0, 1000)] if shape != "two_column_key_and_prefix" else [s0[1].slice(0, 1000)])
     assert sj2.next()["dense"]
     sj2.close()
+
+
+@pytest.mark.parametrize("general", [False, True])
+def test_stream_join_reports_positions(ctx, general):
+    """cph_stream_join_set_positions: chunks carry sorted positions; perm[position] is the row the default mode reports."""
+    rng = np.random.default_rng(12)
+    cust = dg.customers(30_000)["id"]
+    prod = StrCol.from_values([b"p%d" % int(x) for x in (rng.integers(0, 200, 900) if general else rng.permutation(900))])
+    gix = [DeviceIndex(ctx, [cust], unique=True), DeviceIndex(ctx, [prod], unique=not general)]
+    o = dg.orders(200_000, 40_000, 10)
+    s1 = StrCol.from_values([b"p%d" % int(x) for x in rng.integers(0, 1000, 200_000)])
+    kw = dict(ncols=[1, 1]) if general else {}
+    out = {}
+    for pos in (False, True):
+        sj = StreamJoin(ctx, gix, nslots=2, positions=pos, **kw)
+        res = []
+        for b in (0, 70_000, 140_000):
+            sj.submit([o["cust_id"].slice(b, b + 70_000 if b < 140_000 else 200_000), s1.slice(b, b + 70_000 if b < 140_000 else 200_000)], probe_base=b)
+            res.append(sj.next())
+        out[pos] = res
+        sj.close()
+    perms = [g.perm() for g in gix]
+    for a, b in zip(out[False], out[True]):
+        assert a["nmatches"] == b["nmatches"] and a["dense"] == b["dense"] == (not general)
+        if general:
+            np.testing.assert_array_equal(a["stream_row"], b["stream_row"])
+            for k in range(2):
+                np.testing.assert_array_equal(perms[k][b["build_row"][k]], a["build_row"][k])
+        else:
+            np.testing.assert_array_equal(a["bitmap"], b["bitmap"])
+            hit = bitmap_to_rows(a["bitmap"], a["nrows"])
+            for k in range(2):
+                np.testing.assert_array_equal(perms[k][b["build_row"][k][hit]], a["build_row"][k][hit])
+    assert sum(r["nmatches"] for r in out[True]) > 0
