@@ -52,6 +52,9 @@ def parse_args():
     ap.add_argument("--no-index-1e8", action="store_true", help="skip the extra IndexOn-at-full-size measurements")
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
     ap.add_argument("--no-verify", action="store_true", help="skip the full-size checks of the timed outputs")
+    ap.add_argument("--positions", action="store_true",
+                    help="the timed step itself reports sorted positions (cph_join_chain_ex CPH_CHAIN_POSITIONS) instead of original "
+                         "row ids; the default keeps row ids as `value` and measures positions beside it (join_positions)")
     ap.add_argument("--no-positions", action="store_true",
                     help="skip the second measurement of the step with the Join reporting sorted positions instead of row ids")
     ap.add_argument("--no-e2e", action="store_true", help="skip the pinned-host -> pinned-host scope (cph_stream_join_*)")
@@ -255,7 +258,7 @@ def main():
         # no torch views of the result — it needs the row count only.  stream_row is NULL when every order joined
         # (the result row IS the stream row): then only the two build-row arrays exist, and only they are exchanged.
         ch = N.join_chain(eng.ctx, [(ia, [d_ord["cust_id"]]), (ib, [d_ord["prod_id"]])], probe_base=begin,
-                          out_mem=N.CPH_MEM_DEVICE)
+                          out_mem=N.CPH_MEM_DEVICE, positions=args.positions)
         if cdist is not None:          # one count exchange + one grouped batch for all arrays (cph_dist_chain_allgather)
             g = cdist.chain_allgather(ch)
             n = g.total
@@ -435,7 +438,8 @@ def main():
                    "rows": args.rows, "customers": args.customers, "products": args.products,
                    "rows_this_rank": nloc, "exchange": args.exchange if world > 1 else "none (1 GPU)",
                    "exchange_transport": transport, "rccl_nranks": rccl_nranks,
-                   "inputs": "resident in HBM before the timed region"},
+                   "inputs": "resident in HBM before the timed region",
+                   "build_row_mode": "sorted positions (--positions)" if args.positions else "original row ids"},
         "joined_rows_per_step": total_joined,
         "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
         "index_build": {"GBps_algorithmic": round(build_gb / (build_ms / 1e3), 1) if build_ms else None,
