@@ -26,6 +26,26 @@ def _ensure_built():
 _ensure_built()
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _gpu_box_ready(request):
+    """GPU runs only: before the first test (some start with a SUBPROCESS: bench.py), wait until the device answers in this
+    process — a box that has just been handed out may need a moment before its first HIP call succeeds."""
+    if not any(item.get_closest_marker("gpu") for item in request.session.items):
+        return
+    import time
+
+    import torch
+
+    for _ in range(60):
+        try:
+            if torch.cuda.is_available() and torch.cuda.device_count() > 0:
+                torch.zeros(1, device="cuda").item()
+                break
+        except Exception:   # noqa: BLE001 — keep waiting
+            pass
+        time.sleep(1)
+
+
 @pytest.fixture(scope="session")
 def ctx():
     """One cph_ctx on GPU 0 (gpu tests only)."""

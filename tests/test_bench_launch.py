@@ -75,8 +75,11 @@ SMALL = ["--rows", "300000", "--customers", "20000", "--products", "700", "--ste
 
 @pytest.mark.gpu
 def test_one_gpu_line_has_the_contract_fields():
-    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", *SMALL, "--verify-sample", "5000"], env=_env(), capture_output=True,
-                       text=True, timeout=900)
+    cmd = [sys.executable, BENCH, "--gpus", "1", *SMALL, "--verify-sample", "5000"]
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
+    if r.returncode != 0:   # the first GPU process on a box that has just been handed out: say what happened, try once more
+        print("first attempt failed:", r.returncode, r.stderr[-3000:], file=sys.stderr)
+        r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _json_line(r.stdout)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
