@@ -677,6 +677,12 @@ def main():
                                              "GBps": round(bts / 1e9 / (ms / 1e3), 1),
                                              "frac": round(bts / 1e9 / (ms / 1e3) / HBM_PEAK_GBPS, 4),
                                              "index_ms": r["ms"], "step_ms": round(ms_per_step, 3)}
+                if out.get("join_positions"):   # the same sum with the step that reports sorted positions (same byte model)
+                    msp = r["ms"] + out["join_positions"]["ms_per_step"]
+                    comb[name + "_plus_positions_step"] = {"ms": round(msp, 3), "algorithmic_bytes": bts,
+                                                           "GBps": round(bts / 1e9 / (msp / 1e3), 1),
+                                                           "frac": round(bts / 1e9 / (msp / 1e3) / HBM_PEAK_GBPS, 4),
+                                                           "index_ms": r["ms"], "step_ms": out["join_positions"]["ms_per_step"]}
             comb["note"] = ("IndexOn over 1e8 rows (index_on_1e8.*: wall ms, pass-model bytes) + one bench step (2 index builds + "
                             "chained Join of 1e8 rows: ms_per_step, roofline.step_algorithmic_bytes), summed; frac = bytes / ms / 8 TB/s")
             out["index_plus_join_1e8"] = comb
