@@ -40,15 +40,79 @@ __global__ void k_first_dup(const void* __restrict__ codes, uint64_t n, int nwor
     if (lane_id() == 0 && best != 0xFFFFFFFFu) atomicMin(result, best);
 }
 
+// One-word codes, vectorised: a thread owns V consecutive codes (one 16-byte load), compares them with each other and its
+// first one with the last code of the lane below (shuffle; lane 0 loads that one code itself) — one load instruction per
+// 16 bytes instead of two per code.
+template <class K>
+__global__ __launch_bounds__(256) void k_first_dup_vec(const K* __restrict__ codes, uint64_t n, uint32_t* __restrict__ result) {
+    constexpr int V = 16 / (int)sizeof(K);
+    typedef K vec_t __attribute__((ext_vector_type(V)));
+    const uint64_t nvec = n / V;   // whole vectors; the tail (< V codes) is checked by thread 0 of block 0
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t rounds = (nvec + stride - 1) / stride;
+    uint32_t best = 0xFFFFFFFFu;
+    constexpr int U = 4;   // vectors in flight per thread
+    for (uint64_t r0 = 0; r0 < rounds; r0 += U) {
+        uint4 raw[U];
+        K prev0[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t v = (r0 + u) * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+            const bool valid = v < nvec;
+            raw[u] = valid ? reinterpret_cast<const uint4*>(codes)[v] : make_uint4(0, 0, 0, 0);   // one 16-byte load
+            prev0[u] = valid && lane_id() == 0 && v > 0 ? codes[v * V - 1] : (K)0;             // lane 0: the code in front of its vector
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t v = (r0 + u) * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+            const bool valid = v < nvec;
+            vec_t x;
+            if constexpr (sizeof(K) == 4) {
+                x[0] = raw[u].x; x[1] = raw[u].y; x[2] = raw[u].z; x[3] = raw[u].w;
+            } else {
+                x[0] = (K)raw[u].x | ((K)raw[u].y << 32);
+                x[1] = (K)raw[u].z | ((K)raw[u].w << 32);
+            }
+            K prev = __shfl_up(x[V - 1], 1, kWave);
+            if (lane_id() == 0) prev = prev0[u];
+            if (valid) {
+                if (v > 0 && prev == x[0] && (uint32_t)(v * V) < best) best = (uint32_t)(v * V);
+#pragma unroll
+                for (int k = 1; k < V; k++)
+                    if (x[k] == x[k - 1] && (uint32_t)(v * V + k) < best) best = (uint32_t)(v * V + k);
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (uint64_t i = nvec * V > 0 ? nvec * V : 1; i < n; i++)
+            if (codes[i] == codes[i - 1] && (uint32_t)i < best) best = (uint32_t)i;
+    best = wave_min(best);
+    if (lane_id() == 0 && best != 0xFFFFFFFFu) atomicMin(result, best);
+}
+
 // Launches the adjacent-equal scan; the result stays on the device (ix->first_dup_dev) until it is read back.
 Status index_first_dup_launch(cph_ctx* ctx, cph_index* ix) {
     const uint64_t n = ix->nrows;
     CPH_TRY(ix->first_dup_dev.alloc(&ctx->pool, sizeof(uint32_t)));
     CPH_HIP_TRY(hipMemsetAsync(ix->first_dup_dev.get(), 0xFF, sizeof(uint32_t), ctx->stream));
     if (n < 2) return {};
+    uint32_t* d = ix->first_dup_dev.as<uint32_t>();
+    // 32-bit codes only: with 64-bit codes (two per 16-byte load) the vectorised scan measured slower (0.41 vs 0.29 ms per 1e8)
+    if (ix->codec.key32 && ((uintptr_t)ix->sorted_codes.get() & 15) == 0) {
+        ProfScope ps(ctx, "k_first_dup", (double)n * (ix->codec.key32 ? 4.0 : 8.0));
+        const uint64_t nvec = n / (ix->codec.key32 ? 4 : 2);
+        uint64_t nblk = (nvec + 255) / 256;
+        if (nblk > 8192) nblk = 8192;
+        if (nblk < 1) nblk = 1;
+        if (ix->codec.key32)
+            hipLaunchKernelGGL(k_first_dup_vec<uint32_t>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, ix->sorted_codes.as<uint32_t>(), n, d);
+        else
+            hipLaunchKernelGGL(k_first_dup_vec<uint64_t>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, ix->sorted_codes.as<uint64_t>(), n, d);
+        CPH_HIP_TRY(hipGetLastError());
+        return {};
+    }
     uint64_t nblk = (n + 255) / 256;
     if (nblk > 4096) nblk = 4096;
-    uint32_t* d = ix->first_dup_dev.as<uint32_t>();
     {
         ProfScope ps(ctx, "k_first_dup", (double)n * (ix->codec.key32 ? 4.0 : 8.0 * ix->total_words()));
         if (ix->codec.key32)
