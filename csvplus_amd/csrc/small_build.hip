@@ -118,10 +118,13 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_build(const SmallArg a)
     if (tid < kMaxKeyCols) { s_min[tid] = 0xFFFFFFFFu; s_max[tid] = 0; }
     if (tid == 0) { s_status = kSmallBuilt; s_dup = 0xFFFFFFFFu; }
     __syncthreads();
-    for (uint32_t r0 = (uint32_t)tid; r0 < n; r0 += kSmallThreads * kSmallRows) {
+    // EVERY thread walks the same number of batches (rows past the end repeat the last row: harmless for statistics), so
+    // that the wave reductions below see defined values in all 64 lanes
+    for (uint32_t base = 0; base < n; base += kSmallThreads * kSmallRows) {
+        const uint32_t r0 = base + (uint32_t)tid;
         uint32_t row[kSmallRows];
 #pragma unroll
-        for (int k = 0; k < kSmallRows; k++) {   // rows past the end repeat the last row: harmless for statistics
+        for (int k = 0; k < kSmallRows; k++) {
             const uint32_t r = r0 + (uint32_t)k * kSmallThreads;
             row[k] = r < n ? r : n - 1;
         }
