@@ -52,11 +52,14 @@ def parse_args():
     ap.add_argument("--no-index-1e8", action="store_true", help="skip the extra IndexOn-at-full-size measurements")
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
     ap.add_argument("--no-verify", action="store_true", help="skip the full-size checks of the timed outputs")
-    ap.add_argument("--positions", action="store_true",
-                    help="the timed step itself reports sorted positions (cph_join_chain_ex CPH_CHAIN_POSITIONS) instead of original "
-                         "row ids; the default keeps row ids as `value` and measures positions beside it (join_positions)")
+    ap.add_argument("--row-ids", action="store_true",
+                    help="the timed step reports ORIGINAL ROW IDS (cph_join_chain, the rounds 1-2 mode) instead of sorted positions; "
+                         "by default the step reports sorted positions — the reference's own row handle, what its Join reads "
+                         "(index.impl.rows[first()+i], csvplus.go:553-567) and what the cgo shim / the C++ facade consume — and the "
+                         "row-id mode is measured beside it (join_row_ids)")
+    ap.add_argument("--positions", action="store_true", help="(the default since round 3; accepted for old command lines)")
     ap.add_argument("--no-positions", action="store_true",
-                    help="skip the second measurement of the step with the Join reporting sorted positions instead of row ids")
+                    help="skip the second measurement of the step in the OTHER output mode (row ids by default)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the pinned-host -> pinned-host scope (cph_stream_join_*)")
     ap.add_argument("--verify-sample", type=int, default=100_000)
     ap.add_argument("--no-traffic", action="store_true",
@@ -146,7 +149,7 @@ def measure_traffic(kernel_prefix, args):
         cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
                sys.executable, str(ROOT / "bench.py"), "--steps", "2", "--warmup", "1", "--rows", str(args.rows),
                "--customers", str(args.customers), "--products", str(args.products), "--no-cpu-baseline",
-               "--no-index-1e8", "--no-verify", "--no-e2e", "--no-traffic", "--no-positions"]
+               "--no-index-1e8", "--no-verify", "--no-e2e", "--no-traffic", "--no-positions"] + (["--row-ids"] if args.row_ids else [])
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300,
                            check=True)
@@ -249,6 +252,7 @@ def main():
     gen_s = time.time() - t0
     nloc = end - begin
 
+    POS = not args.row_ids          # the timed step's output mode: sorted positions (default) or original row ids
     step_info = {}
 
     def step():
@@ -258,7 +262,7 @@ def main():
         # no torch views of the result — it needs the row count only.  stream_row is NULL when every order joined
         # (the result row IS the stream row): then only the two build-row arrays exist, and only they are exchanged.
         ch = N.join_chain(eng.ctx, [(ia, [d_ord["cust_id"]]), (ib, [d_ord["prod_id"]])], probe_base=begin,
-                          out_mem=N.CPH_MEM_DEVICE, positions=args.positions)
+                          out_mem=N.CPH_MEM_DEVICE, positions=POS)
         if cdist is not None:          # one count exchange + one grouped batch for all arrays (cph_dist_chain_allgather)
             g = cdist.chain_allgather(ch)
             n = g.total
@@ -351,8 +355,9 @@ def main():
     }
     # compulsory bytes (SURVEY.md §8d "useful"): every input read once, each table read once (not one entry per
     # probe), every output written once
-    useful = {"k_chain_dense": K * (host_bytes["cust_id"] + host_bytes["prod_id"] + off_o
-                                    + 4 * (ia_info["table_entries"] + ib_info["table_entries"]) + 8 * total_joined_local)}
+    # (tables: 4 bytes per code for row ids, presence bits + counts = 8 bytes per 32 codes for positions)
+    table_bytes = (ia_info["table_entries"] + ib_info["table_entries"]) * (0.25 if POS else 4)
+    useful = {"k_chain_dense": K * (host_bytes["cust_id"] + host_bytes["prod_id"] + off_o + table_bytes + 8 * total_joined_local)}
     kernels = {}
     for name, st in prof.items():
         b = st["algo_bytes"] + extra.get(name, 0.0)
@@ -395,14 +400,16 @@ def main():
             g_ms = eng.ctx.calibrate("gather", tb, nloc, 5)
             c_bytes = 1 << 30
             c_ms = eng.ctx.calibrate("copy", c_bytes, 0, 5)
-            roofline["gather_ceiling_ms"] = round(g_ms, 4)
-            roofline["gather_ceiling"] = {"table_bytes": tb, "lookups": nloc, "ms": round(g_ms, 4),
-                                          "Glookups_per_s": round(nloc / g_ms / 1e6, 1),
-                                          "kernel_over_ceiling": round(dom[1]["avg_ms"] / g_ms, 3),
-                                          "what": "plain 4-byte gather, same number of lookups, table of the customers row table's size, "
-                                                  "measured in this run (cph_calibrate): the floor of the customers step of k_chain_dense"}
+            calib = {"table_bytes": tb, "lookups": nloc, "ms": round(g_ms, 4), "Glookups_per_s": round(nloc / g_ms / 1e6, 1),
+                     "what": "plain 4-byte gather, same number of lookups, table of the customers ROW table's size, measured in this "
+                             "run (cph_calibrate): the floor of the customers step of k_chain_dense when it reports original row ids"}
+            if not POS:
+                calib["kernel_over_ceiling"] = round(dom[1]["avg_ms"] / g_ms, 3)
+                roofline["gather_ceiling_ms"] = round(g_ms, 4)
+            roofline["gather_ceiling"] = calib
             roofline["copy_TBps"] = round(2 * c_bytes / (c_ms / 1e3) / 1e12, 3)
             roofline["copy_note"] = "streaming copy of 1 GiB, read + written bytes per second, measured in this run"
+        roofline["output_mode"] = "sorted positions" if POS else "original row ids"
     # HBM-side traffic of the dominant kernel: PMC counters cannot be collected inside this process, so
     # two child runs of this script under `rocprofv3 --pmc` (one counter each) measure them NOW, on this box.
     # gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE tallies a 128-byte request of a wide coalesced
@@ -439,7 +446,8 @@ def main():
                    "rows_this_rank": nloc, "exchange": args.exchange if world > 1 else "none (1 GPU)",
                    "exchange_transport": transport, "rccl_nranks": rccl_nranks,
                    "inputs": "resident in HBM before the timed region",
-                   "build_row_mode": "sorted positions (--positions)" if args.positions else "original row ids"},
+                   "build_row_mode": ("sorted positions in each index (cph_join_chain_ex CPH_CHAIN_POSITIONS; the reference's row handle: "
+                                      "csvplus.go:553-567 reads index.impl.rows[first()+i])" if POS else "original row ids (--row-ids)")},
         "joined_rows_per_step": total_joined,
         "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
         "index_build": {"GBps_algorithmic": round(build_gb / (build_ms / 1e3), 1) if build_ms else None,
@@ -460,26 +468,34 @@ def main():
 
         t0 = time.perf_counter()
         ia, ib = eng.index_on_many([[d_cust], [d_prod]], unique=True)
-        res = eng.chained_join([(ia, d_ord["cust_id"]), (ib, d_ord["prod_id"])], probe_base=begin)
+        from csvplus_amd.engine import device_view
+        res = eng.chained_join([(ia, d_ord["cust_id"]), (ib, d_ord["prod_id"])], probe_base=begin, positions=POS)
         all_joined = res.n == nloc and res.stream_row is None
-        ver = {"joined_rows": res.n, "every_stream_row_joined_once": all_joined}
+        ver = {"joined_rows": res.n, "every_stream_row_joined_once": all_joined, "output_mode": "sorted positions" if POS else "original row ids"}
+        # what was timed reports sorted positions: the row a position names is perm[position] (cph_index_perm) — the checks
+        # below (key equality at the emitted row, digests, the oracle prefix) run on those rows
+        brows = list(res.build_rows)
+        if POS and res.n:
+            for k, ix in enumerate((ia, ib)):
+                pk = device_view(ix.perm_device_ptr(), ix.nrows, "<i4", ix, dev)
+                ver[f"digest_positions_{k}"] = f"{V.digest_u64(res.build_rows[k]):016x}"
+                brows[k] = pk[res.build_rows[k].long()]
         if all_joined:
             rows = V.sample_rows(nloc, args.verify_sample)
             idx = torch.from_numpy(rows).to(dev)
-            b0 = res.build_rows[0][idx].cpu().numpy()
-            b1 = res.build_rows[1][idx].cpu().numpy()
+            b0 = brows[0][idx].cpu().numpy()
+            b1 = brows[1][idx].cpu().numpy()
             ver["sample_rows"] = int(rows.size)
             # csvplus.go:553-567: the emitted build row is the one whose key equals the stream row's key
             ver["cust_key_mismatches"] = V.check_join_sample(ords["cust_id"], cust_id, b0, rows)
             ver["prod_key_mismatches"] = V.check_join_sample(ords["prod_id"], prod_id, b1, rows)
-            ver["digest_cust_rows"] = f"{V.digest_u64(res.build_rows[0]):016x}"
-            ver["digest_prod_rows"] = f"{V.digest_u64(res.build_rows[1]):016x}"
+            ver["digest_cust_rows"] = f"{V.digest_u64(brows[0]):016x}"
+            ver["digest_prod_rows"] = f"{V.digest_u64(brows[1]):016x}"
             ns = min(args.cpu_sample_rows, nloc)
-            gpu_prefix = (res.build_rows[0][:ns].cpu().numpy().view(np.uint32).copy(),
-                          res.build_rows[1][:ns].cpu().numpy().view(np.uint32).copy())
+            gpu_prefix = (brows[0][:ns].cpu().numpy().view(np.uint32).copy(),
+                          brows[1][:ns].cpu().numpy().view(np.uint32).copy())
         # the two indexes of the step: perm is a permutation, keys ascend through it, ties keep input order
         for name, ix, col in (("customers", ia, d_cust), ("products", ib, d_prod)):
-            from csvplus_amd.engine import device_view
             perm = device_view(ix.perm_device_ptr(), ix.nrows, "<i4", ix, dev)
             ver[f"index_{name}"] = V.check_index_order(col, perm)
         ok = all_joined and ver.get("cust_key_mismatches") == 0 and ver.get("prod_key_mismatches") == 0 \
@@ -489,57 +505,64 @@ def main():
         out["verified"] = bool(ok)
         out["verify"] = ver
 
-    # ---- the same step reporting SORTED POSITIONS (cph_join_chain_ex CPH_CHAIN_POSITIONS) -------------------------
+    # ---- the same step in the OTHER output mode ------------------------------------------------------------------
     # The reference's Join reads index.impl.rows[first() + i]: rows of an Index are kept in sorted order (csvplus.go:736,
-    # :553-567), so the position in the sorted index IS its row handle; the original row id is one more indirection
-    # (perm[position]) that only this ABI's default mode offers.  Reporting positions lets a duplicate-free index over a
-    # dense code space answer from presence bits + a running count per 64 codes (2.5 MB for the 1e7 customers: L2
-    # resident) instead of the 40 MB row table (one Infinity-Fabric sector per probe row).  Measured like the main
-    # step (same builds, same inputs, K steps between synchronisations), reported BESIDE `value`, never as it; the
-    # result is checked at full size against the row-id mode: perm[position] == build row for all rows of both steps.
+    # :553-567), so the position in the sorted index IS its row handle — it is what the cgo shim and the
+    # C++ facade consume; the original row id is one more indirection (perm[position]) that this ABI ALSO offers
+    # (cph_join_chain).  Positions let a duplicate-free index over a dense code space answer from presence bits + a running
+    # count per 32 codes (2.5 MB for the 1e7 customers: L2 resident) instead of the 40 MB row table (one Infinity-Fabric
+    # sector per probe row).  The timed step reports positions (row ids with --row-ids); the other mode is measured here the
+    # same way (same builds, same inputs, K steps between synchronisations) and reported beside `value`.  The two results are
+    # compared at full size: perm[position] == row id for all rows of both steps.
     if world == 1 and not args.no_positions:
-        def step_pos():
+        OTHER = not POS                   # the other mode reports positions?
+        other_name = "join_positions" if OTHER else "join_row_ids"
+
+        def step_other():
             ia, ib = eng.index_on_many([[d_cust], [d_prod]], unique=True)
             ch = N.join_chain(eng.ctx, [(ia, [d_ord["cust_id"]]), (ib, [d_ord["prod_id"]])], probe_base=begin,
-                              out_mem=N.CPH_MEM_DEVICE, positions=True)
+                              out_mem=N.CPH_MEM_DEVICE, positions=OTHER)
             n = ch.nrows
             ch.release(); ia.close(); ib.close()
             return n
 
         for _ in range(max(1, args.warmup)):
-            step_pos()
+            step_other()
         eng.ctx.profile_only("k_chain_dense")
         eng.ctx.profile_read(reset=True)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            jp = step_pos()
+            jp = step_other()
         torch.cuda.synchronize(dev)
         dtp = time.perf_counter() - t0
         pp = eng.ctx.profile_read(reset=True)
         eng.ctx.profile(True)
-        step_pos()
+        step_other()
         pb = eng.ctx.profile_read(reset=True)
         eng.ctx.profile(False)
-        ms_pos = dtp / args.steps * 1e3
+        ms_o = dtp / args.steps * 1e3
         kd = pp.get("k_chain_dense", {"launches": 0, "total_ms": 0.0})
         kd_ms = kd["total_ms"] / max(1, kd["launches"])
-        # the job's algorithmic bytes are those of the row-id step (same inputs, same outputs, one table entry per row and
-        # step): the fraction below prices this kernel's time against THAT model, so the two modes compare directly
-        algo_pos = roofline.get("algorithmic_bytes_per_launch") if roofline else None
-        blk = {"ms_per_step": round(ms_pos, 4), "value": jp / (dtp / args.steps), "unit": "rows/s", "joined_rows_per_step": jp,
-               "speedup_vs_row_ids": round(ms_per_step / ms_pos, 3),
+        # one byte model for both modes (same inputs, same outputs, one 4-byte table entry per row and step), so that the
+        # two fractions compare directly
+        algo_o = roofline.get("algorithmic_bytes_per_launch") if roofline else None
+        blk = {"mode": "sorted positions" if OTHER else "original row ids",
+               "ms_per_step": round(ms_o, 4), "value": jp / (dtp / args.steps), "unit": "rows/s", "joined_rows_per_step": jp,
+               "timed_step_over_this": round(ms_per_step / ms_o, 3),
                "k_chain_dense_ms": round(kd_ms, 4),
                "kernels_ms": {k: round(v["total_ms"], 4) for k, v in pb.items()},
-               "what": "same step (2 index builds + chained Join of the same rows), build_row[k] = sorted position in index k "
-                       "(the reference's own row handle) instead of the original row id; reported beside `value`, not as it"}
-        if algo_pos and kd_ms:
-            blk["roofline"] = {"kernel": "k_chain_dense (positions)", "algorithmic_bytes_per_launch": int(algo_pos),
-                               "bytes_model": "the row-id step's (roofline.algorithmic_bytes_per_launch)",
-                               "achieved": round(algo_pos / 1e9 / (kd_ms / 1e3), 1), "unit": "GB/s", "peak": HBM_PEAK_GBPS,
-                               "frac": round(algo_pos / 1e9 / (kd_ms / 1e3) / HBM_PEAK_GBPS, 4)}
+               "what": "the same step (2 index builds + chained Join of the same rows) in the other output mode; reported beside "
+                       "`value`, not as it"}
+        if algo_o and kd_ms:
+            blk["roofline"] = {"kernel": "k_chain_dense (%s)" % ("positions" if OTHER else "row ids"),
+                               "algorithmic_bytes_per_launch": int(algo_o), "bytes_model": "roofline.algorithmic_bytes_per_launch",
+                               "achieved": round(algo_o / 1e9 / (kd_ms / 1e3), 1), "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+                               "frac": round(algo_o / 1e9 / (kd_ms / 1e3) / HBM_PEAK_GBPS, 4)}
             if roofline.get("step_algorithmic_bytes"):
-                blk["roofline"]["step_frac"] = round(roofline["step_algorithmic_bytes"] / 1e9 / (ms_pos / 1e3) / HBM_PEAK_GBPS, 4)
+                blk["roofline"]["step_frac"] = round(roofline["step_algorithmic_bytes"] / 1e9 / (ms_o / 1e3) / HBM_PEAK_GBPS, 4)
+            if not OTHER and (roofline.get("gather_ceiling") or {}).get("ms"):   # the row-id kernel against this box's gather floor
+                blk["roofline"]["kernel_over_gather_ceiling"] = round(kd_ms / roofline["gather_ceiling"]["ms"], 3)
         if not args.no_verify:
             from csvplus_amd.engine import device_view
             ia, ib = eng.index_on_many([[d_cust], [d_prod]], unique=True)
@@ -553,14 +576,15 @@ def main():
             blk["verify"] = {"rows": r_pos.n, "perm_of_position_differs_from_row_id": bad, "ok": bool(same and not any(bad))}
             out["verified"] = bool(out.get("verified")) and blk["verify"]["ok"]
             r_rows.release(); r_pos.release(); ia.close(); ib.close()
-        out["join_positions"] = blk
+        out[other_name] = blk
         if roofline is not None:   # a compact copy where the driver's record keeps it (the roofline object)
-            roofline["positions_mode"] = {
-                "k_chain_dense_ms": blk["k_chain_dense_ms"], "frac": (blk.get("roofline") or {}).get("frac"),
-                "ms_per_step": blk["ms_per_step"], "value": blk["value"], "verified": (blk.get("verify") or {}).get("ok"),
-                "note": "the same step with the Join reporting sorted positions (the reference's row handle) instead of original "
-                        "row ids: a 2.5 MB rank table replaces the 40 MB row table; frac on THIS object's byte model; "
-                        "details under join_positions; `value` above stays the row-id mode"}
+            roofline["other_output_mode"] = {
+                "mode": blk["mode"], "k_chain_dense_ms": blk["k_chain_dense_ms"], "frac": (blk.get("roofline") or {}).get("frac"),
+                "ms_per_step": blk["ms_per_step"], "value": blk["value"],
+                "positions_equal_row_ids_through_perm": (blk.get("verify") or {}).get("ok"),
+                "note": "the same step in the other output mode of the ABI (details under %s); fractions on THIS object's byte "
+                        "model.  Rounds 1-2 timed the row-id mode (cph_join_chain); since round 3 the timed step reports sorted "
+                        "positions (cph_join_chain_ex, CPH_CHAIN_POSITIONS): the reference's own row handle" % other_name}
 
     # ---- end-to-end C-ABI scope: pinned host SoA in -> pinned host row ids out (PCIe inclusive) ----
     # cph_stream_join_*: 2^24-row chunks of the same orders table, H2D / kernel / D2H of consecutive chunks
@@ -578,7 +602,7 @@ def main():
         best = None
         # ONE pipeline for all repetitions: the first pass page-locks the slots' result blocks and sizes their device
         # buffers (a long-running caller pays that once), the best of the following passes is reported
-        sj = StreamJoin(eng.ctx, [ia, ib], nslots=nslots)
+        sj = StreamJoin(eng.ctx, [ia, ib], nslots=nslots, positions=POS)
         for rep in range(4):
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
@@ -598,7 +622,7 @@ def main():
         h2d = host_bytes["cust_id"] + host_bytes["prod_id"] + off_o
         d2h = 8 * nloc + nloc // 8
         out["e2e_pinned_host"] = {
-            "scope": "pinned host key columns in -> pinned host build-row ids + match bitmap out (cph_stream_join_*), "
+            "scope": "pinned host key columns in -> pinned host " + ("sorted positions" if POS else "build-row ids") + " + match bitmap out (cph_stream_join_*), "
                      "indexes already built; PCIe inclusive; one pipeline reused, first pass (page-locking of the result blocks) not counted",
             "rows": nloc, "chunk_rows": chunk, "slots": nslots, "in_flight": inflight, "ms": round(best * 1e3, 2),
             "rows_per_s": nloc / best, "joined": joined_e2e,
@@ -677,12 +701,13 @@ def main():
                                              "GBps": round(bts / 1e9 / (ms / 1e3), 1),
                                              "frac": round(bts / 1e9 / (ms / 1e3) / HBM_PEAK_GBPS, 4),
                                              "index_ms": r["ms"], "step_ms": round(ms_per_step, 3)}
-                if out.get("join_positions"):   # the same sum with the step that reports sorted positions (same byte model)
-                    msp = r["ms"] + out["join_positions"]["ms_per_step"]
-                    comb[name + "_plus_positions_step"] = {"ms": round(msp, 3), "algorithmic_bytes": bts,
-                                                           "GBps": round(bts / 1e9 / (msp / 1e3), 1),
-                                                           "frac": round(bts / 1e9 / (msp / 1e3) / HBM_PEAK_GBPS, 4),
-                                                           "index_ms": r["ms"], "step_ms": out["join_positions"]["ms_per_step"]}
+                for oname in ("join_positions", "join_row_ids"):   # the same sum with the step in the other output mode
+                    if out.get(oname):
+                        msp = r["ms"] + out[oname]["ms_per_step"]
+                        comb[name + "_plus_" + oname + "_step"] = {"ms": round(msp, 3), "algorithmic_bytes": bts,
+                                                                    "GBps": round(bts / 1e9 / (msp / 1e3), 1),
+                                                                    "frac": round(bts / 1e9 / (msp / 1e3) / HBM_PEAK_GBPS, 4),
+                                                                    "index_ms": r["ms"], "step_ms": out[oname]["ms_per_step"]}
             comb["note"] = ("IndexOn over 1e8 rows (index_on_1e8.*: wall ms, pass-model bytes) + one bench step (2 index builds + "
                             "chained Join of 1e8 rows: ms_per_step, roofline.step_algorithmic_bytes), summed; frac = bytes / ms / 8 TB/s")
             out["index_plus_join_1e8"] = comb

@@ -18,13 +18,17 @@ for k, v in (d.get("index_on_1e8") or {}).items():
         continue
     print(k, "ms", v["ms"], "kernel_ms", v["kernel_ms"], "pass", v.get("frac_pass_model"), "verified", v.get("verified"))
     print("    ", v["kernels_ms"])
-jp = d.get("join_positions")
-if jp:
-    print("join_positions ms_per_step %.3f (x%.2f) k_chain_dense %.3f ms frac %s verified %s" % (
-        jp["ms_per_step"], jp["speedup_vs_row_ids"], jp["k_chain_dense_ms"], (jp.get("roofline") or {}).get("frac"), (jp.get("verify") or {}).get("ok")))
+print("timed step output mode:", r.get("output_mode"), "|", (d.get("config") or {}).get("build_row_mode", "")[:60])
+for name in ("join_positions", "join_row_ids"):
+    jp = d.get(name)
+    if jp:
+        print("%s ms_per_step %.3f (timed step / this = %.2f) k_chain_dense %.3f ms frac %s over gather ceiling %s verified %s" % (
+            name, jp["ms_per_step"], jp.get("timed_step_over_this", jp.get("speedup_vs_row_ids", 0)), jp["k_chain_dense_ms"],
+            (jp.get("roofline") or {}).get("frac"), (jp.get("roofline") or {}).get("kernel_over_gather_ceiling"),
+            (jp.get("verify") or {}).get("ok")))
 gc = r.get("gather_ceiling")
 if gc:
-    print("gather ceiling %.3f ms (%s G lookups/s), kernel / ceiling %s, copy %s TB/s" % (gc["ms"], gc["Glookups_per_s"], gc["kernel_over_ceiling"], r.get("copy_TBps")))
+    print("gather ceiling %.3f ms (%s G lookups/s), kernel / ceiling %s, copy %s TB/s" % (gc["ms"], gc["Glookups_per_s"], gc.get("kernel_over_ceiling"), r.get("copy_TBps")))
 for k in ("e2e_pinned_host", "cpu_baseline"):
     if k in d:
         print(k, {a: b for a, b in d[k].items() if a not in ("scope", "sample", "variants", "extrapolated_full_size")})
