@@ -7,11 +7,16 @@ resident in HBM,
 
     customers.UniqueIndexOn("id")        (1e7 rows, 8-byte ids)      } cph_index_build_many
     products.UniqueIndexOn("prod_id")    (1e5 rows)                  } (one batch of two builds)
-    orders.Join(customers,"cust_id").Join(products,"prod_id")       cph_join_probe x2
+    orders.Join(customers,"cust_id").Join(products,"prod_id")       cph_join_chain_ex (one fused pass)
         over 1e8 orders rows x 3 string columns (cust_id, prod_id, qty)
 
+The Join reports, per joined row and index, the SORTED POSITION of the matching index row — the reference's own row
+handle (its Join reads index.impl.rows[first()+i], csvplus.go:553-567; the cgo shim and the C++ facade consume exactly
+that).  The mode rounds 1-2 timed, original row ids (= perm[position]), is measured in the same run and reported beside
+`value` as `join_row_ids`; `--row-ids` swaps the two.
+
 and, for N > 1, the probe rows are split into N contiguous ranges (strong scaling:
-the 1e8 rows are fixed), the build side is replicated, and the joined row-id lists are
+the 1e8 rows are fixed), the build side is replicated, and the joined position lists are
 allgatherv'ed over RCCL behind the C ABI (cph_dist_chain_allgather) so that every rank holds the
 whole list in emission order.
 
