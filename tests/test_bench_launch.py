@@ -42,6 +42,15 @@ def test_plain_command_starts_its_own_ranks(n):
     assert d == {"launch_check": True, "n_gpus": n, "world": n, "ranks_seen": list(range(n)), "backend": "gloo"}
 
 
+def test_output_mode_flags_are_accepted():
+    """--row-ids (the rounds 1-2 output mode) and the old --positions spelling parse; the self-launched ranks get them too."""
+    for flag in ("--row-ids", "--positions"):
+        r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launch-check", flag], env=_env(), capture_output=True, text=True,
+                           timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert _json_line(r.stdout)["ranks_seen"] == [0, 1]
+
+
 def test_under_a_launcher_it_is_one_of_the_ranks():
     """The driver's way: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N."""
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
