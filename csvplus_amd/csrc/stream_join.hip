@@ -22,6 +22,7 @@
 // stream synchronisations block that thread only, so the uploads, kernels and downloads of the
 // other slots' chunks go on meanwhile.  Lookup structures of the indexes are built once, in create.
 #include <condition_variable>
+#include <exception>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -170,7 +171,12 @@ static void slot_worker(cph_stream_join* sj, cph_stream_join::Slot* sl) {
         if (sl->quit) return;
         sl->has_job = false;
         lk.unlock();
-        Status st = general_chunk(sj, *sl);
+        Status st;
+        try {
+            st = general_chunk(sj, *sl);
+        } catch (const std::exception& e) {   // host allocation failure inside the worker: report it, do not take the process down
+            st = {CPH_ERR_NOMEM, std::string("stream join worker: ") + e.what()};
+        }
         if (!st.ok()) (void)hipStreamSynchronize(sl->sctx.stream);
         lk.lock();
         sl->job_status = st;
