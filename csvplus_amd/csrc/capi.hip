@@ -1272,7 +1272,12 @@ CPH_API int32_t cph_index_find_many(cph_ctx* ctx, const cph_index* ix, const cph
     if (nkeys > (1ull << 28)) return fail(ctx, {CPH_ERR_INVALID, "cph_index_find_many: at most 2^28 keys per call"});
     // query block per key: stride words = [nq | q_exact ... | qlo | qhi]; nq = ~0 marks "cannot occur"
     const size_t stride = (size_t)ix->total_words() + 2;
-    std::vector<uint64_t> host(stride * nkeys, 0), q_exact;
+    std::vector<uint64_t> host, q_exact;
+    try {
+        host.assign(stride * nkeys, 0);
+    } catch (const std::exception&) {
+        return fail(ctx, {CPH_ERR_NOMEM, "cph_index_find_many: out of host memory for the query blocks"});
+    }
     for (uint64_t k = 0; k < nkeys; k++) {
         int32_t nq = 0;
         uint64_t qlo = 0, qhi = 0;
