@@ -289,7 +289,7 @@ CPH_API int32_t cph_join_chain(cph_ctx* ctx, const cph_chain_step* steps, int32_
  * its index rows sorted (as the reference does) reaches the joined row with one array access; the original row id is
  * cph_index_perm(index)[position].  For the device this removes the one random access per probe row that cannot be
  * cached: a duplicate-free index over a dense code space maps code -> position through presence bits and a running count
- * per 64 codes (16 bytes per 64 codes: 2.5 MB for a 1e7-code space, resident in every XCD's L2) instead of a 4-byte
+ * per 32 codes (8 bytes per 32 codes: 2.5 MB for a 1e7-code space, resident in every XCD's L2) instead of a 4-byte
  * row id per code (40 MB: one 64-byte Infinity-Fabric sector per probe row).
  */
 #define CPH_CHAIN_POSITIONS 1u
@@ -601,12 +601,14 @@ CPH_API int32_t cph_index_get_info(const cph_index* index, cph_index_info* info)
 /*
  * Join looks a probe row's key up in a structure that is not part of the Index (csvplus.go:612-614: the sorted rows
  * ARE the index) and is therefore built by the first Join that wants it: a direct-address table over the key codes
- * when the code space is dense (<= 24 codes per row), a hash table over the codes otherwise (one 64-byte sector per
- * probe row for any key: random ids, hashes, several columns, keys of any length); a PREFIX join (fewer columns than
+ * when the code space is dense (<= 24 codes per row) — for a duplicate-free index asked for sorted positions or for
+ * bounds only (cph_join_chain_ex CPH_CHAIN_POSITIONS, cph_join_probe with want_pairs = 0) a RANK table instead: presence
+ * bits + a running count per 32 codes, 1/16 the size of the 4-byte row table —, a hash table over the codes otherwise
+ * (one 64-byte sector per probe row for any key: random ids, hashes, several columns, keys of any length); a PREFIX join (fewer columns than
  * the index has, csvplus.go:546-550) needs the order and searches the sorted codes, as does every Join when the
  * structure cannot be allocated.  This call builds the structure NOW — `chained` = 1: the one cph_join_chain /
  * cph_stream_join use (4-byte row table for a duplicate-free index), 2: the one cph_join_chain_ex uses with
- * CPH_CHAIN_POSITIONS (presence bits + running count per 64 codes), 0: the one cph_join_probe uses — so that
+ * CPH_CHAIN_POSITIONS (the rank table), 0: the one cph_join_probe uses for pairs — so that
  * the first Join does not pay for it.
  *
  * Sharing an index between ctxs: the structures are built on the INDEX's ctx (its stream, its pool) whatever ctx
