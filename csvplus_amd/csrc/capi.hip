@@ -19,6 +19,7 @@ constexpr size_t kGuardBytes = 256;
 constexpr uint8_t kGuardByte = 0xA5;
 
 Status DevicePool::alloc(size_t bytes, void** out) {
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     const size_t want = (bytes + (guard ? kGuardBytes : 0) + 255) & ~(size_t)255;
     int best = -1;
     for (int i = 0; i < (int)free_.size(); i++) {
@@ -87,10 +88,12 @@ void DevicePool::check_block(const Block& b) {
 }
 
 void DevicePool::check_live() {
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     for (const auto& b : live_) check_block(b);
 }
 
 void DevicePool::release(void* p) {
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     for (size_t i = 0; i < live_.size(); i++) {
         if (live_[i].p == p) {
             check_block(live_[i]);
@@ -120,6 +123,7 @@ void DevicePool::release(void* p) {
 }
 
 Status DevicePool::reserve(size_t bytes) {
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     if (slab_) return {CPH_ERR_INVALID, "the pool already has a reserved slab"};
     bytes = (bytes + 255) & ~(size_t)255;
     void* p = nullptr;
@@ -135,6 +139,7 @@ Status DevicePool::reserve(size_t bytes) {
 }
 
 void DevicePool::trim() {
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     for (auto& b : free_) (void)hipFree(b.p);
     free_.clear();
     bytes_cached = 0;
@@ -260,7 +265,7 @@ Status pinned_upload(cph_ctx* ctx, size_t bytes, void** out) {
 
 // ---- per-kernel timing --------------------------------------------------------------------------
 ProfScope::ProfScope(cph_ctx* ctx, const char* name, double bytes) : ctx_(ctx), bytes_(bytes) {
-    if (!ctx->profiling) return;
+    if (!ctx || !ctx->profiling) return;   // ctx == nullptr: a launch on another ctx's stream (probe.hip: accel_ctx) is not timed
     if (!ctx->prof_only.empty() && ctx->prof_only != name) return;   // the pair of events costs ~10 us of stream time
     for (size_t i = 0; i < ctx->prof_stats.size(); i++)
         if (ctx->prof_stats[i].name == name) { idx_ = (int)i; break; }
@@ -285,7 +290,7 @@ ProfScope::ProfScope(cph_ctx* ctx, const char* name, double bytes) : ctx_(ctx), 
 }
 
 ProfScope::~ProfScope() {
-    if (!ctx_->profiling || !start_) return;
+    if (!ctx_ || !ctx_->profiling || !start_) return;
     hipEvent_t stop = nullptr;
     if (!ctx_->prof_free_events.empty()) {
         stop = ctx_->prof_free_events.back();
@@ -772,6 +777,8 @@ CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value
     else if (k == "stream_zero_copy_out") ctx->stream_zero_copy_out = value != 0;
     else if (k == "chain_nt_streams") ctx->chain_nt_streams = value < 0 || value > 2 ? 0 : (int)value;
     else if (k == "chain_rank_lds") ctx->chain_rank_lds = value != 0;
+    else if (k == "chain_arith") ctx->chain_arith = value != 0;
+    else if (k == "chain_identity") ctx->chain_identity = value != 0;
     else if (k == "probe_hash_rows") ctx->probe_hash_rows = value == 4 ? 4 : 2;
     else if (k == "small_build_rows") ctx->small_build_rows = value < 0 ? 0 : value > (1 << 20) ? (1 << 20) : (int)value;
     else if (k == "plan_threads") ctx->plan_threads = (int)value;

@@ -57,7 +57,7 @@ struct ChainStepArg {
     const void* codes;          // sorted codes (u32 if key32 else u64)
     const uint32_t* perm;
     uint64_t n_index;
-    int32_t codec_bytes;
+    int32_t codec_bytes;        // 0: a lean step (k_chain_dense's LEAN mask): no codec block is copied into LDS
     int32_t key32;
 };
 struct ChainArgs {
@@ -66,6 +66,12 @@ struct ChainArgs {
     int32_t nt_streams;         // the stream's offsets / key bytes are loaded and the results stored non-temporally: they pass
                                 // through once and must not push the lookup tables out of the L2
     int32_t reserved_;
+};
+// what only the lean kernels read (LEAN != 0), as the kernel's LAST argument
+struct LeanArgs {
+    int32_t identity[kMaxChain];   // duplicate-free index whose code space has exactly as many states as the index has rows:
+                                   // every code occurs, the sorted position of a key IS its code — no lookup at all
+    ArithPlan arith[kMaxChain];    // lean steps: the key code as a dot product of the key's bytes (codec_device.hpp)
 };
 
 // DBG: attribution switches for tools/microbench (results are wrong when set):
@@ -77,10 +83,15 @@ struct ChainArgs {
 // lookups — is straight-line code over all kChainRows rows and all S steps: rows past the end are clamped to the
 // last row and unmatched codes to entry 0 (results masked afterwards) instead of being branched around, so the
 // kChainRows * S loads of a phase are in flight together.  No workgroup-level synchronisation in the tile loop.
-template <int S, bool LONG, bool WIDE, bool DBG>
+// LEAN: bit s set = step s is a "lean" step, decided on the host (enqueue_dense): its stream column is fixed-width 8 at an
+//      8-byte aligned address (a value is ONE aligned 8-byte load) and its code is a dot product of the key's bytes
+//      (ArithPlan) — no codec block in LDS, no LUT walk, no length compare.  A compile-time property: the other steps'
+//      code is not even instantiated for it (fewer live SGPRs / VGPRs than a uniform branch leaves behind).  Only
+//      instantiated for !LONG && !WIDE && !DBG.
+template <int S, bool LONG, bool WIDE, bool DBG, uint32_t LEAN = 0>
 __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint64_t nprobe, uint64_t probe_base,
                                                               uint64_t ntiles, uint64_t* __restrict__ masks,
-                                                              uint32_t* __restrict__ wave_counts, int dbg_flags) {
+                                                              uint32_t* __restrict__ wave_counts, int dbg_flags, LeanArgs la) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // dynamic LDS layout: [codec 0][codec 1]...   (no static LDS: keeps 16-B alignment)
     using B = std::conditional_t<WIDE, uint64_t, uint32_t>;    // byte offset of a value from its (uniform) base
@@ -91,6 +102,7 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
         uint8_t* p = smem;
 #pragma unroll
         for (int s = 0; s < S; s++) {
+            if ((LEAN >> s) & 1u) continue;   // codec_bytes == 0: nothing of it is needed
             cv[s] = codec_load_to_lds(a.step[s].codec, p);   // syncs inside
             p += a.step[s].codec_bytes;
         }
@@ -107,7 +119,13 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
         for (int s = 0; s < S; s++) {
             rank_lds[s] = nullptr;
             const int nblk = a.step[s].ranktab_lds;
-            if (nblk) {
+            if (LEAN != 0 && nblk) {   // the blocks as they are: 8 bytes per 32 codes, one ds_read_b64 and 32-bit arithmetic per lookup
+                uint2* dst = reinterpret_cast<uint2*>(p);
+                for (int i = threadIdx.x; i < 2 * nblk; i += kChainThreads) dst[i] = a.step[s].ranktab[i];
+                rank_lds[s] = (const CPH_LDS uint32_t*)p;
+                p += (size_t)nblk * 16;
+                any = true;
+            } else if (nblk) {
                 uint32_t* dst = reinterpret_cast<uint32_t*>(p);
                 for (int i = threadIdx.x; i < nblk; i += kChainThreads) {   // two 32-code blocks -> {bits, bits, keys before}
                     const uint2 b0 = a.step[s].ranktab[2 * i], b1 = a.step[s].ranktab[2 * i + 1];
@@ -134,6 +152,7 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
         WaveSpans<kChainRows, B> sp[S];
 #pragma unroll
         for (int s = 0; s < S; s++) {
+            if ((LEAN >> s) & 1u) continue;   // a lean step needs no spans: value k is the 8-byte word rbase + rel[k]
             if (a.nt_streams) wave_spans<kChainRows, B, false, true>(a.step[s].col, wr, &sp[s]);   // uniform branch
             else wave_spans<kChainRows, B>(a.step[s].col, wr, &sp[s]);
         }
@@ -141,6 +160,18 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
         uint64_t c0[S][kChainRows], c1[LONG ? S : 1][kChainRows];
 #pragma unroll
         for (int s = 0; s < S; s++) {
+            if ((LEAN >> s) & 1u) {
+                typedef const __attribute__((address_space(1))) uint64_t* global_u64_ptr;
+                const global_u64_ptr w = (global_u64_ptr)a.step[s].col.data + wr.rbase;
+                if (a.nt_streams) {   // uniform, outside the row loop
+#pragma unroll
+                    for (int k = 0; k < kChainRows; k++) c0[s][k] = __builtin_nontemporal_load(&w[wr.rel[k]]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < kChainRows; k++) c0[s][k] = w[wr.rel[k]];
+                }
+                continue;
+            }
 #pragma unroll
             for (int k = 0; k < kChainRows; k++) {
                 c0[s][k] = a.nt_streams ? sp[s].chunk_nt(k, 0) : sp[s].chunk(k, 0);
@@ -154,6 +185,8 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
             if (DBG && (dbg & 2)) {
 #pragma unroll
                 for (int k = 0; k < kChainRows; k++) code[s][k] = (CW)((c0[s][k] ^ (LONG ? c1[LONG ? s : 0][k] : 0ull)) & 1023);
+            } else if ((LEAN >> s) & 1u) {   // the code is a dot product of the key's bytes
+                encode_rows_arith<kChainRows, CW>(la.arith[s], c0[s], code[s], &okm);
             } else if (!WIDE || cv[s].hdr->lutw_bits == 32) {
                 encode_rows<kChainRows, uint32_t, B, CW, LONG>(cv[s], sp[s], c0[s], c1[LONG ? s : 0], code[s], &okm,
                                                                a.step[s].col.fixed_width != 0 && (int)a.step[s].col.fixed_width == cv[s].hdr->col_maxlen[0]);
@@ -167,7 +200,34 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
 #pragma unroll
         for (int s = 0; s < S; s++) {
             const ChainStepArg& st = a.step[s];
-            if (st.ranktab) {
+            if constexpr (LEAN != 0) {
+                // a lean kernel reports positions and every step is answered by one of three lookups (enqueue_dense checks)
+                if (la.identity[s]) {   // every code below n_index occurs and is its own sorted position: no lookup at all
+#pragma unroll
+                    for (int k = 0; k < kChainRows; k++)
+                        brow[s][k] = ((okm >> k) & 1u) && (uint32_t)code[s][k] < (uint32_t)st.n_index ? (uint32_t)code[s][k] : kTableAbsent;
+                } else if (rank_lds[s]) {   // 8-byte rank blocks in LDS
+#pragma unroll
+                    for (int k = 0; k < kChainRows; k++) {
+                        const uint32_t cidx = (okm >> k) & 1u ? (uint32_t)code[s][k] : 0u;
+                        const CPH_LDS uint32_t* e = rank_lds[s] + 2u * (cidx >> 5);
+                        const uint32_t bits = e[0], before = e[1], bit = cidx & 31u;
+                        brow[s][k] = (bits >> bit) & 1u ? before + (uint32_t)__popc(bits & ((1u << bit) - 1u)) : kTableAbsent;
+                    }
+                } else {             // rank blocks in global memory (L2-resident for a 1e7-row index)
+                    uint2 blk[kChainRows];
+#pragma unroll
+                    for (int k = 0; k < kChainRows; k++) {
+                        const uint32_t cidx = (okm >> k) & 1u ? (uint32_t)code[s][k] : 0u;   // block 0 always exists
+                        blk[k] = st.ranktab[cidx >> 5];
+                    }
+#pragma unroll
+                    for (int k = 0; k < kChainRows; k++) {
+                        const uint32_t bit = (uint32_t)code[s][k] & 31u;
+                        brow[s][k] = (blk[k].x >> bit) & 1u ? blk[k].y + (uint32_t)__popc(blk[k].x & ((1u << bit) - 1u)) : kTableAbsent;
+                    }
+                }
+            } else if (st.ranktab) {
                 // the key's rank among the index keys = its sorted position: one 8-byte block per row from a table
                 // 1/16 the size of rowtab (L2-resident for the 1e7-row customers index: no Infinity-Fabric sector per
                 // row), or 12 bytes per 64 codes from LDS
@@ -351,24 +411,75 @@ static Status enqueue_dense(cph_ctx* ctx, const ChainStep* steps, uint64_t nprob
                             ChainArgs* args_out, unsigned* grid_out, bool positions) {
     const uint64_t ntiles = (nprobe + kChainTile - 1) / kChainTile;
     ChainArgs args{};
+    LeanArgs largs{};
     size_t lds = 0, rank_lds_bytes = 0;
-    for (int s = 0; s < S; s++) lds += steps[s].index->codec_dev.bytes();
+    const int dbg = ctx->chain_debug;
+    bool long_keys = false, wide = false;
+    for (int s = 0; s < S; s++) {
+        const cph_index* ix = steps[s].index;
+        const DevCol& c = steps[s].cols[0];
+        long_keys |= ix->codec.col_maxlen[0] > 8;
+        // 32-bit registers for value offsets and codes need: 32-bit offsets (addresses are formed in 64 bits at the
+        // load), a 32-bit pre-multiplied LUT, a code that fits 32 bits
+        wide |= codec_premultiplied_bits(ix->codec) != 32 || !ix->codec.key32;
+        wide |= !col_is_narrow(c);
+    }
+    // lean steps (k_chain_dense's LEAN mask): a fixed-width-8 stream column at an 8-byte aligned address joined with an
+    // index whose 8-byte keys code arithmetically (codec_arith_plan: contiguous alphabets, no pad).  Every subset of the
+    // steps of chains of one or two Joins is instantiated; longer chains are lean in all steps or in none.
+    // A lean kernel reports POSITIONS and answers every step from the code itself (identity) or from a rank table.
+    uint32_t lean = 0;
+    bool ident[kMaxChain] = {false, false, false, false};
+    if (positions)
+        for (int s = 0; s < S; s++) {
+            const cph_index* ix = steps[s].index;
+            ident[s] = ctx->chain_identity && ix->table_entries != 0 && ix->table_entries == ix->nrows &&
+                       ix->first_dup == UINT64_MAX && ix->windows.empty();
+        }
+    if (positions && ctx->chain_arith && !long_keys && !wide && !dbg) {
+        bool all_ranked = true;
+        for (int s = 0; s < S; s++) {
+            const cph_index* ix = steps[s].index;
+            const DevCol& c = steps[s].cols[0];
+            ArithPlan ap;
+            codec_arith_plan(ix->codec, &ap);
+            if (ap.enabled && ap.keylen == 8 && c.fixed_width == 8 && ((uintptr_t)c.data & 7u) == 0) lean |= 1u << s;
+            if (!ident[s]) {
+                CPH_TRY(index_ensure_ranktab(ctx, ix));
+                all_ranked &= (bool)ix->ranktab;
+            }
+        }
+        if (!all_ranked) lean = 0;
+    }
+    if (S > 2 && lean != (1u << S) - 1u) lean = 0;
+    if (!lean)
+        for (int s = 0; s < S; s++) ident[s] = false;   // the general kernel looks every key up
+    for (int s = 0; s < S; s++)
+        if (!((lean >> s) & 1u)) lds += steps[s].index->codec_dev.bytes();
     for (int s = 0; s < S; s++) {
         const cph_index* ix = steps[s].index;
         ChainStepArg& st = args.step[s];
         st.col = steps[s].cols[0];
         st.codec = ix->codec_dev.as<uint8_t>();
         st.codec_bytes = (int32_t)ix->codec_dev.bytes();
+        if ((lean >> s) & 1u) {   // no codec block in LDS for this step
+            codec_arith_plan(ix->codec, &largs.arith[s]);
+            st.codec_bytes = 0;
+        }
         // lookup structure of the step, built on first use (on the index's own ctx; other ctxs wait for it): the
         // 4-byte row table over a dense code space, else the hash table, else (allocation failed) the sorted codes
         st.positions = positions ? 1 : 0;
         st.rowtab = nullptr;
         st.ranktab = nullptr;
-        if (positions) {
+        largs.identity[s] = ident[s] ? 1 : 0;
+        if (ident[s]) {
+        } else if (positions) {
             CPH_TRY(index_ensure_ranktab(ctx, ix));
             st.ranktab = ix->ranktab ? ix->ranktab.as<uint2>() : nullptr;
-            const size_t nblk = ranktab_blocks(ix->table_entries) / 2, rb = (nblk * 12 + 15) & ~(size_t)15;
-            if (st.ranktab && ctx->chain_rank_lds && lds + rank_lds_bytes + rb <= 52 * 1024) {   // three workgroups per CU stay resident
+            // in LDS when three workgroups per CU stay resident: a lean kernel keeps the plain 8-byte blocks (cheaper
+            // lookups), the general one packs pairs of blocks into 12 bytes
+            const size_t nblk = ranktab_blocks(ix->table_entries) / 2, rb = lean ? nblk * 16 : (nblk * 12 + 15) & ~(size_t)15;
+            if (st.ranktab && ctx->chain_rank_lds && lds + rank_lds_bytes + rb <= 52 * 1024) {
                 st.ranktab_lds = (int32_t)nblk;
                 rank_lds_bytes += rb;
             }
@@ -378,7 +489,7 @@ static Status enqueue_dense(cph_ctx* ctx, const ChainStep* steps, uint64_t nprob
         }
         st.hash = nullptr;
         st.hash_sectors = 0;
-        if (!st.rowtab && !st.ranktab && index_wants_hash(ix)) {
+        if (!st.rowtab && !st.ranktab && !ident[s] && index_wants_hash(ix)) {
             CPH_TRY(index_ensure_hash(ctx, ix));
             if (ix->hash_mode == kHashK1) {
                 st.hash = ix->hash.as<uint4>();
@@ -394,24 +505,21 @@ static Status enqueue_dense(cph_ctx* ctx, const ChainStep* steps, uint64_t nprob
     lds += rank_lds_bytes;
     args.nt_streams = ctx->chain_nt_streams == 1 || (ctx->chain_nt_streams == 2 && positions) ? 1 : 0;
     const uint64_t ncounts = ntiles * kChainWaves;   // one match count per (tile, wave), tile-major
-    const int dbg = ctx->chain_debug;
-    bool long_keys = false, wide = false;
-    for (int s = 0; s < S; s++) {
-        const cph_index* ix = steps[s].index;
-        const DevCol& c = steps[s].cols[0];
-        long_keys |= ix->codec.col_maxlen[0] > 8;
-        // 32-bit registers for value offsets and codes need: 32-bit offsets (addresses are formed in 64 bits at the
-        // load), a 32-bit pre-multiplied LUT, a code that fits 32 bits
-        wide |= codec_premultiplied_bits(ix->codec) != 32 || !ix->codec.key32;
-        wide |= !col_is_narrow(c);
-    }
-    using KernelFn = void (*)(ChainArgs, uint64_t, uint64_t, uint64_t, uint64_t*, uint32_t*, int);
+    using KernelFn = void (*)(ChainArgs, uint64_t, uint64_t, uint64_t, uint64_t*, uint32_t*, int, LeanArgs);
     static const KernelFn variants[2][2][2] = {
         {{&k_chain_dense<S, false, false, false>, &k_chain_dense<S, false, false, true>},
          {&k_chain_dense<S, false, true, false>, &k_chain_dense<S, false, true, true>}},
         {{&k_chain_dense<S, true, false, false>, &k_chain_dense<S, true, false, true>},
          {&k_chain_dense<S, true, true, false>, &k_chain_dense<S, true, true, true>}}};
-    const KernelFn kernel = variants[long_keys ? 1 : 0][wide ? 1 : 0][dbg ? 1 : 0];
+    KernelFn kernel = variants[long_keys ? 1 : 0][wide ? 1 : 0][dbg ? 1 : 0];
+    if (lean) {
+        constexpr uint32_t kAll = (1u << S) - 1u;
+        if (lean == kAll) kernel = &k_chain_dense<S, false, false, false, kAll>;
+        if constexpr (S == 2) {
+            if (lean == 1u) kernel = &k_chain_dense<S, false, false, false, 1u>;
+            if (lean == 2u) kernel = &k_chain_dense<S, false, false, false, 2u>;
+        }
+    }
     // persistent workgroups: exactly as many as are resident at once (no tail wave), each walking
     // tiles blockIdx, blockIdx + grid, ...
     int per_cu = 1, cus = 256;
@@ -421,7 +529,7 @@ static Status enqueue_dense(cph_ctx* ctx, const ChainStep* steps, uint64_t nprob
     {
         ProfScope ps(ctx, "k_chain_dense", 0);
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(kChainThreads), lds, ctx->stream, args, nprobe, probe_base,
-                           ntiles, d_masks, d_counts, dbg);
+                           ntiles, d_masks, d_counts, dbg, largs);
     }
     {
         ProfScope ps(ctx, "k_sum_counts", 4.0 * (double)ncounts);

@@ -314,6 +314,71 @@ __device__ __forceinline__ void encode_rows(const CodecView& cv, const WaveSpans
     *okmask = m;
 }
 
+// ---- arithmetic encode: no LUT, no LDS -------------------------------------------------------------------------
+// When every byte position of a single-column, single-word codec holds a CONTIGUOUS range of byte values
+// [lo_p, hi_p] (decimal ids: '0'..'9') and every index key has the same length (no pad symbol anywhere), the rank
+// of a byte is byte - lo_p and the code is a dot product — and for a FIXED-WIDTH stream column of that very width the
+// whole key sits in one 8-byte register pair.  All 8 positions are then handled at once:
+//   z  = x - LO                       bytewise (no borrow between the bytes of a key that can be in the index)
+//   ok = no byte of  x | z | (z + (0x7F - RANGE))  has its top bit set
+//                                     (x: bytes >= 0x80 are outside every alphabet this path accepts; z: byte < lo
+//                                      wrapped; z + ...: byte > hi.  The LOWEST offending byte of a key has no borrow /
+//                                      carry coming in, so it is always flagged, whatever happens above it.)
+//   code = mixed-radix value of the bytes of z: two positions per v_dot4_u32_u8 (weights (r_{p+1}, 1)), the pairs
+//          combined with 24-bit multiply-adds.
+// ~20 VALU instructions per key instead of 4-6 per byte position plus an LDS load each (chain.hip: the 8-byte
+// customer ids of the benchmark).  keycodec.hip: codec_arith_plan decides and fills the constants; they travel as
+// kernel arguments (uniform: SGPRs).
+struct ArithPlan {
+    uint32_t enabled;      // 0: the codec does not qualify (LUT walk)
+    uint32_t mul24;        // != 0: every product below fits a 24 x 24-bit multiply
+    uint32_t keylen;       // byte positions of the key (1..8): the stream column must be fixed-width of exactly this
+    uint32_t keep[2];      // byte mask of the key's positions (bytes past keylen of the 8-byte load are cleared)
+    uint32_t lo[2];        // byte p: smallest byte value of position p (0 past the key)
+    uint32_t rngc[2];      // byte p: 0x7F - (largest - smallest byte value of position p)
+    uint32_t wa[2], wb[2]; // word w (positions 4w..4w+3): dot weights of positions (4w, 4w+1) and of (4w+2, 4w+3)
+    uint32_t ma[2];        // word w: states of positions (4w+2, 4w+3)
+    uint32_t s1;           // states of word 1 (positions 4..7)
+};
+
+// host (keycodec.hip): fills *ap; ap->enabled = 0 when the codec does not qualify
+void codec_arith_plan(const CodecHost& codec, ArithPlan* ap);
+
+// c0[k] = the 8 bytes of row k's value (callers use the plan only when keylen == 8: chain.hip's lean steps).  Clears the okm bit of a row
+// whose key cannot occur in the index.
+template <int R, class CW>
+__device__ __forceinline__ void encode_rows_arith(const ArithPlan& ap, const uint64_t (&c0)[R], CW (&code)[R], uint32_t* okmask) {
+    uint32_t m = *okmask;
+    uint32_t zl[R], zh[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        const uint32_t xl = (uint32_t)c0[k], xh = (uint32_t)(c0[k] >> 32);   // keylen == 8: every byte belongs to the key
+        zl[k] = xl - ap.lo[0];
+        zh[k] = xh - ap.lo[1];
+        const uint32_t tl = zl[k] + ap.rngc[0], th = zh[k] + ap.rngc[1];
+        const uint32_t bad = ((xl | zl[k] | tl) | (xh | zh[k] | th)) & 0x80808080u;
+        if (bad) m &= ~(1u << k);
+    }
+    if (ap.mul24) {   // uniform, outside the row loop: one branch per wave-tile
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const uint32_t pa0 = __builtin_amdgcn_udot4(zl[k], ap.wa[0], 0u, false);
+            const uint32_t pa1 = __builtin_amdgcn_udot4(zh[k], ap.wa[1], 0u, false);
+            const uint32_t w0 = __builtin_amdgcn_udot4(zl[k], ap.wb[0], __umul24(pa0, ap.ma[0]), false);
+            code[k] = (CW)__builtin_amdgcn_udot4(zh[k], ap.wb[1], __umul24(pa1, ap.ma[1]) + __umul24(w0, ap.s1), false);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const uint32_t pa0 = __builtin_amdgcn_udot4(zl[k], ap.wa[0], 0u, false);
+            const uint32_t pa1 = __builtin_amdgcn_udot4(zh[k], ap.wa[1], 0u, false);
+            const uint32_t w0 = __builtin_amdgcn_udot4(zl[k], ap.wb[0], pa0 * ap.ma[0], false);
+            code[k] = (CW)__builtin_amdgcn_udot4(zh[k], ap.wb[1], pa1 * ap.ma[1] + w0 * ap.s1, false);
+        }
+    }
+    *okmask = m;
+}
+
 // The first 24 bytes of a value, fetched with three independent loads right after its span (two dependent
 // memory round trips per value instead of one per 8-byte chunk).  LONGV = false: the caller guarantees that no
 // offset beyond 23 is asked for (all key columns are at most 24 bytes long), and chunk selection is branch-free;

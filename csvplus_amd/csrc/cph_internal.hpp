@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -51,6 +52,8 @@ struct Status {
 // All work of a ctx runs on one stream, so a block freed (in host program order)
 // after the kernels using it were enqueued can be handed to the next user: reuse is
 // stream-ordered.  Blocks are cached until cph_ctx_destroy / trim().
+// The bookkeeping is locked: a Join running on another ctx (another thread) may build a lookup structure of an
+// index, and that allocates from the pool of the INDEX's ctx (probe.hip: accel_ctx).
 class DevicePool {
 public:
     Status alloc(size_t bytes, void** out);
@@ -71,6 +74,7 @@ public:
 private:
     struct Block { void* p; size_t cap; size_t user; bool guarded = false; bool in_slab = false; };
     void check_block(const Block& b);
+    std::recursive_mutex mu_;
     uint8_t* slab_ = nullptr;
     size_t slab_bytes_ = 0;
     std::vector<std::pair<size_t, size_t>> slab_free_;   // (offset, length), sorted by offset, coalesced
@@ -236,6 +240,8 @@ struct cph_ctx {
     int stream_role_streams = 0;   // cph_stream_join (fused mode): 1 = one stream for all uploads, one for all downloads; 0 (default, faster at 2 and 4 slots): everything of a slot on its own stream
     int stream_zero_copy_out = 0;  // cph_stream_join (fused mode): the kernel stores the row ids straight into the slot's pinned block
     int chain_nt_streams = 0;      // chained join: non-temporal loads / stores for the stream's bytes and the results (0 never, 1 always, 2 positions mode)
+    int chain_arith = 1;           // chained join: fixed-width key columns over contiguous alphabets are encoded arithmetically (codec_device.hpp: ArithPlan) and read with one aligned load (A/B switch)
+    int chain_identity = 1;        // positions mode: an index whose code space is exactly as large as the index needs no lookup (A/B switch)
     int chain_rank_lds = 1;        // positions mode: rank tables of small indexes are copied into LDS by every workgroup (A/B switch)
     int probe_hash_rows = 2;       // rows per phase of the generic hash probe (2 / 4): 4 rows need 164 VGPRs (3 waves per SIMD) and measured 20 % slower
     int join_hash = 1;             // 0: indexes of this ctx never get a hash table (A/B switch: sorted search instead)
@@ -294,6 +300,8 @@ struct cph_index {
     uint32_t hash_sectors = 0;
     int32_t hash_mode = 0;         // kHashNone until built, then kHashK1 / kHashK3 / kHashTag
     bool accel_failed = false;     // a lookup structure could not be allocated (or tags collided): sorted search from now on
+    std::mutex accel_mu;           // held by index_ensure_* from the "is it there" test to the recorded event: Joins of several
+                                   // ctxs / threads (the slot workers of a general stream join) may ask for the same structure
     // Lookup structures are built on the INDEX's ctx (its stream, its pool: they live and die with the index); the
     // event is recorded behind the newest one, and a Join running on another ctx makes its stream wait for it.
     hipEvent_t accel_ready = nullptr;

@@ -783,6 +783,45 @@ int codec_premultiplied_bits(const CodecHost& cd) {
     return (size_t)cd.npos * kLutStride * (size_t)(bits / 8) <= 48 * 1024 ? bits : 0;
 }
 
+// Arithmetic encode (codec_device.hpp: ArithPlan): one key column of at most 8 bytes, every index key of the same
+// length (no pad symbol), a single code word below 2^31, every position's byte values one contiguous range below 0x80.
+void codec_arith_plan(const CodecHost& cd, ArithPlan* ap) {
+    *ap = ArithPlan{};
+    if (cd.ncols != 1 || cd.nwords != 1 || cd.has_groups() || cd.npos < 1 || cd.npos > 8) return;
+    if (cd.col_minlen[0] != cd.col_maxlen[0] || cd.word_states[0] > (1ull << 31)) return;
+    uint32_t lo[8] = {0}, rng[8] = {0}, radix[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+    for (int p = 0; p < cd.npos; p++) {
+        const uint16_t* lut = &cd.lut[(size_t)p * kLutStride];
+        if (lut[0] != kLutInvalid) return;   // a pad at this position: values of different lengths
+        int first = -1, last = -1, count = 0;
+        for (int b = 0; b < 256; b++)
+            if (lut[1 + b] != kLutInvalid) { if (first < 0) first = b; last = b; count++; }
+        if (first < 0 || last >= 0x80 || last - first + 1 != count || count > 255 || count != (int)cd.radix[(size_t)p]) return;
+        for (int b = first; b <= last; b++)
+            if (lut[1 + b] != (uint16_t)(b - first)) return;   // ranks follow the byte order by construction; be sure
+        lo[p] = (uint32_t)first;
+        rng[p] = (uint32_t)(last - first);
+        radix[p] = (uint32_t)count;
+    }
+    ap->keylen = (uint32_t)cd.npos;
+    for (int w = 0; w < 2; w++) {
+        for (int i = 0; i < 4; i++) {
+            const int p = 4 * w + i;
+            if (p < cd.npos) ap->keep[w] |= 0xFFu << (8 * i);
+            ap->lo[w] |= lo[p] << (8 * i);
+            ap->rngc[w] |= (0x7Fu - rng[p]) << (8 * i);
+        }
+        ap->wa[w] = radix[4 * w + 1] | 1u << 8;                     // positions 4w, 4w+1 -> d0 * r1 + d1
+        ap->wb[w] = radix[4 * w + 3] << 16 | 1u << 24;              // positions 4w+2, 4w+3 -> d2 * r3 + d3
+        ap->ma[w] = radix[4 * w + 2] * radix[4 * w + 3];
+    }
+    const uint64_t s0 = (uint64_t)radix[0] * radix[1] * radix[2] * radix[3];
+    const uint64_t s1 = (uint64_t)radix[4] * radix[5] * radix[6] * radix[7];
+    ap->s1 = (uint32_t)s1;   // s0 * s1 = states <= 2^31
+    ap->mul24 = s0 <= (1ull << 24) && s1 < (1ull << 24) ? 1u : 0u;
+    ap->enabled = 1;
+}
+
 Status codec_upload(cph_ctx* ctx, const CodecHost& cd, DevBuf* dev) {
     CodecDevHeader h{};
     h.ncols = cd.ncols;

@@ -207,6 +207,7 @@ static bool accel_alloc(cph_ctx* bctx, cph_index* ix, DevBuf* buf, size_t bytes)
 
 Status index_ensure_table(cph_ctx* ctx, const cph_index* cix) {
     cph_index* ix = const_cast<cph_index*>(cix);   // a cache inside the index; a ctx is single-threaded
+    std::lock_guard<std::mutex> accel_lock(ix->accel_mu);
     if (!ix->table_entries || ix->accel_failed) return {};
     if (ix->table) return accel_wait(ctx, ix);
     cph_ctx* bctx = accel_ctx(ctx, ix);
@@ -215,7 +216,7 @@ Status index_ensure_table(cph_ctx* ctx, const cph_index* cix) {
     if (!accel_alloc(bctx, ix, &t, states * sizeof(TableEntry))) return {};
     CPH_HIP_TRY(hipMemsetAsync(t.get(), 0xFF, states * sizeof(TableEntry), bctx->stream));
     {
-        ProfScope ps(bctx, "k_build_table", (double)n * (ix->codec.key32 ? 4.0 : 8.0) + 4.0 * (double)n + 8.0 * (double)n);
+        ProfScope ps(ctx == bctx ? bctx : nullptr, "k_build_table", (double)n * (ix->codec.key32 ? 4.0 : 8.0) + 4.0 * (double)n + 8.0 * (double)n);
         const dim3 grid(grid_for_items(n)), block(256);
         const bool unique = ix->first_dup == UINT64_MAX;
         if (ix->codec.key32)
@@ -233,6 +234,7 @@ Status index_ensure_table(cph_ctx* ctx, const cph_index* cix) {
 
 Status index_ensure_rowtab(cph_ctx* ctx, const cph_index* cix) {
     cph_index* ix = const_cast<cph_index*>(cix);
+    std::lock_guard<std::mutex> accel_lock(ix->accel_mu);
     if (!ix->table_entries || ix->accel_failed || ix->first_dup != UINT64_MAX) return {};
     if (ix->rowtab) return accel_wait(ctx, ix);
     cph_ctx* bctx = accel_ctx(ctx, ix);
@@ -241,7 +243,7 @@ Status index_ensure_rowtab(cph_ctx* ctx, const cph_index* cix) {
     if (!accel_alloc(bctx, ix, &t, states * sizeof(uint32_t))) return {};
     CPH_HIP_TRY(hipMemsetAsync(t.get(), 0xFF, states * sizeof(uint32_t), bctx->stream));
     {
-        ProfScope ps(bctx, "k_build_table", (double)n * (ix->codec.key32 ? 4.0 : 8.0) + 4.0 * (double)n + 4.0 * (double)n);
+        ProfScope ps(ctx == bctx ? bctx : nullptr, "k_build_table", (double)n * (ix->codec.key32 ? 4.0 : 8.0) + 4.0 * (double)n + 4.0 * (double)n);
         const dim3 grid(grid_for_items(n)), block(256);
         if (ix->codec.key32)
             hipLaunchKernelGGL(k_build_rowtab<uint32_t>, grid, block, 0, bctx->stream, ix->sorted_codes.as<uint32_t>(),
@@ -291,6 +293,7 @@ __global__ void k_build_ranktab(const K* __restrict__ codes, uint64_t n, uint2* 
 
 Status index_ensure_ranktab(cph_ctx* ctx, const cph_index* cix) {
     cph_index* ix = const_cast<cph_index*>(cix);
+    std::lock_guard<std::mutex> accel_lock(ix->accel_mu);
     if (!ix->table_entries || ix->accel_failed || ix->first_dup != UINT64_MAX || !ix->windows.empty()) return {};
     if (ix->ranktab) return accel_wait(ctx, ix);
     cph_ctx* bctx = accel_ctx(ctx, ix);
@@ -299,7 +302,7 @@ Status index_ensure_ranktab(cph_ctx* ctx, const cph_index* cix) {
     if (!accel_alloc(bctx, ix, &t, nblocks * sizeof(uint2))) return {};
     CPH_HIP_TRY(hipMemsetAsync(t.get(), 0, nblocks * sizeof(uint2), bctx->stream));
     {
-        ProfScope ps(bctx, "k_build_ranktab", (double)n * (ix->codec.key32 ? 4.0 : 8.0) + 2.0 * 8.0 * (double)nblocks);
+        ProfScope ps(ctx == bctx ? bctx : nullptr, "k_build_ranktab", (double)n * (ix->codec.key32 ? 4.0 : 8.0) + 2.0 * 8.0 * (double)nblocks);
         const dim3 grid(grid_for_items(n)), block(256);
         if (ix->codec.key32)
             hipLaunchKernelGGL(k_build_ranktab<uint32_t>, grid, block, 0, bctx->stream, ix->sorted_codes.as<uint32_t>(), n, t.as<uint2>());
@@ -434,6 +437,7 @@ bool index_wants_hash(const cph_index* ix) { return ix->nrows != 0 && ix->table_
 
 Status index_ensure_hash(cph_ctx* ctx, const cph_index* cix) {
     cph_index* ix = const_cast<cph_index*>(cix);
+    std::lock_guard<std::mutex> accel_lock(ix->accel_mu);
     if (!index_wants_hash(ix) || ix->accel_failed) return {};
     if (ix->hash_mode != kHashNone) return accel_wait(ctx, ix);
     cph_ctx* bctx = accel_ctx(ctx, ix);
@@ -448,7 +452,7 @@ Status index_ensure_hash(cph_ctx* ctx, const cph_index* cix) {
     if (nsec > 0xFFFFFFFFull) nsec = 0xFFFFFFFFull;
     DevBuf t, flag;
     if (!accel_alloc(bctx, ix, &t, nsec * 64)) return {};
-    CPH_TRY(flag.alloc(&bctx->pool, sizeof(uint32_t)));
+    if (!accel_alloc(bctx, ix, &flag, sizeof(uint32_t))) return {};
     CPH_HIP_TRY(hipMemsetAsync(t.get(), 0xFF, nsec * 64, bctx->stream));
     CPH_HIP_TRY(hipMemsetAsync(flag.get(), 0, sizeof(uint32_t), bctx->stream));
     const CodesView cv{ix->sorted_codes.get(), n, ix->codec.key32 ? 1 : nw, ix->codec.key32 ? 1 : 0};
@@ -457,7 +461,7 @@ Status index_ensure_hash(cph_ctx* ctx, const cph_index* cix) {
     uint4* sec = t.as<uint4>();
     uint32_t* fl = flag.as<uint32_t>();
     {
-        ProfScope ps(bctx, "k_hash_build", (double)n * (8.0 * nw + 4.0) + 64.0 * (double)n);
+        ProfScope ps(ctx == bctx ? bctx : nullptr, "k_hash_build", (double)n * (8.0 * nw + 4.0) + 64.0 * (double)n);
         if (mode == kHashK1) hipLaunchKernelGGL(k_hash_build<kHashK1>, grid, block, 0, bctx->stream, cv, ix->perm.as<uint32_t>(), unique, sec, (uint32_t)nsec, fl);
         else if (mode == kHashK3) hipLaunchKernelGGL(k_hash_build<kHashK3>, grid, block, 0, bctx->stream, cv, ix->perm.as<uint32_t>(), unique, sec, (uint32_t)nsec, fl);
         else hipLaunchKernelGGL(k_hash_build<kHashTag>, grid, block, 0, bctx->stream, cv, ix->perm.as<uint32_t>(), unique, sec, (uint32_t)nsec, fl);
@@ -470,8 +474,14 @@ Status index_ensure_hash(cph_ctx* ctx, const cph_index* cix) {
     }
     if (mode == kHashTag) {
         // two distinct keys with one 64-bit tag (about n^2 / 2^65: 3e-6 at 1e7 rows): no hash table for this index
-        uint32_t collided = 0;
-        CPH_TRY(read_device_value(bctx, fl, &collided));
+        // (read into a local: the pinned scratch of the index's ctx may be in use by its own thread; a failed read-back is
+        // no error of the Join either — the sorted codes answer every probe)
+        uint32_t collided = 1;
+        if (hipMemcpyAsync(&collided, fl, sizeof collided, hipMemcpyDeviceToHost, bctx->stream) != hipSuccess ||
+            hipStreamSynchronize(bctx->stream) != hipSuccess) {
+            (void)hipGetLastError();
+            collided = 1;
+        }
         if (collided) {
             ix->accel_failed = true;
             return {};

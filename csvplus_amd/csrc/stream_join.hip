@@ -276,9 +276,11 @@ CPH_API int32_t cph_stream_join_set_positions(cph_stream_join* sj, int32_t on) {
     cph_ctx* ctx = sj->parent;
     if (!sj->fifo.empty() || sj->submit_seq != 0) return sj_fail(ctx, CPH_ERR_INVALID, "cph_stream_join_set_positions: call before the first submit");
     if (hipSetDevice(ctx->device) != hipSuccess) return sj_fail(ctx, CPH_ERR_HIP, "hipSetDevice failed");
-    if (on && !sj->general) {   // the fused kernel then looks positions up in the rank tables: build them now, once
+    if (on) {   // positions are looked up in the rank tables (the fused kernel; the general chain for duplicate-free indexes over
+                // a dense code space): build them now, once, on this thread — the slot workers then only read the indexes
+                // (index_ensure_* is locked per index, so a worker asking again is safe; it just must not pay for the build)
         for (int s = 0; s < sj->nsteps; s++) {
-            Status st = index_ensure_ranktab(ctx, sj->index[s]);
+            Status st = index_ensure_ranktab(ctx, sj->index[s]);   // a no-op for indexes that do not qualify
             if (!st.ok()) return sj_fail(ctx, st.code, st.msg);
         }
         (void)hipStreamSynchronize(ctx->stream);

@@ -146,6 +146,10 @@ CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
  *                   workgroup and one synchronisation (small_build.hip); 0 = always the general path
  *   "probe_hash_rows"  2 / 4: rows per phase of the generic hash probe (default 2)
  *   "chain_rank_lds"  0 / 1: a Join that reports positions copies the rank tables of small indexes into LDS (default 1)
+ *   "chain_arith"   0 / 1 (default 1): the fused chained Join encodes fixed-width key columns over contiguous alphabets
+ *                   (decimal ids) arithmetically — one aligned 8-byte load and a dot product instead of a LUT walk (A/B switch)
+ *   "chain_identity" 0 / 1 (default 1): reporting positions, an index whose code space has exactly as many states as the
+ *                   index has rows needs no lookup: the position of a key is its code (A/B switch)
  *   "pool_reserve_mb"  reserves ONE device slab of that many MiB now; later requests are carved out of it first
  *                   (first fit, coalesced on release) and only fall back to hipMalloc when it cannot serve them —
  *                   a one-shot caller pays its device allocations here, not inside its first call
@@ -612,9 +616,11 @@ CPH_API int32_t cph_index_get_info(const cph_index* index, cph_index_info* info)
  * the first Join does not pay for it.
  *
  * Sharing an index between ctxs: the structures are built on the INDEX's ctx (its stream, its pool) whatever ctx
- * runs the Join, and a Join on another ctx of the same device orders its stream behind that build.  A ctx is
- * single-threaded: two threads with a ctx each may join against one index at the same time only once its lookup
- * structure exists — call cph_index_prepare_join first.
+ * runs the Join, and a Join on another ctx of the same device orders its stream behind that build.  Two threads
+ * with a ctx each may join against one index at the same time: the lazy build is serialised per index and the
+ * index ctx's device pool is locked (since round 4; cph_index_prepare_join remains the way to keep the build out
+ * of the first Join).  The index's OWN ctx must not be destroyed — nor the index itself — while another thread joins
+ * against it.
  */
 CPH_API int32_t cph_index_prepare_join(cph_index* index, int32_t chained);
 

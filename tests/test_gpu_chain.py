@@ -295,3 +295,101 @@ def test_profile_only_times_one_kernel(ctx):
     ctx.profile(False)
     one()
     assert ctx.profile_read(reset=True) == {}
+
+
+# ---- lean steps of the fused kernel (round 4): fixed-width 8-byte stream keys over contiguous alphabets are encoded
+# arithmetically (codec_device.hpp: ArithPlan) and, reporting positions, answered from the code itself when the index
+# fills its code space (identity) or from a rank table ----------------------------------------------------------------
+def _fixed8(vals):
+    col = StrCol.from_values(vals)
+    assert col.fixed_width == 8
+    return col
+
+
+def _nasty_fixed8_probes(rng, good, m):
+    """Stream keys for an index of decimal 8-byte ids: hits, misses inside the alphabets, and bytes chosen to trip a
+    bytewise-parallel range check — just below '0', just above '9', NUL, 0x7F, 0x80, 0xFF, and pairs where a borrow /
+    carry out of one byte would repair or spoil its neighbour."""
+    out = [good[i] for i in rng.integers(0, len(good), m)]
+    bad_bytes = [0x2F, 0x3A, 0x00, 0x7F, 0x80, 0xFF, 0x30 + 10, 0x20, 0xB0, 0xC6]
+    for j in range(0, m, 3):
+        v = bytearray(out[j])
+        p = int(rng.integers(0, 8))
+        v[p] = bad_bytes[int(rng.integers(0, len(bad_bytes)))]
+        if j % 2 and p + 1 < 8:
+            v[p + 1] = [0x30, 0x39, 0x2F, 0x3A][int(rng.integers(0, 4))]   # neighbour at the edge of its range
+        out[j] = bytes(v)
+    for j in range(1, m, 7):   # in-alphabet misses
+        out[j] = b"%08d" % int(rng.integers(0, 10 ** 8))
+    return out
+
+
+@pytest.mark.parametrize("dense", [True, False])
+def test_chain_lean_step_validity(ctx, dense):
+    """One lean step.  dense: the index holds every code of its code space (identity, no lookup); otherwise a rank
+    table.  Both output modes against the oracle (check_chain), with adversarial stream bytes."""
+    rng = np.random.default_rng(41 if dense else 42)
+    n = 40_000
+    ids = rng.permutation(n) if dense else rng.permutation(3 * n)[:n] + 20_000_000
+    keys = [b"%08d" % int(i) for i in ids]
+    probes = _nasty_fixed8_probes(rng, keys, 150_000)
+    ch = check_chain(ctx, [[_fixed8(keys)]], [_fixed8(probes)], probe_base=7)
+    assert 0 < ch.nrows < len(probes)
+
+
+def test_chain_lean_masks(ctx):
+    """Two- and three-step chains with the lean step first, last, everywhere; letters as well as digits (contiguous
+    ranges other than '0'..'9'), and an index whose first positions are constant."""
+    rng = np.random.default_rng(43)
+    m = 120_000
+    a = [b"%08d" % int(i) for i in rng.permutation(90_000)[:60_000]]
+    b = [b"k%d" % int(i) for i in rng.permutation(3000)[:2000]]                     # variable length: never lean
+    c = [bytes(rng.integers(ord("a"), ord("h") + 1, 8).astype(np.uint8)) for _ in range(30_000)]
+    c = sorted(set(c))
+    ka = _fixed8(_nasty_fixed8_probes(rng, a, m))
+    kb = StrCol.from_values([b"k%d" % int(i) for i in rng.integers(0, 3300, m)])
+    kc_vals = [c[i] for i in rng.integers(0, len(c), m)]
+    kc_vals[::5] = [bytes(rng.integers(ord("a"), ord("j") + 1, 8).astype(np.uint8)) for _ in kc_vals[::5]]
+    kc_vals[::11] = [b"abc\x00defg"] * len(kc_vals[::11])
+    kc = _fixed8(kc_vals)
+    A, B, C = [_fixed8(a)], [StrCol.from_values(b)], [_fixed8(c)]
+    check_chain(ctx, [A, B], [ka, kb])          # mask 01
+    check_chain(ctx, [B, A], [kb, ka])          # mask 10
+    check_chain(ctx, [A, C], [ka, kc])          # mask 11
+    check_chain(ctx, [A, C, A], [ka, kc, ka])   # three steps, all lean
+    check_chain(ctx, [A, B, C], [ka, kb, kc])   # three steps, one not lean: the general kernel
+
+
+def test_chain_lean_needs_aligned_fixed8(ctx):
+    """The same keys handed over as a device column that starts at an odd address, and as a variable-length column:
+    not lean, same result."""
+    import torch
+
+    rng = np.random.default_rng(44)
+    keys = [b"%08d" % int(i) for i in rng.permutation(50_000)]
+    probes = _nasty_fixed8_probes(rng, keys, 60_000)
+    ix = DeviceIndex(ctx, [_fixed8(keys)])
+    oix = orc.OracleIndex([_fixed8(keys)])
+    col = _fixed8(probes)
+    want = oix.join([col])
+    raw = torch.zeros(col.data.nbytes + 24, dtype=torch.uint8, device="cuda:0")
+    for shift in (0, 1, 4):
+        raw[shift: shift + col.data.nbytes].copy_(torch.from_numpy(col.data))
+        dcol = StrCol(raw[shift:], None, col.nrows, 32, N.CPH_MEM_DEVICE, fixed_width=8)
+        chp = join_chain(ctx, [(ix, [dcol])], positions=True)
+        np.testing.assert_array_equal(chp.stream_row, want["probe_idx"])
+        np.testing.assert_array_equal(ix.perm()[chp.build_row(0)], want["build_row"])
+        chp.release()
+    chv = join_chain(ctx, [(ix, [col.as_variable()])], positions=True)
+    np.testing.assert_array_equal(chv.stream_row, want["probe_idx"])
+    np.testing.assert_array_equal(ix.perm()[chv.build_row(0)], want["build_row"])
+    # A/B switches: the LUT walk and the rank-table lookup give the same answer
+    from csvplus_amd import Context
+    c2 = Context(0)
+    c2.set_option("chain_arith", 0)
+    c2.set_option("chain_identity", 0)
+    ix2 = DeviceIndex(c2, [_fixed8(keys)])
+    ch2 = join_chain(c2, [(ix2, [col])], positions=True)
+    np.testing.assert_array_equal(ch2.stream_row, want["probe_idx"])
+    np.testing.assert_array_equal(ix2.perm()[ch2.build_row(0)], want["build_row"])
+    c2.close()
