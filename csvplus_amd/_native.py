@@ -96,7 +96,7 @@ class cph_index_info(C.Structure):
         ("hash_mode", C.c_int32),
         ("hash_bytes", C.c_uint64),
         ("build_path", C.c_int32),
-        ("reserved_", C.c_int32),
+        ("split", C.c_int32),
     ]
 
 

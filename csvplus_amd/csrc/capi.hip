@@ -395,6 +395,8 @@ struct BuildJob {
     GroupSpec spec;              // speculative dictionaries (codec_try_groups)
     bool small = false;          // one-launch build (small_build.hip): no statistics pass, no second synchronisation
     SmallBufs sbufs;
+    bool no_split = false;       // second attempt after a split codec met a row it could not code (keycodec.hip: codec_try_split)
+    DevBuf split_miss;           // u32 raised by the encode kernel of a split codec; read back with the first duplicate
 };
 
 static Status build_phase1(cph_ctx* ctx, const cph_strcol* keycols, int32_t nkeycols, BuildJob* job) {
@@ -464,23 +466,44 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
     for (size_t i = 0; i < nj; i++)
         if (status[i].ok() && !jobs[i].small) status[i] = build_phase2(ctx, &jobs[i], stats_host[i].data());
     // ---- sync 2: first duplicates ----
+    std::vector<size_t> resplit;   // jobs whose split codec met a row it could not code: once more without the split
     if (any_general) {
-        s = ensure_pinned_scratch(ctx, sizeof(uint32_t) * nj + 64);
+        s = ensure_pinned_scratch(ctx, 2 * sizeof(uint32_t) * nj + 64);
         if (!s.ok()) return fail_all(s);
         uint32_t* fd = static_cast<uint32_t*>(ctx->pinned_scratch);
+        uint32_t* sm = fd + nj;
         for (size_t i = 0; i < nj; i++) {
             if (!status[i].ok() || jobs[i].small) continue;
             hipError_t e = hipMemcpyAsync(&fd[i], jobs[i].ix->first_dup_dev.get(), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+            sm[i] = 0;
+            if (e == hipSuccess && jobs[i].split_miss)
+                e = hipMemcpyAsync(&sm[i], jobs[i].split_miss.get(), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
             if (e != hipSuccess) status[i] = {CPH_ERR_HIP, std::string("first-duplicate read-back: ") + hipGetErrorString(e)};
         }
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail_all({CPH_ERR_HIP, "hipStreamSynchronize failed"});
         for (size_t i = 0; i < nj; i++) {
             if (!status[i].ok() || jobs[i].small) continue;
             cph_index* ix = jobs[i].ix;
+            if (sm[i]) { resplit.push_back(i); continue; }
             ix->first_dup = fd[i] != 0xFFFFFFFFu ? (uint64_t)fd[i] : UINT64_MAX;
             ix->first_dup_dev.reset();
             index_plan_table(ix);
         }
+    }
+    for (size_t i : resplit) {
+        std::vector<BuildJob> one;
+        one.push_back(std::move(jobs[i]));
+        std::vector<Status> st1(1);
+        BuildJob& j = one[0];
+        j.no_split = true;
+        j.split_miss.reset();
+        cph_index* ix = j.ix;
+        ix->codec = CodecHost{};
+        ix->codec_dev.reset(); ix->sorted_codes.reset(); ix->perm.reset(); ix->first_dup_dev.reset();
+        st1[0] = codec_stats_launch(ctx, j.dcols, j.nkeycols, &j.stats_dev);
+        if (st1[0].ok()) build_run(ctx, one, st1);
+        status[i] = st1[0];
+        jobs[i] = std::move(one[0]);
     }
     // keys the one-workgroup build could not take (more than kSmallMaxPos byte positions, codes of several words)
     for (size_t i : retry) {
@@ -611,7 +634,13 @@ static Status build_phase2(cph_ctx* ctx, BuildJob* job, const void* stats_host) 
     for (const auto& s : stats) positions += s.maxlen;
     if (positions > (uint64_t)kMaxKeyBytes) return build_multi_window(ctx, job, stats);
     CPH_TRY(codec_build(stats, &ix->codec));
-    CPH_TRY(codec_try_groups(ctx, dcols, nkeycols, n, &ix->codec, &job->spec));   // only acts on codes of several words
+    if (!job->no_split) CPH_TRY(codec_try_split(ctx, dcols, nkeycols, n, stats, &ix->codec));   // only acts on codes beyond 32 bits
+    if (ix->codec.has_split()) {
+        CPH_TRY(job->split_miss.alloc(&ctx->pool, sizeof(uint32_t)));
+        CPH_HIP_TRY(hipMemsetAsync(job->split_miss.get(), 0, sizeof(uint32_t), ctx->stream));
+    } else {
+        CPH_TRY(codec_try_groups(ctx, dcols, nkeycols, n, &ix->codec, &job->spec));   // only acts on codes of several words
+    }
     CPH_TRY(codec_upload(ctx, ix->codec, &ix->codec_dev));
     return build_encode_sort(ctx, job);
 }
@@ -643,7 +672,7 @@ static Status build_encode_sort(cph_ctx* ctx, BuildJob* job) {
             eh.bins = 1u << plan.rbits;
             eh.counts = counts.as<uint32_t>();
         }
-        CPH_TRY(codec_encode_build(ctx, cd, ix->codec_dev, dcols, n, ka.get(), &eh, &job->spec));
+        CPH_TRY(codec_encode_build(ctx, cd, ix->codec_dev, dcols, n, ka.get(), &eh, &job->spec, job->split_miss.as<uint32_t>()));
         if (job->spec.active) {
             // speculative dictionaries (from a sample of the rows): did the encode kernel meet a window they lack?  Then
             // it has added every such window to the device sets: rebuild the codec from the now complete sets and encode
@@ -682,7 +711,7 @@ static Status build_encode_sort(cph_ctx* ctx, BuildJob* job) {
         // multi-word codes: LSD over the words, least significant word first
         DevBuf all;
         CPH_TRY(all.alloc(&ctx->pool, (size_t)cd.nwords * n * sizeof(uint64_t)));
-        CPH_TRY(codec_encode_build(ctx, cd, ix->codec_dev, dcols, n, all.get()));
+        CPH_TRY(codec_encode_build(ctx, cd, ix->codec_dev, dcols, n, all.get(), nullptr, nullptr, job->split_miss.as<uint32_t>()));
         CPH_TRY(sort_words_lsd(ctx, ix, all.as<uint64_t>(), cd.nwords, cd.word_bits, n, va, vb));
     }
 
@@ -777,6 +806,7 @@ CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value
     else if (k == "stream_zero_copy_out") ctx->stream_zero_copy_out = value != 0;
     else if (k == "chain_nt_streams") ctx->chain_nt_streams = value < 0 || value > 2 ? 0 : (int)value;
     else if (k == "chain_rank_lds") ctx->chain_rank_lds = value != 0;
+    else if (k == "codec_split") ctx->codec_split = value != 0;
     else if (k == "chain_arith") ctx->chain_arith = value != 0;
     else if (k == "chain_identity") ctx->chain_identity = value != 0;
     else if (k == "probe_hash_rows") ctx->probe_hash_rows = value == 4 ? 4 : 2;
@@ -1324,7 +1354,8 @@ CPH_API int32_t cph_index_get_info(const cph_index* ix, cph_index_info* info) {
     info->sort_passes = ix->sort_passes;
     info->direct_table = ix->table_entries ? 1 : 0;
     info->table_entries = ix->table_entries;
-    info->dict_entries = (int32_t)ix->codec.dict.size();
+    info->dict_entries = (int32_t)(ix->codec.dict.size() + ix->codec.wdict.size());
+    info->split = ix->codec.has_split() ? 0x100 * (1 + ix->codec.split_col) + ix->codec.split_byte : 0;
     info->lookup_built = (ix->table ? 1 : 0) | (ix->rowtab ? 2 : 0) | (ix->hash_mode ? 4 : 0) | (ix->ranktab ? 8 : 0);
     info->hash_mode = ix->hash_mode;
     info->hash_bytes = (uint64_t)ix->hash_sectors * 64;

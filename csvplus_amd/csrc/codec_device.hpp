@@ -11,9 +11,41 @@ struct ColsArg {
     DevCol c[kMaxKeyCols];
 };
 
+// Offset of the first byte `d` in the value [begin, begin + len) of `data`, len when it holds none.  Generic and
+// unhurried (a loop over the value's 8-byte chunks): the virtual columns of a split codec on the probe side; the build
+// kernels of keycodec.hip find the delimiter in registers.
+__device__ __forceinline__ uint64_t find_first_byte(const uint8_t* data, uint64_t begin, uint64_t len, uint32_t d) {
+    const uint64_t dv = 0x0101010101010101ull * (uint64_t)(d & 0xFFu);
+    for (uint64_t j = 0; 8 * j < len; j++) {
+        const uint64_t x = load_value_chunk(data, begin, len, (int)j) ^ dv;
+        const uint64_t t = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;   // lowest set bit: the first zero byte of x (exact)
+        if (t) {
+            const uint64_t pos = 8 * j + (uint64_t)((__ffsll((long long)t) - 1) >> 3);
+            return pos < len ? pos : len;
+        }
+    }
+    return len;
+}
+
 // [begin, begin+len) of value `row` inside col.data (of the column's SEGMENT when the column is one: DevCol.skip /
-// .take): no memory access for fixed-width columns.
+// .take; of its prefix / suffix part when it is a virtual column of a split codec): no memory access for plain
+// fixed-width columns.
+__device__ __forceinline__ void value_span_whole(const DevCol& col, uint64_t row, uint64_t* begin, uint64_t* len);
 __device__ __forceinline__ void value_span(const DevCol& col, uint64_t row, uint64_t* begin, uint64_t* len) {
+    value_span_whole(col, row, begin, len);
+    if (col.split) {   // uniform
+        const uint64_t b = *begin, l = *len;
+        const uint64_t at = find_first_byte(col.data, b, l, col.split);
+        const uint64_t head = at < l ? at + 1 : l;   // bytes of the prefix part
+        if (col.part == 0) {
+            *len = head;
+        } else {
+            *begin = b + head;
+            *len = l - head;
+        }
+    }
+}
+__device__ __forceinline__ void value_span_whole(const DevCol& col, uint64_t row, uint64_t* begin, uint64_t* len) {
     uint64_t b, l;
     if (col.fixed_width) {
         b = row * (uint64_t)col.fixed_width;
@@ -49,6 +81,9 @@ struct CodecView {
     const CPH_LDS int32_t* hash_off;
     const CPH_LDS int32_t* hash_bits;
     const CPH_LDS uint16_t* hash;
+    // split codec (hdr->wide_pos >= 0): the prefix column's whole-value dictionary
+    const CPH_LDS WideKey* wide;
+    const CPH_LDS uint16_t* wide_hash;
 };
 
 // Cooperative copy of the codec block (global) into dynamic LDS; returns a view.
@@ -74,7 +109,36 @@ __device__ __forceinline__ CodecView codec_load_to_lds(const uint8_t* g_blob, ui
     v.hash_off = (const CPH_LDS int32_t*)(l + v.hdr->hashoff_off);
     v.hash_bits = (const CPH_LDS int32_t*)(l + v.hdr->hashbits_off);
     v.hash = (const CPH_LDS uint16_t*)(l + v.hdr->hash_off);
+    v.wide = (const CPH_LDS WideKey*)(l + v.hdr->wide_off);
+    v.wide_hash = (const CPH_LDS uint16_t*)(l + v.hdr->wide_hash_off);
     return v;
+}
+
+// Rank of a whole value (at most kWideBytes bytes, zero padded into four words) in the codec's wide dictionary, -1 when
+// it is not there.  One hash, one u16 slot, the entry's words compared.
+__device__ __forceinline__ int wide_lookup(const CodecView& cv, uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3, uint32_t len) {
+    const uint32_t mask = (1u << cv.hdr->wide_hash_bits) - 1u;
+    uint32_t sl = (uint32_t)wide_hash(w0, w1, w2, w3, len) & mask;
+    for (;;) {
+        const uint32_t e = cv.wide_hash[sl];
+        if (e == 0) return -1;
+        const CPH_LDS WideKey* k = cv.wide + (e - 1);
+        if (k->len == len && k->w[0] == w0 && k->w[1] == w1 && k->w[2] == w2 && k->w[3] == w3) return (int)(e - 1);
+        sl = (sl + 1) & mask;
+    }
+}
+// The value [begin, begin + len) of col.data as a WideKey's words (len <= kWideBytes).
+__device__ __forceinline__ void wide_words(const uint8_t* data, uint64_t begin, uint64_t len, uint64_t (&w)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        uint64_t v = 0;
+        if (8ull * (uint64_t)j < len) {
+            v = load_value_chunk(data, begin, len, j);
+            const uint64_t nb = len - 8ull * (uint64_t)j;
+            if (nb < 8) v &= (1ull << (8 * nb)) - 1ull;
+        }
+        w[j] = v;
+    }
 }
 
 // Sum of pre-multiplied LUT entries over the leading columns: the whole (single-word) code in
@@ -487,7 +551,16 @@ __device__ __forceinline__ bool encode_key_groups(const CodecView& cv, const Col
             const int p = p0 + q;
             const uint32_t kind = cv.unit[p];
             uint64_t r = 0;
-            if (kind == kUnitHead) {
+            if (kind == kUnitWide) {   // the whole value through the prefix dictionary of a split codec
+                int rank = -1;
+                if (len <= (uint64_t)kWideBytes) {
+                    uint64_t w[4];
+                    wide_words(col.data, begin, len, w);
+                    rank = wide_lookup(cv, w[0], w[1], w[2], w[3], (uint32_t)len);
+                }
+                if (rank < 0) valid = false;
+                r = rank < 0 ? 0ull : (uint64_t)rank;
+            } else if (kind == kUnitHead) {
                 int span = 1;
                 while (span < kGroupSpan && q + span < maxlen && cv.unit[p + span] == kUnitAbsorbed) span++;
                 const uint64_t joint = v.raw(col, q, span);

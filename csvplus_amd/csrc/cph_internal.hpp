@@ -120,6 +120,35 @@ private:
 // ---- key codec description (host + device copies) -------------------------------------
 namespace cph {
 
+// A whole value of at most 32 bytes as a dictionary key: its bytes little-endian in four words, zero padded, + its length.
+constexpr int kWideBytes = 32;
+constexpr int kWideDictMax = 1024;          // distinct prefixes a split codec takes (40 KiB of LDS)
+struct WideKey {
+    uint64_t w[4];
+    uint32_t len;
+    uint32_t pad_;
+};
+#if defined(__HIPCC__)
+#define CPH_HD2 __host__ __device__
+#else
+#define CPH_HD2
+#endif
+// 64-bit hash of a WideKey (host and device agree): the low half picks the slot of the codec block's lookup table, the
+// whole value is the tag under which the statistics pass collects the distinct prefixes.  Never 0 (0 = empty slot).
+CPH_HD2 inline uint32_t wide_rotl(uint32_t v, int r) { return (v << r) | (v >> (32 - r)); }
+CPH_HD2 inline uint64_t wide_hash(uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3, uint32_t len) {
+    const uint32_t x = (uint32_t)w0 ^ wide_rotl((uint32_t)w1, 9) ^ wide_rotl((uint32_t)w2, 18) ^ wide_rotl((uint32_t)w3, 27) ^ (len * 0x01000193u);
+    const uint32_t y = (uint32_t)(w0 >> 32) ^ wide_rotl((uint32_t)(w1 >> 32), 7) ^ wide_rotl((uint32_t)(w2 >> 32), 14) ^ wide_rotl((uint32_t)(w3 >> 32), 21);
+    uint32_t h1 = (x * 0x9E3779B1u) ^ (y * 0x85EBCA6Bu);
+    h1 ^= h1 >> 15;
+    h1 *= 0xC2B2AE35u;
+    h1 ^= h1 >> 13;
+    uint32_t h2 = (x * 0xCC9E2D51u + wide_rotl(y, 13)) * 0x1B873593u;
+    h2 ^= h2 >> 16;
+    const uint64_t h = (uint64_t)h1 | ((uint64_t)h2 << 32);
+    return h ? h : 1ull;
+}
+
 // How the key columns map to the mixed-radix code (see keycodec.hip).
 struct CodecHost {
     int32_t ncols = 0;
@@ -146,10 +175,24 @@ struct CodecHost {
     std::vector<int32_t>  dict_len;         // [npos] head: number of entries
     std::vector<uint64_t> dict;             // raw keys of all heads, each head's in rank order
     bool has_groups() const { return !unit.empty(); }
+    // Delimiter split (round 4, keycodec.hip "split codec"): key column `split_col` of the TABLE is coded as two virtual
+    // columns — the prefix up to and including the first byte `split_byte` (the whole value when it holds none) and the
+    // suffix behind it.  No prefix is a proper prefix of another one that ends in the delimiter, so comparing
+    // (prefix, suffix) tuples with strings.Compare equals comparing the values (csvplus.go:794-807 order kept).
+    // ncols / col_start / col_maxlen / col_minlen then describe the VIRTUAL columns (one more than the index has key
+    // columns: codec_virtual_cols maps), the prefix column is one kUnitWide head (radix = number of distinct prefixes,
+    // rank = index into wdict, which lists them in strings.Compare order) followed by absorbed positions, the suffix
+    // column is coded per position like any column.  Fields whose digits FLOAT behind a variable-length head
+    // ("Smith/Amelia#12345") cost their information, not their byte positions: BASELINE config 3 codes in 25 bits.
+    int32_t split_col = -1;                 // key column of the table that is split (-1: none)
+    uint8_t split_byte = 0;
+    std::vector<WideKey> wdict;             // distinct prefixes in rank order
+    bool has_split() const { return split_col >= 0; }
+    int32_t virtual_cols(int32_t real_cols) const { return real_cols + (has_split() && split_col < real_cols ? 1 : 0); }
 };
 constexpr int kGroupSpan = 7;               // positions per group: 7 bytes + a length fit one 64-bit raw key
 constexpr int kGroupDictMax = 4096;         // dictionary entries per index (32 KiB of LDS)
-enum : uint8_t { kUnitPos = 0, kUnitHead = 1, kUnitAbsorbed = 2 };
+enum : uint8_t { kUnitPos = 0, kUnitHead = 1, kUnitAbsorbed = 2, kUnitWide = 3 };   // kUnitWide: head of a whole-column dictionary (split codec)
 
 // Device-side codec block, laid out for one cooperative copy into LDS:
 //   header (CodecDevHeader) | mult[npos] u64 | word_of[npos] u8 (padded) | lut[npos*257] u16
@@ -180,6 +223,15 @@ struct CodecDevHeader {
     int32_t hashoff_off;   // i32[npos]
     int32_t hashbits_off;  // i32[npos]
     int32_t hash_off;      // u16[]
+    // split codec (all 0 / -1 when there is none): the whole-column dictionary of the prefix column
+    int32_t wide_pos;      // position of the kUnitWide head, -1: none
+    int32_t wide_n;        // entries
+    int32_t wide_off;      // WideKey[wide_n], rank order
+    int32_t wide_hash_off; // u16[1 << wide_hash_bits]: rank + 1 (0 = empty), slot = low bits of wide_hash, linear probing
+    int32_t wide_hash_bits;
+    int32_t split_vcol;    // virtual column that is the prefix (its successor is the suffix), -1: none
+    int32_t split_byte;
+    int32_t pad_[1];
 };
 #if defined(__HIPCC__)
 #define CPH_HD __host__ __device__
@@ -246,6 +298,7 @@ struct cph_ctx {
     int probe_hash_rows = 2;       // rows per phase of the generic hash probe (2 / 4): 4 rows need 164 VGPRs (3 waves per SIMD) and measured 20 % slower
     int join_hash = 1;             // 0: indexes of this ctx never get a hash table (A/B switch: sorted search instead)
     int codec_debug = 0;           // prints the window choice of codec_try_groups to stderr
+    int codec_split = 1;           // the delimiter split of keycodec.hip is tried (A/B switch; 0: never)
     int plan_threads = 0, gstats_threads = 0;   // tuning: workgroup sizes of k_encode_build_plan / k_group_stats (0: default)
     int speculative_groups = 1;    // dictionaries of large inputs from a sample, completed by the encode kernel (keycodec.hip):
                                    // 0 never, 1 when the sample holds no value seen only once, 2 always
@@ -346,7 +399,15 @@ struct DevCol {
     // the build side's longest stays longer than the window's maxlen and is recognised as absent).
     uint32_t skip = 0, take = 0xFFFFFFFFu;
     bool segmented() const { return skip != 0 || take != 0xFFFFFFFFu; }
+    // virtual column of a split codec (CodecHost::split_col): split = 0x100 | delimiter byte, part 0 = the value up to and
+    // including its first delimiter (all of it when it holds none), part 1 = what follows the first delimiter
+    uint16_t split = 0;
+    uint16_t part = 0;
 };
+// The key columns as the codec sees them: `real` = the table's (or the stream's) leading nreal key columns; a split
+// codec gets its split column twice (prefix part, suffix part).  Returns the number of virtual columns written to out
+// (room for kMaxKeyCols).
+int codec_virtual_cols(const CodecHost& codec, const DevCol* real, int nreal, DevCol* out);
 
 // keycodec.hip
 struct ColStats {              // per column, produced by one pass over the column
@@ -389,8 +450,13 @@ struct EncodeHist {
     uint32_t* counts = nullptr;   // device [bins][ntiles], digit-major
     bool done = false;
 };
+// cols = the TABLE's key columns (a split codec's virtual columns are formed inside).  miss (optional, device u32): set
+// when a row did not code (split codecs only: see codec_try_split).
 Status codec_encode_build(cph_ctx* ctx, const CodecHost& codec, const DevBuf& codec_dev, const DevCol* cols,
-                          uint64_t n, void* out_codes, const EncodeHist* hist = nullptr, const GroupSpec* spec = nullptr);
+                          uint64_t n, void* out_codes, const EncodeHist* hist = nullptr, const GroupSpec* spec = nullptr,
+                          uint32_t* miss = nullptr);
+// The delimiter split (keycodec.hip "split codec"): tried when the plain code does not fit 32 bits.
+Status codec_try_split(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t n, const std::vector<ColStats>& stats, CodecHost* codec);
 // Host-side encoding of literal values (cph_index_find).  Returns false when a
 // value cannot occur in the index (symbol outside the alphabet / too long).
 bool codec_encode_values_host(const CodecHost& codec, const cph_strval* values, int32_t nvalues,

@@ -159,7 +159,8 @@ static size_t code_bytes(const cph_index* ix) {
 //               | nwindows  > 0:  nwindows x (WindowHeader, CodecBlock)   
 //   CodecBlock = CodecHeader + radix u16[npos] + mult u64[npos] + word_of i32[npos] + lut u16[npos*257]
 //                [+ unit u8[npos] + dict_off i32[npos] + dict_len i32[npos] + dict u64[ndict]   when has_groups]
-constexpr char kMagic[8] = {'C', 'P', 'H', 'I', 'D', 'X', '4', '\n'};
+//                [+ WideKey[nwide]   when split_col >= 0: the prefix dictionary of a split codec, rank order]
+constexpr char kMagic[8] = {'C', 'P', 'H', 'I', 'D', 'X', '5', '\n'};   // 5: split codecs (CodecHeader.split_col / nwide + WideKey[nwide])
 struct IndexHeader {
     char magic[8];
     uint64_t desc_bytes;         // size of the whole descriptor, this header included
@@ -175,6 +176,7 @@ struct WindowHeader {
 struct CodecHeader {
     int32_t ncols, npos, nwords, key32;
     int32_t has_groups, ndict;   // dictionary-coded groups: unit/dict_off/dict_len per position + ndict entries
+    int32_t split_col, split_byte, nwide, reserved_;   // split codec: the table's key column that is cut (-1: none), the delimiter, prefixes
     int32_t col_start[kMaxKeyCols + 1];
     int32_t col_maxlen[kMaxKeyCols];
     int32_t col_minlen[kMaxKeyCols];
@@ -196,6 +198,9 @@ static void codec_block_serialize(const CodecHost& cd, std::vector<uint8_t>* out
     h.key32 = cd.key32 ? 1 : 0;
     h.has_groups = cd.has_groups() ? 1 : 0;
     h.ndict = (int32_t)cd.dict.size();
+    h.split_col = cd.split_col;
+    h.split_byte = cd.split_byte;
+    h.nwide = (int32_t)cd.wdict.size();
     memcpy(h.col_start, cd.col_start, sizeof h.col_start);
     memcpy(h.col_maxlen, cd.col_maxlen, sizeof h.col_maxlen);
     memcpy(h.col_minlen, cd.col_minlen, sizeof h.col_minlen);
@@ -212,6 +217,7 @@ static void codec_block_serialize(const CodecHost& cd, std::vector<uint8_t>* out
         put_bytes(out, cd.dict_len.data(), cd.dict_len.size() * sizeof(int32_t));
         put_bytes(out, cd.dict.data(), cd.dict.size() * sizeof(uint64_t));
     }
+    if (cd.has_split()) put_bytes(out, cd.wdict.data(), cd.wdict.size() * sizeof(WideKey));
 }
 
 void index_desc_serialize(const cph_index* ix, std::vector<uint8_t>* out) {
@@ -262,7 +268,11 @@ static bool codec_block_parse(const uint8_t* p, size_t n, size_t* at, CodecHost*
     memcpy(&h, p + *at, sizeof h);
     *at += sizeof h;
     if (h.ncols < 1 || h.ncols > kMaxKeyCols || h.npos < 0 || h.npos > kMaxKeyBytes || h.nwords < 1 || h.nwords > kMaxWords ||
-        (h.has_groups && (h.ndict < 1 || h.ndict > kGroupDictMax)))
+        (h.has_groups && (h.ndict < 0 || h.ndict > kGroupDictMax || (h.ndict == 0 && h.split_col < 0))))
+        return false;
+    if (h.split_col < -1 || h.split_col >= h.ncols - 1 || (h.split_col >= 0 && (!h.has_groups || h.nwide < 1 || h.nwide > kWideDictMax ||
+                                                                                h.split_byte < 0 || h.split_byte > 255)) ||
+        (h.split_col < 0 && h.nwide != 0))
         return false;
     CodecHost& cd = *out;
     cd = CodecHost{};
@@ -310,8 +320,38 @@ static bool codec_block_parse(const uint8_t* p, size_t n, size_t* at, CodecHost*
                 }
             } else if (u == kUnitAbsorbed) {
                 if (q == 0 || cd.unit[(size_t)q - 1] == kUnitPos || cd.radix[(size_t)q] != 1) return false;
+            } else if (u == kUnitWide) {   // the head of a split codec's prefix column, exactly there
+                if (h.split_col < 0 || q != cd.col_start[h.split_col] || cd.radix[(size_t)q] != h.nwide) return false;
+                for (int i = 1; i < cd.col_maxlen[h.split_col]; i++)
+                    if (q + i >= cd.npos || cd.unit[(size_t)(q + i)] != kUnitAbsorbed) return false;
             } else if (u != kUnitPos) {
                 return false;
+            }
+        }
+    }
+    if (h.split_col >= 0) {
+        cd.split_col = h.split_col;
+        cd.split_byte = (uint8_t)h.split_byte;
+        cd.wdict.resize((size_t)h.nwide);
+        if (!get(cd.wdict.data(), cd.wdict.size() * sizeof(WideKey))) return false;
+        if (cd.col_maxlen[h.split_col] < 1 || cd.col_maxlen[h.split_col] > kWideBytes ||
+            cd.unit[(size_t)cd.col_start[h.split_col]] != kUnitWide)
+            return false;
+        for (size_t i = 0; i < cd.wdict.size(); i++) {   // well formed, in strict strings.Compare order
+            const WideKey& k = cd.wdict[i];
+            if (k.len > (uint32_t)cd.col_maxlen[h.split_col] || k.pad_ != 0) return false;
+            for (uint32_t b = k.len; b < (uint32_t)kWideBytes; b++)
+                if ((k.w[b >> 3] >> (8 * (b & 7))) & 0xFFull) return false;
+            if (i > 0) {
+                const WideKey& a = cd.wdict[i - 1];
+                const uint32_t m = a.len < k.len ? a.len : k.len;
+                int cmp = 0;
+                for (uint32_t b = 0; b < m && cmp == 0; b++) {
+                    const int x = (int)((a.w[b >> 3] >> (8 * (b & 7))) & 0xFFull), y = (int)((k.w[b >> 3] >> (8 * (b & 7))) & 0xFFull);
+                    cmp = x - y;
+                }
+                if (cmp == 0) cmp = (int)a.len - (int)k.len;
+                if (cmp >= 0) return false;
             }
         }
     }
@@ -322,7 +362,7 @@ static bool codec_block_parse(const uint8_t* p, size_t n, size_t* at, CodecHost*
             return false;
     for (int q = 0; q < cd.npos; q++)
         if (cd.word_of[(size_t)q] < 0 || cd.word_of[(size_t)q] >= cd.nwords || cd.radix[(size_t)q] < 1 ||
-            cd.radix[(size_t)q] > ((cd.has_groups() && cd.unit[(size_t)q] == kUnitHead) ? kGroupDictMax : 257))
+            cd.radix[(size_t)q] > ((cd.has_groups() && (cd.unit[(size_t)q] == kUnitHead || cd.unit[(size_t)q] == kUnitWide)) ? kGroupDictMax : 257))
             return false;
     for (size_t i = 0; i < cd.lut.size(); i++)
         if (cd.lut[i] != kLutInvalid && cd.lut[i] >= cd.radix[i / kLutStride]) return false;
@@ -357,7 +397,7 @@ bool index_desc_parse(const uint8_t* p, size_t n, cph_index* ix) {
     size_t at = sizeof h;
     ix->windows.clear();
     if (h.nwindows == 0) {
-        if (!codec_block_parse(p, n, &at, &ix->codec) || ix->codec.ncols != h.nkeycols) return false;
+        if (!codec_block_parse(p, n, &at, &ix->codec) || ix->codec.ncols != ix->codec.virtual_cols(h.nkeycols)) return false;
     } else {
         int words = 0, last_col = 0;
         for (int k = 0; k < h.nwindows; k++) {
@@ -377,7 +417,7 @@ bool index_desc_parse(const uint8_t* p, size_t n, cph_index* ix) {
                 if (w.seg_col[s] < last_col || w.seg_col[s] >= h.nkeycols) return false;
                 last_col = w.seg_col[s];
             }
-            if (!codec_block_parse(p, n, &at, &w.codec) || w.codec.ncols != w.nseg || w.codec.key32) return false;
+            if (!codec_block_parse(p, n, &at, &w.codec) || w.codec.ncols != w.nseg || w.codec.key32 || w.codec.has_split()) return false;
             words += w.codec.nwords;
         }
         ix->codec = ix->windows[0].codec;

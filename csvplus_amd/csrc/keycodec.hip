@@ -542,7 +542,7 @@ static int codec_sort_passes(const CodecHost& c) {
 static bool codec_uses_plan_kernel(const CodecHost& c) {   // k_encode_build_plan: single-word codes with groups
     int units = 0;
     for (int p = 0; p < c.npos; p++) units += c.unit[(size_t)p] != kUnitAbsorbed;
-    return c.has_groups() && c.nwords == 1 && units <= kPlanMaxUnits;
+    return c.has_groups() && !c.has_split() && c.nwords == 1 && units <= kPlanMaxUnits;
 }
 static double group_saved_bits(const CodecHost& cd, int p0, int span, uint32_t count) {   // < 0: unusable
     if (count == 0 || count > (uint32_t)kGroupDictMax) return -1.0;
@@ -775,6 +775,554 @@ Status codec_try_groups(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_
     return {};
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Split codec (round 4).  Per-position alphabets and fixed-position windows both price a field by WHERE its bytes
+// sit; a field that floats behind a variable-length head ("Smith/Amelia#12345": the number starts at byte 10..17)
+// smears its symbols over many positions — BASELINE config 3 carries 23.5 bits of information in 81 bits of
+// per-position code (47 with the dictionary windows above).  The split codec cuts the key column at its first
+// delimiter byte d into two VIRTUAL columns (CodecHost::split_col):
+//   prefix = the bytes up to and including the first d (the whole value when it holds no d)
+//   suffix = what follows
+// and codes the prefix by a dictionary of WHOLE values (kUnitWide: at most kWideDictMax distinct prefixes of at most
+// kWideBytes bytes, ranked in strings.Compare order) and the suffix per byte position relative to the cut.  Order: if
+// two values have different prefixes, neither prefix is a proper prefix of the other unless the shorter one is a whole
+// value without d (then it is a proper prefix of the other VALUE, and sorts first both ways); otherwise they differ at a
+// byte both have, which decides both comparisons alike.  Equal prefixes: the suffixes decide, bytewise.  So comparing
+// (prefix, suffix) tuples == comparing the values (csvplus.go:794-807), and everything behind the codec (words, sort,
+// probe, find) is the multi-column machinery it already was.
+//   k_split_sample   one workgroup per candidate delimiter over the staged sample of the rows: distinct prefixes (64-bit
+//                    tags in an LDS set), suffix alphabets and lengths -> the host picks the byte with the fewest code bits
+//   k_split_stats    all rows once: the prefixes go into a device set (tag claimed by CAS, payload written by the winner;
+//                    a per-workgroup LDS set of the tags already met keeps almost every row on the CU), suffix byte flags
+//                    in LDS as k_col_stats keeps them
+//   (host)           dictionary sorted, suffix LUT, words -> codec block
+//   k_encode_split   all rows again: delimiter found in registers, prefix looked up in the LDS dictionary and VERIFIED
+//                    byte for byte, suffix through the rank LUT; leaves the first radix pass's histogram.  A row whose
+//                    prefix is not in the dictionary (two prefixes with one 64-bit tag in k_split_stats: ~1e-14) raises
+//                    `miss`, and the build starts over without the split.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSplitMaxSuffix = 16;           // suffix byte positions the split codec takes
+constexpr int kSplitMaxValue = 40;            // value bytes the split kernels hold in registers (5 chunks)
+constexpr int kSplitSetSlots = 4096;          // device set of prefix tags: 4 slots per dictionary entry
+constexpr int kSplitSeenSlots = 2048;         // per-workgroup LDS set of tags already met
+constexpr int kSplitRows = 4;                 // rows per thread and iteration
+constexpr int kSplitThreads = 256;
+
+struct SplitSlot {                            // one entry of the device set
+    unsigned long long tag;                   // 0 = empty
+    uint64_t w[4];
+    uint32_t len, pad_;
+};
+struct SplitStats {                           // what k_split_stats / k_split_sample leave behind
+    uint32_t count;                           // distinct prefixes (may exceed the capacity: then the set is incomplete)
+    uint32_t flags;                           // bit 0: a prefix longer than kWideBytes, bit 1: a suffix longer than kSplitMaxSuffix,
+                                              // bit 2: the set ran full
+    uint32_t rows_with;                       // rows that hold the delimiter
+    uint32_t pmin, pmax, smin, smax;          // prefix / suffix lengths
+    uint32_t pad_;
+    uint32_t mask[kSplitMaxSuffix][8];        // byte presence per suffix position
+};
+
+// NCH chunks of a value without a branch (rows past the value's end read base8: load_chunk_nobranch)
+template <int NCH>
+struct ValueRegs {
+    uint64_t c[NCH];
+    uint32_t len;
+    __device__ __forceinline__ void load(const DevCol& col, uint64_t begin, uint64_t l) {
+        const uint64_t p = (uint64_t)(uintptr_t)col.data;
+        const uint8_t* base8 = (const uint8_t*)(uintptr_t)(p & ~7ull);
+        const uint32_t delta = (uint32_t)(p & 7ull);
+        len = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;
+#pragma unroll
+        for (int j = 0; j < NCH; j++) c[j] = load_chunk_nobranch<uint64_t>(base8, delta, begin, len, (uint32_t)j);
+    }
+    // offset of the first byte equal to the bytes of dv (d repeated 8 times), len when there is none
+    __device__ __forceinline__ uint32_t find(uint64_t dv) const {
+        uint32_t at = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = NCH - 1; j >= 0; j--) {
+            const uint64_t x = c[j] ^ dv;
+            const uint64_t t = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
+            const uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
+            const uint32_t pos = lo ? (uint32_t)(__ffs((int)lo) - 1) >> 3 : 4u + ((uint32_t)(__ffs((int)hi) - 1) >> 3);
+            at = t ? 8u * (uint32_t)j + pos : at;
+        }
+        return at < len ? at : len;
+    }
+    // the first four chunks with the bytes from offset n on cleared (n <= 32): a WideKey's words
+    __device__ __forceinline__ void head_words(uint32_t n, uint64_t (&w)[4]) const {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t have = n > 8u * j ? n - 8u * j : 0u;   // bytes of chunk j that belong
+            const uint64_t m = have >= 8u ? ~0ull : ((1ull << (8u * have)) - 1ull);
+            w[j] = j < NCH ? c[j] & m : 0ull;
+        }
+    }
+    // bytes [s, s + 8) and [s + 8, s + 16) of the value (unspecified past its end)
+    __device__ __forceinline__ void window(uint32_t s, uint64_t* w0, uint64_t* w1) const {
+        const uint32_t j0 = s >> 3;
+        uint64_t a = 0, b = 0, d = 0;
+#pragma unroll
+        for (int j = 0; j < NCH; j++) {
+            if ((uint32_t)j == j0) a = c[j];
+            if ((uint32_t)j == j0 + 1) b = c[j];
+            if ((uint32_t)j == j0 + 2) d = c[j];
+        }
+        const uint32_t sh = (s & 7u) * 8u;
+        *w0 = sh ? (a >> sh) | (b << (64u - sh)) : a;
+        *w1 = sh ? (b >> sh) | (d << (64u - sh)) : b;
+    }
+};
+
+// Where a value is cut: plen = bytes of the prefix part (through the first delimiter, or all of it), slen = the rest.
+template <int NCH>
+__device__ __forceinline__ bool split_lengths(const ValueRegs<NCH>& v, uint64_t dv, uint32_t* plen, uint32_t* slen) {
+    const uint32_t at = v.find(dv);
+    *plen = at < v.len ? at + 1u : v.len;
+    *slen = v.len - *plen;
+    return at < v.len;
+}
+
+// LDS: set of tags (kSplitSeenSlots u64) | suffix byte flags (kSplitMaxSuffix * 256 u8)
+template <int NCH>
+__global__ __launch_bounds__(kSplitThreads) void k_split_stats(DevCol col, uint32_t d, uint64_t step, uint64_t n /* rows looked at: 0, step, 2 step, ... */,
+                                                              SplitSlot* __restrict__ slots, SplitStats* __restrict__ out) {
+    __shared__ unsigned long long s_seen[kSplitSeenSlots];
+    __shared__ __attribute__((aligned(16))) uint8_t s_flag[kSplitMaxSuffix * 256];
+    __shared__ uint32_t s_pmin, s_pmax, s_smin, s_smax, s_with, s_flags;
+    for (int i = threadIdx.x; i < kSplitSeenSlots; i += kSplitThreads) s_seen[i] = 0ull;
+    for (int i = threadIdx.x; i < kSplitMaxSuffix * 256 / 16; i += kSplitThreads) reinterpret_cast<uint4*>(s_flag)[i] = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x == 0) { s_pmin = 0xFFFFFFFFu; s_pmax = 0; s_smin = 0xFFFFFFFFu; s_smax = 0; s_with = 0; s_flags = 0; }
+    __syncthreads();
+    const uint64_t dv = 0x0101010101010101ull * (uint64_t)(d & 0xFFu);
+    uint32_t pmin = 0xFFFFFFFFu, pmax = 0, smin = 0xFFFFFFFFu, smax = 0, with = 0, flags = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * kSplitThreads * kSplitRows;
+    for (uint64_t base = (uint64_t)blockIdx.x * kSplitThreads * kSplitRows; base < n; base += stride) {
+        ValueRegs<NCH> v[kSplitRows];
+        uint64_t b[kSplitRows], l[kSplitRows];
+#pragma unroll
+        for (int k = 0; k < kSplitRows; k++) {   // rows past the end repeat the last row: harmless for statistics
+            const uint64_t i = base + (uint64_t)k * kSplitThreads + threadIdx.x;
+            value_span_whole(col, (i < n ? i : n - 1) * step, &b[k], &l[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < kSplitRows; k++) v[k].load(col, b[k], l[k]);
+#pragma unroll
+        for (int k = 0; k < kSplitRows; k++) {
+            if (v[k].len > (uint32_t)(8 * NCH)) { flags |= 1u; continue; }   // (the host does not split such a column)
+            uint32_t plen, slen;
+            const bool has = split_lengths(v[k], dv, &plen, &slen);
+            with += has && base + (uint64_t)k * kSplitThreads + threadIdx.x < n ? 1u : 0u;
+            pmin = plen < pmin ? plen : pmin;
+            pmax = plen > pmax ? plen : pmax;
+            smin = slen < smin ? slen : smin;
+            smax = slen > smax ? slen : smax;
+            if (plen > (uint32_t)kWideBytes) { flags |= 1u; continue; }
+            if (slen > (uint32_t)kSplitMaxSuffix) flags |= 2u;
+            // ---- the prefix: met before by this workgroup? ----
+            uint64_t w[4];
+            v[k].head_words(plen, w);
+            const unsigned long long tag = wide_hash(w[0], w[1], w[2], w[3], plen);
+            uint32_t h = (uint32_t)(tag >> 32) & (kSplitSeenSlots - 1);
+            bool known = false;
+            for (int pr = 0; pr < 8; pr++, h = (h + 1) & (kSplitSeenSlots - 1)) {
+                const unsigned long long cur = s_seen[h];
+                if (cur == tag) { known = true; break; }
+                if (cur == 0ull) break;
+            }
+            if (!known) {
+                uint32_t g = (uint32_t)tag & (kSplitSetSlots - 1);
+                bool placed = false;
+                for (int pr = 0; pr < kSplitSetSlots; pr++, g = (g + 1) & (kSplitSetSlots - 1)) {
+                    unsigned long long cur = __hip_atomic_load(&slots[g].tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (cur == 0ull) {
+                        cur = atomicCAS(&slots[g].tag, 0ull, tag);
+                        if (cur == 0ull) {   // this thread's slot: the payload is read by the host only
+                            slots[g].w[0] = w[0]; slots[g].w[1] = w[1]; slots[g].w[2] = w[2]; slots[g].w[3] = w[3];
+                            slots[g].len = plen;
+                            atomicAdd(&out->count, 1u);
+                            placed = true;
+                            break;
+                        }
+                    }
+                    if (cur == tag) { placed = true; break; }
+                }
+                if (!placed) flags |= 4u;
+                if (s_seen[h] == 0ull) atomicCAS(&s_seen[h], 0ull, tag);   // (a lost race only costs another global look-up later)
+            }
+            // ---- the suffix: byte presence per position ----
+            uint64_t w0, w1;
+            v[k].window(plen, &w0, &w1);
+            const uint32_t lim = slen < (uint32_t)kSplitMaxSuffix ? slen : (uint32_t)kSplitMaxSuffix;
+            for (uint32_t q = 0; q < lim; q++) {
+                const uint64_t src = q < 8u ? w0 : w1;
+                s_flag[q * 256u + ((uint32_t)(src >> (8u * (q & 7u))) & 0xFFu)] = 1;
+            }
+        }
+    }
+    pmin = wave_min(pmin); pmax = wave_max(pmax); smin = wave_min(smin); smax = wave_max(smax); with = wave_sum(with);
+    if (lane_id() == 0) {
+        atomicMin(&s_pmin, pmin); atomicMax(&s_pmax, pmax); atomicMin(&s_smin, smin); atomicMax(&s_smax, smax);
+        atomicAdd(&s_with, with);
+    }
+    if (flags) atomicOr(&s_flags, flags);
+    __syncthreads();
+    for (int i = threadIdx.x; i < kSplitMaxSuffix * 8; i += kSplitThreads) {   // mask word i = flags [32 i, 32 i + 32)
+        const uint32_t* f = reinterpret_cast<const uint32_t*>(s_flag + 32 * i);
+        uint32_t bits = 0;
+#pragma unroll
+        for (int x = 0; x < 8; x++) {
+            const uint32_t q = f[x];
+            bits |= ((q & 1u) | ((q >> 7) & 2u) | ((q >> 14) & 4u) | ((q >> 21) & 8u)) << (4 * x);
+        }
+        uint32_t* gm = &out->mask[0][0] + i;
+        if (bits && (__hip_atomic_load(gm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bits) != bits) atomicOr(gm, bits);
+    }
+    if (threadIdx.x == 0) {
+        atomicMin(&out->pmin, s_pmin); atomicMax(&out->pmax, s_pmax); atomicMin(&out->smin, s_smin); atomicMax(&out->smax, s_smax);
+        if (s_with) atomicAdd(&out->rows_with, s_with);
+        if (s_flags) atomicOr(&out->flags, s_flags);
+    }
+}
+
+
+// Rows (0, step, 2 step, ... : n of them) that hold each byte value at least once, and the longest of them — where a
+// delimiter could be.  A byte is counted at its FIRST occurrence in a value.
+template <int NCH>
+__global__ __launch_bounds__(kSplitThreads) void k_split_count(DevCol col, uint64_t step, uint64_t n, uint32_t* __restrict__ counts /* [256] + maxlen */) {
+    __shared__ uint32_t s_cnt[256];
+    __shared__ uint32_t s_max;
+    for (int i = threadIdx.x; i < 256; i += kSplitThreads) s_cnt[i] = 0;
+    if (threadIdx.x == 0) s_max = 0;
+    __syncthreads();
+    uint32_t mx = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * kSplitThreads;
+    for (uint64_t i = (uint64_t)blockIdx.x * kSplitThreads + threadIdx.x; i < n; i += stride) {
+        uint64_t b, l;
+        value_span_whole(col, i * step, &b, &l);
+        ValueRegs<NCH> v;
+        v.load(col, b, l);
+        mx = v.len > mx ? v.len : mx;
+        const uint32_t lim = v.len < (uint32_t)(8 * NCH) ? v.len : (uint32_t)(8 * NCH);
+        for (uint32_t q = 0; q < lim; q++) {
+            uint64_t w0, w1;
+            v.window(q, &w0, &w1);
+            const uint32_t byte = (uint32_t)w0 & 0xFFu;
+            if (v.find(0x0101010101010101ull * (uint64_t)byte) == q) atomicAdd(&s_cnt[byte], 1u);
+        }
+    }
+    mx = wave_max(mx);
+    if (lane_id() == 0) atomicMax(&s_max, mx);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += kSplitThreads)
+        if (s_cnt[i]) atomicAdd(&counts[i], s_cnt[i]);
+    if (threadIdx.x == 0) atomicMax(&counts[256], s_max);
+}
+
+// Build-side encode of ONE key column through a split codec (single word): the value's chunks in registers, the
+// delimiter found there, the prefix looked up in the LDS dictionary (verified byte for byte), the suffix through the rank
+// LUT.  A workgroup walks whole SORT tiles and leaves the first radix pass's histogram behind (k_encode_build_fast).
+// *miss is raised by a row the codec cannot code: the caller starts over without the split.
+template <class OUT, int NCH>
+__global__ __launch_bounds__(kSplitThreads) void k_encode_split(DevCol col, const uint8_t* __restrict__ g_codec, uint64_t n,
+                                                               OUT* __restrict__ out, uint32_t tile_rows, uint32_t ntiles,
+                                                               uint32_t* __restrict__ counts, uint32_t digit_mask, uint32_t bins,
+                                                               int codec_bytes, uint32_t* __restrict__ miss) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const CodecView cv = codec_load_to_lds(g_codec, smem);
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + codec_bytes);
+    const uint64_t dv = 0x0101010101010101ull * (uint64_t)((uint32_t)cv.hdr->split_byte & 0xFFu);
+    const int vp = cv.hdr->split_vcol;                 // the prefix column; vp + 1 is the suffix column
+    const int ps = cv.hdr->col_start[vp + 1];          // first suffix position
+    const uint32_t smaxlen = (uint32_t)cv.hdr->col_maxlen[vp + 1];
+    const OUT pmult = (OUT)cv.mult[cv.hdr->wide_pos];
+    const uint32_t per_xcd = (ntiles + 7) / 8, xcd = blockIdx.x & 7u;   // XCD-contiguous tile ranges (k_encode_build_fast)
+    const uint32_t t_end = (xcd + 1) * per_xcd < ntiles ? (xcd + 1) * per_xcd : ntiles;
+    uint32_t missed = 0;
+    for (uint32_t tile = xcd * per_xcd + (blockIdx.x >> 3); tile < t_end; tile += gridDim.x >> 3) {
+        if (counts) {
+            for (uint32_t x = threadIdx.x; x < bins; x += kSplitThreads) s_hist[x] = 0;
+            __syncthreads();
+        }
+        const uint64_t tile_end = (uint64_t)(tile + 1) * tile_rows < n ? (uint64_t)(tile + 1) * tile_rows : n;
+        for (uint64_t base = (uint64_t)tile * tile_rows; base < tile_end; base += (uint64_t)kSplitThreads * kSplitRows) {
+            ValueRegs<NCH> v[kSplitRows];
+            uint64_t b[kSplitRows], l[kSplitRows];
+#pragma unroll
+            for (int k = 0; k < kSplitRows; k++) {   // rows past the end re-read the last row (never stored)
+                const uint64_t i = base + (uint64_t)k * kSplitThreads + threadIdx.x;
+                value_span_whole(col, i < n ? i : n - 1, &b[k], &l[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < kSplitRows; k++) v[k].load(col, b[k], l[k]);
+            uint32_t plen[kSplitRows], slen[kSplitRows];
+            uint64_t w[kSplitRows][4];
+            uint32_t sl[kSplitRows];
+            const uint32_t hmask = (1u << cv.hdr->wide_hash_bits) - 1u;
+#pragma unroll
+            for (int k = 0; k < kSplitRows; k++) {
+                split_lengths(v[k], dv, &plen[k], &slen[k]);
+                v[k].head_words(plen[k] < (uint32_t)kWideBytes ? plen[k] : (uint32_t)kWideBytes, w[k]);
+                sl[k] = (uint32_t)wide_hash(w[k][0], w[k][1], w[k][2], w[k][3], plen[k]) & hmask;
+            }
+            OUT acc[kSplitRows];
+#pragma unroll
+            for (int k = 0; k < kSplitRows; k++) {
+                bool ok = v[k].len <= (uint32_t)(8 * NCH) && plen[k] <= (uint32_t)kWideBytes && slen[k] <= smaxlen;
+                int rank = -1;
+                for (;;) {   // ends on the entry (every build prefix is in the dictionary) or on an empty slot
+                    const uint32_t e = cv.wide_hash[sl[k]];
+                    if (e == 0) break;
+                    const CPH_LDS WideKey* key = cv.wide + (e - 1);
+                    if (key->len == plen[k] && key->w[0] == w[k][0] && key->w[1] == w[k][1] && key->w[2] == w[k][2] && key->w[3] == w[k][3]) { rank = (int)(e - 1); break; }
+                    sl[k] = (sl[k] + 1) & hmask;
+                }
+                ok = ok && rank >= 0;
+                acc[k] = (OUT)(rank < 0 ? 0 : rank) * pmult;
+                uint64_t w0, w1;
+                v[k].window(plen[k], &w0, &w1);
+                for (uint32_t q = 0; q < smaxlen; q++) {   // uniform bound
+                    const uint64_t src = q < 8u ? w0 : w1;
+                    const uint32_t sym = q < slen[k] ? ((uint32_t)(src >> (8u * (q & 7u))) & 0xFFu) + 1u : 0u;
+                    const uint32_t r = cv.lut[(ps + (int)q) * kLutStride + (int)sym];
+                    ok = ok && r != kLutInvalid;
+                    acc[k] += (OUT)r * (OUT)cv.mult[ps + (int)q];
+                }
+                const uint64_t i = base + (uint64_t)k * kSplitThreads + threadIdx.x;
+                if (i < tile_end) {
+                    out[i] = acc[k];
+                    if (counts) atomicAdd(&s_hist[(uint32_t)acc[k] & digit_mask], 1u);
+                    if (!ok) missed = 1;
+                }
+            }
+        }
+        if (counts) {
+            __syncthreads();
+            for (uint32_t x = threadIdx.x; x < bins; x += kSplitThreads) counts[(uint64_t)x * ntiles + tile] = s_hist[x];
+            __syncthreads();
+        }
+    }
+    if (__ballot(missed) && lane_id() == 0) atomicOr(miss, 1u);
+}
+
+
+// ---- split codec: host side -------------------------------------------------------------------------------------
+int codec_virtual_cols(const CodecHost& cd, const DevCol* real, int nreal, DevCol* out) {
+    int nv = 0;
+    for (int c = 0; c < nreal; c++) {
+        if (cd.has_split() && c == cd.split_col) {
+            DevCol a = real[c], b = real[c];
+            a.split = b.split = (uint16_t)(0x100u | cd.split_byte);
+            a.part = 0;
+            b.part = 1;
+            out[nv++] = a;
+            out[nv++] = b;
+        } else {
+            out[nv++] = real[c];
+        }
+    }
+    return nv;
+}
+
+// bytes of a WideKey in strings.Compare order
+static bool wide_less(const WideKey& a, const WideKey& b) {
+    const uint32_t m = a.len < b.len ? a.len : b.len;
+    for (uint32_t i = 0; i < m; i++) {
+        const uint8_t x = (uint8_t)(a.w[i >> 3] >> (8 * (i & 7))), y = (uint8_t)(b.w[i >> 3] >> (8 * (i & 7)));
+        if (x != y) return x < y;
+    }
+    return a.len < b.len;
+}
+
+// What the sort pays for a codec: radix passes x bytes moved per key and pass (key + row id), a gather per extra word.
+static double codec_sort_cost(const CodecHost& c) {
+    if (c.nwords == 1) return (double)((c.word_bits[0] + 7) / 8) * (c.key32 ? 8.0 : 12.0);
+    double cost = 0;
+    for (int w = 0; w < c.nwords; w++) cost += (double)((c.word_bits[w] + 7) / 8) * 12.0 + 16.0;
+    return cost;
+}
+static double radix_bits(const ColStats& st, uint32_t q) {
+    int cnt = q >= st.minlen ? 1 : 0;
+    for (int w = 0; w < 8; w++) cnt += __builtin_popcount(st.mask[q][w]);
+    return std::log2((double)(cnt > 1 ? cnt : 1));
+}
+
+template <int NCH>
+static void launch_split_stats(cph_ctx* ctx, const DevCol& col, uint32_t d, uint64_t step, uint64_t rows, SplitSlot* slots, SplitStats* out) {
+    uint64_t nblk = (rows + (uint64_t)kSplitThreads * kSplitRows - 1) / ((uint64_t)kSplitThreads * kSplitRows);
+    if (nblk > 2048) nblk = 2048;
+    if (nblk < 1) nblk = 1;
+    hipLaunchKernelGGL((k_split_stats<NCH>), dim3((unsigned)nblk), dim3(kSplitThreads), 0, ctx->stream, col, d, step, rows, slots, out);
+}
+
+// Tries the delimiter split on the key column that costs the most code bits.  stats = the plain statistics *codec was
+// built from.  On success *codec is the split codec, built from exact statistics over all rows; otherwise it is left
+// alone.  Three small synchronisations (byte counts of a sample, the candidates' sample statistics, the exact pass).
+Status codec_try_split(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t n, const std::vector<ColStats>& stats, CodecHost* codec) {
+    const CodecHost& plain = *codec;
+    if (!ctx->codec_split || n < (1ull << 16) || plain.key32 || ncols >= kMaxKeyCols || plain.has_groups()) return {};
+    // the column to cut: variable length, short enough for the kernels' registers, the most plain code bits
+    int c = -1;
+    double most = 0;
+    for (int k = 0; k < ncols; k++) {
+        if (cols[k].fixed_width || cols[k].segmented() || stats[(size_t)k].maxlen > (uint32_t)kSplitMaxValue || stats[(size_t)k].maxlen < 4) continue;
+        double bits = 0;
+        for (uint32_t q = 0; q < stats[(size_t)k].maxlen; q++) bits += radix_bits(stats[(size_t)k], q);
+        if (bits > most) { most = bits; c = k; }
+    }
+    if (c < 0 || most < 24.0) return {};
+    const bool small_values = stats[(size_t)c].maxlen <= 24;
+    const DevCol& col = cols[c];
+    const uint64_t step = n > (1ull << 19) ? n >> 18 : 1;
+    const uint64_t nsel = (n + step - 1) / step;
+
+    // ---- 1. which bytes occur in (nearly) every sampled value ----
+    DevBuf counts;
+    CPH_TRY(counts.alloc(&ctx->pool, 257 * sizeof(uint32_t)));
+    CPH_HIP_TRY(hipMemsetAsync(counts.get(), 0, 257 * sizeof(uint32_t), ctx->stream));
+    {
+        ProfScope ps(ctx, "k_split_count", 0);
+        uint64_t nblk = (nsel + kSplitThreads - 1) / kSplitThreads;
+        if (nblk > 1024) nblk = 1024;
+        if (small_values) hipLaunchKernelGGL((k_split_count<3>), dim3((unsigned)nblk), dim3(kSplitThreads), 0, ctx->stream, col, step, nsel, counts.as<uint32_t>());
+        else hipLaunchKernelGGL((k_split_count<5>), dim3((unsigned)nblk), dim3(kSplitThreads), 0, ctx->stream, col, step, nsel, counts.as<uint32_t>());
+        CPH_HIP_TRY(hipGetLastError());
+    }
+    uint32_t hcnt[257];
+    CPH_TRY(ensure_pinned_scratch(ctx, sizeof hcnt));
+    CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, counts.get(), sizeof hcnt, hipMemcpyDeviceToHost, ctx->stream));
+    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    memcpy(hcnt, ctx->pinned_scratch, sizeof hcnt);
+    std::vector<int> cand;
+    for (int b = 0; b < 256; b++)
+        if ((double)hcnt[b] >= 0.99 * (double)nsel) cand.push_back(b);
+    std::sort(cand.begin(), cand.end(), [&](int a, int b) { return hcnt[a] > hcnt[b]; });
+    if (cand.size() > 6) cand.resize(6);
+    if (cand.empty()) return {};
+
+    // ---- 2. the candidates on the sample: distinct prefixes, suffix alphabets ----
+    const size_t set_bytes = (size_t)kSplitSetSlots * sizeof(SplitSlot);
+    DevBuf sets, sstats;
+    CPH_TRY(sets.alloc(&ctx->pool, cand.size() * set_bytes));
+    CPH_TRY(sstats.alloc(&ctx->pool, cand.size() * sizeof(SplitStats)));
+    auto reset_stats = [&](size_t k) -> Status {   // everything 0, the two minima all ones
+        uint8_t* base = sstats.as<uint8_t>() + k * sizeof(SplitStats);
+        CPH_HIP_TRY(hipMemsetAsync(base, 0, sizeof(SplitStats), ctx->stream));
+        CPH_HIP_TRY(hipMemsetAsync(base + offsetof(SplitStats, pmin), 0xFF, sizeof(uint32_t), ctx->stream));
+        CPH_HIP_TRY(hipMemsetAsync(base + offsetof(SplitStats, smin), 0xFF, sizeof(uint32_t), ctx->stream));
+        return {};
+    };
+    CPH_HIP_TRY(hipMemsetAsync(sets.get(), 0, cand.size() * set_bytes, ctx->stream));
+    {
+        ProfScope ps(ctx, "k_split_sample", 0);
+        for (size_t k = 0; k < cand.size(); k++) {
+            CPH_TRY(reset_stats(k));
+            SplitSlot* sl = reinterpret_cast<SplitSlot*>(sets.as<uint8_t>() + k * set_bytes);
+            SplitStats* st = sstats.as<SplitStats>() + k;
+            if (small_values) launch_split_stats<3>(ctx, col, (uint32_t)cand[k], step, nsel, sl, st);
+            else launch_split_stats<5>(ctx, col, (uint32_t)cand[k], step, nsel, sl, st);
+        }
+        CPH_HIP_TRY(hipGetLastError());
+    }
+    std::vector<SplitStats> hs(cand.size());
+    CPH_TRY(ensure_pinned_scratch(ctx, cand.size() * sizeof(SplitStats)));
+    CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, sstats.get(), cand.size() * sizeof(SplitStats), hipMemcpyDeviceToHost, ctx->stream));
+    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    memcpy(hs.data(), ctx->pinned_scratch, cand.size() * sizeof(SplitStats));
+    auto split_bits = [&](const SplitStats& st) {
+        double bits = std::log2((double)(st.count > 1 ? st.count : 1));
+        ColStats tmp{};
+        tmp.minlen = st.smin;
+        memcpy(tmp.mask, st.mask, sizeof st.mask);
+        for (uint32_t q = 0; q < st.smax && q < (uint32_t)kSplitMaxSuffix; q++) bits += radix_bits(tmp, q);
+        return bits;
+    };
+    int best = -1;
+    double best_bits = 1e30;
+    for (size_t k = 0; k < cand.size(); k++) {
+        const SplitStats& st = hs[k];
+        if (st.flags || st.count == 0 || st.count > (uint32_t)kWideDictMax / (step > 1 ? 2 : 1) || st.smax > (uint32_t)kSplitMaxSuffix) continue;
+        const double bits = split_bits(st);
+        if (ctx->codec_debug) fprintf(stderr, "codec_try_split: column %d, byte 0x%02x: %u prefixes, suffix %u..%u bytes, %.1f bits (plain %.1f)\n", c, cand[k], st.count, st.smin, st.smax, bits, most);
+        if (bits < best_bits) { best_bits = bits; best = (int)k; }
+    }
+    if (best < 0 || best_bits > most - 8.0) return {};   // not worth a radix pass
+
+    // ---- 3. the exact statistics of the chosen byte, over all rows (the sample's set stays: it is a subset) ----
+    SplitSlot* slots = reinterpret_cast<SplitSlot*>(sets.as<uint8_t>() + (size_t)best * set_bytes);
+    SplitStats* dstat = sstats.as<SplitStats>() + best;
+    const uint32_t d = (uint32_t)cand[(size_t)best];
+    if (step > 1) {
+        ProfScope ps(ctx, "k_split_stats", 0);
+        if (small_values) launch_split_stats<3>(ctx, col, d, 1, n, slots, dstat);
+        else launch_split_stats<5>(ctx, col, d, 1, n, slots, dstat);
+        CPH_HIP_TRY(hipGetLastError());
+    }
+    CPH_TRY(ensure_pinned_scratch(ctx, sizeof(SplitStats) + set_bytes));
+    uint8_t* hp = static_cast<uint8_t*>(ctx->pinned_scratch);
+    CPH_HIP_TRY(hipMemcpyAsync(hp, dstat, sizeof(SplitStats), hipMemcpyDeviceToHost, ctx->stream));
+    CPH_HIP_TRY(hipMemcpyAsync(hp + sizeof(SplitStats), slots, set_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    SplitStats st;
+    memcpy(&st, hp, sizeof st);
+    if (st.flags || st.count == 0 || st.count > (uint32_t)kWideDictMax || st.pmax > (uint32_t)kWideBytes || st.smax > (uint32_t)kSplitMaxSuffix) return {};
+    std::vector<WideKey> dict;
+    const SplitSlot* hsl = reinterpret_cast<const SplitSlot*>(hp + sizeof(SplitStats));
+    for (int i = 0; i < kSplitSetSlots; i++)
+        if (hsl[i].tag) {
+            WideKey k{};
+            for (int j = 0; j < 4; j++) k.w[j] = hsl[i].w[j];
+            k.len = hsl[i].len;
+            dict.push_back(k);
+        }
+    if (dict.size() != st.count) return {};
+    std::sort(dict.begin(), dict.end(), wide_less);
+    for (size_t i = 1; i < dict.size(); i++)
+        if (!wide_less(dict[i - 1], dict[i])) return {};   // the same prefix twice under two tags cannot happen; be sure
+
+    // ---- 4. the codec over the virtual columns ----
+    std::vector<ColStats> vstats;
+    for (int k = 0; k < ncols; k++) {
+        if (k != c) { vstats.push_back(stats[(size_t)k]); continue; }
+        ColStats pre{}, suf{};
+        pre.minlen = st.pmin;
+        pre.maxlen = st.pmax;
+        for (uint32_t q = 0; q < st.pmax; q++) pre.mask[q][0] = 1u;   // placeholders: the positions are absorbed below
+        suf.minlen = st.smin;
+        suf.maxlen = st.smax;
+        memcpy(suf.mask, st.mask, sizeof st.mask);
+        vstats.push_back(pre);
+        vstats.push_back(suf);
+    }
+    uint64_t positions = 0;
+    for (const auto& v : vstats) positions += v.maxlen;
+    if (positions > (uint64_t)kMaxKeyBytes) return {};
+    CodecHost trial;
+    CPH_TRY(codec_build(vstats, &trial));
+    const int p0 = trial.col_start[c];
+    trial.unit.assign((size_t)trial.npos, kUnitPos);
+    trial.dict_off.assign((size_t)trial.npos, 0);
+    trial.dict_len.assign((size_t)trial.npos, 0);
+    trial.unit[(size_t)p0] = kUnitWide;
+    trial.radix[(size_t)p0] = (uint16_t)dict.size();
+    for (int sym = 0; sym < kLutStride; sym++) trial.lut[(size_t)p0 * kLutStride + (size_t)sym] = kLutInvalid;   // never consulted
+    for (uint32_t i = 1; i < st.pmax; i++) {
+        trial.unit[(size_t)p0 + i] = kUnitAbsorbed;
+        trial.radix[(size_t)p0 + i] = 1;
+        for (int sym = 0; sym < kLutStride; sym++) trial.lut[((size_t)p0 + i) * kLutStride + (size_t)sym] = 0;
+    }
+    trial.split_col = c;
+    trial.split_byte = (uint8_t)d;
+    trial.wdict = std::move(dict);
+    CPH_TRY(codec_split_words(&trial));
+    if (ctx->codec_debug)
+        fprintf(stderr, "codec_try_split: column %d cut at 0x%02x: %zu prefixes (<= %u bytes), suffix %u..%u bytes: %d word(s), %d bits (plain: %d word(s), %d bits in the first)\n",
+                c, d, trial.wdict.size(), st.pmax, st.smin, st.smax, trial.nwords, trial.word_bits[0], plain.nwords, plain.word_bits[0]);
+    if (codec_sort_cost(trial) < codec_sort_cost(plain)) *codec = std::move(trial);
+    return {};
+}
+
 // Width (32/64) of the pre-multiplied LUT the device codec block carries, 0 if none: single-word
 // codes whose table stays within 48 KiB of LDS.
 int codec_premultiplied_bits(const CodecHost& cd) {
@@ -851,7 +1399,7 @@ Status codec_upload(cph_ctx* ctx, const CodecHost& cd, DevBuf* dev) {
     }
     if (cd.has_groups()) {
         h.ngroups = 0;
-        for (int p = 0; p < cd.npos; p++) h.ngroups += cd.unit[(size_t)p] == kUnitHead;
+        for (int p = 0; p < cd.npos; p++) h.ngroups += cd.unit[(size_t)p] == kUnitHead || cd.unit[(size_t)p] == kUnitWide;
         h.unit_off = (int32_t)off;
         off = align16(off + (size_t)cd.npos);
         h.dictoff_off = (int32_t)off;
@@ -870,10 +1418,37 @@ Status codec_upload(cph_ctx* ctx, const CodecHost& cd, DevBuf* dev) {
             if (cd.unit[(size_t)p] == kUnitHead) slots += (size_t)1 << (bits_needed((uint64_t)cd.dict_len[(size_t)p] * 2) + 0);
         off = align16(off + sizeof(uint16_t) * slots);
     }
+    h.wide_pos = -1;
+    h.split_vcol = -1;
+    int wide_bits = 0;
+    if (cd.has_split()) {
+        h.split_vcol = cd.split_col;
+        h.split_byte = cd.split_byte;
+        h.wide_pos = cd.col_start[cd.split_col];
+        h.wide_n = (int32_t)cd.wdict.size();
+        h.wide_off = (int32_t)off;
+        off = align16(off + sizeof(WideKey) * cd.wdict.size());
+        wide_bits = bits_needed((uint64_t)cd.wdict.size() * 2);
+        if (wide_bits < 1) wide_bits = 1;
+        h.wide_hash_bits = wide_bits;
+        h.wide_hash_off = (int32_t)off;
+        off = align16(off + sizeof(uint16_t) * ((size_t)1 << wide_bits));
+    }
     h.total_bytes = (int32_t)off;
 
     std::vector<uint8_t> blob(off, 0);
     memcpy(blob.data(), &h, sizeof h);
+    if (cd.has_split()) {
+        memcpy(blob.data() + h.wide_off, cd.wdict.data(), sizeof(WideKey) * cd.wdict.size());
+        uint16_t* ht = reinterpret_cast<uint16_t*>(blob.data() + h.wide_hash_off);
+        const uint32_t mask = (1u << wide_bits) - 1u;
+        for (size_t r = 0; r < cd.wdict.size(); r++) {
+            const WideKey& k = cd.wdict[r];
+            uint32_t sl = (uint32_t)wide_hash(k.w[0], k.w[1], k.w[2], k.w[3], k.len) & mask;
+            while (ht[sl]) sl = (sl + 1) & mask;
+            ht[sl] = (uint16_t)(r + 1);
+        }
+    }
     if (cd.has_groups()) {
         memcpy(blob.data() + h.unit_off, cd.unit.data(), (size_t)cd.npos);
         memcpy(blob.data() + h.dictoff_off, cd.dict_off.data(), sizeof(int32_t) * (size_t)cd.npos);
@@ -931,24 +1506,28 @@ Status codec_upload(cph_ctx* ctx, const CodecHost& cd, DevBuf* dev) {
 // ---------------------------------------------------------------------------------------------
 constexpr int kEncodeThreads = 256;
 
+// miss (optional): raised when a row's key does not code (a split codec whose dictionary lacks the row's prefix: the
+// caller then starts over without the split; with exact per-position statistics every build row codes)
 template <bool KEY32>
 __global__ __launch_bounds__(kEncodeThreads) void k_encode_build(ColsArg cols, const uint8_t* __restrict__ g_codec,
-                                                                uint64_t n, void* __restrict__ out) {
+                                                                uint64_t n, void* __restrict__ out, uint32_t* __restrict__ miss) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const CodecView cv = codec_load_to_lds(g_codec, smem);
     const int ncols = cv.hdr->ncols;
     const uint64_t stride = (uint64_t)gridDim.x * kEncodeThreads;
+    bool all_valid = true;
     for (uint64_t row = (uint64_t)blockIdx.x * kEncodeThreads + threadIdx.x; row < n; row += stride) {
         if constexpr (KEY32) {
             uint32_t code = 0;
-            encode_key(cv, cols, ncols, row, [&](int, uint64_t v, int) { code = (uint32_t)v; });
+            all_valid &= encode_key(cv, cols, ncols, row, [&](int, uint64_t v, int) { code = (uint32_t)v; });
             reinterpret_cast<uint32_t*>(out)[row] = code;
         } else {
             uint64_t* o = reinterpret_cast<uint64_t*>(out);
             if (cv.hdr->npos == 0) o[row] = 0;
-            encode_key(cv, cols, ncols, row, [&](int word, uint64_t v, int) { o[(uint64_t)word * n + row] = v; });
+            all_valid &= encode_key(cv, cols, ncols, row, [&](int word, uint64_t v, int) { o[(uint64_t)word * n + row] = v; });
         }
     }
+    if (miss && !all_valid) atomicOr(miss, 1u);
 }
 
 // Fast path: one key column, single-word code, pre-multiplied LUT.  Wave-tile access pattern (codec_device.hpp);
@@ -1164,8 +1743,44 @@ __global__ __launch_bounds__(THREADS) void k_encode_build_plan(ColsArg cols, con
 }
 
 Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec_dev, const DevCol* cols, uint64_t n,
-                          void* out_codes, const EncodeHist* hist, const GroupSpec* spec) {
+                          void* out_codes, const EncodeHist* hist, const GroupSpec* spec, uint32_t* miss) {
     if (n == 0) return {};
+    if (cd.has_split() && cd.ncols == 2 && cd.nwords == 1 && !cols[0].segmented() &&
+        cd.col_maxlen[0] + cd.col_maxlen[1] <= kSplitMaxValue && cd.col_maxlen[1] <= kSplitMaxSuffix && miss) {
+        // one key column through a split codec: the dedicated kernel (tiles = the sort's tiles when it asked for the first
+        // pass's histogram, else 4096 rows)
+        const bool want_hist = hist && hist->counts;
+        const uint32_t tile_rows = want_hist ? hist->tile_rows : 4096u;
+        const uint64_t ntiles64 = (n + tile_rows - 1) / tile_rows;
+        const uint32_t ntiles = (uint32_t)ntiles64;
+        const uint32_t bins = want_hist ? hist->bins : 0u, mask = want_hist ? hist->digit_mask : 0u;
+        const size_t codec_bytes = codec_dev.bytes();
+        const size_t lds = codec_bytes + (size_t)bins * sizeof(uint32_t);
+        const bool small_values = cd.col_maxlen[0] + cd.col_maxlen[1] <= 24;
+        int per_cu = 1, cus = 256;
+        CPH_TRY(device_cus(ctx, &cus));
+        ProfScope ps(ctx, "k_encode_build", 4.0 * (double)bins * (double)ntiles);
+        auto launch = [&](auto fn, auto* out) -> Status {
+            CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(fn), kSplitThreads, lds, &per_cu));
+            unsigned grid = (unsigned)std::min<uint64_t>(ntiles64, (uint64_t)cus * (uint64_t)per_cu);
+            grid = (grid + 7u) & ~7u;   // the kernel splits its tiles over blockIdx % 8
+            hipLaunchKernelGGL(fn, dim3(grid), dim3(kSplitThreads), lds, ctx->stream, cols[0], codec_dev.as<uint8_t>(), n, out, tile_rows, ntiles,
+                               want_hist ? hist->counts : nullptr, mask, bins, (int)codec_bytes, miss);
+            return {};
+        };
+        if (cd.key32) {
+            uint32_t* o = reinterpret_cast<uint32_t*>(out_codes);
+            if (small_values) CPH_TRY(launch(&k_encode_split<uint32_t, 3>, o));
+            else CPH_TRY(launch(&k_encode_split<uint32_t, 5>, o));
+        } else {
+            uint64_t* o = reinterpret_cast<uint64_t*>(out_codes);
+            if (small_values) CPH_TRY(launch(&k_encode_split<uint64_t, 3>, o));
+            else CPH_TRY(launch(&k_encode_split<uint64_t, 5>, o));
+        }
+        CPH_HIP_TRY(hipGetLastError());
+        if (hist) const_cast<EncodeHist*>(hist)->done = want_hist;
+        return {};
+    }
     const int lutw_bits = codec_premultiplied_bits(cd);
     if (cd.ncols == 1 && lutw_bits != 0 && !cols[0].segmented()) {
         // tiles = the sort's tiles when it asked for the first pass's histogram, else 4096 rows
@@ -1213,12 +1828,12 @@ Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec
     }
     if (hist) const_cast<EncodeHist*>(hist)->done = false;
     ColsArg arg{};
-    for (int c = 0; c < cd.ncols; c++) arg.c[c] = cols[c];
+    codec_virtual_cols(cd, cols, cd.ncols - (cd.has_split() ? 1 : 0), arg.c);   // `cols` are the table's key columns
     uint64_t nblk = (n + kEncodeThreads - 1) / kEncodeThreads;
     if (nblk > 4096) nblk = 4096;
     int plan_units = 0;
     for (int p = 0; p < cd.npos && cd.has_groups(); p++) plan_units += cd.unit[(size_t)p] != kUnitAbsorbed;
-    if (cd.has_groups() && cd.nwords == 1 && plan_units <= kPlanMaxUnits) {
+    if (cd.has_groups() && !cd.has_split() && cd.nwords == 1 && plan_units <= kPlanMaxUnits) {
         // tiles = the sort's tiles when it asked for the first pass's histogram, else 4096 rows
         const bool want_hist = hist && hist->counts;
         const uint32_t tile_rows = want_hist ? hist->tile_rows : 4096u;
@@ -1299,12 +1914,12 @@ Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec
         CPH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode_build<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_encode_build<true>, dim3((unsigned)nblk), dim3(kEncodeThreads), lds, ctx->stream, arg,
-                           codec_dev.as<uint8_t>(), n, out_codes);
+                           codec_dev.as<uint8_t>(), n, out_codes, miss);
     } else {
         CPH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode_build<false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_encode_build<false>, dim3((unsigned)nblk), dim3(kEncodeThreads), lds, ctx->stream, arg,
-                           codec_dev.as<uint8_t>(), n, out_codes);
+                           codec_dev.as<uint8_t>(), n, out_codes, miss);
     }
     CPH_HIP_TRY(hipGetLastError());
     return {};
@@ -1313,11 +1928,33 @@ Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec
 // ---------------------------------------------------------------------------------------------
 // Host-side encoding of literal values (Index.Find / SubIndex bounds, csvplus.go:870-891).
 // ---------------------------------------------------------------------------------------------
-bool codec_encode_values_host(const CodecHost& cd, const cph_strval* values, int32_t nvalues, uint64_t* q_exact,
+bool codec_encode_values_host(const CodecHost& cd, const cph_strval* real_values, int32_t nreal, uint64_t* q_exact,
                               int32_t* nq, uint64_t* qlo, uint64_t* qhi) {
     *nq = 0;
     *qlo = 0;
     *qhi = 0;
+    // a split codec sees the split column's value as two: through the first delimiter, and the rest
+    cph_strval vbuf[kMaxKeyCols + 1];
+    int32_t nvalues = 0;
+    for (int32_t c = 0; c < nreal; c++) {
+        if (cd.has_split() && c == cd.split_col) {
+            const cph_strval& v = real_values[c];
+            uint64_t at = v.len;
+            for (uint64_t i = 0; i < v.len; i++)
+                if (v.data[i] == cd.split_byte) { at = i; break; }
+            const uint64_t head = at < v.len ? at + 1 : v.len;
+            vbuf[nvalues] = v;
+            vbuf[nvalues].len = head;
+            nvalues++;
+            vbuf[nvalues] = v;
+            vbuf[nvalues].data = v.data + head;
+            vbuf[nvalues].len = v.len - head;
+            nvalues++;
+        } else {
+            vbuf[nvalues++] = real_values[c];
+        }
+    }
+    const cph_strval* values = vbuf;
     const int p_end = cd.col_start[nvalues];
     const bool groups = cd.has_groups();
     uint64_t acc = 0;
@@ -1329,6 +1966,14 @@ bool codec_encode_values_host(const CodecHost& cd, const cph_strval* values, int
             const uint8_t kind = groups ? cd.unit[(size_t)p] : kUnitPos;
             if (kind == kUnitAbsorbed) {
                 r = 0;
+            } else if (kind == kUnitWide) {
+                if (values[c].len > (uint64_t)kWideBytes) return false;
+                WideKey k{};
+                for (uint64_t i = 0; i < values[c].len; i++) k.w[i >> 3] |= (uint64_t)values[c].data[i] << (8 * (i & 7));
+                k.len = (uint32_t)values[c].len;
+                const auto it = std::lower_bound(cd.wdict.begin(), cd.wdict.end(), k, wide_less);
+                if (it == cd.wdict.end() || wide_less(k, *it)) return false;
+                r = (uint64_t)(it - cd.wdict.begin());
             } else if (kind == kUnitHead) {
                 int span = 1;
                 while (span < kGroupSpan && q + span < cd.col_maxlen[c] && cd.unit[(size_t)(p + span)] == kUnitAbsorbed) span++;

@@ -1148,7 +1148,7 @@ Status probe_run(cph_ctx* ctx, const cph_index* ix, const DevCol* cols, int32_t 
     DevBuf tiles;
     CPH_TRY(tiles.alloc(&ctx->pool, (ntiles64 + 1) * sizeof(uint64_t)));
     ColsArg arg{};
-    for (int c = 0; c < ncols; c++) arg.c[c] = cols[c];
+    const int nvcols = codec_virtual_cols(ix->codec, cols, ncols, arg.c);   // a split codec sees its split column twice
     // How a probe row finds its keys: a FULL-key probe looks them up — direct-address table when the code space is
     // dense, hash table otherwise (both built by the first Join that wants them; when that fails, or for a PREFIX
     // join, which needs the order of the codes: csvplus.go:910) — the sorted codes are searched.
@@ -1205,7 +1205,7 @@ Status probe_run(cph_ctx* ctx, const cph_index* ix, const DevCol* cols, int32_t 
         // one key column, single-word code, pre-multiplied LUT: 4 rows in flight per thread
         CPH_PROBE_DISPATCH(launch_probe_fast, ctx, ix, cols[0], look, row_sel, nprobe, lo, cnt, ts, ntiles, first_row);
     } else {
-        CPH_PROBE_DISPATCH(launch_probe, ctx, ix, arg, ncols, look, row_sel, nprobe, lo, cnt, ts, ntiles, first_row);
+        CPH_PROBE_DISPATCH(launch_probe, ctx, ix, arg, nvcols, look, row_sel, nprobe, lo, cnt, ts, ntiles, first_row);
     }
 #undef CPH_PROBE_DISPATCH
     CPH_TRY(exclusive_scan_u64(ctx, ts, ntiles64, ts + ntiles64));   // tile bases; the total lands behind them

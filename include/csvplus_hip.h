@@ -141,6 +141,9 @@ CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
  *   "plan_threads" / "gstats_threads"  workgroup sizes of the dictionary encode / window statistics kernels (0 = default)
  *   "join_hash"     0: indexes built on this ctx never get a hash table — their sparse-key Joins binary-search the
  *                   sorted codes as before (A/B switch for measurements and for the fallback's tests; default 1)
+ *   "codec_split"   0 / 1 (default 1): keys that do not code in 32 bits are tried with the delimiter split — the costliest
+ *                   variable-length key column cut at its first delimiter byte into a dictionary-coded prefix and a
+ *                   per-position suffix (floating fields like "Smith/Amelia#12345": 25 bits instead of 47; A/B switch)
  *   "codec_debug"   1: the window choice of every index build (and the phase times of a one-launch build) go to stderr
  *   "small_build_rows"  tables of at most this many rows (default 8192, at most 16384) are indexed by ONE launch of one
  *                   workgroup and one synchronisation (small_build.hip); 0 = always the general path
@@ -597,7 +600,9 @@ typedef struct {
     uint64_t hash_bytes;      /* size of the hash table                                                         */
     int32_t  build_path;      /* 0: general path (statistics, host codec, encode, multi-launch radix sort);
                                  1: the one-launch build of small tables (ctx option "small_build_rows", default 8192) */
-    int32_t  reserved_;
+    int32_t  split;           /* 0: none; else 0x100 * (1 + key column that is cut) + the delimiter byte: the key codec codes that
+                                 column as (prefix through its first delimiter, suffix) — whole-value dictionary + per-position
+                                 suffix (round 4; dict_entries then counts the prefixes) */
 } cph_index_info;
 
 CPH_API int32_t cph_index_get_info(const cph_index* index, cph_index_info* info);

@@ -12,6 +12,15 @@ from tests.helpers import assert_join_equal, random_keys
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _no_split(ctx):
+    """These tests are about the dictionary WINDOWS: since round 4 keys like config 3's take the delimiter split first
+    (tests/test_gpu_split_codec.py), so it is switched off here."""
+    ctx.set_option("codec_split", 0)
+    yield
+    ctx.set_option("codec_split", 1)
+
+
 def same_bounds(a, b):
     """find() bounds agree; for an absent value only emptiness is observable (rows[lower:upper], csvplus.go:625-641)."""
     return a == b or (a[0] == a[1] and b[0] == b[1])

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE config 3 (IndexOn over 1e8 variable-length duplicate keys): kernel times for the statistics / encode
-configurations (ctx options speculative_groups, plan_threads, gstats_threads).  Usage: config3.py [rows]"""
+configurations (ctx options codec_split [round 4: the delimiter split], speculative_groups, plan_threads, gstats_threads).  Usage: config3.py [rows]"""
 import sys
 import time
 from pathlib import Path
@@ -12,13 +12,15 @@ from csvplus_amd.engine import Engine
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100_000_000
 eng = Engine(0)
 col = dg.varkeys(n).to_device(eng.device)
-cases = [dict(speculative_groups=0, codec_debug=1), dict(speculative_groups=0, plan_threads=512, gstats_threads=256),
-         dict(speculative_groups=2), dict(speculative_groups=1)]
+cases = [dict(codec_split=1, codec_debug=1), dict(codec_split=1), dict(codec_split=0, speculative_groups=0, codec_debug=1),
+         dict(codec_split=0, speculative_groups=1)]
 if len(sys.argv) > 2:
     cases = cases[:int(sys.argv[2])]
 for case in cases:
     for k in ("plan_threads", "gstats_threads", "codec_debug"):
         eng.ctx.set_option(k, 0)
+    eng.ctx.set_option("codec_split", 1)
+    eng.ctx.set_option("speculative_groups", 1)
     for k, v in case.items():
         eng.ctx.set_option(k, v)
     eng.index_on([col]).close()
