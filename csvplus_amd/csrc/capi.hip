@@ -395,6 +395,8 @@ struct BuildJob {
     GroupSpec spec;              // speculative dictionaries (codec_try_groups)
     bool small = false;          // one-launch build (small_build.hip): no statistics pass, no second synchronisation
     SmallBufs sbufs;
+    bool presplit = false;       // a large single-column table whose split codec was built from a sample + one exact pass BEFORE any plain
+                                 // statistics (build_phase1): no statistics pass at all
     bool no_split = false;       // second attempt after a split codec met a row it could not code (keycodec.hip: codec_try_split)
     DevBuf split_miss;           // u32 raised by the encode kernel of a split codec; read back with the first duplicate
 };
@@ -409,7 +411,13 @@ static Status build_phase1(cph_ctx* ctx, const cph_strcol* keycols, int32_t nkey
     job->nkeycols = nkeycols;
     CPH_TRY(stage_cols(ctx, keycols, nkeycols, &job->staged, job->dcols));
     job->small = small_build_applies(ctx, job->dcols, nkeycols, ix->nrows);   // launched by build_run (needs its result slot)
-    if (!job->small) CPH_TRY(codec_stats_launch(ctx, job->dcols, nkeycols, &job->stats_dev));   // K0: alphabets
+    // "sample first": a large table over ONE variable-length key column asks a sample whether its keys want the delimiter split
+    // (keycodec.hip); when they do, the exact split statistics replace the plain statistics pass (one read of the strings less)
+    if (!job->small && !job->no_split && nkeycols == 1 && !job->dcols[0].fixed_width && ix->nrows >= (1ull << 22)) {
+        CPH_TRY(codec_try_split(ctx, job->dcols, 1, ix->nrows, nullptr, &ix->codec));
+        job->presplit = ix->codec.has_split();
+    }
+    if (!job->small && !job->presplit) CPH_TRY(codec_stats_launch(ctx, job->dcols, nkeycols, &job->stats_dev));   // K0: alphabets
     return {};
 }
 
@@ -428,7 +436,7 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
     bool any_general = false;
     for (size_t i = 0; i < nj; i++) {
         jobs[i].scratch_off = total;
-        total += jobs[i].small ? sizeof(SmallResult) : sizeof(ColStats) * (size_t)jobs[i].nkeycols;
+        total += jobs[i].small ? sizeof(SmallResult) : jobs[i].presplit ? 0 : sizeof(ColStats) * (size_t)jobs[i].nkeycols;
         total = (total + 63) & ~(size_t)63;
         if (status[i].ok() && !jobs[i].small) any_general = true;
     }
@@ -442,6 +450,7 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
                                            reinterpret_cast<SmallResult*>(h + jobs[i].scratch_off));
             continue;
         }
+        if (jobs[i].presplit) continue;
         hipError_t e = hipMemcpyAsync(h + jobs[i].scratch_off, jobs[i].stats_dev.get(), sizeof(ColStats) * (size_t)jobs[i].nkeycols,
                                       hipMemcpyDeviceToHost, ctx->stream);
         if (e != hipSuccess) status[i] = {CPH_ERR_HIP, std::string("statistics read-back: ") + hipGetErrorString(e)};
@@ -461,7 +470,7 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
             else if (status[i].ok()) index_plan_table(jobs[i].ix);
             continue;
         }
-        stats_host[i].assign(h + jobs[i].scratch_off, h + jobs[i].scratch_off + sizeof(ColStats) * (size_t)jobs[i].nkeycols);
+        if (!jobs[i].presplit) stats_host[i].assign(h + jobs[i].scratch_off, h + jobs[i].scratch_off + sizeof(ColStats) * (size_t)jobs[i].nkeycols);
     }
     for (size_t i = 0; i < nj; i++)
         if (status[i].ok() && !jobs[i].small) status[i] = build_phase2(ctx, &jobs[i], stats_host[i].data());
@@ -496,6 +505,7 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
         std::vector<Status> st1(1);
         BuildJob& j = one[0];
         j.no_split = true;
+        j.presplit = false;
         j.split_miss.reset();
         cph_index* ix = j.ix;
         ix->codec = CodecHost{};
@@ -628,13 +638,19 @@ static Status build_phase2(cph_ctx* ctx, BuildJob* job, const void* stats_host) 
     const uint64_t n = ix->nrows;
     const int32_t nkeycols = job->nkeycols;
     const DevCol* dcols = job->dcols;
+    if (job->presplit) {   // the codec is there already (build_phase1)
+        CPH_TRY(job->split_miss.alloc(&ctx->pool, sizeof(uint32_t)));
+        CPH_HIP_TRY(hipMemsetAsync(job->split_miss.get(), 0, sizeof(uint32_t), ctx->stream));
+        CPH_TRY(codec_upload(ctx, ix->codec, &ix->codec_dev));
+        return build_encode_sort(ctx, job);
+    }
     std::vector<ColStats> stats;
     codec_stats_finish(dcols, nkeycols, stats_host, &stats);
     uint64_t positions = 0;
     for (const auto& s : stats) positions += s.maxlen;
     if (positions > (uint64_t)kMaxKeyBytes) return build_multi_window(ctx, job, stats);
     CPH_TRY(codec_build(stats, &ix->codec));
-    if (!job->no_split) CPH_TRY(codec_try_split(ctx, dcols, nkeycols, n, stats, &ix->codec));   // only acts on codes beyond 32 bits
+    if (!job->no_split) CPH_TRY(codec_try_split(ctx, dcols, nkeycols, n, &stats, &ix->codec));   // only acts on codes beyond 32 bits
     if (ix->codec.has_split()) {
         CPH_TRY(job->split_miss.alloc(&ctx->pool, sizeof(uint32_t)));
         CPH_HIP_TRY(hipMemsetAsync(job->split_miss.get(), 0, sizeof(uint32_t), ctx->stream));

@@ -118,7 +118,7 @@ __device__ __forceinline__ CodecView codec_load_to_lds(const uint8_t* g_blob, ui
 // it is not there.  One hash, one u16 slot, the entry's words compared.
 __device__ __forceinline__ int wide_lookup(const CodecView& cv, uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3, uint32_t len) {
     const uint32_t mask = (1u << cv.hdr->wide_hash_bits) - 1u;
-    uint32_t sl = (uint32_t)wide_hash(w0, w1, w2, w3, len) & mask;
+    uint32_t sl = wide_hash_lo(w0, w1, w2, w3, len) & mask;
     for (;;) {
         const uint32_t e = cv.wide_hash[sl];
         if (e == 0) return -1;

@@ -136,15 +136,26 @@ struct WideKey {
 // 64-bit hash of a WideKey (host and device agree): the low half picks the slot of the codec block's lookup table, the
 // whole value is the tag under which the statistics pass collects the distinct prefixes.  Never 0 (0 = empty slot).
 CPH_HD2 inline uint32_t wide_rotl(uint32_t v, int r) { return (v << r) | (v >> (32 - r)); }
-CPH_HD2 inline uint64_t wide_hash(uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3, uint32_t len) {
-    const uint32_t x = (uint32_t)w0 ^ wide_rotl((uint32_t)w1, 9) ^ wide_rotl((uint32_t)w2, 18) ^ wide_rotl((uint32_t)w3, 27) ^ (len * 0x01000193u);
-    const uint32_t y = (uint32_t)(w0 >> 32) ^ wide_rotl((uint32_t)(w1 >> 32), 7) ^ wide_rotl((uint32_t)(w2 >> 32), 14) ^ wide_rotl((uint32_t)(w3 >> 32), 21);
+// (two functions: the kernel that only looks prefixes up pays for the low half alone)
+CPH_HD2 inline void wide_fold(uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3, uint32_t len, uint32_t* x, uint32_t* y) {
+    *x = (uint32_t)w0 ^ wide_rotl((uint32_t)w1, 9) ^ wide_rotl((uint32_t)w2, 18) ^ wide_rotl((uint32_t)w3, 27) ^ (len * 0x01000193u);
+    *y = (uint32_t)(w0 >> 32) ^ wide_rotl((uint32_t)(w1 >> 32), 7) ^ wide_rotl((uint32_t)(w2 >> 32), 14) ^ wide_rotl((uint32_t)(w3 >> 32), 21);
+}
+CPH_HD2 inline uint32_t wide_hash_lo(uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3, uint32_t len) {
+    uint32_t x, y;
+    wide_fold(w0, w1, w2, w3, len, &x, &y);
     uint32_t h1 = (x * 0x9E3779B1u) ^ (y * 0x85EBCA6Bu);
     h1 ^= h1 >> 15;
-    h1 *= 0xC2B2AE35u;
-    h1 ^= h1 >> 13;
+    return h1;
+}
+CPH_HD2 inline uint64_t wide_hash(uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3, uint32_t len) {
+    uint32_t x, y;
+    wide_fold(w0, w1, w2, w3, len, &x, &y);
+    const uint32_t h1 = wide_hash_lo(w0, w1, w2, w3, len);
     uint32_t h2 = (x * 0xCC9E2D51u + wide_rotl(y, 13)) * 0x1B873593u;
     h2 ^= h2 >> 16;
+    h2 *= 0xC2B2AE35u;
+    h2 ^= h2 >> 13;
     const uint64_t h = (uint64_t)h1 | ((uint64_t)h2 << 32);
     return h ? h : 1ull;
 }
@@ -186,6 +197,7 @@ struct CodecHost {
     // ("Smith/Amelia#12345") cost their information, not their byte positions: BASELINE config 3 codes in 25 bits.
     int32_t split_col = -1;                 // key column of the table that is split (-1: none)
     uint8_t split_byte = 0;
+    int32_t split_maxlen = 0;               // longest value of the split column in the build table (which kernel instantiation encodes it)
     std::vector<WideKey> wdict;             // distinct prefixes in rank order
     bool has_split() const { return split_col >= 0; }
     int32_t virtual_cols(int32_t real_cols) const { return real_cols + (has_split() && split_col < real_cols ? 1 : 0); }
@@ -455,8 +467,10 @@ struct EncodeHist {
 Status codec_encode_build(cph_ctx* ctx, const CodecHost& codec, const DevBuf& codec_dev, const DevCol* cols,
                           uint64_t n, void* out_codes, const EncodeHist* hist = nullptr, const GroupSpec* spec = nullptr,
                           uint32_t* miss = nullptr);
-// The delimiter split (keycodec.hip "split codec"): tried when the plain code does not fit 32 bits.
-Status codec_try_split(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t n, const std::vector<ColStats>& stats, CodecHost* codec);
+// The delimiter split (keycodec.hip "split codec"): tried when the plain code does not fit 32 bits.  stats: the plain
+// statistics *codec was built from, or nullptr for ONE variable-length key column before any statistics exist (a large
+// table then skips the plain statistics pass); codec->has_split() tells whether the split was taken.
+Status codec_try_split(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t n, const std::vector<ColStats>* stats, CodecHost* codec);
 // Host-side encoding of literal values (cph_index_find).  Returns false when a
 // value cannot occur in the index (symbol outside the alphabet / too long).
 bool codec_encode_values_host(const CodecHost& codec, const cph_strval* values, int32_t nvalues,

@@ -176,7 +176,7 @@ struct WindowHeader {
 struct CodecHeader {
     int32_t ncols, npos, nwords, key32;
     int32_t has_groups, ndict;   // dictionary-coded groups: unit/dict_off/dict_len per position + ndict entries
-    int32_t split_col, split_byte, nwide, reserved_;   // split codec: the table's key column that is cut (-1: none), the delimiter, prefixes
+    int32_t split_col, split_byte, nwide, split_maxlen;   // split codec: the table's key column that is cut (-1: none), the delimiter, prefixes, longest value
     int32_t col_start[kMaxKeyCols + 1];
     int32_t col_maxlen[kMaxKeyCols];
     int32_t col_minlen[kMaxKeyCols];
@@ -201,6 +201,7 @@ static void codec_block_serialize(const CodecHost& cd, std::vector<uint8_t>* out
     h.split_col = cd.split_col;
     h.split_byte = cd.split_byte;
     h.nwide = (int32_t)cd.wdict.size();
+    h.split_maxlen = cd.split_maxlen;
     memcpy(h.col_start, cd.col_start, sizeof h.col_start);
     memcpy(h.col_maxlen, cd.col_maxlen, sizeof h.col_maxlen);
     memcpy(h.col_minlen, cd.col_minlen, sizeof h.col_minlen);
@@ -332,6 +333,8 @@ static bool codec_block_parse(const uint8_t* p, size_t n, size_t* at, CodecHost*
     if (h.split_col >= 0) {
         cd.split_col = h.split_col;
         cd.split_byte = (uint8_t)h.split_byte;
+        cd.split_maxlen = h.split_maxlen;
+        if (h.split_maxlen < 0) return false;
         cd.wdict.resize((size_t)h.nwide);
         if (!get(cd.wdict.data(), cd.wdict.size() * sizeof(WideKey))) return false;
         if (cd.col_maxlen[h.split_col] < 1 || cd.col_maxlen[h.split_col] > kWideBytes ||

@@ -814,14 +814,23 @@ struct SplitSlot {                            // one entry of the device set
     uint64_t w[4];
     uint32_t len, pad_;
 };
-struct SplitStats {                           // what k_split_stats / k_split_sample leave behind
+struct SplitStats {                           // what k_split_stats leaves behind (all zero before the first launch)
     uint32_t count;                           // distinct prefixes (may exceed the capacity: then the set is incomplete)
-    uint32_t flags;                           // bit 0: a prefix longer than kWideBytes, bit 1: a suffix longer than kSplitMaxSuffix,
-                                              // bit 2: the set ran full
+    uint32_t flags;                           // bit 0: a value longer than the kernel's registers or a prefix longer than kWideBytes,
+                                              // bit 1: a suffix longer than kSplitMaxSuffix, bit 2: the set ran full
     uint32_t rows_with;                       // rows that hold the delimiter
-    uint32_t pmin, pmax, smin, smax;          // prefix / suffix lengths
-    uint32_t pad_;
+    uint32_t pmin_inv, pmax, smin_inv, smax;  // prefix / suffix lengths; the minima as ~min (so that zero means "no row yet")
+    uint32_t vmax;                            // longest whole value
     uint32_t mask[kSplitMaxSuffix][8];        // byte presence per suffix position
+};
+struct SplitCands {                           // the delimiter candidates one launch examines: blockIdx.y picks one
+    uint32_t n;
+    uint8_t d[12];
+};
+struct SplitSample {                          // k_split_count: what a sample of the rows says about the column
+    uint32_t cnt[256];                        // rows holding each byte value
+    uint32_t maxlen, minlen_inv, pad_[2];
+    uint32_t mask[kSplitMaxValue][8];         // byte presence per position (the plain per-position code's alphabets)
 };
 
 // NCH chunks of a value without a branch (rows past the value's end read base8: load_chunk_nobranch)
@@ -884,87 +893,111 @@ __device__ __forceinline__ bool split_lengths(const ValueRegs<NCH>& v, uint64_t 
     return at < v.len;
 }
 
-// LDS: set of tags (kSplitSeenSlots u64) | suffix byte flags (kSplitMaxSuffix * 256 u8)
+// LDS: set of tags (kSplitSeenSlots u64) | suffix byte flags (kSplitMaxSuffix * 256 u8).  blockIdx.y = candidate.
+// Phases over kSplitRows rows per lane, each straight-line (spans | chunks | cut + tag | first look into the LDS set |
+// — rarely — the device set | suffix flags).
 template <int NCH>
-__global__ __launch_bounds__(kSplitThreads) void k_split_stats(DevCol col, uint32_t d, uint64_t step, uint64_t n /* rows looked at: 0, step, 2 step, ... */,
-                                                              SplitSlot* __restrict__ slots, SplitStats* __restrict__ out) {
+__global__ __launch_bounds__(kSplitThreads) void k_split_stats(DevCol col, SplitCands cands, uint64_t step, uint64_t n /* rows looked at: 0, step, 2 step, ... */,
+                                                              SplitSlot* __restrict__ all_slots, SplitStats* __restrict__ all_out) {
     __shared__ unsigned long long s_seen[kSplitSeenSlots];
     __shared__ __attribute__((aligned(16))) uint8_t s_flag[kSplitMaxSuffix * 256];
-    __shared__ uint32_t s_pmin, s_pmax, s_smin, s_smax, s_with, s_flags;
+    __shared__ uint32_t s_pmin, s_pmax, s_smin, s_smax, s_with, s_flags, s_vmax;
+    const uint32_t d = cands.d[blockIdx.y];
+    SplitSlot* __restrict__ slots = all_slots + (size_t)blockIdx.y * kSplitSetSlots;
+    SplitStats* __restrict__ out = all_out + blockIdx.y;
     for (int i = threadIdx.x; i < kSplitSeenSlots; i += kSplitThreads) s_seen[i] = 0ull;
     for (int i = threadIdx.x; i < kSplitMaxSuffix * 256 / 16; i += kSplitThreads) reinterpret_cast<uint4*>(s_flag)[i] = make_uint4(0, 0, 0, 0);
-    if (threadIdx.x == 0) { s_pmin = 0xFFFFFFFFu; s_pmax = 0; s_smin = 0xFFFFFFFFu; s_smax = 0; s_with = 0; s_flags = 0; }
+    if (threadIdx.x == 0) { s_pmin = 0xFFFFFFFFu; s_pmax = 0; s_smin = 0xFFFFFFFFu; s_smax = 0; s_with = 0; s_flags = 0; s_vmax = 0; }
     __syncthreads();
     const uint64_t dv = 0x0101010101010101ull * (uint64_t)(d & 0xFFu);
-    uint32_t pmin = 0xFFFFFFFFu, pmax = 0, smin = 0xFFFFFFFFu, smax = 0, with = 0, flags = 0;
+    uint32_t pmin = 0xFFFFFFFFu, pmax = 0, smin = 0xFFFFFFFFu, smax = 0, with = 0, flags = 0, vmax = 0;
     const uint64_t stride = (uint64_t)gridDim.x * kSplitThreads * kSplitRows;
     for (uint64_t base = (uint64_t)blockIdx.x * kSplitThreads * kSplitRows; base < n; base += stride) {
         ValueRegs<NCH> v[kSplitRows];
-        uint64_t b[kSplitRows], l[kSplitRows];
+        {
+            uint64_t b[kSplitRows], l[kSplitRows];
 #pragma unroll
-        for (int k = 0; k < kSplitRows; k++) {   // rows past the end repeat the last row: harmless for statistics
-            const uint64_t i = base + (uint64_t)k * kSplitThreads + threadIdx.x;
-            value_span_whole(col, (i < n ? i : n - 1) * step, &b[k], &l[k]);
+            for (int k = 0; k < kSplitRows; k++) {   // rows past the end repeat the last row: harmless for statistics
+                const uint64_t i = base + (uint64_t)k * kSplitThreads + threadIdx.x;
+                value_span_whole(col, (i < n ? i : n - 1) * step, &b[k], &l[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < kSplitRows; k++) v[k].load(col, b[k], l[k]);
         }
-#pragma unroll
-        for (int k = 0; k < kSplitRows; k++) v[k].load(col, b[k], l[k]);
+        uint32_t plen[kSplitRows], slen[kSplitRows], h[kSplitRows];
+        uint64_t w[kSplitRows][4];
+        unsigned long long tag[kSplitRows], cur[kSplitRows];
+        bool usable[kSplitRows];
 #pragma unroll
         for (int k = 0; k < kSplitRows; k++) {
-            if (v[k].len > (uint32_t)(8 * NCH)) { flags |= 1u; continue; }   // (the host does not split such a column)
-            uint32_t plen, slen;
-            const bool has = split_lengths(v[k], dv, &plen, &slen);
+            const bool has = split_lengths(v[k], dv, &plen[k], &slen[k]);
+            usable[k] = v[k].len <= (uint32_t)(8 * NCH) && plen[k] <= (uint32_t)kWideBytes;   // (the host does not split otherwise)
+            if (!usable[k]) flags |= 1u;
+            if (slen[k] > (uint32_t)kSplitMaxSuffix) flags |= 2u;
             with += has && base + (uint64_t)k * kSplitThreads + threadIdx.x < n ? 1u : 0u;
-            pmin = plen < pmin ? plen : pmin;
-            pmax = plen > pmax ? plen : pmax;
-            smin = slen < smin ? slen : smin;
-            smax = slen > smax ? slen : smax;
-            if (plen > (uint32_t)kWideBytes) { flags |= 1u; continue; }
-            if (slen > (uint32_t)kSplitMaxSuffix) flags |= 2u;
-            // ---- the prefix: met before by this workgroup? ----
-            uint64_t w[4];
-            v[k].head_words(plen, w);
-            const unsigned long long tag = wide_hash(w[0], w[1], w[2], w[3], plen);
-            uint32_t h = (uint32_t)(tag >> 32) & (kSplitSeenSlots - 1);
+            pmin = plen[k] < pmin ? plen[k] : pmin;
+            pmax = plen[k] > pmax ? plen[k] : pmax;
+            smin = slen[k] < smin ? slen[k] : smin;
+            smax = slen[k] > smax ? slen[k] : smax;
+            vmax = v[k].len > vmax ? v[k].len : vmax;
+            v[k].head_words(plen[k] < (uint32_t)kWideBytes ? plen[k] : (uint32_t)kWideBytes, w[k]);
+            tag[k] = wide_hash(w[k][0], w[k][1], w[k][2], w[k][3], plen[k]);
+            h[k] = (uint32_t)(tag[k] >> 32) & (kSplitSeenSlots - 1);
+        }
+#pragma unroll
+        for (int k = 0; k < kSplitRows; k++) cur[k] = s_seen[h[k]];
+#pragma unroll
+        for (int k = 0; k < kSplitRows; k++) {
+            if (cur[k] == tag[k] || !usable[k]) continue;   // met before by this workgroup: already in the device set
             bool known = false;
-            for (int pr = 0; pr < 8; pr++, h = (h + 1) & (kSplitSeenSlots - 1)) {
-                const unsigned long long cur = s_seen[h];
-                if (cur == tag) { known = true; break; }
-                if (cur == 0ull) break;
+            for (int pr = 0; pr < 8 && cur[k] != 0ull; pr++) {
+                h[k] = (h[k] + 1) & (kSplitSeenSlots - 1);
+                cur[k] = s_seen[h[k]];
+                if (cur[k] == tag[k]) { known = true; break; }
             }
-            if (!known) {
-                uint32_t g = (uint32_t)tag & (kSplitSetSlots - 1);
-                bool placed = false;
-                for (int pr = 0; pr < kSplitSetSlots; pr++, g = (g + 1) & (kSplitSetSlots - 1)) {
-                    unsigned long long cur = __hip_atomic_load(&slots[g].tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (cur == 0ull) {
-                        cur = atomicCAS(&slots[g].tag, 0ull, tag);
-                        if (cur == 0ull) {   // this thread's slot: the payload is read by the host only
-                            slots[g].w[0] = w[0]; slots[g].w[1] = w[1]; slots[g].w[2] = w[2]; slots[g].w[3] = w[3];
-                            slots[g].len = plen;
-                            atomicAdd(&out->count, 1u);
-                            placed = true;
-                            break;
-                        }
+            if (known) continue;
+            uint32_t g = (uint32_t)tag[k] & (kSplitSetSlots - 1);
+            bool placed = false;
+            for (int pr = 0; pr < kSplitSetSlots; pr++, g = (g + 1) & (kSplitSetSlots - 1)) {
+                unsigned long long c2 = __hip_atomic_load(&slots[g].tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (c2 == 0ull) {
+                    c2 = atomicCAS(&slots[g].tag, 0ull, tag[k]);
+                    if (c2 == 0ull) {   // this thread's slot: the payload is read by the host only
+                        slots[g].w[0] = w[k][0]; slots[g].w[1] = w[k][1]; slots[g].w[2] = w[k][2]; slots[g].w[3] = w[k][3];
+                        slots[g].len = plen[k];
+                        atomicAdd(&out->count, 1u);
+                        placed = true;
+                        break;
                     }
-                    if (cur == tag) { placed = true; break; }
                 }
-                if (!placed) flags |= 4u;
-                if (s_seen[h] == 0ull) atomicCAS(&s_seen[h], 0ull, tag);   // (a lost race only costs another global look-up later)
+                if (c2 == tag[k]) { placed = true; break; }
             }
-            // ---- the suffix: byte presence per position ----
-            uint64_t w0, w1;
-            v[k].window(plen, &w0, &w1);
-            const uint32_t lim = slen < (uint32_t)kSplitMaxSuffix ? slen : (uint32_t)kSplitMaxSuffix;
-            for (uint32_t q = 0; q < lim; q++) {
-                const uint64_t src = q < 8u ? w0 : w1;
-                s_flag[q * 256u + ((uint32_t)(src >> (8u * (q & 7u))) & 0xFFu)] = 1;
+            if (!placed) flags |= 4u;
+            if (cur[k] == 0ull) atomicCAS(&s_seen[h[k]], 0ull, tag[k]);   // (a lost race only costs another global look-up later)
+        }
+        // ---- the suffix: byte presence per position ----
+        uint32_t lim = 0;
+        uint64_t w0[kSplitRows], w1[kSplitRows];
+#pragma unroll
+        for (int k = 0; k < kSplitRows; k++) {
+            v[k].window(plen[k], &w0[k], &w1[k]);
+            lim = slen[k] > lim ? slen[k] : lim;
+        }
+        lim = wave_max(lim);
+        lim = lim < (uint32_t)kSplitMaxSuffix ? lim : (uint32_t)kSplitMaxSuffix;   // wave-uniform
+        for (uint32_t q = 0; q < lim; q++) {
+#pragma unroll
+            for (int k = 0; k < kSplitRows; k++) {
+                const uint64_t src = q < 8u ? w0[k] : w1[k];
+                if (q < slen[k]) s_flag[q * 256u + ((uint32_t)(src >> (8u * (q & 7u))) & 0xFFu)] = 1;
             }
         }
     }
-    pmin = wave_min(pmin); pmax = wave_max(pmax); smin = wave_min(smin); smax = wave_max(smax); with = wave_sum(with);
+    pmin = wave_min(pmin); pmax = wave_max(pmax); smin = wave_min(smin); smax = wave_max(smax); with = wave_sum(with); vmax = wave_max(vmax);
     if (lane_id() == 0) {
         atomicMin(&s_pmin, pmin); atomicMax(&s_pmax, pmax); atomicMin(&s_smin, smin); atomicMax(&s_smax, smax);
         atomicAdd(&s_with, with);
+        atomicMax(&s_vmax, vmax);
     }
     if (flags) atomicOr(&s_flags, flags);
     __syncthreads();
@@ -980,23 +1013,26 @@ __global__ __launch_bounds__(kSplitThreads) void k_split_stats(DevCol col, uint3
         if (bits && (__hip_atomic_load(gm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bits) != bits) atomicOr(gm, bits);
     }
     if (threadIdx.x == 0) {
-        atomicMin(&out->pmin, s_pmin); atomicMax(&out->pmax, s_pmax); atomicMin(&out->smin, s_smin); atomicMax(&out->smax, s_smax);
+        atomicMax(&out->pmin_inv, ~s_pmin); atomicMax(&out->pmax, s_pmax); atomicMax(&out->smin_inv, ~s_smin); atomicMax(&out->smax, s_smax);
+        atomicMax(&out->vmax, s_vmax);
         if (s_with) atomicAdd(&out->rows_with, s_with);
         if (s_flags) atomicOr(&out->flags, s_flags);
     }
 }
 
-
-// Rows (0, step, 2 step, ... : n of them) that hold each byte value at least once, and the longest of them — where a
-// delimiter could be.  A byte is counted at its FIRST occurrence in a value.
-template <int NCH>
-__global__ __launch_bounds__(kSplitThreads) void k_split_count(DevCol col, uint64_t step, uint64_t n, uint32_t* __restrict__ counts /* [256] + maxlen */) {
+// Rows (0, step, 2 step, ... : n of them) that hold each byte value at least once (a byte is counted at its FIRST
+// occurrence in a value) — where a delimiter could be —, and the plain per-position statistics of those rows (lengths,
+// byte presence per position) — what the per-position code would cost.
+__global__ __launch_bounds__(kSplitThreads) void k_split_count(DevCol col, uint64_t step, uint64_t n, SplitSample* __restrict__ out) {
+    constexpr int NCH = kSplitMaxValue / 8;
     __shared__ uint32_t s_cnt[256];
-    __shared__ uint32_t s_max;
+    __shared__ __attribute__((aligned(16))) uint8_t s_flag[kSplitMaxValue * 256];
+    __shared__ uint32_t s_max, s_min;
     for (int i = threadIdx.x; i < 256; i += kSplitThreads) s_cnt[i] = 0;
-    if (threadIdx.x == 0) s_max = 0;
+    for (int i = threadIdx.x; i < kSplitMaxValue * 256 / 16; i += kSplitThreads) reinterpret_cast<uint4*>(s_flag)[i] = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x == 0) { s_max = 0; s_min = 0xFFFFFFFFu; }
     __syncthreads();
-    uint32_t mx = 0;
+    uint32_t mx = 0, mn = 0xFFFFFFFFu;
     const uint64_t stride = (uint64_t)gridDim.x * kSplitThreads;
     for (uint64_t i = (uint64_t)blockIdx.x * kSplitThreads + threadIdx.x; i < n; i += stride) {
         uint64_t b, l;
@@ -1004,26 +1040,44 @@ __global__ __launch_bounds__(kSplitThreads) void k_split_count(DevCol col, uint6
         ValueRegs<NCH> v;
         v.load(col, b, l);
         mx = v.len > mx ? v.len : mx;
+        mn = v.len < mn ? v.len : mn;
         const uint32_t lim = v.len < (uint32_t)(8 * NCH) ? v.len : (uint32_t)(8 * NCH);
         for (uint32_t q = 0; q < lim; q++) {
             uint64_t w0, w1;
             v.window(q, &w0, &w1);
             const uint32_t byte = (uint32_t)w0 & 0xFFu;
+            s_flag[q * 256u + byte] = 1;
             if (v.find(0x0101010101010101ull * (uint64_t)byte) == q) atomicAdd(&s_cnt[byte], 1u);
         }
     }
     mx = wave_max(mx);
-    if (lane_id() == 0) atomicMax(&s_max, mx);
+    mn = wave_min(mn);
+    if (lane_id() == 0) { atomicMax(&s_max, mx); atomicMin(&s_min, mn); }
     __syncthreads();
     for (int i = threadIdx.x; i < 256; i += kSplitThreads)
-        if (s_cnt[i]) atomicAdd(&counts[i], s_cnt[i]);
-    if (threadIdx.x == 0) atomicMax(&counts[256], s_max);
+        if (s_cnt[i]) atomicAdd(&out->cnt[i], s_cnt[i]);
+    for (int i = threadIdx.x; i < kSplitMaxValue * 8; i += kSplitThreads) {
+        const uint32_t* f = reinterpret_cast<const uint32_t*>(s_flag + 32 * i);
+        uint32_t bits = 0;
+#pragma unroll
+        for (int x = 0; x < 8; x++) {
+            const uint32_t q = f[x];
+            bits |= ((q & 1u) | ((q >> 7) & 2u) | ((q >> 14) & 4u) | ((q >> 21) & 8u)) << (4 * x);
+        }
+        uint32_t* gm = &out->mask[0][0] + i;
+        if (bits && (__hip_atomic_load(gm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bits) != bits) atomicOr(gm, bits);
+    }
+    if (threadIdx.x == 0) { atomicMax(&out->maxlen, s_max); atomicMax(&out->minlen_inv, ~s_min); }
 }
 
 // Build-side encode of ONE key column through a split codec (single word): the value's chunks in registers, the
-// delimiter found there, the prefix looked up in the LDS dictionary (verified byte for byte), the suffix through the rank
-// LUT.  A workgroup walks whole SORT tiles and leaves the first radix pass's histogram behind (k_encode_build_fast).
-// *miss is raised by a row the codec cannot code: the caller starts over without the split.
+// delimiter found there, the prefix looked up in the LDS dictionary (verified word for word), the suffix through a
+// pre-multiplied LUT the workgroup forms in LDS (rank * weight per (position, symbol): one LDS load + add per suffix
+// byte).  Phases over kSplitRows rows per lane, each straight-line so that the rows' loads overlap (spans | chunks |
+// hash slots | dictionary entries | suffix positions); only a hash collision loops.  A workgroup walks whole SORT tiles
+// and leaves the first radix pass's histogram behind (k_encode_build_fast).  *miss is raised by a row whose prefix is not
+// in the dictionary: the caller starts over without the split.  (Suffix symbols need no check: the alphabets come from
+// exact statistics over these very rows.)
 template <class OUT, int NCH>
 __global__ __launch_bounds__(kSplitThreads) void k_encode_split(DevCol col, const uint8_t* __restrict__ g_codec, uint64_t n,
                                                                OUT* __restrict__ out, uint32_t tile_rows, uint32_t ntiles,
@@ -1031,12 +1085,20 @@ __global__ __launch_bounds__(kSplitThreads) void k_encode_split(DevCol col, cons
                                                                int codec_bytes, uint32_t* __restrict__ miss) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const CodecView cv = codec_load_to_lds(g_codec, smem);
-    uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + codec_bytes);
     const uint64_t dv = 0x0101010101010101ull * (uint64_t)((uint32_t)cv.hdr->split_byte & 0xFFu);
     const int vp = cv.hdr->split_vcol;                 // the prefix column; vp + 1 is the suffix column
     const int ps = cv.hdr->col_start[vp + 1];          // first suffix position
     const uint32_t smaxlen = (uint32_t)cv.hdr->col_maxlen[vp + 1];
     const OUT pmult = (OUT)cv.mult[cv.hdr->wide_pos];
+    // dynamic LDS: [codec block][suffix LUT: smaxlen x 257 x OUT][histogram: bins x u32]
+    CPH_LDS OUT* s_lutw = (CPH_LDS OUT*)(smem + codec_bytes);
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + codec_bytes + (size_t)smaxlen * kLutStride * sizeof(OUT));
+    for (uint32_t i = threadIdx.x; i < smaxlen * (uint32_t)kLutStride; i += kSplitThreads) {
+        const uint32_t r = cv.lut[(uint32_t)ps * kLutStride + i];
+        s_lutw[i] = r == kLutInvalid ? (OUT)0 : (OUT)r * (OUT)cv.mult[ps + (int)(i / kLutStride)];
+    }
+    __syncthreads();
+    const uint32_t hmask = (1u << cv.hdr->wide_hash_bits) - 1u;
     const uint32_t per_xcd = (ntiles + 7) / 8, xcd = blockIdx.x & 7u;   // XCD-contiguous tile ranges (k_encode_build_fast)
     const uint32_t t_end = (xcd + 1) * per_xcd < ntiles ? (xcd + 1) * per_xcd : ntiles;
     uint32_t missed = 0;
@@ -1048,52 +1110,69 @@ __global__ __launch_bounds__(kSplitThreads) void k_encode_split(DevCol col, cons
         const uint64_t tile_end = (uint64_t)(tile + 1) * tile_rows < n ? (uint64_t)(tile + 1) * tile_rows : n;
         for (uint64_t base = (uint64_t)tile * tile_rows; base < tile_end; base += (uint64_t)kSplitThreads * kSplitRows) {
             ValueRegs<NCH> v[kSplitRows];
-            uint64_t b[kSplitRows], l[kSplitRows];
+            {
+                uint64_t b[kSplitRows], l[kSplitRows];
 #pragma unroll
-            for (int k = 0; k < kSplitRows; k++) {   // rows past the end re-read the last row (never stored)
-                const uint64_t i = base + (uint64_t)k * kSplitThreads + threadIdx.x;
-                value_span_whole(col, i < n ? i : n - 1, &b[k], &l[k]);
+                for (int k = 0; k < kSplitRows; k++) {   // rows past the end re-read the last row (never stored)
+                    const uint64_t i = base + (uint64_t)k * kSplitThreads + threadIdx.x;
+                    value_span_whole(col, i < n ? i : n - 1, &b[k], &l[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < kSplitRows; k++) v[k].load(col, b[k], l[k]);
             }
-#pragma unroll
-            for (int k = 0; k < kSplitRows; k++) v[k].load(col, b[k], l[k]);
-            uint32_t plen[kSplitRows], slen[kSplitRows];
+            uint32_t plen[kSplitRows], slen[kSplitRows], sl[kSplitRows], e[kSplitRows];
             uint64_t w[kSplitRows][4];
-            uint32_t sl[kSplitRows];
-            const uint32_t hmask = (1u << cv.hdr->wide_hash_bits) - 1u;
 #pragma unroll
             for (int k = 0; k < kSplitRows; k++) {
                 split_lengths(v[k], dv, &plen[k], &slen[k]);
                 v[k].head_words(plen[k] < (uint32_t)kWideBytes ? plen[k] : (uint32_t)kWideBytes, w[k]);
-                sl[k] = (uint32_t)wide_hash(w[k][0], w[k][1], w[k][2], w[k][3], plen[k]) & hmask;
+                sl[k] = wide_hash_lo(w[k][0], w[k][1], w[k][2], w[k][3], plen[k]) & hmask;
             }
-            OUT acc[kSplitRows];
+#pragma unroll
+            for (int k = 0; k < kSplitRows; k++) e[k] = cv.wide_hash[sl[k]];
+            bool hit[kSplitRows];
+#pragma unroll
+            for (int k = 0; k < kSplitRows; k++) {   // (entry 0 stands in for an empty slot: compared, never accepted)
+                const CPH_LDS WideKey* key = cv.wide + (e[k] ? e[k] - 1 : 0);
+                bool same = key->len == plen[k] && key->w[0] == w[k][0] && key->w[1] == w[k][1] && key->w[2] == w[k][2];
+                if constexpr (NCH > 3) same = same && key->w[3] == w[k][3];
+                hit[k] = e[k] != 0 && same;
+            }
 #pragma unroll
             for (int k = 0; k < kSplitRows; k++) {
-                bool ok = v[k].len <= (uint32_t)(8 * NCH) && plen[k] <= (uint32_t)kWideBytes && slen[k] <= smaxlen;
-                int rank = -1;
-                for (;;) {   // ends on the entry (every build prefix is in the dictionary) or on an empty slot
-                    const uint32_t e = cv.wide_hash[sl[k]];
-                    if (e == 0) break;
-                    const CPH_LDS WideKey* key = cv.wide + (e - 1);
-                    if (key->len == plen[k] && key->w[0] == w[k][0] && key->w[1] == w[k][1] && key->w[2] == w[k][2] && key->w[3] == w[k][3]) { rank = (int)(e - 1); break; }
+                while (e[k] != 0 && !hit[k]) {   // another prefix's slot (rare): linear probing to the entry or an empty slot
                     sl[k] = (sl[k] + 1) & hmask;
+                    e[k] = cv.wide_hash[sl[k]];
+                    if (e[k]) {
+                        const CPH_LDS WideKey* key = cv.wide + (e[k] - 1);
+                        hit[k] = key->len == plen[k] && key->w[0] == w[k][0] && key->w[1] == w[k][1] && key->w[2] == w[k][2] && key->w[3] == w[k][3];
+                    }
                 }
-                ok = ok && rank >= 0;
-                acc[k] = (OUT)(rank < 0 ? 0 : rank) * pmult;
-                uint64_t w0, w1;
-                v[k].window(plen[k], &w0, &w1);
-                for (uint32_t q = 0; q < smaxlen; q++) {   // uniform bound
-                    const uint64_t src = q < 8u ? w0 : w1;
+            }
+            OUT acc[kSplitRows];
+            uint64_t w0[kSplitRows], w1[kSplitRows];
+#pragma unroll
+            for (int k = 0; k < kSplitRows; k++) {
+                const bool ok = hit[k] && v[k].len <= (uint32_t)(8 * NCH) && plen[k] <= (uint32_t)kWideBytes && slen[k] <= smaxlen;
+                if (!ok && base + (uint64_t)k * kSplitThreads + threadIdx.x < tile_end) missed = 1;
+                acc[k] = (OUT)(hit[k] ? e[k] - 1 : 0u) * pmult;
+                v[k].window(plen[k], &w0[k], &w1[k]);
+            }
+            for (uint32_t q = 0; q < smaxlen; q++) {   // uniform bound; the rows' LDS loads of a position overlap
+                const CPH_LDS OUT* lp = s_lutw + q * (uint32_t)kLutStride;
+#pragma unroll
+                for (int k = 0; k < kSplitRows; k++) {
+                    const uint64_t src = q < 8u ? w0[k] : w1[k];
                     const uint32_t sym = q < slen[k] ? ((uint32_t)(src >> (8u * (q & 7u))) & 0xFFu) + 1u : 0u;
-                    const uint32_t r = cv.lut[(ps + (int)q) * kLutStride + (int)sym];
-                    ok = ok && r != kLutInvalid;
-                    acc[k] += (OUT)r * (OUT)cv.mult[ps + (int)q];
+                    acc[k] += lp[sym];
                 }
+            }
+#pragma unroll
+            for (int k = 0; k < kSplitRows; k++) {
                 const uint64_t i = base + (uint64_t)k * kSplitThreads + threadIdx.x;
                 if (i < tile_end) {
                     out[i] = acc[k];
                     if (counts) atomicAdd(&s_hist[(uint32_t)acc[k] & digit_mask], 1u);
-                    if (!ok) missed = 1;
                 }
             }
         }
@@ -1105,7 +1184,6 @@ __global__ __launch_bounds__(kSplitThreads) void k_encode_split(DevCol col, cons
     }
     if (__ballot(missed) && lane_id() == 0) atomicOr(miss, 1u);
 }
-
 
 // ---- split codec: host side -------------------------------------------------------------------------------------
 int codec_virtual_cols(const CodecHost& cd, const DevCol* real, int nreal, DevCol* out) {
@@ -1149,56 +1227,85 @@ static double radix_bits(const ColStats& st, uint32_t q) {
 }
 
 template <int NCH>
-static void launch_split_stats(cph_ctx* ctx, const DevCol& col, uint32_t d, uint64_t step, uint64_t rows, SplitSlot* slots, SplitStats* out) {
+static void launch_split_stats(cph_ctx* ctx, const DevCol& col, const SplitCands& cands, uint64_t step, uint64_t rows, SplitSlot* slots, SplitStats* out) {
     uint64_t nblk = (rows + (uint64_t)kSplitThreads * kSplitRows - 1) / ((uint64_t)kSplitThreads * kSplitRows);
     if (nblk > 2048) nblk = 2048;
     if (nblk < 1) nblk = 1;
-    hipLaunchKernelGGL((k_split_stats<NCH>), dim3((unsigned)nblk), dim3(kSplitThreads), 0, ctx->stream, col, d, step, rows, slots, out);
+    hipLaunchKernelGGL((k_split_stats<NCH>), dim3((unsigned)nblk, cands.n), dim3(kSplitThreads), 0, ctx->stream, col, cands, step, rows, slots, out);
+}
+// sort cost (codec_sort_cost) of a code of `bits` bits that is not built yet
+static double bits_sort_cost(double bits) {
+    if (bits <= 32.0) return std::ceil(bits / 8.0) * 8.0;
+    if (bits <= 63.0) return std::ceil(bits / 8.0) * 12.0;
+    const double words = std::ceil(bits / 63.0);
+    return std::ceil(bits / 8.0) * 12.0 + 16.0 * words;
 }
 
-// Tries the delimiter split on the key column that costs the most code bits.  stats = the plain statistics *codec was
-// built from.  On success *codec is the split codec, built from exact statistics over all rows; otherwise it is left
-// alone.  Three small synchronisations (byte counts of a sample, the candidates' sample statistics, the exact pass).
-Status codec_try_split(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t n, const std::vector<ColStats>& stats, CodecHost* codec) {
-    const CodecHost& plain = *codec;
-    if (!ctx->codec_split || n < (1ull << 16) || plain.key32 || ncols >= kMaxKeyCols || plain.has_groups()) return {};
+// Tries the delimiter split on the key column that costs the most code bits.
+//   stats != nullptr: the plain statistics *codec was built from (any number of key columns); on success *codec becomes the
+//                     split codec, otherwise it is left alone.
+//   stats == nullptr: ONE variable-length key column and no statistics yet ("sample first": a large table skips the plain
+//                     statistics pass when the split is taken); *codec is written on success only (has_split() says so).
+// The split codec comes from exact statistics over all rows.  Three small synchronisations: the sample's byte counts, the
+// candidates' sample statistics (one launch for all of them), the exact pass.
+Status codec_try_split(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t n, const std::vector<ColStats>* stats, CodecHost* codec) {
+    if (!ctx->codec_split || n < (1ull << 16) || ncols >= kMaxKeyCols) return {};
+    if (stats && (codec->key32 || codec->has_groups())) return {};
+    if (!stats && ncols != 1) return {};
     // the column to cut: variable length, short enough for the kernels' registers, the most plain code bits
     int c = -1;
-    double most = 0;
-    for (int k = 0; k < ncols; k++) {
-        if (cols[k].fixed_width || cols[k].segmented() || stats[(size_t)k].maxlen > (uint32_t)kSplitMaxValue || stats[(size_t)k].maxlen < 4) continue;
-        double bits = 0;
-        for (uint32_t q = 0; q < stats[(size_t)k].maxlen; q++) bits += radix_bits(stats[(size_t)k], q);
-        if (bits > most) { most = bits; c = k; }
+    double most = 0, plain_bits = 0;
+    if (stats) {
+        for (int k = 0; k < ncols; k++) {
+            double bits = 0;
+            for (uint32_t q = 0; q < (*stats)[(size_t)k].maxlen; q++) bits += radix_bits((*stats)[(size_t)k], q);
+            plain_bits += bits;
+            if (cols[k].fixed_width || cols[k].segmented() || (*stats)[(size_t)k].maxlen > (uint32_t)kSplitMaxValue || (*stats)[(size_t)k].maxlen < 4) continue;
+            if (bits > most) { most = bits; c = k; }
+        }
+        if (c < 0 || most < 24.0) return {};
+    } else {
+        if (cols[0].fixed_width || cols[0].segmented()) return {};
+        c = 0;
     }
-    if (c < 0 || most < 24.0) return {};
-    const bool small_values = stats[(size_t)c].maxlen <= 24;
     const DevCol& col = cols[c];
     const uint64_t step = n > (1ull << 19) ? n >> 18 : 1;
     const uint64_t nsel = (n + step - 1) / step;
 
-    // ---- 1. which bytes occur in (nearly) every sampled value ----
-    DevBuf counts;
-    CPH_TRY(counts.alloc(&ctx->pool, 257 * sizeof(uint32_t)));
-    CPH_HIP_TRY(hipMemsetAsync(counts.get(), 0, 257 * sizeof(uint32_t), ctx->stream));
+    // ---- 1. which bytes occur in (nearly) every sampled value; what the per-position code of the sample costs ----
+    DevBuf sample;
+    CPH_TRY(sample.alloc(&ctx->pool, sizeof(SplitSample)));
+    CPH_HIP_TRY(hipMemsetAsync(sample.get(), 0, sizeof(SplitSample), ctx->stream));
     {
         ProfScope ps(ctx, "k_split_count", 0);
         uint64_t nblk = (nsel + kSplitThreads - 1) / kSplitThreads;
         if (nblk > 1024) nblk = 1024;
-        if (small_values) hipLaunchKernelGGL((k_split_count<3>), dim3((unsigned)nblk), dim3(kSplitThreads), 0, ctx->stream, col, step, nsel, counts.as<uint32_t>());
-        else hipLaunchKernelGGL((k_split_count<5>), dim3((unsigned)nblk), dim3(kSplitThreads), 0, ctx->stream, col, step, nsel, counts.as<uint32_t>());
+        hipLaunchKernelGGL(k_split_count, dim3((unsigned)nblk), dim3(kSplitThreads), 0, ctx->stream, col, step, nsel, sample.as<SplitSample>());
         CPH_HIP_TRY(hipGetLastError());
     }
-    uint32_t hcnt[257];
-    CPH_TRY(ensure_pinned_scratch(ctx, sizeof hcnt));
-    CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, counts.get(), sizeof hcnt, hipMemcpyDeviceToHost, ctx->stream));
+    CPH_TRY(ensure_pinned_scratch(ctx, sizeof(SplitSample)));
+    CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, sample.get(), sizeof(SplitSample), hipMemcpyDeviceToHost, ctx->stream));
     CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    memcpy(hcnt, ctx->pinned_scratch, sizeof hcnt);
+    std::vector<SplitSample> hsv(1);
+    SplitSample& hsm = hsv[0];
+    memcpy(&hsm, ctx->pinned_scratch, sizeof hsm);
+    if (hsm.maxlen > (uint32_t)kSplitMaxValue || hsm.maxlen < 4) return {};
+    if (!stats) {   // the sample's view of the plain code
+        ColStats tmp{};
+        tmp.minlen = ~hsm.minlen_inv;
+        memcpy(tmp.mask, hsm.mask, sizeof hsm.mask);
+        for (uint32_t q = 0; q < hsm.maxlen; q++) most += radix_bits(tmp, q);
+        plain_bits = most;
+        if (most <= 32.0) return {};   // the plain code fits 32 bits: nothing to gain (and the tuned single-column paths to lose)
+    }
+    const bool small_values = (stats ? (*stats)[(size_t)c].maxlen : hsm.maxlen) <= 24;   // (a longer value in an unsampled row raises flag bit 0)
     std::vector<int> cand;
     for (int b = 0; b < 256; b++)
-        if ((double)hcnt[b] >= 0.99 * (double)nsel) cand.push_back(b);
-    std::sort(cand.begin(), cand.end(), [&](int a, int b) { return hcnt[a] > hcnt[b]; });
-    if (cand.size() > 6) cand.resize(6);
+        if ((double)hsm.cnt[b] >= 0.99 * (double)nsel) cand.push_back(b);
+    // a delimiter is punctuation more often than a letter or a digit: those first, then by how many values hold the byte
+    auto alnum = [](int b) { return (b >= '0' && b <= '9') || (b >= 'a' && b <= 'z') || (b >= 'A' && b <= 'Z'); };
+    std::sort(cand.begin(), cand.end(), [&](int a, int b) { return alnum(a) != alnum(b) ? !alnum(a) : hsm.cnt[a] > hsm.cnt[b]; });
+    if (cand.size() > 8) cand.resize(8);
     if (cand.empty()) return {};
 
     // ---- 2. the candidates on the sample: distinct prefixes, suffix alphabets ----
@@ -1206,23 +1313,15 @@ Status codec_try_split(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t
     DevBuf sets, sstats;
     CPH_TRY(sets.alloc(&ctx->pool, cand.size() * set_bytes));
     CPH_TRY(sstats.alloc(&ctx->pool, cand.size() * sizeof(SplitStats)));
-    auto reset_stats = [&](size_t k) -> Status {   // everything 0, the two minima all ones
-        uint8_t* base = sstats.as<uint8_t>() + k * sizeof(SplitStats);
-        CPH_HIP_TRY(hipMemsetAsync(base, 0, sizeof(SplitStats), ctx->stream));
-        CPH_HIP_TRY(hipMemsetAsync(base + offsetof(SplitStats, pmin), 0xFF, sizeof(uint32_t), ctx->stream));
-        CPH_HIP_TRY(hipMemsetAsync(base + offsetof(SplitStats, smin), 0xFF, sizeof(uint32_t), ctx->stream));
-        return {};
-    };
     CPH_HIP_TRY(hipMemsetAsync(sets.get(), 0, cand.size() * set_bytes, ctx->stream));
+    CPH_HIP_TRY(hipMemsetAsync(sstats.get(), 0, cand.size() * sizeof(SplitStats), ctx->stream));
+    SplitCands all{};
+    all.n = (uint32_t)cand.size();
+    for (size_t k = 0; k < cand.size(); k++) all.d[k] = (uint8_t)cand[k];
     {
         ProfScope ps(ctx, "k_split_sample", 0);
-        for (size_t k = 0; k < cand.size(); k++) {
-            CPH_TRY(reset_stats(k));
-            SplitSlot* sl = reinterpret_cast<SplitSlot*>(sets.as<uint8_t>() + k * set_bytes);
-            SplitStats* st = sstats.as<SplitStats>() + k;
-            if (small_values) launch_split_stats<3>(ctx, col, (uint32_t)cand[k], step, nsel, sl, st);
-            else launch_split_stats<5>(ctx, col, (uint32_t)cand[k], step, nsel, sl, st);
-        }
+        if (small_values) launch_split_stats<3>(ctx, col, all, step, nsel, sets.as<SplitSlot>(), sstats.as<SplitStats>());
+        else launch_split_stats<5>(ctx, col, all, step, nsel, sets.as<SplitSlot>(), sstats.as<SplitStats>());
         CPH_HIP_TRY(hipGetLastError());
     }
     std::vector<SplitStats> hs(cand.size());
@@ -1233,7 +1332,7 @@ Status codec_try_split(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t
     auto split_bits = [&](const SplitStats& st) {
         double bits = std::log2((double)(st.count > 1 ? st.count : 1));
         ColStats tmp{};
-        tmp.minlen = st.smin;
+        tmp.minlen = ~st.smin_inv;
         memcpy(tmp.mask, st.mask, sizeof st.mask);
         for (uint32_t q = 0; q < st.smax && q < (uint32_t)kSplitMaxSuffix; q++) bits += radix_bits(tmp, q);
         return bits;
@@ -1244,19 +1343,23 @@ Status codec_try_split(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t
         const SplitStats& st = hs[k];
         if (st.flags || st.count == 0 || st.count > (uint32_t)kWideDictMax / (step > 1 ? 2 : 1) || st.smax > (uint32_t)kSplitMaxSuffix) continue;
         const double bits = split_bits(st);
-        if (ctx->codec_debug) fprintf(stderr, "codec_try_split: column %d, byte 0x%02x: %u prefixes, suffix %u..%u bytes, %.1f bits (plain %.1f)\n", c, cand[k], st.count, st.smin, st.smax, bits, most);
+        if (ctx->codec_debug) fprintf(stderr, "codec_try_split: column %d, byte 0x%02x: %u prefixes, suffix %u..%u bytes, %.1f bits (plain %.1f)\n", c, cand[k], st.count, ~st.smin_inv, st.smax, bits, most);
         if (bits < best_bits) { best_bits = bits; best = (int)k; }
     }
-    if (best < 0 || best_bits > most - 8.0) return {};   // not worth a radix pass
+    // worth it when the sort gets cheaper by the estimate (the exact codec is compared again below)
+    if (best < 0 || bits_sort_cost(plain_bits - most + best_bits) >= bits_sort_cost(plain_bits)) return {};
 
     // ---- 3. the exact statistics of the chosen byte, over all rows (the sample's set stays: it is a subset) ----
-    SplitSlot* slots = reinterpret_cast<SplitSlot*>(sets.as<uint8_t>() + (size_t)best * set_bytes);
+    SplitSlot* slots = sets.as<SplitSlot>() + (size_t)best * kSplitSetSlots;
     SplitStats* dstat = sstats.as<SplitStats>() + best;
     const uint32_t d = (uint32_t)cand[(size_t)best];
     if (step > 1) {
         ProfScope ps(ctx, "k_split_stats", 0);
-        if (small_values) launch_split_stats<3>(ctx, col, d, 1, n, slots, dstat);
-        else launch_split_stats<5>(ctx, col, d, 1, n, slots, dstat);
+        SplitCands one{};
+        one.n = 1;
+        one.d[0] = (uint8_t)d;
+        if (small_values) launch_split_stats<3>(ctx, col, one, 1, n, slots, dstat);
+        else launch_split_stats<5>(ctx, col, one, 1, n, slots, dstat);
         CPH_HIP_TRY(hipGetLastError());
     }
     CPH_TRY(ensure_pinned_scratch(ctx, sizeof(SplitStats) + set_bytes));
@@ -1266,7 +1369,10 @@ Status codec_try_split(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t
     CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
     SplitStats st;
     memcpy(&st, hp, sizeof st);
-    if (st.flags || st.count == 0 || st.count > (uint32_t)kWideDictMax || st.pmax > (uint32_t)kWideBytes || st.smax > (uint32_t)kSplitMaxSuffix) return {};
+    const uint32_t pmin = ~st.pmin_inv, smin = ~st.smin_inv;
+    if (st.flags || st.count == 0 || st.count > (uint32_t)kWideDictMax || st.pmax > (uint32_t)kWideBytes || st.smax > (uint32_t)kSplitMaxSuffix ||
+        st.vmax > (uint32_t)kSplitMaxValue)
+        return {};
     std::vector<WideKey> dict;
     const SplitSlot* hsl = reinterpret_cast<const SplitSlot*>(hp + sizeof(SplitStats));
     for (int i = 0; i < kSplitSetSlots; i++)
@@ -1284,12 +1390,12 @@ Status codec_try_split(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t
     // ---- 4. the codec over the virtual columns ----
     std::vector<ColStats> vstats;
     for (int k = 0; k < ncols; k++) {
-        if (k != c) { vstats.push_back(stats[(size_t)k]); continue; }
+        if (k != c) { vstats.push_back((*stats)[(size_t)k]); continue; }   // (ncols > 1 only comes with statistics)
         ColStats pre{}, suf{};
-        pre.minlen = st.pmin;
+        pre.minlen = pmin;
         pre.maxlen = st.pmax;
         for (uint32_t q = 0; q < st.pmax; q++) pre.mask[q][0] = 1u;   // placeholders: the positions are absorbed below
-        suf.minlen = st.smin;
+        suf.minlen = smin;
         suf.maxlen = st.smax;
         memcpy(suf.mask, st.mask, sizeof st.mask);
         vstats.push_back(pre);
@@ -1297,7 +1403,7 @@ Status codec_try_split(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t
     }
     uint64_t positions = 0;
     for (const auto& v : vstats) positions += v.maxlen;
-    if (positions > (uint64_t)kMaxKeyBytes) return {};
+    if (positions > (uint64_t)kMaxKeyBytes || st.pmax == 0) return {};
     CodecHost trial;
     CPH_TRY(codec_build(vstats, &trial));
     const int p0 = trial.col_start[c];
@@ -1314,12 +1420,15 @@ Status codec_try_split(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t
     }
     trial.split_col = c;
     trial.split_byte = (uint8_t)d;
+    trial.split_maxlen = (int32_t)st.vmax;
     trial.wdict = std::move(dict);
     CPH_TRY(codec_split_words(&trial));
+    const double plain_cost = stats ? codec_sort_cost(*codec) : bits_sort_cost(plain_bits);
     if (ctx->codec_debug)
-        fprintf(stderr, "codec_try_split: column %d cut at 0x%02x: %zu prefixes (<= %u bytes), suffix %u..%u bytes: %d word(s), %d bits (plain: %d word(s), %d bits in the first)\n",
-                c, d, trial.wdict.size(), st.pmax, st.smin, st.smax, trial.nwords, trial.word_bits[0], plain.nwords, plain.word_bits[0]);
-    if (codec_sort_cost(trial) < codec_sort_cost(plain)) *codec = std::move(trial);
+        fprintf(stderr, "codec_try_split: column %d cut at 0x%02x: %zu prefixes (<= %u bytes), suffix %u..%u bytes: %d word(s), %d bits, sort cost %.0f (plain: %.1f bits%s, cost %.0f)\n",
+                c, d, trial.wdict.size(), st.pmax, smin, st.smax, trial.nwords, trial.word_bits[0], codec_sort_cost(trial), plain_bits,
+                stats ? "" : " by the sample", plain_cost);
+    if (codec_sort_cost(trial) < plain_cost) *codec = std::move(trial);
     return {};
 }
 
@@ -1444,7 +1553,7 @@ Status codec_upload(cph_ctx* ctx, const CodecHost& cd, DevBuf* dev) {
         const uint32_t mask = (1u << wide_bits) - 1u;
         for (size_t r = 0; r < cd.wdict.size(); r++) {
             const WideKey& k = cd.wdict[r];
-            uint32_t sl = (uint32_t)wide_hash(k.w[0], k.w[1], k.w[2], k.w[3], k.len) & mask;
+            uint32_t sl = wide_hash_lo(k.w[0], k.w[1], k.w[2], k.w[3], k.len) & mask;
             while (ht[sl]) sl = (sl + 1) & mask;
             ht[sl] = (uint16_t)(r + 1);
         }
@@ -1746,7 +1855,7 @@ Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec
                           void* out_codes, const EncodeHist* hist, const GroupSpec* spec, uint32_t* miss) {
     if (n == 0) return {};
     if (cd.has_split() && cd.ncols == 2 && cd.nwords == 1 && !cols[0].segmented() &&
-        cd.col_maxlen[0] + cd.col_maxlen[1] <= kSplitMaxValue && cd.col_maxlen[1] <= kSplitMaxSuffix && miss) {
+        cd.split_maxlen <= kSplitMaxValue && cd.col_maxlen[1] <= kSplitMaxSuffix && miss) {
         // one key column through a split codec: the dedicated kernel (tiles = the sort's tiles when it asked for the first
         // pass's histogram, else 4096 rows)
         const bool want_hist = hist && hist->counts;
@@ -1755,8 +1864,8 @@ Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec
         const uint32_t ntiles = (uint32_t)ntiles64;
         const uint32_t bins = want_hist ? hist->bins : 0u, mask = want_hist ? hist->digit_mask : 0u;
         const size_t codec_bytes = codec_dev.bytes();
-        const size_t lds = codec_bytes + (size_t)bins * sizeof(uint32_t);
-        const bool small_values = cd.col_maxlen[0] + cd.col_maxlen[1] <= 24;
+        const size_t lds = codec_bytes + (size_t)cd.col_maxlen[1] * kLutStride * (cd.key32 ? 4 : 8) + (size_t)bins * sizeof(uint32_t);
+        const bool small_values = cd.split_maxlen <= 24;
         int per_cu = 1, cus = 256;
         CPH_TRY(device_cus(ctx, &cus));
         ProfScope ps(ctx, "k_encode_build", 4.0 * (double)bins * (double)ntiles);

@@ -34,10 +34,11 @@ __global__ void k_first_dup(const void* __restrict__ codes, uint64_t n, int nwor
             const uint64_t* c = reinterpret_cast<const uint64_t*>(codes);
             for (int w = 0; w < nwords && eq; w++) eq = c[(uint64_t)w * n + i] == c[(uint64_t)w * n + i - 1];
         }
-        if (eq && (uint32_t)i < best) best = (uint32_t)i;
+        if (eq && (uint32_t)i < best) { best = (uint32_t)i; break; }   // this thread's later positions are larger
+        if ((uint64_t)__hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < i) break;   // a pair in front of everything still to come
     }
     best = wave_min(best);
-    if (lane_id() == 0 && best != 0xFFFFFFFFu) atomicMin(result, best);
+    if (lane_id() == 0 && best != 0xFFFFFFFFu && best < __hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(result, best);
 }
 
 // One-word codes, vectorised: a thread owns V consecutive codes (one 16-byte load), compares them with each other and its
@@ -53,6 +54,14 @@ __global__ __launch_bounds__(256) void k_first_dup_vec(const K* __restrict__ cod
     uint32_t best = 0xFFFFFFFFu;
     constexpr int U = 4;   // vectors in flight per thread
     for (uint64_t r0 = 0; r0 < rounds; r0 += U) {
+        // Positions only grow with r0, so a wave that has found a pair is done, and so is every wave once a pair in front of
+        // its next vectors is known (an index with duplicate keys — IndexOn, BASELINE config 3 — has one within the first
+        // few rows: the scan ends at once, and without 30 000 waves queueing on one atomicMin).  Wave-uniform exits: the
+        // loop body shuffles.
+        const uint32_t known = __hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint64_t)known < r0 * stride * V) break;
+        const uint32_t wbest = wave_min(best);
+        if (wbest != 0xFFFFFFFFu) break;
         uint4 raw[U];
         K prev0[U];
 #pragma unroll
@@ -87,7 +96,7 @@ __global__ __launch_bounds__(256) void k_first_dup_vec(const K* __restrict__ cod
         for (uint64_t i = nvec * V > 0 ? nvec * V : 1; i < n; i++)
             if (codes[i] == codes[i - 1] && (uint32_t)i < best) best = (uint32_t)i;
     best = wave_min(best);
-    if (lane_id() == 0 && best != 0xFFFFFFFFu) atomicMin(result, best);
+    if (lane_id() == 0 && best != 0xFFFFFFFFu && best < __hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(result, best);
 }
 
 // Launches the adjacent-equal scan; the result stays on the device (ix->first_dup_dev) until it is read back.
