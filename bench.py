@@ -699,7 +699,9 @@ def main():
             # n*K code bytes.  Every term is printed so that the fraction can be recomputed from the line alone.
             K_ = inf["key_bytes"] * inf["code_words"]
             src = col.nbytes_values() + col.nbytes_offsets()
-            src_readers = {k: p[k]["launches"] for k in ("k_col_stats", "k_group_stats", "k_encode_build") if k in p}
+            # (round 4: k_split_stats = the exact statistics pass of the delimiter-split codec; its sample passes k_split_count /
+            # k_split_sample read 2^18 rows and are not charged)
+            src_readers = {k: p[k]["launches"] for k in ("k_col_stats", "k_group_stats", "k_split_stats", "k_encode_build") if k in p}
             lib_bytes = {k: v["algo_bytes"] for k, v in p.items() if v["algo_bytes"] > 0}
             algo = src * sum(src_readers.values()) + n * K_ * src_readers.get("k_encode_build", 1) + sum(lib_bytes.values())
             compulsory = src + n * (K_ + 4)    # the column read once, sorted codes + perm written once

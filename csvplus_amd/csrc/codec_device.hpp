@@ -84,6 +84,7 @@ struct CodecView {
     // split codec (hdr->wide_pos >= 0): the prefix column's whole-value dictionary
     const CPH_LDS WideKey* wide;
     const CPH_LDS uint16_t* wide_hash;
+    const CPH_LDS uint16_t* wide_disp;
 };
 
 // Cooperative copy of the codec block (global) into dynamic LDS; returns a view.
@@ -111,21 +112,22 @@ __device__ __forceinline__ CodecView codec_load_to_lds(const uint8_t* g_blob, ui
     v.hash = (const CPH_LDS uint16_t*)(l + v.hdr->hash_off);
     v.wide = (const CPH_LDS WideKey*)(l + v.hdr->wide_off);
     v.wide_hash = (const CPH_LDS uint16_t*)(l + v.hdr->wide_hash_off);
+    v.wide_disp = (const CPH_LDS uint16_t*)(l + v.hdr->wide_disp_off);
     return v;
 }
 
+// Slot of a key in the codec's perfect-hash table (CodecHost::wide_disp): h = wide_hash_lo of the key.
+__device__ __forceinline__ uint32_t wide_slot(const CodecView& cv, uint32_t h) {
+    const uint32_t disp = cv.wide_disp[h & ((1u << cv.hdr->wide_disp_bits) - 1u)];
+    return ((h >> 16) + disp) & ((1u << cv.hdr->wide_hash_bits) - 1u);
+}
 // Rank of a whole value (at most kWideBytes bytes, zero padded into four words) in the codec's wide dictionary, -1 when
-// it is not there.  One hash, one u16 slot, the entry's words compared.
+// it is not there.  One hash, two u16 loads, the one candidate entry compared.
 __device__ __forceinline__ int wide_lookup(const CodecView& cv, uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3, uint32_t len) {
-    const uint32_t mask = (1u << cv.hdr->wide_hash_bits) - 1u;
-    uint32_t sl = wide_hash_lo(w0, w1, w2, w3, len) & mask;
-    for (;;) {
-        const uint32_t e = cv.wide_hash[sl];
-        if (e == 0) return -1;
-        const CPH_LDS WideKey* k = cv.wide + (e - 1);
-        if (k->len == len && k->w[0] == w0 && k->w[1] == w1 && k->w[2] == w2 && k->w[3] == w3) return (int)(e - 1);
-        sl = (sl + 1) & mask;
-    }
+    const uint32_t e = cv.wide_hash[wide_slot(cv, wide_hash_lo(w0, w1, w2, w3, len))];
+    if (e == 0) return -1;
+    const CPH_LDS WideKey* k = cv.wide + (e - 1);
+    return k->len == len && k->w[0] == w0 && k->w[1] == w1 && k->w[2] == w2 && k->w[3] == w3 ? (int)(e - 1) : -1;
 }
 // The value [begin, begin + len) of col.data as a WideKey's words (len <= kWideBytes).
 __device__ __forceinline__ void wide_words(const uint8_t* data, uint64_t begin, uint64_t len, uint64_t (&w)[4]) {

@@ -199,6 +199,10 @@ struct CodecHost {
     uint8_t split_byte = 0;
     int32_t split_maxlen = 0;               // longest value of the split column in the build table (which kernel instantiation encodes it)
     std::vector<WideKey> wdict;             // distinct prefixes in rank order
+    // PERFECT hash of wdict (codec_wide_perfect_hash; derived, not serialised): a lookup is h = wide_hash_lo(key),
+    // slot = ((h >> 16) + wide_disp[h & (nbuckets - 1)]) & (nslots - 1), wide_slots[slot] = rank + 1 (0: no such key) —
+    // no probe sequence, so a wave never loops over its unluckiest lane
+    std::vector<uint16_t> wide_disp, wide_slots;
     bool has_split() const { return split_col >= 0; }
     int32_t virtual_cols(int32_t real_cols) const { return real_cols + (has_split() && split_col < real_cols ? 1 : 0); }
 };
@@ -239,11 +243,13 @@ struct CodecDevHeader {
     int32_t wide_pos;      // position of the kUnitWide head, -1: none
     int32_t wide_n;        // entries
     int32_t wide_off;      // WideKey[wide_n], rank order
-    int32_t wide_hash_off; // u16[1 << wide_hash_bits]: rank + 1 (0 = empty), slot = low bits of wide_hash, linear probing
+    int32_t wide_hash_off; // u16[1 << wide_hash_bits]: rank + 1 (0 = empty); perfect hash (CodecHost::wide_disp)
     int32_t wide_hash_bits;
     int32_t split_vcol;    // virtual column that is the prefix (its successor is the suffix), -1: none
     int32_t split_byte;
-    int32_t pad_[1];
+    int32_t wide_disp_off; // u16[1 << wide_disp_bits]: displacement of each bucket
+    int32_t wide_disp_bits;
+    int32_t pad_[3];
 };
 #if defined(__HIPCC__)
 #define CPH_HD __host__ __device__
@@ -420,6 +426,9 @@ struct DevCol {
 // codec gets its split column twice (prefix part, suffix part).  Returns the number of virtual columns written to out
 // (room for kMaxKeyCols).
 int codec_virtual_cols(const CodecHost& codec, const DevCol* real, int nreal, DevCol* out);
+// Builds CodecHost::wide_disp / wide_slots from wdict; false when no perfect hash was found (two prefixes with one 32-bit
+// hash: the caller then does without the split).
+bool codec_wide_perfect_hash(CodecHost* codec);
 
 // keycodec.hip
 struct ColStats {              // per column, produced by one pass over the column

@@ -357,6 +357,7 @@ static bool codec_block_parse(const uint8_t* p, size_t n, size_t* at, CodecHost*
                 if (cmp >= 0) return false;
             }
         }
+        if (!codec_wide_perfect_hash(&cd)) return false;
     }
     if (cd.col_start[0] != 0 || cd.col_start[cd.ncols] != cd.npos) return false;
     for (int c = 0; c < cd.ncols; c++)

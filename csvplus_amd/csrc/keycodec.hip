@@ -1098,7 +1098,7 @@ __global__ __launch_bounds__(kSplitThreads) void k_encode_split(DevCol col, cons
         s_lutw[i] = r == kLutInvalid ? (OUT)0 : (OUT)r * (OUT)cv.mult[ps + (int)(i / kLutStride)];
     }
     __syncthreads();
-    const uint32_t hmask = (1u << cv.hdr->wide_hash_bits) - 1u;
+    const uint32_t hmask = (1u << cv.hdr->wide_hash_bits) - 1u, dmask = (1u << cv.hdr->wide_disp_bits) - 1u;
     const uint32_t per_xcd = (ntiles + 7) / 8, xcd = blockIdx.x & 7u;   // XCD-contiguous tile ranges (k_encode_build_fast)
     const uint32_t t_end = (xcd + 1) * per_xcd < ntiles ? (xcd + 1) * per_xcd : ntiles;
     uint32_t missed = 0;
@@ -1120,16 +1120,19 @@ __global__ __launch_bounds__(kSplitThreads) void k_encode_split(DevCol col, cons
 #pragma unroll
                 for (int k = 0; k < kSplitRows; k++) v[k].load(col, b[k], l[k]);
             }
-            uint32_t plen[kSplitRows], slen[kSplitRows], sl[kSplitRows], e[kSplitRows];
+            uint32_t plen[kSplitRows], slen[kSplitRows], hh[kSplitRows], disp[kSplitRows], e[kSplitRows];
             uint64_t w[kSplitRows][4];
 #pragma unroll
             for (int k = 0; k < kSplitRows; k++) {
                 split_lengths(v[k], dv, &plen[k], &slen[k]);
                 v[k].head_words(plen[k] < (uint32_t)kWideBytes ? plen[k] : (uint32_t)kWideBytes, w[k]);
-                sl[k] = wide_hash_lo(w[k][0], w[k][1], w[k][2], w[k][3], plen[k]) & hmask;
+                hh[k] = wide_hash_lo(w[k][0], w[k][1], w[k][2], w[k][3], plen[k]);
             }
+            // perfect hash (CodecHost::wide_disp): bucket displacement, slot, entry — three dependent LDS loads, no loop
 #pragma unroll
-            for (int k = 0; k < kSplitRows; k++) e[k] = cv.wide_hash[sl[k]];
+            for (int k = 0; k < kSplitRows; k++) disp[k] = cv.wide_disp[hh[k] & dmask];
+#pragma unroll
+            for (int k = 0; k < kSplitRows; k++) e[k] = cv.wide_hash[((hh[k] >> 16) + disp[k]) & hmask];
             bool hit[kSplitRows];
 #pragma unroll
             for (int k = 0; k < kSplitRows; k++) {   // (entry 0 stands in for an empty slot: compared, never accepted)
@@ -1137,17 +1140,6 @@ __global__ __launch_bounds__(kSplitThreads) void k_encode_split(DevCol col, cons
                 bool same = key->len == plen[k] && key->w[0] == w[k][0] && key->w[1] == w[k][1] && key->w[2] == w[k][2];
                 if constexpr (NCH > 3) same = same && key->w[3] == w[k][3];
                 hit[k] = e[k] != 0 && same;
-            }
-#pragma unroll
-            for (int k = 0; k < kSplitRows; k++) {
-                while (e[k] != 0 && !hit[k]) {   // another prefix's slot (rare): linear probing to the entry or an empty slot
-                    sl[k] = (sl[k] + 1) & hmask;
-                    e[k] = cv.wide_hash[sl[k]];
-                    if (e[k]) {
-                        const CPH_LDS WideKey* key = cv.wide + (e[k] - 1);
-                        hit[k] = key->len == plen[k] && key->w[0] == w[k][0] && key->w[1] == w[k][1] && key->w[2] == w[k][2] && key->w[3] == w[k][3];
-                    }
-                }
             }
             OUT acc[kSplitRows];
             uint64_t w0[kSplitRows], w1[kSplitRows];
@@ -1201,6 +1193,54 @@ int codec_virtual_cols(const CodecHost& cd, const DevCol* real, int nreal, DevCo
         }
     }
     return nv;
+}
+
+// Hash-and-displace perfect hash of the wide dictionary (CodecHost::wide_disp / wide_slots): buckets by the low bits of
+// wide_hash_lo, the largest bucket first, every bucket takes the first displacement that drops all its keys on free slots.
+bool codec_wide_perfect_hash(CodecHost* codec) {
+    CodecHost& cd = *codec;
+    const size_t n = cd.wdict.size();
+    cd.wide_disp.clear();
+    cd.wide_slots.clear();
+    if (n == 0 || n > (size_t)kWideDictMax) return false;
+    std::vector<uint32_t> h(n);
+    for (size_t i = 0; i < n; i++) h[i] = wide_hash_lo(cd.wdict[i].w[0], cd.wdict[i].w[1], cd.wdict[i].w[2], cd.wdict[i].w[3], cd.wdict[i].len);
+    size_t nslots = 4;
+    while (nslots < 2 * n) nslots <<= 1;
+    for (int attempt = 0; attempt < 3; attempt++, nslots <<= 1) {   // load <= 1/2, 1/4, 1/8
+        const size_t nbuckets = nslots / 4 > 0 ? nslots / 4 : 1;
+        std::vector<std::vector<uint32_t>> bucket(nbuckets);
+        for (size_t i = 0; i < n; i++) bucket[h[i] & (nbuckets - 1)].push_back((uint32_t)i);
+        std::vector<size_t> order(nbuckets);
+        for (size_t b = 0; b < nbuckets; b++) order[b] = b;
+        std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return bucket[a].size() > bucket[b].size(); });
+        std::vector<uint16_t> slots(nslots, 0), disp(nbuckets, 0);
+        bool ok = true;
+        for (size_t b : order) {
+            if (bucket[b].empty()) break;
+            bool placed = false;
+            for (uint32_t d = 0; d < 65536u && !placed; d++) {
+                std::vector<uint32_t> at;
+                bool free_ = true;
+                for (uint32_t i : bucket[b]) {
+                    const uint32_t sl = ((h[i] >> 16) + d) & (uint32_t)(nslots - 1);
+                    if (slots[sl] || std::find(at.begin(), at.end(), sl) != at.end()) { free_ = false; break; }
+                    at.push_back(sl);
+                }
+                if (!free_) continue;
+                for (size_t j = 0; j < at.size(); j++) slots[at[j]] = (uint16_t)(bucket[b][j] + 1);
+                disp[b] = (uint16_t)d;
+                placed = true;
+            }
+            if (!placed) { ok = false; break; }
+        }
+        if (ok) {
+            cd.wide_disp = std::move(disp);
+            cd.wide_slots = std::move(slots);
+            return true;
+        }
+    }
+    return false;
 }
 
 // bytes of a WideKey in strings.Compare order
@@ -1422,6 +1462,7 @@ Status codec_try_split(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t
     trial.split_byte = (uint8_t)d;
     trial.split_maxlen = (int32_t)st.vmax;
     trial.wdict = std::move(dict);
+    if (!codec_wide_perfect_hash(&trial)) return {};
     CPH_TRY(codec_split_words(&trial));
     const double plain_cost = stats ? codec_sort_cost(*codec) : bits_sort_cost(plain_bits);
     if (ctx->codec_debug)
@@ -1537,11 +1578,14 @@ Status codec_upload(cph_ctx* ctx, const CodecHost& cd, DevBuf* dev) {
         h.wide_n = (int32_t)cd.wdict.size();
         h.wide_off = (int32_t)off;
         off = align16(off + sizeof(WideKey) * cd.wdict.size());
-        wide_bits = bits_needed((uint64_t)cd.wdict.size() * 2);
-        if (wide_bits < 1) wide_bits = 1;
+        if (cd.wide_slots.empty() || cd.wide_disp.empty()) return {CPH_ERR_INVALID, "internal: split codec without its perfect hash"};
+        wide_bits = bits_needed((uint64_t)cd.wide_slots.size());   // both sizes are powers of two
         h.wide_hash_bits = wide_bits;
         h.wide_hash_off = (int32_t)off;
-        off = align16(off + sizeof(uint16_t) * ((size_t)1 << wide_bits));
+        off = align16(off + sizeof(uint16_t) * cd.wide_slots.size());
+        h.wide_disp_bits = bits_needed((uint64_t)cd.wide_disp.size());
+        h.wide_disp_off = (int32_t)off;
+        off = align16(off + sizeof(uint16_t) * cd.wide_disp.size());
     }
     h.total_bytes = (int32_t)off;
 
@@ -1549,14 +1593,8 @@ Status codec_upload(cph_ctx* ctx, const CodecHost& cd, DevBuf* dev) {
     memcpy(blob.data(), &h, sizeof h);
     if (cd.has_split()) {
         memcpy(blob.data() + h.wide_off, cd.wdict.data(), sizeof(WideKey) * cd.wdict.size());
-        uint16_t* ht = reinterpret_cast<uint16_t*>(blob.data() + h.wide_hash_off);
-        const uint32_t mask = (1u << wide_bits) - 1u;
-        for (size_t r = 0; r < cd.wdict.size(); r++) {
-            const WideKey& k = cd.wdict[r];
-            uint32_t sl = wide_hash_lo(k.w[0], k.w[1], k.w[2], k.w[3], k.len) & mask;
-            while (ht[sl]) sl = (sl + 1) & mask;
-            ht[sl] = (uint16_t)(r + 1);
-        }
+        memcpy(blob.data() + h.wide_hash_off, cd.wide_slots.data(), sizeof(uint16_t) * cd.wide_slots.size());
+        memcpy(blob.data() + h.wide_disp_off, cd.wide_disp.data(), sizeof(uint16_t) * cd.wide_disp.size());
     }
     if (cd.has_groups()) {
         memcpy(blob.data() + h.unit_off, cd.unit.data(), (size_t)cd.npos);
