@@ -207,6 +207,7 @@ PROTOTYPES = [
     ("cph_index_nrows", C.c_uint64, [_P]),
     ("cph_index_nkeycols", C.c_int32, [_P]),
     ("cph_index_perm", C.c_int32, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    ("cph_index_permute", C.c_int32, [_P, _P, C.POINTER(cph_strcol), C.c_int32, C.POINTER(C.POINTER(cph_colbuf))]),
     ("cph_join_probe", C.c_int32,
      [_P, _P, C.POINTER(cph_strcol), C.c_int32, _P, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32,
       C.c_int32, C.POINTER(C.POINTER(cph_matches))]),

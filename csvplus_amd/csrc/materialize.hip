@@ -454,6 +454,28 @@ struct cph_bytes_impl {
 extern "C" {
 
 CPH_API int32_t cph_gather_rows(cph_ctx* ctx, const cph_strcol* col, const void* row_ids, int32_t id_bits, uint64_t id_base,
+                                uint64_t nrows, int32_t out_mem, cph_colbuf** out);
+
+// mergeRows for a caller that works with sorted positions: the payload column in index order (csvplus.go:736: the rows of
+// an Index ARE sorted), gathered once through the index's permutation
+CPH_API int32_t cph_index_permute(cph_ctx* ctx, cph_index* index, const cph_strcol* col, int32_t out_mem, cph_colbuf** out) {
+    if (!ctx || !index || !col || !out) return CPH_ERR_INVALID;
+    *out = nullptr;
+    if (col->nrows < index->table_rows)
+        return fail_with(ctx, {CPH_ERR_INVALID, "cph_index_permute: the column has fewer rows than the table the index was built over"});
+    const uint32_t* perm = nullptr;
+    uint64_t n = 0;
+    const int32_t rc = cph_index_perm(index, col->mem == CPH_MEM_DEVICE ? CPH_MEM_DEVICE : CPH_MEM_HOST, &perm, &n);
+    if (rc != CPH_OK) {
+        if (index->ctx && index->ctx != ctx) ctx->err = index->ctx->err;
+        return rc;
+    }
+    static const uint32_t no_rows = 0;   // an empty index: an empty column (row_ids == NULL would mean "copy the column"; never read)
+    if (n == 0) perm = &no_rows;
+    return cph_gather_rows(ctx, col, perm, 32, 0, n, out_mem, out);
+}
+
+CPH_API int32_t cph_gather_rows(cph_ctx* ctx, const cph_strcol* col, const void* row_ids, int32_t id_bits, uint64_t id_base,
                                 uint64_t nrows, int32_t out_mem, cph_colbuf** out) {
     if (!ctx || !col || !out) return CPH_ERR_INVALID;
     if (hipSetDevice(ctx->device) != hipSuccess) return fail_with(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});

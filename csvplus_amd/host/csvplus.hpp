@@ -24,6 +24,13 @@
 // What runs where: rows stay host-side maps exactly as in the reference; the key columns of
 // a batch are staged into pinned SoA buffers and the sort / unique check / probe run on the
 // GPU.  There is no CPU implementation of those steps here.
+//
+// Chained Joins (round 4): `src.Join(a, ka).Join(b, kb)...` (README.md:56; csvplus.go:545-569 nested: the second Join's
+// source IS the first Join's closure) is recognised — a DataSource returned by Join remembers its upstream and its steps
+// — and a batch of stream rows goes through ONE cph_join_chain_ex(CPH_CHAIN_POSITIONS) call, the entry point bench.py
+// times, as long as every row of the batch carries the later steps' key columns itself: mergeRows
+// lets the stream's value win, so that is the value the later Join sees.  A batch with a row that takes a later key from
+// a BUILD-side column runs the steps one after the other over the merged rows (same emission order, same errors).
 #pragma once
 
 #include <algorithm>
@@ -300,14 +307,22 @@ public:
     DataSource Join(std::shared_ptr<Index> index, std::vector<std::string> columns = {}) const {
         if (columns.empty()) columns = index->impl_columns;                                  // :546-547
         else if (columns.size() > index->impl_columns.size()) throw Panic("too many source columns in Join()");  // :548-550
-        return probeSource(std::move(index), std::move(columns), /*anti=*/false);
+        // a Join over a Join: one more step of the same chain (at most CPH_MAX_CHAIN fused; a longer chain starts a new one)
+        auto spec = std::make_shared<ChainSpec>();
+        if (chain_ && chain_->steps.size() < (size_t)CPH_MAX_CHAIN) *spec = *chain_;
+        else spec->upstream = fn_;
+        spec->steps.push_back(ChainStepSpec{std::move(index), std::move(columns)});
+        DataSource out = spec->steps.size() == 1 ? probeSource(spec->upstream, spec->steps[0].index, spec->steps[0].columns, /*anti=*/false)
+                                                 : chainSource(spec);
+        out.chain_ = spec;
+        return out;
     }
 
     // Except (:588-608)
     DataSource Except(std::shared_ptr<Index> index, std::vector<std::string> columns = {}) const {
         if (columns.empty()) columns = index->impl_columns;
         else if (columns.size() > index->impl_columns.size()) throw Panic("too many source columns in Except()");
-        return probeSource(std::move(index), std::move(columns), /*anti=*/true);
+        return probeSource(fn_, std::move(index), std::move(columns), /*anti=*/true);
     }
 
     // ToRows (:481-490)
@@ -319,6 +334,15 @@ public:
 
 private:
     Fn fn_;
+    struct ChainStepSpec {
+        std::shared_ptr<Index> index;
+        std::vector<std::string> columns;
+    };
+    struct ChainSpec {   // this source == upstream.Join(steps[0])...Join(steps.back())
+        Fn upstream;
+        std::vector<ChainStepSpec> steps;
+    };
+    std::shared_ptr<const ChainSpec> chain_;
 
     // createIndex (:707-738) + createUniqueIndex (:740-756)
     std::pair<std::shared_ptr<Index>, Error> createIndex(const std::vector<std::string>& columns, bool unique) const {
@@ -369,64 +393,156 @@ private:
         return {index, Error()};
     }
 
-    // Shared body of Join / Except: the per-row `first()` + forward scan (:557-563) / `has()` (:599-602)
-    // becomes one GPU probe per batch of stream rows.
-    DataSource probeSource(std::shared_ptr<Index> index, std::vector<std::string> columns, bool anti) const {
-        Fn src = fn_;
+    // One step over a batch of rows that all carry `columns`: the per-row `first()` + forward scan (:557-563) / `has()`
+    // (:599-602) as one GPU probe; `emit` gets every output row in the reference's order.  The batch is consumed.
+    static Error probeBatch(cph_ctx* ctx, const std::shared_ptr<Index>& index, const std::vector<std::string>& columns, bool anti,
+                            std::vector<Row>* batch, const RowFunc& emit) {
+        if (batch->empty()) return Error();
+        std::vector<std::vector<const std::string*>> vals(columns.size());
+        for (auto& v : vals) v.resize(batch->size());
+        for (size_t i = 0; i < batch->size(); i++)
+            for (size_t c = 0; c < columns.size(); c++) vals[c][i] = &(*batch)[i].at(columns[c]);
+        cph_matches* m = nullptr;
+        {
+            detail::StagedColumns st(ctx, columns.size());
+            st.stage(vals, batch->size());
+            int32_t rc = cph_join_probe(ctx, index->device().h, st.cols(), (int32_t)columns.size(), nullptr, 32,
+                                        0, 0, 0, /*want_pairs=*/0, CPH_MEM_HOST, &m);
+            if (rc != CPH_OK) return Error(std::string("csvplus_hip: ") + cph_last_error(ctx));
+        }
+        Error err;
+        // index.impl.rows is read live at iteration time (:557), as in the reference
+        const std::vector<Row>& irows = index->impl_rows;
+        for (size_t i = 0; i < batch->size() && !err; i++) {
+            if (anti) {
+                if (m->cnt[i] == 0) err = emit(std::move((*batch)[i]));                        // :600-602
+            } else {
+                for (uint32_t j = 0; j < m->cnt[i] && !err; j++)                              // :559-563
+                    err = emit(mergeRows(irows[(size_t)m->lo[i] + j], (*batch)[i]));
+            }
+        }
+        cph_matches_release(m);
+        batch->clear();
+        return err;
+    }
+
+    // Reads `src` in batches of Gpu::join_batch_rows rows that carry `columns` (SelectValues, :556 / :599: a row without one
+    // of them ends the iteration with that error — after the rows in front of it went through `flush`) and hands each batch
+    // to `flush`.
+    static Error batched(const Fn& src, const std::vector<std::string>& columns, const std::function<Error(std::vector<Row>*)>& flush) {
+        const size_t batch_rows = std::max<size_t>(1, Gpu::Default().join_batch_rows);
+        std::vector<Row> batch;
+        batch.reserve(batch_rows);
+        Error err = src([&](Row row) -> Error {
+            std::vector<const std::string*> tmp;
+            Error e = SelectValues(row, columns, &tmp);                                       // :556 / :599
+            if (e) {
+                // rows before this one must be delivered first, then the error surfaces
+                Error fe = flush(&batch);
+                return fe ? fe : e;
+            }
+            batch.push_back(std::move(row));
+            if (batch.size() >= batch_rows) return flush(&batch);
+            return Error();
+        });
+        if (err) return err;
+        err = flush(&batch);
+        // an io.EOF from `fn` in the tail batch ends the iteration cleanly, as the source
+        // would have mapped it (:238-239)
+        return err.is_eof() ? Error() : err;
+    }
+
+    // Shared body of a single Join / Except over `src`.
+    static DataSource probeSource(Fn src, std::shared_ptr<Index> index, std::vector<std::string> columns, bool anti) {
         return DataSource([src, index, columns, anti](const RowFunc& fn) -> Error {
             cph_ctx* ctx = Gpu::Default().ctx();
-            const size_t batch_rows = std::max<size_t>(1, Gpu::Default().join_batch_rows);
-            std::vector<Row> batch;
-            batch.reserve(batch_rows);
-
-            auto flush = [&]() -> Error {
-                if (batch.empty()) return Error();
-                std::vector<std::vector<const std::string*>> vals(columns.size());
-                for (auto& v : vals) v.resize(batch.size());
-                for (size_t i = 0; i < batch.size(); i++)
-                    for (size_t c = 0; c < columns.size(); c++) vals[c][i] = &batch[i].at(columns[c]);
-                cph_matches* m = nullptr;
-                {
-                    detail::StagedColumns st(ctx, columns.size());
-                    st.stage(vals, batch.size());
-                    int32_t rc = cph_join_probe(ctx, index->device().h, st.cols(), (int32_t)columns.size(), nullptr, 32,
-                                                0, 0, 0, /*want_pairs=*/0, CPH_MEM_HOST, &m);
-                    if (rc != CPH_OK) return Error(std::string("csvplus_hip: ") + cph_last_error(ctx));
-                }
-                Error err;
-                // index.impl.rows is read live at iteration time (:557), as in the reference
-                const std::vector<Row>& irows = index->impl_rows;
-                for (size_t i = 0; i < batch.size() && !err; i++) {
-                    if (anti) {
-                        if (m->cnt[i] == 0) err = fn(std::move(batch[i]));                        // :600-602
-                    } else {
-                        for (uint32_t j = 0; j < m->cnt[i] && !err; j++)                              // :559-563
-                            err = fn(mergeRows(irows[(size_t)m->lo[i] + j], batch[i]));
-                    }
-                }
-                cph_matches_release(m);
-                batch.clear();
-                return err;
-            };
-
-            Error err = src([&](Row row) -> Error {
-                std::vector<const std::string*> tmp;
-                Error e = SelectValues(row, columns, &tmp);                                       // :556 / :599
-                if (e) {
-                    // rows before this one must be delivered first, then the error surfaces
-                    Error fe = flush();
-                    return fe ? fe : e;
-                }
-                batch.push_back(std::move(row));
-                if (batch.size() >= batch_rows) return flush();
-                return Error();
-            });
-            if (err) return err;
-            err = flush();
-            // an io.EOF from `fn` in the tail batch ends the iteration cleanly, as the source
-            // would have mapped it (:238-239)
-            return err.is_eof() ? Error() : err;
+            return batched(src, columns, [&](std::vector<Row>* batch) { return probeBatch(ctx, index, columns, anti, batch, fn); });
         });
+    }
+
+    // upstream.Join(steps[0])...Join(steps[k]), k >= 1.  Per batch of stream rows: ONE fused device call when every row
+    // carries the key columns of ALL steps (the value a later Join sees is then the stream's own: mergeRows :571-583 lets the
+    // right operand win) — cph_join_chain_ex reporting sorted positions, the subscripts into each index's impl_rows —, else
+    // the steps one after the other over the merged rows.  Either way the rows come out in the reference's nested order:
+    // by stream row, then by position in steps[0]'s index, then in steps[1]'s, ...; a step-k row is merged as
+    // mergeRows(index_k row, mergeRows(index_k-1 row, ... stream row)): on a shared column name the precedence is
+    // stream > steps[0] > steps[1] > ... (csvplus.go:559-560 nested).
+    static DataSource chainSource(std::shared_ptr<const ChainSpec> spec) {
+        return DataSource([spec](const RowFunc& fn) -> Error {
+            cph_ctx* ctx = Gpu::Default().ctx();
+            const size_t S = spec->steps.size();
+            return batched(spec->upstream, spec->steps[0].columns, [&](std::vector<Row>* batch) -> Error {
+                if (batch->empty()) return Error();
+                bool fusable = true;
+                for (size_t k = 1; k < S && fusable; k++)
+                    for (const Row& r : *batch) {
+                        for (const auto& col : spec->steps[k].columns)
+                            if (!HasColumn(r, col)) { fusable = false; break; }
+                        if (!fusable) break;
+                    }
+                // the steps one after the other: step k's output rows are step k+1's stream (same order of outputs and of
+                // errors as the nested closures: a later step sees the rows in emission order)
+                if (!fusable) return runSteps(ctx, *spec, 0, batch, fn);
+                // ---- fused: all steps' key columns from the stream rows, one device call ----
+                std::vector<std::unique_ptr<detail::StagedColumns>> staged;
+                std::vector<cph_chain_step> steps(S);
+                for (size_t k = 0; k < S; k++) {
+                    const auto& cols = spec->steps[k].columns;
+                    std::vector<std::vector<const std::string*>> vals(cols.size());
+                    for (auto& v : vals) v.resize(batch->size());
+                    for (size_t i = 0; i < batch->size(); i++)
+                        for (size_t c = 0; c < cols.size(); c++) vals[c][i] = &(*batch)[i].at(cols[c]);
+                    staged.emplace_back(new detail::StagedColumns(ctx, cols.size()));
+                    staged.back()->stage(vals, batch->size());
+                    steps[k] = cph_chain_step{};
+                    steps[k].index = spec->steps[k].index->device().h;
+                    steps[k].cols = staged.back()->cols();
+                    steps[k].ncols = (int32_t)cols.size();
+                }
+                cph_chain* ch = nullptr;
+                if (cph_join_chain_ex(ctx, steps.data(), (int32_t)S, 0, CPH_MEM_HOST, CPH_CHAIN_POSITIONS, &ch) != CPH_OK)
+                    return Error(std::string("csvplus_hip: ") + cph_last_error(ctx));
+                Error err;
+                for (uint64_t m = 0; m < ch->nrows && !err; m++) {
+                    const uint64_t r = ch->stream_row ? ch->stream_row[m] : m;   // NULL: every row joined exactly once, in order
+                    Row row = mergeRows(spec->steps[0].index->impl_rows[ch->build_row[0][m]], (*batch)[(size_t)r]);
+                    for (size_t k = 1; k < S; k++) row = mergeRows(spec->steps[k].index->impl_rows[ch->build_row[k][m]], row);
+                    err = fn(std::move(row));
+                }
+                cph_chain_release(ch);
+                batch->clear();
+                return err;
+            });
+        });
+    }
+
+    // steps[from..] one after the other over `rows` (rows of step `from`'s stream that all carry its key columns)
+    static Error runSteps(cph_ctx* ctx, const ChainSpec& spec, size_t from, std::vector<Row>* rows, const RowFunc& fn) {
+        std::vector<Row> cur = std::move(*rows);
+        for (size_t k = from; k < spec.steps.size(); k++) {
+            const bool last = k + 1 == spec.steps.size();
+            const auto& st = spec.steps[k];
+            if (k > from) {
+                size_t good = 0;
+                Error miss;
+                for (; good < cur.size(); good++) {
+                    std::vector<const std::string*> tmp;
+                    miss = SelectValues(cur[good], st.columns, &tmp);
+                    if (miss) break;
+                }
+                if (miss) {
+                    cur.resize(good);
+                    Error e = runSteps(ctx, spec, k, &cur, fn);
+                    return e ? e : miss;
+                }
+            }
+            std::vector<Row> next;
+            Error e = probeBatch(ctx, st.index, st.columns, false, &cur,
+                                 last ? fn : RowFunc([&](Row row) { next.push_back(std::move(row)); return Error(); }));
+            if (e) return e;
+            cur = std::move(next);
+        }
+        return Error();
     }
 };
 

@@ -34,6 +34,22 @@ def gather_rows(ctx: N.Context, col: StrCol, row_ids=None, id_base: int = 0, out
     return cb
 
 
+def permute_col(ctx: N.Context, index, col: StrCol, out_mem: int = N.CPH_MEM_DEVICE):
+    """cph_index_permute: `col` (a column of the table `index` was built over) in index order — out[p] = col[perm[p]] — so
+    that the sorted positions a Join reports are row subscripts (csvplus.go:736: the reference keeps its index rows
+    sorted).  Returns a ColBuf (DEVICE) or a host StrCol."""
+    sc, keep = col.as_c()
+    out = C.POINTER(N.cph_colbuf)()
+    ctx._check(ctx.lib.cph_index_permute(ctx.handle, index.handle, C.byref(sc), out_mem, C.byref(out)))
+    del keep
+    cb = ColBuf(ctx, out)
+    if out_mem == N.CPH_MEM_HOST:
+        res = cb.to_strcol()
+        cb.release()
+        return res
+    return cb
+
+
 class ColBuf:
     def __init__(self, ctx, ptr):
         self.ctx, self.ptr = ctx, ptr

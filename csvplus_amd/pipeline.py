@@ -42,11 +42,15 @@ def read_table(ctx: N.Context, text: bytes, select=None, **kw) -> Table:
 
 
 def join_to_csv(ctx: N.Context, stream: Table, steps, out_columns, timings: dict | None = None, out_mem: int = N.CPH_MEM_HOST,
-                fused: bool = True):
+                fused: bool = True, positions: bool = True):
     """steps: [(index_table, index_key_column, stream_key_column), ...] — each index must be unique on its key
     (UniqueIndexOn; a duplicate raises like the reference's error :751).  out_columns: [(output name, table,
     column)] where table is `stream` or one of the index tables; the caller resolves name collisions the way
     mergeRows does (the stream's column wins, :578-580) by naming the table it wants.
+    positions (default since round 4): the Join reports SORTED POSITIONS (cph_join_chain_ex CPH_CHAIN_POSITIONS — the
+    reference's own row handle, csvplus.go:553-567, and the cheap lookup on the device) and the payload columns of every
+    build table are put in index order once (cph_index_permute: the reference's createIndex leaves its rows sorted, :736),
+    so a position IS the row subscript; False: original row ids into the tables as they were read (rounds 1-3).
     Returns the CSV text (header + joined rows, stream order): bytes, or a DeviceBytes handle for out_mem DEVICE."""
     def lap(name, t0):
         if timings is not None:
@@ -63,16 +67,27 @@ def join_to_csv(ctx: N.Context, stream: Table, steps, out_columns, timings: dict
                 raise ValueError(f"duplicate value while creating unique index on {key!r} (sorted position {ix.first_dup})")
         lap("index_ms", t0)
         t0 = time.perf_counter()
-        ch = N.join_chain(ctx, [(ix, [stream[skey]]) for ix, (_, _, skey) in zip(indices, steps)], out_mem=N.CPH_MEM_DEVICE)
+        tabs = [t for t, _, _ in steps]
+        sorted_cols = {}   # (table number, column) -> that column in index order
+        if positions:
+            from .materialize import permute_col
+            for _, tab, col in out_columns:
+                if tab is not stream and (tabs.index(tab), col) not in sorted_cols:
+                    cb = permute_col(ctx, indices[tabs.index(tab)], tab[col])
+                    bufs.append(cb)
+                    sorted_cols[(tabs.index(tab), col)] = cb.as_device_strcol()
+        lap("index_ms", t0)
+        t0 = time.perf_counter()
+        ch = N.join_chain(ctx, [(ix, [stream[skey]]) for ix, (_, _, skey) in zip(indices, steps)], out_mem=N.CPH_MEM_DEVICE,
+                          positions=positions)
         ptrs = ch.device_ptrs()
         n = ch.nrows
         lap("join_ms", t0)
         t0 = time.perf_counter()
         from .materialize import csv_write
-        tabs = [t for t, _, _ in steps]
         cols, ids = [], []
         for _, tab, col in out_columns:
-            cols.append(tab[col])
+            cols.append(tab[col] if tab is stream or not positions else sorted_cols[(tabs.index(tab), col)])
             if tab is stream:
                 ids.append(None if ch.identity or n == 0 else (ptrs["stream_row"], 64, n))
             else:

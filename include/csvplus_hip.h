@@ -456,6 +456,17 @@ CPH_API int32_t cph_gather_rows(cph_ctx* ctx, const cph_strcol* col, const void*
 CPH_API void    cph_colbuf_release(cph_colbuf* c);
 
 /*
+ * A column of the table an index was built over, in INDEX ORDER: out[p] = col[perm[p]] for the index's sorted
+ * positions p (cph_gather_rows through cph_index_perm).  The reference's Index holds its rows sorted (createIndex,
+ * csvplus.go:736) and Join reads index.impl.rows[first() + i]; a device pipeline that keeps the payload columns of a
+ * build table in this order once (IndexOn time) consumes the sorted positions a Join reports (cph_join_chain_ex
+ * CPH_CHAIN_POSITIONS, cph_stream_join_set_positions) directly as row subscripts — in cph_gather_rows, in
+ * cph_csv_write_rows' cph_rowsel — and never needs the original row ids.  col must have the rows of the indexed table
+ * (col->nrows > every perm value) and lives in host or device memory like the columns of cph_gather_rows.
+ */
+CPH_API int32_t cph_index_permute(cph_ctx* ctx, cph_index* index, const cph_strcol* col, int32_t out_mem, cph_colbuf** out);
+
+/*
  * ToCsv (csvplus.go:379-406): the canonical serialisation — a header line (when
  * `header` != NULL: ncols names) and one record per row with the columns in the
  * given order, formatted as Go's encoding/csv Writer does with default settings

@@ -423,6 +423,123 @@ static void TestBatchingSemantics() {
     CHECK(!e);
 }
 
+
+// ---- chained Joins through the facade (round 4): src.Join(a).Join(b) is ONE fused device call per batch when every stream
+// row carries all key columns, the steps one after the other otherwise; either way the reference's nested semantics
+// (csvplus.go:545-569 nested, mergeRows :571-583): precedence stream > first index > second index on a shared column
+// name, emission order by stream row, then position in the first index, then in the second; early stop and errors. ----------
+static std::vector<Row> nestedJoinOnHost(const std::vector<Row>& stream, const Index& ia, const std::vector<std::string>& ka,
+                                         const Index& ib, const std::vector<std::string>& kb, Error* err) {
+    // the reference's closures, literally: for every stream row, for every index row with equal key columns (in index order) ...
+    auto matches = [](const Index& ix, const std::vector<std::string>& cols, const Row& row, std::vector<const Row*>* out, Error* e) {
+        out->clear();
+        std::vector<const std::string*> vals;
+        *e = SelectValues(row, cols, &vals);
+        if (*e) return;
+        for (const Row& r : ix.rows()) {
+            bool eq = true;
+            for (size_t c = 0; c < cols.size() && eq; c++) eq = r.at(ix.columns()[c]) == *vals[c];
+            if (eq) out->push_back(&r);
+        }
+    };
+    std::vector<Row> out;
+    std::vector<const Row*> ma, mb;
+    for (const Row& s : stream) {
+        matches(ia, ka, s, &ma, err);
+        if (*err) return out;
+        for (const Row* a : ma) {
+            Row r1 = mergeRows(*a, s);
+            matches(ib, kb, r1, &mb, err);
+            if (*err) return out;
+            for (const Row* b : mb) out.push_back(mergeRows(*b, r1));
+        }
+    }
+    return out;
+}
+
+static void TestChainPrecedence() {
+    std::mt19937_64 rng(4);
+    // customers and products share the column names "name" and "tag"; some stream rows carry a "name" of their own
+    std::vector<Row> cust, prod, dupcust;
+    for (int i = 0; i < 300; i++)
+        cust.push_back(Row{{"id", std::to_string(i)}, {"name", "cust-" + std::to_string(i)}, {"tag", "C"}, {"fav_prod", std::to_string(i % 40)}});
+    for (int i = 0; i < 40; i++)
+        prod.push_back(Row{{"prod_id", std::to_string(i)}, {"name", "prod-" + std::to_string(i)}, {"tag", "P"}, {"price", std::to_string(i) + ".99"}});
+    for (int i = 0; i < 900; i++)   // three rows per customer id: duplicates in the first index
+        dupcust.push_back(Row{{"id", std::to_string(i % 300)}, {"name", "dup-" + std::to_string(i)}, {"tag", "D"}});
+    auto [ic, e1] = TakeRows(cust).UniqueIndexOn({"id"});
+    auto [ip, e2] = TakeRows(prod).UniqueIndexOn({"prod_id"});
+    auto [id, e3] = TakeRows(dupcust).IndexOn({"id"});
+    CHECK(!e1 && !e2 && !e3);
+    std::vector<Row> stream;
+    for (int i = 0; i < 5000; i++) {
+        Row r{{"order_id", std::to_string(i)}, {"cust_id", std::to_string(rng() % 330)}, {"prod_id", std::to_string(rng() % 44)}};
+        if (i % 3 == 0) r["name"] = "stream-" + std::to_string(i);
+        stream.push_back(r);
+    }
+    auto same = [](const std::vector<Row>& a, const std::vector<Row>& b) {
+        if (a.size() != b.size()) return false;
+        for (size_t i = 0; i < a.size(); i++)
+            if (a[i] != b[i]) return false;
+        return true;
+    };
+    for (size_t batch : {(size_t)1, (size_t)7, (size_t)8192}) {
+        Gpu::Default().join_batch_rows = batch;
+        // (1) fused: both keys from the stream row
+        Error he;
+        std::vector<Row> want = nestedJoinOnHost(stream, *ic, {"cust_id"}, *ip, {"prod_id"}, &he);
+        CHECK(!he && !want.empty());
+        auto [got, ge] = TakeRows(stream).Join(ic, {"cust_id"}).Join(ip, {"prod_id"}).ToRows();
+        CHECK(!ge);
+        CHECK(same(got, want));
+        for (const Row& r : got) {   // stream > customers > products
+            const bool own = atoi_s(r.at("order_id")) % 3 == 0;
+            CHECK(r.at("tag") == "C");
+            CHECK(own ? r.at("name").rfind("stream-", 0) == 0 : r.at("name").rfind("cust-", 0) == 0);
+        }
+        // (2) duplicates in the first index (three matches per stream row, in index order), fused
+        want = nestedJoinOnHost(stream, *id, {"cust_id"}, *ip, {"prod_id"}, &he);
+        auto [got2, ge2] = TakeRows(stream).Join(id, {"cust_id"}).Join(ip, {"prod_id"}).ToRows();
+        CHECK(!he && !ge2 && same(got2, want) && got2.size() > got.size());
+        // (3) the second key comes from the FIRST INDEX's row ("fav_prod" is a customers column): not fusable
+        want = nestedJoinOnHost(stream, *ic, {"cust_id"}, *ip, {"fav_prod"}, &he);
+        auto [got3, ge3] = TakeRows(stream).Join(ic, {"cust_id"}).Join(ip, {"fav_prod"}).ToRows();
+        CHECK(!he && !ge3 && same(got3, want) && !got3.empty());
+        // (4) mixed: every fifth stream row brings its own "fav_prod" (which then wins over the customer's)
+        std::vector<Row> mixed = stream;
+        for (size_t i = 0; i < mixed.size(); i += 5) mixed[i]["fav_prod"] = std::to_string(i % 44);
+        want = nestedJoinOnHost(mixed, *ic, {"cust_id"}, *ip, {"fav_prod"}, &he);
+        auto [got4, ge4] = TakeRows(mixed).Join(ic, {"cust_id"}).Join(ip, {"fav_prod"}).ToRows();
+        CHECK(!he && !ge4 && same(got4, want));
+        // (5) three steps, the last one natural on the first index's own key column
+        auto three = TakeRows(stream).Join(ic, {"cust_id"}).Join(ip, {"prod_id"}).Join(id, {"cust_id"});
+        size_t n3 = 0;
+        Error e5 = three([&](Row r) { n3++; return r.at("tag") == "C" ? Error() : Error("precedence"); });
+        CHECK(!e5 && n3 == 3 * got.size());
+        // (6) early stop through both Joins: io.EOF ends the pipeline cleanly after exactly 5 rows; an error is reported
+        int k = 0;
+        Error e6 = TakeRows(stream).Join(ic, {"cust_id"}).Join(ip, {"prod_id"})([&](Row) { return ++k == 5 ? io_EOF : Error(); });
+        CHECK(!e6 && k == 5);
+        k = 0;
+        e6 = TakeRows(stream).Join(id, {"cust_id"}).Join(ip, {"prod_id"})([&](Row) { return ++k == 4 ? Error("boom") : Error(); });
+        CHECK(e6 && e6.message().find("boom") != std::string::npos && k == 4);
+        // (7) a row that reaches the second Join without its key column: the rows in front of it are delivered, then the
+        //     error surfaces (csvplus.go:556, :145); a row that does NOT reach the second Join (no customer) raises nothing
+        std::vector<Row> holes;
+        for (int i = 0; i < 40; i++) holes.push_back(Row{{"order_id", std::to_string(i)}, {"cust_id", std::to_string(i)}, {"prod_id", std::to_string(i % 40)}});
+        holes[9].erase("prod_id");
+        holes[9]["cust_id"] = "99999";          // joins nothing: never seen by the second Join
+        holes[20].erase("prod_id");             // joins customer 20: the second Join misses "prod_id"
+        want = nestedJoinOnHost(holes, *ic, {"cust_id"}, *ip, {"prod_id"}, &he);
+        CHECK(he && want.size() == 19);
+        std::vector<Row> got7;
+        Error e7 = TakeRows(holes).Join(ic, {"cust_id"}).Join(ip, {"prod_id"})([&](Row r) { got7.push_back(std::move(r)); return Error(); });
+        CHECK(e7 && e7.message().find("missing column \"prod_id\"") != std::string::npos);
+        CHECK(same(got7, want));
+    }
+    Gpu::Default().join_batch_rows = 8192;
+}
+
 int main() {
     makeFixtures();
     struct T { const char* name; void (*fn)(); };
@@ -431,7 +548,7 @@ int main() {
                        {"TestLongChain", TestLongChain}, {"TestMultiIndex", TestMultiIndex},
                        {"TestExcept", TestExcept}, {"TestErrors", TestErrors},
                        {"TestResolver", TestResolver}, {"TestIndexStore", TestIndexStore},
-                       {"TestBatchingSemantics", TestBatchingSemantics}};
+                       {"TestBatchingSemantics", TestBatchingSemantics}, {"TestChainPrecedence", TestChainPrecedence}};
     int bad = 0;
     for (auto& t : tests) {
         int before = g_failed;

@@ -225,9 +225,10 @@ def test_read_csv_header_modes(ctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("positions", [True, False])
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("missing", [0, 500])
-def test_pipeline_csv_to_csv(ctx, missing, fused):
+def test_pipeline_csv_to_csv(ctx, missing, fused, positions):
     """The README chain end to end (README.md:33-66): three CSV files in, the joined CSV out, every stage on the
     device (csvplus_amd.pipeline), byte-compared with the same pipeline run through the oracle's pieces."""
     from csvplus_amd import datagen as dg
@@ -249,7 +250,9 @@ def test_pipeline_csv_to_csv(ctx, missing, fused):
     to = pipeline.read_table(ctx, files["orders"], select=["cust_id", "prod_id", "qty"])
     out_cols = [("cust_id", to, "cust_id"), ("qty", to, "qty"), ("name", tc, "name"), ("surname", tc, "surname"),
                 ("product", tp, "product"), ("price", tp, "price")]
-    got = pipeline.join_to_csv(ctx, to, [(tc, "id", "cust_id"), (tp, "prod_id", "prod_id")], out_cols, fused=fused)
+    # positions: the Join reports sorted positions and the build tables' payload columns are kept in index order
+    # (cph_index_permute); otherwise original row ids into the tables as parsed
+    got = pipeline.join_to_csv(ctx, to, [(tc, "id", "cust_id"), (tp, "prod_id", "prod_id")], out_cols, fused=fused, positions=positions)
     # oracle pipeline
     def parse(text, idx):
         cols, ek, _ = orc.csv_parse(text, idx, skip_records=1)

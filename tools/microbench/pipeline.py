@@ -47,20 +47,21 @@ def parse(f, idx, nf):
     return pipeline.Table(t)
 
 
-for rep in range(3):
+for rep in range(5):
     tm = {}
-    if rep == 2:
+    POSITIONS = rep != 3   # rep 3: the original-row-id mode of rounds 1-3 for comparison
+    if rep in (2, 3):
         ctx.profile(True); ctx.profile_read(reset=True)
     torch.cuda.synchronize(); t00 = time.perf_counter()
     tc, tp, to = parse(f_c, [0, 1, 2], 3), parse(f_p, [0, 1, 2], 3), parse(f_o, [0, 1, 2], 3)
     torch.cuda.synchronize(); tm["parse_ms"] = (time.perf_counter() - t00) * 1e3
     out_cols = [("cust_id", to, "c0"), ("qty", to, "c2"), ("name", tc, "c1"), ("surname", tc, "c2"), ("product", tp, "c1"), ("price", tp, "c2")]
     t1 = time.perf_counter()
-    text = pipeline.join_to_csv(ctx, to, [(tc, "c0", "c0"), (tp, "c0", "c1")], out_cols, timings=tm, out_mem=N.CPH_MEM_DEVICE)
+    text = pipeline.join_to_csv(ctx, to, [(tc, "c0", "c0"), (tp, "c0", "c1")], out_cols, timings=tm, out_mem=N.CPH_MEM_DEVICE, positions=POSITIONS)
     torch.cuda.synchronize(); total = (time.perf_counter() - t00) * 1e3
-    print(f"rep {rep}: " + ", ".join(f"{k}={v:.2f}" for k, v in tm.items()) + f" | total {total:.1f} ms, output {len(text) / 1e9:.3f} GB "
+    print(f"rep {rep} ({'sorted positions + payload in index order' if POSITIONS else 'original row ids'}): " + ", ".join(f"{k}={v:.2f}" for k, v in tm.items()) + f" | total {total:.1f} ms, output {len(text) / 1e9:.3f} GB "
           f"(text left in HBM) -> {M / total / 1e6:.2f} G joined rows/s end to end", flush=True)
-    if rep == 2:
+    if rep in (2, 3):
         p = ctx.profile_read(reset=True); ctx.profile(False)
         for k, v in sorted(p.items(), key=lambda kv: -kv[1]["total_ms"])[:14]:
             print(f"    {k:24s} {v['launches']:4d} launches {v['total_ms']:8.3f} ms", flush=True)
