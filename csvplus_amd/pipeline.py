@@ -42,21 +42,30 @@ def read_table(ctx: N.Context, text: bytes, select=None, **kw) -> Table:
 
 
 def join_to_csv(ctx: N.Context, stream: Table, steps, out_columns, timings: dict | None = None, out_mem: int = N.CPH_MEM_HOST,
-                fused: bool = True, positions: bool = True):
+                fused: bool = True, positions: bool | None = None):
     """steps: [(index_table, index_key_column, stream_key_column), ...] — each index must be unique on its key
     (UniqueIndexOn; a duplicate raises like the reference's error :751).  out_columns: [(output name, table,
     column)] where table is `stream` or one of the index tables; the caller resolves name collisions the way
     mergeRows does (the stream's column wins, :578-580) by naming the table it wants.
-    positions (default since round 4): the Join reports SORTED POSITIONS (cph_join_chain_ex CPH_CHAIN_POSITIONS — the
+    positions: the Join reports SORTED POSITIONS (cph_join_chain_ex CPH_CHAIN_POSITIONS — the
     reference's own row handle, csvplus.go:553-567, and the cheap lookup on the device) and the payload columns of every
     build table are put in index order once (cph_index_permute: the reference's createIndex leaves its rows sorted, :736),
-    so a position IS the row subscript; False: original row ids into the tables as they were read (rounds 1-3).
+    so a position IS the row subscript; False: original row ids into the tables as they were read (rounds 1-3); None
+    (default): whichever is cheaper by the measured costs (profiles/r04_pipeline.txt) — putting a payload column in index
+    order costs ~0.3 ms per 1e7 table rows, reporting positions saves ~1.0 ms per 1e8 stream rows, so a one-shot pipeline
+    whose stream is only a few times longer than its build tables keeps row ids.
     Returns the CSV text (header + joined rows, stream order): bytes, or a DeviceBytes handle for out_mem DEVICE."""
     def lap(name, t0):
         if timings is not None:
             ctx.synchronize()
             timings[name] = timings.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
 
+    if positions is None:
+        payload = {}
+        for _, tab, col in out_columns:
+            if tab is not stream:
+                payload[(id(tab), col)] = tab.nrows
+        positions = 1.0e-8 * stream.nrows > 3.0e-8 * sum(payload.values())
     indices, ch, bufs = [], None, []
     try:   # whatever fails below, the indexes, the chain and the gathered columns go back to the ctx pool
         t0 = time.perf_counter()

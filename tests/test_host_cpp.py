@@ -1,6 +1,7 @@
 """Runs the C++ host-facade tests (tests/cpp/test_host.cpp): the reference's own hot-path tests
 (TestIndexImpl, TestSimpleUniqueJoin, TestSorted, TestSimpleTotals, TestLongChain, TestMultiIndex,
-TestExcept, TestErrors, TestResolver, TestIndexStore) restated against csvplus_amd/host/csvplus.hpp, which calls the GPU through
+TestExcept, TestErrors, TestResolver, TestIndexStore; plus TestBatchingSemantics and TestChainPrecedence for the batched /
+fused boundary) restated against csvplus_amd/host/csvplus.hpp, which calls the GPU through
 the C ABI."""
 import subprocess
 from pathlib import Path
@@ -35,7 +36,8 @@ def test_reference_tests_through_cpp_facade():
     print(r.stdout)
     print(r.stderr)
     assert r.returncode == 0, r.stdout[-2000:]
-    assert "0 of 11 host tests failed" in r.stdout
+    assert "0 of 12 host tests failed" in r.stdout
+    assert "PASS TestChainPrecedence" in r.stdout   # round 4: src.Join(a).Join(b) fused per batch, stream > a > b
 
 
 C_DEMO = ROOT / "tests" / "c" / "abi_demo"

@@ -49,7 +49,7 @@ def parse(f, idx, nf):
 
 for rep in range(5):
     tm = {}
-    POSITIONS = rep != 3   # rep 3: the original-row-id mode of rounds 1-3 for comparison
+    POSITIONS = rep != 3   # rep 3: the original-row-id mode of rounds 1-3 for comparison (what join_to_csv's default picks at this shape)
     if rep in (2, 3):
         ctx.profile(True); ctx.profile_read(reset=True)
     torch.cuda.synchronize(); t00 = time.perf_counter()
