@@ -86,7 +86,13 @@ SMALL = ["--rows", "300000", "--customers", "20000", "--products", "700", "--ste
 def test_one_gpu_line_has_the_contract_fields():
     cmd = [sys.executable, BENCH, "--gpus", "1", *SMALL, "--verify-sample", "5000"]
     r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
-    if r.returncode != 0:   # the first GPU process on a box that has just been handed out: say what happened, try once more
+    if r.returncode != 0:
+        # Seen once in round 3 on a box that had just been handed out, never reproduced (rounds 3-4: every gpurun call of the
+        # suite since, profiles/r04_bench_first_attempt.txt).  The evidence must not vanish again: the failing attempt's
+        # stderr is written where gpurun brings it back (gpurun_out/), then the bench is tried once more.
+        out = Path(BENCH).resolve().parent / "gpurun_out"
+        out.mkdir(exist_ok=True)
+        (out / "bench_first_attempt_failure.txt").write_text(f"returncode {r.returncode}\n--- stderr ---\n{r.stderr}\n--- stdout ---\n{r.stdout}\n")
         print("first attempt failed:", r.returncode, r.stderr[-3000:], file=sys.stderr)
         r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]

@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Differential fuzz of the HIP path against the oracle on random tables (sizes 1..20000, 1-3 key columns, random alphabets
 and lengths, duplicates or not): IndexOn (both build paths), Join (pairs / bounds only), chain (row ids / sorted positions),
-Find / find_many.  usage: tools/fuzz_gpu.py [seconds] [seed]"""
+Find / find_many.  Round 4: every eighth case is a table of 66 000..90 000 rows whose first key column is built like a
+delimiter-split candidate (random heads + delimiter + digits, a few values without the delimiter, random delimiter byte), so
+the split codec (keycodec.hip) is fuzzed with and without being taken; every seventh case has fixed-width 8-byte decimal
+keys (the lean steps of the fused chain: arithmetic encode, identity / rank-table lookups).
+usage: tools/fuzz_gpu.py [seconds] [seed]"""
 import sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -24,13 +28,37 @@ def rand_col(n, distinct, alphabet, lo, hi):
 ALPHAS = [np.frombuffer(b"0123456789", np.uint8), np.frombuffer(b"abcxyz", np.uint8), np.arange(256, dtype=np.uint8),
           np.frombuffer(b"\x00\xffA", np.uint8), np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789", np.uint8)]
 t_end = time.time() + budget
-cases = 0
+cases = splits = leans = 0
 while time.time() < t_end:
     n = int(rng.choice([1, 2, 63, 64, 65, 500, 4096, 8192, 8193, 16384, 16385, 20000])) if rng.random() < 0.5 else int(rng.integers(1, 20000))
     ncols = int(rng.integers(1, 4))
     unique_wanted = rng.random() < 0.4
+    split_case = cases % 8 == 5
+    lean_case = cases % 7 == 3
+    if split_case:
+        n = int(rng.integers(66_000, 90_000))
+        unique_wanted = False
     build, pools = [], []
     for c in range(ncols):
+        if split_case and c == 0:
+            delim = bytes([int(rng.choice([35, 47, 58, 0, 255, 44, 124]))])
+            nheads = int(rng.choice([1, 3, 40, 300, 1500]))
+            hl = int(rng.integers(0, 14))
+            heads = list({bytes(ALPHAS[int(rng.integers(0, 2)) + 1][rng.integers(0, 6, int(rng.integers(0, hl + 1)))]) for _ in range(nheads)})
+            digits = int(rng.integers(1, 7))
+            pool = [heads[int(rng.integers(0, len(heads)))] + delim + (b"%d" % int(rng.integers(0, 10 ** digits))) for _ in range(max(2, n // int(rng.integers(1, 6))))]
+            for j in range(0, len(pool), int(rng.integers(150, 5000))):
+                pool[j] = heads[int(rng.integers(0, len(heads)))]          # no delimiter at all
+            vals = [pool[int(i)] for i in rng.integers(0, len(pool), n)]
+            build.append(vals); pools.append(pool)
+            continue
+        if lean_case and c == 0:
+            span = int(rng.choice([n, 3 * n]))
+            base = int(rng.choice([0, 20_000_000]))
+            pool = [b"%08d" % (base + int(x)) for x in rng.permutation(span)[:n]]
+            build.append(pool); pools.append(pool)
+            unique_wanted = True
+            continue
         a = ALPHAS[int(rng.integers(0, len(ALPHAS)))]
         lo = int(rng.integers(0, 4)); hi = lo + int(rng.integers(0, 12))
         distinct = n * 4 if (unique_wanted and c == 0) else int(rng.integers(1, max(2, n)))
@@ -53,7 +81,10 @@ while time.time() < t_end:
     for limit in (16384, 0):
         ctx.set_option("small_build_rows", limit)
         g = DeviceIndex(ctx, bcols)
-        tag = (seed, cases, n, ncols, m, limit, g.info()["build_path"])
+        tag = (seed, cases, n, ncols, m, limit, g.info()["build_path"], g.info()["split"])
+        if limit == 0:
+            splits += g.info()["split"] != 0
+            leans += lean_case
         assert np.array_equal(g.perm(), o.perm), tag
         assert g.first_dup == o.first_dup(), tag
         for k in range(1, ncols + 1):
@@ -83,4 +114,4 @@ while time.time() < t_end:
         g.close()
     cases += 1
 ctx.set_option("small_build_rows", 8192)
-print("FUZZ_OK cases", cases, "seed", seed, flush=True)
+print("FUZZ_OK cases", cases, "seed", seed, "| tables coded with the delimiter split:", splits, "| fixed-width 8-byte key tables (lean chain steps):", leans, flush=True)
