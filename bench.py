@@ -658,6 +658,54 @@ def main():
             "rows": nloc, "chunk_rows": chunk, "slots": nslots, "in_flight": inflight, "ms": round(best * 1e3, 2),
             "rows_per_s": nloc / best, "joined": joined_e2e,
             "h2d_GBps": round(h2d / best / 1e9, 1), "d2h_GBps": round(d2h / best / 1e9, 1)}
+        # The same scope with the key codes formed ON THE HOST (cph_host_encoder_*: a pool of worker threads walks the codec's
+        # table over the pinned strings) and shipped as 4 bytes per row and step (cph_stream_join_submit_codes) instead of
+        # the 17 bytes of key strings: the host encode of chunk k+1 overlaps the transfers and kernels of chunk k.  The
+        # encode time is INSIDE the timed loop; it is also timed alone (host_encode_ms: all chunks, nothing else running).
+        try:
+            from csvplus_amd.streaming import HostEncoder, PinnedArray
+
+            encs = [HostEncoder(ia), HostEncoder(ib)]
+            code_bufs = [[PinnedArray(eng.ctx, e - b) for _ in range(2)] for b, e in bounds]
+            t0 = time.perf_counter()
+            for ci, ch_cols in enumerate(chunks):
+                for k in range(2):
+                    encs[k].run([ch_cols[k]], code_bufs[ci][k].array)
+            enc_alone = time.perf_counter() - t0
+            sj = StreamJoin(eng.ctx, [ia, ib], nslots=nslots, positions=POS)
+            best_c = None
+            for rep in range(4):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                sub = done = 0
+                joined_c = 0
+                while done < len(chunks):
+                    while sub < len(chunks) and sj.pending < inflight:
+                        for k in range(2):
+                            encs[k].run([chunks[sub][k]], code_bufs[sub][k].array)
+                        sj.submit_codes([p.array for p in code_bufs[sub]], bounds[sub][1] - bounds[sub][0], probe_base=bounds[sub][0])
+                        sub += 1
+                    r = sj.next(copy=False)
+                    joined_c += r["nmatches"]
+                    done += 1
+                dt_c = time.perf_counter() - t0
+                if rep > 0 and (best_c is None or dt_c < best_c):
+                    best_c = dt_c
+            sj.close()
+            out["e2e_pinned_host_encoded"] = {
+                "scope": "as e2e_pinned_host, but the stream's keys cross PCIe as 4-byte codes formed on the host (cph_host_encoder_run: "
+                         f"{encs[0].threads} worker threads) — host encode time included; key strings in pinned host memory in -> "
+                         "pinned host " + ("sorted positions" if POS else "build-row ids") + " + match bitmap out",
+                "rows": nloc, "ms": round(best_c * 1e3, 2), "rows_per_s": nloc / best_c, "joined": joined_c,
+                "host_encode_ms_alone": round(enc_alone * 1e3, 2), "host_threads": encs[0].threads,
+                "h2d_GBps": round(8 * nloc / best_c / 1e9, 1), "d2h_GBps": round(d2h / best_c / 1e9, 1),
+                "equals_string_pipeline": joined_c == joined_e2e}
+            for e_ in encs:
+                e_.close()
+            for p_ in sum(code_bufs, []):
+                p_.free()
+        except Exception as ex:   # noqa: BLE001 — reported, never fatal for the headline
+            out["e2e_pinned_host_encoded"] = {"error": f"{type(ex).__name__}: {ex}"}
         for c in pc:
             c.free()
         ia.close(); ib.close()

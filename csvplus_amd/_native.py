@@ -222,6 +222,11 @@ PROTOTYPES = [
     ("cph_stream_join_set_positions", C.c_int32, [_P, C.c_int32]),
     ("cph_stream_join_destroy", None, [_P]),
     ("cph_stream_join_submit", C.c_int32, [_P, C.POINTER(cph_strcol), C.c_uint64]),
+    ("cph_stream_join_submit_codes", C.c_int32, [_P, C.POINTER(C.c_void_p), C.c_uint64, C.c_uint64]),
+    ("cph_host_encoder_create", C.c_int32, [_P, C.c_int32, C.POINTER(_P)]),
+    ("cph_host_encoder_threads", C.c_int32, [_P]),
+    ("cph_host_encoder_run", C.c_int32, [_P, C.POINTER(cph_strcol), C.c_int32, C.c_void_p]),
+    ("cph_host_encoder_destroy", None, [_P]),
     ("cph_stream_join_pending", C.c_int32, [_P]),
     ("cph_stream_join_next", C.c_int32, [_P, C.POINTER(cph_stream_chunk)]),
     ("cph_gather_rows", C.c_int32,

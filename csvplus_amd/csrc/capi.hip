@@ -816,7 +816,7 @@ CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value
     else if (k == "sort_rbits") ctx->sort_rbits = (int)value;
     else if (k == "sort_digit_stream") ctx->sort_digit_stream = value != 0;
     else if (k == "sort_xcd_tiles") ctx->sort_xcd_tiles = value != 0;
-    else if (k == "codec_debug") ctx->codec_debug = value != 0;
+    else if (k == "codec_debug") ctx->codec_debug = (int)value;
     else if (k == "join_hash") ctx->join_hash = value != 0;
     else if (k == "stream_role_streams") ctx->stream_role_streams = value != 0;
     else if (k == "stream_zero_copy_out") ctx->stream_zero_copy_out = value != 0;

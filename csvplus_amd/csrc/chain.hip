@@ -333,6 +333,86 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
     }
 }
 
+// The same dense pass over key CODES the host formed (host_encode.hip: cph_host_encoder_run; a stream in host memory then
+// ships 4 bytes per row and step instead of its key strings): no decode at all, one 4-byte load and one lookup per row and
+// step.  Outputs and bookkeeping exactly as k_chain_dense (slot == row, match ballots, per-(tile, wave) counts).
+struct CodeStepArg {
+    const uint32_t* codes;      // the chunk's codes for this step (CPH_CODE_ABSENT: the key cannot be in the index)
+    const uint32_t* rowtab;     // row ids: code -> build row
+    const uint2* ranktab;       // positions: presence bits + keys before per 32 codes
+    uint64_t n_index, table_entries;
+    int32_t identity;           // positions, states == rows: the position is the code
+    int32_t reserved_;
+};
+struct CodeArgs {
+    CodeStepArg step[kMaxChain];
+    uint32_t* out_rows[kMaxChain];
+};
+template <int S>
+__global__ __launch_bounds__(kChainThreads) void k_chain_codes(CodeArgs a, uint64_t nprobe, uint64_t ntiles, uint64_t* __restrict__ masks,
+                                                              uint32_t* __restrict__ wave_counts) {
+    const int lane = lane_id();
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(wave_id());
+#pragma unroll 1
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t wbase = tile * kChainTile + (uint64_t)wave * kWaveTile;
+        const WaveRows<kChainRows> wr = wave_rows<kChainRows>(wbase, nprobe);
+        uint32_t okm = wr.okm;
+        uint32_t code[S][kChainRows], brow[S][kChainRows];
+#pragma unroll
+        for (int s = 0; s < S; s++)
+#pragma unroll
+            for (int k = 0; k < kChainRows; k++) code[s][k] = (a.step[s].codes + wr.rbase)[wr.rel[k]];
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            const CodeStepArg& st = a.step[s];
+            if (st.identity) {
+#pragma unroll
+                for (int k = 0; k < kChainRows; k++) brow[s][k] = (uint64_t)code[s][k] < st.n_index ? code[s][k] : kTableAbsent;
+            } else if (st.ranktab) {
+                uint2 blk[kChainRows];
+#pragma unroll
+                for (int k = 0; k < kChainRows; k++) {
+                    const bool in = (uint64_t)code[s][k] < st.table_entries;
+                    blk[k] = st.ranktab[in ? code[s][k] >> 5 : 0u];
+                    if (!in) blk[k].x = 0u;
+                }
+#pragma unroll
+                for (int k = 0; k < kChainRows; k++) {
+                    const uint32_t bit = code[s][k] & 31u;
+                    brow[s][k] = (blk[k].x >> bit) & 1u ? blk[k].y + (uint32_t)__popc(blk[k].x & ((1u << bit) - 1u)) : kTableAbsent;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < kChainRows; k++) {
+                    const bool in = (uint64_t)code[s][k] < st.table_entries;
+                    const uint32_t r = st.rowtab[in ? code[s][k] : 0u];
+                    brow[s][k] = in ? r : kTableAbsent;
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < S; s++)
+#pragma unroll
+            for (int k = 0; k < kChainRows; k++)
+                if (brow[s][k] == kTableAbsent) okm &= ~(1u << k);
+        uint32_t wave_matches = 0;
+        const uint64_t mword = (tile * kChainWaves + wave) * kChainRows;
+#pragma unroll
+        for (int k = 0; k < kChainRows; k++) {
+            const bool ok = (okm >> k) & 1u;
+            const uint64_t bal = __ballot(ok);
+            wave_matches += (uint32_t)__popcll(bal);
+            if (lane == 0) masks[mword + k] = bal;
+            if (ok) {
+#pragma unroll
+                for (int s = 0; s < S; s++) (a.out_rows[s] + wr.rbase)[wr.rel[k]] = brow[s][k];
+            }
+        }
+        if (lane == 0) wave_counts[tile * kChainWaves + wave] = wave_matches;
+    }
+}
+
 // total += sum of the per-(tile, wave) counts (grid-stride; one atomic per workgroup)
 __global__ __launch_bounds__(256) void k_sum_counts(const uint32_t* __restrict__ counts, uint64_t n,
                                                    unsigned long long* __restrict__ total) {
@@ -553,6 +633,62 @@ Status chain_enqueue_dense(cph_ctx* ctx, const ChainStep* steps, int nsteps, uin
     case 2: return enqueue_dense<2>(ctx, steps, nprobe, probe_base, d_rows, d_masks, d_counts, d_total, nullptr, nullptr, positions);
     case 3: return enqueue_dense<3>(ctx, steps, nprobe, probe_base, d_rows, d_masks, d_counts, d_total, nullptr, nullptr, positions);
     case 4: return enqueue_dense<4>(ctx, steps, nprobe, probe_base, d_rows, d_masks, d_counts, d_total, nullptr, nullptr, positions);
+    }
+    return {CPH_ERR_INVALID, "bad chain length"};
+}
+// d_codes[s] = the chunk's host-formed codes for step s, already in device memory.  Every index needs a direct lookup over
+// its code space: the rank table (or nothing, when the index fills its code space) for positions, the row table otherwise.
+template <int S>
+static Status enqueue_codes(cph_ctx* ctx, const cph_index* const* idx, const uint32_t* const* d_codes, uint64_t nprobe, uint32_t* const* d_rows,
+                            uint64_t* d_masks, uint32_t* d_counts, uint64_t* d_total, bool positions) {
+    const uint64_t ntiles = (nprobe + kChainTile - 1) / kChainTile;
+    CodeArgs args{};
+    for (int s = 0; s < S; s++) {
+        const cph_index* ix = idx[s];
+        if (ix->nkeycols < 1 || ix->codec.nwords != 1 || !ix->codec.key32 || !ix->windows.empty() || ix->first_dup != UINT64_MAX)
+            return {CPH_ERR_INVALID, "joining host-formed codes needs duplicate-free indexes with one-word 32-bit codes"};
+        CodeStepArg& st = args.step[s];
+        st.codes = d_codes[s];
+        st.n_index = ix->nrows;
+        st.table_entries = ix->table_entries;
+        if (positions && ix->table_entries != 0 && ix->table_entries == ix->nrows) {
+            st.identity = 1;
+        } else if (positions) {
+            CPH_TRY(index_ensure_ranktab(ctx, ix));
+            st.ranktab = ix->ranktab ? ix->ranktab.as<uint2>() : nullptr;
+        } else {
+            CPH_TRY(index_ensure_rowtab(ctx, ix));
+            st.rowtab = ix->rowtab ? ix->rowtab.as<uint32_t>() : nullptr;
+        }
+        if (!st.identity && !st.ranktab && !st.rowtab)
+            return {CPH_ERR_INVALID, "joining host-formed codes needs a direct lookup structure (dense code space) for every index"};
+        args.out_rows[s] = d_rows[s];
+    }
+    int per_cu = 1, cus = 256;
+    CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_chain_codes<S>), kChainThreads, 0, &per_cu));
+    CPH_TRY(device_cus(ctx, &cus));
+    const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)cus * (uint64_t)per_cu);
+    {
+        ProfScope ps(ctx, "k_chain_codes", (double)nprobe * 8.0 * S);
+        hipLaunchKernelGGL(k_chain_codes<S>, dim3(grid), dim3(kChainThreads), 0, ctx->stream, args, nprobe, ntiles, d_masks, d_counts);
+    }
+    const uint64_t ncounts = ntiles * kChainWaves;
+    {
+        ProfScope ps(ctx, "k_sum_counts", 4.0 * (double)ncounts);
+        CPH_HIP_TRY(hipMemsetAsync(d_total, 0, sizeof(uint64_t), ctx->stream));
+        const unsigned sgrid = (unsigned)std::min<uint64_t>((ncounts + 255) / 256, 512);
+        hipLaunchKernelGGL(k_sum_counts, dim3(sgrid), dim3(256), 0, ctx->stream, d_counts, ncounts, reinterpret_cast<unsigned long long*>(d_total));
+    }
+    CPH_HIP_TRY(hipGetLastError());
+    return {};
+}
+Status chain_enqueue_codes(cph_ctx* ctx, const cph_index* const* idx, const uint32_t* const* d_codes, int nsteps, uint64_t nprobe,
+                           uint32_t* const* d_rows, uint64_t* d_masks, uint32_t* d_counts, uint64_t* d_total, bool positions) {
+    switch (nsteps) {
+    case 1: return enqueue_codes<1>(ctx, idx, d_codes, nprobe, d_rows, d_masks, d_counts, d_total, positions);
+    case 2: return enqueue_codes<2>(ctx, idx, d_codes, nprobe, d_rows, d_masks, d_counts, d_total, positions);
+    case 3: return enqueue_codes<3>(ctx, idx, d_codes, nprobe, d_rows, d_masks, d_counts, d_total, positions);
+    case 4: return enqueue_codes<4>(ctx, idx, d_codes, nprobe, d_rows, d_masks, d_counts, d_total, positions);
     }
     return {CPH_ERR_INVALID, "bad chain length"};
 }

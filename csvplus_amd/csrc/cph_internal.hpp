@@ -567,6 +567,9 @@ Status chain_run(cph_ctx* ctx, const ChainStep* steps, int nsteps, uint64_t prob
 bool chain_fast_path_ok(const ChainStep* steps, int nsteps);
 Status chain_enqueue_dense(cph_ctx* ctx, const ChainStep* steps, int nsteps, uint64_t nprobe, uint64_t probe_base,
                            uint32_t* const* d_rows, uint64_t* d_masks, uint32_t* d_counts, uint64_t* d_total, bool positions = false);
+// the same over host-formed key codes (host_encode.hip) that already sit in device memory
+Status chain_enqueue_codes(cph_ctx* ctx, const cph_index* const* idx, const uint32_t* const* d_codes, int nsteps, uint64_t nprobe,
+                           uint32_t* const* d_rows, uint64_t* d_masks, uint32_t* d_counts, uint64_t* d_total, bool positions);
 uint64_t chain_dense_mask_words(uint64_t nprobe);
 uint64_t chain_dense_count_words(uint64_t nprobe);
 

@@ -54,6 +54,17 @@ __device__ __forceinline__ T wave_min(T v) {
     return v;
 }
 
+// Workgroup barrier BEHIND LDS ATOMICS.  __syncthreads() makes the compiler wait for a wave's earlier LDS loads and stores, but
+// for no-return LDS atomics (atomicAdd / atomicMin / ... on __shared__ memory: ds_add_u32 ...) hipcc 7.0 emits the s_barrier
+// without an s_waitcnt lgkmcnt(0): on gfx950 a wave can then signal the barrier while its atomics are still queued, and a wave
+// of the same workgroup that reads the counters right behind the barrier sees them short (found in round 4 by the
+// differential fuzz: the first-pass histogram of k_encode_split lost ~1 % of its increments in ~1 % of the builds and the
+// radix sort scattered into holes).  Every barrier that separates LDS atomics from reads of their targets goes through here.
+__device__ __forceinline__ void lds_atomics_barrier() {
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0), nothing else waited for
+    __syncthreads();
+}
+
 // Exclusive workgroup scan of one value per thread.  `smem` needs NWAVES+1
 // entries of T.  Returns the exclusive prefix; *total gets the workgroup sum.
 // Contains __syncthreads: every thread of the block must call it.

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kStatsThreads) void k_col_stats(DevCol col, uint32_
     mn = wave_min(mn);
     mx = wave_max(mx);
     if (lane_id() == 0) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); }
-    __syncthreads();
+    lds_atomics_barrier();
     const int npos = s_max < (uint32_t)kMaxKeyBytes ? (int)s_max : kMaxKeyBytes;
     for (int i = threadIdx.x; i < npos * 8; i += kStatsThreads) {   // mask word i = flags [32 i, 32 i + 32)
         const uint32_t* f = reinterpret_cast<const uint32_t*>(s_flag + 32 * i);
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(kSampleThreads) void k_group_sample(StageArg st, co
             }
         }
     }
-    __syncthreads();
+    lds_atomics_barrier();
     const bool over = s_count > (uint32_t)kGroupDictMax;
     uint32_t once = 0;
     if (!over)
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(kSampleThreads) void k_group_sample(StageArg st, co
         }
     once = wave_sum(once);
     if (lane_id() == 0 && once) atomicAdd(&s_single, once);
-    __syncthreads();
+    lds_atomics_barrier();
     if (threadIdx.x == 0) {
         counts[blockIdx.x] = over ? (s_count | kGroupOverflow) : s_count;
         singles[blockIdx.x] = s_single;
@@ -1000,7 +1000,7 @@ __global__ __launch_bounds__(kSplitThreads) void k_split_stats(DevCol col, Split
         atomicMax(&s_vmax, vmax);
     }
     if (flags) atomicOr(&s_flags, flags);
-    __syncthreads();
+    lds_atomics_barrier();
     for (int i = threadIdx.x; i < kSplitMaxSuffix * 8; i += kSplitThreads) {   // mask word i = flags [32 i, 32 i + 32)
         const uint32_t* f = reinterpret_cast<const uint32_t*>(s_flag + 32 * i);
         uint32_t bits = 0;
@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(kSplitThreads) void k_split_count(DevCol col, uint6
     mx = wave_max(mx);
     mn = wave_min(mn);
     if (lane_id() == 0) { atomicMax(&s_max, mx); atomicMin(&s_min, mn); }
-    __syncthreads();
+    lds_atomics_barrier();
     for (int i = threadIdx.x; i < 256; i += kSplitThreads)
         if (s_cnt[i]) atomicAdd(&out->cnt[i], s_cnt[i]);
     for (int i = threadIdx.x; i < kSplitMaxValue * 8; i += kSplitThreads) {
@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(kSplitThreads) void k_encode_split(DevCol col, cons
             }
         }
         if (counts) {
-            __syncthreads();
+            lds_atomics_barrier();   // (device_utils.hpp: the histogram's ds_add must have been performed)
             for (uint32_t x = threadIdx.x; x < bins; x += kSplitThreads) counts[(uint64_t)x * ntiles + tile] = s_hist[x];
             __syncthreads();
         }
@@ -1424,8 +1424,6 @@ Status codec_try_split(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t
         }
     if (dict.size() != st.count) return {};
     std::sort(dict.begin(), dict.end(), wide_less);
-    for (size_t i = 1; i < dict.size(); i++)
-        if (!wide_less(dict[i - 1], dict[i])) return {};   // the same prefix twice under two tags cannot happen; be sure
 
     // ---- 4. the codec over the virtual columns ----
     std::vector<ColStats> vstats;
@@ -1728,7 +1726,7 @@ __global__ __launch_bounds__(kEncodeThreads) void k_encode_build_fast(DevCol col
             }
         }
         if (counts) {
-            __syncthreads();
+            lds_atomics_barrier();
             for (uint32_t d = threadIdx.x; d < bins; d += kEncodeThreads) counts[(uint64_t)d * ntiles + tile] = s_hist[d];
             __syncthreads();
         }
@@ -1882,7 +1880,7 @@ __global__ __launch_bounds__(THREADS) void k_encode_build_plan(ColsArg cols, con
             }
       }
       if (counts) {
-          __syncthreads();
+          lds_atomics_barrier();
           for (uint32_t d = threadIdx.x; d < bins; d += THREADS) counts[(uint64_t)d * ntiles + tile] = s_hist[d];
           __syncthreads();
       }

@@ -870,7 +870,7 @@ __global__ __launch_bounds__(kProbeThreads) void k_expand(const uint32_t* __rest
         run += v[k];
     }
     if (threadIdx.x == kProbeThreads - 1) s_off[kProbeTile] = run;
-    __syncthreads();
+    lds_atomics_barrier();
     const uint64_t out0 = tile_base[blockIdx.x];
     if (s_max <= 1) {
         // at most one match per stream row (unique build side): direct placement

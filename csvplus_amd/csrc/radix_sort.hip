@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const K* __restrict
         const uint64_t i = tile0 + (uint64_t)k * kSortThreads + threadIdx.x;
         if (i < n) atomicAdd(&s_hist[w][(uint32_t)(key[k] >> shift) & digit_mask], 1u);
     }
-    __syncthreads();
+    lds_atomics_barrier();
     for (int d = threadIdx.x; d < BINS; d += kSortThreads) {
         uint32_t c = 0;
 #pragma unroll
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist_bytes(const uint8_t
     } else {
         for (uint64_t i = first; i < n && i < first + kSortItems; i++) atomicAdd(&s_hist[w][digits[i]], 1u);
     }
-    __syncthreads();
+    lds_atomics_barrier();
     for (int d = threadIdx.x; d < BINS; d += kSortThreads) {
         uint32_t c = 0;
 #pragma unroll

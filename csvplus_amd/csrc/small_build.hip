@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_build(const SmallArg a)
             if (lane == 0) { atomicMin(&s_min[c], mn); atomicMax(&s_max[c], mx); }
         }
     }
-    __syncthreads();
+    lds_atomics_barrier();
     if (tid == 0) {
         uint64_t start = 0;
         for (int c = 0; c < ncols; c++) {
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_build(const SmallArg a)
         best = wave_min(best);
         if (lane == 0 && best != 0xFFFFFFFFu) atomicMin(&s_dup, best);
     }
-    __syncthreads();
+    lds_atomics_barrier();
     if (w == 0) {   // one wave talks to the host: result block first, then (behind a system-scope fence) the status word
         SmallResult* res = a.res;
         for (int i = lane; i < npos * 8; i += kWave) res->mask[i >> 3][i & 7] = s_mask[i];

@@ -329,9 +329,26 @@ CPH_API void cph_stream_join_destroy(cph_stream_join* sj) {
     delete sj;
 }
 
+static int32_t submit_impl(cph_stream_join* sj, const cph_strcol* step_cols, const uint32_t* const* step_codes, uint64_t nrows_codes,
+                           uint64_t probe_base);
+
 // step_cols[s] = the stream chunk's key column for step s (HOST memory, pinned for real overlap).
 CPH_API int32_t cph_stream_join_submit(cph_stream_join* sj, const cph_strcol* step_cols, uint64_t probe_base) {
     if (!sj || !step_cols) return CPH_ERR_INVALID;
+    return submit_impl(sj, step_cols, nullptr, 0, probe_base);
+}
+
+// step_codes[s] = the chunk's host-formed key codes for step s (cph_host_encoder_run): 4 bytes per row and step travel
+CPH_API int32_t cph_stream_join_submit_codes(cph_stream_join* sj, const uint32_t* const* step_codes, uint64_t nrows, uint64_t probe_base) {
+    if (!sj || !step_codes) return CPH_ERR_INVALID;
+    if (sj->general) return sj_fail(sj->parent, CPH_ERR_INVALID, "cph_stream_join_submit_codes: fused-mode stream joins only (cph_stream_join_create)");
+    for (int s = 0; s < sj->nsteps; s++)
+        if (!step_codes[s]) return sj_fail(sj->parent, CPH_ERR_INVALID, "step_codes[k] is NULL");
+    return submit_impl(sj, nullptr, step_codes, nrows, probe_base);
+}
+
+static int32_t submit_impl(cph_stream_join* sj, const cph_strcol* step_cols, const uint32_t* const* step_codes, uint64_t nrows_codes,
+                           uint64_t probe_base) {
     cph_ctx* pctx = sj->parent;
     if (hipSetDevice(pctx->device) != hipSuccess) return sj_fail(pctx, CPH_ERR_HIP, "hipSetDevice failed");
     // round robin: the arrays cph_stream_join_next handed out for chunk k stay untouched until chunk k + nslots
@@ -340,7 +357,7 @@ CPH_API int32_t cph_stream_join_submit(cph_stream_join* sj, const cph_strcol* st
     if (sj->slots[slot]->busy) return sj_fail(pctx, CPH_ERR_INVALID, "no free slot: call cph_stream_join_next first");
     auto& sl = *sj->slots[slot];
     cph_ctx* ctx = &sl.sctx;
-    const uint64_t n = step_cols[0].nrows;
+    const uint64_t n = step_cols ? step_cols[0].nrows : nrows_codes;
     if (n == 0 || n > 0xFFFFFFFFull) return sj_fail(pctx, CPH_ERR_INVALID, "chunk must have 1 .. 2^32-1 rows");
     if (sj->general) {   // hand the chunk to the slot's worker thread
         {
@@ -360,7 +377,16 @@ CPH_API int32_t cph_stream_join_submit(cph_stream_join* sj, const cph_strcol* st
     auto run = [&]() -> Status {
         sl.d_in.clear();
         ChainStep steps[CPH_MAX_CHAIN];
+        const uint32_t* d_codes[CPH_MAX_CHAIN] = {nullptr};
         for (int s = 0; s < sj->nsteps; s++) {
+            if (step_codes) {   // 4 bytes per row of this step
+                DevBuf b;
+                CPH_TRY(b.alloc(&ctx->pool, n * sizeof(uint32_t)));
+                CPH_HIP_TRY(hipMemcpyAsync(b.get(), step_codes[s], n * sizeof(uint32_t), hipMemcpyHostToDevice, sj->up ? sj->up : ctx->stream));
+                d_codes[s] = b.as<uint32_t>();
+                sl.d_in.push_back(std::move(b));
+                continue;
+            }
             DevCol d;
             CPH_TRY(stage_chunk_col(ctx, step_cols[s], n, &sl.d_in, &d, sj->up));
             steps[s].index = sj->index[s];
@@ -402,8 +428,12 @@ CPH_API int32_t cph_stream_join_submit(cph_stream_join* sj, const cph_strcol* st
         CPH_TRY(sl.d_masks.alloc(&ctx->pool, mw * sizeof(uint64_t)));
         CPH_TRY(sl.d_counts.alloc(&ctx->pool, cw * sizeof(uint32_t)));
         CPH_TRY(sl.d_total.alloc(&ctx->pool, sizeof(uint64_t)));
-        CPH_TRY(chain_enqueue_dense(ctx, steps, sj->nsteps, n, probe_base, rows, sl.d_masks.as<uint64_t>(),
-                                    sl.d_counts.as<uint32_t>(), sl.d_total.as<uint64_t>(), sj->positions));
+        if (step_codes)
+            CPH_TRY(chain_enqueue_codes(ctx, sj->index, d_codes, sj->nsteps, n, rows, sl.d_masks.as<uint64_t>(), sl.d_counts.as<uint32_t>(),
+                                        sl.d_total.as<uint64_t>(), sj->positions));
+        else
+            CPH_TRY(chain_enqueue_dense(ctx, steps, sj->nsteps, n, probe_base, rows, sl.d_masks.as<uint64_t>(),
+                                        sl.d_counts.as<uint32_t>(), sl.d_total.as<uint64_t>(), sj->positions));
         hipStream_t ds = ctx->stream;
         if (sj->down) {   // the downloads queue up behind one another on their own stream, each behind its chunk's kernels
             CPH_HIP_TRY(hipEventRecord(sl.computed, ctx->stream));

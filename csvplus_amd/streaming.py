@@ -38,6 +38,59 @@ class PinnedCol:
         self._ptrs = []
 
 
+class PinnedArray:
+    """nelem elements of `dtype` in pinned host memory (cph_pinned_alloc): e.g. the code arrays of HostEncoder."""
+
+    def __init__(self, ctx: N.Context, nelem: int, dtype=np.uint32):
+        self.ctx = ctx
+        self.ptr = C.c_void_p()
+        nbytes = int(nelem) * np.dtype(dtype).itemsize
+        ctx._check(ctx.lib.cph_pinned_alloc(ctx.handle, nbytes + 64, C.byref(self.ptr)))
+        buf = (C.c_uint8 * nbytes).from_address(self.ptr.value)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(nelem))
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.cph_pinned_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+
+class HostEncoder:
+    """cph_host_encoder_*: the key codes of an index formed on the host by a pool of worker threads, so that a stream in host
+    memory ships 4 bytes per row and step (StreamJoin.submit_codes) instead of its key strings.  Raises CphError
+    (CPH_ERR_INVALID) for an index whose keys do not code in one word below 2^31."""
+
+    def __init__(self, index, nthreads: int = 0):
+        self.ctx = index.ctx
+        self.lib = index.ctx.lib
+        h = C.c_void_p()
+        self.ctx._check(self.lib.cph_host_encoder_create(index.handle, int(nthreads), C.byref(h)))
+        self.handle = h
+        self.threads = int(self.lib.cph_host_encoder_threads(h))
+
+    def run(self, cols, out: np.ndarray):
+        """cols: the index's key columns for the chunk (host StrCols); out: uint32[nrows] (a PinnedArray's .array for overlap)."""
+        arr = (N.cph_strcol * len(cols))()
+        keep = []
+        for i, c in enumerate(cols):
+            sc, k = c.as_c()
+            arr[i] = sc
+            keep.append(k)
+        assert out.dtype == np.uint32 and out.flags.c_contiguous and len(out) >= cols[0].nrows
+        self.ctx._check(self.lib.cph_host_encoder_run(self.handle, arr, len(cols), out.ctypes.data))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.cph_host_encoder_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class StreamJoin:
     def __init__(self, ctx: N.Context, indexes, nslots: int = 3, ncols=None, positions: bool = False):
         """ncols=None: the fused-kernel pipeline (cph_stream_join_create: distinct keys, one key column per index).
@@ -72,6 +125,13 @@ class StreamJoin:
             keep.append(k)
         self.ctx._check(self.lib.cph_stream_join_submit(self.handle, arr, probe_base))
         self._keep.append(keep)
+
+    def submit_codes(self, step_codes, nrows: int, probe_base: int = 0):
+        """step_codes: one uint32 array of host-formed key codes per step (HostEncoder.run; pinned for real overlap), valid
+        until the chunk was returned by next()."""
+        ptrs = (C.c_void_p * len(step_codes))(*[int(a.ctypes.data) for a in step_codes])
+        self.ctx._check(self.lib.cph_stream_join_submit_codes(self.handle, ptrs, int(nrows), int(probe_base)))
+        self._keep.append(list(step_codes))
 
     @property
     def pending(self) -> int:

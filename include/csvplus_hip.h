@@ -418,6 +418,30 @@ CPH_API void    cph_stream_join_destroy(cph_stream_join* sj);
  * for real overlap), borrowed until the chunk has been returned by cph_stream_join_next.
  * Fails with CPH_ERR_INVALID when all slots are in flight. */
 CPH_API int32_t cph_stream_join_submit(cph_stream_join* sj, const cph_strcol* step_cols, uint64_t probe_base);
+
+/*
+ * Key codes formed on the host (round 4): a stream in host memory then crosses PCIe as 4 bytes per row and step instead of
+ * its key strings (17 bytes per row for the benchmark's two keys).  A stream row's key takes part in a Join only through
+ * its code under the index's key codec, so for an index whose keys code in ONE word below 2^31 (cph_index_info:
+ * code_words == 1, code_bits <= 31, dict_entries == 0, split == 0 — decimal ids, short tags) the host can form the code
+ * with the table the device walks:
+ *   cph_host_encoder_create   an encoder for `index` with a pool of `nthreads` worker threads (0: one per hardware
+ *                             thread); CPH_ERR_INVALID when the index's codes do not qualify (ship the strings then)
+ *   cph_host_encoder_run      cols = ALL key columns of the index for the chunk's rows (host memory) -> out_codes[nrows];
+ *                             a key that cannot occur in the index gets CPH_CODE_ABSENT and joins nothing.  Blocks.
+ *   cph_stream_join_submit_codes   like cph_stream_join_submit with step_codes[k] = the chunk's codes for step k (host
+ *                             memory, pinned for real overlap; borrowed until the chunk was returned).  Fused-mode stream
+ *                             joins only (cph_stream_join_create), every index with a direct lookup structure (dense code
+ *                             space: cph_index_info.direct_table); results as for cph_stream_join_submit.
+ * An encoder may be used from one thread at a time; it does not touch the GPU.
+ */
+#define CPH_CODE_ABSENT 0xFFFFFFFFu
+typedef struct cph_host_encoder cph_host_encoder;
+CPH_API int32_t cph_host_encoder_create(const cph_index* index, int32_t nthreads, cph_host_encoder** out);
+CPH_API int32_t cph_host_encoder_threads(const cph_host_encoder* enc);
+CPH_API int32_t cph_host_encoder_run(cph_host_encoder* enc, const cph_strcol* cols, int32_t ncols, uint32_t* out_codes);
+CPH_API void    cph_host_encoder_destroy(cph_host_encoder* enc);
+CPH_API int32_t cph_stream_join_submit_codes(cph_stream_join* sj, const uint32_t* const* step_codes, uint64_t nrows, uint64_t probe_base);
 CPH_API int32_t cph_stream_join_pending(const cph_stream_join* sj);
 /* Waits for the OLDEST chunk in flight.  The arrays are pinned memory owned by the
  * pipeline.  Slots are used round robin — chunk number k (counting submissions from 0)

@@ -209,3 +209,96 @@ def test_stream_join_reports_positions(ctx, general):
             for k in range(2):
                 np.testing.assert_array_equal(perms[k][b["build_row"][k][hit]], a["build_row"][k][hit])
     assert sum(r["nmatches"] for r in out[True]) > 0
+
+
+def test_stream_join_general_positions_two_chunks_in_flight(ctx):
+    """General mode + positions with SEVERAL chunks in flight (round-3 advisor finding): the slot workers used to build the
+    rank table lazily and concurrently; since round 4 cph_stream_join_set_positions builds it up front and index_ensure_* is
+    locked per index.  Results against the row-id mode through perm."""
+    rng = np.random.default_rng(21)
+    cust = dg.customers(50_000)["id"]                                      # duplicate-free, dense: positions through the rank table
+    dup = StrCol.from_values([b"p%d" % int(x) for x in rng.integers(0, 300, 2000)])   # duplicates: makes the chain general
+    gix = [DeviceIndex(ctx, [cust], unique=True), DeviceIndex(ctx, [dup])]
+    o = dg.orders(400_000, 60_000, 10)
+    s1 = StrCol.from_values([b"p%d" % int(x) for x in rng.integers(0, 330, 400_000)])
+    bounds = [(b, min(b + 50_000, 400_000)) for b in range(0, 400_000, 50_000)]
+    out = {}
+    for pos in (False, True):
+        sj = StreamJoin(ctx, gix, nslots=4, positions=pos, ncols=[1, 1])
+        res, sub = [], 0
+        while len(res) < len(bounds):
+            while sub < len(bounds) and sj.pending < 4:                     # four chunks in flight: four workers at once
+                b, e = bounds[sub]
+                sj.submit([o["cust_id"].slice(b, e), s1.slice(b, e)], probe_base=b)
+                sub += 1
+            res.append(sj.next())
+        out[pos] = res
+        sj.close()
+    perms = [g.perm() for g in gix]
+    for a, b in zip(out[False], out[True]):
+        assert a["nmatches"] == b["nmatches"] > 0 and not a["dense"] and not b["dense"]
+        np.testing.assert_array_equal(a["stream_row"], b["stream_row"])
+        for k in range(2):
+            np.testing.assert_array_equal(perms[k][b["build_row"][k]], a["build_row"][k])
+
+
+@pytest.mark.parametrize("positions", [False, True])
+def test_stream_join_host_formed_codes(ctx, positions):
+    """cph_host_encoder_* + cph_stream_join_submit_codes: the chunks travel as 4-byte codes formed on the host; results equal
+    the string pipeline's, chunk by chunk, including keys with bytes outside the alphabets, too long / too short values."""
+    from csvplus_amd.streaming import HostEncoder, PinnedArray
+
+    rng = np.random.default_rng(31)
+    nc, npd = 30_000, 700
+    cust, prod = dg.customers(nc)["id"], dg.products(npd)["prod_id"]      # fixed-width 8-byte ids / unpadded decimal ids
+    gix = [DeviceIndex(ctx, [cust], unique=True), DeviceIndex(ctx, [prod], unique=True)]
+    encs = [HostEncoder(g, nthreads=t) for g, t in zip(gix, (3, 0))]
+    assert encs[0].threads == 3 and encs[1].threads >= 1
+    m = 300_000
+    o = dg.orders(m, 2 * nc, npd + 50)
+    cv, pv = o["cust_id"].values(), o["prod_id"].values()
+    for j in range(0, m, 97):
+        cv[j] = [b"0000A000", b"\x0012345\xff", b"00000/00", b"0000:000", b"99999999"][j % 5]
+    for j in range(0, m, 89):
+        pv[j] = [b"", b"7x", b"1234567", b"-1", b"00"][j % 5]
+    cols = [StrCol.from_values(cv), StrCol.from_values(pv)]
+    assert cols[0].fixed_width == 8
+    bounds = [(0, 100_000), (100_000, 100_001), (100_001, 223_456), (223_456, m)]
+    ref, got = [], []
+    sj = StreamJoin(ctx, gix, nslots=2, positions=positions)
+    for b, e in bounds:
+        sj.submit([c.slice(b, e) for c in cols], probe_base=b)
+        ref.append(sj.next())
+    pins = [[PinnedArray(ctx, e - b) for _ in range(2)] for b, e in bounds]
+    sub = 0
+    while len(got) < len(bounds):
+        while sub < len(bounds) and sj.pending < 2:
+            b, e = bounds[sub]
+            for k in range(2):
+                encs[k].run([cols[k].slice(b, e)], pins[sub][k].array)
+            sj.submit_codes([p.array for p in pins[sub]], e - b, probe_base=b)
+            sub += 1
+        got.append(sj.next())
+    sj.close()
+    total = 0
+    for a, b in zip(ref, got):
+        assert a["nmatches"] == b["nmatches"] and b["dense"]
+        np.testing.assert_array_equal(a["bitmap"], b["bitmap"])
+        hit = bitmap_to_rows(a["bitmap"], a["nrows"])
+        total += len(hit)
+        for k in range(2):
+            np.testing.assert_array_equal(a["build_row"][k][hit], b["build_row"][k][hit])
+    assert 0 < total < m
+    # the codes themselves: ABSENT exactly where the oracle finds nothing for that column alone
+    codes = np.zeros(m, np.uint32)
+    encs[0].run([cols[0]], codes)
+    oj = orc.OracleIndex([cust]).join([cols[0]])
+    assert ((codes == 0xFFFFFFFF) <= (oj["cnt"] == 0)).all()              # an ABSENT code never hides a match
+    for p in sum(pins, []):
+        p.free()
+    for e_ in encs:
+        e_.close()
+    # an index whose keys need a dictionary / several words is refused
+    long_ix = DeviceIndex(ctx, [StrCol.from_values([bytes(rng.integers(97, 123, 30).astype(np.uint8)) for _ in range(500)])])
+    with pytest.raises(N.CphError):
+        HostEncoder(long_ix)

@@ -6,7 +6,7 @@ delimiter-split candidate (random heads + delimiter + digits, a few values witho
 the split codec (keycodec.hip) is fuzzed with and without being taken; every seventh case has fixed-width 8-byte decimal
 keys (the lean steps of the fused chain: arithmetic encode, identity / rank-table lookups).
 usage: tools/fuzz_gpu.py [seconds] [seed]"""
-import sys, time
+import os, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import numpy as np
@@ -29,6 +29,10 @@ ALPHAS = [np.frombuffer(b"0123456789", np.uint8), np.frombuffer(b"abcxyz", np.ui
           np.frombuffer(b"\x00\xffA", np.uint8), np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789", np.uint8)]
 t_end = time.time() + budget
 cases = splits = leans = 0
+ONLY = int(os.environ.get("FUZZ_ONLY", "-1"))   # replay: generate every case of the seed, check only this one (and stop)
+FROM = int(os.environ.get("FUZZ_FROM", str(ONLY)))   # ... or the cases FROM..ONLY (state left behind by earlier builds)
+if os.environ.get("FUZZ_GUARD") == "1":
+    ctx.set_option("pool_guard", 1)
 while time.time() < t_end:
     n = int(rng.choice([1, 2, 63, 64, 65, 500, 4096, 8192, 8193, 16384, 16385, 20000])) if rng.random() < 0.5 else int(rng.integers(1, 20000))
     ncols = int(rng.integers(1, 4))
@@ -75,6 +79,10 @@ while time.time() < t_end:
         for j in rng.integers(0, m, m // 10):
             pv[int(j)] = pv[int(j)] + b"!" if rng.random() < 0.5 else pv[int(j)][:-1]
         probe.append(pv)
+    if ONLY >= 0 and not (FROM <= cases <= ONLY):
+        cases += 1
+        t_end = time.time() + budget
+        continue
     bcols = [StrCol.from_values(v) for v in build]
     pcols = [StrCol.from_values(v) for v in probe]
     o = orc.OracleIndex(bcols)
@@ -85,7 +93,15 @@ while time.time() < t_end:
         if limit == 0:
             splits += g.info()["split"] != 0
             leans += lean_case
-        assert np.array_equal(g.perm(), o.perm), tag
+        if not np.array_equal(g.perm(), o.perm):
+            gp, op = g.perm(), o.perm
+            i = int(np.argmax(gp != op))
+            print("PERM MISMATCH", tag, "first at sorted position", i, "info", g.info(), flush=True)
+            print("  rows out of range in the GPU perm:", int((gp >= n).sum()), "| positions that differ:", int((gp != op).sum()), flush=True)
+            for j in range(max(0, i - 2), min(n, i + 6)):
+                print("  pos", j, "gpu row", int(gp[j]), [build[c][int(gp[j])] for c in range(ncols)] if gp[j] < n else "OUT OF RANGE",
+                      "| oracle row", int(op[j]), [build[c][int(op[j])] for c in range(ncols)], flush=True)
+            raise AssertionError(tag)
         assert g.first_dup == o.first_dup(), tag
         for k in range(1, ncols + 1):
             oj = o.join(pcols[:k])
@@ -113,5 +129,9 @@ while time.time() < t_end:
             assert int(b_) - int(a_) == oh - ol and (oh == ol or int(a_) == ol), (tag, key)
         g.close()
     cases += 1
+    if ONLY >= 0 and cases > ONLY:
+        if os.environ.get("FUZZ_GUARD") == "1":
+            ctx.set_option("pool_guard_check", 0)
+        break
 ctx.set_option("small_build_rows", 8192)
 print("FUZZ_OK cases", cases, "seed", seed, "| tables coded with the delimiter split:", splits, "| fixed-width 8-byte key tables (lean chain steps):", leans, flush=True)

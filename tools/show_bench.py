@@ -29,7 +29,7 @@ for name in ("join_positions", "join_row_ids"):
 gc = r.get("gather_ceiling")
 if gc:
     print("gather ceiling %.3f ms (%s G lookups/s), kernel / ceiling %s, copy %s TB/s" % (gc["ms"], gc["Glookups_per_s"], gc.get("kernel_over_ceiling"), r.get("copy_TBps")))
-for k in ("e2e_pinned_host", "cpu_baseline"):
+for k in ("e2e_pinned_host", "e2e_pinned_host_encoded", "cpu_baseline"):
     if k in d:
         print(k, {a: b for a, b in d[k].items() if a not in ("scope", "sample", "variants", "extrapolated_full_size")})
 for k, v in ((d.get("cpu_baseline") or {}).get("variants") or {}).items():
