@@ -823,6 +823,7 @@ CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value
     else if (k == "chain_nt_streams") ctx->chain_nt_streams = value < 0 || value > 2 ? 0 : (int)value;
     else if (k == "chain_rank_lds") ctx->chain_rank_lds = value != 0;
     else if (k == "codec_split") ctx->codec_split = value != 0;
+    else if (k == "scan_lookback") ctx->scan_lookback = value != 0;
     else if (k == "chain_arith") ctx->chain_arith = value != 0;
     else if (k == "chain_identity") ctx->chain_identity = value != 0;
     else if (k == "probe_hash_rows") ctx->probe_hash_rows = value == 4 ? 4 : 2;

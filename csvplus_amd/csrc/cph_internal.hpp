@@ -317,6 +317,10 @@ struct cph_ctx {
     int join_hash = 1;             // 0: indexes of this ctx never get a hash table (A/B switch: sorted search instead)
     int codec_debug = 0;           // prints the window choice of codec_try_groups to stderr
     int codec_split = 1;           // the delimiter split of keycodec.hip is tried (A/B switch; 0: never)
+    int scan_lookback = 1;         // exclusive_scan_u32 as ONE launch (decoupled look-back, radix_sort.hip) instead of three (A/B switch)
+    cph::DevBuf scan_state;        // its state words (+ ticket counter), zeroed once; epochs / relative tickets make a scan memset-free
+    uint64_t scan_state_tiles = 0, scan_epoch = 0;
+    uint32_t scan_tickets = 0;
     int plan_threads = 0, gstats_threads = 0;   // tuning: workgroup sizes of k_encode_build_plan / k_group_stats (0: default)
     int speculative_groups = 1;    // dictionaries of large inputs from a sample, completed by the encode kernel (keycodec.hip):
                                    // 0 never, 1 when the sample holds no value seen only once, 2 always

@@ -323,6 +323,110 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(T* __restrict__ dat
     }
 }
 
+// ---- one-launch exclusive scan of uint32 (round 4): decoupled look-back ------------------------------------------------
+// The three-kernel scan above costs three launches per radix pass (15 of the ~50 launches of a benchmark step).  Here a
+// workgroup takes a TICKET (its tile number: tickets are handed out in start order, so every lower tile belongs to a
+// workgroup that is already running — no deadlock), scans its 4096 values, publishes its tile total and walks back over its
+// predecessors' state words until it meets an inclusive prefix.  State word = epoch << 34 | flag << 32 | value: the words
+// live in a per-ctx buffer that is zeroed ONCE; every scan call uses a new epoch (words of older epochs read as "not
+// published yet"), and tickets are relative to the counter value the host knows the call starts at — so a scan is exactly
+// one launch, no memset.  Values are sums of uint32 counts modulo 2^32 (the callers' contract: totals below 2^32, or
+// parity-only users).
+constexpr uint64_t kScanAggregate = 1ull << 32, kScanInclusive = 2ull << 32;
+__global__ __launch_bounds__(kScanThreads) void k_scan_lookback(uint32_t* __restrict__ data, uint64_t n, unsigned long long* __restrict__ state,
+                                                               uint32_t* __restrict__ ticket, uint32_t first_ticket, uint64_t epoch,
+                                                               uint32_t* __restrict__ total_out, uint32_t ntiles) {
+    __shared__ uint32_t s_tmp[kScanThreads / kWave + 1];
+    __shared__ uint32_t s_tile, s_prefix;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u) - first_ticket;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    constexpr int kVecs = kScanItems / 4;
+    const uint64_t base = (uint64_t)tile * kScanTile + (uint64_t)threadIdx.x * kScanItems;
+    const bool vec = (((uintptr_t)data & 15) == 0) && base + kScanItems <= n;
+    union {
+        uint32_t v[kScanItems];
+        u32x4 q[kVecs];
+    } u;
+    if (vec) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(data + base);
+#pragma unroll
+        for (int k = 0; k < kVecs; k++) u.q[k] = src[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < kScanItems; k++) u.v[k] = (base + k) < n ? data[base + k] : 0u;
+    }
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; k++) sum += u.v[k];
+    uint32_t total;
+    uint32_t run = block_exclusive_sum<uint32_t, kScanThreads>(sum, s_tmp, &total);
+    if (threadIdx.x == 0) {
+        const uint64_t tagged = epoch << 34;
+        uint32_t excl = 0;
+        if (tile == 0) {
+            __hip_atomic_store(&state[0], tagged | kScanInclusive | (uint64_t)total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_store(&state[tile], tagged | kScanAggregate | (uint64_t)total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            for (uint32_t j = tile; j-- > 0;) {
+                unsigned long long w;
+                do {
+                    w = __hip_atomic_load(&state[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                } while ((w >> 34) != epoch || (w & (kScanAggregate | kScanInclusive)) == 0);
+                excl += (uint32_t)w;
+                if (w & kScanInclusive) break;
+            }
+            __hip_atomic_store(&state[tile], tagged | kScanInclusive | (uint64_t)(uint32_t)(excl + total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_prefix = excl;
+        if (total_out && tile + 1 == ntiles) *total_out = excl + total;
+    }
+    __syncthreads();
+    run += s_prefix;
+#pragma unroll
+    for (int k = 0; k < kScanItems; k++) {
+        const uint32_t x = u.v[k];
+        u.v[k] = run;
+        run += x;
+    }
+    if (vec) {
+        u32x4* dst = reinterpret_cast<u32x4*>(data + base);
+#pragma unroll
+        for (int k = 0; k < kVecs; k++) dst[k] = u.q[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < kScanItems; k++)
+            if ((base + k) < n) data[base + k] = u.v[k];
+    }
+}
+
+static Status exclusive_scan_lookback(cph_ctx* ctx, uint32_t* data, uint64_t n, uint32_t* total_out, const char* name) {
+    const uint64_t nblk = (n + kScanTile - 1) / kScanTile;
+    if (nblk > ctx->scan_state_tiles) {   // state words + the ticket counter: zeroed once per (re)allocation
+        const uint64_t cap = nblk < 4096 ? 4096 : nblk * 2;
+        CPH_TRY(ctx->scan_state.alloc(&ctx->pool, (cap + 2) * sizeof(unsigned long long)));
+        CPH_HIP_TRY(hipMemsetAsync(ctx->scan_state.get(), 0, (cap + 2) * sizeof(unsigned long long), ctx->stream));
+        ctx->scan_state_tiles = cap;
+        ctx->scan_tickets = 0;
+        ctx->scan_epoch = 0;
+    }
+    ctx->scan_epoch++;
+    if (ctx->scan_epoch >= (1ull << 30)) {   // the epoch field is 30 bits: start over with zeroed words
+        CPH_HIP_TRY(hipMemsetAsync(ctx->scan_state.get(), 0, (ctx->scan_state_tiles + 2) * sizeof(unsigned long long), ctx->stream));
+        ctx->scan_tickets = 0;
+        ctx->scan_epoch = 1;
+    }
+    unsigned long long* state = ctx->scan_state.as<unsigned long long>();
+    uint32_t* ticket = reinterpret_cast<uint32_t*>(state + ctx->scan_state_tiles);
+    ProfScope ps(ctx, name, 2.0 * sizeof(uint32_t) * (double)n);
+    hipLaunchKernelGGL(k_scan_lookback, dim3((unsigned)nblk), dim3(kScanThreads), 0, ctx->stream, data, n, state, ticket, ctx->scan_tickets,
+                       ctx->scan_epoch, total_out, (uint32_t)nblk);
+    ctx->scan_tickets += (uint32_t)nblk;   // (wraps like the device counter)
+    CPH_HIP_TRY(hipGetLastError());
+    return {};
+}
+
 template <class T>
 static Status exclusive_scan_impl(cph_ctx* ctx, T* data, uint64_t n, T* total_out, const char* name) {
     if (n == 0) {
@@ -341,9 +445,11 @@ static Status exclusive_scan_impl(cph_ctx* ctx, T* data, uint64_t n, T* total_ou
 }
 
 Status exclusive_scan_u32(cph_ctx* ctx, uint32_t* data, uint64_t n) {
+    if (ctx->scan_lookback && n != 0 && n < (1ull << 40)) return exclusive_scan_lookback(ctx, data, n, nullptr, "exclusive_scan_u32");
     return exclusive_scan_impl<uint32_t>(ctx, data, n, nullptr, "exclusive_scan_u32");
 }
 Status exclusive_scan_u32_total(cph_ctx* ctx, uint32_t* data, uint64_t n, uint32_t* total_out) {
+    if (ctx->scan_lookback && n != 0 && n < (1ull << 40)) return exclusive_scan_lookback(ctx, data, n, total_out, "exclusive_scan_u32");
     return exclusive_scan_impl<uint32_t>(ctx, data, n, total_out, "exclusive_scan_u32");
 }
 // In-place exclusive scan of 64-bit counts; *total_out (device, optional) receives the sum.

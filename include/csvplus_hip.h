@@ -144,6 +144,8 @@ CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
  *   "codec_split"   0 / 1 (default 1): keys that do not code in 32 bits are tried with the delimiter split — the costliest
  *                   variable-length key column cut at its first delimiter byte into a dictionary-coded prefix and a
  *                   per-position suffix (floating fields like "Smith/Amelia#12345": 25 bits instead of 47; A/B switch)
+ *   "scan_lookback" 0 / 1 (default 1): the 32-bit exclusive scans (radix count matrices, compaction offsets) run as ONE launch
+ *                   (decoupled look-back) instead of three (A/B switch)
  *   "codec_debug"   1: the window choice of every index build (and the phase times of a one-launch build) go to stderr
  *   "small_build_rows"  tables of at most this many rows (default 8192, at most 16384) are indexed by ONE launch of one
  *                   workgroup and one synchronisation (small_build.hip); 0 = always the general path

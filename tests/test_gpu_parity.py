@@ -520,3 +520,22 @@ def test_build_many_mixes_one_launch_and_general_jobs(ctx):
         pr = [StrCol.from_values([c[0].value(i) for i in rng.integers(0, c[0].nrows, 300)] + [b"nope"])]
         assert_join_equal(r.probe(pr), o.join(pr))
         r.close()
+
+
+@pytest.mark.parametrize("n", [1, 4095, 4096, 4097, 70_001, 1_300_003])
+def test_scan_lookback_matches_three_kernel_scan(ctx, n):
+    """radix_sort.hip k_scan_lookback (one launch, epoch-tagged state words, relative tickets) against the three-kernel scan
+    it replaces: the same index, built with either, has the same order and first duplicate as the oracle's
+    (csvplus.go:794-807).  Several builds on ONE ctx exercise the epoch / ticket bookkeeping across calls and across a
+    growing state buffer."""
+    rng = np.random.default_rng(n)
+    keys = StrCol.from_values(random_keys(rng, n, 2, 6, alphabet=np.frombuffer(b"abcdefgh0123", np.uint8), distinct=min(n, 50_000)))
+    o = orc.OracleIndex([keys])
+    for mode in (1, 0, 1, 1):
+        ctx.set_option("scan_lookback", mode)
+        try:
+            g = DeviceIndex(ctx, [keys])
+            np.testing.assert_array_equal(g.perm(), o.perm)
+            assert g.first_dup == o.first_dup()
+        finally:
+            ctx.set_option("scan_lookback", 1)

@@ -262,7 +262,6 @@ def test_stream_join_host_formed_codes(ctx, positions):
     for j in range(0, m, 89):
         pv[j] = [b"", b"7x", b"1234567", b"-1", b"00"][j % 5]
     cols = [StrCol.from_values(cv), StrCol.from_values(pv)]
-    assert cols[0].fixed_width == 8
     bounds = [(0, 100_000), (100_000, 100_001), (100_001, 223_456), (223_456, m)]
     ref, got = [], []
     sj = StreamJoin(ctx, gix, nslots=2, positions=positions)
