@@ -52,7 +52,15 @@ def parse_args():
     ap.add_argument("--rows", type=int, default=100_000_000, help="orders (probe) rows, whole job")
     ap.add_argument("--customers", type=int, default=10_000_000)
     ap.add_argument("--products", type=int, default=100_000)
-    ap.add_argument("--exchange", choices=["allgatherv", "none"], default="allgatherv")
+    ap.add_argument("--exchange", choices=["allgatherv", "host", "oneshot", "none"], default="allgatherv",
+                    help="N > 1: allgatherv = cph_dist_join_chain (sub-chunks of a shard leave over xGMI while the next one is joined; "
+                         "every rank ends with the whole list in HBM); host = the same pipeline, each rank copying its chunks into ITS range "
+                         "of one pinned host buffer shared by the ranks (no xGMI traffic, N PCIe links in parallel, SURVEY 8e); oneshot = join "
+                         "the shard, then cph_dist_chain_allgather (rounds 1-3); none = every rank keeps its shard's list")
+    ap.add_argument("--chunks", type=int, default=0, help="sub-chunks per shard for --exchange allgatherv / host (0: the library picks, 1..8)")
+    ap.add_argument("--ctx-option", action="append", default=[], metavar="KEY=INT",
+                    help="cph_ctx_set_option on the bench's ctx before anything runs (A/B switches: scan_lookback=0, chain_arith=0 ...)")
+    ap.add_argument("--no-n1", action="store_true", help="N > 1: skip rank 0's one-GPU run of the whole stream behind efficiency_vs_n1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-index-1e8", action="store_true", help="skip the extra IndexOn-at-full-size measurements")
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
@@ -217,12 +225,22 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     eng = Engine(local_rank)
+    for kv in args.ctx_option:      # A/B switches of the library (cph_ctx_set_option), e.g. scan_lookback=0
+        k, _, v = kv.partition("=")
+        eng.ctx.set_option(k, int(v))
     # the exchange runs behind the C ABI (cph_dist_*: RCCL); torch.distributed only ships the communicator id (and
     # provides the barrier / max-over-ranks of the timing contract).  If the communicator cannot be created on ANY rank
     # the whole job stops with a non-zero exit code: a scaling curve is a measurement of cph_dist_* or it is nothing.
     # Debug mode with several ranks on one GPU (CPH_BENCH_SHARE_GPU=1, gloo): the torch transport of csvplus_amd/dist.py.
     cdist, transport, rccl_nranks = None, "none", None
-    if world > 1 and args.exchange == "allgatherv":
+    # CPH_BENCH_FORCE_DIST=1: take the N > 1 code path (communicator, cph_dist_join_chain, the multi_gpu report) with ONE rank
+    # — what a one-GPU box can execute of it (tests/test_bench_launch.py)
+    force_dist = world == 1 and os.environ.get("CPH_BENCH_FORCE_DIST") == "1" and args.exchange != "none"
+    if force_dist:
+        cdist = connect(eng.ctx)
+        rccl_nranks = cdist.size
+        transport = "cph_dist_* (RCCL behind the C ABI): " + cdist.transport()
+    if world > 1 and args.exchange != "none":
         if share_gpu:
             transport = "torch.distributed gloo (DEBUG: ranks share one GPU; not an RCCL measurement)"
         else:
@@ -259,6 +277,8 @@ def main():
 
     POS = not args.row_ids          # the timed step's output mode: sorted positions (default) or original row ids
     step_info = {}
+    shard_rows = [shard_range(args.rows, r, world)[1] - shard_range(args.rows, r, world)[0] for r in range(world)]
+    xstats = []                     # cph_dist_join_stats of every step (N > 1)
 
     def step():
         # both build sides as one batch (cph_index_build_many): their host round trips are shared
@@ -266,13 +286,26 @@ def main():
         # the chained join straight through the binding (cph_join_chain, results left in HBM): the timed loop holds
         # no torch views of the result — it needs the row count only.  stream_row is NULL when every order joined
         # (the result row IS the stream row): then only the two build-row arrays exist, and only they are exchanged.
+        if cdist is not None and args.exchange in ("allgatherv", "host"):
+            # the shard in sub-chunks, chunk k travelling while chunk k+1 is joined (cph_dist_join_chain); the shard sizes of a
+            # range split are known to everybody, so the call's only host wait is for the match totals at its end
+            g = cdist.join_chain([(ia, [d_ord["cust_id"]]), (ib, [d_ord["prod_id"]])], probe_base=begin, shard_rows=shard_rows,
+                                 nchunks=args.chunks, positions=POS, host=args.exchange == "host")
+            n = g.total
+            xstats.append(g.stats)
+            g.release()
+            if not step_info:
+                step_info["info"] = (ia.info(), ib.info())
+            ia.close()
+            ib.close()
+            return n, step_info["info"]
         ch = N.join_chain(eng.ctx, [(ia, [d_ord["cust_id"]]), (ib, [d_ord["prod_id"]])], probe_base=begin,
                           out_mem=N.CPH_MEM_DEVICE, positions=POS)
         if cdist is not None:          # one count exchange + one grouped batch for all arrays (cph_dist_chain_allgather)
             g = cdist.chain_allgather(ch)
             n = g.total
             g.release()
-        elif world > 1 and args.exchange == "allgatherv":
+        elif world > 1 and args.exchange != "none":
             from csvplus_amd.engine import device_view
             p = ch.device_ptrs()
             ts = [device_view(q, ch.nrows, "<i4", ch, dev) for q in p["build_row"]]
@@ -305,6 +338,7 @@ def main():
     dom_name = max(pick.items(), key=lambda kv: kv[1]["total_ms"])[0] if pick else "k_chain_dense"
     eng.ctx.profile_only(dom_name)
     sync_all()
+    del xstats[:]
     t0 = time.perf_counter()
     joined = 0
     for _ in range(args.steps):
@@ -312,6 +346,7 @@ def main():
         joined = n
     sync_all()
     dt = time.perf_counter() - t0
+    xtimed = list(xstats)
     prof_timed = eng.ctx.profile_read(reset=True)
     breakdown_steps = 3
     eng.ctx.profile(True)
@@ -326,7 +361,7 @@ def main():
         dist.all_gather_into_tensor(allt, torch.tensor([dt], dtype=torch.float64, device=cdev))
         per_rank_ms = [float(x) / args.steps * 1e3 for x in allt.tolist()]
         dt = float(allt.max().item())          # the job is as slow as its slowest rank
-    total_joined = joined if (world == 1 or args.exchange == "allgatherv") else None
+    total_joined = joined if (world == 1 or args.exchange != "none") else None
     if total_joined is None:
         t = torch.tensor([joined], dtype=torch.int64, device="cpu" if share_gpu else dev)
         dist.all_reduce(t)
@@ -346,6 +381,46 @@ def main():
     ia_info, ib_info = info
     K = breakdown_steps   # the `kernels` table comes from the fully profiled steps behind the timed region
     total_joined_local = joined if world == 1 or args.exchange == "none" else nloc
+    # ---- N > 1: where the step went (rank 0's view), and what one GPU needs for the WHOLE stream ----------------
+    multi = None
+    if world > 1 or force_dist:
+        from csvplus_amd.dist import build_side_estimate
+
+        def mean(key):
+            return round(sum(x[key] for x in xtimed) / len(xtimed), 4) if xtimed else None
+
+        exposed = mean("exposed_exchange_ms")
+        multi = {"mode": args.exchange, "chunks": xtimed[0]["chunks"] if xtimed else None,
+                 "join_compute_ms": mean("compute_ms"), "exchange_ms": mean("exchange_ms"), "exposed_exchange_ms": exposed,
+                 "bytes_sent_per_step": xtimed[0]["bytes_sent"] if xtimed else None,
+                 "bytes_received_per_step": xtimed[0]["bytes_received"] if xtimed else None,
+                 "note": "events on the ctx stream (join of all chunks) and on the exchange stream (first chunk ready -> match totals of "
+                         "all ranks received); exposed = the part of the exchange behind the last chunk's join, which nothing hides"}
+        n1_ms = None
+        if not args.no_n1 and not share_gpu:
+            # strong scaling's reference point, measured here: rank 0 alone runs the step over ALL rows (no exchange)
+            full = dg.orders(args.rows, args.customers, args.products)
+            d_full = {k: full[k].to_device(dev) for k in ("cust_id", "prod_id")}
+
+            def step1():
+                a, b = eng.index_on_many([[d_cust], [d_prod]], unique=True)
+                c = N.join_chain(eng.ctx, [(a, [d_full["cust_id"]]), (b, [d_full["prod_id"]])], out_mem=N.CPH_MEM_DEVICE, positions=POS)
+                c.release(); a.close(); b.close()
+
+            step1()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                step1()
+            torch.cuda.synchronize(dev)
+            n1_ms = (time.perf_counter() - t1) / 3 * 1e3
+            del d_full, full
+        multi["n1_ms_per_step"] = round(n1_ms, 4) if n1_ms else None
+        multi["efficiency_vs_n1"] = round(n1_ms / (world * dt / args.steps * 1e3), 4) if n1_ms else None
+        code_bytes = 4
+        multi["build_side"] = dict(build_side_estimate(args.customers, code_bytes, world, 3.0e10),
+                                   note="customers table: every rank builds (A) vs rank 0 builds + cph_dist_index_broadcast (B), "
+                                        "critical path per rank; 3e10 rows/s build rate and 50 GB/s per xGMI link assumed")
     off_c, off_p = cust_id.nbytes_offsets(), prod_id.nbytes_offsets()   # 0 for fixed-width columns
     off_o = ords["cust_id"].nbytes_offsets() + ords["prod_id"].nbytes_offsets()
     cust_bytes, prod_bytes = cust_id.nbytes_values(), prod_id.nbytes_values()
@@ -473,13 +548,17 @@ def main():
         "config": {"workload": "orders(1e8 x {cust_id,prod_id,qty}) JOIN customers(1e7, UniqueIndexOn id) "
                                "JOIN products(1e5, UniqueIndexOn prod_id); BASELINE configs[3] shape, probe rows sharded over n_gpus",
                    "rows": args.rows, "customers": args.customers, "products": args.products,
-                   "rows_this_rank": nloc, "exchange": args.exchange if world > 1 else "none (1 GPU)",
+                   "rows_this_rank": nloc, "exchange": args.exchange if (world > 1 or force_dist) else "none (1 GPU)",
                    "exchange_transport": transport, "rccl_nranks": rccl_nranks,
                    "inputs": "resident in HBM before the timed region",
                    "build_row_mode": ("sorted positions in each index (cph_join_chain_ex CPH_CHAIN_POSITIONS; the reference's row handle: "
                                       "csvplus.go:553-567 reads index.impl.rows[first()+i])" if POS else "original row ids (--row-ids)")},
         "joined_rows_per_step": total_joined,
         "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
+        "exchange_ms": multi["exchange_ms"] if multi else None,
+        "compute_ms": (round(ms_per_step - (multi["exposed_exchange_ms"] or 0.0), 4) if multi else round(ms_per_step, 4)),
+        "efficiency_vs_n1": multi["efficiency_vs_n1"] if multi else None,
+        "multi_gpu": multi,
         "index_build": {"GBps_algorithmic": round(build_gb / (build_ms / 1e3), 1) if build_ms else None,
                         "kernel_ms_per_step": round(build_ms / K, 4),
                         "customers": ia_info, "products": ib_info},

@@ -117,6 +117,7 @@ class cph_chain(C.Structure):
 
 
 CPH_CHAIN_POSITIONS = 1
+CPH_DIST_HOST_GATHER = 0x100
 
 
 class cph_colbuf(C.Structure):
@@ -156,7 +157,13 @@ CPH_MAX_GATHER = 8
 class cph_gathered(C.Structure):
     _fields_ = [("total", C.c_uint64), ("narrays", C.c_int32), ("nranks", C.c_int32),
                 ("counts", C.POINTER(C.c_uint64)), ("displs", C.POINTER(C.c_uint64)),
-                ("data", C.c_void_p * CPH_MAX_GATHER)]
+                ("data", C.c_void_p * CPH_MAX_GATHER), ("mem", C.c_int32), ("reserved_", C.c_int32)]
+
+
+class cph_dist_join_stats(C.Structure):
+    _fields_ = [("chunks", C.c_int32), ("pipelined", C.c_int32), ("compute_ms", C.c_double), ("exchange_ms", C.c_double),
+                ("exposed_exchange_ms", C.c_double), ("total_ms", C.c_double), ("bytes_sent", C.c_uint64),
+                ("bytes_received", C.c_uint64)]
 
 
 class cph_stream_chunk(C.Structure):
@@ -203,6 +210,9 @@ PROTOTYPES = [
     ("cph_gathered_release", None, [C.POINTER(cph_gathered)]),
     ("cph_dist_chain_allgather", C.c_int32,
      [_P, C.POINTER(cph_chain), C.c_uint64, C.POINTER(C.POINTER(cph_gathered)), C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
+    ("cph_dist_join_chain", C.c_int32,
+     [_P, C.POINTER(cph_chain_step), C.c_int32, C.c_uint64, C.POINTER(C.c_uint64), C.c_int32, C.c_uint32,
+      C.POINTER(C.POINTER(cph_gathered)), C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.POINTER(cph_dist_join_stats)]),
     ("cph_dist_index_broadcast", C.c_int32, [_P, _P, C.c_int32, C.POINTER(_P)]),
     ("cph_index_nrows", C.c_uint64, [_P]),
     ("cph_index_nkeycols", C.c_int32, [_P]),
@@ -653,6 +663,8 @@ class Gathered:
         self.counts = [int(g.counts[r]) for r in range(int(g.nranks))]
         self.displs = [int(g.displs[r]) for r in range(int(g.nranks))]
         self.data_ptrs = [int(g.data[a] or 0) for a in range(self.narrays)]
+        self.mem = int(g.mem)
+        self.stats = None
         self.identity = identity
         self.stream_base = stream_base
         ctx._children.add(self)
@@ -719,6 +731,30 @@ class Dist:
         self.ctx._check(self.lib.cph_dist_chain_allgather(self.handle, chain.ptr, chain.probe_base, C.byref(out),
                                                           C.byref(ident), C.byref(base)))
         return Gathered(self.ctx, out, identity=bool(ident.value), stream_base=int(base.value))
+
+    def join_chain(self, steps, probe_base: int = 0, shard_rows=None, nchunks: int = 0, positions: bool = False,
+                   host: bool = False) -> Gathered:
+        """cph_dist_join_chain: this rank's shard joined in sub-chunks, chunk k exchanged (xGMI; host=True: copied into the
+        node's shared host buffer) while chunk k+1 is joined.  steps = [(DeviceIndex, [shard key columns]), ...]."""
+        arr = (cph_chain_step * len(steps))()
+        keep = []
+        for i, (index, cols) in enumerate(steps):
+            carr, k = _cols_array(cols)
+            keep.append((carr, k, index))
+            arr[i].index = index.handle
+            arr[i].cols = carr
+            arr[i].ncols = len(cols)
+        sr = (C.c_uint64 * self.size)(*shard_rows) if shard_rows is not None else None
+        flags = (CPH_CHAIN_POSITIONS if positions else 0) | (CPH_DIST_HOST_GATHER if host else 0)
+        out = C.POINTER(cph_gathered)()
+        ident, base, st = C.c_int32(0), C.c_uint64(0), cph_dist_join_stats()
+        rc = self.lib.cph_dist_join_chain(self.handle, arr, len(steps), probe_base, sr, nchunks, flags, C.byref(out), C.byref(ident),
+                                          C.byref(base), C.byref(st))
+        del keep
+        self.ctx._check(rc)
+        g = Gathered(self.ctx, out, identity=bool(ident.value), stream_base=int(base.value))
+        g.stats = {f: getattr(st, f) for f, _ in cph_dist_join_stats._fields_}
+        return g
 
     def index_broadcast(self, index, root: int = 0):
         """Root passes its DeviceIndex and gets it back; the other ranks pass None and receive an equal index."""

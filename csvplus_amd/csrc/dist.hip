@@ -18,16 +18,23 @@
 // multi-rank control flow (counts, displacements, unequal and empty shards, the identity rule) runs on a
 // one-GPU box.  Everything is enqueued on the ctx's stream; the only host wait is for the 3*N count words.
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <link.h>
 #include <rccl/rccl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
+#include <cerrno>
 #include <condition_variable>
+#include <cstring>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <new>
 
 #include "cph_internal.hpp"
+#include "device_utils.hpp"
 
 using namespace cph;
 
@@ -195,8 +202,8 @@ struct RcclTransport : Transport {
     };
     Status exchange_v(const void* const* send, void* const* recv, const int32_t* eb, int narrays, const uint64_t* counts,
                       const uint64_t* displs, hipStream_t stream) override {
-        bool equal = true;
-        for (int r = 1; r < size_; r++) equal = equal && counts[r] == counts[0];
+        bool equal = true;   // ... AND laid out as ncclAllGather lays them out (a sub-chunk of a shard is not: displs say where)
+        for (int r = 0; r < size_; r++) equal = equal && counts[r] == counts[0] && displs[r] == (uint64_t)r * counts[0];
         Group grp(api);
         CPH_NCCL_TRY(api, grp.start());
         for (int a = 0; a < narrays; a++) {
@@ -214,9 +221,11 @@ struct RcclTransport : Transport {
         }
         CPH_NCCL_TRY(api, grp.end());
         if (!equal && counts[rank_])
-            for (int a = 0; a < narrays; a++)
-                CPH_HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(recv[a]) + displs[rank_] * (size_t)eb[a], send[a],
-                                           counts[rank_] * (size_t)eb[a], hipMemcpyDeviceToDevice, stream));
+            for (int a = 0; a < narrays; a++) {
+                uint8_t* own = static_cast<uint8_t*>(recv[a]) + displs[rank_] * (size_t)eb[a];
+                if (own != send[a])   // (a rank that produced its rows in place has nothing to copy)
+                    CPH_HIP_TRY(hipMemcpyAsync(own, send[a], counts[rank_] * (size_t)eb[a], hipMemcpyDeviceToDevice, stream));
+            }
         return {};
     }
     Status broadcast(void* buf, size_t bytes, int root, hipStream_t stream) override {
@@ -303,6 +312,7 @@ struct LoopTransport : Transport {
                 for (int dst = 0; dst < h.nranks; dst++)
                     for (int src = 0; src < h.nranks; src++)
                         if (counts[src] &&
+                            static_cast<uint8_t*>(h.posts[dst].vrecv[a]) + displs[src] * (size_t)eb[a] != h.posts[src].vsend[a] &&
                             hipMemcpyAsync(static_cast<uint8_t*>(h.posts[dst].vrecv[a]) + displs[src] * (size_t)eb[a], h.posts[src].vsend[a],
                                            counts[src] * (size_t)eb[a], hipMemcpyDeviceToDevice, h.stream) != hipSuccess)
                             return false;
@@ -333,10 +343,39 @@ __global__ void k_iota_u64(uint64_t* __restrict__ dst, uint64_t n, uint64_t base
 
 }  // namespace
 
+// One POSIX shared-memory segment per cph_dist, mapped by every rank and registered with HIP: the landing zone of the
+// host-gather exchange (cph_dist_join_chain with CPH_DIST_HOST_GATHER).  Grows, never shrinks; rank 0 creates a
+// generation, the others open it, rank 0 unlinks the name once everybody has it mapped.
+struct HostShare {
+    void* base = nullptr;
+    size_t bytes = 0;
+    bool registered = false;
+    uint64_t generation = 0;
+    void release() {
+        if (base) {
+            if (registered) (void)hipHostUnregister(base);
+            (void)munmap(base, bytes);
+        }
+        base = nullptr;
+        bytes = 0;
+        registered = false;
+    }
+    ~HostShare() { release(); }
+};
+
 struct cph_dist {
     cph_ctx* ctx = nullptr;
     std::unique_ptr<Transport> t;
     std::string desc;
+    std::string share_key;              // the same on every rank of the communicator, different between communicators
+    hipStream_t xstream = nullptr;      // the exchange stream of cph_dist_join_chain (created on first use)
+    std::vector<hipEvent_t> events;     // chunk events + 4 timing events, reused between calls
+    HostShare share;
+    uint64_t share_calls = 0;           // host-gather calls so far: results alternate between the two halves of the segment
+    ~cph_dist() {
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+        if (xstream) (void)hipStreamDestroy(xstream);
+    }
 };
 
 struct cph_gathered_impl {
@@ -439,6 +478,11 @@ CPH_API int32_t cph_dist_create(cph_ctx* ctx, const uint8_t* id, int32_t rank, i
     if (!d) return fail_with(ctx, {CPH_ERR_NOMEM, "out of host memory"});
     d->ctx = ctx;
     d->t = std::move(t);
+    uint64_t h = 0xcbf29ce484222325ull;   // FNV-1a of the communicator id: every rank derives the same segment name
+    for (size_t i = 0; i < sizeof uid; i++) h = (h ^ id[i]) * 0x100000001b3ull;
+    char key[40];
+    snprintf(key, sizeof key, "%016llx", (unsigned long long)h);
+    d->share_key = key;
     *out = d;
     return CPH_OK;
 }
@@ -469,6 +513,8 @@ CPH_API int32_t cph_dist_create_loopback(cph_ctx* ctx, const char* group, int32_
     t->rank_ = rank;
     d->ctx = ctx;
     d->t = std::move(t);
+    d->share_key = "loop_" + std::to_string((long long)getpid()) + "_";
+    for (const char* c = group; *c; c++) d->share_key += (isalnum((unsigned char)*c) ? *c : '_');
     *out = d;
     return CPH_OK;
 }
@@ -501,6 +547,7 @@ CPH_API int32_t cph_dist_allgatherv(cph_dist* d, const void* const* send, const 
     auto* g = new (std::nothrow) cph_gathered_impl();
     if (!g) return fail_with(ctx, {CPH_ERR_NOMEM, "out of host memory"});
     memset(&g->pub, 0, sizeof g->pub);
+    g->pub.mem = CPH_MEM_DEVICE;
     auto run = [&]() -> Status {
         std::vector<uint64_t> w;
         CPH_TRY(exchange_counts(d, count, 0, 0, &w));
@@ -525,6 +572,53 @@ CPH_API void cph_gathered_release(cph_gathered* pub) {
     delete g;
 }
 
+// The exchange of one rank's COMPACT result (nrows tuples; stream_row NULL = the identity over [probe_base, +nrows)).
+static Status chain_allgather_impl(cph_dist* d, uint64_t cnt, const uint64_t* stream_row, const uint32_t* const* build_row, int nsteps,
+                                   uint64_t probe_base, cph_gathered_impl* g, int32_t* identity, uint64_t* stream_base) {
+    cph_ctx* ctx = d->ctx;
+    const int n = d->t->size();
+    const bool my_identity = stream_row == nullptr;   // also true for an empty result
+    std::vector<uint64_t> w;
+    CPH_TRY(exchange_counts(d, cnt, my_identity ? 1 : 0, probe_base, &w));
+    std::vector<uint64_t> counts((size_t)n);
+    // the gathered list is the identity over [base0, base0 + total) iff every rank's is over its own range and
+    // the ranges follow each other (ranks without rows do not matter)
+    bool all_identity = true;
+    uint64_t next = 0, base0 = 0;
+    bool have = false;
+    for (int r = 0; r < n; r++) {
+        counts[(size_t)r] = w[3 * (size_t)r];
+        if (!counts[(size_t)r]) continue;
+        all_identity = all_identity && w[3 * (size_t)r + 1] != 0 && (!have || w[3 * (size_t)r + 2] == next);
+        if (!have) base0 = w[3 * (size_t)r + 2];
+        have = true;
+        next = w[3 * (size_t)r + 2] + counts[(size_t)r];
+    }
+    const void* send[CPH_MAX_GATHER];
+    int32_t eb[CPH_MAX_GATHER];
+    int na = 0;
+    DevBuf iota;
+    if (!all_identity) {
+        const uint64_t* sr = stream_row;
+        if (my_identity && cnt) {   // some other rank lost rows: this rank's implicit stream rows become explicit
+            CPH_TRY(iota.alloc(&ctx->pool, cnt * sizeof(uint64_t)));
+            hipLaunchKernelGGL(k_iota_u64, dim3(grid_for_items(cnt)), dim3(256), 0, ctx->stream, iota.as<uint64_t>(), cnt, probe_base);
+            CPH_HIP_TRY(hipGetLastError());
+            sr = iota.as<uint64_t>();
+        }
+        send[na] = sr;
+        eb[na++] = 8;
+    }
+    for (int k = 0; k < nsteps; k++) {
+        send[na] = build_row[k];
+        eb[na++] = 4;
+    }
+    CPH_TRY(gather_arrays(d, send, eb, na, counts, g));
+    if (identity) *identity = all_identity ? 1 : 0;
+    if (stream_base) *stream_base = all_identity ? base0 : 0;
+    return {};
+}
+
 CPH_API int32_t cph_dist_chain_allgather(cph_dist* d, const cph_chain* chain, uint64_t probe_base, cph_gathered** out,
                                          int32_t* identity, uint64_t* stream_base) {
     if (!d || !chain || !out) return CPH_ERR_INVALID;
@@ -536,53 +630,519 @@ CPH_API int32_t cph_dist_chain_allgather(cph_dist* d, const cph_chain* chain, ui
     auto* g = new (std::nothrow) cph_gathered_impl();
     if (!g) return fail_with(ctx, {CPH_ERR_NOMEM, "out of host memory"});
     memset(&g->pub, 0, sizeof g->pub);
-    auto run = [&]() -> Status {
-        const int n = d->t->size();
-        const uint64_t cnt = chain->nrows;
-        const bool my_identity = chain->stream_row == nullptr;   // also true for an empty result
-        std::vector<uint64_t> w;
-        CPH_TRY(exchange_counts(d, cnt, my_identity ? 1 : 0, probe_base, &w));
-        std::vector<uint64_t> counts((size_t)n);
-        // the gathered list is the identity over [base0, base0 + total) iff every rank's is over its own range and
-        // the ranges follow each other (ranks without rows do not matter)
-        bool all_identity = true;
-        uint64_t next = 0, base0 = 0;
-        bool have = false;
-        for (int r = 0; r < n; r++) {
-            counts[(size_t)r] = w[3 * (size_t)r];
-            if (!counts[(size_t)r]) continue;
-            all_identity = all_identity && w[3 * (size_t)r + 1] != 0 && (!have || w[3 * (size_t)r + 2] == next);
-            if (!have) base0 = w[3 * (size_t)r + 2];
-            have = true;
-            next = w[3 * (size_t)r + 2] + counts[(size_t)r];
+    g->pub.mem = CPH_MEM_DEVICE;
+    Status s = chain_allgather_impl(d, chain->nrows, chain->stream_row, chain->build_row, chain->nsteps, probe_base, g, identity, stream_base);
+    if (!s.ok()) {
+        (void)hipStreamSynchronize(ctx->stream);
+        delete g;
+        return fail_with(ctx, s);
+    }
+    *out = &g->pub;
+    return CPH_OK;
+}
+
+// ---- cph_dist_join_chain: the sharded chained Join, its exchange pipelined behind the compute ---------------------------
+//
+// cph_dist_chain_allgather moves a FINISHED shard result: join, wait, exchange — nothing overlaps, and one count exchange
+// sits in the middle.  Here the shard is cut into sub-chunks; chunk k's rows leave for the peers (or for the host) on the
+// exchange stream while chunk k+1 is in k_chain_dense on the ctx's stream.  What makes that possible without a count
+// exchange per chunk: a chain of duplicate-free single-column indexes (chain_fast_path_ok — the benchmark's, and the one
+// csvplus.go:553-567 runs per row) produces at most one tuple per stream row, so the DENSE form — slot == stream row,
+// build_row[0][slot] == kAbsentRow where the row did not join — has a size every rank knows in advance.  Chunks travel
+// dense, straight into their final place in the gathered arrays (rank r's slots begin at displs[r]); the match totals are
+// exchanged ONCE at the end (the call's only host wait), and only if some row of some rank did not join are the gathered
+// slots compacted (locally, one pass) into the (stream_row, build_row...) list.  Any other chain takes the one-shot path.
+namespace {
+
+constexpr int kPipeMaxRanks = 64;
+constexpr int kPipeMaxChunks = 64;
+constexpr int kSlotRows = 8;   // slots per lane of the compaction: a wave owns 512 consecutive slots
+constexpr uint64_t kSlotWave = (uint64_t)kSlotRows * kWave;
+constexpr uint32_t kAbsentRow = 0xFFFFFFFFu;   // never a row id or position: an index has at most 2^32-1 rows
+
+struct RowPtrs {
+    uint32_t* p[CPH_MAX_CHAIN];
+};
+
+// bit r%64 of masks[r/64] == "slot r joined" (chain.hip's dense bitmap): the slots that did not get the sentinel
+__global__ __launch_bounds__(256) void k_mark_absent(uint32_t* __restrict__ rows0, const uint64_t* __restrict__ masks, uint64_t n,
+                                                    const uint64_t* __restrict__ total) {
+    if (*total == n) return;   // every row of the chunk joined (the common case): nothing to mark
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        if (!((masks[i >> 6] >> (i & 63)) & 1ull)) rows0[i] = kAbsentRow;
+}
+
+__global__ void k_sum_totals(const uint64_t* __restrict__ totals, int n, uint64_t* __restrict__ out) {
+    uint64_t t = 0;
+    for (int i = 0; i < n; i++) t += totals[i];
+    out[0] = t;
+}
+
+__global__ __launch_bounds__(256) void k_slots_count(const uint32_t* __restrict__ rows0, uint64_t n, uint32_t* __restrict__ wave_counts,
+                                                    uint64_t nwaves) {
+    const int lane = lane_id();
+    for (uint64_t w = (uint64_t)blockIdx.x * 4 + wave_id(); w < nwaves; w += (uint64_t)gridDim.x * 4) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int k = 0; k < kSlotRows; k++) {
+            const uint64_t slot = w * kSlotWave + (uint64_t)k * kWave + lane;
+            c += (uint32_t)__popcll(__ballot(slot < n && rows0[slot] != kAbsentRow));
         }
-        const void* send[CPH_MAX_GATHER];
-        int32_t eb[CPH_MAX_GATHER];
-        int na = 0;
-        DevBuf iota;
-        if (!all_identity) {
-            const uint64_t* sr = chain->stream_row;
-            if (my_identity && cnt) {   // some other rank lost rows: this rank's implicit stream rows become explicit
-                CPH_TRY(iota.alloc(&ctx->pool, cnt * sizeof(uint64_t)));
-                hipLaunchKernelGGL(k_iota_u64, dim3(grid_for_items(cnt)), dim3(256), 0, ctx->stream, iota.as<uint64_t>(), cnt, probe_base);
-                CPH_HIP_TRY(hipGetLastError());
-                sr = iota.as<uint64_t>();
+        if (lane == 0) wave_counts[w] = c;
+    }
+}
+
+// Slots -> tuples.  rank r's slots are [displs[r], displs[r+1]) and slot displs[r] + i is stream row base[r] + i.
+__global__ __launch_bounds__(256) void k_slots_compact(RowPtrs in, int nsteps, uint64_t n, const uint32_t* __restrict__ wave_base, uint64_t nwaves,
+                                                      int nranks, const uint64_t* __restrict__ displs, const uint64_t* __restrict__ base,
+                                                      uint64_t* __restrict__ out_stream, RowPtrs out) {
+    const int lane = lane_id();
+    const uint64_t lt = lanemask_lt();
+    for (uint64_t w = (uint64_t)blockIdx.x * 4 + wave_id(); w < nwaves; w += (uint64_t)gridDim.x * 4) {
+        uint64_t pos = wave_base[w];
+        int r0 = 0;
+        while (r0 + 1 < nranks && w * kSlotWave >= displs[r0 + 1]) r0++;
+#pragma unroll
+        for (int k = 0; k < kSlotRows; k++) {
+            const uint64_t slot = w * kSlotWave + (uint64_t)k * kWave + lane;
+            const bool ok = slot < n && in.p[0][slot] != kAbsentRow;
+            const uint64_t bal = __ballot(ok);
+            if (ok) {
+                int r = r0;
+                while (r + 1 < nranks && slot >= displs[r + 1]) r++;
+                const uint64_t p = pos + (uint64_t)__popcll(bal & lt);
+                out_stream[p] = base[r] + (slot - displs[r]);
+                for (int s = 0; s < nsteps; s++) out.p[s][p] = in.p[s][slot];
             }
-            send[na] = sr;
-            eb[na++] = 8;
+            pos += (uint64_t)__popcll(bal);
         }
-        for (int k = 0; k < chain->nsteps; k++) {
-            send[na] = chain->build_row[k];
-            eb[na++] = 4;
+    }
+}
+
+// Dense slots (device) -> compact tuples (device): out_stream / out_rows get `total` entries (the caller knows the total).
+static Status compact_slots(cph_ctx* ctx, uint32_t* const* rows, int nsteps, uint64_t nslots, int nranks, const uint64_t* displs,
+                            const uint64_t* base, uint64_t* out_stream, uint32_t* const* out_rows) {
+    if (!nslots) return {};
+    const uint64_t nwaves = (nslots + kSlotWave - 1) / kSlotWave;
+    DevBuf wave_counts, map;
+    CPH_TRY(wave_counts.alloc(&ctx->pool, nwaves * sizeof(uint32_t)));
+    CPH_TRY(map.alloc(&ctx->pool, (2 * (size_t)nranks + 1) * sizeof(uint64_t)));
+    void* up = nullptr;
+    CPH_TRY(pinned_upload(ctx, (2 * (size_t)nranks + 1) * sizeof(uint64_t), &up));
+    uint64_t* u = static_cast<uint64_t*>(up);
+    for (int r = 0; r <= nranks; r++) u[r] = displs[r];
+    for (int r = 0; r < nranks; r++) u[nranks + 1 + r] = base[r];
+    CPH_HIP_TRY(hipMemcpyAsync(map.get(), up, (2 * (size_t)nranks + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    RowPtrs in{}, out{};
+    for (int s = 0; s < nsteps; s++) {
+        in.p[s] = rows[s];
+        out.p[s] = out_rows[s];
+    }
+    const unsigned grid = (unsigned)std::min<uint64_t>((nwaves + 3) / 4, 16384);
+    {
+        ProfScope ps(ctx, "k_slots_count", 4.0 * (double)nslots);
+        hipLaunchKernelGGL(k_slots_count, dim3(grid), dim3(256), 0, ctx->stream, rows[0], nslots, wave_counts.as<uint32_t>(), nwaves);
+    }
+    CPH_HIP_TRY(hipGetLastError());
+    CPH_TRY(exclusive_scan_u32(ctx, wave_counts.as<uint32_t>(), nwaves));
+    {
+        ProfScope ps(ctx, "k_slots_compact", (double)nslots * (4.0 + (8.0 + 8.0 * nsteps)));
+        hipLaunchKernelGGL(k_slots_compact, dim3(grid), dim3(256), 0, ctx->stream, in, nsteps, nslots, wave_counts.as<uint32_t>(), nwaves, nranks,
+                           map.as<uint64_t>(), map.as<uint64_t>() + nranks + 1, out_stream, out);
+    }
+    CPH_HIP_TRY(hipGetLastError());
+    return {};
+}
+
+// (Re)creates the shared landing zone with room for two results of `result_bytes`.  COLLECTIVE: every rank calls it with
+// the same size (they all hold a segment of the same size, so they all take the same branch).  Two halves, used in turn: a
+// rank that is already in call k+1 writes into the other half than the one a slower rank still reads call k's result from —
+// and nobody reaches call k+2 before everybody has entered call k+1 (its closing count exchange is a barrier).
+static Status ensure_share(cph_dist* d, size_t result_bytes) {
+    const size_t need = 2 * ((result_bytes + 4095) & ~(size_t)4095);
+    if (need <= d->share.bytes) return {};
+    cph_ctx* ctx = d->ctx;
+    d->share.release();
+    d->share.generation++;
+    const std::string name = "/cph_" + d->share_key + "_" + std::to_string((unsigned long long)d->share.generation);
+    const size_t two_mb = (size_t)2 << 20;
+    const size_t bytes = ((need + need / 4 + two_mb - 1) / two_mb) * two_mb;
+    const bool root = d->t->rank() == 0;
+    int fd = -1;
+    std::string err;
+    if (root) {
+        (void)shm_unlink(name.c_str());
+        fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0) err = "shm_open(" + name + "): " + strerror(errno);
+        else if (int e = posix_fallocate(fd, 0, (off_t)bytes)) err = "the shared host buffer of the host-gather exchange does not fit /dev/shm (" + std::to_string(bytes >> 20) + " MiB): " + strerror(e);
+    }
+    std::vector<uint64_t> w;
+    Status st = exchange_counts(d, err.empty() ? 1 : 0, 0, 0, &w);   // barrier 1: the segment exists (or rank 0 says it does not)
+    if (st.ok() && w[0] == 0 && !root) err = "rank 0 could not create the shared host buffer";
+    if (st.ok() && err.empty() && !root) {
+        fd = shm_open(name.c_str(), O_RDWR, 0600);
+        if (fd < 0) err = "shm_open(" + name + "): " + strerror(errno);
+    }
+    void* base = MAP_FAILED;
+    if (st.ok() && err.empty()) {
+        base = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        if (base == MAP_FAILED) err = std::string("mmap of the shared host buffer: ") + strerror(errno);
+    }
+    if (fd >= 0) (void)close(fd);
+    if (base != MAP_FAILED) {
+        d->share.base = base;
+        d->share.bytes = bytes;
+        if (hipHostRegister(base, bytes, hipHostRegisterPortable) == hipSuccess) d->share.registered = true;
+        else {
+            (void)hipGetLastError();
+            err = "hipHostRegister of the shared host buffer failed";
         }
-        CPH_TRY(gather_arrays(d, send, eb, na, counts, g));
-        if (identity) *identity = all_identity ? 1 : 0;
-        if (stream_base) *stream_base = all_identity ? base0 : 0;
+    }
+    std::vector<uint64_t> w2;
+    Status st2 = exchange_counts(d, err.empty() ? 1 : 0, 0, 0, &w2);   // barrier 2: everybody has it mapped
+    if (root) (void)shm_unlink(name.c_str());                          // the mappings keep it alive; nothing is left behind
+    if (!st.ok()) return st;
+    if (!st2.ok()) return st2;
+    bool all = err.empty();
+    for (int r = 0; r < d->t->size(); r++) all = all && w2[3 * (size_t)r] != 0;
+    if (!all) {
+        d->share.release();
+        return {CPH_ERR_NOMEM, err.empty() ? std::string("another rank could not map the shared host buffer") : err};
+    }
+    (void)ctx;
+    return {};
+}
+
+static uint8_t* share_half(cph_dist* d) { return static_cast<uint8_t*>(d->share.base) + (d->share_calls++ & 1) * (d->share.bytes / 2); }
+
+struct ShareLayout {   // stream rows first (room for the compact form), then one row array per step; `cap` entries each
+    uint8_t* base;
+    uint64_t cap;
+    uint64_t* stream() const { return reinterpret_cast<uint64_t*>(base); }
+    uint32_t* rows(int a) const { return reinterpret_cast<uint32_t*>(base + 8 * cap + (size_t)a * 4 * cap); }
+    static size_t bytes(uint64_t cap, int nsteps) { return (size_t)cap * (8 + 4 * (size_t)nsteps); }
+};
+
+static void fill_gathered(cph_gathered_impl* g, cph_ctx* ctx, int mem, const std::vector<uint64_t>& counts, int narrays) {
+    g->ctx = ctx;
+    g->counts = counts;
+    g->displs.assign(counts.size(), 0);
+    uint64_t total = 0;
+    for (size_t r = 0; r < counts.size(); r++) {
+        g->displs[r] = total;
+        total += counts[r];
+    }
+    g->pub.total = total;
+    g->pub.narrays = narrays;
+    g->pub.nranks = (int32_t)counts.size();
+    g->pub.counts = g->counts.data();
+    g->pub.displs = g->displs.data();
+    g->pub.mem = mem;
+}
+
+// This rank's COMPACT tuples (device) -> their place in the shared host buffer; `with_stream`: stream rows travel too.
+// Collective (ends with a barrier: when it returns, every rank's part is in the buffer).
+static Status host_place_compact(cph_dist* d, const std::vector<uint64_t>& totals, const ShareLayout& lay, int nsteps, bool with_stream,
+                                 const uint64_t* stream_row, const uint32_t* const* rows, hipStream_t stream) {
+    const int me = d->t->rank();
+    uint64_t off = 0;
+    for (int r = 0; r < me; r++) off += totals[(size_t)r];
+    const uint64_t cnt = totals[(size_t)me];
+    if (cnt) {
+        if (with_stream) CPH_HIP_TRY(hipMemcpyAsync(lay.stream() + off, stream_row, cnt * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+        for (int a = 0; a < nsteps; a++)
+            CPH_HIP_TRY(hipMemcpyAsync(lay.rows(a) + off, rows[a], cnt * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    }
+    CPH_HIP_TRY(hipStreamSynchronize(stream));
+    std::vector<uint64_t> w;
+    return exchange_counts(d, 1, 0, 0, &w);
+}
+
+static bool ranges_follow(const std::vector<uint64_t>& rows, const std::vector<uint64_t>& base, uint64_t* base0) {
+    bool have = false, ok = true;
+    uint64_t next = 0;
+    *base0 = 0;
+    for (size_t r = 0; r < rows.size(); r++) {
+        if (!rows[r]) continue;
+        ok = ok && (!have || base[r] == next);
+        if (!have) *base0 = base[r];
+        have = true;
+        next = base[r] + rows[r];
+    }
+    return ok;
+}
+
+static DevCol slice_rows(DevCol c, uint64_t begin, uint64_t n) {
+    if (c.fixed_width) c.data += begin * c.fixed_width;
+    else c.offsets = static_cast<const uint8_t*>(c.offsets) + begin * (size_t)(c.offset_bits / 8);
+    c.nrows = n;
+    return c;
+}
+
+}  // namespace
+
+CPH_API int32_t cph_dist_join_chain(cph_dist* d, const cph_chain_step* steps, int32_t nsteps, uint64_t probe_base, const uint64_t* shard_rows,
+                                    int32_t nchunks, uint32_t flags, cph_gathered** out, int32_t* identity, uint64_t* stream_base,
+                                    cph_dist_join_stats* stats) {
+    if (!d || !out) return CPH_ERR_INVALID;
+    *out = nullptr;
+    cph_ctx* ctx = d->ctx;
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail_with(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});
+    if (!steps || nsteps < 1 || nsteps > CPH_MAX_CHAIN || nsteps + 1 > CPH_MAX_GATHER) return fail_with(ctx, {CPH_ERR_INVALID, "bad chain"});
+    if (flags & ~(uint32_t)(CPH_CHAIN_POSITIONS | CPH_DIST_HOST_GATHER)) return fail_with(ctx, {CPH_ERR_INVALID, "unknown cph_dist_join_chain flag"});
+    if (nchunks < 0 || nchunks > kPipeMaxChunks) return fail_with(ctx, {CPH_ERR_INVALID, "nchunks must be 0 (automatic) .. 64"});
+    const bool positions = (flags & CPH_CHAIN_POSITIONS) != 0, to_host = (flags & CPH_DIST_HOST_GATHER) != 0;
+    for (int k = 0; k < nsteps; k++) {
+        if (!steps[k].index) return fail_with(ctx, {CPH_ERR_INVALID, "chain step without index"});
+        if (steps[k].ncols > steps[k].index->nkeycols) return fail_with(ctx, {CPH_ERR_TOO_MANY_COLS, "too many source columns in Join()"});
+        Status v = validate_cols(steps[k].cols, steps[k].ncols);
+        if (!v.ok()) return fail_with(ctx, v);
+        if (steps[k].cols[0].nrows != steps[0].cols[0].nrows) return fail_with(ctx, {CPH_ERR_INVALID, "chain steps must use columns of one stream table"});
+    }
+    auto* g = new (std::nothrow) cph_gathered_impl();
+    if (!g) return fail_with(ctx, {CPH_ERR_NOMEM, "out of host memory"});
+    memset(&g->pub, 0, sizeof g->pub);
+    cph_dist_join_stats st{};
+    auto run = [&]() -> Status {
+        const int n = d->t->size(), me = d->t->rank();
+        const uint64_t nloc = steps[0].cols[0].nrows;
+        std::vector<DevBuf> staged;
+        ChainStep cs[CPH_MAX_CHAIN];
+        size_t lds = 0;
+        for (int k = 0; k < nsteps; k++) {
+            cs[k].index = steps[k].index;
+            cs[k].ncols = steps[k].ncols;
+            CPH_TRY(stage_cols(ctx, steps[k].cols, steps[k].ncols, &staged, cs[k].cols));
+            lds += steps[k].index->codec_dev.bytes();
+        }
+        // who has how many stream rows, and where they begin
+        std::vector<uint64_t> rows((size_t)n), base((size_t)n), displs((size_t)n + 1, 0);
+        if (shard_rows) {   // the caller's promise: consecutive ranges in rank order
+            if (shard_rows[me] != nloc) return {CPH_ERR_INVALID, "shard_rows[rank] is not this rank's row count"};
+            uint64_t before = 0;
+            for (int r = 0; r < me; r++) before += shard_rows[r];
+            if (probe_base < before) return {CPH_ERR_INVALID, "probe_base is smaller than the rows of the ranks before this one"};
+            uint64_t b = probe_base - before;
+            for (int r = 0; r < n; r++) {
+                rows[(size_t)r] = shard_rows[r];
+                base[(size_t)r] = b;
+                b += shard_rows[r];
+            }
+        } else {
+            std::vector<uint64_t> w;
+            CPH_TRY(exchange_counts(d, nloc, 0, probe_base, &w));
+            for (int r = 0; r < n; r++) {
+                rows[(size_t)r] = w[3 * (size_t)r];
+                base[(size_t)r] = w[3 * (size_t)r + 2];
+            }
+        }
+        uint64_t T = 0, maxrows = 0;
+        for (int r = 0; r < n; r++) {
+            displs[(size_t)r] = T;
+            T += rows[(size_t)r];
+            maxrows = std::max(maxrows, rows[(size_t)r]);
+        }
+        displs[(size_t)n] = T;
+        uint64_t base0 = 0;
+        const bool follow = ranges_follow(rows, base, &base0);
+        const bool dense_ok = T > 0 && T < (1ull << 32) && n <= kPipeMaxRanks && chain_fast_path_ok(cs, nsteps) && lds <= 150 * 1024;
+
+        if (!dense_ok) {
+            // ---- one shot: join the shard, then exchange the finished (compact) result --------------------------------
+            ChainOut co;
+            CPH_TRY(chain_run(ctx, cs, nsteps, probe_base, &co, positions));
+            const uint32_t* brow[CPH_MAX_CHAIN] = {nullptr};
+            for (int k = 0; k < nsteps; k++) brow[k] = co.nrows ? co.build_row[k].as<uint32_t>() : nullptr;
+            const uint64_t* srow = (co.nrows && !co.identity) ? co.stream_row.as<uint64_t>() : nullptr;
+            st.chunks = 0;
+            if (!to_host) return chain_allgather_impl(d, co.nrows, srow, brow, nsteps, probe_base, g, identity, stream_base);
+            std::vector<uint64_t> w;
+            CPH_TRY(exchange_counts(d, co.nrows, srow ? 0 : 1, probe_base, &w));
+            std::vector<uint64_t> totals((size_t)n), bases((size_t)n);
+            bool all_id = true;
+            uint64_t total = 0;
+            for (int r = 0; r < n; r++) {
+                totals[(size_t)r] = w[3 * (size_t)r];
+                bases[(size_t)r] = w[3 * (size_t)r + 2];
+                all_id = all_id && (totals[(size_t)r] == 0 || w[3 * (size_t)r + 1] != 0);
+                total += totals[(size_t)r];
+            }
+            uint64_t b0 = 0;
+            all_id = ranges_follow(totals, bases, &b0) && all_id;
+            CPH_TRY(ensure_share(d, ShareLayout::bytes(total, nsteps)));
+            const ShareLayout lay{share_half(d), total};
+            DevBuf iota;
+            if (!all_id && !srow && co.nrows) {
+                CPH_TRY(iota.alloc(&ctx->pool, co.nrows * sizeof(uint64_t)));
+                hipLaunchKernelGGL(k_iota_u64, dim3(grid_for_items(co.nrows)), dim3(256), 0, ctx->stream, iota.as<uint64_t>(), co.nrows, probe_base);
+                CPH_HIP_TRY(hipGetLastError());
+                srow = iota.as<uint64_t>();
+            }
+            CPH_TRY(host_place_compact(d, totals, lay, nsteps, !all_id, srow, brow, ctx->stream));
+            fill_gathered(g, ctx, CPH_MEM_HOST, totals, all_id ? nsteps : nsteps + 1);
+            int a = 0;
+            if (!all_id) g->pub.data[a++] = total ? lay.stream() : nullptr;
+            for (int k = 0; k < nsteps; k++) g->pub.data[a++] = total ? lay.rows(k) : nullptr;
+            if (identity) *identity = all_id ? 1 : 0;
+            if (stream_base) *stream_base = all_id ? b0 : 0;
+            return {};
+        }
+
+        // ---- pipelined: dense chunks, exchange behind the compute ------------------------------------------------------
+        int C = nchunks > 0 ? nchunks : (int)std::min<uint64_t>(8, std::max<uint64_t>(1, maxrows >> 20));
+        st.chunks = C;
+        st.pipelined = C > 1;
+        if (!d->xstream) CPH_HIP_TRY(hipStreamCreateWithFlags(&d->xstream, hipStreamNonBlocking));
+        while ((int)d->events.size() < kPipeMaxChunks + 4) {
+            hipEvent_t e;
+            CPH_HIP_TRY(hipEventCreate(&e));
+            d->events.push_back(e);
+        }
+        hipEvent_t* ev = d->events.data();
+        hipEvent_t ev_c0 = ev[kPipeMaxChunks], ev_c1 = ev[kPipeMaxChunks + 1], ev_x0 = ev[kPipeMaxChunks + 2], ev_x1 = ev[kPipeMaxChunks + 3];
+        ShareLayout lay{nullptr, T};
+        DevBuf local[CPH_MAX_CHAIN];
+        uint32_t* mine[CPH_MAX_CHAIN] = {nullptr};   // this rank's slots: inside the gathered arrays, or its own buffers
+        if (to_host) {
+            CPH_TRY(ensure_share(d, ShareLayout::bytes(T, nsteps)));
+            lay.base = share_half(d);
+            for (int a = 0; a < nsteps; a++) {
+                CPH_TRY(local[a].alloc(&ctx->pool, nloc * sizeof(uint32_t)));
+                mine[a] = local[a].as<uint32_t>();
+            }
+        } else {
+            for (int a = 0; a < nsteps; a++) {
+                CPH_TRY(g->data[a].alloc(&ctx->pool, T * sizeof(uint32_t)));
+                mine[a] = g->data[a].as<uint32_t>() + displs[(size_t)me];
+            }
+        }
+        DevBuf totals_dev, words;
+        CPH_TRY(totals_dev.alloc(&ctx->pool, (size_t)C * sizeof(uint64_t)));
+        CPH_TRY(words.alloc(&ctx->pool, ((size_t)n + 1) * sizeof(uint64_t)));
+        CPH_HIP_TRY(hipMemsetAsync(totals_dev.get(), 0, (size_t)C * sizeof(uint64_t), ctx->stream));
+        CPH_HIP_TRY(hipEventRecord(ev_c0, ctx->stream));
+        int32_t eb[CPH_MAX_CHAIN];
+        for (int a = 0; a < nsteps; a++) eb[a] = 4;
+        std::vector<uint64_t> ccounts((size_t)n), cdispls((size_t)n);
+        for (int c = 0; c < C; c++) {
+            const uint64_t cb = nloc / (uint64_t)C * (uint64_t)c + std::min<uint64_t>((uint64_t)c, nloc % (uint64_t)C);
+            const uint64_t ncur = nloc / (uint64_t)C + ((uint64_t)c < nloc % (uint64_t)C ? 1 : 0);
+            if (ncur) {
+                ChainStep sub[CPH_MAX_CHAIN];
+                uint32_t* rp[CPH_MAX_CHAIN] = {nullptr};
+                for (int k = 0; k < nsteps; k++) {
+                    sub[k] = cs[k];
+                    for (int j = 0; j < cs[k].ncols; j++) sub[k].cols[j] = slice_rows(cs[k].cols[j], cb, ncur);
+                    rp[k] = mine[k] + cb;
+                }
+                DevBuf masks, counts;
+                CPH_TRY(masks.alloc(&ctx->pool, chain_dense_mask_words(ncur) * sizeof(uint64_t)));
+                CPH_TRY(counts.alloc(&ctx->pool, chain_dense_count_words(ncur) * sizeof(uint32_t)));
+                CPH_TRY(chain_enqueue_dense(ctx, sub, nsteps, ncur, probe_base + cb, rp, masks.as<uint64_t>(), counts.as<uint32_t>(),
+                                            totals_dev.as<uint64_t>() + c, positions));
+                hipLaunchKernelGGL(k_mark_absent, dim3(grid_for_items(ncur, 2048)), dim3(256), 0, ctx->stream, rp[0], masks.as<uint64_t>(), ncur,
+                                   totals_dev.as<uint64_t>() + c);
+                CPH_HIP_TRY(hipGetLastError());
+            }
+            CPH_HIP_TRY(hipEventRecord(ev[c], ctx->stream));
+            CPH_HIP_TRY(hipStreamWaitEvent(d->xstream, ev[c], 0));
+            if (c == 0) CPH_HIP_TRY(hipEventRecord(ev_x0, d->xstream));
+            if (to_host) {
+                for (int a = 0; a < nsteps && ncur; a++)
+                    CPH_HIP_TRY(hipMemcpyAsync(lay.rows(a) + displs[(size_t)me] + cb, mine[a] + cb, ncur * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                               d->xstream));
+                st.bytes_sent += ncur * 4 * (uint64_t)nsteps;
+            } else if (n > 1) {
+                // every rank cuts every shard the same way, so chunk c of rank r is [rows[r]*c/C ...) for everybody
+                bool any = false;
+                for (int r = 0; r < n; r++) {
+                    const uint64_t q = rows[(size_t)r] / (uint64_t)C, m = rows[(size_t)r] % (uint64_t)C;
+                    ccounts[(size_t)r] = q + ((uint64_t)c < m ? 1 : 0);
+                    cdispls[(size_t)r] = displs[(size_t)r] + q * (uint64_t)c + std::min<uint64_t>((uint64_t)c, m);
+                    any = any || ccounts[(size_t)r] != 0;
+                    if (r != me) st.bytes_received += ccounts[(size_t)r] * 4 * (uint64_t)nsteps;
+                }
+                st.bytes_sent += ncur * 4 * (uint64_t)nsteps * (uint64_t)(n - 1);
+                if (any) {
+                    const void* send[CPH_MAX_CHAIN];
+                    void* recv[CPH_MAX_CHAIN];
+                    for (int a = 0; a < nsteps; a++) {
+                        send[a] = mine[a] + cb;
+                        recv[a] = g->data[a].get();
+                    }
+                    CPH_TRY(d->t->exchange_v(send, recv, eb, nsteps, ccounts.data(), cdispls.data(), d->xstream));
+                }
+            }
+        }
+        // the match totals: summed on the device, exchanged once, read once — the only host wait of the call
+        hipLaunchKernelGGL(k_sum_totals, dim3(1), dim3(1), 0, ctx->stream, totals_dev.as<uint64_t>(), C, words.as<uint64_t>());
+        CPH_HIP_TRY(hipGetLastError());
+        CPH_HIP_TRY(hipEventRecord(ev_c1, ctx->stream));
+        CPH_HIP_TRY(hipStreamWaitEvent(d->xstream, ev_c1, 0));
+        CPH_TRY(d->t->allgather(words.get(), words.as<uint64_t>() + 1, sizeof(uint64_t), d->xstream));
+        CPH_TRY(ensure_pinned_scratch(ctx, sizeof(uint64_t) * (size_t)n));
+        CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, words.as<uint64_t>() + 1, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost, d->xstream));
+        CPH_HIP_TRY(hipEventRecord(ev_x1, d->xstream));
+        CPH_HIP_TRY(hipStreamSynchronize(d->xstream));
+        std::vector<uint64_t> totals(static_cast<uint64_t*>(ctx->pinned_scratch), static_cast<uint64_t*>(ctx->pinned_scratch) + n);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev_c0, ev_c1) == hipSuccess) st.compute_ms = ms;
+        if (hipEventElapsedTime(&ms, ev_x0, ev_x1) == hipSuccess) st.exchange_ms = ms;
+        if (hipEventElapsedTime(&ms, ev_c0, ev_x1) == hipSuccess) st.total_ms = ms;
+        if (hipEventElapsedTime(&ms, ev_c1, ev_x1) == hipSuccess) st.exposed_exchange_ms = ms;
+        (void)hipGetLastError();
+        uint64_t joined = 0;
+        for (int r = 0; r < n; r++) {
+            if (totals[(size_t)r] > rows[(size_t)r]) return {CPH_ERR_HIP, "a rank reports more joined rows than it has stream rows"};
+            joined += totals[(size_t)r];
+        }
+        const bool all_id = joined == T && follow;
+        if (identity) *identity = all_id ? 1 : 0;
+        if (stream_base) *stream_base = all_id ? base0 : 0;
+        if (all_id) {   // the slots ARE the result
+            fill_gathered(g, ctx, to_host ? CPH_MEM_HOST : CPH_MEM_DEVICE, rows, nsteps);
+            for (int a = 0; a < nsteps; a++) g->pub.data[a] = to_host ? static_cast<void*>(lay.rows(a)) : g->data[a].get();
+            return {};
+        }
+        // some stream row did not join (or the ranges do not follow each other): slots -> tuples
+        if (to_host) {   // each rank compacts its own slots and places the tuples where the totals say
+            const uint64_t cnt = totals[(size_t)me];
+            DevBuf cstream, crows[CPH_MAX_CHAIN];
+            uint32_t* cr[CPH_MAX_CHAIN] = {nullptr};
+            CPH_TRY(cstream.alloc(&ctx->pool, cnt * sizeof(uint64_t)));
+            for (int a = 0; a < nsteps; a++) {
+                CPH_TRY(crows[a].alloc(&ctx->pool, cnt * sizeof(uint32_t)));
+                cr[a] = crows[a].as<uint32_t>();
+            }
+            const uint64_t one_displs[2] = {0, nloc}, one_base[1] = {probe_base};
+            CPH_TRY(compact_slots(ctx, mine, nsteps, nloc, 1, one_displs, one_base, cstream.as<uint64_t>(), cr));
+            CPH_TRY(host_place_compact(d, totals, lay, nsteps, true, cstream.as<uint64_t>(), cr, ctx->stream));
+            fill_gathered(g, ctx, CPH_MEM_HOST, totals, nsteps + 1);
+            g->pub.data[0] = joined ? lay.stream() : nullptr;
+            for (int a = 0; a < nsteps; a++) g->pub.data[a + 1] = joined ? lay.rows(a) : nullptr;
+            return {};
+        }
+        DevBuf fin_stream, fin_rows[CPH_MAX_CHAIN];
+        uint32_t *in_rows[CPH_MAX_CHAIN] = {nullptr}, *out_rows[CPH_MAX_CHAIN] = {nullptr};
+        CPH_TRY(fin_stream.alloc(&ctx->pool, joined * sizeof(uint64_t)));
+        for (int a = 0; a < nsteps; a++) {
+            CPH_TRY(fin_rows[a].alloc(&ctx->pool, joined * sizeof(uint32_t)));
+            in_rows[a] = g->data[a].as<uint32_t>();
+            out_rows[a] = fin_rows[a].as<uint32_t>();
+        }
+        CPH_TRY(compact_slots(ctx, in_rows, nsteps, T, n, displs.data(), base.data(), fin_stream.as<uint64_t>(), out_rows));
+        for (int a = nsteps; a >= 1; a--) g->data[a] = std::move(fin_rows[a - 1]);
+        g->data[0] = std::move(fin_stream);
+        fill_gathered(g, ctx, CPH_MEM_DEVICE, totals, nsteps + 1);
+        for (int a = 0; a <= nsteps; a++) g->pub.data[a] = joined ? g->data[a].get() : nullptr;
         return {};
     };
     Status s = run();
+    if (stats) *stats = st;
     if (!s.ok()) {
         (void)hipStreamSynchronize(ctx->stream);
+        if (d->xstream) (void)hipStreamSynchronize(d->xstream);
         delete g;
         return fail_with(ctx, s);
     }

@@ -9,6 +9,13 @@ grouped send/recv batch for all arrays of a result).  This module is the thin ho
                           torch.distributed group the launcher set up, then cph_dist_create
   chain_allgather(...)    ChainResult of this rank -> ChainResult of the whole stream (torch views of the
                           library's gathered device arrays)
+  N.Dist.join_chain(...)  cph_dist_join_chain: the shard joined in sub-chunks, chunk k on the wire (or on its way to the
+                          node's shared host buffer) while chunk k+1 is joined — what `bench.py --gpus N` times
+  build_side_estimate()   replicated builds vs. one build + cph_dist_index_broadcast, in milliseconds (printed by bench.py)
+
+`pipelined_dense_exchange` is the control flow of cph_dist_join_chain written against torch.distributed (same chunk cut,
+same displacements, dense slots with the ABSENT sentinel, ONE exchange of totals at the end, local compaction): the
+transport of the CPU tests (gloo).
 
 `allgatherv_many` is the same exchange written against torch.distributed (count all_gather + one
 batch_isend_irecv for all tensors).  It is the transport of the CPU tests (gloo) and of the debug mode in
@@ -131,3 +138,79 @@ def sharded_chained_join(total_stream_rows: int, local_join, group=None, exchang
         return s, a, b, [int(s.numel())]
     (gs, ga, gb), counts = allgatherv_many([s, a, b], group)
     return gs, ga, gb, counts
+
+
+# ---- the pipelined exchange of cph_dist_join_chain over torch.distributed (gloo on CPU) ---------------------------
+ABSENT = -1   # 0xFFFFFFFF as int32: "this stream row did not join" in the dense form
+
+
+def chunk_range(n: int, c: int, nchunks: int):
+    """Rows [begin, end) of chunk c when n rows are cut into nchunks (csrc/dist.hip cuts every shard the same way)."""
+    q, m = divmod(n, nchunks)
+    b = q * c + min(c, m)
+    return b, b + q + (1 if c < m else 0)
+
+
+def pipelined_dense_exchange(shard_rows, dense_chunk, nsteps: int, nchunks: int, group=None):
+    """shard_rows: the row counts of ALL ranks' shards (consecutive ranges in rank order).  dense_chunk(begin, end) -> nsteps
+    int32 tensors of end - begin slots for THIS rank's shard rows [begin, end): slot i holds the build row of stream row i,
+    ABSENT in array 0 where the row did not join.  Chunk c's sends are posted before chunk c + 1 is computed and awaited only
+    at the end.  Returns (stream_row or None when every row of every rank joined, [build rows...], per-rank totals)."""
+    import torch
+    import torch.distributed as dist
+
+    on = dist.is_initialized()
+    world = dist.get_world_size(group) if on else 1
+    rank = dist.get_rank(group) if on else 0
+    rows = [int(x) for x in shard_rows]
+    displs = [0]
+    for x in rows:
+        displs.append(displs[-1] + x)
+    total = displs[-1]
+    slots = [torch.empty(total, dtype=torch.int32) for _ in range(nsteps)]
+    pending = []
+    joined = 0
+    for c in range(nchunks):
+        b, e = chunk_range(rows[rank], c, nchunks)
+        if e > b:
+            part = dense_chunk(b, e)
+            joined += int((part[0] != ABSENT).sum())
+            for a in range(nsteps):
+                slots[a][displs[rank] + b:displs[rank] + e].copy_(part[a])
+        if world == 1:
+            continue
+        ops = []
+        for a in range(nsteps):      # same order on every rank: array-major, then peer
+            for peer in range(world):
+                if peer == rank:
+                    continue
+                gpeer = dist.get_global_rank(group, peer) if group is not None else peer
+                if e > b:
+                    ops.append(dist.P2POp(dist.isend, slots[a][displs[rank] + b:displs[rank] + e], gpeer, group=group))
+                pb, pe = chunk_range(rows[peer], c, nchunks)
+                if pe > pb:
+                    ops.append(dist.P2POp(dist.irecv, slots[a][displs[peer] + pb:displs[peer] + pe], gpeer, group=group))
+        if ops:
+            pending.extend(dist.batch_isend_irecv(ops))      # posted; chunk c + 1 is computed while they move
+    for req in pending:
+        req.wait()
+    totals = [joined]
+    if world > 1:
+        t = torch.zeros(world, dtype=torch.int64)
+        dist.all_gather_into_tensor(t, torch.tensor([joined], dtype=torch.int64), group=group)   # the one count exchange
+        totals = [int(x) for x in t.tolist()]
+    if sum(totals) == total:
+        return None, slots, totals
+    keep = slots[0] != ABSENT
+    return torch.nonzero(keep).flatten(), [x[keep] for x in slots], totals
+
+
+def build_side_estimate(build_rows: int, code_bytes: int, n_ranks: int, build_rows_per_s: float, link_gb_per_s: float = 50.0):
+    """SURVEY.md §8e options for the build side, in milliseconds on the critical path of one rank:
+    A `replicated`  every rank sorts the same table:            build_rows / build_rows_per_s
+    B `broadcast`   rank 0 sorts, then ncclBroadcast of sorted codes + perm (code_bytes + 4 per row) — a ring/tree broadcast
+                    is bound by ONE xGMI link:                   A + (code_bytes + 4) * build_rows / link
+    B never wins on time (it adds the transfer to the same sort); it saves (N - 1) sorts' worth of energy and HBM traffic."""
+    a = build_rows / build_rows_per_s * 1e3
+    b = a + (code_bytes + 4) * build_rows / (link_gb_per_s * 1e9) * 1e3 if n_ranks > 1 else a
+    return {"replicated_ms": a, "broadcast_ms": b, "choice": "replicated" if a <= b else "broadcast"}

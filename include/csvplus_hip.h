@@ -347,6 +347,9 @@ typedef struct {
     const uint64_t* counts;
     const uint64_t* displs;
     void*           data[CPH_MAX_GATHER];
+    int32_t         mem;            /* CPH_MEM_DEVICE, or CPH_MEM_HOST: the arrays lie in the communicator's shared host
+                                       buffer (cph_dist_join_chain with CPH_DIST_HOST_GATHER) */
+    int32_t         reserved_;
 } cph_gathered;
 
 /* allgatherv of `narrays` device arrays that all hold `count` elements on this rank (elem_bytes[a] each):
@@ -361,6 +364,41 @@ CPH_API void    cph_gathered_release(cph_gathered* g);
  * behind it (data[1..nsteps]) when some stream row of some rank did not join. */
 CPH_API int32_t cph_dist_chain_allgather(cph_dist* d, const cph_chain* chain, uint64_t probe_base, cph_gathered** out,
                                          int32_t* identity, uint64_t* stream_base);
+
+/*
+ * The sharded chained Join in ONE call, its exchange pipelined behind the compute (round 4; csvplus.go:553-567 — rows are
+ * independent, so a shard may be cut anywhere).  `steps` describe THIS rank's shard of the stream (its rows are stream rows
+ * [probe_base, probe_base + nrows)); every rank passes the same chain.  The shard is cut into `nchunks` sub-chunks (0: the
+ * library picks, 1..8 by shard size; the same value on every rank) and chunk k's rows travel while chunk k+1 is being joined:
+ *   - default: to every peer over xGMI (RCCL send/recv batches on a second stream), straight into their final place in
+ *     the gathered arrays — every rank ends up with the whole list in device memory, as with cph_dist_chain_allgather;
+ *   - CPH_DIST_HOST_GATHER: each rank copies its chunks device -> host into ITS range of one host buffer that all ranks
+ *     of the node share (POSIX shared memory, registered with HIP; created on first use and kept): no xGMI traffic at all,
+ *     N PCIe links in parallel, and the joined list ends where a host program consumes it.  out->mem == CPH_MEM_HOST; the
+ *     arrays stay valid until THIS rank's next CPH_DIST_HOST_GATHER call on the communicator or cph_dist_destroy (results
+ *     alternate between two halves of the buffer, so a faster rank's next call does not touch what this rank still reads).
+ * The pipeline needs results of a known size: a chain of duplicate-free single-column indexes yields at most one tuple per
+ * stream row, so chunks travel in the dense form (slot == stream row) and the match totals are exchanged once at the end —
+ * the call's only host wait; when some row of some rank did not join, the slots are compacted afterwards (one local pass).
+ * Any other chain is joined whole and exchanged like cph_dist_chain_allgather does (stats->chunks == 0).
+ *   shard_rows   optional: the row counts of ALL ranks' shards (nranks entries) when the caller knows them — as it does for
+ *                a range split — and the ranges follow each other in rank order; NULL: one more count exchange up front.
+ *   flags        CPH_CHAIN_POSITIONS (see cph_join_chain_ex) | CPH_DIST_HOST_GATHER
+ *   identity / stream_base / out: as cph_dist_chain_allgather.
+ */
+#define CPH_DIST_HOST_GATHER 0x100u
+typedef struct {
+    int32_t  chunks;               /* sub-chunks per shard; 0: the one-shot path ran                                      */
+    int32_t  pipelined;            /* 1: more than one chunk, exchange and compute on separate streams                    */
+    double   compute_ms;           /* ctx stream: first chunk's join enqueued -> last chunk's join done                   */
+    double   exchange_ms;          /* exchange stream: first chunk ready -> match totals of all ranks received            */
+    double   exposed_exchange_ms;  /* last chunk's join done -> totals received: the part of the exchange nothing hides   */
+    double   total_ms;             /* first chunk's join enqueued -> totals received                                      */
+    uint64_t bytes_sent, bytes_received;   /* this rank, row arrays only (xGMI; host gather: bytes_sent = PCIe bytes)     */
+} cph_dist_join_stats;
+CPH_API int32_t cph_dist_join_chain(cph_dist* d, const cph_chain_step* steps, int32_t nsteps, uint64_t probe_base,
+                                    const uint64_t* shard_rows, int32_t nchunks, uint32_t flags, cph_gathered** out,
+                                    int32_t* identity, uint64_t* stream_base, cph_dist_join_stats* stats /* may be NULL */);
 
 /* Build side, option B: rank `root` built `root_index` (others pass NULL); every other rank
  * receives an equal index (*out; NULL on the root) — descriptor, sorted codes and perm travel by ncclBroadcast

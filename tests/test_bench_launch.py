@@ -114,3 +114,20 @@ def test_shared_gpu_debug_mode_still_runs_and_says_what_it_is():
     assert d["n_gpus"] == 2 and d["joined_rows_per_step"] == 300000
     assert "DEBUG" in d["config"]["exchange_transport"] and d["config"]["rccl_nranks"] is None
     assert len(d["per_rank_ms_per_step"]) == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exchange", ["allgatherv", "host"])
+def test_multi_gpu_code_path_with_one_rank(exchange):
+    """CPH_BENCH_FORCE_DIST=1: what a one-GPU box can execute of the N > 1 step — the RCCL communicator behind the C ABI
+    (nranks=1), cph_dist_join_chain with 3 sub-chunks (xGMI mode / shared host buffer), the multi_gpu report."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", *SMALL, "--exchange", exchange, "--chunks", "3", "--no-verify"],
+                       env=_env(CPH_BENCH_FORCE_DIST="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert d["joined_rows_per_step"] == 300000 and d["config"]["rccl_nranks"] == 1 and d["config"]["exchange"] == exchange
+    m = d["multi_gpu"]
+    assert m["mode"] == exchange and m["chunks"] == 3 and m["join_compute_ms"] > 0 and m["exchange_ms"] > 0
+    assert m["n1_ms_per_step"] > 0 and 0 < d["efficiency_vs_n1"] < 3 and d["exchange_ms"] == m["exchange_ms"] and d["compute_ms"] > 0
+    assert m["build_side"]["choice"] == "replicated"
+    assert m["bytes_sent_per_step"] == (300000 * 8 if exchange == "host" else 0)

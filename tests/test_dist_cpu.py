@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from csvplus_amd import datagen as dg
-from csvplus_amd.dist import allgatherv, sharded_chained_join
+from csvplus_amd.dist import ABSENT, allgatherv, build_side_estimate, chunk_range, pipelined_dense_exchange, sharded_chained_join
 from csvplus_amd.engine import shard_range
 
 
@@ -96,3 +96,84 @@ def test_sharded_join_allgatherv_gloo(world):
     for p in procs:
         p.join(timeout=60)
     assert sorted(results) == [(r, "ok") for r in range(world)], results
+
+
+def _pipe_worker(rank, world, port, m, nc, npd, factor, nchunks, cuts, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import orc
+
+        cust = dg.column(dg.SEQ_PERM, nc, nc, encoding=dg.FIXED8, seed=dg.SEED + 1)
+        prod = dg.column(dg.SEQ_PERM, npd, npd, encoding=dg.ITOA, seed=dg.SEED + 2)
+        ia, ib = orc.OracleIndex([cust]), orc.OracleIndex([prod])
+        begin = cuts[rank]
+        calls = []
+
+        def dense_chunk(b, e):
+            # the dense form of the fused chain: one slot per stream row, ABSENT where the row did not join both
+            calls.append((b, e))
+            o = dg.orders(m, factor * nc, npd, row0=begin + b, nrows=e - b)
+            j1 = ia.join([o["cust_id"]])
+            j2 = ib.join([o["prod_id"]])
+            a = np.full(e - b, ABSENT, np.int32)
+            bb = np.full(e - b, ABSENT, np.int32)
+            a[j1["probe_idx"].astype(np.int64)] = j1["build_row"].astype(np.int32)
+            bb[j2["probe_idx"].astype(np.int64)] = j2["build_row"].astype(np.int32)
+            a[bb == ABSENT] = ABSENT
+            return [torch.from_numpy(a), torch.from_numpy(bb)]
+
+        shard_rows = [cuts[r + 1] - cuts[r] for r in range(world)]
+        s, rows, totals = pipelined_dense_exchange(shard_rows, dense_chunk, 2, nchunks)
+        assert calls == [chunk_range(shard_rows[rank], c, nchunks) for c in range(nchunks) if chunk_range(shard_rows[rank], c, nchunks)[1] >
+                         chunk_range(shard_rows[rank], c, nchunks)[0]]
+        o = dg.orders(m, factor * nc, npd)
+        j1 = ia.join([o["cust_id"]])
+        j2 = ib.join([o["prod_id"]], row_sel=j1["probe_idx"].astype(np.uint32))
+        pick = j2["probe_idx"].astype(np.int64)
+        assert sum(totals) == len(pick) and len(totals) == world
+        if factor == 1:
+            assert s is None and len(pick) == m
+        else:
+            np.testing.assert_array_equal(s.numpy(), j1["probe_idx"][pick].astype(np.int64))
+        np.testing.assert_array_equal(rows[0].numpy(), j1["build_row"][pick].astype(np.int32))
+        np.testing.assert_array_equal(rows[1].numpy(), j2["build_row"].astype(np.int32))
+        q.put((rank, "ok"))
+    except Exception as e:   # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,factor,nchunks,uneven", [(2, 2, 4, False), (2, 1, 3, True), (3, 2, 5, True)])
+def test_pipelined_dense_exchange_gloo(world, factor, nchunks, uneven):
+    """The control flow of cph_dist_join_chain (csrc/dist.hip) over gloo: sub-chunks posted while the next one is computed,
+    uneven shards and an empty one, identity and not — the gathered list equals the oracle's join over the whole stream."""
+    m = 20_011
+    if uneven:
+        cuts = [0, m // 5] + ([m // 5] if world == 3 else []) + [m]
+    else:
+        cuts = [shard_range(m, r, world)[0] for r in range(world)] + [m]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, m, 3000, 50, factor, nchunks, cuts, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(r, "ok") for r in range(world)], results
+
+
+def test_chunk_ranges_and_build_side_estimate():
+    for n in (0, 1, 7, 8, 1000, 12_500_001):
+        for c in (1, 3, 8):
+            r = [chunk_range(n, k, c) for k in range(c)]
+            assert r[0][0] == 0 and r[-1][1] == n and all(r[k][1] == r[k + 1][0] for k in range(c - 1))
+            assert max(e - b for b, e in r) - min(e - b for b, e in r) <= 1
+    est = build_side_estimate(10_000_000, 4, 8, 3.0e10)
+    assert est["choice"] == "replicated" and est["broadcast_ms"] > est["replicated_ms"] > 0
+    assert build_side_estimate(10_000_000, 4, 1, 3.0e10)["broadcast_ms"] == build_side_estimate(10_000_000, 4, 1, 3.0e10)["replicated_ms"]

@@ -162,6 +162,108 @@ def run_sharded_chain(world, domain_factor, make_dist, expect_transport="loopbac
     run_ranks(world, rank_body)
 
 
+def gathered_array(g, a, dtype):
+    """Host copy of array a of a Gathered, wherever it lives (device memory / the shared host buffer)."""
+    if g.total == 0 or not g.data_ptrs[a]:
+        return np.empty(0, dtype=dtype)
+    if g.mem == N.CPH_MEM_HOST:
+        import ctypes as C
+
+        nb = g.total * np.dtype(dtype).itemsize
+        return np.frombuffer((C.c_uint8 * nb).from_address(g.data_ptrs[a]), dtype=dtype).copy()
+    return dev_array(g.data_ptrs[a], g.total, dtype)
+
+
+def cut_points(m, world, unequal):
+    """Shard boundaries: the even range split, or deliberately uneven ones (with an EMPTY shard when world >= 3)."""
+    if not unequal:
+        return [shard_range(m, r, world)[0] for r in range(world)] + [m]
+    cuts = [0, m // 7] + ([m // 7] if world >= 3 else []) + [m * 5 // 7 + 3 * k for k in range(world)]
+    return sorted(cuts[:world]) + [m]
+
+
+@pytest.mark.parametrize("host", [False, True])
+@pytest.mark.parametrize("world,domain_factor,nchunks,unequal,positions,shard_given",
+                         [(2, 1, 4, False, True, True), (3, 1, 5, True, False, True), (3, 2, 3, True, True, False),
+                          (2, 2, 1, False, False, True), (1, 2, 4, False, True, False)])
+def test_loopback_pipelined_join_chain(world, domain_factor, nchunks, unequal, positions, shard_given, host):
+    run_pipelined_chain(world, domain_factor, loopback_factory(f"pipe-{world}-{domain_factor}-{nchunks}-{host}", world), nchunks,
+                        host=host, positions=positions, unequal=unequal, shard_given=shard_given)
+
+
+def run_pipelined_chain(world, domain_factor, make_dist, nchunks, host=False, positions=False, unequal=False, shard_given=True,
+                        expect_transport="loopback"):
+    """cph_dist_join_chain: every rank joins its shard in `nchunks` sub-chunks whose rows are exchanged (xGMI path / shared host
+    buffer) while the next chunk is joined; the gathered list of EVERY rank equals the oracle's join over the whole stream
+    (csvplus.go:553-567), for even and uneven shards, an empty shard, all rows joining (identity) or half of them."""
+    m, nc, npd = 61_003, 4000, 60
+    cust, prod = dg.customers(nc)["id"], dg.products(npd)["prod_id"]
+    o = dg.orders(m, nc * domain_factor, npd)
+    cols = [o["cust_id"], o["prod_id"]]
+    es, ea, eb = oracle_whole(cust, prod, cols)
+    cuts = cut_points(m, world, unequal)
+    shard_rows = [cuts[r + 1] - cuts[r] for r in range(world)]
+
+    def rank_body(r):
+        ctx = Context(0)
+        d = make_dist(ctx, r)
+        assert d.transport().startswith(expect_transport), d.transport()
+        ia, ib = DeviceIndex(ctx, [cust], unique=True), DeviceIndex(ctx, [prod], unique=True)
+        perms = [ia.perm(), ib.perm()]
+        b, e = cuts[r], cuts[r + 1]
+        for rep in range(2):   # the second call reuses the exchange stream, the events and the shared host buffer
+            g = d.join_chain([(ia, [cols[0].slice(b, e)]), (ib, [cols[1].slice(b, e)])], probe_base=b,
+                             shard_rows=shard_rows if shard_given else None, nchunks=nchunks, positions=positions, host=host)
+            ctx.synchronize()
+            assert g.stats["chunks"] == nchunks and g.stats["pipelined"] == (1 if nchunks > 1 else 0), g.stats
+            assert g.mem == (N.CPH_MEM_HOST if host else N.CPH_MEM_DEVICE)
+            assert g.total == len(es) and sum(g.counts) == g.total and len(g.counts) == world
+            assert g.identity == (domain_factor == 1)
+            first = 0
+            if g.identity:
+                assert g.stream_base == 0 and g.total == m and g.counts == shard_rows and g.narrays == 2
+            else:
+                assert g.narrays == 3
+                np.testing.assert_array_equal(gathered_array(g, 0, np.uint64), es)
+                first = 1
+            ga, gb = gathered_array(g, first, np.uint32), gathered_array(g, first + 1, np.uint32)
+            if positions:
+                ga, gb = perms[0][ga], perms[1][gb]
+            np.testing.assert_array_equal(ga, ea)
+            np.testing.assert_array_equal(gb, eb)
+            g.release()
+        d.close()
+        ctx.close()
+
+    run_ranks(world, rank_body)
+
+
+@pytest.mark.parametrize("host", [False, True])
+def test_loopback_join_chain_one_shot_for_duplicate_keys(host):
+    """A chain the dense pipeline cannot carry (an index with duplicate keys: several tuples per stream row) is joined whole
+    and exchanged compact — same entry point, stats say so."""
+    world, m = 2, 20_000
+    keys = dg.varkeys(3000)                                   # duplicates
+    probe = dg.varkeys(m, 3000, seed=dg.SEED + 5)
+    oj = orc.OracleIndex([keys]).join([probe])
+
+    def rank_body(r):
+        ctx = Context(0)
+        d = loopback_factory(f"oneshot-{host}", world)(ctx, r)
+        ix = DeviceIndex(ctx, [keys])
+        b, e = shard_range(m, r, world)
+        g = d.join_chain([(ix, [probe.slice(b, e)])], probe_base=b, nchunks=4, host=host)
+        ctx.synchronize()
+        assert g.stats["chunks"] == 0 and not g.identity and g.narrays == 2 and g.total == len(oj["probe_idx"])
+        np.testing.assert_array_equal(gathered_array(g, 0, np.uint64), oj["probe_idx"].astype(np.uint64))
+        np.testing.assert_array_equal(gathered_array(g, 1, np.uint32), oj["build_row"])
+        g.release()
+        d.close()
+        ctx.close()
+
+    run_ranks(world, rank_body)
+
+
 def test_loopback_index_broadcast_option_b():
     run_index_broadcast(3, loopback_factory("bcast", 3))
 

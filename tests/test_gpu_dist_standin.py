@@ -35,6 +35,15 @@ for world, factor in ((2, 1), (2, 2), (3, 2), (3, 1)):
     T.run_sharded_chain(world, factor, factory(world), expect_transport="rccl nranks=%d lib=%s" % (world, os.environ["CPH_RCCL_LIBRARY"]))
     print("chain", world, factor, "ok", flush=True)
 T.run_index_broadcast(3, factory(3))
+# the pipelined sharded join (cph_dist_join_chain): per-chunk ncclSend / ncclRecv batches with displacements on the exchange
+# stream, 3..5 chunks in flight, even / uneven / empty shards, identity and not; and the host-gather variant, whose only
+# collectives are the count words
+tr = "rccl nranks=%d lib=%s"
+for world, factor, nchunks, unequal, positions, given, host in ((2, 1, 4, False, True, True, False), (3, 1, 5, True, False, True, False),
+                                                               (3, 2, 3, True, True, False, False), (3, 2, 4, True, False, True, True)):
+    T.run_pipelined_chain(world, factor, factory(world), nchunks, host=host, positions=positions, unequal=unequal, shard_given=given,
+                          expect_transport=tr % (world, os.environ["CPH_RCCL_LIBRARY"]))
+    print("pipelined", world, factor, nchunks, unequal, host, "ok", flush=True)
 print("STANDIN_RANKS_OK", flush=True)
 """
 
