@@ -92,8 +92,25 @@ void DevicePool::check_live() {
     for (const auto& b : live_) check_block(b);
 }
 
+void DevicePool::begin_defer() {
+    std::lock_guard<std::recursive_mutex> lk(mu_);
+    defer_depth_++;
+}
+void DevicePool::end_defer() {
+    std::lock_guard<std::recursive_mutex> lk(mu_);
+    if (defer_depth_ > 0 && --defer_depth_ == 0) {
+        std::vector<void*> d;
+        d.swap(deferred_);
+        for (void* p : d) release(p);
+    }
+}
+
 void DevicePool::release(void* p) {
     std::lock_guard<std::recursive_mutex> lk(mu_);
+    if (defer_depth_ > 0 && p) {
+        deferred_.push_back(p);
+        return;
+    }
     for (size_t i = 0; i < live_.size(); i++) {
         if (live_[i].p == p) {
             check_block(live_[i]);
@@ -246,6 +263,7 @@ Status pinned_upload(cph_ctx* ctx, size_t bytes, void** out) {
     if (need > ctx->upload_cap) {
         if (ctx->upload_ring) {
             CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+            if (ctx->other_stream()) CPH_HIP_TRY(hipStreamSynchronize(ctx->other_stream()));
             (void)hipHostFree(ctx->upload_ring);
             ctx->upload_ring = nullptr;
         }
@@ -256,6 +274,7 @@ Status pinned_upload(cph_ctx* ctx, size_t bytes, void** out) {
     }
     if (ctx->upload_pos + need > ctx->upload_cap) {
         CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));   // every earlier upload has been consumed
+        if (ctx->other_stream()) CPH_HIP_TRY(hipStreamSynchronize(ctx->other_stream()));
         ctx->upload_pos = 0;
     }
     *out = static_cast<uint8_t*>(ctx->upload_ring) + ctx->upload_pos;
@@ -397,6 +416,7 @@ struct BuildJob {
     SmallBufs sbufs;
     bool presplit = false;       // a large single-column table whose split codec was built from a sample + one exact pass BEFORE any plain
                                  // statistics (build_phase1): no statistics pass at all
+    bool side = false;           // this job's work is enqueued on the ctx's side stream (cph_index_build_many: it overlaps its neighbour's)
     bool no_split = false;       // second attempt after a split codec met a row it could not code (keycodec.hip: codec_try_split)
     DevBuf split_miss;           // u32 raised by the encode kernel of a split codec; read back with the first duplicate
 };
@@ -446,16 +466,22 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
     for (size_t i = 0; i < nj; i++) {
         if (!status[i].ok()) continue;
         if (jobs[i].small) {
+            SideStream on_side(ctx, jobs[i].side);   // (its columns were staged on that stream)
             status[i] = small_build_launch(ctx, jobs[i].dcols, jobs[i].nkeycols, jobs[i].ix->nrows, &jobs[i].sbufs,
                                            reinterpret_cast<SmallResult*>(h + jobs[i].scratch_off));
             continue;
         }
         if (jobs[i].presplit) continue;
         hipError_t e = hipMemcpyAsync(h + jobs[i].scratch_off, jobs[i].stats_dev.get(), sizeof(ColStats) * (size_t)jobs[i].nkeycols,
-                                      hipMemcpyDeviceToHost, ctx->stream);
+                                      hipMemcpyDeviceToHost, jobs[i].side ? ctx->side_stream : ctx->stream);
         if (e != hipSuccess) status[i] = {CPH_ERR_HIP, std::string("statistics read-back: ") + hipGetErrorString(e)};
     }
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail_all({CPH_ERR_HIP, "hipStreamSynchronize failed"});
+    bool any_side = false;
+    for (size_t i = 0; i < nj; i++) any_side = any_side || jobs[i].side;
+    auto sync_streams = [&]() {
+        return hipStreamSynchronize(ctx->stream) == hipSuccess && (!any_side || hipStreamSynchronize(ctx->side_stream) == hipSuccess);
+    };
+    if (!sync_streams()) return fail_all({CPH_ERR_HIP, "hipStreamSynchronize failed"});
     // the host copies must survive phase 2 (which may reuse the scratch): take them out
     std::vector<std::vector<uint8_t>> stats_host(nj);
     std::vector<size_t> retry;   // small-table candidates whose key needs the general path after all
@@ -473,7 +499,10 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
         if (!jobs[i].presplit) stats_host[i].assign(h + jobs[i].scratch_off, h + jobs[i].scratch_off + sizeof(ColStats) * (size_t)jobs[i].nkeycols);
     }
     for (size_t i = 0; i < nj; i++)
-        if (status[i].ok() && !jobs[i].small) status[i] = build_phase2(ctx, &jobs[i], stats_host[i].data());
+        if (status[i].ok() && !jobs[i].small) {
+            SideStream on_side(ctx, jobs[i].side);
+            status[i] = build_phase2(ctx, &jobs[i], stats_host[i].data());
+        }
     // ---- sync 2: first duplicates ----
     std::vector<size_t> resplit;   // jobs whose split codec met a row it could not code: once more without the split
     if (any_general) {
@@ -483,13 +512,14 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
         uint32_t* sm = fd + nj;
         for (size_t i = 0; i < nj; i++) {
             if (!status[i].ok() || jobs[i].small) continue;
-            hipError_t e = hipMemcpyAsync(&fd[i], jobs[i].ix->first_dup_dev.get(), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+            hipStream_t js = jobs[i].side ? ctx->side_stream : ctx->stream;
+            hipError_t e = hipMemcpyAsync(&fd[i], jobs[i].ix->first_dup_dev.get(), sizeof(uint32_t), hipMemcpyDeviceToHost, js);
             sm[i] = 0;
             if (e == hipSuccess && jobs[i].split_miss)
-                e = hipMemcpyAsync(&sm[i], jobs[i].split_miss.get(), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+                e = hipMemcpyAsync(&sm[i], jobs[i].split_miss.get(), sizeof(uint32_t), hipMemcpyDeviceToHost, js);
             if (e != hipSuccess) status[i] = {CPH_ERR_HIP, std::string("first-duplicate read-back: ") + hipGetErrorString(e)};
         }
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail_all({CPH_ERR_HIP, "hipStreamSynchronize failed"});
+        if (!sync_streams()) return fail_all({CPH_ERR_HIP, "hipStreamSynchronize failed"});
         for (size_t i = 0; i < nj; i++) {
             if (!status[i].ok() || jobs[i].small) continue;
             cph_index* ix = jobs[i].ix;
@@ -504,6 +534,7 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
         one.push_back(std::move(jobs[i]));
         std::vector<Status> st1(1);
         BuildJob& j = one[0];
+        j.side = false;   // (both streams are idle here: the second attempt runs on the ctx's own)
         j.no_split = true;
         j.presplit = false;
         j.split_miss.reset();
@@ -521,6 +552,7 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
         one.push_back(std::move(jobs[i]));
         std::vector<Status> st1(1);
         one[0].small = false;
+        one[0].side = false;
         st1[0] = codec_stats_launch(ctx, one[0].dcols, one[0].nkeycols, &one[0].stats_dev);
         if (st1[0].ok()) build_run(ctx, one, st1);
         status[i] = st1[0];
@@ -803,6 +835,11 @@ CPH_API void cph_ctx_destroy(cph_ctx* ctx) {
     for (auto& p : ctx->prof_pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
     for (hipEvent_t e : ctx->prof_free_events) (void)hipEventDestroy(e);
     hipStream_t own = ctx->own_stream ? ctx->stream : nullptr;
+    if (ctx->side_stream) {
+        (void)hipStreamSynchronize(ctx->side_stream);
+        (void)hipStreamDestroy(ctx->side_stream);
+    }
+    for (auto& sc : ctx->scan) sc.words.reset();
     ctx->pool.trim();
     if (own) (void)hipStreamDestroy(own);
     delete ctx;
@@ -824,6 +861,7 @@ CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value
     else if (k == "chain_rank_lds") ctx->chain_rank_lds = value != 0;
     else if (k == "codec_split") ctx->codec_split = value != 0;
     else if (k == "scan_lookback") ctx->scan_lookback = value != 0;
+    else if (k == "build_side_stream") ctx->build_side_stream = value != 0;
     else if (k == "chain_arith") ctx->chain_arith = value != 0;
     else if (k == "chain_identity") ctx->chain_identity = value != 0;
     else if (k == "probe_hash_rows") ctx->probe_hash_rows = value == 4 ? 4 : 2;
@@ -980,10 +1018,31 @@ CPH_API int32_t cph_index_build_many(cph_ctx* ctx, const cph_index_spec* specs, 
     if (!specs || !out || nspecs < 1 || nspecs > 64) return fail(ctx, {CPH_ERR_INVALID, "bad cph_index_build_many arguments"});
     std::vector<BuildJob> jobs((size_t)nspecs);
     std::vector<Status> st((size_t)nspecs);
+    // Two streams for a batch: every second build is enqueued on the side stream, so a small table's launch-latency-bound
+    // kernels (products: 1e5 rows, ~15 launches of a few microseconds of work each) run inside the gaps and beside the kernels
+    // of its neighbour (customers: 1e7 rows) instead of behind them.  Both streams are idle again when the call returns.
+    bool two_streams = nspecs >= 2 && ctx->build_side_stream != 0;
+    if (two_streams && !ctx->side_stream && hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->side_stream = nullptr;
+        two_streams = false;
+    }
+    struct DeferGuard {   // no block changes hands between the two streams' kernels while both run
+        cph_ctx* c;
+        ~DeferGuard() {
+            if (!c) return;
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipStreamSynchronize(c->side_stream);
+            c->pool.end_defer();
+        }
+    } defer{two_streams ? ctx : nullptr};
+    if (two_streams) ctx->pool.begin_defer();
     for (int i = 0; i < nspecs; i++) {
         out[i] = nullptr;
         if (first_dup_pos) first_dup_pos[i] = UINT64_MAX;
         jobs[i].ix = new (std::nothrow) cph_index();
+        jobs[i].side = two_streams && (i & 1);
+        SideStream on_side(ctx, jobs[i].side);
         if (!jobs[i].ix) st[i] = {CPH_ERR_NOMEM, "out of host memory"};
         else st[i] = build_phase1(ctx, specs[i].keycols, specs[i].nkeycols, &jobs[i]);
     }

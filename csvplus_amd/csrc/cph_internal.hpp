@@ -70,6 +70,11 @@ public:
     uint64_t guard_violations = 0;
     std::string first_violation;
     void check_live();
+    // While a batch of builds runs on TWO streams (capi.hip: cph_index_build_many), reuse is no longer stream-ordered: a
+    // block released by one build could be handed to the other while kernels still use it.  Between begin_defer and
+    // end_defer released blocks are parked instead; end_defer (called once both streams are idle) really releases them.
+    void begin_defer();
+    void end_defer();
 
 private:
     struct Block { void* p; size_t cap; size_t user; bool guarded = false; bool in_slab = false; };
@@ -80,6 +85,8 @@ private:
     std::vector<std::pair<size_t, size_t>> slab_free_;   // (offset, length), sorted by offset, coalesced
     std::vector<Block> free_;
     std::vector<Block> live_;
+    int defer_depth_ = 0;
+    std::vector<void*> deferred_;
 };
 
 // RAII handle on a pool block.
@@ -318,9 +325,16 @@ struct cph_ctx {
     int codec_debug = 0;           // prints the window choice of codec_try_groups to stderr
     int codec_split = 1;           // the delimiter split of keycodec.hip is tried (A/B switch; 0: never)
     int scan_lookback = 1;         // exclusive_scan_u32 as ONE launch (decoupled look-back, radix_sort.hip) instead of three (A/B switch)
-    cph::DevBuf scan_state;        // its state words (+ ticket counter), zeroed once; epochs / relative tickets make a scan memset-free
-    uint64_t scan_state_tiles = 0, scan_epoch = 0;
-    uint32_t scan_tickets = 0;
+    struct ScanState {             // its state words (+ ticket counter), zeroed once; epochs / relative tickets make a scan memset-free
+        cph::DevBuf words;
+        uint64_t tiles = 0, epoch = 0;
+        uint32_t tickets = 0;
+    } scan[2];                     // one per stream slot (scans of the two streams of a build batch run concurrently)
+    int build_side_stream = 1;     // cph_index_build_many: every second general build of a batch runs on a second stream (A/B switch)
+    hipStream_t side_stream = nullptr;   // created on first use
+    int stream_slot = 0;           // 0: `stream` is the ctx's own; 1: it is side_stream for the moment (cph::SideStream)
+    hipStream_t swapped_main = nullptr;  // ... and this is the ctx's own meanwhile
+    hipStream_t other_stream() const { return stream_slot ? swapped_main : side_stream; }   // may be null
     int plan_threads = 0, gstats_threads = 0;   // tuning: workgroup sizes of k_encode_build_plan / k_group_stats (0: default)
     int speculative_groups = 1;    // dictionaries of large inputs from a sample, completed by the encode kernel (keycodec.hip):
                                    // 0 never, 1 when the sample holds no value seen only once, 2 always
@@ -333,6 +347,30 @@ struct cph_ctx {
     std::vector<cph::ProfStat> prof_stats;
     std::vector<hipEvent_t> prof_free_events;
 };
+
+namespace cph {
+// Everything a ctx enqueues goes to ctx->stream; for the duration of this guard that is the side stream.
+struct SideStream {
+    cph_ctx* ctx;
+    hipStream_t saved;
+    SideStream(cph_ctx* c, bool on) : ctx(on ? c : nullptr), saved(c->stream) {
+        if (ctx) {
+            ctx->swapped_main = saved;
+            ctx->stream = ctx->side_stream;
+            ctx->stream_slot = 1;
+        }
+    }
+    ~SideStream() {
+        if (ctx) {
+            ctx->stream = saved;
+            ctx->stream_slot = 0;
+            ctx->swapped_main = nullptr;
+        }
+    }
+    SideStream(const SideStream&) = delete;
+    SideStream& operator=(const SideStream&) = delete;
+};
+}  // namespace cph
 
 // One window of at most kMaxKeyBytes key byte positions (positions run column-major over the key columns, so a
 // window is a list of column SEGMENTS).  Keys that fit one window — every key the tuned paths ever see — have

@@ -362,25 +362,37 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_lookback(uint32_t* __rest
     for (int k = 0; k < kScanItems; k++) sum += u.v[k];
     uint32_t total;
     uint32_t run = block_exclusive_sum<uint32_t, kScanThreads>(sum, s_tmp, &total);
-    if (threadIdx.x == 0) {
-        const uint64_t tagged = epoch << 34;
+    const uint64_t tagged = epoch << 34;
+    if (threadIdx.x == 0)   // published before the look-back starts: the successors only need the aggregate to move on
+        __hip_atomic_store(&state[tile], tagged | (tile == 0 ? kScanInclusive : kScanAggregate) | (uint64_t)total, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < kWave) {
+        // wave 0 looks back 64 predecessors at a time: lane l reads tile - 1 - l (- the window offset), the wave stops at the
+        // nearest predecessor that already knows its inclusive prefix and adds up the aggregates in front of it
+        const int lane = (int)threadIdx.x;
         uint32_t excl = 0;
-        if (tile == 0) {
-            __hip_atomic_store(&state[0], tagged | kScanInclusive | (uint64_t)total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            __hip_atomic_store(&state[tile], tagged | kScanAggregate | (uint64_t)total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            for (uint32_t j = tile; j-- > 0;) {
-                unsigned long long w;
+        int64_t hi = (int64_t)tile - 1;   // the nearest tile not yet accounted for
+        while (hi >= 0) {
+            const int64_t j = hi - lane;
+            unsigned long long w = tagged | kScanInclusive;   // lanes in front of tile 0: an inclusive prefix of 0
+            if (j >= 0) {
                 do {
                     w = __hip_atomic_load(&state[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
                 } while ((w >> 34) != epoch || (w & (kScanAggregate | kScanInclusive)) == 0);
-                excl += (uint32_t)w;
-                if (w & kScanInclusive) break;
             }
-            __hip_atomic_store(&state[tile], tagged | kScanInclusive | (uint64_t)(uint32_t)(excl + total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const uint64_t incl = __ballot((w & kScanInclusive) != 0);
+            const int stop = incl ? __builtin_ctzll(incl) : kWave;   // lanes 0..stop take part (stop == 64: all, none inclusive)
+            excl += wave_sum(lane <= stop ? (uint32_t)w : 0u);
+            if (incl) break;
+            hi -= kWave;
         }
-        s_prefix = excl;
-        if (total_out && tile + 1 == ntiles) *total_out = excl + total;
+        if (lane == 0) {
+            if (tile != 0)
+                __hip_atomic_store(&state[tile], tagged | kScanInclusive | (uint64_t)(uint32_t)(excl + total), __ATOMIC_RELEASE,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            s_prefix = excl;
+            if (total_out && tile + 1 == ntiles) *total_out = excl + total;
+        }
     }
     __syncthreads();
     run += s_prefix;
@@ -403,26 +415,27 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_lookback(uint32_t* __rest
 
 static Status exclusive_scan_lookback(cph_ctx* ctx, uint32_t* data, uint64_t n, uint32_t* total_out, const char* name) {
     const uint64_t nblk = (n + kScanTile - 1) / kScanTile;
-    if (nblk > ctx->scan_state_tiles) {   // state words + the ticket counter: zeroed once per (re)allocation
+    cph_ctx::ScanState& sc = ctx->scan[ctx->stream_slot];
+    if (nblk > sc.tiles) {   // state words + the ticket counter: zeroed once per (re)allocation
         const uint64_t cap = nblk < 4096 ? 4096 : nblk * 2;
-        CPH_TRY(ctx->scan_state.alloc(&ctx->pool, (cap + 2) * sizeof(unsigned long long)));
-        CPH_HIP_TRY(hipMemsetAsync(ctx->scan_state.get(), 0, (cap + 2) * sizeof(unsigned long long), ctx->stream));
-        ctx->scan_state_tiles = cap;
-        ctx->scan_tickets = 0;
-        ctx->scan_epoch = 0;
+        CPH_TRY(sc.words.alloc(&ctx->pool, (cap + 2) * sizeof(unsigned long long)));
+        CPH_HIP_TRY(hipMemsetAsync(sc.words.get(), 0, (cap + 2) * sizeof(unsigned long long), ctx->stream));
+        sc.tiles = cap;
+        sc.tickets = 0;
+        sc.epoch = 0;
     }
-    ctx->scan_epoch++;
-    if (ctx->scan_epoch >= (1ull << 30)) {   // the epoch field is 30 bits: start over with zeroed words
-        CPH_HIP_TRY(hipMemsetAsync(ctx->scan_state.get(), 0, (ctx->scan_state_tiles + 2) * sizeof(unsigned long long), ctx->stream));
-        ctx->scan_tickets = 0;
-        ctx->scan_epoch = 1;
+    sc.epoch++;
+    if (sc.epoch >= (1ull << 30)) {   // the epoch field is 30 bits: start over with zeroed words
+        CPH_HIP_TRY(hipMemsetAsync(sc.words.get(), 0, (sc.tiles + 2) * sizeof(unsigned long long), ctx->stream));
+        sc.tickets = 0;
+        sc.epoch = 1;
     }
-    unsigned long long* state = ctx->scan_state.as<unsigned long long>();
-    uint32_t* ticket = reinterpret_cast<uint32_t*>(state + ctx->scan_state_tiles);
+    unsigned long long* state = sc.words.as<unsigned long long>();
+    uint32_t* ticket = reinterpret_cast<uint32_t*>(state + sc.tiles);
     ProfScope ps(ctx, name, 2.0 * sizeof(uint32_t) * (double)n);
-    hipLaunchKernelGGL(k_scan_lookback, dim3((unsigned)nblk), dim3(kScanThreads), 0, ctx->stream, data, n, state, ticket, ctx->scan_tickets,
-                       ctx->scan_epoch, total_out, (uint32_t)nblk);
-    ctx->scan_tickets += (uint32_t)nblk;   // (wraps like the device counter)
+    hipLaunchKernelGGL(k_scan_lookback, dim3((unsigned)nblk), dim3(kScanThreads), 0, ctx->stream, data, n, state, ticket, sc.tickets, sc.epoch,
+                       total_out, (uint32_t)nblk);
+    sc.tickets += (uint32_t)nblk;   // (wraps like the device counter)
     CPH_HIP_TRY(hipGetLastError());
     return {};
 }

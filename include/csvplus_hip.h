@@ -146,6 +146,9 @@ CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
  *                   per-position suffix (floating fields like "Smith/Amelia#12345": 25 bits instead of 47; A/B switch)
  *   "scan_lookback" 0 / 1 (default 1): the 32-bit exclusive scans (radix count matrices, compaction offsets) run as ONE launch
  *                   (decoupled look-back) instead of three (A/B switch)
+ *   "build_side_stream" 0 / 1 (default 1): cph_index_build_many enqueues every second build of a batch on a second stream of
+ *                   the ctx, so the launch-latency-bound kernels of a small table run beside its neighbour's instead of behind
+ *                   them; both streams are idle when the call returns (A/B switch)
  *   "codec_debug"   1: the window choice of every index build (and the phase times of a one-launch build) go to stderr
  *   "small_build_rows"  tables of at most this many rows (default 8192, at most 16384) are indexed by ONE launch of one
  *                   workgroup and one synchronisation (small_build.hip); 0 = always the general path

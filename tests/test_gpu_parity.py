@@ -539,3 +539,36 @@ def test_scan_lookback_matches_three_kernel_scan(ctx, n):
             assert g.first_dup == o.first_dup()
         finally:
             ctx.set_option("scan_lookback", 1)
+
+
+@pytest.mark.parametrize("side", [1, 0])
+def test_build_many_on_two_streams(ctx, side):
+    """cph_index_build_many enqueues every second build on the ctx's side stream (ctx option build_side_stream): concurrent
+    statistics / encode / radix passes / one-launch scans of neighbouring jobs, pool blocks parked until both streams are idle.
+    Same indexes as the oracle's (csvplus.go:707-756), batch after batch on one ctx, device-resident and host-resident columns,
+    and the join that follows on the ctx's own stream sees finished indexes."""
+    ctx.set_option("build_side_stream", side)
+    try:
+        rng = np.random.default_rng(17)
+        tables = [
+            [dg.customers(400_000)["id"]],
+            [dg.products(100_000)["prod_id"]],
+            [dg.varkeys(80_000)],                                                                       # delimiter-split candidate
+            [StrCol.from_values([b"%d" % int(x) for x in rng.permutation(6000)])],                    # one-launch build
+            [StrCol.from_values(random_keys(rng, 50_000, 0, 20, alphabet=np.frombuffer(b"abc\x00", np.uint8), distinct=900))],
+        ]
+        oracles = [orc.OracleIndex(t) for t in tables]
+        dev = [[c.to_device("cuda:0") for c in t] for t in tables[:2]] + tables[2:]
+        o = dg.orders(200_000, 400_000, 100_000)
+        probe = [o["cust_id"], o["prod_id"]]
+        for rep in range(3):
+            res = DeviceIndex.build_many(ctx, [(t, False) for t in (dev if rep != 1 else tables)])
+            for ix, oix in zip(res, oracles):
+                np.testing.assert_array_equal(ix.perm(), oix.perm)
+                assert ix.first_dup == oix.first_dup()
+            for k in range(2):
+                assert_join_equal(res[k].probe([probe[k]]), oracles[k].join([probe[k]]))
+            for ix in res:
+                ix.close()
+    finally:
+        ctx.set_option("build_side_stream", 1)
