@@ -416,6 +416,9 @@ struct BuildJob {
     SmallBufs sbufs;
     bool presplit = false;       // a large single-column table whose split codec was built from a sample + one exact pass BEFORE any plain
                                  // statistics (build_phase1): no statistics pass at all
+    bool sampled = false;        // alphabets from a sample of the rows (keycodec.hip: codec_sample_*): the encode kernel checks every row, a
+                                 // miss (split_miss) starts the build over with the exact statistics pass
+    bool no_sample = false;
     bool side = false;           // this job's work is enqueued on the ctx's side stream (cph_index_build_many: it overlaps its neighbour's)
     bool no_split = false;       // second attempt after a split codec met a row it could not code (keycodec.hip: codec_try_split)
     DevBuf split_miss;           // u32 raised by the encode kernel of a split codec; read back with the first duplicate
@@ -437,12 +440,18 @@ static Status build_phase1(cph_ctx* ctx, const cph_strcol* keycols, int32_t nkey
         CPH_TRY(codec_try_split(ctx, job->dcols, 1, ix->nrows, nullptr, &ix->codec));
         job->presplit = ix->codec.has_split();
     }
-    if (!job->small && !job->presplit) CPH_TRY(codec_stats_launch(ctx, job->dcols, nkeycols, &job->stats_dev));   // K0: alphabets
+    job->sampled = !job->small && !job->presplit && !job->no_sample && codec_sample_applies(ctx, job->dcols, nkeycols, ix->nrows);
+    if (job->sampled) CPH_TRY(codec_sample_launch(ctx, job->dcols[0], ix->nrows, &job->stats_dev));
+    else if (!job->small && !job->presplit) CPH_TRY(codec_stats_launch(ctx, job->dcols, nkeycols, &job->stats_dev));   // K0: alphabets
     return {};
 }
 
 static Status build_phase2(cph_ctx* ctx, BuildJob* job, const void* stats_host);
 static Status build_encode_sort(cph_ctx* ctx, BuildJob* job);
+
+static size_t job_readback_bytes(const BuildJob& j) {   // what sync 1 brings to the host for this job
+    return j.small ? sizeof(SmallResult) : j.presplit ? 0 : j.sampled ? codec_sample_bytes() : sizeof(ColStats) * (size_t)j.nkeycols;
+}
 
 // Runs a batch of jobs whose phase 1 succeeded (ok[i]); status[i] receives each job's outcome.
 static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Status>& status) {
@@ -456,7 +465,7 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
     bool any_general = false;
     for (size_t i = 0; i < nj; i++) {
         jobs[i].scratch_off = total;
-        total += jobs[i].small ? sizeof(SmallResult) : jobs[i].presplit ? 0 : sizeof(ColStats) * (size_t)jobs[i].nkeycols;
+        total += job_readback_bytes(jobs[i]);
         total = (total + 63) & ~(size_t)63;
         if (status[i].ok() && !jobs[i].small) any_general = true;
     }
@@ -472,7 +481,7 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
             continue;
         }
         if (jobs[i].presplit) continue;
-        hipError_t e = hipMemcpyAsync(h + jobs[i].scratch_off, jobs[i].stats_dev.get(), sizeof(ColStats) * (size_t)jobs[i].nkeycols,
+        hipError_t e = hipMemcpyAsync(h + jobs[i].scratch_off, jobs[i].stats_dev.get(), job_readback_bytes(jobs[i]),
                                       hipMemcpyDeviceToHost, jobs[i].side ? ctx->side_stream : ctx->stream);
         if (e != hipSuccess) status[i] = {CPH_ERR_HIP, std::string("statistics read-back: ") + hipGetErrorString(e)};
     }
@@ -496,7 +505,7 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
             else if (status[i].ok()) index_plan_table(jobs[i].ix);
             continue;
         }
-        if (!jobs[i].presplit) stats_host[i].assign(h + jobs[i].scratch_off, h + jobs[i].scratch_off + sizeof(ColStats) * (size_t)jobs[i].nkeycols);
+        if (!jobs[i].presplit) stats_host[i].assign(h + jobs[i].scratch_off, h + jobs[i].scratch_off + job_readback_bytes(jobs[i]));
     }
     for (size_t i = 0; i < nj; i++)
         if (status[i].ok() && !jobs[i].small) {
@@ -536,6 +545,8 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
         BuildJob& j = one[0];
         j.side = false;   // (both streams are idle here: the second attempt runs on the ctx's own)
         j.no_split = true;
+        j.no_sample = true;
+        j.sampled = false;
         j.presplit = false;
         j.split_miss.reset();
         cph_index* ix = j.ix;
@@ -677,7 +688,22 @@ static Status build_phase2(cph_ctx* ctx, BuildJob* job, const void* stats_host) 
         return build_encode_sort(ctx, job);
     }
     std::vector<ColStats> stats;
-    codec_stats_finish(dcols, nkeycols, stats_host, &stats);
+    if (job->sampled) {
+        codec_sample_finish(dcols[0], stats_host, &stats);
+        CPH_TRY(codec_build(stats, &ix->codec));
+        if (codec_sample_checked(ix->codec, dcols)) {
+            CPH_TRY(job->split_miss.alloc(&ctx->pool, sizeof(uint32_t)));
+            CPH_HIP_TRY(hipMemsetAsync(job->split_miss.get(), 0, sizeof(uint32_t), ctx->stream));
+            CPH_TRY(codec_upload(ctx, ix->codec, &ix->codec_dev));
+            return build_encode_sort(ctx, job);
+        }
+        // a code the checking encode kernel does not handle (several words, ...): the exact pass after all, here and now
+        job->sampled = false;
+        ix->codec = CodecHost{};
+        CPH_TRY(codec_collect_stats(ctx, dcols, nkeycols, &stats));
+    } else {
+        codec_stats_finish(dcols, nkeycols, stats_host, &stats);
+    }
     uint64_t positions = 0;
     for (const auto& s : stats) positions += s.maxlen;
     if (positions > (uint64_t)kMaxKeyBytes) return build_multi_window(ctx, job, stats);
@@ -862,6 +888,7 @@ CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value
     else if (k == "codec_split") ctx->codec_split = value != 0;
     else if (k == "scan_lookback") ctx->scan_lookback = value != 0;
     else if (k == "build_side_stream") ctx->build_side_stream = value != 0;
+    else if (k == "stats_sample") ctx->stats_sample = value != 0;
     else if (k == "chain_arith") ctx->chain_arith = value != 0;
     else if (k == "chain_identity") ctx->chain_identity = value != 0;
     else if (k == "probe_hash_rows") ctx->probe_hash_rows = value == 4 ? 4 : 2;

@@ -330,6 +330,8 @@ struct cph_ctx {
         uint64_t tiles = 0, epoch = 0;
         uint32_t tickets = 0;
     } scan[2];                     // one per stream slot (scans of the two streams of a build batch run concurrently)
+    int stats_sample = 1;          // IndexOn over ONE fixed-width key column of >= 2^20 rows takes its alphabets from a sample; the encode
+                                   // kernel checks every row against them and the build starts over with exact statistics on a miss (A/B switch)
     int build_side_stream = 1;     // cph_index_build_many: every second general build of a batch runs on a second stream (A/B switch)
     hipStream_t side_stream = nullptr;   // created on first use
     int stream_slot = 0;           // 0: `stream` is the ctx's own; 1: it is side_stream for the moment (cph::SideStream)
@@ -482,6 +484,12 @@ Status codec_collect_stats(cph_ctx* ctx, const DevCol* cols, int32_t ncols, std:
 Status codec_stats_launch(cph_ctx* ctx, const DevCol* cols, int32_t ncols, DevBuf* dev_stats);
 void codec_stats_finish(const DevCol* cols, int32_t ncols, const void* host_copy, std::vector<ColStats>* out);
 Status codec_build(const std::vector<ColStats>& stats, CodecHost* codec);   // host only
+// alphabets from a sample of the rows instead of a pass over all of them (keycodec.hip; capi.hip: BuildJob::sampled)
+bool codec_sample_applies(const cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t n);
+size_t codec_sample_bytes();
+Status codec_sample_launch(cph_ctx* ctx, const DevCol& col, uint64_t n, DevBuf* dev);
+void codec_sample_finish(const DevCol& col, const void* host_copy, std::vector<ColStats>* out);
+bool codec_sample_checked(const CodecHost& codec, const DevCol* cols);
 // When the per-position code needs several words: one more pass over the key columns collects the distinct
 // joint symbols of every 7-position group; groups with few of them are dictionary-coded (codec rebuilt in place).
 // On large inputs the dictionaries can be SPECULATIVE (spec != nullptr): they are taken from a sample of the rows, the

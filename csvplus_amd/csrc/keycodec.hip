@@ -1288,6 +1288,41 @@ static double bits_sort_cost(double bits) {
 //                     statistics pass when the split is taken); *codec is written on success only (has_split() says so).
 // The split codec comes from exact statistics over all rows.  Three small synchronisations: the sample's byte counts, the
 // candidates' sample statistics (one launch for all of them), the exact pass.
+// ---- alphabets from a sample (fixed-width single-column keys) --------------------------------------------------------------
+// The statistics pass reads every key once only to learn which byte values occur at which position; for ids and the like a
+// few ten thousand rows spread over the table show them all.  k_split_count already collects per-position byte presence
+// over rows 0, step, 2 step, ...: its result stands in for the exact ColStats, the encode kernel (k_encode_build_fast) flags
+// any row the sampled alphabets cannot code, and a flagged build starts over with the exact pass (capi.hip).
+bool codec_sample_applies(const cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t n) {
+    return ctx->stats_sample != 0 && ncols == 1 && cols[0].fixed_width >= 1 && cols[0].fixed_width <= (uint32_t)kSplitMaxValue &&
+           !cols[0].segmented() && n >= (1ull << 20);
+}
+size_t codec_sample_bytes() { return sizeof(SplitSample); }
+Status codec_sample_launch(cph_ctx* ctx, const DevCol& col, uint64_t n, DevBuf* dev) {
+    const uint64_t step = n >> 16;   // 65 536 .. 131 071 sampled rows
+    const uint64_t nsel = (n + step - 1) / step;
+    CPH_TRY(dev->alloc(&ctx->pool, sizeof(SplitSample)));
+    CPH_HIP_TRY(hipMemsetAsync(dev->get(), 0, sizeof(SplitSample), ctx->stream));
+    ProfScope ps(ctx, "k_split_count", 0);
+    uint64_t nblk = (nsel + kSplitThreads - 1) / kSplitThreads;
+    if (nblk > 1024) nblk = 1024;
+    hipLaunchKernelGGL(k_split_count, dim3((unsigned)nblk), dim3(kSplitThreads), 0, ctx->stream, col, step, nsel, dev->as<SplitSample>());
+    CPH_HIP_TRY(hipGetLastError());
+    return {};
+}
+void codec_sample_finish(const DevCol& col, const void* host_copy, std::vector<ColStats>* out) {
+    const SplitSample* sm = static_cast<const SplitSample*>(host_copy);
+    out->assign(1, ColStats{});
+    ColStats& st = (*out)[0];
+    st.minlen = st.maxlen = col.fixed_width;
+    static_assert(sizeof(sm->mask) <= sizeof(st.mask), "the sample's positions must fit ColStats");
+    memcpy(st.mask, sm->mask, sizeof sm->mask);
+}
+// the one encode kernel that checks its rows against the alphabets: k_encode_build_fast
+bool codec_sample_checked(const CodecHost& cd, const DevCol* cols) {
+    return !cd.has_split() && !cd.has_groups() && cd.ncols == 1 && cd.nwords == 1 && codec_premultiplied_bits(cd) != 0 && !cols[0].segmented();
+}
+
 Status codec_try_split(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t n, const std::vector<ColStats>* stats, CodecHost* codec) {
     if (!ctx->codec_split || n < (1ull << 16) || ncols >= kMaxKeyCols) return {};
     if (stats && (codec->key32 || codec->has_groups())) return {};
@@ -1686,7 +1721,7 @@ template <class W, class OUT, class B, bool LONG>
 __global__ __launch_bounds__(kEncodeThreads) void k_encode_build_fast(DevCol col, const uint8_t* __restrict__ g_codec,
                                                                      uint64_t n, OUT* __restrict__ out, uint32_t tile_rows,
                                                                      uint32_t ntiles, uint32_t* __restrict__ counts,
-                                                                     uint32_t digit_mask, uint32_t bins, int codec_bytes) {
+                                                                     uint32_t digit_mask, uint32_t bins, int codec_bytes, uint32_t* __restrict__ miss) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const CodecView cv = codec_load_to_lds(g_codec, smem);
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + codec_bytes);   // [bins], only when counts != nullptr
@@ -1714,9 +1749,12 @@ __global__ __launch_bounds__(kEncodeThreads) void k_encode_build_fast(DevCol col
                 c1[k] = LONG ? sp.chunk(k, 1) : 0;
             }
             OUT code[kEncodeFastRows];
-            uint32_t okm = wr.okm;   // every build key encodes: only the existence bits matter here
+            uint32_t okm = wr.okm;   // every build key encodes under alphabets taken from ALL rows: only the existence bits matter
             encode_rows<kEncodeFastRows, W, B, OUT, LONG>(cv, sp, c0, c1, code, &okm,
                                                           col.fixed_width != 0 && (int)col.fixed_width == cv.hdr->col_maxlen[0]);
+            // alphabets from a SAMPLE of the rows (capi.hip: BuildJob::sampled): a row with a byte the sample never showed at
+            // that position does not encode — its code is meaningless, the caller starts over with exact statistics
+            if (miss && okm != wr.okm) *miss = 1u;
 #pragma unroll
             for (int k = 0; k < kEncodeFastRows; k++) {
                 if ((wr.okm >> k) & 1u) {
@@ -1940,8 +1978,8 @@ Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec
         const uint8_t* blob = codec_dev.as<uint8_t>();
         const bool narrow = col_is_narrow(cols[0]);
         const bool long_keys = cd.col_maxlen[0] > 8;
-        using Fn32 = void (*)(DevCol, const uint8_t*, uint64_t, uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t, uint32_t, int);
-        using Fn64 = void (*)(DevCol, const uint8_t*, uint64_t, uint64_t*, uint32_t, uint32_t, uint32_t*, uint32_t, uint32_t, int);
+        using Fn32 = void (*)(DevCol, const uint8_t*, uint64_t, uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t, uint32_t, int, uint32_t*);
+        using Fn64 = void (*)(DevCol, const uint8_t*, uint64_t, uint64_t*, uint32_t, uint32_t, uint32_t*, uint32_t, uint32_t, int, uint32_t*);
         int per_cu = 1, cus = 256;
         CPH_TRY(device_cus(ctx, &cus));
         ProfScope ps(ctx, "k_encode_build", 4.0 * (double)bins * (double)ntiles);
@@ -1950,7 +1988,7 @@ Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec
             unsigned grid = (unsigned)std::min<uint64_t>(ntiles64, (uint64_t)cus * (uint64_t)per_cu);
             grid = (grid + 7u) & ~7u;   // the kernel splits its tiles over blockIdx % 8
             hipLaunchKernelGGL(fn, dim3(grid), dim3(kEncodeThreads), lds, ctx->stream, cols[0], blob, n, out, tile_rows, ntiles,
-                               want_hist ? hist->counts : nullptr, mask, bins, (int)codec_bytes);
+                               want_hist ? hist->counts : nullptr, mask, bins, (int)codec_bytes, miss);
             return {};
         };
         if (cd.key32) {

@@ -572,3 +572,37 @@ def test_build_many_on_two_streams(ctx, side):
                 ix.close()
     finally:
         ctx.set_option("build_side_stream", 1)
+
+
+@pytest.mark.parametrize("rare_row", [None, 777_777])
+def test_alphabets_from_a_sample_fixed_width_ids(ctx, rare_row):
+    """IndexOn over one fixed-width key column of >= 2^20 rows takes its alphabets from a sample of the rows (ctx option
+    stats_sample) instead of a pass over all of them; the encode kernel checks every row against them.  Same index as the oracle's
+    (csvplus.go:794-807) when the sample showed every byte (no statistics pass ran) and when ONE row, which the sample does not
+    visit, holds a byte seen nowhere else (the build notices and starts over with the exact pass)."""
+    n = (1 << 20) + 12_345
+    rng = np.random.default_rng(3)
+    ids = rng.permutation(5 * n)[:n]
+    raw = np.char.zfill(ids.astype("U8"), 8).astype("S8")
+    data = np.frombuffer(raw.tobytes(), np.uint8).copy()
+    if rare_row is not None:
+        assert rare_row % (n >> 16) != 0                       # not a sampled row
+        data[8 * rare_row + 3] = ord("A")
+    col = StrCol.from_arrays(data, np.arange(n + 1, dtype=np.uint32) * 8, fixed_width=8)
+    o = orc.OracleIndex([col])
+    ctx.profile(True)
+    ctx.profile_read(reset=True)
+    g = DeviceIndex(ctx, [col.to_device("cuda:0")], unique=True)
+    prof = ctx.profile_read(reset=True)
+    ctx.profile(False)
+    assert prof.get("k_col_stats", {"launches": 0})["launches"] == (0 if rare_row is None else 1), prof.keys()
+    assert prof["k_split_count"]["launches"] == 1
+    np.testing.assert_array_equal(g.perm(), o.perm)
+    assert g.first_dup == o.first_dup()
+    ctx.set_option("stats_sample", 0)
+    try:
+        g0 = DeviceIndex(ctx, [col.to_device("cuda:0")], unique=True)
+        assert g0.info() == g.info()
+        np.testing.assert_array_equal(g0.perm(), o.perm)
+    finally:
+        ctx.set_option("stats_sample", 1)
