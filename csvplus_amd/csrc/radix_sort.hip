@@ -457,12 +457,17 @@ static Status exclusive_scan_impl(cph_ctx* ctx, T* data, uint64_t n, T* total_ou
     return {};
 }
 
+// One launch pays off where a scan is launch-latency (a count matrix of a 1e7-row sort: ~150 tiles, 13 us as three kernels);
+// over thousands of tiles the chain of look-backs is slower than three fully parallel kernels (1e8 rows, 1526 tiles: 0.24 ms
+// against 0.04 ms, profiles/r04_scan_lookback.txt).
+static bool scan_lookback_pays(const cph_ctx* ctx, uint64_t n) { return ctx->scan_lookback && n != 0 && n <= 512ull * kScanTile; }
+
 Status exclusive_scan_u32(cph_ctx* ctx, uint32_t* data, uint64_t n) {
-    if (ctx->scan_lookback && n != 0 && n < (1ull << 40)) return exclusive_scan_lookback(ctx, data, n, nullptr, "exclusive_scan_u32");
+    if (scan_lookback_pays(ctx, n)) return exclusive_scan_lookback(ctx, data, n, nullptr, "exclusive_scan_u32");
     return exclusive_scan_impl<uint32_t>(ctx, data, n, nullptr, "exclusive_scan_u32");
 }
 Status exclusive_scan_u32_total(cph_ctx* ctx, uint32_t* data, uint64_t n, uint32_t* total_out) {
-    if (ctx->scan_lookback && n != 0 && n < (1ull << 40)) return exclusive_scan_lookback(ctx, data, n, total_out, "exclusive_scan_u32");
+    if (scan_lookback_pays(ctx, n)) return exclusive_scan_lookback(ctx, data, n, total_out, "exclusive_scan_u32");
     return exclusive_scan_impl<uint32_t>(ctx, data, n, total_out, "exclusive_scan_u32");
 }
 // In-place exclusive scan of 64-bit counts; *total_out (device, optional) receives the sum.
