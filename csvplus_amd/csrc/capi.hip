@@ -419,6 +419,8 @@ struct BuildJob {
     bool sampled = false;        // alphabets from a sample of the rows (keycodec.hip: codec_sample_*): the encode kernel checks every row, a
                                  // miss (split_miss) starts the build over with the exact statistics pass
     bool no_sample = false;
+    bool unique = false;         // the caller expects distinct keys (UniqueIndexOn): the optimistic direct sort may be tried
+    bool no_direct = false;
     bool side = false;           // this job's work is enqueued on the ctx's side stream (cph_index_build_many: it overlaps its neighbour's)
     bool no_split = false;       // second attempt after a split codec met a row it could not code (keycodec.hip: codec_try_split)
     DevBuf split_miss;           // u32 raised by the encode kernel of a split codec; read back with the first duplicate
@@ -547,6 +549,7 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
         j.no_split = true;
         j.no_sample = true;
         j.sampled = false;
+        j.no_direct = true;
         j.presplit = false;
         j.split_miss.reset();
         cph_index* ix = j.ix;
@@ -739,6 +742,25 @@ static Status build_encode_sort(cph_ctx* ctx, BuildJob* job) {
         CPH_TRY(kb.alloc(&ctx->pool, n * kb_));
         const RadixPlan plan = radix_plan(ctx, n, cd.word_bits[0]);
         EncodeHist eh;
+        // distinct keys expected over a dense code space: slot[code] = row instead of radix passes (radix_sort.hip)
+        const uint64_t states = cd.word_states[0];
+        const bool direct = job->unique && !job->no_direct && ctx->direct_sort != 0 && cd.key32 && !job->spec.active && n >= (1ull << 16) &&
+                            states >= n && states <= 2 * n && states < 0xFFFFFFFFull;
+        if (direct) {
+            if (!job->split_miss) {
+                CPH_TRY(job->split_miss.alloc(&ctx->pool, sizeof(uint32_t)));
+                CPH_HIP_TRY(hipMemsetAsync(job->split_miss.get(), 0, sizeof(uint32_t), ctx->stream));
+            }
+            CPH_TRY(codec_encode_build(ctx, cd, ix->codec_dev, dcols, n, ka.get(), &eh, nullptr, job->split_miss.as<uint32_t>()));
+            CPH_TRY(direct_sort_distinct(ctx, ka.as<uint32_t>(), n, states, va.as<uint32_t>(), ka.as<uint32_t>(), job->split_miss.as<uint32_t>()));
+            ix->sorted_codes = std::move(ka);
+            ix->perm = std::move(va);
+            ix->sort_passes = 0;
+            // no adjacent-equal scan: either the keys are distinct or the flag sends the build down the general path
+            CPH_TRY(ix->first_dup_dev.alloc(&ctx->pool, sizeof(uint32_t)));
+            CPH_HIP_TRY(hipMemsetAsync(ix->first_dup_dev.get(), 0xFF, sizeof(uint32_t), ctx->stream));
+            return {};
+        }
         if (plan.npass > 0) {
             CPH_TRY(counts.alloc(&ctx->pool, plan.count_words() * sizeof(uint32_t)));
             eh.tile_rows = plan.tile;
@@ -794,10 +816,11 @@ static Status build_encode_sort(cph_ctx* ctx, BuildJob* job) {
     return {};
 }
 
-static Status index_build_impl(cph_ctx* ctx, const cph_strcol* keycols, int32_t nkeycols, cph_index* ix) {
+static Status index_build_impl(cph_ctx* ctx, const cph_strcol* keycols, int32_t nkeycols, cph_index* ix, bool unique) {
     std::vector<BuildJob> jobs(1);
     std::vector<Status> st(1);
     jobs[0].ix = ix;
+    jobs[0].unique = unique;
     st[0] = build_phase1(ctx, keycols, nkeycols, &jobs[0]);
     if (st[0].ok()) build_run(ctx, jobs, st);
     return st[0];
@@ -889,6 +912,7 @@ CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value
     else if (k == "scan_lookback") ctx->scan_lookback = value != 0;
     else if (k == "build_side_stream") ctx->build_side_stream = value != 0;
     else if (k == "stats_sample") ctx->stats_sample = value != 0;
+    else if (k == "direct_sort") ctx->direct_sort = value != 0;
     else if (k == "chain_arith") ctx->chain_arith = value != 0;
     else if (k == "chain_identity") ctx->chain_identity = value != 0;
     else if (k == "probe_hash_rows") ctx->probe_hash_rows = value == 4 ? 4 : 2;
@@ -1022,7 +1046,7 @@ CPH_API int32_t cph_index_build(cph_ctx* ctx, const cph_strcol* keycols, int32_t
     if (first_dup_pos) *first_dup_pos = UINT64_MAX;
     cph_index* ix = new (std::nothrow) cph_index();
     if (!ix) return fail(ctx, {CPH_ERR_NOMEM, "out of host memory"});
-    s = index_build_impl(ctx, keycols, nkeycols, ix);
+    s = index_build_impl(ctx, keycols, nkeycols, ix, unique != 0);
     if (!s.ok()) {
         delete ix;
         return fail(ctx, s);
@@ -1069,6 +1093,7 @@ CPH_API int32_t cph_index_build_many(cph_ctx* ctx, const cph_index_spec* specs, 
         if (first_dup_pos) first_dup_pos[i] = UINT64_MAX;
         jobs[i].ix = new (std::nothrow) cph_index();
         jobs[i].side = two_streams && (i & 1);
+        jobs[i].unique = specs[i].unique != 0;
         SideStream on_side(ctx, jobs[i].side);
         if (!jobs[i].ix) st[i] = {CPH_ERR_NOMEM, "out of host memory"};
         else st[i] = build_phase1(ctx, specs[i].keycols, specs[i].nkeycols, &jobs[i]);

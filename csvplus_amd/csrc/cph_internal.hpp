@@ -330,6 +330,9 @@ struct cph_ctx {
         uint64_t tiles = 0, epoch = 0;
         uint32_t tickets = 0;
     } scan[2];                     // one per stream slot (scans of the two streams of a build batch run concurrently)
+    int direct_sort = 1;           // a build that expects distinct keys (UniqueIndexOn) over a dense 32-bit code space (rows <= states <= 2 rows)
+                                   // sorts by ONE scatter, slot[code] = row (radix_sort.hip: direct_sort_distinct); a duplicate is noticed on
+                                   // the device and the build starts over the general way (A/B switch)
     int stats_sample = 1;          // IndexOn over ONE fixed-width key column of >= 2^20 rows takes its alphabets from a sample; the encode
                                    // kernel checks every row against them and the build starts over with exact statistics on a miss (A/B switch)
     int build_side_stream = 1;     // cph_index_build_many: every second general build of a batch runs on a second stream (A/B switch)
@@ -552,6 +555,9 @@ template <class K>
 Status radix_sort_pairs(cph_ctx* ctx, K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b, bool vals_iota,
                         uint64_t n, int bits, K** keys_out, uint32_t** vals_out, int* passes,
                         uint32_t* counts = nullptr, bool first_hist_done = false);
+// distinct 32-bit codes over a dense space: one scatter instead of radix passes (optimistic; *flag raised on a duplicate)
+Status direct_sort_distinct(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out, uint32_t* sorted_out,
+                            uint32_t* flag);
 Status exclusive_scan_u32(cph_ctx* ctx, uint32_t* data, uint64_t n);
 Status exclusive_scan_u32_total(cph_ctx* ctx, uint32_t* data, uint64_t n, uint32_t* total_out);   // total_out: device
 Status exclusive_scan_u64(cph_ctx* ctx, uint64_t* data, uint64_t n, uint64_t* total_out);

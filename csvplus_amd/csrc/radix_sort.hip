@@ -508,6 +508,137 @@ Status fill_iota_u32(cph_ctx* ctx, uint32_t* dst, uint64_t n) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Direct sort of DISTINCT keys over a dense code space (UniqueIndexOn of ids): one scatter instead of radix passes
+// ---------------------------------------------------------------------------------------------
+// When a table is expected to hold no duplicates (createUniqueIndex, csvplus.go:740-756) and its codes fill their space
+// densely (states <= 2 n: decimal ids, row numbers), the sorted order IS the code: slot[code] = row, then the slots in code
+// order are the permutation.  No histogram, no count matrix, no scan per digit — one random 4-byte store per row into a table
+// the size of the index instead of three passes of 16 bytes per row.  Optimistic: two rows with one code overwrite each other
+// and a slot stays empty; the number of filled slots is checked against the row count on the device and a mismatch raises
+// *flag — the caller then builds the index the general way (which also finds WHERE the first duplicate is).
+constexpr uint32_t kEmptySlot = 0xFFFFFFFFu;   // never a row id (at most 2^32 - 1 rows)
+constexpr int kDirectRows = 8;                 // slots per lane of the compaction: a wave owns 512 consecutive slots
+
+// (a code at or beyond `states` can only come from a row the encode kernel flagged — alphabets from a sample, capi.hip —: the
+// build starts over anyway, the store is simply skipped)
+__global__ __launch_bounds__(256) void k_direct_scatter(const uint32_t* __restrict__ codes, uint64_t n, uint32_t* __restrict__ slots,
+                                                       uint32_t states) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const uint64_t nvec = n / 4, stride = (uint64_t)gridDim.x * 256;
+    const bool aligned = ((uintptr_t)codes & 15) == 0;
+    for (uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += stride) {
+        u32x4 c;
+        if (aligned) c = reinterpret_cast<const u32x4*>(codes)[v];
+        else { c.x = codes[4 * v]; c.y = codes[4 * v + 1]; c.z = codes[4 * v + 2]; c.w = codes[4 * v + 3]; }
+        const uint32_t r = (uint32_t)(4 * v);
+        if (c.x < states) slots[c.x] = r;
+        if (c.y < states) slots[c.y] = r + 1;
+        if (c.z < states) slots[c.z] = r + 2;
+        if (c.w < states) slots[c.w] = r + 3;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const uint64_t i = 4 * nvec + threadIdx.x;
+        if (codes[i] < states) slots[codes[i]] = (uint32_t)i;
+    }
+}
+
+// states == n: every slot must be filled; the slots ARE the permutation, the sorted codes are 0..n-1
+__global__ __launch_bounds__(256) void k_direct_check_iota(const uint32_t* __restrict__ slots, uint64_t n, uint32_t* __restrict__ sorted,
+                                                          uint32_t* __restrict__ flag) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    bool empty = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        empty = empty || slots[i] == kEmptySlot;
+        sorted[i] = (uint32_t)i;
+    }
+    if (__ballot(empty) && lane_id() == 0) *flag = 1u;
+}
+
+__global__ __launch_bounds__(256) void k_direct_count(const uint32_t* __restrict__ slots, uint64_t states, uint32_t* __restrict__ wave_counts,
+                                                     uint64_t nwaves) {
+    const int lane = lane_id();
+    for (uint64_t w = (uint64_t)blockIdx.x * 4 + wave_id(); w < nwaves; w += (uint64_t)gridDim.x * 4) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int k = 0; k < kDirectRows; k++) {
+            const uint64_t s = (w * kDirectRows + (uint64_t)k) * kWave + lane;
+            c += (uint32_t)__popcll(__ballot(s < states && slots[s] != kEmptySlot));
+        }
+        if (lane == 0) wave_counts[w] = c;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_direct_compact(const uint32_t* __restrict__ slots, uint64_t states, const uint32_t* __restrict__ wave_base,
+                                                       uint64_t nwaves, uint32_t* __restrict__ perm, uint32_t* __restrict__ sorted,
+                                                       const uint32_t* __restrict__ total, uint64_t n, uint32_t* __restrict__ flag) {
+    const int lane = lane_id();
+    const uint64_t lt = lanemask_lt();
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (uint64_t)*total != n) *flag = 1u;   // fewer filled slots than rows: duplicates
+    if ((uint64_t)*total != n) return;   // (the arrays have room for n entries only)
+    for (uint64_t w = (uint64_t)blockIdx.x * 4 + wave_id(); w < nwaves; w += (uint64_t)gridDim.x * 4) {
+        uint64_t pos = wave_base[w];
+#pragma unroll
+        for (int k = 0; k < kDirectRows; k++) {
+            const uint64_t s = (w * kDirectRows + (uint64_t)k) * kWave + lane;
+            const uint32_t v = s < states ? slots[s] : kEmptySlot;
+            const uint64_t bal = __ballot(v != kEmptySlot);
+            if (v != kEmptySlot) {
+                const uint64_t p = pos + (uint64_t)__popcll(bal & lt);
+                perm[p] = v;
+                sorted[p] = (uint32_t)s;
+            }
+            pos += (uint64_t)__popcll(bal);
+        }
+    }
+}
+
+// codes[n] (32-bit, below `states`) -> perm_out[n] (rows in code order), sorted_out[n] (the codes in order); *flag (device,
+// zeroed by the caller) is raised when two rows share a code — the outputs are then meaningless.  codes and sorted_out may be
+// the same buffer.  scratch: states == n needs none (perm_out holds the slots).
+Status direct_sort_distinct(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out, uint32_t* sorted_out,
+                            uint32_t* flag) {
+    if (n == 0) return {};
+    const unsigned grid = grid_for(n / 4 + 1, 256, 16384);
+    if (states == n) {
+        CPH_HIP_TRY(hipMemsetAsync(perm_out, 0xFF, n * sizeof(uint32_t), ctx->stream));
+        {
+            ProfScope ps(ctx, "k_direct_scatter", 8.0 * (double)n);
+            hipLaunchKernelGGL(k_direct_scatter, dim3(grid), dim3(256), 0, ctx->stream, codes, n, perm_out, (uint32_t)states);
+        }
+        {
+            ProfScope ps(ctx, "k_direct_finish", 8.0 * (double)n);
+            hipLaunchKernelGGL(k_direct_check_iota, dim3(grid_for(n, 256, 8192)), dim3(256), 0, ctx->stream, perm_out, n, sorted_out, flag);
+        }
+        CPH_HIP_TRY(hipGetLastError());
+        return {};
+    }
+    DevBuf slots, wave_counts, total;
+    const uint64_t nwaves = (states + (uint64_t)kDirectRows * kWave - 1) / ((uint64_t)kDirectRows * kWave);
+    CPH_TRY(slots.alloc(&ctx->pool, states * sizeof(uint32_t)));
+    CPH_TRY(wave_counts.alloc(&ctx->pool, nwaves * sizeof(uint32_t)));
+    CPH_TRY(total.alloc(&ctx->pool, sizeof(uint32_t)));
+    CPH_HIP_TRY(hipMemsetAsync(slots.get(), 0xFF, states * sizeof(uint32_t), ctx->stream));
+    {
+        ProfScope ps(ctx, "k_direct_scatter", 8.0 * (double)n);
+        hipLaunchKernelGGL(k_direct_scatter, dim3(grid), dim3(256), 0, ctx->stream, codes, n, slots.as<uint32_t>(), (uint32_t)states);
+    }
+    const unsigned wgrid = (unsigned)std::min<uint64_t>((nwaves + 3) / 4, 16384);
+    {
+        ProfScope ps(ctx, "k_direct_finish", 8.0 * (double)states + 8.0 * (double)n);
+        hipLaunchKernelGGL(k_direct_count, dim3(wgrid), dim3(256), 0, ctx->stream, slots.as<uint32_t>(), states, wave_counts.as<uint32_t>(), nwaves);
+    }
+    CPH_HIP_TRY(hipGetLastError());
+    CPH_TRY(exclusive_scan_u32_total(ctx, wave_counts.as<uint32_t>(), nwaves, total.as<uint32_t>()));
+    {
+        ProfScope ps(ctx, "k_direct_finish", 0);
+        hipLaunchKernelGGL(k_direct_compact, dim3(wgrid), dim3(256), 0, ctx->stream, slots.as<uint32_t>(), states, wave_counts.as<uint32_t>(), nwaves,
+                           perm_out, sorted_out, total.as<uint32_t>(), n, flag);
+    }
+    CPH_HIP_TRY(hipGetLastError());
+    return {};
+}
+
+// ---------------------------------------------------------------------------------------------
 // driver
 // ---------------------------------------------------------------------------------------------
 template <class K, int RBITS, int THREADS>

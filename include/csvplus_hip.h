@@ -146,6 +146,10 @@ CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
  *                   per-position suffix (floating fields like "Smith/Amelia#12345": 25 bits instead of 47; A/B switch)
  *   "scan_lookback" 0 / 1 (default 1): the 32-bit exclusive scans (radix count matrices, compaction offsets) run as ONE launch
  *                   (decoupled look-back) instead of three (A/B switch)
+ *   "direct_sort"   0 / 1 (default 1): a build that expects distinct keys (cph_index_build with unique = 1, cph_index_spec.unique) over a
+ *                   dense 32-bit code space (rows <= code states <= 2 rows: decimal ids, row numbers) sorts by ONE scatter — slot[code] = row
+ *                   — instead of radix passes; a duplicate is noticed on the device and the build starts over the general way, which
+ *                   also reports where the first duplicate is (A/B switch)
  *   "stats_sample"  0 / 1 (default 1): IndexOn over ONE fixed-width key column (<= 40 bytes) of >= 2^20 rows learns its per-position
  *                   alphabets from ~65 536 rows spread over the table instead of a pass over all rows; the encode kernel checks every
  *                   row against them, and a row with a byte the sample did not show makes the build start over with the exact

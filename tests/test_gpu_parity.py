@@ -606,3 +606,47 @@ def test_alphabets_from_a_sample_fixed_width_ids(ctx, rare_row):
         np.testing.assert_array_equal(g0.perm(), o.perm)
     finally:
         ctx.set_option("stats_sample", 1)
+
+
+@pytest.mark.parametrize("shape", ["full_space", "dense_space", "duplicate", "not_unique_call"])
+def test_direct_sort_of_distinct_keys_over_a_dense_code_space(ctx, shape):
+    """UniqueIndexOn (csvplus.go:740-756) over ids that fill their code space densely sorts by one scatter, slot[code] = row
+    (radix_sort.hip: direct_sort_distinct), not by radix passes: same perm as the oracle when the space is full (the slots ARE
+    the permutation) or up to twice the rows (slots compacted); a duplicate is noticed on the device, the build starts over the
+    general way and reports the oracle's first duplicate; a build that does not ask for distinct keys never takes the path."""
+    rng = np.random.default_rng(11)
+    if shape == "full_space":
+        ids = rng.permutation(100_000)                       # "00000".."99999": 10^5 states for 10^5 rows
+        width = 5
+    else:
+        ids = rng.permutation(1_000_000)[:620_000]           # 10^6 states, 6.2e5 rows
+        width = 6
+    if shape == "duplicate":
+        ids[123_457] = ids[17]
+    col = StrCol.from_values([b"%0*d" % (width, int(x)) for x in ids])
+    o = orc.OracleIndex([col])
+    unique = shape != "not_unique_call"
+    ctx.profile(True)
+    ctx.profile_read(reset=True)
+    g = DeviceIndex(ctx, [col], unique=unique)
+    prof = ctx.profile_read(reset=True)
+    ctx.profile(False)
+    took_direct, took_radix = "k_direct_scatter" in prof, "k_radix_scatter_u32" in prof
+    assert took_direct == unique and took_radix == (shape in ("duplicate", "not_unique_call")), sorted(prof)
+    np.testing.assert_array_equal(g.perm(), o.perm)
+    assert g.first_dup == o.first_dup()
+    assert g.status == (N.CPH_ERR_DUPLICATE if shape == "duplicate" else N.CPH_OK)
+    probe = [StrCol.from_values([col.value(int(i)) for i in rng.integers(0, col.nrows, 2000)] + [b"9" * width, b"12", b""])]
+    assert_join_equal(g.probe(probe), o.join(probe))
+    for v in (col.value(5), b"0" * width, b"5" * (width - 1)):
+        assert g.find(v) == o.find(v) or (g.find(v)[0] == g.find(v)[1] and o.find(v)[0] == o.find(v)[1])
+    if unique and shape != "duplicate":   # the fused chain over this index, both output modes
+        from csvplus_amd import join_chain
+
+        want = o.join(probe)
+        for positions in (False, True):
+            ch = join_chain(ctx, [(g, probe)], positions=positions)
+            np.testing.assert_array_equal(ch.stream_row, want["probe_idx"])
+            rows = ch.build_row(0)
+            np.testing.assert_array_equal(g.perm()[rows] if positions else rows, want["build_row"])
+            ch.release()
