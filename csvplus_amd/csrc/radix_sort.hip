@@ -542,6 +542,31 @@ __global__ __launch_bounds__(256) void k_direct_scatter(const uint32_t* __restri
     }
 }
 
+// The same after the rows were PARTITIONED by the top digit of their codes (one radix pass, direct_sort_distinct): bucket b's
+// pairs lie together and write into one window of the slots (1e7 rows, 256 buckets: 156 KB), so the partial-sector stores of
+// neighbouring workgroups meet in the L2 and leave it as whole lines.  XCD x walks the contiguous part x of the pairs, so that a
+// window is written through ONE L2.
+__global__ __launch_bounds__(256) void k_direct_scatter_pairs(const uint32_t* __restrict__ codes, const uint32_t* __restrict__ rows, uint64_t n,
+                                                             uint32_t* __restrict__ slots, uint32_t states) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const uint64_t nvec = n / 4;
+    const uint64_t per_xcd = (nvec + 7) / 8, xcd = blockIdx.x & 7u;
+    const uint64_t v_end = (xcd + 1) * per_xcd < nvec ? (xcd + 1) * per_xcd : nvec;
+    const uint64_t stride = (uint64_t)(gridDim.x >> 3) * 256;
+    for (uint64_t v = xcd * per_xcd + (uint64_t)(blockIdx.x >> 3) * 256 + threadIdx.x; v < v_end; v += stride) {
+        const u32x4 c = reinterpret_cast<const u32x4*>(codes)[v];
+        const u32x4 r = reinterpret_cast<const u32x4*>(rows)[v];
+        if (c.x < states) slots[c.x] = r.x;
+        if (c.y < states) slots[c.y] = r.y;
+        if (c.z < states) slots[c.z] = r.z;
+        if (c.w < states) slots[c.w] = r.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const uint64_t i = 4 * nvec + threadIdx.x;
+        if (codes[i] < states) slots[codes[i]] = rows[i];
+    }
+}
+
 // states == n: every slot must be filled; the slots ARE the permutation, the sorted codes are 0..n-1
 __global__ __launch_bounds__(256) void k_direct_check_iota(const uint32_t* __restrict__ slots, uint64_t n, uint32_t* __restrict__ sorted,
                                                           uint32_t* __restrict__ flag) {
@@ -590,52 +615,6 @@ __global__ __launch_bounds__(256) void k_direct_compact(const uint32_t* __restri
             pos += (uint64_t)__popcll(bal);
         }
     }
-}
-
-// codes[n] (32-bit, below `states`) -> perm_out[n] (rows in code order), sorted_out[n] (the codes in order); *flag (device,
-// zeroed by the caller) is raised when two rows share a code — the outputs are then meaningless.  codes and sorted_out may be
-// the same buffer.  scratch: states == n needs none (perm_out holds the slots).
-Status direct_sort_distinct(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out, uint32_t* sorted_out,
-                            uint32_t* flag) {
-    if (n == 0) return {};
-    const unsigned grid = grid_for(n / 4 + 1, 256, 16384);
-    if (states == n) {
-        CPH_HIP_TRY(hipMemsetAsync(perm_out, 0xFF, n * sizeof(uint32_t), ctx->stream));
-        {
-            ProfScope ps(ctx, "k_direct_scatter", 8.0 * (double)n);
-            hipLaunchKernelGGL(k_direct_scatter, dim3(grid), dim3(256), 0, ctx->stream, codes, n, perm_out, (uint32_t)states);
-        }
-        {
-            ProfScope ps(ctx, "k_direct_finish", 8.0 * (double)n);
-            hipLaunchKernelGGL(k_direct_check_iota, dim3(grid_for(n, 256, 8192)), dim3(256), 0, ctx->stream, perm_out, n, sorted_out, flag);
-        }
-        CPH_HIP_TRY(hipGetLastError());
-        return {};
-    }
-    DevBuf slots, wave_counts, total;
-    const uint64_t nwaves = (states + (uint64_t)kDirectRows * kWave - 1) / ((uint64_t)kDirectRows * kWave);
-    CPH_TRY(slots.alloc(&ctx->pool, states * sizeof(uint32_t)));
-    CPH_TRY(wave_counts.alloc(&ctx->pool, nwaves * sizeof(uint32_t)));
-    CPH_TRY(total.alloc(&ctx->pool, sizeof(uint32_t)));
-    CPH_HIP_TRY(hipMemsetAsync(slots.get(), 0xFF, states * sizeof(uint32_t), ctx->stream));
-    {
-        ProfScope ps(ctx, "k_direct_scatter", 8.0 * (double)n);
-        hipLaunchKernelGGL(k_direct_scatter, dim3(grid), dim3(256), 0, ctx->stream, codes, n, slots.as<uint32_t>(), (uint32_t)states);
-    }
-    const unsigned wgrid = (unsigned)std::min<uint64_t>((nwaves + 3) / 4, 16384);
-    {
-        ProfScope ps(ctx, "k_direct_finish", 8.0 * (double)states + 8.0 * (double)n);
-        hipLaunchKernelGGL(k_direct_count, dim3(wgrid), dim3(256), 0, ctx->stream, slots.as<uint32_t>(), states, wave_counts.as<uint32_t>(), nwaves);
-    }
-    CPH_HIP_TRY(hipGetLastError());
-    CPH_TRY(exclusive_scan_u32_total(ctx, wave_counts.as<uint32_t>(), nwaves, total.as<uint32_t>()));
-    {
-        ProfScope ps(ctx, "k_direct_finish", 0);
-        hipLaunchKernelGGL(k_direct_compact, dim3(wgrid), dim3(256), 0, ctx->stream, slots.as<uint32_t>(), states, wave_counts.as<uint32_t>(), nwaves,
-                           perm_out, sorted_out, total.as<uint32_t>(), n, flag);
-    }
-    CPH_HIP_TRY(hipGetLastError());
-    return {};
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -761,6 +740,71 @@ template Status radix_sort_pairs<uint32_t>(cph_ctx*, uint32_t*, uint32_t*, uint3
                                            uint32_t**, uint32_t**, int*, uint32_t*, bool);
 template Status radix_sort_pairs<uint64_t>(cph_ctx*, uint64_t*, uint64_t*, uint32_t*, uint32_t*, bool, uint64_t, int,
                                            uint64_t**, uint32_t**, int*, uint32_t*, bool);
+
+// codes[n] (32-bit, below `states`) -> perm_out[n] (rows in code order), sorted_out[n] (the codes in order); *flag (device,
+// zeroed by the caller) is raised when two rows share a code — the outputs are then meaningless.  codes and sorted_out may be
+// the same buffer.  scratch: states == n needs none (perm_out holds the slots).
+Status direct_sort_distinct(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out, uint32_t* sorted_out,
+                            uint32_t* flag) {
+    if (n == 0) return {};
+    const unsigned grid = grid_for(n / 4 + 1, 256, 16384);
+    // Slots beyond what an L2 holds: a random 4-byte store per row runs at the chip's L2-miss rate (62 G stores/s measured: 1e8
+    // rows 1.6 ms, as long as three radix passes).  One radix pass on the TOP 8 bits of the codes first (16 streaming bytes per
+    // row) makes the stores local.
+    DevBuf part_codes, part_rows, counts;
+    const bool two_level = ctx->direct_sort >= 1 && ctx->direct_sort != 3 && states * sizeof(uint32_t) > (2u << 20) && n >= (1u << 20);
+    if (two_level) {
+        int bits = 0;
+        while (bits < 32 && (1ull << bits) < states) bits++;
+        const int shift = bits > 8 ? bits - 8 : 0;
+        const uint32_t tile = 256u * kSortItems, ntiles = (uint32_t)((n + tile - 1) / tile);
+        CPH_TRY(part_codes.alloc(&ctx->pool, n * sizeof(uint32_t) + 16));
+        CPH_TRY(part_rows.alloc(&ctx->pool, n * sizeof(uint32_t) + 16));
+        CPH_TRY(counts.alloc(&ctx->pool, (size_t)256 * ntiles * sizeof(uint32_t)));
+        CPH_TRY((radix_pass<uint32_t, 8, 256>(ctx, codes, nullptr, part_codes.as<uint32_t>(), part_rows.as<uint32_t>(), n, shift, bits - shift,
+                                              counts.as<uint32_t>(), ntiles, false, nullptr, nullptr, 0, 0)));
+    }
+    auto scatter = [&](uint32_t* slots) {
+        ProfScope ps(ctx, "k_direct_scatter", (two_level ? 12.0 : 8.0) * (double)n);
+        if (two_level)
+            hipLaunchKernelGGL(k_direct_scatter_pairs, dim3((grid + 7u) & ~7u), dim3(256), 0, ctx->stream, part_codes.as<uint32_t>(),
+                               part_rows.as<uint32_t>(), n, slots, (uint32_t)states);
+        else
+            hipLaunchKernelGGL(k_direct_scatter, dim3(grid), dim3(256), 0, ctx->stream, codes, n, slots, (uint32_t)states);
+    };
+    if (states == n) {
+        CPH_HIP_TRY(hipMemsetAsync(perm_out, 0xFF, n * sizeof(uint32_t), ctx->stream));
+        scatter(perm_out);
+        {
+            ProfScope ps(ctx, "k_direct_finish", 8.0 * (double)n);
+            hipLaunchKernelGGL(k_direct_check_iota, dim3(grid_for(n, 256, 8192)), dim3(256), 0, ctx->stream, perm_out, n, sorted_out, flag);
+        }
+        CPH_HIP_TRY(hipGetLastError());
+        return {};
+    }
+    DevBuf slots, wave_counts, total;
+    const uint64_t nwaves = (states + (uint64_t)kDirectRows * kWave - 1) / ((uint64_t)kDirectRows * kWave);
+    CPH_TRY(slots.alloc(&ctx->pool, states * sizeof(uint32_t)));
+    CPH_TRY(wave_counts.alloc(&ctx->pool, nwaves * sizeof(uint32_t)));
+    CPH_TRY(total.alloc(&ctx->pool, sizeof(uint32_t)));
+    CPH_HIP_TRY(hipMemsetAsync(slots.get(), 0xFF, states * sizeof(uint32_t), ctx->stream));
+    scatter(slots.as<uint32_t>());
+    const unsigned wgrid = (unsigned)std::min<uint64_t>((nwaves + 3) / 4, 16384);
+    {
+        ProfScope ps(ctx, "k_direct_finish", 8.0 * (double)states + 8.0 * (double)n);
+        hipLaunchKernelGGL(k_direct_count, dim3(wgrid), dim3(256), 0, ctx->stream, slots.as<uint32_t>(), states, wave_counts.as<uint32_t>(), nwaves);
+    }
+    CPH_HIP_TRY(hipGetLastError());
+    CPH_TRY(exclusive_scan_u32_total(ctx, wave_counts.as<uint32_t>(), nwaves, total.as<uint32_t>()));
+    {
+        ProfScope ps(ctx, "k_direct_finish", 0);
+        hipLaunchKernelGGL(k_direct_compact, dim3(wgrid), dim3(256), 0, ctx->stream, slots.as<uint32_t>(), states, wave_counts.as<uint32_t>(), nwaves,
+                           perm_out, sorted_out, total.as<uint32_t>(), n, flag);
+    }
+    CPH_HIP_TRY(hipGetLastError());
+    return {};
+}
+
 
 }  // namespace cph
 

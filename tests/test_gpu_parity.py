@@ -342,7 +342,8 @@ def test_config2_properties_1e7(ctx):
     np.testing.assert_array_equal(val[m.build_row], ov)          # every pair joins equal keys
     np.testing.assert_array_equal(m.lo.astype(np.int64), ov)      # lo == sorted position == id
     info = g.info()
-    assert info["sort_passes"] == 3 and info["key_bytes"] == 4 and info["code_bits"] == 24
+    # distinct keys over a full code space (1e7 states for 1e7 rows): one scatter, no radix pass (radix_sort.hip: direct_sort_distinct)
+    assert info["sort_passes"] == 0 and info["key_bytes"] == 4 and info["code_bits"] == 24
 
 
 def test_fixed_width_columns_match_variable_path(ctx):
@@ -608,7 +609,7 @@ def test_alphabets_from_a_sample_fixed_width_ids(ctx, rare_row):
         ctx.set_option("stats_sample", 1)
 
 
-@pytest.mark.parametrize("shape", ["full_space", "dense_space", "duplicate", "not_unique_call"])
+@pytest.mark.parametrize("shape", ["full_space", "dense_space", "duplicate", "not_unique_call", "two_level", "two_level_duplicate"])
 def test_direct_sort_of_distinct_keys_over_a_dense_code_space(ctx, shape):
     """UniqueIndexOn (csvplus.go:740-756) over ids that fill their code space densely sorts by one scatter, slot[code] = row
     (radix_sort.hip: direct_sort_distinct), not by radix passes: same perm as the oracle when the space is full (the slots ARE
@@ -618,12 +619,18 @@ def test_direct_sort_of_distinct_keys_over_a_dense_code_space(ctx, shape):
     if shape == "full_space":
         ids = rng.permutation(100_000)                       # "00000".."99999": 10^5 states for 10^5 rows
         width = 5
+    elif shape.startswith("two_level"):
+        ids = rng.permutation(1_200_000)                     # 2 x 10^6 states, 1.2e6 rows: slots beyond an L2 -> partition pass first
+        width = 7
+        if shape == "two_level_duplicate":
+            ids[1_000_003] = ids[999]
     else:
         ids = rng.permutation(1_000_000)[:620_000]           # 10^6 states, 6.2e5 rows
         width = 6
     if shape == "duplicate":
         ids[123_457] = ids[17]
-    col = StrCol.from_values([b"%0*d" % (width, int(x)) for x in ids])
+    raw = np.char.zfill(ids.astype(f"U{width}"), width).astype(f"S{width}")
+    col = StrCol.from_arrays(np.frombuffer(raw.tobytes(), np.uint8).copy(), np.arange(len(ids) + 1, dtype=np.uint32) * width, fixed_width=width)
     o = orc.OracleIndex([col])
     unique = shape != "not_unique_call"
     ctx.profile(True)
@@ -632,15 +639,18 @@ def test_direct_sort_of_distinct_keys_over_a_dense_code_space(ctx, shape):
     prof = ctx.profile_read(reset=True)
     ctx.profile(False)
     took_direct, took_radix = "k_direct_scatter" in prof, "k_radix_scatter_u32" in prof
-    assert took_direct == unique and took_radix == (shape in ("duplicate", "not_unique_call")), sorted(prof)
+    # (the partition pass of the two-level variant is one radix scatter)
+    assert took_direct == unique and took_radix == (shape in ("duplicate", "not_unique_call", "two_level", "two_level_duplicate")), sorted(prof)
+    if shape == "two_level":
+        assert prof["k_radix_scatter_u32"]["launches"] == 1
     np.testing.assert_array_equal(g.perm(), o.perm)
     assert g.first_dup == o.first_dup()
-    assert g.status == (N.CPH_ERR_DUPLICATE if shape == "duplicate" else N.CPH_OK)
+    assert g.status == (N.CPH_ERR_DUPLICATE if shape.endswith("duplicate") else N.CPH_OK)
     probe = [StrCol.from_values([col.value(int(i)) for i in rng.integers(0, col.nrows, 2000)] + [b"9" * width, b"12", b""])]
     assert_join_equal(g.probe(probe), o.join(probe))
     for v in (col.value(5), b"0" * width, b"5" * (width - 1)):
         assert g.find(v) == o.find(v) or (g.find(v)[0] == g.find(v)[1] and o.find(v)[0] == o.find(v)[1])
-    if unique and shape != "duplicate":   # the fused chain over this index, both output modes
+    if unique and not shape.endswith("duplicate"):   # the fused chain over this index, both output modes
         from csvplus_amd import join_chain
 
         want = o.join(probe)
