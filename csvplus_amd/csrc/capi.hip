@@ -912,7 +912,7 @@ CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value
     else if (k == "scan_lookback") ctx->scan_lookback = value != 0;
     else if (k == "build_side_stream") ctx->build_side_stream = value != 0;
     else if (k == "stats_sample") ctx->stats_sample = value != 0;
-    else if (k == "direct_sort") ctx->direct_sort = value < 0 || value > 3 ? 1 : (int)value;   // 3: without the partition pass (A/B)
+    else if (k == "direct_sort") ctx->direct_sort = value < 0 || value > 2 ? 1 : (int)value;   // 2: with a partition pass first (A/B)
     else if (k == "chain_arith") ctx->chain_arith = value != 0;
     else if (k == "chain_identity") ctx->chain_identity = value != 0;
     else if (k == "probe_hash_rows") ctx->probe_hash_rows = value == 4 ? 4 : 2;

@@ -748,11 +748,13 @@ Status direct_sort_distinct(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uin
                             uint32_t* flag) {
     if (n == 0) return {};
     const unsigned grid = grid_for(n / 4 + 1, 256, 16384);
-    // Slots beyond what an L2 holds: a random 4-byte store per row runs at the chip's L2-miss rate (62 G stores/s measured: 1e8
-    // rows 1.6 ms, as long as three radix passes).  One radix pass on the TOP 8 bits of the codes first (16 streaming bytes per
-    // row) makes the stores local.
+    // A random 4-byte store per row runs at 62 G stores/s on this chip (1e8 rows: 1.6 ms — as long as three radix passes, but
+    // without their histograms, scans and duplicate scan).  ctx option direct_sort = 2 partitions the pairs by the TOP 8 bits of
+    // the codes first (one radix pass), so that neighbouring stores fall into one L2-sized window of the slots: the stores then
+    // run twice as fast (1e7 rows: 0.083 against 0.170 ms) and the pass costs what they save (0.10 ms) — measured, kept as an
+    // A/B switch, not the default (profiles/r04_direct_sort.txt).
     DevBuf part_codes, part_rows, counts;
-    const bool two_level = ctx->direct_sort >= 1 && ctx->direct_sort != 3 && states * sizeof(uint32_t) > (2u << 20) && n >= (1u << 20);
+    const bool two_level = ctx->direct_sort == 2 && states * sizeof(uint32_t) > (2u << 20) && n >= (1u << 20);
     if (two_level) {
         int bits = 0;
         while (bits < 32 && (1ull << bits) < states) bits++;

@@ -633,9 +633,13 @@ def test_direct_sort_of_distinct_keys_over_a_dense_code_space(ctx, shape):
     col = StrCol.from_arrays(np.frombuffer(raw.tobytes(), np.uint8).copy(), np.arange(len(ids) + 1, dtype=np.uint32) * width, fixed_width=width)
     o = orc.OracleIndex([col])
     unique = shape != "not_unique_call"
+    ctx.set_option("direct_sort", 2 if shape.startswith("two_level") else 1)   # 2: the variant with a partition pass first (A/B switch)
     ctx.profile(True)
     ctx.profile_read(reset=True)
-    g = DeviceIndex(ctx, [col], unique=unique)
+    try:
+        g = DeviceIndex(ctx, [col], unique=unique)
+    finally:
+        ctx.set_option("direct_sort", 1)
     prof = ctx.profile_read(reset=True)
     ctx.profile(False)
     took_direct, took_radix = "k_direct_scatter" in prof, "k_radix_scatter_u32" in prof
