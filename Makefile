@@ -13,14 +13,14 @@ LIBDIR  = csvplus_amd/lib
 CSRC    = csvplus_amd/csrc
 HIP_SRCS = $(CSRC)/capi.hip $(CSRC)/keycodec.hip $(CSRC)/radix_sort.hip $(CSRC)/probe.hip $(CSRC)/chain.hip $(CSRC)/stream_join.hip $(CSRC)/materialize.hip $(CSRC)/csv_ingest.hip $(CSRC)/index_ops.hip $(CSRC)/dist.hip $(CSRC)/calibrate.hip $(CSRC)/small_build.hip $(CSRC)/host_encode.hip
 HIP_OBJS = $(patsubst $(CSRC)/%.hip,$(LIBDIR)/obj/%.o,$(HIP_SRCS))
-HIP_HDRS = $(CSRC)/cph_internal.hpp $(CSRC)/device_utils.hpp $(CSRC)/codec_device.hpp $(CSRC)/probe_device.hpp $(CSRC)/hash_device.hpp $(CSRC)/lds_stage.hpp include/csvplus_hip.h
+HIP_HDRS = $(CSRC)/cph_internal.hpp $(CSRC)/device_utils.hpp $(CSRC)/codec_device.hpp $(CSRC)/probe_device.hpp $(CSRC)/hash_device.hpp $(CSRC)/lds_stage.hpp $(CSRC)/host_encode_kernels.hpp include/csvplus_hip.h
 
 all: hip datagen oracle host
 
 hip: $(LIBDIR)/libcsvplus_hip.so
 datagen: $(LIBDIR)/libcph_datagen.so
 oracle: oracle/_build/liboracle.so oracle/_build/libfaithful.so
-host: tests/cpp/test_host tests/c/abi_demo tests/c/libnccl_standin.so
+host: tests/cpp/test_host tests/cpp/test_host_encode tests/c/abi_demo tests/c/libnccl_standin.so
 
 $(LIBDIR)/obj/%.o: $(CSRC)/%.hip $(HIP_HDRS)
 	@mkdir -p $(LIBDIR)/obj
@@ -43,6 +43,10 @@ oracle/_build/libfaithful.so: oracle/faithful.cpp
 
 tests/cpp/test_host: tests/cpp/test_host.cpp csvplus_amd/host/csvplus.hpp include/csvplus_hip.h $(LIBDIR)/libcsvplus_hip.so
 	$(CXX) -O2 -std=c++17 -Wall -Iinclude -Icsvplus_amd/host $< -L$(LIBDIR) -lcsvplus_hip -Wl,-rpath,'$$ORIGIN/../../csvplus_amd/lib' -o $@
+
+# the host-side key encoder's loops and worker pool on their own (CPU only)
+tests/cpp/test_host_encode: tests/cpp/test_host_encode.cpp $(CSRC)/host_encode_kernels.hpp
+	$(CXX) -O2 -std=c++17 -Wall -pthread $< -o $@
 
 tests/c/abi_demo: tests/c/abi_demo.c include/csvplus_hip.h $(LIBDIR)/libcsvplus_hip.so
 	$(CC) -O2 -std=c99 -Wall -Wextra -Iinclude $< -L$(LIBDIR) -lcsvplus_hip -Wl,-rpath,'$$ORIGIN/../../csvplus_amd/lib' -o $@

@@ -8,15 +8,14 @@
 // (a byte outside an alphabet, a value longer than the longest index key) gets CPH_CODE_ABSENT and joins nothing, exactly
 // like the device encode's invalid flag.
 //
-// The encoder owns a small pool of worker threads (the loop is per row and embarrassingly parallel; one host thread does
-// ~0.1-0.3 G rows/s, the PCIe link needs ~5): cph_host_encoder_run cuts the chunk into one range per thread.
-#include <atomic>
-#include <condition_variable>
-#include <mutex>
+// The loops and the worker pool live in host_encode_kernels.hpp (no HIP types: tested on their own on CPU): 8-byte decimal ids
+// take 1 ns per row and thread (AVX2: bytewise range check + pmaddubsw / pmaddwd), short variable-length ids 4 ns (one 8-byte
+// load, positions unrolled), anything else the plain LUT walk; cph_host_encoder_run hands 65 536-row blocks of the chunk to
+// the pool's workers and to the calling thread.
 #include <new>
-#include <thread>
 
 #include "codec_device.hpp"
+#include "host_encode_kernels.hpp"
 
 using namespace cph;
 
@@ -25,97 +24,14 @@ struct cph_host_encoder {
     int32_t ncols = 0, npos = 0;
     int32_t col_start[kMaxKeyCols + 1] = {0};
     int32_t col_maxlen[kMaxKeyCols] = {0};
-    ArithPlan arith{};                   // one column of 8-byte fixed-width values over contiguous alphabets: no table at all
-    uint32_t arith_mult[8] = {0};
-    // worker pool
-    std::vector<std::thread> workers;
-    std::mutex mu;
-    std::condition_variable cv_job, cv_done;
-    uint64_t generation = 0;
-    int pending = 0;
-    bool quit = false;
-    const cph_strcol* job_cols = nullptr;
-    uint32_t* job_out = nullptr;
-    uint64_t job_rows = 0;
-    std::string err;
+    bool arith = false, arith_vector = false;   // one column of 8-byte fixed-width values over contiguous alphabets: no table at all
+    cph_host::Arith8 arith8{};
+    std::unique_ptr<cph_host::BlockPool> pool;
+    std::mutex run_mu;                   // one job at a time
 };
 
-namespace {
-
-inline uint64_t load_off(const cph_strcol& c, uint64_t i) {
-    return c.offset_bits == 32 ? (uint64_t) reinterpret_cast<const uint32_t*>(c.offsets)[i] : reinterpret_cast<const uint64_t*>(c.offsets)[i];
-}
-
-void encode_range(const cph_host_encoder* e, const cph_strcol* cols, uint64_t r0, uint64_t r1, uint32_t* out) {
-    if (e->arith.enabled && cols[0].fixed_width == 8) {
-        const ArithPlan& ap = e->arith;
-        const uint64_t lo = (uint64_t)ap.lo[0] | ((uint64_t)ap.lo[1] << 32), rngc = (uint64_t)ap.rngc[0] | ((uint64_t)ap.rngc[1] << 32);
-        const uint8_t* d = cols[0].data;
-        for (uint64_t r = r0; r < r1; r++) {
-            uint64_t x;
-            memcpy(&x, d + 8 * r, 8);
-            // bytewise range check without carries between the bytes of a key that can be in the index (codec_device.hpp)
-            const uint64_t z = x - lo, t = z + rngc;
-            if ((x | z | t) & 0x8080808080808080ull) { out[r] = CPH_CODE_ABSENT; continue; }
-            uint32_t code = 0;
-            for (int p = 0; p < 8; p++) code += (uint32_t)((z >> (8 * p)) & 0xFFu) * e->arith_mult[p];
-            out[r] = code;
-        }
-        return;
-    }
-    const uint32_t* lutw = e->lutw.data();
-    for (uint64_t r = r0; r < r1; r++) {
-        uint32_t acc = 0, bad = 0;
-        for (int c = 0; c < e->ncols; c++) {
-            const cph_strcol& col = cols[c];
-            uint64_t b, l;
-            if (col.fixed_width) {
-                b = r * (uint64_t)col.fixed_width;
-                l = col.fixed_width;
-            } else {
-                b = load_off(col, r);
-                l = load_off(col, r + 1) - b;
-            }
-            const int maxlen = e->col_maxlen[c];
-            if (l > (uint64_t)maxlen) { bad = 0x80000000u; break; }
-            const uint32_t* lp = lutw + (size_t)e->col_start[c] * kLutStride;
-            const uint8_t* v = col.data + b;
-            int q = 0;
-            for (; q < (int)l; q++) {
-                const uint32_t w = lp[(size_t)q * kLutStride + 1u + v[q]];
-                bad |= w;
-                acc += w;
-            }
-            for (; q < maxlen; q++) {   // the value ended: the pad symbol
-                const uint32_t w = lp[(size_t)q * kLutStride];
-                bad |= w;
-                acc += w;
-            }
-        }
-        out[r] = (bad >> 31) ? CPH_CODE_ABSENT : acc;
-    }
-}
-
-void worker_main(cph_host_encoder* e, int me, int nworkers) {
-    uint64_t seen = 0;
-    for (;;) {
-        std::unique_lock<std::mutex> lk(e->mu);
-        e->cv_job.wait(lk, [&] { return e->quit || e->generation != seen; });
-        if (e->quit) return;
-        seen = e->generation;
-        const cph_strcol* cols = e->job_cols;
-        uint32_t* out = e->job_out;
-        const uint64_t n = e->job_rows;
-        lk.unlock();
-        const uint64_t per = (n + (uint64_t)nworkers - 1) / (uint64_t)nworkers;
-        const uint64_t r0 = std::min<uint64_t>(n, per * (uint64_t)me), r1 = std::min<uint64_t>(n, r0 + per);
-        if (r1 > r0) encode_range(e, cols, r0, r1, out);
-        lk.lock();
-        if (--e->pending == 0) e->cv_done.notify_all();
-    }
-}
-
-}  // namespace
+static_assert(cph_host::kLutRow == kLutStride, "the host loops walk the device's LUT layout");
+static_assert(cph_host::kCodeAbsent == CPH_CODE_ABSENT, "one ABSENT code");
 
 extern "C" {
 
@@ -139,22 +55,26 @@ CPH_API int32_t cph_host_encoder_create(const cph_index* ix, int32_t nthreads, c
             const uint16_t r = cd.lut[i];
             e->lutw[i] = r == kLutInvalid ? 0x80000000u : (uint32_t)((uint64_t)r * cd.mult[i / kLutStride]);
         }
-        codec_arith_plan(cd, &e->arith);
-        if (e->arith.enabled && e->arith.keylen == 8)
-            for (int p = 0; p < 8; p++) e->arith_mult[p] = (uint32_t)cd.mult[(size_t)p];
-        else
-            e->arith.enabled = 0;
-        int nt = nthreads > 0 ? nthreads : (int)std::thread::hardware_concurrency();
+        ArithPlan ap{};
+        codec_arith_plan(cd, &ap);
+        if (ap.enabled && ap.keylen == 8 && cd.ncols == 1) {
+            e->arith = true;
+            e->arith8.lo = (uint64_t)ap.lo[0] | ((uint64_t)ap.lo[1] << 32);
+            e->arith8.rngc = (uint64_t)ap.rngc[0] | ((uint64_t)ap.rngc[1] << 32);
+            for (int p = 0; p < 8; p++) {
+                e->arith8.mult[p] = (uint32_t)cd.mult[(size_t)p];
+                e->arith8.radix[p] = 0x80u - (uint32_t)((e->arith8.rngc >> (8 * p)) & 0xFFu);   // rngc byte = 0x7F - (radix - 1)
+            }
+            e->arith_vector = cph_host::arith8_vector_ok(e->arith8);
+        }
+        // workers: the loops are memory-bound well before every hardware thread is busy, and idle workers spin for a moment
+        // before they sleep — half the hardware threads, at most 64 (+ the calling thread, which takes blocks too)
+        int nt = nthreads > 0 ? nthreads : (int)std::thread::hardware_concurrency() / 2;
         if (nt < 1) nt = 1;
         if (nt > 256) nt = 256;
-        for (int i = 0; i < nt; i++) e->workers.emplace_back(worker_main, e, i, nt);
+        if (nthreads <= 0 && nt > 64) nt = 64;
+        e->pool.reset(new cph_host::BlockPool(nt - 1));
     } catch (const std::exception& ex) {
-        {
-            std::lock_guard<std::mutex> lk(e->mu);
-            e->quit = true;
-        }
-        e->cv_job.notify_all();
-        for (auto& t : e->workers) t.join();
         delete e;
         return fail_with(ctx, {CPH_ERR_NOMEM, std::string("cph_host_encoder_create: ") + ex.what()});
     }
@@ -162,7 +82,7 @@ CPH_API int32_t cph_host_encoder_create(const cph_index* ix, int32_t nthreads, c
     return CPH_OK;
 }
 
-CPH_API int32_t cph_host_encoder_threads(const cph_host_encoder* e) { return e ? (int32_t)e->workers.size() : 0; }
+CPH_API int32_t cph_host_encoder_threads(const cph_host_encoder* e) { return e && e->pool ? e->pool->workers() + 1 : 0; }
 
 // cols = the stream's key columns for the index (ALL its key columns, host memory), out_codes = nrows u32 (any host
 // memory; pinned — cph_pinned_alloc — when cph_stream_join_submit_codes is to overlap its upload).  Blocks until done.
@@ -175,26 +95,30 @@ CPH_API int32_t cph_host_encoder_run(cph_host_encoder* e, const cph_strcol* cols
             return CPH_ERR_INVALID;
     }
     if (n == 0) return CPH_OK;
-    std::unique_lock<std::mutex> lk(e->mu);
-    e->job_cols = cols;
-    e->job_out = out_codes;
-    e->job_rows = n;
-    e->pending = (int)e->workers.size();
-    e->generation++;
-    e->cv_job.notify_all();
-    e->cv_done.wait(lk, [&] { return e->pending == 0; });
+    cph_host::HostCol hc[kMaxKeyCols];
+    for (int c = 0; c < ncols; c++) {
+        hc[c].data = cols[c].data;
+        hc[c].offsets = cols[c].offsets;
+        hc[c].offset_bits = cols[c].offset_bits;
+        hc[c].fixed_width = cols[c].fixed_width;
+        // readable bytes = up to the end of the chunk's last value (the caller's buffer may end right there)
+        hc[c].data_bytes = cols[c].fixed_width ? n * (uint64_t)cols[c].fixed_width : cph_host::col_offset(hc[c], n);
+    }
+    std::lock_guard<std::mutex> lk(e->run_mu);
+    if (e->arith && hc[0].fixed_width == 8) {
+        const uint8_t* d = hc[0].data;
+        if (e->arith_vector) e->pool->run(n, [&](uint64_t r0, uint64_t r1) { cph_host::encode_arith8_avx2(e->arith8, d, r0, r1, out_codes); });
+        else e->pool->run(n, [&](uint64_t r0, uint64_t r1) { cph_host::encode_arith8(e->arith8, d, r0, r1, out_codes); });
+    } else if (ncols == 1 && e->npos <= 8) {
+        e->pool->run(n, [&](uint64_t r0, uint64_t r1) { cph_host::encode_lut_short(e->lutw.data(), e->npos, hc[0], r0, r1, out_codes); });
+    } else {
+        e->pool->run(n, [&](uint64_t r0, uint64_t r1) {
+            cph_host::encode_lut(e->lutw.data(), e->ncols, e->col_start, e->col_maxlen, hc, r0, r1, out_codes);
+        });
+    }
     return CPH_OK;
 }
 
-CPH_API void cph_host_encoder_destroy(cph_host_encoder* e) {
-    if (!e) return;
-    {
-        std::lock_guard<std::mutex> lk(e->mu);
-        e->quit = true;
-    }
-    e->cv_job.notify_all();
-    for (auto& t : e->workers) t.join();
-    delete e;
-}
+CPH_API void cph_host_encoder_destroy(cph_host_encoder* e) { delete e; }
 
 }  // extern "C"

@@ -1,0 +1,208 @@
+// The host-side key encoder's loops and worker pool (csvplus_amd/csrc/host_encode_kernels.hpp) on their own: the short-key
+// and arithmetic loops against the plain LUT walk on random columns (bytes outside the alphabets, values that are too long,
+// empty values, the last values of a buffer without slack), the pool over many job sizes, and a rate print.
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <random>
+#include <string>
+
+#include "../../csvplus_amd/csrc/host_encode_kernels.hpp"
+
+using namespace cph_host;
+
+static int failures = 0;
+#define CHECK(cond)                                                  \
+    do {                                                             \
+        if (!(cond)) {                                               \
+            failures++;                                              \
+            fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+        }                                                            \
+    } while (0)
+
+// a random codec over npos positions: per position an alphabet (plus the END symbol from position minlen on), mixed-radix weights
+struct Codec {
+    int npos, minlen;
+    std::vector<uint32_t> lut;   // [npos][257], top bit = absent
+};
+static Codec make_codec(std::mt19937_64& rng, int npos, int minlen, const std::string& alphabet) {
+    Codec c{npos, minlen, std::vector<uint32_t>((size_t)npos * kLutRow, 0x80000000u)};
+    std::vector<uint32_t> radix((size_t)npos);
+    std::vector<std::vector<int>> syms((size_t)npos);
+    for (int p = 0; p < npos; p++) {
+        if (p >= minlen) syms[p].push_back(0);
+        for (char ch : alphabet)
+            if (rng() % 4 != 0 || syms[p].size() < 2) syms[p].push_back(1 + (unsigned char)ch);
+        std::sort(syms[p].begin(), syms[p].end());
+        syms[p].erase(std::unique(syms[p].begin(), syms[p].end()), syms[p].end());
+        radix[p] = (uint32_t)syms[p].size();
+    }
+    uint64_t w = 1;
+    for (int p = npos - 1; p >= 0; p--) {
+        for (size_t k = 0; k < syms[p].size(); k++) c.lut[(size_t)p * kLutRow + syms[p][k]] = (uint32_t)(k * w);
+        w *= radix[p];
+    }
+    CHECK(w < (1ull << 31));
+    return c;
+}
+
+static void test_short_against_walk() {
+    std::mt19937_64 rng(7);
+    for (int round = 0; round < 40; round++) {
+        const int npos = 1 + (int)(rng() % 8), minlen = (int)(rng() % (npos + 1));
+        const Codec c = make_codec(rng, npos, minlen, "0123456789");
+        const uint64_t n = 1 + rng() % 5000;
+        std::vector<uint8_t> data;
+        std::vector<uint32_t> off{0};
+        for (uint64_t r = 0; r < n; r++) {
+            int l = (int)(rng() % (npos + 2));                      // sometimes too long, sometimes empty
+            for (int q = 0; q < l; q++) data.push_back(rng() % 23 == 0 ? (uint8_t)(rng() & 0xFF) : (uint8_t)('0' + rng() % 10));
+            off.push_back((uint32_t)data.size());
+        }
+        HostCol col{data.data(), off.data(), 32, 0, data.size()};   // NO slack behind the last value
+        std::vector<uint32_t> a(n), b(n);
+        const int32_t start[2] = {0, npos}, maxlen[1] = {npos};
+        encode_lut(c.lut.data(), 1, start, maxlen, &col, 0, n, a.data());
+        encode_lut_short(c.lut.data(), npos, col, 0, n, b.data());
+        CHECK(a == b);
+        uint64_t present = 0;
+        for (uint32_t x : a) present += x != kCodeAbsent;
+        CHECK(present > 0 || n < 20);
+        // the same column with 64-bit offsets, and a middle range only
+        std::vector<uint64_t> off64(off.begin(), off.end());
+        HostCol col64{data.data(), off64.data(), 64, 0, data.size()};
+        std::vector<uint32_t> c2(n, 12345u);
+        encode_lut_short(c.lut.data(), npos, col64, n / 3, n, c2.data());
+        for (uint64_t r = 0; r < n; r++) CHECK(c2[r] == (r < n / 3 ? 12345u : a[r]));
+    }
+}
+
+static int vector_rounds = 0;
+static void test_arith_against_walk() {
+    std::mt19937_64 rng(11);
+    for (int round = 0; round < 20; round++) {
+        // 8 positions, contiguous ranges [lo_p, lo_p + r_p)
+        Arith8 ar{};
+        Codec c{8, 8, std::vector<uint32_t>((size_t)8 * kLutRow, 0x80000000u)};
+        uint32_t radix[8], lo[8];
+        for (int p = 0; p < 8; p++) {
+            radix[p] = round == 0 ? 10 : 1 + (uint32_t)(rng() % 12);
+            lo[p] = round == 0 ? '0' : 33 + (uint32_t)(rng() % 60);
+        }
+        uint64_t w = 1;
+        for (int p = 7; p >= 0; p--) {
+            ar.mult[p] = (uint32_t)w;
+            ar.radix[p] = radix[p];
+            for (uint32_t k = 0; k < radix[p]; k++) c.lut[(size_t)p * kLutRow + 1 + lo[p] + k] = (uint32_t)(k * w);
+            ar.lo |= (uint64_t)lo[p] << (8 * p);
+            ar.rngc |= (uint64_t)(0x7F - (radix[p] - 1)) << (8 * p);
+            w *= radix[p];
+        }
+        if (w >= (1ull << 31)) continue;
+        const uint64_t n = 20000;
+        std::vector<uint8_t> data(8 * n);
+        for (uint64_t r = 0; r < n; r++)
+            for (int p = 0; p < 8; p++) {
+                const uint32_t k = rng() % 29 == 0 ? (uint32_t)(rng() & 0xFF) : lo[p] + (uint32_t)(rng() % radix[p]);
+                data[8 * r + p] = (uint8_t)k;
+            }
+        HostCol col{data.data(), nullptr, 32, 8, data.size()};
+        std::vector<uint32_t> a(n), b(n);
+        const int32_t start[2] = {0, 8}, maxlen[1] = {8};
+        encode_lut(c.lut.data(), 1, start, maxlen, &col, 0, n, a.data());
+        encode_arith8(ar, data.data(), 0, n, b.data());
+        CHECK(a == b);
+#if defined(__x86_64__)
+        if (arith8_vector_ok(ar)) {
+            std::vector<uint32_t> v(n, 7u);
+            encode_arith8_avx2(ar, data.data(), 3, n - 2, v.data());      // unaligned start, a scalar tail
+            for (uint64_t r = 0; r < n; r++) CHECK(v[r] == (r < 3 || r >= n - 2 ? 7u : a[r]));
+            vector_rounds++;
+        }
+#endif
+    }
+    CHECK(vector_rounds > 0 || !__builtin_cpu_supports("avx2"));
+}
+
+static void test_pool_and_rate() {
+    const int hw = (int)std::thread::hardware_concurrency();
+    BlockPool pool(hw > 1 ? hw - 1 : 0);
+    std::mt19937_64 rng(3);
+    for (uint64_t n : {(uint64_t)1, (uint64_t)65535, (uint64_t)65536, (uint64_t)65537, (uint64_t)1000003, (uint64_t)5}) {
+        for (int rep = 0; rep < 30; rep++) {
+            std::vector<uint8_t> hit(n, 0);
+            pool.run(n, [&](uint64_t r0, uint64_t r1) {
+                for (uint64_t r = r0; r < r1; r++) hit[r]++;
+            });
+            bool ok = true;
+            for (uint8_t h : hit) ok = ok && h == 1;
+            CHECK(ok);
+        }
+    }
+    // rate: 2^23-row chunks of 8-byte decimal ids (the benchmark's customer ids), fork-join per chunk as the stream join does
+    const uint64_t n = 1u << 23;
+    std::vector<uint8_t> data(8 * n);
+    for (uint64_t r = 0; r < n; r++) {
+        char b[16];
+        snprintf(b, sizeof b, "%08llu", (unsigned long long)(rng() % 10000000));
+        memcpy(&data[8 * r], b, 8);
+    }
+    Arith8 ar{};
+    uint64_t w = 1;
+    for (int p = 7; p >= 0; p--) {
+        ar.mult[p] = (uint32_t)w;
+        ar.radix[p] = 10;
+        ar.lo |= (uint64_t)'0' << (8 * p);
+        ar.rngc |= (uint64_t)(0x7F - 9) << (8 * p);
+        w *= 10;
+    }
+    std::vector<uint32_t> out(n);
+    for (int rep = 0; rep < 3; rep++) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int chunk = 0; chunk < 8; chunk++)
+            pool.run(n, [&](uint64_t r0, uint64_t r1) { encode_arith8(ar, data.data(), r0, r1, out.data()); });
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (rep == 2) printf("arith8: %.2f G rows/s on %d threads (8 chunks of 2^23 rows, %.2f ms per chunk)\n", 8.0 * n / s / 1e9, pool.workers() + 1, s / 8 * 1e3);
+    }
+#if defined(__x86_64__)
+    if (arith8_vector_ok(ar)) {
+        std::vector<uint32_t> ref(out);
+        for (int rep = 0; rep < 3; rep++) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int chunk = 0; chunk < 8; chunk++)
+                pool.run(n, [&](uint64_t r0, uint64_t r1) { encode_arith8_avx2(ar, data.data(), r0, r1, out.data()); });
+            const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (rep == 2) printf("arith8 avx2: %.2f G rows/s on %d threads (%.2f ms per chunk)\n", 8.0 * n / s / 1e9, pool.workers() + 1, s / 8 * 1e3);
+        }
+        CHECK(out == ref);
+    }
+#endif
+    CHECK(out[12345] != kCodeAbsent);
+    // short LUT keys (unpadded decimal ids of up to 6 digits)
+    std::vector<uint8_t> vdata;
+    std::vector<uint32_t> off{0};
+    for (uint64_t r = 0; r < n; r++) {
+        char b[16];
+        const int l = snprintf(b, sizeof b, "%llu", (unsigned long long)(rng() % 100000));
+        vdata.insert(vdata.end(), b, b + l);
+        off.push_back((uint32_t)vdata.size());
+    }
+    std::mt19937_64 r2(5);
+    const Codec c = make_codec(r2, 5, 1, "0123456789");
+    HostCol col{vdata.data(), off.data(), 32, 0, vdata.size()};
+    for (int rep = 0; rep < 3; rep++) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int chunk = 0; chunk < 8; chunk++)
+            pool.run(n, [&](uint64_t r0, uint64_t r1) { encode_lut_short(c.lut.data(), 5, col, r0, r1, out.data()); });
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (rep == 2) printf("lut_short<5>: %.2f G rows/s on %d threads (%.2f ms per chunk)\n", 8.0 * n / s / 1e9, pool.workers() + 1, s / 8 * 1e3);
+    }
+}
+
+int main() {
+    test_short_against_walk();
+    test_arith_against_walk();
+    test_pool_and_rate();
+    printf("%d host encoder checks failed\n", failures);
+    return failures ? 1 : 0;
+}

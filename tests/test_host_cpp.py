@@ -60,3 +60,12 @@ def test_plain_c_consumer_on_gpu():
     r = subprocess.run([str(C_DEMO)], capture_output=True, text=True, timeout=300)
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and "WRONG" not in r.stdout and r.stdout.count(" ok") == 4
+
+
+def test_host_encoder_loops_and_pool_on_cpu():
+    """csvplus_amd/csrc/host_encode_kernels.hpp (the loops cph_host_encoder_run runs on the host: arithmetic, AVX2, short-key LUT,
+    plain walk; the block pool) against each other on random codecs and columns — no GPU involved."""
+    subprocess.check_call(["make", "-C", str(ROOT), "tests/cpp/test_host_encode"])
+    r = subprocess.run([str(ROOT / "tests" / "cpp" / "test_host_encode")], capture_output=True, text=True, timeout=600)
+    print(r.stdout)
+    assert r.returncode == 0 and "0 host encoder checks failed" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
