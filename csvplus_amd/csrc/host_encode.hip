@@ -12,6 +12,7 @@
 // take 1 ns per row and thread (AVX2: bytewise range check + pmaddubsw / pmaddwd), short variable-length ids 4 ns (one 8-byte
 // load, positions unrolled), anything else the plain LUT walk; cph_host_encoder_run hands 65 536-row blocks of the chunk to
 // the pool's workers and to the calling thread.
+#include <chrono>
 #include <new>
 
 #include "codec_device.hpp"
@@ -65,7 +66,26 @@ CPH_API int32_t cph_host_encoder_create(const cph_index* ix, int32_t nthreads, c
                 e->arith8.mult[p] = (uint32_t)cd.mult[(size_t)p];
                 e->arith8.radix[p] = 0x80u - (uint32_t)((e->arith8.rngc >> (8 * p)) & 0xFFu);   // rngc byte = 0x7F - (radix - 1)
             }
-            e->arith_vector = cph_host::arith8_vector_ok(e->arith8);
+            // The vector loop is 6x the scalar one on the build container's Xeon and 20x SLOWER on the GPU box's host
+            // (profiles/r04_host_encode.txt: 0.92 against 18.5 G rows/s on 256 threads) — so it is not assumed, it is timed:
+            // both loops over 32 768 valid keys, the faster one serves this encoder.
+            if (cph_host::arith8_vector_ok(e->arith8)) {
+                const uint64_t n = 32768;
+                std::vector<uint8_t> keys(8 * n);
+                for (uint64_t i = 0; i < 8 * n; i++) keys[i] = (uint8_t)(e->arith8.lo >> (8 * (i & 7)));
+                std::vector<uint32_t> codes(n);
+                auto time_of = [&](bool vec) {
+                    double best = 1e9;
+                    for (int rep = 0; rep < 3; rep++) {
+                        const auto t0 = std::chrono::steady_clock::now();
+                        if (vec) cph_host::encode_arith8_avx2(e->arith8, keys.data(), 0, n, codes.data());
+                        else cph_host::encode_arith8(e->arith8, keys.data(), 0, n, codes.data());
+                        best = std::min(best, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+                    }
+                    return best;
+                };
+                e->arith_vector = time_of(true) < time_of(false);
+            }
         }
         // workers: the loops are memory-bound well before every hardware thread is busy, and idle workers spin for a moment
         // before they sleep — half the hardware threads, at most 64 (+ the calling thread, which takes blocks too)
