@@ -649,7 +649,14 @@ struct SmallResult {                          // written by k_small_build into p
     uint32_t minlen[kMaxKeyCols], maxlen[kMaxKeyCols];
     uint32_t mask[kSmallMaxPos][8];           // ColStats::mask of the positions, column-major
     uint64_t t[10];                           // wall_clock64() at the phase boundaries (ctx option codec_debug prints them)
+    uint64_t codec_check;                     // small_codec_check over the kernel's own radices and weights: the host-rebuilt codec must give the same
 };
+// Fold of a codec's per-position radices and weights (device: what k_small_build encoded and sorted by; host: what codec_build
+// rebuilt from the same statistics and what every later probe will encode by).
+CPH_HD inline uint64_t small_codec_check(uint64_t h, uint64_t radix, uint64_t mult) {
+    h = (h ^ radix) * 0x9E3779B97F4A7C15ull;
+    return (h ^ mult) * 0xC2B2AE3D27D4EB4Full + 1;
+}
 struct SmallBufs {
     DevBuf ka, kb, va, vb, sorted, perm;
 };

@@ -431,6 +431,9 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_build(const SmallArg a)
             res->bits = s_bits;
             res->key32 = s_key32;
             res->passes = (uint32_t)npass;
+            uint64_t h = 0;
+            for (int p = 0; p < npos; p++) h = small_codec_check(h, s_radix[p], s_mult[p]);
+            res->codec_check = h;
         }
         __threadfence_system();
         if (lane == 0) res->status = kSmallBuilt;
@@ -492,8 +495,14 @@ Status small_build_finish(cph_ctx* ctx, cph_index* ix, int32_t ncols, SmallBufs*
         p0 += s.maxlen;
     }
     CPH_TRY(codec_build(stats, &ix->codec));
-    if (ix->codec.nwords != 1 || (ix->codec.key32 ? 1u : 0u) != res->key32 || (uint32_t)ix->codec.word_bits[0] != res->bits) {
-        *not_small = true;   // cannot happen (same construction on both sides); the general path is always right
+    uint64_t check = 0;
+    for (int p = 0; p < ix->codec.npos && ix->codec.nwords == 1; p++) check = small_codec_check(check, ix->codec.radix[(size_t)p], ix->codec.mult[(size_t)p]);
+    if (ix->codec.nwords != 1 || (ix->codec.key32 ? 1u : 0u) != res->key32 || (uint32_t)ix->codec.word_bits[0] != res->bits ||
+        check != res->codec_check) {
+        // cannot happen (same construction on both sides) — but if the two ever drift, the sorted codes and every later probe
+        // would disagree silently: the general path is always right
+        *not_small = true;
+        ix->codec = CodecHost{};
         return {};
     }
     CPH_TRY(codec_upload(ctx, ix->codec, &ix->codec_dev));

@@ -11,10 +11,11 @@ from csvplus_amd import datagen as dg
 from csvplus_amd.engine import Engine
 
 eng = Engine(0)
+eng.ctx.set_option("direct_sort", 0)   # the radix path is what is measured here (UniqueIndexOn over dense ids would take one scatter)
 cols = {"1e8 fixed8": (dg.column(dg.SEQ_PERM, 100_000_000, 100_000_000, encoding=dg.FIXED8, seed=7).to_device(eng.device), True),
         "1e7 fixed8": (dg.column(dg.SEQ_PERM, 10_000_000, 10_000_000, encoding=dg.FIXED8, seed=7).to_device(eng.device), True),
         "1e8 varkeys": (dg.varkeys(100_000_000).to_device(eng.device), False)}
-for rep in range(2):
+for rep in range(1):
     for rbits, threads in ((0, 0), (8, 256), (9, 256), (9, 512), (8, 512)):
         eng.ctx.set_option("sort_rbits", rbits)
         eng.ctx.set_option("sort_threads", threads)
