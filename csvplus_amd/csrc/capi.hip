@@ -751,8 +751,14 @@ static Status build_encode_sort(cph_ctx* ctx, BuildJob* job) {
                 CPH_TRY(job->split_miss.alloc(&ctx->pool, sizeof(uint32_t)));
                 CPH_HIP_TRY(hipMemsetAsync(job->split_miss.get(), 0, sizeof(uint32_t), ctx->stream));
             }
+            if (states == n && ctx->direct_sort == 1) {   // a full code space: the encode kernel fills the slots itself when it can (no code array)
+                CPH_HIP_TRY(hipMemsetAsync(va.get(), 0xFF, n * sizeof(uint32_t), ctx->stream));
+                eh.slots = va.as<uint32_t>();
+                eh.slot_states = (uint32_t)states;
+            }
             CPH_TRY(codec_encode_build(ctx, cd, ix->codec_dev, dcols, n, ka.get(), &eh, nullptr, job->split_miss.as<uint32_t>()));
-            CPH_TRY(direct_sort_distinct(ctx, ka.as<uint32_t>(), n, states, va.as<uint32_t>(), ka.as<uint32_t>(), job->split_miss.as<uint32_t>()));
+            if (eh.scattered) CPH_TRY(direct_sort_finish_full(ctx, va.as<uint32_t>(), n, ka.as<uint32_t>(), job->split_miss.as<uint32_t>()));
+            else CPH_TRY(direct_sort_distinct(ctx, ka.as<uint32_t>(), n, states, va.as<uint32_t>(), ka.as<uint32_t>(), job->split_miss.as<uint32_t>()));
             ix->sorted_codes = std::move(ka);
             ix->perm = std::move(va);
             ix->sort_passes = 0;
@@ -912,7 +918,7 @@ CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value
     else if (k == "scan_lookback") ctx->scan_lookback = value != 0;
     else if (k == "build_side_stream") ctx->build_side_stream = value != 0;
     else if (k == "stats_sample") ctx->stats_sample = value != 0;
-    else if (k == "direct_sort") ctx->direct_sort = value < 0 || value > 2 ? 1 : (int)value;   // 2: with a partition pass first (A/B)
+    else if (k == "direct_sort") ctx->direct_sort = value < 0 || value > 3 ? 1 : (int)value;   // 2: with a partition pass first, 3: without the fused encode (A/B)
     else if (k == "chain_arith") ctx->chain_arith = value != 0;
     else if (k == "chain_identity") ctx->chain_identity = value != 0;
     else if (k == "probe_hash_rows") ctx->probe_hash_rows = value == 4 ? 4 : 2;

@@ -523,6 +523,12 @@ struct EncodeHist {
     uint32_t bins = 0;            // digits per pass of the sort (256 or 512 >= digit_mask + 1)
     uint32_t* counts = nullptr;   // device [bins][ntiles], digit-major
     bool done = false;
+    // Direct sort of distinct keys over a FULL code space (radix_sort.hip): instead of writing the codes, the encode kernel stores
+    // slot[code] = row straight away (slots: device u32[states], preset to 0xFFFFFFFF).  scattered = the kernel that ran did so
+    // (only the single-column fast path can); otherwise the codes were written as usual.
+    uint32_t* slots = nullptr;
+    uint32_t slot_states = 0;
+    bool scattered = false;
 };
 // cols = the TABLE's key columns (a split codec's virtual columns are formed inside).  miss (optional, device u32): set
 // when a row did not code (split codecs only: see codec_try_split).
@@ -558,6 +564,8 @@ Status radix_sort_pairs(cph_ctx* ctx, K* keys_a, K* keys_b, uint32_t* vals_a, ui
 // distinct 32-bit codes over a dense space: one scatter instead of radix passes (optimistic; *flag raised on a duplicate)
 Status direct_sort_distinct(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out, uint32_t* sorted_out,
                             uint32_t* flag);
+// the second half of it for a full code space whose slots the encode kernel already filled: every slot taken? + the sorted codes
+Status direct_sort_finish_full(cph_ctx* ctx, const uint32_t* slots, uint64_t n, uint32_t* sorted_out, uint32_t* flag);
 Status exclusive_scan_u32(cph_ctx* ctx, uint32_t* data, uint64_t n);
 Status exclusive_scan_u32_total(cph_ctx* ctx, uint32_t* data, uint64_t n, uint32_t* total_out);   // total_out: device
 Status exclusive_scan_u64(cph_ctx* ctx, uint64_t* data, uint64_t n, uint64_t* total_out);

@@ -1721,7 +1721,8 @@ template <class W, class OUT, class B, bool LONG>
 __global__ __launch_bounds__(kEncodeThreads) void k_encode_build_fast(DevCol col, const uint8_t* __restrict__ g_codec,
                                                                      uint64_t n, OUT* __restrict__ out, uint32_t tile_rows,
                                                                      uint32_t ntiles, uint32_t* __restrict__ counts,
-                                                                     uint32_t digit_mask, uint32_t bins, int codec_bytes, uint32_t* __restrict__ miss) {
+                                                                     uint32_t digit_mask, uint32_t bins, int codec_bytes, uint32_t* __restrict__ miss,
+                                                                     uint32_t* __restrict__ slots, uint32_t slot_states) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const CodecView cv = codec_load_to_lds(g_codec, smem);
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + codec_bytes);   // [bins], only when counts != nullptr
@@ -1758,6 +1759,10 @@ __global__ __launch_bounds__(kEncodeThreads) void k_encode_build_fast(DevCol col
 #pragma unroll
             for (int k = 0; k < kEncodeFastRows; k++) {
                 if ((wr.okm >> k) & 1u) {
+                    if (slots) {   // direct sort over a full code space: the row goes straight to its slot, no code array
+                        if (((okm >> k) & 1u) && (uint32_t)code[k] < slot_states) slots[(uint32_t)code[k]] = (uint32_t)(wr.rbase + wr.rel[k]);
+                        continue;
+                    }
                     (out + wr.rbase)[wr.rel[k]] = code[k];
                     if (counts) atomicAdd(&s_hist[(uint32_t)code[k] & digit_mask], 1u);
                 }
@@ -1978,8 +1983,10 @@ Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec
         const uint8_t* blob = codec_dev.as<uint8_t>();
         const bool narrow = col_is_narrow(cols[0]);
         const bool long_keys = cd.col_maxlen[0] > 8;
-        using Fn32 = void (*)(DevCol, const uint8_t*, uint64_t, uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t, uint32_t, int, uint32_t*);
-        using Fn64 = void (*)(DevCol, const uint8_t*, uint64_t, uint64_t*, uint32_t, uint32_t, uint32_t*, uint32_t, uint32_t, int, uint32_t*);
+        using Fn32 = void (*)(DevCol, const uint8_t*, uint64_t, uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t, uint32_t, int, uint32_t*, uint32_t*, uint32_t);
+        using Fn64 = void (*)(DevCol, const uint8_t*, uint64_t, uint64_t*, uint32_t, uint32_t, uint32_t*, uint32_t, uint32_t, int, uint32_t*, uint32_t*, uint32_t);
+        uint32_t* slots = hist && cd.key32 ? hist->slots : nullptr;
+        const uint32_t slot_states = slots ? hist->slot_states : 0u;
         int per_cu = 1, cus = 256;
         CPH_TRY(device_cus(ctx, &cus));
         ProfScope ps(ctx, "k_encode_build", 4.0 * (double)bins * (double)ntiles);
@@ -1988,7 +1995,7 @@ Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec
             unsigned grid = (unsigned)std::min<uint64_t>(ntiles64, (uint64_t)cus * (uint64_t)per_cu);
             grid = (grid + 7u) & ~7u;   // the kernel splits its tiles over blockIdx % 8
             hipLaunchKernelGGL(fn, dim3(grid), dim3(kEncodeThreads), lds, ctx->stream, cols[0], blob, n, out, tile_rows, ntiles,
-                               want_hist ? hist->counts : nullptr, mask, bins, (int)codec_bytes, miss);
+                               want_hist ? hist->counts : nullptr, mask, bins, (int)codec_bytes, miss, slots, slot_states);
             return {};
         };
         if (cd.key32) {
@@ -2006,7 +2013,10 @@ Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec
             CPH_TRY(launch(fn, o));
         }
         CPH_HIP_TRY(hipGetLastError());
-        if (hist) const_cast<EncodeHist*>(hist)->done = want_hist;
+        if (hist) {
+            const_cast<EncodeHist*>(hist)->done = want_hist;
+            const_cast<EncodeHist*>(hist)->scattered = slots != nullptr;
+        }
         return {};
     }
     if (hist) const_cast<EncodeHist*>(hist)->done = false;

@@ -741,6 +741,14 @@ template Status radix_sort_pairs<uint32_t>(cph_ctx*, uint32_t*, uint32_t*, uint3
 template Status radix_sort_pairs<uint64_t>(cph_ctx*, uint64_t*, uint64_t*, uint32_t*, uint32_t*, bool, uint64_t, int,
                                            uint64_t**, uint32_t**, int*, uint32_t*, bool);
 
+Status direct_sort_finish_full(cph_ctx* ctx, const uint32_t* slots, uint64_t n, uint32_t* sorted_out, uint32_t* flag) {
+    if (n == 0) return {};
+    ProfScope ps(ctx, "k_direct_finish", 8.0 * (double)n);
+    hipLaunchKernelGGL(k_direct_check_iota, dim3(grid_for(n, 256, 8192)), dim3(256), 0, ctx->stream, slots, n, sorted_out, flag);
+    CPH_HIP_TRY(hipGetLastError());
+    return {};
+}
+
 // codes[n] (32-bit, below `states`) -> perm_out[n] (rows in code order), sorted_out[n] (the codes in order); *flag (device,
 // zeroed by the caller) is raised when two rows share a code — the outputs are then meaningless.  codes and sorted_out may be
 // the same buffer.  scratch: states == n needs none (perm_out holds the slots).
