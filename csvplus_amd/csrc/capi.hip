@@ -751,7 +751,10 @@ static Status build_encode_sort(cph_ctx* ctx, BuildJob* job) {
                 CPH_TRY(job->split_miss.alloc(&ctx->pool, sizeof(uint32_t)));
                 CPH_HIP_TRY(hipMemsetAsync(job->split_miss.get(), 0, sizeof(uint32_t), ctx->stream));
             }
-            if (states == n && ctx->direct_sort == 1) {   // a full code space: the encode kernel fills the slots itself when it can (no code array)
+            // ctx option direct_sort = 3: over a full code space the encode kernel fills the slots itself (no code array).  Measured
+            // SLOWER than encode + a dedicated scatter kernel (1e7 rows: 0.26 against 0.047 + 0.164 ms — the scattered stores stall the
+            // LDS-heavy encode workgroups; profiles/r04_direct_sort.txt): an A/B switch, not the default.
+            if (states == n && ctx->direct_sort == 3) {
                 CPH_HIP_TRY(hipMemsetAsync(va.get(), 0xFF, n * sizeof(uint32_t), ctx->stream));
                 eh.slots = va.as<uint32_t>();
                 eh.slot_states = (uint32_t)states;
@@ -918,7 +921,7 @@ CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value
     else if (k == "scan_lookback") ctx->scan_lookback = value != 0;
     else if (k == "build_side_stream") ctx->build_side_stream = value != 0;
     else if (k == "stats_sample") ctx->stats_sample = value != 0;
-    else if (k == "direct_sort") ctx->direct_sort = value < 0 || value > 3 ? 1 : (int)value;   // 2: with a partition pass first, 3: without the fused encode (A/B)
+    else if (k == "direct_sort") ctx->direct_sort = value < 0 || value > 3 ? 1 : (int)value;   // 2: with a partition pass first, 3: the encode kernel fills the slots (A/B)
     else if (k == "chain_arith") ctx->chain_arith = value != 0;
     else if (k == "chain_identity") ctx->chain_identity = value != 0;
     else if (k == "probe_hash_rows") ctx->probe_hash_rows = value == 4 ? 4 : 2;

@@ -150,8 +150,8 @@ CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
  *                   dense 32-bit code space (rows <= code states <= 2 rows: decimal ids, row numbers) sorts by ONE scatter — slot[code] = row
  *                   — instead of radix passes; a duplicate is noticed on the device and the build starts over the general way, which
  *                   also reports where the first duplicate is.  (2: one radix pass on the top 8 bits of the codes first, so that the
- *                   stores fall into L2-sized windows — measured no faster; 3: the encode kernel writes the codes and a second
- *                   kernel scatters them, instead of the encode kernel filling the slots of a full code space itself; A/B switches)
+ *                   stores fall into L2-sized windows — measured no faster; 3: the encode kernel fills the slots of a full code space itself
+ *                   instead of writing codes for a scatter kernel — measured slower; A/B switches)
  *   "stats_sample"  0 / 1 (default 1): IndexOn over ONE fixed-width key column (<= 40 bytes) of >= 2^20 rows learns its per-position
  *                   alphabets from ~65 536 rows spread over the table instead of a pass over all rows; the encode kernel checks every
  *                   row against them, and a row with a byte the sample did not show makes the build start over with the exact

@@ -609,14 +609,14 @@ def test_alphabets_from_a_sample_fixed_width_ids(ctx, rare_row):
         ctx.set_option("stats_sample", 1)
 
 
-@pytest.mark.parametrize("shape", ["full_space", "dense_space", "duplicate", "not_unique_call", "two_level", "two_level_duplicate"])
+@pytest.mark.parametrize("shape", ["full_space", "dense_space", "duplicate", "not_unique_call", "two_level", "two_level_duplicate", "fused_full_space"])
 def test_direct_sort_of_distinct_keys_over_a_dense_code_space(ctx, shape):
     """UniqueIndexOn (csvplus.go:740-756) over ids that fill their code space densely sorts by one scatter, slot[code] = row
     (radix_sort.hip: direct_sort_distinct), not by radix passes: same perm as the oracle when the space is full (the slots ARE
     the permutation) or up to twice the rows (slots compacted); a duplicate is noticed on the device, the build starts over the
     general way and reports the oracle's first duplicate; a build that does not ask for distinct keys never takes the path."""
     rng = np.random.default_rng(11)
-    if shape == "full_space":
+    if shape in ("full_space", "fused_full_space"):
         ids = rng.permutation(100_000)                       # "00000".."99999": 10^5 states for 10^5 rows
         width = 5
     elif shape.startswith("two_level"):
@@ -633,7 +633,8 @@ def test_direct_sort_of_distinct_keys_over_a_dense_code_space(ctx, shape):
     col = StrCol.from_arrays(np.frombuffer(raw.tobytes(), np.uint8).copy(), np.arange(len(ids) + 1, dtype=np.uint32) * width, fixed_width=width)
     o = orc.OracleIndex([col])
     unique = shape != "not_unique_call"
-    ctx.set_option("direct_sort", 2 if shape.startswith("two_level") else 1)   # 2: the variant with a partition pass first (A/B switch)
+    # 2: the variant with a partition pass first, 3: the encode kernel fills the slots itself (A/B switches)
+    ctx.set_option("direct_sort", 2 if shape.startswith("two_level") else 3 if shape == "fused_full_space" else 1)
     ctx.profile(True)
     ctx.profile_read(reset=True)
     try:
@@ -642,11 +643,9 @@ def test_direct_sort_of_distinct_keys_over_a_dense_code_space(ctx, shape):
         ctx.set_option("direct_sort", 1)
     prof = ctx.profile_read(reset=True)
     ctx.profile(False)
-    # (k_direct_finish closes every variant of the direct sort; over a FULL code space the encode kernel fills the slots itself
-    # and no k_direct_scatter runs)
-    took_direct, took_radix = "k_direct_finish" in prof, "k_radix_scatter_u32" in prof
-    if shape == "full_space":
-        assert "k_direct_scatter" not in prof
+    # (k_direct_finish closes every variant of the direct sort)
+    took_direct = "k_direct_finish" in prof and ("k_direct_scatter" in prof) == (shape != "fused_full_space")
+    took_radix = "k_radix_scatter_u32" in prof
     # (the partition pass of the two-level variant is one radix scatter)
     assert took_direct == unique and took_radix == (shape in ("duplicate", "not_unique_call", "two_level", "two_level_duplicate")), sorted(prof)
     if shape == "two_level":
