@@ -74,6 +74,11 @@ def parse_args():
     ap.add_argument("--no-positions", action="store_true",
                     help="skip the second measurement of the step in the OTHER output mode (row ids by default)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the pinned-host -> pinned-host scope (cph_stream_join_*)")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the `variants` block: the same step (2 index builds + chained Join of all rows) on other key shapes — "
+                         "unpadded Itoa ids, a half-occupied id space, sparse random keys — and with the payload columns laid out in "
+                         "index order (cph_index_permute)")
+    ap.add_argument("--variants", default="all", help="comma list out of: itoa,half,sparse,permute (default all)")
     ap.add_argument("--verify-sample", type=int, default=100_000)
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the two rocprofv3 --pmc child runs (FETCH_SIZE, WRITE_SIZE) behind roofline.traffic")
@@ -162,7 +167,7 @@ def measure_traffic(kernel_prefix, args):
         cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
                sys.executable, str(ROOT / "bench.py"), "--steps", "2", "--warmup", "1", "--rows", str(args.rows),
                "--customers", str(args.customers), "--products", str(args.products), "--no-cpu-baseline",
-               "--no-index-1e8", "--no-verify", "--no-e2e", "--no-traffic", "--no-positions"] + (["--row-ids"] if args.row_ids else [])
+               "--no-index-1e8", "--no-verify", "--no-e2e", "--no-traffic", "--no-positions", "--no-variants"] + (["--row-ids"] if args.row_ids else [])
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300,
                            check=True)
@@ -696,6 +701,157 @@ def main():
                 "note": "the same step in the other output mode of the ABI (details under %s); fractions on THIS object's byte "
                         "model.  Rounds 1-2 timed the row-id mode (cph_join_chain); since round 3 the timed step reports sorted "
                         "positions (cph_join_chain_ex, CPH_CHAIN_POSITIONS): the reference's own row handle" % other_name}
+
+    # ---- the same step on other data (reported beside `value`, each timed and verified like it) --------------------
+    # The timed step's customers are zero-padded 8-byte ids that fill their id space: the kernel's best case (aligned 8-byte
+    # loads, arithmetic codes, position == code).  `variants` runs the SAME step — both builds + the chained Join of all
+    # rows, sorted positions out — where that does not hold:
+    #   itoa     customers' ids / orders' cust_id as unpadded decimal strings (the reference's own fixture format,
+    #            csvplus_test.go:1241, 1321-1324): variable-length values behind 32-bit offsets, a LUT walk, a rank table
+    #   half     8-byte ids over a HALF-occupied id space (1e7 ids drawn from [0, 2e7)): no identity, every key goes through the
+    #            rank table of a code space twice the index
+    #   sparse   12 random [a-z0-9] characters: a 62-bit code space, the radix sort and the hash probe
+    #   permute  the timed step + cph_index_permute of customers(name, surname) and products(product, price): what a consumer of
+    #            positions pays per build to have its payload rows in index order (csvplus.go:736 moves the rows themselves)
+    if world == 1 and not args.no_variants:
+        from csvplus_amd import verify as V
+        from csvplus_amd.engine import device_view
+
+        want = {"itoa", "half", "sparse", "permute"} if args.variants == "all" else set(args.variants.split(","))
+        variants = {}
+
+        def run_variant(name, what, v_cust, v_ocust, extra_build=None, sample_check=True):
+            """v_cust: the customers' id column (host), v_ocust: the orders' cust_id column (host, all rows)."""
+            torch.cuda.empty_cache()
+            dc, do_ = v_cust.to_device(dev), v_ocust.to_device(dev)
+            keep = []
+
+            def vstep():
+                a, b = eng.index_on_many([[dc], [d_prod]], unique=True)
+                if extra_build:
+                    keep[:] = extra_build(a, b)
+                c = N.join_chain(eng.ctx, [(a, [do_]), (b, [d_ord["prod_id"]])], probe_base=begin, out_mem=N.CPH_MEM_DEVICE, positions=True)
+                n_ = c.nrows
+                inf_ = (a.info(), b.info()) if "info" not in vstep.__dict__ else vstep.info
+                vstep.info = inf_
+                c.release()
+                for x in keep:
+                    x.release()
+                keep[:] = []
+                a.close(); b.close()
+                return n_
+
+            for _ in range(max(1, args.warmup)):
+                vstep()
+            eng.ctx.profile_only("k_chain_dense")
+            eng.ctx.profile_read(reset=True)
+            torch.cuda.synchronize(dev)
+            t0_ = time.perf_counter()
+            for _ in range(args.steps):
+                nj = vstep()
+            torch.cuda.synchronize(dev)
+            dt_ = (time.perf_counter() - t0_) / args.steps
+            pk = eng.ctx.profile_read(reset=True)
+            eng.ctx.profile(True)
+            vstep()
+            pb_ = eng.ctx.profile_read(reset=True)
+            eng.ctx.profile(False)
+            kd_ = pk.get("k_chain_dense", {"launches": 0, "total_ms": 0.0})
+            kd_ms_ = kd_["total_ms"] / kd_["launches"] if kd_["launches"] else None
+            ia_i, ib_i = vstep.info
+            # byte model of the chain pass on THIS data (DESIGN.md §6): both key columns' value bytes + offsets in, two 4-byte
+            # positions out per joined row, each lookup structure charged ONCE at its size (rank table: 8 B per 32 codes of a
+            # code space the index does not fill; hash table: its sectors), as in roofline.bytes_model of the timed step
+            s_in = v_ocust.nbytes_values() + v_ocust.nbytes_offsets() + host_bytes["prod_id"] + ords["prod_id"].nbytes_offsets()
+            look = 0.0
+            for inf_, rows_ in ((ia_i, args.customers), (ib_i, args.products)):
+                if inf_["hash_bytes"]:
+                    look += inf_["hash_bytes"]
+                elif inf_["table_entries"] and inf_["table_entries"] != rows_:
+                    look += 0.25 * inf_["table_entries"]
+            algo = s_in + look + 8.0 * nj
+            blk = {"what": what, "ms_per_step": round(dt_ * 1e3, 4), "value": nj / dt_, "unit": "rows/s", "joined_rows_per_step": nj,
+                   "timed_step_over_this": round(ms_per_step / (dt_ * 1e3), 3),
+                   "k_chain_dense_ms": round(kd_ms_, 4) if kd_ms_ else None,
+                   "kernels_ms": {k: round(v["total_ms"], 4) for k, v in sorted(pb_.items(), key=lambda kv: -kv[1]["total_ms"])},
+                   "customers_index": ia_i,
+                   "roofline": {"kernel": "k_chain_dense" if kd_ms_ else None, "algorithmic_bytes_per_launch": round(algo),
+                                "bytes_model": {"streams_in": round(s_in), "lookup_structures_once": round(look), "results_out": 8 * nj},
+                                "achieved": round(algo / 1e9 / (kd_ms_ / 1e3), 1) if kd_ms_ else None, "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+                                "frac": round(algo / 1e9 / (kd_ms_ / 1e3) / HBM_PEAK_GBPS, 4) if kd_ms_ else None}}
+            if not args.no_verify:
+                a, b = eng.index_on_many([[dc], [d_prod]], unique=True)
+                res_ = eng.chained_join([(a, do_), (b, d_ord["prod_id"])], probe_base=begin, positions=True)
+                allj = res_.n == nloc and res_.stream_row is None
+                ver_ = {"joined_rows": res_.n, "every_stream_row_joined_once": allj}
+                ok_ = allj
+                if allj and sample_check:
+                    rows_ = V.sample_rows(nloc, args.verify_sample)
+                    idx_ = torch.from_numpy(rows_).to(dev)
+                    pk_ = device_view(a.perm_device_ptr(), a.nrows, "<i4", a, dev)
+                    b0_ = pk_[res_.build_rows[0][idx_].long()].cpu().numpy()
+                    ver_["sample_rows"] = int(rows_.size)
+                    ver_["cust_key_mismatches"] = V.check_join_sample(v_ocust, v_cust, b0_, rows_)
+                    ver_["digest_positions_0"] = f"{V.digest_u64(res_.build_rows[0]):016x}"
+                    ok_ = ok_ and ver_["cust_key_mismatches"] == 0
+                    del pk_, idx_
+                pm_ = device_view(a.perm_device_ptr(), a.nrows, "<i4", a, dev)
+                ver_["index_customers"] = V.check_index_order(dc, pm_)
+                ok_ = ok_ and bool(ver_["index_customers"].get("ok"))
+                del pm_
+                res_.release(); a.close(); b.close()
+                blk["verified"] = bool(ok_)
+                blk["verify"] = ver_
+            del dc, do_
+            torch.cuda.empty_cache()
+            return blk
+
+        def guarded(name, fn):
+            try:
+                variants[name] = fn()
+            except Exception as ex:   # noqa: BLE001 — a variant never takes the headline down; the error is the record
+                variants[name] = {"error": f"{type(ex).__name__}: {ex}"}
+
+        if "itoa" in want:
+            guarded("itoa_ids", lambda: run_variant(
+                "itoa_ids", "customers.id / orders.cust_id as unpadded decimal strings (strconv.Itoa, the reference's fixture format: "
+                "csvplus_test.go:1241, 1321-1324): 1-8 byte values behind 32-bit offsets",
+                dg.column(dg.SEQ_PERM, args.customers, args.customers, encoding=dg.ITOA, seed=dg.SEED + 1),
+                dg.column(dg.UNIFORM, nloc, args.customers, encoding=dg.ITOA, seed=dg.SEED + 3, row0=begin)))
+        if "half" in want:
+            guarded("half_occupied_ids", lambda: run_variant(
+                "half_occupied_ids", "8-byte zero-padded ids drawn from an id space TWICE the table (%d ids out of [0, %d)): no identity "
+                "lookup, every key goes through the rank table" % (args.customers, 2 * args.customers),
+                dg.column(dg.SEQ_PERM, args.customers, 2 * args.customers, encoding=dg.FIXED8, seed=dg.SEED + 11),
+                dg.column(dg.FK_SUBSET, nloc, 2 * args.customers, encoding=dg.FIXED8, base=args.customers, seed=dg.SEED + 11, row0=begin)))
+        if "sparse" in want:
+            guarded("sparse_random_keys", lambda: run_variant(
+                "sparse_random_keys", "customers keyed by 12 random [a-z0-9] characters (62-bit code space): radix-sorted index, hash probe",
+                dg.column(dg.RANDKEY, args.customers, 0, seed=dg.SEED + 12),
+                dg.column(dg.RANDKEY, nloc, 0, base=args.customers, seed=dg.SEED + 12, row0=begin)))
+        if "permute" in want:
+            from csvplus_amd.materialize import permute_col
+
+            cust_pay = [dg.column(k_, args.customers, args.customers, seed=dg.SEED + 1).to_device(dev) for k_ in (dg.NAME, dg.SURNAME)]
+            prod_pay = [dg.column(k_, args.products, args.products, seed=dg.SEED + 2).to_device(dev) for k_ in (dg.PRODUCT, dg.PRICE)]
+
+            def lay_out(a, b):
+                return [permute_col(eng.ctx, a, c_) for c_ in cust_pay] + [permute_col(eng.ctx, b, c_) for c_ in prod_pay]
+
+            guarded("step_plus_permute", lambda: run_variant(
+                "step_plus_permute", "the timed step + cph_index_permute of customers(name, surname) and products(product, price) inside "
+                "every step: the payload rows in index order, what a consumer of sorted positions needs per build (csvplus.go:736 moves "
+                "the rows; :553-567 reads index.impl.rows[i])", cust_id, ords["cust_id"], extra_build=lay_out))
+            del cust_pay, prod_pay
+        out["variants"] = variants
+        out["variants_note"] = ("the SAME step as `value` (both index builds + the chained Join of all %d rows, sorted positions out) on other key "
+                                "shapes, each timed over %d steps between synchronisations and verified like `value`; reported beside it" % (args.rows, args.steps))
+        if roofline is not None:   # a compact copy inside the object the driver's record keeps
+            roofline["variants"] = {k: ({"ms_per_step": v.get("ms_per_step"), "k_chain_dense_ms": v.get("k_chain_dense_ms"),
+                                         "frac": (v.get("roofline") or {}).get("frac"), "verified": v.get("verified")}
+                                        if "error" not in v else v) for k, v in variants.items()}
+        if all("error" not in v for v in variants.values()) and not args.no_verify:
+            out["verified"] = bool(out.get("verified")) and all(v.get("verified") for v in variants.values())
 
     # ---- end-to-end C-ABI scope: pinned host SoA in -> pinned host row ids out (PCIe inclusive) ----
     # cph_stream_join_*: 2^24-row chunks of the same orders table, H2D / kernel / D2H of consecutive chunks

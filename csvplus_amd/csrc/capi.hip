@@ -105,6 +105,17 @@ void DevicePool::end_defer() {
     }
 }
 
+void DevicePool::flush_deferred() {
+    std::lock_guard<std::recursive_mutex> lk(mu_);
+    if (defer_depth_ == 0 || deferred_.empty()) return;
+    std::vector<void*> d;
+    d.swap(deferred_);
+    const int depth = defer_depth_;
+    defer_depth_ = 0;
+    for (void* p : d) release(p);
+    defer_depth_ = depth;
+}
+
 void DevicePool::release(void* p) {
     std::lock_guard<std::recursive_mutex> lk(mu_);
     if (defer_depth_ > 0 && p) {
@@ -493,6 +504,7 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
         return hipStreamSynchronize(ctx->stream) == hipSuccess && (!any_side || hipStreamSynchronize(ctx->side_stream) == hipSuccess);
     };
     if (!sync_streams()) return fail_all({CPH_ERR_HIP, "hipStreamSynchronize failed"});
+    ctx->pool.flush_deferred();   // every stream that carries work of this batch is idle: parked blocks may change hands
     // the host copies must survive phase 2 (which may reuse the scratch): take them out
     std::vector<std::vector<uint8_t>> stats_host(nj);
     std::vector<size_t> retry;   // small-table candidates whose key needs the general path after all
@@ -531,6 +543,7 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
             if (e != hipSuccess) status[i] = {CPH_ERR_HIP, std::string("first-duplicate read-back: ") + hipGetErrorString(e)};
         }
         if (!sync_streams()) return fail_all({CPH_ERR_HIP, "hipStreamSynchronize failed"});
+        ctx->pool.flush_deferred();
         for (size_t i = 0; i < nj; i++) {
             if (!status[i].ok() || jobs[i].small) continue;
             cph_index* ix = jobs[i].ix;
@@ -897,6 +910,7 @@ CPH_API void cph_ctx_destroy(cph_ctx* ctx) {
         (void)hipStreamSynchronize(ctx->side_stream);
         (void)hipStreamDestroy(ctx->side_stream);
     }
+    if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
     for (auto& sc : ctx->scan) sc.words.reset();
     ctx->pool.trim();
     if (own) (void)hipStreamDestroy(own);
@@ -954,6 +968,10 @@ CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream) {
     Status s = enter(ctx);
     if (!s.ok()) return fail(ctx, s);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
+    // the one-launch scans keep tickets / epochs per stream slot: nothing of the old stream is in flight any more (synchronised
+    // above), but start them over so that the new stream never depends on what the old one left there
+    for (auto& sc : ctx->scan) { sc.words.reset(); sc.tiles = 0; sc.tickets = 0; sc.epoch = 0; }
     if (hip_stream) {
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
         ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
@@ -1096,6 +1114,19 @@ CPH_API int32_t cph_index_build_many(cph_ctx* ctx, const cph_index_spec* specs, 
             c->pool.end_defer();
         }
     } defer{two_streams ? ctx : nullptr};
+    if (two_streams) {
+        // The header's promise — all work of a ctx is ordered on the stream set with cph_ctx_set_stream — must hold for the side
+        // jobs too: they may read key columns that kernels of the CALLER, queued on ctx->stream, are still producing, and they take
+        // pool blocks whose last users run on ctx->stream.  So the side stream first waits for everything enqueued there so far.
+        hipError_t fe = ctx->side_fork ? hipSuccess : hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming);
+        if (fe == hipSuccess) fe = hipEventRecord(ctx->side_fork, ctx->stream);
+        if (fe == hipSuccess) fe = hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0);
+        if (fe != hipSuccess) {
+            (void)hipGetLastError();
+            two_streams = false;
+            defer.c = nullptr;
+        }
+    }
     if (two_streams) ctx->pool.begin_defer();
     for (int i = 0; i < nspecs; i++) {
         out[i] = nullptr;

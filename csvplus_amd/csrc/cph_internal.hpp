@@ -75,6 +75,9 @@ public:
     // end_defer released blocks are parked instead; end_defer (called once both streams are idle) really releases them.
     void begin_defer();
     void end_defer();
+    // Both streams of the batch are idle (the caller has just synchronised them): the parked blocks go back to the cache now, so
+    // that the batch's peak footprint stays one phase's worth instead of the sum over all jobs; parking goes on afterwards.
+    void flush_deferred();
 
 private:
     struct Block { void* p; size_t cap; size_t user; bool guarded = false; bool in_slab = false; };
@@ -337,6 +340,8 @@ struct cph_ctx {
                                    // kernel checks every row against them and the build starts over with exact statistics on a miss (A/B switch)
     int build_side_stream = 1;     // cph_index_build_many: every second general build of a batch runs on a second stream (A/B switch)
     hipStream_t side_stream = nullptr;   // created on first use
+    hipEvent_t side_fork = nullptr;      // recorded on `stream` when a two-stream batch starts; side_stream waits for it, so that the
+                                         // side jobs are ordered behind everything the caller had enqueued on the ctx's stream
     int stream_slot = 0;           // 0: `stream` is the ctx's own; 1: it is side_stream for the moment (cph::SideStream)
     hipStream_t swapped_main = nullptr;  // ... and this is the ctx's own meanwhile
     hipStream_t other_stream() const { return stream_slot ? swapped_main : side_stream; }   // may be null

@@ -28,7 +28,12 @@ enum {
     DG_PRICE     = 5, /* "%.2f" of (id%8+1)/100 + (id/8 % 1000)                      */
     DG_VARKEY    = 6, /* surname "/" name "#" decimal(U[0,domain))  (config 3)        */
     DG_SEQ       = 7, /* value = row (sorted ids, for adversarial/sorted-input tests) */
-    DG_UNIFORM_PERM = 8 /* value = feistel_perm(U[0,domain)) — same set as UNIFORM   */
+    DG_UNIFORM_PERM = 8, /* value = feistel_perm(U[0,domain)) — same set as UNIFORM  */
+    DG_FK_SUBSET = 9, /* value = feistel_perm(U[0,base), domain, seed): the id of a uniformly drawn row among the FIRST
+                         `base` rows of the DG_SEQ_PERM column with this domain and seed — foreign keys into a table
+                         whose ids occupy only part of their id space (domain > rows)                                */
+    DG_RANDKEY   = 10 /* 12 characters [a-z0-9]: the base-36 digits of a 62-bit bijection of id, id = row (base == 0:
+                         distinct keys of a build table) or U[0,base) (foreign keys into its first `base` rows)      */
 };
 enum { DG_ITOA = 0, DG_FIXED8 = 1 };
 
@@ -115,6 +120,15 @@ static int gen_value(const dg_spec* s, uint64_t row, char* out) {
     case DG_UNIFORM_PERM:
         return fmt_u64(s->base + feistel_perm(bounded(rnd(s->seed, row, 1), s->domain), s->domain, s->seed ^ 0x51ED),
                        s->encoding, out);
+    case DG_FK_SUBSET:
+        return fmt_u64(feistel_perm(bounded(rnd(s->seed ^ 0xF00Dull, row, 1), s->base), s->domain, s->seed), s->encoding, out);
+    case DG_RANDKEY: {
+        static const char kA36[] = "abcdefghijklmnopqrstuvwxyz0123456789";
+        uint64_t id = s->base ? bounded(rnd(s->seed ^ 0xF00Dull, row, 1), s->base) : row;
+        uint64_t v = feistel_perm(id, (uint64_t)1 << 62, s->seed);   /* < 2^62 < 36^12 */
+        for (int i = 11; i >= 0; i--) { out[i] = kA36[v % 36]; v /= 36; }
+        return 12;
+    }
     case DG_NAME: {
         uint64_t id = feistel_perm(row, s->domain, s->seed);
         const char* p = kNames[(id / 12) % 10];
@@ -167,8 +181,9 @@ static int gen_value(const dg_spec* s, uint64_t row, char* out) {
 /* Total data bytes of rows [row0, row0+nrows). */
 DG_API uint64_t dg_column_bytes(const dg_spec* s, uint64_t row0, uint64_t nrows) {
     if (s->encoding == DG_FIXED8 &&
-        (s->kind == DG_SEQ_PERM || s->kind == DG_UNIFORM || s->kind == DG_SEQ || s->kind == DG_UNIFORM_PERM))
+        (s->kind == DG_SEQ_PERM || s->kind == DG_UNIFORM || s->kind == DG_SEQ || s->kind == DG_UNIFORM_PERM || s->kind == DG_FK_SUBSET))
         return nrows * 8;
+    if (s->kind == DG_RANDKEY) return nrows * 12;
     uint64_t total = 0;
 #pragma omp parallel for reduction(+ : total) schedule(static)
     for (int64_t i = 0; i < (int64_t)nrows; i++) {
@@ -238,6 +253,8 @@ DG_API uint64_t dg_value_u64(const dg_spec* s, uint64_t row) {
     case DG_UNIFORM: return s->base + bounded(rnd(s->seed, row, 1), s->domain);
     case DG_UNIFORM_PERM:
         return s->base + feistel_perm(bounded(rnd(s->seed, row, 1), s->domain), s->domain, s->seed ^ 0x51ED);
+    case DG_FK_SUBSET: return feistel_perm(bounded(rnd(s->seed ^ 0xF00Dull, row, 1), s->base), s->domain, s->seed);
+    case DG_RANDKEY: return feistel_perm(s->base ? bounded(rnd(s->seed ^ 0xF00Dull, row, 1), s->base) : row, (uint64_t)1 << 62, s->seed);
     default: return 0;
     }
 }

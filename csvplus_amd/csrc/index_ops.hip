@@ -299,6 +299,13 @@ static bool codec_block_parse(const uint8_t* p, size_t n, size_t* at, CodecHost*
     if (!get(cd.radix.data(), cd.radix.size() * sizeof(uint16_t)) || !get(cd.mult.data(), cd.mult.size() * sizeof(uint64_t)) ||
         !get(cd.word_of.data(), cd.word_of.size() * sizeof(int32_t)) || !get(cd.lut.data(), cd.lut.size() * sizeof(uint16_t)))
         return false;
+    // the column layout first: everything below subscripts unit[] / radix[] with col_start[] values
+    if (cd.ncols < 0 || cd.ncols > kMaxKeyCols || cd.col_start[0] != 0 || cd.col_start[cd.ncols] != cd.npos) return false;
+    for (int c = 0; c < cd.ncols; c++)
+        if (cd.col_start[c + 1] < cd.col_start[c] || cd.col_maxlen[c] != cd.col_start[c + 1] - cd.col_start[c] ||
+            cd.col_minlen[c] < 0 || cd.col_minlen[c] > cd.col_maxlen[c])
+            return false;
+    if (h.split_col >= cd.ncols || (h.split_col >= 0 && (!h.has_groups || cd.col_start[h.split_col] >= cd.npos))) return false;
     if (h.has_groups) {
         cd.unit.resize((size_t)h.npos);
         cd.dict_off.resize((size_t)h.npos);

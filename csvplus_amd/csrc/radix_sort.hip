@@ -435,8 +435,15 @@ static Status exclusive_scan_lookback(cph_ctx* ctx, uint32_t* data, uint64_t n, 
     ProfScope ps(ctx, name, 2.0 * sizeof(uint32_t) * (double)n);
     hipLaunchKernelGGL(k_scan_lookback, dim3((unsigned)nblk), dim3(kScanThreads), 0, ctx->stream, data, n, state, ticket, sc.tickets, sc.epoch,
                        total_out, (uint32_t)nblk);
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) {
+        // the launch did not happen: host and device tickets must not drift apart (the next scan would compute wrong tile numbers
+        // and spin or write out of bounds) — start the state over
+        sc.words.reset();
+        sc.tiles = 0; sc.tickets = 0; sc.epoch = 0;
+        return {CPH_ERR_HIP, std::string("k_scan_lookback launch failed: ") + hipGetErrorString(le)};
+    }
     sc.tickets += (uint32_t)nblk;   // (wraps like the device counter)
-    CPH_HIP_TRY(hipGetLastError());
     return {};
 }
 

@@ -15,7 +15,7 @@ from .columns import StrCol
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libcph_datagen.so"
 
-SEQ_PERM, UNIFORM, NAME, SURNAME, PRODUCT, PRICE, VARKEY, SEQ, UNIFORM_PERM = range(9)
+SEQ_PERM, UNIFORM, NAME, SURNAME, PRODUCT, PRICE, VARKEY, SEQ, UNIFORM_PERM, FK_SUBSET, RANDKEY = range(11)
 ITOA, FIXED8 = 0, 1
 SEED = 0xC5F1D5
 

@@ -78,10 +78,11 @@ func batched(src DataSource, columns []string, flush func(batch []Row) error) er
 	batch := make([]Row, 0, joinBatch)
 	err := src(func(row Row) error {
 		if _, e := row.SelectValues(columns...); e != nil { // rows before this one first, then the error
-			if fe := flush(batch); fe != nil {
+			fe := flush(batch)
+			batch = batch[:0] // whatever flush said: these rows were handed over, they must not be emitted again
+			if fe != nil {
 				return fe
 			}
-			batch = batch[:0]
 			return e
 		}
 		batch = append(batch, row)
