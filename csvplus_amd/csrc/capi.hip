@@ -888,6 +888,7 @@ CPH_API int32_t cph_ctx_create(int32_t device_id, cph_ctx** out) {
     warm_csv_ingest();
     warm_index_ops();
     warm_small_build();
+    warm_window_sort();
     (void)ensure_pinned_scratch(ctx, 1 << 16);
     void* ring = nullptr;
     (void)pinned_upload(ctx, 64, &ring);
@@ -931,11 +932,12 @@ CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value
     else if (k == "stream_zero_copy_out") ctx->stream_zero_copy_out = value != 0;
     else if (k == "chain_nt_streams") ctx->chain_nt_streams = value < 0 || value > 2 ? 0 : (int)value;
     else if (k == "chain_rank_lds") ctx->chain_rank_lds = value != 0;
+    else if (k == "chain_rows4") ctx->chain_rows4 = value < 0 || value > 2 ? 1 : (int)value;
     else if (k == "codec_split") ctx->codec_split = value != 0;
     else if (k == "scan_lookback") ctx->scan_lookback = value != 0;
     else if (k == "build_side_stream") ctx->build_side_stream = value != 0;
     else if (k == "stats_sample") ctx->stats_sample = value != 0;
-    else if (k == "direct_sort") ctx->direct_sort = value < 0 || value > 3 ? 1 : (int)value;   // 2: with a partition pass first, 3: the encode kernel fills the slots (A/B)
+    else if (k == "direct_sort") ctx->direct_sort = value < 0 || value > 4 ? 1 : (int)value;   // 1: LDS windows (window_sort.hip); A/B: 4 plain scatter, 2 partition pass + scatter, 3 the encode kernel fills the slots
     else if (k == "chain_arith") ctx->chain_arith = value != 0;
     else if (k == "chain_identity") ctx->chain_identity = value != 0;
     else if (k == "probe_hash_rows") ctx->probe_hash_rows = value == 4 ? 4 : 2;

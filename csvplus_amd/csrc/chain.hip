@@ -88,7 +88,11 @@ struct LeanArgs {
 //      (ArithPlan) — no codec block in LDS, no LUT walk, no length compare.  A compile-time property: the other steps'
 //      code is not even instantiated for it (fewer live SGPRs / VGPRs than a uniform branch leaves behind).  Only
 //      instantiated for !LONG && !WIDE && !DBG.
-template <int S, bool LONG, bool WIDE, bool DBG, uint32_t LEAN = 0>
+// R: rows per lane and phase (8, or 4 for the register-heavy instantiations — long keys AND 64-bit codes in a chain of two or
+//      more steps need 256+ VGPRs at 8 rows: one wave per SIMD, and a hash probe's sector loads want many waves in flight).
+//      The wave still owns kWaveTile rows per tile: it walks them in kChainRows / R parts, so the tile geometry, the match
+//      bitmap and the per-(tile, wave) counts are the same for every R.
+template <int S, bool LONG, bool WIDE, bool DBG, uint32_t LEAN = 0, int R = kChainRows>
 __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint64_t nprobe, uint64_t probe_base,
                                                               uint64_t ntiles, uint64_t* __restrict__ masks,
                                                               uint32_t* __restrict__ wave_counts, int dbg_flags, LeanArgs la) {
@@ -145,19 +149,22 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
 
 #pragma unroll 1
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint64_t wbase = tile * kChainTile + (uint64_t)wave * kWaveTile;   // wave-uniform
-        const WaveRows<kChainRows> wr = wave_rows<kChainRows>(wbase, nprobe);
+        uint32_t wave_matches = 0;
+#pragma unroll 1
+      for (int part = 0; part < kChainRows / R; part++) {
+        const uint64_t wbase = tile * kChainTile + (uint64_t)wave * kWaveTile + (uint64_t)part * (R * kWave);   // wave-uniform
+        const WaveRows<R> wr = wave_rows<R>(wbase, nprobe);
         uint32_t okm = wr.okm;                  // bit k: row k of this lane is (still) joined
         // ---- A: value spans ----------------------------------------------------------------------
-        WaveSpans<kChainRows, B> sp[S];
+        WaveSpans<R, B> sp[S];
 #pragma unroll
         for (int s = 0; s < S; s++) {
             if ((LEAN >> s) & 1u) continue;   // a lean step needs no spans: value k is the 8-byte word rbase + rel[k]
-            if (a.nt_streams) wave_spans<kChainRows, B, false, true>(a.step[s].col, wr, &sp[s]);   // uniform branch
-            else wave_spans<kChainRows, B>(a.step[s].col, wr, &sp[s]);
+            if (a.nt_streams) wave_spans<R, B, false, true>(a.step[s].col, wr, &sp[s]);   // uniform branch
+            else wave_spans<R, B>(a.step[s].col, wr, &sp[s]);
         }
         // ---- B: first 8 (16) key bytes ---------------------------------------------------------------
-        uint64_t c0[S][kChainRows], c1[LONG ? S : 1][kChainRows];
+        uint64_t c0[S][R], c1[LONG ? S : 1][R];
 #pragma unroll
         for (int s = 0; s < S; s++) {
             if ((LEAN >> s) & 1u) {
@@ -165,38 +172,38 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
                 const global_u64_ptr w = (global_u64_ptr)a.step[s].col.data + wr.rbase;
                 if (a.nt_streams) {   // uniform, outside the row loop
 #pragma unroll
-                    for (int k = 0; k < kChainRows; k++) c0[s][k] = __builtin_nontemporal_load(&w[wr.rel[k]]);
+                    for (int k = 0; k < R; k++) c0[s][k] = __builtin_nontemporal_load(&w[wr.rel[k]]);
                 } else {
 #pragma unroll
-                    for (int k = 0; k < kChainRows; k++) c0[s][k] = w[wr.rel[k]];
+                    for (int k = 0; k < R; k++) c0[s][k] = w[wr.rel[k]];
                 }
                 continue;
             }
 #pragma unroll
-            for (int k = 0; k < kChainRows; k++) {
+            for (int k = 0; k < R; k++) {
                 c0[s][k] = a.nt_streams ? sp[s].chunk_nt(k, 0) : sp[s].chunk(k, 0);
                 if constexpr (LONG) c1[s][k] = a.nt_streams ? sp[s].chunk_nt(k, 1) : sp[s].chunk(k, 1);
             }
         }
         // ---- C: codes -----------------------------------------------------------------------------------
-        CW code[S][kChainRows];
+        CW code[S][R];
 #pragma unroll
         for (int s = 0; s < S; s++) {
             if (DBG && (dbg & 2)) {
 #pragma unroll
-                for (int k = 0; k < kChainRows; k++) code[s][k] = (CW)((c0[s][k] ^ (LONG ? c1[LONG ? s : 0][k] : 0ull)) & 1023);
+                for (int k = 0; k < R; k++) code[s][k] = (CW)((c0[s][k] ^ (LONG ? c1[LONG ? s : 0][k] : 0ull)) & 1023);
             } else if ((LEAN >> s) & 1u) {   // the code is a dot product of the key's bytes
-                encode_rows_arith<kChainRows, CW>(la.arith[s], c0[s], code[s], &okm);
+                encode_rows_arith<R, CW>(la.arith[s], c0[s], code[s], &okm);
             } else if (!WIDE || cv[s].hdr->lutw_bits == 32) {
-                encode_rows<kChainRows, uint32_t, B, CW, LONG>(cv[s], sp[s], c0[s], c1[LONG ? s : 0], code[s], &okm,
+                encode_rows<R, uint32_t, B, CW, LONG>(cv[s], sp[s], c0[s], c1[LONG ? s : 0], code[s], &okm,
                                                                a.step[s].col.fixed_width != 0 && (int)a.step[s].col.fixed_width == cv[s].hdr->col_maxlen[0]);
             } else {
-                encode_rows<kChainRows, uint64_t, B, CW, LONG>(cv[s], sp[s], c0[s], c1[LONG ? s : 0], code[s], &okm,
+                encode_rows<R, uint64_t, B, CW, LONG>(cv[s], sp[s], c0[s], c1[LONG ? s : 0], code[s], &okm,
                                                                a.step[s].col.fixed_width != 0 && (int)a.step[s].col.fixed_width == cv[s].hdr->col_maxlen[0]);
             }
         }
         // ---- D: lookups ---------------------------------------------------------------------------------
-        uint32_t brow[S][kChainRows];
+        uint32_t brow[S][R];
 #pragma unroll
         for (int s = 0; s < S; s++) {
             const ChainStepArg& st = a.step[s];
@@ -204,25 +211,25 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
                 // a lean kernel reports positions and every step is answered by one of three lookups (enqueue_dense checks)
                 if (la.identity[s]) {   // every code below n_index occurs and is its own sorted position: no lookup at all
 #pragma unroll
-                    for (int k = 0; k < kChainRows; k++)
+                    for (int k = 0; k < R; k++)
                         brow[s][k] = ((okm >> k) & 1u) && (uint32_t)code[s][k] < (uint32_t)st.n_index ? (uint32_t)code[s][k] : kTableAbsent;
                 } else if (rank_lds[s]) {   // 8-byte rank blocks in LDS
 #pragma unroll
-                    for (int k = 0; k < kChainRows; k++) {
+                    for (int k = 0; k < R; k++) {
                         const uint32_t cidx = (okm >> k) & 1u ? (uint32_t)code[s][k] : 0u;
                         const CPH_LDS uint32_t* e = rank_lds[s] + 2u * (cidx >> 5);
                         const uint32_t bits = e[0], before = e[1], bit = cidx & 31u;
                         brow[s][k] = (bits >> bit) & 1u ? before + (uint32_t)__popc(bits & ((1u << bit) - 1u)) : kTableAbsent;
                     }
                 } else {             // rank blocks in global memory (L2-resident for a 1e7-row index)
-                    uint2 blk[kChainRows];
+                    uint2 blk[R];
 #pragma unroll
-                    for (int k = 0; k < kChainRows; k++) {
+                    for (int k = 0; k < R; k++) {
                         const uint32_t cidx = (okm >> k) & 1u ? (uint32_t)code[s][k] : 0u;   // block 0 always exists
                         blk[k] = st.ranktab[cidx >> 5];
                     }
 #pragma unroll
-                    for (int k = 0; k < kChainRows; k++) {
+                    for (int k = 0; k < R; k++) {
                         const uint32_t bit = (uint32_t)code[s][k] & 31u;
                         brow[s][k] = (blk[k].x >> bit) & 1u ? blk[k].y + (uint32_t)__popc(blk[k].x & ((1u << bit) - 1u)) : kTableAbsent;
                     }
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
                 // row), or 12 bytes per 64 codes from LDS
                 if (rank_lds[s]) {   // uniform branch
 #pragma unroll
-                    for (int k = 0; k < kChainRows; k++) {
+                    for (int k = 0; k < R; k++) {
                         const CW cidx = (okm >> k) & 1u ? code[s][k] : (CW)0;
                         const CPH_LDS uint32_t* e = rank_lds[s] + 3u * (uint32_t)((uint64_t)cidx >> 6);
                         const uint32_t bit = (uint32_t)cidx & 63u;
@@ -242,14 +249,14 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
                         brow[s][k] = present ? e[2] + (uint32_t)__popcll(bits & ((1ull << bit) - 1ull)) : kTableAbsent;
                     }
                 } else {
-                    uint2 blk[kChainRows];
+                    uint2 blk[R];
 #pragma unroll
-                    for (int k = 0; k < kChainRows; k++) {
+                    for (int k = 0; k < R; k++) {
                         const CW cidx = (okm >> k) & 1u ? code[s][k] : (CW)0;   // block 0 always exists
                         blk[k] = (DBG && (dbg & 1)) ? make_uint2(~0u, 0u) : st.ranktab[(uint64_t)cidx >> 5];
                     }
 #pragma unroll
-                    for (int k = 0; k < kChainRows; k++) {
+                    for (int k = 0; k < R; k++) {
                         const uint32_t bit = (uint32_t)code[s][k] & 31u;
                         const bool present = (blk[k].x >> bit) & 1u;
                         brow[s][k] = present ? blk[k].y + (uint32_t)__popc(blk[k].x & ((1u << bit) - 1u)) : kTableAbsent;
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
                 }
             } else if (st.rowtab) {
 #pragma unroll
-                for (int k = 0; k < kChainRows; k++) {
+                for (int k = 0; k < R; k++) {
                     const CW cidx = (okm >> k) & 1u ? code[s][k] : (CW)0;   // entry 0 always exists
                     brow[s][k] = (DBG && (dbg & 1)) ? 0u : st.rowtab[cidx];
                 }
@@ -266,7 +273,7 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
                 // per lane); entry.aux is the build row (duplicate-free index)
                 const HashView hv{st.hash, st.hash_sectors};
 #pragma unroll
-                for (int g = 0; g < kChainRows; g += 4) {
+                for (int g = 0; g < R; g += 4) {
                     HashSector sc[4];
                     uint32_t home[4];
 #pragma unroll
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < kChainRows; k++) {
+                for (int k = 0; k < R; k++) {
                     brow[s][k] = kTableAbsent;
                     if (!((okm >> k) & 1u)) continue;
                     uint64_t lo;
@@ -308,13 +315,12 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
 #pragma unroll
         for (int s = 0; s < S; s++)
 #pragma unroll
-            for (int k = 0; k < kChainRows; k++)
+            for (int k = 0; k < R; k++)
                 if (brow[s][k] == kTableAbsent) okm &= ~(1u << k);
         // ---- dense output + match bookkeeping ----------------------------------------------------------
-        uint32_t wave_matches = 0;
-        const uint64_t mword = (tile * kChainWaves + wave) * kChainRows;   // == wbase / 64
+        const uint64_t mword = (tile * kChainWaves + wave) * kChainRows + (uint64_t)part * R;   // == wbase / 64
 #pragma unroll
-        for (int k = 0; k < kChainRows; k++) {
+        for (int k = 0; k < R; k++) {
             const bool ok = (okm >> k) & 1u;
             const uint64_t bal = __ballot(ok);
             wave_matches += (uint32_t)__popcll(bal);
@@ -328,6 +334,7 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
                 }
             }
         }
+      }
         // per-(tile, wave) match count
         if (lane == 0) wave_counts[tile * kChainWaves + wave] = wave_matches;
     }
@@ -592,6 +599,13 @@ static Status enqueue_dense(cph_ctx* ctx, const ChainStep* steps, uint64_t nprob
         {{&k_chain_dense<S, true, false, false>, &k_chain_dense<S, true, false, true>},
          {&k_chain_dense<S, true, true, false>, &k_chain_dense<S, true, true, true>}}};
     KernelFn kernel = variants[long_keys ? 1 : 0][wide ? 1 : 0][dbg ? 1 : 0];
+    // register-heavy instantiations (tools/kernel_usage.sh: 256 VGPRs + AGPR copies at 8 rows per lane = ONE wave per SIMD) walk the
+    // wave's rows 4 at a time: long keys with 64-bit codes from two steps on, any long or wide chain from three steps on
+    if (!dbg && ctx->chain_rows4 != 0 && ((S == 2 && long_keys && wide) || (S >= 3 && (long_keys || wide)) || S == 4 || ctx->chain_rows4 == 2)) {
+        static const KernelFn r4[2][2] = {{&k_chain_dense<S, false, false, false, 0u, 4>, &k_chain_dense<S, false, true, false, 0u, 4>},
+                                          {&k_chain_dense<S, true, false, false, 0u, 4>, &k_chain_dense<S, true, true, false, 0u, 4>}};
+        kernel = r4[long_keys ? 1 : 0][wide ? 1 : 0];
+    }
     if (lean) {
         constexpr uint32_t kAll = (1u << S) - 1u;
         if (lean == kAll) kernel = &k_chain_dense<S, false, false, false, kAll>;

@@ -322,6 +322,7 @@ struct cph_ctx {
     int chain_nt_streams = 0;      // chained join: non-temporal loads / stores for the stream's bytes and the results (0 never, 1 always, 2 positions mode)
     int chain_arith = 1;           // chained join: fixed-width key columns over contiguous alphabets are encoded arithmetically (codec_device.hpp: ArithPlan) and read with one aligned load (A/B switch)
     int chain_identity = 1;        // positions mode: an index whose code space is exactly as large as the index needs no lookup (A/B switch)
+    int chain_rows4 = 1;           // chained join: register-heavy kernel variants walk 4 rows per lane and phase instead of 8 (0: never, 2: every non-lean chain; A/B switch)
     int chain_rank_lds = 1;        // positions mode: rank tables of small indexes are copied into LDS by every workgroup (A/B switch)
     int probe_hash_rows = 2;       // rows per phase of the generic hash probe (2 / 4): 4 rows need 164 VGPRs (3 waves per SIMD) and measured 20 % slower
     int join_hash = 1;             // 0: indexes of this ctx never get a hash table (A/B switch: sorted search instead)
@@ -569,6 +570,9 @@ Status radix_sort_pairs(cph_ctx* ctx, K* keys_a, K* keys_b, uint32_t* vals_a, ui
 // distinct 32-bit codes over a dense space: one scatter instead of radix passes (optimistic; *flag raised on a duplicate)
 Status direct_sort_distinct(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out, uint32_t* sorted_out,
                             uint32_t* flag);
+// the same through LDS windows: a partition by the top code bits, then every window placed in LDS and streamed out (window_sort.hip)
+Status direct_sort_windows(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out, uint32_t* sorted_out,
+                           uint32_t* flag);
 // the second half of it for a full code space whose slots the encode kernel already filled: every slot taken? + the sorted codes
 Status direct_sort_finish_full(cph_ctx* ctx, const uint32_t* slots, uint64_t n, uint32_t* sorted_out, uint32_t* flag);
 Status exclusive_scan_u32(cph_ctx* ctx, uint32_t* data, uint64_t n);
@@ -651,6 +655,7 @@ void warm_materialize();
 void warm_csv_ingest();
 void warm_index_ops();
 void warm_small_build();
+void warm_window_sort();
 
 // small_build.hip: IndexOn of a small table in one launch (one workgroup) and one synchronisation
 constexpr int kSmallMaxPos = 64;              // byte positions of the key the one-workgroup build takes

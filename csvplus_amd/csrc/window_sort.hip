@@ -1,0 +1,339 @@
+// window_sort.hip — direct sort of DISTINCT keys over a dense code space at sequential-store speed
+// (UniqueIndexOn of ids: createUniqueIndex, csvplus.go:740-756; replaces sort.Sort(&index.impl), :736, for that case).
+//
+// When a table is expected to hold no duplicates and its codes fill their space densely (rows <= states <= 2 rows), the
+// sorted order IS the code: slot[code] = row.  radix_sort.hip's k_direct_scatter does exactly that with one random 4-byte
+// store per row — 62 G stores/s on this chip and 8x write amplification (a 32-byte partial sector per store), the kernel
+// furthest below its roofline in round 4.  Here the random placement happens in LDS instead:
+//
+//   k_win_partition   the rows are split by the TOP bits of their codes into buckets that each cover one WINDOW of
+//                     2^14 slots (64 KB of LDS).  Keys are distinct, so a bucket can never hold more entries than its
+//                     window has slots: buckets have a fixed capacity and fixed place — no histogram pass, no count
+//                     matrix, no scan; a tile of 8192 rows counts its rows per bucket in LDS, reserves room with ONE
+//                     global atomic per (tile, bucket) and writes its entries bucket by bucket (coalesced runs, staged
+//                     through LDS).  Code spaces beyond 2048 windows (1e8 ids: 6104) take two such levels.
+//   k_win_place       one workgroup per window: its entries (contiguous) are placed at slot = code - window base in LDS,
+//                     then the window leaves as ONE sequential stream: perm (rows in code order) and the sorted codes,
+//                     compacted over the empty slots of a code space that is larger than the table.
+//
+// Optimistic like the scatter it replaces: two rows with one code overwrite each other in LDS (or overflow a bucket); the
+// window then holds fewer rows than entries and *flag is raised — the caller builds the index the general way, which also
+// says WHERE the first duplicate is (csvplus.go:749-753).
+//
+// Algorithmic bytes per row (one level): codes in 4, entries out 8 | entries in 8, perm + sorted codes out 8 = 28.
+#include "cph_internal.hpp"
+#include "device_utils.hpp"
+
+namespace cph {
+
+constexpr int kWpThreads = 256;
+constexpr int kWpItems = 32;
+constexpr int kWpTile = kWpThreads * kWpItems;   // rows per partition tile
+constexpr int kWpMaxBuckets = 2048;              // buckets one partition level splits into
+constexpr int kWinBits = 14;                     // window = 2^14 slots = 64 KB of LDS
+constexpr uint32_t kWinSlots = 1u << kWinBits;
+constexpr uint32_t kWinEmpty = 0xFFFFFFFFu;      // never a row id (at most 2^32 - 1 rows)
+constexpr int kPlaceThreads = 512;
+
+struct WpArgs {
+    const uint32_t* codes;       // FROM_CODES: codes[n], the row is the index
+    const uint64_t* entries;     // else: source bucket sb holds src_count[sb] entries at entries + sb * src_cap
+    const uint32_t* src_count;
+    uint64_t n;
+    uint32_t src_cap;
+    uint32_t tiles_per_src;      // grid = sources * tiles_per_src
+    uint32_t shift;              // destination bucket = within >> shift; a destination bucket covers 2^shift codes
+    uint32_t nb;                 // destination buckets per source
+    uint64_t* dst;               // destination bucket d = sb * nb + b starts at dst + (d << shift)
+    uint32_t* dst_count;         // one cursor per destination bucket (zeroed by the host)
+    uint32_t states;             // FROM_CODES: a code at or beyond it comes from a row the encode kernel flagged: skipped
+    uint32_t* flag;
+};
+
+// entry = (code relative to its bucket's first code) << 32 | row
+template <bool FROM_CODES>
+__global__ __launch_bounds__(kWpThreads) void k_win_partition(WpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ uint32_t s_tmp[kWpThreads / kWave + 1];
+    const uint32_t nbp = (a.nb + (uint32_t)kWpThreads - 1u) & ~((uint32_t)kWpThreads - 1u);
+    uint32_t* s_code = reinterpret_cast<uint32_t*>(smem);                   // [kWpTile] code within the source bucket
+    uint16_t* s_stage = reinterpret_cast<uint16_t*>(s_code + kWpTile);      // [kWpTile] tile-local row numbers, bucket by bucket
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(s_stage + kWpTile);      // [nbp]
+    uint32_t* s_start = s_hist + nbp;                                       // [nbp] first staged entry of the bucket
+    uint32_t* s_gbase = s_start + nbp;                                      // [nbp] its room in the destination bucket
+    const uint32_t sb = blockIdx.x / a.tiles_per_src, tl = blockIdx.x % a.tiles_per_src;
+    uint64_t cnt = a.n;
+    if constexpr (!FROM_CODES) {
+        const uint32_t c = a.src_count[sb];
+        cnt = c < a.src_cap ? c : a.src_cap;   // (a count beyond the capacity: duplicates — the writer raised the flag)
+    }
+    const uint64_t t0 = (uint64_t)tl * kWpTile;
+    if (t0 >= cnt) return;
+    const uint32_t m = cnt - t0 < (uint64_t)kWpTile ? (uint32_t)(cnt - t0) : (uint32_t)kWpTile;
+    const uint64_t src0 = FROM_CODES ? t0 : (uint64_t)sb * a.src_cap + t0;
+    const uint32_t t = threadIdx.x;
+    for (uint32_t i = t; i < nbp; i += kWpThreads) s_hist[i] = 0;
+    __syncthreads();
+    // ---- load, count per bucket; rank = arrival number inside the bucket (any order will do) ----
+    uint16_t rank[kWpItems];
+    if constexpr (FROM_CODES) {
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const bool vec = m == (uint32_t)kWpTile && (((uintptr_t)(a.codes + src0)) & 15) == 0;
+#pragma unroll
+        for (int j = 0; j < kWpItems / 4; j++) {
+            const uint32_t i4 = 4u * ((uint32_t)j * kWpThreads + t);
+            uint32_t w[4];
+            if (vec) {
+                const u32x4 v = reinterpret_cast<const u32x4*>(a.codes + src0)[i4 >> 2];
+                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; c++) w[c] = i4 + c < m ? a.codes[src0 + i4 + c] : kWinEmpty;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const bool ok = i4 + c < m && w[c] < a.states;
+                s_code[i4 + c] = ok ? w[c] : kWinEmpty;
+                rank[4 * j + c] = ok ? (uint16_t)atomicAdd(&s_hist[w[c] >> a.shift], 1u) : (uint16_t)0;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kWpItems; j++) {
+            const uint32_t i = (uint32_t)j * kWpThreads + t;
+            const bool ok = i < m;
+            const uint32_t w = ok ? (uint32_t)(a.entries[src0 + i] >> 32) : kWinEmpty;
+            s_code[i] = w;
+            rank[j] = ok ? (uint16_t)atomicAdd(&s_hist[w >> a.shift], 1u) : (uint16_t)0;
+        }
+    }
+    lds_atomics_barrier();
+    // ---- tile-local starts (exclusive scan over the buckets) + room in the destination buckets ----
+    {
+        const uint32_t per = nbp / kWpThreads;   // <= 8
+        uint32_t h[kWpMaxBuckets / kWpThreads], sum = 0;
+#pragma unroll
+        for (int k = 0; k < kWpMaxBuckets / kWpThreads; k++) {
+            h[k] = (uint32_t)k < per ? s_hist[t * per + k] : 0u;
+            sum += h[k];
+        }
+        uint32_t total;
+        uint32_t run = block_exclusive_sum<uint32_t, kWpThreads>(sum, s_tmp, &total);
+#pragma unroll
+        for (int k = 0; k < kWpMaxBuckets / kWpThreads; k++) {
+            if ((uint32_t)k < per) {
+                const uint32_t b = t * per + k;
+                s_start[b] = run;
+                run += h[k];
+                if (h[k]) s_gbase[b] = atomicAdd(&a.dst_count[(uint64_t)sb * a.nb + b], h[k]);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- stage the tile's rows bucket by bucket ----
+    if constexpr (FROM_CODES) {
+#pragma unroll
+        for (int j = 0; j < kWpItems / 4; j++) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const uint32_t i = 4u * ((uint32_t)j * kWpThreads + t) + c;
+                const uint32_t w = s_code[i];
+                if (w != kWinEmpty) s_stage[s_start[w >> a.shift] + rank[4 * j + c]] = (uint16_t)i;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kWpItems; j++) {
+            const uint32_t i = (uint32_t)j * kWpThreads + t;
+            const uint32_t w = s_code[i];
+            if (w != kWinEmpty) s_stage[s_start[w >> a.shift] + rank[j]] = (uint16_t)i;
+        }
+    }
+    __syncthreads();
+    // ---- write them out: consecutive threads, consecutive entries of one destination bucket ----
+    const uint32_t last = a.nb - 1u;
+    const uint32_t tot = s_start[last] + s_hist[last];
+    const uint32_t cap = 1u << a.shift, mask = cap - 1u;
+    bool over = false;
+    for (uint32_t i = t; i < tot; i += kWpThreads) {
+        const uint32_t idx = s_stage[i];
+        const uint32_t w = s_code[idx];
+        const uint32_t b = w >> a.shift;
+        const uint32_t pos = s_gbase[b] + (i - s_start[b]);
+        uint32_t row;
+        if constexpr (FROM_CODES) row = (uint32_t)(t0 + idx);
+        else row = (uint32_t)a.entries[src0 + idx];
+        if (pos < cap) a.dst[(((uint64_t)sb * a.nb + b) << a.shift) + pos] = ((uint64_t)(w & mask) << 32) | row;
+        else over = true;   // more rows than the bucket has codes: duplicates
+    }
+    if (__ballot(over) && lane_id() == 0) *a.flag = 1u;
+}
+
+// exclusive scan of min(count, window slots) over the windows: where each window's rows start in perm / sorted
+__global__ __launch_bounds__(1024) void k_win_offsets(const uint32_t* __restrict__ counts, uint32_t nwin, uint32_t* __restrict__ off) {
+    __shared__ uint32_t s_tmp[1024 / kWave + 1];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nwin; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        uint32_t v = i < nwin ? counts[i] : 0u;
+        v = v < kWinSlots ? v : kWinSlots;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_sum<uint32_t, 1024>(v, s_tmp, &total);
+        if (i < nwin) off[i] = carry + ex;
+        carry += total;
+    }
+}
+
+// One workgroup per window g (codes [g << 14, (g + 1) << 14)): place, then stream out compacted.
+// off == nullptr: every window in front of g is full (states == n and no duplicates — anything else raises the flag): its
+// rows start at g << 14.
+__global__ __launch_bounds__(kPlaceThreads) void k_win_place(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ counts,
+                                                            const uint32_t* __restrict__ off, uint64_t n, uint32_t* __restrict__ perm,
+                                                            uint32_t* __restrict__ sorted, uint32_t* __restrict__ flag) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ uint32_t s_wcount[kPlaceThreads / kWave];
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    uint32_t* win = reinterpret_cast<uint32_t*>(smem);
+    const uint32_t g = blockIdx.x, t = threadIdx.x;
+    const uint32_t craw = counts[g], cnt = craw < kWinSlots ? craw : kWinSlots;
+    {
+        u32x4 e;
+        e.x = e.y = e.z = e.w = kWinEmpty;
+        for (uint32_t i = t; i < kWinSlots / 4; i += kPlaceThreads) reinterpret_cast<u32x4*>(win)[i] = e;
+    }
+    __syncthreads();
+    const uint64_t* src = entries + ((uint64_t)g << kWinBits);
+    for (uint32_t i = t; i < cnt; i += kPlaceThreads) {
+        const uint64_t e = src[i];
+        win[(uint32_t)(e >> 32) & (kWinSlots - 1u)] = (uint32_t)e;
+    }
+    __syncthreads();
+    // every wave owns a contiguous stretch of the window: count, exchange, write
+    constexpr uint32_t kWaves = kPlaceThreads / kWave, kPerWave = kWinSlots / kWaves, kIters = kPerWave / kWave;
+    const uint32_t wave = (uint32_t)wave_id(), lane = (uint32_t)lane_id();
+    const uint32_t s0 = wave * kPerWave;
+    uint32_t c = 0;
+#pragma unroll 4
+    for (uint32_t it = 0; it < kIters; it++) c += (uint32_t)__popcll(__ballot(win[s0 + it * kWave + lane] != kWinEmpty));
+    if (lane == 0) s_wcount[wave] = c;
+    __syncthreads();
+    uint32_t before = 0, filled = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kWaves; w++) {
+        const uint32_t x = s_wcount[w];
+        before += w < wave ? x : 0u;
+        filled += x;
+    }
+    if (t == 0 && (filled != craw)) *flag = 1u;   // two rows shared a slot, or the bucket overflowed: duplicates
+    uint64_t pos = (off ? (uint64_t)off[g] : ((uint64_t)g << kWinBits)) + before;
+    const uint64_t lt = lanemask_lt();
+    const uint32_t code0 = (g << kWinBits) + s0;
+    for (uint32_t it = 0; it < kIters; it++) {
+        const uint32_t v = win[s0 + it * kWave + lane];
+        const uint64_t bal = __ballot(v != kWinEmpty);
+        if (v != kWinEmpty) {
+            const uint64_t p = pos + (uint64_t)__popcll(bal & lt);
+            if (p < n) {   // (always, unless duplicates already raised the flag)
+                perm[p] = v;
+                sorted[p] = code0 + it * kWave + lane;
+            }
+        }
+        pos += (uint64_t)__popcll(bal);
+    }
+}
+
+// codes[n] (32-bit, distinct, below `states`) -> perm_out[n] (rows in code order), sorted_out[n] (the codes in order); *flag
+// (device, zeroed by the caller) is raised when two rows share a code — the outputs are then meaningless.  codes and sorted_out
+// may be the same buffer (the codes are consumed by the first partition pass before anything is written there).
+Status direct_sort_windows(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out, uint32_t* sorted_out,
+                           uint32_t* flag) {
+    if (n == 0) return {};
+    const uint64_t nwin = (states + kWinSlots - 1) >> kWinBits;
+    const bool two = nwin > (uint64_t)kWpMaxBuckets;
+    // two levels: level 2 splits a level-1 bucket into nb2 = 2^k2 windows
+    int k2 = 0;
+    if (two) {
+        int wb = 0;
+        while ((1ull << wb) < nwin) wb++;
+        k2 = (wb + 1) / 2;
+    }
+    const uint32_t nb2 = 1u << k2;
+    const uint32_t shift1 = (uint32_t)kWinBits + (uint32_t)k2;
+    const uint64_t nb1 = two ? (states + (1ull << shift1) - 1) >> shift1 : nwin;
+    if (nb1 > (uint64_t)kWpMaxBuckets) return {CPH_ERR_INVALID, "direct_sort_windows: code space too large"};
+    const uint64_t nwin_total = two ? nb1 * nb2 : nwin;   // windows that exist as buckets (the last level-1 bucket may reach past `states`)
+    DevBuf ent1, ent2, words;
+    CPH_TRY(ent1.alloc(&ctx->pool, (nb1 << shift1) * sizeof(uint64_t)));
+    if (two) CPH_TRY(ent2.alloc(&ctx->pool, (nwin_total << kWinBits) * sizeof(uint64_t)));
+    // cursors of both levels + the windows' output offsets: one block, one memset
+    const uint64_t nwords = nb1 + (two ? nwin_total : 0) + nwin_total;
+    CPH_TRY(words.alloc(&ctx->pool, nwords * sizeof(uint32_t)));
+    uint32_t* cur1 = words.as<uint32_t>();
+    uint32_t* cur2 = two ? cur1 + nb1 : cur1;
+    uint32_t* off = (two ? cur2 + nwin_total : cur1 + nb1);
+    CPH_HIP_TRY(hipMemsetAsync(words.get(), 0, (nb1 + (two ? nwin_total : 0)) * sizeof(uint32_t), ctx->stream));
+    auto lds_for = [](uint32_t nb) {
+        const uint32_t nbp = (nb + (uint32_t)kWpThreads - 1u) & ~((uint32_t)kWpThreads - 1u);
+        return (size_t)kWpTile * 4 + (size_t)kWpTile * 2 + (size_t)nbp * 12;
+    };
+    {
+        WpArgs a{};
+        a.codes = codes;
+        a.n = n;
+        a.tiles_per_src = (uint32_t)((n + kWpTile - 1) / kWpTile);
+        a.shift = shift1;
+        a.nb = (uint32_t)nb1;
+        a.dst = ent1.as<uint64_t>();
+        a.dst_count = cur1;
+        a.states = (uint32_t)states;
+        a.flag = flag;
+        const size_t lds = lds_for(a.nb);
+        CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_win_partition<true>), kWpThreads, lds, nullptr));
+        ProfScope ps(ctx, "k_win_partition", 12.0 * (double)n);
+        hipLaunchKernelGGL(k_win_partition<true>, dim3(a.tiles_per_src), dim3(kWpThreads), lds, ctx->stream, a);
+    }
+    CPH_HIP_TRY(hipGetLastError());
+    if (two) {
+        WpArgs a{};
+        a.entries = ent1.as<uint64_t>();
+        a.src_count = cur1;
+        a.src_cap = 1u << shift1;
+        a.tiles_per_src = (a.src_cap + kWpTile - 1) / kWpTile;
+        a.shift = (uint32_t)kWinBits;
+        a.nb = nb2;
+        a.dst = ent2.as<uint64_t>();
+        a.dst_count = cur2;
+        a.flag = flag;
+        const size_t lds = lds_for(a.nb);
+        CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_win_partition<false>), kWpThreads, lds, nullptr));
+        ProfScope ps(ctx, "k_win_partition", 16.0 * (double)n);
+        hipLaunchKernelGGL(k_win_partition<false>, dim3((unsigned)(nb1 * a.tiles_per_src)), dim3(kWpThreads), lds, ctx->stream, a);
+        CPH_HIP_TRY(hipGetLastError());
+    }
+    const uint32_t* counts = two ? cur2 : cur1;
+    const bool need_off = states != n;   // a full code space: window g starts at g << 14 (or the flag goes up)
+    if (need_off) {
+        ProfScope ps(ctx, "k_win_place", 0);
+        hipLaunchKernelGGL(k_win_offsets, dim3(1), dim3(1024), 0, ctx->stream, counts, (uint32_t)nwin_total, off);
+    }
+    {
+        const size_t lds = (size_t)kWinSlots * sizeof(uint32_t);
+        CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_win_place), kPlaceThreads, lds, nullptr));
+        ProfScope ps(ctx, "k_win_place", 16.0 * (double)n);
+        hipLaunchKernelGGL(k_win_place, dim3((unsigned)nwin_total), dim3(kPlaceThreads), lds, ctx->stream, two ? ent2.as<uint64_t>() : ent1.as<uint64_t>(),
+                           counts, need_off ? off : nullptr, n, perm_out, sorted_out, flag);
+    }
+    CPH_HIP_TRY(hipGetLastError());
+    return {};
+}
+
+}  // namespace cph
+
+// Loads this translation unit's code object now (cph_ctx_create) instead of inside the first timed call.
+namespace cph {
+void warm_window_sort() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_win_offsets));
+    (void)hipGetLastError();
+}
+}  // namespace cph

@@ -147,11 +147,12 @@ CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
  *   "scan_lookback" 0 / 1 (default 1): the 32-bit exclusive scans (radix count matrices, compaction offsets) run as ONE launch
  *                   (decoupled look-back) instead of three (A/B switch)
  *   "direct_sort"   0 / 1 (default 1): a build that expects distinct keys (cph_index_build with unique = 1, cph_index_spec.unique) over a
- *                   dense 32-bit code space (rows <= code states <= 2 rows: decimal ids, row numbers) sorts by ONE scatter — slot[code] = row
- *                   — instead of radix passes; a duplicate is noticed on the device and the build starts over the general way, which
- *                   also reports where the first duplicate is.  (2: one radix pass on the top 8 bits of the codes first, so that the
- *                   stores fall into L2-sized windows — measured no faster; 3: the encode kernel fills the slots of a full code space itself
- *                   instead of writing codes for a scatter kernel — measured slower; A/B switches)
+ *                   dense 32-bit code space (rows <= code states <= 2 rows: decimal ids, row numbers) sorts without radix passes: the rows
+ *                   are split by the top bits of their codes into 2^14-slot windows, every window is filled in LDS (slot = code) and
+ *                   streamed out — all global stores sequential; a duplicate is noticed on the device and the build starts over the
+ *                   general way, which also reports where the first duplicate is.  (A/B switches: 4 = slot[code] = row as one random
+ *                   4-byte store per row, the round-4 path; 2 = that behind one radix pass on the top 8 bits; 3 = the encode kernel
+ *                   fills the slots of a full code space itself)
  *   "stats_sample"  0 / 1 (default 1): IndexOn over ONE fixed-width key column (<= 40 bytes) of >= 2^20 rows learns its per-position
  *                   alphabets from ~65 536 rows spread over the table instead of a pass over all rows; the encode kernel checks every
  *                   row against them, and a row with a byte the sample did not show makes the build start over with the exact
@@ -164,6 +165,9 @@ CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
  *                   workgroup and one synchronisation (small_build.hip); 0 = always the general path
  *   "probe_hash_rows"  2 / 4: rows per phase of the generic hash probe (default 2)
  *   "chain_rank_lds"  0 / 1: a Join that reports positions copies the rank tables of small indexes into LDS (default 1)
+ *   "chain_rows4"   0 / 1 / 2 (default 1): the register-heavy variants of the fused chained Join (keys beyond 8 bytes with 64-bit codes
+ *                   from two steps on, long or wide chains from three steps on) keep 4 rows per lane in flight instead of 8, which
+ *                   lets three waves per SIMD run instead of one; 0 = always 8, 2 = every general (non-lean) chain 4 (A/B switch)
  *   "chain_arith"   0 / 1 (default 1): the fused chained Join encodes fixed-width key columns over contiguous alphabets
  *                   (decimal ids) arithmetically — one aligned 8-byte load and a dot product instead of a LUT walk (A/B switch)
  *   "chain_identity" 0 / 1 (default 1): reporting positions, an index whose code space has exactly as many states as the

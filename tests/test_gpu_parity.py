@@ -609,15 +609,21 @@ def test_alphabets_from_a_sample_fixed_width_ids(ctx, rare_row):
         ctx.set_option("stats_sample", 1)
 
 
-@pytest.mark.parametrize("shape", ["full_space", "dense_space", "duplicate", "not_unique_call", "two_level", "two_level_duplicate", "fused_full_space"])
+@pytest.mark.parametrize("shape", ["full_space", "dense_space", "duplicate", "not_unique_call", "tail_window", "scatter_full_space", "scatter_dense_space",
+                                   "scatter_duplicate", "two_level", "two_level_duplicate", "fused_full_space"])
 def test_direct_sort_of_distinct_keys_over_a_dense_code_space(ctx, shape):
-    """UniqueIndexOn (csvplus.go:740-756) over ids that fill their code space densely sorts by one scatter, slot[code] = row
-    (radix_sort.hip: direct_sort_distinct), not by radix passes: same perm as the oracle when the space is full (the slots ARE
-    the permutation) or up to twice the rows (slots compacted); a duplicate is noticed on the device, the build starts over the
-    general way and reports the oracle's first duplicate; a build that does not ask for distinct keys never takes the path."""
+    """UniqueIndexOn (csvplus.go:740-756) over ids that fill their code space densely sorts without radix passes: rows split by
+    the top bits of their codes into LDS-sized windows, slot = code inside the window, windows streamed out (window_sort.hip;
+    the round-4 variants — one random store per row, radix_sort.hip: direct_sort_distinct — stay as A/B switches and are
+    checked here too): same perm as the oracle when the space is full (the slots ARE the permutation) or up to twice the rows
+    (slots compacted); a duplicate is noticed on the device, the build starts over the general way and reports the oracle's
+    first duplicate; a build that does not ask for distinct keys never takes the path."""
     rng = np.random.default_rng(11)
-    if shape in ("full_space", "fused_full_space"):
+    if shape in ("full_space", "fused_full_space", "scatter_full_space"):
         ids = rng.permutation(100_000)                       # "00000".."99999": 10^5 states for 10^5 rows
+        width = 5
+    elif shape == "tail_window":
+        ids = rng.permutation(70_001)                        # states 8 * 10^4 (first digit 0..7), the last window partly outside the ids
         width = 5
     elif shape.startswith("two_level"):
         ids = rng.permutation(1_200_000)                     # 2 x 10^6 states, 1.2e6 rows: slots beyond an L2 -> partition pass first
@@ -627,14 +633,15 @@ def test_direct_sort_of_distinct_keys_over_a_dense_code_space(ctx, shape):
     else:
         ids = rng.permutation(1_000_000)[:620_000]           # 10^6 states, 6.2e5 rows
         width = 6
-    if shape == "duplicate":
+    if shape.endswith("duplicate") and not shape.startswith("two_level"):
         ids[123_457] = ids[17]
     raw = np.char.zfill(ids.astype(f"U{width}"), width).astype(f"S{width}")
     col = StrCol.from_arrays(np.frombuffer(raw.tobytes(), np.uint8).copy(), np.arange(len(ids) + 1, dtype=np.uint32) * width, fixed_width=width)
     o = orc.OracleIndex([col])
     unique = shape != "not_unique_call"
-    # 2: the variant with a partition pass first, 3: the encode kernel fills the slots itself (A/B switches)
-    ctx.set_option("direct_sort", 2 if shape.startswith("two_level") else 3 if shape == "fused_full_space" else 1)
+    # 1 (default): LDS windows; A/B switches: 4 one random store per row, 2 that behind a partition pass, 3 the encode kernel fills the slots
+    opt = 2 if shape.startswith("two_level") else 3 if shape == "fused_full_space" else 4 if shape.startswith("scatter") else 1
+    ctx.set_option("direct_sort", opt)
     ctx.profile(True)
     ctx.profile_read(reset=True)
     try:
@@ -643,11 +650,14 @@ def test_direct_sort_of_distinct_keys_over_a_dense_code_space(ctx, shape):
         ctx.set_option("direct_sort", 1)
     prof = ctx.profile_read(reset=True)
     ctx.profile(False)
-    # (k_direct_finish closes every variant of the direct sort)
-    took_direct = "k_direct_finish" in prof and ("k_direct_scatter" in prof) == (shape != "fused_full_space")
+    if opt == 1:
+        took_direct = "k_win_partition" in prof and "k_win_place" in prof and "k_direct_scatter" not in prof
+        assert prof.get("k_win_partition", {"launches": 1})["launches"] == 1   # these code spaces take one partition level
+    else:   # (k_direct_finish closes every round-4 variant of the direct sort)
+        took_direct = "k_direct_finish" in prof and ("k_direct_scatter" in prof) == (shape != "fused_full_space")
     took_radix = "k_radix_scatter_u32" in prof
     # (the partition pass of the two-level variant is one radix scatter)
-    assert took_direct == unique and took_radix == (shape in ("duplicate", "not_unique_call", "two_level", "two_level_duplicate")), sorted(prof)
+    assert took_direct == unique and took_radix == (shape.endswith("duplicate") or shape in ("not_unique_call", "two_level")), sorted(prof)
     if shape == "two_level":
         assert prof["k_radix_scatter_u32"]["launches"] == 1
     np.testing.assert_array_equal(g.perm(), o.perm)
@@ -667,3 +677,4 @@ def test_direct_sort_of_distinct_keys_over_a_dense_code_space(ctx, shape):
             rows = ch.build_row(0)
             np.testing.assert_array_equal(g.perm()[rows] if positions else rows, want["build_row"])
             ch.release()
+
