@@ -108,7 +108,7 @@ class cph_index_spec(C.Structure):
 
 
 class cph_chain_step(C.Structure):
-    _fields_ = [("index", C.c_void_p), ("cols", C.POINTER(cph_strcol)), ("ncols", C.c_int32), ("reserved_", C.c_int32)]
+    _fields_ = [("index", C.c_void_p), ("cols", C.POINTER(cph_strcol)), ("ncols", C.c_int32), ("source", C.c_int32)]
 
 
 class cph_chain(C.Structure):
@@ -582,16 +582,20 @@ class DeviceIndex:
 
 
 def join_chain(ctx: Context, steps, probe_base: int = 0, out_mem: int = CPH_MEM_HOST, positions: bool = False) -> "Chain":
-    """cph_join_chain[_ex]: steps = [(DeviceIndex, [stream key columns]), ...].  positions=True (CPH_CHAIN_POSITIONS):
-    build_row[k] holds sorted positions in index k (original row = index.perm()[position])."""
+    """cph_join_chain[_ex]: steps = [(DeviceIndex, [key columns]) or (DeviceIndex, [key columns], source), ...].  source
+    (cph_chain_step.source): 0 = the columns belong to the stream table; k > 0 = to the build table of step k-1 in its original
+    row order; -k = the same in step k-1's sorted order.  positions=True (CPH_CHAIN_POSITIONS): build_row[k] holds sorted
+    positions in index k (original row = index.perm()[position])."""
     arr = (cph_chain_step * len(steps))()
     keep = []
-    for i, (index, cols) in enumerate(steps):
+    for i, step in enumerate(steps):
+        index, cols = step[0], step[1]
         carr, k = _cols_array(cols)
         keep.append((carr, k, index))
         arr[i].index = index.handle
         arr[i].cols = carr
         arr[i].ncols = len(cols)
+        arr[i].source = int(step[2]) if len(step) > 2 else 0
     out = C.POINTER(cph_chain)()
     if positions:
         rc = ctx.lib.cph_join_chain_ex(ctx.handle, arr, len(steps), probe_base, out_mem, CPH_CHAIN_POSITIONS, C.byref(out))

@@ -1326,8 +1326,19 @@ CPH_API int32_t cph_join_chain_ex(cph_ctx* ctx, const cph_chain_step* steps, int
             return fail(ctx, {CPH_ERR_TOO_MANY_COLS, "too many source columns in Join()"});
         s = validate_cols(steps[k].cols, steps[k].ncols);
         if (!s.ok()) return fail(ctx, s);
-        if (steps[k].cols[0].nrows != steps[0].cols[0].nrows)
-            return fail(ctx, {CPH_ERR_INVALID, "chain steps must use columns of one stream table"});
+        const int32_t src = steps[k].source;
+        if (src == 0) {
+            if (steps[k].cols[0].nrows != steps[0].cols[0].nrows)
+                return fail(ctx, {CPH_ERR_INVALID, "chain steps must use columns of one stream table"});
+        } else {
+            // the key comes from the row an EARLIER step matched in its build table (csvplus_test.go:280-285)
+            const int32_t t = (src < 0 ? -src : src) - 1;
+            if (t >= k) return fail(ctx, {CPH_ERR_INVALID, "cph_chain_step.source must name an earlier step of the chain"});
+            if (src < 0 && !positions)
+                return fail(ctx, {CPH_ERR_INVALID, "cph_chain_step.source < 0 (columns in sorted order) needs CPH_CHAIN_POSITIONS"});
+            if (steps[k].cols[0].nrows != steps[t].index->nrows)
+                return fail(ctx, {CPH_ERR_INVALID, "a build-side chain step needs columns with as many rows as its source step's index"});
+        }
     }
     cph_chain_impl* c = new (std::nothrow) cph_chain_impl();
     if (!c) return fail(ctx, {CPH_ERR_NOMEM, "out of host memory"});
@@ -1338,6 +1349,7 @@ CPH_API int32_t cph_join_chain_ex(cph_ctx* ctx, const cph_chain_step* steps, int
         for (int k = 0; k < nsteps; k++) {
             cs[k].index = steps[k].index;
             cs[k].ncols = steps[k].ncols;
+            cs[k].source = steps[k].source;
             CPH_TRY(stage_cols(ctx, steps[k].cols, steps[k].ncols, &staged, cs[k].cols));
         }
         ChainOut co;

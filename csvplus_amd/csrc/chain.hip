@@ -53,7 +53,8 @@ struct ChainStepArg {
     int32_t ranktab_lds;        // != 0: PAIRS of blocks of ranktab every workgroup copies into LDS (a small index: no L2 -> L1 line per row)
     const uint4* hash;          // no rowtab: hash table over the codes (hash_device.hpp, kHashK1 entries), or nullptr -> binary search
     uint32_t hash_sectors;
-    uint32_t reserved_;
+    int32_t src;                // cph_chain_step.source: 0 = col belongs to the stream; k / -k = to the build table of step k-1 (DEP kernels only)
+    const uint32_t* src_perm;   // src > 0 in positions mode: the source index's perm (sorted position -> original row), else nullptr
     const void* codes;          // sorted codes (u32 if key32 else u64)
     const uint32_t* perm;
     uint64_t n_index;
@@ -92,7 +93,13 @@ struct LeanArgs {
 //      more steps need 256+ VGPRs at 8 rows: one wave per SIMD, and a hash probe's sector loads want many waves in flight).
 //      The wave still owns kWaveTile rows per tile: it walks them in kChainRows / R parts, so the tile geometry, the match
 //      bitmap and the per-(tile, wave) counts are the same for every R.
-template <int S, bool LONG, bool WIDE, bool DBG, uint32_t LEAN = 0, int R = kChainRows>
+// DEP: some step reads its key from the BUILD TABLE of an earlier step (cph_chain_step.source != 0: people.Join(orders, "id")
+//      .Join(products), csvplus_test.go:280-285 — prod_id is a column of the orders row the first Join matched, which mergeRows
+//      copied into the row the second Join sees, csvplus.go:571-583).  The phases then run step by step instead of all steps
+//      per phase: step s gathers its value from row brow[source][k] of its column (through the source index's perm when the
+//      chain reports positions and the column is in the table's original order), so a step starts when its source step's
+//      lookups are back.  Instantiated for LONG && WIDE && !LEAN, R = 4 only (the general register types).
+template <int S, bool LONG, bool WIDE, bool DBG, uint32_t LEAN = 0, int R = kChainRows, bool DEP = false>
 __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint64_t nprobe, uint64_t probe_base,
                                                               uint64_t ntiles, uint64_t* __restrict__ masks,
                                                               uint32_t* __restrict__ wave_counts, int dbg_flags, LeanArgs la) {
@@ -155,18 +162,46 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
         const uint64_t wbase = tile * kChainTile + (uint64_t)wave * kWaveTile + (uint64_t)part * (R * kWave);   // wave-uniform
         const WaveRows<R> wr = wave_rows<R>(wbase, nprobe);
         uint32_t okm = wr.okm;                  // bit k: row k of this lane is (still) joined
-        // ---- A: value spans ----------------------------------------------------------------------
         WaveSpans<R, B> sp[S];
+        uint64_t c0[S][R], c1[LONG ? S : 1][R];
+        CW code[S][R];
+        uint32_t brow[S][R];
+        // !DEP: ONE level, every phase covers all steps.  DEP: level l is step l alone (its source step's rows are known by then).
+#pragma unroll
+      for (int lvl = 0; lvl < (DEP ? S : 1); lvl++) {
+        // ---- A: value spans ----------------------------------------------------------------------
 #pragma unroll
         for (int s = 0; s < S; s++) {
+            if (DEP && s != lvl) continue;
             if ((LEAN >> s) & 1u) continue;   // a lean step needs no spans: value k is the 8-byte word rbase + rel[k]
+            if constexpr (DEP) {
+                const int32_t src = a.step[s].src;
+                if (src != 0) {   // uniform: the key sits in the row an earlier step matched
+                    const int t = (src < 0 ? -src : src) - 1;
+                    uint32_t grow[R];
+#pragma unroll
+                    for (int k = 0; k < R; k++) grow[k] = 0u;
+#pragma unroll
+                    for (int u = 0; u < S; u++)
+                        if (u < s && u == t) {
+#pragma unroll
+                            for (int k = 0; k < R; k++) grow[k] = (okm >> k) & 1u ? brow[u][k] : 0u;   // row 0 exists (no index of the chain is empty)
+                        }
+                    if (a.step[s].src_perm) {
+#pragma unroll
+                        for (int k = 0; k < R; k++) grow[k] = a.step[s].src_perm[grow[k]];
+                    }
+                    gather_spans<R, B>(a.step[s].col, grow, &sp[s]);
+                    continue;
+                }
+            }
             if (a.nt_streams) wave_spans<R, B, false, true>(a.step[s].col, wr, &sp[s]);   // uniform branch
             else wave_spans<R, B>(a.step[s].col, wr, &sp[s]);
         }
         // ---- B: first 8 (16) key bytes ---------------------------------------------------------------
-        uint64_t c0[S][R], c1[LONG ? S : 1][R];
 #pragma unroll
         for (int s = 0; s < S; s++) {
+            if (DEP && s != lvl) continue;
             if ((LEAN >> s) & 1u) {
                 typedef const __attribute__((address_space(1))) uint64_t* global_u64_ptr;
                 const global_u64_ptr w = (global_u64_ptr)a.step[s].col.data + wr.rbase;
@@ -186,9 +221,9 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
             }
         }
         // ---- C: codes -----------------------------------------------------------------------------------
-        CW code[S][R];
 #pragma unroll
         for (int s = 0; s < S; s++) {
+            if (DEP && s != lvl) continue;
             if (DBG && (dbg & 2)) {
 #pragma unroll
                 for (int k = 0; k < R; k++) code[s][k] = (CW)((c0[s][k] ^ (LONG ? c1[LONG ? s : 0][k] : 0ull)) & 1023);
@@ -203,9 +238,9 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
             }
         }
         // ---- D: lookups ---------------------------------------------------------------------------------
-        uint32_t brow[S][R];
 #pragma unroll
         for (int s = 0; s < S; s++) {
+            if (DEP && s != lvl) continue;
             const ChainStepArg& st = a.step[s];
             if constexpr (LEAN != 0) {
                 // a lean kernel reports positions and every step is answered by one of three lookups (enqueue_dense checks)
@@ -313,10 +348,13 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
             }
         }
 #pragma unroll
-        for (int s = 0; s < S; s++)
+        for (int s = 0; s < S; s++) {
+            if (DEP && s != lvl) continue;
 #pragma unroll
             for (int k = 0; k < R; k++)
                 if (brow[s][k] == kTableAbsent) okm &= ~(1u << k);
+        }
+      }
         // ---- dense output + match bookkeeping ----------------------------------------------------------
         const uint64_t mword = (tile * kChainWaves + wave) * kChainRows + (uint64_t)part * R;   // == wbase / 64
 #pragma unroll
@@ -476,6 +514,12 @@ __global__ void k_compose_u32(const uint32_t* __restrict__ src, const uint64_t* 
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[idx[i]];
 }
 
+// dst[i] = perm[pos[i]]: sorted positions -> original rows (a later step reads its key from an earlier build table's columns)
+__global__ void k_perm_rows(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ pos, uint32_t* __restrict__ dst, uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = perm[pos[i]];
+}
+
 bool chain_fast_path_ok(const ChainStep* steps, int nsteps) {
     for (int s = 0; s < nsteps; s++) {
         const cph_index* ix = steps[s].index;
@@ -501,7 +545,9 @@ static Status enqueue_dense(cph_ctx* ctx, const ChainStep* steps, uint64_t nprob
     LeanArgs largs{};
     size_t lds = 0, rank_lds_bytes = 0;
     const int dbg = ctx->chain_debug;
-    bool long_keys = false, wide = false;
+    bool long_keys = false, wide = false, dep = false;
+    for (int s = 0; s < S; s++) dep |= steps[s].source != 0;
+    if (dep) long_keys = wide = true;   // the DEP kernels exist in the general register types only (and are never lean)
     for (int s = 0; s < S; s++) {
         const cph_index* ix = steps[s].index;
         const DevCol& c = steps[s].cols[0];
@@ -574,6 +620,8 @@ static Status enqueue_dense(cph_ctx* ctx, const ChainStep* steps, uint64_t nprob
             CPH_TRY(index_ensure_rowtab(ctx, ix));
             st.rowtab = ix->rowtab ? ix->rowtab.as<uint32_t>() : nullptr;
         }
+        st.src = steps[s].source;
+        st.src_perm = (steps[s].source > 0 && positions) ? steps[steps[s].source - 1].index->perm.as<uint32_t>() : nullptr;
         st.hash = nullptr;
         st.hash_sectors = 0;
         if (!st.rowtab && !st.ranktab && !ident[s] && index_wants_hash(ix)) {
@@ -598,13 +646,16 @@ static Status enqueue_dense(cph_ctx* ctx, const ChainStep* steps, uint64_t nprob
          {&k_chain_dense<S, false, true, false>, &k_chain_dense<S, false, true, true>}},
         {{&k_chain_dense<S, true, false, false>, &k_chain_dense<S, true, false, true>},
          {&k_chain_dense<S, true, true, false>, &k_chain_dense<S, true, true, true>}}};
-    KernelFn kernel = variants[long_keys ? 1 : 0][wide ? 1 : 0][dbg ? 1 : 0];
+    KernelFn kernel = variants[long_keys ? 1 : 0][wide ? 1 : 0][(dbg && !dep) ? 1 : 0];
     // register-heavy instantiations (tools/kernel_usage.sh: 256 VGPRs + AGPR copies at 8 rows per lane = ONE wave per SIMD) walk the
     // wave's rows 4 at a time: long keys with 64-bit codes from two steps on, any long or wide chain from three steps on
     if (!dbg && ctx->chain_rows4 != 0 && ((S == 2 && long_keys && wide) || (S >= 3 && (long_keys || wide)) || S == 4 || ctx->chain_rows4 == 2)) {
         static const KernelFn r4[2][2] = {{&k_chain_dense<S, false, false, false, 0u, 4>, &k_chain_dense<S, false, true, false, 0u, 4>},
                                           {&k_chain_dense<S, true, false, false, 0u, 4>, &k_chain_dense<S, true, true, false, 0u, 4>}};
         kernel = r4[long_keys ? 1 : 0][wide ? 1 : 0];
+    }
+    if constexpr (S >= 2) {
+        if (dep) kernel = &k_chain_dense<S, true, true, false, 0u, 4, true>;
     }
     if (lean) {
         constexpr uint32_t kAll = (1u << S) - 1u;
@@ -623,7 +674,7 @@ static Status enqueue_dense(cph_ctx* ctx, const ChainStep* steps, uint64_t nprob
     {
         ProfScope ps(ctx, "k_chain_dense", 0);
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(kChainThreads), lds, ctx->stream, args, nprobe, probe_base,
-                           ntiles, d_masks, d_counts, dbg, largs);
+                           ntiles, d_masks, d_counts, dep ? 0 : dbg, largs);
     }
     {
         ProfScope ps(ctx, "k_sum_counts", 4.0 * (double)ncounts);
@@ -762,6 +813,8 @@ Status chain_run(cph_ctx* ctx, const ChainStep* steps, int nsteps, uint64_t prob
     out->nrows = 0;
     out->nsteps = nsteps;
     if (nprobe == 0) return {};
+    for (int s = 0; s < nsteps; s++)
+        if (steps[s].index->nrows == 0) return {};   // a Join with an empty index emits nothing (csvplus.go:557-559: the loop body never runs)
 
     if (chain_fast_path_ok(steps, nsteps)) {
         size_t lds = 0;
@@ -784,10 +837,28 @@ Status chain_run(cph_ctx* ctx, const ChainStep* steps, int nsteps, uint64_t prob
     cur_rows[0] = std::move(first.brow);
     uint64_t n = first.nmatches;
     for (int s = 1; s < nsteps && n > 0; s++) {
+        // the rows this step reads its key from: the stream rows of the tuples so far, or the rows an earlier step matched
+        // in that step's build table (cph_chain_step.source; mergeRows put that row's columns into the row this Join sees)
         RowSel sel;
-        sel.ptr = cur_stream.get();
-        sel.bits = 64;
-        sel.base = probe_base;
+        DevBuf src_rows;
+        if (steps[s].source == 0) {
+            sel.ptr = cur_stream.get();
+            sel.bits = 64;
+            sel.base = probe_base;
+        } else {
+            const int t = (steps[s].source < 0 ? -steps[s].source : steps[s].source) - 1;
+            sel.ptr = cur_rows[t].get();
+            sel.bits = 32;
+            sel.base = 0;
+            if (steps[s].source > 0 && positions) {   // columns in the table's original order, tuples hold sorted positions
+                CPH_TRY(src_rows.alloc(&ctx->pool, n * sizeof(uint32_t)));
+                ProfScope ps(ctx, "k_compose", (double)n * 12.0);
+                hipLaunchKernelGGL(k_perm_rows, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, ctx->stream,
+                                   steps[t].index->perm.as<uint32_t>(), cur_rows[t].as<uint32_t>(), src_rows.as<uint32_t>(), n);
+                CPH_HIP_TRY(hipGetLastError());
+                sel.ptr = src_rows.get();
+            }
+        }
         ProbeOut po;
         CPH_TRY(probe_run(ctx, steps[s].index, steps[s].cols, steps[s].ncols, sel, n, 0, true, &po, positions));
         const uint64_t m = po.nmatches;

@@ -306,6 +306,54 @@ __device__ __forceinline__ void wave_spans_whole(const DevCol& c, const WaveRows
         for (int k = 0; k < R; k++) { sp->x[k] = 0; sp->len[k] = 0; }
     }
 }
+// The same for R ARBITRARY rows of the column per lane (a chained Join whose key sits in the row an earlier step matched,
+// chain.hip DEP): x[k] is the value's byte offset from the column's first byte.  B = uint64_t unless the whole column is
+// below 4 GiB.
+template <int R, class B>
+__device__ __forceinline__ void gather_spans(const DevCol& c, const uint32_t (&row)[R], WaveSpans<R, B>* sp) {
+    const uint64_t p = (uint64_t)(uintptr_t)c.data;
+    sp->base8 = (const uint8_t*)(uintptr_t)(p & ~7ull);
+    sp->delta = (uint32_t)(p & 7ull);
+    if (c.fixed_width) {
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            sp->x[k] = (B)row[k] * (B)c.fixed_width;
+            sp->len[k] = c.fixed_width;
+        }
+        return;
+    }
+    if (c.offset_bits == 32) {
+        const uint32_t* off = reinterpret_cast<const uint32_t*>(c.offsets);
+        uint32_t b[R], e[R];
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            b[k] = off[row[k]];
+            e[k] = off[(uint64_t)row[k] + 1];
+        }
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            sp->x[k] = b[k];
+            sp->len[k] = e[k] - b[k];
+        }
+    } else if constexpr (sizeof(B) == 8) {
+        const uint64_t* off = reinterpret_cast<const uint64_t*>(c.offsets);
+        uint64_t b[R], e[R];
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            b[k] = off[row[k]];
+            e[k] = off[(uint64_t)row[k] + 1];
+        }
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            sp->x[k] = b[k];
+            const uint64_t l = e[k] - b[k];
+            sp->len[k] = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;
+        }
+    } else {   // not reachable: the host picks B = uint64_t for 64-bit offsets
+#pragma unroll
+        for (int k = 0; k < R; k++) { sp->x[k] = 0; sp->len[k] = 0; }
+    }
+}
 // true when a column can be walked with B = uint32_t
 inline bool col_is_narrow(const DevCol& c) { return c.fixed_width ? c.fixed_width <= 0xFFFFu : c.offset_bits == 32; }
 

@@ -625,6 +625,8 @@ struct ChainStep {
     const cph_index* index = nullptr;
     DevCol cols[kMaxKeyCols];
     int32_t ncols = 0;
+    int32_t source = 0;        // cph_chain_step.source: 0 = cols belong to the stream table; k / -k = to the build table of step k-1
+                               // (original row order / that index's sorted order)
 };
 struct ChainOut {
     DevBuf stream_row;

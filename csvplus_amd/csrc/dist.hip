@@ -898,6 +898,7 @@ CPH_API int32_t cph_dist_join_chain(cph_dist* d, const cph_chain_step* steps, in
         if (steps[k].ncols > steps[k].index->nkeycols) return fail_with(ctx, {CPH_ERR_TOO_MANY_COLS, "too many source columns in Join()"});
         Status v = validate_cols(steps[k].cols, steps[k].ncols);
         if (!v.ok()) return fail_with(ctx, v);
+        if (steps[k].source != 0) return fail_with(ctx, {CPH_ERR_INVALID, "cph_dist_join_chain: every step must read the stream shard (cph_chain_step.source == 0)"});
         if (steps[k].cols[0].nrows != steps[0].cols[0].nrows) return fail_with(ctx, {CPH_ERR_INVALID, "chain steps must use columns of one stream table"});
     }
     auto* g = new (std::nothrow) cph_gathered_impl();

@@ -29,8 +29,13 @@
 // source IS the first Join's closure) is recognised — a DataSource returned by Join remembers its upstream and its steps
 // — and a batch of stream rows goes through ONE cph_join_chain_ex(CPH_CHAIN_POSITIONS) call, the entry point bench.py
 // times, as long as every row of the batch carries the later steps' key columns itself: mergeRows
-// lets the stream's value win, so that is the value the later Join sees.  A batch with a row that takes a later key from
-// a BUILD-side column runs the steps one after the other over the merged rows (same emission order, same errors).
+// lets the stream's value win, so that is the value the later Join sees.  Round 5: a later key that NO stream row of the
+// batch carries but every row of an earlier index does — people.Join(orders, "id").DropColumns(...).Join(products),
+// csvplus_test.go:280-285: prod_id is a column of the orders index rows — is fused too: the step names its source
+// (cph_chain_step.source) and the device gathers the key from the row that earlier step matched.  DropColumns between the
+// Joins of a chain is part of the chain (the columns are dropped when the merged row is built).  A batch whose rows
+// disagree about where a key comes from runs the steps one after the other over the merged rows (same emission order,
+// same errors).
 #pragma once
 
 #include <algorithm>
@@ -285,6 +290,32 @@ public:
         return *dev_;
     }
     mutable std::shared_ptr<detail::DeviceIndex> dev_;
+
+    // A column of impl_rows as pinned SoA in SORTED order (row i = impl_rows[i]), staged once: what a later Join of a chain reads
+    // its key from when the key is a column of THIS index's rows (cph_chain_step.source < 0).  nullptr when some row lacks it.
+    const cph_strcol* side_column(cph_ctx* ctx, const std::string& name) const {
+        auto it = side_cols_.find(name);
+        if (it == side_cols_.end()) {
+            std::shared_ptr<detail::StagedColumns> st;
+            bool all = !impl_rows.empty();
+            for (const Row& r : impl_rows)
+                if (!r.count(name)) { all = false; break; }
+            if (all) {
+                std::vector<std::vector<const std::string*>> vals(1);
+                vals[0].resize(impl_rows.size());
+                for (size_t i = 0; i < impl_rows.size(); i++) vals[0][i] = &impl_rows[i].at(name);
+                st = std::make_shared<detail::StagedColumns>(ctx, 1);
+                st->stage(vals, impl_rows.size());
+            }
+            it = side_cols_.emplace(name, std::move(st)).first;
+        }
+        return it->second ? it->second->cols() : nullptr;
+    }
+    void invalidate_device() {   // impl_rows changed (ResolveDuplicates): the device twin and the staged columns are rebuilt on next use
+        dev_.reset();
+        side_cols_.clear();
+    }
+    mutable std::map<std::string, std::shared_ptr<detail::StagedColumns>> side_cols_;
 };
 
 // ---- DataSource (:215) ---------------------------------------------------------------------------------
@@ -313,7 +344,7 @@ public:
         else spec->upstream = fn_;
         spec->steps.push_back(ChainStepSpec{std::move(index), std::move(columns)});
         DataSource out = spec->steps.size() == 1 ? probeSource(spec->upstream, spec->steps[0].index, spec->steps[0].columns, /*anti=*/false)
-                                                 : chainSource(spec);
+                                                 : chainSource(spec);   // (a one-step chain gets its drops in DropColumns)
         out.chain_ = spec;
         return out;
     }
@@ -323,6 +354,43 @@ public:
         if (columns.empty()) columns = index->impl_columns;
         else if (columns.size() > index->impl_columns.size()) throw Panic("too many source columns in Except()");
         return probeSource(fn_, std::move(index), std::move(columns), /*anti=*/true);
+    }
+
+    // DropColumns (:493-509).  Between the Joins of a chain it stays part of the chain: the columns leave the merged row when
+    // it is built, and a later Join that needs one of them fails as in the reference (missing column).
+    DataSource DropColumns(std::vector<std::string> columns) const {
+        if (columns.empty()) throw Panic("no columns specified in DropColumns()");
+        if (chain_) {
+            auto spec = std::make_shared<ChainSpec>(*chain_);
+            auto& d = spec->steps.back().drop_after;
+            d.insert(d.end(), columns.begin(), columns.end());
+            DataSource out = chainSource(spec);
+            out.chain_ = spec;
+            return out;
+        }
+        Fn src = fn_;
+        return DataSource([src, columns](const RowFunc& fn) {
+            return src([&](Row row) {
+                for (const auto& c : columns) row.erase(c);
+                return fn(std::move(row));
+            });
+        });
+    }
+    // SelectColumns (:511-525)
+    DataSource SelectColumns(std::vector<std::string> columns) const {
+        if (columns.empty()) throw Panic("no columns specified in SelectColumns()");
+        Fn src = fn_;
+        return DataSource([src, columns](const RowFunc& fn) {
+            return src([&](Row row) {
+                Row r;
+                for (const auto& c : columns) {
+                    auto it = row.find(c);
+                    if (it == row.end()) return Error("missing column " + quote(c));   // Row.Select :122-135
+                    r[c] = it->second;
+                }
+                return fn(std::move(r));
+            });
+        });
     }
 
     // ToRows (:481-490)
@@ -337,6 +405,7 @@ private:
     struct ChainStepSpec {
         std::shared_ptr<Index> index;
         std::vector<std::string> columns;
+        std::vector<std::string> drop_after;   // DropColumns applied to this step's output rows
     };
     struct ChainSpec {   // this source == upstream.Join(steps[0])...Join(steps.back())
         Fn upstream;
@@ -460,11 +529,13 @@ private:
         });
     }
 
-    // upstream.Join(steps[0])...Join(steps[k]), k >= 1.  Per batch of stream rows: ONE fused device call when every row
-    // carries the key columns of ALL steps (the value a later Join sees is then the stream's own: mergeRows :571-583 lets the
-    // right operand win) — cph_join_chain_ex reporting sorted positions, the subscripts into each index's impl_rows —, else
-    // the steps one after the other over the merged rows.  Either way the rows come out in the reference's nested order:
-    // by stream row, then by position in steps[0]'s index, then in steps[1]'s, ...; a step-k row is merged as
+    // upstream.Join(steps[0])...Join(steps[k]) (with the DropColumns between them).  Per batch of stream rows: ONE fused device
+    // call — cph_join_chain_ex reporting sorted positions, the subscripts into each index's impl_rows — when every later key
+    // has ONE origin for the whole batch: every stream row carries it (the value a later Join sees is then the stream's own:
+    // mergeRows :571-583 lets the right operand win), or no stream row does and every row of an earlier index does
+    // (cph_chain_step.source: the device reads the key from the row that step matched; the earliest such index wins, as in the
+    // nested merges).  Else the steps one after the other over the merged rows.  Either way the rows come out in the reference's
+    // nested order: by stream row, then by position in steps[0]'s index, then in steps[1]'s, ...; a step-k row is merged as
     // mergeRows(index_k row, mergeRows(index_k-1 row, ... stream row)): on a shared column name the precedence is
     // stream > steps[0] > steps[1] > ... (csvplus.go:559-560 nested).
     static DataSource chainSource(std::shared_ptr<const ChainSpec> spec) {
@@ -473,40 +544,58 @@ private:
             const size_t S = spec->steps.size();
             return batched(spec->upstream, spec->steps[0].columns, [&](std::vector<Row>* batch) -> Error {
                 if (batch->empty()) return Error();
+                // origin[k]: 0 = step k's key columns come from the stream rows, t + 1 = from the rows of steps[t].index
+                std::vector<int> origin(S, 0);
                 bool fusable = true;
-                for (size_t k = 1; k < S && fusable; k++)
-                    for (const Row& r : *batch) {
-                        for (const auto& col : spec->steps[k].columns)
-                            if (!HasColumn(r, col)) { fusable = false; break; }
-                        if (!fusable) break;
+                for (size_t k = 1; k < S && fusable; k++) {
+                    int org = -2;   // not decided
+                    for (const auto& col : spec->steps[k].columns) {
+                        const int o = columnOrigin(ctx, *spec, k, col, *batch);
+                        if (o < 0 || (org != -2 && o != org)) { fusable = false; break; }
+                        org = o;
                     }
+                    origin[k] = org;
+                }
                 // the steps one after the other: step k's output rows are step k+1's stream (same order of outputs and of
                 // errors as the nested closures: a later step sees the rows in emission order)
                 if (!fusable) return runSteps(ctx, *spec, 0, batch, fn);
-                // ---- fused: all steps' key columns from the stream rows, one device call ----
+                // ---- fused: one device call ----
                 std::vector<std::unique_ptr<detail::StagedColumns>> staged;
+                std::vector<std::vector<cph_strcol>> side(S);
                 std::vector<cph_chain_step> steps(S);
                 for (size_t k = 0; k < S; k++) {
                     const auto& cols = spec->steps[k].columns;
-                    std::vector<std::vector<const std::string*>> vals(cols.size());
-                    for (auto& v : vals) v.resize(batch->size());
-                    for (size_t i = 0; i < batch->size(); i++)
-                        for (size_t c = 0; c < cols.size(); c++) vals[c][i] = &(*batch)[i].at(cols[c]);
-                    staged.emplace_back(new detail::StagedColumns(ctx, cols.size()));
-                    staged.back()->stage(vals, batch->size());
                     steps[k] = cph_chain_step{};
                     steps[k].index = spec->steps[k].index->device().h;
-                    steps[k].cols = staged.back()->cols();
                     steps[k].ncols = (int32_t)cols.size();
+                    if (origin[k] == 0) {
+                        std::vector<std::vector<const std::string*>> vals(cols.size());
+                        for (auto& v : vals) v.resize(batch->size());
+                        for (size_t i = 0; i < batch->size(); i++)
+                            for (size_t c = 0; c < cols.size(); c++) vals[c][i] = &(*batch)[i].at(cols[c]);
+                        staged.emplace_back(new detail::StagedColumns(ctx, cols.size()));
+                        staged.back()->stage(vals, batch->size());
+                        steps[k].cols = staged.back()->cols();
+                    } else {   // the index's own rows, in sorted order (impl_rows), staged once per index
+                        const Index& from = *spec->steps[(size_t)origin[k] - 1].index;
+                        (void)from.device();   // positions must refer to impl_rows as they are now
+                        for (const auto& c : cols) side[k].push_back(*from.side_column(ctx, c));
+                        steps[k].cols = side[k].data();
+                        steps[k].source = -origin[k];
+                    }
                 }
                 cph_chain* ch = nullptr;
                 if (cph_join_chain_ex(ctx, steps.data(), (int32_t)S, 0, CPH_MEM_HOST, CPH_CHAIN_POSITIONS, &ch) != CPH_OK)
                     return Error(std::string("csvplus_hip: ") + cph_last_error(ctx));
+                fused_calls()++;
                 Error err;
                 for (uint64_t m = 0; m < ch->nrows && !err; m++) {
                     const uint64_t r = ch->stream_row ? ch->stream_row[m] : m;   // NULL: every row joined exactly once, in order
-                    Row row = mergeRows(spec->steps[0].index->impl_rows[ch->build_row[0][m]], (*batch)[(size_t)r]);
-                    for (size_t k = 1; k < S; k++) row = mergeRows(spec->steps[k].index->impl_rows[ch->build_row[k][m]], row);
+                    Row row = (*batch)[(size_t)r];
+                    for (size_t k = 0; k < S; k++) {
+                        row = mergeRows(spec->steps[k].index->impl_rows[ch->build_row[k][m]], row);
+                        for (const auto& c : spec->steps[k].drop_after) row.erase(c);
+                    }
                     err = fn(std::move(row));
                 }
                 cph_chain_release(ch);
@@ -516,6 +605,37 @@ private:
         });
     }
 
+    // Where the value of `col` in the row that step k's Join sees comes from, for a whole batch: 0 = every stream row carries
+    // it (and no DropColumns in between removed it), t + 1 = no stream row does and every row of steps[t].index does (the
+    // earliest such t < k: mergeRows lets the earlier, right-hand row win), -1 = the rows disagree or the column is gone.
+    static int columnOrigin(cph_ctx* ctx, const ChainSpec& spec, size_t k, const std::string& col, const std::vector<Row>& batch) {
+        auto dropped_between = [&](size_t from_step) {   // a DropColumns behind steps[from_step .. k-1] names the column
+            for (size_t j = from_step; j < k; j++)
+                for (const auto& d : spec.steps[j].drop_after)
+                    if (d == col) return true;
+            return false;
+        };
+        size_t have = 0;
+        for (const Row& r : batch) have += HasColumn(r, col) ? 1 : 0;
+        if (have == batch.size()) return dropped_between(0) ? -1 : 0;
+        if (have != 0) return -1;
+        for (size_t t = 0; t < k; t++) {
+            const Index& ix = *spec.steps[t].index;
+            if (ix.side_column(ctx, col)) return dropped_between(t) ? -1 : (int)t + 1;
+            for (const Row& r : ix.impl_rows)
+                if (HasColumn(r, col)) return -1;   // some rows of this index carry it, some do not
+        }
+        return -1;
+    }
+
+public:
+    // number of fused device calls made so far (tests: one call per batch)
+    static uint64_t& fused_calls() {
+        static uint64_t n = 0;
+        return n;
+    }
+
+private:
     // steps[from..] one after the other over `rows` (rows of step `from`'s stream that all carry its key columns)
     static Error runSteps(cph_ctx* ctx, const ChainSpec& spec, size_t from, std::vector<Row>* rows, const RowFunc& fn) {
         std::vector<Row> cur = std::move(*rows);
@@ -537,8 +657,12 @@ private:
                 }
             }
             std::vector<Row> next;
+            const RowFunc sink = last ? fn : RowFunc([&](Row row) { next.push_back(std::move(row)); return Error(); });
             Error e = probeBatch(ctx, st.index, st.columns, false, &cur,
-                                 last ? fn : RowFunc([&](Row row) { next.push_back(std::move(row)); return Error(); }));
+                                 st.drop_after.empty() ? sink : RowFunc([&](Row row) {
+                                     for (const auto& c : st.drop_after) row.erase(c);
+                                     return sink(std::move(row));
+                                 }));
             if (e) return e;
             cur = std::move(next);
         }
@@ -607,7 +731,7 @@ inline Error Index::ResolveDuplicates(const ResolveFunc& resolve) {
         std::vector<Row> pack(impl_rows.begin() + (long)lo, impl_rows.begin() + (long)hi);
         auto res = resolve(pack);                                                   // :835
         if (res.second) {                                                           // :835-837: rows stay as they are now
-            dev_.reset();
+            invalidate_device();
             return res.second;
         }
         if (res.first.size() >= impl_columns.size()) impl_rows[dest++] = std::move(res.first);   // :842-845
@@ -616,7 +740,7 @@ inline Error Index::ResolveDuplicates(const ResolveFunc& resolve) {
             if (dest != i) impl_rows[dest] = impl_rows[i];   // a copy, as the reference's slice assignment: the source slot keeps its row
     }
     impl_rows.resize(dest);                                                         // :862-864
-    dev_.reset();   // the device twin is rebuilt from the surviving rows on next use
+    invalidate_device();   // the device twin is rebuilt from the surviving rows on next use
     return Error();
 }
 

@@ -268,13 +268,23 @@ CPH_API void    cph_matches_release(cph_matches* m);
 
 #define CPH_MAX_CHAIN 4
 
-/* One Join of a chain: stream.Join(index, cols...).  `cols` are columns of the
- * STREAM table (all steps see the same nrows); ncols <= the index's key columns. */
+/* One Join of a chain: stream.Join(index, cols...).  ncols <= the index's key columns.
+ *   source == 0   `cols` are columns of the STREAM table (all such steps see the same nrows): the value the Join reads when
+ *                 the stream row carries the column (mergeRows lets the stream's value win, csvplus.go:571-583).
+ *   source == k   (1 <= k <= this step's number) `cols` are columns of the BUILD TABLE of step k-1 — the table steps[k-1].index
+ *                 was built from, in that table's ORIGINAL row order (cols[j].nrows == cph_index_nrows(steps[k-1].index)): the
+ *                 key of this Join is read from the row that step k-1 matched.  This is the reference's flagship chain,
+ *                 people.Join(orders, "id").Join(products) (csvplus_test.go:280-285): prod_id is a column of the ORDERS index
+ *                 row, which mergeRows copied into the joined row the second Join sees.
+ *   source == -k  the same with `cols` laid out in step k-1's SORTED order (row i of cols = the row at sorted position i:
+ *                 how the reference holds index.impl.rows after createIndex, csvplus.go:736; what cph_index_permute produces);
+ *                 needs CPH_CHAIN_POSITIONS.
+ * Step 0 always reads the stream. */
 typedef struct {
     const cph_index*  index;
     const cph_strcol* cols;
     int32_t           ncols;
-    int32_t           reserved_;
+    int32_t           source;
 } cph_chain_step;
 
 /*
@@ -299,11 +309,11 @@ typedef struct {
 } cph_chain;
 
 /*
- * Every key of the chain must be a column of the stream table, which is what
- * mergeRows guarantees whenever the stream row has that column (the stream's value
- * wins on a name collision).  A later key that exists only on an index side is
- * chained with cph_join_probe + row_sel instead.  When every index has distinct
- * keys over a single column the whole chain runs as ONE pass over the stream rows.
+ * A key of a later step is either a column of the stream table (source == 0) or a column of an earlier step's build table
+ * (source != 0, see cph_chain_step) — between them the two cover every value mergeRows can hand to a later Join.  When every
+ * index has distinct keys over a single column the whole chain runs as ONE pass over the stream rows, whatever the sources
+ * (a build-side key is gathered from the matched row inside the kernel); otherwise the steps run one after the other ON THE
+ * DEVICE (probe, expand, compose), still one call.
  */
 CPH_API int32_t cph_join_chain(cph_ctx* ctx, const cph_chain_step* steps, int32_t nsteps, uint64_t probe_base,
                                int32_t out_mem, cph_chain** out);

@@ -78,14 +78,6 @@ static DataSource SelectColumns(DataSource src, std::vector<std::string> cols) {
         });
     });
 }
-static DataSource DropColumns(DataSource src, std::vector<std::string> cols) {
-    return DataSource([src, cols](const RowFunc& fn) {
-        return src([&](Row row) {
-            for (auto& c : cols) row.erase(c);
-            return fn(std::move(row));
-        });
-    });
-}
 static DataSource Filter(DataSource src, std::function<bool(const Row&)> pred) {
     return DataSource([src, pred](const RowFunc& fn) {
         return src([&](Row row) { return pred(row) ? fn(std::move(row)) : Error(); });
@@ -192,6 +184,8 @@ static void TestSimpleTotals() {
 }
 
 // ---- TestLongChain (csvplus_test.go:248-366) -----------------------------------------------------------------------------
+static std::vector<Row> nestedJoinOnHost(const std::vector<Row>& stream, const Index& ia, const std::vector<std::string>& ka,
+                                         const Index& ib, const std::vector<std::string>& kb, Error* err);
 static void TestLongChain() {
     auto [orders, err] = SelectColumns(TakeRows(ordersRows), {"order_id", "cust_id", "prod_id", "qty", "ts"}).IndexOn({"cust_id"});
     CHECK(!err);
@@ -199,17 +193,20 @@ static void TestLongChain() {
     CHECK(!err2);
     auto people = SelectColumns(TakeRows(peopleRows), {"id", "name", "surname", "born"});
     int n = 0;
-    auto chain = DropColumns(
-        Top(Filter(Map(DropColumns(DropColumns(SelectColumns(Filter(people, [](const Row& r) { return atoi_s(r.at("born")) > 1970; }),
-                                                             {"id", "name", "surname"})
-                                                   .Join(orders, {"id"}),
-                                               {"ts", "order_id", "cust_id"})
-                                       .Join(products),
-                                   {"prod_id"}),
-                       [](Row row) { if (row["name"] == "Amelia") row["name"] = "Julia"; return row; }),
-                   [](const Row& r) { return r.at("surname") == "Smith"; }),
-            10),
-        {"id"});
+    // the reference's pipeline, method for method (csvplus_test.go:270-293).  Round 5: the two Joins and the DropColumns between
+    // them are ONE chain: prod_id — the key of the second Join — is a column of the ORDERS index rows, which the device reads
+    // from the row the first Join matched (cph_chain_step.source): one fused device call for the batch, no host round trip per step.
+    auto chain = Top(Filter(Map(Filter(people, [](const Row& r) { return atoi_s(r.at("born")) > 1970; })
+                                    .SelectColumns({"id", "name", "surname"})
+                                    .Join(orders, {"id"})
+                                    .DropColumns({"ts", "order_id", "cust_id"})
+                                    .Join(products)
+                                    .DropColumns({"prod_id"}),
+                                [](Row row) { if (row["name"] == "Amelia") row["name"] = "Julia"; return row; }),
+                            [](const Row& r) { return r.at("surname") == "Smith"; }),
+                     10)
+                     .DropColumns({"id"});
+    const uint64_t calls_before = DataSource::fused_calls();
     Error e = chain([&](Row row) -> Error {
         if (++n > 10) return Error("Too many rows");
         if (row.at("surname") != "Smith") return Error("Surname \"Smith\" not found");
@@ -221,6 +218,27 @@ static void TestLongChain() {
     if (e) std::printf("  chain: %s\n", e.message().c_str());
     CHECK(!e);
     CHECK(n == 10);
+    CHECK(DataSource::fused_calls() == calls_before + 1);   // the whole (one-batch) pipeline was ONE cph_join_chain_ex call
+    {
+        // all rows of the same chain against the nested joins run on the host (duplicates on the first build side: ~83 orders per person)
+        auto people3 = TakeRows(peopleRows).SelectColumns({"id", "name", "surname"});
+        Error he;
+        std::vector<Row> stream;
+        Error se = people3([&](Row r) { stream.push_back(std::move(r)); return Error(); });
+        CHECK(!se);
+        std::vector<Row> want = nestedJoinOnHost(stream, *orders, {"id"}, *products, {"prod_id"}, &he);
+        for (size_t batch : {(size_t)1, (size_t)50, (size_t)8192}) {
+            Gpu::Default().join_batch_rows = batch;
+            const uint64_t c0 = DataSource::fused_calls();
+            auto [got, ge] = people3.Join(orders, {"id"}).Join(products).ToRows();
+            CHECK(!he && !ge && got.size() == (size_t)numOrders && got == want);
+            CHECK(DataSource::fused_calls() == c0 + (stream.size() + batch - 1) / batch);
+        }
+        Gpu::Default().join_batch_rows = 8192;
+        // a DropColumns that removes the later key: the reference fails with `missing column "prod_id"` on the first joined row
+        auto [none, me] = people3.Join(orders, {"id"}).DropColumns({"prod_id"}).Join(products).ToRows();
+        CHECK(me && me.message() == "missing column \"prod_id\"" && none.empty());
+    }
     // the indices are unchanged afterwards (:325-365)
     n = 0;
     e = Take(orders)([&](Row row) { n++; return row.size() == 5 ? Error() : Error("bad order row"); });
@@ -501,10 +519,12 @@ static void TestChainPrecedence() {
         want = nestedJoinOnHost(stream, *id, {"cust_id"}, *ip, {"prod_id"}, &he);
         auto [got2, ge2] = TakeRows(stream).Join(id, {"cust_id"}).Join(ip, {"prod_id"}).ToRows();
         CHECK(!he && !ge2 && same(got2, want) && got2.size() > got.size());
-        // (3) the second key comes from the FIRST INDEX's row ("fav_prod" is a customers column): not fusable
+        // (3) the second key comes from the FIRST INDEX's row ("fav_prod" is a customers column): fused, the device gathers it
         want = nestedJoinOnHost(stream, *ic, {"cust_id"}, *ip, {"fav_prod"}, &he);
+        const uint64_t f3 = DataSource::fused_calls();
         auto [got3, ge3] = TakeRows(stream).Join(ic, {"cust_id"}).Join(ip, {"fav_prod"}).ToRows();
         CHECK(!he && !ge3 && same(got3, want) && !got3.empty());
+        CHECK(DataSource::fused_calls() == f3 + (stream.size() + batch - 1) / batch);
         // (4) mixed: every fifth stream row brings its own "fav_prod" (which then wins over the customer's)
         std::vector<Row> mixed = stream;
         for (size_t i = 0; i < mixed.size(); i += 5) mixed[i]["fav_prod"] = std::to_string(i % 44);
