@@ -78,7 +78,7 @@ def parse_args():
                     help="skip the `variants` block: the same step (2 index builds + chained Join of all rows) on other key shapes — "
                          "unpadded Itoa ids, a half-occupied id space, sparse random keys — and with the payload columns laid out in "
                          "index order (cph_index_permute)")
-    ap.add_argument("--variants", default="all", help="comma list out of: itoa,half,sparse,permute (default all)")
+    ap.add_argument("--variants", default="all", help="comma list out of: itoa,half,sparse,side,permute (default all)")
     ap.add_argument("--verify-sample", type=int, default=100_000)
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the two rocprofv3 --pmc child runs (FETCH_SIZE, WRITE_SIZE) behind roofline.traffic")
@@ -717,20 +717,26 @@ def main():
         from csvplus_amd import verify as V
         from csvplus_amd.engine import device_view
 
-        want = {"itoa", "half", "sparse", "permute"} if args.variants == "all" else set(args.variants.split(","))
+        want = {"itoa", "half", "sparse", "side", "permute"} if args.variants == "all" else set(args.variants.split(","))
         variants = {}
 
-        def run_variant(name, what, v_cust, v_ocust, extra_build=None, sample_check=True):
-            """v_cust: the customers' id column (host), v_ocust: the orders' cust_id column (host, all rows)."""
+        def run_variant(name, what, v_cust, v_ocust, extra_build=None, sample_check=True, side_key=None):
+            """v_cust: the customers' id column (host), v_ocust: the orders' cust_id column (host, all rows).  side_key: a HOST
+            column of the customers table the products step reads its key from (cph_chain_step.source = 1) instead of
+            orders.prod_id."""
             torch.cuda.empty_cache()
             dc, do_ = v_cust.to_device(dev), v_ocust.to_device(dev)
+            d_side = side_key.to_device(dev) if side_key is not None else None
             keep = []
+
+            def chain_of(a, b):
+                return [(a, [do_]), (b, [d_side], 1)] if d_side is not None else [(a, [do_]), (b, [d_ord["prod_id"]])]
 
             def vstep():
                 a, b = eng.index_on_many([[dc], [d_prod]], unique=True)
                 if extra_build:
                     keep[:] = extra_build(a, b)
-                c = N.join_chain(eng.ctx, [(a, [do_]), (b, [d_ord["prod_id"]])], probe_base=begin, out_mem=N.CPH_MEM_DEVICE, positions=True)
+                c = N.join_chain(eng.ctx, chain_of(a, b), probe_base=begin, out_mem=N.CPH_MEM_DEVICE, positions=True)
                 n_ = c.nrows
                 inf_ = (a.info(), b.info()) if "info" not in vstep.__dict__ else vstep.info
                 vstep.info = inf_
@@ -763,6 +769,8 @@ def main():
             # positions out per joined row, each lookup structure charged ONCE at its size (rank table: 8 B per 32 codes of a
             # code space the index does not fill; hash table: its sectors), as in roofline.bytes_model of the timed step
             s_in = v_ocust.nbytes_values() + v_ocust.nbytes_offsets() + host_bytes["prod_id"] + ords["prod_id"].nbytes_offsets()
+            if side_key is not None:   # per joined row: perm[position] (4 B), two offsets (8 B) and the key bytes of the customer row it matched
+                s_in = v_ocust.nbytes_values() + v_ocust.nbytes_offsets() + nloc * (4.0 + 8.0 + side_key.nbytes_values() / side_key.nrows)
             look = 0.0
             for inf_, rows_ in ((ia_i, args.customers), (ib_i, args.products)):
                 if inf_["hash_bytes"]:
@@ -781,7 +789,14 @@ def main():
                                 "frac": round(algo / 1e9 / (kd_ms_ / 1e3) / HBM_PEAK_GBPS, 4) if kd_ms_ else None}}
             if not args.no_verify:
                 a, b = eng.index_on_many([[dc], [d_prod]], unique=True)
-                res_ = eng.chained_join([(a, do_), (b, d_ord["prod_id"])], probe_base=begin, positions=True)
+                if d_side is not None:
+                    ch_ = N.join_chain(eng.ctx, chain_of(a, b), probe_base=begin, out_mem=N.CPH_MEM_DEVICE, positions=True)
+                    p_ = ch_.device_ptrs()
+                    from csvplus_amd.engine import ChainResult
+                    res_ = ChainResult(None if ch_.identity else device_view(p_["stream_row"], ch_.nrows, "<i8", ch_, dev),
+                                       [device_view(q_, ch_.nrows, "<i4", ch_, dev) for q_ in p_["build_row"]], ch_.nrows, keep=(ch_,), stream_base=begin)
+                else:
+                    res_ = eng.chained_join([(a, do_), (b, d_ord["prod_id"])], probe_base=begin, positions=True)
                 allj = res_.n == nloc and res_.stream_row is None
                 ver_ = {"joined_rows": res_.n, "every_stream_row_joined_once": allj}
                 ok_ = allj
@@ -794,6 +809,12 @@ def main():
                     ver_["cust_key_mismatches"] = V.check_join_sample(v_ocust, v_cust, b0_, rows_)
                     ver_["digest_positions_0"] = f"{V.digest_u64(res_.build_rows[0]):016x}"
                     ok_ = ok_ and ver_["cust_key_mismatches"] == 0
+                    if side_key is not None:   # the product a row reports carries the key of the CUSTOMER row it matched
+                        pb2_ = device_view(b.perm_device_ptr(), b.nrows, "<i4", b, dev)
+                        b1_ = pb2_[res_.build_rows[1][idx_].long()].cpu().numpy()
+                        ver_["side_key_mismatches"] = V.check_join_sample(side_key, prod_id, b1_, b0_.astype(np.int64) & 0xFFFFFFFF)
+                        ok_ = ok_ and ver_["side_key_mismatches"] == 0
+                        del pb2_
                     del pk_, idx_
                 pm_ = device_view(a.perm_device_ptr(), a.nrows, "<i4", a, dev)
                 ver_["index_customers"] = V.check_index_order(dc, pm_)
@@ -829,6 +850,13 @@ def main():
                 "sparse_random_keys", "customers keyed by 12 random [a-z0-9] characters (62-bit code space): radix-sorted index, hash probe",
                 dg.column(dg.RANDKEY, args.customers, 0, seed=dg.SEED + 12),
                 dg.column(dg.RANDKEY, nloc, 0, base=args.customers, seed=dg.SEED + 12, row0=begin)))
+        if "side" in want:
+            guarded("build_side_key", lambda: run_variant(
+                "build_side_key", "orders.Join(customers, cust_id).Join(products, fav_prod) with fav_prod a column of the CUSTOMERS table "
+                "(cph_chain_step.source = 1; the shape of the reference's people.Join(orders).Join(products), csvplus_test.go:280-285): "
+                "the fused kernel gathers the second key from the customer row it matched (perm, offsets, key bytes: three dependent "
+                "random accesses per row)", cust_id, ords["cust_id"],
+                side_key=dg.column(dg.UNIFORM, args.customers, args.products, encoding=dg.ITOA, seed=dg.SEED + 21)))
         if "permute" in want:
             from csvplus_amd.materialize import permute_col
 

@@ -233,6 +233,35 @@ Status ensure_pinned_scratch(cph_ctx* ctx, size_t bytes) {
     return {};
 }
 
+uint32_t* host_word(cph_ctx* ctx, uint32_t n) {
+    if (!ctx->host_words) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, kHostWords * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        ctx->host_words = static_cast<uint32_t*>(p);
+        ctx->host_words_pos = 0;
+    }
+    n = (n + 1u) & ~1u;
+    if (n > kHostWords) return nullptr;
+    if (ctx->host_words_pos + n > kHostWords) ctx->host_words_pos = 0;
+    uint32_t* w = ctx->host_words + ctx->host_words_pos;
+    ctx->host_words_pos += n;
+    for (uint32_t i = 0; i < n; i++) w[i] = 0;
+    return w;
+}
+
+Status self_clean_block(cph_ctx* ctx, DevBuf* b, size_t bytes) {
+    if (*b && b->bytes() >= bytes) return {};
+    if (*b) CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));   // (its last user may still run)
+    b->reset();
+    CPH_TRY(b->alloc(&ctx->pool, bytes));
+    CPH_HIP_TRY(hipMemsetAsync(b->get(), 0, b->bytes(), ctx->stream));
+    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));   // once: the block is zero at rest from here on, whichever stream uses it
+    return {};
+}
+
 Status pinned_cache_get(cph_ctx* ctx, size_t bytes, void** out, size_t* cap) {
     int best = -1;
     for (int i = 0; i < (int)ctx->pinned_cache.size(); i++)
@@ -421,6 +450,7 @@ struct BuildJob {
     std::vector<DevBuf> staged;
     DevCol dcols[kMaxKeyCols];
     DevBuf stats_dev;
+    const void* sample_host = nullptr;   // sampled: where the sample kernel itself leaves its result (report words of the ctx: no read-back copy)
     size_t scratch_off = 0;      // where this job's read-backs land in ctx->pinned_scratch
     GroupSpec spec;              // speculative dictionaries (codec_try_groups)
     bool small = false;          // one-launch build (small_build.hip): no statistics pass, no second synchronisation
@@ -428,13 +458,14 @@ struct BuildJob {
     bool presplit = false;       // a large single-column table whose split codec was built from a sample + one exact pass BEFORE any plain
                                  // statistics (build_phase1): no statistics pass at all
     bool sampled = false;        // alphabets from a sample of the rows (keycodec.hip: codec_sample_*): the encode kernel checks every row, a
-                                 // miss (split_miss) starts the build over with the exact statistics pass
+                                 // miss (BuildJob::miss) starts the build over with the exact statistics pass
     bool no_sample = false;
     bool unique = false;         // the caller expects distinct keys (UniqueIndexOn): the optimistic direct sort may be tried
     bool no_direct = false;
     bool side = false;           // this job's work is enqueued on the ctx's side stream (cph_index_build_many: it overlaps its neighbour's)
     bool no_split = false;       // second attempt after a split codec met a row it could not code (keycodec.hip: codec_try_split)
-    DevBuf split_miss;           // u32 raised by the encode kernel of a split codec; read back with the first duplicate
+    uint32_t* miss = nullptr;    // report word (pinned host memory, host_word) raised by the encode kernel of a split / sampled codec and by the
+                                 // optimistic direct sort; read after the build's last synchronisation
 };
 
 static Status build_phase1(cph_ctx* ctx, const cph_strcol* keycols, int32_t nkeycols, BuildJob* job) {
@@ -454,16 +485,20 @@ static Status build_phase1(cph_ctx* ctx, const cph_strcol* keycols, int32_t nkey
         job->presplit = ix->codec.has_split();
     }
     job->sampled = !job->small && !job->presplit && !job->no_sample && codec_sample_applies(ctx, job->dcols, nkeycols, ix->nrows);
-    if (job->sampled) CPH_TRY(codec_sample_launch(ctx, job->dcols[0], ix->nrows, &job->stats_dev));
+    if (job->sampled) CPH_TRY(codec_sample_launch(ctx, job->dcols[0], ix->nrows, &job->sample_host));
     else if (!job->small && !job->presplit) CPH_TRY(codec_stats_launch(ctx, job->dcols, nkeycols, &job->stats_dev));   // K0: alphabets
     return {};
 }
 
 static Status build_phase2(cph_ctx* ctx, BuildJob* job, const void* stats_host);
+static Status job_arm_miss(cph_ctx* ctx, BuildJob* job) {
+    job->miss = host_word(ctx);
+    return job->miss ? Status{} : Status{CPH_ERR_HIP, "no pinned host memory for the report words of a build"};
+}
 static Status build_encode_sort(cph_ctx* ctx, BuildJob* job);
 
 static size_t job_readback_bytes(const BuildJob& j) {   // what sync 1 brings to the host for this job
-    return j.small ? sizeof(SmallResult) : j.presplit ? 0 : j.sampled ? codec_sample_bytes() : sizeof(ColStats) * (size_t)j.nkeycols;
+    return j.small ? sizeof(SmallResult) : (j.presplit || j.sampled) ? 0 : sizeof(ColStats) * (size_t)j.nkeycols;
 }
 
 // Runs a batch of jobs whose phase 1 succeeded (ok[i]); status[i] receives each job's outcome.
@@ -493,7 +528,7 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
                                            reinterpret_cast<SmallResult*>(h + jobs[i].scratch_off));
             continue;
         }
-        if (jobs[i].presplit) continue;
+        if (jobs[i].presplit || jobs[i].sampled) continue;   // (a sample's result is written to the host by its kernel)
         hipError_t e = hipMemcpyAsync(h + jobs[i].scratch_off, jobs[i].stats_dev.get(), job_readback_bytes(jobs[i]),
                                       hipMemcpyDeviceToHost, jobs[i].side ? ctx->side_stream : ctx->stream);
         if (e != hipSuccess) status[i] = {CPH_ERR_HIP, std::string("statistics read-back: ") + hipGetErrorString(e)};
@@ -519,7 +554,12 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
             else if (status[i].ok()) index_plan_table(jobs[i].ix);
             continue;
         }
-        if (!jobs[i].presplit) stats_host[i].assign(h + jobs[i].scratch_off, h + jobs[i].scratch_off + job_readback_bytes(jobs[i]));
+        if (jobs[i].sampled) {
+            const uint8_t* sh = static_cast<const uint8_t*>(jobs[i].sample_host);
+            stats_host[i].assign(sh, sh + codec_sample_bytes());
+        } else if (!jobs[i].presplit) {
+            stats_host[i].assign(h + jobs[i].scratch_off, h + jobs[i].scratch_off + job_readback_bytes(jobs[i]));
+        }
     }
     for (size_t i = 0; i < nj; i++)
         if (status[i].ok() && !jobs[i].small) {
@@ -536,10 +576,10 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
         for (size_t i = 0; i < nj; i++) {
             if (!status[i].ok() || jobs[i].small) continue;
             hipStream_t js = jobs[i].side ? ctx->side_stream : ctx->stream;
-            hipError_t e = hipMemcpyAsync(&fd[i], jobs[i].ix->first_dup_dev.get(), sizeof(uint32_t), hipMemcpyDeviceToHost, js);
+            fd[i] = 0xFFFFFFFFu;   // no adjacent-equal scan ran (the direct sort): distinct keys, or the miss word sends the build round again
             sm[i] = 0;
-            if (e == hipSuccess && jobs[i].split_miss)
-                e = hipMemcpyAsync(&sm[i], jobs[i].split_miss.get(), sizeof(uint32_t), hipMemcpyDeviceToHost, js);
+            if (!jobs[i].ix->first_dup_dev) continue;
+            hipError_t e = hipMemcpyAsync(&fd[i], jobs[i].ix->first_dup_dev.get(), sizeof(uint32_t), hipMemcpyDeviceToHost, js);
             if (e != hipSuccess) status[i] = {CPH_ERR_HIP, std::string("first-duplicate read-back: ") + hipGetErrorString(e)};
         }
         if (!sync_streams()) return fail_all({CPH_ERR_HIP, "hipStreamSynchronize failed"});
@@ -547,6 +587,7 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
         for (size_t i = 0; i < nj; i++) {
             if (!status[i].ok() || jobs[i].small) continue;
             cph_index* ix = jobs[i].ix;
+            if (jobs[i].miss) sm[i] = *(volatile uint32_t*)jobs[i].miss;   // written by the kernels themselves (pinned host memory)
             if (sm[i]) { resplit.push_back(i); continue; }
             ix->first_dup = fd[i] != 0xFFFFFFFFu ? (uint64_t)fd[i] : UINT64_MAX;
             ix->first_dup_dev.reset();
@@ -564,7 +605,7 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
         j.sampled = false;
         j.no_direct = true;
         j.presplit = false;
-        j.split_miss.reset();
+        j.miss = nullptr;
         cph_index* ix = j.ix;
         ix->codec = CodecHost{};
         ix->codec_dev.reset(); ix->sorted_codes.reset(); ix->perm.reset(); ix->first_dup_dev.reset();
@@ -698,8 +739,7 @@ static Status build_phase2(cph_ctx* ctx, BuildJob* job, const void* stats_host) 
     const int32_t nkeycols = job->nkeycols;
     const DevCol* dcols = job->dcols;
     if (job->presplit) {   // the codec is there already (build_phase1)
-        CPH_TRY(job->split_miss.alloc(&ctx->pool, sizeof(uint32_t)));
-        CPH_HIP_TRY(hipMemsetAsync(job->split_miss.get(), 0, sizeof(uint32_t), ctx->stream));
+        CPH_TRY(job_arm_miss(ctx, job));
         CPH_TRY(codec_upload(ctx, ix->codec, &ix->codec_dev));
         return build_encode_sort(ctx, job);
     }
@@ -708,8 +748,7 @@ static Status build_phase2(cph_ctx* ctx, BuildJob* job, const void* stats_host) 
         codec_sample_finish(dcols[0], stats_host, &stats);
         CPH_TRY(codec_build(stats, &ix->codec));
         if (codec_sample_checked(ix->codec, dcols)) {
-            CPH_TRY(job->split_miss.alloc(&ctx->pool, sizeof(uint32_t)));
-            CPH_HIP_TRY(hipMemsetAsync(job->split_miss.get(), 0, sizeof(uint32_t), ctx->stream));
+            CPH_TRY(job_arm_miss(ctx, job));
             CPH_TRY(codec_upload(ctx, ix->codec, &ix->codec_dev));
             return build_encode_sort(ctx, job);
         }
@@ -726,8 +765,7 @@ static Status build_phase2(cph_ctx* ctx, BuildJob* job, const void* stats_host) 
     CPH_TRY(codec_build(stats, &ix->codec));
     if (!job->no_split) CPH_TRY(codec_try_split(ctx, dcols, nkeycols, n, &stats, &ix->codec));   // only acts on codes beyond 32 bits
     if (ix->codec.has_split()) {
-        CPH_TRY(job->split_miss.alloc(&ctx->pool, sizeof(uint32_t)));
-        CPH_HIP_TRY(hipMemsetAsync(job->split_miss.get(), 0, sizeof(uint32_t), ctx->stream));
+        CPH_TRY(job_arm_miss(ctx, job));
     } else {
         CPH_TRY(codec_try_groups(ctx, dcols, nkeycols, n, &ix->codec, &job->spec));   // only acts on codes of several words
     }
@@ -760,9 +798,8 @@ static Status build_encode_sort(cph_ctx* ctx, BuildJob* job) {
         const bool direct = job->unique && !job->no_direct && ctx->direct_sort != 0 && cd.key32 && !job->spec.active && n >= (1ull << 16) &&
                             states >= n && states <= 2 * n && states < 0xFFFFFFFFull;
         if (direct) {
-            if (!job->split_miss) {
-                CPH_TRY(job->split_miss.alloc(&ctx->pool, sizeof(uint32_t)));
-                CPH_HIP_TRY(hipMemsetAsync(job->split_miss.get(), 0, sizeof(uint32_t), ctx->stream));
+            if (!job->miss) {
+                CPH_TRY(job_arm_miss(ctx, job));
             }
             // ctx option direct_sort = 3: over a full code space the encode kernel fills the slots itself (no code array).  Measured
             // SLOWER than encode + a dedicated scatter kernel (1e7 rows: 0.26 against 0.047 + 0.164 ms — the scattered stores stall the
@@ -772,15 +809,13 @@ static Status build_encode_sort(cph_ctx* ctx, BuildJob* job) {
                 eh.slots = va.as<uint32_t>();
                 eh.slot_states = (uint32_t)states;
             }
-            CPH_TRY(codec_encode_build(ctx, cd, ix->codec_dev, dcols, n, ka.get(), &eh, nullptr, job->split_miss.as<uint32_t>()));
-            if (eh.scattered) CPH_TRY(direct_sort_finish_full(ctx, va.as<uint32_t>(), n, ka.as<uint32_t>(), job->split_miss.as<uint32_t>()));
-            else CPH_TRY(direct_sort_distinct(ctx, ka.as<uint32_t>(), n, states, va.as<uint32_t>(), ka.as<uint32_t>(), job->split_miss.as<uint32_t>()));
+            CPH_TRY(codec_encode_build(ctx, cd, ix->codec_dev, dcols, n, ka.get(), &eh, nullptr, job->miss));
+            if (eh.scattered) CPH_TRY(direct_sort_finish_full(ctx, va.as<uint32_t>(), n, ka.as<uint32_t>(), job->miss));
+            else CPH_TRY(direct_sort_distinct(ctx, ka.as<uint32_t>(), n, states, va.as<uint32_t>(), ka.as<uint32_t>(), job->miss));
             ix->sorted_codes = std::move(ka);
             ix->perm = std::move(va);
             ix->sort_passes = 0;
-            // no adjacent-equal scan: either the keys are distinct or the flag sends the build down the general path
-            CPH_TRY(ix->first_dup_dev.alloc(&ctx->pool, sizeof(uint32_t)));
-            CPH_HIP_TRY(hipMemsetAsync(ix->first_dup_dev.get(), 0xFF, sizeof(uint32_t), ctx->stream));
+            // no adjacent-equal scan (first_dup_dev stays empty): either the keys are distinct or the miss word sends the build down the general path
             return {};
         }
         if (plan.npass > 0) {
@@ -790,7 +825,7 @@ static Status build_encode_sort(cph_ctx* ctx, BuildJob* job) {
             eh.bins = 1u << plan.rbits;
             eh.counts = counts.as<uint32_t>();
         }
-        CPH_TRY(codec_encode_build(ctx, cd, ix->codec_dev, dcols, n, ka.get(), &eh, &job->spec, job->split_miss.as<uint32_t>()));
+        CPH_TRY(codec_encode_build(ctx, cd, ix->codec_dev, dcols, n, ka.get(), &eh, &job->spec, job->miss));
         if (job->spec.active) {
             // speculative dictionaries (from a sample of the rows): did the encode kernel meet a window they lack?  Then
             // it has added every such window to the device sets: rebuild the codec from the now complete sets and encode
@@ -829,7 +864,7 @@ static Status build_encode_sort(cph_ctx* ctx, BuildJob* job) {
         // multi-word codes: LSD over the words, least significant word first
         DevBuf all;
         CPH_TRY(all.alloc(&ctx->pool, (size_t)cd.nwords * n * sizeof(uint64_t)));
-        CPH_TRY(codec_encode_build(ctx, cd, ix->codec_dev, dcols, n, all.get(), nullptr, nullptr, job->split_miss.as<uint32_t>()));
+        CPH_TRY(codec_encode_build(ctx, cd, ix->codec_dev, dcols, n, all.get(), nullptr, nullptr, job->miss));
         CPH_TRY(sort_words_lsd(ctx, ix, all.as<uint64_t>(), cd.nwords, cd.word_bits, n, va, vb));
     }
 
@@ -892,6 +927,7 @@ CPH_API int32_t cph_ctx_create(int32_t device_id, cph_ctx** out) {
     (void)ensure_pinned_scratch(ctx, 1 << 16);
     void* ring = nullptr;
     (void)pinned_upload(ctx, 64, &ring);
+    (void)host_word(ctx);
     *out = ctx;
     return CPH_OK;
 }
@@ -902,6 +938,7 @@ CPH_API void cph_ctx_destroy(cph_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->pinned_scratch) (void)hipHostFree(ctx->pinned_scratch);
     if (ctx->upload_ring) (void)hipHostFree(ctx->upload_ring);
+    if (ctx->host_words) (void)hipHostFree(ctx->host_words);
     for (void* p : ctx->pinned_user) (void)hipHostFree(p);
     for (auto& b : ctx->pinned_cache) (void)hipHostFree(b.first);
     for (auto& p : ctx->prof_pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
@@ -913,6 +950,7 @@ CPH_API void cph_ctx_destroy(cph_ctx* ctx) {
     }
     if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
     for (auto& sc : ctx->scan) sc.words.reset();
+    for (auto& sc : ctx->self_clean) { sc.sum.reset(); sc.sample.reset(); sc.win.reset(); }
     ctx->pool.trim();
     if (own) (void)hipStreamDestroy(own);
     delete ctx;

@@ -475,6 +475,32 @@ __global__ __launch_bounds__(256) void k_sum_counts(const uint32_t* __restrict__
     }
 }
 
+// The same, reporting straight to the host: the sum gathers in a SELF-CLEANING device accumulator (cph_ctx::SelfClean::sum:
+// {u64 total, u32 ticket}, zero at rest) and the LAST workgroup stores it into *host_out (pinned host memory: cph::host_word)
+// and zeroes the accumulator again — no memset in front of this launch, no device-to-host copy behind it.
+__global__ __launch_bounds__(256) void k_sum_counts_report(const uint32_t* __restrict__ counts, uint64_t n, unsigned long long* __restrict__ acc,
+                                                          uint32_t* __restrict__ ticket, unsigned long long* __restrict__ host_out) {
+    __shared__ uint64_t s_w[256 / kWave];
+    uint64_t t = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) t += counts[i];
+    t = wave_sum(t);
+    if (lane_id() == 0) s_w[wave_id()] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t r = 0;
+        for (int w = 0; w < 256 / kWave; w++) r += s_w[w];
+        if (r) atomicAdd(acc, (unsigned long long)r);
+        __threadfence();
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1u) {   // every other workgroup's add happened before its ticket
+            const unsigned long long total = atomicExch(acc, 0ull);
+            atomicExch(ticket, 0u);
+            *host_out = total;
+            __threadfence_system();
+        }
+    }
+}
+
 // Moves the matched tuples of a wave's rows from slot == row to their final slots (wave_base = the exclusive scan
 // of the (tile, wave) counts).  Wave-local: no LDS, no barrier.
 template <int S>
@@ -539,7 +565,7 @@ bool chain_fast_path_ok(const ChainStep* steps, int nsteps) {
 template <int S>
 static Status enqueue_dense(cph_ctx* ctx, const ChainStep* steps, uint64_t nprobe, uint64_t probe_base,
                             uint32_t* const* d_rows, uint64_t* d_masks, uint32_t* d_counts, uint64_t* d_total,
-                            ChainArgs* args_out, unsigned* grid_out, bool positions) {
+                            ChainArgs* args_out, unsigned* grid_out, bool positions, uint64_t* host_total = nullptr) {
     const uint64_t ntiles = (nprobe + kChainTile - 1) / kChainTile;
     ChainArgs args{};
     LeanArgs largs{};
@@ -676,7 +702,14 @@ static Status enqueue_dense(cph_ctx* ctx, const ChainStep* steps, uint64_t nprob
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(kChainThreads), lds, ctx->stream, args, nprobe, probe_base,
                            ntiles, d_masks, d_counts, dep ? 0 : dbg, largs);
     }
-    {
+    if (host_total) {   // the total goes straight into a report word of the host (d_total unused)
+        DevBuf& acc = ctx->self_clean[ctx->stream_slot].sum;
+        CPH_TRY(self_clean_block(ctx, &acc, 16));
+        ProfScope ps(ctx, "k_sum_counts", 4.0 * (double)ncounts);
+        const unsigned sgrid = (unsigned)std::min<uint64_t>((ncounts + 255) / 256, 512);
+        hipLaunchKernelGGL(k_sum_counts_report, dim3(sgrid), dim3(256), 0, ctx->stream, d_counts, ncounts, acc.as<unsigned long long>(),
+                           acc.as<uint32_t>() + 2, reinterpret_cast<unsigned long long*>(host_total));
+    } else {
         ProfScope ps(ctx, "k_sum_counts", 4.0 * (double)ncounts);
         CPH_HIP_TRY(hipMemsetAsync(d_total, 0, sizeof(uint64_t), ctx->stream));
         const unsigned sgrid = (unsigned)std::min<uint64_t>((ncounts + 255) / 256, 512);
@@ -769,18 +802,17 @@ static Status run_fast(cph_ctx* ctx, const ChainStep* steps, uint64_t nprobe, ui
         CPH_TRY(out->build_row[s].alloc(&ctx->pool, nprobe * sizeof(uint32_t)));
         rows[s] = out->build_row[s].as<uint32_t>();
     }
-    DevBuf masks, counts, total;
+    DevBuf masks, counts;
     CPH_TRY(masks.alloc(&ctx->pool, ntiles * kChainMasks * sizeof(uint64_t)));
     CPH_TRY(counts.alloc(&ctx->pool, ncounts * sizeof(uint32_t)));
-    CPH_TRY(total.alloc(&ctx->pool, sizeof(uint64_t)));
+    // the match total lands in a report word of the host (written by k_sum_counts_report's last workgroup): one wait, no copy
+    volatile uint64_t* h = reinterpret_cast<volatile uint64_t*>(host_word(ctx, 2));
+    if (!h) return {CPH_ERR_HIP, "no pinned host memory for the match total"};
     ChainArgs args{};
     unsigned grid = 1;
     CPH_TRY(enqueue_dense<S>(ctx, steps, nprobe, probe_base, rows, masks.as<uint64_t>(), counts.as<uint32_t>(),
-                             total.as<uint64_t>(), &args, &grid, positions));
+                             nullptr, &args, &grid, positions, const_cast<uint64_t*>(h)));
     CPH_HIP_TRY(hipGetLastError());
-    CPH_TRY(ensure_pinned_scratch(ctx, sizeof(uint64_t)));
-    uint64_t* h = reinterpret_cast<uint64_t*>(ctx->pinned_scratch);
-    CPH_HIP_TRY(hipMemcpyAsync(h, total.get(), sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
     const uint64_t nmatch = h[0];
     out->nrows = nmatch;

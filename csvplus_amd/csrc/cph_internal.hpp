@@ -309,6 +309,20 @@ struct cph_ctx {
     // pinned blocks of released host-side results (cph_index_perm copies), reused by the next one of a fitting size:
     // page-locking 400 MB costs tens of milliseconds, a caller that builds index after index should pay it once
     std::vector<std::pair<void*, size_t>> pinned_cache;
+    // pinned, device-visible words for what kernels REPORT to the host: a kernel stores into them directly (plain stores over
+    // PCIe: rare, a flag or a total), the host reads them after its next synchronisation — no memset to arm one (the host
+    // writes it), no device-to-host copy to read it.  Taken round robin (host_word): a word is in use for one call only.
+    uint32_t* host_words = nullptr;
+    uint32_t host_words_pos = 0;
+    // Device accumulators that CLEAN UP AFTER THEMSELVES (zeroed once when allocated; the last workgroup of the kernel that
+    // fills one exports the result to a report word and zeroes it again): no memset in front of the kernel, no copy behind it.
+    // One set per stream slot (the two streams of a build batch run concurrently).
+    struct SelfClean {
+        cph::DevBuf sum;           // k_sum_counts_report: {u64 total, u32 ticket, u32 pad}
+        cph::DevBuf sample;        // k_split_count of a sampled build: SplitSample + ticket
+        cph::DevBuf win;           // window_sort.hip: bucket cursors
+        uint64_t win_words = 0;
+    } self_clean[2];
     cph::DevBuf safe_words;        // 64 readable device bytes: the data base of columns that come without a buffer
     // per-ctx launch state (a process may hold one ctx per device: nothing of this may be static)
     int cus = 0;                   // compute units of `device` (0: not queried yet)
@@ -360,6 +374,12 @@ struct cph_ctx {
 };
 
 namespace cph {
+constexpr uint32_t kHostWords = 16384;
+// n consecutive report words (8-byte aligned), zeroed by the host; nullptr when the block could not be allocated
+uint32_t* host_word(cph_ctx* ctx, uint32_t n = 1);
+// a zeroed device block of at least `bytes` for a self-cleaning accumulator (allocated / grown on demand: one memset and
+// one synchronisation, once)
+Status self_clean_block(cph_ctx* ctx, cph::DevBuf* b, size_t bytes);
 // Everything a ctx enqueues goes to ctx->stream; for the duration of this guard that is the side stream.
 struct SideStream {
     cph_ctx* ctx;
@@ -496,7 +516,7 @@ Status codec_build(const std::vector<ColStats>& stats, CodecHost* codec);   // h
 // alphabets from a sample of the rows instead of a pass over all of them (keycodec.hip; capi.hip: BuildJob::sampled)
 bool codec_sample_applies(const cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t n);
 size_t codec_sample_bytes();
-Status codec_sample_launch(cph_ctx* ctx, const DevCol& col, uint64_t n, DevBuf* dev);
+Status codec_sample_launch(cph_ctx* ctx, const DevCol& col, uint64_t n, const void** host_copy);
 void codec_sample_finish(const DevCol& col, const void* host_copy, std::vector<ColStats>* out);
 bool codec_sample_checked(const CodecHost& codec, const DevCol* cols);
 // When the per-position code needs several words: one more pass over the key columns collects the distinct

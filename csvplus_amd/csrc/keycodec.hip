@@ -104,17 +104,15 @@ __global__ __launch_bounds__(kStatsThreads) void k_col_stats(DevCol col, uint32_
         // most workgroups find their bits already set by an earlier one: look before the (contended) atomic
         if (bits && (__hip_atomic_load(&g_mask[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bits) != bits) atomicOr(&g_mask[i], bits);
     }
-    if (threadIdx.x == 0) { atomicMin(&g_minmax[0], s_min); atomicMax(&g_minmax[1], s_max); }
+    if (threadIdx.x == 0) { atomicMax(&g_minmax[0], ~s_min); atomicMax(&g_minmax[1], s_max); }   // the minimum INVERTED: the whole block starts as zeros
 }
 
 // Enqueues the statistics pass of every column; the results stay on the device (block d: ColStats per column).
 Status codec_stats_launch(cph_ctx* ctx, const DevCol* cols, int32_t ncols, DevBuf* d) {
     const size_t per = sizeof(ColStats);
     CPH_TRY(d->alloc(&ctx->pool, per * (size_t)ncols));
-    // init: minlen = 0xFFFFFFFF, everything else 0
+    // init: all zeros (the kernel keeps the minimum length inverted; codec_stats_finish turns it back)
     CPH_HIP_TRY(hipMemsetAsync(d->get(), 0, per * (size_t)ncols, ctx->stream));
-    for (int c = 0; c < ncols; c++)
-        CPH_HIP_TRY(hipMemsetAsync(d->as<uint8_t>() + per * (size_t)c, 0xFF, sizeof(uint32_t), ctx->stream));
     int cus = 256;
     CPH_TRY(device_cus(ctx, &cus));
     for (int c = 0; c < ncols; c++) {
@@ -139,8 +137,10 @@ Status codec_stats_launch(cph_ctx* ctx, const DevCol* cols, int32_t ncols, DevBu
 void codec_stats_finish(const DevCol* cols, int32_t ncols, const void* host, std::vector<ColStats>* out) {
     out->assign((size_t)ncols, ColStats{});
     memcpy(out->data(), host, sizeof(ColStats) * (size_t)ncols);
-    for (int c = 0; c < ncols; c++)
+    for (int c = 0; c < ncols; c++) {
+        (*out)[c].minlen = ~(*out)[c].minlen;
         if (cols[c].nrows == 0) { (*out)[c].minlen = 0; (*out)[c].maxlen = 0; }
+    }
 }
 
 Status codec_collect_stats(cph_ctx* ctx, const DevCol* cols, int32_t ncols, std::vector<ColStats>* out) {
@@ -1023,7 +1023,10 @@ __global__ __launch_bounds__(kSplitThreads) void k_split_stats(DevCol col, Split
 // Rows (0, step, 2 step, ... : n of them) that hold each byte value at least once (a byte is counted at its FIRST
 // occurrence in a value) — where a delimiter could be —, and the plain per-position statistics of those rows (lengths,
 // byte presence per position) — what the per-position code would cost.
-__global__ __launch_bounds__(kSplitThreads) void k_split_count(DevCol col, uint64_t step, uint64_t n, SplitSample* __restrict__ out) {
+// host_out != nullptr: *out is a SELF-CLEANING accumulator (zero at rest; ticket behind it): the last workgroup moves the result into
+// *host_out (pinned host memory) and leaves *out zero again — no memset in front of the launch, no copy behind it.
+__global__ __launch_bounds__(kSplitThreads) void k_split_count(DevCol col, uint64_t step, uint64_t n, SplitSample* __restrict__ out,
+                                                              SplitSample* __restrict__ host_out) {
     constexpr int NCH = kSplitMaxValue / 8;
     __shared__ uint32_t s_cnt[256];
     __shared__ __attribute__((aligned(16))) uint8_t s_flag[kSplitMaxValue * 256];
@@ -1068,6 +1071,21 @@ __global__ __launch_bounds__(kSplitThreads) void k_split_count(DevCol col, uint6
         if (bits && (__hip_atomic_load(gm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bits) != bits) atomicOr(gm, bits);
     }
     if (threadIdx.x == 0) { atomicMax(&out->maxlen, s_max); atomicMax(&out->minlen_inv, ~s_min); }
+    if (host_out) {   // uniform
+        __shared__ uint32_t s_last;
+        uint32_t* ticket = reinterpret_cast<uint32_t*>(out + 1);
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+        __syncthreads();
+        if (s_last) {   // every other workgroup's atomics happened before its ticket
+            uint32_t* src = reinterpret_cast<uint32_t*>(out);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(host_out);
+            for (uint32_t i = threadIdx.x; i < (uint32_t)(sizeof(SplitSample) / 4); i += kSplitThreads) dst[i] = atomicExch(&src[i], 0u);
+            if (threadIdx.x == 0) atomicExch(ticket, 0u);
+            __threadfence_system();
+        }
+    }
 }
 
 // Build-side encode of ONE key column through a split codec (single word): the value's chunks in registers, the
@@ -1174,7 +1192,7 @@ __global__ __launch_bounds__(kSplitThreads) void k_encode_split(DevCol col, cons
             __syncthreads();
         }
     }
-    if (__ballot(missed) && lane_id() == 0) atomicOr(miss, 1u);
+    if (__ballot(missed) && lane_id() == 0) *miss = 1u;   // a flag, possibly in pinned host memory: a plain store
 }
 
 // ---- split codec: host side -------------------------------------------------------------------------------------
@@ -1298,16 +1316,25 @@ bool codec_sample_applies(const cph_ctx* ctx, const DevCol* cols, int32_t ncols,
            !cols[0].segmented() && n >= (1ull << 20);
 }
 size_t codec_sample_bytes() { return sizeof(SplitSample); }
-Status codec_sample_launch(cph_ctx* ctx, const DevCol& col, uint64_t n, DevBuf* dev) {
+// *host_copy: where the sample's result will be once the stream is synchronised (a block of the ctx's report words: the kernel's
+// last workgroup writes it; no memset, no copy — cph_ctx::SelfClean)
+Status codec_sample_launch(cph_ctx* ctx, const DevCol& col, uint64_t n, const void** host_copy) {
     const uint64_t step = n >> 16;   // 65 536 .. 131 071 sampled rows
     const uint64_t nsel = (n + step - 1) / step;
-    CPH_TRY(dev->alloc(&ctx->pool, sizeof(SplitSample)));
-    CPH_HIP_TRY(hipMemsetAsync(dev->get(), 0, sizeof(SplitSample), ctx->stream));
+    DevBuf& acc = ctx->self_clean[ctx->stream_slot].sample;
+    CPH_TRY(self_clean_block(ctx, &acc, sizeof(SplitSample) + 16));
+    uint32_t* hw = host_word(ctx, (uint32_t)(sizeof(SplitSample) / 4));
+    if (!hw) return {CPH_ERR_HIP, "no pinned host memory for the sample's statistics"};
     ProfScope ps(ctx, "k_split_count", 0);
     uint64_t nblk = (nsel + kSplitThreads - 1) / kSplitThreads;
     if (nblk > 1024) nblk = 1024;
-    hipLaunchKernelGGL(k_split_count, dim3((unsigned)nblk), dim3(kSplitThreads), 0, ctx->stream, col, step, nsel, dev->as<SplitSample>());
-    CPH_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_split_count, dim3((unsigned)nblk), dim3(kSplitThreads), 0, ctx->stream, col, step, nsel, acc.as<SplitSample>(),
+                       reinterpret_cast<SplitSample*>(hw));
+    if (hipGetLastError() != hipSuccess) {
+        acc.reset();   // (the accumulator may not be zero any more)
+        return {CPH_ERR_HIP, "k_split_count launch failed"};
+    }
+    *host_copy = hw;
     return {};
 }
 void codec_sample_finish(const DevCol& col, const void* host_copy, std::vector<ColStats>* out) {
@@ -1355,7 +1382,7 @@ Status codec_try_split(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t
         ProfScope ps(ctx, "k_split_count", 0);
         uint64_t nblk = (nsel + kSplitThreads - 1) / kSplitThreads;
         if (nblk > 1024) nblk = 1024;
-        hipLaunchKernelGGL(k_split_count, dim3((unsigned)nblk), dim3(kSplitThreads), 0, ctx->stream, col, step, nsel, sample.as<SplitSample>());
+        hipLaunchKernelGGL(k_split_count, dim3((unsigned)nblk), dim3(kSplitThreads), 0, ctx->stream, col, step, nsel, sample.as<SplitSample>(), (SplitSample*)nullptr);
         CPH_HIP_TRY(hipGetLastError());
     }
     CPH_TRY(ensure_pinned_scratch(ctx, sizeof(SplitSample)));
@@ -1707,7 +1734,7 @@ __global__ __launch_bounds__(kEncodeThreads) void k_encode_build(ColsArg cols, c
             all_valid &= encode_key(cv, cols, ncols, row, [&](int word, uint64_t v, int) { o[(uint64_t)word * n + row] = v; });
         }
     }
-    if (miss && !all_valid) atomicOr(miss, 1u);
+    if (miss && !all_valid) *miss = 1u;
 }
 
 // Fast path: one key column, single-word code, pre-multiplied LUT.  Wave-tile access pattern (codec_device.hpp);

@@ -187,9 +187,13 @@ __global__ __launch_bounds__(1024) void k_win_offsets(const uint32_t* __restrict
 // One workgroup per window g (codes [g << 14, (g + 1) << 14)): place, then stream out compacted.
 // off == nullptr: every window in front of g is full (states == n and no duplicates — anything else raises the flag): its
 // rows start at g << 14.
-__global__ __launch_bounds__(kPlaceThreads) void k_win_place(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ counts,
+// The cursors are SELF-CLEANING (cph_ctx::SelfClean::win: zero at rest): this kernel is the last reader of counts[g] and leaves
+// it zero, and workgroups g < nclear do the same for clear_also[g] (the first level's cursors of a two-level partition) — no
+// memset in front of the next sort.
+__global__ __launch_bounds__(kPlaceThreads) void k_win_place(const uint64_t* __restrict__ entries, uint32_t* __restrict__ counts,
                                                             const uint32_t* __restrict__ off, uint64_t n, uint32_t* __restrict__ perm,
-                                                            uint32_t* __restrict__ sorted, uint32_t* __restrict__ flag) {
+                                                            uint32_t* __restrict__ sorted, uint32_t* __restrict__ flag,
+                                                            uint32_t* __restrict__ clear_also, uint32_t nclear) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ uint32_t s_wcount[kPlaceThreads / kWave];
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -202,6 +206,10 @@ __global__ __launch_bounds__(kPlaceThreads) void k_win_place(const uint64_t* __r
         for (uint32_t i = t; i < kWinSlots / 4; i += kPlaceThreads) reinterpret_cast<u32x4*>(win)[i] = e;
     }
     __syncthreads();
+    if (t == 0) {   // every thread has read counts[g] by now
+        counts[g] = 0u;
+        if (g < nclear) clear_also[g] = 0u;
+    }
     const uint64_t* src = entries + ((uint64_t)g << kWinBits);
     for (uint32_t i = t; i < cnt; i += kPlaceThreads) {
         const uint64_t e = src[i];
@@ -262,16 +270,26 @@ Status direct_sort_windows(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint
     const uint64_t nb1 = two ? (states + (1ull << shift1) - 1) >> shift1 : nwin;
     if (nb1 > (uint64_t)kWpMaxBuckets) return {CPH_ERR_INVALID, "direct_sort_windows: code space too large"};
     const uint64_t nwin_total = two ? nb1 * nb2 : nwin;   // windows that exist as buckets (the last level-1 bucket may reach past `states`)
-    DevBuf ent1, ent2, words;
+    DevBuf ent1, ent2;
     CPH_TRY(ent1.alloc(&ctx->pool, (nb1 << shift1) * sizeof(uint64_t)));
     if (two) CPH_TRY(ent2.alloc(&ctx->pool, (nwin_total << kWinBits) * sizeof(uint64_t)));
-    // cursors of both levels + the windows' output offsets: one block, one memset
-    const uint64_t nwords = nb1 + (two ? nwin_total : 0) + nwin_total;
-    CPH_TRY(words.alloc(&ctx->pool, nwords * sizeof(uint32_t)));
+    // cursors of both levels: one block that belongs to the ctx's stream slot and is ZERO AT REST
+    // (k_win_place leaves every cursor it read zero): no memset per sort
+    const uint64_t nwords = nb1 + (two ? nwin_total : 0);
+    DevBuf& words = ctx->self_clean[ctx->stream_slot].win;
+    CPH_TRY(self_clean_block(ctx, &words, nwords * sizeof(uint32_t)));
     uint32_t* cur1 = words.as<uint32_t>();
     uint32_t* cur2 = two ? cur1 + nb1 : cur1;
-    uint32_t* off = (two ? cur2 + nwin_total : cur1 + nb1);
-    CPH_HIP_TRY(hipMemsetAsync(words.get(), 0, (nb1 + (two ? nwin_total : 0)) * sizeof(uint32_t), ctx->stream));
+    const bool need_off = states != n;   // a full code space: window g starts at g << 14 (or the flag goes up)
+    DevBuf offsets;                      // (not part of the zero-at-rest block: offsets stay behind)
+    if (need_off) CPH_TRY(offsets.alloc(&ctx->pool, nwin_total * sizeof(uint32_t)));
+    uint32_t* off = offsets.as<uint32_t>();
+    // a launch that fails leaves cursors behind: the block is dropped then (and zeroed afresh by the next sort)
+    struct Guard {
+        DevBuf* b;
+        bool done = false;
+        ~Guard() { if (!done) b->reset(); }
+    } guard{&words};
     auto lds_for = [](uint32_t nb) {
         const uint32_t nbp = (nb + (uint32_t)kWpThreads - 1u) & ~((uint32_t)kWpThreads - 1u);
         return (size_t)kWpTile * 4 + (size_t)kWpTile * 2 + (size_t)nbp * 12;
@@ -310,8 +328,7 @@ Status direct_sort_windows(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint
         hipLaunchKernelGGL(k_win_partition<false>, dim3((unsigned)(nb1 * a.tiles_per_src)), dim3(kWpThreads), lds, ctx->stream, a);
         CPH_HIP_TRY(hipGetLastError());
     }
-    const uint32_t* counts = two ? cur2 : cur1;
-    const bool need_off = states != n;   // a full code space: window g starts at g << 14 (or the flag goes up)
+    uint32_t* counts = two ? cur2 : cur1;
     if (need_off) {
         ProfScope ps(ctx, "k_win_place", 0);
         hipLaunchKernelGGL(k_win_offsets, dim3(1), dim3(1024), 0, ctx->stream, counts, (uint32_t)nwin_total, off);
@@ -321,9 +338,10 @@ Status direct_sort_windows(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint
         CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_win_place), kPlaceThreads, lds, nullptr));
         ProfScope ps(ctx, "k_win_place", 16.0 * (double)n);
         hipLaunchKernelGGL(k_win_place, dim3((unsigned)nwin_total), dim3(kPlaceThreads), lds, ctx->stream, two ? ent2.as<uint64_t>() : ent1.as<uint64_t>(),
-                           counts, need_off ? off : nullptr, n, perm_out, sorted_out, flag);
+                           counts, need_off ? off : nullptr, n, perm_out, sorted_out, flag, cur1, two ? (uint32_t)nb1 : 0u);
     }
     CPH_HIP_TRY(hipGetLastError());
+    guard.done = true;
     return {};
 }
 
