@@ -1087,27 +1087,52 @@ def main():
 
             def time_index_host(col, unique, reps):
                 pc = PinnedCol(eng.ctx, col)
-                ix = N.DeviceIndex(eng.ctx, [pc.col], unique=unique)   # warm-up: device pool, pinned perm block
-                ix.perm_host_view()
-                ix.close()
-                torch.cuda.synchronize(dev)
-                t0 = time.perf_counter()
-                for _ in range(reps):
-                    ix = N.DeviceIndex(eng.ctx, [pc.col], unique=unique)
-                    pv = ix.perm_host_view()
-                    first, last = int(pv[0]), int(pv[-1])
+
+                def timed():
+                    ix = N.DeviceIndex(eng.ctx, [pc.col], unique=unique)   # warm-up: device pool, pinned blocks, the host worker pool
+                    ix.perm_host_view()
                     ix.close()
-                wall = (time.perf_counter() - t0) / reps
-                pc.free()
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        ix = N.DeviceIndex(eng.ctx, [pc.col], unique=unique)
+                        pv = ix.perm_host_view()
+                        first, last = int(pv[0]), int(pv[-1])
+                        path = ix.info()["build_path"]
+                        ix.close()
+                    wall_ = (time.perf_counter() - t0) / reps
+                    dig = None
+                    if not args.no_verify:   # (outside the timing) the permutation's digest
+                        ix = N.DeviceIndex(eng.ctx, [pc.col], unique=unique)
+                        dig = V.digest_u64(np.asarray(ix.perm_host_view()))
+                        ix.close()
+                    return wall_, path, first, last, dig, None
+
+                from csvplus_amd import verify as V
+                wall, path, first, last, dig, _tb = timed()
                 h2d = col.nbytes_values() + col.nbytes_offsets()
                 d2h = 4 * col.nrows
-                return {"rows": col.nrows, "ms": round(wall * 1e3, 2), "rows_per_s": col.nrows / wall,
-                        "h2d_bytes": h2d, "d2h_bytes": d2h, "pcie_GBps": round((h2d + d2h) / wall / 1e9, 1),
-                        "perm_first_last": [first, last]}
+                blk = {"rows": col.nrows, "ms": round(wall * 1e3, 2), "rows_per_s": col.nrows / wall,
+                       "build_path": {0: "strings uploaded, device encode", 2: "host-formed codes (4 B/row uploaded)"}.get(path, path),
+                       "h2d_bytes": 4 * col.nrows if path == 2 else h2d, "d2h_bytes": d2h,
+                       "pcie_GBps": round(((4 * col.nrows if path == 2 else h2d) + d2h) / wall / 1e9, 1),
+                       "perm_first_last": [first, last]}
+                if path == 2:   # the A/B inside the same run: the same call with the strings uploaded (ctx option host_build = 0)
+                    eng.ctx.set_option("host_build", 0)
+                    wall0, path0, f0, l0, dig0, _ = timed()
+                    eng.ctx.set_option("host_build", 1)
+                    blk["strings_uploaded_ms"] = round(wall0 * 1e3, 2)
+                    if dig is not None:
+                        blk["verified"] = bool(dig == dig0 and (first, last) == (f0, l0))   # the same permutation either way
+                        blk["perm_digest"] = f"{dig:016x}"
+                pc.free()
+                return blk
 
             out["index_on_1e8"]["e2e_pinned_host"] = {
                 "scope": "key column in pinned host memory -> host perm (cph_index_build on host columns + cph_index_perm(HOST)); "
-                         "PCIe inclusive: upload, build and download run one after the other",
+                         "PCIe inclusive.  Round 5: ONE key column of <= 8 byte positions is coded by host threads in 2^22-row chunks, "
+                         "each uploaded (4 B/row) while the next is coded, the device only sorts (build_path); any other key uploads "
+                         "its strings, builds and downloads one after the other",
                 "unique_fixed8_ids": time_index_host(dg.column(dg.SEQ_PERM, n8, n8, encoding=dg.FIXED8, seed=7), True, 2),
                 "varlen_dup_keys_config3": time_index_host(dg.varkeys(n8), False, 2)}
 

@@ -874,6 +874,11 @@ static Status build_encode_sort(cph_ctx* ctx, BuildJob* job) {
 }
 
 static Status index_build_impl(cph_ctx* ctx, const cph_strcol* keycols, int32_t nkeycols, cph_index* ix, bool unique) {
+    if (nkeycols == 1 && keycols && keycols[0].mem == CPH_MEM_HOST && validate_cols(keycols, nkeycols).ok()) {
+        bool taken = false;
+        CPH_TRY(build_from_host_codes(ctx, keycols, nkeycols, ix, unique, &taken));   // only the key CODES cross PCIe
+        if (taken) return {};
+    }
     std::vector<BuildJob> jobs(1);
     std::vector<Status> st(1);
     jobs[0].ix = ix;
@@ -951,6 +956,7 @@ CPH_API void cph_ctx_destroy(cph_ctx* ctx) {
     if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
     for (auto& sc : ctx->scan) sc.words.reset();
     for (auto& sc : ctx->self_clean) { sc.sum.reset(); sc.sample.reset(); sc.win.reset(); }
+    host_pool_destroy(ctx);
     ctx->pool.trim();
     if (own) (void)hipStreamDestroy(own);
     delete ctx;
@@ -975,6 +981,8 @@ CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value
     else if (k == "scan_lookback") ctx->scan_lookback = value != 0;
     else if (k == "build_side_stream") ctx->build_side_stream = value != 0;
     else if (k == "stats_sample") ctx->stats_sample = value != 0;
+    else if (k == "host_build") ctx->host_build = value != 0;
+    else if (k == "host_threads") { ctx->host_threads = value < 0 || value > 256 ? 0 : (int)value; host_pool_destroy(ctx); }
     else if (k == "direct_sort") ctx->direct_sort = value < 0 || value > 4 ? 1 : (int)value;   // 1: LDS windows (window_sort.hip); A/B: 4 plain scatter, 2 partition pass + scatter, 3 the encode kernel fills the slots
     else if (k == "chain_arith") ctx->chain_arith = value != 0;
     else if (k == "chain_identity") ctx->chain_identity = value != 0;
@@ -1579,7 +1587,7 @@ CPH_API int32_t cph_index_get_info(const cph_index* ix, cph_index_info* info) {
     info->lookup_built = (ix->table ? 1 : 0) | (ix->rowtab ? 2 : 0) | (ix->hash_mode ? 4 : 0) | (ix->ranktab ? 8 : 0);
     info->hash_mode = ix->hash_mode;
     info->hash_bytes = (uint64_t)ix->hash_sectors * 64;
-    info->build_path = ix->small_built ? 1 : 0;
+    info->build_path = ix->small_built ? 1 : ix->host_coded ? 2 : 0;
     return CPH_OK;
 }
 

@@ -353,6 +353,10 @@ struct cph_ctx {
                                    // the device and the build starts over the general way (A/B switch)
     int stats_sample = 1;          // IndexOn over ONE fixed-width key column of >= 2^20 rows takes its alphabets from a sample; the encode
                                    // kernel checks every row against them and the build starts over with exact statistics on a miss (A/B switch)
+    int host_build = 1;            // cph_index_build over ONE key column of <= 8 byte positions in HOST memory: the codes are formed by host
+                                   // threads and only they are uploaded (host_encode.hip: build_from_host_codes); 0: always upload the strings
+    int host_threads = 0;          // threads of the ctx's host worker pool (0: half the hardware threads, at most 32)
+    void* host_pool = nullptr;     // cph::HostPool, created on first use (host_encode.hip)
     int build_side_stream = 1;     // cph_index_build_many: every second general build of a batch runs on a second stream (A/B switch)
     hipStream_t side_stream = nullptr;   // created on first use
     hipEvent_t side_fork = nullptr;      // recorded on `stream` when a two-stream batch starts; side_stream waits for it, so that the
@@ -454,6 +458,7 @@ struct cph_index {
     }
     int32_t sort_passes = 0;
     bool small_built = false;      // built by the one-launch path (small_build.hip)
+    bool host_coded = false;       // built from codes the host formed (host_encode.hip: build_from_host_codes)
     uint64_t first_dup = UINT64_MAX;
     uint32_t* perm_host = nullptr; // pinned copy (lazy)
     size_t perm_host_cap = 0;
@@ -593,6 +598,23 @@ Status direct_sort_distinct(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uin
 // the same through LDS windows: a partition by the top code bits, then every window placed in LDS and streamed out (window_sort.hip)
 Status direct_sort_windows(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out, uint32_t* sorted_out,
                            uint32_t* flag);
+// ... in steps, for a table whose codes arrive in chunks (host_encode.hip): begin | add(chunk) per chunk — the first partition level of
+// that chunk, enqueued behind its upload — | finish.  Whether the direct sort applies (distinct keys expected, dense space) is the caller's call.
+struct WindowSort {
+    Status begin(cph_ctx* ctx, uint64_t n, uint64_t states);
+    Status add(cph_ctx* ctx, const uint32_t* codes, uint64_t row0, uint64_t m, uint32_t* flag);
+    Status finish(cph_ctx* ctx, uint32_t* perm_out, uint32_t* sorted_out, uint32_t* flag);
+    ~WindowSort();
+    WindowSort() = default;
+    WindowSort(const WindowSort&) = delete;
+    WindowSort& operator=(const WindowSort&) = delete;
+    uint64_t n = 0, states = 0, nb1 = 0, nwin_total = 0;
+    uint32_t nb2 = 1, shift1 = 0;
+    bool two = false, started = false, finished = false;
+    DevBuf ent1, ent2;
+    DevBuf* words = nullptr;
+    uint32_t *cur1 = nullptr, *cur2 = nullptr;
+};
 // the second half of it for a full code space whose slots the encode kernel already filled: every slot taken? + the sorted codes
 Status direct_sort_finish_full(cph_ctx* ctx, const uint32_t* slots, uint64_t n, uint32_t* sorted_out, uint32_t* flag);
 Status exclusive_scan_u32(cph_ctx* ctx, uint32_t* data, uint64_t n);
@@ -678,6 +700,10 @@ void warm_csv_ingest();
 void warm_index_ops();
 void warm_small_build();
 void warm_window_sort();
+// host_encode.hip: IndexOn over one short key column in host memory through host-formed codes; *taken = false: not applicable
+// (or a row the sampled alphabets could not code / duplicates under the direct sort): the index is untouched, the general path runs
+Status build_from_host_codes(cph_ctx* ctx, const cph_strcol* keycols, int32_t nkeycols, cph_index* ix, bool unique, bool* taken);
+void host_pool_destroy(cph_ctx* ctx);
 
 // small_build.hip: IndexOn of a small table in one launch (one workgroup) and one synchronisation
 constexpr int kSmallMaxPos = 64;              // byte positions of the key the one-workgroup build takes

@@ -47,9 +47,28 @@ inline uint64_t col_offset(const HostCol& c, uint64_t i) {
     return c.offset_bits == 32 ? (uint64_t) static_cast<const uint32_t*>(c.offsets)[i] : static_cast<const uint64_t*>(c.offsets)[i];
 }
 
-inline void encode_arith8(const Arith8& a, const uint8_t* data, uint64_t r0, uint64_t r1, uint32_t* out) {
+// The code stores of a block may be NON-TEMPORAL (nt): the codes are read next by the DMA engine that uploads them, never by
+// this core — a regular store would first read every output line into the cache (1e8 codes: 400 MB of extra DRAM reads on the
+// one NUMA node that holds the pinned buffers, which is what bounds these loops).  Every loop returns whether any row got
+// CPH_CODE_ABSENT and fences its non-temporal stores before it returns.
+inline void store_code(uint32_t* p, uint32_t v, bool nt) {
+#if defined(__x86_64__)
+    if (nt) { _mm_stream_si32(reinterpret_cast<int*>(p), (int)v); return; }
+#endif
+    (void)nt;
+    *p = v;
+}
+inline void store_fence(bool nt) {
+#if defined(__x86_64__)
+    if (nt) _mm_sfence();
+#endif
+    (void)nt;
+}
+
+inline bool encode_arith8(const Arith8& a, const uint8_t* data, uint64_t r0, uint64_t r1, uint32_t* out, bool nt = false) {
     const uint64_t lo = a.lo, rngc = a.rngc;
     const uint32_t m0 = a.mult[0], m1 = a.mult[1], m2 = a.mult[2], m3 = a.mult[3], m4 = a.mult[4], m5 = a.mult[5], m6 = a.mult[6], m7 = a.mult[7];
+    uint64_t any = 0;
     for (uint64_t r = r0; r < r1; r++) {
         uint64_t x;
         memcpy(&x, data + 8 * r, 8);
@@ -58,8 +77,12 @@ inline void encode_arith8(const Arith8& a, const uint8_t* data, uint64_t r0, uin
         const uint32_t zl = (uint32_t)z, zh = (uint32_t)(z >> 32);
         const uint32_t code = (zl & 0xFFu) * m0 + ((zl >> 8) & 0xFFu) * m1 + ((zl >> 16) & 0xFFu) * m2 + (zl >> 24) * m3 + (zh & 0xFFu) * m4 +
                               ((zh >> 8) & 0xFFu) * m5 + ((zh >> 16) & 0xFFu) * m6 + (zh >> 24) * m7;
-        out[r] = ((x | z | t) & 0x8080808080808080ull) ? kCodeAbsent : code;
+        const uint64_t bad = (x | z | t) & 0x8080808080808080ull;
+        any |= bad;
+        store_code(out + r, bad ? kCodeAbsent : code, nt);
     }
+    store_fence(nt);
+    return any != 0;
 }
 
 #if defined(__x86_64__)
@@ -74,7 +97,7 @@ inline bool arith8_vector_ok(const Arith8& a) {
     }
     return (uint64_t)a.radix[2] * a.radix[3] <= 32767 && (uint64_t)a.radix[6] * a.radix[7] <= 32767;
 }
-__attribute__((target("avx2"))) inline void encode_arith8_avx2(const Arith8& a, const uint8_t* data, uint64_t r0, uint64_t r1, uint32_t* out) {
+__attribute__((target("avx2"))) inline bool encode_arith8_avx2(const Arith8& a, const uint8_t* data, uint64_t r0, uint64_t r1, uint32_t* out, bool nt = false) {
     alignas(32) uint8_t lo[32], rng[32];
     alignas(32) int8_t w1[32];
     alignas(32) int16_t w2[16];
@@ -93,6 +116,14 @@ __attribute__((target("avx2"))) inline void encode_arith8_avx2(const Arith8& a, 
     const uint32_t s_low = a.radix[4] * a.radix[5] * a.radix[6] * a.radix[7];
     const __m256i S = _mm256_set1_epi32((int)s_low), ABSENT = _mm256_set1_epi32(-1);
     uint64_t r = r0;
+    __m256i allok = ABSENT;
+    bool any = false;
+    if (nt) {   // 16-byte streaming stores want 16-byte aligned addresses: the first rows one by one
+        uint64_t head = r0;
+        while (head < r1 && (reinterpret_cast<uintptr_t>(out + head) & 15u)) head++;
+        if (head > r0) any |= encode_arith8(a, data, r0, head, out, true);
+        r = head;
+    }
     for (; r + 4 <= r1; r += 4) {
         const __m256i x = _mm256_loadu_si256((const __m256i*)(data + 8 * r));
         const __m256i z = _mm256_sub_epi8(x, LO);
@@ -105,9 +136,14 @@ __attribute__((target("avx2"))) inline void encode_arith8_avx2(const Arith8& a, 
         const __m256i res = _mm256_blendv_epi8(ABSENT, code, ok64);
         // the even dwords of the four 64-bit lanes -> four consecutive u32
         const __m256i packed = _mm256_permutevar8x32_epi32(res, _mm256_setr_epi32(0, 2, 4, 6, 0, 0, 0, 0));
-        _mm_storeu_si128((__m128i*)(out + r), _mm256_castsi256_si128(packed));
+        allok = _mm256_and_si256(allok, ok64);
+        if (nt) _mm_stream_si128((__m128i*)(out + r), _mm256_castsi256_si128(packed));
+        else _mm_storeu_si128((__m128i*)(out + r), _mm256_castsi256_si128(packed));
     }
-    if (r < r1) encode_arith8(a, data, r, r1, out);
+    any |= _mm256_movemask_epi8(allok) != -1;
+    if (r < r1) any |= encode_arith8(a, data, r, r1, out, nt);
+    if (nt) _mm_sfence();
+    return any;
 }
 #else
 inline bool arith8_vector_ok(const Arith8&) { return false; }
@@ -115,8 +151,9 @@ inline bool arith8_vector_ok(const Arith8&) { return false; }
 
 // One column, at most 8 positions.  NPOS positions are unrolled; lut = [NPOS][kLutRow].
 template <int NPOS>
-inline void encode_lut_short_n(const uint32_t* lut, const HostCol& col, uint64_t r0, uint64_t r1, uint32_t* out) {
+inline bool encode_lut_short_n(const uint32_t* lut, const HostCol& col, uint64_t r0, uint64_t r1, uint32_t* out, bool nt) {
     const bool fixed = col.fixed_width != 0;
+    uint32_t any = 0;
     uint64_t b = fixed ? r0 * (uint64_t)col.fixed_width : (r0 < r1 ? col_offset(col, r0) : 0);
     for (uint64_t r = r0; r < r1; r++) {
         uint64_t e = fixed ? b + col.fixed_width : col_offset(col, r + 1);
@@ -132,27 +169,31 @@ inline void encode_lut_short_n(const uint32_t* lut, const HostCol& col, uint64_t
             acc += w;
             bad |= w;
         }
-        out[r] = (bad >> 31) ? kCodeAbsent : acc;
+        any |= bad;
+        store_code(out + r, (bad >> 31) ? kCodeAbsent : acc, nt);
         b = e;
     }
+    store_fence(nt);
+    return (any >> 31) != 0;
 }
 
-inline void encode_lut_short(const uint32_t* lut, int npos, const HostCol& col, uint64_t r0, uint64_t r1, uint32_t* out) {
+inline bool encode_lut_short(const uint32_t* lut, int npos, const HostCol& col, uint64_t r0, uint64_t r1, uint32_t* out, bool nt = false) {
     switch (npos) {
-    case 1: return encode_lut_short_n<1>(lut, col, r0, r1, out);
-    case 2: return encode_lut_short_n<2>(lut, col, r0, r1, out);
-    case 3: return encode_lut_short_n<3>(lut, col, r0, r1, out);
-    case 4: return encode_lut_short_n<4>(lut, col, r0, r1, out);
-    case 5: return encode_lut_short_n<5>(lut, col, r0, r1, out);
-    case 6: return encode_lut_short_n<6>(lut, col, r0, r1, out);
-    case 7: return encode_lut_short_n<7>(lut, col, r0, r1, out);
-    default: return encode_lut_short_n<8>(lut, col, r0, r1, out);
+    case 1: return encode_lut_short_n<1>(lut, col, r0, r1, out, nt);
+    case 2: return encode_lut_short_n<2>(lut, col, r0, r1, out, nt);
+    case 3: return encode_lut_short_n<3>(lut, col, r0, r1, out, nt);
+    case 4: return encode_lut_short_n<4>(lut, col, r0, r1, out, nt);
+    case 5: return encode_lut_short_n<5>(lut, col, r0, r1, out, nt);
+    case 6: return encode_lut_short_n<6>(lut, col, r0, r1, out, nt);
+    case 7: return encode_lut_short_n<7>(lut, col, r0, r1, out, nt);
+    default: return encode_lut_short_n<8>(lut, col, r0, r1, out, nt);
     }
 }
 
 // Any number of columns and positions: col_start[c] = first position of column c, col_maxlen[c] = its positions.
-inline void encode_lut(const uint32_t* lut, int ncols, const int32_t* col_start, const int32_t* col_maxlen, const HostCol* cols, uint64_t r0,
-                       uint64_t r1, uint32_t* out) {
+inline bool encode_lut(const uint32_t* lut, int ncols, const int32_t* col_start, const int32_t* col_maxlen, const HostCol* cols, uint64_t r0,
+                       uint64_t r1, uint32_t* out, bool nt = false) {
+    uint32_t any = 0;
     for (uint64_t r = r0; r < r1; r++) {
         uint32_t acc = 0, bad = 0;
         for (int c = 0; c < ncols; c++) {
@@ -181,8 +222,11 @@ inline void encode_lut(const uint32_t* lut, int ncols, const int32_t* col_start,
                 acc += w;
             }
         }
-        out[r] = (bad >> 31) ? kCodeAbsent : acc;
+        any |= bad;
+        store_code(out + r, (bad >> 31) ? kCodeAbsent : acc, nt);
     }
+    store_fence(nt);
+    return (any >> 31) != 0;
 }
 
 // ---- worker pool ----------------------------------------------------------------------------------------------------------
@@ -208,9 +252,10 @@ public:
     int workers() const { return (int)workers_.size(); }
 
     template <class F>
-    void run(uint64_t nrows, F&& fn) {
+    void run(uint64_t nrows, F&& fn, uint64_t block_rows = kBlockRows) {
         if (nrows == 0) return;
-        const uint64_t nblocks = (nrows + kBlockRows - 1) / kBlockRows;
+        if (block_rows == 0) block_rows = kBlockRows;
+        const uint64_t nblocks = (nrows + block_rows - 1) / block_rows;
         if (nblocks == 1 || workers_.empty()) {
             fn((uint64_t)0, nrows);
             return;
@@ -219,6 +264,7 @@ public:
         job_call_ = &Fn<F>::call;
         job_ctx_ = &job;
         job_rows_ = nrows;
+        job_block_ = block_rows;
         base_ = limit_.load(std::memory_order_relaxed);
         done_.store(0, std::memory_order_relaxed);
         limit_.store(base_ + nblocks, std::memory_order_seq_cst);   // publishes the job: blocks [base_, base_ + nblocks)
@@ -251,7 +297,7 @@ private:
             if (b >= limit_.load(std::memory_order_acquire)) return any;
             if (!next_.compare_exchange_weak(b, b + 1, std::memory_order_acq_rel)) continue;
             const uint64_t i = b - base_;
-            const uint64_t r0 = i * kBlockRows, r1 = r0 + kBlockRows < job_rows_ ? r0 + kBlockRows : job_rows_;
+            const uint64_t r0 = i * job_block_, r1 = r0 + job_block_ < job_rows_ ? r0 + job_block_ : job_rows_;
             job_call_(job_ctx_, r0, r1);
             done_.fetch_add(1, std::memory_order_acq_rel);
             any = true;
@@ -287,7 +333,7 @@ private:
     // the current job (written by run() before limit_ is raised; read by whoever holds one of its blocks)
     void (*job_call_)(void*, uint64_t, uint64_t) = nullptr;
     void* job_ctx_ = nullptr;
-    uint64_t job_rows_ = 0, base_ = 0;
+    uint64_t job_rows_ = 0, job_block_ = kBlockRows, base_ = 0;
 };
 
 }  // namespace cph_host

@@ -47,6 +47,7 @@ struct WpArgs {
     uint64_t* dst;               // destination bucket d = sb * nb + b starts at dst + (d << shift)
     uint32_t* dst_count;         // one cursor per destination bucket (zeroed by the host)
     uint32_t states;             // FROM_CODES: a code at or beyond it comes from a row the encode kernel flagged: skipped
+    uint32_t row_base;           // FROM_CODES: codes[0] belongs to this row (the table may arrive in chunks: WindowSort::add)
     uint32_t* flag;
 };
 
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(kWpThreads) void k_win_partition(WpArgs a) {
         const uint32_t b = w >> a.shift;
         const uint32_t pos = s_gbase[b] + (i - s_start[b]);
         uint32_t row;
-        if constexpr (FROM_CODES) row = (uint32_t)(t0 + idx);
+        if constexpr (FROM_CODES) row = a.row_base + (uint32_t)(t0 + idx);
         else row = (uint32_t)a.entries[src0 + idx];
         if (pos < cap) a.dst[(((uint64_t)sb * a.nb + b) << a.shift) + pos] = ((uint64_t)(w & mask) << 32) | row;
         else over = true;   // more rows than the bucket has codes: duplicates
@@ -251,13 +252,15 @@ __global__ __launch_bounds__(kPlaceThreads) void k_win_place(const uint64_t* __r
 }
 
 // codes[n] (32-bit, distinct, below `states`) -> perm_out[n] (rows in code order), sorted_out[n] (the codes in order); *flag
-// (device, zeroed by the caller) is raised when two rows share a code — the outputs are then meaningless.  codes and sorted_out
-// may be the same buffer (the codes are consumed by the first partition pass before anything is written there).
-Status direct_sort_windows(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out, uint32_t* sorted_out,
-                           uint32_t* flag) {
-    if (n == 0) return {};
+// (zeroed by the caller; device or pinned host memory) is raised when two rows share a code — the outputs are then meaningless.
+// codes and sorted_out may be the same buffer (the codes are consumed by the first partition pass before anything is written there).
+// In three steps, so that a table that ARRIVES in chunks (host-formed codes uploaded chunk by chunk: host_encode.hip) has its first
+// partition level done behind each chunk's copy: begin | add(chunk) ... | finish.
+Status WindowSort::begin(cph_ctx* ctx, uint64_t n_, uint64_t states_) {
+    n = n_;
+    states = states_;
     const uint64_t nwin = (states + kWinSlots - 1) >> kWinBits;
-    const bool two = nwin > (uint64_t)kWpMaxBuckets;
+    two = nwin > (uint64_t)kWpMaxBuckets;
     // two levels: level 2 splits a level-1 bucket into nb2 = 2^k2 windows
     int k2 = 0;
     if (two) {
@@ -265,52 +268,61 @@ Status direct_sort_windows(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint
         while ((1ull << wb) < nwin) wb++;
         k2 = (wb + 1) / 2;
     }
-    const uint32_t nb2 = 1u << k2;
-    const uint32_t shift1 = (uint32_t)kWinBits + (uint32_t)k2;
-    const uint64_t nb1 = two ? (states + (1ull << shift1) - 1) >> shift1 : nwin;
+    nb2 = 1u << k2;
+    shift1 = (uint32_t)kWinBits + (uint32_t)k2;
+    nb1 = two ? (states + (1ull << shift1) - 1) >> shift1 : nwin;
     if (nb1 > (uint64_t)kWpMaxBuckets) return {CPH_ERR_INVALID, "direct_sort_windows: code space too large"};
-    const uint64_t nwin_total = two ? nb1 * nb2 : nwin;   // windows that exist as buckets (the last level-1 bucket may reach past `states`)
-    DevBuf ent1, ent2;
+    nwin_total = two ? nb1 * nb2 : nwin;   // windows that exist as buckets (the last level-1 bucket may reach past `states`)
     CPH_TRY(ent1.alloc(&ctx->pool, (nb1 << shift1) * sizeof(uint64_t)));
     if (two) CPH_TRY(ent2.alloc(&ctx->pool, (nwin_total << kWinBits) * sizeof(uint64_t)));
     // cursors of both levels: one block that belongs to the ctx's stream slot and is ZERO AT REST
     // (k_win_place leaves every cursor it read zero): no memset per sort
     const uint64_t nwords = nb1 + (two ? nwin_total : 0);
-    DevBuf& words = ctx->self_clean[ctx->stream_slot].win;
-    CPH_TRY(self_clean_block(ctx, &words, nwords * sizeof(uint32_t)));
-    uint32_t* cur1 = words.as<uint32_t>();
-    uint32_t* cur2 = two ? cur1 + nb1 : cur1;
+    words = &ctx->self_clean[ctx->stream_slot].win;
+    CPH_TRY(self_clean_block(ctx, words, nwords * sizeof(uint32_t)));
+    cur1 = words->as<uint32_t>();
+    cur2 = two ? cur1 + nb1 : cur1;
+    started = true;
+    return {};
+}
+// a sort that does not reach finish() leaves cursors behind: the block is dropped then (and zeroed afresh by the next sort).  The
+// caller synchronises the stream before it lets go of an unfinished sort.
+WindowSort::~WindowSort() {
+    if (started && !finished && words) words->reset();
+}
+
+static size_t win_partition_lds(uint32_t nb) {
+    const uint32_t nbp = (nb + (uint32_t)kWpThreads - 1u) & ~((uint32_t)kWpThreads - 1u);
+    return (size_t)kWpTile * 4 + (size_t)kWpTile * 2 + (size_t)nbp * 12;
+}
+
+// rows [row0, row0 + m): codes[0] is row row0's code
+Status WindowSort::add(cph_ctx* ctx, const uint32_t* codes, uint64_t row0, uint64_t m, uint32_t* flag) {
+    if (m == 0) return {};
+    WpArgs a{};
+    a.codes = codes;
+    a.n = m;
+    a.tiles_per_src = (uint32_t)((m + kWpTile - 1) / kWpTile);
+    a.shift = shift1;
+    a.nb = (uint32_t)nb1;
+    a.dst = ent1.as<uint64_t>();
+    a.dst_count = cur1;
+    a.states = (uint32_t)states;
+    a.row_base = (uint32_t)row0;
+    a.flag = flag;
+    const size_t lds = win_partition_lds(a.nb);
+    CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_win_partition<true>), kWpThreads, lds, nullptr));
+    ProfScope ps(ctx, "k_win_partition", 12.0 * (double)m);
+    hipLaunchKernelGGL(k_win_partition<true>, dim3(a.tiles_per_src), dim3(kWpThreads), lds, ctx->stream, a);
+    CPH_HIP_TRY(hipGetLastError());
+    return {};
+}
+
+Status WindowSort::finish(cph_ctx* ctx, uint32_t* perm_out, uint32_t* sorted_out, uint32_t* flag) {
     const bool need_off = states != n;   // a full code space: window g starts at g << 14 (or the flag goes up)
     DevBuf offsets;                      // (not part of the zero-at-rest block: offsets stay behind)
     if (need_off) CPH_TRY(offsets.alloc(&ctx->pool, nwin_total * sizeof(uint32_t)));
     uint32_t* off = offsets.as<uint32_t>();
-    // a launch that fails leaves cursors behind: the block is dropped then (and zeroed afresh by the next sort)
-    struct Guard {
-        DevBuf* b;
-        bool done = false;
-        ~Guard() { if (!done) b->reset(); }
-    } guard{&words};
-    auto lds_for = [](uint32_t nb) {
-        const uint32_t nbp = (nb + (uint32_t)kWpThreads - 1u) & ~((uint32_t)kWpThreads - 1u);
-        return (size_t)kWpTile * 4 + (size_t)kWpTile * 2 + (size_t)nbp * 12;
-    };
-    {
-        WpArgs a{};
-        a.codes = codes;
-        a.n = n;
-        a.tiles_per_src = (uint32_t)((n + kWpTile - 1) / kWpTile);
-        a.shift = shift1;
-        a.nb = (uint32_t)nb1;
-        a.dst = ent1.as<uint64_t>();
-        a.dst_count = cur1;
-        a.states = (uint32_t)states;
-        a.flag = flag;
-        const size_t lds = lds_for(a.nb);
-        CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_win_partition<true>), kWpThreads, lds, nullptr));
-        ProfScope ps(ctx, "k_win_partition", 12.0 * (double)n);
-        hipLaunchKernelGGL(k_win_partition<true>, dim3(a.tiles_per_src), dim3(kWpThreads), lds, ctx->stream, a);
-    }
-    CPH_HIP_TRY(hipGetLastError());
     if (two) {
         WpArgs a{};
         a.entries = ent1.as<uint64_t>();
@@ -322,7 +334,7 @@ Status direct_sort_windows(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint
         a.dst = ent2.as<uint64_t>();
         a.dst_count = cur2;
         a.flag = flag;
-        const size_t lds = lds_for(a.nb);
+        const size_t lds = win_partition_lds(a.nb);
         CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_win_partition<false>), kWpThreads, lds, nullptr));
         ProfScope ps(ctx, "k_win_partition", 16.0 * (double)n);
         hipLaunchKernelGGL(k_win_partition<false>, dim3((unsigned)(nb1 * a.tiles_per_src)), dim3(kWpThreads), lds, ctx->stream, a);
@@ -341,8 +353,17 @@ Status direct_sort_windows(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint
                            counts, need_off ? off : nullptr, n, perm_out, sorted_out, flag, cur1, two ? (uint32_t)nb1 : 0u);
     }
     CPH_HIP_TRY(hipGetLastError());
-    guard.done = true;
+    finished = true;
     return {};
+}
+
+Status direct_sort_windows(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out, uint32_t* sorted_out,
+                           uint32_t* flag) {
+    if (n == 0) return {};
+    WindowSort ws;
+    CPH_TRY(ws.begin(ctx, n, states));
+    CPH_TRY(ws.add(ctx, codes, 0, n, flag));
+    return ws.finish(ctx, perm_out, sorted_out, flag);
 }
 
 }  // namespace cph

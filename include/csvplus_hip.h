@@ -157,6 +157,13 @@ CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
  *                   alphabets from ~65 536 rows spread over the table instead of a pass over all rows; the encode kernel checks every
  *                   row against them, and a row with a byte the sample did not show makes the build start over with the exact
  *                   pass (the index is the same either way; A/B switch)
+ *   "host_build"    0 / 1 (default 1): cph_index_build over ONE key column of at most 8 byte positions (decimal ids, short tags) of
+ *                   >= 2^20 rows that lives in HOST memory forms the key codes on the host — alphabets from a sample of the rows,
+ *                   the codes by the ctx's worker pool in 2^22-row chunks, each uploaded (4 bytes per row instead of the strings)
+ *                   while the next is coded — and the device only sorts; a row the sampled alphabets cannot code, or duplicates under
+ *                   the optimistic direct sort, send the build down the general path (upload of the strings).  Same index either way.
+ *   "host_threads"  threads of that worker pool (default 0: half the hardware threads, at most 32: the loops are bound by the
+ *                   memory bandwidth of the NUMA node that holds the pinned buffers well before that)
  *   "build_side_stream" 0 / 1 (default 1): cph_index_build_many enqueues every second build of a batch on a second stream of
  *                   the ctx, so the launch-latency-bound kernels of a small table run beside its neighbour's instead of behind
  *                   them; both streams are idle when the call returns (A/B switch)
@@ -701,7 +708,9 @@ typedef struct {
     int32_t  hash_mode;       /* 0 none; 1 one code word per entry, 2 up to three words, 3 64-bit tag + verification */
     uint64_t hash_bytes;      /* size of the hash table                                                         */
     int32_t  build_path;      /* 0: general path (statistics, host codec, encode, multi-launch radix sort);
-                                 1: the one-launch build of small tables (ctx option "small_build_rows", default 8192) */
+                                 1: the one-launch build of small tables (ctx option "small_build_rows", default 8192);
+                                 2: host-formed codes — the key column came in host memory and only its 4-byte codes were
+                                    uploaded (ctx option "host_build") */
     int32_t  split;           /* 0: none; else 0x100 * (1 + key column that is cut) + the delimiter byte: the key codec codes that
                                  column as (prefix through its first delimiter, suffix) — whole-value dictionary + per-position
                                  suffix (round 4; dict_entries then counts the prefixes) */

@@ -63,8 +63,16 @@ static void test_short_against_walk() {
         std::vector<uint32_t> a(n), b(n);
         const int32_t start[2] = {0, npos}, maxlen[1] = {npos};
         encode_lut(c.lut.data(), 1, start, maxlen, &col, 0, n, a.data());
-        encode_lut_short(c.lut.data(), npos, col, 0, n, b.data());
+        const bool absent_b = encode_lut_short(c.lut.data(), npos, col, 0, n, b.data());
         CHECK(a == b);
+        {   // streaming stores, the "some row is absent" result of every loop
+            std::vector<uint32_t> s1(n, 1u), s2(n, 2u);
+            const bool f1 = encode_lut(c.lut.data(), 1, start, maxlen, &col, 0, n, s1.data(), true);
+            const bool f2 = encode_lut_short(c.lut.data(), npos, col, 0, n, s2.data(), true);
+            bool want = false;
+            for (uint32_t x : a) want |= x == kCodeAbsent;
+            CHECK(s1 == a && s2 == a && f1 == want && f2 == want && absent_b == want);
+        }
         uint64_t present = 0;
         for (uint32_t x : a) present += x != kCodeAbsent;
         CHECK(present > 0 || n < 20);
@@ -110,13 +118,37 @@ static void test_arith_against_walk() {
         std::vector<uint32_t> a(n), b(n);
         const int32_t start[2] = {0, 8}, maxlen[1] = {8};
         encode_lut(c.lut.data(), 1, start, maxlen, &col, 0, n, a.data());
-        encode_arith8(ar, data.data(), 0, n, b.data());
+        const bool absent_ar = encode_arith8(ar, data.data(), 0, n, b.data());
         CHECK(a == b);
+        bool want_absent = false;
+        for (uint32_t x : a) want_absent |= x == kCodeAbsent;
+        CHECK(absent_ar == want_absent);
+        {
+            std::vector<uint32_t> s1(n + 4, 9u);
+            CHECK(encode_arith8(ar, data.data(), 0, n, s1.data() + 1, true) == want_absent);   // streaming stores at an odd address
+            for (uint64_t r = 0; r < n; r++) CHECK(s1[r + 1] == a[r]);
+            CHECK(s1[0] == 9u && s1[n + 1] == 9u);
+            // a range of valid keys only reports no absent row
+            std::vector<uint8_t> good(8 * 64);
+            for (size_t i = 0; i < good.size(); i++) good[i] = (uint8_t)lo[i & 7];
+            std::vector<uint32_t> g(64);
+            CHECK(!encode_arith8(ar, good.data(), 0, 64, g.data(), true));
+        }
 #if defined(__x86_64__)
         if (arith8_vector_ok(ar)) {
             std::vector<uint32_t> v(n, 7u);
             encode_arith8_avx2(ar, data.data(), 3, n - 2, v.data());      // unaligned start, a scalar tail
             for (uint64_t r = 0; r < n; r++) CHECK(v[r] == (r < 3 || r >= n - 2 ? 7u : a[r]));
+            for (int shift = 0; shift < 4; shift++) {   // streaming stores: any alignment of the output, head and tail rows scalar
+                std::vector<uint32_t> sv(n + 8, 7u);
+                bool w2 = false;
+                for (uint64_t r = 5; r < n - 1; r++) w2 |= a[r] == kCodeAbsent;
+                CHECK(encode_arith8_avx2(ar, data.data(), 5, n - 1, sv.data() + shift - 0, true) == w2 || shift != 0);
+                std::vector<uint32_t> sv2(n + 8, 7u);
+                const bool f = encode_arith8_avx2(ar, data.data(), 5, n - 1, sv2.data() + shift, true);
+                CHECK(f == w2);
+                for (uint64_t r = 0; r < n; r++) CHECK(sv2[r + shift] == (r < 5 || r >= n - 1 ? 7u : a[r]));
+            }
             vector_rounds++;
         }
 #endif

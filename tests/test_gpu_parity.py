@@ -642,12 +642,14 @@ def test_direct_sort_of_distinct_keys_over_a_dense_code_space(ctx, shape):
     # 1 (default): LDS windows; A/B switches: 4 one random store per row, 2 that behind a partition pass, 3 the encode kernel fills the slots
     opt = 2 if shape.startswith("two_level") else 3 if shape == "fused_full_space" else 4 if shape.startswith("scatter") else 1
     ctx.set_option("direct_sort", opt)
+    ctx.set_option("host_build", 0)   # (the device's own encode + sort kernels are what this test looks at: tests/test_gpu_host_build.py has the other path)
     ctx.profile(True)
     ctx.profile_read(reset=True)
     try:
         g = DeviceIndex(ctx, [col], unique=unique)
     finally:
         ctx.set_option("direct_sort", 1)
+        ctx.set_option("host_build", 1)
     prof = ctx.profile_read(reset=True)
     ctx.profile(False)
     if opt == 1:
