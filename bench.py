@@ -401,7 +401,7 @@ def main():
                  "bytes_received_per_step": xtimed[0]["bytes_received"] if xtimed else None,
                  "note": "events on the ctx stream (join of all chunks) and on the exchange stream (first chunk ready -> match totals of "
                          "all ranks received); exposed = the part of the exchange behind the last chunk's join, which nothing hides"}
-        n1_ms = None
+        n1_ms, n1_all = None, []
         if not args.no_n1 and not share_gpu:
             # strong scaling's reference point, measured here: rank 0 alone runs the step over ALL rows (no exchange)
             full = dg.orders(args.rows, args.customers, args.products)
@@ -413,14 +413,19 @@ def main():
                 c.release(); a.close(); b.close()
 
             step1()
-            torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            for _ in range(3):
+            # median of five single steps: one stall of the box (seen: 87 ms in one step out of twenty at 3e5 rows,
+            # profiles/r05_n1_outlier.txt — in a cph_dist step as well as in a plain one) must not become the reference point
+            n1_all = []
+            for _ in range(5):
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
                 step1()
-            torch.cuda.synchronize(dev)
-            n1_ms = (time.perf_counter() - t1) / 3 * 1e3
+                torch.cuda.synchronize(dev)
+                n1_all.append((time.perf_counter() - t1) * 1e3)
+            n1_ms = sorted(n1_all)[len(n1_all) // 2]
             del d_full, full
         multi["n1_ms_per_step"] = round(n1_ms, 4) if n1_ms else None
+        multi["n1_ms_single_steps"] = [round(x, 4) for x in n1_all] if n1_ms else None
         multi["efficiency_vs_n1"] = round(n1_ms / (world * dt / args.steps * 1e3), 4) if n1_ms else None
         code_bytes = 4
         multi["build_side"] = dict(build_side_estimate(args.customers, code_bytes, world, 3.0e10),
