@@ -463,6 +463,8 @@ struct BuildJob {
     bool unique = false;         // the caller expects distinct keys (UniqueIndexOn): the optimistic direct sort may be tried
     bool no_direct = false;
     bool side = false;           // this job's work is enqueued on the ctx's side stream (cph_index_build_many: it overlaps its neighbour's)
+    bool spec_split = false;     // presplit from the SAMPLE alone (codec_try_split speculate): a miss starts over with the exact split statistics
+    bool exact_split = false;    // ... that second attempt
     bool no_split = false;       // second attempt after a split codec met a row it could not code (keycodec.hip: codec_try_split)
     uint32_t* miss = nullptr;    // report word (pinned host memory, host_word) raised by the encode kernel of a split / sampled codec and by the
                                  // optimistic direct sort; read after the build's last synchronisation
@@ -481,7 +483,7 @@ static Status build_phase1(cph_ctx* ctx, const cph_strcol* keycols, int32_t nkey
     // "sample first": a large table over ONE variable-length key column asks a sample whether its keys want the delimiter split
     // (keycodec.hip); when they do, the exact split statistics replace the plain statistics pass (one read of the strings less)
     if (!job->small && !job->no_split && nkeycols == 1 && !job->dcols[0].fixed_width && ix->nrows >= (1ull << 22)) {
-        CPH_TRY(codec_try_split(ctx, job->dcols, 1, ix->nrows, nullptr, &ix->codec));
+        CPH_TRY(codec_try_split(ctx, job->dcols, 1, ix->nrows, nullptr, &ix->codec, !job->exact_split, &job->spec_split));
         job->presplit = ix->codec.has_split();
     }
     job->sampled = !job->small && !job->presplit && !job->no_sample && codec_sample_applies(ctx, job->dcols, nkeycols, ix->nrows);
@@ -600,7 +602,10 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
         std::vector<Status> st1(1);
         BuildJob& j = one[0];
         j.side = false;   // (both streams are idle here: the second attempt runs on the ctx's own)
-        j.no_split = true;
+        const bool again_exact = j.spec_split;   // the sample's split codec met a row it could not code: the exact split statistics next
+        j.spec_split = false;
+        j.exact_split = again_exact;
+        j.no_split = !again_exact;
         j.no_sample = true;
         j.sampled = false;
         j.no_direct = true;
@@ -609,7 +614,12 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
         cph_index* ix = j.ix;
         ix->codec = CodecHost{};
         ix->codec_dev.reset(); ix->sorted_codes.reset(); ix->perm.reset(); ix->first_dup_dev.reset();
-        st1[0] = codec_stats_launch(ctx, j.dcols, j.nkeycols, &j.stats_dev);
+        if (again_exact) {
+            ctx->n_split_respec++;
+            st1[0] = codec_try_split(ctx, j.dcols, 1, ix->nrows, nullptr, &ix->codec, false, nullptr);
+            j.presplit = st1[0].ok() && ix->codec.has_split();
+        }
+        if (st1[0].ok() && !j.presplit) st1[0] = codec_stats_launch(ctx, j.dcols, j.nkeycols, &j.stats_dev);
         if (st1[0].ok()) build_run(ctx, one, st1);
         status[i] = st1[0];
         jobs[i] = std::move(one[0]);
@@ -978,6 +988,7 @@ CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value
     else if (k == "chain_rank_lds") ctx->chain_rank_lds = value != 0;
     else if (k == "chain_rows4") ctx->chain_rows4 = value < 0 || value > 2 ? 1 : (int)value;
     else if (k == "codec_split") ctx->codec_split = value != 0;
+    else if (k == "split_speculative") ctx->split_speculative = value != 0;
     else if (k == "scan_lookback") ctx->scan_lookback = value != 0;
     else if (k == "build_side_stream") ctx->build_side_stream = value != 0;
     else if (k == "stats_sample") ctx->stats_sample = value != 0;

@@ -207,6 +207,7 @@ struct CodecHost {
     // ("Smith/Amelia#12345") cost their information, not their byte positions: BASELINE config 3 codes in 25 bits.
     int32_t split_col = -1;                 // key column of the table that is split (-1: none)
     uint8_t split_byte = 0;
+    bool spec_checked = false;              // split codec built from a SAMPLE (codec_try_split speculate): the build's encode kernel checks suffix bytes too
     int32_t split_maxlen = 0;               // longest value of the split column in the build table (which kernel instantiation encodes it)
     std::vector<WideKey> wdict;             // distinct prefixes in rank order
     // PERFECT hash of wdict (codec_wide_perfect_hash; derived, not serialised): a lookup is h = wide_hash_lo(key),
@@ -341,6 +342,8 @@ struct cph_ctx {
     int probe_hash_rows = 2;       // rows per phase of the generic hash probe (2 / 4): 4 rows need 164 VGPRs (3 waves per SIMD) and measured 20 % slower
     int join_hash = 1;             // 0: indexes of this ctx never get a hash table (A/B switch: sorted search instead)
     int codec_debug = 0;           // prints the window choice of codec_try_groups to stderr
+    uint64_t n_split_respec = 0;   // builds whose sampled split codec missed a row and that started over with the exact statistics (cph_ctx_get_stat)
+    int split_speculative = 1;     // the split codec of a large single-column table is taken from its sample, checked by the encode kernel (0: exact pass)
     int codec_split = 1;           // the delimiter split of keycodec.hip is tried (A/B switch; 0: never)
     int scan_lookback = 1;         // exclusive_scan_u32 as ONE launch (decoupled look-back, radix_sort.hip) instead of three (A/B switch)
     struct ScanState {             // its state words (+ ticket counter), zeroed once; epochs / relative tickets make a scan memset-free
@@ -569,7 +572,8 @@ Status codec_encode_build(cph_ctx* ctx, const CodecHost& codec, const DevBuf& co
 // The delimiter split (keycodec.hip "split codec"): tried when the plain code does not fit 32 bits.  stats: the plain
 // statistics *codec was built from, or nullptr for ONE variable-length key column before any statistics exist (a large
 // table then skips the plain statistics pass); codec->has_split() tells whether the split was taken.
-Status codec_try_split(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t n, const std::vector<ColStats>* stats, CodecHost* codec);
+Status codec_try_split(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t n, const std::vector<ColStats>* stats, CodecHost* codec,
+                       bool speculate = false, bool* speculated = nullptr);
 // Host-side encoding of literal values (cph_index_find).  Returns false when a
 // value cannot occur in the index (symbol outside the alphabet / too long).
 bool codec_encode_values_host(const CodecHost& codec, const cph_strval* values, int32_t nvalues,

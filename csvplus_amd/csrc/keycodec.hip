@@ -1100,7 +1100,7 @@ template <class OUT, int NCH>
 __global__ __launch_bounds__(kSplitThreads) void k_encode_split(DevCol col, const uint8_t* __restrict__ g_codec, uint64_t n,
                                                                OUT* __restrict__ out, uint32_t tile_rows, uint32_t ntiles,
                                                                uint32_t* __restrict__ counts, uint32_t digit_mask, uint32_t bins,
-                                                               int codec_bytes, uint32_t* __restrict__ miss) {
+                                                               int codec_bytes, uint32_t* __restrict__ miss, OUT inv, uint32_t vmax) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const CodecView cv = codec_load_to_lds(g_codec, smem);
     const uint64_t dv = 0x0101010101010101ull * (uint64_t)((uint32_t)cv.hdr->split_byte & 0xFFu);
@@ -1113,7 +1113,7 @@ __global__ __launch_bounds__(kSplitThreads) void k_encode_split(DevCol col, cons
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + codec_bytes + (size_t)smaxlen * kLutStride * sizeof(OUT));
     for (uint32_t i = threadIdx.x; i < smaxlen * (uint32_t)kLutStride; i += kSplitThreads) {
         const uint32_t r = cv.lut[(uint32_t)ps * kLutStride + i];
-        s_lutw[i] = r == kLutInvalid ? (OUT)0 : (OUT)r * (OUT)cv.mult[ps + (int)(i / kLutStride)];
+        s_lutw[i] = r == kLutInvalid ? inv : (OUT)r * (OUT)cv.mult[ps + (int)(i / kLutStride)];
     }
     __syncthreads();
     const uint32_t hmask = (1u << cv.hdr->wide_hash_bits) - 1u, dmask = (1u << cv.hdr->wide_disp_bits) - 1u;
@@ -1163,7 +1163,7 @@ __global__ __launch_bounds__(kSplitThreads) void k_encode_split(DevCol col, cons
             uint64_t w0[kSplitRows], w1[kSplitRows];
 #pragma unroll
             for (int k = 0; k < kSplitRows; k++) {
-                const bool ok = hit[k] && v[k].len <= (uint32_t)(8 * NCH) && plen[k] <= (uint32_t)kWideBytes && slen[k] <= smaxlen;
+                const bool ok = hit[k] && v[k].len <= vmax && plen[k] <= (uint32_t)kWideBytes && slen[k] <= smaxlen;
                 if (!ok && base + (uint64_t)k * kSplitThreads + threadIdx.x < tile_end) missed = 1;
                 acc[k] = (OUT)(hit[k] ? e[k] - 1 : 0u) * pmult;
                 v[k].window(plen[k], &w0[k], &w1[k]);
@@ -1181,6 +1181,7 @@ __global__ __launch_bounds__(kSplitThreads) void k_encode_split(DevCol col, cons
             for (int k = 0; k < kSplitRows; k++) {
                 const uint64_t i = base + (uint64_t)k * kSplitThreads + threadIdx.x;
                 if (i < tile_end) {
+                    if (inv && acc[k] >= inv) missed = 1;   // a suffix byte (or END) its position's alphabet does not hold
                     out[i] = acc[k];
                     if (counts) atomicAdd(&s_hist[(uint32_t)acc[k] & digit_mask], 1u);
                 }
@@ -1350,7 +1351,9 @@ bool codec_sample_checked(const CodecHost& cd, const DevCol* cols) {
     return !cd.has_split() && !cd.has_groups() && cd.ncols == 1 && cd.nwords == 1 && codec_premultiplied_bits(cd) != 0 && !cols[0].segmented();
 }
 
-Status codec_try_split(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t n, const std::vector<ColStats>* stats, CodecHost* codec) {
+Status codec_try_split(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t n, const std::vector<ColStats>* stats, CodecHost* codec,
+                       bool speculate, bool* speculated) {
+    if (speculated) *speculated = false;
     if (!ctx->codec_split || n < (1ull << 16) || ncols >= kMaxKeyCols) return {};
     if (stats && (codec->key32 || codec->has_groups())) return {};
     if (!stats && ncols != 1) return {};
@@ -1455,7 +1458,11 @@ Status codec_try_split(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t
     SplitSlot* slots = sets.as<SplitSlot>() + (size_t)best * kSplitSetSlots;
     SplitStats* dstat = sstats.as<SplitStats>() + best;
     const uint32_t d = (uint32_t)cand[(size_t)best];
-    if (step > 1) {
+    // speculate: the SAMPLE's dictionary and alphabets stand in for the exact ones (§4.5's argument, for the split codec): the encode
+    // kernel checks every row against them — prefix in the dictionary, every suffix byte (and END) in its position's alphabet, lengths
+    // within the sample's — and raises `miss` for a row it cannot code; no miss ⇒ the exact pass would have found exactly this codec.
+    const bool spec = speculate && step > 1 && ctx->split_speculative != 0;
+    if (step > 1 && !spec) {
         ProfScope ps(ctx, "k_split_stats", 0);
         SplitCands one{};
         one.n = 1;
@@ -1529,7 +1536,17 @@ Status codec_try_split(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t
         fprintf(stderr, "codec_try_split: column %d cut at 0x%02x: %zu prefixes (<= %u bytes), suffix %u..%u bytes: %d word(s), %d bits, sort cost %.0f (plain: %.1f bits%s, cost %.0f)\n",
                 c, d, trial.wdict.size(), st.pmax, smin, st.smax, trial.nwords, trial.word_bits[0], codec_sort_cost(trial), plain_bits,
                 stats ? "" : " by the sample", plain_cost);
-    if (codec_sort_cost(trial) < plain_cost) *codec = std::move(trial);
+    if (spec) {
+        // the encode kernel marks a suffix byte outside its alphabet by adding 2^27 (2^58) to the code: 16 positions of it cannot wrap,
+        // a valid code stays below it — larger code spaces take the exact pass (from here, once)
+        trial.spec_checked = true;
+        if (trial.nwords != 1 || trial.word_states[0] > (trial.key32 ? (1ull << 27) : (1ull << 58)))
+            return codec_try_split(ctx, cols, ncols, n, stats, codec, false, nullptr);
+    }
+    if (codec_sort_cost(trial) < plain_cost) {
+        *codec = std::move(trial);
+        if (speculated) *speculated = spec;
+    }
     return {};
 }
 
@@ -1980,7 +1997,9 @@ Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec
             unsigned grid = (unsigned)std::min<uint64_t>(ntiles64, (uint64_t)cus * (uint64_t)per_cu);
             grid = (grid + 7u) & ~7u;   // the kernel splits its tiles over blockIdx % 8
             hipLaunchKernelGGL(fn, dim3(grid), dim3(kSplitThreads), lds, ctx->stream, cols[0], codec_dev.as<uint8_t>(), n, out, tile_rows, ntiles,
-                               want_hist ? hist->counts : nullptr, mask, bins, (int)codec_bytes, miss);
+                               want_hist ? hist->counts : nullptr, mask, bins, (int)codec_bytes, miss,
+                               (std::remove_pointer_t<decltype(out)>)(cd.spec_checked ? (cd.key32 ? (1ull << 27) : (1ull << 58)) : 0ull),
+                               (uint32_t)std::min<int64_t>(cd.split_maxlen, small_values ? 24 : kSplitMaxValue));
             return {};
         };
         if (cd.key32) {

@@ -144,6 +144,11 @@ CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
  *   "codec_split"   0 / 1 (default 1): keys that do not code in 32 bits are tried with the delimiter split — the costliest
  *                   variable-length key column cut at its first delimiter byte into a dictionary-coded prefix and a
  *                   per-position suffix (floating fields like "Smith/Amelia#12345": 25 bits instead of 47; A/B switch)
+ *   "split_speculative" 0 / 1 (default 1): IndexOn over ONE variable-length key column of >= 2^22 rows takes the split codec's prefix
+ *                   dictionary and suffix alphabets from its 2^18-row sample alone; the encode kernel checks every row against them
+ *                   (prefix in the dictionary, every suffix byte and the end of the suffix in its position's alphabet, lengths within
+ *                   the sample's) and a row it cannot code makes the build start over with the exact statistics pass — the index
+ *                   is the same either way (A/B switch: 0 = always the exact pass)
  *   "scan_lookback" 0 / 1 (default 1): the 32-bit exclusive scans (radix count matrices, compaction offsets) run as ONE launch
  *                   (decoupled look-back) instead of three (A/B switch)
  *   "direct_sort"   0 / 1 (default 1): a build that expects distinct keys (cph_index_build with unique = 1, cph_index_spec.unique) over a

@@ -187,3 +187,68 @@ def test_split_chain_and_stream_join_over_a_split_index(ctx):
         np.testing.assert_array_equal(r0, j1["build_row"][pick])
         np.testing.assert_array_equal(r1, j2["build_row"])
         ch.release()
+
+
+def _replace_rows(col, repl):
+    """A copy of a variable-length column with some rows' values replaced ({row: bytes})."""
+    data = np.asarray(col.data)
+    off = np.asarray(col.offsets).astype(np.int64)
+    parts, lens, prev = [], (off[1:] - off[:-1]).copy(), 0
+    for r in sorted(repl):
+        parts.append(data[off[prev]:off[r]])
+        parts.append(np.frombuffer(repl[r], np.uint8))
+        lens[r] = len(repl[r])
+        prev = r + 1
+    parts.append(data[off[prev]:off[-1]])
+    noff = np.zeros(len(off), np.uint32)
+    np.cumsum(lens, out=noff[1:])
+    return StrCol.from_arrays(np.concatenate(parts), noff)
+
+
+@pytest.mark.parametrize("rare", ["none", "prefix", "suffix_byte", "long_suffix", "short_suffix", "no_delimiter", "long_value"])
+def test_split_codec_from_the_sample_alone(ctx, rare):
+    """Round 5: a large table over ONE variable-length key column (>= 2^22 rows) takes the split codec's dictionary and suffix
+    alphabets from the 2^18-row sample; the exact pass over all rows (k_split_stats) is gone, the encode kernel checks every row
+    instead — prefix in the dictionary, every suffix byte and END in its position's alphabet, lengths within the sample's.  One
+    row the sample does not visit and cannot code makes the build start over with the exact statistics: same index as the
+    oracle's (csvplus.go:794-807) either way, and the same index as a build with the speculation switched off."""
+    n = (1 << 22) + 12_345
+    keys = dg.varkeys(n)
+    step = n >> 18
+    row = 1_234_567
+    assert row % step != 0   # not a sampled row
+    repl = {"none": None, "prefix": b"Zeppelin/Qq#12345", "suffix_byte": b"Smith/Amelia#12x45", "long_suffix": b"Smith/Amelia#1234567",
+            "short_suffix": b"Smith/Amelia#", "no_delimiter": b"Smith/Amelia", "long_value": b"Smith/Amelia-and-a-very-long-middle-name#123"}[rare]
+    if repl is not None:
+        keys = _replace_rows(keys, {row: repl})
+    o = orc.OracleIndex([keys])
+    dk = keys.to_device("cuda:0")
+    ctx.profile(True)
+    ctx.profile_read(reset=True)
+    g = DeviceIndex(ctx, [dk])
+    prof = ctx.profile_read(reset=True)
+    ctx.profile(False)
+    exact_passes = prof.get("k_split_stats", {"launches": 0})["launches"]
+    info = g.info()
+    if rare == "none":
+        assert exact_passes == 0 and info["split"] & 0xFF == ord("#"), (prof.keys(), info)
+    else:
+        assert exact_passes <= 1, prof
+    np.testing.assert_array_equal(g.perm(), o.perm)
+    assert g.first_dup == o.first_dup()
+    ctx.set_option("split_speculative", 0)
+    try:
+        ctx.profile(True)
+        g0 = DeviceIndex(ctx, [dk])
+        prof0 = ctx.profile_read(reset=True)
+        ctx.profile(False)
+        l0 = prof0.get("k_split_stats", {"launches": 0})["launches"]   # (a value beyond the split kernels' 40 bytes: the exact pass ran and said no)
+        assert l0 <= 1 and (l0 == 1 or not g0.info()["split"])
+        assert g0.info() == info
+        np.testing.assert_array_equal(g0.perm(), o.perm)
+    finally:
+        ctx.set_option("split_speculative", 1)
+    probe = dg.varkeys(50_000, 300_000, seed=dg.SEED + 78)
+    if repl is not None:
+        probe = _replace_rows(probe, {5: repl, 6: repl + b"0"})
+    assert_join_equal(g.probe([probe]), o.join([probe]))
