@@ -997,6 +997,8 @@ CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value
     else if (k == "direct_sort") ctx->direct_sort = value < 0 || value > 4 ? 1 : (int)value;   // 1: LDS windows (window_sort.hip); A/B: 4 plain scatter, 2 partition pass + scatter, 3 the encode kernel fills the slots
     else if (k == "chain_arith") ctx->chain_arith = value != 0;
     else if (k == "chain_identity") ctx->chain_identity = value != 0;
+    else if (k == "chain_prejoin") ctx->chain_prejoin = value != 0;
+    else if (k == "hash_load_pct") ctx->hash_load_pct = value < 25 ? 25 : value > 90 ? 90 : (int)value;
     else if (k == "probe_hash_rows") ctx->probe_hash_rows = value == 4 ? 4 : 2;
     else if (k == "small_build_rows") ctx->small_build_rows = value < 0 ? 0 : value > (1 << 20) ? (1 << 20) : (int)value;
     else if (k == "plan_threads") ctx->plan_threads = (int)value;

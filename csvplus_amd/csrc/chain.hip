@@ -546,6 +546,82 @@ __global__ void k_perm_rows(const uint32_t* __restrict__ perm, const uint32_t* _
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = perm[pos[i]];
 }
 
+// dst[i] = tab[idx[i]] (kTableAbsent stays kTableAbsent): a pre-joined table from the build table's row order into its sorted order
+__global__ void k_gather_rows(const uint32_t* __restrict__ tab, const uint32_t* __restrict__ idx, uint32_t* __restrict__ dst, uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = tab[idx[i]];
+}
+
+// Steps whose key is a column of an EARLIER step's build table (cph_chain_step.source != 0), answered from PRE-JOINED tables:
+// tab[j][h] = what step dst[j] finds for the row with handle h (sorted position / original row) of its source step's table —
+// the build sides were joined with each other first (run_prejoined), so per stream row such a step is ONE 4-byte gather instead
+// of perm + offsets + key bytes + encode + lookup.  Runs behind k_chain_dense over the stream-keyed steps, in its geometry
+// (a wave owns kWaveTile consecutive rows; masks = a plain bitmap; one count per (tile, wave)): clears the bit of a row whose
+// step finds nothing and rewrites the counts.
+struct PrejoinArgs {
+    int32_t n;                       // dependent steps, in chain order
+    int32_t src_dep[kMaxChain - 1];  // >= 0: the source is dependent step src_dep[j] of THIS list (its value is in registers); < 0: read src_rows[j]
+    const uint32_t* src_rows[kMaxChain - 1];
+    const uint32_t* tab[kMaxChain - 1];
+    uint32_t* out_rows[kMaxChain - 1];
+};
+__global__ __launch_bounds__(kChainThreads) void k_chain_prejoined(PrejoinArgs a, uint64_t nprobe, uint64_t ntiles, uint64_t* __restrict__ masks,
+                                                                  uint32_t* __restrict__ wave_counts) {
+    const int lane = lane_id();
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(wave_id());
+#pragma unroll 1
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t wbase = tile * kChainTile + (uint64_t)wave * kWaveTile;
+        const uint64_t mword = (tile * kChainWaves + wave) * kChainRows;
+        uint32_t okm = 0;
+#pragma unroll
+        for (int k = 0; k < kChainRows; k++) okm |= (uint32_t)((masks[mword + k] >> lane) & 1ull) << k;
+        uint32_t val[kMaxChain - 1][kChainRows];
+#pragma unroll
+        for (int j = 0; j < kMaxChain - 1; j++) {
+            if (j >= a.n) break;   // uniform
+            uint32_t h[kChainRows];
+            const int sd = a.src_dep[j];
+            if (sd < 0) {
+#pragma unroll
+                for (int k = 0; k < kChainRows; k++) {
+                    const uint64_t r = wbase + (uint64_t)k * kWave + lane;
+                    h[k] = (okm >> k) & 1u ? a.src_rows[j][r] : 0u;   // (row 0 of a table exists: no index of the chain is empty)
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < kChainRows; k++) h[k] = 0u;
+#pragma unroll
+                for (int u = 0; u < kMaxChain - 1; u++)
+                    if (u < j && u == sd) {
+#pragma unroll
+                        for (int k = 0; k < kChainRows; k++) h[k] = (okm >> k) & 1u ? val[u][k] : 0u;
+                    }
+            }
+#pragma unroll
+            for (int k = 0; k < kChainRows; k++) val[j][k] = a.tab[j][h[k]];
+#pragma unroll
+            for (int k = 0; k < kChainRows; k++)
+                if (val[j][k] == kTableAbsent) okm &= ~(1u << k);
+        }
+        uint32_t wave_matches = 0;
+#pragma unroll
+        for (int k = 0; k < kChainRows; k++) {
+            const bool ok = (okm >> k) & 1u;
+            const uint64_t bal = __ballot(ok);
+            wave_matches += (uint32_t)__popcll(bal);
+            if (lane == 0) masks[mword + k] = bal;
+            if (ok) {
+                const uint64_t r = wbase + (uint64_t)k * kWave + lane;
+#pragma unroll
+                for (int j = 0; j < kMaxChain - 1; j++)
+                    if (j < a.n) __builtin_nontemporal_store(val[j][k], a.out_rows[j] + r);
+            }
+        }
+        if (lane == 0) wave_counts[tile * kChainWaves + wave] = wave_matches;
+    }
+}
+
 bool chain_fast_path_ok(const ChainStep* steps, int nsteps) {
     for (int s = 0; s < nsteps; s++) {
         const cph_index* ix = steps[s].index;
@@ -565,7 +641,8 @@ bool chain_fast_path_ok(const ChainStep* steps, int nsteps) {
 template <int S>
 static Status enqueue_dense(cph_ctx* ctx, const ChainStep* steps, uint64_t nprobe, uint64_t probe_base,
                             uint32_t* const* d_rows, uint64_t* d_masks, uint32_t* d_counts, uint64_t* d_total,
-                            ChainArgs* args_out, unsigned* grid_out, bool positions, uint64_t* host_total = nullptr) {
+                            ChainArgs* args_out, unsigned* grid_out, bool positions, uint64_t* host_total = nullptr,
+                            const char* prof_name = "k_chain_dense") {
     const uint64_t ntiles = (nprobe + kChainTile - 1) / kChainTile;
     ChainArgs args{};
     LeanArgs largs{};
@@ -698,7 +775,7 @@ static Status enqueue_dense(cph_ctx* ctx, const ChainStep* steps, uint64_t nprob
     CPH_TRY(device_cus(ctx, &cus));
     const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)cus * (uint64_t)per_cu);
     {
-        ProfScope ps(ctx, "k_chain_dense", 0);
+        ProfScope ps(ctx, prof_name, 0);
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(kChainThreads), lds, ctx->stream, args, nprobe, probe_base,
                            ntiles, d_masks, d_counts, dep ? 0 : dbg, largs);
     }
@@ -709,7 +786,7 @@ static Status enqueue_dense(cph_ctx* ctx, const ChainStep* steps, uint64_t nprob
         const unsigned sgrid = (unsigned)std::min<uint64_t>((ncounts + 255) / 256, 512);
         hipLaunchKernelGGL(k_sum_counts_report, dim3(sgrid), dim3(256), 0, ctx->stream, d_counts, ncounts, acc.as<unsigned long long>(),
                            acc.as<uint32_t>() + 2, reinterpret_cast<unsigned long long*>(host_total));
-    } else {
+    } else if (d_total) {   // (neither: the caller adds passes that change the counts and sums them itself — run_prejoined)
         ProfScope ps(ctx, "k_sum_counts", 4.0 * (double)ncounts);
         CPH_HIP_TRY(hipMemsetAsync(d_total, 0, sizeof(uint64_t), ctx->stream));
         const unsigned sgrid = (unsigned)std::min<uint64_t>((ncounts + 255) / 256, 512);
@@ -793,6 +870,87 @@ Status chain_enqueue_codes(cph_ctx* ctx, const cph_index* const* idx, const uint
 uint64_t chain_dense_mask_words(uint64_t nprobe) { return (nprobe + kChainTile - 1) / kChainTile * kChainMasks; }
 uint64_t chain_dense_count_words(uint64_t nprobe) { return (nprobe + kChainTile - 1) / kChainTile * kChainWaves; }
 
+// The chain's build sides joined with each other first: for every step whose key is a column of an earlier step's build table,
+// tab[s][h] = the row (position) that step finds for the table row with handle h — one dense pass over that TABLE's column (1e7
+// rows instead of 1e8 stream rows), brought into the source index's sorted order when the chain reports positions.  Then the
+// stream rows take the stream-keyed steps through k_chain_dense (its lean variants included) and k_chain_prejoined answers the
+// rest with one gather each; the total is summed behind it.  (people.Join(orders, "id").Join(products): csvplus_test.go:280-285.)
+static Status run_prejoined(cph_ctx* ctx, const ChainStep* steps, int S, uint64_t nprobe, uint64_t probe_base, uint32_t* const* rows,
+                            uint64_t* masks, uint32_t* counts, unsigned* grid_out, bool positions, uint64_t* host_total) {
+    const uint64_t ntiles = (nprobe + kChainTile - 1) / kChainTile;
+    const uint64_t ncounts = ntiles * kChainWaves;
+    DevBuf tabs[kMaxChain];
+    for (int s = 0; s < S; s++) {
+        if (steps[s].source == 0) continue;
+        const int t = (steps[s].source < 0 ? -steps[s].source : steps[s].source) - 1;
+        const uint64_t nt = steps[t].index->nrows;
+        ChainStep one = steps[s];
+        one.source = 0;
+        DevBuf trow, tmask, tcount;
+        CPH_TRY(trow.alloc(&ctx->pool, nt * sizeof(uint32_t)));
+        CPH_TRY(tmask.alloc(&ctx->pool, chain_dense_mask_words(nt) * sizeof(uint64_t)));
+        CPH_TRY(tcount.alloc(&ctx->pool, chain_dense_count_words(nt) * sizeof(uint32_t)));
+        CPH_HIP_TRY(hipMemsetAsync(trow.get(), 0xFF, nt * sizeof(uint32_t), ctx->stream));   // the dense pass stores matches only
+        uint32_t* r1[kMaxChain] = {trow.as<uint32_t>(), nullptr, nullptr, nullptr};
+        CPH_TRY(enqueue_dense<1>(ctx, &one, nt, 0, r1, tmask.as<uint64_t>(), tcount.as<uint32_t>(), nullptr, nullptr, nullptr, positions, nullptr,
+                                 "k_chain_prejoin_table"));
+        if (positions && steps[s].source > 0) {   // the column is in the table's row order, the chain hands sorted positions on
+            CPH_TRY(tabs[s].alloc(&ctx->pool, nt * sizeof(uint32_t)));
+            ProfScope ps(ctx, "k_chain_prejoin_table", 0);
+            hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)std::min<uint64_t>((nt + 255) / 256, 8192)), dim3(256), 0, ctx->stream,
+                               trow.as<uint32_t>(), steps[t].index->perm.as<uint32_t>(), tabs[s].as<uint32_t>(), nt);
+            CPH_HIP_TRY(hipGetLastError());
+        } else {
+            tabs[s] = std::move(trow);
+        }
+    }
+    ChainStep ind[kMaxChain];
+    uint32_t* irows[kMaxChain] = {nullptr, nullptr, nullptr, nullptr};
+    int ni = 0;
+    PrejoinArgs pa{};
+    int dep_of[kMaxChain] = {-1, -1, -1, -1};
+    for (int s = 0; s < S; s++) {
+        if (steps[s].source == 0) {
+            ind[ni] = steps[s];
+            irows[ni++] = rows[s];
+            continue;
+        }
+        const int t = (steps[s].source < 0 ? -steps[s].source : steps[s].source) - 1;
+        const int j = pa.n++;
+        dep_of[s] = j;
+        pa.src_dep[j] = dep_of[t];
+        pa.src_rows[j] = rows[t];
+        pa.tab[j] = tabs[s].as<uint32_t>();
+        pa.out_rows[j] = rows[s];
+    }
+    switch (ni) {
+    case 1: CPH_TRY(enqueue_dense<1>(ctx, ind, nprobe, probe_base, irows, masks, counts, nullptr, nullptr, grid_out, positions)); break;
+    case 2: CPH_TRY(enqueue_dense<2>(ctx, ind, nprobe, probe_base, irows, masks, counts, nullptr, nullptr, grid_out, positions)); break;
+    case 3: CPH_TRY(enqueue_dense<3>(ctx, ind, nprobe, probe_base, irows, masks, counts, nullptr, nullptr, grid_out, positions)); break;
+    default: return {CPH_ERR_INVALID, "a chain needs a step keyed by the stream"};
+    }
+    {
+        int per_cu = 1, cus = 256;
+        CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_chain_prejoined), kChainThreads, 0, &per_cu));
+        CPH_TRY(device_cus(ctx, &cus));
+        const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)cus * (uint64_t)per_cu);
+        ProfScope ps(ctx, "k_chain_prejoined", (double)nprobe * 8.0 * pa.n);
+        hipLaunchKernelGGL(k_chain_prejoined, dim3(grid), dim3(kChainThreads), 0, ctx->stream, pa, nprobe, ntiles, masks, counts);
+        CPH_HIP_TRY(hipGetLastError());
+    }
+    {
+        DevBuf& acc = ctx->self_clean[ctx->stream_slot].sum;
+        CPH_TRY(self_clean_block(ctx, &acc, 16));
+        ProfScope ps(ctx, "k_sum_counts", 4.0 * (double)ncounts);
+        const unsigned sgrid = (unsigned)std::min<uint64_t>((ncounts + 255) / 256, 512);
+        hipLaunchKernelGGL(k_sum_counts_report, dim3(sgrid), dim3(256), 0, ctx->stream, counts, ncounts, acc.as<unsigned long long>(),
+                           acc.as<uint32_t>() + 2, reinterpret_cast<unsigned long long*>(host_total));
+        CPH_HIP_TRY(hipGetLastError());
+    }
+    // the tables are released here: stream-ordered reuse keeps them alive for the kernels already enqueued
+    return {};
+}
+
 template <int S>
 static Status run_fast(cph_ctx* ctx, const ChainStep* steps, uint64_t nprobe, uint64_t probe_base, ChainOut* out, bool positions) {
     const uint64_t ntiles = (nprobe + kChainTile - 1) / kChainTile;
@@ -810,8 +968,26 @@ static Status run_fast(cph_ctx* ctx, const ChainStep* steps, uint64_t nprobe, ui
     if (!h) return {CPH_ERR_HIP, "no pinned host memory for the match total"};
     ChainArgs args{};
     unsigned grid = 1;
-    CPH_TRY(enqueue_dense<S>(ctx, steps, nprobe, probe_base, rows, masks.as<uint64_t>(), counts.as<uint32_t>(),
-                             nullptr, &args, &grid, positions, const_cast<uint64_t*>(h)));
+    // steps keyed by an earlier build table: worth pre-joining the tables when the stream is much longer than they are
+    bool prejoin = ctx->chain_prejoin != 0;
+    {
+        bool dep = false;
+        for (int s = 0; s < S; s++) {
+            if (steps[s].source == 0) continue;
+            dep = true;
+            const int t = (steps[s].source < 0 ? -steps[s].source : steps[s].source) - 1;
+            if (steps[t].index->nrows * 2 > nprobe) prejoin = false;
+        }
+        prejoin = prejoin && dep;
+    }
+    if (prejoin) {
+        CPH_TRY(run_prejoined(ctx, steps, S, nprobe, probe_base, rows, masks.as<uint64_t>(), counts.as<uint32_t>(), &grid, positions,
+                              const_cast<uint64_t*>(h)));
+        for (int s = 0; s < S; s++) args.out_rows[s] = rows[s];   // (all the compaction reads of it)
+    } else {
+        CPH_TRY(enqueue_dense<S>(ctx, steps, nprobe, probe_base, rows, masks.as<uint64_t>(), counts.as<uint32_t>(),
+                                 nullptr, &args, &grid, positions, const_cast<uint64_t*>(h)));
+    }
     CPH_HIP_TRY(hipGetLastError());
     CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
     const uint64_t nmatch = h[0];

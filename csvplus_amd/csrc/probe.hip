@@ -399,6 +399,22 @@ __global__ void k_hash_build(CodesView cv, const uint32_t* __restrict__ perm, bo
     }
 }
 
+// number of DISTINCT keys of an index with duplicates (heads of the runs of equal codes): what the table is sized by
+__global__ __launch_bounds__(256) void k_hash_count_heads(CodesView cv, unsigned long long* __restrict__ out) {
+    __shared__ uint32_t s_w[256 / kWave];
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t c = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cv.n; i += stride) c += (i == 0 || !codes_equal(cv, i, i - 1)) ? 1u : 0u;
+    c = wave_sum(c);
+    if (lane_id() == 0) s_w[wave_id()] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t r = 0;
+        for (int w = 0; w < 256 / kWave; w++) r += s_w[w];
+        if (r) atomicAdd(out, (unsigned long long)r);
+    }
+}
+
 // index with duplicate keys: the LAST row of every run looks its key up and stores the end of the run
 template <int MODE>
 __global__ void k_hash_set_ends(CodesView cv, uint4* __restrict__ sectors, uint32_t nsectors) {
@@ -454,18 +470,34 @@ Status index_ensure_hash(cph_ctx* ctx, const cph_index* cix) {
     const uint64_t n = ix->nrows;
     const int nw = ix->total_words();
     const int mode = !ix->windows.empty() ? kHashTag : nw == 1 ? kHashK1 : nw <= 3 ? kHashK3 : kHashTag;
-    // load factor <= 0.5 with one slot per ROW (the number of distinct keys is not known): n / 2 sectors of 4 slots,
-    // n sectors of 2 slots
-    uint64_t nsec = mode == kHashK3 ? n : (n + 1) / 2;
-    if (nsec < 1) nsec = 1;
-    if (nsec > 0xFFFFFFFFull) nsec = 0xFFFFFFFFull;
-    DevBuf t, flag;
-    if (!accel_alloc(bctx, ix, &t, nsec * 64)) return {};
-    if (!accel_alloc(bctx, ix, &flag, sizeof(uint32_t))) return {};
-    CPH_HIP_TRY(hipMemsetAsync(t.get(), 0xFF, nsec * 64, bctx->stream));
-    CPH_HIP_TRY(hipMemsetAsync(flag.get(), 0, sizeof(uint32_t), bctx->stream));
     const CodesView cv{ix->sorted_codes.get(), n, ix->codec.key32 ? 1 : nw, ix->codec.key32 ? 1 : 0};
     const bool unique = ix->first_dup == UINT64_MAX;
+    // One slot per DISTINCT key (rounds 3-4 sized by rows: a table with many rows per key paid for slots it never used) at the load
+    // factor of ctx option hash_load_pct: 75 % of the 4 slots of a sector (round 4: 50 % — a 1e7-key table was 320 MB, mostly served
+    // by HBM; 213 MB stay in the Infinity Cache, and ~1.15 sectors per lookup instead of ~1.05 is the cheaper side of that trade),
+    // 62 % of the 2 slots of a three-word sector (small buckets overflow sooner).
+    uint64_t distinct = n;
+    DevBuf flag;
+    if (!accel_alloc(bctx, ix, &flag, 2 * sizeof(uint64_t))) return {};
+    CPH_HIP_TRY(hipMemsetAsync(flag.get(), 0, 2 * sizeof(uint64_t), bctx->stream));
+    if (!unique) {
+        hipLaunchKernelGGL(k_hash_count_heads, dim3(grid_for_items(n)), dim3(256), 0, bctx->stream, cv, flag.as<unsigned long long>() + 1);
+        unsigned long long d = 0;
+        if (hipGetLastError() == hipSuccess &&
+            hipMemcpyAsync(&d, flag.as<unsigned long long>() + 1, sizeof d, hipMemcpyDeviceToHost, bctx->stream) == hipSuccess &&
+            hipStreamSynchronize(bctx->stream) == hipSuccess && d >= 1 && d <= n)
+            distinct = d;
+        else
+            (void)hipGetLastError();   // (a failed count is no error of the Join: the table is sized by rows then)
+    }
+    const uint64_t pct = (uint64_t)(bctx->hash_load_pct < 25 ? 25 : bctx->hash_load_pct > 90 ? 90 : bctx->hash_load_pct);
+    const uint64_t pct3 = pct > 62 ? 62 : pct;
+    uint64_t nsec = mode == kHashK3 ? (distinct * 100 + 2 * pct3 - 1) / (2 * pct3) : (distinct * 100 + 4 * pct - 1) / (4 * pct);
+    nsec += 1;   // (always an empty slot somewhere: every probe sequence ends)
+    if (nsec > 0xFFFFFFFFull) nsec = 0xFFFFFFFFull;
+    DevBuf t;
+    if (!accel_alloc(bctx, ix, &t, nsec * 64)) return {};
+    CPH_HIP_TRY(hipMemsetAsync(t.get(), 0xFF, nsec * 64, bctx->stream));
     const dim3 grid(grid_for_items(n)), block(256);
     uint4* sec = t.as<uint4>();
     uint32_t* fl = flag.as<uint32_t>();

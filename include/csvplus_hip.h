@@ -144,6 +144,12 @@ CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
  *   "codec_split"   0 / 1 (default 1): keys that do not code in 32 bits are tried with the delimiter split — the costliest
  *                   variable-length key column cut at its first delimiter byte into a dictionary-coded prefix and a
  *                   per-position suffix (floating fields like "Smith/Amelia#12345": 25 bits instead of 47; A/B switch)
+ *   "chain_prejoin" 0 / 1 (default 1): chain steps whose key is a column of an earlier step's build table (cph_chain_step.source != 0)
+ *                   are answered from PRE-JOINED tables when the stream is at least twice as long as those tables: the build sides are
+ *                   joined with each other first (one pass over the table's column), the stream rows then need one 4-byte gather per
+ *                   such step (0: the fused kernel gathers and encodes the key per stream row; A/B switch)
+ *   "hash_load_pct" 25..90 (default 75): load factor of the Join hash tables (sparse key spaces), per cent of a 64-byte sector's slots;
+ *                   the tables hold one slot per DISTINCT key (rounds 3-4: 50 % and one slot per row)
  *   "split_speculative" 0 / 1 (default 1): IndexOn over ONE variable-length key column of >= 2^22 rows takes the split codec's prefix
  *                   dictionary and suffix alphabets from its 2^18-row sample alone; the encode kernel checks every row against them
  *                   (prefix in the dictionary, every suffix byte and the end of the suffix in its position's alphabet, lengths within

@@ -34,6 +34,18 @@ def take_rows(col: StrCol, rows) -> StrCol:
 
 
 def check(ctx, builds, steps, probe_base=0, expect_fused=None):
+    """Both ways of answering a build-side key on the fused path: from tables pre-joined with each other (run_prejoined, round 5:
+    one gather per stream row) and by the kernel that gathers and encodes the key per stream row (ctx option chain_prejoin = 0)."""
+    try:
+        for pj in (1, 0):
+            ctx.set_option("chain_prejoin", pj)
+            n = _check(ctx, builds, steps, probe_base, expect_fused, expect_prejoin=bool(pj) and bool(expect_fused))
+    finally:
+        ctx.set_option("chain_prejoin", 1)
+    return n
+
+
+def _check(ctx, builds, steps, probe_base=0, expect_fused=None, expect_prejoin=False):
     """builds[k] = key columns of table k; steps[k] = (columns, source >= 0).  Runs row ids, positions, and positions with the
     build-side columns laid out in sorted order (source -k)."""
     gix = [DeviceIndex(ctx, b) for b in builds]
@@ -47,6 +59,7 @@ def check(ctx, builds, steps, probe_base=0, expect_fused=None):
     ctx.profile(False)
     if expect_fused is not None:
         assert ("k_chain_dense" in prof) == expect_fused and any(k.startswith("k_probe") for k in prof) != expect_fused, sorted(prof)
+        assert ("k_chain_prejoined" in prof) == expect_prejoin, sorted(prof)
     assert ch.nrows == len(es)
     np.testing.assert_array_equal(ch.stream_row, es)
     for k in range(len(gix)):
