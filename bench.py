@@ -49,7 +49,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--rows", type=int, default=100_000_000, help="orders (probe) rows, whole job")
+    ap.add_argument("--rows", type=int, default=None, help="orders (probe) rows, whole job (default 1e8; 1e9 with --stream)")
     ap.add_argument("--customers", type=int, default=10_000_000)
     ap.add_argument("--products", type=int, default=100_000)
     ap.add_argument("--exchange", choices=["allgatherv", "host", "oneshot", "none"], default="allgatherv",
@@ -60,6 +60,12 @@ def parse_args():
     ap.add_argument("--chunks", type=int, default=0, help="sub-chunks per shard for --exchange allgatherv / host (0: the library picks, 1..8)")
     ap.add_argument("--ctx-option", action="append", default=[], metavar="KEY=INT",
                     help="cph_ctx_set_option on the bench's ctx before anything runs (A/B switches: scan_lookback=0, chain_arith=0 ...)")
+    ap.add_argument("--stream", action="store_true",
+                    help="BASELINE config 5 shape: every rank streams ITS shard of the orders from pinned host memory through "
+                         "cph_stream_join_* (chunks uploaded, joined and downloaded on overlapping HIP streams), results land in the "
+                         "node's host memory; --rows defaults to 1e9 here.  PCIe inclusive: not the `value` of the default mode")
+    ap.add_argument("--no-alternatives", action="store_true",
+                    help="N > 1: skip the same-run figures of the other exchange modes and the measured exchange rate")
     ap.add_argument("--no-n1", action="store_true", help="N > 1: skip rank 0's one-GPU run of the whole stream behind efficiency_vs_n1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-index-1e8", action="store_true", help="skip the extra IndexOn-at-full-size measurements")
@@ -88,7 +94,10 @@ def parse_args():
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous only: every rank joins the process group (gloo when no GPU is visible) and rank 0 "
                          "prints which ranks it saw; no compute (what tests/test_bench_launch.py drives on CPU)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.rows is None:
+        args.rows = 1_000_000_000 if args.stream else 100_000_000
+    return args
 
 
 EXIT_USAGE, EXIT_NO_GPUS, EXIT_NO_RCCL = 2, 2, 3
@@ -191,6 +200,102 @@ def measure_traffic(kernel_prefix, args):
     return vals, "measured in this run"
 
 
+def stream_mode(args, eng, dev, rank, world, share_gpu):
+    """BASELINE.json configs[4] (1e9-row orders joined against resident indexes) on N ranks: the build side is replicated (every
+    rank builds both indexes in its HBM), the orders are sharded by row range and every rank streams ITS shard from pinned host
+    memory through cph_stream_join_* — 2^23-row chunks, upload / join / download of consecutive chunks overlapped on the
+    pipeline's HIP streams — and leaves the joined tuples (sorted positions + match bitmap) in pinned host memory: the node's
+    host memory then holds the whole result in row order (rank r's block follows rank r-1's), which is what the Go caller of
+    INTEGRATION.md iterates over.  No collective on the data path ("weak" in the sense of the contract: units per rank fixed
+    by the shard).  A step = one pass of the rank's whole shard; timing as in the default mode (barrier + synchronize on both
+    sides, max over ranks).  PCIe inclusive by construction."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from csvplus_amd import datagen as dg
+    from csvplus_amd.engine import shard_range
+    from csvplus_amd.streaming import PinnedCol, StreamJoin
+
+    begin, end = shard_range(args.rows, rank, world)
+    nloc = end - begin
+    cust_id = dg.column(dg.SEQ_PERM, args.customers, args.customers, encoding=dg.FIXED8, seed=dg.SEED + 1)
+    prod_id = dg.column(dg.SEQ_PERM, args.products, args.products, encoding=dg.ITOA, seed=dg.SEED + 2)
+    ia, ib = eng.index_on_many([[cust_id.to_device(dev)], [prod_id.to_device(dev)]], unique=True)
+    POS = not args.row_ids
+    # the shard is generated and pinned in pieces of 2^26 rows (the generator's temporaries stay small)
+    piece = 1 << 26
+    chunk = 1 << 23
+    pinned, chunks, bounds, h2d = [], [], [], 0
+    for p0 in range(0, nloc, piece):
+        p1 = min(p0 + piece, nloc)
+        o = dg.orders(args.rows, args.customers, args.products, row0=begin + p0, nrows=p1 - p0)
+        pc = [PinnedCol(eng.ctx, o["cust_id"]), PinnedCol(eng.ctx, o["prod_id"])]
+        h2d += o["cust_id"].nbytes_values() + o["prod_id"].nbytes_values() + o["cust_id"].nbytes_offsets() + o["prod_id"].nbytes_offsets()
+        pinned.append(pc)
+        for b in range(0, p1 - p0, chunk):
+            e = min(b + chunk, p1 - p0)
+            chunks.append([c.col.slice(b, e) for c in pc])
+            bounds.append(begin + p0 + b)
+        del o
+    sj = StreamJoin(eng.ctx, [ia, ib], nslots=2, positions=POS)
+
+    def one_pass():
+        sub = done = joined = 0
+        while done < len(chunks):
+            while sub < len(chunks) and sj.pending < 2:
+                sj.submit(chunks[sub], probe_base=bounds[sub])
+                sub += 1
+            joined += sj.next(copy=False)["nmatches"]
+            done += 1
+        return joined
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(max(args.warmup, 1)):   # (the first pass page-locks the slots' result blocks)
+        one_pass()
+    sync_all()
+    t0 = time.perf_counter()
+    joined = 0
+    for _ in range(args.steps):
+        joined = one_pass()
+    sync_all()
+    dt = time.perf_counter() - t0
+    sj.close()
+    per_rank_ms = [dt / args.steps * 1e3]
+    total = joined
+    if world > 1:
+        cdev = "cpu" if share_gpu else dev
+        allt = torch.zeros(world, dtype=torch.float64, device=cdev)
+        dist.all_gather_into_tensor(allt, torch.tensor([dt], dtype=torch.float64, device=cdev))
+        per_rank_ms = [float(x) / args.steps * 1e3 for x in allt.tolist()]
+        dt = float(allt.max().item())
+        t = torch.tensor([joined], dtype=torch.int64, device=cdev)
+        dist.all_reduce(t)
+        total = int(t.item())
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+    ms = dt / args.steps * 1e3
+    d2h = 8 * nloc + nloc // 8
+    print(json.dumps({
+        "metric": "joined rows/sec (streaming Join of host-resident orders against HBM-resident indexes, PCIe inclusive)",
+        "value": total / (dt / args.steps), "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
+        "ms_per_step": ms, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+        "dtype": "u32 codes of byte-string keys", "data": "synthetic",
+        "config": {"workload": f"BASELINE config 5 shape: {args.rows:.0e} orders streamed from pinned host memory in 2^23-row chunks x "
+                               f"{args.customers:.0e} customers x {args.products:.0e} products, indexes resident in HBM on every rank",
+                   "rows": args.rows, "shard_rows_rank0": nloc, "chunk_rows": chunk, "slots": 2,
+                   "output": "sorted positions" if POS else "build-row ids", "exchange": "none (results stay in the node's host memory, rank blocks in row order)"},
+        "scope": "pcie_inclusive: NOT comparable with the default mode's value (inputs resident in HBM)",
+        "joined_rows_per_step": total, "per_rank_ms_per_step": [round(x, 3) for x in per_rank_ms],
+        "h2d_GBps_rank0": round(h2d / (per_rank_ms[0] / 1e3) / 1e9, 1), "d2h_GBps_rank0": round(d2h / (per_rank_ms[0] / 1e3) / 1e9, 1),
+        "verified": bool(total == args.rows), "verify": {"every_order_joined_once": total == args.rows}}))
+
+
 def main():
     args = parse_args()
     if args.gpus < 1:
@@ -266,6 +371,9 @@ def main():
                 sys.exit(EXIT_NO_RCCL)
             rccl_nranks = cdist.size
             transport = "cph_dist_* (RCCL behind the C ABI): " + cdist.transport()
+
+    if args.stream:
+        return stream_mode(args, eng, dev, rank, world, share_gpu)
 
     # ---- synthetic tables (deterministic), staged to HBM before timing ------------
     t0 = time.time()
@@ -372,6 +480,63 @@ def main():
         dist.all_reduce(t)
         total_joined = int(t.item())
 
+    # ---- N > 1: the other exchange modes and the exchange's own rate, IN THIS RUN (every rank takes part) --------------------
+    # A scaling curve of the default mode alone reads as a failure of the join when it is the price of the mandated all-gather:
+    # the same step with the node's shared host buffer as the meeting point and with no exchange at all (every rank keeps its
+    # shard's result) are timed right here, 3 steps each, max over ranks — and one large cph_dist_allgatherv says what a rank
+    # actually receives per second over the links (DESIGN §7 assumed 50 GB/s per link until measured).
+    alternatives, measured_rate = None, None
+    if (world > 1 or force_dist) and not args.no_alternatives:
+        alternatives = {}
+        cdev = "cpu" if share_gpu else dev
+
+        def max_over_ranks(x):
+            if world == 1:
+                return x
+            allx = torch.zeros(world, dtype=torch.float64, device=cdev)
+            dist.all_gather_into_tensor(allx, torch.tensor([x], dtype=torch.float64, device=cdev))
+            return float(allx.max().item())
+
+        timed_mode = args.exchange
+        for mode in ("allgatherv", "host", "none"):
+            if mode == timed_mode or (mode != "none" and cdist is None):
+                continue
+            args.exchange = mode
+            try:
+                del xstats[:]
+                step()
+                sync_all()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    step()
+                sync_all()
+                ms_mode = max_over_ranks((time.perf_counter() - t1) / 3 * 1e3)
+                alternatives[mode] = {"ms_per_step": round(ms_mode, 4),
+                                      "exposed_exchange_ms": round(sum(x["exposed_exchange_ms"] for x in xstats) / len(xstats), 4) if xstats else None}
+            except Exception as ex:   # noqa: BLE001 — an extra figure must not cost the line
+                alternatives[mode] = {"error": f"{type(ex).__name__}: {ex}"}
+            finally:
+                args.exchange = timed_mode
+        if cdist is not None:
+            try:
+                words = 16 << 20   # 64 MB per rank
+                buf = torch.zeros(words, dtype=torch.int32, device=dev)
+                cdist.allgatherv([buf.data_ptr()], [4], words).release()
+                sync_all()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    cdist.allgatherv([buf.data_ptr()], [4], words).release()
+                sync_all()
+                ms_x = max_over_ranks((time.perf_counter() - t1) / 3 * 1e3)
+                recv = 4 * words * (world - 1)
+                measured_rate = {"what": "cph_dist_allgatherv of 64 MB per rank (grouped ncclSend / ncclRecv to every peer), max over ranks",
+                                 "ms": round(ms_x, 3), "bytes_received_per_rank": recv,
+                                 "GBps_received_per_rank": round(recv / ms_x / 1e6, 1) if recv else None,
+                                 "GBps_per_peer_link": round(4 * words / ms_x / 1e6, 1) if recv else None}
+                del buf
+            except Exception as ex:   # noqa: BLE001
+                measured_rate = {"error": f"{type(ex).__name__}: {ex}"}
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -424,13 +589,17 @@ def main():
                 n1_all.append((time.perf_counter() - t1) * 1e3)
             n1_ms = sorted(n1_all)[len(n1_all) // 2]
             del d_full, full
+        multi["same_run_other_modes"] = alternatives
+        multi["measured_exchange_rate"] = measured_rate
         multi["n1_ms_per_step"] = round(n1_ms, 4) if n1_ms else None
         multi["n1_ms_single_steps"] = [round(x, 4) for x in n1_all] if n1_ms else None
         multi["efficiency_vs_n1"] = round(n1_ms / (world * dt / args.steps * 1e3), 4) if n1_ms else None
         code_bytes = 4
-        multi["build_side"] = dict(build_side_estimate(args.customers, code_bytes, world, 3.0e10),
+        link = (measured_rate or {}).get("GBps_per_peer_link")
+        multi["build_side"] = dict(build_side_estimate(args.customers, code_bytes, world, 3.0e10, link or 50.0),
                                    note="customers table: every rank builds (A) vs rank 0 builds + cph_dist_index_broadcast (B), "
-                                        "critical path per rank; 3e10 rows/s build rate and 50 GB/s per xGMI link assumed")
+                                        "critical path per rank; 3e10 rows/s build rate; link rate " +
+                                        (f"{link} GB/s measured in this run (measured_exchange_rate)" if link else "50 GB/s ASSUMED (one rank: nothing to measure)"))
     off_c, off_p = cust_id.nbytes_offsets(), prod_id.nbytes_offsets()   # 0 for fixed-width columns
     off_o = ords["cust_id"].nbytes_offsets() + ords["prod_id"].nbytes_offsets()
     cust_bytes, prod_bytes = cust_id.nbytes_values(), prod_id.nbytes_values()

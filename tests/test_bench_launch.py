@@ -131,3 +131,23 @@ def test_multi_gpu_code_path_with_one_rank(exchange):
     assert m["n1_ms_per_step"] > 0 and 0 < d["efficiency_vs_n1"] < 3 and d["exchange_ms"] == m["exchange_ms"] and d["compute_ms"] > 0
     assert m["build_side"]["choice"] == "replicated"
     assert m["bytes_sent_per_step"] == (300000 * 8 if exchange == "host" else 0)
+    # the other exchange modes and the exchange's own rate, measured in the same run
+    others = m["same_run_other_modes"]
+    assert set(others) == {"allgatherv", "host", "none"} - {exchange}
+    assert all(v.get("ms_per_step", 0) > 0 for v in others.values()), others
+    assert m["measured_exchange_rate"]["ms"] > 0 and m["measured_exchange_rate"]["bytes_received_per_rank"] == 0   # (one rank)
+    assert len(m["n1_ms_single_steps"]) == 5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [1, 2])
+def test_stream_mode_config5_shape(ranks):
+    """--stream: every rank streams its shard of the orders from pinned host memory through cph_stream_join_* (BASELINE config 5's
+    shape at test size); two ranks share the one GPU here (gloo): the control flow of the N-rank line."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", str(ranks), "--stream", "--rows", "600000", "--customers", "20000", "--products", "700",
+                        "--steps", "2", "--warmup", "1"], env=_env(CPH_BENCH_SHARE_GPU="1") if ranks > 1 else _env(), capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == ranks and d["joined_rows_per_step"] == 600000 and d["verified"] is True
+    assert d["scope"].startswith("pcie_inclusive") and len(d["per_rank_ms_per_step"]) == ranks and d["value"] > 0
