@@ -343,7 +343,7 @@ struct cph_ctx {
     int join_hash = 1;             // 0: indexes of this ctx never get a hash table (A/B switch: sorted search instead)
     int codec_debug = 0;           // prints the window choice of codec_try_groups to stderr
     uint64_t n_split_respec = 0;   // builds whose sampled split codec missed a row and that started over with the exact statistics (cph_ctx_get_stat)
-    int hash_load_pct = 75;        // load factor of the Join hash tables, per cent of a sector's slots (probe.hip: index_ensure_hash)
+    int hash_load_pct = 50;        // load factor of the Join hash tables, per cent of a sector's slots (probe.hip: index_ensure_hash)
     int chain_prejoin = 1;         // chain steps keyed by an earlier build table are answered from pre-joined tables (chain.hip: run_prejoined; 0: the DEP kernel)
     int split_speculative = 1;     // the split codec of a large single-column table is taken from its sample, checked by the encode kernel (0: exact pass)
     int codec_split = 1;           // the delimiter split of keycodec.hip is tried (A/B switch; 0: never)

@@ -473,9 +473,7 @@ Status index_ensure_hash(cph_ctx* ctx, const cph_index* cix) {
     const CodesView cv{ix->sorted_codes.get(), n, ix->codec.key32 ? 1 : nw, ix->codec.key32 ? 1 : 0};
     const bool unique = ix->first_dup == UINT64_MAX;
     // One slot per DISTINCT key (rounds 3-4 sized by rows: a table with many rows per key paid for slots it never used) at the load
-    // factor of ctx option hash_load_pct: 75 % of the 4 slots of a sector (round 4: 50 % — a 1e7-key table was 320 MB, mostly served
-    // by HBM; 213 MB stay in the Infinity Cache, and ~1.15 sectors per lookup instead of ~1.05 is the cheaper side of that trade),
-    // 62 % of the 2 slots of a three-word sector (small buckets overflow sooner).
+    // factor of ctx option hash_load_pct: 50 % of the slots of a sector by default (75 % and 85 % measured slower, profiles/r05_hash_load.txt).
     uint64_t distinct = n;
     DevBuf flag;
     if (!accel_alloc(bctx, ix, &flag, 2 * sizeof(uint64_t))) return {};
@@ -491,7 +489,7 @@ Status index_ensure_hash(cph_ctx* ctx, const cph_index* cix) {
             (void)hipGetLastError();   // (a failed count is no error of the Join: the table is sized by rows then)
     }
     const uint64_t pct = (uint64_t)(bctx->hash_load_pct < 25 ? 25 : bctx->hash_load_pct > 90 ? 90 : bctx->hash_load_pct);
-    const uint64_t pct3 = pct > 62 ? 62 : pct;
+    const uint64_t pct3 = pct;
     uint64_t nsec = mode == kHashK3 ? (distinct * 100 + 2 * pct3 - 1) / (2 * pct3) : (distinct * 100 + 4 * pct - 1) / (4 * pct);
     nsec += 1;   // (always an empty slot somewhere: every probe sequence ends)
     if (nsec > 0xFFFFFFFFull) nsec = 0xFFFFFFFFull;

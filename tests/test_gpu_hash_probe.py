@@ -171,7 +171,7 @@ def test_prepare_join_builds_the_table_up_front(ctx):
     assert g.info()["lookup_built"] == 0
     g.prepare_join()
     inf = g.info()
-    assert inf["lookup_built"] == HASH_BUILT and inf["hash_mode"] == 1 and inf["hash_bytes"] >= 16 * 2 * 20_000
+    assert inf["lookup_built"] == HASH_BUILT and inf["hash_mode"] == 1 and inf["hash_bytes"] >= 16 * 2 * 20_000   # one 16-byte slot per distinct key at load 0.5
     probe = StrCol.from_values(build[::3] + [b"nope"])
     assert_join_equal(g.probe([probe]), orc.OracleIndex([StrCol.from_values(build)]).join([probe]))
     # a dense code space gets a direct-address table instead, and prepare_join(chained) its 4-byte form
