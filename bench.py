@@ -1348,7 +1348,7 @@ def main():
         #     first fn customers / fm orders of tables of the same shape, extrapolated with n*log(n) (index) and
         #     m*log(n) (probe).  The extrapolation is labelled; the measured sample stands beside it.
         import math
-        fn, fm = min(1_000_000, args.customers), min(500_000, args.rows)
+        fn, fm = min(4_000_000, args.customers), min(2_000_000, args.rows)   # ~17 s on one core (round 4: 1e6 / 5e5, 4 s)
         f_cust = dg.customers(fn)
         f_prod = dg.products(args.products)
         f_ords = dg.orders(fm, fn, args.products)
