@@ -473,7 +473,7 @@ Status index_ensure_hash(cph_ctx* ctx, const cph_index* cix) {
     const CodesView cv{ix->sorted_codes.get(), n, ix->codec.key32 ? 1 : nw, ix->codec.key32 ? 1 : 0};
     const bool unique = ix->first_dup == UINT64_MAX;
     // One slot per DISTINCT key (rounds 3-4 sized by rows: a table with many rows per key paid for slots it never used) at the load
-    // factor of ctx option hash_load_pct: 50 % of the slots of a sector by default (75 % and 85 % measured slower, profiles/r05_hash_load.txt).
+    // factor of ctx option hash_load_pct: 50 % of the slots of a sector by default (75 % and 85 % measured slower, profiles/r05_tried_not_kept.txt).
     uint64_t distinct = n;
     DevBuf flag;
     if (!accel_alloc(bctx, ix, &flag, 2 * sizeof(uint64_t))) return {};

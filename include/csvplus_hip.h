@@ -150,7 +150,7 @@ CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
  *                   such step (0: the fused kernel gathers and encodes the key per stream row; A/B switch)
  *   "hash_load_pct" 25..90 (default 50): load factor of the Join hash tables (sparse key spaces), per cent of a 64-byte sector's slots,
  *                   counted in DISTINCT keys (rounds 3-4 counted rows).  Measured at 1e7 keys x 1e8 probes: 50 % 2.69 ms, 75 % 3.58 ms,
- *                   85 % 5.5 ms — a smaller table does not pay for the longer probe sequences (profiles/r05_hash_load.txt)
+ *                   85 % 5.5 ms — a smaller table does not pay for the longer probe sequences (profiles/r05_tried_not_kept.txt)
  *   "split_speculative" 0 / 1 (default 1): IndexOn over ONE variable-length key column of >= 2^22 rows takes the split codec's prefix
  *                   dictionary and suffix alphabets from its 2^18-row sample alone; the encode kernel checks every row against them
  *                   (prefix in the dictionary, every suffix byte and the end of the suffix in its position's alphabet, lengths within
