@@ -8,6 +8,7 @@
 #include <new>
 
 #include "cph_internal.hpp"
+#include "codec_device.hpp"
 
 namespace cph {
 
@@ -819,6 +820,20 @@ static Status build_encode_sort(cph_ctx* ctx, BuildJob* job) {
                 eh.slots = va.as<uint32_t>();
                 eh.slot_states = (uint32_t)states;
             }
+            // fixed-width 8-byte keys under an arithmetic codec (decimal ids): the first partition level of the window sort codes the keys
+            // itself — no encode kernel, no code array written and read again
+            ArithPlan ap;
+            codec_arith_plan(cd, &ap);
+            const DevCol& kc = dcols[0];
+            if (ctx->direct_sort == 1 && ctx->direct_fused_encode && job->nkeycols == 1 && ap.enabled && ap.keylen == 8 && kc.fixed_width == 8 &&
+                !kc.segmented() && ((uintptr_t)kc.data & 15) == 0) {
+                CPH_TRY(direct_sort_windows_keys(ctx, reinterpret_cast<const uint64_t*>(kc.data), ap, n, states, va.as<uint32_t>(), ka.as<uint32_t>(),
+                                                 job->miss));
+                ix->sorted_codes = std::move(ka);
+                ix->perm = std::move(va);
+                ix->sort_passes = 0;
+                return {};
+            }
             CPH_TRY(codec_encode_build(ctx, cd, ix->codec_dev, dcols, n, ka.get(), &eh, nullptr, job->miss));
             if (eh.scattered) CPH_TRY(direct_sort_finish_full(ctx, va.as<uint32_t>(), n, ka.as<uint32_t>(), job->miss));
             else CPH_TRY(direct_sort_distinct(ctx, ka.as<uint32_t>(), n, states, va.as<uint32_t>(), ka.as<uint32_t>(), job->miss));
@@ -998,6 +1013,7 @@ CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value
     else if (k == "chain_arith") ctx->chain_arith = value != 0;
     else if (k == "chain_identity") ctx->chain_identity = value != 0;
     else if (k == "chain_prejoin") ctx->chain_prejoin = value != 0;
+    else if (k == "direct_fused_encode") ctx->direct_fused_encode = value != 0;
     else if (k == "hash_load_pct") ctx->hash_load_pct = value < 25 ? 25 : value > 90 ? 90 : (int)value;
     else if (k == "probe_hash_rows") ctx->probe_hash_rows = value == 4 ? 4 : 2;
     else if (k == "small_build_rows") ctx->small_build_rows = value < 0 ? 0 : value > (1 << 20) ? (1 << 20) : (int)value;

@@ -344,6 +344,7 @@ struct cph_ctx {
     int codec_debug = 0;           // prints the window choice of codec_try_groups to stderr
     uint64_t n_split_respec = 0;   // builds whose sampled split codec missed a row and that started over with the exact statistics (cph_ctx_get_stat)
     int hash_load_pct = 50;        // load factor of the Join hash tables, per cent of a sector's slots (probe.hip: index_ensure_hash)
+    int direct_fused_encode = 1;   // the direct sort of fixed-width 8-byte ids codes the keys inside its first partition level (no encode kernel; A/B switch)
     int chain_prejoin = 1;         // chain steps keyed by an earlier build table are answered from pre-joined tables (chain.hip: run_prejoined; 0: the DEP kernel)
     int split_speculative = 1;     // the split codec of a large single-column table is taken from its sample, checked by the encode kernel (0: exact pass)
     int codec_split = 1;           // the delimiter split of keycodec.hip is tried (A/B switch; 0: never)
@@ -602,13 +603,16 @@ Status radix_sort_pairs(cph_ctx* ctx, K* keys_a, K* keys_b, uint32_t* vals_a, ui
 Status direct_sort_distinct(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out, uint32_t* sorted_out,
                             uint32_t* flag);
 // the same through LDS windows: a partition by the top code bits, then every window placed in LDS and streamed out (window_sort.hip)
+struct ArithPlan;   // codec_device.hpp
+Status direct_sort_windows_keys(cph_ctx* ctx, const uint64_t* keys, const ArithPlan& ap, uint64_t n, uint64_t states, uint32_t* perm_out,
+                                uint32_t* sorted_out, uint32_t* flag);
 Status direct_sort_windows(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out, uint32_t* sorted_out,
                            uint32_t* flag);
 // ... in steps, for a table whose codes arrive in chunks (host_encode.hip): begin | add(chunk) per chunk — the first partition level of
 // that chunk, enqueued behind its upload — | finish.  Whether the direct sort applies (distinct keys expected, dense space) is the caller's call.
 struct WindowSort {
     Status begin(cph_ctx* ctx, uint64_t n, uint64_t states);
-    Status add(cph_ctx* ctx, const uint32_t* codes, uint64_t row0, uint64_t m, uint32_t* flag);
+    Status add(cph_ctx* ctx, const uint32_t* codes, uint64_t row0, uint64_t m, uint32_t* flag, const uint64_t* keys = nullptr, const ArithPlan* ap = nullptr);
     Status finish(cph_ctx* ctx, uint32_t* perm_out, uint32_t* sorted_out, uint32_t* flag);
     ~WindowSort();
     WindowSort() = default;

@@ -22,6 +22,7 @@
 //
 // Algorithmic bytes per row (one level): codes in 4, entries out 8 | entries in 8, perm + sorted codes out 8 = 28.
 #include "cph_internal.hpp"
+#include "codec_device.hpp"
 #include "device_utils.hpp"
 
 namespace cph {
@@ -36,7 +37,9 @@ constexpr uint32_t kWinEmpty = 0xFFFFFFFFu;      // never a row id (at most 2^32
 constexpr int kPlaceThreads = 512;
 
 struct WpArgs {
-    const uint32_t* codes;       // FROM_CODES: codes[n], the row is the index
+    const uint64_t* keys;        // SRC == 2: the table's 8-byte keys themselves (fixed width 8, 16-byte aligned) — coded here by `ap`
+    ArithPlan ap;
+    const uint32_t* codes;       // SRC == 1: codes[n], the row is the index
     const uint64_t* entries;     // else: source bucket sb holds src_count[sb] entries at entries + sb * src_cap
     const uint32_t* src_count;
     uint64_t n;
@@ -56,8 +59,12 @@ struct WpArgs {
 // bucket by bucket, in LDS; the staged entries then leave as coalesced runs, 16 per thread in flight.  (Round 5's first version
 // staged 16-bit row numbers and fetched code and row again per entry inside a rolled loop — a chain of four LDS loads and, for
 // the second level, a global load per iteration: 0.7 ms per level at 1e8 rows, 2 TB/s.)
-template <bool FROM_CODES>
+// SRC: 0 = entries of a source bucket (second level), 1 = the code array, 2 = the key column itself (an arithmetic codec over
+// fixed-width 8-byte keys, codec_device.hpp: ArithPlan — the encode kernel and its 4-byte code per row written and read again
+// are gone: 1e8 ids 0.26 + 0.31 -> one pass)
+template <int SRC>
 __global__ __launch_bounds__(kWpThreads) void k_win_partition(WpArgs a) {
+    constexpr bool FROM_CODES = SRC != 0;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ uint32_t s_tmp[kWpThreads / kWave + 1];
     const uint32_t nbp = (a.nb + (uint32_t)kWpThreads - 1u) & ~((uint32_t)kWpThreads - 1u);
@@ -81,7 +88,40 @@ __global__ __launch_bounds__(kWpThreads) void k_win_partition(WpArgs a) {
     // ---- load, count per bucket; rank = arrival number inside the bucket (any order will do) ----
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     uint32_t code[kWpItems], row[kWpItems], rank[kWpItems];
-    if constexpr (FROM_CODES) {
+    if constexpr (SRC == 2) {
+        uint64_t c0[kWpItems];
+        uint32_t okm = 0;
+#pragma unroll
+        for (int j = 0; j < kWpItems / 4; j++) {
+            const uint32_t i4 = 4u * ((uint32_t)j * kWpThreads + t);
+            if (i4 + 3 < m) {   // (the keys are 16-byte aligned: two 16-byte loads)
+                const u32x4 v0 = reinterpret_cast<const u32x4*>(a.keys + src0 + i4)[0], v1 = reinterpret_cast<const u32x4*>(a.keys + src0 + i4)[1];
+                c0[4 * j] = (uint64_t)v0.x | ((uint64_t)v0.y << 32);
+                c0[4 * j + 1] = (uint64_t)v0.z | ((uint64_t)v0.w << 32);
+                c0[4 * j + 2] = (uint64_t)v1.x | ((uint64_t)v1.y << 32);
+                c0[4 * j + 3] = (uint64_t)v1.z | ((uint64_t)v1.w << 32);
+                okm |= 0xFu << (4 * j);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    c0[4 * j + c] = i4 + c < m ? a.keys[src0 + i4 + c] : 0ull;
+                    okm |= (i4 + c < m ? 1u : 0u) << (4 * j + c);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) row[4 * j + c] = a.row_base + (uint32_t)(t0 + i4 + c);
+        }
+        const uint32_t have = okm;
+        encode_rows_arith<kWpItems, uint32_t>(a.ap, c0, code, &okm);
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < kWpItems; k++) {
+            const bool ok = ((okm >> k) & 1u) && code[k] < a.states;
+            bad |= ((have >> k) & 1u) && !ok;   // a key the (sampled) alphabets cannot code: the build starts over
+            code[k] = ok ? code[k] : kWinEmpty;
+        }
+        if (__ballot(bad) && lane_id() == 0) *a.flag = 1u;
+    } else if constexpr (SRC == 1) {
         const bool vec = m == (uint32_t)kWpTile && (((uintptr_t)(a.codes + src0)) & 15) == 0;
 #pragma unroll
         for (int j = 0; j < kWpItems / 4; j++) {
@@ -302,11 +342,13 @@ static size_t win_partition_lds(uint32_t nb) {
     return (size_t)kWpTile * 8 + (size_t)nbp * 12;
 }
 
-// rows [row0, row0 + m): codes[0] is row row0's code
-Status WindowSort::add(cph_ctx* ctx, const uint32_t* codes, uint64_t row0, uint64_t m, uint32_t* flag) {
+// rows [row0, row0 + m): codes[0] is row row0's code (keys != nullptr: keys[0] its 8-byte key, coded by *ap inside the pass)
+Status WindowSort::add(cph_ctx* ctx, const uint32_t* codes, uint64_t row0, uint64_t m, uint32_t* flag, const uint64_t* keys, const ArithPlan* ap) {
     if (m == 0) return {};
     WpArgs a{};
     a.codes = codes;
+    a.keys = keys;
+    if (keys) a.ap = *ap;
     a.n = m;
     a.tiles_per_src = (uint32_t)((m + kWpTile - 1) / kWpTile);
     a.shift = shift1;
@@ -317,9 +359,15 @@ Status WindowSort::add(cph_ctx* ctx, const uint32_t* codes, uint64_t row0, uint6
     a.row_base = (uint32_t)row0;
     a.flag = flag;
     const size_t lds = win_partition_lds(a.nb);
-    CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_win_partition<true>), kWpThreads, lds, nullptr));
-    ProfScope ps(ctx, "k_win_partition", 12.0 * (double)m);
-    hipLaunchKernelGGL(k_win_partition<true>, dim3(a.tiles_per_src), dim3(kWpThreads), lds, ctx->stream, a);
+    if (keys) {
+        CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_win_partition<2>), kWpThreads, lds, nullptr));
+        ProfScope ps(ctx, "k_win_partition", 16.0 * (double)m);   // keys in (8), entries out (8)
+        hipLaunchKernelGGL(k_win_partition<2>, dim3(a.tiles_per_src), dim3(kWpThreads), lds, ctx->stream, a);
+    } else {
+        CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_win_partition<1>), kWpThreads, lds, nullptr));
+        ProfScope ps(ctx, "k_win_partition", 12.0 * (double)m);
+        hipLaunchKernelGGL(k_win_partition<1>, dim3(a.tiles_per_src), dim3(kWpThreads), lds, ctx->stream, a);
+    }
     CPH_HIP_TRY(hipGetLastError());
     return {};
 }
@@ -341,9 +389,9 @@ Status WindowSort::finish(cph_ctx* ctx, uint32_t* perm_out, uint32_t* sorted_out
         a.dst_count = cur2;
         a.flag = flag;
         const size_t lds = win_partition_lds(a.nb);
-        CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_win_partition<false>), kWpThreads, lds, nullptr));
+        CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_win_partition<0>), kWpThreads, lds, nullptr));
         ProfScope ps(ctx, "k_win_partition", 16.0 * (double)n);
-        hipLaunchKernelGGL(k_win_partition<false>, dim3((unsigned)(nb1 * a.tiles_per_src)), dim3(kWpThreads), lds, ctx->stream, a);
+        hipLaunchKernelGGL(k_win_partition<0>, dim3((unsigned)(nb1 * a.tiles_per_src)), dim3(kWpThreads), lds, ctx->stream, a);
         CPH_HIP_TRY(hipGetLastError());
     }
     uint32_t* counts = two ? cur2 : cur1;
@@ -369,6 +417,16 @@ Status direct_sort_windows(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint
     WindowSort ws;
     CPH_TRY(ws.begin(ctx, n, states));
     CPH_TRY(ws.add(ctx, codes, 0, n, flag));
+    return ws.finish(ctx, perm_out, sorted_out, flag);
+}
+// the same straight from the key column: keys[n] (fixed width 8, 16-byte aligned), coded by `ap` inside the first partition level;
+// *flag is also raised by a key `ap` cannot code (alphabets from a sample)
+Status direct_sort_windows_keys(cph_ctx* ctx, const uint64_t* keys, const ArithPlan& ap, uint64_t n, uint64_t states, uint32_t* perm_out,
+                                uint32_t* sorted_out, uint32_t* flag) {
+    if (n == 0) return {};
+    WindowSort ws;
+    CPH_TRY(ws.begin(ctx, n, states));
+    CPH_TRY(ws.add(ctx, nullptr, 0, n, flag, keys, &ap));
     return ws.finish(ctx, perm_out, sorted_out, flag);
 }
 

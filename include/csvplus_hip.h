@@ -144,6 +144,9 @@ CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
  *   "codec_split"   0 / 1 (default 1): keys that do not code in 32 bits are tried with the delimiter split — the costliest
  *                   variable-length key column cut at its first delimiter byte into a dictionary-coded prefix and a
  *                   per-position suffix (floating fields like "Smith/Amelia#12345": 25 bits instead of 47; A/B switch)
+ *   "direct_fused_encode" 0 / 1 (default 1): the direct sort of ONE fixed-width 8-byte key column under an arithmetic codec (decimal ids; the
+ *                   column 16-byte aligned) codes the keys inside its first partition level — no encode kernel, no 4-byte code per row written
+ *                   and read again (1e8 ids: 1.30 -> 1.12 ms; A/B switch)
  *   "chain_prejoin" 0 / 1 (default 1): chain steps whose key is a column of an earlier step's build table (cph_chain_step.source != 0)
  *                   are answered from PRE-JOINED tables when the stream is at least twice as long as those tables: the build sides are
  *                   joined with each other first (one pass over the table's column), the stream rows then need one 4-byte gather per

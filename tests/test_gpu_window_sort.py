@@ -47,3 +47,56 @@ def test_window_sort_over_two_partition_levels(shape):
         assert chk["ok"], chk
     del pg, pr
     g.close(); r.close(); ctx.close()
+
+
+@pytest.mark.parametrize("shape", ["full", "dense", "duplicate", "rare_byte", "unaligned"])
+def test_keys_coded_inside_the_first_partition_level(shape):
+    """Round 5: fixed-width 8-byte decimal ids (an arithmetic codec) are coded by the window sort's first partition level itself
+    (k_win_partition<2>): no encode kernel, no code array.  Same index as the oracle's (csvplus.go:740-756, :794-807) and as the
+    two-kernel path (ctx option direct_fused_encode = 0); a duplicate or a row the sampled alphabets cannot code sends the build
+    down the general path; a key column that is not 16-byte aligned keeps the encode kernel."""
+    import torch
+
+    from csvplus_amd import Context, StrCol
+    from oracle import orc
+
+    ctx = Context(0)
+    rng = np.random.default_rng(5)
+    n = (1 << 20) + 4321 if shape == "rare_byte" else 300_000
+    ids = rng.permutation(n if shape in ("full", "unaligned") else int(1.6 * n))[:n]
+    if shape == "duplicate":
+        ids[200_001] = ids[7]
+    raw = np.char.zfill(ids.astype("U8"), 8).astype("S8")
+    data = np.frombuffer(raw.tobytes(), np.uint8).copy()
+    if shape == "rare_byte":
+        row = 777_777
+        assert row % (n >> 16) != 0
+        data[8 * row + 5] = ord("x")
+    col = StrCol.from_arrays(data, np.arange(n + 1, dtype=np.uint32) * 8, fixed_width=8)
+    o = orc.OracleIndex([col])
+    if shape == "unaligned":   # the same keys at an address that is 8 but not 16 modulo 16
+        buf = torch.zeros(8 * n + 16, dtype=torch.uint8, device="cuda:0")   # (8 bytes of slack behind the last key, as to_device leaves)
+        buf[8:8 + 8 * n] = torch.from_numpy(data).to("cuda:0")
+        dcol = StrCol(buf[8:], None, n, 32, mem=N.CPH_MEM_DEVICE, fixed_width=8)
+    else:
+        dcol = col.to_device("cuda:0")
+    for fused in (1, 0):
+        ctx.set_option("direct_fused_encode", fused)
+        ctx.profile(True)
+        ctx.profile_read(reset=True)
+        g = DeviceIndex(ctx, [dcol], unique=True)
+        prof = ctx.profile_read(reset=True)
+        ctx.profile(False)
+        np.testing.assert_array_equal(g.perm(), o.perm)
+        assert g.first_dup == o.first_dup()
+        encodes = prof.get("k_encode_build", {"launches": 0})["launches"]
+        if shape in ("full", "dense"):
+            assert "k_win_partition" in prof and encodes == (0 if fused else 1), sorted(prof)
+        elif shape == "unaligned":
+            assert "k_win_partition" in prof and encodes == 1, sorted(prof)
+        else:   # the optimistic sort noticed, the general path (encode kernel + radix passes) built the index
+            assert "k_radix_scatter_u32" in prof and encodes >= 1, sorted(prof)
+        if shape == "full":
+            assert g.info()["table_entries"] == n
+        g.close()
+    ctx.close()
