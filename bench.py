@@ -955,12 +955,23 @@ def main():
                 elif inf_["table_entries"] and inf_["table_entries"] != rows_:
                     look += 0.25 * inf_["table_entries"]
             algo = s_in + look + 8.0 * nj
+            kname = "k_chain_dense"
+            if side_key is not None and "k_chain_prejoined" in pb_:
+                # pre-joined build sides: the chain is three kernels — the table pass over the customers' side column,
+                # the fused pass over the stream-keyed step, the gather pass — timed together (one fully profiled step); bytes: the
+                # stream's key column in, one 4-byte pre-joined entry per row (contract model, as for row ids), two positions out,
+                # + the table pass (side column in, 4 B out, perm 4 B + 4 B out for the sorted order) per customers row
+                kname = "k_chain_prejoin_table + k_chain_dense + k_chain_prejoined"
+                kd_ms_ = sum(pb_[k]["total_ms"] for k in ("k_chain_prejoin_table", "k_chain_dense", "k_chain_prejoined") if k in pb_)
+                s_in = v_ocust.nbytes_values() + v_ocust.nbytes_offsets() + 4.0 * nloc
+                look = side_key.nbytes_values() + side_key.nbytes_offsets() + 12.0 * side_key.nrows
+                algo = s_in + look + 8.0 * nj
             blk = {"what": what, "ms_per_step": round(dt_ * 1e3, 4), "value": nj / dt_, "unit": "rows/s", "joined_rows_per_step": nj,
                    "timed_step_over_this": round(ms_per_step / (dt_ * 1e3), 3),
                    "k_chain_dense_ms": round(kd_ms_, 4) if kd_ms_ else None,
                    "kernels_ms": {k: round(v["total_ms"], 4) for k, v in sorted(pb_.items(), key=lambda kv: -kv[1]["total_ms"])},
                    "customers_index": ia_i,
-                   "roofline": {"kernel": "k_chain_dense" if kd_ms_ else None, "algorithmic_bytes_per_launch": round(algo),
+                   "roofline": {"kernel": kname if kd_ms_ else None, "algorithmic_bytes_per_launch": round(algo),
                                 "bytes_model": {"streams_in": round(s_in), "lookup_structures_once": round(look), "results_out": 8 * nj},
                                 "achieved": round(algo / 1e9 / (kd_ms_ / 1e3), 1) if kd_ms_ else None, "unit": "GB/s", "peak": HBM_PEAK_GBPS,
                                 "frac": round(algo / 1e9 / (kd_ms_ / 1e3) / HBM_PEAK_GBPS, 4) if kd_ms_ else None}}
@@ -1031,8 +1042,9 @@ def main():
             guarded("build_side_key", lambda: run_variant(
                 "build_side_key", "orders.Join(customers, cust_id).Join(products, fav_prod) with fav_prod a column of the CUSTOMERS table "
                 "(cph_chain_step.source = 1; the shape of the reference's people.Join(orders).Join(products), csvplus_test.go:280-285): "
-                "the fused kernel gathers the second key from the customer row it matched (perm, offsets, key bytes: three dependent "
-                "random accesses per row)", cust_id, ords["cust_id"],
+                "the build sides are joined with each other first (one pass over the customers' fav_prod column), a stream row then takes "
+                "ONE 4-byte gather for that step (chain.hip: run_prejoined; round 5's first version gathered and coded the key per stream "
+                "row: 7.0 ms)", cust_id, ords["cust_id"],
                 side_key=dg.column(dg.UNIFORM, args.customers, args.products, encoding=dg.ITOA, seed=dg.SEED + 21)))
         if "permute" in want:
             from csvplus_amd.materialize import permute_col
