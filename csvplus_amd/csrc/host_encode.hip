@@ -159,7 +159,10 @@ CPH_API int32_t cph_host_encoder_run(cph_host_encoder* e, const cph_strcol* cols
         hc[c].data_bytes = cols[c].fixed_width ? n * (uint64_t)cols[c].fixed_width : cph_host::col_offset(hc[c], n);
     }
     std::lock_guard<std::mutex> lk(e->run_mu);
-    encode_rows_on(*e->pool, *e, hc, ncols, 0, n, out_codes, nullptr);
+    // a chunk's codes are read next by the DMA engine that uploads them (cph_stream_join_submit_codes), not by these cores: streaming
+    // stores from 2^16 rows on (no read-for-ownership of the output lines — what made the build side's encode 2.7x faster in round 5,
+    // profiles/r05_host_build.txt); a small batch, which its caller may well read back itself, keeps regular stores
+    encode_rows_on(*e->pool, *e, hc, ncols, 0, n, out_codes, nullptr, n >= (1ull << 16));
     return CPH_OK;
 }
 
