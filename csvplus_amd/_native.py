@@ -100,7 +100,7 @@ class cph_index_info(C.Structure):
     ]
 
 
-CPH_MAX_CHAIN = 4
+CPH_MAX_CHAIN = 8
 
 
 class cph_index_spec(C.Structure):

@@ -42,7 +42,7 @@ constexpr int kChainRows    = 8;                                   // rows in fl
 constexpr int kWaveTile     = kWave * kChainRows;                  // consecutive stream rows owned by one wave
 constexpr int kChainTile    = kChainThreads * kChainRows;          // stream rows per workgroup tile
 constexpr int kChainMasks   = kChainRows * kChainWaves;            // ballot words per tile (a plain bitmap: word r/64)
-constexpr int kMaxChain     = CPH_MAX_CHAIN;
+constexpr int kMaxChain     = 4;                                   // Joins of one FUSED pass (the kernels' argument blocks); CPH_MAX_CHAIN (8) is the limit of a call
 
 struct ChainStepArg {
     DevCol col;                 // the stream's key column for this step
@@ -623,6 +623,7 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_prejoined(PrejoinArgs a
 }
 
 bool chain_fast_path_ok(const ChainStep* steps, int nsteps) {
+    if (nsteps > kMaxChain) return false;   // longer chains: the general path below, on the device, in the same call
     for (int s = 0; s < nsteps; s++) {
         const cph_index* ix = steps[s].index;
         if (steps[s].ncols != 1 || ix->nkeycols != 1) return false;
@@ -1041,7 +1042,7 @@ Status chain_run(cph_ctx* ctx, const ChainStep* steps, int nsteps, uint64_t prob
     ProbeOut first;
     CPH_TRY(probe_run(ctx, steps[0].index, steps[0].cols, steps[0].ncols, RowSel{}, nprobe, probe_base, true, &first, positions));
     DevBuf cur_stream = std::move(first.pidx);
-    DevBuf cur_rows[kMaxChain];
+    DevBuf cur_rows[CPH_MAX_CHAIN];
     cur_rows[0] = std::move(first.brow);
     uint64_t n = first.nmatches;
     for (int s = 1; s < nsteps && n > 0; s++) {

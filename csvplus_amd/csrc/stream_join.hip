@@ -63,7 +63,8 @@ struct cph_stream_join {
     hipStream_t up = nullptr, down = nullptr;
     bool general = false;
     bool positions = false;                // build_row[k] = sorted position in index k (cph_stream_join_set_positions)
-    int ncols[CPH_MAX_CHAIN] = {1, 1, 1, 1};
+    int ncols[CPH_MAX_CHAIN] = {1, 1, 1, 1, 1, 1, 1, 1};
+    static_assert(CPH_MAX_CHAIN == 8, "one initialiser per step");
     int total_cols = 0;
     std::vector<Slot*> slots;
     std::vector<int> fifo;                 // slot numbers in submission order

@@ -46,7 +46,7 @@ type JoinStep struct {
 }
 
 // JoinChain(s0, s1, ...) returns the rows of src.Join(s0.Index, s0.Columns...).Join(s1.Index, s1.Columns...)... — same
-// rows, same order, same errors — with ONE device call per batch of stream rows for all steps (at most CPH_MAX_CHAIN = 4
+// rows, same order, same errors — with ONE device call per batch of stream rows for all steps (at most CPH_MAX_CHAIN = 8
 // per call; longer chains are cut into several).  It is an ADDITION to the reference's method set: the reference's
 // DataSource is a bare func type, so a Join cannot see that its source is another Join's closure (Go func values have no
 // identity to look up) and `a.Join(x).Join(y)` written with the unchanged API stays two probes per batch.  A maintainer

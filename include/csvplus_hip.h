@@ -288,7 +288,10 @@ CPH_API void    cph_matches_release(cph_matches* m);
 
 /* ---- chained Join on the device (README.md:56; csvplus.go:545-569 nested) ---- */
 
-#define CPH_MAX_CHAIN 4
+/* Joins per device call.  Chains of up to 4 Joins over duplicate-free single-column indexes run as ONE fused pass over the stream
+ * rows; longer ones (and chains with duplicate keys / several key columns) run the general chain — probe, select, compose, one
+ * step at a time — on the device, still inside one call (round 5: was 4, a fifth Join started a second call). */
+#define CPH_MAX_CHAIN 8
 
 /* One Join of a chain: stream.Join(index, cols...).  ncols <= the index's key columns.
  *   source == 0   `cols` are columns of the STREAM table (all such steps see the same nrows): the value the Join reads when

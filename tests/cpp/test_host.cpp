@@ -536,6 +536,19 @@ static void TestChainPrecedence() {
         size_t n3 = 0;
         Error e5 = three([&](Row r) { n3++; return r.at("tag") == "C" ? Error() : Error("precedence"); });
         CHECK(!e5 && n3 == 3 * got.size());
+        // (5b) six Joins in a row: one device call per batch (CPH_MAX_CHAIN = 8 since round 5; the general chain runs on the device),
+        //      same rows as three nested pairs on the host
+        {
+            std::vector<Row> w2 = nestedJoinOnHost(stream, *ic, {"cust_id"}, *ip, {"prod_id"}, &he);
+            std::vector<Row> w4 = nestedJoinOnHost(w2, *id, {"cust_id"}, *ip, {"fav_prod"}, &he);
+            std::vector<Row> w6 = nestedJoinOnHost(w4, *ic, {"id"}, *ip, {"prod_id"}, &he);
+            CHECK(!he && !w6.empty());
+            const uint64_t f6 = DataSource::fused_calls();
+            auto [got6, ge6] = TakeRows(stream).Join(ic, {"cust_id"}).Join(ip, {"prod_id"}).Join(id, {"cust_id"}).Join(ip, {"fav_prod"})
+                                   .Join(ic, {"id"}).Join(ip, {"prod_id"}).ToRows();
+            CHECK(!ge6 && same(got6, w6));
+            CHECK(DataSource::fused_calls() == f6 + (stream.size() + batch - 1) / batch);
+        }
         // (6) early stop through both Joins: io.EOF ends the pipeline cleanly after exactly 5 rows; an error is reported
         int k = 0;
         Error e6 = TakeRows(stream).Join(ic, {"cust_id"}).Join(ip, {"prod_id"})([&](Row) { return ++k == 5 ? io_EOF : Error(); });

@@ -29,7 +29,13 @@ def check_chain(ctx, build_tables, stream_keys, probe_base=0, expect_fast=None):
     gix = [DeviceIndex(ctx, cols) for cols in build_tables]
     oix = [orc.OracleIndex(cols) for cols in build_tables]
     steps = [(g, k if isinstance(k, list) else [k]) for g, k in zip(gix, stream_keys)]
+    ctx.profile(True)
+    ctx.profile_read(reset=True)
     ch = join_chain(ctx, steps, probe_base=probe_base)
+    prof = ctx.profile_read(reset=True)
+    ctx.profile(False)
+    if expect_fast is not None:   # one fused pass, or the general chain (probe / select / compose per step) on the device
+        assert ("k_chain_dense" in prof) == expect_fast and any(k.startswith("k_probe") for k in prof) != expect_fast, sorted(prof)
     es, erows = oracle_chain(oix, [k if isinstance(k, list) else k for k in stream_keys], probe_base)
     assert ch.nrows == len(es)
     np.testing.assert_array_equal(ch.stream_row, es)
@@ -71,8 +77,9 @@ def test_chain_unique_with_misses(ctx):
     assert 0 < ch.nrows < m
 
 
-@pytest.mark.parametrize("nsteps", [1, 3, 4])
+@pytest.mark.parametrize("nsteps", [1, 3, 4, 5, 8])
 def test_chain_lengths(ctx, nsteps):
+    """1-4 Joins: one fused pass; 5-8 (CPH_MAX_CHAIN, round 5): the general chain on the device, still ONE call."""
     rng = np.random.default_rng(nsteps)
     m = 50_000
     builds, keys = [], []
@@ -81,7 +88,11 @@ def test_chain_lengths(ctx, nsteps):
         vals = [b"%d" % i for i in rng.permutation(dom)[: dom * 3 // 4]]
         builds.append([StrCol.from_values(vals)])
         keys.append(StrCol.from_values([b"%d" % i for i in rng.integers(0, dom, m)]))
-    check_chain(ctx, builds, keys)
+    check_chain(ctx, builds, keys, expect_fast=nsteps <= 4)
+    if nsteps == 8:   # one Join more than a call takes
+        gix = [DeviceIndex(ctx, b) for b in builds] + [DeviceIndex(ctx, builds[0])]
+        with pytest.raises(Exception, match="bad chain"):
+            join_chain(ctx, [(g, [k]) for g, k in zip(gix, keys + [keys[0]])])
 
 
 def test_chain_search_path_sparse_codes(ctx):
