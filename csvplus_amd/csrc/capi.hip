@@ -614,7 +614,7 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
         j.miss = nullptr;
         cph_index* ix = j.ix;
         ix->codec = CodecHost{};
-        ix->codec_dev.reset(); ix->sorted_codes.reset(); ix->perm.reset(); ix->first_dup_dev.reset();
+        ix->codec_dev.reset(); ix->sorted_codes.reset(); ix->perm.reset(); ix->first_dup_dev.reset(); ix->ranktab.reset();
         if (again_exact) {
             ctx->n_split_respec++;
             st1[0] = codec_try_split(ctx, j.dcols, 1, ix->nrows, nullptr, &ix->codec, false, nullptr);
@@ -822,21 +822,34 @@ static Status build_encode_sort(cph_ctx* ctx, BuildJob* job) {
             }
             // fixed-width 8-byte keys under an arithmetic codec (decimal ids): the first partition level of the window sort codes the keys
             // itself — no encode kernel, no code array written and read again
+            // a code space larger than the table: the Join's rank table (8 bytes per 32 codes) falls out of the window sort for free
+            DevBuf rt;
+            uint64_t rt_blocks = 0;
+            if (ctx->direct_ranktab && ctx->direct_sort == 1 && states != n && states <= (1ull << 30)) {   // (index_plan_table's limit)
+                rt_blocks = ranktab_blocks(states);
+                if (!rt.alloc(&ctx->pool, rt_blocks * 8).ok()) rt_blocks = 0;   // (then the first Join builds it, or does without)
+            }
+            void* rtp = rt_blocks ? rt.get() : nullptr;
             ArithPlan ap;
             codec_arith_plan(cd, &ap);
             const DevCol& kc = dcols[0];
             if (ctx->direct_sort == 1 && ctx->direct_fused_encode && job->nkeycols == 1 && ap.enabled && ap.keylen == 8 && kc.fixed_width == 8 &&
                 !kc.segmented() && ((uintptr_t)kc.data & 15) == 0) {
                 CPH_TRY(direct_sort_windows_keys(ctx, reinterpret_cast<const uint64_t*>(kc.data), ap, n, states, va.as<uint32_t>(), ka.as<uint32_t>(),
-                                                 job->miss));
+                                                 job->miss, rtp, rt_blocks));
                 ix->sorted_codes = std::move(ka);
                 ix->perm = std::move(va);
                 ix->sort_passes = 0;
+                if (rtp) ix->ranktab = std::move(rt);   // (a miss starts the build over and drops it: build_run)
                 return {};
             }
             CPH_TRY(codec_encode_build(ctx, cd, ix->codec_dev, dcols, n, ka.get(), &eh, nullptr, job->miss));
             if (eh.scattered) CPH_TRY(direct_sort_finish_full(ctx, va.as<uint32_t>(), n, ka.as<uint32_t>(), job->miss));
-            else CPH_TRY(direct_sort_distinct(ctx, ka.as<uint32_t>(), n, states, va.as<uint32_t>(), ka.as<uint32_t>(), job->miss));
+            else {
+                bool rt_written = false;
+                CPH_TRY(direct_sort_distinct(ctx, ka.as<uint32_t>(), n, states, va.as<uint32_t>(), ka.as<uint32_t>(), job->miss, rtp, rt_blocks, &rt_written));
+                if (rt_written) ix->ranktab = std::move(rt);
+            }
             ix->sorted_codes = std::move(ka);
             ix->perm = std::move(va);
             ix->sort_passes = 0;
@@ -1014,6 +1027,7 @@ CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value
     else if (k == "chain_identity") ctx->chain_identity = value != 0;
     else if (k == "chain_prejoin") ctx->chain_prejoin = value != 0;
     else if (k == "direct_fused_encode") ctx->direct_fused_encode = value != 0;
+    else if (k == "direct_ranktab") ctx->direct_ranktab = value != 0;
     else if (k == "hash_load_pct") ctx->hash_load_pct = value < 25 ? 25 : value > 90 ? 90 : (int)value;
     else if (k == "probe_hash_rows") ctx->probe_hash_rows = value == 4 ? 4 : 2;
     else if (k == "small_build_rows") ctx->small_build_rows = value < 0 ? 0 : value > (1 << 20) ? (1 << 20) : (int)value;

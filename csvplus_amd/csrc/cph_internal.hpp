@@ -345,6 +345,7 @@ struct cph_ctx {
     uint64_t n_split_respec = 0;   // builds whose sampled split codec missed a row and that started over with the exact statistics (cph_ctx_get_stat)
     int hash_load_pct = 50;        // load factor of the Join hash tables, per cent of a sector's slots (probe.hip: index_ensure_hash)
     int direct_fused_encode = 1;   // the direct sort of fixed-width 8-byte ids codes the keys inside its first partition level (no encode kernel; A/B switch)
+    int direct_ranktab = 1;        // the window sort writes the index's rank table while it streams its windows out (no k_build_ranktab at the first Join; A/B switch)
     int chain_prejoin = 1;         // chain steps keyed by an earlier build table are answered from pre-joined tables (chain.hip: run_prejoined; 0: the DEP kernel)
     int split_speculative = 1;     // the split codec of a large single-column table is taken from its sample, checked by the encode kernel (0: exact pass)
     int codec_split = 1;           // the delimiter split of keycodec.hip is tried (A/B switch; 0: never)
@@ -601,19 +602,20 @@ Status radix_sort_pairs(cph_ctx* ctx, K* keys_a, K* keys_b, uint32_t* vals_a, ui
                         uint32_t* counts = nullptr, bool first_hist_done = false);
 // distinct 32-bit codes over a dense space: one scatter instead of radix passes (optimistic; *flag raised on a duplicate)
 Status direct_sort_distinct(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out, uint32_t* sorted_out,
-                            uint32_t* flag);
+                            uint32_t* flag, void* ranktab = nullptr, uint64_t rank_blocks = 0, bool* ranktab_written = nullptr);
 // the same through LDS windows: a partition by the top code bits, then every window placed in LDS and streamed out (window_sort.hip)
 struct ArithPlan;   // codec_device.hpp
 Status direct_sort_windows_keys(cph_ctx* ctx, const uint64_t* keys, const ArithPlan& ap, uint64_t n, uint64_t states, uint32_t* perm_out,
-                                uint32_t* sorted_out, uint32_t* flag);
+                                uint32_t* sorted_out, uint32_t* flag, void* ranktab = nullptr, uint64_t rank_blocks = 0);
 Status direct_sort_windows(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out, uint32_t* sorted_out,
-                           uint32_t* flag);
+                           uint32_t* flag, void* ranktab = nullptr, uint64_t rank_blocks = 0);
 // ... in steps, for a table whose codes arrive in chunks (host_encode.hip): begin | add(chunk) per chunk — the first partition level of
 // that chunk, enqueued behind its upload — | finish.  Whether the direct sort applies (distinct keys expected, dense space) is the caller's call.
 struct WindowSort {
     Status begin(cph_ctx* ctx, uint64_t n, uint64_t states);
     Status add(cph_ctx* ctx, const uint32_t* codes, uint64_t row0, uint64_t m, uint32_t* flag, const uint64_t* keys = nullptr, const ArithPlan* ap = nullptr);
-    Status finish(cph_ctx* ctx, uint32_t* perm_out, uint32_t* sorted_out, uint32_t* flag);
+    // ranktab != nullptr: the rank table of the index (uint2 {presence bits, keys before} per 32 codes, rank_blocks of them) is written too
+    Status finish(cph_ctx* ctx, uint32_t* perm_out, uint32_t* sorted_out, uint32_t* flag, void* ranktab = nullptr, uint64_t rank_blocks = 0);
     ~WindowSort();
     WindowSort() = default;
     WindowSort(const WindowSort&) = delete;

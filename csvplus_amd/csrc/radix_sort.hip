@@ -760,11 +760,15 @@ Status direct_sort_finish_full(cph_ctx* ctx, const uint32_t* slots, uint64_t n, 
 // zeroed by the caller) is raised when two rows share a code — the outputs are then meaningless.  codes and sorted_out may be
 // the same buffer.  scratch: states == n needs none (perm_out holds the slots).
 Status direct_sort_distinct(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out, uint32_t* sorted_out,
-                            uint32_t* flag) {
+                            uint32_t* flag, void* ranktab, uint64_t rank_blocks, bool* ranktab_written) {
+    if (ranktab_written) *ranktab_written = false;
     if (n == 0) return {};
     // default since round 5: the random placement happens in LDS windows and every global store is sequential (window_sort.hip);
     // ctx option direct_sort = 4 keeps the plain scatter below as the A/B baseline
-    if (ctx->direct_sort == 1) return direct_sort_windows(ctx, codes, n, states, perm_out, sorted_out, flag);
+    if (ctx->direct_sort == 1) {
+        if (ranktab_written) *ranktab_written = ranktab != nullptr;
+        return direct_sort_windows(ctx, codes, n, states, perm_out, sorted_out, flag, ranktab, rank_blocks);
+    }
     const unsigned grid = grid_for(n / 4 + 1, 256, 16384);
     // A random 4-byte store per row runs at 62 G stores/s on this chip (1e8 rows: 1.6 ms — as long as three radix passes, but
     // without their histograms, scans and duplicate scan).  ctx option direct_sort = 2 partitions the pairs by the TOP 8 bits of

@@ -240,7 +240,8 @@ __global__ __launch_bounds__(1024) void k_win_offsets(const uint32_t* __restrict
 __global__ __launch_bounds__(kPlaceThreads) void k_win_place(const uint64_t* __restrict__ entries, uint32_t* __restrict__ counts,
                                                             const uint32_t* __restrict__ off, uint64_t n, uint32_t* __restrict__ perm,
                                                             uint32_t* __restrict__ sorted, uint32_t* __restrict__ flag,
-                                                            uint32_t* __restrict__ clear_also, uint32_t nclear) {
+                                                            uint32_t* __restrict__ clear_also, uint32_t nclear, uint2* __restrict__ ranktab,
+                                                            uint32_t rank_blocks) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ uint32_t s_wcount[kPlaceThreads / kWave];
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -286,6 +287,11 @@ __global__ __launch_bounds__(kPlaceThreads) void k_win_place(const uint64_t* __r
     for (uint32_t it = 0; it < kIters; it++) {
         const uint32_t v = win[s0 + it * kWave + lane];
         const uint64_t bal = __ballot(v != kWinEmpty);
+        if (ranktab && lane < 2) {   // the Join's rank table falls out of the window: presence bits + keys before, per 32 codes (probe.hip: k_build_ranktab)
+            const uint32_t blk = ((code0 + it * kWave) >> 5) + lane;
+            if (blk < rank_blocks)
+                ranktab[blk] = make_uint2(lane ? (uint32_t)(bal >> 32) : (uint32_t)bal, (uint32_t)pos + (lane ? (uint32_t)__popc((uint32_t)bal) : 0u));
+        }
         if (v != kWinEmpty) {
             const uint64_t p = pos + (uint64_t)__popcll(bal & lt);
             if (p < n) {   // (always, unless duplicates already raised the flag)
@@ -372,7 +378,7 @@ Status WindowSort::add(cph_ctx* ctx, const uint32_t* codes, uint64_t row0, uint6
     return {};
 }
 
-Status WindowSort::finish(cph_ctx* ctx, uint32_t* perm_out, uint32_t* sorted_out, uint32_t* flag) {
+Status WindowSort::finish(cph_ctx* ctx, uint32_t* perm_out, uint32_t* sorted_out, uint32_t* flag, void* ranktab, uint64_t rank_blocks) {
     const bool need_off = states != n;   // a full code space: window g starts at g << 14 (or the flag goes up)
     DevBuf offsets;                      // (not part of the zero-at-rest block: offsets stay behind)
     if (need_off) CPH_TRY(offsets.alloc(&ctx->pool, nwin_total * sizeof(uint32_t)));
@@ -404,7 +410,8 @@ Status WindowSort::finish(cph_ctx* ctx, uint32_t* perm_out, uint32_t* sorted_out
         CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_win_place), kPlaceThreads, lds, nullptr));
         ProfScope ps(ctx, "k_win_place", 16.0 * (double)n);
         hipLaunchKernelGGL(k_win_place, dim3((unsigned)nwin_total), dim3(kPlaceThreads), lds, ctx->stream, two ? ent2.as<uint64_t>() : ent1.as<uint64_t>(),
-                           counts, need_off ? off : nullptr, n, perm_out, sorted_out, flag, cur1, two ? (uint32_t)nb1 : 0u);
+                           counts, need_off ? off : nullptr, n, perm_out, sorted_out, flag, cur1, two ? (uint32_t)nb1 : 0u,
+                           static_cast<uint2*>(ranktab), (uint32_t)rank_blocks);
     }
     CPH_HIP_TRY(hipGetLastError());
     finished = true;
@@ -412,22 +419,22 @@ Status WindowSort::finish(cph_ctx* ctx, uint32_t* perm_out, uint32_t* sorted_out
 }
 
 Status direct_sort_windows(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out, uint32_t* sorted_out,
-                           uint32_t* flag) {
+                           uint32_t* flag, void* ranktab, uint64_t rank_blocks) {
     if (n == 0) return {};
     WindowSort ws;
     CPH_TRY(ws.begin(ctx, n, states));
     CPH_TRY(ws.add(ctx, codes, 0, n, flag));
-    return ws.finish(ctx, perm_out, sorted_out, flag);
+    return ws.finish(ctx, perm_out, sorted_out, flag, ranktab, rank_blocks);
 }
 // the same straight from the key column: keys[n] (fixed width 8, 16-byte aligned), coded by `ap` inside the first partition level;
 // *flag is also raised by a key `ap` cannot code (alphabets from a sample)
 Status direct_sort_windows_keys(cph_ctx* ctx, const uint64_t* keys, const ArithPlan& ap, uint64_t n, uint64_t states, uint32_t* perm_out,
-                                uint32_t* sorted_out, uint32_t* flag) {
+                                uint32_t* sorted_out, uint32_t* flag, void* ranktab, uint64_t rank_blocks) {
     if (n == 0) return {};
     WindowSort ws;
     CPH_TRY(ws.begin(ctx, n, states));
     CPH_TRY(ws.add(ctx, nullptr, 0, n, flag, keys, &ap));
-    return ws.finish(ctx, perm_out, sorted_out, flag);
+    return ws.finish(ctx, perm_out, sorted_out, flag, ranktab, rank_blocks);
 }
 
 }  // namespace cph

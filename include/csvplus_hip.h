@@ -147,6 +147,9 @@ CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
  *   "direct_fused_encode" 0 / 1 (default 1): the direct sort of ONE fixed-width 8-byte key column under an arithmetic codec (decimal ids; the
  *                   column 16-byte aligned) codes the keys inside its first partition level — no encode kernel, no 4-byte code per row written
  *                   and read again (1e8 ids: 1.30 -> 1.12 ms; A/B switch)
+ *   "direct_ranktab" 0 / 1 (default 1): the window sort of a code space larger than its table writes the Join's rank table (presence bits +
+ *                   keys before, 8 bytes per 32 codes) while it streams its windows out: a Join that reports positions finds it ready
+ *                   (0: built by the first such Join, k_build_ranktab; A/B switch)
  *   "chain_prejoin" 0 / 1 (default 1): chain steps whose key is a column of an earlier step's build table (cph_chain_step.source != 0)
  *                   are answered from PRE-JOINED tables when the stream is at least twice as long as those tables: the build sides are
  *                   joined with each other first (one pass over the table's column), the stream rows then need one 4-byte gather per

