@@ -35,7 +35,9 @@ def table():
         ids = rng.permutation(space)[:n]
         if kind == 2:
             ids[int(rng.integers(1, n))] = ids[int(rng.integers(0, n))] if rng.random() < 0.7 else ids[0]
-        return fixed_ids(ids, len(str(space - 1))), True, "dense%d" % kind
+        # (round 5: every third table zero-padded to 8 bytes — the window sort then codes the keys inside its first partition level)
+        w8 = rng.random() < 0.35
+        return fixed_ids(ids, 8 if w8 else len(str(space - 1))), True, "dense%d%s" % (kind, "w8" if w8 else "")
     if kind == 3:      # the sampled-alphabet path: >= 2^20 rows, sometimes a byte only an unsampled row holds
         n = (1 << 20) + int(rng.integers(0, 50_000))
         ids = rng.integers(0, 5_000_000, n)
