@@ -118,7 +118,63 @@ func (s *staging) stage(ctx *C.cph_ctx, rows []Row, columns []string) ([]C.cph_s
 }
 
 // gpuIndex keeps the device twin of index.impl.rows' key columns alive (a field `gpu *gpuIndex` of Index).
-type gpuIndex struct{ h *C.cph_index }
+// side: columns of impl.rows staged once, in SORTED order (row i = impl.rows[i]), for chains whose later key is a column of
+// THIS index's rows (cph_chain_step.source < 0: join.go columnOrigin / fusedBatch); a nil entry = some row lacks the column.
+type gpuIndex struct {
+	h    *C.cph_index
+	side map[string]*sideColumn
+}
+
+// sideColumn is one column of an index's rows as pinned SoA (its blocks live as long as the index: they are freed by the
+// index's finalizer, not reused between batches like the stagePool).
+type sideColumn struct {
+	data, offs pinnedBuf
+	col        C.cph_strcol
+}
+
+// sideColumn stages column `name` of index.impl.rows (sorted order) on first use.  Call with gpuMu held.
+func (index *Index) sideColumn(ctx *C.cph_ctx, name string) (*C.cph_strcol, error) {
+	g := index.gpu
+	if g.side == nil {
+		g.side = map[string]*sideColumn{}
+	}
+	if sc, seen := g.side[name]; seen {
+		if sc == nil {
+			return nil, nil
+		}
+		return &sc.col, nil
+	}
+	rows := index.impl.rows
+	total := 0
+	for _, r := range rows {
+		v, ok := r[name]
+		if !ok {
+			g.side[name] = nil // (mergeRows would then take the column from further down the chain, or miss it)
+			return nil, nil
+		}
+		total += len(v)
+	}
+	sc := &sideColumn{}
+	data, err := sc.data.need(ctx, total+8)
+	if err != nil {
+		return nil, err
+	}
+	offs, err := sc.offs.need(ctx, 8*(len(rows)+1))
+	if err != nil {
+		return nil, err
+	}
+	d := unsafe.Slice((*byte)(data), total+8)
+	o := unsafe.Slice((*uint64)(offs), len(rows)+1)
+	pos := 0
+	for i, r := range rows {
+		o[i] = uint64(pos)
+		pos += copy(d[pos:], r[name])
+	}
+	o[len(rows)] = uint64(pos)
+	sc.col = C.cph_strcol{data: (*C.uint8_t)(data), offsets: offs, nrows: C.uint64_t(len(rows)), offset_bits: 64, mem: C.CPH_MEM_HOST}
+	g.side[name] = sc
+	return &sc.col, nil
+}
 
 // sortOnGPU replaces `sort.Sort(&index.impl)` (csvplus.go:736) and, for unique indices, the adjacent-equal scan of
 // createUniqueIndex (:749-753).  impl.rows come back sorted (stable: rows with equal keys keep their input order, one of
@@ -165,10 +221,16 @@ func sortOnGPU(impl *indexImpl, unique bool) (*gpuIndex, int, error) {
 		C.cph_index_destroy(h) // the reference returns a nil index (:751); the caller formats the error from rows[dup]
 		return nil, int(dup), nil
 	}
-	g := &gpuIndex{h}
+	g := &gpuIndex{h: h}
 	runtime.SetFinalizer(g, func(g *gpuIndex) {
 		gpuMu.Lock()
 		C.cph_index_destroy(g.h)
+		for _, sc := range g.side {
+			if sc != nil {
+				C.cph_pinned_free(gpuCtx, sc.data.p)
+				C.cph_pinned_free(gpuCtx, sc.offs.p)
+			}
+		}
 		gpuMu.Unlock()
 	})
 	return g, -1, nil

@@ -3,7 +3,7 @@
 // per batch (cph_join_chain_ex reporting sorted positions — the entry point bench.py times).
 //
 // NOT COMPILED IN THIS REPOSITORY (no Go toolchain in the build image); compiled and tested twin:
-// csvplus_amd/host/csvplus.hpp (probeSource / chainSource), tests/cpp/test_host.cpp (TestBatchingSemantics,
+// csvplus_amd/host/csvplus.hpp (probeSource / chainSource / columnOrigin), tests/cpp/test_host.cpp (TestBatchingSemantics,
 // TestChainPrecedence).  See gpu.go for the build line.
 package csvplus
 
@@ -13,6 +13,7 @@ package csvplus
 import "C"
 
 import (
+	"errors"
 	"io"
 	"unsafe"
 )
@@ -191,20 +192,66 @@ func chainSource(spec *chainSpec) DataSource {
 			if len(spec.steps) == 1 {
 				return probeBatch(spec.steps[0].index, spec.steps[0].columns, false, batch, fn)
 			}
-			for _, st := range spec.steps[1:] {
-				for _, r := range batch {
-					if !r.HasColumn(st.columns...) { // a later key comes from a BUILD-side column (or is missing)
-						return runSteps(spec, 0, batch, fn)
+			// origin[k]: 0 = step k's key columns come from the stream rows, t+1 = from the rows of steps[t].index (round 5:
+			// cph_chain_step.source — people.Join(orders, "id").Join(products), csvplus_test.go:280-285, stays ONE device call)
+			origin := make([]int, len(spec.steps))
+			for k := 1; k < len(spec.steps); k++ {
+				org := -2
+				for _, col := range spec.steps[k].columns {
+					o := columnOrigin(spec, k, col, batch)
+					if o < 0 || (org != -2 && o != org) {
+						return runSteps(spec, 0, batch, fn) // the rows disagree, or the column is missing: step by step
 					}
+					org = o
 				}
+				origin[k] = org
 			}
-			return fusedBatch(spec, batch, fn)
+			return fusedBatch(spec, origin, batch, fn)
 		})
 	}
 }
 
-// fusedBatch: all steps' key columns staged from the stream rows, one cph_join_chain_ex call, positions out.
-func fusedBatch(spec *chainSpec, batch []Row, fn RowFunc) error {
+// columnOrigin says where the value of `col` in the row that step k's Join sees comes from, for a whole batch: 0 = every
+// stream row carries it (mergeRows, :571-583, lets the stream's value win), t+1 = no stream row does and every row of
+// steps[t].index does (the earliest such t < k: the nested merges let the earlier, right-hand row win), -1 = the rows
+// disagree or the column is missing (runSteps then reports what the reference reports).
+func columnOrigin(spec *chainSpec, k int, col string, batch []Row) int {
+	have := 0
+	for _, r := range batch {
+		if _, ok := r[col]; ok {
+			have++
+		}
+	}
+	if have == len(batch) {
+		return 0
+	}
+	if have != 0 {
+		return -1
+	}
+	for t := 0; t < k; t++ {
+		all := len(spec.steps[t].index.impl.rows) > 0
+		for _, r := range spec.steps[t].index.impl.rows {
+			if _, ok := r[col]; !ok {
+				all = false
+				break
+			}
+		}
+		if all {
+			return t + 1
+		}
+		for _, r := range spec.steps[t].index.impl.rows { // SOME rows of an earlier index carry it: no single origin
+			if _, ok := r[col]; ok {
+				return -1
+			}
+		}
+	}
+	return -1
+}
+
+// fusedBatch: one cph_join_chain_ex call, positions out.  origin[k] == 0: step k's key columns are staged from the stream rows;
+// t+1: they are columns of steps[t].index's rows, staged once per index in sorted order (cph_chain_step.source = -(t+1)) — the
+// device reads the key from the row that step matched (or answers it from build tables joined with each other first).
+func fusedBatch(spec *chainSpec, origin []int, batch []Row, fn RowFunc) error {
 	ctx, err := gpu()
 	if err != nil {
 		return err
@@ -214,13 +261,31 @@ func fusedBatch(spec *chainSpec, batch []Row, fn RowFunc) error {
 	steps := make([]C.cph_chain_step, len(spec.steps))
 	keep := make([][]C.cph_strcol, len(spec.steps)) // the descriptors must outlive the call
 	for k, st := range spec.steps {
-		cols, err := stagePool.stage(ctx, batch, st.columns)
-		if err != nil {
-			gpuMu.Unlock()
-			return err
+		if origin[k] == 0 {
+			cols, err := stagePool.stage(ctx, batch, st.columns)
+			if err != nil {
+				gpuMu.Unlock()
+				return err
+			}
+			keep[k] = cols
+			steps[k] = C.cph_chain_step{index: st.index.gpu.h, cols: &cols[0], ncols: C.int32_t(len(cols))}
+			continue
+		}
+		from := spec.steps[origin[k]-1].index
+		cols := make([]C.cph_strcol, len(st.columns))
+		for c, name := range st.columns {
+			sc, err := from.sideColumn(ctx, name)
+			if err != nil || sc == nil { // (columnOrigin saw the column in every row: only an allocation can fail here)
+				gpuMu.Unlock()
+				if err == nil {
+					err = errors.New("csvplus: build-side key column vanished")
+				}
+				return err
+			}
+			cols[c] = *sc
 		}
 		keep[k] = cols
-		steps[k] = C.cph_chain_step{index: st.index.gpu.h, cols: &cols[0], ncols: C.int32_t(len(cols))}
+		steps[k] = C.cph_chain_step{index: st.index.gpu.h, cols: &cols[0], ncols: C.int32_t(len(cols)), source: C.int32_t(-origin[k])}
 	}
 	var ch *C.cph_chain
 	rc := C.cph_join_chain_ex(ctx, &steps[0], C.int32_t(len(steps)), 0, C.CPH_MEM_HOST, C.CPH_CHAIN_POSITIONS, &ch)
