@@ -538,16 +538,18 @@ static void TestChainPrecedence() {
         CHECK(!e5 && n3 == 3 * got.size());
         // (5b) six Joins in a row: one device call per batch (CPH_MAX_CHAIN = 8 since round 5; the general chain runs on the device),
         //      same rows as three nested pairs on the host
+        //      (the whole stream in one batch; the first 70 rows in batches of 7 and of 1: a general-chain call is ~20 launches)
         {
-            std::vector<Row> w2 = nestedJoinOnHost(stream, *ic, {"cust_id"}, *ip, {"prod_id"}, &he);
+            const std::vector<Row> part(stream.begin(), stream.begin() + (batch == 8192 ? (long)stream.size() : 70));
+            std::vector<Row> w2 = nestedJoinOnHost(part, *ic, {"cust_id"}, *ip, {"prod_id"}, &he);
             std::vector<Row> w4 = nestedJoinOnHost(w2, *id, {"cust_id"}, *ip, {"fav_prod"}, &he);
             std::vector<Row> w6 = nestedJoinOnHost(w4, *ic, {"id"}, *ip, {"prod_id"}, &he);
             CHECK(!he && !w6.empty());
             const uint64_t f6 = DataSource::fused_calls();
-            auto [got6, ge6] = TakeRows(stream).Join(ic, {"cust_id"}).Join(ip, {"prod_id"}).Join(id, {"cust_id"}).Join(ip, {"fav_prod"})
+            auto [got6, ge6] = TakeRows(part).Join(ic, {"cust_id"}).Join(ip, {"prod_id"}).Join(id, {"cust_id"}).Join(ip, {"fav_prod"})
                                    .Join(ic, {"id"}).Join(ip, {"prod_id"}).ToRows();
             CHECK(!ge6 && same(got6, w6));
-            CHECK(DataSource::fused_calls() == f6 + (stream.size() + batch - 1) / batch);
+            CHECK(DataSource::fused_calls() == f6 + (part.size() + batch - 1) / batch);
         }
         // (6) early stop through both Joins: io.EOF ends the pipeline cleanly after exactly 5 rows; an error is reported
         int k = 0;
