@@ -287,6 +287,12 @@ Status pinned_cache_get(cph_ctx* ctx, size_t bytes, void** out, size_t* cap) {
     return {};
 }
 
+// result blocks of per-batch calls: sizes rounded up to a power of two (>= 64 KB) so that consecutive batches find each other's block
+static size_t result_block_bytes(size_t need) {
+    size_t b = 64 * 1024;
+    while (b < need) b <<= 1;
+    return b;
+}
 void pinned_cache_put(cph_ctx* ctx, void* p, size_t cap) {
     if (!p) return;
     ctx->pinned_cache.push_back({p, cap});
@@ -983,6 +989,7 @@ CPH_API void cph_ctx_destroy(cph_ctx* ctx) {
     if (ctx->upload_ring) (void)hipHostFree(ctx->upload_ring);
     if (ctx->host_words) (void)hipHostFree(ctx->host_words);
     for (void* p : ctx->pinned_user) (void)hipHostFree(p);
+    for (auto& b : ctx->pinned_user_free) (void)hipHostFree(b.first);
     for (auto& b : ctx->pinned_cache) (void)hipHostFree(b.first);
     for (auto& p : ctx->prof_pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
     for (hipEvent_t e : ctx->prof_free_events) (void)hipEventDestroy(e);
@@ -1138,9 +1145,31 @@ CPH_API int32_t cph_pinned_alloc(cph_ctx* ctx, size_t bytes, void** out) {
     if (!s.ok()) return fail(ctx, s);
     if (!out) return fail(ctx, {CPH_ERR_INVALID, "out is NULL"});
     void* p = nullptr;
-    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
-    if (e != hipSuccess) return fail(ctx, {CPH_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)});
+    constexpr size_t kRecycleMax = 4u << 20;
+    size_t cap = bytes ? bytes : 1;
+    if (cap <= kRecycleMax) {   // recycled blocks come in powers of two from 4 KB on
+        size_t c2 = 4096;
+        while (c2 < cap) c2 <<= 1;
+        cap = c2;
+        for (size_t i = 0; i < ctx->pinned_user_free.size(); i++)
+            if (ctx->pinned_user_free[i].second == cap) {
+                p = ctx->pinned_user_free[i].first;
+                ctx->pinned_user_free.erase(ctx->pinned_user_free.begin() + (long)i);
+                break;
+            }
+    }
+    if (!p) {
+        hipError_t e = hipHostMalloc(&p, cap, hipHostMallocDefault);
+        if (e != hipSuccess) {   // give the kept blocks back and try once more
+            (void)hipGetLastError();
+            for (auto& b : ctx->pinned_user_free) (void)hipHostFree(b.first);
+            ctx->pinned_user_free.clear();
+            e = hipHostMalloc(&p, cap, hipHostMallocDefault);
+        }
+        if (e != hipSuccess) return fail(ctx, {CPH_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)});
+    }
     ctx->pinned_user.push_back(p);
+    if (cap <= kRecycleMax) ctx->pinned_user_cap.push_back({p, cap});
     *out = p;
     return CPH_OK;
 }
@@ -1151,6 +1180,16 @@ CPH_API int32_t cph_pinned_free(cph_ctx* ctx, void* p) {
     auto it = std::find(ctx->pinned_user.begin(), ctx->pinned_user.end(), p);
     if (it == ctx->pinned_user.end()) return fail(ctx, {CPH_ERR_INVALID, "not a cph_pinned_alloc block"});
     ctx->pinned_user.erase(it);
+    for (size_t i = 0; i < ctx->pinned_user_cap.size(); i++)
+        if (ctx->pinned_user_cap[i].first == p) {
+            const size_t cap = ctx->pinned_user_cap[i].second;
+            ctx->pinned_user_cap.erase(ctx->pinned_user_cap.begin() + (long)i);
+            if (ctx->pinned_user_free.size() < 32) {
+                ctx->pinned_user_free.push_back({p, cap});
+                return CPH_OK;
+            }
+            break;
+        }
     (void)hipHostFree(p);
     return CPH_OK;
 }
@@ -1355,7 +1394,7 @@ CPH_API int32_t cph_join_probe(cph_ctx* ctx, const cph_index* ix, const cph_strc
             const size_t b_pi = pairs ? a16(po.nmatches * sizeof(uint64_t)) : 0;
             const size_t b_br = pairs ? a16(po.nmatches * sizeof(uint32_t)) : 0;
             const size_t total = 2 * b_lo + b_pi + b_br + 16;
-            CPH_HIP_TRY(hipHostMalloc(&m->h_block, total, hipHostMallocDefault));
+            CPH_TRY(pinned_cache_get(ctx, result_block_bytes(total), &m->h_block, &m->h_cap));
             uint8_t* h = static_cast<uint8_t*>(m->h_block);
             uint8_t* h_pidx = h;                       // u64 first: keeps 8-byte alignment
             uint8_t* h_lo = h + b_pi;
@@ -1379,7 +1418,8 @@ CPH_API int32_t cph_join_probe(cph_ctx* ctx, const cph_index* ix, const cph_strc
     };
     s = run();
     if (!s.ok()) {
-        if (m->h_block) (void)hipHostFree(m->h_block);
+        (void)hipStreamSynchronize(ctx->stream);   // (copies into the block may still be queued)
+        if (m->h_block) pinned_cache_put(ctx, m->h_block, m->h_cap);
         delete m;
         return fail(ctx, s);
     }
@@ -1391,7 +1431,10 @@ CPH_API void cph_matches_release(cph_matches* pub) {
     if (!pub) return;
     cph_matches_impl* m = reinterpret_cast<cph_matches_impl*>(pub);
     if (m->ctx) (void)hipSetDevice(m->ctx->device);
-    if (m->h_block) (void)hipHostFree(m->h_block);
+    if (m->h_block) {
+        if (m->ctx) pinned_cache_put(m->ctx, m->h_block, m->h_cap);
+        else (void)hipHostFree(m->h_block);
+    }
     delete m;
 }
 
@@ -1459,7 +1502,7 @@ CPH_API int32_t cph_join_chain_ex(cph_ctx* ctx, const cph_chain_step* steps, int
         } else if (n) {
             auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
             const size_t b64 = a16(n * sizeof(uint64_t)), b32 = a16(n * sizeof(uint32_t));
-            CPH_HIP_TRY(hipHostMalloc(&c->h_block, b64 + (size_t)nsteps * b32, hipHostMallocDefault));
+            CPH_TRY(pinned_cache_get(ctx, result_block_bytes(b64 + (size_t)nsteps * b32), &c->h_block, &c->h_cap));
             uint8_t* h = static_cast<uint8_t*>(c->h_block);
             if (!co.identity) {
                 CPH_HIP_TRY(hipMemcpyAsync(h, co.stream_row.get(), n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -1476,7 +1519,8 @@ CPH_API int32_t cph_join_chain_ex(cph_ctx* ctx, const cph_chain_step* steps, int
     };
     s = run();
     if (!s.ok()) {
-        if (c->h_block) (void)hipHostFree(c->h_block);
+        (void)hipStreamSynchronize(ctx->stream);
+        if (c->h_block) pinned_cache_put(ctx, c->h_block, c->h_cap);
         delete c;
         return fail(ctx, s);
     }
@@ -1488,7 +1532,10 @@ CPH_API void cph_chain_release(cph_chain* pub) {
     if (!pub) return;
     cph_chain_impl* c = reinterpret_cast<cph_chain_impl*>(pub);
     if (c->ctx) (void)hipSetDevice(c->ctx->device);
-    if (c->h_block) (void)hipHostFree(c->h_block);
+    if (c->h_block) {
+        if (c->ctx) pinned_cache_put(c->ctx, c->h_block, c->h_cap);
+        else (void)hipHostFree(c->h_block);
+    }
     delete c;
 }
 

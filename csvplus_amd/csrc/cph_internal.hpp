@@ -307,6 +307,11 @@ struct cph_ctx {
     void* upload_ring = nullptr;
     size_t upload_cap = 0, upload_pos = 0;
     std::vector<void*> pinned_user;
+    // small blocks handed back through cph_pinned_free are kept for the next cph_pinned_alloc (a host side that stages a batch of
+    // 8192 rows per call page-locks four blocks per batch otherwise: 4 x 90 us against 60-80 us for the Join itself): blocks of at
+    // most 4 MB, at most 32 of them; {block, capacity}
+    std::vector<std::pair<void*, size_t>> pinned_user_free;
+    std::vector<std::pair<void*, size_t>> pinned_user_cap;   // capacity of every live cph_pinned_alloc block that came from / may go to the list
     // pinned blocks of released host-side results (cph_index_perm copies), reused by the next one of a fitting size:
     // page-locking 400 MB costs tens of milliseconds, a caller that builds index after index should pay it once
     std::vector<std::pair<void*, size_t>> pinned_cache;
@@ -477,14 +482,16 @@ struct cph_chain_impl {
     cph_ctx* ctx = nullptr;
     cph::DevBuf d_stream;
     cph::DevBuf d_rows[CPH_MAX_CHAIN];
-    void* h_block = nullptr;
+    void* h_block = nullptr;       // pinned, out of the ctx's cache of pinned blocks (pinned_cache_get): a Join per batch of 8192 rows must not page-lock
+    size_t h_cap = 0;
 };
 
 struct cph_matches_impl {
     cph_matches pub;               // must stay first: the public view
     cph_ctx* ctx = nullptr;
     cph::DevBuf d_lo, d_cnt, d_pidx, d_brow;
-    void* h_block = nullptr;       // one pinned block holding the host copies
+    void* h_block = nullptr;       // one pinned block holding the host copies (out of the ctx's cache of pinned blocks)
+    size_t h_cap = 0;
 };
 
 // ---- cross-file entry points (host functions launching kernels) -------------------------------

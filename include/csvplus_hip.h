@@ -211,7 +211,11 @@ CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value
 CPH_API int32_t cph_ctx_synchronize(cph_ctx* ctx);
 
 /* Pinned (page-locked) host staging memory: cgo must not hand Go-heap pointers
- * that C retains, and pinned buffers make H2D/D2H copies asynchronous. */
+ * that C retains, and pinned buffers make H2D/D2H copies asynchronous.
+ * Page-locking costs ~90 us per block — more than a Join of a batch of 8192 rows (60-80 us) — so blocks of at most 4 MB
+ * handed back through cph_pinned_free are kept by the ctx (up to 32) and handed out again; a host side may allocate and
+ * free its staging per batch (round 5; before, only a caller that kept its blocks — the Go shim's stagePool — avoided it).
+ * A block must not be freed while a call that reads or writes it is still in flight (cph_stream_join_submit ... next). */
 CPH_API int32_t cph_pinned_alloc(cph_ctx* ctx, size_t bytes, void** out);
 CPH_API int32_t cph_pinned_free(cph_ctx* ctx, void* p);
 
