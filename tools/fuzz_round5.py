@@ -43,13 +43,13 @@ def ids(prefix, space, n, unique):
 
 
 def chain_case():
-    nsteps = int(rng.integers(2, 4))
+    nsteps = int(rng.integers(2, 5)) if rng.random() < 0.9 else int(rng.integers(5, 7))   # (5-6 Joins: the general chain in one call)
     na = int(rng.integers(50, 30_000))
     m = int(rng.integers(2 * na + 1, 12 * na + 2)) if rng.random() < 0.8 else int(rng.integers(1, 2 * na))   # (short streams: no pre-join)
     uniq = [rng.random() < 0.8 for _ in range(nsteps)]
     sizes = [na] + [int(rng.integers(5, 3000)) for _ in range(nsteps - 1)]
     spaces = [int(s * rng.uniform(1.0, 1.4)) + 1 for s in sizes]
-    pre = [b"a", b"b", b"c"]
+    pre = [b"a", b"b", b"c", b"d", b"e", b"f"]
     tables = [ids(pre[k], spaces[k], sizes[k], uniq[k]) for k in range(nsteps)]
     # every table carries one key column per later table
     fk = [[None] * nsteps for _ in range(nsteps)]
