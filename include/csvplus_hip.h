@@ -134,6 +134,14 @@ CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
  *   "sort_threads"  256 / 512: workgroup size of the radix sort (0 = automatic)
  *   "sort_rbits"    8 / 9: digit width of the radix sort (0 = automatic)
  *   "sort_xcd_tiles" 0 / 1: the scatter kernel gives every XCD a contiguous range of tiles (default 1)
+ *   "sort_digit_stream" 0 / 1 (default 1): a radix scatter over 64-bit keys leaves the next pass's digits behind as a byte stream, so that
+ *                   pass's histogram reads 1 byte per key instead of 8
+ *   "chain_nt_streams" 0 / 1 / 2 (default 0): the chained Join loads the stream's bytes and stores its results non-temporally — never,
+ *                   always, in positions mode only (measured: within 1 %)
+ *   "stream_role_streams" 0 / 1 (default 0): cph_stream_join in fused mode with one HIP stream for all uploads and one for all downloads
+ *                   instead of one stream per slot (slower at 2 and 4 slots)
+ *   "stream_zero_copy_out" 0 / 1 (default 0): cph_stream_join in fused mode lets the kernel store its results straight into the slot's
+ *                   pinned host block
  *   "speculative_groups"  dictionary windows of long keys on large inputs: 0 = always the exact pass over all rows,
  *                   1 = dictionaries straight from the row sample when every value of every chosen window is COMMON in it
  *                   (met 16 times or more: a closed vocabulary; default),

@@ -82,3 +82,18 @@ def test_product_does_not_import_oracle():
     for p in (ROOT / "csvplus_amd").rglob("*"):
         if p.suffix in (".py", ".hip", ".hpp", ".cpp", ".c", ".h") and p.is_file():
             assert "oracle" not in p.read_text(errors="ignore").lower().replace("no oracle", ""), p
+
+
+def test_every_ctx_option_is_documented_in_the_header():
+    """cph_ctx_set_option's switch (csrc/capi.hip) and the comment block above its declaration (include/csvplus_hip.h) name the
+    same options: an A/B switch nobody can find is not a switch."""
+    import re
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    src = (root / "csvplus_amd" / "csrc" / "capi.hip").read_text()
+    hdr = (root / "include" / "csvplus_hip.h").read_text()
+    opts = re.findall(r'k == "([a-z_0-9]+)"', src)
+    assert len(opts) >= 30
+    undocumented = [o for o in opts if f'"{o}"' not in hdr]
+    assert not undocumented, undocumented
