@@ -753,661 +753,674 @@ def main():
         "host": {"nproc": os.cpu_count(), "gpu": torch.cuda.get_device_name(dev), "datagen_s": round(gen_s, 1)},
     }
 
-    # ---- full-size verification of what was just timed (outside the timed region) ----------------
-    gpu_prefix = None
-    if world == 1 and not args.no_verify:
-        from csvplus_amd import verify as V
+    # Everything from here to the print is measured and reported BESIDE the contract fields above.  A failure in one of these
+    # blocks (a verification helper, an extra measurement, the CPU baseline) must not cost the run its line: the line is printed with
+    # what was gathered, `extras_error` says what broke, and `verified` is false unless the checks had already passed.
+    try:
+        if os.environ.get("CPH_BENCH_FAIL_EXTRAS") == "1":   # test hook (tests/test_bench_launch.py)
+            raise RuntimeError("CPH_BENCH_FAIL_EXTRAS")
+        # ---- full-size verification of what was just timed (outside the timed region) ----------------
+        gpu_prefix = None
+        if world == 1 and not args.no_verify:
+            from csvplus_amd import verify as V
 
-        t0 = time.perf_counter()
-        ia, ib = eng.index_on_many([[d_cust], [d_prod]], unique=True)
-        from csvplus_amd.engine import device_view
-        res = eng.chained_join([(ia, d_ord["cust_id"]), (ib, d_ord["prod_id"])], probe_base=begin, positions=POS)
-        all_joined = res.n == nloc and res.stream_row is None
-        ver = {"joined_rows": res.n, "every_stream_row_joined_once": all_joined, "output_mode": "sorted positions" if POS else "original row ids"}
-        # what was timed reports sorted positions: the row a position names is perm[position] (cph_index_perm) — the checks
-        # below (key equality at the emitted row, digests, the oracle prefix) run on those rows
-        brows = list(res.build_rows)
-        if POS and res.n:
-            for k, ix in enumerate((ia, ib)):
-                pk = device_view(ix.perm_device_ptr(), ix.nrows, "<i4", ix, dev)
-                ver[f"digest_positions_{k}"] = f"{V.digest_u64(res.build_rows[k]):016x}"
-                brows[k] = pk[res.build_rows[k].long()]
-        if all_joined:
-            rows = V.sample_rows(nloc, args.verify_sample)
-            idx = torch.from_numpy(rows).to(dev)
-            b0 = brows[0][idx].cpu().numpy()
-            b1 = brows[1][idx].cpu().numpy()
-            ver["sample_rows"] = int(rows.size)
-            # csvplus.go:553-567: the emitted build row is the one whose key equals the stream row's key
-            ver["cust_key_mismatches"] = V.check_join_sample(ords["cust_id"], cust_id, b0, rows)
-            ver["prod_key_mismatches"] = V.check_join_sample(ords["prod_id"], prod_id, b1, rows)
-            ver["digest_cust_rows"] = f"{V.digest_u64(brows[0]):016x}"
-            ver["digest_prod_rows"] = f"{V.digest_u64(brows[1]):016x}"
-            ns = min(args.cpu_sample_rows, nloc)
-            gpu_prefix = (brows[0][:ns].cpu().numpy().view(np.uint32).copy(),
-                          brows[1][:ns].cpu().numpy().view(np.uint32).copy())
-        # the two indexes of the step: perm is a permutation, keys ascend through it, ties keep input order
-        for name, ix, col in (("customers", ia, d_cust), ("products", ib, d_prod)):
-            perm = device_view(ix.perm_device_ptr(), ix.nrows, "<i4", ix, dev)
-            ver[f"index_{name}"] = V.check_index_order(col, perm)
-        ok = all_joined and ver.get("cust_key_mismatches") == 0 and ver.get("prod_key_mismatches") == 0 \
-            and all(ver[f"index_{n_}"].get("ok") for n_ in ("customers", "products"))
-        res.release(); ia.close(); ib.close()
-        ver["seconds"] = round(time.perf_counter() - t0, 2)
-        out["verified"] = bool(ok)
-        out["verify"] = ver
-
-    # ---- the same step in the OTHER output mode ------------------------------------------------------------------
-    # The reference's Join reads index.impl.rows[first() + i]: rows of an Index are kept in sorted order (csvplus.go:736,
-    # :553-567), so the position in the sorted index IS its row handle — it is what the cgo shim and the
-    # C++ facade consume; the original row id is one more indirection (perm[position]) that this ABI ALSO offers
-    # (cph_join_chain).  Positions let a duplicate-free index over a dense code space answer from presence bits + a running
-    # count per 32 codes (2.5 MB for the 1e7 customers: L2 resident) instead of the 40 MB row table (one Infinity-Fabric
-    # sector per probe row).  The timed step reports positions (row ids with --row-ids); the other mode is measured here the
-    # same way (same builds, same inputs, K steps between synchronisations) and reported beside `value`.  The two results are
-    # compared at full size: perm[position] == row id for all rows of both steps.
-    if world == 1 and not args.no_positions:
-        OTHER = not POS                   # the other mode reports positions?
-        other_name = "join_positions" if OTHER else "join_row_ids"
-
-        def step_other():
+            t0 = time.perf_counter()
             ia, ib = eng.index_on_many([[d_cust], [d_prod]], unique=True)
-            ch = N.join_chain(eng.ctx, [(ia, [d_ord["cust_id"]]), (ib, [d_ord["prod_id"]])], probe_base=begin,
-                              out_mem=N.CPH_MEM_DEVICE, positions=OTHER)
-            n = ch.nrows
-            ch.release(); ia.close(); ib.close()
-            return n
-
-        for _ in range(max(1, args.warmup)):
-            step_other()
-        eng.ctx.profile_only("k_chain_dense")
-        eng.ctx.profile_read(reset=True)
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            jp = step_other()
-        torch.cuda.synchronize(dev)
-        dtp = time.perf_counter() - t0
-        pp = eng.ctx.profile_read(reset=True)
-        eng.ctx.profile(True)
-        step_other()
-        pb = eng.ctx.profile_read(reset=True)
-        eng.ctx.profile(False)
-        ms_o = dtp / args.steps * 1e3
-        kd = pp.get("k_chain_dense", {"launches": 0, "total_ms": 0.0})
-        kd_ms = kd["total_ms"] / max(1, kd["launches"])
-        # the OTHER mode's own byte model (chain_bytes above): row ids pay one 4-byte entry per row and step, positions the
-        # rank tables once
-        algo_o, hbm_o = chain_bytes(OTHER)
-        blk = {"mode": "sorted positions" if OTHER else "original row ids",
-               "ms_per_step": round(ms_o, 4), "value": jp / (dtp / args.steps), "unit": "rows/s", "joined_rows_per_step": jp,
-               "timed_step_over_this": round(ms_per_step / ms_o, 3),
-               "k_chain_dense_ms": round(kd_ms, 4),
-               "kernels_ms": {k: round(v["total_ms"], 4) for k, v in pb.items()},
-               "what": "the same step (2 index builds + chained Join of the same rows) in the other output mode; reported beside "
-                       "`value`, not as it"}
-        if algo_o and kd_ms:
-            blk["roofline"] = {"kernel": "k_chain_dense (%s)" % ("positions" if OTHER else "row ids"),
-                               "algorithmic_bytes_per_launch": int(algo_o), "bytes_model": "chain_bytes(%s)" % ("positions" if OTHER else "row ids"),
-                               "achieved": round(algo_o / 1e9 / (kd_ms / 1e3), 1), "unit": "GB/s", "peak": HBM_PEAK_GBPS,
-                               "frac": round(algo_o / 1e9 / (kd_ms / 1e3) / HBM_PEAK_GBPS, 4),
-                               "frac_hbm": round(hbm_o / 1e9 / (kd_ms / 1e3) / HBM_PEAK_GBPS, 4)}
-            if roofline.get("step_algorithmic_bytes"):
-                blk["roofline"]["step_frac"] = round(roofline["step_algorithmic_bytes"] / 1e9 / (ms_o / 1e3) / HBM_PEAK_GBPS, 4)
-            if not OTHER and (roofline.get("gather_ceiling") or {}).get("ms"):   # the row-id kernel against this box's gather floor
-                blk["roofline"]["kernel_over_gather_ceiling"] = round(kd_ms / roofline["gather_ceiling"]["ms"], 3)
-        if not args.no_verify:
             from csvplus_amd.engine import device_view
-            ia, ib = eng.index_on_many([[d_cust], [d_prod]], unique=True)
-            r_rows = eng.chained_join([(ia, d_ord["cust_id"]), (ib, d_ord["prod_id"])], probe_base=begin)
-            r_pos = eng.chained_join([(ia, d_ord["cust_id"]), (ib, d_ord["prod_id"])], probe_base=begin, positions=True)
-            same = r_rows.n == r_pos.n and (r_rows.stream_row is None) == (r_pos.stream_row is None)
-            bad = []
-            for k, ix in enumerate((ia, ib)):
+            res = eng.chained_join([(ia, d_ord["cust_id"]), (ib, d_ord["prod_id"])], probe_base=begin, positions=POS)
+            all_joined = res.n == nloc and res.stream_row is None
+            ver = {"joined_rows": res.n, "every_stream_row_joined_once": all_joined, "output_mode": "sorted positions" if POS else "original row ids"}
+            # what was timed reports sorted positions: the row a position names is perm[position] (cph_index_perm) — the checks
+            # below (key equality at the emitted row, digests, the oracle prefix) run on those rows
+            brows = list(res.build_rows)
+            if POS and res.n:
+                for k, ix in enumerate((ia, ib)):
+                    pk = device_view(ix.perm_device_ptr(), ix.nrows, "<i4", ix, dev)
+                    ver[f"digest_positions_{k}"] = f"{V.digest_u64(res.build_rows[k]):016x}"
+                    brows[k] = pk[res.build_rows[k].long()]
+            if all_joined:
+                rows = V.sample_rows(nloc, args.verify_sample)
+                idx = torch.from_numpy(rows).to(dev)
+                b0 = brows[0][idx].cpu().numpy()
+                b1 = brows[1][idx].cpu().numpy()
+                ver["sample_rows"] = int(rows.size)
+                # csvplus.go:553-567: the emitted build row is the one whose key equals the stream row's key
+                ver["cust_key_mismatches"] = V.check_join_sample(ords["cust_id"], cust_id, b0, rows)
+                ver["prod_key_mismatches"] = V.check_join_sample(ords["prod_id"], prod_id, b1, rows)
+                ver["digest_cust_rows"] = f"{V.digest_u64(brows[0]):016x}"
+                ver["digest_prod_rows"] = f"{V.digest_u64(brows[1]):016x}"
+                ns = min(args.cpu_sample_rows, nloc)
+                gpu_prefix = (brows[0][:ns].cpu().numpy().view(np.uint32).copy(),
+                              brows[1][:ns].cpu().numpy().view(np.uint32).copy())
+            # the two indexes of the step: perm is a permutation, keys ascend through it, ties keep input order
+            for name, ix, col in (("customers", ia, d_cust), ("products", ib, d_prod)):
                 perm = device_view(ix.perm_device_ptr(), ix.nrows, "<i4", ix, dev)
-                bad.append(int((perm[r_pos.build_rows[k].long()] != r_rows.build_rows[k]).sum().item()) if same else -1)
-            blk["verify"] = {"rows": r_pos.n, "perm_of_position_differs_from_row_id": bad, "ok": bool(same and not any(bad))}
-            out["verified"] = bool(out.get("verified")) and blk["verify"]["ok"]
-            r_rows.release(); r_pos.release(); ia.close(); ib.close()
-        out[other_name] = blk
-        if roofline is not None:   # a compact copy where the driver's record keeps it (the roofline object)
-            roofline["other_output_mode"] = {
-                "mode": blk["mode"], "k_chain_dense_ms": blk["k_chain_dense_ms"], "frac": (blk.get("roofline") or {}).get("frac"),
-                "ms_per_step": blk["ms_per_step"], "value": blk["value"],
-                "positions_equal_row_ids_through_perm": (blk.get("verify") or {}).get("ok"),
-                "note": "the same step in the other output mode of the ABI (details under %s); fractions on THIS object's byte "
-                        "model.  Rounds 1-2 timed the row-id mode (cph_join_chain); since round 3 the timed step reports sorted "
-                        "positions (cph_join_chain_ex, CPH_CHAIN_POSITIONS): the reference's own row handle" % other_name}
+                ver[f"index_{name}"] = V.check_index_order(col, perm)
+            ok = all_joined and ver.get("cust_key_mismatches") == 0 and ver.get("prod_key_mismatches") == 0 \
+                and all(ver[f"index_{n_}"].get("ok") for n_ in ("customers", "products"))
+            res.release(); ia.close(); ib.close()
+            ver["seconds"] = round(time.perf_counter() - t0, 2)
+            out["verified"] = bool(ok)
+            out["verify"] = ver
 
-    # ---- the same step on other data (reported beside `value`, each timed and verified like it) --------------------
-    # The timed step's customers are zero-padded 8-byte ids that fill their id space: the kernel's best case (aligned 8-byte
-    # loads, arithmetic codes, position == code).  `variants` runs the SAME step — both builds + the chained Join of all
-    # rows, sorted positions out — where that does not hold:
-    #   itoa     customers' ids / orders' cust_id as unpadded decimal strings (the reference's own fixture format,
-    #            csvplus_test.go:1241, 1321-1324): variable-length values behind 32-bit offsets, a LUT walk, a rank table
-    #   half     8-byte ids over a HALF-occupied id space (1e7 ids drawn from [0, 2e7)): no identity, every key goes through the
-    #            rank table of a code space twice the index
-    #   sparse   12 random [a-z0-9] characters: a 62-bit code space, the radix sort and the hash probe
-    #   permute  the timed step + cph_index_permute of customers(name, surname) and products(product, price): what a consumer of
-    #            positions pays per build to have its payload rows in index order (csvplus.go:736 moves the rows themselves)
-    if world == 1 and not args.no_variants:
-        from csvplus_amd import verify as V
-        from csvplus_amd.engine import device_view
+        # ---- the same step in the OTHER output mode ------------------------------------------------------------------
+        # The reference's Join reads index.impl.rows[first() + i]: rows of an Index are kept in sorted order (csvplus.go:736,
+        # :553-567), so the position in the sorted index IS its row handle — it is what the cgo shim and the
+        # C++ facade consume; the original row id is one more indirection (perm[position]) that this ABI ALSO offers
+        # (cph_join_chain).  Positions let a duplicate-free index over a dense code space answer from presence bits + a running
+        # count per 32 codes (2.5 MB for the 1e7 customers: L2 resident) instead of the 40 MB row table (one Infinity-Fabric
+        # sector per probe row).  The timed step reports positions (row ids with --row-ids); the other mode is measured here the
+        # same way (same builds, same inputs, K steps between synchronisations) and reported beside `value`.  The two results are
+        # compared at full size: perm[position] == row id for all rows of both steps.
+        if world == 1 and not args.no_positions:
+            OTHER = not POS                   # the other mode reports positions?
+            other_name = "join_positions" if OTHER else "join_row_ids"
 
-        want = {"itoa", "half", "sparse", "side", "permute"} if args.variants == "all" else set(args.variants.split(","))
-        variants = {}
-
-        def run_variant(name, what, v_cust, v_ocust, extra_build=None, sample_check=True, side_key=None):
-            """v_cust: the customers' id column (host), v_ocust: the orders' cust_id column (host, all rows).  side_key: a HOST
-            column of the customers table the products step reads its key from (cph_chain_step.source = 1) instead of
-            orders.prod_id."""
-            torch.cuda.empty_cache()
-            dc, do_ = v_cust.to_device(dev), v_ocust.to_device(dev)
-            d_side = side_key.to_device(dev) if side_key is not None else None
-            keep = []
-
-            def chain_of(a, b):
-                return [(a, [do_]), (b, [d_side], 1)] if d_side is not None else [(a, [do_]), (b, [d_ord["prod_id"]])]
-
-            def vstep():
-                a, b = eng.index_on_many([[dc], [d_prod]], unique=True)
-                if extra_build:
-                    keep[:] = extra_build(a, b)
-                c = N.join_chain(eng.ctx, chain_of(a, b), probe_base=begin, out_mem=N.CPH_MEM_DEVICE, positions=True)
-                n_ = c.nrows
-                inf_ = (a.info(), b.info()) if "info" not in vstep.__dict__ else vstep.info
-                vstep.info = inf_
-                c.release()
-                for x in keep:
-                    x.release()
-                keep[:] = []
-                a.close(); b.close()
-                return n_
+            def step_other():
+                ia, ib = eng.index_on_many([[d_cust], [d_prod]], unique=True)
+                ch = N.join_chain(eng.ctx, [(ia, [d_ord["cust_id"]]), (ib, [d_ord["prod_id"]])], probe_base=begin,
+                                  out_mem=N.CPH_MEM_DEVICE, positions=OTHER)
+                n = ch.nrows
+                ch.release(); ia.close(); ib.close()
+                return n
 
             for _ in range(max(1, args.warmup)):
-                vstep()
+                step_other()
             eng.ctx.profile_only("k_chain_dense")
             eng.ctx.profile_read(reset=True)
             torch.cuda.synchronize(dev)
-            t0_ = time.perf_counter()
+            t0 = time.perf_counter()
             for _ in range(args.steps):
-                nj = vstep()
+                jp = step_other()
             torch.cuda.synchronize(dev)
-            dt_ = (time.perf_counter() - t0_) / args.steps
-            pk = eng.ctx.profile_read(reset=True)
+            dtp = time.perf_counter() - t0
+            pp = eng.ctx.profile_read(reset=True)
             eng.ctx.profile(True)
-            vstep()
-            pb_ = eng.ctx.profile_read(reset=True)
+            step_other()
+            pb = eng.ctx.profile_read(reset=True)
             eng.ctx.profile(False)
-            kd_ = pk.get("k_chain_dense", {"launches": 0, "total_ms": 0.0})
-            kd_ms_ = kd_["total_ms"] / kd_["launches"] if kd_["launches"] else None
-            ia_i, ib_i = vstep.info
-            # byte model of the chain pass on THIS data (DESIGN.md §6): both key columns' value bytes + offsets in, two 4-byte
-            # positions out per joined row, each lookup structure charged ONCE at its size (rank table: 8 B per 32 codes of a
-            # code space the index does not fill; hash table: its sectors), as in roofline.bytes_model of the timed step
-            s_in = v_ocust.nbytes_values() + v_ocust.nbytes_offsets() + host_bytes["prod_id"] + ords["prod_id"].nbytes_offsets()
-            if side_key is not None:   # per joined row: perm[position] (4 B), two offsets (8 B) and the key bytes of the customer row it matched
-                s_in = v_ocust.nbytes_values() + v_ocust.nbytes_offsets() + nloc * (4.0 + 8.0 + side_key.nbytes_values() / side_key.nrows)
-            look = 0.0
-            for inf_, rows_ in ((ia_i, args.customers), (ib_i, args.products)):
-                if inf_["hash_bytes"]:
-                    look += inf_["hash_bytes"]
-                elif inf_["table_entries"] and inf_["table_entries"] != rows_:
-                    look += 0.25 * inf_["table_entries"]
-            algo = s_in + look + 8.0 * nj
-            kname = "k_chain_dense"
-            if side_key is not None and "k_chain_prejoined" in pb_:
-                # pre-joined build sides (DESIGN §5.8): the chain is three kernels — the table pass over the customers' side column,
-                # the fused pass over the stream-keyed step, the gather pass — timed together (one fully profiled step); bytes: the
-                # stream's key column in, one 4-byte pre-joined entry per row (contract model, as for row ids), two positions out,
-                # + the table pass (side column in, 4 B out, perm 4 B + 4 B out for the sorted order) per customers row
-                kname = "k_chain_prejoin_table + k_chain_dense + k_chain_prejoined"
-                kd_ms_ = sum(pb_[k]["total_ms"] for k in ("k_chain_prejoin_table", "k_chain_dense", "k_chain_prejoined") if k in pb_)
-                s_in = v_ocust.nbytes_values() + v_ocust.nbytes_offsets() + 4.0 * nloc
-                look = side_key.nbytes_values() + side_key.nbytes_offsets() + 12.0 * side_key.nrows
-                algo = s_in + look + 8.0 * nj
-            blk = {"what": what, "ms_per_step": round(dt_ * 1e3, 4), "value": nj / dt_, "unit": "rows/s", "joined_rows_per_step": nj,
-                   "timed_step_over_this": round(ms_per_step / (dt_ * 1e3), 3),
-                   "k_chain_dense_ms": round(kd_ms_, 4) if kd_ms_ else None,
-                   "kernels_ms": {k: round(v["total_ms"], 4) for k, v in sorted(pb_.items(), key=lambda kv: -kv[1]["total_ms"])},
-                   "customers_index": ia_i,
-                   "roofline": {"kernel": kname if kd_ms_ else None, "algorithmic_bytes_per_launch": round(algo),
-                                "bytes_model": {"streams_in": round(s_in), "lookup_structures_once": round(look), "results_out": 8 * nj},
-                                "achieved": round(algo / 1e9 / (kd_ms_ / 1e3), 1) if kd_ms_ else None, "unit": "GB/s", "peak": HBM_PEAK_GBPS,
-                                "frac": round(algo / 1e9 / (kd_ms_ / 1e3) / HBM_PEAK_GBPS, 4) if kd_ms_ else None}}
+            ms_o = dtp / args.steps * 1e3
+            kd = pp.get("k_chain_dense", {"launches": 0, "total_ms": 0.0})
+            kd_ms = kd["total_ms"] / max(1, kd["launches"])
+            # the OTHER mode's own byte model (chain_bytes above): row ids pay one 4-byte entry per row and step, positions the
+            # rank tables once
+            algo_o, hbm_o = chain_bytes(OTHER)
+            blk = {"mode": "sorted positions" if OTHER else "original row ids",
+                   "ms_per_step": round(ms_o, 4), "value": jp / (dtp / args.steps), "unit": "rows/s", "joined_rows_per_step": jp,
+                   "timed_step_over_this": round(ms_per_step / ms_o, 3),
+                   "k_chain_dense_ms": round(kd_ms, 4),
+                   "kernels_ms": {k: round(v["total_ms"], 4) for k, v in pb.items()},
+                   "what": "the same step (2 index builds + chained Join of the same rows) in the other output mode; reported beside "
+                           "`value`, not as it"}
+            if algo_o and kd_ms:
+                blk["roofline"] = {"kernel": "k_chain_dense (%s)" % ("positions" if OTHER else "row ids"),
+                                   "algorithmic_bytes_per_launch": int(algo_o), "bytes_model": "chain_bytes(%s)" % ("positions" if OTHER else "row ids"),
+                                   "achieved": round(algo_o / 1e9 / (kd_ms / 1e3), 1), "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+                                   "frac": round(algo_o / 1e9 / (kd_ms / 1e3) / HBM_PEAK_GBPS, 4),
+                                   "frac_hbm": round(hbm_o / 1e9 / (kd_ms / 1e3) / HBM_PEAK_GBPS, 4)}
+                if roofline.get("step_algorithmic_bytes"):
+                    blk["roofline"]["step_frac"] = round(roofline["step_algorithmic_bytes"] / 1e9 / (ms_o / 1e3) / HBM_PEAK_GBPS, 4)
+                if not OTHER and (roofline.get("gather_ceiling") or {}).get("ms"):   # the row-id kernel against this box's gather floor
+                    blk["roofline"]["kernel_over_gather_ceiling"] = round(kd_ms / roofline["gather_ceiling"]["ms"], 3)
             if not args.no_verify:
-                a, b = eng.index_on_many([[dc], [d_prod]], unique=True)
-                if d_side is not None:
-                    ch_ = N.join_chain(eng.ctx, chain_of(a, b), probe_base=begin, out_mem=N.CPH_MEM_DEVICE, positions=True)
-                    p_ = ch_.device_ptrs()
-                    from csvplus_amd.engine import ChainResult
-                    res_ = ChainResult(None if ch_.identity else device_view(p_["stream_row"], ch_.nrows, "<i8", ch_, dev),
-                                       [device_view(q_, ch_.nrows, "<i4", ch_, dev) for q_ in p_["build_row"]], ch_.nrows, keep=(ch_,), stream_base=begin)
-                else:
-                    res_ = eng.chained_join([(a, do_), (b, d_ord["prod_id"])], probe_base=begin, positions=True)
-                allj = res_.n == nloc and res_.stream_row is None
-                ver_ = {"joined_rows": res_.n, "every_stream_row_joined_once": allj}
-                ok_ = allj
-                if allj and sample_check:
-                    rows_ = V.sample_rows(nloc, args.verify_sample)
-                    idx_ = torch.from_numpy(rows_).to(dev)
-                    pk_ = device_view(a.perm_device_ptr(), a.nrows, "<i4", a, dev)
-                    b0_ = pk_[res_.build_rows[0][idx_].long()].cpu().numpy()
-                    ver_["sample_rows"] = int(rows_.size)
-                    ver_["cust_key_mismatches"] = V.check_join_sample(v_ocust, v_cust, b0_, rows_)
-                    ver_["digest_positions_0"] = f"{V.digest_u64(res_.build_rows[0]):016x}"
-                    ok_ = ok_ and ver_["cust_key_mismatches"] == 0
-                    if side_key is not None:   # the product a row reports carries the key of the CUSTOMER row it matched
-                        pb2_ = device_view(b.perm_device_ptr(), b.nrows, "<i4", b, dev)
-                        b1_ = pb2_[res_.build_rows[1][idx_].long()].cpu().numpy()
-                        ver_["side_key_mismatches"] = V.check_join_sample(side_key, prod_id, b1_, b0_.astype(np.int64) & 0xFFFFFFFF)
-                        ok_ = ok_ and ver_["side_key_mismatches"] == 0
-                        del pb2_
-                    del pk_, idx_
-                pm_ = device_view(a.perm_device_ptr(), a.nrows, "<i4", a, dev)
-                ver_["index_customers"] = V.check_index_order(dc, pm_)
-                ok_ = ok_ and bool(ver_["index_customers"].get("ok"))
-                del pm_
-                res_.release(); a.close(); b.close()
-                blk["verified"] = bool(ok_)
-                blk["verify"] = ver_
-            del dc, do_
-            torch.cuda.empty_cache()
-            return blk
+                from csvplus_amd.engine import device_view
+                ia, ib = eng.index_on_many([[d_cust], [d_prod]], unique=True)
+                r_rows = eng.chained_join([(ia, d_ord["cust_id"]), (ib, d_ord["prod_id"])], probe_base=begin)
+                r_pos = eng.chained_join([(ia, d_ord["cust_id"]), (ib, d_ord["prod_id"])], probe_base=begin, positions=True)
+                same = r_rows.n == r_pos.n and (r_rows.stream_row is None) == (r_pos.stream_row is None)
+                bad = []
+                for k, ix in enumerate((ia, ib)):
+                    perm = device_view(ix.perm_device_ptr(), ix.nrows, "<i4", ix, dev)
+                    bad.append(int((perm[r_pos.build_rows[k].long()] != r_rows.build_rows[k]).sum().item()) if same else -1)
+                blk["verify"] = {"rows": r_pos.n, "perm_of_position_differs_from_row_id": bad, "ok": bool(same and not any(bad))}
+                out["verified"] = bool(out.get("verified")) and blk["verify"]["ok"]
+                r_rows.release(); r_pos.release(); ia.close(); ib.close()
+            out[other_name] = blk
+            if roofline is not None:   # a compact copy where the driver's record keeps it (the roofline object)
+                roofline["other_output_mode"] = {
+                    "mode": blk["mode"], "k_chain_dense_ms": blk["k_chain_dense_ms"], "frac": (blk.get("roofline") or {}).get("frac"),
+                    "ms_per_step": blk["ms_per_step"], "value": blk["value"],
+                    "positions_equal_row_ids_through_perm": (blk.get("verify") or {}).get("ok"),
+                    "note": "the same step in the other output mode of the ABI (details under %s); fractions on THIS object's byte "
+                            "model.  Rounds 1-2 timed the row-id mode (cph_join_chain); since round 3 the timed step reports sorted "
+                            "positions (cph_join_chain_ex, CPH_CHAIN_POSITIONS): the reference's own row handle" % other_name}
 
-        def guarded(name, fn):
-            try:
-                variants[name] = fn()
-            except Exception as ex:   # noqa: BLE001 — a variant never takes the headline down; the error is the record
-                variants[name] = {"error": f"{type(ex).__name__}: {ex}"}
+        # ---- the same step on other data (reported beside `value`, each timed and verified like it) --------------------
+        # The timed step's customers are zero-padded 8-byte ids that fill their id space: the kernel's best case (aligned 8-byte
+        # loads, arithmetic codes, position == code).  `variants` runs the SAME step — both builds + the chained Join of all
+        # rows, sorted positions out — where that does not hold:
+        #   itoa     customers' ids / orders' cust_id as unpadded decimal strings (the reference's own fixture format,
+        #            csvplus_test.go:1241, 1321-1324): variable-length values behind 32-bit offsets, a LUT walk, a rank table
+        #   half     8-byte ids over a HALF-occupied id space (1e7 ids drawn from [0, 2e7)): no identity, every key goes through the
+        #            rank table of a code space twice the index
+        #   sparse   12 random [a-z0-9] characters: a 62-bit code space, the radix sort and the hash probe
+        #   permute  the timed step + cph_index_permute of customers(name, surname) and products(product, price): what a consumer of
+        #            positions pays per build to have its payload rows in index order (csvplus.go:736 moves the rows themselves)
+        if world == 1 and not args.no_variants:
+            from csvplus_amd import verify as V
+            from csvplus_amd.engine import device_view
 
-        if "itoa" in want:
-            guarded("itoa_ids", lambda: run_variant(
-                "itoa_ids", "customers.id / orders.cust_id as unpadded decimal strings (strconv.Itoa, the reference's fixture format: "
-                "csvplus_test.go:1241, 1321-1324): 1-8 byte values behind 32-bit offsets",
-                dg.column(dg.SEQ_PERM, args.customers, args.customers, encoding=dg.ITOA, seed=dg.SEED + 1),
-                dg.column(dg.UNIFORM, nloc, args.customers, encoding=dg.ITOA, seed=dg.SEED + 3, row0=begin)))
-        if "half" in want:
-            guarded("half_occupied_ids", lambda: run_variant(
-                "half_occupied_ids", "8-byte zero-padded ids drawn from an id space TWICE the table (%d ids out of [0, %d)): no identity "
-                "lookup, every key goes through the rank table" % (args.customers, 2 * args.customers),
-                dg.column(dg.SEQ_PERM, args.customers, 2 * args.customers, encoding=dg.FIXED8, seed=dg.SEED + 11),
-                dg.column(dg.FK_SUBSET, nloc, 2 * args.customers, encoding=dg.FIXED8, base=args.customers, seed=dg.SEED + 11, row0=begin)))
-        if "sparse" in want:
-            guarded("sparse_random_keys", lambda: run_variant(
-                "sparse_random_keys", "customers keyed by 12 random [a-z0-9] characters (62-bit code space): radix-sorted index, hash probe",
-                dg.column(dg.RANDKEY, args.customers, 0, seed=dg.SEED + 12),
-                dg.column(dg.RANDKEY, nloc, 0, base=args.customers, seed=dg.SEED + 12, row0=begin)))
-        if "side" in want:
-            guarded("build_side_key", lambda: run_variant(
-                "build_side_key", "orders.Join(customers, cust_id).Join(products, fav_prod) with fav_prod a column of the CUSTOMERS table "
-                "(cph_chain_step.source = 1; the shape of the reference's people.Join(orders).Join(products), csvplus_test.go:280-285): "
-                "the build sides are joined with each other first (one pass over the customers' fav_prod column), a stream row then takes "
-                "ONE 4-byte gather for that step (chain.hip: run_prejoined; round 5's first version gathered and coded the key per stream "
-                "row: 7.0 ms)", cust_id, ords["cust_id"],
-                side_key=dg.column(dg.UNIFORM, args.customers, args.products, encoding=dg.ITOA, seed=dg.SEED + 21)))
-        if "permute" in want:
-            from csvplus_amd.materialize import permute_col
+            want = {"itoa", "half", "sparse", "side", "permute"} if args.variants == "all" else set(args.variants.split(","))
+            variants = {}
 
-            cust_pay = [dg.column(k_, args.customers, args.customers, seed=dg.SEED + 1).to_device(dev) for k_ in (dg.NAME, dg.SURNAME)]
-            prod_pay = [dg.column(k_, args.products, args.products, seed=dg.SEED + 2).to_device(dev) for k_ in (dg.PRODUCT, dg.PRICE)]
+            def run_variant(name, what, v_cust, v_ocust, extra_build=None, sample_check=True, side_key=None):
+                """v_cust: the customers' id column (host), v_ocust: the orders' cust_id column (host, all rows).  side_key: a HOST
+                column of the customers table the products step reads its key from (cph_chain_step.source = 1) instead of
+                orders.prod_id."""
+                torch.cuda.empty_cache()
+                dc, do_ = v_cust.to_device(dev), v_ocust.to_device(dev)
+                d_side = side_key.to_device(dev) if side_key is not None else None
+                keep = []
 
-            def lay_out(a, b):
-                return [permute_col(eng.ctx, a, c_) for c_ in cust_pay] + [permute_col(eng.ctx, b, c_) for c_ in prod_pay]
+                def chain_of(a, b):
+                    return [(a, [do_]), (b, [d_side], 1)] if d_side is not None else [(a, [do_]), (b, [d_ord["prod_id"]])]
 
-            guarded("step_plus_permute", lambda: run_variant(
-                "step_plus_permute", "the timed step + cph_index_permute of customers(name, surname) and products(product, price) inside "
-                "every step: the payload rows in index order, what a consumer of sorted positions needs per build (csvplus.go:736 moves "
-                "the rows; :553-567 reads index.impl.rows[i])", cust_id, ords["cust_id"], extra_build=lay_out))
-            del cust_pay, prod_pay
-        out["variants"] = variants
-        out["variants_note"] = ("the SAME step as `value` (both index builds + the chained Join of all %d rows, sorted positions out) on other key "
-                                "shapes, each timed over %d steps between synchronisations and verified like `value`; reported beside it" % (args.rows, args.steps))
-        if roofline is not None:   # a compact copy inside the object the driver's record keeps
-            roofline["variants"] = {k: ({"ms_per_step": v.get("ms_per_step"), "k_chain_dense_ms": v.get("k_chain_dense_ms"),
-                                         "frac": (v.get("roofline") or {}).get("frac"), "verified": v.get("verified")}
-                                        if "error" not in v else v) for k, v in variants.items()}
-        if all("error" not in v for v in variants.values()) and not args.no_verify:
-            out["verified"] = bool(out.get("verified")) and all(v.get("verified") for v in variants.values())
+                def vstep():
+                    a, b = eng.index_on_many([[dc], [d_prod]], unique=True)
+                    if extra_build:
+                        keep[:] = extra_build(a, b)
+                    c = N.join_chain(eng.ctx, chain_of(a, b), probe_base=begin, out_mem=N.CPH_MEM_DEVICE, positions=True)
+                    n_ = c.nrows
+                    inf_ = (a.info(), b.info()) if "info" not in vstep.__dict__ else vstep.info
+                    vstep.info = inf_
+                    c.release()
+                    for x in keep:
+                        x.release()
+                    keep[:] = []
+                    a.close(); b.close()
+                    return n_
 
-    # ---- end-to-end C-ABI scope: pinned host SoA in -> pinned host row ids out (PCIe inclusive) ----
-    # cph_stream_join_*: 2^24-row chunks of the same orders table, H2D / kernel / D2H of consecutive chunks
-    # overlapped on the pipeline's HIP streams.  Reported beside `value`, never part of it.
-    if world == 1 and not args.no_e2e:
-        from csvplus_amd.streaming import PinnedCol, StreamJoin
+                for _ in range(max(1, args.warmup)):
+                    vstep()
+                eng.ctx.profile_only("k_chain_dense")
+                eng.ctx.profile_read(reset=True)
+                torch.cuda.synchronize(dev)
+                t0_ = time.perf_counter()
+                for _ in range(args.steps):
+                    nj = vstep()
+                torch.cuda.synchronize(dev)
+                dt_ = (time.perf_counter() - t0_) / args.steps
+                pk = eng.ctx.profile_read(reset=True)
+                eng.ctx.profile(True)
+                vstep()
+                pb_ = eng.ctx.profile_read(reset=True)
+                eng.ctx.profile(False)
+                kd_ = pk.get("k_chain_dense", {"launches": 0, "total_ms": 0.0})
+                kd_ms_ = kd_["total_ms"] / kd_["launches"] if kd_["launches"] else None
+                ia_i, ib_i = vstep.info
+                # byte model of the chain pass on THIS data (DESIGN.md §6): both key columns' value bytes + offsets in, two 4-byte
+                # positions out per joined row, each lookup structure charged ONCE at its size (rank table: 8 B per 32 codes of a
+                # code space the index does not fill; hash table: its sectors), as in roofline.bytes_model of the timed step
+                s_in = v_ocust.nbytes_values() + v_ocust.nbytes_offsets() + host_bytes["prod_id"] + ords["prod_id"].nbytes_offsets()
+                if side_key is not None:   # per joined row: perm[position] (4 B), two offsets (8 B) and the key bytes of the customer row it matched
+                    s_in = v_ocust.nbytes_values() + v_ocust.nbytes_offsets() + nloc * (4.0 + 8.0 + side_key.nbytes_values() / side_key.nrows)
+                look = 0.0
+                for inf_, rows_ in ((ia_i, args.customers), (ib_i, args.products)):
+                    if inf_["hash_bytes"]:
+                        look += inf_["hash_bytes"]
+                    elif inf_["table_entries"] and inf_["table_entries"] != rows_:
+                        look += 0.25 * inf_["table_entries"]
+                algo = s_in + look + 8.0 * nj
+                kname = "k_chain_dense"
+                if side_key is not None and "k_chain_prejoined" in pb_:
+                    # pre-joined build sides (DESIGN §5.8): the chain is three kernels — the table pass over the customers' side column,
+                    # the fused pass over the stream-keyed step, the gather pass — timed together (one fully profiled step); bytes: the
+                    # stream's key column in, one 4-byte pre-joined entry per row (contract model, as for row ids), two positions out,
+                    # + the table pass (side column in, 4 B out, perm 4 B + 4 B out for the sorted order) per customers row
+                    kname = "k_chain_prejoin_table + k_chain_dense + k_chain_prejoined"
+                    kd_ms_ = sum(pb_[k]["total_ms"] for k in ("k_chain_prejoin_table", "k_chain_dense", "k_chain_prejoined") if k in pb_)
+                    s_in = v_ocust.nbytes_values() + v_ocust.nbytes_offsets() + 4.0 * nloc
+                    look = side_key.nbytes_values() + side_key.nbytes_offsets() + 12.0 * side_key.nrows
+                    algo = s_in + look + 8.0 * nj
+                blk = {"what": what, "ms_per_step": round(dt_ * 1e3, 4), "value": nj / dt_, "unit": "rows/s", "joined_rows_per_step": nj,
+                       "timed_step_over_this": round(ms_per_step / (dt_ * 1e3), 3),
+                       "k_chain_dense_ms": round(kd_ms_, 4) if kd_ms_ else None,
+                       "kernels_ms": {k: round(v["total_ms"], 4) for k, v in sorted(pb_.items(), key=lambda kv: -kv[1]["total_ms"])},
+                       "customers_index": ia_i,
+                       "roofline": {"kernel": kname if kd_ms_ else None, "algorithmic_bytes_per_launch": round(algo),
+                                    "bytes_model": {"streams_in": round(s_in), "lookup_structures_once": round(look), "results_out": 8 * nj},
+                                    "achieved": round(algo / 1e9 / (kd_ms_ / 1e3), 1) if kd_ms_ else None, "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+                                    "frac": round(algo / 1e9 / (kd_ms_ / 1e3) / HBM_PEAK_GBPS, 4) if kd_ms_ else None}}
+                if not args.no_verify:
+                    a, b = eng.index_on_many([[dc], [d_prod]], unique=True)
+                    if d_side is not None:
+                        ch_ = N.join_chain(eng.ctx, chain_of(a, b), probe_base=begin, out_mem=N.CPH_MEM_DEVICE, positions=True)
+                        p_ = ch_.device_ptrs()
+                        from csvplus_amd.engine import ChainResult
+                        res_ = ChainResult(None if ch_.identity else device_view(p_["stream_row"], ch_.nrows, "<i8", ch_, dev),
+                                           [device_view(q_, ch_.nrows, "<i4", ch_, dev) for q_ in p_["build_row"]], ch_.nrows, keep=(ch_,), stream_base=begin)
+                    else:
+                        res_ = eng.chained_join([(a, do_), (b, d_ord["prod_id"])], probe_base=begin, positions=True)
+                    allj = res_.n == nloc and res_.stream_row is None
+                    ver_ = {"joined_rows": res_.n, "every_stream_row_joined_once": allj}
+                    ok_ = allj
+                    if allj and sample_check:
+                        rows_ = V.sample_rows(nloc, args.verify_sample)
+                        idx_ = torch.from_numpy(rows_).to(dev)
+                        pk_ = device_view(a.perm_device_ptr(), a.nrows, "<i4", a, dev)
+                        b0_ = pk_[res_.build_rows[0][idx_].long()].cpu().numpy()
+                        ver_["sample_rows"] = int(rows_.size)
+                        ver_["cust_key_mismatches"] = V.check_join_sample(v_ocust, v_cust, b0_, rows_)
+                        ver_["digest_positions_0"] = f"{V.digest_u64(res_.build_rows[0]):016x}"
+                        ok_ = ok_ and ver_["cust_key_mismatches"] == 0
+                        if side_key is not None:   # the product a row reports carries the key of the CUSTOMER row it matched
+                            pb2_ = device_view(b.perm_device_ptr(), b.nrows, "<i4", b, dev)
+                            b1_ = pb2_[res_.build_rows[1][idx_].long()].cpu().numpy()
+                            ver_["side_key_mismatches"] = V.check_join_sample(side_key, prod_id, b1_, b0_.astype(np.int64) & 0xFFFFFFFF)
+                            ok_ = ok_ and ver_["side_key_mismatches"] == 0
+                            del pb2_
+                        del pk_, idx_
+                    pm_ = device_view(a.perm_device_ptr(), a.nrows, "<i4", a, dev)
+                    ver_["index_customers"] = V.check_index_order(dc, pm_)
+                    ok_ = ok_ and bool(ver_["index_customers"].get("ok"))
+                    del pm_
+                    res_.release(); a.close(); b.close()
+                    blk["verified"] = bool(ok_)
+                    blk["verify"] = ver_
+                del dc, do_
+                torch.cuda.empty_cache()
+                return blk
 
-        ia = eng.index_on([d_cust], unique=True)
-        ib = eng.index_on([d_prod], unique=True)
-        pc = [PinnedCol(eng.ctx, ords["cust_id"]), PinnedCol(eng.ctx, ords["prod_id"])]
-        chunk = 1 << 23
-        bounds = [(b, min(b + chunk, nloc)) for b in range(0, nloc, chunk)]
-        chunks = [[c.col.slice(b, e) for c in pc] for b, e in bounds]
-        nslots, inflight = 2, 2   # two slots, both in flight: the best of 1-4 slots on every box measured (profiles/r03_stream_join_pcie.txt)
-        best = None
-        # ONE pipeline for all repetitions: the first pass page-locks the slots' result blocks and sizes their device
-        # buffers (a long-running caller pays that once), the best of the following passes is reported
-        sj = StreamJoin(eng.ctx, [ia, ib], nslots=nslots, positions=POS)
-        for rep in range(4):
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            sub = done = 0
-            joined_e2e = 0
-            while done < len(chunks):
-                while sub < len(chunks) and sj.pending < inflight:
-                    sj.submit(chunks[sub], probe_base=bounds[sub][0])
-                    sub += 1
-                r = sj.next(copy=False)
-                joined_e2e += r["nmatches"]
-                done += 1
-            dt_e2e = time.perf_counter() - t0
-            if rep > 0 and (best is None or dt_e2e < best):
-                best = dt_e2e
-        sj.close()
-        h2d = host_bytes["cust_id"] + host_bytes["prod_id"] + off_o
-        d2h = 8 * nloc + nloc // 8
-        out["e2e_pinned_host"] = {
-            "scope": "pinned host key columns in -> pinned host " + ("sorted positions" if POS else "build-row ids") + " + match bitmap out (cph_stream_join_*), "
-                     "indexes already built; PCIe inclusive; one pipeline reused, first pass (page-locking of the result blocks) not counted",
-            "rows": nloc, "chunk_rows": chunk, "slots": nslots, "in_flight": inflight, "ms": round(best * 1e3, 2),
-            "rows_per_s": nloc / best, "joined": joined_e2e,
-            "h2d_GBps": round(h2d / best / 1e9, 1), "d2h_GBps": round(d2h / best / 1e9, 1)}
-        # The same scope with the key codes formed ON THE HOST (cph_host_encoder_*: a pool of worker threads walks the codec's
-        # table over the pinned strings) and shipped as 4 bytes per row and step (cph_stream_join_submit_codes) instead of
-        # the 17 bytes of key strings: the host encode of chunk k+1 overlaps the transfers and kernels of chunk k.  The
-        # encode time is INSIDE the timed loop; it is also timed alone (host_encode_ms: all chunks, nothing else running).
-        try:
-            from csvplus_amd.streaming import HostEncoder, PinnedArray
+            def guarded(name, fn):
+                try:
+                    variants[name] = fn()
+                except Exception as ex:   # noqa: BLE001 — a variant never takes the headline down; the error is the record
+                    variants[name] = {"error": f"{type(ex).__name__}: {ex}"}
 
-            encs = [HostEncoder(ia), HostEncoder(ib)]
-            code_bufs = [[PinnedArray(eng.ctx, e - b) for _ in range(2)] for b, e in bounds]
-            t0 = time.perf_counter()
-            for ci, ch_cols in enumerate(chunks):
-                for k in range(2):
-                    encs[k].run([ch_cols[k]], code_bufs[ci][k].array)
-            enc_alone = time.perf_counter() - t0
+            if "itoa" in want:
+                guarded("itoa_ids", lambda: run_variant(
+                    "itoa_ids", "customers.id / orders.cust_id as unpadded decimal strings (strconv.Itoa, the reference's fixture format: "
+                    "csvplus_test.go:1241, 1321-1324): 1-8 byte values behind 32-bit offsets",
+                    dg.column(dg.SEQ_PERM, args.customers, args.customers, encoding=dg.ITOA, seed=dg.SEED + 1),
+                    dg.column(dg.UNIFORM, nloc, args.customers, encoding=dg.ITOA, seed=dg.SEED + 3, row0=begin)))
+            if "half" in want:
+                guarded("half_occupied_ids", lambda: run_variant(
+                    "half_occupied_ids", "8-byte zero-padded ids drawn from an id space TWICE the table (%d ids out of [0, %d)): no identity "
+                    "lookup, every key goes through the rank table" % (args.customers, 2 * args.customers),
+                    dg.column(dg.SEQ_PERM, args.customers, 2 * args.customers, encoding=dg.FIXED8, seed=dg.SEED + 11),
+                    dg.column(dg.FK_SUBSET, nloc, 2 * args.customers, encoding=dg.FIXED8, base=args.customers, seed=dg.SEED + 11, row0=begin)))
+            if "sparse" in want:
+                guarded("sparse_random_keys", lambda: run_variant(
+                    "sparse_random_keys", "customers keyed by 12 random [a-z0-9] characters (62-bit code space): radix-sorted index, hash probe",
+                    dg.column(dg.RANDKEY, args.customers, 0, seed=dg.SEED + 12),
+                    dg.column(dg.RANDKEY, nloc, 0, base=args.customers, seed=dg.SEED + 12, row0=begin)))
+            if "side" in want:
+                guarded("build_side_key", lambda: run_variant(
+                    "build_side_key", "orders.Join(customers, cust_id).Join(products, fav_prod) with fav_prod a column of the CUSTOMERS table "
+                    "(cph_chain_step.source = 1; the shape of the reference's people.Join(orders).Join(products), csvplus_test.go:280-285): "
+                    "the build sides are joined with each other first (one pass over the customers' fav_prod column), a stream row then takes "
+                    "ONE 4-byte gather for that step (chain.hip: run_prejoined; round 5's first version gathered and coded the key per stream "
+                    "row: 7.0 ms)", cust_id, ords["cust_id"],
+                    side_key=dg.column(dg.UNIFORM, args.customers, args.products, encoding=dg.ITOA, seed=dg.SEED + 21)))
+            if "permute" in want:
+                from csvplus_amd.materialize import permute_col
+
+                cust_pay = [dg.column(k_, args.customers, args.customers, seed=dg.SEED + 1).to_device(dev) for k_ in (dg.NAME, dg.SURNAME)]
+                prod_pay = [dg.column(k_, args.products, args.products, seed=dg.SEED + 2).to_device(dev) for k_ in (dg.PRODUCT, dg.PRICE)]
+
+                def lay_out(a, b):
+                    return [permute_col(eng.ctx, a, c_) for c_ in cust_pay] + [permute_col(eng.ctx, b, c_) for c_ in prod_pay]
+
+                guarded("step_plus_permute", lambda: run_variant(
+                    "step_plus_permute", "the timed step + cph_index_permute of customers(name, surname) and products(product, price) inside "
+                    "every step: the payload rows in index order, what a consumer of sorted positions needs per build (csvplus.go:736 moves "
+                    "the rows; :553-567 reads index.impl.rows[i])", cust_id, ords["cust_id"], extra_build=lay_out))
+                del cust_pay, prod_pay
+            out["variants"] = variants
+            out["variants_note"] = ("the SAME step as `value` (both index builds + the chained Join of all %d rows, sorted positions out) on other key "
+                                    "shapes, each timed over %d steps between synchronisations and verified like `value`; reported beside it" % (args.rows, args.steps))
+            if roofline is not None:   # a compact copy inside the object the driver's record keeps
+                roofline["variants"] = {k: ({"ms_per_step": v.get("ms_per_step"), "k_chain_dense_ms": v.get("k_chain_dense_ms"),
+                                             "frac": (v.get("roofline") or {}).get("frac"), "verified": v.get("verified")}
+                                            if "error" not in v else v) for k, v in variants.items()}
+            if all("error" not in v for v in variants.values()) and not args.no_verify:
+                out["verified"] = bool(out.get("verified")) and all(v.get("verified") for v in variants.values())
+
+        # ---- end-to-end C-ABI scope: pinned host SoA in -> pinned host row ids out (PCIe inclusive) ----
+        # cph_stream_join_*: 2^24-row chunks of the same orders table, H2D / kernel / D2H of consecutive chunks
+        # overlapped on the pipeline's HIP streams.  Reported beside `value`, never part of it.
+        if world == 1 and not args.no_e2e:
+            from csvplus_amd.streaming import PinnedCol, StreamJoin
+
+            ia = eng.index_on([d_cust], unique=True)
+            ib = eng.index_on([d_prod], unique=True)
+            pc = [PinnedCol(eng.ctx, ords["cust_id"]), PinnedCol(eng.ctx, ords["prod_id"])]
+            chunk = 1 << 23
+            bounds = [(b, min(b + chunk, nloc)) for b in range(0, nloc, chunk)]
+            chunks = [[c.col.slice(b, e) for c in pc] for b, e in bounds]
+            nslots, inflight = 2, 2   # two slots, both in flight: the best of 1-4 slots on every box measured (profiles/r03_stream_join_pcie.txt)
+            best = None
+            # ONE pipeline for all repetitions: the first pass page-locks the slots' result blocks and sizes their device
+            # buffers (a long-running caller pays that once), the best of the following passes is reported
             sj = StreamJoin(eng.ctx, [ia, ib], nslots=nslots, positions=POS)
-            best_c = None
-            import queue
-            import threading
-
             for rep in range(4):
                 torch.cuda.synchronize(dev)
                 t0 = time.perf_counter()
-                # a host application's shape: one thread forms the codes of chunk after chunk (cph_host_encoder_run hands the rows to
-                # its worker pool; ctypes drops the GIL), the other feeds the join pipeline with whatever chunk is ready
-                ready = queue.Queue()
-                enc_err = []
-
-                def producer():
-                    try:
-                        for ci in range(len(chunks)):
-                            for k in range(2):
-                                encs[k].run([chunks[ci][k]], code_bufs[ci][k].array)
-                            ready.put(ci)
-                    except Exception as ex_:   # noqa: BLE001 — re-raised by the consumer
-                        enc_err.append(ex_)
-                        ready.put(None)
-
-                th = threading.Thread(target=producer)
-                th.start()
                 sub = done = 0
-                joined_c = 0
+                joined_e2e = 0
                 while done < len(chunks):
                     while sub < len(chunks) and sj.pending < inflight:
-                        ci = ready.get()
-                        if ci is None:
-                            raise enc_err[0]
-                        sj.submit_codes([p.array for p in code_bufs[ci]], bounds[ci][1] - bounds[ci][0], probe_base=bounds[ci][0])
+                        sj.submit(chunks[sub], probe_base=bounds[sub][0])
                         sub += 1
                     r = sj.next(copy=False)
-                    joined_c += r["nmatches"]
+                    joined_e2e += r["nmatches"]
                     done += 1
-                th.join()
-                dt_c = time.perf_counter() - t0
-                if rep > 0 and (best_c is None or dt_c < best_c):
-                    best_c = dt_c
+                dt_e2e = time.perf_counter() - t0
+                if rep > 0 and (best is None or dt_e2e < best):
+                    best = dt_e2e
             sj.close()
-            out["e2e_pinned_host_encoded"] = {
-                "scope": "as e2e_pinned_host, but the stream's keys cross PCIe as 4-byte codes formed on the host (cph_host_encoder_run: "
-                         f"{encs[0].threads} threads, on a producer thread that runs beside the submit / next loop) — host encode time "
-                         "included; key strings in pinned host memory in -> "
-                         "pinned host " + ("sorted positions" if POS else "build-row ids") + " + match bitmap out",
-                "rows": nloc, "ms": round(best_c * 1e3, 2), "rows_per_s": nloc / best_c, "joined": joined_c,
-                "host_encode_ms_alone": round(enc_alone * 1e3, 2), "host_threads": encs[0].threads,
-                "h2d_GBps": round(8 * nloc / best_c / 1e9, 1), "d2h_GBps": round(d2h / best_c / 1e9, 1),
-                "equals_string_pipeline": joined_c == joined_e2e}
-            for e_ in encs:
-                e_.close()
-            for p_ in sum(code_bufs, []):
-                p_.free()
-        except Exception as ex:   # noqa: BLE001 — reported, never fatal for the headline
-            out["e2e_pinned_host_encoded"] = {"error": f"{type(ex).__name__}: {ex}"}
-        for c in pc:
-            c.free()
-        ia.close(); ib.close()
+            h2d = host_bytes["cust_id"] + host_bytes["prod_id"] + off_o
+            d2h = 8 * nloc + nloc // 8
+            out["e2e_pinned_host"] = {
+                "scope": "pinned host key columns in -> pinned host " + ("sorted positions" if POS else "build-row ids") + " + match bitmap out (cph_stream_join_*), "
+                         "indexes already built; PCIe inclusive; one pipeline reused, first pass (page-locking of the result blocks) not counted",
+                "rows": nloc, "chunk_rows": chunk, "slots": nslots, "in_flight": inflight, "ms": round(best * 1e3, 2),
+                "rows_per_s": nloc / best, "joined": joined_e2e,
+                "h2d_GBps": round(h2d / best / 1e9, 1), "d2h_GBps": round(d2h / best / 1e9, 1)}
+            # The same scope with the key codes formed ON THE HOST (cph_host_encoder_*: a pool of worker threads walks the codec's
+            # table over the pinned strings) and shipped as 4 bytes per row and step (cph_stream_join_submit_codes) instead of
+            # the 17 bytes of key strings: the host encode of chunk k+1 overlaps the transfers and kernels of chunk k.  The
+            # encode time is INSIDE the timed loop; it is also timed alone (host_encode_ms: all chunks, nothing else running).
+            try:
+                from csvplus_amd.streaming import HostEncoder, PinnedArray
 
-    # ---- IndexOn at 1e8 rows (the other half of BASELINE's metric; reported, not part of `value`) ---
-    if world == 1 and not args.no_index_1e8:
-        def time_index(col, unique, reps):
-            d = col.to_device(dev)
-            eng.index_on([d], unique=unique).close()   # warm-up (pool, LDS attributes)
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                ix = eng.index_on([d], unique=unique)
-                inf = ix.info()
-                ix.close()
-            torch.cuda.synchronize(dev)
-            wall = (time.perf_counter() - t0) / reps
-            eng.ctx.profile(True)                      # the per-kernel breakdown: one more build, outside the timing
-            eng.ctx.profile_read(reset=True)
-            eng.index_on([d], unique=unique).close()
-            p = eng.ctx.profile_read(reset=True)
-            eng.ctx.profile(False)
-            check = None
-            if not args.no_verify:
-                from csvplus_amd import verify as V
-                from csvplus_amd.engine import device_view
-                ix = eng.index_on([d], unique=unique)
-                check = V.check_index_order(d, device_view(ix.perm_device_ptr(), ix.nrows, "<i4", ix, dev))
-                ix.close()
-                torch.cuda.empty_cache()
-            kms = sum(v["total_ms"] for v in p.values())
-            n = col.nrows
-            # ALGORITHMIC bytes of the build = what the kernels that RAN move (pass model, DESIGN.md §5): the library
-            # records the bytes of every sort / scan / scan-for-duplicates launch itself (radix histogram: K bytes per
-            # key, 1 byte with the digit stream; scatter: 2K+8 [+1 digit byte], first pass 2K+4; first_dup: K*w; a
-            # direct table or hash table only if a kernel built one — IndexOn alone builds none); added here are the
-            # passes over the SOURCE column, whose bytes the library cannot know: statistics (k_col_stats, and
-            # k_group_stats when dictionary windows are completed over all rows) and the encode, which also writes the
-            # n*K code bytes.  Every term is printed so that the fraction can be recomputed from the line alone.
-            K_ = inf["key_bytes"] * inf["code_words"]
-            src = col.nbytes_values() + col.nbytes_offsets()
-            # (round 4: k_split_stats = the exact statistics pass of the delimiter-split codec; its sample passes k_split_count /
-            # k_split_sample read 2^18 rows and are not charged)
-            src_readers = {k: p[k]["launches"] for k in ("k_col_stats", "k_group_stats", "k_split_stats", "k_encode_build") if k in p}
-            lib_bytes = {k: v["algo_bytes"] for k, v in p.items() if v["algo_bytes"] > 0}
-            # (round 5: the direct sort of fixed-width 8-byte ids codes the keys inside its first partition level — no k_encode_build
-            # launch, no code array; the library charges that pass with the 8 bytes of key it reads per row)
-            fused_encode = "k_encode_build" not in p and "k_win_partition" in p
-            algo = src * sum(src_readers.values()) + n * K_ * src_readers.get("k_encode_build", 0 if fused_encode else 1) + sum(lib_bytes.values())
-            compulsory = src + n * (K_ + 4)    # the column read once, sorted codes + perm written once
-            return {"rows": n, "ms": round(wall * 1e3, 3), "kernel_ms": round(kms, 3), "rows_per_s": n / wall,
-                    "GBps_algorithmic": round(algo / 1e9 / wall, 1),
-                    "frac_pass_model": round(algo / 1e9 / wall / HBM_PEAK_GBPS, 4),
-                    "frac_compulsory": round(compulsory / 1e9 / wall / HBM_PEAK_GBPS, 4),
-                    "algorithmic_bytes": round(algo), "compulsory_bytes": round(compulsory),
-                    "byte_terms": {"source_bytes": src, "source_reads": src_readers, "code_bytes_written": n * K_,
-                                   "library_kernels": {k: round(v) for k, v in lib_bytes.items()}},
-                    "verified": (check or {}).get("ok"), "verify": check, "info": inf,
-                    "kernels_ms": {k: round(v["total_ms"], 3) for k, v in p.items()}}
+                encs = [HostEncoder(ia), HostEncoder(ib)]
+                code_bufs = [[PinnedArray(eng.ctx, e - b) for _ in range(2)] for b, e in bounds]
+                t0 = time.perf_counter()
+                for ci, ch_cols in enumerate(chunks):
+                    for k in range(2):
+                        encs[k].run([ch_cols[k]], code_bufs[ci][k].array)
+                enc_alone = time.perf_counter() - t0
+                sj = StreamJoin(eng.ctx, [ia, ib], nslots=nslots, positions=POS)
+                best_c = None
+                import queue
+                import threading
 
-        n8 = args.rows
-        out["index_on_1e8"] = {
-            "unique_fixed8_ids": time_index(dg.column(dg.SEQ_PERM, n8, n8, encoding=dg.FIXED8, seed=7), True, 3),
-            "varlen_dup_keys_config3": time_index(dg.varkeys(n8), False, 2),
-        }
-
-        # IndexOn(1e8) + Join(1e8): what the north star's 40 % is quoted on — bytes and milliseconds of the 1e8-row
-        # index build and of the bench step (two build-side indexes + the chained Join of 1e8 stream rows) SUMMED
-        if roofline and "step_algorithmic_bytes" in roofline:
-            comb = {}
-            for name, r in out["index_on_1e8"].items():
-                if not isinstance(r, dict) or "algorithmic_bytes" not in r:
-                    continue
-                bts = r["algorithmic_bytes"] + roofline["step_algorithmic_bytes"]
-                ms = r["ms"] + ms_per_step
-                comb[name + "_plus_step"] = {"ms": round(ms, 3), "algorithmic_bytes": bts,
-                                             "GBps": round(bts / 1e9 / (ms / 1e3), 1),
-                                             "frac": round(bts / 1e9 / (ms / 1e3) / HBM_PEAK_GBPS, 4),
-                                             "index_ms": r["ms"], "step_ms": round(ms_per_step, 3)}
-                for oname in ("join_positions", "join_row_ids"):   # the same sum with the step in the other output mode
-                    if out.get(oname):
-                        msp = r["ms"] + out[oname]["ms_per_step"]
-                        comb[name + "_plus_" + oname + "_step"] = {"ms": round(msp, 3), "algorithmic_bytes": bts,
-                                                                    "GBps": round(bts / 1e9 / (msp / 1e3), 1),
-                                                                    "frac": round(bts / 1e9 / (msp / 1e3) / HBM_PEAK_GBPS, 4),
-                                                                    "index_ms": r["ms"], "step_ms": out[oname]["ms_per_step"]}
-            comb["note"] = ("IndexOn over 1e8 rows (index_on_1e8.*: wall ms, pass-model bytes) + one bench step (2 index builds + "
-                            "chained Join of 1e8 rows: ms_per_step, roofline.step_algorithmic_bytes), summed; frac = bytes / ms / 8 TB/s")
-            out["index_plus_join_1e8"] = comb
-
-        # IndexOn end to end through the C ABI as a cgo caller sees createIndex (csvplus.go:707-738): key column in PINNED
-        # HOST memory in -> host perm out (cph_index_build on host columns + cph_index_perm(HOST)); PCIe inclusive
-        if not args.no_e2e:
-            from csvplus_amd.streaming import PinnedCol
-
-            def time_index_host(col, unique, reps):
-                pc = PinnedCol(eng.ctx, col)
-
-                def timed():
-                    ix = N.DeviceIndex(eng.ctx, [pc.col], unique=unique)   # warm-up: device pool, pinned blocks, the host worker pool
-                    ix.perm_host_view()
-                    ix.close()
+                for rep in range(4):
                     torch.cuda.synchronize(dev)
                     t0 = time.perf_counter()
-                    for _ in range(reps):
-                        ix = N.DeviceIndex(eng.ctx, [pc.col], unique=unique)
-                        pv = ix.perm_host_view()
-                        first, last = int(pv[0]), int(pv[-1])
-                        path = ix.info()["build_path"]
+                    # a host application's shape: one thread forms the codes of chunk after chunk (cph_host_encoder_run hands the rows to
+                    # its worker pool; ctypes drops the GIL), the other feeds the join pipeline with whatever chunk is ready
+                    ready = queue.Queue()
+                    enc_err = []
+
+                    def producer():
+                        try:
+                            for ci in range(len(chunks)):
+                                for k in range(2):
+                                    encs[k].run([chunks[ci][k]], code_bufs[ci][k].array)
+                                ready.put(ci)
+                        except Exception as ex_:   # noqa: BLE001 — re-raised by the consumer
+                            enc_err.append(ex_)
+                            ready.put(None)
+
+                    th = threading.Thread(target=producer)
+                    th.start()
+                    sub = done = 0
+                    joined_c = 0
+                    while done < len(chunks):
+                        while sub < len(chunks) and sj.pending < inflight:
+                            ci = ready.get()
+                            if ci is None:
+                                raise enc_err[0]
+                            sj.submit_codes([p.array for p in code_bufs[ci]], bounds[ci][1] - bounds[ci][0], probe_base=bounds[ci][0])
+                            sub += 1
+                        r = sj.next(copy=False)
+                        joined_c += r["nmatches"]
+                        done += 1
+                    th.join()
+                    dt_c = time.perf_counter() - t0
+                    if rep > 0 and (best_c is None or dt_c < best_c):
+                        best_c = dt_c
+                sj.close()
+                out["e2e_pinned_host_encoded"] = {
+                    "scope": "as e2e_pinned_host, but the stream's keys cross PCIe as 4-byte codes formed on the host (cph_host_encoder_run: "
+                             f"{encs[0].threads} threads, on a producer thread that runs beside the submit / next loop) — host encode time "
+                             "included; key strings in pinned host memory in -> "
+                             "pinned host " + ("sorted positions" if POS else "build-row ids") + " + match bitmap out",
+                    "rows": nloc, "ms": round(best_c * 1e3, 2), "rows_per_s": nloc / best_c, "joined": joined_c,
+                    "host_encode_ms_alone": round(enc_alone * 1e3, 2), "host_threads": encs[0].threads,
+                    "h2d_GBps": round(8 * nloc / best_c / 1e9, 1), "d2h_GBps": round(d2h / best_c / 1e9, 1),
+                    "equals_string_pipeline": joined_c == joined_e2e}
+                for e_ in encs:
+                    e_.close()
+                for p_ in sum(code_bufs, []):
+                    p_.free()
+            except Exception as ex:   # noqa: BLE001 — reported, never fatal for the headline
+                out["e2e_pinned_host_encoded"] = {"error": f"{type(ex).__name__}: {ex}"}
+            for c in pc:
+                c.free()
+            ia.close(); ib.close()
+
+        # ---- IndexOn at 1e8 rows (the other half of BASELINE's metric; reported, not part of `value`) ---
+        if world == 1 and not args.no_index_1e8:
+            def time_index(col, unique, reps):
+                d = col.to_device(dev)
+                eng.index_on([d], unique=unique).close()   # warm-up (pool, LDS attributes)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    ix = eng.index_on([d], unique=unique)
+                    inf = ix.info()
+                    ix.close()
+                torch.cuda.synchronize(dev)
+                wall = (time.perf_counter() - t0) / reps
+                eng.ctx.profile(True)                      # the per-kernel breakdown: one more build, outside the timing
+                eng.ctx.profile_read(reset=True)
+                eng.index_on([d], unique=unique).close()
+                p = eng.ctx.profile_read(reset=True)
+                eng.ctx.profile(False)
+                check = None
+                if not args.no_verify:
+                    from csvplus_amd import verify as V
+                    from csvplus_amd.engine import device_view
+                    ix = eng.index_on([d], unique=unique)
+                    check = V.check_index_order(d, device_view(ix.perm_device_ptr(), ix.nrows, "<i4", ix, dev))
+                    ix.close()
+                    torch.cuda.empty_cache()
+                kms = sum(v["total_ms"] for v in p.values())
+                n = col.nrows
+                # ALGORITHMIC bytes of the build = what the kernels that RAN move (pass model, DESIGN.md §5): the library
+                # records the bytes of every sort / scan / scan-for-duplicates launch itself (radix histogram: K bytes per
+                # key, 1 byte with the digit stream; scatter: 2K+8 [+1 digit byte], first pass 2K+4; first_dup: K*w; a
+                # direct table or hash table only if a kernel built one — IndexOn alone builds none); added here are the
+                # passes over the SOURCE column, whose bytes the library cannot know: statistics (k_col_stats, and
+                # k_group_stats when dictionary windows are completed over all rows) and the encode, which also writes the
+                # n*K code bytes.  Every term is printed so that the fraction can be recomputed from the line alone.
+                K_ = inf["key_bytes"] * inf["code_words"]
+                src = col.nbytes_values() + col.nbytes_offsets()
+                # (round 4: k_split_stats = the exact statistics pass of the delimiter-split codec; its sample passes k_split_count /
+                # k_split_sample read 2^18 rows and are not charged)
+                src_readers = {k: p[k]["launches"] for k in ("k_col_stats", "k_group_stats", "k_split_stats", "k_encode_build") if k in p}
+                lib_bytes = {k: v["algo_bytes"] for k, v in p.items() if v["algo_bytes"] > 0}
+                # (round 5: the direct sort of fixed-width 8-byte ids codes the keys inside its first partition level — no k_encode_build
+                # launch, no code array; the library charges that pass with the 8 bytes of key it reads per row)
+                fused_encode = "k_encode_build" not in p and "k_win_partition" in p
+                algo = src * sum(src_readers.values()) + n * K_ * src_readers.get("k_encode_build", 0 if fused_encode else 1) + sum(lib_bytes.values())
+                compulsory = src + n * (K_ + 4)    # the column read once, sorted codes + perm written once
+                return {"rows": n, "ms": round(wall * 1e3, 3), "kernel_ms": round(kms, 3), "rows_per_s": n / wall,
+                        "GBps_algorithmic": round(algo / 1e9 / wall, 1),
+                        "frac_pass_model": round(algo / 1e9 / wall / HBM_PEAK_GBPS, 4),
+                        "frac_compulsory": round(compulsory / 1e9 / wall / HBM_PEAK_GBPS, 4),
+                        "algorithmic_bytes": round(algo), "compulsory_bytes": round(compulsory),
+                        "byte_terms": {"source_bytes": src, "source_reads": src_readers, "code_bytes_written": n * K_,
+                                       "library_kernels": {k: round(v) for k, v in lib_bytes.items()}},
+                        "verified": (check or {}).get("ok"), "verify": check, "info": inf,
+                        "kernels_ms": {k: round(v["total_ms"], 3) for k, v in p.items()}}
+
+            n8 = args.rows
+            out["index_on_1e8"] = {
+                "unique_fixed8_ids": time_index(dg.column(dg.SEQ_PERM, n8, n8, encoding=dg.FIXED8, seed=7), True, 3),
+                "varlen_dup_keys_config3": time_index(dg.varkeys(n8), False, 2),
+            }
+
+            # IndexOn(1e8) + Join(1e8): what the north star's 40 % is quoted on — bytes and milliseconds of the 1e8-row
+            # index build and of the bench step (two build-side indexes + the chained Join of 1e8 stream rows) SUMMED
+            if roofline and "step_algorithmic_bytes" in roofline:
+                comb = {}
+                for name, r in out["index_on_1e8"].items():
+                    if not isinstance(r, dict) or "algorithmic_bytes" not in r:
+                        continue
+                    bts = r["algorithmic_bytes"] + roofline["step_algorithmic_bytes"]
+                    ms = r["ms"] + ms_per_step
+                    comb[name + "_plus_step"] = {"ms": round(ms, 3), "algorithmic_bytes": bts,
+                                                 "GBps": round(bts / 1e9 / (ms / 1e3), 1),
+                                                 "frac": round(bts / 1e9 / (ms / 1e3) / HBM_PEAK_GBPS, 4),
+                                                 "index_ms": r["ms"], "step_ms": round(ms_per_step, 3)}
+                    for oname in ("join_positions", "join_row_ids"):   # the same sum with the step in the other output mode
+                        if out.get(oname):
+                            msp = r["ms"] + out[oname]["ms_per_step"]
+                            comb[name + "_plus_" + oname + "_step"] = {"ms": round(msp, 3), "algorithmic_bytes": bts,
+                                                                        "GBps": round(bts / 1e9 / (msp / 1e3), 1),
+                                                                        "frac": round(bts / 1e9 / (msp / 1e3) / HBM_PEAK_GBPS, 4),
+                                                                        "index_ms": r["ms"], "step_ms": out[oname]["ms_per_step"]}
+                comb["note"] = ("IndexOn over 1e8 rows (index_on_1e8.*: wall ms, pass-model bytes) + one bench step (2 index builds + "
+                                "chained Join of 1e8 rows: ms_per_step, roofline.step_algorithmic_bytes), summed; frac = bytes / ms / 8 TB/s")
+                out["index_plus_join_1e8"] = comb
+
+            # IndexOn end to end through the C ABI as a cgo caller sees createIndex (csvplus.go:707-738): key column in PINNED
+            # HOST memory in -> host perm out (cph_index_build on host columns + cph_index_perm(HOST)); PCIe inclusive
+            if not args.no_e2e:
+                from csvplus_amd.streaming import PinnedCol
+
+                def time_index_host(col, unique, reps):
+                    pc = PinnedCol(eng.ctx, col)
+
+                    def timed():
+                        ix = N.DeviceIndex(eng.ctx, [pc.col], unique=unique)   # warm-up: device pool, pinned blocks, the host worker pool
+                        ix.perm_host_view()
                         ix.close()
-                    wall_ = (time.perf_counter() - t0) / reps
-                    dig = None
-                    if not args.no_verify:   # (outside the timing) the permutation's digest
-                        ix = N.DeviceIndex(eng.ctx, [pc.col], unique=unique)
-                        dig = V.digest_u64(np.asarray(ix.perm_host_view()))
-                        ix.close()
-                    return wall_, path, first, last, dig, None
+                        torch.cuda.synchronize(dev)
+                        t0 = time.perf_counter()
+                        for _ in range(reps):
+                            ix = N.DeviceIndex(eng.ctx, [pc.col], unique=unique)
+                            pv = ix.perm_host_view()
+                            first, last = int(pv[0]), int(pv[-1])
+                            path = ix.info()["build_path"]
+                            ix.close()
+                        wall_ = (time.perf_counter() - t0) / reps
+                        dig = None
+                        if not args.no_verify:   # (outside the timing) the permutation's digest
+                            ix = N.DeviceIndex(eng.ctx, [pc.col], unique=unique)
+                            dig = V.digest_u64(np.asarray(ix.perm_host_view()))
+                            ix.close()
+                        return wall_, path, first, last, dig, None
 
-                from csvplus_amd import verify as V
-                wall, path, first, last, dig, _tb = timed()
-                h2d = col.nbytes_values() + col.nbytes_offsets()
-                d2h = 4 * col.nrows
-                blk = {"rows": col.nrows, "ms": round(wall * 1e3, 2), "rows_per_s": col.nrows / wall,
-                       "build_path": {0: "strings uploaded, device encode", 2: "host-formed codes (4 B/row uploaded)"}.get(path, path),
-                       "h2d_bytes": 4 * col.nrows if path == 2 else h2d, "d2h_bytes": d2h,
-                       "pcie_GBps": round(((4 * col.nrows if path == 2 else h2d) + d2h) / wall / 1e9, 1),
-                       "perm_first_last": [first, last]}
-                if path == 2:   # the A/B inside the same run: the same call with the strings uploaded (ctx option host_build = 0)
-                    eng.ctx.set_option("host_build", 0)
-                    wall0, path0, f0, l0, dig0, _ = timed()
-                    eng.ctx.set_option("host_build", 1)
-                    blk["strings_uploaded_ms"] = round(wall0 * 1e3, 2)
-                    if dig is not None:
-                        blk["verified"] = bool(dig == dig0 and (first, last) == (f0, l0))   # the same permutation either way
-                        blk["perm_digest"] = f"{dig:016x}"
-                pc.free()
-                return blk
+                    from csvplus_amd import verify as V
+                    wall, path, first, last, dig, _tb = timed()
+                    h2d = col.nbytes_values() + col.nbytes_offsets()
+                    d2h = 4 * col.nrows
+                    blk = {"rows": col.nrows, "ms": round(wall * 1e3, 2), "rows_per_s": col.nrows / wall,
+                           "build_path": {0: "strings uploaded, device encode", 2: "host-formed codes (4 B/row uploaded)"}.get(path, path),
+                           "h2d_bytes": 4 * col.nrows if path == 2 else h2d, "d2h_bytes": d2h,
+                           "pcie_GBps": round(((4 * col.nrows if path == 2 else h2d) + d2h) / wall / 1e9, 1),
+                           "perm_first_last": [first, last]}
+                    if path == 2:   # the A/B inside the same run: the same call with the strings uploaded (ctx option host_build = 0)
+                        eng.ctx.set_option("host_build", 0)
+                        wall0, path0, f0, l0, dig0, _ = timed()
+                        eng.ctx.set_option("host_build", 1)
+                        blk["strings_uploaded_ms"] = round(wall0 * 1e3, 2)
+                        if dig is not None:
+                            blk["verified"] = bool(dig == dig0 and (first, last) == (f0, l0))   # the same permutation either way
+                            blk["perm_digest"] = f"{dig:016x}"
+                    pc.free()
+                    return blk
 
-            out["index_on_1e8"]["e2e_pinned_host"] = {
-                "scope": "key column in pinned host memory -> host perm (cph_index_build on host columns + cph_index_perm(HOST)); "
-                         "PCIe inclusive.  Round 5: ONE key column of <= 8 byte positions is coded by host threads in 2^22-row chunks, "
-                         "each uploaded (4 B/row) while the next is coded, the device only sorts (build_path); any other key uploads "
-                         "its strings, builds and downloads one after the other",
-                "unique_fixed8_ids": time_index_host(dg.column(dg.SEQ_PERM, n8, n8, encoding=dg.FIXED8, seed=7), True, 2),
-                "varlen_dup_keys_config3": time_index_host(dg.varkeys(n8), False, 2)}
+                out["index_on_1e8"]["e2e_pinned_host"] = {
+                    "scope": "key column in pinned host memory -> host perm (cph_index_build on host columns + cph_index_perm(HOST)); "
+                             "PCIe inclusive.  Round 5: ONE key column of <= 8 byte positions is coded by host threads in 2^22-row chunks, "
+                             "each uploaded (4 B/row) while the next is coded, the device only sorts (build_path); any other key uploads "
+                             "its strings, builds and downloads one after the other",
+                    "unique_fixed8_ids": time_index_host(dg.column(dg.SEQ_PERM, n8, n8, encoding=dg.FIXED8, seed=7), True, 2),
+                    "varlen_dup_keys_config3": time_index_host(dg.varkeys(n8), False, 2)}
 
-    # ---- CPU baseline: the oracle (C restatement of the reference), bounded sample ----------------
-    if world == 1 and not args.no_cpu_baseline:
-        from oracle import orc
+        # ---- CPU baseline: the oracle (C restatement of the reference), bounded sample ----------------
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import orc
 
-        ns = min(args.cpu_sample_rows, nloc)
-        s_cust = ords["cust_id"].slice(0, ns)
-        s_prod = ords["prod_id"].slice(0, ns)
-        t0 = time.perf_counter()
-        oa = orc.OracleIndex([cust_id])
-        ob = orc.OracleIndex([prod_id])
-        assert oa.first_dup() is None and ob.first_dup() is None
-        t_build = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        j1 = oa.join([s_cust])
-        sel = j1["probe_idx"].astype(np.uint32)
-        j2 = ob.join([s_prod], row_sel=sel)
-        t_probe = time.perf_counter() - t0
-        est = t_build + t_probe * (args.rows / ns)
-        if gpu_prefix is not None:
-            # bit-exact comparison of the first `ns` result rows of the timed configuration with the oracle
-            eq = bool(j1["nmatches"] == ns and j2["nmatches"] == ns
-                      and np.array_equal(j1["build_row"].astype(np.uint32), gpu_prefix[0][:ns])
-                      and np.array_equal(j2["build_row"].astype(np.uint32), gpu_prefix[1][:ns]))
-            out.setdefault("verify", {})["oracle_prefix_rows"] = ns
-            out["verify"]["oracle_prefix_bit_exact"] = eq
-            out["verified"] = bool(out.get("verified")) and eq
-        lean_1 = {
-            "value": args.rows / est, "unit": "rows/s", "cores": 1,
-            "sample": f"oracle (C restatement, SoA strings, comparison sort + binary-search probe; 1 thread): both "
-                      f"index builds in full ({t_build:.2f} s) + chained probe of the first {ns} of {args.rows} "
-                      f"orders rows ({t_probe:.2f} s, {j2['nmatches']} joined), probe time scaled to all rows",
-            "build_s": round(t_build, 3), "probe_sample_s": round(t_probe, 3),
-        }
-        # (i) the reference's own cost model — one hash map per row, comparison sort through map lookups, a merged
-        #     map per match (oracle/faithful.cpp), single thread like the reference — on a bounded sample: the
-        #     first fn customers / fm orders of tables of the same shape, extrapolated with n*log(n) (index) and
-        #     m*log(n) (probe).  The extrapolation is labelled; the measured sample stands beside it.
-        import math
-        fn, fm = min(4_000_000, args.customers), min(2_000_000, args.rows)   # ~17 s on one core (round 4: 1e6 / 5e5, 4 s)
-        f_cust = dg.customers(fn)
-        f_prod = dg.products(args.products)
-        f_ords = dg.orders(fm, fn, args.products)
-        fr = orc.faithful_chain_join(f_cust, "id", f_prod, "prod_id", f_ords, "cust_id", "prod_id")
-        assert fr["joined"] == fm
-        scale_ix = (args.customers * math.log2(max(2, args.customers))) / (fn * math.log2(max(2, fn)))
-        scale_pr = (args.rows / fm) * (math.log2(max(2, args.customers)) / math.log2(max(2, fn)))
-        f_est = fr["index_s"] * scale_ix + fr["join_s"] * scale_pr
-        # (ii) the lean algorithm on all host cores
-        mt_n = min(20_000_000, nloc)
-        r1, jn1, s1, p1, threads = orc.lean_mt_join(cust_id, ords["cust_id"].slice(0, mt_n))
-        r2, jn2, s2, p2, _ = orc.lean_mt_join(prod_id, ords["prod_id"].slice(0, mt_n))
-        assert jn1 == mt_n and jn2 == mt_n
-        if gpu_prefix is not None:
-            k = min(mt_n, ns)
-            assert np.array_equal(r1[:k], gpu_prefix[0][:k]) and np.array_equal(r2[:k], gpu_prefix[1][:k])
-        mt_est = s1 + s2 + (p1 + p2) * (args.rows / mt_n)
-        f_meas = fr["index_s"] + fr["join_s"]
-        out["cpu_baseline"] = {
-            # MEASURED: the whole job at sample size (index builds + chained Join), joined rows per second of that run;
-            # the full-size figure is an extrapolation and stands apart
-            "value": fm / f_meas, "unit": "rows/s", "cores": 1, "kind": "port",
-            "sample": f"map-per-row restatement of csvplus.go (Row = hash map, sort.Sort through Less, mergeRows per match; "
-                      f"oracle/faithful.cpp, 1 thread like the reference), MEASURED on a sample of the workload: UniqueIndexOn over "
-                      f"{fn} customers + {args.products} products ({fr['index_s']:.2f} s) + chained Join of {fm} orders "
-                      f"({fr['join_s']:.2f} s) = {fm} joined rows in {f_meas:.2f} s; not the Go binary (no Go toolchain here)",
-            "measured_sample": {"customers": fn, "orders": fm, "row_maps_s": round(fr["rows_s"], 3),
-                                "index_s": round(fr["index_s"], 3), "join_s": round(fr["join_s"], 3)},
-            "extrapolated_full_size": {
-                "value": args.rows / f_est, "unit": "rows/s", "seconds": round(f_est, 1),
-                "how": f"index time x{scale_ix:.1f} (n*log2 n), join time x{scale_pr:.1f} (m*log2 n) to {args.customers} customers / "
-                       f"{args.rows} orders: an estimate, not a measurement"},
-            "variants": {
-                "lean_soa_1_thread": lean_1,
-                "lean_soa_all_cores": {
-                    "value": args.rows / mt_est, "unit": "rows/s", "cores": threads,
-                    "sample": f"sort of (key,row) pairs + binary-search probe on {threads} threads (OpenMP, libstdc++ "
-                              f"parallel stable_sort): both index builds in full ({s1 + s2:.2f} s) + both probes of the first "
-                              f"{mt_n} orders rows ({p1 + p2:.2f} s), probe time scaled to all rows; nproc={os.cpu_count()}"},
-            },
-        }
+            ns = min(args.cpu_sample_rows, nloc)
+            s_cust = ords["cust_id"].slice(0, ns)
+            s_prod = ords["prod_id"].slice(0, ns)
+            t0 = time.perf_counter()
+            oa = orc.OracleIndex([cust_id])
+            ob = orc.OracleIndex([prod_id])
+            assert oa.first_dup() is None and ob.first_dup() is None
+            t_build = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            j1 = oa.join([s_cust])
+            sel = j1["probe_idx"].astype(np.uint32)
+            j2 = ob.join([s_prod], row_sel=sel)
+            t_probe = time.perf_counter() - t0
+            est = t_build + t_probe * (args.rows / ns)
+            if gpu_prefix is not None:
+                # bit-exact comparison of the first `ns` result rows of the timed configuration with the oracle
+                eq = bool(j1["nmatches"] == ns and j2["nmatches"] == ns
+                          and np.array_equal(j1["build_row"].astype(np.uint32), gpu_prefix[0][:ns])
+                          and np.array_equal(j2["build_row"].astype(np.uint32), gpu_prefix[1][:ns]))
+                out.setdefault("verify", {})["oracle_prefix_rows"] = ns
+                out["verify"]["oracle_prefix_bit_exact"] = eq
+                out["verified"] = bool(out.get("verified")) and eq
+            lean_1 = {
+                "value": args.rows / est, "unit": "rows/s", "cores": 1,
+                "sample": f"oracle (C restatement, SoA strings, comparison sort + binary-search probe; 1 thread): both "
+                          f"index builds in full ({t_build:.2f} s) + chained probe of the first {ns} of {args.rows} "
+                          f"orders rows ({t_probe:.2f} s, {j2['nmatches']} joined), probe time scaled to all rows",
+                "build_s": round(t_build, 3), "probe_sample_s": round(t_probe, 3),
+            }
+            # (i) the reference's own cost model — one hash map per row, comparison sort through map lookups, a merged
+            #     map per match (oracle/faithful.cpp), single thread like the reference — on a bounded sample: the
+            #     first fn customers / fm orders of tables of the same shape, extrapolated with n*log(n) (index) and
+            #     m*log(n) (probe).  The extrapolation is labelled; the measured sample stands beside it.
+            import math
+            fn, fm = min(4_000_000, args.customers), min(2_000_000, args.rows)   # ~17 s on one core (round 4: 1e6 / 5e5, 4 s)
+            f_cust = dg.customers(fn)
+            f_prod = dg.products(args.products)
+            f_ords = dg.orders(fm, fn, args.products)
+            fr = orc.faithful_chain_join(f_cust, "id", f_prod, "prod_id", f_ords, "cust_id", "prod_id")
+            assert fr["joined"] == fm
+            scale_ix = (args.customers * math.log2(max(2, args.customers))) / (fn * math.log2(max(2, fn)))
+            scale_pr = (args.rows / fm) * (math.log2(max(2, args.customers)) / math.log2(max(2, fn)))
+            f_est = fr["index_s"] * scale_ix + fr["join_s"] * scale_pr
+            # (ii) the lean algorithm on all host cores
+            mt_n = min(20_000_000, nloc)
+            r1, jn1, s1, p1, threads = orc.lean_mt_join(cust_id, ords["cust_id"].slice(0, mt_n))
+            r2, jn2, s2, p2, _ = orc.lean_mt_join(prod_id, ords["prod_id"].slice(0, mt_n))
+            assert jn1 == mt_n and jn2 == mt_n
+            if gpu_prefix is not None:
+                k = min(mt_n, ns)
+                assert np.array_equal(r1[:k], gpu_prefix[0][:k]) and np.array_equal(r2[:k], gpu_prefix[1][:k])
+            mt_est = s1 + s2 + (p1 + p2) * (args.rows / mt_n)
+            f_meas = fr["index_s"] + fr["join_s"]
+            out["cpu_baseline"] = {
+                # MEASURED: the whole job at sample size (index builds + chained Join), joined rows per second of that run;
+                # the full-size figure is an extrapolation and stands apart
+                "value": fm / f_meas, "unit": "rows/s", "cores": 1, "kind": "port",
+                "sample": f"map-per-row restatement of csvplus.go (Row = hash map, sort.Sort through Less, mergeRows per match; "
+                          f"oracle/faithful.cpp, 1 thread like the reference), MEASURED on a sample of the workload: UniqueIndexOn over "
+                          f"{fn} customers + {args.products} products ({fr['index_s']:.2f} s) + chained Join of {fm} orders "
+                          f"({fr['join_s']:.2f} s) = {fm} joined rows in {f_meas:.2f} s; not the Go binary (no Go toolchain here)",
+                "measured_sample": {"customers": fn, "orders": fm, "row_maps_s": round(fr["rows_s"], 3),
+                                    "index_s": round(fr["index_s"], 3), "join_s": round(fr["join_s"], 3)},
+                "extrapolated_full_size": {
+                    "value": args.rows / f_est, "unit": "rows/s", "seconds": round(f_est, 1),
+                    "how": f"index time x{scale_ix:.1f} (n*log2 n), join time x{scale_pr:.1f} (m*log2 n) to {args.customers} customers / "
+                           f"{args.rows} orders: an estimate, not a measurement"},
+                "variants": {
+                    "lean_soa_1_thread": lean_1,
+                    "lean_soa_all_cores": {
+                        "value": args.rows / mt_est, "unit": "rows/s", "cores": threads,
+                        "sample": f"sort of (key,row) pairs + binary-search probe on {threads} threads (OpenMP, libstdc++ "
+                                  f"parallel stable_sort): both index builds in full ({s1 + s2:.2f} s) + both probes of the first "
+                                  f"{mt_n} orders rows ({p1 + p2:.2f} s), probe time scaled to all rows; nproc={os.cpu_count()}"},
+                },
+            }
+    except Exception as ex:   # noqa: BLE001
+        import traceback
+        out["extras_error"] = f"{type(ex).__name__}: {ex}"
+        out["extras_traceback"] = traceback.format_exc()[-1500:]
+        if "cpu_baseline" not in out:   # (the checks run in front of it: without them nothing is claimed)
+            out["verified"] = bool(out.get("verified")) and "verify" in out and "index_on_1e8" in out
+        print(f"bench.py: an extra block failed ({out['extras_error']}); the line is printed without it", file=sys.stderr, flush=True)
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

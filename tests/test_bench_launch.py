@@ -151,3 +151,15 @@ def test_stream_mode_config5_shape(ranks):
     d = _json_line(r.stdout)
     assert d["n_gpus"] == ranks and d["joined_rows_per_step"] == 600000 and d["verified"] is True
     assert d["scope"].startswith("pcie_inclusive") and len(d["per_rank_ms_per_step"]) == ranks and d["value"] > 0
+
+
+@pytest.mark.gpu
+def test_a_failing_extra_block_does_not_cost_the_line():
+    """Everything bench.py reports beside the contract fields (verification, variants, end-to-end scopes, CPU baseline) runs
+    inside one try: when one of them raises, the line is still printed — with `extras_error`, and without a verified claim."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", *SMALL], env=_env(CPH_BENCH_FAIL_EXTRAS="1"), capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert d["extras_error"].startswith("RuntimeError: CPH_BENCH_FAIL_EXTRAS") and d["verified"] is False
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
