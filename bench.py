@@ -200,6 +200,17 @@ def measure_traffic(kernel_prefix, args):
     return vals, "measured in this run"
 
 
+def flush_c_stdio():
+    """RCCL announces itself with printf ("RCCL version : ...") into C's stdout buffer, which — stdout being a pipe under the driver —
+    is only flushed at exit, i.e. BEHIND the JSON line Python prints: flush it first, so that the JSON line is the last line of stdout."""
+    try:
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+    except Exception:   # noqa: BLE001
+        pass
+
+
 def stream_mode(args, eng, dev, rank, world, share_gpu):
     """BASELINE.json configs[4] (1e9-row orders joined against resident indexes) on N ranks: the build side is replicated (every
     rank builds both indexes in its HBM), the orders are sharded by row range and every rank streams ITS shard from pinned host
@@ -281,6 +292,7 @@ def stream_mode(args, eng, dev, rank, world, share_gpu):
         return
     ms = dt / args.steps * 1e3
     d2h = 8 * nloc + nloc // 8
+    flush_c_stdio()
     print(json.dumps({
         "metric": "joined rows/sec (streaming Join of host-resident orders against HBM-resident indexes, PCIe inclusive)",
         "value": total / (dt / args.steps), "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
@@ -1421,9 +1433,16 @@ def main():
         if "cpu_baseline" not in out:   # (the checks run in front of it: without them nothing is claimed)
             out["verified"] = bool(out.get("verified")) and "verify" in out and "index_on_1e8" in out
         print(f"bench.py: an extra block failed ({out['extras_error']}); the line is printed without it", file=sys.stderr, flush=True)
-    print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    # the communicators go first, C's stdout buffer is flushed, THEN the line: nothing a library prints can land behind it
+    try:
+        if cdist is not None:
+            cdist.close()
+        if world > 1:
+            dist.destroy_process_group()
+    except Exception as ex:   # noqa: BLE001
+        print(f"bench.py: closing the communicators: {type(ex).__name__}: {ex}", file=sys.stderr, flush=True)
+    flush_c_stdio()
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
