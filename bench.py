@@ -426,7 +426,7 @@ def main():
             return n, step_info["info"]
         ch = N.join_chain(eng.ctx, [(ia, [d_ord["cust_id"]]), (ib, [d_ord["prod_id"]])], probe_base=begin,
                           out_mem=N.CPH_MEM_DEVICE, positions=POS)
-        if cdist is not None:          # one count exchange + one grouped batch for all arrays (cph_dist_chain_allgather)
+        if cdist is not None and args.exchange != "none":   # one count exchange + one grouped batch for all arrays (cph_dist_chain_allgather)
             g = cdist.chain_allgather(ch)
             n = g.total
             g.release()
