@@ -1433,16 +1433,30 @@ def main():
         if "cpu_baseline" not in out:   # (the checks run in front of it: without them nothing is claimed)
             out["verified"] = bool(out.get("verified")) and "verify" in out and "index_on_1e8" in out
         print(f"bench.py: an extra block failed ({out['extras_error']}); the line is printed without it", file=sys.stderr, flush=True)
-    # the communicators go first, C's stdout buffer is flushed, THEN the line: nothing a library prints can land behind it
-    try:
-        if cdist is not None:
-            cdist.close()
-        if world > 1:
-            dist.destroy_process_group()
-    except Exception as ex:   # noqa: BLE001
-        print(f"bench.py: closing the communicators: {type(ex).__name__}: {ex}", file=sys.stderr, flush=True)
+    # the communicators go first, C's stdout buffer is flushed, THEN the line: nothing a library prints can land behind it.  The
+    # other ranks left long ago; should a teardown wait for them all the same, the line is printed after 15 s without it
+    def close_communicators():
+        try:
+            if cdist is not None:
+                cdist.close()
+            if world > 1:
+                dist.destroy_process_group()
+        except Exception as ex:   # noqa: BLE001
+            print(f"bench.py: closing the communicators: {type(ex).__name__}: {ex}", file=sys.stderr, flush=True)
+
+    if cdist is not None or world > 1:
+        import threading
+
+        closer = threading.Thread(target=close_communicators, daemon=True)
+        closer.start()
+        closer.join(15.0)
+        if closer.is_alive():
+            print("bench.py: the communicators did not close within 15 s; printing the line first", file=sys.stderr, flush=True)
     flush_c_stdio()
     print(json.dumps(out), flush=True)
+    if (cdist is not None or world > 1) and closer.is_alive():
+        sys.stdout.flush()
+        os._exit(0)   # (a hung teardown must not keep the process, and with it the driver, waiting)
 
 
 if __name__ == "__main__":
