@@ -91,6 +91,8 @@ def parse_args():
     ap.add_argument("--no-calibration", action="store_true",
                     help="skip the in-run box calibration (plain 4-byte gather into a table of the customers row table's size, "
                          "streaming copy) behind roofline.gather_ceiling_ms / copy_TBps")
+    ap.add_argument("--extras", default=None, metavar="PATH",
+                    help="where the FULL record goes (default gpurun_out/bench_extras.json); stdout carries one compact line")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous only: every rank joins the process group (gloo when no GPU is visible) and rank 0 "
                          "prints which ranks it saw; no compute (what tests/test_bench_launch.py drives on CPU)")
@@ -176,7 +178,7 @@ def measure_traffic(kernel_prefix, args):
         cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
                sys.executable, str(ROOT / "bench.py"), "--steps", "2", "--warmup", "1", "--rows", str(args.rows),
                "--customers", str(args.customers), "--products", str(args.products), "--no-cpu-baseline",
-               "--no-index-1e8", "--no-verify", "--no-e2e", "--no-traffic", "--no-positions", "--no-variants"] + (["--row-ids"] if args.row_ids else [])
+               "--no-index-1e8", "--no-verify", "--no-e2e", "--no-traffic", "--no-positions", "--no-variants", "--extras", os.devnull] + (["--row-ids"] if args.row_ids else [])
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300,
                            check=True)
@@ -209,6 +211,139 @@ def flush_c_stdio():
         ctypes.CDLL(None).fflush(None)
     except Exception:   # noqa: BLE001
         pass
+
+
+LINE_BUDGET = 6000      # bytes of the ONE stdout line (round 5's 22 KB line left the driver's record with parsed = null)
+
+
+def _r(x, nd=4):
+    return round(x, nd) if isinstance(x, float) else x
+
+
+def _finite(o):
+    """NaN / Infinity are not JSON: they become null."""
+    if isinstance(o, float):
+        return o if o == o and abs(o) != float("inf") else None
+    if isinstance(o, dict):
+        return {k: _finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v) for v in o]
+    return o
+
+
+def compact_line(out, extras_path):
+    """The ONE stdout line: the contract's fields, a compact `roofline` and `cpu_baseline`, and the other measurements of the run as
+    bare numbers.  Everything else — per-kernel tables, byte models term by term, verification details, notes — stays in the
+    full record `out`, which emit() writes to `extras_path`.  Lists are positional; `cols` names the positions."""
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data") if k in out}
+    cfg = out.get("config") or {}
+    line["config"] = {k: (v[:160] if isinstance(v, str) else v) for k, v in cfg.items()
+                      if k in ("workload", "rows", "customers", "products", "rows_this_rank", "exchange", "rccl_nranks", "chunk_rows", "slots",
+                               "output", "shard_rows_rank0")}
+    if cfg.get("build_row_mode"):
+        line["config"]["output"] = "sorted positions" if cfg["build_row_mode"].startswith("sorted") else "original row ids"
+    if cfg.get("exchange_transport") and cfg["exchange_transport"] != "none":
+        line["config"]["transport"] = cfg["exchange_transport"][:80]
+    for k in ("scope", "joined_rows_per_step", "per_rank_ms_per_step", "verified", "efficiency_vs_n1", "exchange_ms", "compute_ms",
+              "kernel_ms_per_step", "h2d_GBps_rank0", "d2h_GBps_rank0"):
+        if out.get(k) is not None:
+            line[k] = out[k]
+    rf = out.get("roofline")
+    if rf:
+        c = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches",
+                                    "algorithmic_bytes_per_launch", "useful_bytes_per_launch", "frac_hbm", "step_algorithmic_bytes",
+                                    "step_frac", "copy_TBps", "output_mode") if k in rf}
+        if rf.get("traffic") is None and rf.get("traffic_note"):
+            c["traffic_note"] = rf["traffic_note"][:100]
+        if (rf.get("gather_ceiling") or {}).get("ms"):
+            c["gather_ceiling_ms"] = rf["gather_ceiling"]["ms"]
+        om = rf.get("other_output_mode")
+        if om:
+            c["other_output_mode"] = [om.get("mode"), _r(om.get("ms_per_step")), _r(om.get("k_chain_dense_ms")), om.get("frac"),
+                                      om.get("positions_equal_row_ids_through_perm")]
+        vs = out.get("variants")
+        if vs:
+            c["variants_cols"] = "ms_per_step,kernel_ms,frac,verified"
+            c["variants"] = {k: ([v.get("ms_per_step"), v.get("k_chain_dense_ms"), (v.get("roofline") or {}).get("frac"), v.get("verified")]
+                                 if "error" not in v else {"error": str(v["error"])[:80]}) for k, v in vs.items()}
+        line["roofline"] = c
+    cb = out.get("cpu_baseline")
+    if cb:
+        c = {"value": _r(cb.get("value"), 1), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+             "sample": (cb.get("sample") or "")[:200]}
+        if (cb.get("extrapolated_full_size") or {}).get("value"):
+            c["extrapolated_full_size"] = _r(cb["extrapolated_full_size"]["value"], 1)
+        for name, v in (cb.get("variants") or {}).items():
+            c[name] = [_r(v.get("value"), 1), v.get("cores")]
+        line["cpu_baseline"] = c
+    ix = out.get("index_on_1e8")
+    if ix:
+        c = {"cols": "ms,kernel_ms,frac_pass_model,frac_compulsory,verified"}
+        for name, v in ix.items():
+            if isinstance(v, dict) and "ms" in v:
+                c[name] = [v["ms"], v.get("kernel_ms"), v.get("frac_pass_model"), v.get("frac_compulsory"), v.get("verified")]
+        e2e = ix.get("e2e_pinned_host") or {}
+        hc = {name: [v.get("ms"), v.get("strings_uploaded_ms"), v.get("verified")] for name, v in e2e.items() if isinstance(v, dict) and "ms" in v}
+        if hc:
+            c["from_pinned_host_cols"] = "ms,strings_uploaded_ms,verified"
+            c["from_pinned_host"] = hc
+        line["index_on_1e8"] = c
+    comb = out.get("index_plus_join_1e8")
+    if comb:
+        line["index_plus_join_1e8"] = {"cols": "ms,frac", **{k: [v["ms"], v["frac"]] for k, v in comb.items() if isinstance(v, dict)}}
+    e2e = {k: [_r(out[k].get("ms")), _r(out[k].get("rows_per_s"), 0)] for k in ("e2e_pinned_host", "e2e_pinned_host_encoded")
+           if isinstance(out.get(k), dict) and "ms" in out[k]}
+    if e2e:
+        line["e2e"] = {"cols": "ms,rows_per_s", **e2e}
+    m = out.get("multi_gpu")
+    if m:
+        c = {k: m.get(k) for k in ("mode", "chunks", "join_compute_ms", "exchange_ms", "exposed_exchange_ms", "bytes_sent_per_step",
+                                   "bytes_received_per_step", "n1_ms_per_step", "efficiency_vs_n1")}
+        if m.get("same_run_other_modes"):
+            c["other_modes_ms"] = {k: v.get("ms_per_step", v.get("error")) for k, v in m["same_run_other_modes"].items()}
+        mr = m.get("measured_exchange_rate") or {}
+        c["link_GBps"] = mr.get("GBps_per_peer_link")
+        c["recv_GBps"] = mr.get("GBps_received_per_rank")
+        if m.get("build_side"):
+            c["build_side"] = m["build_side"].get("choice")
+        line["multi_gpu"] = c
+    ks = out.get("kernels")
+    if ks:   # the five largest kernels of a step, avg ms per launch
+        top = sorted(ks.items(), key=lambda kv: -kv[1]["total_ms"] / max(1, kv[1]["launches"]))[:5]
+        line["kernels_avg_ms"] = {k: v["avg_ms"] for k, v in top}
+    if out.get("host"):
+        line["host"] = out["host"]
+    if out.get("extras_error"):
+        line["extras_error"] = str(out["extras_error"])[:200]
+    line["extras"] = extras_path
+    # the budget is a hard limit: optional blocks go, in this order, until the line fits
+    for drop in ("kernels_avg_ms", "e2e", "host", "index_plus_join_1e8", "multi_gpu", "index_on_1e8"):
+        if len(json.dumps(line)) <= LINE_BUDGET:
+            break
+        line.pop(drop, None)
+    if len(json.dumps(line)) > LINE_BUDGET and "roofline" in line:
+        line["roofline"].pop("variants", None)
+    return line
+
+
+def emit(out, args):
+    """Write the full record beside the repo (gpurun_out/bench_extras.json unless --extras says otherwise), then print the ONE
+    compact line — last thing on stdout."""
+    path = Path(args.extras) if args.extras else ROOT / "gpurun_out" / "bench_extras.json"
+    shown = str(path)
+    try:
+        path.parent.mkdir(parents=True, exist_ok=True)
+        path.write_text(json.dumps(out, indent=1) + "\n")
+        try:
+            shown = str(path.resolve().relative_to(ROOT))
+        except ValueError:
+            pass
+    except OSError as ex:
+        shown = f"not written: {type(ex).__name__}: {ex}"[:120]
+    flush_c_stdio()
+    sys.stdout.flush()
+    print(json.dumps(_finite(compact_line(out, shown)), allow_nan=False), flush=True)
 
 
 def stream_mode(args, eng, dev, rank, world, share_gpu):
@@ -292,8 +427,7 @@ def stream_mode(args, eng, dev, rank, world, share_gpu):
         return
     ms = dt / args.steps * 1e3
     d2h = 8 * nloc + nloc // 8
-    flush_c_stdio()
-    print(json.dumps({
+    emit({
         "metric": "joined rows/sec (streaming Join of host-resident orders against HBM-resident indexes, PCIe inclusive)",
         "value": total / (dt / args.steps), "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
         "ms_per_step": ms, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
@@ -305,7 +439,7 @@ def stream_mode(args, eng, dev, rank, world, share_gpu):
         "scope": "pcie_inclusive: NOT comparable with the default mode's value (inputs resident in HBM)",
         "joined_rows_per_step": total, "per_rank_ms_per_step": [round(x, 3) for x in per_rank_ms],
         "h2d_GBps_rank0": round(h2d / (per_rank_ms[0] / 1e3) / 1e9, 1), "d2h_GBps_rank0": round(d2h / (per_rank_ms[0] / 1e3) / 1e9, 1),
-        "verified": bool(total == args.rows), "verify": {"every_order_joined_once": total == args.rows}}))
+        "verified": bool(total == args.rows), "verify": {"every_order_joined_once": total == args.rows}}, args)
 
 
 def main():
@@ -675,7 +809,8 @@ def main():
                     "avg_launch_ms": dom[1]["avg_ms"], "launches": dom[1]["launches"],
                     "algorithmic_bytes_per_launch": round(dom[1]["algo_GB"] * 1e9 / dom[1]["launches"])}
         if dom[0] in useful and dom[1]["total_ms"] > 0:
-            ub = useful[dom[0]] / K   # `useful` was summed over the K breakdown steps, one launch of this kernel each
+            # `useful` was summed over the K breakdown steps; a step of the N > 1 path launches the kernel once per sub-chunk
+            ub = useful[dom[0]] / K / max(1.0, dom[1]["launches"] / args.steps if dom[1].get("timed_region") else dom[1]["launches"] / K)
             roofline["useful_bytes_per_launch"] = round(ub)
             roofline["useful"] = round(ub / 1e9 / (dom[1]["avg_ms"] / 1e3) / HBM_PEAK_GBPS, 4)
             roofline["frac_hbm"] = roofline["useful"]
@@ -740,8 +875,8 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "u32", "dtype_note": "byte-string keys (u8) re-coded to order-preserving u32 codes; integer work only",
         "data": "synthetic",
-        "config": {"workload": "orders(1e8 x {cust_id,prod_id,qty}) JOIN customers(1e7, UniqueIndexOn id) "
-                               "JOIN products(1e5, UniqueIndexOn prod_id); BASELINE configs[3] shape, probe rows sharded over n_gpus",
+        "config": {"workload": "BASELINE configs[3]: orders(1e8 x {cust_id,prod_id,qty}).Join(UniqueIndexOn customers.id 1e7).Join(UniqueIndexOn products.prod_id 1e5)",
+                   "sharding": "probe rows split into n_gpus contiguous ranges, build side replicated",
                    "rows": args.rows, "customers": args.customers, "products": args.products,
                    "rows_this_rank": nloc, "exchange": args.exchange if (world > 1 or force_dist) else "none (1 GPU)",
                    "exchange_transport": transport, "rccl_nranks": rccl_nranks,
@@ -1452,8 +1587,7 @@ def main():
         closer.join(15.0)
         if closer.is_alive():
             print("bench.py: the communicators did not close within 15 s; printing the line first", file=sys.stderr, flush=True)
-    flush_c_stdio()
-    print(json.dumps(out), flush=True)
+    emit(out, args)
     if (cdist is not None or world > 1) and closer.is_alive():
         sys.stdout.flush()
         os._exit(0)   # (a hung teardown must not keep the process, and with it the driver, waiting)

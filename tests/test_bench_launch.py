@@ -27,6 +27,13 @@ def _json_line(out: str) -> dict:
     return json.loads(lines[-1])
 
 
+def _full(d: dict) -> dict:
+    """The full record behind the compact stdout line (bench.py: emit): the line names the file."""
+    p = Path(d["extras"])
+    p = p if p.is_absolute() else ROOT / p
+    return json.loads(p.read_text())
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -78,6 +85,37 @@ def test_more_ranks_than_gpus_is_refused_clearly():
     assert f"needs 2 visible GPUs, this machine shows {have}" in r.stderr and "Traceback" not in r.stderr
 
 
+def test_compact_line_of_the_kept_full_records_fits_the_budget():
+    """bench.compact_line on the full records kept under profiles/ (round 5's 22 KB line among them): under the budget, strict JSON,
+    `roofline` and `cpu_baseline` with the contract's keys."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    seen = 0
+    for f in sorted((ROOT / "profiles").glob("r0[56]*bench*.json")):
+        full = json.loads(f.read_text())
+        if "metric" not in full or "extras" in full:     # (a compact line kept beside its full record)
+            continue
+        line = json.dumps(b._finite(b.compact_line(full, "gpurun_out/bench_extras.json")), allow_nan=False)
+        assert len(line) < b.LINE_BUDGET, (f.name, len(line))
+        d = json.loads(line)
+        assert {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config"} <= set(d), f.name
+        if "roofline" in full and full["roofline"]:
+            assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"]), f.name
+        if "cpu_baseline" in full:
+            assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"]) and len(d["cpu_baseline"]["sample"]) <= 200
+        seen += 1
+    assert seen >= 3
+    # a record bloated far past the budget still yields a line inside it (optional blocks are dropped, the contract fields stay)
+    full = json.loads((ROOT / "profiles" / "r05e_bench.json").read_text())
+    full["variants"] = {f"variant_{i}": dict(full["variants"]["itoa_ids"]) for i in range(200)}
+    line = json.dumps(b.compact_line(full, "x"))
+    assert len(line) < b.LINE_BUDGET and json.loads(line)["roofline"]["frac"] > 0 and "cpu_baseline" in json.loads(line)
+
+
 SMALL = ["--rows", "300000", "--customers", "20000", "--products", "700", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
          "--no-index-1e8", "--no-e2e", "--no-traffic"]
 
@@ -102,6 +140,37 @@ def test_one_gpu_line_has_the_contract_fields():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["joined_rows_per_step"] == 300000 and d["verified"] is True
     assert d["config"]["rccl_nranks"] is None and len(d["per_rank_ms_per_step"]) == 1
+    f = _full(d)   # the full record: per-kernel table, verification details, variants with their byte models
+    assert f["value"] == d["value"] and f["kernels"] and f["verify"]["joined_rows"] == 300000 and set(f["variants"]) == set(d["roofline"]["variants"])
+
+
+def _no_constants(x):
+    raise AssertionError(f"{x} in the bench line")
+
+
+@pytest.mark.gpu
+def test_the_stdout_line_is_small_and_last(tmp_path):
+    """Round 5's line had grown to 22 KB and the driver's record of it came back with parsed = null.  The line is the contract's
+    fields + compact `roofline` / `cpu_baseline` + bare numbers, under 6000 bytes, strict JSON, the LAST line of stdout — with
+    every optional block switched on (variants, IndexOn at full test size, the end-to-end scopes, the CPU baseline)."""
+    extras = tmp_path / "full.json"
+    cmd = [sys.executable, BENCH, "--gpus", "1", "--rows", "300000", "--customers", "20000", "--products", "700", "--steps", "2", "--warmup", "1",
+           "--no-traffic", "--cpu-sample-rows", "50000", "--verify-sample", "5000", "--extras", str(extras)]
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    line = lines[-1]
+    assert line.startswith("{") and len(line) < 6000, len(line)
+    d = json.loads(line, parse_constant=_no_constants)
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["kernel"] and d["roofline"]["avg_launch_ms"] > 0
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0 and d["roofline"]["unit"] == "GB/s"
+    cb = d["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] == 1 and cb["kind"] == "port" and 0 < len(cb["sample"]) <= 200
+    assert set(d["roofline"]["variants"]) >= {"itoa_ids", "half_occupied_ids", "sparse_random_keys", "build_side_key", "step_plus_permute"}
+    assert all(v[3] is True for v in d["roofline"]["variants"].values()), d["roofline"]["variants"]
+    assert d["verified"] is True and d["extras"] == str(extras)
+    f = json.loads(extras.read_text())
+    assert f["cpu_baseline"]["measured_sample"] and f["index_on_1e8"]["varlen_dup_keys_config3"]["verified"] is True
 
 
 @pytest.mark.gpu
@@ -112,7 +181,7 @@ def test_shared_gpu_debug_mode_still_runs_and_says_what_it_is():
     assert r.returncode == 0, r.stderr[-3000:]
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["joined_rows_per_step"] == 300000
-    assert "DEBUG" in d["config"]["exchange_transport"] and d["config"]["rccl_nranks"] is None
+    assert "DEBUG" in d["config"]["transport"] and d["config"]["rccl_nranks"] is None
     assert len(d["per_rank_ms_per_step"]) == 2
 
 
@@ -126,7 +195,8 @@ def test_multi_gpu_code_path_with_one_rank(exchange):
     assert r.returncode == 0, r.stderr[-3000:]
     d = _json_line(r.stdout)
     assert d["joined_rows_per_step"] == 300000 and d["config"]["rccl_nranks"] == 1 and d["config"]["exchange"] == exchange
-    m = d["multi_gpu"]
+    assert d["multi_gpu"]["mode"] == exchange and d["multi_gpu"]["chunks"] == 3 and len(r.stdout.splitlines()[-1]) < 6000
+    m = _full(d)["multi_gpu"]
     assert m["mode"] == exchange and m["chunks"] == 3 and m["join_compute_ms"] > 0 and m["exchange_ms"] > 0
     assert m["n1_ms_per_step"] > 0 and 0 < d["efficiency_vs_n1"] < 3 and d["exchange_ms"] == m["exchange_ms"] and d["compute_ms"] > 0
     assert m["build_side"]["choice"] == "replicated"

@@ -19,11 +19,21 @@ def short(name):
 
 
 dur = defaultdict(lambda: [0, 0.0])
+launches = defaultdict(list)      # kernel -> [(start_ns, duration_us)] in launch order
 for f in root.glob("trace/**/*kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
         dur[k][0] += 1
         dur[k][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        launches[k].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+# the per-launch durations of the kernel with the largest total (the one `roofline` is quoted on): small enough to be tracked
+if dur:
+    dom = max(dur.items(), key=lambda kv: kv[1][1])[0]
+    rows = sorted(launches[dom])
+    with open(root / "dominant_kernel_launches.csv", "w") as fh:
+        fh.write(f"# {dom}\nlaunch,duration_us\n")
+        for i, (_, d_us) in enumerate(rows):
+            fh.write(f"{i},{d_us:.2f}\n")
 pmc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
 for f in root.glob("pmc_*/**/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
