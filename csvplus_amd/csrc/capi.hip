@@ -253,6 +253,12 @@ uint32_t* host_word(cph_ctx* ctx, uint32_t n) {
     return w;
 }
 
+bool host_words_reserve(cph_ctx* ctx, uint32_t n) {
+    if (n > kHostWords) return false;
+    if (ctx->host_words_pos + n > kHostWords) ctx->host_words_pos = 0;
+    return true;
+}
+
 Status self_clean_block(cph_ctx* ctx, DevBuf* b, size_t bytes) {
     if (*b && b->bytes() >= bytes) return {};
     if (*b) CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));   // (its last user may still run)
@@ -263,10 +269,15 @@ Status self_clean_block(cph_ctx* ctx, DevBuf* b, size_t bytes) {
     return {};
 }
 
+constexpr size_t kPinnedSmall = 4u << 20;   // blocks up to here: per-batch results, staging; above: one-shot results, perm copies
 Status pinned_cache_get(cph_ctx* ctx, size_t bytes, void** out, size_t* cap) {
+    // best fit; a small request (a per-batch result block) never takes a large block (a 400 MB perm copy) out of the cache
     int best = -1;
+    const size_t limit = bytes <= kPinnedSmall ? kPinnedSmall : ~(size_t)0;
     for (int i = 0; i < (int)ctx->pinned_cache.size(); i++)
-        if (ctx->pinned_cache[i].second >= bytes && (best < 0 || ctx->pinned_cache[i].second < ctx->pinned_cache[best].second)) best = i;
+        if (ctx->pinned_cache[i].second >= bytes && ctx->pinned_cache[i].second <= limit &&
+            (best < 0 || ctx->pinned_cache[i].second < ctx->pinned_cache[best].second))
+            best = i;
     if (best >= 0) {
         *out = ctx->pinned_cache[best].first;
         *cap = ctx->pinned_cache[best].second;
@@ -288,7 +299,10 @@ Status pinned_cache_get(cph_ctx* ctx, size_t bytes, void** out, size_t* cap) {
 }
 
 // result blocks of per-batch calls: sizes rounded up to a power of two (>= 64 KB) so that consecutive batches find each other's block
+// — up to 4 MB; a larger result takes what it needs rounded to 2 MB (a 1.6 GB result used to page-lock 2 GiB, 2.1 GB 4 GiB)
 static size_t result_block_bytes(size_t need) {
+    constexpr size_t kSmall = 4u << 20, kStep = 2u << 20;
+    if (need > kSmall) return (need + kStep - 1) / kStep * kStep;
     size_t b = 64 * 1024;
     while (b < need) b <<= 1;
     return b;
@@ -296,12 +310,21 @@ static size_t result_block_bytes(size_t need) {
 void pinned_cache_put(cph_ctx* ctx, void* p, size_t cap) {
     if (!p) return;
     ctx->pinned_cache.push_back({p, cap});
-    while (ctx->pinned_cache.size() > 2) {   // keep the two largest
-        size_t small = 0;
-        for (size_t i = 1; i < ctx->pinned_cache.size(); i++)
-            if (ctx->pinned_cache[i].second < ctx->pinned_cache[small].second) small = i;
-        (void)hipHostFree(ctx->pinned_cache[small].first);
-        ctx->pinned_cache.erase(ctx->pinned_cache.begin() + (long)small);
+    // two classes, each with its own limit, so that neither evicts the other: the two largest of the large blocks, the four
+    // largest of the small ones
+    for (int cls = 0; cls < 2; cls++) {
+        const size_t keep = cls ? 2 : 4;
+        for (;;) {
+            size_t count = 0, small = (size_t)-1;
+            for (size_t i = 0; i < ctx->pinned_cache.size(); i++) {
+                if ((ctx->pinned_cache[i].second > kPinnedSmall) != (cls == 1)) continue;
+                count++;
+                if (small == (size_t)-1 || ctx->pinned_cache[i].second < ctx->pinned_cache[small].second) small = i;
+            }
+            if (count <= keep) break;
+            (void)hipHostFree(ctx->pinned_cache[small].first);
+            ctx->pinned_cache.erase(ctx->pinned_cache.begin() + (long)small);
+        }
     }
 }
 
@@ -1226,6 +1249,10 @@ CPH_API int32_t cph_index_build_many(cph_ctx* ctx, const cph_index_spec* specs, 
     if (!specs || !out || nspecs < 1 || nspecs > 64) return fail(ctx, {CPH_ERR_INVALID, "bad cph_index_build_many arguments"});
     std::vector<BuildJob> jobs((size_t)nspecs);
     std::vector<Status> st((size_t)nspecs);
+    // every job may take one SplitSample of report words + a few single ones, all read by the host only at the batch's
+    // synchronisation points: they must not wrap around the ring inside this call (64 jobs x 600 words < kHostWords)
+    if (!host_words_reserve(ctx, (uint32_t)nspecs * (uint32_t)(codec_sample_bytes() / 4 + 16)))
+        return fail(ctx, {CPH_ERR_INVALID, "cph_index_build_many: the batch needs more report words than the ctx holds"});
     // Two streams for a batch: every second build is enqueued on the side stream, so a small table's launch-latency-bound
     // kernels (products: 1e5 rows, ~15 launches of a few microseconds of work each) run inside the gaps and beside the kernels
     // of its neighbour (customers: 1e7 rows) instead of behind them.  Both streams are idle again when the call returns.

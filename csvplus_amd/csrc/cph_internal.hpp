@@ -390,9 +390,14 @@ struct cph_ctx {
 };
 
 namespace cph {
-constexpr uint32_t kHostWords = 16384;
-// n consecutive report words (8-byte aligned), zeroed by the host; nullptr when the block could not be allocated
+constexpr uint32_t kHostWords = 65536;
+// n consecutive report words (8-byte aligned), zeroed by the host; nullptr when the block could not be allocated.  The ring
+// wraps without looking: a word is in use for ONE API call only, so a call that takes many of them (a batch of builds: up to
+// 64 jobs x one SplitSample each) first makes sure they fit in front of the wrap point (host_words_reserve) — no word handed out
+// inside a call is ever handed out again before the call returns.
 uint32_t* host_word(cph_ctx* ctx, uint32_t n = 1);
+// at an API call's entry (nothing outstanding): the next `n` words will come without a wrap; false if n can never fit
+bool host_words_reserve(cph_ctx* ctx, uint32_t n);
 // a zeroed device block of at least `bytes` for a self-cleaning accumulator (allocated / grown on demand: one memset and
 // one synchronisation, once)
 Status self_clean_block(cph_ctx* ctx, cph::DevBuf* b, size_t bytes);

@@ -120,9 +120,44 @@ func (s *staging) stage(ctx *C.cph_ctx, rows []Row, columns []string) ([]C.cph_s
 // gpuIndex keeps the device twin of index.impl.rows' key columns alive (a field `gpu *gpuIndex` of Index).
 // side: columns of impl.rows staged once, in SORTED order (row i = impl.rows[i]), for chains whose later key is a column of
 // THIS index's rows (cph_chain_step.source < 0: join.go columnOrigin / fusedBatch); a nil entry = some row lacks the column.
+// presence: per column name, how many rows of impl.rows carry it (all / none / some) — one walk over the rows per column,
+// then the answer is a map lookup per batch (join.go columnOrigin asks once per 8192 stream rows and earlier index).
+// Both maps die with the gpuIndex: whatever replaces impl.rows (ResolveDuplicates) builds a new device twin.
 type gpuIndex struct {
-	h    *C.cph_index
-	side map[string]*sideColumn
+	h        *C.cph_index
+	side     map[string]*sideColumn
+	presence map[string]int8
+}
+
+const (
+	colNone int8 = iota
+	colSome
+	colAll
+)
+
+// columnPresence: colAll / colNone / colSome for column `name` over index.impl.rows, cached.  Call with gpuMu held.
+func (index *Index) columnPresence(name string) int8 {
+	g := index.gpu
+	if g.presence == nil {
+		g.presence = map[string]int8{}
+	}
+	if p, seen := g.presence[name]; seen {
+		return p
+	}
+	have := 0
+	for _, r := range index.impl.rows {
+		if _, ok := r[name]; ok {
+			have++
+		}
+	}
+	p := colSome
+	if have == 0 {
+		p = colNone
+	} else if have == len(index.impl.rows) {
+		p = colAll
+	}
+	g.presence[name] = p
+	return p
 }
 
 // sideColumn is one column of an index's rows as pinned SoA (its blocks live as long as the index: they are freed by the
@@ -145,14 +180,13 @@ func (index *Index) sideColumn(ctx *C.cph_ctx, name string) (*C.cph_strcol, erro
 		return &sc.col, nil
 	}
 	rows := index.impl.rows
+	if index.columnPresence(name) != colAll {
+		g.side[name] = nil // (mergeRows would then take the column from further down the chain, or miss it)
+		return nil, nil
+	}
 	total := 0
 	for _, r := range rows {
-		v, ok := r[name]
-		if !ok {
-			g.side[name] = nil // (mergeRows would then take the column from further down the chain, or miss it)
-			return nil, nil
-		}
-		total += len(v)
+		total += len(r[name])
 	}
 	sc := &sideColumn{}
 	data, err := sc.data.need(ctx, total+8)

@@ -228,21 +228,16 @@ func columnOrigin(spec *chainSpec, k int, col string, batch []Row) int {
 	if have != 0 {
 		return -1
 	}
+	// per (index, column) the answer is cached in the index's device twin (gpu.go columnPresence): the rows of an earlier index
+	// are walked once per column, not once per batch
+	gpuMu.Lock()
+	defer gpuMu.Unlock()
 	for t := 0; t < k; t++ {
-		all := len(spec.steps[t].index.impl.rows) > 0
-		for _, r := range spec.steps[t].index.impl.rows {
-			if _, ok := r[col]; !ok {
-				all = false
-				break
-			}
-		}
-		if all {
+		switch spec.steps[t].index.columnPresence(col) {
+		case colAll:
 			return t + 1
-		}
-		for _, r := range spec.steps[t].index.impl.rows { // SOME rows of an earlier index carry it: no single origin
-			if _, ok := r[col]; ok {
-				return -1
-			}
+		case colSome: // SOME rows of an earlier index carry it: no single origin
+			return -1
 		}
 	}
 	return -1

@@ -6,7 +6,7 @@ mkdir -p gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 ROOTDIR=$(pwd)
 OUT=$ROOTDIR/gpurun_out/prof_$TAG
-ARGS="--extras /dev/null --steps 3 --warmup 1 --no-cpu-baseline --no-index-1e8 --no-verify --no-e2e --no-traffic --no-positions $@"
+ARGS="--extras /dev/null --steps 3 --warmup 1 --no-cpu-baseline --no-index-1e8 --no-verify --no-e2e --no-traffic --no-positions --no-calibration $@"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $ROOTDIR/bench.py $ARGS > $OUT/trace.log 2>&1
 echo "trace rc=$?" >> $OUT/trace.log

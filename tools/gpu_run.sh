@@ -17,8 +17,9 @@ case $R in
 driver)
   TAG=${1:-r06}
   python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-  /usr/bin/time -v timeout 1200 python3 bench.py --gpus 1 --steps 20 --warmup 5 --extras $OUT/${TAG}_bench_full.json > $OUT/bench.out 2> $OUT/bench.err
-  echo "bench rc=$?"; grep "Elapsed (wall clock)" $OUT/bench.err
+  T0=$(date +%s)
+  timeout 1200 python3 bench.py --gpus 1 --steps 20 --warmup 5 --extras $OUT/${TAG}_bench_full.json > $OUT/bench.out 2> $OUT/bench.err
+  echo "bench rc=$? wall $(( $(date +%s) - T0 )) s"; tail -3 $OUT/bench.err
   tail -1 $OUT/bench.out > $OUT/${TAG}_bench_line.json
   wc -c $OUT/${TAG}_bench_line.json
   python -c "import json,sys; d=json.load(open('$OUT/${TAG}_bench_line.json')); print(json.dumps(d, indent=1)[:6000])"

@@ -28,7 +28,7 @@ for f in root.glob("trace/**/*kernel_trace.csv"):
         launches[k].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
 # the per-launch durations of the kernel with the largest total (the one `roofline` is quoted on): small enough to be tracked
 if dur:
-    dom = max(dur.items(), key=lambda kv: kv[1][1])[0]
+    dom = max(((k, v) for k, v in dur.items() if not k.startswith("k_cal_")), key=lambda kv: kv[1][1], default=(None, None))[0] or max(dur.items(), key=lambda kv: kv[1][1])[0]
     rows = sorted(launches[dom])
     with open(root / "dominant_kernel_launches.csv", "w") as fh:
         fh.write(f"# {dom}\nlaunch,duration_us\n")
