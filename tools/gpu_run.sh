@@ -9,6 +9,7 @@
 #   fuzz [seconds]      the three differential fuzzers
 #   bench <args>        bench.py with the given arguments (line + full record kept under gpurun_out/bench/)
 #   py <script> [args]  any python script (microbenchmarks under tools/microbench/)
+#   csv [rows]          CSV / materialisation tests + tools/microbench/csv_ingest.py and pipeline.py (default 5e7 rows)
 export TMPDIR=/tmp
 R=${1:-driver}; shift
 OUT=gpurun_out/$R
@@ -50,6 +51,12 @@ bench)
   ;;
 py)
   timeout 1500 python "$@" 2>&1 | grep -v amdgpu.ids | tee $OUT/$(basename $1 .py).txt | tail -60
+  ;;
+csv)
+  ROWS=${1:-5e7}
+  timeout 900 python -m pytest tests/test_csv_ingest.py tests/test_materialize.py -m gpu -x -q 2>&1 | tail -3
+  timeout 600 python tools/microbench/csv_ingest.py $ROWS 2>&1 | grep -v amdgpu.ids | tee $OUT/csv_ingest.txt | tail -12
+  timeout 600 python tools/microbench/pipeline.py $ROWS 2>&1 | grep -v amdgpu.ids | tee $OUT/pipeline.txt | tail -24
   ;;
 *)
   echo "unknown recipe $R"; exit 2;;
