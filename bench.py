@@ -84,7 +84,7 @@ def parse_args():
                     help="skip the `variants` block: the same step (2 index builds + chained Join of all rows) on other key shapes — "
                          "unpadded Itoa ids, a half-occupied id space, sparse random keys — and with the payload columns laid out in "
                          "index order (cph_index_permute)")
-    ap.add_argument("--variants", default="all", help="comma list out of: itoa,half,sparse,side,permute (default all)")
+    ap.add_argument("--variants", default="all", help="comma list out of: itoa,half,sparse,side,permute,dup (default all)")
     ap.add_argument("--verify-sample", type=int, default=100_000)
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the two rocprofv3 --pmc child runs (FETCH_SIZE, WRITE_SIZE) behind roofline.traffic")
@@ -1041,13 +1041,15 @@ def main():
         #   half     8-byte ids over a HALF-occupied id space (1e7 ids drawn from [0, 2e7)): no identity, every key goes through the
         #            rank table of a code space twice the index
         #   sparse   12 random [a-z0-9] characters: a 62-bit code space, the radix sort and the hash probe
+        #   dup      people.Join(IndexOn(orders.cust_id) over all orders rows).Join(products keyed by the orders row): a NON-unique build
+        #            side — probe -> scan -> k_expand and the pre-joined second step (csvplus_test.go:252-285, 1161-1186)
         #   permute  the timed step + cph_index_permute of customers(name, surname) and products(product, price): what a consumer of
         #            positions pays per build to have its payload rows in index order (csvplus.go:736 moves the rows themselves)
         if world == 1 and not args.no_variants:
             from csvplus_amd import verify as V
             from csvplus_amd.engine import device_view
 
-            want = {"itoa", "half", "sparse", "side", "permute"} if args.variants == "all" else set(args.variants.split(","))
+            want = {"itoa", "half", "sparse", "side", "permute", "dup"} if args.variants == "all" else set(args.variants.split(","))
             variants = {}
 
             def run_variant(name, what, v_cust, v_ocust, extra_build=None, sample_check=True, side_key=None):
@@ -1213,6 +1215,128 @@ def main():
                     "every step: the payload rows in index order, what a consumer of sorted positions needs per build (csvplus.go:736 moves "
                     "the rows; :553-567 reads index.impl.rows[i])", cust_id, ords["cust_id"], extra_build=lay_out))
                 del cust_pay, prod_pay
+            if "dup" in want:
+                def dup_build_side():
+                    """people(1e7).Join(IndexOn(orders.cust_id) over ALL orders rows, "id").Join(UniqueIndexOn(products.prod_id), prod_id of the
+                    ORDERS row): the reference's TestLongChain / BenchmarkJoinOnBiggerMultiIndex shape (csvplus_test.go:252-285, 1161-1186;
+                    csvplus.go:559 emits EVERY equal index row, in ascending index position) — a non-unique build side 10x the stream, so the
+                    Join is probe -> scan -> k_expand, and the second Join reads its key from the orders row the first one
+                    matched (cph_chain_step.source = 1), answered from the orders table joined with the products index once."""
+                    torch.cuda.empty_cache()
+                    d_people = cust_id.to_device(dev)        # people.id: the same 1e7 distinct 8-byte ids
+
+                    def chain_of(io, ip):
+                        return [(io, [d_people]), (ip, [d_ord["prod_id"]], 1)]
+
+                    def dstep():
+                        io, ip = eng.index_on_many([[d_ord["cust_id"]], [d_prod]], unique=[False, True])
+                        c = N.join_chain(eng.ctx, chain_of(io, ip), out_mem=N.CPH_MEM_DEVICE, positions=True)
+                        n_ = c.nrows
+                        dstep.info = (io.info(), ip.info())
+                        c.release(); io.close(); ip.close()
+                        return n_
+
+                    for _ in range(max(1, args.warmup)):
+                        dstep()
+                    torch.cuda.synchronize(dev)
+                    t0_ = time.perf_counter()
+                    for _ in range(args.steps):
+                        nj = dstep()
+                    torch.cuda.synchronize(dev)
+                    dt_ = (time.perf_counter() - t0_) / args.steps
+                    eng.ctx.profile(True)
+                    eng.ctx.profile_read(reset=True)
+                    dstep()
+                    pb_ = eng.ctx.profile_read(reset=True)
+                    eng.ctx.profile(False)
+                    # the Join alone, indexes resident (what a caller that keeps its Index pays per Join)
+                    io, ip = eng.index_on_many([[d_ord["cust_id"]], [d_prod]], unique=[False, True])
+                    N.join_chain(eng.ctx, chain_of(io, ip), out_mem=N.CPH_MEM_DEVICE, positions=True).release()
+                    torch.cuda.synchronize(dev)
+                    t0_ = time.perf_counter()
+                    for _ in range(args.steps):
+                        N.join_chain(eng.ctx, chain_of(io, ip), out_mem=N.CPH_MEM_DEVICE, positions=True).release()
+                    torch.cuda.synchronize(dev)
+                    join_ms = (time.perf_counter() - t0_) / args.steps * 1e3
+                    t0_ = time.perf_counter()
+                    for _ in range(args.steps):
+                        N.join_chain(eng.ctx, [(io, [d_people])], out_mem=N.CPH_MEM_DEVICE, positions=True).release()
+                    torch.cuda.synchronize(dev)
+                    join1_ms = (time.perf_counter() - t0_) / args.steps * 1e3
+                    join_names = ("k_probe_table", "k_probe_rank", "k_probe", "k_probe_fast", "exclusive_scan_u64", "k_expand", "k_chain_prejoin_table",
+                                  "k_prejoin_tuples", "k_sum_counts", "k_compose")
+                    jk_ms = sum(pb_[k]["total_ms"] for k in join_names if k in pb_)
+                    # byte model of the two Joins (per launch set): stream keys in; (lo, cnt) per stream row written and read back by the scan /
+                    # expand; per pair 8 B stream row + 4 B position out; the orders table's prod_id column + offsets in and 4 B out per
+                    # orders row (table pass); per tuple position 4 + perm 4 + table entry 4 in, 4 out
+                    npeople = args.customers
+                    s_in = cust_id.nbytes_values() + cust_id.nbytes_offsets() + 16.0 * npeople
+                    pairs = 12.0 * nj
+                    tpass = host_bytes["prod_id"] + ords["prod_id"].nbytes_offsets() + 4.0 * nloc
+                    tup = 16.0 * nj
+                    algo = s_in + pairs + tpass + tup
+                    blk = {"what": "people(%d).Join(IndexOn(orders.cust_id) over %d rows, id).Join(UniqueIndexOn(products.prod_id), prod_id of the ORDERS row): "
+                                   "a NON-unique build side (csvplus_test.go:252-285, 1161-1186; csvplus.go:559); step = both builds + the chain" % (npeople, nloc),
+                           "ms_per_step": round(dt_ * 1e3, 4), "value": nj / dt_, "unit": "rows/s", "joined_rows_per_step": nj,
+                           "timed_step_over_this": round(ms_per_step / (dt_ * 1e3), 3),
+                           "k_chain_dense_ms": round(jk_ms, 4),
+                           "join_only_ms": round(join_ms, 4), "first_join_only_ms": round(join1_ms, 4),
+                           "first_join_pairs_per_s": nj / (join1_ms / 1e3),
+                           "kernels_ms": {k: round(v["total_ms"], 4) for k, v in sorted(pb_.items(), key=lambda kv: -kv[1]["total_ms"])},
+                           "customers_index": dstep.info[0],
+                           "roofline": {"kernel": "probe + scan + k_expand + k_chain_prejoin_table + k_prejoin_tuples (the two Joins' kernels, summed)",
+                                        "algorithmic_bytes_per_launch": round(algo),
+                                        "bytes_model": {"stream_keys_and_bounds": round(s_in), "pairs_out": round(pairs), "table_pass": round(tpass),
+                                                        "tuples": round(tup)},
+                                        "achieved": round(algo / 1e9 / (jk_ms / 1e3), 1) if jk_ms else None, "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+                                        "frac": round(algo / 1e9 / (jk_ms / 1e3) / HBM_PEAK_GBPS, 4) if jk_ms else None}}
+                    if not args.no_verify:
+                        ch_ = N.join_chain(eng.ctx, chain_of(io, ip), out_mem=N.CPH_MEM_DEVICE, positions=True)
+                        p_ = ch_.device_ptrs()
+                        n_ = ch_.nrows
+                        srow = device_view(p_["stream_row"], n_, "<i8", ch_, dev) if p_["stream_row"] else None
+                        pos0 = device_view(p_["build_row"][0], n_, "<i4", ch_, dev).long() & 0xFFFFFFFF
+                        pos1 = device_view(p_["build_row"][1], n_, "<i4", ch_, dev).long() & 0xFFFFFFFF
+                        ver_ = {"joined_rows": n_, "every_order_joined_once": n_ == nloc}
+                        ok_ = n_ == nloc and srow is not None
+                        if ok_:
+                            # emission order (csvplus.go:553-567): stream rows ascend; inside one stream row the index positions ascend by one;
+                            # every index position is emitted exactly once (the positions of all pairs are a permutation of 0..n-1)
+                            same = srow[1:] == srow[:-1]
+                            ver_["stream_rows_ascend"] = bool((srow[1:] >= srow[:-1]).all().item())
+                            ver_["positions_consecutive_inside_a_stream_row"] = bool((pos0[1:][same] == pos0[:-1][same] + 1).all().item())
+                            seen = torch.zeros(n_, dtype=torch.bool, device=dev)
+                            seen[pos0] = True
+                            ver_["every_index_position_once"] = bool(seen.all().item())
+                            del seen, same
+                            rows_ = V.sample_rows(n_, args.verify_sample)
+                            idx_ = torch.from_numpy(rows_).to(dev)
+                            permo = device_view(io.perm_device_ptr(), io.nrows, "<i4", io, dev)
+                            permp = device_view(ip.perm_device_ptr(), ip.nrows, "<i4", ip, dev)
+                            orow = (permo[pos0[idx_]].long() & 0xFFFFFFFF)
+                            prow = (permp[pos1[idx_]].long() & 0xFFFFFFFF).cpu().numpy()
+                            srs = srow[idx_].cpu().numpy()
+                            orow_h = orow.cpu().numpy()
+                            ver_["sample_rows"] = int(rows_.size)
+                            # the orders row a pair names carries the person's id; the product it names carries that orders row's prod_id
+                            ver_["cust_key_mismatches"] = V.check_join_sample(cust_id, ords["cust_id"], orow_h, srs)
+                            ver_["prod_key_mismatches"] = V.check_join_sample(ords["prod_id"], prod_id, prow, orow_h)
+                            ver_["digest_positions_0"] = f"{V.digest_u64(pos0):016x}"
+                            ok_ = (ver_["stream_rows_ascend"] and ver_["positions_consecutive_inside_a_stream_row"] and ver_["every_index_position_once"]
+                                   and ver_["cust_key_mismatches"] == 0 and ver_["prod_key_mismatches"] == 0)
+                            del permo, permp, idx_
+                        ver_["index_orders"] = V.check_index_order(d_ord["cust_id"], device_view(io.perm_device_ptr(), io.nrows, "<i4", io, dev))
+                        ok_ = ok_ and bool(ver_["index_orders"].get("ok"))
+                        del srow, pos0, pos1
+                        ch_.release()
+                        blk["verified"] = bool(ok_)
+                        blk["verify"] = ver_
+                    io.close(); ip.close()
+                    del d_people
+                    torch.cuda.empty_cache()
+                    return blk
+
+                guarded("dup_build_side", dup_build_side)
             out["variants"] = variants
             out["variants_note"] = ("the SAME step as `value` (both index builds + the chained Join of all %d rows, sorted positions out) on other key "
                                     "shapes, each timed over %d steps between synchronisations and verified like `value`; reported beside it" % (args.rows, args.steps))

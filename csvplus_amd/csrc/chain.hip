@@ -622,6 +622,82 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_prejoined(PrejoinArgs a
     }
 }
 
+
+// ---- general path: a unique-index step keyed by an EARLIER BUILD TABLE, answered from a pre-joined table -----------------------
+// (round 6) people.Join(IndexOn(orders.cust_id), "id").Join(products, prod_id of the ORDERS row) — csvplus_test.go:280-285 with a
+// NON-unique first index (csvplus.go:559 emits every equal index row): the tuples in front of the second Join are pairs, the fast
+// path does not apply, and per tuple the generic probe gathered perm + offsets + key bytes of the orders row (three random sectors,
+// 4.5-5.2 ms per 1e8 tuples).  The table that step reads is joined with the products index ONCE instead (one dense, streaming pass over
+// its nt rows: tab[row] = what the step finds), then a tuple costs one 4-byte gather; nothing is compacted when every tuple survives.
+constexpr int kPjThreads = 256, kPjItems = 8, kPjTile = kPjThreads * kPjItems;
+// perm != nullptr: the tuples hold sorted positions and the table is in its original row order (row = perm[position]; the positions of one
+// stream row's matches are consecutive, so these reads are nearly sequential)
+__global__ __launch_bounds__(kPjThreads) void k_prejoin_tuples(const uint32_t* __restrict__ tab, const uint32_t* __restrict__ h,
+                                                              const uint32_t* __restrict__ perm, uint64_t n,
+                                                              uint32_t* __restrict__ out_v, uint32_t* __restrict__ tile_counts) {
+    __shared__ uint32_t s_w[kPjThreads / kWave];
+    const uint64_t base = (uint64_t)blockIdx.x * kPjTile;
+    uint32_t hv[kPjItems], v[kPjItems];
+#pragma unroll
+    for (int k = 0; k < kPjItems; k++) {
+        const uint64_t i = base + (uint64_t)k * kPjThreads + threadIdx.x;
+        hv[k] = i < n ? __builtin_nontemporal_load(h + i) : 0u;   // (row 0 of the table exists)
+    }
+    if (perm) {   // uniform
+#pragma unroll
+        for (int k = 0; k < kPjItems; k++) hv[k] = perm[hv[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < kPjItems; k++) v[k] = tab[hv[k]];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kPjItems; k++) {
+        const uint64_t i = base + (uint64_t)k * kPjThreads + threadIdx.x;
+        if (i < n) {
+            __builtin_nontemporal_store(v[k], out_v + i);
+            cnt += v[k] != kTableAbsent ? 1u : 0u;
+        }
+    }
+    cnt = wave_sum(cnt);
+    if (lane_id() == 0) s_w[wave_id()] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < kPjThreads / kWave; w++) t += s_w[w];
+        tile_counts[blockIdx.x] = t;
+    }
+}
+// the surviving tuples (v != absent) move to their final slots, in order: thread t owns kPjItems CONSECUTIVE tuples of the tile
+struct PjCompactArgs {
+    int32_t n32;
+    const uint32_t* src32[CPH_MAX_CHAIN];
+    uint32_t* dst32[CPH_MAX_CHAIN];
+    const uint64_t* src64;
+    uint64_t* dst64;
+};
+__global__ __launch_bounds__(kPjThreads) void k_prejoin_compact(PjCompactArgs a, const uint32_t* __restrict__ v, uint64_t n,
+                                                               const uint32_t* __restrict__ tile_base) {
+    __shared__ uint32_t s_tmp[kPjThreads / kWave + 1];
+    const uint64_t i0 = (uint64_t)blockIdx.x * kPjTile + (uint64_t)threadIdx.x * kPjItems;
+    uint32_t keep = 0, mine = 0;
+#pragma unroll
+    for (int k = 0; k < kPjItems; k++)
+        if (i0 + k < n && v[i0 + k] != kTableAbsent) {
+            keep |= 1u << k;
+            mine++;
+        }
+    uint32_t total;
+    uint32_t run = block_exclusive_sum<uint32_t, kPjThreads>(mine, s_tmp, &total);   // syncs inside
+    uint64_t o = (uint64_t)tile_base[blockIdx.x] + run;
+#pragma unroll
+    for (int k = 0; k < kPjItems; k++) {
+        if (!((keep >> k) & 1u)) continue;
+        a.dst64[o] = a.src64[i0 + k];
+        for (int j = 0; j < a.n32; j++) a.dst32[j][o] = a.src32[j][i0 + k];
+        o++;
+    }
+}
+
 bool chain_fast_path_ok(const ChainStep* steps, int nsteps) {
     if (nsteps > kMaxChain) return false;   // longer chains: the general path below, on the device, in the same call
     for (int s = 0; s < nsteps; s++) {
@@ -1017,6 +1093,76 @@ static Status run_fast(cph_ctx* ctx, const ChainStep* steps, uint64_t nprobe, ui
     return {};
 }
 
+// One step of the general path through a pre-joined table (k_prejoin_tuples / k_prejoin_compact above).  h = the row of table t
+// every tuple reads its key from (the handle the step's columns are indexed by); *n tuples in, *n out.
+static Status prejoin_general_step(cph_ctx* ctx, const ChainStep* steps, int s, int t, const uint32_t* h, const uint32_t* h_perm, uint64_t n_in, bool positions,
+                                   DevBuf* cur_stream, DevBuf* cur_rows, uint64_t* n_out, bool* all) {
+    const uint64_t nt = steps[s].cols[0].nrows;
+    // the table pass: tab[row of table t] = the sorted position / build row this step finds for that row's key, or absent
+    ChainStep one = steps[s];
+    one.source = 0;
+    DevBuf tab, tmask, tcount;
+    CPH_TRY(tab.alloc(&ctx->pool, nt * sizeof(uint32_t)));
+    CPH_TRY(tmask.alloc(&ctx->pool, chain_dense_mask_words(nt) * sizeof(uint64_t)));
+    CPH_TRY(tcount.alloc(&ctx->pool, chain_dense_count_words(nt) * sizeof(uint32_t)));
+    CPH_HIP_TRY(hipMemsetAsync(tab.get(), 0xFF, nt * sizeof(uint32_t), ctx->stream));   // the dense pass stores matches only
+    uint32_t* r1[kMaxChain] = {tab.as<uint32_t>(), nullptr, nullptr, nullptr};
+    CPH_TRY(enqueue_dense<1>(ctx, &one, nt, 0, r1, tmask.as<uint64_t>(), tcount.as<uint32_t>(), nullptr, nullptr, nullptr, positions, nullptr,
+                             "k_chain_prejoin_table"));
+    const uint64_t ntiles = (n_in + kPjTile - 1) / kPjTile;
+    DevBuf v, counts;
+    CPH_TRY(v.alloc(&ctx->pool, n_in * sizeof(uint32_t)));
+    CPH_TRY(counts.alloc(&ctx->pool, (ntiles + 1) * sizeof(uint32_t)));
+    volatile uint64_t* host_total = reinterpret_cast<volatile uint64_t*>(host_word(ctx, 2));
+    if (!host_total) return {CPH_ERR_HIP, "no pinned host memory for the match total"};
+    {
+        ProfScope ps(ctx, "k_prejoin_tuples", (double)n_in * (h_perm ? 16.0 : 12.0));
+        hipLaunchKernelGGL(k_prejoin_tuples, dim3((unsigned)ntiles), dim3(kPjThreads), 0, ctx->stream, tab.as<uint32_t>(), h, h_perm, n_in, v.as<uint32_t>(),
+                           counts.as<uint32_t>());
+        CPH_HIP_TRY(hipGetLastError());
+    }
+    {
+        DevBuf& acc = ctx->self_clean[ctx->stream_slot].sum;
+        CPH_TRY(self_clean_block(ctx, &acc, 16));
+        ProfScope ps(ctx, "k_sum_counts", 4.0 * (double)ntiles);
+        const unsigned sgrid = (unsigned)std::min<uint64_t>((ntiles + 255) / 256, 512);
+        hipLaunchKernelGGL(k_sum_counts_report, dim3(sgrid), dim3(256), 0, ctx->stream, counts.as<uint32_t>(), ntiles, acc.as<unsigned long long>(),
+                           acc.as<uint32_t>() + 2, reinterpret_cast<unsigned long long*>(const_cast<uint64_t*>(host_total)));
+        CPH_HIP_TRY(hipGetLastError());
+    }
+    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const uint64_t m = host_total[0];
+    *all = m == n_in;
+    *n_out = m;
+    if (m == n_in) {   // every tuple survived: the step only adds its column
+        cur_rows[s] = std::move(v);
+        return {};
+    }
+    if (m == 0) return {};
+    CPH_TRY(exclusive_scan_u32(ctx, counts.as<uint32_t>(), ntiles));
+    PjCompactArgs ca{};
+    DevBuf nstream, nrows[CPH_MAX_CHAIN];
+    CPH_TRY(nstream.alloc(&ctx->pool, m * sizeof(uint64_t)));
+    ca.src64 = cur_stream->as<uint64_t>();
+    ca.dst64 = nstream.as<uint64_t>();
+    for (int u = 0; u < s; u++) {
+        CPH_TRY(nrows[u].alloc(&ctx->pool, m * sizeof(uint32_t)));
+        ca.src32[ca.n32] = cur_rows[u].as<uint32_t>();
+        ca.dst32[ca.n32++] = nrows[u].as<uint32_t>();
+    }
+    CPH_TRY(nrows[s].alloc(&ctx->pool, m * sizeof(uint32_t)));
+    ca.src32[ca.n32] = v.as<uint32_t>();
+    ca.dst32[ca.n32++] = nrows[s].as<uint32_t>();
+    {
+        ProfScope ps(ctx, "k_compose", (double)n_in * (12.0 + 4.0 * s) + (double)m * (12.0 + 4.0 * s));
+        hipLaunchKernelGGL(k_prejoin_compact, dim3((unsigned)ntiles), dim3(kPjThreads), 0, ctx->stream, ca, v.as<uint32_t>(), n_in, counts.as<uint32_t>());
+        CPH_HIP_TRY(hipGetLastError());
+    }
+    *cur_stream = std::move(nstream);
+    for (int u = 0; u <= s; u++) cur_rows[u] = std::move(nrows[u]);
+    return {};
+}
+
 Status chain_run(cph_ctx* ctx, const ChainStep* steps, int nsteps, uint64_t probe_base, ChainOut* out, bool positions) {
     const uint64_t nprobe = steps[0].cols[0].nrows;
     out->nrows = 0;
@@ -1050,6 +1196,20 @@ Status chain_run(cph_ctx* ctx, const ChainStep* steps, int nsteps, uint64_t prob
         // in that step's build table (cph_chain_step.source; mergeRows put that row's columns into the row this Join sees)
         RowSel sel;
         DevBuf src_rows;
+        // (round 6) a duplicate-free single-column index keyed by an earlier build table whose rows are not many more than the tuples:
+        // join the TABLE with this index once (dense pass), then one 4-byte gather per tuple
+        if (steps[s].source != 0 && ctx->chain_prejoin != 0 && n < (1ull << 32) && chain_fast_path_ok(&steps[s], 1) &&
+            steps[s].index->codec_dev.bytes() <= 150 * 1024) {
+            const int t = (steps[s].source < 0 ? -steps[s].source : steps[s].source) - 1;
+            const uint64_t nt = steps[s].cols[0].nrows;
+            if (nt <= 2 * n && nt == steps[t].index->nrows) {
+                bool survived_all = false;
+                CPH_TRY(prejoin_general_step(ctx, steps, s, t, cur_rows[t].as<uint32_t>(),
+                                             steps[s].source > 0 && positions ? steps[t].index->perm.as<uint32_t>() : nullptr, n, positions,
+                                             &cur_stream, cur_rows, &n, &survived_all));
+                continue;
+            }
+        }
         if (steps[s].source == 0) {
             sel.ptr = cur_stream.get();
             sel.bits = 64;

@@ -91,10 +91,12 @@ class Engine:
             raise N.CphError(N.CPH_ERR_DUPLICATE, self.ctx.last_error())
         return ix
 
-    def index_on_many(self, specs, unique: bool = False) -> list:
-        """Several IndexOn / UniqueIndexOn calls as one batch (cph_index_build_many): specs = [keycols, ...]."""
-        res = N.DeviceIndex.build_many(self.ctx, [(cols, unique) for cols in specs])
-        if unique and any(ix.status == N.CPH_ERR_DUPLICATE for ix in res):
+    def index_on_many(self, specs, unique=False) -> list:
+        """Several IndexOn / UniqueIndexOn calls as one batch (cph_index_build_many): specs = [keycols, ...]; unique: one flag for
+        all of them or one per spec."""
+        flags = list(unique) if isinstance(unique, (list, tuple)) else [bool(unique)] * len(specs)
+        res = N.DeviceIndex.build_many(self.ctx, [(cols, u) for cols, u in zip(specs, flags)])
+        if any(u and ix.status == N.CPH_ERR_DUPLICATE for u, ix in zip(flags, res)):
             msg = self.ctx.last_error()
             for ix in res:
                 ix.close()

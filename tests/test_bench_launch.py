@@ -166,7 +166,7 @@ def test_the_stdout_line_is_small_and_last(tmp_path):
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0 and d["roofline"]["unit"] == "GB/s"
     cb = d["cpu_baseline"]
     assert cb["value"] > 0 and cb["cores"] == 1 and cb["kind"] == "port" and 0 < len(cb["sample"]) <= 200
-    assert set(d["roofline"]["variants"]) >= {"itoa_ids", "half_occupied_ids", "sparse_random_keys", "build_side_key", "step_plus_permute"}
+    assert set(d["roofline"]["variants"]) >= {"itoa_ids", "half_occupied_ids", "sparse_random_keys", "build_side_key", "step_plus_permute", "dup_build_side"}
     assert all(v[3] is True for v in d["roofline"]["variants"].values()), d["roofline"]["variants"]
     assert d["verified"] is True and d["extras"] == str(extras)
     f = json.loads(extras.read_text())

@@ -161,3 +161,33 @@ def test_source_errors(ctx):
     ch = join_chain(ctx, [(a, s, 0), (b, good, 1)])
     assert ch.nrows == 2 and list(ch.build_row(1)) == [0, 0]
     ch.release()
+
+
+@pytest.mark.parametrize("missing", [False, True])
+@pytest.mark.parametrize("layout", ["itoa", "fixed"])
+def test_duplicate_first_index_second_key_from_its_rows_is_prejoined(ctx, missing, layout):
+    """(round 6) people.Join(IndexOn(orders.cust_id), "id").Join(UniqueIndexOn(products), prod_id of the ORDERS row) at a size where the
+    general path answers the second Join from a table joined with the products index once (chain.hip: prejoin_general_step) instead
+    of probing per tuple — bit-exact either way; with `missing` some orders name products that do not exist (tuples are dropped:
+    the compaction pass) and some people have no orders."""
+    rng = np.random.default_rng(61 + missing)
+    npeople, nord, nprod = 4000, 50_000, 300
+    fmt = (lambda p, v: b"%s%06d" % (p, v)) if layout == "fixed" else (lambda p, v: b"%s%d" % (p, v))
+    people = [fmt(b"", i) for i in rng.permutation(npeople + 500)[:npeople]]
+    o_cust = [fmt(b"", i) for i in rng.integers(0, npeople + 500, nord)]
+    o_prod = [fmt(b"p", i) for i in rng.integers(0, nprod + (60 if missing else 0), nord)]
+    prods = [fmt(b"p", i) for i in rng.permutation(nprod)]
+    mk = StrCol.from_values
+    builds = [[mk(o_cust)], [mk(prods)]]
+    steps = [([mk(people)], 0), ([mk(o_prod)], 1)]
+    gix = [DeviceIndex(ctx, b) for b in builds]
+    ctx.profile(True)
+    ctx.profile_read(reset=True)
+    ch = join_chain(ctx, [(gix[0], steps[0][0], 0), (gix[1], steps[1][0], 1)], positions=bool(missing))
+    prof = ctx.profile_read(reset=True)
+    ctx.profile(False)
+    assert "k_prejoin_tuples" in prof and "k_chain_prejoin_table" in prof, sorted(prof)
+    assert ("k_compose" in prof) == missing, sorted(prof)      # nothing is compacted when every tuple survives
+    ch.release()
+    n = check(ctx, builds, steps, probe_base=3, expect_fused=False)
+    assert (n < nord) if missing else (0 < n <= nord)
