@@ -11,7 +11,7 @@ CXX     ?= g++
 
 LIBDIR  = csvplus_amd/lib
 CSRC    = csvplus_amd/csrc
-HIP_SRCS = $(CSRC)/capi.hip $(CSRC)/keycodec.hip $(CSRC)/radix_sort.hip $(CSRC)/probe.hip $(CSRC)/chain.hip $(CSRC)/stream_join.hip $(CSRC)/materialize.hip $(CSRC)/csv_ingest.hip $(CSRC)/index_ops.hip $(CSRC)/dist.hip $(CSRC)/calibrate.hip $(CSRC)/small_build.hip $(CSRC)/host_encode.hip $(CSRC)/window_sort.hip
+HIP_SRCS = $(CSRC)/capi.hip $(CSRC)/keycodec.hip $(CSRC)/radix_sort.hip $(CSRC)/probe.hip $(CSRC)/chain.hip $(CSRC)/stream_join.hip $(CSRC)/materialize.hip $(CSRC)/csv_ingest.hip $(CSRC)/index_ops.hip $(CSRC)/dist.hip $(CSRC)/calibrate.hip $(CSRC)/small_build.hip $(CSRC)/host_encode.hip $(CSRC)/window_sort.hip $(CSRC)/counted_sort.hip
 HIP_OBJS = $(patsubst $(CSRC)/%.hip,$(LIBDIR)/obj/%.o,$(HIP_SRCS))
 HIP_HDRS = $(CSRC)/cph_internal.hpp $(CSRC)/device_utils.hpp $(CSRC)/codec_device.hpp $(CSRC)/probe_device.hpp $(CSRC)/hash_device.hpp $(CSRC)/lds_stage.hpp $(CSRC)/host_encode_kernels.hpp include/csvplus_hip.h
 

@@ -864,7 +864,7 @@ def main():
             roofline["traffic_note"] = f"not measured: {note}"
     build_names = ("k_col_stats", "k_encode_build", "k_radix_hist_u32", "k_radix_hist_u64", "k_radix_scatter_u32",
                    "k_radix_scatter_u64", "exclusive_scan_u32", "k_first_dup", "k_build_table", "k_gather_u64", "k_split_count",
-                   "k_direct_scatter", "k_direct_finish", "k_win_partition", "k_win_place")
+                   "k_direct_scatter", "k_direct_finish", "k_win_partition", "k_win_place", "k_cs_hist", "k_cs_scan", "k_cs_partition", "k_cs_window")
     build_ms = sum(kernels[k]["total_ms"] for k in build_names if k in kernels)
     build_gb = sum(kernels[k]["algo_GB"] for k in build_names if k in kernels)
     kernel_ms_per_step = sum(v["total_ms"] / (args.steps if v.get("timed_region") else K) for v in kernels.values())

@@ -498,6 +498,8 @@ struct BuildJob {
     bool no_split = false;       // second attempt after a split codec met a row it could not code (keycodec.hip: codec_try_split)
     uint32_t* miss = nullptr;    // report word (pinned host memory, host_word) raised by the encode kernel of a split / sampled codec and by the
                                  // optimistic direct sort; read after the build's last synchronisation
+    uint32_t* cs_over = nullptr; // counted window sort (counted_sort.hip): report word raised when a window does not fit — nothing was sorted then,
+    DevBuf cs_codes;             // ... and the classic passes run over these (untouched) codes after the build's last synchronisation
 };
 
 static Status build_phase1(cph_ctx* ctx, const cph_strcol* keycols, int32_t nkeycols, BuildJob* job) {
@@ -600,6 +602,7 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
         }
     // ---- sync 2: first duplicates ----
     std::vector<size_t> resplit;   // jobs whose split codec met a row it could not code: once more without the split
+    std::vector<size_t> resort;    // jobs whose counted window sort met a window beyond its capacity: the classic passes over the same codes
     if (any_general) {
         s = ensure_pinned_scratch(ctx, 2 * sizeof(uint32_t) * nj + 64);
         if (!s.ok()) return fail_all(s);
@@ -620,11 +623,38 @@ static void build_run(cph_ctx* ctx, std::vector<BuildJob>& jobs, std::vector<Sta
             if (!status[i].ok() || jobs[i].small) continue;
             cph_index* ix = jobs[i].ix;
             if (jobs[i].miss) sm[i] = *(volatile uint32_t*)jobs[i].miss;   // written by the kernels themselves (pinned host memory)
-            if (sm[i]) { resplit.push_back(i); continue; }
+            if (sm[i]) { jobs[i].cs_codes.reset(); jobs[i].cs_over = nullptr; resplit.push_back(i); continue; }
+            if (jobs[i].cs_over && *(volatile uint32_t*)jobs[i].cs_over) { resort.push_back(i); continue; }
+            jobs[i].cs_codes.reset();
             ix->first_dup = fd[i] != 0xFFFFFFFFu ? (uint64_t)fd[i] : UINT64_MAX;
             ix->first_dup_dev.reset();
             index_plan_table(ix);
         }
+    }
+    for (size_t i : resort) {   // (both streams are idle here; the codes the encode kernel wrote are untouched)
+        BuildJob& j = jobs[i];
+        cph_index* ix = j.ix;
+        const uint64_t n = ix->nrows;
+        j.cs_over = nullptr;
+        ix->sorted_codes.reset(); ix->perm.reset(); ix->first_dup_dev.reset();
+        DevBuf kb, va, vb;
+        Status r = kb.alloc(&ctx->pool, n * sizeof(uint32_t));
+        if (r.ok()) r = va.alloc(&ctx->pool, n * sizeof(uint32_t));
+        if (r.ok()) r = vb.alloc(&ctx->pool, n * sizeof(uint32_t));
+        uint32_t *kout = nullptr, *vout = nullptr;
+        int passes = 0;
+        if (r.ok()) r = radix_sort_pairs<uint32_t>(ctx, j.cs_codes.as<uint32_t>(), kb.as<uint32_t>(), va.as<uint32_t>(), vb.as<uint32_t>(), true, n,
+                                                   ix->codec.word_bits[0], &kout, &vout, &passes);
+        if (r.ok()) {
+            ix->sorted_codes = std::move(kout == j.cs_codes.as<uint32_t>() ? j.cs_codes : kb);
+            ix->perm = std::move(vout == va.as<uint32_t>() ? va : vb);
+            ix->sort_passes = passes;
+            r = index_first_dup_launch(ctx, ix);
+        }
+        if (r.ok()) r = index_first_dup_read(ctx, ix);
+        j.cs_codes.reset();
+        if (r.ok()) index_plan_table(ix);
+        status[i] = r;
     }
     for (size_t i : resplit) {
         std::vector<BuildJob> one;
@@ -885,6 +915,23 @@ static Status build_encode_sort(cph_ctx* ctx, BuildJob* job) {
             // no adjacent-equal scan (first_dup_dev stays empty): either the keys are distinct or the miss word sends the build down the general path
             return {};
         }
+        // duplicates allowed, 32-bit codes, a window of the code space holds a few thousand rows: MSD sort through counted LDS windows
+        // (counted_sort.hip) instead of 3-4 classic passes; the adjacent-equal scan falls out of it
+        CountedSortPlan csp;
+        if (cd.key32 && !job->spec.active && counted_sort_plan(ctx, n, states, &csp)) {
+            uint32_t* over = host_word(ctx);
+            if (!over) return {CPH_ERR_HIP, "no pinned host memory for the report words of a build"};
+            vb.reset();
+            CPH_TRY(codec_encode_build(ctx, cd, ix->codec_dev, dcols, n, ka.get(), &eh, &job->spec, job->miss));
+            CPH_TRY(ix->first_dup_dev.alloc(&ctx->pool, sizeof(uint32_t)));
+            CPH_TRY(counted_sort(ctx, csp, ka.as<uint32_t>(), n, states, va.as<uint32_t>(), kb.as<uint32_t>(), ix->first_dup_dev.as<uint32_t>(), over));
+            job->cs_over = over;
+            job->cs_codes = std::move(ka);
+            ix->sorted_codes = std::move(kb);
+            ix->perm = std::move(va);
+            ix->sort_passes = 0;
+            return {};
+        }
         if (plan.npass > 0) {
             CPH_TRY(counts.alloc(&ctx->pool, plan.count_words() * sizeof(uint32_t)));
             eh.tile_rows = plan.tile;
@@ -996,6 +1043,7 @@ CPH_API int32_t cph_ctx_create(int32_t device_id, cph_ctx** out) {
     warm_index_ops();
     warm_small_build();
     warm_window_sort();
+    warm_counted_sort();
     (void)ensure_pinned_scratch(ctx, 1 << 16);
     void* ring = nullptr;
     (void)pinned_upload(ctx, 64, &ring);
@@ -1052,6 +1100,7 @@ CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value
     else if (k == "stats_sample") ctx->stats_sample = value != 0;
     else if (k == "host_build") ctx->host_build = value != 0;
     else if (k == "host_threads") { ctx->host_threads = value < 0 || value > 256 ? 0 : (int)value; host_pool_destroy(ctx); }
+    else if (k == "counted_sort") ctx->counted_sort = value != 0;
     else if (k == "direct_sort") ctx->direct_sort = value < 0 || value > 4 ? 1 : (int)value;   // 1: LDS windows (window_sort.hip); A/B: 4 plain scatter, 2 partition pass + scatter, 3 the encode kernel fills the slots
     else if (k == "chain_arith") ctx->chain_arith = value != 0;
     else if (k == "chain_identity") ctx->chain_identity = value != 0;

@@ -360,6 +360,7 @@ struct cph_ctx {
         uint64_t tiles = 0, epoch = 0;
         uint32_t tickets = 0;
     } scan[2];                     // one per stream slot (scans of the two streams of a build batch run concurrently)
+    int counted_sort = 1;          // IndexOn over 32-bit codes with duplicates: MSD sort through counted LDS windows (counted_sort.hip); 0: the classic passes
     int direct_sort = 1;           // a build that expects distinct keys (UniqueIndexOn) over a dense 32-bit code space (rows <= states <= 2 rows)
                                    // sorts by ONE scatter, slot[code] = row (radix_sort.hip: direct_sort_distinct); a duplicate is noticed on
                                    // the device and the build starts over the general way (A/B switch)
@@ -612,6 +613,15 @@ template <class K>
 Status radix_sort_pairs(cph_ctx* ctx, K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b, bool vals_iota,
                         uint64_t n, int bits, K** keys_out, uint32_t** vals_out, int* passes,
                         uint32_t* counts = nullptr, bool first_hist_done = false);
+// 32-bit codes WITH duplicates: MSD sort through counted LDS windows (counted_sort.hip); plan() says whether it applies
+struct CountedSortPlan {
+    uint32_t wbits = 0, k2 = 0, nb1 = 0, nwt = 0;
+    bool two = false;
+};
+bool counted_sort_plan(const cph_ctx* ctx, uint64_t n, uint64_t states, CountedSortPlan* p);
+Status counted_sort(cph_ctx* ctx, const CountedSortPlan& p, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out,
+                    uint32_t* sorted_out, uint32_t* first_dup_dev, uint32_t* over_host);
+void warm_counted_sort();
 // distinct 32-bit codes over a dense space: one scatter instead of radix passes (optimistic; *flag raised on a duplicate)
 Status direct_sort_distinct(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out, uint32_t* sorted_out,
                             uint32_t* flag, void* ranktab = nullptr, uint64_t rank_blocks = 0, bool* ranktab_written = nullptr);

@@ -991,7 +991,12 @@ CPH_API int32_t cph_dist_join_chain(cph_dist* d, const cph_chain_step* steps, in
         }
 
         // ---- pipelined: dense chunks, exchange behind the compute ------------------------------------------------------
-        int C = nchunks > 0 ? nchunks : (int)std::min<uint64_t>(8, std::max<uint64_t>(1, maxrows >> 20));
+        // Sub-chunks buy overlap (chunk k travels while chunk k+1 is joined) and cost launches: per chunk one dense pass, its
+        // match total, the absent marks, two events — ~40 us of stream time whatever the chunk's size, against 5 us of join per
+        // million rows.  Round 5 cut every shard of >= 8 M rows into 8: 1.09 ms for a one-rank run of a 0.76 ms step.  Now a
+        // chunk holds at least 2^24 rows (80 us of join), and a communicator of ONE rank that keeps its result on the device has
+        // nothing to overlap at all: one chunk.
+        int C = nchunks > 0 ? nchunks : (n == 1 && !to_host) ? 1 : (int)std::min<uint64_t>(8, std::max<uint64_t>(1, maxrows >> 24));
         st.chunks = C;
         st.pipelined = C > 1;
         if (!d->xstream) CPH_HIP_TRY(hipStreamCreateWithFlags(&d->xstream, hipStreamNonBlocking));

@@ -436,7 +436,8 @@ CPH_API int32_t cph_dist_chain_allgather(cph_dist* d, const cph_chain* chain, ui
  * The sharded chained Join in ONE call, its exchange pipelined behind the compute (round 4; csvplus.go:553-567 — rows are
  * independent, so a shard may be cut anywhere).  `steps` describe THIS rank's shard of the stream (its rows are stream rows
  * [probe_base, probe_base + nrows)); every rank passes the same chain.  The shard is cut into `nchunks` sub-chunks (0: the
- * library picks, 1..8 by shard size; the same value on every rank) and chunk k's rows travel while chunk k+1 is being joined:
+ * library picks — one chunk per 2^24 rows of the largest shard, 1..8, and ONE for a single-rank communicator that keeps the result
+ * on the device; the same value on every rank) and chunk k's rows travel while chunk k+1 is being joined:
  *   - default: to every peer over xGMI (RCCL send/recv batches on a second stream), straight into their final place in
  *     the gathered arrays — every rank ends up with the whole list in device memory, as with cph_dist_chain_allgather;
  *   - CPH_DIST_HOST_GATHER: each rank copies its chunks device -> host into ITS range of one host buffer that all ranks

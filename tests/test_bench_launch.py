@@ -233,3 +233,17 @@ def test_a_failing_extra_block_does_not_cost_the_line():
     d = _json_line(r.stdout)
     assert d["extras_error"].startswith("RuntimeError: CPH_BENCH_FAIL_EXTRAS") and d["verified"] is False
     assert d["value"] > 0 and d["ms_per_step"] > 0 and d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
+
+
+@pytest.mark.gpu
+def test_one_rank_run_of_the_multi_gpu_path_at_bench_size():
+    """The N > 1 step (communicator, cph_dist_join_chain, match totals over the exchange stream) with ONE rank at the bench's own size must
+    cost little more than the plain step: round 5 measured 1.09 ms against 0.76 ms (8 sub-chunks of a shard that has nobody to send to);
+    the library now sizes its sub-chunks by the shard (dist.hip) — efficiency_vs_n1 = n1 step / this step >= 0.88."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-index-1e8", "--no-e2e",
+                        "--no-traffic", "--no-verify", "--no-variants", "--no-positions", "--no-calibration"],
+                       env=_env(CPH_BENCH_FORCE_DIST="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert d["joined_rows_per_step"] == 100_000_000 and d["config"]["rccl_nranks"] == 1 and d["multi_gpu"]["chunks"] == 1
+    assert d["efficiency_vs_n1"] >= 0.88, (d["efficiency_vs_n1"], d["ms_per_step"], d["multi_gpu"])
