@@ -360,6 +360,7 @@ struct cph_ctx {
         uint64_t tiles = 0, epoch = 0;
         uint32_t tickets = 0;
     } scan[2];                     // one per stream slot (scans of the two streams of a build batch run concurrently)
+    int csv_fast = 1;              // cph_csv_parse: byte-parallel passes over text tiles for texts without quotes (csv_ingest.hip: k_csv_fast); 0: the record-parallel kernels
     int counted_sort = 1;          // IndexOn over 32-bit codes with duplicates: MSD sort through counted LDS windows (counted_sort.hip); 0: the classic passes
     int direct_sort = 1;           // a build that expects distinct keys (UniqueIndexOn) over a dense 32-bit code space (rows <= states <= 2 rows)
                                    // sorts by ONE scatter, slot[code] = row (radix_sort.hip: direct_sort_distinct); a duplicate is noticed on

@@ -130,7 +130,7 @@ __device__ __forceinline__ TileScan scan_tile(const uint8_t* __restrict__ d, uin
 // ---- 1. per tile: quotes, newlines at even / odd parity relative to the tile start ---------------------------
 __global__ __launch_bounds__(kCsvThreads) void k_csv_tile_stats(const uint8_t* __restrict__ d, uint64_t size,
                                                                uint32_t* __restrict__ tile_quotes, uint32_t* __restrict__ tile_even,
-                                                               uint32_t* __restrict__ tile_odd) {
+                                                               uint32_t* __restrict__ tile_odd, uint64_t* __restrict__ any_quote) {
     __shared__ uint32_t s_par[kCsvChunks * kCsvWaves];
     __shared__ uint32_t s_red[3 * kCsvWaves];
     const uint64_t t = blockIdx.x;
@@ -154,6 +154,7 @@ __global__ __launch_bounds__(kCsvThreads) void k_csv_tile_stats(const uint8_t* _
         uint32_t s = 0;
         for (int w = 0; w < kCsvWaves; w++) s += s_red[threadIdx.x * kCsvWaves + w];
         (threadIdx.x == 0 ? tile_quotes : threadIdx.x == 1 ? tile_even : tile_odd)[t] = s;
+        if (threadIdx.x == 0 && s) *any_quote = 1ull;   // (the fast path is for texts without a single quote)
     }
 }
 
@@ -701,6 +702,407 @@ __global__ __launch_bounds__(kCsvThreads) void k_csv_copy_fields(const uint8_t* 
     }
 }
 
+// ================================================================================================================
+// (round 6) The fast path: BYTE-parallel passes over TEXT tiles.
+//
+// k_csv_fields / k_csv_copy_fields above are record-parallel: one thread walks one record byte by byte through LDS, twice
+// (lengths, then bytes) — 0.85 + 1.28 ms per 0.89 GB, 0.036 of the HBM roof, waiting on LDS byte work.  When the text holds NO quote
+// at all (k_csv_tile_stats counts them), TrimLeadingSpace is off and no line in the middle is blank or a comment, every byte's
+// role follows from two bit masks (delimiter, newline) and three workgroup scans:
+//   record of a byte       = newlines before it                                  (sum scan)
+//   field index of a byte  = delimiters since the last newline                   (segmented sum scan)
+//   start of its field     = position behind the last delimiter / newline       (max scan)
+// A tile OWNS the records that begin behind a newline inside its 16 KiB (tile 0 also owns record 0) and reads up to 8 KiB
+// past its end to finish the last one.  Each thread looks at 64 bytes = two 64-bit masks, walks the ~10 terminators in them
+// and knows for each the record, the field index and the field's extent:
+//   k_csv_fast_count   bytes of every wanted column per tile (+ the field counts' minimum / maximum, and anything the fast
+//                      path cannot do — a blank or comment line, a record beyond the staged window — raises *slow: the
+//                      classic kernels then parse the text; the first error, if any, is theirs to report)
+//   (one scan over the tiles' totals of all columns)
+//   k_csv_fast_copy    the same walk with the tile's base known: offsets per record, field bytes gathered per column in LDS
+//                      and streamed out.
+// Neither k_csv_separators (0.22 ms, 8 bytes per record written) nor k_csv_classify (0.29 ms) runs: the text is read three times
+// (tile statistics, count, copy), never walked byte by byte.
+// ================================================================================================================
+constexpr int kFtThreads = 384;
+constexpr int kFtWaves = kFtThreads / kWave;
+constexpr int kFtStage = kFtThreads * 64;   // 24 KiB staged per 16 KiB tile
+constexpr int kFtOwn = kCsvTile / 64;       // the chunks (threads) of the tile's own 16 KiB
+constexpr int kFtMaxCols = 4;
+static_assert(kFtStage > kCsvTile && kFtStage % 64 == 0, "a tile's stage must reach past its end");
+struct FtCols {
+    int32_t ncols;
+    int32_t index[kFtMaxCols];
+};
+// device words the two kernels share with the host
+struct FtFlags {
+    uint32_t slow;         // something the fast path cannot do
+    uint32_t min_nf;       // fields per record, over all records
+    uint32_t max_nf;
+    uint32_t last_empty;   // nothing (or a lone '\r') behind the text's last newline: that line is no record
+};
+
+struct FtScan {   // what a thread's 64 bytes contribute, and the operator that chains them
+    uint32_t nsep;   // newlines
+    uint32_t cc;     // delimiters behind the last newline (all of them when there is none)
+    uint32_t hs;     // has a newline
+};
+__device__ __forceinline__ FtScan ft_combine(const FtScan& a, const FtScan& b) {   // a in front of b
+    FtScan r;
+    r.nsep = a.nsep + b.nsep;
+    r.cc = b.hs ? b.cc : a.cc + b.cc;
+    r.hs = a.hs | b.hs;
+    return r;
+}
+__device__ __forceinline__ FtScan ft_shfl_up(const FtScan& v, int d) {
+    FtScan r;
+    r.nsep = __shfl_up(v.nsep, d, kWave);
+    r.cc = __shfl_up(v.cc, d, kWave);
+    r.hs = __shfl_up(v.hs, d, kWave);
+    return r;
+}
+// Exclusive scan over the workgroup's threads.  *own = the newlines of the tile's own 16 KiB (threads 0 .. kFtOwn - 1), *all = those of
+// the whole staged window.  s_w: kFtWaves + 1 entries.  Two barriers.
+__device__ __forceinline__ FtScan ft_block_exclusive(FtScan v, FtScan* s_w, uint32_t* own, uint32_t* all) {
+    FtScan incl = v;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const FtScan o = ft_shfl_up(incl, d);
+        if (lane_id() >= d) incl = ft_combine(o, incl);
+    }
+    if (lane_id() == kWave - 1) s_w[wave_id()] = incl;
+    FtScan ex = ft_shfl_up(incl, 1);
+    if (lane_id() == 0) ex = FtScan{0, 0, 0};
+    __syncthreads();
+    FtScan pre{0, 0, 0};
+    uint32_t o = 0, a = 0;
+#pragma unroll
+    for (int w = 0; w < kFtWaves; w++) {
+        if (w < wave_id()) pre = ft_combine(pre, s_w[w]);
+        if (w < kFtOwn / kWave) o += s_w[w].nsep;
+        a += s_w[w].nsep;
+    }
+    __syncthreads();
+    *own = o;
+    *all = a;
+    return ft_combine(pre, ex);
+}
+
+// 0x80 in every byte of w that equals the pattern's byte
+__device__ __forceinline__ uint32_t eq_hi4(uint32_t w, uint32_t pat) {
+    const uint32_t x = w ^ pat;
+    return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+}
+// Stages [tile_start, tile_start + kFtStage) (zeros past the text's end) and one bit per byte for delimiter / newline / '\r'; the
+// text's end counts as a newline (it terminates the last record).  Returns whether this thread saw a quote.
+__device__ __forceinline__ bool ft_stage(const uint8_t* __restrict__ d, uint64_t size, uint64_t tile_start, uint8_t comma, CPH_LDS uint8_t* stage,
+                                         CPH_LDS uint16_t* cmask, CPH_LDS uint16_t* nmask, CPH_LDS uint16_t* rmask) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t cpat = 0x01010101u * comma;
+    uint32_t quote = 0;
+#pragma unroll
+    for (int i = 0; i < kFtStage / (kFtThreads * 16); i++) {
+        const uint32_t off = ((uint32_t)i * kFtThreads + threadIdx.x) * 16u;
+        const uint64_t g = tile_start + off;
+        u32x4 v = {0, 0, 0, 0};
+        if (g + 16 <= size) {
+            v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(d + g));
+        } else if (g < size) {
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (uint64_t q = g; q < size; q++) w[(q - g) >> 2] |= (uint32_t)d[q] << (8 * ((q - g) & 3));
+            v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+        }
+        *(CPH_LDS u32x4*)(stage + off) = v;
+        quote |= eq_hi4(v.x, 0x22222222u) | eq_hi4(v.y, 0x22222222u) | eq_hi4(v.z, 0x22222222u) | eq_hi4(v.w, 0x22222222u);
+        cmask[off >> 4] = (uint16_t)(eq_mask4(v.x, cpat) | eq_mask4(v.y, cpat) << 4 | eq_mask4(v.z, cpat) << 8 | eq_mask4(v.w, cpat) << 12);
+        uint32_t nl = eq_mask4(v.x, 0x0A0A0A0Au) | eq_mask4(v.y, 0x0A0A0A0Au) << 4 | eq_mask4(v.z, 0x0A0A0A0Au) << 8 | eq_mask4(v.w, 0x0A0A0A0Au) << 12;
+        if (size >= g && size - g < 16u) nl |= 1u << (uint32_t)(size - g);
+        nmask[off >> 4] = (uint16_t)nl;
+        rmask[off >> 4] = (uint16_t)(eq_mask4(v.x, 0x0D0D0D0Du) | eq_mask4(v.y, 0x0D0D0D0Du) << 4 | eq_mask4(v.z, 0x0D0D0D0Du) << 8 |
+                                     eq_mask4(v.w, 0x0D0D0D0Du) << 12);
+    }
+    return quote != 0;
+}
+
+// inclusive XOR scan over the 64 positions, restarting where `cont` is clear (cont bit i: position i continues position i - 1)
+__device__ __forceinline__ uint64_t ft_seg_xor(uint64_t v, uint64_t p) {
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        v ^= (v << s) & p;
+        p &= (p << s) | ((1ull << s) - 1ull);
+    }
+    return v;
+}
+// the positions up to and including the k-th (k >= 1) set bit of m; all of them when m has fewer
+__device__ __forceinline__ uint64_t ft_through_kth(uint64_t m, uint32_t k) {
+    while (k > 1 && m) { m &= m - 1; k--; }
+    return m ? (((m & (0ull - m)) << 1) - 1ull) : ~0ull;
+}
+
+// A tile OWNS the records that begin behind a newline of its own 16 KiB (tile 0: also record 0): in the staged window these are the
+// bytes whose LOCAL record number (newlines in front of them, from the window's start) lies in [t ? 1 : 0, own]; record `own` ends at
+// the window's newline number own + 1 — when the window holds it.
+//   COUNT: tile_tot[c][t] = bytes of wanted column c; tile_tot[ncols][t] = newlines of the tile's own 16 KiB; flags.
+//   COPY:  tile_tot holds the exclusive scan over the concatenation of these arrays.
+template <bool COPY>
+__global__ __launch_bounds__(kFtThreads) void k_csv_fast(const uint8_t* __restrict__ d, uint64_t size, uint64_t ntiles, CsvOpts o, FtCols cols,
+                                                        uint64_t first, uint64_t nrec /* COPY only */, uint64_t* __restrict__ tile_tot,
+                                                        FtFlags* __restrict__ flags, uint32_t* __restrict__ offs /* column c at offs + c * stride */,
+                                                        uint64_t stride, uint8_t* const* __restrict__ out_data, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ FtScan s_w[kFtWaves + 1];
+    __shared__ uint32_t s_col[kFtMaxCols][kFtWaves + 1];
+    __shared__ uint32_t s_sel[16];
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    CPH_LDS uint8_t* stage = (CPH_LDS uint8_t*)smem;
+    CPH_LDS uint16_t* cmask = (CPH_LDS uint16_t*)(stage + kFtStage + 16);
+    CPH_LDS uint16_t* nmask = cmask + kFtStage / 16 + 8;
+    CPH_LDS uint16_t* rmask = nmask + kFtStage / 16 + 8;
+    CPH_LDS uint8_t* ostage = (CPH_LDS uint8_t*)(rmask + kFtStage / 16 + 8);
+    const uint64_t t = blockIdx.x;
+    const uint64_t tile_start = t * kCsvTile;
+    const uint32_t base = threadIdx.x * 64u;
+    const bool quote = ft_stage(d, size, tile_start, o.comma, stage, cmask, nmask, rmask);
+    if (threadIdx.x < 4) nmask[kFtStage / 16 + threadIdx.x] = 0;   // (the word behind the last chunk's: read as "the next chunk")
+    if (COPY) {
+        if (threadIdx.x < 16) {   // v_perm_b32 selectors: the bytes of a word that a 4-bit mask keeps, moved to its low end (0x0C = a zero byte)
+            uint32_t sel = 0x0C0C0C0Cu, k = 0;
+            for (uint32_t b = 0; b < 4; b++)
+                if ((threadIdx.x >> b) & 1u) {
+                    sel = (sel & ~(0xFFu << (8 * k))) | (b << (8 * k));
+                    k++;
+                }
+            s_sel[threadIdx.x] = sel;
+        }
+        const u32x4 z = {0, 0, 0, 0};
+        for (uint32_t i = threadIdx.x; i < (uint32_t)(kFtStage + 64) / 16; i += kFtThreads) ((CPH_LDS u32x4*)ostage)[i] = z;
+    } else if (__ballot(quote) && lane_id() == 0) {
+        atomicOr(&flags->slow, 1u);   // a quote: quoted fields are the classic kernels' business
+    }
+    __syncthreads();
+    if (dbg & 1) return;
+    const uint64_t cm = ((const CPH_LDS uint64_t*)cmask)[threadIdx.x], nm = ((const CPH_LDS uint64_t*)nmask)[threadIdx.x];
+    const uint64_t rm = ((const CPH_LDS uint64_t*)rmask)[threadIdx.x];
+    const uint64_t next_nl = ((const CPH_LDS uint64_t*)nmask)[threadIdx.x + 1] & 1ull;   // is the byte behind this chunk a newline
+    FtScan mine;
+    mine.nsep = (uint32_t)__popcll(nm);
+    mine.hs = nm ? 1u : 0u;
+    mine.cc = (uint32_t)__popcll(nm ? cm & ~((2ull << (63 - __clzll((long long)nm))) - 1ull) : cm);
+    uint32_t own, all;
+    const FtScan ex = ft_block_exclusive(mine, s_w, &own, &all);
+    if (size - tile_start < (uint64_t)kCsvTile) own--;   // the text's end terminates a record, it does not begin one
+    const uint32_t lo_rec = t ? 1u : 0u;
+    const bool any = own >= lo_rec;          // (tile 0 always owns record 0)
+    const bool slow = any && all < own + 1u;   // the last owned record's end is not in the window
+    if (!COPY && slow && threadIdx.x == 0) atomicOr(&flags->slow, 1u);
+    if (!any || slow) {
+        if (!COPY && threadIdx.x <= (uint32_t)cols.ncols) tile_tot[(uint64_t)threadIdx.x * ntiles + t] = threadIdx.x == (uint32_t)cols.ncols && !slow ? own : 0;
+        return;
+    }
+    // the bytes of owned records: local record number in [lo_rec, own]
+    uint64_t vm = ~0ull;
+    if (ex.nsep < lo_rec) vm = nm ? ~ft_through_kth(nm, 1) : 0ull;                       // behind the window's first newline
+    if (ex.nsep > own) vm = 0;
+    else if (ex.nsep + mine.nsep > own) vm &= ft_through_kth(nm, own - ex.nsep + 1u);   // through the newline that ends record `own`
+    // a '\r' right in front of a record's terminating newline (or of the text's end) is not data: "\r\n" -> "\n" (segment_range)
+    const uint64_t cr_strip = rm & ((nm >> 1) | (next_nl << 63));
+    const uint64_t data = vm & ~(cm | nm) & ~cr_strip;
+    const uint64_t nmv = nm & vm;   // the newlines that end owned records
+
+    // ---- which of this thread's 64 bytes belong to which wanted column ----
+    // The field index of a byte = the delimiters between the last newline and it, as FOUR BIT PLANES over the 64 positions: plane 0 is a
+    // segmented prefix parity of the delimiter mask (segments restart behind newlines), plane b + 1 the same over the positions where
+    // plane b carries.  No loop over the chunk's ~11 terminators, no divergence (the first version walked them: 1200 instructions
+    // per chunk).  Positions in front of the chunk's first newline continue a record of the chunk before: their index starts at ex.cc.
+    // A record with a 16th delimiter inside one chunk's reach aliases: *slow.
+    uint64_t wm[kFtMaxCols] = {0, 0, 0, 0};
+    bool bad = false;
+    const uint64_t cont = ~(nm << 1);   // position i continues the record of position i - 1
+    uint64_t e[4];                      // bit b of the number of delimiters in front of every position, since its record began (or the chunk)
+    {
+        uint64_t carry = cm;            // positions whose delimiter increments bit b
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const uint64_t incl = (dbg & 2) ? carry : ft_seg_xor(carry, cont);
+            e[b] = (incl << 1) & cont;
+            carry &= e[b];
+        }
+        if (carry & vm) bad = true;     // a 16th delimiter in one record
+    }
+    const uint64_t open = nm ? (((nm & (0ull - nm)) << 1) - 1ull) : ~0ull;   // up to and including the chunk's first newline
+    // the record of the chunk's first byte.  COUNT does not know the records in front of its tile: only tile 0 can hold header records
+    // (skip_records) — the kernel raises *slow otherwise
+    const uint64_t rs = COPY ? tile_tot[(uint64_t)cols.ncols * ntiles + t] - tile_tot[(uint64_t)cols.ncols * ntiles] + ex.nsep
+                             : (t ? first + ex.nsep : (uint64_t)ex.nsep);
+    uint64_t keep = data;
+    if (rs < first) keep = data & ~ft_through_kth(nm, (uint32_t)(first - rs));   // header records end inside or behind this chunk
+    if (!COPY && t == 0 && threadIdx.x == 0 && first > (uint64_t)own + 1u) atomicOr(&flags->slow, 1u);
+#pragma unroll
+    for (int c = 0; c < kFtMaxCols; c++) {
+        if (c >= cols.ncols) continue;
+        const uint32_t k = (uint32_t)cols.index[c];
+        uint64_t m_closed = k < 16u ? ~open : 0ull, m_open = (k >= ex.cc && k - ex.cc < 16u) ? open : 0ull;
+        const uint32_t ko = k - ex.cc;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            m_closed &= (k >> b) & 1u ? e[b] : ~e[b];
+            m_open &= (ko >> b) & 1u ? e[b] : ~e[b];
+        }
+        wm[c] = (m_closed | m_open) & keep;
+    }
+    uint32_t colbytes[kFtMaxCols];
+#pragma unroll
+    for (int c = 0; c < kFtMaxCols; c++) colbytes[c] = (uint32_t)__popcll(wm[c]);
+    if (!COPY) {
+        uint32_t nf_min = 0xFFFFFFFFu, nf_max = 0;
+        if (!(dbg & 4)) {
+            // empty lines (Go's Reader skips them; the classic path does): a newline right behind a newline or the text's first byte, also
+            // with a '\r' in between
+            const uint64_t pN = threadIdx.x ? ((const CPH_LDS uint64_t*)nmask)[threadIdx.x - 1] : 0ull;
+            const uint64_t pR = threadIdx.x ? ((const CPH_LDS uint64_t*)rmask)[threadIdx.x - 1] : 0ull;
+            const uint64_t st = (t == 0 && threadIdx.x == 0) ? 1ull : 0ull;
+            const uint64_t PN = (nm << 1) | (pN >> 63) | st;          // position i begins a line
+            const uint64_t PNm1 = (PN << 1) | ((pN >> 62) & 1ull);      // position i - 1 begins a line
+            const uint64_t Rm1 = (rm << 1) | (pR >> 63);                // position i - 1 is a '\r'
+            const uint64_t blank = nmv & (PN | (Rm1 & PNm1));
+            const uint64_t eofpos = size - tile_start;
+            const uint64_t eofbit = (eofpos >= base && eofpos < (uint64_t)base + 64u) ? 1ull << (eofpos - base) : 0ull;
+            if (blank & ~eofbit) bad = true;
+            if (blank & eofbit) flags->last_empty = 1u;
+            // fields per record, at every newline that ends one
+            uint64_t nls = nmv & ~blank;
+            while (nls) {
+                const uint32_t bit = (uint32_t)__ffsll((long long)nls) - 1u;
+                nls &= nls - 1;
+                uint32_t cntf = (uint32_t)((e[0] >> bit) & 1ull) | (uint32_t)((e[1] >> bit) & 1ull) << 1 | (uint32_t)((e[2] >> bit) & 1ull) << 2 |
+                                (uint32_t)((e[3] >> bit) & 1ull) << 3;
+                if ((open >> bit) & 1ull) cntf += ex.cc;
+                nf_min = cntf + 1 < nf_min ? cntf + 1 : nf_min;
+                nf_max = cntf + 1 > nf_max ? cntf + 1 : nf_max;
+            }
+            if (o.comment) {   // a record whose first byte is the comment character (Go's Reader skips the line): the classic path
+                uint64_t starts = PN & vm;
+                while (starts) {
+                    const uint32_t bit = (uint32_t)__ffsll((long long)starts) - 1u;
+                    starts &= starts - 1;
+                    if (stage[base + bit] == o.comment) bad = true;
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < kFtMaxCols; c++) {
+            const uint32_t v = wave_sum(colbytes[c]);
+            if (lane_id() == 0) s_col[c][wave_id()] = v;
+        }
+        nf_min = wave_min(nf_min);
+        nf_max = wave_max(nf_max);
+        if (lane_id() == 0) {
+            if (nf_min != 0xFFFFFFFFu && nf_min < __hip_atomic_load(&flags->min_nf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&flags->min_nf, nf_min);
+            if (nf_max > __hip_atomic_load(&flags->max_nf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&flags->max_nf, nf_max);
+        }
+        if (__ballot(bad) && lane_id() == 0) atomicOr(&flags->slow, 1u);
+        __syncthreads();
+        if (threadIdx.x < (uint32_t)cols.ncols) {
+            uint64_t tsum = 0;
+            for (int w = 0; w < kFtWaves; w++) tsum += s_col[threadIdx.x][w];
+            tile_tot[(uint64_t)threadIdx.x * ntiles + t] = tsum;
+        } else if (threadIdx.x == (uint32_t)cols.ncols) {
+            tile_tot[(uint64_t)threadIdx.x * ntiles + t] = own;
+        }
+        return;
+    }
+    // ---- COPY: where this thread's bytes of every column go inside the tile ----
+    uint32_t pos[kFtMaxCols];       // bytes of column c in this tile in front of this thread's chunk
+    uint64_t obase[kFtMaxCols];     // the tile's first byte of column c in the column's data
+    uint32_t span[kFtMaxCols];
+#pragma unroll
+    for (int c = 0; c < kFtMaxCols; c++) {
+        const uint32_t incl = wave_inclusive_sum(colbytes[c]);
+        if (lane_id() == kWave - 1) s_col[c][wave_id()] = incl;
+        pos[c] = incl - colbytes[c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < kFtMaxCols; c++) {
+        uint32_t pre = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < kFtWaves; w++) {
+            pre += w < wave_id() ? s_col[c][w] : 0u;
+            tot += s_col[c][w];
+        }
+        pos[c] += pre;
+        span[c] = tot;
+        obase[c] = c < cols.ncols ? tile_tot[(uint64_t)c * ntiles + t] - tile_tot[(uint64_t)c * ntiles] : 0ull;
+    }
+    // offsets: record r + 1's value of column c begins behind the bytes of column c in front of record r's terminating newline
+    // (entry nout: the column's size); the first owned record's offsets: the tile in front wrote the same values behind ITS last record
+    {
+        const uint64_t r_first = tile_tot[(uint64_t)cols.ncols * ntiles + t] - tile_tot[(uint64_t)cols.ncols * ntiles] + lo_rec;
+        if (threadIdx.x == 0 && r_first >= first && r_first <= nrec) {
+#pragma unroll
+            for (int c = 0; c < kFtMaxCols; c++)
+                if (c < cols.ncols) offs[(uint64_t)c * stride + (r_first - first)] = (uint32_t)obase[c];
+        }
+    }
+    if (!(dbg & 4)) {
+        uint64_t nls = nmv;
+        uint64_t r = rs + (uint32_t)__popcll(nm & (nmv ? ((nmv & (0ull - nmv)) - 1ull) : 0ull));   // (+ the chunk's newlines in front of the owned ones)
+        while (nls) {
+            const uint32_t bit = (uint32_t)__ffsll((long long)nls) - 1u;
+            nls &= nls - 1;
+            if (r + 1 >= first && r + 1 <= nrec) {
+                const uint64_t below = (1ull << bit) - 1ull;
+#pragma unroll
+                for (int c = 0; c < kFtMaxCols; c++)
+                    if (c < cols.ncols) offs[(uint64_t)c * stride + (r + 1 - first)] = (uint32_t)(obase[c] + pos[c] + (uint32_t)__popcll(wm[c] & below));
+            }
+            r++;
+        }
+    }
+    // ---- the chunk's wanted bytes, compacted word by word (v_perm_b32) and OR-ed into the zeroed output stage, one column at a time
+    // (the same field may be wanted as several columns: the output can be larger than the text), then streamed out ----
+    uint32_t w32[16];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const u32x4 v = ((const CPH_LDS u32x4*)(stage + base))[i];
+        w32[4 * i] = v.x; w32[4 * i + 1] = v.y; w32[4 * i + 2] = v.z; w32[4 * i + 3] = v.w;
+    }
+    // (a plain pointer into the dynamic LDS block: atomicOr has no overload for address-space pointers; the compiler still emits ds_or_b32)
+    uint32_t* ost32 = reinterpret_cast<uint32_t*>(smem + ((size_t)kFtStage + 16 + 3 * (size_t)(kFtStage / 16 + 8) * sizeof(uint16_t)));
+#pragma unroll
+    for (int c = 0; c < kFtMaxCols; c++) {
+        if (c >= cols.ncols) break;   // uniform
+        const uint32_t phase = (uint32_t)(obase[c] & 15);   // the stage is phase-aligned with the column's place in global memory (flush_stage)
+        if (c > 0) {   // (zeroed before the kernel's first barrier for column 0)
+            __syncthreads();
+            const u32x4 z = {0, 0, 0, 0};
+            for (uint32_t i = threadIdx.x; i < (span[c] + 47u) / 16u; i += kFtThreads) ((CPH_LDS u32x4*)ostage)[i] = z;
+            __syncthreads();
+        }
+        if (wm[c] && !(dbg & 8)) {
+            const uint32_t a0 = phase + pos[c];
+            uint32_t fill = a0 & 3u, w = a0 >> 2;
+            uint64_t acc = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const uint32_t m4 = (uint32_t)(wm[c] >> (4 * i)) & 0xFu;
+                const uint32_t cw = __builtin_amdgcn_perm(0u, w32[i], s_sel[m4]);
+                acc |= (uint64_t)cw << (8u * fill);
+                fill += (uint32_t)__popc(m4);
+                if (fill >= 4u) {
+                    atomicOr(&ost32[w], (uint32_t)acc);
+                    w++;
+                    acc >>= 32;
+                    fill -= 4u;
+                }
+            }
+            if (fill) atomicOr(&ost32[w], (uint32_t)acc);
+        }
+        lds_atomics_barrier();
+        flush_stage(ostage, out_data[c], obase[c], span[c]);
+    }
+}
+
 __global__ void k_csv_set_u64(uint64_t* p, uint64_t v) { *p = v; }
 
 }  // namespace cph
@@ -713,6 +1115,95 @@ struct cph_csv_table_impl {
     DevBuf d_data[CPH_MAX_KEY_COLS], d_offs;
     void* h_block = nullptr;
 };
+
+// The fast path's host side: count pass, one scan, copy pass — tried FIRST (it needs neither the quote parity nor the separator
+// positions of the classic passes).  *done stays false when the text needs the classic kernels (a quote, a blank or comment line, a
+// record beyond the staged window, field counts that differ, 16 fields or more): nothing has been published then.
+static Status csv_fast_path(cph_ctx* ctx, cph_csv_table_impl* t, const uint8_t* d, uint64_t size, const CsvOpts& o, const int32_t* col_index,
+                            int32_t ncols, const cph_csv_options* opt, uint64_t lead, bool* done, uint64_t* nrec_out, uint64_t* first_out,
+                            uint64_t* nout_out, uint64_t* stride_out, uint8_t** offs_all_out, std::vector<uint64_t>* totals) {
+    const uint64_t ntiles = (size + kCsvTile - 1) / kCsvTile;
+    if (ntiles > 0x7FFFFFFFull) return {};
+    for (int c = 0; c < ncols; c++)
+        if (col_index[c] > 0xFFFF) return {};
+    FtCols fc{};
+    fc.ncols = ncols;
+    for (int c = 0; c < ncols; c++) fc.index[c] = col_index[c];
+    DevBuf flags, ttot;
+    const uint64_t narr = (uint64_t)ncols + 1;   // bytes per wanted column, newlines: per tile
+    CPH_TRY(flags.alloc(&ctx->pool, sizeof(FtFlags)));
+    CPH_TRY(ttot.alloc(&ctx->pool, (narr * ntiles + 1) * sizeof(uint64_t)));
+    {
+        void* up = nullptr;
+        CPH_TRY(pinned_upload(ctx, sizeof(FtFlags), &up));
+        *static_cast<FtFlags*>(up) = FtFlags{0u, 0xFFFFFFFFu, 0u, 0u};
+        CPH_HIP_TRY(hipMemcpyAsync(flags.get(), up, sizeof(FtFlags), hipMemcpyHostToDevice, ctx->stream));
+    }
+    const size_t lds_count = (size_t)kFtStage + 16 + 3 * (size_t)(kFtStage / 16 + 8) * sizeof(uint16_t) + 16;
+    const size_t lds_copy = lds_count + (size_t)kFtStage + 64;
+    const uint64_t first_req = opt->skip_records;
+    {
+        CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_csv_fast<false>), kFtThreads, lds_count, nullptr));
+        ProfScope ps(ctx, "k_csv_fast_count", (double)size);
+        hipLaunchKernelGGL(k_csv_fast<false>, dim3((unsigned)ntiles), dim3(kFtThreads), lds_count, ctx->stream, d, size, ntiles, o, fc, first_req, 0ull,
+                           ttot.as<uint64_t>(), flags.as<FtFlags>(), (uint32_t*)nullptr, 0ull, (uint8_t* const*)nullptr, ctx->chain_debug >> 16);
+        CPH_HIP_TRY(hipGetLastError());
+    }
+    CPH_TRY(exclusive_scan_u64(ctx, ttot.as<uint64_t>(), narr * ntiles, ttot.as<uint64_t>() + narr * ntiles));
+    // one wait: the flags + where every array's tiles begin in the scan (an array's total = the difference to the next one's start)
+    CPH_TRY(ensure_pinned_scratch(ctx, sizeof(FtFlags) + ((size_t)narr + 1) * sizeof(uint64_t)));
+    uint8_t* h = static_cast<uint8_t*>(ctx->pinned_scratch);
+    CPH_HIP_TRY(hipMemcpyAsync(h, flags.get(), sizeof(FtFlags), hipMemcpyDeviceToHost, ctx->stream));
+    for (uint64_t c = 0; c <= narr; c++)
+        CPH_HIP_TRY(hipMemcpyAsync(h + sizeof(FtFlags) + (size_t)c * sizeof(uint64_t), ttot.as<uint64_t>() + c * ntiles, sizeof(uint64_t),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const FtFlags fl = *reinterpret_cast<const FtFlags*>(h);
+    const uint64_t* bounds = reinterpret_cast<const uint64_t*>(h + sizeof(FtFlags));
+    if (fl.slow) return {};
+    const uint64_t nsep = bounds[narr] - bounds[narr - 1];
+    const uint64_t nrec = nsep + (fl.last_empty ? 0 : 1);
+    if (nrec == 0 || nrec > 0xFFFFFFFFull) return {};
+    if (opt->fields_per_record >= 0) {   // 0: every record as many fields as the first one (csv.Reader.FieldsPerRecord)
+        if (fl.min_nf != fl.max_nf) return {};   // the classic path finds WHICH record is the first wrong one
+        if (opt->fields_per_record > 0 && (uint32_t)opt->fields_per_record != fl.min_nf) return {};
+    }
+    const uint64_t first = std::min<uint64_t>(first_req, nrec);
+    const uint64_t nout = nrec - first;
+    if (nout == 0) return {};
+    const uint64_t stride = (nrec + 1 + lead + 3) & ~3ull;
+    CPH_TRY(t->d_offs.alloc(&ctx->pool, (size_t)ncols * stride * sizeof(uint32_t) + 64));
+    uint8_t* offs_all = t->d_offs.as<uint8_t>() + lead * sizeof(uint32_t);
+    for (int c = 0; c < ncols; c++) {
+        (*totals)[(size_t)c] = bounds[c + 1] - bounds[c];
+        if ((*totals)[(size_t)c] > 0xFFFFFFFFull) return {CPH_ERR_INVALID, "a column beyond 4 GiB with 32-bit offsets"};   // (cannot happen: text < 4 GiB)
+        CPH_TRY(t->d_data[c].alloc(&ctx->pool, (*totals)[(size_t)c] + 16));
+    }
+    DevBuf ptrs;
+    CPH_TRY(ptrs.alloc(&ctx->pool, (size_t)ncols * sizeof(uint8_t*)));
+    void* slot = nullptr;
+    CPH_TRY(pinned_upload(ctx, (size_t)ncols * sizeof(uint8_t*), &slot));
+    for (int c = 0; c < ncols; c++) static_cast<uint8_t**>(slot)[c] = t->d_data[c].as<uint8_t>();
+    CPH_HIP_TRY(hipMemcpyAsync(ptrs.get(), slot, (size_t)ncols * sizeof(uint8_t*), hipMemcpyHostToDevice, ctx->stream));
+    {
+        double out_bytes = 0;
+        for (int c = 0; c < ncols; c++) out_bytes += (double)(*totals)[(size_t)c];
+        CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_csv_fast<true>), kFtThreads, lds_copy, nullptr));
+        ProfScope ps(ctx, "k_csv_fast_copy", (double)size + out_bytes + (double)nout * 4.0 * ncols);
+        // offs: entry r - first of column c at offs + c * stride
+        hipLaunchKernelGGL(k_csv_fast<true>, dim3((unsigned)ntiles), dim3(kFtThreads), lds_copy, ctx->stream, d, size, ntiles, o, fc, first, nrec,
+                           ttot.as<uint64_t>(), flags.as<FtFlags>(), reinterpret_cast<uint32_t*>(offs_all) + first, stride, ptrs.as<uint8_t*>(),
+                           ctx->chain_debug >> 16);
+        CPH_HIP_TRY(hipGetLastError());
+    }
+    *done = true;
+    *nrec_out = nrec;
+    *first_out = first;
+    *nout_out = nout;
+    *stride_out = stride;
+    *offs_all_out = offs_all;
+    return {};
+}
 
 extern "C" {
 
@@ -752,27 +1243,50 @@ CPH_API int32_t cph_csv_parse(cph_ctx* ctx, const uint8_t* data, uint64_t size, 
         uint64_t first = 0, nout = 0;
         t->pub.error_kind = 0;
         t->pub.error_record = 0;
-        if (size) {
+        // Offsets are 32-bit whenever the text is smaller than 4 GiB (no column can then be larger).
+        const char* force64 = getenv("CPH_CSV_OFFSETS64");   // test hook for the >= 4 GiB code path
+        const bool off32 = size < (1ull << 32) && !(force64 && force64[0] == '1');
+        const size_t osz = off32 ? sizeof(uint32_t) : sizeof(uint64_t);
+        // column c's entries start `lead` elements into its stride so that the first RETURNED record (index
+        // skip_records) lands on a 16-byte boundary: the offset scans then move 16-byte vectors
+        const uint64_t lead = (4 - (opt->skip_records & 3)) & 3;
+        uint64_t stride = 0;
+        uint8_t* offs_all = nullptr;
+        std::vector<uint64_t> totals((size_t)ncols, 0);
+        bool fast_done = false;
+        // ---- the fast path (k_csv_fast): no TrimLeadingSpace, at most kFtMaxCols columns, 32-bit offsets; the kernels themselves find what
+        // else sends a text to the classic passes below ----
+        if (size && ctx->csv_fast && !o.trim && ncols <= kFtMaxCols && off32)
+            CPH_TRY(csv_fast_path(ctx, t, d, size, o, col_index, ncols, opt, lead, &fast_done, &nrec, &first, &nout, &stride, &offs_all, &totals));
+        if (size && !fast_done) {
             const uint64_t ntiles = (size + kCsvTile - 1) / kCsvTile;
             if (ntiles > 0x7FFFFFFFull) return {CPH_ERR_INVALID, "text too large"};
             DevBuf tq, tev, tod, cnt;
             CPH_TRY(tq.alloc(&ctx->pool, ntiles * sizeof(uint32_t)));
             CPH_TRY(tev.alloc(&ctx->pool, ntiles * sizeof(uint32_t)));
             CPH_TRY(tod.alloc(&ctx->pool, ntiles * sizeof(uint32_t)));
-            CPH_TRY(cnt.alloc(&ctx->pool, (ntiles + 1) * sizeof(uint64_t)));
+            CPH_TRY(cnt.alloc(&ctx->pool, (ntiles + 2) * sizeof(uint64_t)));   // [separators before tile t | their total | any quote]
+            CPH_HIP_TRY(hipMemsetAsync(cnt.as<uint64_t>() + ntiles + 1, 0, sizeof(uint64_t), ctx->stream));
             {
                 ProfScope ps(ctx, "k_csv_tile_stats", (double)size);
                 hipLaunchKernelGGL(k_csv_tile_stats, dim3((unsigned)ntiles), dim3(kCsvThreads), 0, ctx->stream, d, size,
-                                   tq.as<uint32_t>(), tev.as<uint32_t>(), tod.as<uint32_t>());
+                                   tq.as<uint32_t>(), tev.as<uint32_t>(), tod.as<uint32_t>(), cnt.as<uint64_t>() + ntiles + 1);
             }
             CPH_TRY(exclusive_scan_u32(ctx, tq.as<uint32_t>(), ntiles));   // mod 2^32 keeps the parity
             hipLaunchKernelGGL(k_csv_pick_counts, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, ctx->stream, tq.as<uint32_t>(),
                                tev.as<uint32_t>(), tod.as<uint32_t>(), cnt.as<uint64_t>(), ntiles);
             CPH_TRY(exclusive_scan_u64(ctx, cnt.as<uint64_t>(), ntiles, cnt.as<uint64_t>() + ntiles));
-            uint64_t nsep = 0;
-            CPH_TRY(read_device_value(ctx, cnt.as<uint64_t>() + ntiles, &nsep));
+            uint64_t nsep = 0, any_quote = 0;
+            {
+                CPH_TRY(ensure_pinned_scratch(ctx, 2 * sizeof(uint64_t)));
+                CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, cnt.as<uint64_t>() + ntiles, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+                CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+                nsep = static_cast<const uint64_t*>(ctx->pinned_scratch)[0];
+                any_quote = static_cast<const uint64_t*>(ctx->pinned_scratch)[1];
+            }
             const uint64_t nseg = nsep + 1;   // the bytes after the last separator (possibly none) form the last segment
             if (nseg > 0xFFFFFFFFull) return {CPH_ERR_TOO_MANY_ROWS, "more than 2^32-1 lines"};
+            {
             DevBuf seps;
             CPH_TRY(seps.alloc(&ctx->pool, nseg * sizeof(uint64_t)));
             {
@@ -816,18 +1330,14 @@ CPH_API int32_t cph_csv_parse(cph_ctx* ctx, const uint8_t* data, uint64_t size, 
                 ri.rec_e = rec_e.as<uint64_t>();
             }
             CPH_HIP_TRY(hipGetLastError());
+            }   // (!fast_done)
         }
-        // fields: lengths (written where the offsets will be), counts, first error.  Offsets are 32-bit
-        // whenever the text is smaller than 4 GiB (no column can then be larger).
-        const char* force64 = getenv("CPH_CSV_OFFSETS64");   // test hook for the >= 4 GiB code path
-        const bool off32 = size < (1ull << 32) && !(force64 && force64[0] == '1');
-        const size_t osz = off32 ? sizeof(uint32_t) : sizeof(uint64_t);
-        // column c's entries start `lead` elements into its stride so that the first RETURNED record (index
-        // skip_records) lands on a 16-byte boundary: the offset scans then move 16-byte vectors
-        const uint64_t lead = (4 - (opt->skip_records & 3)) & 3;
-        const uint64_t stride = (nrec + 1 + lead + 3) & ~3ull;
+        auto col_offs = [&](int c) { return offs_all + ((uint64_t)c * stride + first) * osz; };
+        if (!fast_done) {
+        // fields: lengths (written where the offsets will be), counts, first error.
+        stride = (nrec + 1 + lead + 3) & ~3ull;
         CPH_TRY(t->d_offs.alloc(&ctx->pool, (size_t)ncols * stride * osz + 64));
-        uint8_t* offs_all = t->d_offs.as<uint8_t>() + lead * osz;
+        offs_all = t->d_offs.as<uint8_t>() + lead * osz;
         uint64_t good = nrec;   // records before the first error
         // LDS stage of the record-parallel kernels: the smallest power of two holding 1.5x an average 256-record tile
         // (small stages leave room for more workgroups per CU; tiles that do not fit are parsed from global memory)
@@ -875,8 +1385,6 @@ CPH_API int32_t cph_csv_parse(cph_ctx* ctx, const uint8_t* data, uint64_t size, 
         // offsets (in place, over the records that are returned) + copy
         t->pub.nrecords = nout;
         t->pub.ncols = ncols;
-        std::vector<uint64_t> totals((size_t)ncols, 0);
-        auto col_offs = [&](int c) { return offs_all + ((uint64_t)c * stride + first) * osz; };
         // ONE scan over the tiles' totals of all columns (the concatenation [ncols][ntile]; the copy pass takes differences):
         // the per-record offsets are formed by the copy pass itself.  totals[c] = the bytes of the tiles that hold returned
         // records — the column's size, or a few values more when the text ends in an error inside the last tile (the
@@ -924,6 +1432,9 @@ CPH_API int32_t cph_csv_parse(cph_ctx* ctx, const uint8_t* data, uint64_t size, 
                                    tile_tot.as<uint64_t>(), ntile, T0);
             CPH_HIP_TRY(hipGetLastError());
         }
+        }   // (!fast_done)
+        t->pub.nrecords = nout;
+        t->pub.ncols = ncols;
         // publish
         if (out_mem == CPH_MEM_DEVICE) {
             for (int c = 0; c < ncols; c++) {

@@ -455,3 +455,130 @@ def test_gpu_small_mixed_cases_match_oracle(ctx):
         got = [[t.columns[c].value(r) for c in range(len(cols))] for r in range(t.nrecords)]
         assert got == [[ocols[c].value(r) for c in range(len(cols))] for r in range(ocols[0].nrows)]
         assert (t.error_kind, t.error_record if t.error_kind else 0) == (oek, oer if oek else 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# (round 6) the byte-parallel fast path (csv_ingest.hip: k_csv_fast): texts without quotes, <= 4 columns
+# ---------------------------------------------------------------------------------------------------------------
+def _parse_profiled(ctx, text, cols, **kw):
+    from csvplus_amd import ingest
+    from csvplus_amd import _native as N
+    ctx.profile(True)
+    ctx.profile_read(reset=True)
+    t = ingest.csv_parse(ctx, text, cols, out_mem=N.CPH_MEM_HOST, **kw)
+    prof = ctx.profile_read(reset=True)
+    ctx.profile(False)
+    vals = [t.columns[c].values() for c in range(len(cols))]
+    return vals, t.nrecords, t.error_kind, (t.error_record if t.error_kind else 0), prof
+
+
+def _fast_vs_classic(ctx, text, cols, expect_fast=True, oracle=True, **kw):
+    got = _parse_profiled(ctx, text, cols, **kw)
+    assert ("k_csv_fast_copy" in got[4]) == expect_fast and ("k_csv_copy_fields" in got[4]) != expect_fast, sorted(got[4])
+    ctx.set_option("csv_fast", 0)
+    try:
+        ref = _parse_profiled(ctx, text, cols, **kw)
+    finally:
+        ctx.set_option("csv_fast", 1)
+    assert "k_csv_fast_count" not in ref[4]
+    assert got[1:4] == ref[1:4], (got[1:4], ref[1:4])
+    for c in range(len(cols)):
+        if got[0][c] != ref[0][c]:
+            r = next(i for i, (x, y) in enumerate(zip(got[0][c], ref[0][c])) if x != y)
+            raise AssertionError(f"column {c} (field {cols[c]}) record {r}: fast {got[0][c][r - 1:r + 2]} classic {ref[0][c][r - 1:r + 2]}; "
+                                 f"{len(text)} bytes, kw {kw}")
+    if oracle:
+        ocols, oek, oer = orc.csv_parse(text, cols, **kw)
+        assert got[1] == ocols[0].nrows and (got[2], got[3]) == (oek, oer if oek else 0)
+        assert got[0] == [ocols[c].values() for c in range(len(cols))]
+    return got
+
+
+@pytest.mark.gpu
+def test_fast_path_random_unquoted_texts(ctx):
+    """Line-end styles, a missing final newline, a final lone '\\r', stray '\\r' inside fields, empty fields, ragged records with
+    FieldsPerRecord < 0, skipped header records, one field asked for twice, 1-4 columns — through k_csv_fast, equal to the classic
+    kernels and to the oracle."""
+    rng = np.random.default_rng(606)
+    for it in range(40):
+        nf = int(rng.integers(1, 7))
+        nrec = int(rng.integers(1, 80)) if it % 4 else int(rng.integers(4000, 30000))     # the large ones span many 16 KiB tiles
+        text = _gen_unquoted(rng, nrec, nf, crlf_prob=[0.0, 1.0, 0.4][it % 3], blank_prob=0.0, trailing_nl=bool(it % 5))
+        if it % 11 == 0:
+            text += b"\r"
+        ncols = int(rng.integers(1, min(nf, 4) + 1))
+        cols = sorted(rng.choice(nf, size=ncols, replace=False).tolist())
+        if it % 6 == 0 and ncols < 4:
+            cols = cols + [cols[0]]                         # the same field as two columns
+        if it % 9 == 0:
+            cols[-1] = nf + 2                               # a field no record has: "" everywhere (FieldsPerRecord < 0 only)
+        fpr = -1 if it % 9 == 0 else [0, -1, nf][it % 3]
+        _fast_vs_classic(ctx, text, cols, fields_per_record=fpr, skip_records=int(rng.integers(0, 4)))
+
+
+@pytest.mark.gpu
+def test_fast_path_ragged_records_and_tile_edges(ctx):
+    rng = np.random.default_rng(607)
+    # ragged: records with 1..5 fields, FieldsPerRecord < 0: missing values are ""
+    lines = [b",".join(b"%d" % int(v) for v in rng.integers(0, 10 ** int(rng.integers(1, 8)), int(rng.integers(1, 6)))) for _ in range(20000)]
+    text = b"\n".join(lines) + b"\n"
+    _fast_vs_classic(ctx, text, [0, 2, 4], fields_per_record=-1)
+    _fast_vs_classic(ctx, text, [1], fields_per_record=-1, skip_records=2)
+    # differing field counts with FieldsPerRecord = 0: the classic kernels report the first wrong record
+    got = _fast_vs_classic(ctx, text, [0, 1], expect_fast=False, fields_per_record=0)
+    assert got[2] != 0
+    # newlines exactly at, before and behind the 16 KiB tile boundaries; texts of exactly k tiles; one record per tile
+    for pad in (16382, 16383, 16384, 16385, 32767, 32768):
+        first = b"h1,h2\n"
+        body = b"x" * (pad - len(first) - 3) + b",y\n" + b"a,b\nc,d\n"
+        fits = pad < 20000                                                     # (a record may run 8 KiB past the end of its tile)
+        _fast_vs_classic(ctx, first + body, [0, 1], expect_fast=fits)
+        _fast_vs_classic(ctx, first + body[:-1], [1, 0], expect_fast=fits, skip_records=1)      # no final newline
+    text = (b"k" * 8 + b",v\n") * 2048 * 3                                       # 11 bytes x 6144 records: not a multiple of the tile
+    _fast_vs_classic(ctx, text, [0, 1])
+    text = (b"k" * 13 + b",v\n") * 1024 * 4                                      # 16-byte records: every tile ends with a newline
+    assert len(text) % 16384 == 0
+    _fast_vs_classic(ctx, text, [0, 1])
+    _fast_vs_classic(ctx, text[:-1], [0, 1])
+    # a record that runs ~8 KiB past the end of its tile still fits the staged window; a longer one goes to the classic kernels
+    fits = b"a,b\n" * 4000 + b"x" * 7000 + b",y\n" + b"c,d\n" * 10
+    _fast_vs_classic(ctx, fits, [0, 1])
+    too_long = b"a,b\n" * 4000 + b"x" * 30000 + b",y\n" + b"c,d\n" * 10
+    _fast_vs_classic(ctx, too_long, [0, 1], expect_fast=False)
+
+
+@pytest.mark.gpu
+def test_fast_path_gives_way_to_the_classic_kernels(ctx):
+    """A quote anywhere, TrimLeadingSpace, a blank line in the middle, a comment line, more than 4 columns: the record-parallel kernels."""
+    base = b"id,name,qty\n" + b"".join(b"%d,n%d,%d\n" % (i, i % 97, i % 13) for i in range(5000))
+    _fast_vs_classic(ctx, base, [0, 2], skip_records=1)
+    _fast_vs_classic(ctx, base, [0, 2], comment=b"#")                                        # a comment character, no comment line
+    _fast_vs_classic(ctx, base + b'7,"q",1\n', [0, 2], expect_fast=False)
+    _fast_vs_classic(ctx, base, [0, 2], expect_fast=False, trim_leading_space=True)
+    _fast_vs_classic(ctx, base[:3000] + b"\n" + base[3000:], [0, 2], expect_fast=False, fields_per_record=-1)
+    _fast_vs_classic(ctx, base.replace(b"\n2500,", b"\n#2500,"), [0, 2], expect_fast=False, comment=b"#")
+    _fast_vs_classic(ctx, b"#c\n" + base, [0, 2], expect_fast=False, comment=b"#")
+    _fast_vs_classic(ctx, base + b"\n", [0, 2], expect_fast=False)                             # a blank line at the very end
+    wide = b"".join(b",".join(b"%d" % (i * j) for j in range(1, 7)) + b"\n" for i in range(3000))
+    _fast_vs_classic(ctx, wide, [0, 1, 2, 3, 4], expect_fast=False)
+
+
+@pytest.mark.gpu
+def test_fast_path_at_bench_shape(ctx):
+    """The orders file of tools/microbench/csv_ingest.py at 2e6 records, device-resident text and output: both paths, same columns."""
+    import torch
+    from csvplus_amd import datagen as dg, ingest, _native as N
+
+    ords = dg.orders(2_000_000, 100_000, 1000)
+    a, b, c = (ords[k].values() for k in ("cust_id", "prod_id", "qty"))
+    text = b"cust_id,prod_id,qty\n" + b"".join(x + b"," + y + b"," + z + b"\n" for x, y, z in zip(a, b, c))
+    dtext = torch.frombuffer(bytearray(text), dtype=torch.uint8).to("cuda:0")
+    res = []
+    for fast in (1, 0):
+        ctx.set_option("csv_fast", fast)
+        t = ingest.csv_parse(ctx, None, [0, 1], skip_records=1, out_mem=N.CPH_MEM_HOST, device_ptr=dtext.data_ptr(), size=dtext.numel())
+        assert t.nrecords == 2_000_000 and t.error_kind == 0
+        res.append([(np.asarray(t.columns[k].data).tobytes(), np.asarray(t.columns[k].offsets).tobytes()) for k in range(2)])
+    ctx.set_option("csv_fast", 1)
+    assert res[0] == res[1]
+    assert res[0][0][0] == b"".join(a) and res[0][1][0] == b"".join(b)

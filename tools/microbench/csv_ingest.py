@@ -43,3 +43,17 @@ timed("parse -> cust_id, prod_id (device out)", lambda: ingest.csv_parse(ctx, No
                                                                         out_mem=N.CPH_MEM_DEVICE, device_ptr=ptr, size=size))
 timed("parse -> all 3 columns (device out)", lambda: ingest.csv_parse(ctx, None, [0, 1, 2], fields_per_record=3, skip_records=1,
                                                                      out_mem=N.CPH_MEM_DEVICE, device_ptr=ptr, size=size))
+
+import os
+if os.environ.get("CSV_DBG"):   # attribution of the fast path's two kernels (results are wrong with a bit set): csv_ingest.hip `dbg`
+    for dbg in (0, 1, 2, 4, 8, 2 | 4 | 8):
+        ctx.set_option("chain_debug", dbg << 16)
+        ctx.profile(True); ctx.profile_read(reset=True)
+        for _ in range(3):
+            try:
+                ingest.csv_parse(ctx, None, [0, 1], fields_per_record=-1, skip_records=1, out_mem=N.CPH_MEM_DEVICE, device_ptr=ptr, size=size).release()
+            except Exception as ex:
+                print("dbg", dbg, type(ex).__name__); break
+        p = ctx.profile_read(reset=True); ctx.profile(False)
+        print("dbg", dbg, " ".join(f"{k}={v['total_ms'] / max(1, v['launches']):.3f}" for k, v in p.items() if k.startswith("k_csv")), flush=True)
+    ctx.set_option("chain_debug", 0)
