@@ -712,7 +712,7 @@ __global__ __launch_bounds__(kCsvThreads) void k_csv_copy_fields(const uint8_t* 
 //   record of a byte       = newlines before it                                  (sum scan)
 //   field index of a byte  = delimiters since the last newline                   (segmented sum scan)
 //   start of its field     = position behind the last delimiter / newline       (max scan)
-// A tile OWNS the records that begin behind a newline inside its 16 KiB (tile 0 also owns record 0) and reads up to 8 KiB
+// A tile OWNS the records that begin behind a newline inside its 16 KiB (tile 0 also owns record 0) and reads up to 4 KiB
 // past its end to finish the last one.  Each thread looks at 64 bytes = two 64-bit masks, walks the ~10 terminators in them
 // and knows for each the record, the field index and the field's extent:
 //   k_csv_fast_count   bytes of every wanted column per tile (+ the field counts' minimum / maximum, and anything the fast
@@ -724,9 +724,9 @@ __global__ __launch_bounds__(kCsvThreads) void k_csv_copy_fields(const uint8_t* 
 // Neither k_csv_separators (0.22 ms, 8 bytes per record written) nor k_csv_classify (0.29 ms) runs: the text is read three times
 // (tile statistics, count, copy), never walked byte by byte.
 // ================================================================================================================
-constexpr int kFtThreads = 384;
+constexpr int kFtThreads = 320;
 constexpr int kFtWaves = kFtThreads / kWave;
-constexpr int kFtStage = kFtThreads * 64;   // 24 KiB staged per 16 KiB tile
+constexpr int kFtStage = kFtThreads * 64;   // 20 KiB staged per 16 KiB tile: a record may run 4 KiB past its tile
 constexpr int kFtOwn = kCsvTile / 64;       // the chunks (threads) of the tile's own 16 KiB
 constexpr int kFtMaxCols = 4;
 static_assert(kFtStage > kCsvTile && kFtStage % 64 == 0, "a tile's stage must reach past its end");
@@ -918,8 +918,9 @@ __global__ __launch_bounds__(kFtThreads) void k_csv_fast(const uint8_t* __restri
     uint64_t wm[kFtMaxCols] = {0, 0, 0, 0};
     bool bad = false;
     const uint64_t cont = ~(nm << 1);   // position i continues the record of position i - 1
-    uint64_t e[4];                      // bit b of the number of delimiters in front of every position, since its record began (or the chunk)
-    {
+    uint64_t e[4] = {0, 0, 0, 0};       // bit b of the number of delimiters in front of every position, since its record began (or the chunk)
+    const bool wave_owns = __ballot(vm != 0) != 0;   // (the waves behind the last owned record's end — most of the overhang — have nothing to do)
+    if (wave_owns) {
         uint64_t carry = cm;            // positions whose delimiter increments bit b
 #pragma unroll
         for (int b = 0; b < 4; b++) {
@@ -939,7 +940,7 @@ __global__ __launch_bounds__(kFtThreads) void k_csv_fast(const uint8_t* __restri
     if (!COPY && t == 0 && threadIdx.x == 0 && first > (uint64_t)own + 1u) atomicOr(&flags->slow, 1u);
 #pragma unroll
     for (int c = 0; c < kFtMaxCols; c++) {
-        if (c >= cols.ncols) continue;
+        if (c >= cols.ncols || !wave_owns) continue;
         const uint32_t k = (uint32_t)cols.index[c];
         uint64_t m_closed = k < 16u ? ~open : 0ull, m_open = (k >= ex.cc && k - ex.cc < 16u) ? open : 0ull;
         const uint32_t ko = k - ex.cc;
@@ -955,7 +956,7 @@ __global__ __launch_bounds__(kFtThreads) void k_csv_fast(const uint8_t* __restri
     for (int c = 0; c < kFtMaxCols; c++) colbytes[c] = (uint32_t)__popcll(wm[c]);
     if (!COPY) {
         uint32_t nf_min = 0xFFFFFFFFu, nf_max = 0;
-        if (!(dbg & 4)) {
+        if (!(dbg & 4) && wave_owns) {
             // empty lines (Go's Reader skips them; the classic path does): a newline right behind a newline or the text's first byte, also
             // with a '\r' in between
             const uint64_t pN = threadIdx.x ? ((const CPH_LDS uint64_t*)nmask)[threadIdx.x - 1] : 0ull;

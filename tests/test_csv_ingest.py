@@ -531,7 +531,7 @@ def test_fast_path_ragged_records_and_tile_edges(ctx):
     for pad in (16382, 16383, 16384, 16385, 32767, 32768):
         first = b"h1,h2\n"
         body = b"x" * (pad - len(first) - 3) + b",y\n" + b"a,b\nc,d\n"
-        fits = pad < 20000                                                     # (a record may run 8 KiB past the end of its tile)
+        fits = pad < 20000                                                     # (a record may run 4 KiB past the end of its tile)
         _fast_vs_classic(ctx, first + body, [0, 1], expect_fast=fits)
         _fast_vs_classic(ctx, first + body[:-1], [1, 0], expect_fast=fits, skip_records=1)      # no final newline
     text = (b"k" * 8 + b",v\n") * 2048 * 3                                       # 11 bytes x 6144 records: not a multiple of the tile
@@ -540,8 +540,8 @@ def test_fast_path_ragged_records_and_tile_edges(ctx):
     assert len(text) % 16384 == 0
     _fast_vs_classic(ctx, text, [0, 1])
     _fast_vs_classic(ctx, text[:-1], [0, 1])
-    # a record that runs ~8 KiB past the end of its tile still fits the staged window; a longer one goes to the classic kernels
-    fits = b"a,b\n" * 4000 + b"x" * 7000 + b",y\n" + b"c,d\n" * 10
+    # a record that runs ~4 KiB past the end of its tile still fits the staged window; a longer one goes to the classic kernels
+    fits = b"a,b\n" * 4000 + b"x" * 3500 + b",y\n" + b"c,d\n" * 10
     _fast_vs_classic(ctx, fits, [0, 1])
     too_long = b"a,b\n" * 4000 + b"x" * 30000 + b",y\n" + b"c,d\n" * 10
     _fast_vs_classic(ctx, too_long, [0, 1], expect_fast=False)
