@@ -126,7 +126,11 @@ __device__ __forceinline__ uint64_t load_chunk_nobranch(const uint8_t* base8, ui
     const bool has = len > off;
     const uint32_t left = len - off;
     const uint32_t nb = has ? (left < 8u ? left : 8u) : 1u;
-    const uint64_t a = has ? (uint64_t)x + (delta + off) : 0ull;
+    // a chunk past the value's end reads the word at the value's OWN first byte (never used): always inside the column's allocation
+    // (+ its slack).  Round 6: it used to read the column's base pointer — which a chunk column of the streaming Join biases by the
+    // chunk's first offset (stream_join.hip: stage_chunk_col), i.e. an address in front of the allocation: a GPU memory fault whenever
+    // that page happened to be unmapped (found by the full suite after the allocation pattern of the CSV tests changed).
+    const uint64_t a = (uint64_t)x + (has ? delta + off : delta);
     const uint32_t a7 = (uint32_t)a & 7u;
     const bool straddles = a7 + nb > 8u;
     const global_u64u_ptr wp = (global_u64u_ptr)((global_u8_ptr)base8 + (straddles ? a : a & ~7ull));

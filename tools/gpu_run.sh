@@ -34,7 +34,9 @@ profile-variant)
   timeout 1200 bash tools/gpu_profile.sh ${TAG}_$V --variants $V 2>&1 | tail -40
   ;;
 suite)
-  timeout 2400 python -m pytest tests -m gpu -q "$@" 2>&1 | tail -25 | tee $OUT/pytest.txt
+  timeout 2400 python -m pytest tests -m gpu -q "$@" > $OUT/pytest_full.txt 2>&1
+  grep -n "Fatal Python\|^tests/.*::\|File \"/root\|File \".*/tests/\|File \".*/csvplus_amd/" $OUT/pytest_full.txt | head -20
+  tail -25 $OUT/pytest_full.txt | tee $OUT/pytest.txt
   ;;
 tests)
   timeout 2400 python -m pytest -m gpu -q "$@" 2>&1 | tail -40 | tee $OUT/pytest.txt
