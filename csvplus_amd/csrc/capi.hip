@@ -922,9 +922,11 @@ static Status build_encode_sort(cph_ctx* ctx, BuildJob* job) {
             uint32_t* over = host_word(ctx);
             if (!over) return {CPH_ERR_HIP, "no pinned host memory for the report words of a build"};
             vb.reset();
+            CountedSort cs;
+            CPH_TRY(cs.begin(ctx, csp, n));
             CPH_TRY(codec_encode_build(ctx, cd, ix->codec_dev, dcols, n, ka.get(), &eh, &job->spec, job->miss));
             CPH_TRY(ix->first_dup_dev.alloc(&ctx->pool, sizeof(uint32_t)));
-            CPH_TRY(counted_sort(ctx, csp, ka.as<uint32_t>(), n, states, va.as<uint32_t>(), kb.as<uint32_t>(), ix->first_dup_dev.as<uint32_t>(), over));
+            CPH_TRY(cs.run(ctx, ka.as<uint32_t>(), n, states, va.as<uint32_t>(), kb.as<uint32_t>(), ix->first_dup_dev.as<uint32_t>(), over, false));
             job->cs_over = over;
             job->cs_codes = std::move(ka);
             ix->sorted_codes = std::move(kb);

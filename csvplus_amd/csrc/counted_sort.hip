@@ -384,28 +384,33 @@ bool counted_sort_plan(const cph_ctx* ctx, uint64_t n, uint64_t states, CountedS
 
 // codes[n] -> perm_out[n], sorted_out[n] (neither aliases codes: on *over_host != 0 — read after the stream is synchronised —
 // nothing was sorted and the caller runs the classic passes over the untouched codes); *first_dup_dev (device, preset to
-// 0xFFFFFFFF by this function) gets the sorted position of the first row equal to its predecessor.
-Status counted_sort(cph_ctx* ctx, const CountedSortPlan& p, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out,
-                    uint32_t* sorted_out, uint32_t* first_dup_dev, uint32_t* over_host) {
+// 0xFFFFFFFF by run) gets the sorted position of the first row equal to its predecessor.
+Status CountedSort::begin(cph_ctx* ctx, const CountedSortPlan& plan, uint64_t n) {
+    p = plan;
     const uint32_t nwt = p.nwt;
-    // [counts nwt | flag 1 | first_dup preset lives with the caller] [wbase nwt+1] [cur2 nwt] [base1 nb1+1] [cur1 nb1]
-    DevBuf words, ent1, ent2;
+    // [counts nwt | flag 1] [wbase nwt+1] [cur2 nwt] [base1 nb1+1] [cur1 nb1]
     const size_t nwords = (size_t)nwt + 1 + (size_t)nwt + 1 + (size_t)nwt + (size_t)p.nb1 + 1 + (size_t)p.nb1;
     CPH_TRY(words.alloc(&ctx->pool, nwords * sizeof(uint32_t)));
-    uint32_t* counts = words.as<uint32_t>();
+    counts = words.as<uint32_t>();
+    CPH_TRY(ent1.alloc(&ctx->pool, n * sizeof(uint64_t)));
+    if (p.two) CPH_TRY(ent2.alloc(&ctx->pool, n * sizeof(uint64_t)));
+    CPH_HIP_TRY(hipMemsetAsync(counts, 0, ((size_t)nwt + 1) * sizeof(uint32_t), ctx->stream));
+    return {};
+}
+
+Status CountedSort::run(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out, uint32_t* sorted_out,
+                        uint32_t* first_dup_dev, uint32_t* over_host, bool hist_done) {
+    const uint32_t nwt = p.nwt;
     uint32_t* flag = counts + nwt;
     uint32_t* wbase = flag + 1;
     uint32_t* cur2 = wbase + nwt + 1;
     uint32_t* base1 = cur2 + nwt;
     uint32_t* cur1 = base1 + p.nb1 + 1;
-    CPH_TRY(ent1.alloc(&ctx->pool, n * sizeof(uint64_t)));
-    if (p.two) CPH_TRY(ent2.alloc(&ctx->pool, n * sizeof(uint64_t)));
-    CPH_HIP_TRY(hipMemsetAsync(counts, 0, ((size_t)nwt + 1) * sizeof(uint32_t), ctx->stream));
     CPH_HIP_TRY(hipMemsetAsync(first_dup_dev, 0xFF, sizeof(uint32_t), ctx->stream));
     *over_host = 0;
     int cus = 256;
     CPH_TRY(device_cus(ctx, &cus));
-    {
+    if (!hist_done) {
         const size_t lds = (size_t)nwt * sizeof(uint32_t);
         CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_cs_hist), kCsHistThreads, lds, nullptr));
         ProfScope ps(ctx, "k_cs_hist", 4.0 * (double)n);
@@ -464,6 +469,13 @@ Status counted_sort(cph_ctx* ctx, const CountedSortPlan& p, const uint32_t* code
         CPH_HIP_TRY(hipGetLastError());
     }
     return {};
+}
+
+Status counted_sort(cph_ctx* ctx, const CountedSortPlan& plan, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out,
+                    uint32_t* sorted_out, uint32_t* first_dup_dev, uint32_t* over_host) {
+    CountedSort cs;
+    CPH_TRY(cs.begin(ctx, plan, n));
+    return cs.run(ctx, codes, n, states, perm_out, sorted_out, first_dup_dev, over_host, false);
 }
 
 }  // namespace cph

@@ -620,8 +620,17 @@ struct CountedSortPlan {
     bool two = false;
 };
 bool counted_sort_plan(const cph_ctx* ctx, uint64_t n, uint64_t states, CountedSortPlan* p);
-Status counted_sort(cph_ctx* ctx, const CountedSortPlan& p, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out,
-                    uint32_t* sorted_out, uint32_t* first_dup_dev, uint32_t* over_host);
+// In two steps: begin (buffers, zeroed counters) | run.  (hist_done: somebody else filled the counters.  Counting the rows per window
+// inside the split-codec encode kernel was tried in round 6: its LDS atomics and the 34 KB of counters cost the kernel 0.23 ms, the
+// separate k_cs_hist pass 0.10 ms.)
+struct CountedSort {
+    CountedSortPlan p;
+    DevBuf words, ent1, ent2;
+    uint32_t* counts = nullptr;
+    Status begin(cph_ctx* ctx, const CountedSortPlan& plan, uint64_t n);
+    Status run(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out, uint32_t* sorted_out, uint32_t* first_dup_dev,
+               uint32_t* over_host, bool hist_done);
+};
 void warm_counted_sort();
 // distinct 32-bit codes over a dense space: one scatter instead of radix passes (optimistic; *flag raised on a duplicate)
 Status direct_sort_distinct(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out, uint32_t* sorted_out,

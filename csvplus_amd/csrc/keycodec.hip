@@ -1096,7 +1096,10 @@ __global__ __launch_bounds__(kSplitThreads) void k_split_count(DevCol col, uint6
 // and leaves the first radix pass's histogram behind (k_encode_build_fast).  *miss is raised by a row whose prefix is not
 // in the dictionary: the caller starts over without the split.  (Suffix symbols need no check: the alphabets come from
 // exact statistics over these very rows.)
-template <class OUT, int NCH>
+// PLAIN32: a variable-length column with 32-bit offsets and neither skip nor take (the usual key column): the value spans come from
+// two plain loads per row — value_span_whole's uniform branches (fixed width? 64-bit offsets? a segment?) ended a basic block per row
+// and kept the four rows' loads from being issued together.
+template <class OUT, int NCH, bool PLAIN32 = false>
 __global__ __launch_bounds__(kSplitThreads) void k_encode_split(DevCol col, const uint8_t* __restrict__ g_codec, uint64_t n,
                                                                OUT* __restrict__ out, uint32_t tile_rows, uint32_t ntiles,
                                                                uint32_t* __restrict__ counts, uint32_t digit_mask, uint32_t bins,
@@ -1130,10 +1133,27 @@ __global__ __launch_bounds__(kSplitThreads) void k_encode_split(DevCol col, cons
             ValueRegs<NCH> v[kSplitRows];
             {
                 uint64_t b[kSplitRows], l[kSplitRows];
+                if constexpr (PLAIN32) {
+                    const uint32_t* __restrict__ offs = reinterpret_cast<const uint32_t*>(col.offsets);
+                    uint32_t o0[kSplitRows], o1[kSplitRows];
 #pragma unroll
-                for (int k = 0; k < kSplitRows; k++) {   // rows past the end re-read the last row (never stored)
-                    const uint64_t i = base + (uint64_t)k * kSplitThreads + threadIdx.x;
-                    value_span_whole(col, i < n ? i : n - 1, &b[k], &l[k]);
+                    for (int k = 0; k < kSplitRows; k++) {   // rows past the end re-read the last row (never stored)
+                        const uint64_t i = base + (uint64_t)k * kSplitThreads + threadIdx.x;
+                        const uint64_t r = i < n ? i : n - 1;
+                        o0[k] = offs[r];
+                        o1[k] = offs[r + 1];
+                    }
+#pragma unroll
+                    for (int k = 0; k < kSplitRows; k++) {
+                        b[k] = o0[k];
+                        l[k] = o1[k] - o0[k];
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < kSplitRows; k++) {   // rows past the end re-read the last row (never stored)
+                        const uint64_t i = base + (uint64_t)k * kSplitThreads + threadIdx.x;
+                        value_span_whole(col, i < n ? i : n - 1, &b[k], &l[k]);
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < kSplitRows; k++) v[k].load(col, b[k], l[k]);
@@ -2002,9 +2022,11 @@ Status codec_encode_build(cph_ctx* ctx, const CodecHost& cd, const DevBuf& codec
                                (uint32_t)std::min<int64_t>(cd.split_maxlen, small_values ? 24 : kSplitMaxValue));
             return {};
         };
+        const bool plain32 = !cols[0].fixed_width && cols[0].offset_bits == 32 && cols[0].skip == 0 && cols[0].take == 0xFFFFFFFFu;
         if (cd.key32) {
             uint32_t* o = reinterpret_cast<uint32_t*>(out_codes);
-            if (small_values) CPH_TRY(launch(&k_encode_split<uint32_t, 3>, o));
+            if (small_values && plain32) CPH_TRY(launch(&k_encode_split<uint32_t, 3, true>, o));
+            else if (small_values) CPH_TRY(launch(&k_encode_split<uint32_t, 3>, o));
             else CPH_TRY(launch(&k_encode_split<uint32_t, 5>, o));
         } else {
             uint64_t* o = reinterpret_cast<uint64_t*>(out_codes);
