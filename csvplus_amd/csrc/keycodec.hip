@@ -846,6 +846,15 @@ struct ValueRegs {
 #pragma unroll
         for (int j = 0; j < NCH; j++) c[j] = load_chunk_nobranch<uint64_t>(base8, delta, begin, len, (uint32_t)j);
     }
+    // the same for a column whose values lie within 4 GiB (32-bit offsets): one 32-bit register per row until the address is formed
+    __device__ __forceinline__ void load32(const DevCol& col, uint32_t begin, uint32_t l) {
+        const uint64_t p = (uint64_t)(uintptr_t)col.data;
+        const uint8_t* base8 = (const uint8_t*)(uintptr_t)(p & ~7ull);
+        const uint32_t delta = (uint32_t)(p & 7ull);
+        len = l;
+#pragma unroll
+        for (int j = 0; j < NCH; j++) c[j] = load_chunk_nobranch<uint32_t>(base8, delta, begin, len, (uint32_t)j);
+    }
     // offset of the first byte equal to the bytes of dv (d repeated 8 times), len when there is none
     __device__ __forceinline__ uint32_t find(uint64_t dv) const {
         uint32_t at = 0xFFFFFFFFu;
@@ -1144,19 +1153,16 @@ __global__ __launch_bounds__(kSplitThreads) void k_encode_split(DevCol col, cons
                         o1[k] = offs[r + 1];
                     }
 #pragma unroll
-                    for (int k = 0; k < kSplitRows; k++) {
-                        b[k] = o0[k];
-                        l[k] = o1[k] - o0[k];
-                    }
+                    for (int k = 0; k < kSplitRows; k++) v[k].load32(col, o0[k], o1[k] - o0[k]);
                 } else {
 #pragma unroll
                     for (int k = 0; k < kSplitRows; k++) {   // rows past the end re-read the last row (never stored)
                         const uint64_t i = base + (uint64_t)k * kSplitThreads + threadIdx.x;
                         value_span_whole(col, i < n ? i : n - 1, &b[k], &l[k]);
                     }
-                }
 #pragma unroll
-                for (int k = 0; k < kSplitRows; k++) v[k].load(col, b[k], l[k]);
+                    for (int k = 0; k < kSplitRows; k++) v[k].load(col, b[k], l[k]);
+                }
             }
             uint32_t plen[kSplitRows], slen[kSplitRows], hh[kSplitRows], disp[kSplitRows], e[kSplitRows];
             uint64_t w[kSplitRows][4];
@@ -1174,10 +1180,13 @@ __global__ __launch_bounds__(kSplitThreads) void k_encode_split(DevCol col, cons
             bool hit[kSplitRows];
 #pragma unroll
             for (int k = 0; k < kSplitRows; k++) {   // (entry 0 stands in for an empty slot: compared, never accepted)
+                // (all of the entry's words are loaded, then compared: a short-circuit && put a branch and an LDS wait between them)
                 const CPH_LDS WideKey* key = cv.wide + (e[k] ? e[k] - 1 : 0);
-                bool same = key->len == plen[k] && key->w[0] == w[k][0] && key->w[1] == w[k][1] && key->w[2] == w[k][2];
-                if constexpr (NCH > 3) same = same && key->w[3] == w[k][3];
-                hit[k] = e[k] != 0 && same;
+                const uint32_t klen = key->len;
+                const uint64_t k0 = key->w[0], k1 = key->w[1], k2 = key->w[2];
+                uint64_t diff = (k0 ^ w[k][0]) | (k1 ^ w[k][1]) | (k2 ^ w[k][2]);
+                if constexpr (NCH > 3) diff |= key->w[3] ^ w[k][3];
+                hit[k] = (e[k] != 0) & (klen == plen[k]) & (diff == 0);
             }
             OUT acc[kSplitRows];
             uint64_t w0[kSplitRows], w1[kSplitRows];
