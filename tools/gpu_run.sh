@@ -43,6 +43,7 @@ tests)
   ;;
 fuzz)
   S=${1:-60}
+  timeout $((S*3+100)) python tools/fuzz_round6.py $S 604 2>&1 | grep -v amdgpu.ids | tee $OUT/fuzz_round6.txt | tail -4
   timeout $((S*3+100)) python tools/fuzz_round5.py $S 601 2>&1 | grep -v amdgpu.ids | tee $OUT/fuzz_round5.txt | tail -4
   timeout $((S*3+100)) python tools/fuzz_gpu.py $S 602 2>&1 | grep -v amdgpu.ids | tee $OUT/fuzz_gpu.txt | tail -3
   timeout $((S*3+100)) python tools/fuzz_builds.py $S 603 2>&1 | grep -v amdgpu.ids | tee $OUT/fuzz_builds.txt | tail -3
