@@ -728,7 +728,7 @@ constexpr int kFtThreads = 320;
 constexpr int kFtWaves = kFtThreads / kWave;
 constexpr int kFtStage = kFtThreads * 64;   // 20 KiB staged per 16 KiB tile: a record may run 4 KiB past its tile
 constexpr int kFtOwn = kCsvTile / 64;       // the chunks (threads) of the tile's own 16 KiB
-constexpr int kFtMaxCols = 4;
+constexpr int kFtMaxCols = 8;
 static_assert(kFtStage > kCsvTile && kFtStage % 64 == 0, "a tile's stage must reach past its end");
 struct FtCols {
     int32_t ncols;
@@ -844,14 +844,15 @@ __device__ __forceinline__ uint64_t ft_through_kth(uint64_t m, uint32_t k) {
 // the window's newline number own + 1 — when the window holds it.
 //   COUNT: tile_tot[c][t] = bytes of wanted column c; tile_tot[ncols][t] = newlines of the tile's own 16 KiB; flags.
 //   COPY:  tile_tot holds the exclusive scan over the concatenation of these arrays.
-template <bool COPY>
+// MAXC: 4 or 8 — the wanted columns the instantiation has registers for (per column: a 64-bit byte mask, position, span, base)
+template <bool COPY, int MAXC>
 __global__ __launch_bounds__(kFtThreads) void k_csv_fast(const uint8_t* __restrict__ d, uint64_t size, uint64_t ntiles, CsvOpts o, FtCols cols,
                                                         uint64_t first, uint64_t nrec /* COPY only */, uint64_t* __restrict__ tile_tot,
                                                         FtFlags* __restrict__ flags, uint32_t* __restrict__ offs /* column c at offs + c * stride */,
                                                         uint64_t stride, uint8_t* const* __restrict__ out_data, int dbg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ FtScan s_w[kFtWaves + 1];
-    __shared__ uint32_t s_col[kFtMaxCols][kFtWaves + 1];
+    __shared__ uint32_t s_col[MAXC][kFtWaves + 1];
     __shared__ uint32_t s_sel[16];
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     CPH_LDS uint8_t* stage = (CPH_LDS uint8_t*)smem;
@@ -915,7 +916,7 @@ __global__ __launch_bounds__(kFtThreads) void k_csv_fast(const uint8_t* __restri
     // plane b carries.  No loop over the chunk's ~11 terminators, no divergence (the first version walked them: 1200 instructions
     // per chunk).  Positions in front of the chunk's first newline continue a record of the chunk before: their index starts at ex.cc.
     // A record with a 16th delimiter inside one chunk's reach aliases: *slow.
-    uint64_t wm[kFtMaxCols] = {0, 0, 0, 0};
+    uint64_t wm[MAXC] = {};
     bool bad = false;
     const uint64_t cont = ~(nm << 1);   // position i continues the record of position i - 1
     uint64_t e[4] = {0, 0, 0, 0};       // bit b of the number of delimiters in front of every position, since its record began (or the chunk)
@@ -939,7 +940,7 @@ __global__ __launch_bounds__(kFtThreads) void k_csv_fast(const uint8_t* __restri
     if (rs < first) keep = data & ~ft_through_kth(nm, (uint32_t)(first - rs));   // header records end inside or behind this chunk
     if (!COPY && t == 0 && threadIdx.x == 0 && first > (uint64_t)own + 1u) atomicOr(&flags->slow, 1u);
 #pragma unroll
-    for (int c = 0; c < kFtMaxCols; c++) {
+    for (int c = 0; c < MAXC; c++) {
         if (c >= cols.ncols || !wave_owns) continue;
         const uint32_t k = (uint32_t)cols.index[c];
         uint64_t m_closed = k < 16u ? ~open : 0ull, m_open = (k >= ex.cc && k - ex.cc < 16u) ? open : 0ull;
@@ -951,9 +952,9 @@ __global__ __launch_bounds__(kFtThreads) void k_csv_fast(const uint8_t* __restri
         }
         wm[c] = (m_closed | m_open) & keep;
     }
-    uint32_t colbytes[kFtMaxCols];
+    uint32_t colbytes[MAXC];
 #pragma unroll
-    for (int c = 0; c < kFtMaxCols; c++) colbytes[c] = (uint32_t)__popcll(wm[c]);
+    for (int c = 0; c < MAXC; c++) colbytes[c] = (uint32_t)__popcll(wm[c]);
     if (!COPY) {
         uint32_t nf_min = 0xFFFFFFFFu, nf_max = 0;
         if (!(dbg & 4) && wave_owns) {
@@ -991,7 +992,7 @@ __global__ __launch_bounds__(kFtThreads) void k_csv_fast(const uint8_t* __restri
             }
         }
 #pragma unroll
-        for (int c = 0; c < kFtMaxCols; c++) {
+        for (int c = 0; c < MAXC; c++) {
             const uint32_t v = wave_sum(colbytes[c]);
             if (lane_id() == 0) s_col[c][wave_id()] = v;
         }
@@ -1013,18 +1014,18 @@ __global__ __launch_bounds__(kFtThreads) void k_csv_fast(const uint8_t* __restri
         return;
     }
     // ---- COPY: where this thread's bytes of every column go inside the tile ----
-    uint32_t pos[kFtMaxCols];       // bytes of column c in this tile in front of this thread's chunk
-    uint64_t obase[kFtMaxCols];     // the tile's first byte of column c in the column's data
-    uint32_t span[kFtMaxCols];
+    uint32_t pos[MAXC];       // bytes of column c in this tile in front of this thread's chunk
+    uint64_t obase[MAXC];     // the tile's first byte of column c in the column's data
+    uint32_t span[MAXC];
 #pragma unroll
-    for (int c = 0; c < kFtMaxCols; c++) {
+    for (int c = 0; c < MAXC; c++) {
         const uint32_t incl = wave_inclusive_sum(colbytes[c]);
         if (lane_id() == kWave - 1) s_col[c][wave_id()] = incl;
         pos[c] = incl - colbytes[c];
     }
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < kFtMaxCols; c++) {
+    for (int c = 0; c < MAXC; c++) {
         uint32_t pre = 0, tot = 0;
 #pragma unroll
         for (int w = 0; w < kFtWaves; w++) {
@@ -1041,7 +1042,7 @@ __global__ __launch_bounds__(kFtThreads) void k_csv_fast(const uint8_t* __restri
         const uint64_t r_first = tile_tot[(uint64_t)cols.ncols * ntiles + t] - tile_tot[(uint64_t)cols.ncols * ntiles] + lo_rec;
         if (threadIdx.x == 0 && r_first >= first && r_first <= nrec) {
 #pragma unroll
-            for (int c = 0; c < kFtMaxCols; c++)
+            for (int c = 0; c < MAXC; c++)
                 if (c < cols.ncols) offs[(uint64_t)c * stride + (r_first - first)] = (uint32_t)obase[c];
         }
     }
@@ -1054,7 +1055,7 @@ __global__ __launch_bounds__(kFtThreads) void k_csv_fast(const uint8_t* __restri
             if (r + 1 >= first && r + 1 <= nrec) {
                 const uint64_t below = (1ull << bit) - 1ull;
 #pragma unroll
-                for (int c = 0; c < kFtMaxCols; c++)
+                for (int c = 0; c < MAXC; c++)
                     if (c < cols.ncols) offs[(uint64_t)c * stride + (r + 1 - first)] = (uint32_t)(obase[c] + pos[c] + (uint32_t)__popcll(wm[c] & below));
             }
             r++;
@@ -1071,7 +1072,7 @@ __global__ __launch_bounds__(kFtThreads) void k_csv_fast(const uint8_t* __restri
     // (a plain pointer into the dynamic LDS block: atomicOr has no overload for address-space pointers; the compiler still emits ds_or_b32)
     uint32_t* ost32 = reinterpret_cast<uint32_t*>(smem + ((size_t)kFtStage + 16 + 3 * (size_t)(kFtStage / 16 + 8) * sizeof(uint16_t)));
 #pragma unroll
-    for (int c = 0; c < kFtMaxCols; c++) {
+    for (int c = 0; c < MAXC; c++) {
         if (c >= cols.ncols) break;   // uniform
         const uint32_t phase = (uint32_t)(obase[c] & 15);   // the stage is phase-aligned with the column's place in global memory (flush_stage)
         if (c > 0) {   // (zeroed before the kernel's first barrier for column 0)
@@ -1144,10 +1145,13 @@ static Status csv_fast_path(cph_ctx* ctx, cph_csv_table_impl* t, const uint8_t* 
     const size_t lds_copy = lds_count + (size_t)kFtStage + 64;
     const uint64_t first_req = opt->skip_records;
     {
-        CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_csv_fast<false>), kFtThreads, lds_count, nullptr));
+        const void* fn = ncols <= 4 ? reinterpret_cast<const void*>(&k_csv_fast<false, 4>) : reinterpret_cast<const void*>(&k_csv_fast<false, 8>);
+        CPH_TRY(kernel_setup(ctx, fn, kFtThreads, lds_count, nullptr));
         ProfScope ps(ctx, "k_csv_fast_count", (double)size);
-        hipLaunchKernelGGL(k_csv_fast<false>, dim3((unsigned)ntiles), dim3(kFtThreads), lds_count, ctx->stream, d, size, ntiles, o, fc, first_req, 0ull,
-                           ttot.as<uint64_t>(), flags.as<FtFlags>(), (uint32_t*)nullptr, 0ull, (uint8_t* const*)nullptr, ctx->chain_debug >> 16);
+        auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3((unsigned)ntiles), dim3(kFtThreads), lds_count, ctx->stream, d, size, ntiles, o, fc, first_req, 0ull,
+                           ttot.as<uint64_t>(), flags.as<FtFlags>(), (uint32_t*)nullptr, 0ull, (uint8_t* const*)nullptr, ctx->chain_debug >> 16); };
+        if (ncols <= 4) go(&k_csv_fast<false, 4>);
+        else go(&k_csv_fast<false, 8>);
         CPH_HIP_TRY(hipGetLastError());
     }
     CPH_TRY(exclusive_scan_u64(ctx, ttot.as<uint64_t>(), narr * ntiles, ttot.as<uint64_t>() + narr * ntiles));
@@ -1189,12 +1193,15 @@ static Status csv_fast_path(cph_ctx* ctx, cph_csv_table_impl* t, const uint8_t* 
     {
         double out_bytes = 0;
         for (int c = 0; c < ncols; c++) out_bytes += (double)(*totals)[(size_t)c];
-        CPH_TRY(kernel_setup(ctx, reinterpret_cast<const void*>(&k_csv_fast<true>), kFtThreads, lds_copy, nullptr));
+        const void* fn = ncols <= 4 ? reinterpret_cast<const void*>(&k_csv_fast<true, 4>) : reinterpret_cast<const void*>(&k_csv_fast<true, 8>);
+        CPH_TRY(kernel_setup(ctx, fn, kFtThreads, lds_copy, nullptr));
         ProfScope ps(ctx, "k_csv_fast_copy", (double)size + out_bytes + (double)nout * 4.0 * ncols);
         // offs: entry r - first of column c at offs + c * stride
-        hipLaunchKernelGGL(k_csv_fast<true>, dim3((unsigned)ntiles), dim3(kFtThreads), lds_copy, ctx->stream, d, size, ntiles, o, fc, first, nrec,
+        auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3((unsigned)ntiles), dim3(kFtThreads), lds_copy, ctx->stream, d, size, ntiles, o, fc, first, nrec,
                            ttot.as<uint64_t>(), flags.as<FtFlags>(), reinterpret_cast<uint32_t*>(offs_all) + first, stride, ptrs.as<uint8_t*>(),
-                           ctx->chain_debug >> 16);
+                           ctx->chain_debug >> 16); };
+        if (ncols <= 4) go(&k_csv_fast<true, 4>);
+        else go(&k_csv_fast<true, 8>);
         CPH_HIP_TRY(hipGetLastError());
     }
     *done = true;

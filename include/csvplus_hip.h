@@ -178,7 +178,7 @@ CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
  *                   (one key with more duplicates, a dense cluster in a sparse code space) is noticed on the device and the classic
  *                   passes sort the same codes.  Same index either way (A/B switch)
  *   "csv_fast"      0 / 1 (default 1): cph_csv_parse first tries byte-parallel passes over 16 KiB text tiles (texts without any quote,
- *                   no TrimLeadingSpace, <= 4 columns, < 4 GiB, no blank / comment line inside, records that end within 4 KiB of their
+ *                   no TrimLeadingSpace, <= 8 columns, < 4 GiB, no blank / comment line inside, records that end within 4 KiB of their
  *                   tile); anything else — and every error — goes through the record-parallel kernels.  Same columns either way
  *   "direct_sort"   0 / 1 (default 1): a build that expects distinct keys (cph_index_build with unique = 1, cph_index_spec.unique) over a
  *                   dense 32-bit code space (rows <= code states <= 2 rows: decimal ids, row numbers) sorts without radix passes: the rows

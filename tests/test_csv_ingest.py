@@ -458,7 +458,7 @@ def test_gpu_small_mixed_cases_match_oracle(ctx):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# (round 6) the byte-parallel fast path (csv_ingest.hip: k_csv_fast): texts without quotes, <= 4 columns
+# (round 6) the byte-parallel fast path (csv_ingest.hip: k_csv_fast): texts without quotes, <= 8 columns
 # ---------------------------------------------------------------------------------------------------------------
 def _parse_profiled(ctx, text, cols, **kw):
     from csvplus_amd import ingest
@@ -549,7 +549,7 @@ def test_fast_path_ragged_records_and_tile_edges(ctx):
 
 @pytest.mark.gpu
 def test_fast_path_gives_way_to_the_classic_kernels(ctx):
-    """A quote anywhere, TrimLeadingSpace, a blank line in the middle, a comment line, more than 4 columns: the record-parallel kernels."""
+    """A quote anywhere, TrimLeadingSpace, a blank line in the middle, a comment line, more than 8 columns: the record-parallel kernels."""
     base = b"id,name,qty\n" + b"".join(b"%d,n%d,%d\n" % (i, i % 97, i % 13) for i in range(5000))
     _fast_vs_classic(ctx, base, [0, 2], skip_records=1)
     _fast_vs_classic(ctx, base, [0, 2], comment=b"#")                                        # a comment character, no comment line
@@ -559,8 +559,10 @@ def test_fast_path_gives_way_to_the_classic_kernels(ctx):
     _fast_vs_classic(ctx, base.replace(b"\n2500,", b"\n#2500,"), [0, 2], expect_fast=False, comment=b"#")
     _fast_vs_classic(ctx, b"#c\n" + base, [0, 2], expect_fast=False, comment=b"#")
     _fast_vs_classic(ctx, base + b"\n", [0, 2], expect_fast=False)                             # a blank line at the very end
-    wide = b"".join(b",".join(b"%d" % (i * j) for j in range(1, 7)) + b"\n" for i in range(3000))
-    _fast_vs_classic(ctx, wide, [0, 1, 2, 3, 4], expect_fast=False)
+    wide = b"".join(b",".join(b"%d" % (i * j) for j in range(1, 12)) + b"\n" for i in range(3000))
+    _fast_vs_classic(ctx, wide, [0, 1, 2, 3, 4])                                               # 5-8 columns: the 8-column instantiation
+    _fast_vs_classic(ctx, wide, [10, 0, 3, 3, 7, 1, 2, 9], skip_records=2)
+    _fast_vs_classic(ctx, wide, [0, 1, 2, 3, 4, 5, 6, 7, 8], expect_fast=False)               # 9 columns: the record-parallel kernels
 
 
 @pytest.mark.gpu

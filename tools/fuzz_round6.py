@@ -105,7 +105,7 @@ def parse(text, cols, **kw):
 
 
 def csv_case():
-    nf = int(rng.integers(1, 7))
+    nf = int(rng.integers(1, 10))
     big = rng.random() < 0.5
     nrec = int(rng.integers(2000, 40_000)) if big else int(rng.integers(1, 120))
     ragged = rng.random() < 0.3
@@ -121,9 +121,9 @@ def csv_case():
             text = text[:p + 1] + b'"q"' + text[p + 1:]               # a quoted field (or a bare quote: the error must agree too)
     elif spoil == 2 and rng.random() < 0.5:
         text += b"\r"
-    ncols = int(rng.integers(1, min(nf, 4) + 1))
+    ncols = int(rng.integers(1, min(nf, 8) + 1))
     cols = sorted(rng.choice(nf, size=ncols, replace=False).tolist())
-    if ncols < 4 and rng.random() < 0.2:
+    if ncols < 8 and rng.random() < 0.2:
         cols = cols + [cols[0]]
     kw = dict(fields_per_record=-1 if ragged else int(rng.choice([0, -1, nf])), skip_records=int(rng.integers(0, 4)))
     if spoil == 3:
