@@ -364,10 +364,11 @@ __global__ __launch_bounds__(kCsWinThreads) void k_cs_window(const uint64_t* __r
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------------
-bool counted_sort_plan(const cph_ctx* ctx, uint64_t n, uint64_t states, CountedSortPlan* p) {
+// max_wbits: an upper bound for the window width (the retry behind an overflow: narrower windows for a code space whose rows cluster)
+bool counted_sort_plan(const cph_ctx* ctx, uint64_t n, uint64_t states, CountedSortPlan* p, int max_wbits) {
     if (!ctx->counted_sort || n < (1ull << 21) || n >= (1ull << 32) - 1 || states == 0 || states >= 0xFFFFFFFFull) return false;
     // the widest window whose average load stays below ~0.72 of the capacity
-    int w = kCsMaxWinBits;
+    int w = max_wbits < kCsMaxWinBits ? max_wbits : kCsMaxWinBits;
     while (w >= kCsMinWinBits && (double)n / (double)states * (double)(1u << w) > 0.72 * (double)kCsCap) w--;
     if (w < kCsMinWinBits) return false;   // hundreds of rows per code: the classic passes
     const uint64_t nwin = (states + (1ull << w) - 1) >> w;

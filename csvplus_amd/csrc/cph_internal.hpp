@@ -619,7 +619,7 @@ struct CountedSortPlan {
     uint32_t wbits = 0, k2 = 0, nb1 = 0, nwt = 0;
     bool two = false;
 };
-bool counted_sort_plan(const cph_ctx* ctx, uint64_t n, uint64_t states, CountedSortPlan* p);
+bool counted_sort_plan(const cph_ctx* ctx, uint64_t n, uint64_t states, CountedSortPlan* p, int max_wbits = 31);
 // In two steps: begin (buffers, zeroed counters) | run.  (hist_done: somebody else filled the counters.  Counting the rows per window
 // inside the split-codec encode kernel was tried in round 6: its LDS atomics and the 34 KB of counters cost the kernel 0.23 ms, the
 // separate k_cs_hist pass 0.10 ms.)
@@ -631,6 +631,8 @@ struct CountedSort {
     Status run(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out, uint32_t* sorted_out, uint32_t* first_dup_dev,
                uint32_t* over_host, bool hist_done);
 };
+Status counted_sort(cph_ctx* ctx, const CountedSortPlan& p, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out,
+                    uint32_t* sorted_out, uint32_t* first_dup_dev, uint32_t* over_host);
 void warm_counted_sort();
 // distinct 32-bit codes over a dense space: one scatter instead of radix passes (optimistic; *flag raised on a duplicate)
 Status direct_sort_distinct(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out, uint32_t* sorted_out,

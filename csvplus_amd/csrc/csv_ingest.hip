@@ -130,7 +130,7 @@ __device__ __forceinline__ TileScan scan_tile(const uint8_t* __restrict__ d, uin
 // ---- 1. per tile: quotes, newlines at even / odd parity relative to the tile start ---------------------------
 __global__ __launch_bounds__(kCsvThreads) void k_csv_tile_stats(const uint8_t* __restrict__ d, uint64_t size,
                                                                uint32_t* __restrict__ tile_quotes, uint32_t* __restrict__ tile_even,
-                                                               uint32_t* __restrict__ tile_odd, uint64_t* __restrict__ any_quote) {
+                                                               uint32_t* __restrict__ tile_odd) {
     __shared__ uint32_t s_par[kCsvChunks * kCsvWaves];
     __shared__ uint32_t s_red[3 * kCsvWaves];
     const uint64_t t = blockIdx.x;
@@ -154,7 +154,6 @@ __global__ __launch_bounds__(kCsvThreads) void k_csv_tile_stats(const uint8_t* _
         uint32_t s = 0;
         for (int w = 0; w < kCsvWaves; w++) s += s_red[threadIdx.x * kCsvWaves + w];
         (threadIdx.x == 0 ? tile_quotes : threadIdx.x == 1 ? tile_even : tile_odd)[t] = s;
-        if (threadIdx.x == 0 && s) *any_quote = 1ull;   // (the fast path is for texts without a single quote)
     }
 }
 
@@ -1273,25 +1272,18 @@ CPH_API int32_t cph_csv_parse(cph_ctx* ctx, const uint8_t* data, uint64_t size, 
             CPH_TRY(tq.alloc(&ctx->pool, ntiles * sizeof(uint32_t)));
             CPH_TRY(tev.alloc(&ctx->pool, ntiles * sizeof(uint32_t)));
             CPH_TRY(tod.alloc(&ctx->pool, ntiles * sizeof(uint32_t)));
-            CPH_TRY(cnt.alloc(&ctx->pool, (ntiles + 2) * sizeof(uint64_t)));   // [separators before tile t | their total | any quote]
-            CPH_HIP_TRY(hipMemsetAsync(cnt.as<uint64_t>() + ntiles + 1, 0, sizeof(uint64_t), ctx->stream));
+            CPH_TRY(cnt.alloc(&ctx->pool, (ntiles + 1) * sizeof(uint64_t)));
             {
                 ProfScope ps(ctx, "k_csv_tile_stats", (double)size);
                 hipLaunchKernelGGL(k_csv_tile_stats, dim3((unsigned)ntiles), dim3(kCsvThreads), 0, ctx->stream, d, size,
-                                   tq.as<uint32_t>(), tev.as<uint32_t>(), tod.as<uint32_t>(), cnt.as<uint64_t>() + ntiles + 1);
+                                   tq.as<uint32_t>(), tev.as<uint32_t>(), tod.as<uint32_t>());
             }
             CPH_TRY(exclusive_scan_u32(ctx, tq.as<uint32_t>(), ntiles));   // mod 2^32 keeps the parity
             hipLaunchKernelGGL(k_csv_pick_counts, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, ctx->stream, tq.as<uint32_t>(),
                                tev.as<uint32_t>(), tod.as<uint32_t>(), cnt.as<uint64_t>(), ntiles);
             CPH_TRY(exclusive_scan_u64(ctx, cnt.as<uint64_t>(), ntiles, cnt.as<uint64_t>() + ntiles));
-            uint64_t nsep = 0, any_quote = 0;
-            {
-                CPH_TRY(ensure_pinned_scratch(ctx, 2 * sizeof(uint64_t)));
-                CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, cnt.as<uint64_t>() + ntiles, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-                CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
-                nsep = static_cast<const uint64_t*>(ctx->pinned_scratch)[0];
-                any_quote = static_cast<const uint64_t*>(ctx->pinned_scratch)[1];
-            }
+            uint64_t nsep = 0;
+            CPH_TRY(read_device_value(ctx, cnt.as<uint64_t>() + ntiles, &nsep));
             const uint64_t nseg = nsep + 1;   // the bytes after the last separator (possibly none) form the last segment
             if (nseg > 0xFFFFFFFFull) return {CPH_ERR_TOO_MANY_ROWS, "more than 2^32-1 lines"};
             {

@@ -64,6 +64,23 @@ def test_counted_windows_equal_stable_argsort(shape):
     g.close(); r.close(); u.close(); ctx.close()
 
 
+def test_a_dense_cluster_is_sorted_with_narrower_windows():
+    """The plan sizes the windows by the AVERAGE rows per code; a dense block of keys in a sparse code space overflows them.  Before
+    the classic passes the build tries windows a quarter (then a sixteenth) as wide over the same codes."""
+    rng = np.random.default_rng(10)
+    n = 9_000_000
+    ids = np.concatenate([rng.integers(0, 600_000, n - 40_000), rng.integers(600_000, 9_990_000, 40_000)])   # 15 rows per code in the block
+    rng.shuffle(ids)
+    ctx = Context(0)
+    g, prof = build(ctx, fixed8(ids))
+    assert prof["k_cs_scan"]["launches"] == 2 and prof["k_cs_window"]["launches"] == 2 and "k_radix_scatter_u32" not in prof, sorted(prof)
+    want = stable_order(ids)
+    np.testing.assert_array_equal(g.perm(), want)
+    s = ids[want]
+    assert g.first_dup == int(np.flatnonzero(s[1:] == s[:-1])[0]) + 1
+    g.close(); ctx.close()
+
+
 @pytest.mark.parametrize("shape", ["groups_beyond_32", "one_key_beyond_a_window", "all_rows_one_key"])
 def test_large_groups_and_the_overflow_path(shape):
     """Groups of equal keys beyond 32 members are put in row order by a wave's bitonic network; a key with more duplicates than a
