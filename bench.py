@@ -52,11 +52,12 @@ def parse_args():
     ap.add_argument("--rows", type=int, default=None, help="orders (probe) rows, whole job (default 1e8; 1e9 with --stream)")
     ap.add_argument("--customers", type=int, default=10_000_000)
     ap.add_argument("--products", type=int, default=100_000)
-    ap.add_argument("--exchange", choices=["allgatherv", "host", "oneshot", "none"], default="allgatherv",
+    ap.add_argument("--exchange", choices=["allgatherv", "packed", "host", "oneshot", "none"], default="allgatherv",
                     help="N > 1: allgatherv = cph_dist_join_chain (sub-chunks of a shard leave over xGMI while the next one is joined; "
                          "every rank ends with the whole list in HBM); host = the same pipeline, each rank copying its chunks into ITS range "
                          "of one pinned host buffer shared by the ranks (no xGMI traffic, N PCIe links in parallel, SURVEY 8e); oneshot = join "
-                         "the shard, then cph_dist_chain_allgather (rounds 1-3); none = every rank keeps its shard's list")
+                         "the shard, then cph_dist_chain_allgather (rounds 1-3); none = every rank keeps its shard's list; packed = allgatherv with "
+                         "CPH_DIST_PACKED (24 + 17 bits per row on the links instead of 64; packed and unpacked on the device)")
     ap.add_argument("--chunks", type=int, default=0, help="sub-chunks per shard for --exchange allgatherv / host (0: the library picks, 1..8)")
     ap.add_argument("--ctx-option", action="append", default=[], metavar="KEY=INT",
                     help="cph_ctx_set_option on the bench's ctx before anything runs (A/B switches: scan_lookback=0, chain_arith=0 ...)")
@@ -545,11 +546,11 @@ def main():
         # the chained join straight through the binding (cph_join_chain, results left in HBM): the timed loop holds
         # no torch views of the result — it needs the row count only.  stream_row is NULL when every order joined
         # (the result row IS the stream row): then only the two build-row arrays exist, and only they are exchanged.
-        if cdist is not None and args.exchange in ("allgatherv", "host"):
+        if cdist is not None and args.exchange in ("allgatherv", "packed", "host"):
             # the shard in sub-chunks, chunk k travelling while chunk k+1 is joined (cph_dist_join_chain); the shard sizes of a
             # range split are known to everybody, so the call's only host wait is for the match totals at its end
             g = cdist.join_chain([(ia, [d_ord["cust_id"]]), (ib, [d_ord["prod_id"]])], probe_base=begin, shard_rows=shard_rows,
-                                 nchunks=args.chunks, positions=POS, host=args.exchange == "host")
+                                 nchunks=args.chunks, positions=POS, host=args.exchange == "host", packed=args.exchange == "packed")
             n = g.total
             xstats.append(g.stats)
             g.release()
@@ -644,7 +645,7 @@ def main():
             return float(allx.max().item())
 
         timed_mode = args.exchange
-        for mode in ("allgatherv", "host", "none"):
+        for mode in ("allgatherv", "packed", "host", "none"):
             if mode == timed_mode or (mode != "none" and cdist is None):
                 continue
             args.exchange = mode
@@ -657,7 +658,7 @@ def main():
                     step()
                 sync_all()
                 ms_mode = max_over_ranks((time.perf_counter() - t1) / 3 * 1e3)
-                alternatives[mode] = {"ms_per_step": round(ms_mode, 4),
+                alternatives[mode] = {"ms_per_step": round(ms_mode, 4), "bytes_sent": xstats[0]["bytes_sent"] if xstats else None,
                                       "exposed_exchange_ms": round(sum(x["exposed_exchange_ms"] for x in xstats) / len(xstats), 4) if xstats else None}
             except Exception as ex:   # noqa: BLE001 — an extra figure must not cost the line
                 alternatives[mode] = {"error": f"{type(ex).__name__}: {ex}"}
@@ -710,6 +711,7 @@ def main():
                  "join_compute_ms": mean("compute_ms"), "exchange_ms": mean("exchange_ms"), "exposed_exchange_ms": exposed,
                  "bytes_sent_per_step": xtimed[0]["bytes_sent"] if xtimed else None,
                  "bytes_received_per_step": xtimed[0]["bytes_received"] if xtimed else None,
+                 "packed_bits_per_row": xtimed[0].get("packed_bits") if xtimed else None,
                  "note": "events on the ctx stream (join of all chunks) and on the exchange stream (first chunk ready -> match totals of "
                          "all ranks received); exposed = the part of the exchange behind the last chunk's join, which nothing hides"}
         n1_ms, n1_all = None, []

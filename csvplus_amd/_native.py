@@ -118,6 +118,7 @@ class cph_chain(C.Structure):
 
 CPH_CHAIN_POSITIONS = 1
 CPH_DIST_HOST_GATHER = 0x100
+CPH_DIST_PACKED = 0x200
 
 
 class cph_colbuf(C.Structure):
@@ -163,7 +164,7 @@ class cph_gathered(C.Structure):
 class cph_dist_join_stats(C.Structure):
     _fields_ = [("chunks", C.c_int32), ("pipelined", C.c_int32), ("compute_ms", C.c_double), ("exchange_ms", C.c_double),
                 ("exposed_exchange_ms", C.c_double), ("total_ms", C.c_double), ("bytes_sent", C.c_uint64),
-                ("bytes_received", C.c_uint64)]
+                ("bytes_received", C.c_uint64), ("packed_bits", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class cph_stream_chunk(C.Structure):
@@ -737,9 +738,10 @@ class Dist:
         return Gathered(self.ctx, out, identity=bool(ident.value), stream_base=int(base.value))
 
     def join_chain(self, steps, probe_base: int = 0, shard_rows=None, nchunks: int = 0, positions: bool = False,
-                   host: bool = False) -> Gathered:
+                   host: bool = False, packed: bool = False) -> Gathered:
         """cph_dist_join_chain: this rank's shard joined in sub-chunks, chunk k exchanged (xGMI; host=True: copied into the
-        node's shared host buffer) while chunk k+1 is joined.  steps = [(DeviceIndex, [shard key columns]), ...]."""
+        node's shared host buffer) while chunk k+1 is joined.  steps = [(DeviceIndex, [shard key columns]), ...].
+        packed=True: CPH_DIST_PACKED, the chunks cross the links bit-packed (g.stats["packed_bits"] per row)."""
         arr = (cph_chain_step * len(steps))()
         keep = []
         for i, (index, cols) in enumerate(steps):
@@ -749,7 +751,7 @@ class Dist:
             arr[i].cols = carr
             arr[i].ncols = len(cols)
         sr = (C.c_uint64 * self.size)(*shard_rows) if shard_rows is not None else None
-        flags = (CPH_CHAIN_POSITIONS if positions else 0) | (CPH_DIST_HOST_GATHER if host else 0)
+        flags = (CPH_CHAIN_POSITIONS if positions else 0) | (CPH_DIST_HOST_GATHER if host else 0) | (CPH_DIST_PACKED if packed else 0)
         out = C.POINTER(cph_gathered)()
         ident, base, st = C.c_int32(0), C.c_uint64(0), cph_dist_join_stats()
         rc = self.lib.cph_dist_join_chain(self.handle, arr, len(steps), probe_base, sr, nchunks, flags, C.byref(out), C.byref(ident),

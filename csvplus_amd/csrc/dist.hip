@@ -673,6 +673,90 @@ __global__ __launch_bounds__(256) void k_mark_absent(uint32_t* __restrict__ rows
         if (!((masks[i >> 6] >> (i & 63)) & 1ull)) rows0[i] = kAbsentRow;
 }
 
+// ---- bit-packed chunks (CPH_DIST_PACKED) -----------------------------------------------------------------------------------
+// A position in an index of n rows needs ceil(log2 n) bits, not 32: 24 + 17 = 41 bits per row for the benchmark's chain instead of 64.
+// A chunk's rows are packed row-major (step 0 in the low bits; step 0's value `absent_code` = "this row did not join"), 64 rows = B
+// words, so that a thread owns whole words; the receiver unpacks into the gathered u32 arrays.
+struct PackArgs {
+    uint32_t* rows[CPH_MAX_CHAIN];
+    uint32_t bits[CPH_MAX_CHAIN];
+    int32_t nsteps;
+    uint32_t B;             // bits per row (<= 64)
+    uint32_t absent_code;   // step 0
+};
+// A block takes tiles of 256 rows = 4 groups = 4 * B words: the rows' values go through LDS (thread = row, coalesced reads of the u32
+// arrays), then thread w composes output word w from the <= 3 rows that overlap it (coalesced 8-byte stores); unpacking is the mirror.
+constexpr int kPackTile = 256, kPackTilesPerBlock = 8;
+__device__ __forceinline__ uint32_t low_mask32(uint32_t bits) { return bits >= 32 ? 0xFFFFFFFFu : (1u << bits) - 1u; }
+__global__ __launch_bounds__(256) void k_pack_rows(PackArgs a, uint64_t n, uint64_t* __restrict__ out) {
+    __shared__ uint64_t s_v[kPackTile + 2];
+    const uint32_t t = threadIdx.x, B = a.B;
+    for (int it = 0; it < kPackTilesPerBlock; it++) {
+        const uint64_t tile = (uint64_t)blockIdx.x * kPackTilesPerBlock + it, r0 = tile * kPackTile;
+        if (r0 >= n) return;
+        const uint64_t r = r0 + t;
+        uint64_t v = 0;
+        if (r < n) {
+            uint32_t shift = 0;
+            for (int s = 0; s < a.nsteps; s++) {
+                uint32_t x = __builtin_nontemporal_load(a.rows[s] + r);
+                if (s == 0 && x == kAbsentRow) x = a.absent_code;
+                v |= (uint64_t)(x & low_mask32(a.bits[s])) << shift;
+                shift += a.bits[s];
+            }
+        }
+        s_v[t] = v;
+        if (t < 2) s_v[kPackTile + t] = 0;
+        __syncthreads();
+        const uint32_t groups = (uint32_t)(((n - r0 < kPackTile ? n - r0 : (uint64_t)kPackTile) + 63) / 64);   // whole groups of 64 rows are written
+        if (t < groups * B) {
+            const uint32_t bit = t * 64, first = bit / B;
+            int32_t sh = (int32_t)(first * B) - (int32_t)bit;     // where row `first` begins relative to the word: <= 0
+            uint64_t w = s_v[first] >> (uint32_t)(-sh);
+            sh += (int32_t)B;
+            for (uint32_t q = first + 1; sh < 64; q++, sh += (int32_t)B) w |= s_v[q] << (uint32_t)sh;
+            __builtin_nontemporal_store(w, out + tile * (4 * (uint64_t)B) + t);
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k_unpack_rows(PackArgs a, uint64_t n, const uint64_t* __restrict__ in) {
+    __shared__ uint64_t s_w[kPackTile + 1];
+    const uint32_t t = threadIdx.x, B = a.B;
+    const uint64_t rowmask = B >= 64 ? ~0ull : (1ull << B) - 1ull;
+    for (int it = 0; it < kPackTilesPerBlock; it++) {
+        const uint64_t tile = (uint64_t)blockIdx.x * kPackTilesPerBlock + it, r0 = tile * kPackTile;
+        if (r0 >= n) return;
+        const uint32_t groups = (uint32_t)(((n - r0 < kPackTile ? n - r0 : (uint64_t)kPackTile) + 63) / 64);
+        if (t < groups * B) s_w[t] = __builtin_nontemporal_load(in + tile * (4 * (uint64_t)B) + t);
+        if (t == 0) s_w[kPackTile] = 0;
+        __syncthreads();
+        const uint64_t r = r0 + t;
+        if (r < n) {
+            const uint32_t bit = t * B, word = bit >> 6, off = bit & 63;
+            uint64_t v = s_w[word] >> off;
+            if (off + B > 64) v |= s_w[word + 1] << (64 - off);
+            v &= rowmask;
+            uint32_t shift = 0;
+            for (int s = 0; s < a.nsteps; s++) {
+                uint32_t x = (uint32_t)(v >> shift) & low_mask32(a.bits[s]);
+                if (s == 0 && x == a.absent_code) x = kAbsentRow;
+                a.rows[s][r] = x;
+                shift += a.bits[s];
+            }
+        }
+        __syncthreads();
+    }
+}
+static unsigned pack_grid(uint64_t rows) { return (unsigned)((rows + (uint64_t)kPackTile * kPackTilesPerBlock - 1) / ((uint64_t)kPackTile * kPackTilesPerBlock)); }
+static uint32_t bit_length(uint64_t x) {
+    uint32_t b = 0;
+    while (x) { b++; x >>= 1; }
+    return b;
+}
+// words of a packed chunk of `rows` rows: whole groups of 64 rows, a multiple of 2 words (16-byte aligned pieces)
+static uint64_t packed_words(uint64_t rows, uint32_t B) { return (((rows + 63) / 64) * B + 1) & ~1ull; }
+
 __global__ void k_sum_totals(const uint64_t* __restrict__ totals, int n, uint64_t* __restrict__ out) {
     uint64_t t = 0;
     for (int i = 0; i < n; i++) t += totals[i];
@@ -890,7 +974,7 @@ CPH_API int32_t cph_dist_join_chain(cph_dist* d, const cph_chain_step* steps, in
     cph_ctx* ctx = d->ctx;
     if (hipSetDevice(ctx->device) != hipSuccess) return fail_with(ctx, {CPH_ERR_HIP, "hipSetDevice failed"});
     if (!steps || nsteps < 1 || nsteps > CPH_MAX_CHAIN || nsteps + 1 > CPH_MAX_GATHER) return fail_with(ctx, {CPH_ERR_INVALID, "bad chain"});
-    if (flags & ~(uint32_t)(CPH_CHAIN_POSITIONS | CPH_DIST_HOST_GATHER)) return fail_with(ctx, {CPH_ERR_INVALID, "unknown cph_dist_join_chain flag"});
+    if (flags & ~(uint32_t)(CPH_CHAIN_POSITIONS | CPH_DIST_HOST_GATHER | CPH_DIST_PACKED)) return fail_with(ctx, {CPH_ERR_INVALID, "unknown cph_dist_join_chain flag"});
     if (nchunks < 0 || nchunks > kPipeMaxChunks) return fail_with(ctx, {CPH_ERR_INVALID, "nchunks must be 0 (automatic) .. 64"});
     const bool positions = (flags & CPH_CHAIN_POSITIONS) != 0, to_host = (flags & CPH_DIST_HOST_GATHER) != 0;
     for (int k = 0; k < nsteps; k++) {
@@ -1023,6 +1107,36 @@ CPH_API int32_t cph_dist_join_chain(cph_dist* d, const cph_chain_step* steps, in
                 mine[a] = g->data[a].as<uint32_t>() + displs[(size_t)me];
             }
         }
+        // CPH_DIST_PACKED: the chunks cross the links bit-packed (xGMI mode, more than one rank, at most 64 bits per row)
+        PackArgs pa{};
+        bool packed = (flags & CPH_DIST_PACKED) != 0 && !to_host && n > 1;
+        if (packed) {
+            pa.nsteps = nsteps;
+            for (int k = 0; k < nsteps; k++) {
+                const uint64_t limit = positions ? cs[k].index->nrows : cs[k].index->table_rows;   // values 0 .. limit - 1
+                pa.bits[k] = std::max<uint32_t>(1u, bit_length(k == 0 ? limit : (limit ? limit - 1 : 0)));   // step 0: + the absent code `limit`
+                pa.B += pa.bits[k];
+            }
+            pa.absent_code = (uint32_t)(positions ? cs[0].index->nrows : cs[0].index->table_rows);
+            if (pa.B > 64 || pa.bits[0] > 32) packed = false;
+        }
+        DevBuf pk;
+        std::vector<uint64_t> pwords, pdispl;   // [r * C + c]: words of rank r's chunk c, where they begin in pk
+        if (packed) {
+            pwords.assign((size_t)n * C, 0);
+            pdispl.assign((size_t)n * C, 0);
+            uint64_t at = 0;
+            for (int r = 0; r < n; r++)
+                for (int c = 0; c < C; c++) {
+                    const uint64_t q = rows[(size_t)r] / (uint64_t)C, m = rows[(size_t)r] % (uint64_t)C;
+                    const uint64_t cnt = q + ((uint64_t)c < m ? 1 : 0);
+                    pwords[(size_t)r * C + c] = cnt ? packed_words(cnt, pa.B) : 0;
+                    pdispl[(size_t)r * C + c] = at;
+                    at += pwords[(size_t)r * C + c];
+                }
+            CPH_TRY(pk.alloc(&ctx->pool, (at + 2) * sizeof(uint64_t)));
+        }
+        st.packed_bits = packed ? (int32_t)pa.B : 0;
         DevBuf totals_dev, words;
         CPH_TRY(totals_dev.alloc(&ctx->pool, (size_t)C * sizeof(uint64_t)));
         CPH_TRY(words.alloc(&ctx->pool, ((size_t)n + 1) * sizeof(uint64_t)));
@@ -1050,6 +1164,14 @@ CPH_API int32_t cph_dist_join_chain(cph_dist* d, const cph_chain_step* steps, in
                 hipLaunchKernelGGL(k_mark_absent, dim3(grid_for_items(ncur, 2048)), dim3(256), 0, ctx->stream, rp[0], masks.as<uint64_t>(), ncur,
                                    totals_dev.as<uint64_t>() + c);
                 CPH_HIP_TRY(hipGetLastError());
+                if (packed) {   // (the absent marks must be in place: a packed row carries them as step 0's absent code)
+                    PackArgs a = pa;
+                    for (int k = 0; k < nsteps; k++) a.rows[k] = rp[k];
+                    // k_mark_absent returns at once when every row joined: rows that did not join then do not exist, nothing to mark
+                    hipLaunchKernelGGL(k_pack_rows, dim3(pack_grid(ncur)), dim3(256), 0, ctx->stream, a, ncur,
+                                       pk.as<uint64_t>() + pdispl[(size_t)me * C + c]);
+                    CPH_HIP_TRY(hipGetLastError());
+                }
             }
             CPH_HIP_TRY(hipEventRecord(ev[c], ctx->stream));
             CPH_HIP_TRY(hipStreamWaitEvent(d->xstream, ev[c], 0));
@@ -1067,10 +1189,32 @@ CPH_API int32_t cph_dist_join_chain(cph_dist* d, const cph_chain_step* steps, in
                     ccounts[(size_t)r] = q + ((uint64_t)c < m ? 1 : 0);
                     cdispls[(size_t)r] = displs[(size_t)r] + q * (uint64_t)c + std::min<uint64_t>((uint64_t)c, m);
                     any = any || ccounts[(size_t)r] != 0;
-                    if (r != me) st.bytes_received += ccounts[(size_t)r] * 4 * (uint64_t)nsteps;
+                    if (r != me) st.bytes_received += packed ? pwords[(size_t)r * C + c] * 8 : ccounts[(size_t)r] * 4 * (uint64_t)nsteps;
                 }
-                st.bytes_sent += ncur * 4 * (uint64_t)nsteps * (uint64_t)(n - 1);
-                if (any) {
+                if (packed) {   // one array of 64-bit words per chunk
+                    if (any) {
+                        std::vector<uint64_t> wc((size_t)n), wd((size_t)n);
+                        for (int r = 0; r < n; r++) {
+                            wc[(size_t)r] = pwords[(size_t)r * C + c];
+                            wd[(size_t)r] = pdispl[(size_t)r * C + c];
+                        }
+                        const void* send[1] = {pk.as<uint64_t>() + pdispl[(size_t)me * C + c]};
+                        void* recv[1] = {pk.get()};
+                        const int32_t eb8[1] = {8};
+                        CPH_TRY(d->t->exchange_v(send, recv, eb8, 1, wc.data(), wd.data(), d->xstream));
+                        // unpack what the peers sent, behind the exchange on the same stream
+                        for (int r = 0; r < n; r++) {
+                            if (r == me || !ccounts[(size_t)r]) continue;
+                            PackArgs a = pa;
+                            for (int k = 0; k < nsteps; k++) a.rows[k] = g->data[k].as<uint32_t>() + cdispls[(size_t)r];
+                            hipLaunchKernelGGL(k_unpack_rows, dim3(pack_grid(ccounts[(size_t)r])), dim3(256), 0, d->xstream, a,
+                                               ccounts[(size_t)r], pk.as<uint64_t>() + pdispl[(size_t)r * C + c]);
+                            CPH_HIP_TRY(hipGetLastError());
+                        }
+                    }
+                }
+                st.bytes_sent += packed ? pwords[(size_t)me * C + c] * 8 * (uint64_t)(n - 1) : ncur * 4 * (uint64_t)nsteps * (uint64_t)(n - 1);
+                if (any && !packed) {
                     const void* send[CPH_MAX_CHAIN];
                     void* recv[CPH_MAX_CHAIN];
                     for (int a = 0; a < nsteps; a++) {

@@ -459,10 +459,15 @@ CPH_API int32_t cph_dist_chain_allgather(cph_dist* d, const cph_chain* chain, ui
  * Any other chain is joined whole and exchanged like cph_dist_chain_allgather does (stats->chunks == 0).
  *   shard_rows   optional: the row counts of ALL ranks' shards (nranks entries) when the caller knows them — as it does for
  *                a range split — and the ranges follow each other in rank order; NULL: one more count exchange up front.
- *   flags        CPH_CHAIN_POSITIONS (see cph_join_chain_ex) | CPH_DIST_HOST_GATHER
+ *   flags        CPH_CHAIN_POSITIONS (see cph_join_chain_ex) | CPH_DIST_HOST_GATHER | CPH_DIST_PACKED
  *   identity / stream_base / out: as cph_dist_chain_allgather.
  */
 #define CPH_DIST_HOST_GATHER 0x100u
+/* (round 6) xGMI mode only: the chunks travel BIT-PACKED — ceil(log2(index rows)) bits per step and row instead of 32 (the benchmark's
+ * chain: 24 + 17 = 41 bits instead of 64), packed by the sender behind every sub-chunk's join, unpacked by the receiver behind the
+ * exchange; the gathered arrays are the same.  Ignored (the plain format travels) when a row needs more than 64 bits, with
+ * CPH_DIST_HOST_GATHER and for a single rank.  stats->packed_bits says what travelled. */
+#define CPH_DIST_PACKED 0x200u
 typedef struct {
     int32_t  chunks;               /* sub-chunks per shard; 0: the one-shot path ran                                      */
     int32_t  pipelined;            /* 1: more than one chunk, exchange and compute on separate streams                    */
@@ -471,6 +476,8 @@ typedef struct {
     double   exposed_exchange_ms;  /* last chunk's join done -> totals received: the part of the exchange nothing hides   */
     double   total_ms;             /* first chunk's join enqueued -> totals received                                      */
     uint64_t bytes_sent, bytes_received;   /* this rank, row arrays only (xGMI; host gather: bytes_sent = PCIe bytes)     */
+    int32_t  packed_bits;          /* CPH_DIST_PACKED in effect: bits per row on the wire; 0: plain 32 bits per step        */
+    int32_t  reserved_;
 } cph_dist_join_stats;
 CPH_API int32_t cph_dist_join_chain(cph_dist* d, const cph_chain_step* steps, int32_t nsteps, uint64_t probe_base,
                                     const uint64_t* shard_rows, int32_t nchunks, uint32_t flags, cph_gathered** out,

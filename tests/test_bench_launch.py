@@ -203,7 +203,7 @@ def test_multi_gpu_code_path_with_one_rank(exchange):
     assert m["bytes_sent_per_step"] == (300000 * 8 if exchange == "host" else 0)
     # the other exchange modes and the exchange's own rate, measured in the same run
     others = m["same_run_other_modes"]
-    assert set(others) == {"allgatherv", "host", "none"} - {exchange}
+    assert set(others) == {"allgatherv", "packed", "host", "none"} - {exchange}
     assert all(v.get("ms_per_step", 0) > 0 for v in others.values()), others
     assert m["measured_exchange_rate"]["ms"] > 0 and m["measured_exchange_rate"]["bytes_received_per_rank"] == 0   # (one rank)
     assert len(m["n1_ms_single_steps"]) == 5

@@ -191,8 +191,17 @@ def test_loopback_pipelined_join_chain(world, domain_factor, nchunks, unequal, p
                         host=host, positions=positions, unequal=unequal, shard_given=shard_given)
 
 
+@pytest.mark.parametrize("world,domain_factor,nchunks,unequal,positions",
+                         [(2, 1, 4, False, True), (3, 2, 5, True, False), (3, 2, 3, True, True), (2, 2, 1, False, False), (4, 1, 2, True, True)])
+def test_loopback_pipelined_join_chain_bit_packed(world, domain_factor, nchunks, unequal, positions):
+    """CPH_DIST_PACKED: 12 + 6 bits per row (row ids: 4000 customers + the absent code, 60 products) cross the transport instead
+    of 64; every rank's gathered arrays are the ones of the plain format."""
+    run_pipelined_chain(world, domain_factor, loopback_factory(f"packed-{world}-{domain_factor}-{nchunks}", world), nchunks,
+                        positions=positions, unequal=unequal, packed=True)
+
+
 def run_pipelined_chain(world, domain_factor, make_dist, nchunks, host=False, positions=False, unequal=False, shard_given=True,
-                        expect_transport="loopback"):
+                        expect_transport="loopback", packed=False):
     """cph_dist_join_chain: every rank joins its shard in `nchunks` sub-chunks whose rows are exchanged (xGMI path / shared host
     buffer) while the next chunk is joined; the gathered list of EVERY rank equals the oracle's join over the whole stream
     (csvplus.go:553-567), for even and uneven shards, an empty shard, all rows joining (identity) or half of them."""
@@ -213,8 +222,16 @@ def run_pipelined_chain(world, domain_factor, make_dist, nchunks, host=False, po
         b, e = cuts[r], cuts[r + 1]
         for rep in range(2):   # the second call reuses the exchange stream, the events and the shared host buffer
             g = d.join_chain([(ia, [cols[0].slice(b, e)]), (ib, [cols[1].slice(b, e)])], probe_base=b,
-                             shard_rows=shard_rows if shard_given else None, nchunks=nchunks, positions=positions, host=host)
+                             shard_rows=shard_rows if shard_given else None, nchunks=nchunks, positions=positions, host=host,
+                             packed=packed)
             ctx.synchronize()
+            if packed:   # ceil(log2(4000 + 1)) + ceil(log2(60)) bits; a shard's chunk travels in whole 64-row groups
+                assert g.stats["packed_bits"] == (18 if world > 1 else 0), g.stats
+                rows_sent = sum(-(-(shard_rows[r] // nchunks + (1 if c < shard_rows[r] % nchunks else 0)) // 64) * 64
+                                for c in range(nchunks)) if world > 1 else 0
+                assert g.stats["bytes_sent"] <= (rows_sent * 18 // 8 + 16 * nchunks) * (world - 1), g.stats
+            else:
+                assert g.stats["packed_bits"] == 0
             assert g.stats["chunks"] == nchunks and g.stats["pipelined"] == (1 if nchunks > 1 else 0), g.stats
             assert g.mem == (N.CPH_MEM_HOST if host else N.CPH_MEM_DEVICE)
             assert g.total == len(es) and sum(g.counts) == g.total and len(g.counts) == world

@@ -44,6 +44,10 @@ for world, factor, nchunks, unequal, positions, given, host in ((2, 1, 4, False,
     T.run_pipelined_chain(world, factor, factory(world), nchunks, host=host, positions=positions, unequal=unequal, shard_given=given,
                           expect_transport=tr % (world, os.environ["CPH_RCCL_LIBRARY"]))
     print("pipelined", world, factor, nchunks, unequal, host, "ok", flush=True)
+for world, factor, nchunks, unequal, positions in ((2, 2, 3, False, True), (3, 2, 4, True, False), (3, 1, 2, True, True)):   # CPH_DIST_PACKED
+    T.run_pipelined_chain(world, factor, factory(world), nchunks, positions=positions, unequal=unequal, packed=True,
+                          expect_transport=tr % (world, os.environ["CPH_RCCL_LIBRARY"]))
+    print("packed", world, factor, nchunks, unequal, "ok", flush=True)
 print("STANDIN_RANKS_OK", flush=True)
 """
 
