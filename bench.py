@@ -1596,14 +1596,30 @@ def main():
                         if dig is not None:
                             blk["verified"] = bool(dig == dig0 and (first, last) == (f0, l0))   # the same permutation either way
                             blk["perm_digest"] = f"{dig:016x}"
+                    elif not col.fixed_width and col.nrows >= (1 << 22):
+                        # variable-length keys the library chose to upload as strings (ctx option host_split = 1 goes by the cgroup's CPU
+                        # quota): the host twin of the split codec forced, for the record — throttled hosts lose, see DESIGN §9
+                        try:
+                            eng.ctx.set_option("host_split", 2)
+                            wall2, path2, f2, l2, dig2, _ = timed()
+                            if path2 == 2:
+                                blk["host_split_forced_ms"] = round(wall2 * 1e3, 2)
+                                if dig is not None:
+                                    blk["host_split_forced_same_perm"] = bool(dig2 == dig)
+                                try:
+                                    blk["cgroup_cpu_max"] = open("/sys/fs/cgroup/cpu.max").read().strip()
+                                except OSError:
+                                    pass
+                        finally:
+                            eng.ctx.set_option("host_split", 1)
                     pc.free()
                     return blk
 
                 out["index_on_1e8"]["e2e_pinned_host"] = {
                     "scope": "key column in pinned host memory -> host perm (cph_index_build on host columns + cph_index_perm(HOST)); "
                              "PCIe inclusive.  Round 5: ONE key column of <= 8 byte positions is coded by host threads in 2^22-row chunks, "
-                             "each uploaded (4 B/row) while the next is coded, the device only sorts (build_path); any other key uploads "
-                             "its strings, builds and downloads one after the other",
+                             "each uploaded (4 B/row) while the next is coded, the device only sorts (build_path).  Round 6: config 3's variable-length keys "
+                             "the same way through the split codec's host twin (ctx option host_split); any other key uploads its strings",
                     "unique_fixed8_ids": time_index_host(dg.column(dg.SEQ_PERM, n8, n8, encoding=dg.FIXED8, seed=7), True, 2),
                     "varlen_dup_keys_config3": time_index_host(dg.varkeys(n8), False, 2)}
 

@@ -127,6 +127,11 @@ private:
 
 }  // namespace cph
 
+namespace cph_host {
+struct HostCol;
+class BlockPool;
+}  // namespace cph_host
+
 // ---- key codec description (host + device copies) -------------------------------------
 namespace cph {
 
@@ -371,6 +376,11 @@ struct cph_ctx {
                                    // threads and only they are uploaded (host_encode.hip: build_from_host_codes); 0: always upload the strings
     int host_threads = 0;          // threads of the ctx's host worker pool (0: half the hardware threads, at most 32)
     void* host_pool = nullptr;     // cph::HostPool, created on first use (host_encode.hip)
+    int host_split = 1;            // ... and a variable-length column the delimiter split codes (config 3's keys): the split codec's host twin — 1: when the
+                                   // host's threads (within the cgroup's CPU quota) beat the upload of the strings by the estimate, 2: always, 0: never
+    int host_split_threads = 0;    // threads of that (compute-bound) loop's own pool (0: 3/8 of the hardware threads, at most 96, at most the CPU quota)
+    void* host_pool_wide = nullptr;
+    int host_numa = 0;             // 1: that pool's workers are bound to the NUMA node that holds the column (opt-in: its effect could not be measured)
     int build_side_stream = 1;     // cph_index_build_many: every second general build of a batch runs on a second stream (A/B switch)
     hipStream_t side_stream = nullptr;   // created on first use
     hipEvent_t side_fork = nullptr;      // recorded on `stream` when a two-stream batch starts; side_stream waits for it, so that the
@@ -592,6 +602,9 @@ Status codec_encode_build(cph_ctx* ctx, const CodecHost& codec, const DevBuf& co
 // table then skips the plain statistics pass); codec->has_split() tells whether the split was taken.
 Status codec_try_split(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t n, const std::vector<ColStats>* stats, CodecHost* codec,
                        bool speculate = false, bool* speculated = nullptr);
+// The same for ONE variable-length column in host memory, its sample read by the host's threads (keycodec.hip; used by
+// host_encode.hip: build_from_host_codes): always the speculative kind — the caller's encode loop checks every row.
+Status codec_split_from_host(cph_ctx* ctx, const cph_host::HostCol& hc, uint64_t n, cph_host::BlockPool& pool, CodecHost* codec);
 // Host-side encoding of literal values (cph_index_find).  Returns false when a
 // value cannot occur in the index (symbol outside the alphabet / too long).
 bool codec_encode_values_host(const CodecHost& codec, const cph_strval* values, int32_t nvalues,

@@ -187,15 +187,111 @@ namespace cph {
 
 struct HostPool {
     cph_host::BlockPool pool;
+    int bound_node = -2;   // NUMA node the workers are bound to (-2: never bound, -1: unbound again)
     explicit HostPool(int workers) : pool(workers) {}
 };
 
+// ---- NUMA placement of the wide pool ----------------------------------------------------------------------------------------
+// A two-socket host: 96 threads land on both sockets, and the ones on the far socket read the column through the inter-socket link —
+// the same build then takes 19 ms or 95 ms depending on where the scheduler put them (profiles/r06_host_split.txt).  The workers
+// are bound to the CPUs of the node that holds the column's first page (get_mempolicy; where the syscall is not permitted: the node
+// the calling thread runs on, which is where a first-touch allocation of the caller sits).
+#if defined(__linux__)
+}  // namespace cph
+#include <sys/syscall.h>
+#include <unistd.h>
+namespace cph {
+static int numa_node_of_addr(const void* addr) {
+    int node = -1;
+    const long rc = syscall(SYS_get_mempolicy, &node, nullptr, 0ul, const_cast<void*>(addr), 3ul /* MPOL_F_NODE | MPOL_F_ADDR */);
+    return rc == 0 ? node : -1;
+}
+static bool numa_node_cpus(int node, cpu_set_t* set) {   // /sys/devices/system/node/nodeN/cpulist: "0-63,128-191"
+    char path[96];
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE* f = fopen(path, "r");
+    if (!f) return false;
+    char buf[4096];
+    const size_t got = fread(buf, 1, sizeof buf - 1, f);
+    fclose(f);
+    buf[got] = 0;
+    CPU_ZERO(set);
+    int count = 0;
+    for (const char* p = buf; *p;) {
+        if (*p < '0' || *p > '9') { p++; continue; }
+        char* e;
+        long a = strtol(p, &e, 10), b = a;
+        if (*e == '-') b = strtol(e + 1, &e, 10);
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++) { CPU_SET((int)c, set); count++; }
+        p = e;
+    }
+    return count > 0;
+}
+static int numa_node_of_cpu(int cpu) {
+    for (int node = 0; node < 64; node++) {
+        cpu_set_t set;
+        if (!numa_node_cpus(node, &set)) { if (node > 8) break; else continue; }
+        if (CPU_ISSET(cpu, &set)) return node;
+    }
+    return -1;
+}
+static void bind_pool_to_data(cph_ctx* ctx, HostPool* hp, const void* data) {
+    if (!ctx->host_numa) {
+        if (hp->bound_node >= 0) {   // switched off after a bound run: every CPU again
+            cpu_set_t all;
+            CPU_ZERO(&all);
+            for (int c = 0; c < CPU_SETSIZE; c++) CPU_SET(c, &all);
+            hp->pool.set_affinity(all);
+            hp->bound_node = -1;
+        }
+        return;
+    }
+    int node = numa_node_of_addr(data);
+    if (node < 0) node = numa_node_of_cpu(sched_getcpu());
+    if (node < 0 || node == hp->bound_node) return;
+    cpu_set_t set;
+    if (!numa_node_cpus(node, &set)) return;
+    hp->pool.set_affinity(set);
+    hp->bound_node = node;
+    if (ctx->codec_debug) fprintf(stderr, "[cph] host pool of %d workers bound to NUMA node %d (%d CPUs)\n", hp->pool.workers(), node, CPU_COUNT(&set));
+}
+#else
+static void bind_pool_to_data(cph_ctx*, HostPool*, const void*) {}
+#endif
+
+// CPUs the process may use per scheduling period: the cgroup's CPU quota (cpu.max of cgroup v2, cfs_quota_us / cfs_period_us of v1),
+// 1e9 when there is none.  A container with 256 visible hardware threads and a quota of 16 runs 96 busy threads for a sixth of each
+// 100 ms period and is THROTTLED for the rest: the split loop's 2 CPU-seconds per 1e8 rows then take 95-180 ms instead of 20
+// (profiles/r06_host_split.txt) — the pool sizes and the choice below go by the quota, not by the thread count.
+static double cgroup_cpu_quota() {
+    auto read2 = [](const char* path, char* buf, size_t cap) -> bool {
+        FILE* f = fopen(path, "r");
+        if (!f) return false;
+        const size_t got = fread(buf, 1, cap - 1, f);
+        fclose(f);
+        buf[got] = 0;
+        return got > 0;
+    };
+    char a[128], b[128];
+    if (read2("/sys/fs/cgroup/cpu.max", a, sizeof a)) {
+        if (strncmp(a, "max", 3) == 0) return 1e9;
+        double quota = 0, period = 0;
+        if (sscanf(a, "%lf %lf", &quota, &period) == 2 && quota > 0 && period > 0) return quota / period;
+        return 1e9;
+    }
+    if (read2("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", a, sizeof a) && read2("/sys/fs/cgroup/cpu/cpu.cfs_period_us", b, sizeof b)) {
+        const double quota = atof(a), period = atof(b);
+        if (quota > 0 && period > 0) return quota / period;
+    }
+    return 1e9;
+}
 static cph_host::BlockPool* ctx_host_pool(cph_ctx* ctx) {
     if (!ctx->host_pool) {
         int nt = ctx->host_threads > 0 ? ctx->host_threads : (int)std::thread::hardware_concurrency() / 2;
         if (nt < 1) nt = 1;
         if (nt > 256) nt = 256;
         if (ctx->host_threads <= 0 && nt > 32) nt = 32;   // memory-bound on the NUMA node of the pinned buffers well before that (profiles/r05_host_build.txt)
+        if (ctx->host_threads <= 0 && (double)nt > cgroup_cpu_quota()) nt = (int)cgroup_cpu_quota() < 1 ? 1 : (int)cgroup_cpu_quota();   // (busy threads beyond the quota get the whole cgroup throttled)
         try {
             ctx->host_pool = new HostPool(nt - 1);
         } catch (const std::exception&) {
@@ -204,9 +300,32 @@ static cph_host::BlockPool* ctx_host_pool(cph_ctx* ctx) {
     }
     return &static_cast<HostPool*>(ctx->host_pool)->pool;
 }
+// threads a compute-bound host loop should use: 3/8 of the hardware threads, at most 96, at most the CPU quota
+static int wide_pool_threads(const cph_ctx* ctx) {
+    if (ctx->host_split_threads > 0) return ctx->host_split_threads > 256 ? 256 : ctx->host_split_threads;
+    int nt = (int)std::thread::hardware_concurrency() * 3 / 8;
+    if (nt > 96) nt = 96;
+    const double q = cgroup_cpu_quota();
+    if ((double)nt > q) nt = (int)q;
+    return nt < 1 ? 1 : nt;
+}
+// the pool of the compute-bound loops (the split codec's; ctx option host_split_threads)
+static cph_host::BlockPool* ctx_host_pool_wide(cph_ctx* ctx) {
+    if (!ctx->host_pool_wide) {
+        const int nt = wide_pool_threads(ctx);
+        try {
+            ctx->host_pool_wide = new HostPool(nt - 1);
+        } catch (const std::exception&) {
+            return nullptr;
+        }
+    }
+    return &static_cast<HostPool*>(ctx->host_pool_wide)->pool;
+}
 void host_pool_destroy(cph_ctx* ctx) {
     delete static_cast<HostPool*>(ctx->host_pool);
     ctx->host_pool = nullptr;
+    delete static_cast<HostPool*>(ctx->host_pool_wide);
+    ctx->host_pool_wide = nullptr;
 }
 
 // per-position byte presence, shortest / longest value of rows 0, step, 2 step, ...; false: a value beyond 8 bytes.  The rows are
@@ -270,38 +389,90 @@ Status build_from_host_codes(cph_ctx* ctx, const cph_strcol* keycols, int32_t nk
     const auto t_enter = clk::now();
     cph_host::BlockPool* pool = ctx_host_pool(ctx);
     if (!pool) return {};
-    std::vector<ColStats> stats(1);
-    if (!host_sample(*pool, hc, n, &stats[0]) || stats[0].maxlen == 0) return {};
-    if (!kc.fixed_width) {
-        // variable-length values: the shortest and the longest value EXACTLY (one pass over the offsets, 4-8 bytes per row) — a table
-        // of decimal ids holds ten one-digit values in a hundred million, which no sample shows, and the pad symbol of every
-        // position behind the shortest value belongs to the alphabets
-        std::atomic<uint32_t> mn{stats[0].minlen}, mx{stats[0].maxlen};
-        pool->run(n, [&](uint64_t r0, uint64_t r1) {
-            uint64_t lo = ~0ull, hi = 0, b = cph_host::col_offset(hc, r0);
-            for (uint64_t r = r0; r < r1; r++) {
-                const uint64_t e = cph_host::col_offset(hc, r + 1), l = e - b;
-                lo = l < lo ? l : lo;
-                hi = l > hi ? l : hi;
-                b = e;
-            }
-            const uint32_t lo32 = lo > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)lo, hi32 = hi > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)hi;
-            uint32_t cur = mn.load(std::memory_order_relaxed);
-            while (lo32 < cur && !mn.compare_exchange_weak(cur, lo32, std::memory_order_relaxed)) {}
-            cur = mx.load(std::memory_order_relaxed);
-            while (hi32 > cur && !mx.compare_exchange_weak(cur, hi32, std::memory_order_relaxed)) {}
-        });
-        if (mx.load() > 8 || mx.load() != stats[0].maxlen) return {};   // (a longer value than any sampled one: its bytes are unknown)
-        stats[0].minlen = mn.load();
-    }
+    // the codec: the per-position code of short keys (<= 8 bytes, one word below 2^31), else — variable-length values — the split codec
+    // of keycodec.hip from the same sample the device would take (prefix dictionary + suffix positions: config 3's 10-22 byte keys)
     CodecHost cd;
-    CPH_TRY(codec_build(stats, &cd));
-    if (cd.nwords != 1 || !cd.key32 || cd.has_groups() || cd.has_split() || cd.npos < 1 || cd.word_states[0] > (1ull << 31)) return {};
+    bool plain = false;
+    {
+        std::vector<ColStats> stats(1);
+        plain = host_sample(*pool, hc, n, &stats[0]) && stats[0].maxlen != 0;
+        if (plain && !kc.fixed_width) {
+            // variable-length values: the shortest and the longest value EXACTLY (one pass over the offsets, 4-8 bytes per row) — a table
+            // of decimal ids holds ten one-digit values in a hundred million, which no sample shows, and the pad symbol of every
+            // position behind the shortest value belongs to the alphabets
+            std::atomic<uint32_t> mn{stats[0].minlen}, mx{stats[0].maxlen};
+            pool->run(n, [&](uint64_t r0, uint64_t r1) {
+                uint64_t lo = ~0ull, hi = 0, b = cph_host::col_offset(hc, r0);
+                for (uint64_t r = r0; r < r1; r++) {
+                    const uint64_t e = cph_host::col_offset(hc, r + 1), l = e - b;
+                    lo = l < lo ? l : lo;
+                    hi = l > hi ? l : hi;
+                    b = e;
+                }
+                const uint32_t lo32 = lo > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)lo, hi32 = hi > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)hi;
+                uint32_t cur = mn.load(std::memory_order_relaxed);
+                while (lo32 < cur && !mn.compare_exchange_weak(cur, lo32, std::memory_order_relaxed)) {}
+                cur = mx.load(std::memory_order_relaxed);
+                while (hi32 > cur && !mx.compare_exchange_weak(cur, hi32, std::memory_order_relaxed)) {}
+            });
+            if (mx.load() > 8 || mx.load() != stats[0].maxlen) plain = false;   // (a longer value than any sampled one: its bytes are unknown)
+            stats[0].minlen = mn.load();
+        }
+        if (plain) {
+            CPH_TRY(codec_build(stats, &cd));
+            if (cd.nwords != 1 || !cd.key32 || cd.has_groups() || cd.has_split() || cd.npos < 1 || cd.word_states[0] > (1ull << 31)) plain = false;
+        }
+    }
+    const bool split = !plain;
+    if (split) {
+        if (kc.fixed_width || ctx->host_split == 0) return {};
+        if (ctx->host_split == 1) {
+            // worth it?  The loop costs ~12 ns per row and thread (measured: 1e8 rows in 72 ms on the 16 threads a quota of 16 CPUs
+            // allows, 19-23 ms on 96 threads in the periods the quota did not throttle); the strings cross PCIe at ~50 GB/s: 44 ms.
+            const double encode_ms = (double)n * 12e-6 / (double)wide_pool_threads(ctx);
+            const double upload_ms = ((double)hc.data_bytes + (double)n * (kc.offset_bits / 8)) / 50e6;
+            if (encode_ms >= upload_ms) return {};
+        }
+        cd = CodecHost{};
+        cph_host::BlockPool* wide = ctx_host_pool_wide(ctx);
+        if (wide) bind_pool_to_data(ctx, static_cast<HostPool*>(ctx->host_pool_wide), hc.data);
+        CPH_TRY(codec_split_from_host(ctx, hc, n, wide ? *wide : *pool, &cd));
+        if (!cd.has_split()) return {};
+    }
+    const auto t_codec = clk::now();
     cph_host_encoder enc;
+    cph_host::SplitEnc<WideKey> se{};
+    std::vector<uint32_t> split_lutw;
     try {
-        encoder_tables(cd, &enc);
+        if (!split) {
+            encoder_tables(cd, &enc);
+        } else {
+            const int p0 = cd.col_start[0], ps = cd.col_start[1];
+            se.delim = cd.split_byte;
+            se.vmax = (uint32_t)cd.split_maxlen;
+            se.smaxlen = (uint32_t)cd.col_maxlen[1];
+            se.pmult = (uint32_t)cd.mult[(size_t)p0];
+            se.hmask = (uint32_t)cd.wide_slots.size() - 1u;
+            se.dmask = (uint32_t)cd.wide_disp.size() - 1u;
+            se.disp = cd.wide_disp.data();
+            se.slots = cd.wide_slots.data();
+            se.dict = cd.wdict.data();
+            split_lutw.resize((size_t)se.smaxlen * kLutStride);
+            for (size_t i = 0; i < split_lutw.size(); i++) {
+                const uint16_t r = cd.lut[(size_t)ps * kLutStride + i];
+                split_lutw[i] = r == kLutInvalid ? 0x80000000u : (uint32_t)((uint64_t)r * cd.mult[(size_t)ps + i / kLutStride]);
+            }
+            se.lutw = split_lutw.data();
+        }
     } catch (const std::exception&) {
         return {};
+    }
+    // the split loop computes (a hash, a dictionary entry, 5-16 table loads per row): it scales with the threads where the 8-byte loops
+    // wait for DRAM — its own, wider pool
+    cph_host::BlockPool* epool = pool;
+    if (split) {
+        epool = ctx_host_pool_wide(ctx);
+        if (!epool) epool = pool;
     }
 
     // ---- code + upload, chunk by chunk ----
@@ -358,7 +529,16 @@ Status build_from_host_codes(cph_ctx* ctx, const cph_strcol* keycols, int32_t nk
         const auto t0 = clk::now();
         if (nchunks >= 2 && hipEventSynchronize(ev[slot]) != hipSuccess) { st = {CPH_ERR_HIP, "hipEventSynchronize failed"}; break; }
         const auto t1 = clk::now();
-        encode_rows_on(*pool, enc, &hc, 1, r0, m, static_cast<uint32_t*>(stage[slot]), &absent, /*nt=*/true);
+        if (!split) {
+            encode_rows_on(*pool, enc, &hc, 1, r0, m, static_cast<uint32_t*>(stage[slot]), &absent, /*nt=*/true);
+        } else {
+            uint32_t* base = static_cast<uint32_t*>(stage[slot]) - r0;   // the loop indexes its output by row number
+            epool->run(m, [&](uint64_t a, uint64_t b) {
+                if (cph_host::encode_split(se, hc, r0 + a, r0 + b, base, /*nt=*/true,
+                                           [](uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3, uint32_t len) { return wide_hash_lo(w0, w1, w2, w3, len); }))
+                    absent.store(1u, std::memory_order_relaxed);
+            }, 8192);
+        }
         t_wait += std::chrono::duration<double>(t1 - t0).count();
         t_enc += std::chrono::duration<double>(clk::now() - t1).count();
         if (absent.load(std::memory_order_relaxed)) break;   // a row the sampled alphabets cannot code: the exact path
@@ -406,6 +586,24 @@ Status build_from_host_codes(cph_ctx* ctx, const cph_strcol* keycols, int32_t nk
         } else {
             DevBuf kb, vb;
             CPH_TRY(kb.alloc(&ctx->pool, n * sizeof(uint32_t)));
+            // duplicates allowed, a window of the code space holds a few thousand rows: the counted LDS windows (counted_sort.hip)
+            CountedSortPlan csp;
+            if (ctx->counted_sort && counted_sort_plan(ctx, n, states, &csp)) {
+                uint32_t* over = host_word(ctx);
+                if (!over) return {CPH_ERR_HIP, "no pinned host memory for the report words of a build"};
+                CPH_TRY(ix->first_dup_dev.alloc(&ctx->pool, sizeof(uint32_t)));
+                CPH_TRY(counted_sort(ctx, csp, ka.as<uint32_t>(), n, states, va.as<uint32_t>(), kb.as<uint32_t>(), ix->first_dup_dev.as<uint32_t>(), over));
+                CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+                if (*(volatile uint32_t*)over == 0) {
+                    ix->sorted_codes = std::move(kb);
+                    ix->perm = std::move(va);
+                    ix->sort_passes = 0;
+                    CPH_TRY(index_first_dup_read(ctx, ix));
+                    index_plan_table(ix);
+                    return {};
+                }
+                ix->first_dup_dev.reset();   // a window beyond its capacity: the classic passes over the same codes
+            }
             CPH_TRY(vb.alloc(&ctx->pool, n * sizeof(uint32_t)));
             uint32_t *kout, *vout;
             int passes = 0;
@@ -423,9 +621,9 @@ Status build_from_host_codes(cph_ctx* ctx, const cph_strcol* keycols, int32_t nk
     const auto t_loop = clk::now();
     st = run();
     if (ctx->codec_debug)
-        fprintf(stderr, "[cph] host-coded build: %llu rows, %llu chunks, %d threads, arith=%d vector=%d: sample + codec + tables + buffers %.2f ms, encode %.2f ms, waits for staging slots %.2f ms, loop %.2f ms, "
-                        "upload tail + sort + wait %.2f ms\n", (unsigned long long)n, (unsigned long long)nchunks, pool->workers() + 1, (int)enc.arith, (int)enc.arith_vector,
-                std::chrono::duration<double>(t_begin - t_enter).count() * 1e3, t_enc * 1e3, t_wait * 1e3, std::chrono::duration<double>(t_loop - t_begin).count() * 1e3,
+        fprintf(stderr, "[cph] host-coded build: %llu rows, %llu chunks, %d threads, split=%d arith=%d vector=%d: sample + codec %.2f ms, tables + buffers %.2f ms, encode %.2f ms, waits for staging slots %.2f ms, loop %.2f ms, "
+                        "upload tail + sort + wait %.2f ms\n", (unsigned long long)n, (unsigned long long)nchunks, epool->workers() + 1, (int)split, (int)enc.arith, (int)enc.arith_vector,
+                std::chrono::duration<double>(t_codec - t_enter).count() * 1e3, std::chrono::duration<double>(t_begin - t_codec).count() * 1e3, t_enc * 1e3, t_wait * 1e3, std::chrono::duration<double>(t_loop - t_begin).count() * 1e3,
                 std::chrono::duration<double>(clk::now() - t_loop).count() * 1e3);
     cleanup();
     if (!st.ok()) {

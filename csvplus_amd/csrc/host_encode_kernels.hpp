@@ -23,6 +23,10 @@
 #if defined(__x86_64__)
 #include <immintrin.h>
 #endif
+#if defined(__linux__)
+#include <pthread.h>
+#include <sched.h>
+#endif
 
 namespace cph_host {
 
@@ -229,6 +233,94 @@ inline bool encode_lut(const uint32_t* lut, int ncols, const int32_t* col_start,
     return (any >> 31) != 0;
 }
 
+// ---- split codec (keycodec.hip "split codec": prefix dictionary + per-position suffix) ---------------------------------------
+// code = rank(prefix) * pmult + sum over suffix positions q of lutw[q][symbol_q]; the prefix is the value through its first `delim`
+// byte (the whole value when it holds none), looked up in the codec's perfect hash and verified word for word.  A row the codec
+// cannot code (prefix not in the dictionary, a suffix byte or END outside its position's alphabet, lengths beyond the codec's)
+// makes the loop return true: the caller then uploads the strings instead (k_encode_split's `miss`).
+template <class Key>
+struct SplitEnc {
+    uint8_t delim;
+    uint32_t vmax, smaxlen, pmult, hmask, dmask;
+    const uint16_t *disp, *slots;    // perfect hash: slot = ((h >> 16) + disp[h & dmask]) & hmask, slots[slot] = rank + 1 (0: none)
+    const Key* dict;                 // .w[4] (bytes little-endian, zero padded), .len
+    const uint32_t* lutw;            // [smaxlen][kLutRow]: rank * weight, top bit = not in the alphabet
+};
+
+// OFF: the offsets' type; SM: suffix positions as a compile-time bound (0: e.smaxlen at run time) — the position loop unrolls.
+template <class Key, class Hash, class OFF, int SM>
+inline bool encode_split_t(const SplitEnc<Key>& e, const HostCol& c, uint64_t r0, uint64_t r1, uint32_t* out, bool nt, Hash hash) {
+    const uint64_t dv = 0x0101010101010101ull * (uint64_t)e.delim;
+    const OFF* off = static_cast<const OFF*>(c.offsets);
+    const uint32_t smaxlen = SM ? (uint32_t)SM : e.smaxlen;
+    uint32_t any = 0;
+    uint64_t end = (uint64_t)off[r0];
+    for (uint64_t r = r0; r < r1; r++) {
+        const uint64_t b = end;
+        end = (uint64_t)off[r + 1];
+        const uint64_t l = end - b;
+        const uint8_t* p = c.data + b;
+        uint64_t w[4], s0, s1;
+        uint8_t tmp[48];
+        if (l > (uint64_t)e.vmax) { any = 1; store_code(out + r, 0u, nt); continue; }
+        if (c.data_bytes == 0 || b + 48 > c.data_bytes) {   // the buffer's last values: through a padded copy
+            memset(tmp, 0, sizeof tmp);
+            memcpy(tmp, p, (size_t)l);   // (vmax <= 40)
+            p = tmp;
+        }
+        memcpy(w, p, 32);
+        // the first delimiter within the first min(l, 32) bytes
+        uint32_t at = 64;
+        for (int j = 3; j >= 0; j--) {
+            const uint64_t x = w[j] ^ dv;
+            const uint64_t t = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
+            at = t ? 8u * (uint32_t)j + ((uint32_t)__builtin_ctzll(t) >> 3) : at;
+        }
+        const uint32_t l32 = (uint32_t)l;
+        const uint32_t plen = at < l32 ? at + 1u : l32;       // (at >= 32 and l > 32: plen = l > 32 -> a miss below)
+        const uint32_t slen = l32 - plen;
+        if (plen > 32u || slen > smaxlen) { any = 1; store_code(out + r, 0u, nt); continue; }
+        memcpy(&s0, p + plen, 8);                            // (plen + 16 <= 48 readable bytes)
+        memcpy(&s1, p + plen + 8, 8);
+        for (int j = 0; j < 4; j++) {
+            const uint32_t have = plen > 8u * (uint32_t)j ? plen - 8u * (uint32_t)j : 0u;
+            w[j] &= have >= 8u ? ~0ull : ((1ull << (8u * have)) - 1ull);
+        }
+        const uint32_t h = hash(w[0], w[1], w[2], w[3], plen);
+        const uint32_t en = e.slots[((h >> 16) + e.disp[h & e.dmask]) & e.hmask];
+        const Key& k = e.dict[en ? en - 1 : 0];
+        const bool hit = en != 0 && k.len == plen && ((k.w[0] ^ w[0]) | (k.w[1] ^ w[1]) | (k.w[2] ^ w[2]) | (k.w[3] ^ w[3])) == 0;
+        uint32_t acc = (hit ? en - 1 : 0u) * e.pmult, bad = hit ? 0u : 0x80000000u;
+        const uint32_t* lp = e.lutw;
+        for (uint32_t q = 0; q < smaxlen; q++, lp += kLutRow) {
+            const uint64_t src = q < 8u ? s0 : s1;
+            const uint32_t byte = (uint32_t)(src >> (8u * (q & 7u))) & 0xFFu;
+            const uint32_t v = lp[q < slen ? byte + 1u : 0u];
+            acc += v & 0x7FFFFFFFu;
+            bad |= v;
+        }
+        any |= bad >> 31;
+        store_code(out + r, acc, nt);
+    }
+    store_fence(nt);
+    return any != 0;
+}
+
+template <class Key, class Hash>
+inline bool encode_split(const SplitEnc<Key>& e, const HostCol& c, uint64_t r0, uint64_t r1, uint32_t* out, bool nt, Hash hash) {
+#define CPH_SPLIT_CASE(SM)                                                                                             \
+    case SM:                                                                                                           \
+        return c.offset_bits == 32 ? encode_split_t<Key, Hash, uint32_t, SM>(e, c, r0, r1, out, nt, hash)              \
+                                   : encode_split_t<Key, Hash, uint64_t, SM>(e, c, r0, r1, out, nt, hash);
+    switch (e.smaxlen <= 8u ? e.smaxlen : 0u) {
+        CPH_SPLIT_CASE(1) CPH_SPLIT_CASE(2) CPH_SPLIT_CASE(3) CPH_SPLIT_CASE(4) CPH_SPLIT_CASE(5) CPH_SPLIT_CASE(6) CPH_SPLIT_CASE(7) CPH_SPLIT_CASE(8)
+        default: break;
+    }
+#undef CPH_SPLIT_CASE
+    return c.offset_bits == 32 ? encode_split_t<Key, Hash, uint32_t, 0>(e, c, r0, r1, out, nt, hash)
+                               : encode_split_t<Key, Hash, uint64_t, 0>(e, c, r0, r1, out, nt, hash);
+}
+
 // ---- worker pool ----------------------------------------------------------------------------------------------------------
 // run(nrows, fn): fn(r0, r1) is called for disjoint row blocks that cover [0, nrows), on the workers and on the calling thread;
 // returns when every block is done.  One job at a time (the caller serialises).
@@ -250,6 +342,12 @@ public:
     BlockPool(const BlockPool&) = delete;
     BlockPool& operator=(const BlockPool&) = delete;
     int workers() const { return (int)workers_.size(); }
+#if defined(__linux__)
+    // the workers may only run on these CPUs from now on (the caller's thread is not touched)
+    void set_affinity(const cpu_set_t& set) {
+        for (auto& t : workers_) (void)pthread_setaffinity_np(t.native_handle(), sizeof set, &set);
+    }
+#endif
 
     template <class F>
     void run(uint64_t nrows, F&& fn, uint64_t block_rows = kBlockRows) {

@@ -22,8 +22,10 @@
 // value) cannot equal any index key: it is "invalid" and matches nothing.
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 
 #include "codec_device.hpp"
+#include "host_encode_kernels.hpp"
 
 namespace cph {
 
@@ -1329,6 +1331,98 @@ static double bits_sort_cost(double bits) {
     return std::ceil(bits / 8.0) * 12.0 + 16.0 * words;
 }
 
+// Which delimiter candidate codes the column in the fewest bits (-1: none is worth it).  hs[k] = the statistics of cand[k] over the
+// rows looked at (every step-th); most = bits of the column's plain per-position code, plain_bits = those of the whole key.
+static int split_pick(const cph_ctx* ctx, int c, const std::vector<int>& cand, const std::vector<SplitStats>& hs, uint64_t step, double most,
+                      double plain_bits) {
+    auto split_bits = [&](const SplitStats& st) {
+        double bits = std::log2((double)(st.count > 1 ? st.count : 1));
+        ColStats tmp{};
+        tmp.minlen = ~st.smin_inv;
+        memcpy(tmp.mask, st.mask, sizeof st.mask);
+        for (uint32_t q = 0; q < st.smax && q < (uint32_t)kSplitMaxSuffix; q++) bits += radix_bits(tmp, q);
+        return bits;
+    };
+    int best = -1;
+    double best_bits = 1e30;
+    for (size_t k = 0; k < cand.size(); k++) {
+        const SplitStats& st = hs[k];
+        if (st.flags || st.count == 0 || st.count > (uint32_t)kWideDictMax / (step > 1 ? 2 : 1) || st.smax > (uint32_t)kSplitMaxSuffix) continue;
+        const double bits = split_bits(st);
+        if (ctx->codec_debug) fprintf(stderr, "codec_try_split: column %d, byte 0x%02x: %u prefixes, suffix %u..%u bytes, %.1f bits (plain %.1f)\n", c, cand[k], st.count, ~st.smin_inv, st.smax, bits, most);
+        if (bits < best_bits) { best_bits = bits; best = (int)k; }
+    }
+    // worth it when the sort gets cheaper by the estimate (the exact codec is compared again by the caller)
+    if (best < 0 || bits_sort_cost(plain_bits - most + best_bits) >= bits_sort_cost(plain_bits)) return -1;
+    return best;
+}
+
+// The delimiter candidates a sample of nsel rows suggests: bytes (nearly) every value holds, punctuation first.
+static std::vector<int> split_candidates(const SplitSample& hsm, uint64_t nsel) {
+    std::vector<int> cand;
+    for (int b = 0; b < 256; b++)
+        if ((double)hsm.cnt[b] >= 0.99 * (double)nsel) cand.push_back(b);
+    // a delimiter is punctuation more often than a letter or a digit: those first, then by how many values hold the byte
+    auto alnum = [](int b) { return (b >= '0' && b <= '9') || (b >= 'a' && b <= 'z') || (b >= 'A' && b <= 'Z'); };
+    std::sort(cand.begin(), cand.end(), [&](int a, int b) { return alnum(a) != alnum(b) ? !alnum(a) : hsm.cnt[a] > hsm.cnt[b]; });
+    if (cand.size() > 8) cand.resize(8);
+    return cand;
+}
+
+// The codec over the virtual columns (prefix dictionary | suffix positions) of column c cut at byte d.  st / dict: the statistics and
+// the distinct prefixes (any order; sorted here).  *usable false: the split cannot be taken (too many positions, no perfect hash).
+static Status split_assemble(const cph_ctx* ctx, int c, int ncols, const std::vector<ColStats>* stats, uint32_t d, const SplitStats& st,
+                             std::vector<WideKey>* dict_io, double plain_bits, CodecHost* out, bool* usable) {
+    *usable = false;
+    std::vector<WideKey>& dict = *dict_io;
+    const uint32_t pmin = ~st.pmin_inv, smin = ~st.smin_inv;
+    std::sort(dict.begin(), dict.end(), wide_less);
+
+    std::vector<ColStats> vstats;
+    for (int k = 0; k < ncols; k++) {
+        if (k != c) { vstats.push_back((*stats)[(size_t)k]); continue; }   // (ncols > 1 only comes with statistics)
+        ColStats pre{}, suf{};
+        pre.minlen = pmin;
+        pre.maxlen = st.pmax;
+        for (uint32_t q = 0; q < st.pmax; q++) pre.mask[q][0] = 1u;   // placeholders: the positions are absorbed below
+        suf.minlen = smin;
+        suf.maxlen = st.smax;
+        memcpy(suf.mask, st.mask, sizeof st.mask);
+        vstats.push_back(pre);
+        vstats.push_back(suf);
+    }
+    uint64_t positions = 0;
+    for (const auto& v : vstats) positions += v.maxlen;
+    if (positions > (uint64_t)kMaxKeyBytes || st.pmax == 0) return {};
+    CodecHost trial;
+    CPH_TRY(codec_build(vstats, &trial));
+    const int p0 = trial.col_start[c];
+    trial.unit.assign((size_t)trial.npos, kUnitPos);
+    trial.dict_off.assign((size_t)trial.npos, 0);
+    trial.dict_len.assign((size_t)trial.npos, 0);
+    trial.unit[(size_t)p0] = kUnitWide;
+    trial.radix[(size_t)p0] = (uint16_t)dict.size();
+    for (int sym = 0; sym < kLutStride; sym++) trial.lut[(size_t)p0 * kLutStride + (size_t)sym] = kLutInvalid;   // never consulted
+    for (uint32_t i = 1; i < st.pmax; i++) {
+        trial.unit[(size_t)p0 + i] = kUnitAbsorbed;
+        trial.radix[(size_t)p0 + i] = 1;
+        for (int sym = 0; sym < kLutStride; sym++) trial.lut[((size_t)p0 + i) * kLutStride + (size_t)sym] = 0;
+    }
+    trial.split_col = c;
+    trial.split_byte = (uint8_t)d;
+    trial.split_maxlen = (int32_t)st.vmax;
+    trial.wdict = std::move(dict);
+    if (!codec_wide_perfect_hash(&trial)) return {};
+    CPH_TRY(codec_split_words(&trial));
+    if (ctx->codec_debug)
+        fprintf(stderr, "codec_try_split: column %d cut at 0x%02x: %zu prefixes (<= %u bytes), suffix %u..%u bytes: %d word(s), %d bits, sort cost %.0f (plain: %.1f bits%s)\n",
+                c, d, trial.wdict.size(), st.pmax, smin, st.smax, trial.nwords, trial.word_bits[0], codec_sort_cost(trial), plain_bits,
+                stats ? "" : " by the sample");
+    *out = std::move(trial);
+    *usable = true;
+    return {};
+}
+
 // Tries the delimiter split on the key column that costs the most code bits.
 //   stats != nullptr: the plain statistics *codec was built from (any number of key columns); on success *codec becomes the
 //                     split codec, otherwise it is left alone.
@@ -1433,13 +1527,7 @@ Status codec_try_split(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t
         if (most <= 32.0) return {};   // the plain code fits 32 bits: nothing to gain (and the tuned single-column paths to lose)
     }
     const bool small_values = (stats ? (*stats)[(size_t)c].maxlen : hsm.maxlen) <= 24;   // (a longer value in an unsampled row raises flag bit 0)
-    std::vector<int> cand;
-    for (int b = 0; b < 256; b++)
-        if ((double)hsm.cnt[b] >= 0.99 * (double)nsel) cand.push_back(b);
-    // a delimiter is punctuation more often than a letter or a digit: those first, then by how many values hold the byte
-    auto alnum = [](int b) { return (b >= '0' && b <= '9') || (b >= 'a' && b <= 'z') || (b >= 'A' && b <= 'Z'); };
-    std::sort(cand.begin(), cand.end(), [&](int a, int b) { return alnum(a) != alnum(b) ? !alnum(a) : hsm.cnt[a] > hsm.cnt[b]; });
-    if (cand.size() > 8) cand.resize(8);
+    const std::vector<int> cand = split_candidates(hsm, nsel);
     if (cand.empty()) return {};
 
     // ---- 2. the candidates on the sample: distinct prefixes, suffix alphabets ----
@@ -1463,25 +1551,8 @@ Status codec_try_split(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t
     CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, sstats.get(), cand.size() * sizeof(SplitStats), hipMemcpyDeviceToHost, ctx->stream));
     CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
     memcpy(hs.data(), ctx->pinned_scratch, cand.size() * sizeof(SplitStats));
-    auto split_bits = [&](const SplitStats& st) {
-        double bits = std::log2((double)(st.count > 1 ? st.count : 1));
-        ColStats tmp{};
-        tmp.minlen = ~st.smin_inv;
-        memcpy(tmp.mask, st.mask, sizeof st.mask);
-        for (uint32_t q = 0; q < st.smax && q < (uint32_t)kSplitMaxSuffix; q++) bits += radix_bits(tmp, q);
-        return bits;
-    };
-    int best = -1;
-    double best_bits = 1e30;
-    for (size_t k = 0; k < cand.size(); k++) {
-        const SplitStats& st = hs[k];
-        if (st.flags || st.count == 0 || st.count > (uint32_t)kWideDictMax / (step > 1 ? 2 : 1) || st.smax > (uint32_t)kSplitMaxSuffix) continue;
-        const double bits = split_bits(st);
-        if (ctx->codec_debug) fprintf(stderr, "codec_try_split: column %d, byte 0x%02x: %u prefixes, suffix %u..%u bytes, %.1f bits (plain %.1f)\n", c, cand[k], st.count, ~st.smin_inv, st.smax, bits, most);
-        if (bits < best_bits) { best_bits = bits; best = (int)k; }
-    }
-    // worth it when the sort gets cheaper by the estimate (the exact codec is compared again below)
-    if (best < 0 || bits_sort_cost(plain_bits - most + best_bits) >= bits_sort_cost(plain_bits)) return {};
+    const int best = split_pick(ctx, c, cand, hs, step, most, plain_bits);
+    if (best < 0) return {};
 
     // ---- 3. the exact statistics of the chosen byte, over all rows (the sample's set stays: it is a subset) ----
     SplitSlot* slots = sets.as<SplitSlot>() + (size_t)best * kSplitSetSlots;
@@ -1507,7 +1578,6 @@ Status codec_try_split(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t
     CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
     SplitStats st;
     memcpy(&st, hp, sizeof st);
-    const uint32_t pmin = ~st.pmin_inv, smin = ~st.smin_inv;
     if (st.flags || st.count == 0 || st.count > (uint32_t)kWideDictMax || st.pmax > (uint32_t)kWideBytes || st.smax > (uint32_t)kSplitMaxSuffix ||
         st.vmax > (uint32_t)kSplitMaxValue)
         return {};
@@ -1521,50 +1591,10 @@ Status codec_try_split(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t
             dict.push_back(k);
         }
     if (dict.size() != st.count) return {};
-    std::sort(dict.begin(), dict.end(), wide_less);
-
-    // ---- 4. the codec over the virtual columns ----
-    std::vector<ColStats> vstats;
-    for (int k = 0; k < ncols; k++) {
-        if (k != c) { vstats.push_back((*stats)[(size_t)k]); continue; }   // (ncols > 1 only comes with statistics)
-        ColStats pre{}, suf{};
-        pre.minlen = pmin;
-        pre.maxlen = st.pmax;
-        for (uint32_t q = 0; q < st.pmax; q++) pre.mask[q][0] = 1u;   // placeholders: the positions are absorbed below
-        suf.minlen = smin;
-        suf.maxlen = st.smax;
-        memcpy(suf.mask, st.mask, sizeof st.mask);
-        vstats.push_back(pre);
-        vstats.push_back(suf);
-    }
-    uint64_t positions = 0;
-    for (const auto& v : vstats) positions += v.maxlen;
-    if (positions > (uint64_t)kMaxKeyBytes || st.pmax == 0) return {};
     CodecHost trial;
-    CPH_TRY(codec_build(vstats, &trial));
-    const int p0 = trial.col_start[c];
-    trial.unit.assign((size_t)trial.npos, kUnitPos);
-    trial.dict_off.assign((size_t)trial.npos, 0);
-    trial.dict_len.assign((size_t)trial.npos, 0);
-    trial.unit[(size_t)p0] = kUnitWide;
-    trial.radix[(size_t)p0] = (uint16_t)dict.size();
-    for (int sym = 0; sym < kLutStride; sym++) trial.lut[(size_t)p0 * kLutStride + (size_t)sym] = kLutInvalid;   // never consulted
-    for (uint32_t i = 1; i < st.pmax; i++) {
-        trial.unit[(size_t)p0 + i] = kUnitAbsorbed;
-        trial.radix[(size_t)p0 + i] = 1;
-        for (int sym = 0; sym < kLutStride; sym++) trial.lut[((size_t)p0 + i) * kLutStride + (size_t)sym] = 0;
-    }
-    trial.split_col = c;
-    trial.split_byte = (uint8_t)d;
-    trial.split_maxlen = (int32_t)st.vmax;
-    trial.wdict = std::move(dict);
-    if (!codec_wide_perfect_hash(&trial)) return {};
-    CPH_TRY(codec_split_words(&trial));
-    const double plain_cost = stats ? codec_sort_cost(*codec) : bits_sort_cost(plain_bits);
-    if (ctx->codec_debug)
-        fprintf(stderr, "codec_try_split: column %d cut at 0x%02x: %zu prefixes (<= %u bytes), suffix %u..%u bytes: %d word(s), %d bits, sort cost %.0f (plain: %.1f bits%s, cost %.0f)\n",
-                c, d, trial.wdict.size(), st.pmax, smin, st.smax, trial.nwords, trial.word_bits[0], codec_sort_cost(trial), plain_bits,
-                stats ? "" : " by the sample", plain_cost);
+    bool usable = false;
+    CPH_TRY(split_assemble(ctx, c, ncols, stats, d, st, &dict, plain_bits, &trial, &usable));
+    if (!usable) return {};
     if (spec) {
         // the encode kernel marks a suffix byte outside its alphabet by adding 2^27 (2^58) to the code: 16 positions of it cannot wrap,
         // a valid code stays below it — larger code spaces take the exact pass (from here, once)
@@ -1572,10 +1602,190 @@ Status codec_try_split(cph_ctx* ctx, const DevCol* cols, int32_t ncols, uint64_t
         if (trial.nwords != 1 || trial.word_states[0] > (trial.key32 ? (1ull << 27) : (1ull << 58)))
             return codec_try_split(ctx, cols, ncols, n, stats, codec, false, nullptr);
     }
+    const double plain_cost = stats ? codec_sort_cost(*codec) : bits_sort_cost(plain_bits);
     if (codec_sort_cost(trial) < plain_cost) {
         *codec = std::move(trial);
         if (speculated) *speculated = spec;
     }
+    return {};
+}
+
+// ---- the split codec of a column in HOST memory (host_encode.hip: build_from_host_codes) --------------------------------------
+// codec_try_split's speculative branch with the statistics taken by the host's threads: the same rows (0, step, 2 step, ...), the same
+// candidates, the same choice, the same assembly — so a table gets the codec its device-resident copy would get.  The caller's encode
+// loop (host_encode_kernels.hpp: encode_split) checks every row against it like k_encode_split does.  codec->has_split() says whether
+// a split codec was found; anything else leaves *codec alone (the caller uploads the strings).
+Status codec_split_from_host(cph_ctx* ctx, const cph_host::HostCol& hc, uint64_t n, cph_host::BlockPool& pool, CodecHost* codec) {
+    if (!ctx->codec_split || !ctx->split_speculative || hc.fixed_width || !hc.offsets || n < (1ull << 22)) return {};
+    const uint64_t step = n >> 18;
+    const uint64_t nsel = (n + step - 1) / step;
+    auto span = [&](uint64_t r, uint64_t* b, uint64_t* l) {
+        *b = cph_host::col_offset(hc, r);
+        *l = cph_host::col_offset(hc, r + 1) - *b;
+    };
+    std::mutex mu;
+    // ---- 1. bytes (nearly) every value holds; the plain per-position code's alphabets (k_split_count) ----
+    SplitSample hsm{};
+    pool.run(nsel, [&](uint64_t i0, uint64_t i1) {
+        std::vector<SplitSample> lv(1);
+        SplitSample& loc = lv[0];
+        memset(&loc, 0, sizeof loc);
+        // every sampled row is a cache miss or two (its offsets, its bytes): spans of a batch first — independent loads —, the
+        // values' lines prefetched, then the work
+        constexpr uint64_t kBatch = 32;
+        uint64_t bb[kBatch], ll[kBatch];
+        for (uint64_t i = i0; i < i1; i++) {
+            if ((i - i0) % kBatch == 0) {
+                const uint64_t m2 = i1 - i < kBatch ? i1 - i : kBatch;
+                for (uint64_t k = 0; k < m2; k++) __builtin_prefetch(static_cast<const uint8_t*>(hc.offsets) + (i + k) * step * (uint64_t)(hc.offset_bits / 8));
+                for (uint64_t k = 0; k < m2; k++) {
+                    span((i + k) * step, &bb[k], &ll[k]);
+                    __builtin_prefetch(hc.data + bb[k]);
+                }
+            }
+            const uint64_t b = bb[(i - i0) % kBatch], l = ll[(i - i0) % kBatch];
+            const uint32_t l32 = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;
+            loc.maxlen = l32 > loc.maxlen ? l32 : loc.maxlen;
+            loc.minlen_inv = ~l32 > loc.minlen_inv ? ~l32 : loc.minlen_inv;
+            uint32_t seen[8] = {0};
+            const uint64_t m = l < (uint64_t)kSplitMaxValue ? l : (uint64_t)kSplitMaxValue;
+            for (uint64_t q = 0; q < m; q++) {
+                const uint8_t v = hc.data[b + q];
+                if (!((seen[v >> 5] >> (v & 31)) & 1u)) {
+                    seen[v >> 5] |= 1u << (v & 31);
+                    loc.cnt[v]++;
+                }
+                loc.mask[q][v >> 5] |= 1u << (v & 31);
+            }
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        for (int b = 0; b < 256; b++) hsm.cnt[b] += loc.cnt[b];
+        hsm.maxlen = loc.maxlen > hsm.maxlen ? loc.maxlen : hsm.maxlen;
+        hsm.minlen_inv = loc.minlen_inv > hsm.minlen_inv ? loc.minlen_inv : hsm.minlen_inv;
+        for (int q = 0; q < kSplitMaxValue; q++)
+            for (int w = 0; w < 8; w++) hsm.mask[q][w] |= loc.mask[q][w];
+    }, 2048);
+    if (hsm.maxlen > (uint32_t)kSplitMaxValue || hsm.maxlen < 4) return {};
+    double most = 0;
+    {
+        ColStats tmp{};
+        tmp.minlen = ~hsm.minlen_inv;
+        memcpy(tmp.mask, hsm.mask, sizeof hsm.mask);
+        for (uint32_t q = 0; q < hsm.maxlen; q++) most += radix_bits(tmp, q);
+    }
+    const double plain_bits = most;
+    if (most <= 32.0) return {};
+    const std::vector<int> cand = split_candidates(hsm, nsel);
+    if (cand.empty()) return {};
+
+    // ---- 2. the candidates on the sample: distinct prefixes, lengths, suffix alphabets (k_split_stats) ----
+    std::vector<SplitStats> hs(cand.size());
+    std::vector<std::vector<WideKey>> dicts(cand.size());
+    std::vector<std::vector<uint64_t>> dtags(cand.size());
+    for (auto& x : hs) memset(&x, 0, sizeof x);
+    pool.run(nsel, [&](uint64_t i0, uint64_t i1) {
+        const size_t nc = cand.size();
+        std::vector<SplitStats> loc(nc);
+        for (auto& x : loc) memset(&x, 0, sizeof x);
+        // per candidate: a small open-addressing set (tag -> key); a candidate whose set passes kWideDictMax entries is flagged (bit 2) and dropped
+        constexpr size_t kSlots = 4096;
+        std::vector<uint64_t> tags(nc * kSlots, 0ull);
+        std::vector<WideKey> keys(nc * kSlots);
+        std::vector<uint32_t> nkeys(nc, 0);
+        constexpr uint64_t kBatch = 32;
+        uint64_t bb[kBatch], ll[kBatch];
+        for (uint64_t i = i0; i < i1; i++) {
+            if ((i - i0) % kBatch == 0) {
+                const uint64_t m2 = i1 - i < kBatch ? i1 - i : kBatch;
+                for (uint64_t k = 0; k < m2; k++) __builtin_prefetch(static_cast<const uint8_t*>(hc.offsets) + (i + k) * step * (uint64_t)(hc.offset_bits / 8));
+                for (uint64_t k = 0; k < m2; k++) {
+                    span((i + k) * step, &bb[k], &ll[k]);
+                    __builtin_prefetch(hc.data + bb[k]);
+                }
+            }
+            const uint64_t b = bb[(i - i0) % kBatch], l = ll[(i - i0) % kBatch];
+            const uint8_t* p = hc.data + b;
+            for (size_t k = 0; k < nc; k++) {
+                SplitStats& st = loc[k];
+                const void* f = l ? memchr(p, cand[k], (size_t)l) : nullptr;
+                const uint64_t plen = f ? (uint64_t)((const uint8_t*)f - p) + 1 : l, slen = l - plen;
+                const bool usable = l <= (uint64_t)kSplitMaxValue && plen <= (uint64_t)kWideBytes;
+                if (!usable) st.flags |= 1u;
+                if (slen > (uint64_t)kSplitMaxSuffix) st.flags |= 2u;
+                st.rows_with += f ? 1u : 0u;
+                const uint32_t pl = plen > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)plen, sl = slen > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)slen;
+                const uint32_t vl = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;
+                st.pmin_inv = ~pl > st.pmin_inv ? ~pl : st.pmin_inv;
+                st.pmax = pl > st.pmax ? pl : st.pmax;
+                st.smin_inv = ~sl > st.smin_inv ? ~sl : st.smin_inv;
+                st.smax = sl > st.smax ? sl : st.smax;
+                st.vmax = vl > st.vmax ? vl : st.vmax;
+                if (usable && !(st.flags & 4u)) {
+                    WideKey key{};
+                    memcpy(key.w, p, (size_t)plen);
+                    key.len = pl;
+                    const uint64_t tag = wide_hash(key.w[0], key.w[1], key.w[2], key.w[3], pl);
+                    uint64_t* tg = &tags[k * kSlots];
+                    WideKey* ky = &keys[k * kSlots];
+                    size_t h = (size_t)(tag >> 32) & (kSlots - 1);
+                    while (tg[h] != 0ull && !(tg[h] == tag && ky[h].len == pl && memcmp(ky[h].w, key.w, sizeof key.w) == 0)) h = (h + 1) & (kSlots - 1);
+                    if (tg[h] == 0ull) {
+                        if (nkeys[k] >= (uint32_t)kWideDictMax) st.flags |= 4u;
+                        else { tg[h] = tag; ky[h] = key; nkeys[k]++; }
+                    }
+                }
+                const uint64_t lim = slen < (uint64_t)kSplitMaxSuffix ? slen : (uint64_t)kSplitMaxSuffix;
+                for (uint64_t q = 0; q < lim; q++) {
+                    const uint8_t v = p[plen + q];
+                    st.mask[q][v >> 5] |= 1u << (v & 31);
+                }
+            }
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        for (size_t k = 0; k < nc; k++) {
+            SplitStats& g = hs[k];
+            const SplitStats& st = loc[k];
+            g.flags |= st.flags;
+            g.rows_with += st.rows_with;
+            g.pmin_inv = st.pmin_inv > g.pmin_inv ? st.pmin_inv : g.pmin_inv;
+            g.pmax = st.pmax > g.pmax ? st.pmax : g.pmax;
+            g.smin_inv = st.smin_inv > g.smin_inv ? st.smin_inv : g.smin_inv;
+            g.smax = st.smax > g.smax ? st.smax : g.smax;
+            g.vmax = st.vmax > g.vmax ? st.vmax : g.vmax;
+            for (int q = 0; q < kSplitMaxSuffix; q++)
+                for (int w = 0; w < 8; w++) g.mask[q][w] |= st.mask[q][w];
+            // merge the block's set into the candidate's (same open addressing, grown never: kSlots >= 4 x kWideDictMax)
+            if (dtags[k].empty()) { dtags[k].assign(kSlots, 0ull); dicts[k].assign(kSlots, WideKey{}); }
+            for (size_t s2 = 0; s2 < kSlots && !(g.flags & 4u); s2++) {
+                const uint64_t tag = tags[k * kSlots + s2];
+                if (!tag) continue;
+                const WideKey& key = keys[k * kSlots + s2];
+                size_t h = (size_t)(tag >> 32) & (kSlots - 1);
+                while (dtags[k][h] != 0ull && !(dtags[k][h] == tag && dicts[k][h].len == key.len && memcmp(dicts[k][h].w, key.w, sizeof key.w) == 0)) h = (h + 1) & (kSlots - 1);
+                if (dtags[k][h] == 0ull) {
+                    if (g.count >= (uint32_t)kWideDictMax) g.flags |= 4u;
+                    else { dtags[k][h] = tag; dicts[k][h] = key; g.count++; }
+                }
+            }
+        }
+    }, 2048);
+    const int best = split_pick(ctx, 0, cand, hs, step, most, plain_bits);
+    if (best < 0) return {};
+    const SplitStats& st = hs[(size_t)best];
+    if (st.flags || st.count == 0 || st.count > (uint32_t)kWideDictMax || st.pmax > (uint32_t)kWideBytes || st.smax > (uint32_t)kSplitMaxSuffix ||
+        st.vmax > (uint32_t)kSplitMaxValue)
+        return {};
+    std::vector<WideKey> dict;
+    for (size_t s2 = 0; s2 < dtags[(size_t)best].size(); s2++)
+        if (dtags[(size_t)best][s2]) dict.push_back(dicts[(size_t)best][s2]);
+    if (dict.size() != st.count) return {};
+    CodecHost trial;
+    bool usable = false;
+    CPH_TRY(split_assemble(ctx, 0, 1, nullptr, (uint32_t)cand[(size_t)best], st, &dict, plain_bits, &trial, &usable));
+    if (!usable) return {};
+    trial.spec_checked = true;
+    if (trial.nwords != 1 || !trial.key32 || trial.word_states[0] > (1ull << 27)) return {};   // (the encode loop marks a bad suffix byte in bit 31)
+    if (codec_sort_cost(trial) < bits_sort_cost(plain_bits)) *codec = std::move(trial);
     return {};
 }
 

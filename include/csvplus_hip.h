@@ -198,6 +198,18 @@ CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
  *                   the optimistic direct sort, send the build down the general path (upload of the strings).  Same index either way.
  *   "host_threads"  threads of that worker pool (default 0: half the hardware threads, at most 32: the loops are bound by the
  *                   memory bandwidth of the NUMA node that holds the pinned buffers well before that)
+ *   "host_split"    0 / 1 / 2 (default 1): the same for ONE variable-length key column of >= 2^22 rows in HOST memory whose values
+ *                   want the delimiter split ("Smith/Amelia#12345": a prefix dictionary + suffix positions, 25 bits for BASELINE
+ *                   config 3's 10-22 byte keys): the codec comes from the sample the device would take, read by the host's threads,
+ *                   the codes (4 bytes per row instead of ~22 bytes of string) from a loop that checks every row like the device's
+ *                   encode kernel — unknown prefix, foreign suffix byte, longer value: the strings are uploaded after all.  Same index.
+ *                   1: taken when the estimate says the host's threads beat the upload (~20 ns per row and thread against ~50 GB/s of
+ *                   PCIe; the threads counted are those the cgroup's CPU QUOTA allows — a container throttled to 16 CPUs codes 1e8
+ *                   rows in ~100 ms, the upload takes 44), 2: always, 0: never
+ *   "host_split_threads" threads of that loop's own pool (default 0: 3/8 of the hardware threads, at most 96, at most the CPU quota —
+ *                   it computes, where the 8-byte loops wait for memory)
+ *   "host_numa"     0 / 1 (default 0): 1 binds that pool's workers to the CPUs of the NUMA node that holds the column's first page
+ *                   (opt-in: its effect could not be measured on the quota-limited test hosts)
  *   "build_side_stream" 0 / 1 (default 1): cph_index_build_many enqueues every second build of a batch on a second stream of
  *                   the ctx, so the launch-latency-bound kernels of a small table run beside its neighbour's instead of behind
  *                   them; both streams are idle when the call returns (A/B switch)

@@ -231,7 +231,142 @@ static void test_pool_and_rate() {
     }
 }
 
+
+// encode_split against a plain restatement: random prefix dictionaries behind a brute-force "perfect hash" (any collision-free
+// placement serves the loop), suffix alphabets with END, rows the codec cannot code (unknown prefix, foreign suffix byte, suffix or
+// value too long, no delimiter), the last values of a buffer without slack.
+struct TKey { uint64_t w[4]; uint32_t len; };
+static uint32_t thash(uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3, uint32_t len) {
+    uint64_t h = w0 * 0x9E3779B97F4A7C15ull ^ (w1 + 0x85EBCA6Bull) * 0xC2B2AE3D27D4EB4Full ^ (w2 * 31 + w3 * 17 + len);
+    h ^= h >> 29;
+    return (uint32_t)(h * 0xBF58476D1CE4E5B9ull >> 32);
+}
+static void test_split_against_walk() {
+    std::mt19937_64 rng(11);
+    for (int round = 0; round < 30; round++) {
+        const uint8_t delim = (uint8_t)"#/:"[rng() % 3];
+        // dictionary: distinct prefixes that END in the delimiter, + now and then a whole value without one
+        const int nd = 1 + (int)(rng() % 200);
+        std::vector<std::string> pre;
+        while ((int)pre.size() < nd) {
+            std::string p;
+            const int l = 1 + (int)(rng() % 30);
+            for (int q = 0; q < l; q++) p.push_back((char)('a' + rng() % 6));
+            if (rng() % 9 != 0 || l == 31) p.push_back((char)delim);
+            if (std::find(pre.begin(), pre.end(), p) == pre.end()) pre.push_back(p);
+        }
+        std::sort(pre.begin(), pre.end());
+        std::vector<TKey> dict(pre.size());
+        for (size_t i = 0; i < pre.size(); i++) {
+            memset(&dict[i], 0, sizeof(TKey));
+            memcpy(dict[i].w, pre[i].data(), pre[i].size());
+            dict[i].len = (uint32_t)pre[i].size();
+        }
+        // hash-and-displace by brute force: one bucket per key's low bits, first displacement that lands every key of it on a free slot
+        uint32_t nslots = 4;
+        while (nslots < 4 * pre.size()) nslots <<= 1;
+        std::vector<uint16_t> disp, slots;
+        for (;; nslots <<= 1) {
+            const uint32_t nb = nslots / 4;
+            disp.assign(nb, 0);
+            slots.assign(nslots, 0);
+            bool ok = true;
+            for (uint32_t b = 0; b < nb && ok; b++) {
+                std::vector<uint32_t> mine;
+                for (size_t i = 0; i < dict.size(); i++)
+                    if ((thash(dict[i].w[0], dict[i].w[1], dict[i].w[2], dict[i].w[3], dict[i].len) & (nb - 1)) == b) mine.push_back((uint32_t)i);
+                bool placed = mine.empty();
+                for (uint32_t d = 0; d < nslots && !placed; d++) {
+                    std::vector<uint32_t> at;
+                    bool fits = true;
+                    for (uint32_t i : mine) {
+                        const uint32_t h = thash(dict[i].w[0], dict[i].w[1], dict[i].w[2], dict[i].w[3], dict[i].len);
+                        const uint32_t s2 = ((h >> 16) + d) & (nslots - 1);
+                        if (slots[s2] || std::find(at.begin(), at.end(), s2) != at.end()) { fits = false; break; }
+                        at.push_back(s2);
+                    }
+                    if (fits) {
+                        for (size_t k = 0; k < mine.size(); k++) slots[at[k]] = (uint16_t)(mine[k] + 1);
+                        disp[b] = (uint16_t)d;
+                        placed = true;
+                    }
+                }
+                ok = placed;
+            }
+            if (ok) break;
+        }
+        const int smax = (int)(rng() % 7), smin = smax ? (int)(rng() % (smax + 1)) : 0;
+        const Codec sc = make_codec(rng, smax ? smax : 1, smin, "0123456789");
+        uint64_t sstates = 1;   // weight of the prefix = product of the suffix radices
+        {
+            std::vector<uint32_t> mx((size_t)sc.npos, 0);
+            for (int p2 = 0; p2 < sc.npos; p2++)
+                for (int sym = 0; sym < kLutRow; sym++)
+                    if (!(sc.lut[(size_t)p2 * kLutRow + sym] >> 31)) mx[p2] = std::max(mx[p2], sc.lut[(size_t)p2 * kLutRow + sym]);
+            sstates = (uint64_t)mx[0] + 1;   // (upper bound of the suffix code + 1 is enough for a weight)
+            for (int p2 = 1; p2 < sc.npos; p2++) sstates += mx[p2];
+        }
+        SplitEnc<TKey> e{};
+        e.delim = delim;
+        e.vmax = 40;
+        e.smaxlen = (uint32_t)smax;
+        e.pmult = (uint32_t)sstates;
+        e.hmask = nslots - 1;
+        e.dmask = nslots / 4 - 1;
+        e.disp = disp.data();
+        e.slots = slots.data();
+        e.dict = dict.data();
+        e.lutw = sc.lut.data();
+        CHECK((uint64_t)pre.size() * sstates < (1ull << 31));
+        // rows
+        const uint64_t n = 1 + rng() % 4000;
+        std::vector<uint8_t> data;
+        std::vector<uint32_t> off{0};
+        for (uint64_t r = 0; r < n; r++) {
+            std::string v = pre[rng() % pre.size()];
+            if (rng() % 40 == 0) v = "zz" + v;                                        // unknown prefix
+            if (rng() % 50 == 0) v = std::string(1 + rng() % 12, 'b');               // no delimiter (usually unknown)
+            if (rng() % 60 == 0) v.clear();
+            if (!v.empty() && (uint8_t)v.back() == delim) {
+                const int sl = (int)(rng() % (smax + 2));                             // sometimes too long
+                for (int q = 0; q < sl; q++) v.push_back(rng() % 37 == 0 ? (char)('a' + rng() % 26) : (char)('0' + rng() % 10));
+            }
+            if (rng() % 200 == 0) v += std::string(45, '7');                         // a value beyond vmax
+            data.insert(data.end(), v.begin(), v.end());
+            off.push_back((uint32_t)data.size());
+        }
+        for (int slack = 0; slack < 2; slack++) {
+            std::vector<uint8_t> buf = data;
+            if (slack) buf.resize(buf.size() + 64, 0xAA);
+            HostCol c{buf.data(), off.data(), 32, 0, slack ? (uint64_t)buf.size() : (uint64_t)data.size()};
+            std::vector<uint32_t> got(n, 0xDEADBEEFu);
+            const bool any = encode_split(e, c, 0, n, got.data(), false, thash);
+            bool want_any = false;
+            for (uint64_t r = 0; r < n; r++) {
+                const std::string v(data.begin() + off[r], data.begin() + off[r + 1]);
+                const size_t at = v.find((char)delim);
+                const std::string p = at == std::string::npos ? v : v.substr(0, at + 1), sfx = v.substr(p.size());
+                const auto it = std::lower_bound(pre.begin(), pre.end(), p);
+                bool bad = v.size() > 40 || p.size() > 32 || sfx.size() > (size_t)smax || it == pre.end() || *it != p;
+                uint32_t code = 0;
+                if (!bad) {
+                    code = (uint32_t)(it - pre.begin()) * e.pmult;
+                    for (int q = 0; q < smax; q++) {
+                        const uint32_t x = sc.lut[(size_t)q * kLutRow + ((size_t)q < sfx.size() ? 1 + (unsigned char)sfx[q] : 0)];
+                        if (x >> 31) bad = true;
+                        code += x & 0x7FFFFFFFu;
+                    }
+                }
+                want_any = want_any || bad;
+                if (!bad) CHECK(got[r] == code);
+            }
+            CHECK(any == want_any);
+        }
+    }
+}
+
 int main() {
+    test_split_against_walk();
     test_short_against_walk();
     test_arith_against_walk();
     test_pool_and_rate();
