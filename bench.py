@@ -232,6 +232,17 @@ def _finite(o):
     return o
 
 
+def _cgroup_cpu_max():
+    """The container's CPU quota ("1600000 100000" = 16 CPUs per period, "max ..." = none): host-side thread pools and the all-cores CPU
+    baseline run inside it whatever nproc says."""
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            return open(path).read().strip()
+        except OSError:
+            continue
+    return None
+
+
 def compact_line(out, extras_path):
     """The ONE stdout line: the contract's fields, a compact `roofline` and `cpu_baseline`, and the other measurements of the run as
     bare numbers.  Everything else — per-kernel tables, byte models term by term, verification details, notes — stays in the
@@ -899,7 +910,7 @@ def main():
         "kernels_note": f"per-kernel times from {K} fully profiled steps run behind the timed region (two HIP events per launch "
                         f"slow a step by ~10 %); {dom_name} is the one kernel timed inside the timed region itself",
         "roofline": roofline,
-        "host": {"nproc": os.cpu_count(), "gpu": torch.cuda.get_device_name(dev), "datagen_s": round(gen_s, 1)},
+        "host": {"nproc": os.cpu_count(), "cgroup_cpu_max": _cgroup_cpu_max(), "gpu": torch.cuda.get_device_name(dev), "datagen_s": round(gen_s, 1)},
     }
 
     # Everything from here to the print is measured and reported BESIDE the contract fields above.  A failure in one of these
@@ -1700,7 +1711,7 @@ def main():
                         "value": args.rows / mt_est, "unit": "rows/s", "cores": threads,
                         "sample": f"sort of (key,row) pairs + binary-search probe on {threads} threads (OpenMP, libstdc++ "
                                   f"parallel stable_sort): both index builds in full ({s1 + s2:.2f} s) + both probes of the first "
-                                  f"{mt_n} orders rows ({p1 + p2:.2f} s), probe time scaled to all rows; nproc={os.cpu_count()}"},
+                                  f"{mt_n} orders rows ({p1 + p2:.2f} s), probe time scaled to all rows; nproc={os.cpu_count()}, cgroup cpu.max={_cgroup_cpu_max()} (the threads share that quota)"},
                 },
             }
     except Exception as ex:   # noqa: BLE001
