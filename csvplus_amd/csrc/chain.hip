@@ -53,6 +53,7 @@ struct ChainStepArg {
     int32_t ranktab_lds;        // != 0: PAIRS of blocks of ranktab every workgroup copies into LDS (a small index: no L2 -> L1 line per row)
     const uint4* hash;          // no rowtab: hash table over the codes (hash_device.hpp, kHashK1 entries), or nullptr -> binary search
     uint32_t hash_sectors;
+    uint32_t hash_slice_mask;
     int32_t src;                // cph_chain_step.source: 0 = col belongs to the stream; k / -k = to the build table of step k-1 (DEP kernels only)
     const uint32_t* src_perm;   // src > 0 in positions mode: the source index's perm (sorted position -> original row), else nullptr
     const void* codes;          // sorted codes (u32 if key32 else u64)
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_dense(ChainArgs a, uint
             } else if (st.hash) {
                 // sparse code space: the home sectors of 4 rows at a time are loaded together (16 x 16 bytes in flight
                 // per lane); entry.aux is the build row (duplicate-free index)
-                const HashView hv{st.hash, st.hash_sectors};
+                const HashView hv{st.hash, st.hash_sectors, st.hash_slice_mask};
 #pragma unroll
                 for (int g = 0; g < R; g += 4) {
                     HashSector sc[4];
@@ -804,11 +805,13 @@ static Status enqueue_dense(cph_ctx* ctx, const ChainStep* steps, uint64_t nprob
         st.src_perm = (steps[s].source > 0 && positions) ? steps[steps[s].source - 1].index->perm.as<uint32_t>() : nullptr;
         st.hash = nullptr;
         st.hash_sectors = 0;
+        st.hash_slice_mask = 0;
         if (!st.rowtab && !st.ranktab && !ident[s] && index_wants_hash(ix)) {
             CPH_TRY(index_ensure_hash(ctx, ix));
             if (ix->hash_mode == kHashK1) {
                 st.hash = ix->hash.as<uint4>();
                 st.hash_sectors = ix->hash_sectors;
+                st.hash_slice_mask = ix->hash_slice_mask;
             }
         }
         st.codes = ix->sorted_codes.get();

@@ -365,8 +365,8 @@ __global__ __launch_bounds__(kCsWinThreads) void k_cs_window(const uint64_t* __r
 
 // ---- host side -----------------------------------------------------------------------------------------------------------
 // max_wbits: an upper bound for the window width (the retry behind an overflow: narrower windows for a code space whose rows cluster)
-bool counted_sort_plan(const cph_ctx* ctx, uint64_t n, uint64_t states, CountedSortPlan* p, int max_wbits) {
-    if (!ctx->counted_sort || n < (1ull << 21) || n >= (1ull << 32) - 1 || states == 0 || states >= 0xFFFFFFFFull) return false;
+bool counted_sort_plan(const cph_ctx* ctx, uint64_t n, uint64_t states, CountedSortPlan* p, int max_wbits, uint64_t min_rows) {
+    if (!ctx->counted_sort || n < min_rows || n == 0 || n >= (1ull << 32) - 1 || states == 0 || states >= 0xFFFFFFFFull) return false;
     // the widest window whose average load stays below ~0.72 of the capacity
     int w = max_wbits < kCsMaxWinBits ? max_wbits : kCsMaxWinBits;
     while (w >= kCsMinWinBits && (double)n / (double)states * (double)(1u << w) > 0.72 * (double)kCsCap) w--;
@@ -399,15 +399,15 @@ Status CountedSort::begin(cph_ctx* ctx, const CountedSortPlan& plan, uint64_t n)
     return {};
 }
 
-Status CountedSort::run(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out, uint32_t* sorted_out,
-                        uint32_t* first_dup_dev, uint32_t* over_host, bool hist_done) {
+// hist -> scan -> partition level(s): afterwards entries()[wbase()[w] .. wbase()[w + 1]) are window w's (code << 32 | row) entries, in
+// no particular order (unless *flag() / *over_host: a window beyond kCsCap rows — nothing was moved)
+Status CountedSort::partition(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* over_host, bool hist_done) {
     const uint32_t nwt = p.nwt;
     uint32_t* flag = counts + nwt;
     uint32_t* wbase = flag + 1;
     uint32_t* cur2 = wbase + nwt + 1;
     uint32_t* base1 = cur2 + nwt;
     uint32_t* cur1 = base1 + p.nb1 + 1;
-    CPH_HIP_TRY(hipMemsetAsync(first_dup_dev, 0xFF, sizeof(uint32_t), ctx->stream));
     *over_host = 0;
     int cus = 256;
     CPH_TRY(device_cus(ctx, &cus));
@@ -460,6 +460,15 @@ Status CountedSort::run(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint64_
         hipLaunchKernelGGL(k_cs_partition<2>, dim3(tiles), dim3(kCsThreads), plds, ctx->stream, a);
         CPH_HIP_TRY(hipGetLastError());
     }
+    return {};
+}
+
+Status CountedSort::run(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out, uint32_t* sorted_out,
+                        uint32_t* first_dup_dev, uint32_t* over_host, bool hist_done) {
+    CPH_HIP_TRY(hipMemsetAsync(first_dup_dev, 0xFF, sizeof(uint32_t), ctx->stream));
+    CPH_TRY(partition(ctx, codes, n, states, over_host, hist_done));
+    uint32_t* flag = counts + p.nwt;
+    uint32_t* wbase = flag + 1;
     {
         const uint32_t nwin = (uint32_t)((states + (1ull << p.wbits) - 1) >> p.wbits);
         const size_t wlds = (size_t)kCsCap * 6 + ((size_t)8 << p.wbits) + 1024;

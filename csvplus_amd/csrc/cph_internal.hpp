@@ -366,6 +366,8 @@ struct cph_ctx {
         uint32_t tickets = 0;
     } scan[2];                     // one per stream slot (scans of the two streams of a build batch run concurrently)
     int csv_fast = 1;              // cph_csv_parse: byte-parallel passes over text tiles for texts without quotes (csv_ingest.hip: k_csv_fast); 0: the record-parallel kernels
+    int hash_partitioned = 1;      // the hash table of a duplicate-free index of >= 2^21 keys is built slice by slice in LDS (probe.hip); 0: CAS into the whole
+                                   // table; 2: slice by slice whatever the size (tests)
     int counted_sort = 1;          // IndexOn over 32-bit codes with duplicates: MSD sort through counted LDS windows (counted_sort.hip); 0: the classic passes
     int direct_sort = 1;           // a build that expects distinct keys (UniqueIndexOn) over a dense 32-bit code space (rows <= states <= 2 rows)
                                    // sorts by ONE scatter, slot[code] = row (radix_sort.hip: direct_sort_distinct); a duplicate is noticed on
@@ -475,6 +477,7 @@ struct cph_index {
     // hash table over the codes for every other index (hash_device.hpp), built by the first full-key Join
     cph::DevBuf hash;              // hash_sectors x 64 bytes
     uint32_t hash_sectors = 0;
+    uint32_t hash_slice_mask = 0;  // != 0: the table was built slice by slice (probe.hip: k_hash_window): a probe sequence wraps inside its slice of mask + 1 sectors
     int32_t hash_mode = 0;         // kHashNone until built, then kHashK1 / kHashK3 / kHashTag
     bool accel_failed = false;     // a lookup structure could not be allocated (or tags collided): sorted search from now on
     std::mutex accel_mu;           // held by index_ensure_* from the "is it there" test to the recorded event: Joins of several
@@ -632,7 +635,7 @@ struct CountedSortPlan {
     uint32_t wbits = 0, k2 = 0, nb1 = 0, nwt = 0;
     bool two = false;
 };
-bool counted_sort_plan(const cph_ctx* ctx, uint64_t n, uint64_t states, CountedSortPlan* p, int max_wbits = 31);
+bool counted_sort_plan(const cph_ctx* ctx, uint64_t n, uint64_t states, CountedSortPlan* p, int max_wbits = 31, uint64_t min_rows = 1ull << 21);
 // In two steps: begin (buffers, zeroed counters) | run.  (hist_done: somebody else filled the counters.  Counting the rows per window
 // inside the split-codec encode kernel was tried in round 6: its LDS atomics and the 34 KB of counters cost the kernel 0.23 ms, the
 // separate k_cs_hist pass 0.10 ms.)
@@ -641,6 +644,11 @@ struct CountedSort {
     DevBuf words, ent1, ent2;
     uint32_t* counts = nullptr;
     Status begin(cph_ctx* ctx, const CountedSortPlan& plan, uint64_t n);
+    // the partition alone (probe.hip builds hash tables slice by slice from it): entries() grouped by window, window w at wbase()[w]
+    Status partition(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* over_host, bool hist_done);
+    const uint64_t* entries() const { return p.two ? ent2.as<uint64_t>() : ent1.as<uint64_t>(); }
+    const uint32_t* flag() const { return counts + p.nwt; }
+    const uint32_t* wbase() const { return counts + p.nwt + 1; }
     Status run(cph_ctx* ctx, const uint32_t* codes, uint64_t n, uint64_t states, uint32_t* perm_out, uint32_t* sorted_out, uint32_t* first_dup_dev,
                uint32_t* over_host, bool hist_done);
 };

@@ -51,6 +51,7 @@ static_assert(sizeof(HashEntry16) == 16 && sizeof(HashEntry32) == 32, "entry lay
 struct HashView {
     const uint4* sectors = nullptr;   // 4 x uint4 per sector
     uint32_t nsectors = 0;
+    uint32_t slice_mask = 0;          // != 0: probe sequences wrap inside slices of slice_mask + 1 sectors (a table built slice by slice)
 };
 
 // ---- the hash -------------------------------------------------------------------------------------------------
@@ -69,6 +70,10 @@ CPH_HD inline uint64_t hash_finish(uint64_t s) { return hash_fmix(s); }
 CPH_HD inline uint64_t hash_one(uint64_t code) { return hash_finish(hash_step(kHashSeed, code)); }
 CPH_HD inline uint64_t hash_tag(uint64_t h) { return h & 0x7FFFFFFFFFFFFFFFull; }
 CPH_HD inline uint32_t hash_home(uint64_t h, uint32_t nsectors) { return (uint32_t)(((h >> 32) * (uint64_t)nsectors) >> 32); }
+// the sector that follows s in a probe sequence
+CPH_HD inline uint32_t hash_next_sector(uint32_t s, uint32_t nsectors, uint32_t slice_mask) {
+    return slice_mask ? ((s & ~slice_mask) | ((s + 1u) & slice_mask)) : (s + 1u == nsectors ? 0u : s + 1u);
+}
 
 #if defined(__HIPCC__)
 // ---- lookups ----------------------------------------------------------------------------------------------------
@@ -137,7 +142,7 @@ __device__ __forceinline__ bool hash_find16(const HashView& hv, uint64_t h, uint
         bool more;
         if (hash_match16(sc, key, lo, aux, &more)) return true;
         if (!more) return false;
-        s = s + 1 == hv.nsectors ? 0 : s + 1;
+        s = hash_next_sector(s, hv.nsectors, hv.slice_mask);
     }
 }
 __device__ __forceinline__ bool hash_find32(const HashView& hv, uint64_t h, uint64_t w0, uint64_t w1, uint64_t w2, uint32_t* lo, uint32_t* aux) {
@@ -147,29 +152,29 @@ __device__ __forceinline__ bool hash_find32(const HashView& hv, uint64_t h, uint
         bool more;
         if (hash_match32(sc, w0, w1, w2, lo, aux, &more)) return true;
         if (!more) return false;
-        s = s + 1 == hv.nsectors ? 0 : s + 1;
+        s = hash_next_sector(s, hv.nsectors, hv.slice_mask);
     }
 }
 // continues a lookup whose home sector was full (the rare tail of the straight-line callers)
 __device__ __forceinline__ bool hash_continue16(const HashView& hv, uint32_t home, uint64_t key, uint32_t* lo, uint32_t* aux) {
-    uint32_t s = home + 1 == hv.nsectors ? 0 : home + 1;
+    uint32_t s = hash_next_sector(home, hv.nsectors, hv.slice_mask);
     for (;;) {
         const HashSector sc = hash_load_sector(hv, s);
         bool more;
         if (hash_match16(sc, key, lo, aux, &more)) return true;
         if (!more) return false;
-        s = s + 1 == hv.nsectors ? 0 : s + 1;
+        s = hash_next_sector(s, hv.nsectors, hv.slice_mask);
     }
 }
 __device__ __forceinline__ bool hash_continue32(const HashView& hv, uint32_t home, uint64_t w0, uint64_t w1, uint64_t w2, uint32_t* lo,
                                                 uint32_t* aux) {
-    uint32_t s = home + 1 == hv.nsectors ? 0 : home + 1;
+    uint32_t s = hash_next_sector(home, hv.nsectors, hv.slice_mask);
     for (;;) {
         const HashSector sc = hash_load_sector(hv, s);
         bool more;
         if (hash_match32(sc, w0, w1, w2, lo, aux, &more)) return true;
         if (!more) return false;
-        s = s + 1 == hv.nsectors ? 0 : s + 1;
+        s = hash_next_sector(s, hv.nsectors, hv.slice_mask);
     }
 }
 #endif

@@ -458,6 +458,182 @@ __global__ void k_hash_set_ends(CodesView cv, uint4* __restrict__ sectors, uint3
     }
 }
 
+// ---- the table of a duplicate-free index, slice by slice (round 6) ----------------------------------------------------------
+// k_hash_build claims its slots by CAS all over a table of 32 bytes per key: 1e7 keys = 320 MB of random read-modify-writes, 0.77 ms.
+// Here the rows are first grouped by the SLICE of the table their home sector lies in (2^wbits sectors = at most 64 KB: the counted
+// partition of counted_sort.hip over the home sectors as 32-bit "codes"), then one workgroup builds each slice in LDS — the same
+// claim-the-first-empty-slot rule, the probe sequence wrapping INSIDE the slice (HashView::slice_mask tells the lookups) — and streams
+// it out: the table is written once, sequentially, and never read by the build.
+template <int MODE>
+__device__ __forceinline__ uint64_t hash_row_words(const CodesView& cv, uint64_t i, uint64_t* key, uint64_t* w1, uint64_t* w2) {
+    *w1 = 0;
+    *w2 = 0;
+    if constexpr (MODE == kHashK1) {
+        *key = code_word(cv, 0, i);
+        return hash_one(*key);
+    } else if constexpr (MODE == kHashK3) {
+        *key = code_word(cv, 0, i);
+        *w1 = code_word(cv, 1, i);
+        *w2 = cv.nwords > 2 ? code_word(cv, 2, i) : 0ull;
+        return codes_hash(cv, i);
+    } else {
+        const uint64_t h = codes_hash(cv, i);
+        *key = hash_tag(h);
+        return h;
+    }
+}
+// homes[i] = home sector of row i; kp[i] = what the slice's workgroup needs of the row besides its number — {key / tag, perm[i]} (16 bytes;
+// three-word codes: {w0, w1, w2, perm[i]}, 32 bytes) — so that its gather by row touches ONE 64-byte sector per key instead of one in
+// the codes and one in the permutation
+template <int MODE>
+__global__ __launch_bounds__(256) void k_hash_homes(CodesView cv, const uint32_t* __restrict__ perm, uint32_t nsectors, uint32_t* __restrict__ homes,
+                                                    uint4* __restrict__ kp) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cv.n; i += stride) {
+        uint64_t key, w1, w2;
+        homes[i] = hash_home(hash_row_words<MODE>(cv, i, &key, &w1, &w2), nsectors);
+        const uint32_t aux = perm[i];
+        if constexpr (MODE == kHashK3) {
+            kp[2 * i] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
+            kp[2 * i + 1] = make_uint4((uint32_t)w2, (uint32_t)(w2 >> 32), (uint32_t)i, aux);
+        } else {
+            kp[i] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)i, aux);
+        }
+    }
+}
+constexpr int kHashWinThreads = 512;
+// one workgroup per slice.  LDS (dynamic, from offset 0: the CAS words stay in the low 64 KB): the slice's sectors.
+template <int MODE>
+__global__ __launch_bounds__(kHashWinThreads) void k_hash_window(const uint64_t* __restrict__ ent, const uint32_t* __restrict__ wbase,
+                                                               const uint32_t* __restrict__ part_flag, uint32_t wbits,
+                                                               const uint4* __restrict__ kp, uint4* __restrict__ sectors,
+                                                               uint32_t* __restrict__ fail, uint32_t* __restrict__ collision) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr uint32_t kSlots = MODE == kHashK3 ? 2 : 4, kStride = MODE == kHashK3 ? 2 : 1;
+    uint4* s_sec = reinterpret_cast<uint4*>(smem);
+    if (*part_flag) return;   // (the partition moved nothing: the host builds the table the old way)
+    const uint32_t g = blockIdx.x, t = threadIdx.x;
+    const uint32_t S = 1u << wbits;                      // sectors of the slice
+    const uint32_t b0 = wbase[g], cnt = wbase[g + 1] - b0;
+    if (cnt > S * kSlots - S * kSlots / 16u) {          // (a slice nearly full: probe sequences without end — never at the load factors in use)
+        if (t == 0) *fail = 1u;
+        return;
+    }
+    for (uint32_t i = t; i < S * 4u; i += kHashWinThreads) s_sec[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    __syncthreads();
+    constexpr int kU = 4;   // entries a thread has in flight: their gathers are issued together, the claims follow
+    for (uint32_t base = 0; base < cnt; base += kHashWinThreads * kU) {
+        uint32_t home[kU];
+        uint4 e0[kU], e1[kU];
+        bool live[kU];
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+            const uint32_t i = base + (uint32_t)u * kHashWinThreads + t;
+            live[u] = i < cnt;
+            const uint64_t e = __builtin_nontemporal_load(ent + b0 + (live[u] ? i : cnt - 1u));
+            home[u] = (uint32_t)(e >> 32) & (S - 1u);
+            const uint32_t row = (uint32_t)e;
+            e1[u] = make_uint4(0, 0, 0, 0);
+            if constexpr (MODE == kHashK3) {
+                e0[u] = kp[2ull * row];
+                e1[u] = kp[2ull * row + 1];
+            } else {
+                e0[u] = kp[row];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+            if (!live[u]) continue;
+            const uint64_t key = (uint64_t)e0[u].x | ((uint64_t)e0[u].y << 32);
+            uint32_t s = home[u];
+            uint4* slot = nullptr;
+            while (!slot) {
+                uint4* sec = s_sec + s * 4u;
+                for (uint32_t j = 0; j < kSlots; j++) {
+                    unsigned long long* kpw = reinterpret_cast<unsigned long long*>(sec + j * kStride);
+                    const unsigned long long cur = atomicCAS(kpw, (unsigned long long)kHashEmpty, (unsigned long long)key);
+                    if (cur == kHashEmpty) { slot = sec + j * kStride; break; }
+                    if (MODE == kHashTag && cur == key) *collision = 1u;
+                }
+                s = (s + 1u) & (S - 1u);
+            }
+            reinterpret_cast<uint2*>(slot)[1] = make_uint2(e0[u].z, e0[u].w);
+            if constexpr (MODE == kHashK3) slot[1] = e1[u];
+        }
+    }
+    lds_atomics_barrier();
+    typedef unsigned int hw_u32x4 __attribute__((ext_vector_type(4)));
+    hw_u32x4* dst = reinterpret_cast<hw_u32x4*>(sectors + ((uint64_t)g << wbits) * 4u);
+    const hw_u32x4* src = reinterpret_cast<const hw_u32x4*>(s_sec);
+    for (uint32_t i = t; i < S * 4u; i += kHashWinThreads) __builtin_nontemporal_store(src[i], dst + i);
+}
+
+// the slice-by-slice build; *built false: not applicable or given up (the caller builds the table the old way)
+static Status hash_build_partitioned(cph_ctx* bctx, cph_index* ix, int mode, const CodesView& cv, uint64_t distinct, uint64_t pct, bool* built) {
+    *built = false;
+    const uint64_t n = ix->nrows;
+    if (!bctx->hash_partitioned || distinct != n) return {};
+    const uint64_t slots = mode == kHashK3 ? 2 : 4;
+    uint64_t nsec = (n * 100 + slots * pct - 1) / (slots * pct) + 1;
+    constexpr int kW = 10;                                 // slices of 1024 sectors = 64 KB
+    nsec = (nsec + (1ull << kW) - 1) >> kW << kW;
+    if (nsec >= 0xFFFFFFFFull) return {};
+    CountedSortPlan plan;
+    if (!counted_sort_plan(bctx, n, nsec, &plan, kW, bctx->hash_partitioned == 2 ? 0 : 1ull << 21) || plan.wbits != (uint32_t)kW) return {};
+    uint32_t* over = host_word(bctx);
+    if (!over) return {};
+    DevBuf homes, kp, t, flags;
+    CountedSort cs;
+    if (!homes.alloc(&bctx->pool, n * sizeof(uint32_t)).ok() || !kp.alloc(&bctx->pool, n * (mode == kHashK3 ? 32 : 16)).ok() || !cs.begin(bctx, plan, n).ok() || !flags.alloc(&bctx->pool, 2 * sizeof(uint32_t)).ok() ||
+        !t.alloc(&bctx->pool, nsec * 64).ok())
+        return {};   // (no memory for the detour: the old way needs less)
+    CPH_HIP_TRY(hipMemsetAsync(flags.get(), 0, 2 * sizeof(uint32_t), bctx->stream));
+    const dim3 grid(grid_for_items(n));
+    {
+        ProfScope ps(bctx, "k_hash_homes", (double)n * (8.0 * cv.nwords + 4.0));
+        if (mode == kHashK1) hipLaunchKernelGGL(k_hash_homes<kHashK1>, grid, dim3(256), 0, bctx->stream, cv, ix->perm.as<uint32_t>(), (uint32_t)nsec, homes.as<uint32_t>(), kp.as<uint4>());
+        else if (mode == kHashK3) hipLaunchKernelGGL(k_hash_homes<kHashK3>, grid, dim3(256), 0, bctx->stream, cv, ix->perm.as<uint32_t>(), (uint32_t)nsec, homes.as<uint32_t>(), kp.as<uint4>());
+        else hipLaunchKernelGGL(k_hash_homes<kHashTag>, grid, dim3(256), 0, bctx->stream, cv, ix->perm.as<uint32_t>(), (uint32_t)nsec, homes.as<uint32_t>(), kp.as<uint4>());
+        CPH_HIP_TRY(hipGetLastError());
+    }
+    CPH_TRY(cs.partition(bctx, homes.as<uint32_t>(), n, nsec, over, false));
+    {
+        const uint32_t nwin = (uint32_t)(nsec >> kW);
+        const size_t lds = (size_t)64 << kW;
+        uint32_t* fl = flags.as<uint32_t>();
+        ProfScope ps(bctx, "k_hash_window", (double)n * (8.0 + 8.0 * cv.nwords + 4.0) + 64.0 * (double)nsec);
+        auto go = [&](auto kernel) -> Status {
+            CPH_TRY(kernel_setup(bctx, reinterpret_cast<const void*>(kernel), kHashWinThreads, lds, nullptr));
+            hipLaunchKernelGGL(kernel, dim3(nwin), dim3(kHashWinThreads), lds, bctx->stream, cs.entries(), cs.wbase(), cs.flag(), (uint32_t)kW,
+                               kp.as<uint4>(), t.as<uint4>(), fl, fl + 1);
+            return {};
+        };
+        if (mode == kHashK1) CPH_TRY(go(&k_hash_window<kHashK1>));
+        else if (mode == kHashK3) CPH_TRY(go(&k_hash_window<kHashK3>));
+        else CPH_TRY(go(&k_hash_window<kHashTag>));
+        CPH_HIP_TRY(hipGetLastError());
+    }
+    // one wait: did the partition overflow, did a slice give up, did two keys share a tag
+    uint32_t host_flags[2] = {1, 1};
+    if (hipMemcpyAsync(host_flags, flags.get(), sizeof host_flags, hipMemcpyDeviceToHost, bctx->stream) != hipSuccess ||
+        hipStreamSynchronize(bctx->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return {};
+    }
+    if (*(volatile uint32_t*)over || host_flags[0]) return {};   // (nothing usable was written: the old way)
+    if (mode == kHashTag && host_flags[1]) {
+        ix->accel_failed = true;   // two distinct keys with one 64-bit tag: no hash table for this index (as k_hash_build decides)
+        *built = true;
+        return {};
+    }
+    ix->hash = std::move(t);
+    ix->hash_sectors = (uint32_t)nsec;
+    ix->hash_slice_mask = (1u << kW) - 1u;
+    ix->hash_mode = mode;
+    *built = true;
+    return {};
+}
+
 bool index_wants_hash(const cph_index* ix) { return ix->nrows != 0 && ix->table_entries == 0; }
 
 Status index_ensure_hash(cph_ctx* ctx, const cph_index* cix) {
@@ -490,6 +666,15 @@ Status index_ensure_hash(cph_ctx* ctx, const cph_index* cix) {
     }
     const uint64_t pct = (uint64_t)(bctx->hash_load_pct < 25 ? 25 : bctx->hash_load_pct > 90 ? 90 : bctx->hash_load_pct);
     const uint64_t pct3 = pct;
+    if (unique) {
+        bool built = false;
+        CPH_TRY(hash_build_partitioned(bctx, ix, mode, cv, distinct, pct, &built));
+        if (built) {
+            if (ix->accel_failed) return {};
+            CPH_TRY(accel_done(bctx, ix));
+            return accel_wait(ctx, ix);
+        }
+    }
     uint64_t nsec = mode == kHashK3 ? (distinct * 100 + 2 * pct3 - 1) / (2 * pct3) : (distinct * 100 + 4 * pct - 1) / (4 * pct);
     nsec += 1;   // (always an empty slot somewhere: every probe sequence ends)
     if (nsec > 0xFFFFFFFFull) nsec = 0xFFFFFFFFull;
@@ -1085,7 +1270,7 @@ static Status probe_windows_hash(cph_ctx* ctx, const cph_index* ix, const DevCol
     }
     {
         ProfScope ps(ctx, "k_window_lookup", 0);
-        const HashView hv{ix->hash.as<uint4>(), ix->hash_sectors};
+        const HashView hv{ix->hash.as<uint4>(), ix->hash_sectors, ix->hash_slice_mask};
         hipLaunchKernelGGL(k_window_lookup, dim3(grid), dim3(kProbeThreads), 0, ctx->stream, hv, ix->first_dup == UINT64_MAX, nprobe,
                            state.as<uint64_t>(), ok.as<uint32_t>(), lo, cnt);
         CPH_HIP_TRY(hipGetLastError());
@@ -1212,7 +1397,7 @@ Status probe_run(cph_ctx* ctx, const cph_index* ix, const DevCol* cols, int32_t 
     LookupArg look;
     look.table = ix->table.as<TableEntry>();
     look.rank = ix->ranktab.as<uint2>();
-    look.hash = HashView{ix->hash.as<uint4>(), ix->hash_sectors};
+    look.hash = HashView{ix->hash.as<uint4>(), ix->hash_sectors, ix->hash_slice_mask};
     look.hash_mode = ix->hash_mode;
     look.unique = ix->first_dup == UINT64_MAX ? 1 : 0;
     uint32_t* lo = out->lo.as<uint32_t>();

@@ -210,6 +210,11 @@ CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
  *                   it computes, where the 8-byte loops wait for memory)
  *   "host_numa"     0 / 1 (default 0): 1 binds that pool's workers to the CPUs of the NUMA node that holds the column's first page
  *                   (opt-in: its effect could not be measured on the quota-limited test hosts)
+ *   "hash_partitioned" 0 / 1 / 2 (default 1): the hash table of a duplicate-free index of >= 2^21 keys (sparse key codes: random ids,
+ *                   hashes) is built SLICE BY SLICE: the rows grouped by the 64 KB slice of the table their home sector lies in, every
+ *                   slice filled in LDS by one workgroup and written out once (probe sequences wrap inside a slice) instead of
+ *                   compare-and-swaps all over the table; 0: the latter; 2: slice by slice whatever the size (tests).  Lookups answer
+ *                   the same either way
  *   "build_side_stream" 0 / 1 (default 1): cph_index_build_many enqueues every second build of a batch on a second stream of
  *                   the ctx, so the launch-latency-bound kernels of a small table run beside its neighbour's instead of behind
  *                   them; both streams are idle when the call returns (A/B switch)

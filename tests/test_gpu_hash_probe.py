@@ -16,6 +16,17 @@ from tests.test_gpu_chain import check_chain, oracle_chain
 
 pytestmark = pytest.mark.gpu
 
+
+
+@pytest.fixture(autouse=True, params=["whole_table_build", "slice_by_slice_build"])
+def hash_build_kind(ctx, request):
+    """Every test twice: the table of a duplicate-free index built by compare-and-swap all over it, and (round 6: ctx option
+    hash_partitioned; 2 = whatever the size) slice by slice in LDS behind a counted partition of the rows by home sector."""
+    ctx.set_option("hash_partitioned", 2 if request.param == "slice_by_slice_build" else 0)
+    yield request.param
+    ctx.set_option("hash_partitioned", 1)
+
+
 ALNUM36 = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz0123456789", dtype=np.uint8)
 ALNUM62 = np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789", dtype=np.uint8)
 HASH_BUILT = 4   # cph_index_info.lookup_built bit
@@ -285,3 +296,39 @@ def test_index_shared_between_two_ctxs():
     assert_join_equal(g.probe([probe]), orc.OracleIndex([col]).join([probe]))
     g.close()
     a.close()
+
+
+@pytest.mark.parametrize("kind", ["k1", "k3", "tag"])
+def test_slice_by_slice_build_at_its_own_size(kind):
+    """2.3e6 distinct sparse keys (the size from which the slice-by-slice build is taken by itself): the table answers exactly like the
+    one built by compare-and-swap — hits with their build rows, misses — for one-word, three-word and tagged entries; the slices show
+    in the table's size (whole 64 KB slices)."""
+    rng = np.random.default_rng({"k1": 1, "k3": 2, "tag": 3}[kind])
+    n, m = 2_300_000, 400_000
+    width = {"k1": 12, "k3": 16, "tag": 28}[kind]
+    alphabet = ALNUM36 if kind == "k1" else np.arange(256, dtype=np.uint8)
+    mat = alphabet[rng.integers(0, len(alphabet), (n, width))]
+    mat = np.unique(mat, axis=0)
+    rng.shuffle(mat)
+    n = len(mat)
+    build = StrCol.from_arrays(np.ascontiguousarray(mat).reshape(-1), (np.arange(n + 1, dtype=np.uint64) * width).astype(np.uint32))
+    pm = mat[rng.integers(0, n, m)].copy()
+    pm[::3, width - 1] ^= 1                                  # a third of the probe keys: (almost surely) absent neighbours
+    probe = StrCol.from_arrays(np.ascontiguousarray(pm).reshape(-1), (np.arange(m + 1, dtype=np.uint64) * width).astype(np.uint32))
+    res = {}
+    for part in (1, 0):
+        c = Context(0)
+        c.set_option("hash_partitioned", part)
+        g = DeviceIndex(c, [build])
+        mt = g.probe([probe])
+        inf = g.info()
+        assert inf["lookup_built"] & HASH_BUILT and inf["hash_mode"] == {"k1": 1, "k3": 2, "tag": 3}[kind], inf
+        assert (inf["hash_bytes"] % 65536 == 0) == (part == 1), inf
+        res[part] = (np.asarray(mt.probe_idx).copy(), np.asarray(mt.build_row).copy(), mt.nmatches)
+        mt.release(); g.close(); c.close()
+    assert res[0][2] == res[1][2] and m // 2 < res[1][2] < m
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    # every reported pair is a true match (bytes of the build row == bytes of the probe row)
+    pi, br = res[1][0][:: 97], res[1][1][:: 97]
+    assert np.array_equal(mat[br], pm[pi])
