@@ -88,6 +88,7 @@ while time.time() < t_end:
     o = orc.OracleIndex(bcols)
     for limit in (16384, 0):
         ctx.set_option("small_build_rows", limit)
+        ctx.set_option("hash_partitioned", 2 if limit == 0 else 0)   # sparse keys: the table slice by slice (round 6) / by CAS over the whole table
         g = DeviceIndex(ctx, bcols)
         tag = (seed, cases, n, ncols, m, limit, g.info()["build_path"], g.info()["split"])
         if limit == 0:
@@ -134,4 +135,5 @@ while time.time() < t_end:
             ctx.set_option("pool_guard_check", 0)
         break
 ctx.set_option("small_build_rows", 8192)
+ctx.set_option("hash_partitioned", 1)
 print("FUZZ_OK cases", cases, "seed", seed, "| tables coded with the delimiter split:", splits, "| fixed-width 8-byte key tables (lean chain steps):", leans, flush=True)
