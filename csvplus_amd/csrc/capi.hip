@@ -1136,6 +1136,7 @@ CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value
     else if (k == "host_threads") { ctx->host_threads = value < 0 || value > 256 ? 0 : (int)value; host_pool_destroy(ctx); }
     else if (k == "host_split") ctx->host_split = value < 0 || value > 2 ? 1 : (int)value;
     else if (k == "host_numa") ctx->host_numa = value != 0;
+    else if (k == "sample_lean") ctx->sample_lean = value != 0;
     else if (k == "hash_partitioned") ctx->hash_partitioned = value < 0 || value > 2 ? 1 : (int)value;
     else if (k == "host_split_threads") { ctx->host_split_threads = value < 0 || value > 256 ? 0 : (int)value; host_pool_destroy(ctx); }
     else if (k == "counted_sort") ctx->counted_sort = value != 0;

@@ -1227,6 +1227,52 @@ __global__ __launch_bounds__(kSplitThreads) void k_encode_split(DevCol col, cons
     if (__ballot(missed) && lane_id() == 0) *miss = 1u;   // a flag, possibly in pinned host memory: a plain store
 }
 
+// The sample of a FIXED-WIDTH column of at most 8 bytes (ids): only the per-position byte presence is wanted (codec_sample_finish) —
+// one 8-byte load per row and 8 LDS bit sets instead of k_split_count's 40-byte windows and first-occurrence counts: the kernel sits
+// on the critical path of every UniqueIndexOn(ids) (bench step: 32 us -> ~10).  Same self-cleaning accumulator, same host block.
+__global__ __launch_bounds__(kSplitThreads) void k_sample_fixed8(DevCol col, uint64_t step, uint64_t n, SplitSample* __restrict__ out,
+                                                                SplitSample* __restrict__ host_out) {
+    __shared__ uint32_t s_mask[8 * 8];
+    __shared__ uint32_t s_last;
+    const uint32_t W = col.fixed_width;   // 1 .. 8
+    if (threadIdx.x < 64) s_mask[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * kSplitThreads;
+    for (uint64_t i = (uint64_t)blockIdx.x * kSplitThreads + threadIdx.x; i < n; i += stride) {
+        uint64_t b, l;
+        value_span_whole(col, i * step, &b, &l);
+        ValueRegs<1> v;
+        v.load(col, b, l);
+        for (uint32_t q = 0; q < W; q++) {
+            const uint32_t byte = (uint32_t)(v.c[0] >> (8u * q)) & 0xFFu, bit = 1u << (byte & 31u);
+            uint32_t* w = &s_mask[q * 8u + (byte >> 5)];
+            if (!(*(volatile uint32_t*)w & bit)) atomicOr(w, bit);
+        }
+    }
+    lds_atomics_barrier();
+    if (threadIdx.x < 64) {
+        const uint32_t bits = s_mask[threadIdx.x];
+        uint32_t* gm = &out->mask[0][0] + threadIdx.x;
+        if (bits && (__hip_atomic_load(gm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bits) != bits) atomicOr(gm, bits);
+    }
+    uint32_t* ticket = reinterpret_cast<uint32_t*>(out + 1);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+    __syncthreads();
+    if (s_last) {   // every other workgroup's atomics happened before its ticket
+        uint32_t* src = &out->mask[0][0];
+        uint32_t* dst = &host_out->mask[0][0];
+        for (uint32_t i = threadIdx.x; i < (uint32_t)(kSplitMaxValue * 8); i += kSplitThreads) dst[i] = i < 64u ? atomicExch(&src[i], 0u) : 0u;
+        if (threadIdx.x == 0) {
+            host_out->maxlen = W;
+            host_out->minlen_inv = ~W;
+            atomicExch(ticket, 0u);
+        }
+        __threadfence_system();
+    }
+}
+
 // ---- split codec: host side -------------------------------------------------------------------------------------
 int codec_virtual_cols(const CodecHost& cd, const DevCol* real, int nreal, DevCol* out) {
     int nv = 0;
@@ -1452,8 +1498,12 @@ Status codec_sample_launch(cph_ctx* ctx, const DevCol& col, uint64_t n, const vo
     ProfScope ps(ctx, "k_split_count", 0);
     uint64_t nblk = (nsel + kSplitThreads - 1) / kSplitThreads;
     if (nblk > 1024) nblk = 1024;
-    hipLaunchKernelGGL(k_split_count, dim3((unsigned)nblk), dim3(kSplitThreads), 0, ctx->stream, col, step, nsel, acc.as<SplitSample>(),
-                       reinterpret_cast<SplitSample*>(hw));
+    if (col.fixed_width <= 8 && ctx->sample_lean)
+        hipLaunchKernelGGL(k_sample_fixed8, dim3((unsigned)nblk), dim3(kSplitThreads), 0, ctx->stream, col, step, nsel, acc.as<SplitSample>(),
+                           reinterpret_cast<SplitSample*>(hw));
+    else
+        hipLaunchKernelGGL(k_split_count, dim3((unsigned)nblk), dim3(kSplitThreads), 0, ctx->stream, col, step, nsel, acc.as<SplitSample>(),
+                           reinterpret_cast<SplitSample*>(hw));
     if (hipGetLastError() != hipSuccess) {
         acc.reset();   // (the accumulator may not be zero any more)
         return {CPH_ERR_HIP, "k_split_count launch failed"};

@@ -210,6 +210,8 @@ CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
  *                   it computes, where the 8-byte loops wait for memory)
  *   "host_numa"     0 / 1 (default 0): 1 binds that pool's workers to the CPUs of the NUMA node that holds the column's first page
  *                   (opt-in: its effect could not be measured on the quota-limited test hosts)
+ *   "sample_lean"   0 / 1 (default 1): the sample of a fixed-width key column of at most 8 bytes is taken by a kernel that collects
+ *                   nothing but the per-position byte presence (the only thing stats_sample uses; A/B switch)
  *   "hash_partitioned" 0 / 1 / 2 (default 1): the hash table of a duplicate-free index of >= 2^21 keys (sparse key codes: random ids,
  *                   hashes) is built SLICE BY SLICE: the rows grouped by the 64 KB slice of the table their home sector lies in, every
  *                   slice filled in LDS by one workgroup and written out once (probe sequences wrap inside a slice) instead of
