@@ -23,6 +23,8 @@ which several ranks share one GPU — RCCL refuses that — never of a real mult
 """
 from __future__ import annotations
 
+import numpy as np
+
 from . import _native as N
 
 
@@ -151,11 +153,71 @@ def chunk_range(n: int, c: int, nchunks: int):
     return b, b + q + (1 if c < m else 0)
 
 
-def pipelined_dense_exchange(shard_rows, dense_chunk, nsteps: int, nchunks: int, group=None):
+def packed_bits(limits):
+    """CPH_DIST_PACKED's widths (csrc/dist.hip): step s carries values 0 .. limits[s] - 1; step 0 also the absent code limits[0]."""
+    return [max(1, int(limits[0]).bit_length())] + [max(1, int(x - 1).bit_length() if x else 1) for x in limits[1:]]
+
+
+def pack_rows(parts, limits):
+    """The wire format of CPH_DIST_PACKED, restated with numpy: B = sum(packed_bits) bits per row, row i of a group of 64 rows in
+    bits [i * B, (i + 1) * B) of the group's B little-endian 64-bit words, step 0 in a row's low bits, ABSENT in step 0 as limits[0];
+    the last group is padded with zero rows and the word count rounded up to an even number."""
+    bits = packed_bits(limits)
+    B = sum(bits)
+    assert B <= 64
+    n = len(parts[0])
+    groups = (n + 63) // 64
+    v = np.zeros(groups * 64, dtype=np.uint64)
+    shift = 0
+    for s, (x, b) in enumerate(zip(parts, bits)):
+        x = np.asarray(x).astype(np.int64) & 0xFFFFFFFF
+        if s == 0:
+            x = np.where(x == (ABSENT & 0xFFFFFFFF), int(limits[0]), x)
+        v[:n] |= (x.astype(np.uint64) & np.uint64((1 << b) - 1)) << np.uint64(shift)
+        shift += b
+    nwords = (groups * B + 1) & ~1
+    out = np.zeros(nwords, dtype=np.uint64)
+    i = np.arange(groups * 64, dtype=np.int64)
+    pos = (i % 64) * B
+    word = (i // 64) * B + (pos >> 6)
+    off = (pos & 63).astype(np.uint64)
+    np.bitwise_or.at(out, word, v << off)
+    spill = (pos & 63) + B > 64
+    np.bitwise_or.at(out, word[spill] + 1, v[spill] >> (np.uint64(64) - off[spill]))
+    return out
+
+
+def unpack_rows(words, n, limits):
+    """pack_rows' inverse: n rows -> one int32 array per step (ABSENT restored in step 0)."""
+    bits = packed_bits(limits)
+    B = sum(bits)
+    words = np.asarray(words, dtype=np.uint64)
+    i = np.arange(n, dtype=np.int64)
+    pos = (i % 64) * B
+    word = (i // 64) * B + (pos >> 6)
+    off = (pos & 63).astype(np.uint64)
+    v = words[word] >> off
+    spill = (pos & 63) + B > 64
+    v[spill] |= words[word[spill] + 1] << (np.uint64(64) - off[spill])
+    if B < 64:
+        v &= np.uint64((1 << B) - 1)
+    out, shift = [], 0
+    for s, b in enumerate(bits):
+        x = ((v >> np.uint64(shift)) & np.uint64((1 << b) - 1)).astype(np.int64)
+        if s == 0:
+            x = np.where(x == int(limits[0]), ABSENT & 0xFFFFFFFF, x)
+        out.append(x.astype(np.uint32).view(np.int32))
+        shift += b
+    return out
+
+
+def pipelined_dense_exchange(shard_rows, dense_chunk, nsteps: int, nchunks: int, group=None, packed_limits=None):
     """shard_rows: the row counts of ALL ranks' shards (consecutive ranges in rank order).  dense_chunk(begin, end) -> nsteps
     int32 tensors of end - begin slots for THIS rank's shard rows [begin, end): slot i holds the build row of stream row i,
     ABSENT in array 0 where the row did not join.  Chunk c's sends are posted before chunk c + 1 is computed and awaited only
-    at the end.  Returns (stream_row or None when every row of every rank joined, [build rows...], per-rank totals)."""
+    at the end.  Returns (stream_row or None when every row of every rank joined, [build rows...], per-rank totals).
+    packed_limits (one value range per step): the chunks travel in CPH_DIST_PACKED's format — one array of 64-bit words per chunk,
+    unpacked by the receiver when all transfers are done."""
     import torch
     import torch.distributed as dist
 
@@ -168,7 +230,7 @@ def pipelined_dense_exchange(shard_rows, dense_chunk, nsteps: int, nchunks: int,
         displs.append(displs[-1] + x)
     total = displs[-1]
     slots = [torch.empty(total, dtype=torch.int32) for _ in range(nsteps)]
-    pending = []
+    pending, inbox, keep_alive = [], [], []
     joined = 0
     for c in range(nchunks):
         b, e = chunk_range(rows[rank], c, nchunks)
@@ -178,6 +240,26 @@ def pipelined_dense_exchange(shard_rows, dense_chunk, nsteps: int, nchunks: int,
             for a in range(nsteps):
                 slots[a][displs[rank] + b:displs[rank] + e].copy_(part[a])
         if world == 1:
+            continue
+        if packed_limits is not None:
+            B = sum(packed_bits(packed_limits))
+            nwords = lambda rows_: ((((rows_ + 63) // 64) * B) + 1) & ~1   # noqa: E731
+            ops = []
+            mine = torch.from_numpy(pack_rows([slots[a][displs[rank] + b:displs[rank] + e].numpy() for a in range(nsteps)], packed_limits).view(np.int64)) if e > b else None
+            keep_alive.append(mine)
+            for peer in range(world):
+                if peer == rank:
+                    continue
+                gpeer = dist.get_global_rank(group, peer) if group is not None else peer
+                if e > b:
+                    ops.append(dist.P2POp(dist.isend, mine, gpeer, group=group))
+                pb, pe = chunk_range(rows[peer], c, nchunks)
+                if pe > pb:
+                    buf = torch.empty(nwords(pe - pb), dtype=torch.int64)
+                    inbox.append((peer, pb, pe, buf))
+                    ops.append(dist.P2POp(dist.irecv, buf, gpeer, group=group))
+            if ops:
+                pending.extend(dist.batch_isend_irecv(ops))
             continue
         ops = []
         for a in range(nsteps):      # same order on every rank: array-major, then peer
@@ -194,6 +276,9 @@ def pipelined_dense_exchange(shard_rows, dense_chunk, nsteps: int, nchunks: int,
             pending.extend(dist.batch_isend_irecv(ops))      # posted; chunk c + 1 is computed while they move
     for req in pending:
         req.wait()
+    for peer, pb, pe, buf in inbox:
+        for a, x in enumerate(unpack_rows(buf.numpy().view(np.uint64), pe - pb, packed_limits)):
+            slots[a][displs[peer] + pb:displs[peer] + pe].copy_(torch.from_numpy(x))
     totals = [joined]
     if world > 1:
         t = torch.zeros(world, dtype=torch.int64)

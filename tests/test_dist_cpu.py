@@ -98,7 +98,7 @@ def test_sharded_join_allgatherv_gloo(world):
     assert sorted(results) == [(r, "ok") for r in range(world)], results
 
 
-def _pipe_worker(rank, world, port, m, nc, npd, factor, nchunks, cuts, q):
+def _pipe_worker(rank, world, port, m, nc, npd, factor, nchunks, cuts, q, packed=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -125,7 +125,7 @@ def _pipe_worker(rank, world, port, m, nc, npd, factor, nchunks, cuts, q):
             return [torch.from_numpy(a), torch.from_numpy(bb)]
 
         shard_rows = [cuts[r + 1] - cuts[r] for r in range(world)]
-        s, rows, totals = pipelined_dense_exchange(shard_rows, dense_chunk, 2, nchunks)
+        s, rows, totals = pipelined_dense_exchange(shard_rows, dense_chunk, 2, nchunks, packed_limits=[nc, npd] if packed else None)
         assert calls == [chunk_range(shard_rows[rank], c, nchunks) for c in range(nchunks) if chunk_range(shard_rows[rank], c, nchunks)[1] >
                          chunk_range(shard_rows[rank], c, nchunks)[0]]
         o = dg.orders(m, factor * nc, npd)
@@ -147,8 +147,34 @@ def _pipe_worker(rank, world, port, m, nc, npd, factor, nchunks, cuts, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,factor,nchunks,uneven", [(2, 2, 4, False), (2, 1, 3, True), (3, 2, 5, True)])
-def test_pipelined_dense_exchange_gloo(world, factor, nchunks, uneven):
+def test_packed_wire_format_round_trip():
+    """CPH_DIST_PACKED's format restated with numpy (csvplus_amd/dist.py: pack_rows / unpack_rows): widths, the absent code, rows that
+    straddle two words, partial last groups, the full 64 bits."""
+    from csvplus_amd.dist import pack_rows, packed_bits, unpack_rows
+
+    assert packed_bits([10_000_000, 100_000]) == [24, 17] and packed_bits([4000, 60]) == [12, 6] and packed_bits([1, 1]) == [1, 1]
+    rng = np.random.default_rng(5)
+    for limits in ([4000, 60], [10_000_000, 100_000], [1, 1], [(1 << 32) - 1, 1 << 32], [300, 7, 90_000]):
+        for n in (0, 1, 63, 64, 65, 1000, 4097):
+            parts = [rng.integers(0, lim, n, dtype=np.int64).astype(np.uint32).view(np.int32) for lim in limits]
+            if n:
+                parts[0][rng.random(n) < 0.3] = ABSENT
+            words = pack_rows(parts, limits)
+            B = sum(packed_bits(limits))
+            assert len(words) == ((((n + 63) // 64) * B) + 1) & ~1
+            back = unpack_rows(words, n, limits)
+            for a, b in zip(parts, back):
+                np.testing.assert_array_equal(a, b)
+    # a hand-made case: 3 rows of 12 + 6 bits — row 1 = bits 18..35, row 3 would start at bit 54 and straddle the word
+    w = pack_rows([np.array([1, ABSENT, 5, 7], np.int32), np.array([2, 3, 4, 9], np.int32)], [4000, 60])
+    v = lambda a, b: a | (b << 12)   # noqa: E731
+    assert int(w[0]) == (v(1, 2) | (v(4000, 3) << 18) | (v(5, 4) << 36) | ((v(7, 9) << 54) & ((1 << 64) - 1)))
+    assert int(w[1]) & 0xFF == v(7, 9) >> 10
+
+
+@pytest.mark.parametrize("world,factor,nchunks,uneven,packed", [(2, 2, 4, False, False), (2, 1, 3, True, False), (3, 2, 5, True, False),
+                                                               (2, 2, 3, False, True), (3, 2, 4, True, True), (3, 1, 2, True, True)])
+def test_pipelined_dense_exchange_gloo(world, factor, nchunks, uneven, packed):
     """The control flow of cph_dist_join_chain (csrc/dist.hip) over gloo: sub-chunks posted while the next one is computed,
     uneven shards and an empty one, identity and not — the gathered list equals the oracle's join over the whole stream."""
     m = 20_011
@@ -159,7 +185,7 @@ def test_pipelined_dense_exchange_gloo(world, factor, nchunks, uneven):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, m, 3000, 50, factor, nchunks, cuts, q)) for r in range(world)]
+    procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, m, 3000, 50, factor, nchunks, cuts, q, packed)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=300) for _ in procs]
