@@ -1141,6 +1141,8 @@ CPH_API int32_t cph_ctx_set_option(cph_ctx* ctx, const char* name, int64_t value
     else if (k == "host_split_threads") { ctx->host_split_threads = value < 0 || value > 256 ? 0 : (int)value; host_pool_destroy(ctx); }
     else if (k == "counted_sort") ctx->counted_sort = value != 0;
     else if (k == "csv_fast") ctx->csv_fast = value != 0;
+    else if (k == "csv_onepass_debug") ctx->csv_onepass_debug = (int)value;
+    else if (k == "csv_onepass") ctx->csv_onepass = value < 0 ? 0 : value > (1 << 20) ? (1 << 20) : (int)value;
     else if (k == "direct_sort") ctx->direct_sort = value < 0 || value > 4 ? 1 : (int)value;   // 1: LDS windows (window_sort.hip); A/B: 4 plain scatter, 2 partition pass + scatter, 3 the encode kernel fills the slots
     else if (k == "chain_arith") ctx->chain_arith = value != 0;
     else if (k == "chain_identity") ctx->chain_identity = value != 0;

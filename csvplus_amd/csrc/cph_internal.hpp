@@ -366,6 +366,9 @@ struct cph_ctx {
         uint32_t tickets = 0;
     } scan[2];                     // one per stream slot (scans of the two streams of a build batch run concurrently)
     int csv_fast = 1;              // cph_csv_parse: byte-parallel passes over text tiles for texts without quotes (csv_ingest.hip: k_csv_fast); 0: the record-parallel kernels
+    int csv_onepass = 1;           // cph_csv_write[_rows]: one pass over the joined rows (materialize.hip: k_csv_onepass; slot tables + decoupled look-back);
+                                   // 0: the two-pass writer; N > 1: taken whatever the row count, with at most N workgroups (tests)
+    int csv_onepass_debug = 0;     // measurement only (wrong text): 1 no look-back, 2 no record bytes, 4 one record per thread
     int sample_lean = 1;           // the sample of a fixed-width key column of <= 8 bytes is taken by k_sample_fixed8 (A/B switch; 0: k_split_count)
     int hash_partitioned = 1;      // the hash table of a duplicate-free index of >= 2^21 keys is built slice by slice in LDS (probe.hip); 0: CAS into the whole
                                    // table; 2: slice by slice whatever the size (tests)

@@ -46,6 +46,9 @@ struct LdsSink {
 struct GlobalSink {
     uint8_t* p;
     __device__ __forceinline__ void put(uint8_t b) { *p++ = b; }
+    __device__ __forceinline__ void put8(uint64_t chunk, uint32_t n) {
+        for (uint32_t j = 0; j < n; j++) put((uint8_t)(chunk >> (8u * j)));
+    }
 };
 
 // (round 6) A tile's bytes assembled WORD-wise: a thread appends its record's bytes to a 64-bit accumulator and ORs whole 32-bit
@@ -208,7 +211,8 @@ __device__ __forceinline__ void csv_put_field(Sink& out, const DevCol& col, uint
     if (quoted) out.put('"');
 }
 
-__device__ __forceinline__ void csv_put_field_words(WordSink& out, const DevCol& col, uint64_t begin, uint64_t len, uint64_t chunk0, bool quoted) {
+template <class Sink>
+__device__ __forceinline__ void csv_put_field_words(Sink& out, const DevCol& col, uint64_t begin, uint64_t len, uint64_t chunk0, bool quoted) {
     if (!quoted) {   // the common case: the value's bytes as they are, 8 at a time
         for (uint64_t q = 0; q < len; q += 8) {
             const uint64_t chunk = q ? load_value_chunk(col.data, begin, len, (int)(q >> 3)) : chunk0;
@@ -265,8 +269,10 @@ struct CsvMode {
 // lens[i] = bytes of record i; qflags[i] bit c = field c is quoted (the copy pass does not look again)
 template <int NC>
 __global__ __launch_bounds__(kMatThreads) void k_csv_lens(ColsArg cols, ColIds ids, int ncols, CsvMode mode, uint64_t n,
-                                                         uint64_t* __restrict__ lens, uint16_t* __restrict__ qflags) {
+                                                         uint64_t* __restrict__ lens, uint16_t* __restrict__ qflags,
+                                                         unsigned long long* __restrict__ max_out) {
     const uint64_t stride = (uint64_t)gridDim.x * kMatThreads;
+    uint64_t longest = 0;   // max_out != nullptr: the longest record goes there (slot tables of the one-pass writer below)
     for (uint64_t i = (uint64_t)blockIdx.x * kMatThreads + threadIdx.x; i < n; i += stride) {
         uint64_t total = (uint64_t)(ncols - 1) + mode.newline;   // commas + '\n'
         uint32_t flags = 0;
@@ -292,6 +298,11 @@ __global__ __launch_bounds__(kMatThreads) void k_csv_lens(ColsArg cols, ColIds i
         }
         lens[i] = total;
         qflags[i] = (uint16_t)flags;
+        longest = total > longest ? total : longest;
+    }
+    if (max_out) {   // (uniform) one atomic per wave at most, and only while it still raises the value
+        longest = wave_max(longest);
+        if (lane_id() == 0 && longest > __hip_atomic_load(max_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_out, (unsigned long long)longest);
     }
 }
 
@@ -487,7 +498,7 @@ static Status csv_render(cph_ctx* ctx, const ColsArg& arg, const ColIds& ids_in,
         {
             ProfScope ps(ctx, mode.newline ? "k_csv_lens" : "k_csv_lens(fragments)", 0);
             CPH_CSV_DISPATCH(k_csv_lens, ncols, dim3(grid_rows(n)), 0, ctx->stream, arg, ids, ncols, mode, n, offs_out->as<uint64_t>(),
-                             qflags.as<uint16_t>());
+                             qflags.as<uint16_t>(), (unsigned long long*)nullptr);
         }
         CPH_HIP_TRY(hipGetLastError());
         CPH_TRY(scan_lengths(ctx, offs_out->as<uint64_t>(), n, &total));
@@ -502,6 +513,495 @@ static Status csv_render(cph_ctx* ctx, const ColsArg& arg, const ColIds& ids_in,
         CPH_HIP_TRY(hipGetLastError());
     }
     *total_out = total;
+    return {};
+}
+
+
+// ---- (round 6) ToCsv in ONE pass over the joined rows ---------------------------------------------------------------------------
+// The two passes above fetch everything twice, and what a joined row costs is its random fetches: the row of a build table is one
+// 64-byte fabric sector for its offsets in the length pass and one or two for its bytes in the copy pass.  Here
+//   * every group of adjacent columns that comes from one table through one row-id array (mergeRows :571-583: the fields a Join
+//     appended) is rendered ONCE per table row into a SLOT table — [length byte][CSV text of the fields, quoted as the Writer
+//     would] at a power-of-two stride of 16..128 bytes — so that an output row takes ONE aligned fetch per table (k_csv_slots);
+//   * k_csv_onepass reads a tile's row ids, slots and stream values once, knows the tile's bytes, learns where they go from a
+//     DECOUPLED LOOK-BACK over the tiles in front of it (no length array, no scan, no second visit) and streams the tile out of
+//     LDS.  The grid is persistent — as many workgroups as are resident together, tile = blockIdx + k * gridDim — so every
+//     lower tile belongs to a running workgroup without a ticket counter (a device-wide atomic sustains ~88 tickets per us,
+//     chain.hip), and all 256 threads look back, one predecessor each: the window must cover the tiles that publish their
+//     size while one look-back is in flight (~100 at 65 tiles / us).
+// The output size is not known before the launch: the buffer is sized from the slot tables' longest entries (exact bound) and
+// the stream columns' byte counts (+ 1/8 for quotes); a tile that would cross the end raises `overflow` and the two-pass
+// writer above renders the text instead (as it does for everything this path does not take: > 8 output columns, fragments
+// beyond 127 bytes, records beyond ~140 bytes on average).  Same bytes either way (tests/test_materialize.py).
+constexpr int kOpThreads = 256;
+constexpr int kOpStage   = 20 * 1024;     // a 256-record tile of ~45-byte records is 11.4 KB; + 2 KB per wave and slot column for the gathers
+constexpr int kOpMaxCols = 8;
+constexpr uint64_t kOpAgg = 1ull << 62, kOpIncl = 2ull << 62, kOpValue = (1ull << 62) - 1;
+typedef unsigned int op_u32x4 __attribute__((ext_vector_type(4)));
+
+struct OpCol {
+    DevCol col;                      // slots == nullptr: the column itself, every value quoted as the Writer decides
+    const uint8_t* slots = nullptr;  // else: one rendered fragment per TABLE row, stride 1 << lg
+    uint32_t lg = 0;
+    RowIds ids;                      // the table row that feeds output row i (ptr == nullptr: row i)
+};
+struct OpArgs {
+    OpCol c[kOpMaxCols];
+};
+struct OpReport {
+    unsigned long long total;        // bytes of all the records
+    unsigned int overflow;           // a tile did not fit the buffer (or a value of >= 4 GiB): nothing usable was written
+    unsigned int pad;
+};
+
+// bytes of every plain column (thread c: column c), for the size of the output buffer
+__global__ void k_csv_col_bytes(OpArgs a, int nf, unsigned long long* __restrict__ out) {
+    const int c = (int)threadIdx.x;
+    if (c >= nf || a.c[c].slots) return;
+    const DevCol& col = a.c[c].col;
+    out[c] = col.fixed_width ? col.nrows * (uint64_t)col.fixed_width
+                             : (col.nrows ? load_offset(col.offsets, col.offset_bits, col.nrows) - load_offset(col.offsets, col.offset_bits, 0) : 0);
+}
+
+// slot i = [lens[i] as one byte][the record of table row i, no newline][zeros]
+template <int NC>
+__global__ __launch_bounds__(kMatThreads) void k_csv_slots(ColsArg cols, int ncols, uint64_t n, const uint64_t* __restrict__ lens,
+                                                          const uint16_t* __restrict__ qflags, uint32_t lg, uint8_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    CPH_LDS uint8_t* stage = (CPH_LDS uint8_t*)smem;
+    const uint32_t rows_per_tile = (8192u >> lg) < (uint32_t)kMatThreads ? (8192u >> lg) : (uint32_t)kMatThreads;
+    const ColIds own{};   // every column's own rows
+    for (uint64_t t0 = (uint64_t)blockIdx.x * rows_per_tile; t0 < n; t0 += (uint64_t)gridDim.x * rows_per_tile) {
+        const uint32_t rows = n - t0 < rows_per_tile ? (uint32_t)(n - t0) : rows_per_tile;
+        stage_clear(stage, (uint64_t)rows << lg);
+        __syncthreads();
+        if (threadIdx.x < rows) {
+            const uint64_t i = t0 + threadIdx.x;
+            WordSink s(reinterpret_cast<uint32_t*>(smem), threadIdx.x << lg);
+            s.put((uint8_t)lens[i]);
+            csv_put_record<NC>(s, cols, own, ncols, CsvMode{0, 0}, i, qflags[i]);
+            s.finish();
+        }
+        lds_atomics_barrier();
+        op_u32x4* dst = reinterpret_cast<op_u32x4*>(out + (t0 << lg));   // pool blocks and strides are multiples of 16
+        const CPH_LDS op_u32x4* src = (const CPH_LDS op_u32x4*)stage;
+        for (uint32_t w = threadIdx.x; w < (rows << lg) >> 4; w += blockDim.x) dst[w] = src[w];
+        __syncthreads();
+    }
+}
+
+// the text of a slot whose first 32 bytes are in registers (q1 = 0 for a 16-byte stride); text beyond them is fetched
+template <class Sink>
+__device__ __forceinline__ void csv_put_slot(Sink& s, const uint8_t* slots, uint64_t slot_off, uint32_t fl, op_u32x4 q0, op_u32x4 q1) {
+    const uint64_t w0 = q0.x | (uint64_t)q0.y << 32, w1 = q0.z | (uint64_t)q0.w << 32;
+    const uint64_t w2 = q1.x | (uint64_t)q1.y << 32, w3 = q1.z | (uint64_t)q1.w << 32;
+    if (fl > 0) s.put8((w0 >> 8) | (w1 << 56), fl < 8u ? fl : 8u);
+    if (fl > 8) s.put8((w1 >> 8) | (w2 << 56), fl - 8u < 8u ? fl - 8u : 8u);
+    if (fl > 16) s.put8((w2 >> 8) | (w3 << 56), fl - 16u < 8u ? fl - 16u : 8u);
+    if (fl > 24) s.put8(fl <= 31u ? (w3 >> 8) : load_value_chunk(slots, slot_off + 1, fl, 3), fl - 24u < 8u ? fl - 24u : 8u);
+    for (uint32_t q = 32; q < fl; q += 8) s.put8(load_value_chunk(slots, slot_off + 1, fl, (int)(q >> 3)), fl - q < 8u ? fl - q : 8u);
+}
+
+// a tile's staged bytes [0, span) to out + obase: 16-byte words out of LDS, stored wherever obase falls (global stores take any
+// byte address; only the two lines at a tile's ends are written in part)
+__device__ __forceinline__ void flush_stage_unaligned(const CPH_LDS uint8_t* stage, uint8_t* out, uint64_t obase, uint64_t span) {
+    typedef op_u32x4 __attribute__((aligned(1))) u32x4_unaligned;
+    const CPH_LDS op_u32x4* src = (const CPH_LDS op_u32x4*)stage;
+    const uint32_t nwords = (uint32_t)(span >> 4);
+    for (uint32_t w = threadIdx.x; w < nwords; w += blockDim.x) *reinterpret_cast<u32x4_unaligned*>(out + obase + 16ull * w) = src[w];
+    for (uint32_t g = (nwords << 4) + threadIdx.x; g < (uint32_t)span; g += blockDim.x) out[obase + g] = stage[g];
+}
+
+// 16 bytes per lane from global memory straight into LDS (gfx950 LDS-DMA): lane i's bytes land at dst + 16 i (dst wave-uniform);
+// no destination registers, so a wave keeps as many gathers in flight as it likes
+__device__ __forceinline__ void dma16(const uint8_t* src, CPH_LDS uint8_t* dst) {
+    typedef const __attribute__((address_space(1))) void* gptr;
+    __builtin_amdgcn_global_load_lds((gptr)(uintptr_t)src, (CPH_LDS void*)dst, 16, 0, 0);
+}
+constexpr int kOpLand = 2048;   // LDS bytes per wave and slot column: 64 lanes x the slot's first 16 bytes, then x its second 16
+
+// A workgroup's loop over its tiles T, T + grid, ... (a tile = 256 records, one per thread):
+//   T's slots have landed in LDS (LDS-DMA gathers, no registers) -> lengths (slot length bytes out of LDS) -> workgroup scan -> T's
+//   size published -> row ids of the NEXT tile requested -> T's records assembled in the LDS stage -> the next tile's gathers and
+//   offsets issued (the wave has read its landing zone) -> look-back for T's place, the gathers in flight meanwhile -> T streamed
+//   out -> the next tile's plain first chunks requested.
+// A tile beyond the LDS stage keeps its landing zone through the look-back and writes its records to global memory itself.
+// Measured and not kept (profiles/r06_tocsv.txt): row ids two tiles ahead, double landing zones, one memory wait per iteration —
+// every deeper pipeline needs more registers than three workgroups per CU leave (168), and spills or a lower occupancy cost more
+// than the exposed round trips.
+// MASK >= 0: bit c = column c is a slot column, known at compile time (<= 4 output columns: half the registers per column, no code
+// for the other kind); MASK < 0: read from the arguments.
+#define CPH_OP_SLOT(c) (MASK < 0 ? a.c[c].slots != nullptr : ((MASK >> (c)) & 1) != 0)
+template <int NC, int MASK>
+__global__ __launch_bounds__(kOpThreads, NC <= 2 ? 4 : NC <= 4 ? 3 : 2) void k_csv_onepass(OpArgs a, uint32_t nslot, uint64_t n, uint32_t ntiles,
+                                                           unsigned long long* __restrict__ state, uint8_t* __restrict__ out,
+                                                           uint64_t out_base, uint64_t cap, OpReport* __restrict__ rep, uint32_t dbg) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    CPH_LDS uint8_t* stage = (CPH_LDS uint8_t*)smem;
+    constexpr int kWaves = kOpThreads / kWave;
+    __shared__ uint64_t s_scan[kWaves + 1];
+    __shared__ uint64_t s_lb_sum[kWaves];
+    __shared__ uint32_t s_lb_hit[kWaves];
+    const int lane = lane_id(), wave = wave_id();
+    CPH_LDS uint8_t* const land = stage + kOpStage + (uint32_t)wave * nslot * kOpLand;   // this wave's landing zone: kOpLand bytes per slot column
+    uint32_t srow[NC];                                  // slot columns: the table row (text beyond a slot's first 32 bytes is fetched)
+    uint64_t vb[NC], vc[NC];                            // plain columns: begin, first chunk
+    uint32_t vl[NC];                                    //                length
+    uint32_t idn[NC];                                   // row ids of the next tile
+    bool huge = false;
+
+    // the record a thread handles in a tile (threads past the tile's end re-read its last record, never written: no load behind a branch)
+    auto record_of = [&](uint32_t tile) {
+        const uint64_t t0 = (uint64_t)tile * kOpThreads, tend = t0 + kOpThreads < n ? t0 + kOpThreads : n;
+        const uint64_t i = t0 + threadIdx.x;
+        return i < tend ? i : tend - 1;
+    };
+    // the table rows that feed a tile's records; 32 bits: a table has fewer than 2^32 rows
+    auto ids_of = [&](uint32_t tile, uint32_t (&id)[NC]) {
+        const uint64_t i = record_of(tile);
+#pragma unroll
+        for (int c = 0; c < NC; c++) id[c] = (CPH_OP_SLOT(c) || a.c[c].ids.ptr) ? (uint32_t)source_row(a.c[c].ids, i) : 0u;
+        if (dbg & 8u) {   // (measurement only) every gather from the table's first 64 Ki rows: cache hits
+#pragma unroll
+            for (int c = 0; c < NC; c++) id[c] &= 0xFFFFu;
+        }
+    };
+    // slot columns: gathers into the landing zone; plain columns: offsets.
+    // A slot of 32 bytes and more is fetched by a PAIR of lanes — lane 2p the first, lane 2p + 1 the second 16 bytes of the slot
+    // of record 32 u + p — in two instructions u = 0, 1: the two halves share a 64-byte sector and travel as one request.
+    // Either way record r's slot image lies at zone + 32 r (16-byte slots: + 16 r).
+    auto gather = [&](uint32_t tile, const uint32_t (&id)[NC]) {
+        const uint64_t i = record_of(tile);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's reads of the landing zone are done
+        uint32_t cs = 0;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const uint64_t row = (CPH_OP_SLOT(c) || a.c[c].ids.ptr) ? (uint64_t)id[c] : i;
+            if (CPH_OP_SLOT(c)) {   // uniform
+                srow[c] = (uint32_t)row;
+                CPH_LDS uint8_t* zone = land + cs * kOpLand;
+                if (a.c[c].lg >= 5) {
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const uint64_t r = (uint64_t)(uint32_t)__shfl((int)(uint32_t)row, u * 32 + (lane >> 1), kWave);
+                        dma16(a.c[c].slots + (r << a.c[c].lg) + (lane & 1) * 16, zone + u * 1024);
+                    }
+                } else {
+                    dma16(a.c[c].slots + (row << 4), zone);
+                }
+                cs++;
+            } else {
+                uint64_t b, l;
+                value_span(a.c[c].col, row, &b, &l);
+                huge |= l > 0xFFFFFFFFull;
+                vb[c] = b;
+                vl[c] = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;
+            }
+        }
+    };
+    auto chunks = [&]() {
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+            if (!CPH_OP_SLOT(c)) vc[c] = first_chunk_nobranch(a.c[c].col, vb[c], vl[c]);
+    };
+    auto emit = [&](auto& s, uint32_t flags) {
+        uint32_t cs = 0;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            if (c) s.put(',');
+            if (CPH_OP_SLOT(c)) {
+                const CPH_LDS uint8_t* img = land + cs * kOpLand + (a.c[c].lg >= 5 ? lane * 32 : lane * 16);
+                const op_u32x4 q0 = *(const CPH_LDS op_u32x4*)img;
+                const op_u32x4 q1 = a.c[c].lg >= 5 ? *(const CPH_LDS op_u32x4*)(img + 16) : op_u32x4{0, 0, 0, 0};
+                csv_put_slot(s, a.c[c].slots, (uint64_t)srow[c] << a.c[c].lg, q0.x & 0xFFu, q0, q1);
+                cs++;
+            } else {
+                csv_put_field_words(s, a.c[c].col, vb[c], vl[c], vc[c], (flags >> c) & 1u);
+            }
+        }
+        s.put('\n');
+    };
+
+    if (blockIdx.x < ntiles) {
+        ids_of(blockIdx.x, idn);
+        gather(blockIdx.x, idn);
+        chunks();
+    }
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t t0 = (uint64_t)tile * kOpThreads;
+        const uint64_t tend = t0 + kOpThreads < n ? t0 + kOpThreads : n;
+        const uint32_t next = tile + gridDim.x;
+        const bool has_next = next < ntiles;   // uniform
+        if (huge) atomicOr(&rep->overflow, 1u);   // (never, in practice: a single value of 4 GiB)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the gathers have landed
+        // the record's length (and which plain fields are quoted)
+        uint64_t len = NC;   // NC - 1 commas + '\n'
+        uint32_t flags = 0;
+        {
+            uint32_t cs = 0;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                if (CPH_OP_SLOT(c)) {
+                    len += *(const CPH_LDS uint8_t*)(land + cs * kOpLand + (a.c[c].lg >= 5 ? lane * 32 : lane * 16));
+                    cs++;
+                } else {
+                    bool q = false;
+                    len += csv_field_len(a.c[c].col, vb[c], vl[c], vc[c], &q);
+                    flags |= (uint32_t)q << c;
+                }
+            }
+        }
+        if (t0 + threadIdx.x >= tend) len = 0;
+        uint64_t total = 0;
+        const uint64_t pos = block_exclusive_sum<uint64_t, kOpThreads>(len, s_scan, &total);
+        // the tile's size is published before its look-back starts: the tiles behind it only need that to move on
+        if (threadIdx.x == 0)
+            __hip_atomic_store(&state[tile], (tile == 0 ? kOpIncl : kOpAgg) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool staged = total + 48 <= (uint64_t)kOpStage;   // uniform
+        if (has_next && staged) ids_of(next, idn);
+        if (staged) {
+            if (!(dbg & 2u)) {
+                stage_clear(stage, total);
+                __syncthreads();
+                if (len) {
+                    WordSink s(reinterpret_cast<uint32_t*>(smem), (uint32_t)pos);
+                    emit(s, flags);
+                    s.finish();
+                }
+            }
+            if (has_next) gather(next, idn);   // the next tile's gathers fly during the look-back
+            lds_atomics_barrier();
+        }
+        uint64_t excl = 0;
+        if (dbg & 1u) excl = t0 * 44;   // (measurement only) no look-back: a made-up place
+        // Look-back: a round covers `width` predecessors, one per thread, nearest first; it ends at the nearest tile that knows its
+        // inclusive prefix.  The first round is wave 0 alone (64 tiles: every state word read is an L2 request, 195 k tiles x 512
+        // words cost 0.2 ms more than x 64), the following ones take all 256 threads.
+        bool found = (dbg & 1u) != 0;
+        int64_t hi = (int64_t)tile - 1;
+        for (uint32_t width = kWave; !found && hi >= 0; hi -= width, width = kOpThreads) {   // uniform
+            unsigned long long w = kOpAgg;   // (threads beyond the round's width: nothing)
+            if (threadIdx.x < width) {
+                const int64_t j = hi - (int64_t)threadIdx.x;
+                w = kOpIncl;   // in front of tile 0: an inclusive prefix of 0
+                if (j >= 0) {
+                    w = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    while ((w >> 62) == 0) {
+                        __builtin_amdgcn_s_sleep(1);
+                        w = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            const uint64_t incl = __ballot((w >> 62) == 2);
+            const int stop = incl ? __builtin_ctzll(incl) : kWave;   // lanes 0..stop count (stop == 64: all of them)
+            const uint64_t part = wave_sum<uint64_t>(lane <= stop ? (uint64_t)(w & kOpValue) : 0ull);
+            if (lane == 0) {
+                s_lb_sum[wave] = part;
+                s_lb_hit[wave] = incl != 0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int v = 0; v < kWaves; v++)
+                if (!found) {
+                    excl += s_lb_sum[v];
+                    found = s_lb_hit[v] != 0;
+                }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            if (tile != 0) __hip_atomic_store(&state[tile], kOpIncl | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tile + 1 == ntiles) rep->total = excl + total;
+            if (excl + total > cap) atomicOr(&rep->overflow, 1u);
+        }
+        const bool fits = excl + total <= cap;   // uniform
+        if (staged) {
+            if (fits && !(dbg & 2u)) flush_stage_unaligned(stage, out, out_base + excl, total);
+            __syncthreads();
+        } else {
+            if (fits && len && !(dbg & 2u)) {
+                GlobalSink s{out + out_base + excl + pos};
+                emit(s, flags);
+            }
+            if (has_next) {
+                ids_of(next, idn);
+                gather(next, idn);
+            }
+        }
+        if (has_next) chunks();
+    }
+}
+
+#undef CPH_OP_SLOT
+
+struct OpLaunch {
+    cph_ctx* ctx;
+    OpArgs oa;
+    int nslot, cus, max_grid;
+    size_t lds;
+    uint64_t n, ntiles, head_bytes, cap;
+    unsigned long long* state;
+    uint8_t* out;
+    OpReport* rep;
+};
+template <int NC, int MASK>
+static Status op_launch(const OpLaunch& L) {
+    auto kern = &k_csv_onepass<NC, MASK>;
+    int per_cu = 0;
+    CPH_TRY(kernel_setup(L.ctx, reinterpret_cast<const void*>(kern), kOpThreads, L.lds, &per_cu));
+    uint64_t grid = (uint64_t)L.cus * (uint64_t)per_cu;   // persistent: every workgroup resident (the look-back waits on lower tiles)
+    if (L.max_grid > 0 && grid > (uint64_t)L.max_grid) grid = (uint64_t)L.max_grid;
+    if (grid > L.ntiles) grid = L.ntiles;
+    ProfScope ps(L.ctx, "k_csv_onepass", 0);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kOpThreads), L.lds, L.ctx->stream, L.oa, (uint32_t)L.nslot, L.n, (uint32_t)L.ntiles,
+                       L.state, L.out, L.head_bytes, L.cap, L.rep, (uint32_t)L.ctx->csv_onepass_debug);
+    return {};
+}
+// <= 4 output columns: one kernel per (column count, which columns are slot columns)
+template <int NC>
+static Status op_launch_masked(const OpLaunch& L, int mask) {
+#define CPH_OP_MASK(M)                                           \
+    case M:                                                      \
+        if constexpr ((M) < (1 << NC)) return op_launch<NC, M>(L); \
+        break;
+    switch (mask) {
+        CPH_OP_MASK(0) CPH_OP_MASK(1) CPH_OP_MASK(2) CPH_OP_MASK(3) CPH_OP_MASK(4) CPH_OP_MASK(5) CPH_OP_MASK(6) CPH_OP_MASK(7)
+        CPH_OP_MASK(8) CPH_OP_MASK(9) CPH_OP_MASK(10) CPH_OP_MASK(11) CPH_OP_MASK(12) CPH_OP_MASK(13) CPH_OP_MASK(14) CPH_OP_MASK(15)
+    }
+#undef CPH_OP_MASK
+    return {CPH_ERR_INVALID, "csv_onepass: no kernel for this shape"};
+}
+
+// ToCsv over n joined rows in one pass (see above).  *done = false: nothing was produced (this path does not take the shape, or
+// its buffer estimate was too small) and the caller renders the text with the two-pass writer.
+// max_grid: 0, or the most workgroups to launch (tests: several tiles per workgroup on small inputs).
+static Status csv_onepass(cph_ctx* ctx, const ColsArg& arg, const ColIds& ids, int ncols, uint64_t n, uint64_t head_bytes, int max_grid,
+                          DevBuf* data_out, uint64_t* total_out, bool* done) {
+    *done = false;
+    if (n == 0 || n >= (1ull << 40)) return {};
+    // adjacent columns of one table through one row-id array: one slot table; everything else as it is
+    struct Group { int first, count; bool slot; };
+    std::vector<Group> groups;
+    for (int c = 0; c < ncols;) {
+        int e = c + 1;
+        const bool table = ids.ids[c].ptr && arg.c[c].nrows <= n && arg.c[c].nrows > 0;
+        while (table && e < ncols && e - c < 8 && ids.ids[e].ptr == ids.ids[c].ptr && ids.ids[e].bits == ids.ids[c].bits &&
+               ids.ids[e].base == ids.ids[c].base && arg.c[e].nrows == arg.c[c].nrows)
+            e++;
+        groups.push_back({c, e - c, table});
+        c = e;
+    }
+    const int nf = (int)groups.size();
+    if (nf > kOpMaxCols) return {};
+    int cus = 0;
+    CPH_TRY(device_cus(ctx, &cus));
+    OpArgs oa{};
+    DevBuf words;   // per output column: the longest fragment (slot groups) or the column's bytes (plain columns)
+    CPH_TRY(words.alloc(&ctx->pool, kOpMaxCols * sizeof(unsigned long long)));
+    CPH_HIP_TRY(hipMemsetAsync(words.get(), 0, kOpMaxCols * sizeof(unsigned long long), ctx->stream));
+    std::vector<DevBuf> lens(nf), qflags(nf), slots(nf);
+    const ColIds own{};              // every column's own rows
+    const CsvMode frag_mode{0, 0};   // fragments: every field quoted as needed, no newline
+    for (int g = 0; g < nf; g++) {
+        const Group& G = groups[g];
+        oa.c[g].ids = ids.ids[G.first];
+        oa.c[g].ids.stash = nullptr;
+        if (!G.slot) {
+            oa.c[g].col = arg.c[G.first];
+            if (oa.c[g].col.split || oa.c[g].col.segmented()) return {};   // (never: such columns only exist inside the key codec)
+            continue;
+        }
+        const uint64_t nt = arg.c[G.first].nrows;
+        ColsArg garg{};
+        for (int k = 0; k < G.count; k++) garg.c[k] = arg.c[G.first + k];
+        CPH_TRY(lens[g].alloc(&ctx->pool, nt * sizeof(uint64_t)));
+        CPH_TRY(qflags[g].alloc(&ctx->pool, nt * sizeof(uint16_t)));
+        ProfScope ps(ctx, "k_csv_lens(fragments)", 0);
+        CPH_CSV_DISPATCH(k_csv_lens, G.count, dim3(grid_rows(nt)), 0, ctx->stream, garg, own, G.count, frag_mode, nt,
+                         lens[g].as<uint64_t>(), qflags[g].as<uint16_t>(), words.as<unsigned long long>() + g);
+        CPH_HIP_TRY(hipGetLastError());
+        oa.c[g].slots = reinterpret_cast<const uint8_t*>(1);   // "a slot column" for k_csv_col_bytes; the table follows below
+    }
+    hipLaunchKernelGGL(k_csv_col_bytes, dim3(1), dim3(64), 0, ctx->stream, oa, nf, words.as<unsigned long long>());
+    CPH_HIP_TRY(hipGetLastError());
+    CPH_TRY(ensure_pinned_scratch(ctx, kOpMaxCols * sizeof(unsigned long long)));
+    CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, words.get(), kOpMaxCols * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    uint64_t w[kOpMaxCols];
+    memcpy(w, ctx->pinned_scratch, sizeof w);
+    // the buffer: exact bound for the slot columns, the plain columns' bytes + 1/8 for quotes
+    uint64_t cap = n * (uint64_t)nf;   // commas + newlines
+    uint64_t slack = 0;
+    for (int g = 0; g < nf; g++) {
+        const Group& G = groups[g];
+        if (G.slot) {
+            if (w[g] > 127) return {};
+            uint32_t lg = 4;
+            while ((1ull << lg) < w[g] + 1) lg++;
+            oa.c[g].lg = lg;
+            cap += n * w[g];
+        } else if (!oa.c[g].ids.ptr) {
+            cap += w[g] + w[g] / 8;
+            slack += 4096;
+        } else {   // a column gathered from a table larger than the output: its mean value, + 1/4
+            const uint64_t nt = arg.c[G.first].nrows ? arg.c[G.first].nrows : 1;
+            const double est = (double)w[g] / (double)nt * (double)n * 1.25;
+            cap += (uint64_t)est;
+            slack += 4096;
+        }
+    }
+    if (cap / n > 72) return {};   // a 256-record tile should fit the LDS stage
+    cap += slack;
+    for (int g = 0; g < nf; g++) {
+        const Group& G = groups[g];
+        if (!G.slot) continue;
+        const uint64_t nt = arg.c[G.first].nrows;
+        ColsArg garg{};
+        for (int k = 0; k < G.count; k++) garg.c[k] = arg.c[G.first + k];
+        CPH_TRY(slots[g].alloc(&ctx->pool, (nt << oa.c[g].lg) + 64));
+        oa.c[g].slots = slots[g].as<uint8_t>();
+        const uint32_t rows_per_tile = (8192u >> oa.c[g].lg) < (uint32_t)kMatThreads ? (8192u >> oa.c[g].lg) : (uint32_t)kMatThreads;
+        uint64_t blocks = (nt + rows_per_tile - 1) / rows_per_tile;
+        if (blocks > 8192) blocks = 8192;
+        ProfScope ps(ctx, "k_csv_slots", 0);
+        CPH_CSV_DISPATCH(k_csv_slots, G.count, dim3((unsigned)blocks), kMatStage, ctx->stream, garg, G.count, nt, lens[g].as<uint64_t>(),
+                         qflags[g].as<uint16_t>(), oa.c[g].lg, slots[g].as<uint8_t>());
+        CPH_HIP_TRY(hipGetLastError());
+    }
+    CPH_TRY(data_out->alloc(&ctx->pool, head_bytes + cap + 64));
+    int nslot = 0;
+    for (int g = 0; g < nf; g++) nslot += groups[g].slot ? 1 : 0;
+    const size_t lds = (size_t)kOpStage + (size_t)(kOpThreads / kWave) * (size_t)nslot * kOpLand;   // stage + a landing zone per wave
+    const uint64_t ntiles = (n + kOpThreads - 1) / kOpThreads;
+    DevBuf state;
+    CPH_TRY(state.alloc(&ctx->pool, ntiles * sizeof(unsigned long long) + sizeof(OpReport)));
+    CPH_HIP_TRY(hipMemsetAsync(state.get(), 0, ntiles * sizeof(unsigned long long) + sizeof(OpReport), ctx->stream));
+    OpReport* rep = reinterpret_cast<OpReport*>(state.as<unsigned long long>() + ntiles);
+    OpLaunch L{ctx, oa, nslot, cus, max_grid, lds, n, ntiles, head_bytes, cap, state.as<unsigned long long>(), data_out->as<uint8_t>(), rep};
+    int mask = 0;
+    for (int g = 0; g < nf; g++) mask |= groups[g].slot ? 1 << g : 0;
+    switch (nf) {
+        case 1: CPH_TRY(op_launch_masked<1>(L, mask)); break;
+        case 2: CPH_TRY(op_launch_masked<2>(L, mask)); break;
+        case 3: CPH_TRY(op_launch_masked<3>(L, mask)); break;
+        case 4: CPH_TRY(op_launch_masked<4>(L, mask)); break;
+        case 5: CPH_TRY((op_launch<5, -1>(L))); break;
+        case 6: CPH_TRY((op_launch<6, -1>(L))); break;
+        case 7: CPH_TRY((op_launch<7, -1>(L))); break;
+        case 8: CPH_TRY((op_launch<8, -1>(L))); break;
+        default: return {CPH_ERR_INVALID, "csv_onepass: no kernel for this shape"};
+    }
+    CPH_HIP_TRY(hipGetLastError());
+    CPH_TRY(ensure_pinned_scratch(ctx, sizeof(OpReport)));
+    CPH_HIP_TRY(hipMemcpyAsync(ctx->pinned_scratch, rep, sizeof(OpReport), hipMemcpyDeviceToHost, ctx->stream));
+    CPH_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    OpReport r;
+    memcpy(&r, ctx->pinned_scratch, sizeof r);
+    if (r.overflow) {
+        data_out->reset();
+        return {};
+    }
+    *total_out = r.total;
+    *done = true;
     return {};
 }
 
@@ -691,6 +1191,11 @@ CPH_API int32_t cph_csv_write_rows(cph_ctx* ctx, const cph_strcol* cols, const c
                 }
             }
         }
+        uint64_t total = 0;
+        bool one_pass = false;   // (round 6) one pass over the joined rows; whatever it does not take goes through the two passes below
+        if (ctx->csv_onepass && n >= (ctx->csv_onepass > 1 ? 1u : 4096u))
+            CPH_TRY(csv_onepass(ctx, arg, ids, ncols, n, head.size(), ctx->csv_onepass > 1 ? ctx->csv_onepass : 0, &r->d_data, &total, &one_pass));
+        if (!one_pass) {
         // Columns that come from the same table through the same row ids, next to each other in the output, and
         // from a table much smaller than the output (every table row is used several times): render the fragment
         // "f1,f2,.." of each TABLE row once, then copy fragments.  The random fetches per output row drop from
@@ -732,8 +1237,8 @@ CPH_API int32_t cph_csv_write_rows(cph_ctx* ctx, const cph_strcol* cols, const c
             c = e;
         }
         DevBuf offs;
-        uint64_t total = 0;
         CPH_TRY(csv_render(ctx, farg, fids, nf, fmode, n, head.size(), &offs, &r->d_data, &total, fbytes));
+        }
         const uint64_t size = head.size() + total;
         if (!head.empty()) {
             void* slot = nullptr;

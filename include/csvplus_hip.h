@@ -180,6 +180,16 @@ CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
  *   "csv_fast"      0 / 1 (default 1): cph_csv_parse first tries byte-parallel passes over 16 KiB text tiles (texts without any quote,
  *                   no TrimLeadingSpace, <= 8 columns, < 4 GiB, no blank / comment line inside, records that end within 4 KiB of their
  *                   tile); anything else — and every error — goes through the record-parallel kernels.  Same columns either way
+ *   "csv_onepass"   0 / 1 / N (default 1): cph_csv_write[_rows] over >= 4096 rows renders the text in ONE pass over the joined rows: every
+ *                   group of adjacent columns gathered from one table (<= the output's rows) through one row-id array is rendered once per
+ *                   table row into a slot table ([length][CSV text], stride 16..128 bytes: one aligned fetch per output row and table),
+ *                   a tile of 256 / 512 records learns its place in the text from a decoupled look-back over the tiles before it
+ *                   (persistent grid, no length array, no scan) and leaves through LDS.  Not taken (-> the two-pass writer, same bytes):
+ *                   more than 8 output columns after grouping, a fragment beyond 127 bytes, records beyond ~140 bytes on average, a
+ *                   buffer estimate (stream columns' bytes + 1/8 for quotes) that a tile overruns.  0: always the two passes; N > 1: the
+ *                   one pass whatever the row count, with at most N workgroups (tests)
+ *   "csv_onepass_debug" bits (default 0; measurement only, the text is wrong when set): 1 = no look-back, 2 = no record bytes, 4 = one
+ *                   record per thread
  *   "direct_sort"   0 / 1 (default 1): a build that expects distinct keys (cph_index_build with unique = 1, cph_index_spec.unique) over a
  *                   dense 32-bit code space (rows <= code states <= 2 rows: decimal ids, row numbers) sorts without radix passes: the rows
  *                   are split by the top bits of their codes into 2^14-slot windows, every window is filled in LDS (slot = code) and

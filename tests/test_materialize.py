@@ -151,3 +151,139 @@ def test_csv_write_many_tiles_and_oversized_records(ctx):
     want = orc.csv_write([s, StrCol.from_values([small[int(i)] for i in ia]), StrCol.from_values([nums[int(i)] for i in ib]), s],
                          ["s", "a", "b", "s2"])
     assert csv_write(ctx, [s, a, b, s], ["s", "a", "b", "s2"], row_ids=[None, ia, ib, None]) == want
+
+
+# ---- (round 6) the one-pass writer: slot tables + decoupled look-back (materialize.hip: k_csv_onepass) -----------------------------
+def _write_with(ctx, mode, *args, **kw):
+    """csv_write under ctx option csv_onepass = mode; returns (text, names of the kernels that ran)."""
+    from csvplus_amd.materialize import csv_write
+    ctx.set_option("csv_onepass", mode)
+    ctx.profile(True); ctx.profile_read(reset=True)
+    try:
+        text = csv_write(ctx, *args, **kw)
+        return text, set(ctx.profile_read(reset=True))
+    finally:
+        ctx.profile(False)
+        ctx.set_option("csv_onepass", 1)
+
+
+def _rand_values(rng, count, lo, hi, alphabet=b'ab ,"\n\rz#\t0123456789'):
+    al = np.frombuffer(alphabet, dtype=np.uint8)
+    return [al[rng.integers(0, len(al), int(rng.integers(lo, hi + 1)))].tobytes() for _ in range(count)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 255, 256, 257, 511, 512, 513, 1024, 5000, 70_000])
+@pytest.mark.parametrize("grid", [2, 3, 1 << 20])
+def test_onepass_writer_equals_oracle_and_two_pass(ctx, n, grid):
+    """Stream columns (every quoting rule), a two-column group and a one-column group gathered from small tables (slot strides 32
+    and 16), 32- and 64-bit row ids with a base — through 2, 3 and all resident workgroups (several tiles per workgroup, look-back
+    across them), against the oracle and the two-pass writer."""
+    rng = np.random.default_rng(n * 7 + grid % 5)
+    s1 = StrCol.from_values([NASTY[i] if len(NASTY[i]) < 50 else b"x" for i in rng.integers(0, len(NASTY), n)])
+    s2 = StrCol.from_values([b"%d" % i for i in rng.integers(0, 1000, n)])
+    ta, tb = _rand_values(rng, 300, 0, 9), _rand_values(rng, 300, 0, 4)   # one table, two columns: fragments up to 9 + 1 + 4 (+ quotes)
+    tc = [b"%d" % (i * 7) for i in range(40)]
+    A, B, Cc = StrCol.from_values(ta), StrCol.from_values(tb), StrCol.from_values(tc)
+    ia = rng.integers(0, 300, n).astype(np.uint32)
+    ic = (rng.integers(0, 40, n) + 500).astype(np.uint64)
+    cols, hdr = [s1, A, B, s2, Cc], ["s1", "a", "b", "s2", "c"]
+    want = orc.csv_write([s1, StrCol.from_values([ta[i] for i in ia]), StrCol.from_values([tb[i] for i in ia]), s2,
+                          StrCol.from_values([tc[int(i) - 500] for i in ic])], hdr)
+    from csvplus_amd.materialize import csv_write
+    ids = [None, ia, ia, None, ic - 500]
+    got, ran = _write_with(ctx, grid, cols, hdr, row_ids=ids)
+    assert got == want
+    assert "k_csv_onepass" in ran and ("k_csv_slots" in ran) == (n >= 40) and "k_csv_copy" not in ran, sorted(ran)
+    two, ran0 = _write_with(ctx, 0, cols, hdr, row_ids=ids)
+    assert two == want and "k_csv_onepass" not in ran0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("maxlen,stride_ok", [(14, True), (15, True), (16, True), (31, True), (32, True), (63, True), (64, True), (127, False), (128, False)])
+def test_onepass_slot_strides(ctx, maxlen, stride_ok):
+    """Fragments of every length up to maxlen: strides 16 / 32 / 64 / 128 (the text beyond a slot's first 32 bytes is fetched, not
+    held); records beyond ~72 bytes by the estimate (a 256-record tile would not fit its LDS stage) and fragments beyond 127 bytes
+    leave the call to the two-pass writer."""
+    rng = np.random.default_rng(maxlen)
+    tab = [bytes(rng.integers(97, 123, L).astype(np.uint8)) for L in list(range(maxlen + 1)) * 3]
+    T = StrCol.from_values(tab)
+    n = 6000
+    it = rng.integers(0, len(tab), n).astype(np.uint32)
+    s = StrCol.from_values([b"r%d" % i for i in range(n)])
+    want = orc.csv_write([s, StrCol.from_values([tab[i] for i in it])], ["s", "t"])
+    got, ran = _write_with(ctx, 1, [s, T], ["s", "t"], row_ids=[None, it])
+    assert got == want
+    assert ("k_csv_onepass" in ran) == stride_ok and ("k_csv_copy" in ran) != stride_ok, sorted(ran)
+
+
+@pytest.mark.gpu
+def test_onepass_buffer_estimate_too_small_falls_back(ctx):
+    """Every value of the stream column needs quotes and doubles its quote characters: the text is far beyond the column's bytes
+    + 1/8; a tile notices, nothing of the one pass is used, the two-pass writer renders the same text."""
+    n = 20_000
+    s = StrCol.from_values([b'""""""""'] * n)
+    want = orc.csv_write([s], ["q"])
+    got, ran = _write_with(ctx, 1, [s], ["q"])
+    assert got == want and len(got) == 2 + n * 19
+    assert "k_csv_onepass" in ran and "k_csv_copy" in ran, sorted(ran)
+
+
+@pytest.mark.gpu
+def test_onepass_tiles_beyond_the_stage_and_a_table_larger_than_the_output(ctx):
+    """A few records larger than a tile's LDS stage (written to global memory directly) among short ones; a column gathered from a
+    table LARGER than the output (no slot table: its values are fetched and quoted per row); empty values; an empty table row."""
+    rng = np.random.default_rng(5)
+    n = 30_000
+    stream = _rand_values(rng, n, 0, 12)
+    for r in (5, 12_345, n - 1):
+        stream[r] = b"x" * 30_000 + b'"' + b"y" * 9000
+    big = _rand_values(rng, 50_000, 0, 20)
+    s, Bg = StrCol.from_values(stream), StrCol.from_values(big)
+    ib = np.sort(rng.choice(50_000, n, replace=False)).astype(np.uint64)
+    want = orc.csv_write([s, StrCol.from_values([big[int(i)] for i in ib]), s], ["s", "b", "s2"])
+    got, ran = _write_with(ctx, 1, [s, Bg, s], ["s", "b", "s2"], row_ids=[None, ib, None])
+    assert got == want
+    assert "k_csv_onepass" in ran and "k_csv_slots" not in ran, sorted(ran)
+    for grid in (1, 2, 5):   # (option value 1 = "auto": a single workgroup is asked for with 2 tiles' worth of rows below)
+        got, ran = _write_with(ctx, max(grid, 2), [s, Bg, s], ["s", "b", "s2"], row_ids=[None, ib, None])
+        assert got == want
+
+
+@pytest.mark.gpu
+def test_onepass_device_columns_and_device_row_ids(ctx):
+    """The pipeline's shape: device columns, device row ids out of a chained Join (positions), text left on the device."""
+    from csvplus_amd import pipeline, ingest
+    from csvplus_amd import _native as N
+    nc, npd, m = 20_000, 300, 150_000
+    cust, prod, ords = dg.customers(nc), dg.products(npd), dg.orders(m, nc, npd)
+    def text_of(cols, names):
+        return orc.csv_write(cols, names)
+    tc = pipeline.read_table(ctx, text_of([cust["id"], cust["name"], cust["surname"]], ["id", "name", "surname"]))
+    tp = pipeline.read_table(ctx, text_of([prod["prod_id"], prod["product"], prod["price"]], ["prod_id", "product", "price"]))
+    to = pipeline.read_table(ctx, text_of([ords["cust_id"], ords["prod_id"], ords["qty"]], ["cust_id", "prod_id", "qty"]))
+    out_cols = [("cust_id", to, "cust_id"), ("qty", to, "qty"), ("name", tc, "name"), ("surname", tc, "surname"),
+                ("product", tp, "product"), ("price", tp, "price")]
+    steps = [(tc, "id", "cust_id"), (tp, "prod_id", "prod_id")]
+    texts = {}
+    for mode in (0, 1):
+        for positions in (True, False):
+            ctx.set_option("csv_onepass", mode)
+            try:
+                texts[(mode, positions)] = bytes(pipeline.join_to_csv(ctx, to, steps, out_cols, positions=positions))
+            finally:
+                ctx.set_option("csv_onepass", 1)
+    assert len(set(texts.values())) == 1
+    # the oracle's joined table
+    cid = {cust["id"].value(i): i for i in range(nc)}
+    pid = {prod["prod_id"].value(i): i for i in range(npd)}
+    lines = [b"cust_id,qty,name,surname,product,price"]
+    for r in range(0, m, 997):
+        x, y = cid[ords["cust_id"].value(r)], pid[ords["prod_id"].value(r)]
+        lines.append(b",".join([ords["cust_id"].value(r), ords["qty"].value(r), cust["name"].value(x), cust["surname"].value(x),
+                                prod["product"].value(y), prod["price"].value(y)]))
+    got = texts[(1, True)].split(b"\n")
+    assert got[0] == lines[0] and len(got) == m + 2
+    assert [got[1 + r] for r in range(0, m, 997)] == lines[1:]
+    for t in (tc, tp, to):
+        t.release()
