@@ -308,6 +308,10 @@ def compact_line(out, extras_path):
            if isinstance(out.get(k), dict) and "ms" in out[k]}
     if e2e:
         line["e2e"] = {"cols": "ms,rows_per_s", **e2e}
+    tc = out.get("to_csv")
+    if tc:
+        line["to_csv"] = ({"cols": "ms,TBps,two_pass_ms,verified", "joined_rows_to_text": [tc.get("ms"), tc.get("TBps"), tc.get("two_pass_ms"), tc.get("verified")]}
+                          if "error" not in tc else {"error": str(tc["error"])[:80]})
     m = out.get("multi_gpu")
     if m:
         c = {k: m.get(k) for k in ("mode", "chunks", "join_compute_ms", "exchange_ms", "exposed_exchange_ms", "bytes_sent_per_step",
@@ -330,7 +334,7 @@ def compact_line(out, extras_path):
         line["extras_error"] = str(out["extras_error"])[:200]
     line["extras"] = extras_path
     # the budget is a hard limit: optional blocks go, in this order, until the line fits
-    for drop in ("kernels_avg_ms", "e2e", "host", "index_plus_join_1e8", "multi_gpu", "index_on_1e8"):
+    for drop in ("kernels_avg_ms", "e2e", "host", "to_csv", "index_plus_join_1e8", "multi_gpu", "index_on_1e8"):
         if len(json.dumps(line)) <= LINE_BUDGET:
             break
         line.pop(drop, None)
@@ -1227,6 +1231,101 @@ def main():
                     "step_plus_permute", "the timed step + cph_index_permute of customers(name, surname) and products(product, price) inside "
                     "every step: the payload rows in index order, what a consumer of sorted positions needs per build (csvplus.go:736 moves "
                     "the rows; :553-567 reads index.impl.rows[i])", cust_id, ords["cust_id"], extra_build=lay_out))
+
+                def to_csv_block():
+                    """The step AFTER the timed path: orders.Join(customers).Join(products).ToCsv(cust_id, qty, name, surname,
+                    product, price) — mergeRows (csvplus.go:571-583) folded into the writer (:379-406) over the joined rows of the timed
+                    chain, text left in HBM.  One pass (slot tables + decoupled look-back, materialize.hip) beside the two-pass writer; the
+                    two texts must be the same bytes and the first rows equal to the oracle's Writer."""
+                    from csvplus_amd.materialize import csv_write
+
+                    torch.cuda.empty_cache()
+                    ia_, ib_ = eng.index_on_many([[d_cust], [d_prod]], unique=True)
+                    ch_ = N.join_chain(eng.ctx, [(ia_, [d_ord["cust_id"]]), (ib_, [d_ord["prod_id"]])], probe_base=begin, out_mem=N.CPH_MEM_DEVICE,
+                                       positions=True)
+                    pay_ = lay_out(ia_, ib_)
+                    try:
+                        n_, p_ = ch_.nrows, ch_.device_ptrs()
+                        if n_ != nloc or p_["stream_row"]:
+                            raise RuntimeError("to_csv block expects every order to join once")
+                        cols_ = [d_ord["cust_id"], d_ord["qty"]] + [c_.as_device_strcol() for c_ in pay_]
+                        ids_ = [None, None] + [(p_["build_row"][0], 32, n_)] * 2 + [(p_["build_row"][1], 32, n_)] * 2
+                        names_ = ["cust_id", "qty", "name", "surname", "product", "price"]
+
+                        def timed(mode, reps):
+                            eng.ctx.set_option("csv_onepass", mode)
+                            try:
+                                csv_write(eng.ctx, cols_, names_, out_mem=N.CPH_MEM_DEVICE, row_ids=ids_, nrows=n_).release()
+                                eng.ctx.profile(True)
+                                eng.ctx.profile_read(reset=True)
+                                torch.cuda.synchronize(dev)
+                                t0_ = time.perf_counter()
+                                for _ in range(reps):
+                                    csv_write(eng.ctx, cols_, names_, out_mem=N.CPH_MEM_DEVICE, row_ids=ids_, nrows=n_).release()
+                                torch.cuda.synchronize(dev)
+                                ms_ = (time.perf_counter() - t0_) / reps * 1e3
+                                pk_ = eng.ctx.profile_read(reset=True)
+                                eng.ctx.profile(False)
+                                text_ = csv_write(eng.ctx, cols_, names_, out_mem=N.CPH_MEM_DEVICE, row_ids=ids_, nrows=n_)
+                                return ms_, {k: round(v["total_ms"] / reps, 4) for k, v in sorted(pk_.items(), key=lambda kv: -kv[1]["total_ms"])[:6]}, text_
+                            finally:
+                                eng.ctx.set_option("csv_onepass", 1)
+
+                        ms1, k1, t1 = timed(1, 3)
+                        ms0, k0, t0x = timed(0, 2)
+                        size_ = len(t1)
+                        blk = {"what": "ToCsv of the timed chain's %d joined rows, 6 columns (2 stream, 2 + 2 gathered through sorted positions), text left "
+                                       "in HBM; bytes per second of TEXT written" % n_, "text_bytes": size_,
+                               "ms": round(ms1, 3), "TBps": round(size_ / ms1 / 1e9, 3), "kernels_ms": k1,
+                               "two_pass_ms": round(ms0, 3), "two_pass_TBps": round(size_ / ms0 / 1e9, 3), "two_pass_kernels_ms": k0,
+                               "one_pass_taken": "k_csv_onepass" in k1}
+                        if not args.no_verify:
+                            from oracle import orc   # the checker
+
+                            def dev_bytes(t_, off, length):   # bytes [off, off + length) of a text in HBM (the blocks end in >= 16 spare bytes)
+                                a0 = off // 8 * 8
+                                w_ = device_view(t_.data_ptr + a0, (off + length - a0 + 7) // 8, "<i8", t_, dev).cpu().numpy().tobytes()
+                                return w_[off - a0: off - a0 + length]
+
+                            same = len(t0x) == size_
+                            if same:
+                                v1 = device_view(t1.data_ptr, size_ // 8, "<i8", t1, dev)
+                                v0 = device_view(t0x.data_ptr, size_ // 8, "<i8", t0x, dev)
+                                same = bool(torch.equal(v1, v0)) and dev_bytes(t1, size_ - 16, 16) == dev_bytes(t0x, size_ - 16, 16)
+                                del v1, v0
+                            # the first rows against the oracle's restatement of the Writer
+                            k_ = min(50_000, n_)
+                            # sorted position -> original table row through the index's permutation; the values from the host tables
+                            perm_a = device_view(ia_.perm_device_ptr(), ia_.nrows, "<i4", ia_, dev)
+                            perm_b = device_view(ib_.perm_device_ptr(), ib_.nrows, "<i4", ib_, dev)
+                            pos_a = device_view(p_["build_row"][0], n_, "<i4", ch_, dev)[:k_].long() & 0xFFFFFFFF
+                            pos_b = device_view(p_["build_row"][1], n_, "<i4", ch_, dev)[:k_].long() & 0xFFFFFFFF
+                            ra = (perm_a[pos_a].long() & 0xFFFFFFFF).cpu().tolist()
+                            rb = (perm_b[pos_b].long() & 0xFFFFFFFF).cpu().tolist()
+                            del perm_a, perm_b, pos_a, pos_b
+                            from csvplus_amd import StrCol
+                            hc = [dg.column(k2, args.customers, args.customers, seed=dg.SEED + 1) for k2 in (dg.NAME, dg.SURNAME)]
+                            hp = [dg.column(k2, args.products, args.products, seed=dg.SEED + 2) for k2 in (dg.PRODUCT, dg.PRICE)]
+                            want_ = orc.csv_write([ords["cust_id"].slice(0, k_), ords["qty"].slice(0, k_)] +
+                                                  [StrCol.from_values([c2.value(i) for i in ra]) for c2 in hc] +
+                                                  [StrCol.from_values([c2.value(i) for i in rb]) for c2 in hp], names_)
+                            head_ok = dev_bytes(t1, 0, len(want_)) == want_
+                            blk["verify"] = {"one_pass_equals_two_pass_bytes": same, "oracle_prefix_rows": k_, "oracle_prefix_bytes_equal": head_ok}
+                            blk["verified"] = bool(same and head_ok)
+                        t1.release()
+                        t0x.release()
+                        return blk
+                    finally:
+                        for c_ in pay_:
+                            c_.release()
+                        ch_.release()
+                        ia_.close()
+                        ib_.close()
+
+                try:
+                    out["to_csv"] = to_csv_block()
+                except Exception as ex:   # noqa: BLE001 — an extra never takes the headline down; the error is the record
+                    out["to_csv"] = {"error": f"{type(ex).__name__}: {ex}"}
                 del cust_pay, prod_pay
             if "dup" in want:
                 def dup_build_side():

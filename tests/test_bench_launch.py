@@ -169,8 +169,10 @@ def test_the_stdout_line_is_small_and_last(tmp_path):
     assert set(d["roofline"]["variants"]) >= {"itoa_ids", "half_occupied_ids", "sparse_random_keys", "build_side_key", "step_plus_permute", "dup_build_side"}
     assert all(v[3] is True for v in d["roofline"]["variants"].values()), d["roofline"]["variants"]
     assert d["verified"] is True and d["extras"] == str(extras)
+    assert d["to_csv"]["joined_rows_to_text"][0] > 0 and d["to_csv"]["joined_rows_to_text"][3] is True, d["to_csv"]   # ToCsv of the joined rows: ms, verified
     f = json.loads(extras.read_text())
     assert f["cpu_baseline"]["measured_sample"] and f["index_on_1e8"]["varlen_dup_keys_config3"]["verified"] is True
+    assert f["to_csv"]["one_pass_taken"] and f["to_csv"]["verify"]["one_pass_equals_two_pass_bytes"] and f["to_csv"]["verify"]["oracle_prefix_bytes_equal"]
 
 
 @pytest.mark.gpu
