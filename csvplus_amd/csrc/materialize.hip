@@ -15,6 +15,7 @@
 // Both are length -> exclusive scan -> copy pipelines.  The copy kernels assemble a tile's bytes in
 // LDS (byte-granular writes are cheap there) and stream them out with 16-byte stores; a tile whose
 // bytes do not fit the LDS stage falls back to direct byte stores.  HBM-bound byte work, no MFMA.
+#include <mutex>
 #include <new>
 
 #include "lds_stage.hpp"
@@ -786,7 +787,15 @@ __global__ __launch_bounds__(kOpThreads, NC <= 2 ? 4 : NC <= 4 ? 3 : 2) void k_c
                 w = kOpIncl;   // in front of tile 0: an inclusive prefix of 0
                 if (j >= 0) {
                     w = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    while ((w >> 62) == 0) {
+                    // a tile in front that never publishes (its workgroup never became resident: the occupancy figure the grid
+                    // was sized by did not hold) must not hang the device: after ~2^22 polls (seconds) the call is given up —
+                    // `overflow` makes the host discard the text and render it with the two-pass writer
+                    for (uint32_t polls = 0; (w >> 62) == 0; polls++) {
+                        if (polls >> 22) {
+                            atomicOr(&rep->overflow, 2u);
+                            w = kOpIncl;
+                            break;
+                        }
                         __builtin_amdgcn_s_sleep(1);
                         w = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
@@ -976,6 +985,12 @@ static Status csv_onepass(cph_ctx* ctx, const ColsArg& arg, const ColIds& ids, i
     CPH_TRY(state.alloc(&ctx->pool, ntiles * sizeof(unsigned long long) + sizeof(OpReport)));
     CPH_HIP_TRY(hipMemsetAsync(state.get(), 0, ntiles * sizeof(unsigned long long) + sizeof(OpReport), ctx->stream));
     OpReport* rep = reinterpret_cast<OpReport*>(state.as<unsigned long long>() + ntiles);
+    // The grid is persistent and its look-back WAITS for lower tiles: all its workgroups must become resident.  Two such grids of one
+    // process (two ctxs, two streams) could each hold part of the device and wait for workgroups the other one keeps out, so one at
+    // a time per device, from the launch to the synchronisation below.  (Other kernels beside it are fine: they finish and make
+    // room.  Two PROCESSES writing CSV on one GPU at the same moment are not covered — set csv_onepass = 0 there.)
+    static std::mutex g_one_grid[8];
+    std::lock_guard<std::mutex> one_grid(g_one_grid[ctx->device & 7]);
     OpLaunch L{ctx, oa, nslot, cus, max_grid, lds, n, ntiles, head_bytes, cap, state.as<unsigned long long>(), data_out->as<uint8_t>(), rep};
     int mask = 0;
     for (int g = 0; g < nf; g++) mask |= groups[g].slot ? 1 << g : 0;

@@ -188,6 +188,8 @@ CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
  *                   more than 8 output columns after grouping, a fragment beyond 127 bytes, records beyond ~140 bytes on average, a
  *                   buffer estimate (stream columns' bytes + 1/8 for quotes) that a tile overruns.  0: always the two passes; N > 1: the
  *                   one pass whatever the row count, with at most N workgroups (tests)
+ *                   The one-pass kernel is a persistent grid whose tiles wait for the tiles in front of them: the library runs one at a time per
+ *                   device and process; two PROCESSES that write CSV on the same GPU at the same moment should set 0
  *   "csv_onepass_debug" bits (default 0; measurement only, the text is wrong when set): 1 = no look-back, 2 = no record bytes, 4 = one
  *                   record per thread
  *   "direct_sort"   0 / 1 (default 1): a build that expects distinct keys (cph_index_build with unique = 1, cph_index_spec.unique) over a

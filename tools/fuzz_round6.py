@@ -10,7 +10,13 @@
             records near the window limit, and texts the fast path must hand over (a quote, a blank line, a comment line)
   chaind    people.Join(IndexOn(orders.key) with duplicates, k).Join(UniqueIndexOn(products), key of the ORDERS row): the general
             chain's pre-joined step (chain.hip: prejoin_general_step) on / off, row ids / positions, against the oracle
-usage: tools/fuzz_round6.py [seconds] [seed]"""
+  tocsv     cph_csv_write_rows through the one-pass writer (materialize.hip: k_csv_slots + k_csv_onepass — slot tables, LDS-DMA gathers,
+            decoupled look-back over 2 .. all workgroups) against the two-pass writer (ctx option csv_onepass = 0) and, for small outputs,
+            the oracle's Writer: 1-6 output columns out of stream columns and 1-3 tables (adjacent columns of a table form one slot
+            group), 32- / 64-bit row ids with a base, values with every quoting trigger, fragments around the stride limits (15 / 31 /
+            63 / 127 bytes), a few records larger than a tile's LDS stage, tables larger than the output, outputs the buffer estimate
+            cannot hold (the overflow path)
+usage: tools/fuzz_round6.py [seconds] [seed] [only: counted | csv | chaind | tocsv | varkey]"""
 import sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -19,6 +25,7 @@ from csvplus_amd import Context, DeviceIndex, StrCol, _native as N, ingest, join
 from oracle import orc
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+only = sys.argv[3] if len(sys.argv) > 3 else None
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
 rng = np.random.default_rng(seed)
 ctx = Context(0)
@@ -174,11 +181,74 @@ def chaind_case():
     return "chaind"
 
 
+def tocsv_case():
+    from csvplus_amd.materialize import csv_write
+    n = int(rng.choice([int(rng.integers(1, 600)), int(rng.integers(600, 20_000)), int(rng.integers(20_000, 400_000))]))
+    nasty = rng.random() < 0.5
+    alpha = np.frombuffer(b'ab ,"\n\rz#\t0123456789' if nasty else b"abcdefghij0123456789", dtype=np.uint8)
+
+    def values(count, lo, hi):
+        lens = rng.integers(lo, hi + 1, count)
+        flat = alpha[rng.integers(0, len(alpha), int(lens.sum()))].tobytes()
+        offs = np.concatenate([[0], np.cumsum(lens)])
+        return [flat[offs[i]:offs[i + 1]] for i in range(count)]
+
+    cols, ids, expect = [], [], []
+    ntab = int(rng.integers(0, 4))
+    layout = ["s"] * int(rng.integers(0 if ntab else 1, 3))
+    for t in range(ntab):
+        layout += [t] * int(rng.integers(1, 3))
+    if rng.random() < 0.4:
+        rng.shuffle(layout)      # a table's columns may end up apart: separate slot groups
+    layout = layout[:6]
+    tabs = {}
+    for what in layout:
+        if what == "s":
+            hi = int(rng.choice([3, 9, 20]))
+            v = values(n, 0, hi)
+            if rng.random() < 0.15 and n > 10:
+                for r in rng.choice(n, 2, replace=False):
+                    v[int(r)] = b"x" * int(rng.integers(15_000, 30_000)) + b'"y'     # beyond the stage
+            if rng.random() < 0.1:
+                v = [b'""' + x for x in v]                                            # quotes everywhere: the buffer estimate falls short
+            c = StrCol.from_values(v)
+            cols.append(c); ids.append(None); expect.append(c)
+        else:
+            if what not in tabs:
+                nt = int(rng.choice([int(rng.integers(1, 50)), int(rng.integers(50, 3000)), int(n * rng.uniform(0.5, 3.0)) + 1]))
+                wide = rng.random() < 0.5
+                tid = rng.integers(0, nt, n)
+                tabs[what] = (nt, (tid + 1000).astype(np.uint64) if wide else tid.astype(np.uint32), 1000 if wide else 0, tid)
+            nt, tid_arr, base, tid = tabs[what]
+            hi = int(rng.choice([4, 7, 14, 15, 16, 30, 31, 32, 62, 64, 126, 130]))
+            v = values(nt, 0 if rng.random() < 0.8 else hi, hi)
+            cols.append(StrCol.from_values(v)); ids.append((tid_arr, base)); expect.append(StrCol.from_values([v[int(i)] for i in tid]) if n <= 20_000 else None)
+    names = ["c%d" % i for i in range(len(cols))] if rng.random() < 0.8 else None
+    row_ids = [None if i is None else i[0] - i[1] for i in ids]   # (the wrapper takes ids relative to the column; 64-bit ids stay 64-bit)
+    texts = []
+    ran = set()
+    for mode in (0, int(rng.choice([1, 2, 3, 7, 1 << 20]))):
+        ctx.set_option("csv_onepass", mode)
+        ctx.profile(True); ctx.profile_read(reset=True)
+        try:
+            texts.append(csv_write(ctx, cols, names, row_ids=row_ids, nrows=n))
+            ran = set(ctx.profile_read(reset=True))
+        finally:
+            ctx.profile(False)
+            ctx.set_option("csv_onepass", 1)
+    assert texts[0] == texts[1], ("tocsv one pass != two passes", n, layout)
+    if n <= 20_000:
+        assert texts[0] == orc.csv_write(expect, names), ("tocsv != oracle", n, layout)
+    return "tocsv_" + ("two_pass" if "k_csv_onepass" not in ran else "overflow" if "k_csv_copy" in ran else "slots" if "k_csv_slots" in ran else "plain")
+
+
 t_end = time.time() + budget
 kinds, cases = {}, 0
 while time.time() < t_end:
     x = rng.random()
-    fn = csv_case if x < 0.55 else chaind_case if x < 0.85 else counted_case if x < 0.97 else varkey_case
+    fn = csv_case if x < 0.40 else tocsv_case if x < 0.62 else chaind_case if x < 0.87 else counted_case if x < 0.97 else varkey_case
+    if only:
+        fn = {"counted": counted_case, "csv": csv_case, "chaind": chaind_case, "tocsv": tocsv_case, "varkey": varkey_case}[only]
     try:
         k = fn()
     except AssertionError as ex:
