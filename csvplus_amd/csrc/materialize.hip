@@ -886,7 +886,7 @@ static Status op_launch_masked(const OpLaunch& L, int mask) {
 static Status csv_onepass(cph_ctx* ctx, const ColsArg& arg, const ColIds& ids, int ncols, uint64_t n, uint64_t head_bytes, int max_grid,
                           DevBuf* data_out, uint64_t* total_out, bool* done) {
     *done = false;
-    if (n == 0 || n >= (1ull << 40)) return {};
+    if (n == 0 || n >= (1ull << 39)) return {};   // (tile numbers are 32 bits)
     // adjacent columns of one table through one row-id array: one slot table; everything else as it is
     struct Group { int first, count; bool slot; };
     std::vector<Group> groups;
@@ -914,6 +914,7 @@ static Status csv_onepass(cph_ctx* ctx, const ColsArg& arg, const ColIds& ids, i
         const Group& G = groups[g];
         oa.c[g].ids = ids.ids[G.first];
         oa.c[g].ids.stash = nullptr;
+        if (oa.c[g].ids.ptr && arg.c[G.first].nrows > 0xFFFFFFFFull) return {};   // the kernel keeps table rows in 32 bits
         if (!G.slot) {
             oa.c[g].col = arg.c[G.first];
             if (oa.c[g].col.split || oa.c[g].col.segmented()) return {};   // (never: such columns only exist inside the key codec)

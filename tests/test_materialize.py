@@ -287,3 +287,43 @@ def test_onepass_device_columns_and_device_row_ids(ctx):
     assert [got[1 + r] for r in range(0, m, 997)] == lines[1:]
     for t in (tc, tp, to):
         t.release()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_onepass_from_two_contexts_at_once():
+    """Two ctxs (two streams) of one process write CSV through the one-pass kernel from two threads at the same time: its persistent
+    grid waits for its own lower tiles, so the library lets one such grid at a time onto the device — neither call may hang, both
+    texts are right."""
+    import threading
+    from csvplus_amd import Context
+    from csvplus_amd.materialize import csv_write
+    rng = np.random.default_rng(404)
+    n = 300_000
+    tab = [b"%d-%s" % (i, b"x" * int(rng.integers(0, 12))) for i in range(5000)]
+    T = StrCol.from_values(tab)
+    jobs = []
+    for k in range(2):
+        it = rng.integers(0, len(tab), n).astype(np.uint32)
+        s = StrCol.from_values([b"r%d" % i for i in range(k, n + k)])
+        jobs.append((s, it, orc.csv_write([s, StrCol.from_values([tab[i] for i in it])], ["s", "t"])))
+    ctxs = [Context(0), Context(0)]
+    got, errs = [None, None], []
+
+    def work(k):
+        try:
+            for _ in range(6):
+                got[k] = csv_write(ctxs[k], [jobs[k][0], T], ["s", "t"], row_ids=[None, jobs[k][1]])
+                assert got[k] == jobs[k][2]
+        except Exception as ex:   # noqa: BLE001
+            errs.append(repr(ex))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=240)
+    assert not any(t.is_alive() for t in th), "a writer hangs"
+    assert not errs, errs
+    for c in ctxs:
+        c.close()
