@@ -312,6 +312,10 @@ def compact_line(out, extras_path):
     if tc:
         line["to_csv"] = ({"cols": "ms,TBps,two_pass_ms,verified", "joined_rows_to_text": [tc.get("ms"), tc.get("TBps"), tc.get("two_pass_ms"), tc.get("verified")]}
                           if "error" not in tc else {"error": str(tc["error"])[:80]})
+    cp = out.get("csv_parse")
+    if cp:
+        line["csv_parse"] = ({"cols": "ms,GBps,verified", "orders_text_to_columns": [cp.get("ms"), cp.get("GBps"), cp.get("verified")]}
+                             if "error" not in cp else {"error": str(cp["error"])[:80]})
     m = out.get("multi_gpu")
     if m:
         c = {k: m.get(k) for k in ("mode", "chunks", "join_compute_ms", "exchange_ms", "exposed_exchange_ms", "bytes_sent_per_step",
@@ -334,7 +338,7 @@ def compact_line(out, extras_path):
         line["extras_error"] = str(out["extras_error"])[:200]
     line["extras"] = extras_path
     # the budget is a hard limit: optional blocks go, in this order, until the line fits
-    for drop in ("kernels_avg_ms", "e2e", "host", "to_csv", "index_plus_join_1e8", "multi_gpu", "index_on_1e8"):
+    for drop in ("kernels_avg_ms", "e2e", "host", "csv_parse", "to_csv", "index_plus_join_1e8", "multi_gpu", "index_on_1e8"):
         if len(json.dumps(line)) <= LINE_BUDGET:
             break
         line.pop(drop, None)
@@ -610,7 +614,12 @@ def main():
     eng.ctx.profile_read(reset=True)
     step()
     pick = eng.ctx.profile_read(reset=True)
-    dom_name = max(pick.items(), key=lambda kv: kv[1]["total_ms"])[0] if pick else "k_chain_dense"
+    # (among the kernels whose byte model moves at least a megabyte per step: at toy sizes a sampling or bookkeeping kernel can be the
+    # longest launch of a step by timing noise alone, and a roofline over its few kilobytes rounds to 0 — tests/test_bench_launch.py ran
+    # into that once in ten runs.  At the benchmark's size every kernel of the step is far above the bar.)
+    # (k_chain_dense's bytes are modelled by bench.py itself — chain_bytes() below — not by the library's launch record)
+    modelled = {k: v for k, v in pick.items() if v.get("algo_bytes", 0) >= 1e6 or k == "k_chain_dense"}
+    dom_name = max(modelled.items(), key=lambda kv: kv[1]["total_ms"])[0] if modelled else "k_chain_dense"
     eng.ctx.profile_only(dom_name)
     sync_all()
     del xstats[:]
@@ -1326,6 +1335,77 @@ def main():
                     out["to_csv"] = to_csv_block()
                 except Exception as ex:   # noqa: BLE001 — an extra never takes the headline down; the error is the record
                     out["to_csv"] = {"error": f"{type(ex).__name__}: {ex}"}
+
+                def csv_parse_block():
+                    """The step IN FRONT of the timed path: orders.csv — a header line + one record of 3 fields per orders row,
+                    written into HBM by cph_csv_write — parsed back into columns by cph_csv_parse (Reader.Iterate, csvplus.go:1080-1146).
+                    Checked at full size through the round trip parse(write(columns)) == columns: every value's bytes and length."""
+                    from csvplus_amd import ingest
+                    from csvplus_amd.materialize import csv_write
+
+                    torch.cuda.empty_cache()
+                    names_ = ["cust_id", "prod_id", "qty"]
+                    cols_ = [d_ord[k2] for k2 in names_]
+                    text_ = csv_write(eng.ctx, cols_, names_, out_mem=N.CPH_MEM_DEVICE)
+                    tab_ = None
+                    try:
+                        size_ = len(text_)
+
+                        def parse():
+                            return ingest.csv_parse(eng.ctx, None, [0, 1, 2], fields_per_record=3, skip_records=1, out_mem=N.CPH_MEM_DEVICE,
+                                                    device_ptr=text_.data_ptr, size=size_)
+
+                        parse().release()
+                        eng.ctx.profile(True)
+                        eng.ctx.profile_read(reset=True)
+                        torch.cuda.synchronize(dev)
+                        t0_ = time.perf_counter()
+                        for _ in range(3):
+                            parse().release()
+                        torch.cuda.synchronize(dev)
+                        ms_ = (time.perf_counter() - t0_) / 3 * 1e3
+                        pk_ = eng.ctx.profile_read(reset=True)
+                        eng.ctx.profile(False)
+                        tab_ = parse()
+                        blk = {"what": "cph_csv_parse of orders.csv in HBM (header + %d records x 3 fields, written by cph_csv_write), 3 columns out, left in HBM; "
+                                       "bytes per second of TEXT read" % nloc, "text_bytes": size_, "ms": round(ms_, 3), "GBps": round(size_ / ms_ / 1e6, 1),
+                               "records": tab_.nrecords, "kernels_ms": {k: round(v["total_ms"] / 3, 4) for k, v in sorted(pk_.items(), key=lambda kv: -kv[1]["total_ms"])[:5]},
+                               "fast_path_taken": "k_csv_fast_copy" in pk_}
+                        if not args.no_verify:
+                            ok_ = tab_.nrecords == nloc and tab_.error_kind == 0
+                            ver_ = {"records": tab_.nrecords, "error_kind": tab_.error_kind}
+                            for k2, oc, pc in zip(names_, cols_, tab_.columns):
+                                nb = ords[k2].nbytes_values()   # (the host twin of the device column knows its size)
+                                pdat = device_view(pc.data.data_ptr(), nb // 8, "<i8", tab_, dev)
+                                odat = oc.data[: nb // 8 * 8].view(torch.int64)
+                                same_bytes = bool(torch.equal(pdat, odat))
+                                poff = device_view(pc.offsets.data_ptr(), nloc + 1, "<i4" if pc.offset_bits == 32 else "<i8", tab_, dev).long()
+                                if pc.offset_bits == 32:
+                                    poff = poff & 0xFFFFFFFF
+                                if oc.fixed_width:
+                                    same_lens = bool((poff == torch.arange(nloc + 1, device=dev, dtype=torch.int64) * oc.fixed_width).all().item())
+                                else:
+                                    ooff = oc.offsets.view(torch.int32 if oc.offset_bits == 32 else torch.int64).long()
+                                    if oc.offset_bits == 32:
+                                        ooff = ooff & 0xFFFFFFFF
+                                    same_lens = bool(torch.equal(poff - poff[0], ooff - ooff[0]))
+                                    del ooff
+                                ver_[k2] = {"value_bytes_equal": same_bytes, "lengths_equal": same_lens, "bytes": nb}
+                                ok_ = ok_ and same_bytes and same_lens
+                                del pdat, odat, poff
+                            blk["verify"] = ver_
+                            blk["verified"] = bool(ok_)
+                        return blk
+                    finally:
+                        if tab_ is not None:
+                            tab_.release()
+                        text_.release()
+
+                try:
+                    out["csv_parse"] = csv_parse_block()
+                except Exception as ex:   # noqa: BLE001
+                    import traceback
+                    out["csv_parse"] = {"error": f"{type(ex).__name__}: {ex}", "traceback": traceback.format_exc()[-800:]}
                 del cust_pay, prod_pay
             if "dup" in want:
                 def dup_build_side():

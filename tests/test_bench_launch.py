@@ -162,7 +162,7 @@ def test_the_stdout_line_is_small_and_last(tmp_path):
     line = lines[-1]
     assert line.startswith("{") and len(line) < 6000, len(line)
     d = json.loads(line, parse_constant=_no_constants)
-    assert d["roofline"]["frac"] > 0 and d["roofline"]["kernel"] and d["roofline"]["avg_launch_ms"] > 0
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["kernel"] == "k_chain_dense" and d["roofline"]["avg_launch_ms"] > 0
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0 and d["roofline"]["unit"] == "GB/s"
     cb = d["cpu_baseline"]
     assert cb["value"] > 0 and cb["cores"] == 1 and cb["kind"] == "port" and 0 < len(cb["sample"]) <= 200
@@ -170,6 +170,7 @@ def test_the_stdout_line_is_small_and_last(tmp_path):
     assert all(v[3] is True for v in d["roofline"]["variants"].values()), d["roofline"]["variants"]
     assert d["verified"] is True and d["extras"] == str(extras)
     assert d["to_csv"]["joined_rows_to_text"][0] > 0 and d["to_csv"]["joined_rows_to_text"][3] is True, d["to_csv"]   # ToCsv of the joined rows: ms, verified
+    assert d["csv_parse"]["orders_text_to_columns"][0] > 0 and d["csv_parse"]["orders_text_to_columns"][2] is True, d["csv_parse"]   # parse(write(columns)) == columns
     f = json.loads(extras.read_text())
     assert f["cpu_baseline"]["measured_sample"] and f["index_on_1e8"]["varlen_dup_keys_config3"]["verified"] is True
     assert f["to_csv"]["one_pass_taken"] and f["to_csv"]["verify"]["one_pass_equals_two_pass_bytes"] and f["to_csv"]["verify"]["oracle_prefix_bytes_equal"]
