@@ -788,10 +788,10 @@ __global__ __launch_bounds__(kOpThreads, NC <= 2 ? 4 : NC <= 4 ? 3 : 2) void k_c
                 if (j >= 0) {
                     w = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     // a tile in front that never publishes (its workgroup never became resident: the occupancy figure the grid
-                    // was sized by did not hold) must not hang the device: after ~2^22 polls (seconds) the call is given up —
+                    // was sized by did not hold) must not hang the device: after 2^18 polls (seconds) the call is given up —
                     // `overflow` makes the host discard the text and render it with the two-pass writer
                     for (uint32_t polls = 0; (w >> 62) == 0; polls++) {
-                        if (polls >> 22) {
+                        if (polls >> 18) {
                             atomicOr(&rep->overflow, 2u);
                             w = kOpIncl;
                             break;
@@ -857,7 +857,19 @@ static Status op_launch(const OpLaunch& L) {
     auto kern = &k_csv_onepass<NC, MASK>;
     int per_cu = 0;
     CPH_TRY(kernel_setup(L.ctx, reinterpret_cast<const void*>(kern), kOpThreads, L.lds, &per_cu));
-    uint64_t grid = (uint64_t)L.cus * (uint64_t)per_cu;   // persistent: every workgroup resident (the look-back waits on lower tiles)
+    // Persistent grid: EVERY workgroup must be resident (a tile waits for the tiles in front of it, and a tile belongs to one
+    // workgroup).  The runtime's occupancy figure is not trusted alone — for the 1-column kernel (69 VGPRs) it said 8 workgroups per
+    // CU where 7 fit, and a 5e7-row call waited for tiles nobody ran until the watchdog ended it — so the count is also derived here
+    // from the kernel's own registers and LDS, and capped at 4 (the occupancy every measured shape ran at).
+    {
+        hipFuncAttributes fa{};
+        CPH_HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern)));
+        const int vgprs = fa.numRegs > 0 ? (fa.numRegs + 7) / 8 * 8 : 128;
+        const int by_regs = 512 / vgprs;                                                    // waves per SIMD = workgroups per CU (4 waves, 4 SIMDs)
+        const int by_lds = (int)(160 * 1024 / ((L.lds + fa.sharedSizeBytes + 1279) / 1280 * 1280));
+        per_cu = std::max(1, std::min(std::min(per_cu, 4), std::min(by_regs, by_lds)));
+    }
+    uint64_t grid = (uint64_t)L.cus * (uint64_t)per_cu;
     if (L.max_grid > 0 && grid > (uint64_t)L.max_grid) grid = (uint64_t)L.max_grid;
     if (grid > L.ntiles) grid = L.ntiles;
     ProfScope ps(L.ctx, "k_csv_onepass", 0);
@@ -901,6 +913,14 @@ static Status csv_onepass(cph_ctx* ctx, const ColsArg& arg, const ColIds& ids, i
     }
     const int nf = (int)groups.size();
     if (nf > kOpMaxCols) return {};
+    // What the one pass saves is the second visit of the build tables' rows.  Without a slot table there is none: stream columns alone
+    // (1 column: 1.58 against 0.87 ms per 5e7 rows; 3 columns: equal) and columns gathered from tables larger than the output (equal)
+    // are left to the two passes unless the option forces the one pass (profiles/r06_tocsv.txt, "other shapes").
+    {
+        bool any_slot = false;
+        for (const Group& G : groups) any_slot |= G.slot;
+        if (!any_slot && max_grid == 0) return {};
+    }
     int cus = 0;
     CPH_TRY(device_cus(ctx, &cus));
     OpArgs oa{};

@@ -180,7 +180,7 @@ CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
  *   "csv_fast"      0 / 1 (default 1): cph_csv_parse first tries byte-parallel passes over 16 KiB text tiles (texts without any quote,
  *                   no TrimLeadingSpace, <= 8 columns, < 4 GiB, no blank / comment line inside, records that end within 4 KiB of their
  *                   tile); anything else — and every error — goes through the record-parallel kernels.  Same columns either way
- *   "csv_onepass"   0 / 1 / N (default 1): cph_csv_write[_rows] over >= 4096 rows renders the text in ONE pass over the joined rows: every
+ *   "csv_onepass"   0 / 1 / N (default 1): cph_csv_write[_rows] over >= 4096 rows with at least one such group renders the text in ONE pass: every
  *                   group of adjacent columns gathered from one table (<= the output's rows) through one row-id array is rendered once per
  *                   table row into a slot table ([length][CSV text], stride 16..128 bytes: one aligned fetch per output row and table),
  *                   a tile of 256 / 512 records learns its place in the text from a decoupled look-back over the tiles before it

@@ -224,7 +224,7 @@ def test_onepass_buffer_estimate_too_small_falls_back(ctx):
     n = 20_000
     s = StrCol.from_values([b'""""""""'] * n)
     want = orc.csv_write([s], ["q"])
-    got, ran = _write_with(ctx, 1, [s], ["q"])
+    got, ran = _write_with(ctx, 1 << 20, [s], ["q"])
     assert got == want and len(got) == 2 + n * 19
     assert "k_csv_onepass" in ran and "k_csv_copy" in ran, sorted(ran)
 
@@ -242,7 +242,7 @@ def test_onepass_tiles_beyond_the_stage_and_a_table_larger_than_the_output(ctx):
     s, Bg = StrCol.from_values(stream), StrCol.from_values(big)
     ib = np.sort(rng.choice(50_000, n, replace=False)).astype(np.uint64)
     want = orc.csv_write([s, StrCol.from_values([big[int(i)] for i in ib]), s], ["s", "b", "s2"])
-    got, ran = _write_with(ctx, 1, [s, Bg, s], ["s", "b", "s2"], row_ids=[None, ib, None])
+    got, ran = _write_with(ctx, 1 << 20, [s, Bg, s], ["s", "b", "s2"], row_ids=[None, ib, None])
     assert got == want
     assert "k_csv_onepass" in ran and "k_csv_slots" not in ran, sorted(ran)
     for grid in (1, 2, 5):   # (option value 1 = "auto": a single workgroup is asked for with 2 tiles' worth of rows below)
@@ -327,3 +327,36 @@ def test_onepass_from_two_contexts_at_once():
     assert not errs, errs
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["1 plain", "2 plain", "3 plain", "1 plain + slots", "5 apart"])
+def test_onepass_with_more_tiles_than_resident_workgroups(ctx, shape):
+    """Enough rows that the persistent grid is as large as it gets (tiles > CUs x workgroups per CU): every workgroup of the grid must
+    be resident, or tiles wait for tiles nobody runs.  (The runtime's occupancy figure was one too high for the 1-column kernel: a 5e7-row
+    call stalled until the watchdog gave it to the two-pass writer; the grid is now sized from the kernel's own registers and LDS.)"""
+    import time
+    n = 700_000     # 2735 tiles of 256 records; 256 CUs x 4-8 workgroups = 1024-2048
+    rng = np.random.default_rng(len(shape))
+    num = np.char.mod("%d", rng.integers(0, 100000, n)).astype("S")
+    def plain(k):
+        vals = np.char.add(num, np.bytes_(b"abcdefgh"[k:k + 1])) if k else num
+        return StrCol.from_values(vals.tolist())
+    tab = [b"t%d" % i for i in range(3000)]
+    T = StrCol.from_values(tab)
+    it = rng.integers(0, len(tab), n).astype(np.uint32)
+    G = StrCol.from_values([tab[i] for i in it])
+    if shape.endswith("plain"):
+        k = int(shape[0]); cols, ids, exp = [plain(j) for j in range(k)], None, None
+    elif shape == "1 plain + slots":
+        p0 = plain(0); cols, ids, exp = [p0, T], [None, it], [p0, G]
+    else:
+        p0, p1, p2 = plain(0), plain(1), plain(2); cols, ids, exp = [p0, T, p1, T, p2], [None, it, None, it, None], [p0, G, p1, G, p2]
+    want = orc.csv_write(exp or cols)
+    t0 = time.perf_counter()
+    got, ran = _write_with(ctx, 1 << 20, cols, None, row_ids=ids)   # (forced: by default only shapes with a slot table take the one pass)
+    dt = time.perf_counter() - t0
+    assert got == want
+    assert "k_csv_onepass" in ran and "k_csv_copy" not in ran and dt < 2.5, (sorted(ran), dt)
+    got1, ran1 = _write_with(ctx, 1, cols, None, row_ids=ids)
+    assert got1 == want and ("k_csv_onepass" in ran1) == ("slots" in shape or "apart" in shape), sorted(ran1)
