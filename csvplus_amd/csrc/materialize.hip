@@ -533,7 +533,7 @@ static Status csv_render(cph_ctx* ctx, const ColsArg& arg, const ColIds& ids_in,
 // The output size is not known before the launch: the buffer is sized from the slot tables' longest entries (exact bound) and
 // the stream columns' byte counts (+ 1/8 for quotes); a tile that would cross the end raises `overflow` and the two-pass
 // writer above renders the text instead (as it does for everything this path does not take: > 8 output columns, fragments
-// beyond 127 bytes, records beyond ~140 bytes on average).  Same bytes either way (tests/test_materialize.py).
+// beyond 127 bytes, records beyond ~72 bytes on average, calls without any slot table).  Same bytes either way (tests/test_materialize.py).
 constexpr int kOpThreads = 256;
 constexpr int kOpStage   = 20 * 1024;     // a 256-record tile of ~45-byte records is 11.4 KB; + 2 KB per wave and slot column for the gathers
 constexpr int kOpMaxCols = 8;

@@ -185,7 +185,7 @@ CPH_API int32_t cph_ctx_set_stream(cph_ctx* ctx, void* hip_stream);
  *                   table row into a slot table ([length][CSV text], stride 16..128 bytes: one aligned fetch per output row and table),
  *                   a tile of 256 / 512 records learns its place in the text from a decoupled look-back over the tiles before it
  *                   (persistent grid, no length array, no scan) and leaves through LDS.  Not taken (-> the two-pass writer, same bytes):
- *                   more than 8 output columns after grouping, a fragment beyond 127 bytes, records beyond ~140 bytes on average, a
+ *                   more than 8 output columns after grouping, a fragment beyond 127 bytes, records beyond ~72 bytes on average, a
  *                   buffer estimate (stream columns' bytes + 1/8 for quotes) that a tile overruns.  0: always the two passes; N > 1: the
  *                   one pass whatever the row count, with at most N workgroups (tests)
  *                   The one-pass kernel is a persistent grid whose tiles wait for the tiles in front of them: the library runs one at a time per
