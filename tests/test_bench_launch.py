@@ -107,6 +107,9 @@ def test_compact_line_of_the_kept_full_records_fits_the_budget():
             assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"]), f.name
         if "cpu_baseline" in full:
             assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"]) and len(d["cpu_baseline"]["sample"]) <= 200
+        for blk, key in (("to_csv", "joined_rows_to_text"), ("csv_parse", "orders_text_to_columns")):   # round 6: the rows either side of the path
+            if blk in full and "error" not in full[blk]:
+                assert d[blk][key][0] == full[blk]["ms"] and d[blk][key][-1] is full[blk].get("verified"), (f.name, blk)
         seen += 1
     assert seen >= 3
     # a record bloated far past the budget still yields a line inside it (optional blocks are dropped, the contract fields stay)
